@@ -1,0 +1,301 @@
+/*
+ * roman_hip.h — C ABI of libroman_hip.so, the MI355X (gfx950) replacement for the
+ * `clipperpy` native module that mit-acl/roman's `roman.align` hot path binds.
+ *
+ * Every entry point names the reference interface it replaces ([REF file:line] is relative
+ * to the reference checkout).  Plain pointers and sizes only: no torch / numpy / C++ types
+ * cross this boundary.  All functions return 0 on success or a negative ROMAN_E_* code; they
+ * never throw.  The library fails (ROMAN_E_NO_DEVICE) when no HIP device is present — there
+ * is no CPU fallback behind this ABI.
+ *
+ * Data conventions (same as the reference's calls into clipperpy):
+ *   - A "feature matrix" is what [REF roman/align/roman_registration.py:91-95] hands to
+ *     `score_pairwise_and_single_consistency` as `map_cl.T`: F x n float64, one COLUMN per
+ *     object, column-major == object-major: object o's F features are the F contiguous
+ *     doubles at feats[o*F .. o*F+F).  Row layout inside a column is
+ *     [x y (z)] ++ ratio features (ratio_feature_dim) ++ cosine features (cos_feature_dim)
+ *     [REF roman/align/roman_registration.py:98-108].
+ *   - An association list is (A,2) int32 row-major; column 0 indexes map 1, column 1 map 2
+ *     [REF roman/align/object_registration.py:110-111].  A NULL list means all-to-all in
+ *     the order of clipperpy.utils.create_all_to_all: row i*n2+j = (i,j)
+ *     [REF roman/align/object_registration.py:41].
+ *   - A pose is a row-major (dim+1)x(dim+1) float64 matrix mapping map 2 into map 1
+ *     [REF roman/align/object_registration.py:88-129]; always stored in 16 doubles.
+ */
+#ifndef ROMAN_HIP_H
+#define ROMAN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* exported from libroman_hip.so (the library is built with -fvisibility=hidden) */
+#if defined(__GNUC__)
+#define ROMAN_API __attribute__((visibility("default")))
+#else
+#define ROMAN_API
+#endif
+
+#define ROMAN_MAX_RATIO_FEATURES 8
+
+/* error codes */
+#define ROMAN_OK                0
+#define ROMAN_E_INVALID        -1   /* bad argument (NULL pointer, dim not 2/3, ...)            */
+#define ROMAN_E_NO_DEVICE      -2   /* no HIP device / wrong architecture                        */
+#define ROMAN_E_HIP            -3   /* a HIP runtime call failed (see roman_last_error)          */
+#define ROMAN_E_NOMEM          -4   /* device or host allocation failed                          */
+#define ROMAN_E_UNSUPPORTED    -5   /* parameter combination the reference does not define       */
+#define ROMAN_E_TOO_LARGE      -6   /* problem exceeds the index width of this build             */
+
+/* per-problem status written to status_out[] (bit flags) */
+#define ROMAN_ST_OK                  0
+#define ROMAN_ST_EMPTY_MAP           1  /* n1==0 or n2==0: register() returns (1,0) array [REF object_registration.py:23-24] */
+#define ROMAN_ST_INSUFFICIENT        2  /* fewer than `dim` associations: T_align raises InsufficientAssociationsException [REF object_registration.py:107-108] */
+#define ROMAN_ST_MAXITER             4  /* solver stopped on maxoliters                          */
+#define ROMAN_ST_ASSOC_TRUNCATED     8  /* more selected associations than kmax (output clipped) */
+#define ROMAN_ST_TIE_FALLBACK       16  /* top-omega boundary tie: sequential heap emulation ran */
+
+/* which invariant scores association pairs */
+#define ROMAN_INV_EUCLIDEAN  0  /* clipperpy.invariants.EuclideanDistance + clipperpy.CLIPPER
+                                   [REF roman/align/dist_reg_with_pruning.py:48-57]            */
+#define ROMAN_INV_ROMAN      1  /* clipperpy.invariants.ROMAN + clipperpy.CLIPPERPairwiseAndSingle
+                                   [REF roman/align/roman_registration.py:82-86]               */
+
+/* clipperpy.invariants.ROMAN.{GEOMETRIC_MEAN,ARITHMETIC_MEAN,PRODUCT}
+   [REF roman/align/roman_registration.py:11-14] */
+#define ROMAN_FUSE_GEOMETRIC_MEAN  0
+#define ROMAN_FUSE_ARITHMETIC_MEAN 1
+#define ROMAN_FUSE_PRODUCT         2
+
+/*
+ * Invariant + solver parameters.  Replaces clipperpy.invariants.ROMANParams /
+ * EuclideanDistanceParams (attributes set at [REF roman/align/roman_registration.py:55-78],
+ * [REF roman/align/dist_reg_with_pruning.py:49-52]) and clipperpy.Params (always
+ * default-constructed: [REF roman/align/roman_registration.py:84]).
+ * roman_params_default() fills the defaults documented in DESIGN.md §"Pinned decisions".
+ */
+typedef struct roman_params {
+    /* invariant */
+    int32_t invariant;            /* ROMAN_INV_*                                              */
+    int32_t point_dim;            /* 2 or 3                                                   */
+    int32_t ratio_feature_dim;    /* <= ROMAN_MAX_RATIO_FEATURES                              */
+    int32_t cos_feature_dim;      /* descriptor length d (0 = no semantics)                   */
+    int32_t fusion_method;        /* ROMAN_FUSE_*                                             */
+    int32_t gravity_guided;       /* 0/1; requires point_dim==3                               */
+    int32_t drift_aware;          /* must be 0 (the reference always passes False)            */
+    int32_t rescale_u0;           /* clipperpy.Params.rescale_u0 (default 1)                  */
+    double  sigma;
+    double  epsilon;
+    double  mindist;
+    double  distance_weight;
+    double  ratio_weight;
+    double  cosine_weight;
+    double  cosine_min;
+    double  cosine_max;
+    double  gravity_unc_ang_rad;
+    double  ratio_epsilon[ROMAN_MAX_RATIO_FEATURES];
+    /* solver: clipperpy.Params */
+    double  tol_u;                /* 1e-8  */
+    double  tol_F;                /* 1e-9  */
+    double  beta;                 /* 0.25  */
+    double  eps;                  /* 1e-9  */
+    double  affinityeps;          /* 1e-4  */
+    int32_t maxiniters;           /* 200   */
+    int32_t maxoliters;           /* 1000  */
+    int32_t maxlsiters;           /* 99    */
+    int32_t reserved;
+} roman_params_t;
+
+/* per-problem statistics (the quantities SURVEY.md §8(d) builds the roofline from) */
+typedef struct roman_stats {
+    int32_t n_assoc_in;    /* A: associations scored                                          */
+    int32_t n_live;        /* L: associations with a non-zero single score (== A for EUCLIDEAN) */
+    int64_t nnz_upper;     /* stored non-zeros of the strict upper triangle of M              */
+    int32_t n_pass;        /* sparse matrix-vector passes over M the solver performed         */
+    int32_t outer_iters;   /* homotopy (d-update) iterations                                  */
+    int32_t inner_iters;   /* accepted projected-gradient steps                               */
+    int32_t ls_trials;     /* line-search trials (each is one pass)                           */
+    double  score;         /* F = u'Mu at exit (clipper.get_solution().score)                 */
+    double  d_final;       /* final homotopy penalty                                          */
+} roman_stats_t;
+
+typedef struct roman_ctx roman_ctx_t;
+
+/* ------------------------------------------------------------------------------------------- */
+/* library / context                                                                           */
+/* ------------------------------------------------------------------------------------------- */
+
+/* Fill *p with the reference defaults: ROMAN invariant, dim 3, sigma .4, epsilon .6,
+   mindist .2 [REF roman/params/submap_align_params.py:66-74], weights 1
+   [REF roman/align/roman_registration.py:64-66], clipperpy.Params() defaults. */
+ROMAN_API int roman_params_default(roman_params_t* p);
+
+/* Create a context bound to HIP device `device`.  `stream` is a hipStream_t passed as void*
+   (NULL = the library creates and owns its own non-blocking stream).  The context owns all
+   device workspace; it grows on demand and is reused across calls.  One context per
+   (device, stream); calls on one context must not overlap.  Replaces the per-call
+   `clipperpy.CLIPPER*(invariant, params)` construction of
+   [REF roman/align/object_registration.py:25]. */
+ROMAN_API int roman_ctx_create(roman_ctx_t** ctx, int device, void* stream);
+ROMAN_API int roman_ctx_destroy(roman_ctx_t* ctx);
+
+/* Human-readable text of the last error on this context (or of the last context-less error
+   when ctx == NULL).  The pointer stays valid until the next call on the same context. */
+ROMAN_API const char* roman_last_error(const roman_ctx_t* ctx);
+
+/* ------------------------------------------------------------------------------------------- */
+/* the hot path, batched: score -> solve -> select -> pose for B independent submap pairs      */
+/* ------------------------------------------------------------------------------------------- */
+
+/*
+ * roman_align_batch_dev: bulk data device-resident.
+ *
+ * Replaces, for each of the B problems, the reference sequence
+ *     clipper.score_pairwise_and_single_consistency(D1, D2, A)   [REF roman/align/roman_registration.py:95]
+ *  or clipper.score_pairwise_consistency(D1, D2, A)              [REF roman/align/object_registration.py:47]
+ *     clipper.solve()                                            [REF roman/align/object_registration.py:27]
+ *     clipper.get_selected_associations()                        [REF roman/align/object_registration.py:28]
+ *     ObjectRegistration.T_align(map1, map2, associations)       [REF roman/align/object_registration.py:88-129]
+ * i.e. the body of the serial double loop at [REF roman/align/submap_align.py:93-200].
+ *
+ *   feats      DEVICE, float64: pool of object-major feature matrices (F doubles per object)
+ *   off1/off2  HOST, int64[B]: index (in objects) of problem b's first map-1 / map-2 object
+ *              in `feats` (several problems may share a submap: the all-pairs grid)
+ *   n1/n2      HOST, int32[B]: objects in map 1 / map 2 of problem b
+ *   F          features per object = point_dim + ratio_feature_dim + cos_feature_dim
+ *   assoc      DEVICE, int32 (sum A_b, 2) or NULL (= all-to-all for every problem)
+ *   assoc_off  HOST, int64[B+1] row offsets into assoc (ignored when assoc == NULL)
+ *   u0         DEVICE, float64 initial vectors, concatenated per problem in association order,
+ *              or NULL (= all ones; DESIGN.md decision H1)
+ *   kmax       capacity (rows) of each problem's slot in assoc_out
+ *   assoc_out  DEVICE, int32[B][kmax][2]: selected associations (map-1 index, map-2 index),
+ *              in clipperpy order (descending u)
+ *   n_assoc_out DEVICE, int32[B]
+ *   T_out      DEVICE, float64[B][16]: pose map2->map1, row-major (dim+1)^2 in the leading
+ *              entries; NaN-filled when status has ROMAN_ST_INSUFFICIENT/EMPTY_MAP
+ *              (the sentinel of [REF roman/align/submap_align.py:179-184])
+ *   status_out DEVICE, int32[B]
+ *   stats_out  DEVICE, roman_stats_t[B] or NULL
+ *
+ * The small per-problem metadata arrays are host memory (the library stages them itself);
+ * all bulk data stays in HBM.
+ * Asynchronous on the context's stream except for one internal 16-byte read-back that sizes
+ * the sparse workspace.  Results are complete once the stream is synchronised.
+ */
+ROMAN_API int roman_align_batch_dev(roman_ctx_t* ctx, const roman_params_t* params, int32_t B,
+                          const double* feats, const int64_t* off1, const int32_t* n1,
+                          const int64_t* off2, const int32_t* n2, int32_t F,
+                          const int32_t* assoc, const int64_t* assoc_off,
+                          const double* u0,
+                          int32_t kmax, int32_t* assoc_out, int32_t* n_assoc_out,
+                          double* T_out, int32_t* status_out, roman_stats_t* stats_out);
+
+/* Same contract with HOST pointers everywhere; `n_objects` = number of objects in `feats`.
+   Copies in, runs roman_align_batch_dev, copies out, synchronises.  This is what a cgo/ctypes
+   binding that holds NumPy arrays calls. */
+ROMAN_API int roman_align_batch(roman_ctx_t* ctx, const roman_params_t* params, int32_t B,
+                      const double* feats, int64_t n_objects,
+                      const int64_t* off1, const int32_t* n1,
+                      const int64_t* off2, const int32_t* n2, int32_t F,
+                      const int32_t* assoc, const int64_t* assoc_off,
+                      const double* u0,
+                      int32_t kmax, int32_t* assoc_out, int32_t* n_assoc_out,
+                      double* T_out, int32_t* status_out, roman_stats_t* stats_out);
+
+/* ------------------------------------------------------------------------------------------- */
+/* stepwise surface for the clipperpy-compatible shim (single problem, host pointers)          */
+/* ------------------------------------------------------------------------------------------- */
+
+/* clipperpy.utils.create_all_to_all(n1, n2) [REF roman/align/object_registration.py:41]:
+   out is (n1*n2, 2) int32, row i*n2+j = (i, j).  Pure host helper. */
+ROMAN_API int roman_create_all_to_all(int32_t n1, int32_t n2, int32_t* out);
+
+/* score_pairwise_consistency / score_pairwise_and_single_consistency
+   [REF roman/align/object_registration.py:47], [REF roman/align/roman_registration.py:95]:
+   builds M (and C, which has M's pattern) for ONE problem on the device and keeps it in the
+   context.  assoc may be NULL (all-to-all). */
+ROMAN_API int roman_score(roman_ctx_t* ctx, const roman_params_t* params,
+                const double* D1, int32_t n1, const double* D2, int32_t n2, int32_t F,
+                const int32_t* assoc, int32_t n_assoc);
+
+/* clipper.set_matrix_data(M=, C=) [REF roman/align/object_registration.py:64]: dense
+   row-major (n,n) float64 M and C; like upstream only the strict upper triangles are used
+   and the diagonal is the implicit identity.  Keeps the matrices in the context. */
+ROMAN_API int roman_set_matrix_data(roman_ctx_t* ctx, const roman_params_t* params,
+                          const double* M, const double* C, int32_t n);
+
+/* clipper.solve() [REF roman/align/object_registration.py:27,65] on the matrices held by
+   the context.  u0 may be NULL (all ones). */
+ROMAN_API int roman_solve(roman_ctx_t* ctx, const double* u0);
+
+/* Size queries + getters for the last roman_score/roman_set_matrix_data/roman_solve. */
+ROMAN_API int roman_num_associations(const roman_ctx_t* ctx, int32_t* n_assoc);       /* rows of A     */
+ROMAN_API int roman_num_selected(const roman_ctx_t* ctx, int32_t* n_sel);             /* len(nodes)    */
+/* clipper.get_selected_associations() [REF object_registration.py:28]: (n_sel,2) int32 */
+ROMAN_API int roman_get_selected_associations(const roman_ctx_t* ctx, int32_t* out);
+/* clipper.get_solution().nodes / .u / .score [REF object_registration.py:67-71] */
+ROMAN_API int roman_get_solution(const roman_ctx_t* ctx, int32_t* nodes, double* u, double* score,
+                       roman_stats_t* stats);
+/* clipper.get_affinity_matrix() / get_constraint_matrix() [REF object_registration.py:53-54]:
+   dense row-major (A,A) float64, symmetric, diagonal included (1 for EUCLIDEAN, the single
+   score for ROMAN; C's diagonal is 1).  Caller provides A*A doubles each; either may be NULL. */
+ROMAN_API int roman_get_dense_matrices(const roman_ctx_t* ctx, double* M, double* C);
+/* Sparse export of the same (strict upper triangle, CSR over association indices, ascending
+   columns) for tests: call with NULL arrays to get nnz first. */
+ROMAN_API int roman_get_upper_csr(const roman_ctx_t* ctx, int64_t* nnz, int64_t* rowptr /*A+1*/,
+                        int32_t* cols, double* vals, double* diag /*A*/);
+
+/* ------------------------------------------------------------------------------------------- */
+/* pose from given correspondences                                                             */
+/* ------------------------------------------------------------------------------------------- */
+
+/* ObjectRegistration.T_align(map1, map2, correspondences) [REF object_registration.py:88-129]
+   for B independent correspondence sets, host pointers.  pts1/pts2: (sum k_b, dim) float64
+   row-major already gathered point pairs ([REF :110-111]); corr_off: int64[B+1].
+   T_out: B x 16 doubles; status_out: ROMAN_ST_INSUFFICIENT when k_b < dim ([REF :107-108]). */
+ROMAN_API int roman_pose_batch(roman_ctx_t* ctx, int32_t dim, int32_t B,
+                     const double* pts1, const double* pts2, const int64_t* corr_off,
+                     double* T_out, int32_t* status_out);
+
+/* ------------------------------------------------------------------------------------------- */
+/* instrumentation                                                                             */
+/* ------------------------------------------------------------------------------------------- */
+
+/* When enabled, the batch call brackets each of its kernels with hipEvents on the context's
+   stream; roman_profile_get returns the accumulated per-stage milliseconds and launch counts
+   since the last roman_profile_reset.  Stage ids: */
+#define ROMAN_STAGE_SINGLE   0   /* norms, cos-sim MFMA GEMM, distance tables, single scores + live compaction */
+#define ROMAN_STAGE_COUNT_PASS 1 /* affinity candidate count + row/problem scans (+ the 16-byte read-back)     */
+#define ROMAN_STAGE_FILL     2   /* affinity fill: candidates -> CSR values                                    */
+#define ROMAN_STAGE_SOLVE    3   /* persistent projected-gradient solver (+ select + pose): ONE kernel launch  */
+#define ROMAN_STAGE_COUNT    4
+ROMAN_API int roman_profile_enable(roman_ctx_t* ctx, int on);
+ROMAN_API int roman_profile_reset(roman_ctx_t* ctx);
+ROMAN_API int roman_profile_get(roman_ctx_t* ctx, double ms[ROMAN_STAGE_COUNT],
+                      int64_t launches[ROMAN_STAGE_COUNT]);
+
+/* Diagnostics for tests: evaluate a device math primitive elementwise (host pointers).
+   kind 0: sqrt(x)  1: exp(x)  2: cbrt(x)  3: x/y (y = in2)  4: pow(x,y).  Used to check that
+   the device's +,-,*,/,sqrt are bit-identical to the host's (pattern parity) and to measure
+   the ulp distance of the transcendental functions. */
+ROMAN_API int roman_debug_math(roman_ctx_t* ctx, int kind, const double* in1, const double* in2,
+                     int64_t n, double* out);
+/* Diagnostics for tests: normalised cosine matrix (n1 x n2, row-major) of the cosine-feature
+   blocks of two object-major feature matrices, computed by the f64 MFMA kernel of stage SINGLE. */
+ROMAN_API int roman_debug_cosine(roman_ctx_t* ctx, const roman_params_t* params,
+                       const double* D1, int32_t n1, const double* D2, int32_t n2, int32_t F,
+                       double* out);
+/* Diagnostics for tests: live association list of the last roman_score (original association
+   index and single score of every live association, ascending). n_live via roman_get_solution
+   stats or by calling with NULL arrays. */
+ROMAN_API int roman_debug_live(const roman_ctx_t* ctx, int32_t* n_live, int32_t* idx, double* score);
+
+/* Library build info: "roman_hip <version> gfx950 ..." */
+ROMAN_API const char* roman_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ROMAN_HIP_H */

@@ -1,0 +1,953 @@
+// kernels.hip.h — gfx950 (CDNA4, wave64) device code of libroman_hip.so.
+//
+// Pipeline for a batch of B independent submap pairs (one "problem" each):
+//   k_norms   per-object descriptor norms                       (cos_feature_dim > 0)
+//   k_cos     normalised cosine matrix, f64 MFMA 16x16x4        (cos_feature_dim > 0)
+//   k_tables  intra-map distance tables with NaN sentinels      (n1^2 + n2^2 entries)
+//   k_live    single scores + ordered compaction of live associations
+//   k_rowbase prefix of live counts over problems
+//   k_pairs<COUNT> / k_rowscan / k_probscan / k_pairs<FILL>     sparse affinity build
+//   k_solve   persistent per-problem projected-gradient solver + top-omega + Umeyama pose
+//
+// Numerics contract (tests/test_gpu_parity.py): every decision that shapes the sparsity
+// pattern of M uses only +,-,*,sqrt and comparisons, compiled with -ffp-contract=off, so the
+// pattern is bit-identical to oracle/clipper_oracle.c; transcendental values (exp, cbrt, pow)
+// may differ from glibc by an ulp.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/roman_hip.h"
+
+namespace roman {
+
+constexpr int WAVE = 64;
+
+struct DevParams {
+    roman_params_t p;
+    double sig2;        // sigma^2
+    double sin_unc;     // sin(gravity_unc_ang_rad)
+    double x_eps;       // smallest x with sqrt(x) >= epsilon   (c < eps  <=>  c*c-sum < x_eps)
+    double x_mindist;   // smallest x with sqrt(x) >= mindist   (l < mindist <=> l^2 < x_mindist)
+    int32_t single;     // invariant has per-association scores
+    int32_t gravity;    // ROMAN invariant && gravity_guided
+    int32_t F;          // features per object
+    int32_t pad;
+};
+
+struct ProbDesc {
+    int64_t off1, off2;    // first object of map 1 / map 2 in the feature pool
+    int64_t assocOff;      // row offset into the explicit association list, -1 = all-to-all
+    int64_t liveOff;       // offset into pools with one slot per input association
+    int64_t cosOff;        // offset into the cosine pool (n1*n2)
+    int64_t tabOff;        // offset into the table pool (n1*n1 then n2*n2)
+    int64_t normOff;       // offset into the norm pool (n1 then n2)
+    int32_t n1, n2, nA, pad;
+};
+
+struct ProbState {
+    int32_t  L;            // live associations
+    int32_t  rowBase;      // prefix of L over the batch
+    int64_t  nnzOff;       // offset of this problem's CSR segment
+    uint32_t nnzCap;       // candidate entries allocated for this problem
+    uint32_t pad;
+    unsigned long long nnzUpper;   // stored strict-upper non-zeros (after the affinityeps filter)
+};
+
+struct BatchTotals {
+    int64_t nnzTotal;      // sum of nnzCap
+    int32_t R;             // sum of L
+    int32_t maxL;
+};
+
+// ---------------------------------------------------------------------------------------------
+// small helpers
+// ---------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ double d_nan() { return __longlong_as_double(0x7ff8000000000000LL); }
+
+// association index p of problem pd -> (map-1 object, map-2 object)
+__device__ __forceinline__ void decode_assoc(const ProbDesc& pd, const int32_t* __restrict__ assoc,
+                                             int p, int& i, int& j)
+{
+    if (pd.assocOff >= 0) { i = assoc[2 * (pd.assocOff + p)]; j = assoc[2 * (pd.assocOff + p) + 1]; }
+    else { i = p / pd.n2; j = p - i * pd.n2; }
+}
+
+__device__ __forceinline__ double root_w(double x, double w)
+{
+    if (w == 1.0) return x;
+    if (w == 2.0) return sqrt(x);
+    if (w == 3.0) return cbrt(x);
+    return pow(x, 1.0 / w);
+}
+__device__ __forceinline__ double pow_w(double x, double w) { return (w == 1.0) ? x : pow(x, w); }
+
+// Single score of one association; mirrors oracle single_score() operation for operation.
+__device__ inline double single_score(const DevParams& D, const double* __restrict__ fi,
+                                      const double* __restrict__ fj, double cosv)
+{
+    const roman_params_t& P = D.p;
+    const int pd = P.point_dim, Fr = P.ratio_feature_dim, Fc = P.cos_feature_dim;
+    double wsum = 0.0, prod = 1.0, asum = 0.0;
+    if (Fr > 0) {
+        double rp = 1.0;
+        for (int f = 0; f < Fr; ++f) {
+            const double a = fi[pd + f], b = fj[pd + f];
+            const double mn = a < b ? a : b, mx = a < b ? b : a;
+            const double r = (mx > 0.0) ? mn / mx : 1.0;
+            if (r < P.ratio_epsilon[f]) return 0.0;
+            rp *= r;
+        }
+        const double R = root_w(rp, (double)Fr);
+        prod *= pow_w(R, P.ratio_weight); asum += P.ratio_weight * R; wsum += P.ratio_weight;
+    }
+    if (Fc > 0) {
+        double c = (cosv - P.cosine_min) / (P.cosine_max - P.cosine_min);
+        if (!(c > 0.0)) return 0.0;
+        if (c > 1.0) c = 1.0;
+        prod *= pow_w(c, P.cosine_weight); asum += P.cosine_weight * c; wsum += P.cosine_weight;
+    }
+    if (wsum == 0.0) return 1.0;
+    switch (P.fusion_method) {
+    case ROMAN_FUSE_ARITHMETIC_MEAN: return asum / wsum;
+    case ROMAN_FUSE_PRODUCT:         return prod;
+    default:                         return root_w(prod, wsum);
+    }
+}
+
+// Fusion of the pair score with the two single scores; mirrors oracle fuse_pair().
+__device__ __forceinline__ double fuse_pair(const DevParams& D, double sa, double sp, double sq)
+{
+    if (!D.single) return sa;
+    if (sa == 0.0 || sp == 0.0 || sq == 0.0) return 0.0;
+    const double ss = sp * sq, wd = D.p.distance_weight;
+    switch (D.p.fusion_method) {
+    case ROMAN_FUSE_ARITHMETIC_MEAN: return (wd * sa + (sp + sq)) / (wd + 2.0);
+    case ROMAN_FUSE_PRODUCT:         return sa * ss;
+    default:                         return root_w(pow_w(sa, wd) * ss, wd + 2.0);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_norms: one wave per object, Euclidean norm of its cosine-feature block
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_norms(DevParams D, const ProbDesc* __restrict__ probs,
+                                               const double* __restrict__ feats,
+                                               double* __restrict__ normPool)
+{
+    const ProbDesc pd = probs[blockIdx.y];
+    const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (o >= pd.n1 + pd.n2) return;
+    const int64_t obj = (o < pd.n1) ? pd.off1 + o : pd.off2 + (o - pd.n1);
+    const double* f = feats + obj * D.F + D.p.point_dim + D.p.ratio_feature_dim;
+    double s = 0.0;
+    for (int k = lane; k < D.p.cos_feature_dim; k += WAVE) s = fma(f[k], f[k], s);
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) normPool[pd.normOff + o] = sqrt(s);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_cos: cos[i][j] = <d1_i, d2_j> / (|d1_i| |d2_j|), one 16x16 tile per wave on the f64 matrix
+// core (v_mfma_f64_16x16x4_f64).  Operand layout: lane l supplies A[i = l&15][k = l>>4] and
+// B[k = l>>4][j = l&15]; result reg r of lane l is C[row = (l>>4) + 4r][col = l&15].
+// ---------------------------------------------------------------------------------------------
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+__global__ void __launch_bounds__(256) k_cos(DevParams D, const ProbDesc* __restrict__ probs,
+                                             const double* __restrict__ feats,
+                                             const double* __restrict__ normPool,
+                                             double* __restrict__ cosPool)
+{
+    const ProbDesc pd = probs[blockIdx.y];
+    const int tj_n = (pd.n2 + 15) >> 4, ti_n = (pd.n1 + 15) >> 4;
+    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= ti_n * tj_n) return;
+    const int lane = threadIdx.x & 63;
+    const int i0 = (tile / tj_n) << 4, j0 = (tile % tj_n) << 4;
+    const int Fc = D.p.cos_feature_dim, coff = D.p.point_dim + D.p.ratio_feature_dim;
+    const int ia = i0 + (lane & 15), jb = j0 + (lane & 15), kq = lane >> 4;
+    const bool va = ia < pd.n1, vb = jb < pd.n2;
+    const double* fa = feats + (pd.off1 + (va ? ia : 0)) * D.F + coff;
+    const double* fb = feats + (pd.off2 + (vb ? jb : 0)) * D.F + coff;
+    double4_t acc = {0.0, 0.0, 0.0, 0.0};
+    int k0 = 0;
+    for (; k0 + 4 <= Fc; k0 += 4) {
+        const double a = va ? fa[k0 + kq] : 0.0;
+        const double b = vb ? fb[k0 + kq] : 0.0;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    }
+    if (k0 < Fc) {                                   // ragged tail of the descriptor
+        const bool vk = (k0 + kq) < Fc;
+        const double a = (va && vk) ? fa[k0 + kq] : 0.0;
+        const double b = (vb && vk) ? fb[k0 + kq] : 0.0;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    }
+    const double* nr1 = normPool + pd.normOff;
+    const double* nr2 = nr1 + pd.n1;
+    const int col = j0 + (lane & 15);
+    if (col < pd.n2) {
+        const double nb = nr2[col];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = i0 + (lane >> 4) + 4 * r;
+            if (row < pd.n1) {
+                const double na = nr1[row];
+                cosPool[pd.cosOff + (int64_t)row * pd.n2 + col] =
+                    (na > 0.0 && nb > 0.0) ? acc[r] / (na * nb) : 0.0;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_tables: TA[i][i'] (n1 x n1) and TB[j][j'] (n2 x n2).  Entry = horizontal distance (gravity)
+// or full distance (otherwise) between two objects of the same map; NaN when the two objects
+// coincide (distinctness) or are closer than mindist — every comparison against NaN is false, so
+// one table lookup implements the distinctness skip, the mindist gate and the distance itself.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_tables(DevParams D, const ProbDesc* __restrict__ probs,
+                                                const double* __restrict__ feats,
+                                                double* __restrict__ tabPool)
+{
+    const ProbDesc pd = probs[blockIdx.y];
+    const int64_t nA2 = (int64_t)pd.n1 * pd.n1, nB2 = (int64_t)pd.n2 * pd.n2;
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nA2 + nB2) return;
+    int64_t base; int n, a, b;
+    if (e < nA2) { n = pd.n1; a = (int)(e / n); b = (int)(e % n); base = pd.off1; }
+    else { const int64_t e2 = e - nA2; n = pd.n2; a = (int)(e2 / n); b = (int)(e2 % n); base = pd.off2; }
+    const double* pa = feats + (base + a) * D.F;
+    const double* pb = feats + (base + b) * D.F;
+    const double dx = pa[0] - pb[0], dy = pa[1] - pb[1];
+    const double dz = (D.p.point_dim == 3) ? pa[2] - pb[2] : 0.0;
+    const double h2 = dx * dx + dy * dy;
+    const double l2 = h2 + dz * dz;
+    const bool bad = (a == b) || (D.p.mindist > 0.0 && l2 < D.x_mindist);
+    const double v = D.gravity ? sqrt(h2) : sqrt(l2);
+    tabPool[pd.tabOff + e] = bad ? d_nan() : v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_live: per problem, single score of every association and ordered (ascending association
+// index) compaction of the live ones.  1024 threads; wave w owns a contiguous segment so the
+// compaction needs a single cross-wave prefix.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) k_live(DevParams D, const ProbDesc* __restrict__ probs,
+                                               ProbState* __restrict__ st,
+                                               const double* __restrict__ feats,
+                                               const int32_t* __restrict__ assoc,
+                                               const double* __restrict__ cosPool,
+                                               double* __restrict__ sTmp,
+                                               int32_t* __restrict__ lp, int32_t* __restrict__ li,
+                                               int32_t* __restrict__ lj, double* __restrict__ ls,
+                                               double* __restrict__ lza, double* __restrict__ lzb)
+{
+    __shared__ int wtot[16];
+    const int b = blockIdx.x;
+    const ProbDesc pd = probs[b];
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, nw = blockDim.x >> 6;
+    const int nA = pd.nA;
+    const int seg = (((nA + nw - 1) / nw) + 63) & ~63;
+    const int p_beg = w * seg, p_end = min(nA, p_beg + seg);
+    const int Fc = D.p.cos_feature_dim;
+    double* sT = sTmp + pd.liveOff;
+
+    int cnt = 0;
+    for (int p0 = p_beg; p0 < p_end; p0 += WAVE) {
+        const int p = p0 + lane;
+        double s = 0.0;
+        if (p < p_end) {
+            int i, j;
+            decode_assoc(pd, assoc, p, i, j);
+            if (D.single) {
+                const double cosv = (Fc > 0) ? cosPool[pd.cosOff + (int64_t)i * pd.n2 + j] : 0.0;
+                s = single_score(D, feats + (pd.off1 + i) * D.F, feats + (pd.off2 + j) * D.F, cosv);
+            } else {
+                s = 1.0;
+            }
+            sT[p] = s;
+        }
+        cnt += __popcll(__ballot(s > 0.0));
+    }
+    if (lane == 0) wtot[w] = cnt;
+    __syncthreads();
+    int base = 0, total = 0;
+    for (int k = 0; k < nw; ++k) { if (k < w) base += wtot[k]; total += wtot[k]; }
+    if (tid == 0) { st[b].L = total; st[b].nnzUpper = 0ull; }
+
+    const int64_t lo = pd.liveOff;
+    for (int p0 = p_beg; p0 < p_end; p0 += WAVE) {
+        const int p = p0 + lane;
+        const double s = (p < p_end) ? sT[p] : 0.0;
+        const bool live = s > 0.0;
+        const unsigned long long m = __ballot(live);
+        if (live) {
+            const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+            int i, j;
+            decode_assoc(pd, assoc, p, i, j);
+            lp[lo + pos] = p; li[lo + pos] = i; lj[lo + pos] = j; ls[lo + pos] = s;
+            const bool has_z = D.p.point_dim == 3;
+            lza[lo + pos] = has_z ? feats[(pd.off1 + i) * D.F + 2] : 0.0;
+            lzb[lo + pos] = has_z ? feats[(pd.off2 + j) * D.F + 2] : 0.0;
+        }
+        base += __popcll(m);
+    }
+}
+
+// k_rowbase: serial prefix of the live counts (B is small); also the batch maxima.
+__global__ void k_rowbase(int B, ProbState* __restrict__ st, BatchTotals* __restrict__ tot)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int acc = 0, mx = 0;
+    for (int b = 0; b < B; ++b) { st[b].rowBase = acc; acc += st[b].L; mx = max(mx, st[b].L); }
+    tot->R = acc; tot->maxL = mx; tot->nnzTotal = 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_pairs: the O(L^2) affinity build.  One wave per live row k=(i,j); lanes sweep the live
+// columns q=(i',j').  The two table rows TA[i][:] and TB[j][:] are staged in this wave's slice
+// of LDS, so a pair costs two LDS gathers, two coalesced loads and ~10 f64 VALU ops.
+//   COUNT pass: candidates per row (pattern only: +,-,*,compare).
+//   FILL pass : candidates ballot-compacted in ascending column order into the row's CSR
+//               segment, then a dense sweep turns them into values (sqrt/exp/cbrt only on
+//               candidates) and drops the rare ones at or below affinityeps.
+// Rows are taken persistently (grid-stride over the batch's flattened row list).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int find_problem(const ProbState* __restrict__ st, int B, int r)
+{
+    int lo = 0, hi = B - 1;                  // last b with rowBase[b] <= r (L may be 0 for some b)
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (st[mid].rowBase <= r) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+template <bool FILL, bool GRAV, typename IdxT>
+__global__ void __launch_bounds__(1024) k_pairs(DevParams D, int B, const ProbDesc* __restrict__ probs,
+                                                ProbState* __restrict__ st,
+                                                const BatchTotals* __restrict__ tot,
+                                                const double* __restrict__ tabPool,
+                                                const int32_t* __restrict__ li, const int32_t* __restrict__ lj,
+                                                const double* __restrict__ ls,
+                                                const double* __restrict__ lza, const double* __restrict__ lzb,
+                                                uint32_t* __restrict__ rowCnt,
+                                                const uint32_t* __restrict__ rowStart,
+                                                uint32_t* __restrict__ rowLen,
+                                                IdxT* __restrict__ cols, double* __restrict__ vals,
+                                                int ldsPerWave /* doubles */)
+{
+    extern __shared__ __attribute__((aligned(16))) double s_tab[];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+    double* tA = s_tab + (size_t)w * ldsPerWave;
+    const int R = tot->R;
+    for (int r = blockIdx.x * wpb + w; r < R; r += gridDim.x * wpb) {
+        const int b = find_problem(st, B, r);
+        const ProbDesc pd = probs[b];
+        const int L = st[b].L, k = r - st[b].rowBase;
+        const int64_t lo = pd.liveOff;
+        const int i = li[lo + k], j = lj[lo + k];
+        const double zi = lza[lo + k], zj = lzb[lo + k];
+        double* tB = tA + pd.n1;
+        // stage the two table rows (wave-private slice; LDS ops of one wave execute in order)
+        const double* gA = tabPool + pd.tabOff + (int64_t)i * pd.n1;
+        const double* gB = tabPool + pd.tabOff + (int64_t)pd.n1 * pd.n1 + (int64_t)j * pd.n2;
+        for (int t = lane; t < pd.n1; t += WAVE) tA[t] = gA[t];
+        for (int t = lane; t < pd.n2; t += WAVE) tB[t] = gB[t];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+        uint32_t cnt = 0;
+        const int64_t segBase = FILL ? st[b].nnzOff + rowStart[lo + k] : 0;
+        for (int q0 = 0; q0 < L; q0 += WAVE) {
+            const int q = q0 + lane;
+            bool is = false; double x = 0.0;
+            if (q < L) {
+                const double a = tA[li[lo + q]], bb = tB[lj[lo + q]];
+                if (GRAV) {
+                    const double ch = fabs(a - bb);
+                    const double hm = a > bb ? a : bb;
+                    double cv = fabs((zi - lza[lo + q]) - (zj - lzb[lo + q])) - D.sin_unc * hm;
+                    if (cv < 0.0) cv = 0.0;
+                    x = ch * ch + cv * cv;
+                    is = x < D.x_eps;              // <=> sqrt(x) < epsilon ; NaN -> false
+                } else {
+                    x = fabs(a - bb);
+                    is = x < D.p.epsilon;
+                }
+            }
+            const unsigned long long m = __ballot(is);
+            if (FILL && is) {
+                const int64_t pos = segBase + cnt + __popcll(m & ((1ull << lane) - 1ull));
+                cols[pos] = (IdxT)q; vals[pos] = x;
+            }
+            cnt += __popcll(m);
+        }
+        if (!FILL) {
+            if (lane == 0) rowCnt[lo + k] = cnt;
+            continue;
+        }
+        // make this wave's candidate writes visible to its own lanes before the value sweep
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const double sk = ls[lo + k];
+        uint32_t kept = 0, upper = 0;
+        for (uint32_t e0 = 0; e0 < cnt; e0 += WAVE) {
+            const uint32_t e = e0 + lane;
+            bool keep = false; double v = 0.0; IdxT q = 0;
+            if (e < cnt) {
+                q = cols[segBase + e];
+                const double x = vals[segBase + e];
+                const double c = GRAV ? sqrt(x) : x;
+                const double sa = exp(((-0.5 * c) * c) / D.sig2);
+                v = fuse_pair(D, sa, sk, ls[lo + (int64_t)q]);
+                keep = v > D.p.affinityeps;
+            }
+            const unsigned long long m = __ballot(keep);
+            if (keep) {
+                const int64_t pos = segBase + kept + __popcll(m & ((1ull << lane) - 1ull));
+                cols[pos] = q; vals[pos] = v;       // pos <= segBase+e: in-place forward compaction
+            }
+            kept += __popcll(m);
+            upper += __popcll(__ballot(keep && (int)q > k));
+        }
+        if (lane == 0) {
+            rowLen[lo + k] = kept;
+            if (upper) atomicAdd(&st[b].nnzUpper, (unsigned long long)upper);
+        }
+    }
+}
+
+// k_rowscan: per problem exclusive scan of the candidate counts -> row starts + total.
+__global__ void __launch_bounds__(1024) k_rowscan(const ProbDesc* __restrict__ probs,
+                                                  ProbState* __restrict__ st,
+                                                  const uint32_t* __restrict__ rowCnt,
+                                                  uint32_t* __restrict__ rowStart)
+{
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t carry_s;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
+    const int L = st[b].L;
+    const int64_t lo = probs[b].liveOff;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int k0 = 0; k0 < L; k0 += blockDim.x) {
+        const int k = k0 + tid;
+        const uint32_t v = (k < L) ? rowCnt[lo + k] : 0u;
+        uint32_t inc = v;                                  // inclusive wave scan
+        for (int off = 1; off < WAVE; off <<= 1) { const uint32_t t = __shfl_up(inc, off); if (lane >= off) inc += t; }
+        if (lane == WAVE - 1) wsum[w] = inc;
+        __syncthreads();
+        uint32_t wbase = 0, tot = 0;
+        for (int t = 0; t < nw; ++t) { if (t < w) wbase += wsum[t]; tot += wsum[t]; }
+        const uint32_t carry = carry_s;
+        if (k < L) rowStart[lo + k] = carry + wbase + inc - v;
+        __syncthreads();
+        if (tid == 0) carry_s = carry + tot;
+        __syncthreads();
+    }
+    if (tid == 0) st[b].nnzCap = carry_s;
+}
+
+// k_probscan: serial prefix of the per-problem candidate totals.
+__global__ void k_probscan(int B, ProbState* __restrict__ st, BatchTotals* __restrict__ tot)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int64_t acc = 0;
+    for (int b = 0; b < B; ++b) { st[b].nnzOff = acc; acc += st[b].nnzCap; }
+    tot->nnzTotal = acc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// solver
+// ---------------------------------------------------------------------------------------------
+
+struct SolveOut {           // device pointers of the batch outputs
+    int32_t* assoc_out; int32_t* n_assoc_out; double* T_out; int32_t* status_out;
+    roman_stats_t* stats_out; int32_t kmax;
+    int32_t* nodesOrig;     // row pool: selected nodes as original association indices
+    int32_t* nSel;          // per problem: number of selected nodes (untruncated)
+    double*  uOut;          // row pool: final u over live associations
+};
+
+// Sum of (a, b) over the block, identical in every thread; fixed reduction tree.
+__device__ __forceinline__ void block_sum2(double& a, double& b, double* red, int tid, int nw)
+{
+    for (int off = 32; off > 0; off >>= 1) { a += __shfl_xor(a, off); b += __shfl_xor(b, off); }
+    if ((tid & 63) == 0) { red[2 * (tid >> 6)] = a; red[2 * (tid >> 6) + 1] = b; }
+    __syncthreads();
+    double ra = 0.0, rb = 0.0;
+    for (int i = 0; i < nw; ++i) { ra += red[2 * i]; rb += red[2 * i + 1]; }
+    __syncthreads();
+    a = ra; b = rb;
+}
+
+template <typename IdxT> struct IdxTraits;
+template <> struct IdxTraits<uint16_t> { static constexpr uint32_t CZ = 0x8000u; static constexpr uint32_t MASK = 0x7fffu; };
+template <> struct IdxTraits<uint32_t> { static constexpr uint32_t CZ = 0x80000000u; static constexpr uint32_t MASK = 0x7fffffffu; };
+
+// (M_off u)_r and (C_off u)_r for every row; T lanes cooperate on a row (T = power of two).
+template <typename IdxT>
+__device__ __forceinline__ void spmv_rows(const double* u, int L, const uint32_t* __restrict__ rowStart,
+                                          const uint32_t* __restrict__ rowLen,
+                                          const IdxT* __restrict__ cols, const double* __restrict__ vals,
+                                          double* __restrict__ Mu, double* __restrict__ Cu,
+                                          int T, int tid, int nt)
+{
+    const int ng = nt / T, g = tid / T, lg = tid & (T - 1);
+    for (int r = g; r < L; r += ng) {
+        const uint32_t s = rowStart[r], n = rowLen[r];
+        double am = 0.0, ac = 0.0;
+        for (uint32_t e = lg; e < n; e += T) {
+            const uint32_t c = cols[s + e];
+            const double v = vals[s + e];
+            const double uq = u[c & IdxTraits<IdxT>::MASK];
+            am = fma(v, uq, am);
+            ac += (c & IdxTraits<IdxT>::CZ) ? 0.0 : uq;
+        }
+        for (int off = T >> 1; off > 0; off >>= 1) { am += __shfl_xor(am, off); ac += __shfl_xor(ac, off); }
+        if (lg == 0) { Mu[r] = am; Cu[r] = ac; }
+    }
+}
+
+// One-sided Jacobi (Hestenes) SVD of a dxd matrix (d = 2 or 3), then the proper rotation
+// R = u1 v1' + u2 v2' + (u1 x u2)(v1 x v2)'   — equal to the reference's  U Vh  with the last
+// row of Vh negated when det = -1 ([REF roman/align/object_registration.py:121-126]).
+__device__ inline void kabsch_rotation(const double* H, int d, double* R)
+{
+    double G[9], V[9];
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) {
+        G[r * 3 + c] = (r < d && c < d) ? H[r * 3 + c] : 0.0;
+        V[r * 3 + c] = (r == c) ? 1.0 : 0.0;
+    }
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        double off = 0.0;
+        for (int p = 0; p < d - 1; ++p) for (int q = p + 1; q < d; ++q) {
+            double al = 0.0, be = 0.0, ga = 0.0;
+            for (int r = 0; r < d; ++r) { al += G[r * 3 + p] * G[r * 3 + p]; be += G[r * 3 + q] * G[r * 3 + q]; ga += G[r * 3 + p] * G[r * 3 + q]; }
+            if (ga == 0.0 || fabs(ga) <= 1e-17 * sqrt(al * be)) continue;
+            off = fmax(off, fabs(ga) / sqrt(al * be));
+            const double zeta = (be - al) / (2.0 * ga);
+            const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+            const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+            for (int r = 0; r < d; ++r) {
+                const double gp = G[r * 3 + p], gq = G[r * 3 + q];
+                G[r * 3 + p] = c * gp - s * gq; G[r * 3 + q] = s * gp + c * gq;
+                const double vp = V[r * 3 + p], vq = V[r * 3 + q];
+                V[r * 3 + p] = c * vp - s * vq; V[r * 3 + q] = s * vp + c * vq;
+            }
+        }
+        if (off < 1e-15) break;
+    }
+    double sg[3] = {0, 0, 0};
+    for (int c = 0; c < d; ++c) { double s = 0.0; for (int r = 0; r < d; ++r) s += G[r * 3 + c] * G[r * 3 + c]; sg[c] = sqrt(s); }
+    int i1 = 0; for (int c = 1; c < d; ++c) if (sg[c] > sg[i1]) i1 = c;
+    int i2 = -1; for (int c = 0; c < d; ++c) if (c != i1 && (i2 < 0 || sg[c] > sg[i2])) i2 = c;
+    double u1[3] = {0, 0, 0}, u2[3] = {0, 0, 0}, v1[3] = {0, 0, 0}, v2[3] = {0, 0, 0};
+    for (int r = 0; r < d; ++r) { v1[r] = V[r * 3 + i1]; v2[r] = V[r * 3 + i2]; }
+    if (sg[i1] > 0.0) { for (int r = 0; r < d; ++r) u1[r] = G[r * 3 + i1] / sg[i1]; }
+    else { u1[0] = 1.0; }                                               // H == 0: any rotation
+    if (d == 2) {
+        // R = u1 v1' + perp(u1) perp(v1)'
+        const double pu[2] = {-u1[1], u1[0]}, pv[2] = {-v1[1], v1[0]};
+        for (int r = 0; r < 2; ++r) for (int c = 0; c < 2; ++c) R[r * 3 + c] = u1[r] * v1[c] + pu[r] * pv[c];
+        return;
+    }
+    if (sg[i2] > 1e-300 && sg[i2] > 1e-14 * sg[i1]) { for (int r = 0; r < 3; ++r) u2[r] = G[r * 3 + i2] / sg[i2]; }
+    else {                                                              // rank <= 1: complete u1 arbitrarily
+        int m = 0; for (int r = 1; r < 3; ++r) if (fabs(u1[r]) < fabs(u1[m])) m = r;
+        double e[3] = {0, 0, 0}; e[m] = 1.0;
+        const double dp = u1[m];
+        double nn = 0.0; for (int r = 0; r < 3; ++r) { u2[r] = e[r] - dp * u1[r]; nn += u2[r] * u2[r]; }
+        nn = sqrt(nn); for (int r = 0; r < 3; ++r) u2[r] /= nn;
+    }
+    const double u3[3] = {u1[1] * u2[2] - u1[2] * u2[1], u1[2] * u2[0] - u1[0] * u2[2], u1[0] * u2[1] - u1[1] * u2[0]};
+    const double v3[3] = {v1[1] * v2[2] - v1[2] * v2[1], v1[2] * v2[0] - v1[0] * v2[2], v1[0] * v2[1] - v1[1] * v2[0]};
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) R[r * 3 + c] = u1[r] * v1[c] + u2[r] * v2[c] + u3[r] * v3[c];
+}
+
+// T (row-major (d+1)x(d+1) in the leading entries of 16 doubles) from centred sums.
+__device__ inline void write_pose(double* T, int d, const double* H, const double* m1, const double* m2)
+{
+    double R[9];
+    kabsch_rotation(H, d, R);
+    for (int t = 0; t < 16; ++t) T[t] = 0.0;
+    const int s = d + 1;
+    for (int r = 0; r < d; ++r) {
+        double tr = m1[r];
+        for (int c = 0; c < d; ++c) { T[r * s + c] = R[r * 3 + c]; tr -= R[r * 3 + c] * m2[c]; }
+        T[r * s + d] = tr;
+    }
+    T[d * s + d] = 1.0;
+}
+
+// Exact emulation of findIndicesOfkLargest (min-heap on (value,index); strict '<' replacement)
+// over the FULL association index space (dead associations have u == 0).  Single thread; only
+// runs when the k-th largest value is tied or fewer than omega entries are positive.
+__device__ inline bool hp_less(double va, int ia, double vb, int ib) { return va < vb || (va == vb && ia < ib); }
+__device__ void heap_select_serial(const double* u, const int32_t* lp, int L, int nA, int k,
+                                   double* hv, int32_t* hi /* capacity k */, int32_t* outNodesOrig)
+{
+    int sz = 0, nl = 0;
+    for (int p = 0; p < nA; ++p) {
+        double x = 0.0;
+        if (nl < L && lp[nl] == p) { x = u[nl]; ++nl; }
+        if (sz < k) {
+            int c = sz++; hv[c] = x; hi[c] = p;
+            while (c > 0) { const int par = (c - 1) >> 1; if (!hp_less(hv[c], hi[c], hv[par], hi[par])) break;
+                const double tv = hv[c]; const int ti = hi[c]; hv[c] = hv[par]; hi[c] = hi[par]; hv[par] = tv; hi[par] = ti; c = par; }
+        } else if (hv[0] < x) {
+            hv[0] = x; hi[0] = p;
+            int c = 0;
+            for (;;) { int l = 2 * c + 1, r = l + 1, s = c;
+                if (l < sz && hp_less(hv[l], hi[l], hv[s], hi[s])) s = l;
+                if (r < sz && hp_less(hv[r], hi[r], hv[s], hi[s])) s = r;
+                if (s == c) break;
+                const double tv = hv[c]; const int ti = hi[c]; hv[c] = hv[s]; hi[c] = hi[s]; hv[s] = tv; hi[s] = ti; c = s; }
+        }
+    }
+    const int kk = sz;
+    for (int t = 0; t < kk; ++t) {
+        outNodesOrig[kk - t - 1] = hi[0];
+        hv[0] = hv[sz - 1]; hi[0] = hi[sz - 1]; --sz;
+        int c = 0;
+        for (;;) { int l = 2 * c + 1, r = l + 1, s = c;
+            if (l < sz && hp_less(hv[l], hi[l], hv[s], hi[s])) s = l;
+            if (r < sz && hp_less(hv[r], hi[r], hv[s], hi[s])) s = r;
+            if (s == c) break;
+            const double tv = hv[c]; const int ti = hi[c]; hv[c] = hv[s]; hi[c] = hi[s]; hv[s] = tv; hi[s] = ti; c = s; }
+    }
+}
+
+/*
+ * solve_one: CLIPPER findDenseClique on one problem, by one workgroup.
+ * Mirrors oracle_solve() step for step (see there for the restated upstream algorithm):
+ * u and u_new live in LDS when they fit (ULDS), the per-row vectors Mu, Cu, Mu_new, Cu_new in
+ * the L2-resident row pools; gradF is recombined on the fly from (u, Mu, Cu, d, sum u).
+ */
+template <typename IdxT, bool ULDS>
+__device__ void solve_one(const DevParams& D, int b, const ProbDesc& pd, ProbState* st,
+                          const double* __restrict__ feats, const int32_t* __restrict__ assoc,
+                          const int32_t* __restrict__ lp, const double* __restrict__ ls,
+                          const uint32_t* __restrict__ rowStart, const uint32_t* __restrict__ rowLen,
+                          const IdxT* __restrict__ colsPool, const double* __restrict__ valsPool,
+                          double* __restrict__ vMu, double* __restrict__ vCu,
+                          double* __restrict__ vMun, double* __restrict__ vCun,
+                          double* __restrict__ gU, double* __restrict__ gUn,
+                          const double* __restrict__ u0, const SolveOut& O,
+                          double* su, double* sun, double* red, int* sint, int T)
+{
+    const roman_params_t& P = D.p;
+    const int tid = threadIdx.x, nt = blockDim.x, nw = nt >> 6;
+    const int L = st[b].L, rb = st[b].rowBase;
+    const int64_t lo = pd.liveOff;
+    const uint32_t* rs = rowStart + lo; const uint32_t* rl = rowLen + lo;
+    const IdxT* cols = colsPool + st[b].nnzOff; const double* vals = valsPool + st[b].nnzOff;
+    const double* sd = ls + lo;                       // diagonal M_pp = single score
+    double* Mu = vMu + rb; double* Cu = vCu + rb; double* Mun = vMun + rb; double* Cun = vCun + rb;
+    double* u = ULDS ? su : gU + rb;
+    double* un = ULDS ? sun : gUn + rb;
+    const int dim = P.point_dim;
+
+    int status = ROMAN_ST_OK;
+    roman_stats_t S;
+    S.n_assoc_in = pd.nA; S.n_live = L; S.nnz_upper = (int64_t)st[b].nnzUpper;
+    S.n_pass = 0; S.outer_iters = 0; S.inner_iters = 0; S.ls_trials = 0; S.score = 0.0; S.d_final = 0.0;
+    int nsel = 0;
+    double F = 0.0, d = 0.0;
+
+    if (pd.n1 == 0 || pd.n2 == 0) status |= ROMAN_ST_EMPTY_MAP;
+    if (L > 0) {
+        // ---- initialisation: u = normalize(M u0 + diag u0) ------------------------------------
+        for (int p = tid; p < L; p += nt) u[p] = u0 ? u0[lo + lp[lo + p]] : 1.0;
+        __syncthreads();
+        if (P.rescale_u0) {
+            spmv_rows<IdxT>(u, L, rs, rl, cols, vals, Mu, Cu, T, tid, nt); ++S.n_pass;
+            __syncthreads();
+            for (int p = tid; p < L; p += nt) u[p] = Mu[p] + sd[p] * u[p];
+            __syncthreads();
+        }
+        {
+            double ss = 0.0, dummy = 0.0;
+            for (int p = tid; p < L; p += nt) ss += u[p] * u[p];
+            block_sum2(ss, dummy, red, tid, nw);
+            const double nr = sqrt(ss);
+            if (nr > 0.0) for (int p = tid; p < L; p += nt) u[p] /= nr;
+            __syncthreads();
+        }
+        spmv_rows<IdxT>(u, L, rs, rl, cols, vals, Mu, Cu, T, tid, nt); ++S.n_pass;
+        double usum = 0.0;
+        { double dummy = 0.0; for (int p = tid; p < L; p += nt) usum += u[p]; block_sum2(usum, dummy, red, tid, nw); }
+        // block_sum2's barriers also order the Mu/Cu stores of spmv_rows before the reads below
+        {   // initial d: signed mean of (Mu)_p / Cbu_p over the active set
+            double acc = 0.0, cnt = 0.0;
+            for (int p = tid; p < L; p += nt) {
+                const double up = u[p], Cbu = (usum - Cu[p]) - up;
+                if (Cbu > P.eps && up > P.eps) { acc += (Mu[p] + sd[p] * up) / Cbu; cnt += 1.0; }
+            }
+            block_sum2(acc, cnt, red, tid, nw);
+            d = (cnt > 0.0) ? acc / cnt : 0.0;
+        }
+        // ---- projected gradient ascent with homotopy on d ---------------------------------------
+        int i;
+        for (i = 0; i < P.maxoliters; ++i) {
+            {
+                double f = 0.0, dummy = 0.0;
+                for (int p = tid; p < L; p += nt) {
+                    const double up = u[p];
+                    const double g = (((sd[p] + d) * up - d * usum) + Mu[p]) + Cu[p] * d;
+                    f += up * g;
+                }
+                block_sum2(f, dummy, red, tid, nw);
+                F = f;
+            }
+            for (int j = 0; j < P.maxiniters; ++j) {
+                double alpha = 1.0, Fnew = 0.0, deltaF = 0.0, unsum = 0.0, du2 = 0.0;
+                for (int k = 0; k < P.maxlsiters; ++k) {
+                    double ss = 0.0, dummy = 0.0;
+                    for (int p = tid; p < L; p += nt) {
+                        const double up = u[p];
+                        const double g = (((sd[p] + d) * up - d * usum) + Mu[p]) + Cu[p] * d;
+                        double t = up + alpha * g;
+                        t = t > 0.0 ? t : 0.0;
+                        un[p] = t; ss += t * t;
+                    }
+                    block_sum2(ss, dummy, red, tid, nw);
+                    const double nr = sqrt(ss);
+                    double s1 = 0.0, dd = 0.0;
+                    for (int p = tid; p < L; p += nt) {
+                        double t = un[p];
+                        if (nr > 0.0) { t /= nr; un[p] = t; }
+                        s1 += t;
+                        const double df = t - u[p]; dd += df * df;
+                    }
+                    block_sum2(s1, dd, red, tid, nw);
+                    unsum = s1; du2 = dd;
+                    spmv_rows<IdxT>(un, L, rs, rl, cols, vals, Mun, Cun, T, tid, nt); ++S.n_pass; ++S.ls_trials;
+                    __syncthreads();
+                    double f = 0.0;
+                    for (int p = tid; p < L; p += nt) {
+                        const double up = un[p];
+                        const double g = (((sd[p] + d) * up - d * unsum) + Mun[p]) + Cun[p] * d;
+                        f += up * g;
+                    }
+                    block_sum2(f, dummy, red, tid, nw);
+                    Fnew = f;
+                    deltaF = Fnew - F;
+                    if (deltaF < -P.eps) alpha *= P.beta; else break;
+                }
+                const double du = sqrt(du2);
+                F = Fnew; usum = unsum;
+                { double* t; t = u; u = un; un = t; t = Mu; Mu = Mun; Mun = t; t = Cu; Cu = Cun; Cun = t; }
+                ++S.inner_iters;
+                if (du < P.tol_u || fabs(deltaF) < P.tol_F) break;
+            }
+            double acc = 0.0, cnt = 0.0;
+            for (int p = tid; p < L; p += nt) {
+                const double up = u[p], Cbu = (usum - Cu[p]) - up;
+                if (Cbu > P.eps && up > P.eps) { acc += fabs((Mu[p] + sd[p] * up) / Cbu); cnt += 1.0; }
+            }
+            block_sum2(acc, cnt, red, tid, nw);
+            if (cnt > 0.0) d += acc / cnt; else break;
+        }
+        if (i >= P.maxoliters) status |= ROMAN_ST_MAXITER;
+        S.outer_iters = i; S.score = F; S.d_final = d;
+
+        // final u to the row pool (stepwise API, tests)
+        for (int p = tid; p < L; p += nt) O.uOut[rb + p] = u[p];
+
+        // ---- top-omega rounding --------------------------------------------------------------
+        const double om = round(F);
+        int omega = (om >= 2147483647.0) ? 2147483647 : (om < 1.0 ? 0 : (int)om);
+        if (omega > pd.nA) omega = pd.nA;
+        int32_t* nodesOrig = O.nodesOrig + rb;        // capacity L
+        int32_t* nodesLive = (int32_t*)Cun;           // scratch (capacity L ints)
+        double*  pv = Mun;                            // scratch: positive values
+        int32_t* pidx = (int32_t*)un;                 // scratch: their live indices (un is free now)
+        if (tid == 0) { sint[0] = 0; sint[1] = 0; }
+        __syncthreads();
+        if (omega > 0) {
+            // compact the positive entries (order irrelevant: ranks below are order-free)
+            for (int p = tid; p < L; p += nt) {
+                const double up = u[p];
+                if (up > 0.0) { const int pos = atomicAdd(&sint[0], 1); pv[pos] = up; pidx[pos] = p; }
+            }
+            __syncthreads();
+            const int Pn = sint[0];
+            bool fallback = (Pn < omega) || (omega > L);
+            if (!fallback) {
+                // rank of e = number of entries greater in (value, index) order
+                for (int e = tid; e < Pn; e += nt) {
+                    const double ve = pv[e]; const int ie = pidx[e];
+                    int rank = 0;
+                    for (int f2 = 0; f2 < Pn; ++f2) { const double vf = pv[f2]; rank += (vf > ve) || (vf == ve && pidx[f2] > ie); }
+                    if (rank < omega) nodesLive[rank] = ie;
+                    if (rank == omega - 1) { red[40] = ve; }
+                }
+                __syncthreads();
+                const double vstar = red[40];
+                int tie = 0;
+                for (int e = tid; e < Pn; e += nt) {
+                    if (pv[e] == vstar) {
+                        const double ve = pv[e]; const int ie = pidx[e];
+                        int rank = 0;
+                        for (int f2 = 0; f2 < Pn; ++f2) { const double vf = pv[f2]; rank += (vf > ve) || (vf == ve && pidx[f2] > ie); }
+                        if (rank >= omega) tie = 1;
+                    }
+                }
+                if (tie) atomicOr(&sint[1], 1);
+                __syncthreads();
+                fallback = sint[1] != 0;
+            }
+            if (fallback) {
+                status |= ROMAN_ST_TIE_FALLBACK;
+                __syncthreads();
+                if (tid == 0) {
+                    const int kk = min(omega, L);      // heap capacity bounded by the scratch size
+                    heap_select_serial(u, lp + lo, L, pd.nA, kk, pv, pidx, nodesOrig);
+                    sint[0] = kk;
+                }
+                __syncthreads();
+                nsel = sint[0];
+            } else {
+                nsel = omega;
+                for (int t = tid; t < nsel; t += nt) nodesOrig[t] = lp[lo + nodesLive[t]];
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- outputs: associations, pose, stats ------------------------------------------------------
+    const int32_t* nodesOrigR = O.nodesOrig + rb;
+    const int kout = min(nsel, O.kmax);
+    if (nsel > O.kmax) status |= ROMAN_ST_ASSOC_TRUNCATED;
+    for (int t = tid; t < kout; t += nt) {
+        int i, j;
+        decode_assoc(pd, assoc, nodesOrigR[t], i, j);
+        O.assoc_out[((int64_t)b * O.kmax + t) * 2 + 0] = i;
+        O.assoc_out[((int64_t)b * O.kmax + t) * 2 + 1] = j;
+    }
+    // pose from ALL selected associations ([REF object_registration.py:110-128], unit weights)
+    double Tp[16];
+    bool have_pose = false;
+    if (nsel >= dim && feats != nullptr && !(status & ROMAN_ST_EMPTY_MAP)) {
+        double m1[3] = {0, 0, 0}, m2[3] = {0, 0, 0};
+        for (int t = tid; t < nsel; t += nt) {
+            int i, j;
+            decode_assoc(pd, assoc, nodesOrigR[t], i, j);
+            const double* a = feats + (pd.off1 + i) * D.F; const double* bb = feats + (pd.off2 + j) * D.F;
+            for (int c = 0; c < dim; ++c) { m1[c] += a[c]; m2[c] += bb[c]; }
+        }
+        block_sum2(m1[0], m1[1], red, tid, nw); block_sum2(m1[2], m2[0], red, tid, nw); block_sum2(m2[1], m2[2], red, tid, nw);
+        for (int c = 0; c < 3; ++c) { m1[c] /= (double)nsel; m2[c] /= (double)nsel; }
+        double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (int t = tid; t < nsel; t += nt) {
+            int i, j;
+            decode_assoc(pd, assoc, nodesOrigR[t], i, j);
+            const double* a = feats + (pd.off1 + i) * D.F; const double* bb = feats + (pd.off2 + j) * D.F;
+            double q1[3] = {0, 0, 0}, q2[3] = {0, 0, 0};
+            for (int c = 0; c < dim; ++c) { q1[c] = a[c] - m1[c]; q2[c] = bb[c] - m2[c]; }
+            for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) H[r * 3 + c] += q1[r] * q2[c];
+        }
+        double z = 0.0;
+        block_sum2(H[0], H[1], red, tid, nw); block_sum2(H[2], H[3], red, tid, nw); block_sum2(H[4], H[5], red, tid, nw);
+        block_sum2(H[6], H[7], red, tid, nw); block_sum2(H[8], z, red, tid, nw);
+        if (tid == 0) write_pose(Tp, dim, H, m1, m2);
+        have_pose = true;
+    } else {
+        status |= ROMAN_ST_INSUFFICIENT;
+    }
+    if (tid == 0) {
+        for (int t = 0; t < 16; ++t) O.T_out[(int64_t)b * 16 + t] = have_pose ? Tp[t] : d_nan();
+        O.n_assoc_out[b] = kout;
+        O.status_out[b] = status;
+        O.nSel[b] = nsel;
+        if (O.stats_out) O.stats_out[b] = S;
+    }
+    __syncthreads();
+}
+
+template <typename IdxT>
+__global__ void __launch_bounds__(1024) k_solve(DevParams D, int B, const ProbDesc* __restrict__ probs,
+                                                ProbState* __restrict__ st,
+                                                const double* __restrict__ feats, const int32_t* __restrict__ assoc,
+                                                const int32_t* __restrict__ lp, const double* __restrict__ ls,
+                                                const uint32_t* __restrict__ rowStart, const uint32_t* __restrict__ rowLen,
+                                                const IdxT* __restrict__ cols, const double* __restrict__ vals,
+                                                double* __restrict__ vMu, double* __restrict__ vCu,
+                                                double* __restrict__ vMun, double* __restrict__ vCun,
+                                                double* __restrict__ gU, double* __restrict__ gUn,
+                                                const double* __restrict__ u0, SolveOut O,
+                                                int* __restrict__ queue, int Lcap, int T)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double* su = reinterpret_cast<double*>(smem);
+    double* sun = su + Lcap;
+    double* red = sun + Lcap;                 // 48 doubles
+    int* sint = reinterpret_cast<int*>(red + 48);   // 4 ints
+    for (;;) {
+        if (threadIdx.x == 0) sint[2] = atomicAdd(queue, 1);
+        __syncthreads();
+        const int b = sint[2];
+        __syncthreads();
+        if (b >= B) break;
+        const ProbDesc pd = probs[b];
+        if (st[b].L <= Lcap)
+            solve_one<IdxT, true>(D, b, pd, st, feats, assoc, lp, ls, rowStart, rowLen, cols, vals,
+                                  vMu, vCu, vMun, vCun, gU, gUn, u0, O, su, sun, red, sint, T);
+        else
+            solve_one<IdxT, false>(D, b, pd, st, feats, assoc, lp, ls, rowStart, rowLen, cols, vals,
+                                   vMu, vCu, vMun, vCun, gU, gUn, u0, O, su, sun, red, sint, T);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// standalone pose kernel: T_align on given correspondences (one wave per problem)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_pose(int dim, const double* __restrict__ pts1,
+                                             const double* __restrict__ pts2,
+                                             const int64_t* __restrict__ corrOff,
+                                             double* __restrict__ T_out, int32_t* __restrict__ status_out)
+{
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int64_t o = corrOff[b]; const int k = (int)(corrOff[b + 1] - o);
+    if (k < dim) {
+        if (lane == 0) { for (int t = 0; t < 16; ++t) T_out[(int64_t)b * 16 + t] = d_nan(); status_out[b] = ROMAN_ST_INSUFFICIENT; }
+        return;
+    }
+    double m1[3] = {0, 0, 0}, m2[3] = {0, 0, 0};
+    for (int t = lane; t < k; t += WAVE) for (int c = 0; c < dim; ++c) { m1[c] += pts1[(o + t) * dim + c]; m2[c] += pts2[(o + t) * dim + c]; }
+    for (int c = 0; c < 3; ++c) for (int off = 32; off > 0; off >>= 1) { m1[c] += __shfl_xor(m1[c], off); m2[c] += __shfl_xor(m2[c], off); }
+    for (int c = 0; c < 3; ++c) { m1[c] /= (double)k; m2[c] /= (double)k; }
+    double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int t = lane; t < k; t += WAVE) {
+        double q1[3] = {0, 0, 0}, q2[3] = {0, 0, 0};
+        for (int c = 0; c < dim; ++c) { q1[c] = pts1[(o + t) * dim + c] - m1[c]; q2[c] = pts2[(o + t) * dim + c] - m2[c]; }
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) H[r * 3 + c] += q1[r] * q2[c];
+    }
+    for (int e = 0; e < 9; ++e) for (int off = 32; off > 0; off >>= 1) H[e] += __shfl_xor(H[e], off);
+    if (lane == 0) { double T[16]; write_pose(T, dim, H, m1, m2); for (int t = 0; t < 16; ++t) T_out[(int64_t)b * 16 + t] = T[t]; status_out[b] = ROMAN_ST_OK; }
+}
+
+// elementwise math probe for tests
+__global__ void k_debug_math(int kind, const double* __restrict__ a, const double* __restrict__ b,
+                             int64_t n, double* __restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double x = a[i], y = b ? b[i] : 0.0;
+    double r;
+    switch (kind) {
+    case 0: r = sqrt(x); break;
+    case 1: r = exp(x); break;
+    case 2: r = cbrt(x); break;
+    case 3: r = x / y; break;
+    default: r = pow(x, y); break;
+    }
+    out[i] = r;
+}
+
+}  // namespace roman

@@ -1,0 +1,879 @@
+// roman_hip.hip — host side of libroman_hip.so: context, HBM workspace, launch sequence and the
+// C ABI declared in include/roman_hip.h.  gfx950 only; no CPU fallback.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "kernels.hip.h"
+
+using namespace roman;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+// grow-only device buffer
+struct DevBuf {
+    void* p = nullptr; size_t cap = 0;
+    hipError_t ensure(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
+        size_t want = bytes + bytes / 4 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) { (void)hipGetLastError(); want = bytes; e = hipMalloc(&p, want); }
+        if (e == hipSuccess) cap = want; else p = nullptr;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+}  // namespace
+
+struct roman_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int num_cu = 256;
+    size_t lds_max = 65536;
+    std::string err;
+
+    // workspace pools (see DESIGN.md "Data layout in HBM")
+    DevBuf probs, state, totals, queue;
+    DevBuf cosPool, normPool, tabPool, sTmp;
+    DevBuf lp, li, lj, ls, lza, lzb;
+    DevBuf rowCnt, rowStart, rowLen, vMu, vCu, vMun, vCun, gU, gUn, uOut, nodesOrig, nSel;
+    DevBuf cols, vals;
+    // staging for the host-pointer entry points
+    DevBuf hFeats, hAssoc, hU0, oAssoc, oN, oT, oStatus, oStats, hAux1, hAux2, hAux3;
+    BatchTotals* pinnedTotals = nullptr;
+
+    // per-stage hipEvent pairs on `stream`
+    bool profile = false;
+    hipEvent_t evA[ROMAN_STAGE_COUNT] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t evB[ROMAN_STAGE_COUNT] = {nullptr, nullptr, nullptr, nullptr};
+    bool pending[ROMAN_STAGE_COUNT] = {false, false, false, false};
+    double prof_ms[ROMAN_STAGE_COUNT] = {0, 0, 0, 0};
+    int64_t prof_n[ROMAN_STAGE_COUNT] = {0, 0, 0, 0};
+
+    // state of the last single-problem call (stepwise API for the clipperpy shim)
+    struct Last {
+        bool scored = false, solved = false, idx16 = true, dense = false;
+        DevParams D;
+        ProbDesc pd;
+        BatchTotals tot;
+        int32_t nA = 0, L = 0, nsel = 0;
+        std::vector<int32_t> assoc;        // (nA,2) host copy (explicit list) — empty for all-to-all
+        std::vector<int32_t> nodes;        // selected nodes (original association indices)
+        std::vector<double> u;             // length nA
+        roman_stats_t stats;
+        int32_t status = 0;
+    } last;
+};
+
+namespace {
+
+int fail(roman_ctx* c, int code, const char* fmt, ...)
+{
+    char buf[640];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap);
+    if (c) c->err = buf; else g_last_error = buf;
+    return code;
+}
+
+#define HIPCHK(c, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { (void)hipGetLastError(); \
+    return fail((c), (e_ == hipErrorOutOfMemory) ? ROMAN_E_NOMEM : ROMAN_E_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); } } while (0)
+
+// smallest x with sqrt(x) >= t  (so  sqrt(x) < t  <=>  x < result ; sqrt is monotone and correctly
+// rounded on host and device)
+double sqrt_threshold(double t)
+{
+    if (!(t > 0.0)) return 0.0;
+    double x = t * t;
+    while (std::sqrt(x) >= t) x = std::nextafter(x, 0.0);
+    while (std::sqrt(x) < t) x = std::nextafter(x, INFINITY);
+    return x;
+}
+
+int make_dev_params(roman_ctx* c, const roman_params_t* p, int32_t F, DevParams* D)
+{
+    if (!p) return fail(c, ROMAN_E_INVALID, "params is NULL");
+    if (p->point_dim != 2 && p->point_dim != 3) return fail(c, ROMAN_E_INVALID, "point_dim must be 2 or 3 (got %d)", p->point_dim);
+    if (p->invariant != ROMAN_INV_EUCLIDEAN && p->invariant != ROMAN_INV_ROMAN) return fail(c, ROMAN_E_INVALID, "unknown invariant %d", p->invariant);
+    if (p->ratio_feature_dim < 0 || p->ratio_feature_dim > ROMAN_MAX_RATIO_FEATURES) return fail(c, ROMAN_E_INVALID, "ratio_feature_dim out of range");
+    if (p->cos_feature_dim < 0) return fail(c, ROMAN_E_INVALID, "cos_feature_dim < 0");
+    if (p->drift_aware) return fail(c, ROMAN_E_UNSUPPORTED, "drift_aware is not defined by the reference call sites (always False)");
+    if (p->invariant == ROMAN_INV_ROMAN && p->gravity_guided && p->point_dim != 3) return fail(c, ROMAN_E_UNSUPPORTED, "gravity_guided requires point_dim == 3");
+    if (p->fusion_method < 0 || p->fusion_method > 2) return fail(c, ROMAN_E_INVALID, "unknown fusion_method");
+    if (!(p->sigma > 0.0)) return fail(c, ROMAN_E_INVALID, "sigma must be > 0");
+    const int need = (p->invariant == ROMAN_INV_ROMAN) ? p->point_dim + p->ratio_feature_dim + p->cos_feature_dim : p->point_dim;
+    if (F < need) return fail(c, ROMAN_E_INVALID, "F=%d smaller than the %d features the invariant reads", F, need);
+    memset(D, 0, sizeof(*D));
+    D->p = *p;
+    if (p->invariant == ROMAN_INV_EUCLIDEAN) { D->p.ratio_feature_dim = 0; D->p.cos_feature_dim = 0; D->p.gravity_guided = 0; }
+    D->sig2 = p->sigma * p->sigma;
+    D->sin_unc = std::sin(p->gravity_unc_ang_rad);
+    D->x_eps = sqrt_threshold(p->epsilon);
+    D->x_mindist = sqrt_threshold(p->mindist);
+    D->single = (p->invariant == ROMAN_INV_ROMAN) && (p->ratio_feature_dim > 0 || p->cos_feature_dim > 0);
+    D->gravity = (p->invariant == ROMAN_INV_ROMAN) && p->gravity_guided;
+    D->F = F;
+    return ROMAN_OK;
+}
+
+void prof_flush(roman_ctx* c, int s)
+{
+    if (!c->pending[s]) return;
+    float ms = 0.f;
+    if (hipEventSynchronize(c->evB[s]) == hipSuccess && hipEventElapsedTime(&ms, c->evA[s], c->evB[s]) == hipSuccess) {
+        c->prof_ms[s] += (double)ms; c->prof_n[s] += 1;
+    }
+    c->pending[s] = false;
+}
+struct StageTimer {
+    roman_ctx* c; int s;
+    StageTimer(roman_ctx* c_, int s_) : c(c_), s(s_) { if (c->profile) { prof_flush(c, s); (void)hipEventRecord(c->evA[s], c->stream); } }
+    void stop() { if (c->profile) { (void)hipEventRecord(c->evB[s], c->stream); c->pending[s] = true; } }
+};
+
+struct BatchIn {
+    int32_t B; const double* feats; const int64_t* off1; const int32_t* n1; const int64_t* off2; const int32_t* n2;
+    int32_t F; const int32_t* assoc; const int64_t* assoc_off;
+};
+
+// Stage A: scoring — norms, cosine, tables, live list, sparse affinity build.  Leaves the CSR and
+// the live pools in the context; returns the host copy of the problem descriptors and totals.
+int stage_score(roman_ctx* c, const DevParams& D, const BatchIn& in, std::vector<ProbDesc>& hd,
+                BatchTotals* totOut, bool* idx16)
+{
+    const int B = in.B;
+    hd.assign(B, ProbDesc{});
+    int64_t sumA = 0, sumCos = 0, sumTab = 0, sumN = 0;
+    int maxN12 = 0, maxTiles = 0, maxN = 0; int64_t maxTab = 0;
+    for (int b = 0; b < B; ++b) {
+        ProbDesc& d = hd[b];
+        d.off1 = in.off1[b]; d.off2 = in.off2[b]; d.n1 = in.n1[b]; d.n2 = in.n2[b];
+        if (d.n1 < 0 || d.n2 < 0) return fail(c, ROMAN_E_INVALID, "negative map size in problem %d", b);
+        if (in.assoc) {
+            d.assocOff = in.assoc_off[b];
+            const int64_t na = in.assoc_off[b + 1] - in.assoc_off[b];
+            if (na < 0 || na > 2147483647LL) return fail(c, ROMAN_E_INVALID, "bad assoc_off at problem %d", b);
+            d.nA = (int32_t)na;
+        } else {
+            d.assocOff = -1;
+            const int64_t na = (int64_t)d.n1 * d.n2;
+            if (na > 2147483647LL) return fail(c, ROMAN_E_TOO_LARGE, "n1*n2 overflows int32 in problem %d", b);
+            d.nA = (int32_t)na;
+        }
+        d.liveOff = sumA; d.cosOff = sumCos; d.tabOff = sumTab; d.normOff = sumN;
+        sumA += d.nA; sumCos += (int64_t)d.n1 * d.n2; sumTab += (int64_t)d.n1 * d.n1 + (int64_t)d.n2 * d.n2; sumN += d.n1 + d.n2;
+        maxN12 = std::max(maxN12, d.n1 + d.n2); maxN = std::max(maxN, std::max(d.n1, d.n2));
+        maxTiles = std::max(maxTiles, ((d.n1 + 15) / 16) * ((d.n2 + 15) / 16));
+        maxTab = std::max(maxTab, (int64_t)d.n1 * d.n1 + (int64_t)d.n2 * d.n2);
+    }
+    if (sumA > 2000000000LL) return fail(c, ROMAN_E_TOO_LARGE, "batch has %lld associations; split it (limit 2e9 per call)", (long long)sumA);
+    const size_t nA1 = (size_t)std::max<int64_t>(sumA, 1);
+    const bool cosOn = D.p.cos_feature_dim > 0;
+
+    HIPCHK(c, c->probs.ensure(sizeof(ProbDesc) * (size_t)B));
+    HIPCHK(c, c->state.ensure(sizeof(ProbState) * (size_t)B));
+    HIPCHK(c, c->totals.ensure(sizeof(BatchTotals)));
+    HIPCHK(c, c->queue.ensure(sizeof(int) * 4));
+    HIPCHK(c, c->cosPool.ensure(sizeof(double) * (size_t)(cosOn ? std::max<int64_t>(sumCos, 1) : 1)));
+    HIPCHK(c, c->normPool.ensure(sizeof(double) * (size_t)(cosOn ? std::max<int64_t>(sumN, 1) : 1)));
+    HIPCHK(c, c->tabPool.ensure(sizeof(double) * (size_t)std::max<int64_t>(sumTab, 1)));
+    HIPCHK(c, c->sTmp.ensure(sizeof(double) * nA1));
+    HIPCHK(c, c->lp.ensure(sizeof(int32_t) * nA1)); HIPCHK(c, c->li.ensure(sizeof(int32_t) * nA1)); HIPCHK(c, c->lj.ensure(sizeof(int32_t) * nA1));
+    HIPCHK(c, c->ls.ensure(sizeof(double) * nA1)); HIPCHK(c, c->lza.ensure(sizeof(double) * nA1)); HIPCHK(c, c->lzb.ensure(sizeof(double) * nA1));
+    HIPCHK(c, c->rowCnt.ensure(sizeof(uint32_t) * nA1)); HIPCHK(c, c->rowStart.ensure(sizeof(uint32_t) * nA1)); HIPCHK(c, c->rowLen.ensure(sizeof(uint32_t) * nA1));
+
+    HIPCHK(c, hipMemcpyAsync(c->probs.p, hd.data(), sizeof(ProbDesc) * (size_t)B, hipMemcpyHostToDevice, c->stream));
+    const ProbDesc* dP = c->probs.as<ProbDesc>();
+    ProbState* dS = c->state.as<ProbState>();
+    BatchTotals* dT = c->totals.as<BatchTotals>();
+
+    StageTimer t0(c, ROMAN_STAGE_SINGLE);
+    if (cosOn && maxN12 > 0) {
+        hipLaunchKernelGGL(k_norms, dim3((maxN12 + 3) / 4, B), dim3(256), 0, c->stream, D, dP, in.feats, c->normPool.as<double>());
+        if (maxTiles > 0)
+            hipLaunchKernelGGL(k_cos, dim3((maxTiles + 3) / 4, B), dim3(256), 0, c->stream, D, dP, in.feats, c->normPool.as<double>(), c->cosPool.as<double>());
+    }
+    if (maxTab > 0)
+        hipLaunchKernelGGL(k_tables, dim3((unsigned)((maxTab + 255) / 256), B), dim3(256), 0, c->stream, D, dP, in.feats, c->tabPool.as<double>());
+    hipLaunchKernelGGL(k_live, dim3(B), dim3(1024), 0, c->stream, D, dP, dS, in.feats, in.assoc, c->cosPool.as<double>(), c->sTmp.as<double>(),
+                       c->lp.as<int32_t>(), c->li.as<int32_t>(), c->lj.as<int32_t>(), c->ls.as<double>(), c->lza.as<double>(), c->lzb.as<double>());
+    hipLaunchKernelGGL(k_rowbase, dim3(1), dim3(64), 0, c->stream, B, dS, dT);
+    t0.stop();
+
+    // per-wave LDS slice for the two table rows of the pair kernels
+    const int ldsPerWave = ((2 * std::max(maxN, 1) + 1) & ~1) + 2;
+    int wpb = 16;
+    while (wpb > 1 && (size_t)wpb * ldsPerWave * sizeof(double) > c->lds_max) wpb >>= 1;
+    if ((size_t)wpb * ldsPerWave * sizeof(double) > c->lds_max)
+        return fail(c, ROMAN_E_TOO_LARGE, "maps of %d objects exceed the LDS table staging of this build", maxN);
+    const size_t pairLds = (size_t)wpb * ldsPerWave * sizeof(double);
+    const int blocksPerCU = std::max(1, std::min(2048 / (wpb * 64), (int)(c->lds_max / pairLds)));
+    const int pairGrid = c->num_cu * blocksPerCU;
+    *idx16 = true;
+    for (int b = 0; b < B; ++b) if (hd[b].nA > 32767) { *idx16 = false; break; }
+
+    StageTimer t1(c, ROMAN_STAGE_COUNT_PASS);
+    {
+        auto kc = D.gravity ? k_pairs<false, true, uint32_t> : k_pairs<false, false, uint32_t>;
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kc), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pairLds));
+        hipLaunchKernelGGL(kc, dim3(pairGrid), dim3(wpb * 64), pairLds, c->stream, D, B, dP, dS, dT, c->tabPool.as<double>(),
+                           c->li.as<int32_t>(), c->lj.as<int32_t>(), c->ls.as<double>(), c->lza.as<double>(), c->lzb.as<double>(),
+                           c->rowCnt.as<uint32_t>(), c->rowStart.as<uint32_t>(), c->rowLen.as<uint32_t>(), (uint32_t*)nullptr, (double*)nullptr, ldsPerWave);
+    }
+    hipLaunchKernelGGL(k_rowscan, dim3(B), dim3(1024), 0, c->stream, dP, dS, c->rowCnt.as<uint32_t>(), c->rowStart.as<uint32_t>());
+    hipLaunchKernelGGL(k_probscan, dim3(1), dim3(64), 0, c->stream, B, dS, dT);
+    // the one read-back of the pipeline: how many candidate entries to allocate
+    HIPCHK(c, hipMemcpyAsync(c->pinnedTotals, dT, sizeof(BatchTotals), hipMemcpyDeviceToHost, c->stream));
+    t1.stop();
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const BatchTotals tot = *c->pinnedTotals;
+    *totOut = tot;
+    const size_t nnz1 = (size_t)std::max<int64_t>(tot.nnzTotal, 1);
+    HIPCHK(c, c->vals.ensure(sizeof(double) * nnz1));
+    HIPCHK(c, c->cols.ensure((*idx16 ? sizeof(uint16_t) : sizeof(uint32_t)) * nnz1));
+
+    StageTimer t2(c, ROMAN_STAGE_FILL);
+    if (tot.R > 0) {
+        if (*idx16) {
+            auto kf = D.gravity ? k_pairs<true, true, uint16_t> : k_pairs<true, false, uint16_t>;
+            HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pairLds));
+            hipLaunchKernelGGL(kf, dim3(pairGrid), dim3(wpb * 64), pairLds, c->stream, D, B, dP, dS, dT, c->tabPool.as<double>(),
+                               c->li.as<int32_t>(), c->lj.as<int32_t>(), c->ls.as<double>(), c->lza.as<double>(), c->lzb.as<double>(),
+                               c->rowCnt.as<uint32_t>(), c->rowStart.as<uint32_t>(), c->rowLen.as<uint32_t>(), c->cols.as<uint16_t>(), c->vals.as<double>(), ldsPerWave);
+        } else {
+            auto kf = D.gravity ? k_pairs<true, true, uint32_t> : k_pairs<true, false, uint32_t>;
+            HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pairLds));
+            hipLaunchKernelGGL(kf, dim3(pairGrid), dim3(wpb * 64), pairLds, c->stream, D, B, dP, dS, dT, c->tabPool.as<double>(),
+                               c->li.as<int32_t>(), c->lj.as<int32_t>(), c->ls.as<double>(), c->lza.as<double>(), c->lzb.as<double>(),
+                               c->rowCnt.as<uint32_t>(), c->rowStart.as<uint32_t>(), c->rowLen.as<uint32_t>(), c->cols.as<uint32_t>(), c->vals.as<double>(), ldsPerWave);
+        }
+    }
+    t2.stop();
+    HIPCHK(c, hipGetLastError());
+    return ROMAN_OK;
+}
+
+// Stage B: solver + rounding + pose on the CSR held by the context.  `feats` may be NULL (dense
+// matrix problems have no points: the pose is skipped).
+int stage_solve(roman_ctx* c, const DevParams& D, int B, const double* feats, const int32_t* assoc,
+                const double* u0, const BatchTotals& tot, bool idx16, int32_t kmax,
+                int32_t* assoc_out, int32_t* n_assoc_out, double* T_out, int32_t* status_out,
+                roman_stats_t* stats_out)
+{
+    const size_t R1 = (size_t)std::max(tot.R, 1);
+    HIPCHK(c, c->vMu.ensure(sizeof(double) * R1)); HIPCHK(c, c->vCu.ensure(sizeof(double) * R1));
+    HIPCHK(c, c->vMun.ensure(sizeof(double) * R1)); HIPCHK(c, c->vCun.ensure(sizeof(double) * R1));
+    HIPCHK(c, c->uOut.ensure(sizeof(double) * R1)); HIPCHK(c, c->nodesOrig.ensure(sizeof(int32_t) * R1));
+    HIPCHK(c, c->nSel.ensure(sizeof(int32_t) * (size_t)B));
+
+    // LDS: u and u_new (Lcap doubles each) + 48 doubles + 4 ints
+    const size_t fixed = 48 * sizeof(double) + 4 * sizeof(int);
+    int Lcap = (std::max(tot.maxL, 64) + 1) & ~1;
+    const size_t maxLcap = (c->lds_max - fixed) / (2 * sizeof(double));
+    bool spill = false;
+    if ((size_t)Lcap > maxLcap) { Lcap = (int)(maxLcap & ~(size_t)1); spill = true; }
+    HIPCHK(c, c->gU.ensure(sizeof(double) * (spill ? R1 : 1))); HIPCHK(c, c->gUn.ensure(sizeof(double) * (spill ? R1 : 1)));
+    const size_t lds = 2 * sizeof(double) * (size_t)Lcap + fixed;
+    const int perCU = (c->lds_max / lds >= 2) ? 2 : 1;
+    const int nt = (perCU >= 2) ? 512 : 1024;
+    const int grid = std::max(1, std::min(B, c->num_cu * perCU));
+    const double avgRow = tot.R > 0 ? (double)tot.nnzTotal / (double)tot.R : 1.0;
+    int T = 4; while (T < 64 && (double)T * 2.0 < avgRow) T <<= 1;
+
+    HIPCHK(c, hipMemsetAsync(c->queue.p, 0, sizeof(int) * 4, c->stream));
+    SolveOut O;
+    O.assoc_out = assoc_out; O.n_assoc_out = n_assoc_out; O.T_out = T_out; O.status_out = status_out; O.stats_out = stats_out; O.kmax = kmax;
+    O.nodesOrig = c->nodesOrig.as<int32_t>(); O.nSel = c->nSel.as<int32_t>(); O.uOut = c->uOut.as<double>();
+
+    StageTimer t3(c, ROMAN_STAGE_SOLVE);
+    if (idx16) {
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve<uint16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_solve<uint16_t>, dim3(grid), dim3(nt), lds, c->stream, D, B, c->probs.as<ProbDesc>(), c->state.as<ProbState>(), feats, assoc,
+                           c->lp.as<int32_t>(), c->ls.as<double>(), c->rowStart.as<uint32_t>(), c->rowLen.as<uint32_t>(), c->cols.as<uint16_t>(), c->vals.as<double>(),
+                           c->vMu.as<double>(), c->vCu.as<double>(), c->vMun.as<double>(), c->vCun.as<double>(), c->gU.as<double>(), c->gUn.as<double>(),
+                           u0, O, c->queue.as<int>(), Lcap, T);
+    } else {
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve<uint32_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_solve<uint32_t>, dim3(grid), dim3(nt), lds, c->stream, D, B, c->probs.as<ProbDesc>(), c->state.as<ProbState>(), feats, assoc,
+                           c->lp.as<int32_t>(), c->ls.as<double>(), c->rowStart.as<uint32_t>(), c->rowLen.as<uint32_t>(), c->cols.as<uint32_t>(), c->vals.as<double>(),
+                           c->vMu.as<double>(), c->vCu.as<double>(), c->vMun.as<double>(), c->vCun.as<double>(), c->gU.as<double>(), c->gUn.as<double>(),
+                           u0, O, c->queue.as<int>(), Lcap, T);
+    }
+    t3.stop();
+    HIPCHK(c, hipGetLastError());
+    return ROMAN_OK;
+}
+
+int ensure_events(roman_ctx* c)
+{
+    for (int s = 0; s < ROMAN_STAGE_COUNT; ++s) {
+        if (!c->evA[s]) HIPCHK(c, hipEventCreate(&c->evA[s]));
+        if (!c->evB[s]) HIPCHK(c, hipEventCreate(&c->evB[s]));
+    }
+    return ROMAN_OK;
+}
+
+// run a B=1 solve on the matrices held by the context and pull the solution to the host
+int solve_last(roman_ctx* c, const double* u0_host)
+{
+    roman_ctx::Last& Lst = c->last;
+    const int32_t nA = Lst.nA;
+    const size_t nA1 = (size_t)std::max(nA, 1);
+    const double* dU0 = nullptr;
+    if (u0_host) {
+        HIPCHK(c, c->hU0.ensure(sizeof(double) * nA1));
+        HIPCHK(c, hipMemcpyAsync(c->hU0.p, u0_host, sizeof(double) * (size_t)nA, hipMemcpyHostToDevice, c->stream));
+        dU0 = c->hU0.as<double>();
+    }
+    const int32_t kmax = std::max(nA, 1);
+    HIPCHK(c, c->oAssoc.ensure(sizeof(int32_t) * 2 * (size_t)kmax)); HIPCHK(c, c->oN.ensure(sizeof(int32_t)));
+    HIPCHK(c, c->oT.ensure(sizeof(double) * 16)); HIPCHK(c, c->oStatus.ensure(sizeof(int32_t))); HIPCHK(c, c->oStats.ensure(sizeof(roman_stats_t)));
+    const double* feats = Lst.dense ? nullptr : c->hFeats.as<double>();
+    const int32_t* assoc = (Lst.pd.assocOff >= 0) ? c->hAssoc.as<int32_t>() : nullptr;
+    int rc = stage_solve(c, Lst.D, 1, feats, assoc, dU0, Lst.tot, Lst.idx16, kmax, c->oAssoc.as<int32_t>(), c->oN.as<int32_t>(),
+                         c->oT.as<double>(), c->oStatus.as<int32_t>(), c->oStats.as<roman_stats_t>());
+    if (rc) return rc;
+    int32_t nsel = 0;
+    HIPCHK(c, hipMemcpyAsync(&nsel, c->nSel.p, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&Lst.stats, c->oStats.p, sizeof(roman_stats_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&Lst.status, c->oStatus.p, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    Lst.nsel = nsel;
+    Lst.nodes.assign((size_t)std::max(nsel, 0), 0);
+    const int L = Lst.tot.R;
+    std::vector<double> ul((size_t)std::max(L, 1)); std::vector<int32_t> lpv((size_t)std::max(L, 1));
+    if (nsel > 0) HIPCHK(c, hipMemcpyAsync(Lst.nodes.data(), c->nodesOrig.p, sizeof(int32_t) * (size_t)nsel, hipMemcpyDeviceToHost, c->stream));
+    if (L > 0) {
+        HIPCHK(c, hipMemcpyAsync(ul.data(), c->uOut.p, sizeof(double) * (size_t)L, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(lpv.data(), c->lp.p, sizeof(int32_t) * (size_t)L, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    Lst.u.assign((size_t)nA, 0.0);
+    for (int k = 0; k < L; ++k) Lst.u[(size_t)lpv[k]] = ul[k];
+    Lst.L = L;
+    Lst.solved = true;
+    return ROMAN_OK;
+}
+
+// download the CSR of the last single problem as full-symmetric host arrays over live indices
+int fetch_last_csr(const roman_ctx* cc, std::vector<uint32_t>& rs, std::vector<uint32_t>& rl, std::vector<uint32_t>& cols,
+                   std::vector<double>& vals, std::vector<int32_t>& lp, std::vector<double>& ls)
+{
+    roman_ctx* c = const_cast<roman_ctx*>(cc);
+    const roman_ctx::Last& Lst = c->last;
+    const int L = Lst.tot.R; const int64_t cap = Lst.tot.nnzTotal;
+    rs.assign((size_t)std::max(L, 1), 0); rl.assign((size_t)std::max(L, 1), 0); lp.assign((size_t)std::max(L, 1), 0); ls.assign((size_t)std::max(L, 1), 0.0);
+    cols.assign((size_t)std::max<int64_t>(cap, 1), 0); vals.assign((size_t)std::max<int64_t>(cap, 1), 0.0);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (L > 0) {
+        HIPCHK(c, hipMemcpy(rs.data(), c->rowStart.p, sizeof(uint32_t) * (size_t)L, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(rl.data(), c->rowLen.p, sizeof(uint32_t) * (size_t)L, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(lp.data(), c->lp.p, sizeof(int32_t) * (size_t)L, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(ls.data(), c->ls.p, sizeof(double) * (size_t)L, hipMemcpyDeviceToHost));
+    }
+    if (cap > 0) {
+        HIPCHK(c, hipMemcpy(vals.data(), c->vals.p, sizeof(double) * (size_t)cap, hipMemcpyDeviceToHost));
+        if (Lst.idx16) {
+            std::vector<uint16_t> c16((size_t)cap);
+            HIPCHK(c, hipMemcpy(c16.data(), c->cols.p, sizeof(uint16_t) * (size_t)cap, hipMemcpyDeviceToHost));
+            for (int64_t k = 0; k < cap; ++k) cols[(size_t)k] = (c16[(size_t)k] & 0x8000u) ? (0x80000000u | (c16[(size_t)k] & 0x7fffu)) : c16[(size_t)k];
+        } else {
+            HIPCHK(c, hipMemcpy(cols.data(), c->cols.p, sizeof(uint32_t) * (size_t)cap, hipMemcpyDeviceToHost));
+        }
+    }
+    return ROMAN_OK;
+}
+
+}  // namespace
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+extern "C" {
+
+const char* roman_version(void) { return "roman_hip 0.1.0 gfx950 (HIP, wave64, f64)"; }
+
+int roman_params_default(roman_params_t* p)
+{
+    if (!p) return fail(nullptr, ROMAN_E_INVALID, "params is NULL");
+    memset(p, 0, sizeof(*p));
+    p->invariant = ROMAN_INV_ROMAN; p->point_dim = 3; p->fusion_method = ROMAN_FUSE_GEOMETRIC_MEAN; p->rescale_u0 = 1;
+    p->sigma = 0.4; p->epsilon = 0.6; p->mindist = 0.2;
+    p->distance_weight = p->ratio_weight = p->cosine_weight = 1.0;
+    p->cosine_min = 0.5; p->cosine_max = 0.7; p->gravity_unc_ang_rad = 0.0872665;
+    p->tol_u = 1e-8; p->tol_F = 1e-9; p->beta = 0.25; p->eps = 1e-9; p->affinityeps = 1e-4;
+    p->maxiniters = 200; p->maxoliters = 1000; p->maxlsiters = 99;
+    return ROMAN_OK;
+}
+
+const char* roman_last_error(const roman_ctx_t* ctx) { return ctx ? ctx->err.c_str() : g_last_error.c_str(); }
+
+int roman_ctx_create(roman_ctx_t** out, int device, void* stream)
+{
+    if (!out) return fail(nullptr, ROMAN_E_INVALID, "ctx out pointer is NULL");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { (void)hipGetLastError(); return fail(nullptr, ROMAN_E_NO_DEVICE, "no HIP device visible (libroman_hip has no CPU fallback)"); }
+    if (device < 0 || device >= ndev) return fail(nullptr, ROMAN_E_NO_DEVICE, "device %d out of range (0..%d)", device, ndev - 1);
+    if (hipSetDevice(device) != hipSuccess) return fail(nullptr, ROMAN_E_HIP, "hipSetDevice(%d) failed", device);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return fail(nullptr, ROMAN_E_HIP, "hipGetDeviceProperties failed");
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return fail(nullptr, ROMAN_E_NO_DEVICE, "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
+    roman_ctx* c = new (std::nothrow) roman_ctx();
+    if (!c) return fail(nullptr, ROMAN_E_NOMEM, "out of host memory");
+    c->device = device;
+    c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    c->lds_max = prop.sharedMemPerBlock >= 163840 ? (size_t)(160 * 1024 - 4096) : (size_t)prop.sharedMemPerBlock;
+    if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
+    else {
+        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return fail(nullptr, ROMAN_E_HIP, "hipStreamCreate failed"); }
+        c->own_stream = true;
+    }
+    if (hipHostMalloc((void**)&c->pinnedTotals, sizeof(BatchTotals), hipHostMallocDefault) != hipSuccess) {
+        if (c->own_stream) (void)hipStreamDestroy(c->stream);
+        delete c; return fail(nullptr, ROMAN_E_NOMEM, "hipHostMalloc failed");
+    }
+    *out = c;
+    return ROMAN_OK;
+}
+
+int roman_ctx_destroy(roman_ctx_t* c)
+{
+    if (!c) return ROMAN_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    DevBuf* all[] = {&c->probs, &c->state, &c->totals, &c->queue, &c->cosPool, &c->normPool, &c->tabPool, &c->sTmp, &c->lp, &c->li, &c->lj, &c->ls, &c->lza, &c->lzb,
+                     &c->rowCnt, &c->rowStart, &c->rowLen, &c->vMu, &c->vCu, &c->vMun, &c->vCun, &c->gU, &c->gUn, &c->uOut, &c->nodesOrig, &c->nSel, &c->cols, &c->vals,
+                     &c->hFeats, &c->hAssoc, &c->hU0, &c->oAssoc, &c->oN, &c->oT, &c->oStatus, &c->oStats, &c->hAux1, &c->hAux2, &c->hAux3};
+    for (DevBuf* b : all) b->release();
+    if (c->pinnedTotals) (void)hipHostFree(c->pinnedTotals);
+    for (int s = 0; s < ROMAN_STAGE_COUNT; ++s) { if (c->evA[s]) (void)hipEventDestroy(c->evA[s]); if (c->evB[s]) (void)hipEventDestroy(c->evB[s]); }
+    if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return ROMAN_OK;
+}
+
+// --- instrumentation -----------------------------------------------------------------------------
+int roman_profile_enable(roman_ctx_t* c, int on)
+{
+    if (!c) return fail(nullptr, ROMAN_E_INVALID, "ctx is NULL");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (on) { int rc = ensure_events(c); if (rc) return rc; }
+    else for (int s = 0; s < ROMAN_STAGE_COUNT; ++s) prof_flush(c, s);
+    c->profile = on != 0;
+    return ROMAN_OK;
+}
+int roman_profile_reset(roman_ctx_t* c)
+{
+    if (!c) return fail(nullptr, ROMAN_E_INVALID, "ctx is NULL");
+    for (int s = 0; s < ROMAN_STAGE_COUNT; ++s) { prof_flush(c, s); c->prof_ms[s] = 0.0; c->prof_n[s] = 0; }
+    return ROMAN_OK;
+}
+int roman_profile_get(roman_ctx_t* c, double ms[ROMAN_STAGE_COUNT], int64_t launches[ROMAN_STAGE_COUNT])
+{
+    if (!c) return fail(nullptr, ROMAN_E_INVALID, "ctx is NULL");
+    for (int s = 0; s < ROMAN_STAGE_COUNT; ++s) { prof_flush(c, s); if (ms) ms[s] = c->prof_ms[s]; if (launches) launches[s] = c->prof_n[s]; }
+    return ROMAN_OK;
+}
+
+// --- the batched hot path --------------------------------------------------------------------------
+int roman_align_batch_dev(roman_ctx_t* c, const roman_params_t* params, int32_t B,
+                          const double* feats, const int64_t* off1, const int32_t* n1,
+                          const int64_t* off2, const int32_t* n2, int32_t F,
+                          const int32_t* assoc, const int64_t* assoc_off, const double* u0,
+                          int32_t kmax, int32_t* assoc_out, int32_t* n_assoc_out,
+                          double* T_out, int32_t* status_out, roman_stats_t* stats_out)
+{
+    if (!c) return fail(nullptr, ROMAN_E_INVALID, "ctx is NULL");
+    if (B < 0) return fail(c, ROMAN_E_INVALID, "B < 0");
+    if (B == 0) return ROMAN_OK;
+    if (!off1 || !n1 || !off2 || !n2 || !assoc_out || !n_assoc_out || !T_out || !status_out || kmax < 0)
+        return fail(c, ROMAN_E_INVALID, "NULL metadata/output pointer or kmax < 0");
+    if (assoc && !assoc_off) return fail(c, ROMAN_E_INVALID, "assoc given without assoc_off");
+    HIPCHK(c, hipSetDevice(c->device));
+    DevParams D;
+    int rc = make_dev_params(c, params, F, &D);
+    if (rc) return rc;
+    if (!feats) {
+        bool any = false;
+        for (int b = 0; b < B; ++b) any = any || (n1[b] > 0 || n2[b] > 0);
+        if (any) return fail(c, ROMAN_E_INVALID, "feats is NULL");
+    }
+    BatchIn in{B, feats, off1, n1, off2, n2, F, assoc, assoc_off};
+    std::vector<ProbDesc> hd;
+    BatchTotals tot{}; bool idx16 = true;
+    rc = stage_score(c, D, in, hd, &tot, &idx16);
+    if (rc) return rc;
+    rc = stage_solve(c, D, B, feats, assoc, u0, tot, idx16, kmax, assoc_out, n_assoc_out, T_out, status_out, stats_out);
+    if (rc) return rc;
+    c->last.scored = false; c->last.solved = false;
+    return ROMAN_OK;
+}
+
+int roman_align_batch(roman_ctx_t* c, const roman_params_t* params, int32_t B,
+                      const double* feats, int64_t n_objects,
+                      const int64_t* off1, const int32_t* n1, const int64_t* off2, const int32_t* n2, int32_t F,
+                      const int32_t* assoc, const int64_t* assoc_off, const double* u0,
+                      int32_t kmax, int32_t* assoc_out, int32_t* n_assoc_out,
+                      double* T_out, int32_t* status_out, roman_stats_t* stats_out)
+{
+    if (!c) return fail(nullptr, ROMAN_E_INVALID, "ctx is NULL");
+    if (B < 0 || n_objects < 0 || F < 0) return fail(c, ROMAN_E_INVALID, "negative size");
+    if (B == 0) return ROMAN_OK;
+    if (!off1 || !n1 || !off2 || !n2 || !assoc_out || !n_assoc_out || !T_out || !status_out || kmax < 0)
+        return fail(c, ROMAN_E_INVALID, "NULL metadata/output pointer or kmax < 0");
+    if (assoc && !assoc_off) return fail(c, ROMAN_E_INVALID, "assoc given without assoc_off");
+    HIPCHK(c, hipSetDevice(c->device));
+    int64_t sumA = 0;
+    for (int b = 0; b < B; ++b) {
+        if (off1[b] < 0 || off2[b] < 0 || off1[b] + n1[b] > n_objects || off2[b] + n2[b] > n_objects)
+            return fail(c, ROMAN_E_INVALID, "problem %d reads objects outside feats[0..%lld)", b, (long long)n_objects);
+        sumA += assoc ? (assoc_off[b + 1] - assoc_off[b]) : (int64_t)n1[b] * n2[b];
+    }
+    const size_t fbytes = sizeof(double) * (size_t)std::max<int64_t>(n_objects * F, 1);
+    HIPCHK(c, c->hFeats.ensure(fbytes));
+    if (n_objects * F > 0) HIPCHK(c, hipMemcpyAsync(c->hFeats.p, feats, sizeof(double) * (size_t)(n_objects * F), hipMemcpyHostToDevice, c->stream));
+    const int32_t* dA = nullptr;
+    if (assoc) {
+        const int64_t rows = assoc_off[B];
+        HIPCHK(c, c->hAssoc.ensure(sizeof(int32_t) * 2 * (size_t)std::max<int64_t>(rows, 1)));
+        if (rows > 0) HIPCHK(c, hipMemcpyAsync(c->hAssoc.p, assoc, sizeof(int32_t) * 2 * (size_t)rows, hipMemcpyHostToDevice, c->stream));
+        dA = c->hAssoc.as<int32_t>();
+    }
+    const double* dU0 = nullptr;
+    if (u0) {
+        HIPCHK(c, c->hU0.ensure(sizeof(double) * (size_t)std::max<int64_t>(sumA, 1)));
+        if (sumA > 0) HIPCHK(c, hipMemcpyAsync(c->hU0.p, u0, sizeof(double) * (size_t)sumA, hipMemcpyHostToDevice, c->stream));
+        dU0 = c->hU0.as<double>();
+    }
+    const size_t kb = (size_t)B * (size_t)std::max(kmax, 1);
+    HIPCHK(c, c->oAssoc.ensure(sizeof(int32_t) * 2 * kb)); HIPCHK(c, c->oN.ensure(sizeof(int32_t) * (size_t)B));
+    HIPCHK(c, c->oT.ensure(sizeof(double) * 16 * (size_t)B)); HIPCHK(c, c->oStatus.ensure(sizeof(int32_t) * (size_t)B));
+    HIPCHK(c, c->oStats.ensure(sizeof(roman_stats_t) * (size_t)B));
+    int rc = roman_align_batch_dev(c, params, B, c->hFeats.as<double>(), off1, n1, off2, n2, F, dA, assoc_off, dU0, kmax,
+                                   c->oAssoc.as<int32_t>(), c->oN.as<int32_t>(), c->oT.as<double>(), c->oStatus.as<int32_t>(), c->oStats.as<roman_stats_t>());
+    if (rc) return rc;
+    if (kmax > 0) HIPCHK(c, hipMemcpyAsync(assoc_out, c->oAssoc.p, sizeof(int32_t) * 2 * (size_t)B * (size_t)kmax, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(n_assoc_out, c->oN.p, sizeof(int32_t) * (size_t)B, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(T_out, c->oT.p, sizeof(double) * 16 * (size_t)B, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(status_out, c->oStatus.p, sizeof(int32_t) * (size_t)B, hipMemcpyDeviceToHost, c->stream));
+    if (stats_out) HIPCHK(c, hipMemcpyAsync(stats_out, c->oStats.p, sizeof(roman_stats_t) * (size_t)B, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return ROMAN_OK;
+}
+
+// --- stepwise surface for the clipperpy-compatible shim -----------------------------------------------
+int roman_create_all_to_all(int32_t n1, int32_t n2, int32_t* out)
+{
+    if (n1 < 0 || n2 < 0 || (!out && (int64_t)n1 * n2 > 0)) return fail(nullptr, ROMAN_E_INVALID, "bad arguments");
+    for (int32_t i = 0; i < n1; ++i) for (int32_t j = 0; j < n2; ++j) { out[2 * ((int64_t)i * n2 + j)] = i; out[2 * ((int64_t)i * n2 + j) + 1] = j; }
+    return ROMAN_OK;
+}
+
+int roman_score(roman_ctx_t* c, const roman_params_t* params, const double* D1, int32_t n1,
+                const double* D2, int32_t n2, int32_t F, const int32_t* assoc, int32_t n_assoc)
+{
+    if (!c) return fail(nullptr, ROMAN_E_INVALID, "ctx is NULL");
+    if (n1 < 0 || n2 < 0 || F < 0 || (assoc && n_assoc < 0)) return fail(c, ROMAN_E_INVALID, "negative size");
+    if ((n1 > 0 && !D1) || (n2 > 0 && !D2)) return fail(c, ROMAN_E_INVALID, "NULL feature matrix");
+    HIPCHK(c, hipSetDevice(c->device));
+    roman_ctx::Last& Lst = c->last;
+    Lst.scored = false; Lst.solved = false; Lst.dense = false;
+    int rc = make_dev_params(c, params, F, &Lst.D);
+    if (rc) return rc;
+    const int64_t nobj = (int64_t)n1 + n2;
+    HIPCHK(c, c->hFeats.ensure(sizeof(double) * (size_t)std::max<int64_t>(nobj * F, 1)));
+    if ((int64_t)n1 * F > 0) HIPCHK(c, hipMemcpyAsync(c->hFeats.p, D1, sizeof(double) * (size_t)n1 * F, hipMemcpyHostToDevice, c->stream));
+    if ((int64_t)n2 * F > 0) HIPCHK(c, hipMemcpyAsync(c->hFeats.as<double>() + (size_t)n1 * F, D2, sizeof(double) * (size_t)n2 * F, hipMemcpyHostToDevice, c->stream));
+    const int32_t* dA = nullptr;
+    int64_t aoff[2] = {0, n_assoc};
+    Lst.assoc.clear();
+    if (assoc) {
+        for (int32_t k = 0; k < n_assoc; ++k)
+            if (assoc[2 * k] < 0 || assoc[2 * k] >= n1 || assoc[2 * k + 1] < 0 || assoc[2 * k + 1] >= n2)
+                return fail(c, ROMAN_E_INVALID, "association %d = (%d,%d) out of range", k, assoc[2 * k], assoc[2 * k + 1]);
+        Lst.assoc.assign(assoc, assoc + 2 * (size_t)n_assoc);
+        HIPCHK(c, c->hAssoc.ensure(sizeof(int32_t) * 2 * (size_t)std::max(n_assoc, 1)));
+        if (n_assoc > 0) HIPCHK(c, hipMemcpyAsync(c->hAssoc.p, assoc, sizeof(int32_t) * 2 * (size_t)n_assoc, hipMemcpyHostToDevice, c->stream));
+        dA = c->hAssoc.as<int32_t>();
+    }
+    const int64_t o1 = 0, o2 = n1;
+    BatchIn in{1, c->hFeats.as<double>(), &o1, &n1, &o2, &n2, F, dA, aoff};
+    std::vector<ProbDesc> hd;
+    rc = stage_score(c, Lst.D, in, hd, &Lst.tot, &Lst.idx16);
+    if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    Lst.pd = hd[0]; Lst.nA = hd[0].nA; Lst.L = Lst.tot.R; Lst.scored = true;
+    return ROMAN_OK;
+}
+
+int roman_set_matrix_data(roman_ctx_t* c, const roman_params_t* params, const double* M, const double* Cm, int32_t n)
+{
+    if (!c) return fail(nullptr, ROMAN_E_INVALID, "ctx is NULL");
+    if (n < 0 || (n > 0 && (!M || !Cm))) return fail(c, ROMAN_E_INVALID, "bad matrix arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    roman_ctx::Last& Lst = c->last;
+    Lst.scored = false; Lst.solved = false; Lst.dense = true; Lst.assoc.clear();
+    roman_params_t p = *params; p.invariant = ROMAN_INV_EUCLIDEAN;          // implicit identity diagonal
+    int rc = make_dev_params(c, &p, p.point_dim, &Lst.D);
+    if (rc) return rc;
+    Lst.idx16 = n <= 32767;
+    // full-symmetric CSR over the union pattern of the strict upper triangles of M and C
+    std::vector<uint32_t> rs((size_t)std::max(n, 1)), rl((size_t)std::max(n, 1), 0);
+    std::vector<uint32_t> cols; std::vector<double> vals;
+    int64_t upper = 0;
+    for (int p_ = 0; p_ < n; ++p_) {
+        rs[(size_t)p_] = (uint32_t)cols.size();
+        for (int q = 0; q < n; ++q) {
+            if (q == p_) continue;
+            const int a = std::min(p_, q), b = std::max(p_, q);
+            const double mv = M[(int64_t)a * n + b], cv = Cm[(int64_t)a * n + b];
+            if (mv != 0.0 || cv != 0.0) {
+                cols.push_back((uint32_t)q | ((cv == 0.0) ? (Lst.idx16 ? 0x8000u : 0x80000000u) : 0u));
+                vals.push_back(mv);
+                if (q > p_) ++upper;
+            }
+        }
+        rl[(size_t)p_] = (uint32_t)cols.size() - rs[(size_t)p_];
+        if (cols.size() > 4000000000ull) return fail(c, ROMAN_E_TOO_LARGE, "dense matrix has too many non-zeros");
+    }
+    const size_t n1_ = (size_t)std::max(n, 1), nnz1 = std::max<size_t>(cols.size(), 1);
+    HIPCHK(c, c->probs.ensure(sizeof(ProbDesc))); HIPCHK(c, c->state.ensure(sizeof(ProbState))); HIPCHK(c, c->queue.ensure(sizeof(int) * 4));
+    HIPCHK(c, c->lp.ensure(sizeof(int32_t) * n1_)); HIPCHK(c, c->ls.ensure(sizeof(double) * n1_));
+    HIPCHK(c, c->rowStart.ensure(sizeof(uint32_t) * n1_)); HIPCHK(c, c->rowLen.ensure(sizeof(uint32_t) * n1_));
+    HIPCHK(c, c->vals.ensure(sizeof(double) * nnz1)); HIPCHK(c, c->cols.ensure((Lst.idx16 ? 2 : 4) * nnz1));
+    ProbDesc pd{}; pd.off1 = 0; pd.off2 = 0; pd.assocOff = -1; pd.liveOff = 0; pd.n1 = n; pd.n2 = 1; pd.nA = n;
+    ProbState ps{}; ps.L = n; ps.rowBase = 0; ps.nnzOff = 0; ps.nnzCap = (uint32_t)cols.size(); ps.nnzUpper = (unsigned long long)upper;
+    std::vector<int32_t> ident((size_t)std::max(n, 1)); std::vector<double> ones((size_t)std::max(n, 1), 1.0);
+    for (int k = 0; k < n; ++k) ident[(size_t)k] = k;
+    HIPCHK(c, hipMemcpy(c->probs.p, &pd, sizeof(pd), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->state.p, &ps, sizeof(ps), hipMemcpyHostToDevice));
+    if (n > 0) {
+        HIPCHK(c, hipMemcpy(c->lp.p, ident.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(c->ls.p, ones.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(c->rowStart.p, rs.data(), sizeof(uint32_t) * (size_t)n, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(c->rowLen.p, rl.data(), sizeof(uint32_t) * (size_t)n, hipMemcpyHostToDevice));
+    }
+    if (!cols.empty()) {
+        HIPCHK(c, hipMemcpy(c->vals.p, vals.data(), sizeof(double) * vals.size(), hipMemcpyHostToDevice));
+        if (Lst.idx16) {
+            std::vector<uint16_t> c16(cols.size());
+            for (size_t k = 0; k < cols.size(); ++k) c16[k] = (uint16_t)cols[k];
+            HIPCHK(c, hipMemcpy(c->cols.p, c16.data(), sizeof(uint16_t) * c16.size(), hipMemcpyHostToDevice));
+        } else {
+            HIPCHK(c, hipMemcpy(c->cols.p, cols.data(), sizeof(uint32_t) * cols.size(), hipMemcpyHostToDevice));
+        }
+    }
+    Lst.pd = pd; Lst.nA = n; Lst.L = n;
+    Lst.tot.nnzTotal = (int64_t)cols.size(); Lst.tot.R = n; Lst.tot.maxL = n;
+    Lst.scored = true;
+    return ROMAN_OK;
+}
+
+int roman_solve(roman_ctx_t* c, const double* u0)
+{
+    if (!c) return fail(nullptr, ROMAN_E_INVALID, "ctx is NULL");
+    if (!c->last.scored) return fail(c, ROMAN_E_INVALID, "roman_solve: no matrices (call roman_score or roman_set_matrix_data first)");
+    HIPCHK(c, hipSetDevice(c->device));
+    return solve_last(c, u0);
+}
+
+int roman_num_associations(const roman_ctx_t* c, int32_t* n)
+{
+    if (!c || !n) return fail(nullptr, ROMAN_E_INVALID, "NULL argument");
+    if (!c->last.scored) return fail(const_cast<roman_ctx*>(c), ROMAN_E_INVALID, "nothing scored yet");
+    *n = c->last.nA; return ROMAN_OK;
+}
+int roman_num_selected(const roman_ctx_t* c, int32_t* n)
+{
+    if (!c || !n) return fail(nullptr, ROMAN_E_INVALID, "NULL argument");
+    if (!c->last.solved) return fail(const_cast<roman_ctx*>(c), ROMAN_E_INVALID, "nothing solved yet");
+    *n = c->last.nsel; return ROMAN_OK;
+}
+int roman_get_selected_associations(const roman_ctx_t* c, int32_t* out)
+{
+    if (!c) return fail(nullptr, ROMAN_E_INVALID, "ctx is NULL");
+    const roman_ctx::Last& L = c->last;
+    if (!L.solved) return fail(const_cast<roman_ctx*>(c), ROMAN_E_INVALID, "nothing solved yet");
+    for (int32_t t = 0; t < L.nsel; ++t) {
+        const int32_t p = L.nodes[(size_t)t];
+        if (!L.assoc.empty()) { out[2 * t] = L.assoc[2 * (size_t)p]; out[2 * t + 1] = L.assoc[2 * (size_t)p + 1]; }
+        else if (L.dense) { out[2 * t] = p; out[2 * t + 1] = p; }
+        else { out[2 * t] = p / L.pd.n2; out[2 * t + 1] = p % L.pd.n2; }
+    }
+    return ROMAN_OK;
+}
+int roman_get_solution(const roman_ctx_t* c, int32_t* nodes, double* u, double* score, roman_stats_t* stats)
+{
+    if (!c) return fail(nullptr, ROMAN_E_INVALID, "ctx is NULL");
+    const roman_ctx::Last& L = c->last;
+    if (!L.solved) return fail(const_cast<roman_ctx*>(c), ROMAN_E_INVALID, "nothing solved yet");
+    if (nodes) for (int32_t t = 0; t < L.nsel; ++t) nodes[t] = L.nodes[(size_t)t];
+    if (u) for (int32_t p = 0; p < L.nA; ++p) u[p] = L.u[(size_t)p];
+    if (score) *score = L.stats.score;
+    if (stats) *stats = L.stats;
+    return ROMAN_OK;
+}
+
+int roman_get_upper_csr(const roman_ctx_t* c, int64_t* nnz, int64_t* rowptr, int32_t* cols_out, double* vals_out, double* diag)
+{
+    if (!c) return fail(nullptr, ROMAN_E_INVALID, "ctx is NULL");
+    const roman_ctx::Last& Lst = c->last;
+    if (!Lst.scored) return fail(const_cast<roman_ctx*>(c), ROMAN_E_INVALID, "nothing scored yet");
+    std::vector<uint32_t> rs, rl, cols; std::vector<double> vals, ls; std::vector<int32_t> lp;
+    int rc = fetch_last_csr(c, rs, rl, cols, vals, lp, ls);
+    if (rc) return rc;
+    const int L = Lst.tot.R, nA = Lst.nA;
+    int64_t cnt = 0;
+    std::vector<int64_t> rp((size_t)nA + 1, 0);
+    for (int k = 0; k < L; ++k) {
+        int64_t rc_ = 0;
+        for (uint32_t e = 0; e < rl[(size_t)k]; ++e) { const uint32_t q = cols[(size_t)rs[(size_t)k] + e] & 0x7fffffffu; if ((int)q > k) ++rc_; }
+        rp[(size_t)lp[(size_t)k] + 1] = rc_; cnt += rc_;
+    }
+    for (int p = 0; p < nA; ++p) rp[(size_t)p + 1] += rp[(size_t)p];
+    if (nnz) *nnz = cnt;
+    if (rowptr) for (int p = 0; p <= nA; ++p) rowptr[p] = rp[(size_t)p];
+    if (cols_out || vals_out) {
+        for (int k = 0; k < L; ++k) {
+            int64_t w = rp[(size_t)lp[(size_t)k]];
+            for (uint32_t e = 0; e < rl[(size_t)k]; ++e) {
+                const uint32_t q = cols[(size_t)rs[(size_t)k] + e] & 0x7fffffffu;
+                if ((int)q > k) { if (cols_out) cols_out[w] = lp[(size_t)q]; if (vals_out) vals_out[w] = vals[(size_t)rs[(size_t)k] + e]; ++w; }
+            }
+        }
+    }
+    if (diag) {
+        const bool single = Lst.D.single && !Lst.dense;
+        for (int p = 0; p < nA; ++p) diag[p] = single ? 0.0 : 1.0;
+        if (single) for (int k = 0; k < L; ++k) diag[(size_t)lp[(size_t)k]] = ls[(size_t)k];
+    }
+    return ROMAN_OK;
+}
+
+int roman_get_dense_matrices(const roman_ctx_t* c, double* M, double* Cm)
+{
+    if (!c) return fail(nullptr, ROMAN_E_INVALID, "ctx is NULL");
+    const roman_ctx::Last& Lst = c->last;
+    if (!Lst.scored) return fail(const_cast<roman_ctx*>(c), ROMAN_E_INVALID, "nothing scored yet");
+    std::vector<uint32_t> rs, rl, cols; std::vector<double> vals, ls; std::vector<int32_t> lp;
+    int rc = fetch_last_csr(c, rs, rl, cols, vals, lp, ls);
+    if (rc) return rc;
+    const int L = Lst.tot.R; const int64_t nA = Lst.nA;
+    if (M) memset(M, 0, sizeof(double) * (size_t)(nA * nA));
+    if (Cm) memset(Cm, 0, sizeof(double) * (size_t)(nA * nA));
+    const bool single = Lst.D.single && !Lst.dense;
+    for (int64_t p = 0; p < nA; ++p) { if (M) M[p * nA + p] = single ? 0.0 : 1.0; if (Cm) Cm[p * nA + p] = 1.0; }
+    for (int k = 0; k < L; ++k) {
+        const int64_t p = lp[(size_t)k];
+        if (single && M) M[p * nA + p] = ls[(size_t)k];
+        for (uint32_t e = 0; e < rl[(size_t)k]; ++e) {
+            const uint32_t cq = cols[(size_t)rs[(size_t)k] + e];
+            const int64_t q = lp[(size_t)(cq & 0x7fffffffu)];
+            if (M) M[p * nA + q] = vals[(size_t)rs[(size_t)k] + e];
+            if (Cm) Cm[p * nA + q] = (cq & 0x80000000u) ? 0.0 : 1.0;
+        }
+    }
+    return ROMAN_OK;
+}
+
+// --- pose from given correspondences -----------------------------------------------------------------
+int roman_pose_batch(roman_ctx_t* c, int32_t dim, int32_t B, const double* pts1, const double* pts2,
+                     const int64_t* corr_off, double* T_out, int32_t* status_out)
+{
+    if (!c) return fail(nullptr, ROMAN_E_INVALID, "ctx is NULL");
+    if (dim != 2 && dim != 3) return fail(c, ROMAN_E_INVALID, "dim must be 2 or 3");
+    if (B < 0 || !corr_off || !T_out || !status_out) return fail(c, ROMAN_E_INVALID, "bad arguments");
+    if (B == 0) return ROMAN_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    const int64_t K = corr_off[B];
+    if (K < 0 || (K > 0 && (!pts1 || !pts2))) return fail(c, ROMAN_E_INVALID, "bad correspondence arrays");
+    HIPCHK(c, c->hAux1.ensure(sizeof(double) * (size_t)std::max<int64_t>(K * dim, 1)));
+    HIPCHK(c, c->hAux2.ensure(sizeof(double) * (size_t)std::max<int64_t>(K * dim, 1)));
+    HIPCHK(c, c->hAux3.ensure(sizeof(int64_t) * ((size_t)B + 1)));
+    HIPCHK(c, c->oT.ensure(sizeof(double) * 16 * (size_t)B)); HIPCHK(c, c->oStatus.ensure(sizeof(int32_t) * (size_t)B));
+    if (K > 0) {
+        HIPCHK(c, hipMemcpyAsync(c->hAux1.p, pts1, sizeof(double) * (size_t)(K * dim), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->hAux2.p, pts2, sizeof(double) * (size_t)(K * dim), hipMemcpyHostToDevice, c->stream));
+    }
+    HIPCHK(c, hipMemcpyAsync(c->hAux3.p, corr_off, sizeof(int64_t) * ((size_t)B + 1), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_pose, dim3(B), dim3(64), 0, c->stream, dim, c->hAux1.as<double>(), c->hAux2.as<double>(), c->hAux3.as<int64_t>(),
+                       c->oT.as<double>(), c->oStatus.as<int32_t>());
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(T_out, c->oT.p, sizeof(double) * 16 * (size_t)B, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(status_out, c->oStatus.p, sizeof(int32_t) * (size_t)B, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return ROMAN_OK;
+}
+
+// --- diagnostics -------------------------------------------------------------------------------------------
+int roman_debug_math(roman_ctx_t* c, int kind, const double* in1, const double* in2, int64_t n, double* out)
+{
+    if (!c) return fail(nullptr, ROMAN_E_INVALID, "ctx is NULL");
+    if (n < 0 || (n > 0 && (!in1 || !out))) return fail(c, ROMAN_E_INVALID, "bad arguments");
+    if (n == 0) return ROMAN_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, c->hAux1.ensure(sizeof(double) * (size_t)n)); HIPCHK(c, c->hAux2.ensure(sizeof(double) * (size_t)n)); HIPCHK(c, c->hAux3.ensure(sizeof(double) * (size_t)n));
+    HIPCHK(c, hipMemcpyAsync(c->hAux1.p, in1, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    if (in2) HIPCHK(c, hipMemcpyAsync(c->hAux2.p, in2, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_debug_math, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, kind, c->hAux1.as<double>(),
+                       in2 ? c->hAux2.as<double>() : (const double*)nullptr, n, c->hAux3.as<double>());
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(out, c->hAux3.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return ROMAN_OK;
+}
+
+int roman_debug_cosine(roman_ctx_t* c, const roman_params_t* params, const double* D1, int32_t n1,
+                       const double* D2, int32_t n2, int32_t F, double* out)
+{
+    if (!c) return fail(nullptr, ROMAN_E_INVALID, "ctx is NULL");
+    if (n1 <= 0 || n2 <= 0 || !D1 || !D2 || !out) return fail(c, ROMAN_E_INVALID, "bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    DevParams D;
+    int rc = make_dev_params(c, params, F, &D);
+    if (rc) return rc;
+    if (D.p.cos_feature_dim <= 0) return fail(c, ROMAN_E_INVALID, "cos_feature_dim is 0");
+    HIPCHK(c, c->hFeats.ensure(sizeof(double) * (size_t)(n1 + n2) * F));
+    HIPCHK(c, hipMemcpyAsync(c->hFeats.p, D1, sizeof(double) * (size_t)n1 * F, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->hFeats.as<double>() + (size_t)n1 * F, D2, sizeof(double) * (size_t)n2 * F, hipMemcpyHostToDevice, c->stream));
+    ProbDesc pd{}; pd.off1 = 0; pd.off2 = n1; pd.assocOff = -1; pd.n1 = n1; pd.n2 = n2; pd.nA = n1 * n2;
+    HIPCHK(c, c->probs.ensure(sizeof(ProbDesc)));
+    HIPCHK(c, c->cosPool.ensure(sizeof(double) * (size_t)n1 * n2)); HIPCHK(c, c->normPool.ensure(sizeof(double) * (size_t)(n1 + n2)));
+    HIPCHK(c, hipMemcpyAsync(c->probs.p, &pd, sizeof(pd), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_norms, dim3((n1 + n2 + 3) / 4, 1), dim3(256), 0, c->stream, D, c->probs.as<ProbDesc>(), c->hFeats.as<double>(), c->normPool.as<double>());
+    const int tiles = ((n1 + 15) / 16) * ((n2 + 15) / 16);
+    hipLaunchKernelGGL(k_cos, dim3((tiles + 3) / 4, 1), dim3(256), 0, c->stream, D, c->probs.as<ProbDesc>(), c->hFeats.as<double>(), c->normPool.as<double>(), c->cosPool.as<double>());
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(out, c->cosPool.p, sizeof(double) * (size_t)n1 * n2, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->last.scored = false; c->last.solved = false;
+    return ROMAN_OK;
+}
+
+int roman_debug_live(const roman_ctx_t* cc, int32_t* n_live, int32_t* idx, double* score)
+{
+    if (!cc) return fail(nullptr, ROMAN_E_INVALID, "ctx is NULL");
+    roman_ctx* c = const_cast<roman_ctx*>(cc);
+    if (!c->last.scored) return fail(c, ROMAN_E_INVALID, "nothing scored yet");
+    const int L = c->last.tot.R;
+    if (n_live) *n_live = L;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (idx && L > 0) HIPCHK(c, hipMemcpy(idx, c->lp.p, sizeof(int32_t) * (size_t)L, hipMemcpyDeviceToHost));
+    if (score && L > 0) HIPCHK(c, hipMemcpy(score, c->ls.p, sizeof(double) * (size_t)L, hipMemcpyDeviceToHost));
+    return ROMAN_OK;
+}
+
+}  // extern "C"
