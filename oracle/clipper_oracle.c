@@ -477,16 +477,16 @@ ORACLE_API int oracle_solve(const roman_params_t* P, const oracle_mat_t* m, cons
     roman_stats_t S; memset(&S, 0, sizeof(S));
     S.n_assoc_in = n; S.nnz_upper = m->nnz;
     { int32_t live = 0; for (int32_t p = 0; p < n; ++p) live += (m->diag[p] != 0.0); S.n_live = live; }
-    if (n == 0) { *n_nodes = 0; if (st) *st = S; return 0; }
+    if (n <= 0) { *n_nodes = 0; if (st) *st = S; return 0; }
 
-    double* u   = (double*)malloc(sizeof(double) * (size_t)n);
-    double* un  = (double*)malloc(sizeof(double) * (size_t)n);
-    double* g   = (double*)malloc(sizeof(double) * (size_t)n);
-    double* gn  = (double*)malloc(sizeof(double) * (size_t)n);
-    double* Mu  = (double*)malloc(sizeof(double) * (size_t)n);
-    double* Cu  = (double*)malloc(sizeof(double) * (size_t)n);
-    double* Mun = (double*)malloc(sizeof(double) * (size_t)n);
-    double* Cun = (double*)malloc(sizeof(double) * (size_t)n);
+    double* u   = (double*)calloc((size_t)n, sizeof(double));
+    double* un  = (double*)calloc((size_t)n, sizeof(double));
+    double* g   = (double*)calloc((size_t)n, sizeof(double));
+    double* gn  = (double*)calloc((size_t)n, sizeof(double));
+    double* Mu  = (double*)calloc((size_t)n, sizeof(double));
+    double* Cu  = (double*)calloc((size_t)n, sizeof(double));
+    double* Mun = (double*)calloc((size_t)n, sizeof(double));
+    double* Cun = (double*)calloc((size_t)n, sizeof(double));
     int32_t npass = 0;
 #define TRACE(vec) do { if (support_trace && npass < trace_cap) { \
         int32_t c_ = 0; \

@@ -43,11 +43,11 @@ def align_sharded(registration, batch: AlignmentBatch, group=None, compute=None,
     dev = device if device is not None else (torch.device("cuda", torch.cuda.current_device())
                                              if dist.get_backend(group) == "nccl" else torch.device("cpu"))
     ti = torch.from_numpy(ints_p).to(dev); tp = torch.from_numpy(poses_p).to(dev)
-    gi = torch.empty((world,) + tuple(ti.shape), dtype=ti.dtype, device=dev)
-    gp = torch.empty((world,) + tuple(tp.shape), dtype=tp.dtype, device=dev)
+    gi = torch.empty((world * per, ti.shape[1]), dtype=ti.dtype, device=dev)    # concatenated along dim 0
+    gp = torch.empty((world * per, tp.shape[1]), dtype=tp.dtype, device=dev)
     dist.all_gather_into_tensor(gi, ti, group=group)
     dist.all_gather_into_tensor(gp, tp, group=group)
-    gi, gp = gi.cpu().numpy(), gp.cpu().numpy()
+    gi = gi.cpu().numpy().reshape(world, per, -1); gp = gp.cpu().numpy().reshape(world, per, -1)
     rows_i, rows_p = [], []
     for r in range(world):
         rlo, rhi = shard_bounds(B, r, world)

@@ -49,6 +49,12 @@ class SyntheticSegment:
     def scattering(self):
         return self._scattering
 
+    def normalized_eigenvalues(self):
+        """Called (result unused) by the reference's clipper+prune plugin
+        [REF roman/align/dist_reg_with_pruning.py:63]; a method there, as on PointCloudObject."""
+        e0 = 1.0 / (1.0 + (1.0 - self._linearity) + self._scattering)
+        return np.array([e0, e0 * (1.0 - self._linearity), e0 * self._scattering])
+
 
 @dataclass
 class SyntheticPair:

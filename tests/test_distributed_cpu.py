@@ -1,0 +1,110 @@
+"""N>1 path on CPU: world_size-2 `gloo` run of roman_amd.align.distributed.align_sharded with the
+oracle as the compute function (the HIP path needs a GPU).  Checks that sharding + one all_gather
+of fixed-size records reproduces the serial result in problem order."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from conftest import registration_for
+from roman_amd import synth
+from roman_amd.align import batch as rb
+from roman_amd.align.distributed import align_sharded, shard_bounds
+from roman_amd.runtime import BatchResult, stats_dtype
+
+
+def oracle_compute(registration, sub):
+    """BatchResult of a sub-batch computed by the CPU oracle (test double for run_batch)."""
+    from oracle import oracle as orc
+    P = registration._abi_params()
+    d = registration.dim
+    assoc, Ts, status = [], [], []
+    for b in range(len(sub)):
+        D1 = sub.feats[sub.off1[b]:sub.off1[b] + sub.n1[b]]; D2 = sub.feats[sub.off2[b]:sub.off2[b] + sub.n2[b]]
+        if len(D1) == 0 or len(D2) == 0:
+            assoc.append(np.zeros((0, 2), np.int32)); Ts.append(np.full((d + 1, d + 1), np.nan)); status.append(3); continue
+        a = orc.register(P, D1, D2)["assoc"]
+        assoc.append(a)
+        if len(a) >= d:
+            Ts.append(orc.t_align(D1[a[:, 0], :d], D2[a[:, 1], :d], d)); status.append(0)
+        else:
+            Ts.append(np.full((d + 1, d + 1), np.nan)); status.append(2)
+    return BatchResult(assoc, np.array(Ts).reshape(-1, d + 1, d + 1), np.array(status, np.int32), np.zeros(len(sub), stats_dtype()))
+
+
+def make_batch(reg):
+    subs, _ = synth.make_submap_grid(4, n=24, d=0, seed0=40)
+    subs[3] = []                                             # an empty submap: ragged + sentinel path
+    return rb.batch_from_submap_grid(reg, subs[:2], subs[2:])      # 2x2 = 4 problems... plus ragged sizes
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        reg = registration_for("gravity")
+        batch = make_batch(reg)
+        assoc, T, status = align_sharded(reg, batch, compute=oracle_compute)
+        q.put((rank, [a.tolist() for a in assoc], T.tolist(), status.tolist()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_shard_bounds_partition():
+    for n in (0, 1, 5, 7, 64, 4096):
+        for w in (1, 2, 3, 8):
+            b = [shard_bounds(n, r, w) for r in range(w)]
+            assert b[0][0] == 0 and b[-1][1] == n
+            assert all(b[r][1] == b[r + 1][0] for r in range(w - 1))
+            sizes = [hi - lo for lo, hi in b]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_record_roundtrip():
+    res = BatchResult([np.array([[1, 2], [3, 4]], np.int32), np.zeros((0, 2), np.int32)],
+                      np.stack([np.arange(16.0).reshape(4, 4), np.full((4, 4), np.nan)]), np.array([0, 2], np.int32), None)
+    ints, poses = rb.pack_records(res, kmax=5)
+    assert ints.shape == (2, 12) and poses.shape == (2, 16)
+    assoc, T, status = rb.unpack_records(ints, poses, 3)
+    assert assoc[0].tolist() == [[1, 2], [3, 4]] and assoc[1].shape == (0, 2)
+    assert np.array_equal(T[0], res.T[0]) and np.all(np.isnan(T[1])) and status.tolist() == [0, 2]
+
+
+def test_batch_layout_shares_the_feature_pool():
+    reg = registration_for("gravity")
+    subs, _ = synth.make_submap_grid(5, n=10, d=0, seed0=41)
+    b = rb.batch_from_submap_grid(reg, subs[:2], subs[2:], mask=np.array([[1, 0, 1], [1, 1, 0]], bool))
+    assert len(b) == 4 and b.feats.shape == (50, 3)
+    assert b.pair_index.tolist() == [[0, 0], [0, 2], [1, 0], [1, 1]]
+    assert b.off1.tolist() == [0, 0, 10, 10] and b.off2.tolist() == [20, 40, 20, 30]
+    sub = b.subset(1, 3)
+    assert len(sub) == 2 and sub.feats is b.feats and sub.off2.tolist() == [40, 20]
+    pairs = [(subs[0], subs[2]), (subs[1], [])]
+    bp = rb.batch_from_pairs(reg, pairs)
+    assert bp.n1.tolist() == [10, 10] and bp.n2.tolist() == [10, 0] and bp.assoc is None
+
+
+def test_world_size_2_gloo_matches_serial():
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    reg = registration_for("gravity")
+    batch = make_batch(reg)
+    serial = oracle_compute(reg, batch)
+    for rank, assoc, T, status in outs:
+        assert len(assoc) == len(batch)
+        for b in range(len(batch)):
+            assert assoc[b] == serial.assoc[b].tolist()
+            assert np.allclose(np.array(T[b]), serial.T[b], equal_nan=True)
+        assert status == serial.status.tolist()
+    assert any(len(a) >= 3 for a in outs[0][1])

@@ -1,0 +1,151 @@
+"""Batched entry point: ragged batches, shared feature pools, explicit lists, edge cases, and
+size-independent properties at BASELINE.json's full sizes (n=m=200, d=512)."""
+import numpy as np
+import pytest
+
+from conftest import registration_for
+from roman_amd import _abi, synth
+from roman_amd.align import batch as rb
+
+pytestmark = pytest.mark.gpu
+POSE_TOL = 1e-5
+
+
+def oracle_one(orc, reg, m1, m2):
+    D1, D2 = reg.pack(m1), reg.pack(m2)
+    A = reg._associations_to_score(m1, m2) if len(m1) and len(m2) else None
+    return orc.register(reg._abi_params(), D1, D2, A)
+
+
+def test_ragged_batch_equals_individual_oracle_solves(ctx, orc):
+    reg = registration_for("semanticgrav", semantics_dim=24); reg.set_context(ctx)
+    sizes = [(30, 30), (12, 40), (40, 9), (3, 3), (0, 10), (10, 0), (1, 1), (25, 26), (2, 30)]
+    pairs = []
+    for k, (n, m) in enumerate(sizes):
+        pr = synth.make_pair(max(n, 1), max(m, 1), 24, 100 + k)
+        pairs.append((pr.map1[:n], pr.map2[:m]))
+    res = reg.register_and_align_batch(pairs)
+    for b, (m1, m2) in enumerate(pairs):
+        if len(m1) == 0 or len(m2) == 0:
+            assert res.status[b] & _abi.ROMAN_ST_EMPTY_MAP and res.assoc[b].shape == (0, 2) and np.all(np.isnan(res.T[b]))
+            continue
+        o = oracle_one(orc, reg, m1, m2)
+        assert np.array_equal(res.assoc[b], o["assoc"]), b
+        assert res.stats["n_pass"][b] == o["stats"].n_pass and res.stats["nnz_upper"][b] == o["stats"].nnz_upper
+        if len(o["assoc"]) >= 3:
+            p1 = np.array([m1[i].center.ravel() for i, _ in o["assoc"]]); p2 = np.array([m2[j].center.ravel() for _, j in o["assoc"]])
+            assert res.status[b] == 0 and np.linalg.norm(res.T[b] - orc.t_align(p1, p2)) < POSE_TOL
+        else:
+            assert res.status[b] & _abi.ROMAN_ST_INSUFFICIENT and np.all(np.isnan(res.T[b]))
+
+
+def test_all_pairs_grid_shares_submaps(ctx, orc):
+    reg = registration_for("gravity"); reg.set_context(ctx)
+    subs, poses = synth.make_submap_grid(5, n=30, d=0, seed0=50)
+    batch = rb.batch_from_submap_grid(reg, subs[:2], subs[2:])
+    assert len(batch) == 6 and batch.feats.shape[0] == 150
+    res = rb.run_batch(reg, batch)
+    for b, (i, j) in enumerate(batch.pair_index):
+        o = oracle_one(orc, reg, subs[i], subs[2 + j])
+        assert np.array_equal(res.assoc[b], o["assoc"])
+        if res.status[b] == 0:                       # pose agrees with the ground-truth relative pose
+            T_gt = np.linalg.inv(poses[i]) @ poses[2 + j]
+            assert np.linalg.norm(res.T[b][:3, 3] - T_gt[:3, 3]) < 0.3
+    assert sum(len(a) >= 10 for a in res.assoc) >= 5
+
+
+def test_explicit_association_lists_in_a_batch(ctx, orc):
+    reg = registration_for("clipper+prune", cosine_min=0.5); reg.set_context(ctx)
+    pairs = []
+    for k in range(4):
+        pr = synth.make_pair(30 + 3 * k, 28, 32, 200 + k)
+        pairs.append((pr.map1, pr.map2))
+    batch = rb.batch_from_pairs(reg, pairs)
+    assert batch.assoc is not None and batch.assoc_off[-1] == len(batch.assoc)
+    res = rb.run_batch(reg, batch)
+    for b, (m1, m2) in enumerate(pairs):
+        assert np.array_equal(res.assoc[b], oracle_one(orc, reg, m1, m2)["assoc"])
+
+
+def test_kmax_truncation_is_flagged(ctx):
+    reg = registration_for("clipper"); reg.set_context(ctx)
+    pr = synth.make_pair(30, 30, 0, 1000)
+    b = rb.batch_from_pairs(reg, [(pr.map1, pr.map2)])
+    full = ctx.align_batch(reg._abi_params(), b.feats, b.off1, b.n1, b.off2, b.n2, kmax=30)
+    cut = ctx.align_batch(reg._abi_params(), b.feats, b.off1, b.n1, b.off2, b.n2, kmax=5)
+    assert len(full.assoc[0]) > 5 and not (full.status[0] & _abi.ROMAN_ST_ASSOC_TRUNCATED)
+    assert cut.status[0] & _abi.ROMAN_ST_ASSOC_TRUNCATED and np.array_equal(cut.assoc[0], full.assoc[0][:5])
+    assert np.allclose(cut.T[0], full.T[0])          # the pose always uses every selected association
+
+
+def test_tie_fallback_matches_published_heap(ctx, orc):
+    """K4 with weight 0.5 -> F = 2.5 -> omega = 3 of four identical u: exact heap emulation on device."""
+    n = 4
+    M = np.full((n, n), 0.5); np.fill_diagonal(M, 1.0)
+    C = np.ones((n, n))
+    P = _abi.RomanParams.default(); P.invariant = _abi.ROMAN_INV_EUCLIDEAN
+    ctx.set_matrix_data(P, M, C); ctx.solve(None)
+    nodes, u, score, _ = ctx.solution()
+    ref = orc.solve(P, orc.matrix_from_dense(M, C))
+    assert nodes.tolist() == ref["nodes"].tolist() == [2, 1, 0]
+    assert abs(score - 2.5) < 1e-12
+
+
+def test_dense_matrix_path_and_mno_clipper(ctx, orc):
+    reg = registration_for("clipper"); reg.set_context(ctx)
+    pr = synth.make_pair(14, 14, 0, 33)
+    M, C, A = reg.get_MCA(pr.map1, pr.map2)
+    D1, D2 = reg.pack(pr.map1), reg.pack(pr.map2)
+    mat, _ = orc.build_matrix(reg._abi_params(), D1, D2)
+    Mo, Co = mat.dense()
+    assert np.array_equal(C, Co) and np.allclose(M, Mo, rtol=1e-13, atol=0) and np.array_equal(M != 0, Mo != 0)
+    sols = reg.mno_clipper(pr.map1, pr.map2, num_solutions=2)
+    # the same loop on the oracle (object_registration.py:57-86)
+    Mw = Mo.copy(); P = reg._abi_params(); P.invariant = _abi.ROMAN_INV_EUCLIDEAN
+    for k in range(2):
+        s = orc.solve(P, orc.matrix_from_dense(Mw, Co))
+        assert np.array_equal(sols[k][0], A[s["nodes"]].astype(np.int64))
+        u_sol = np.zeros_like(s["u"]); u_sol[s["nodes"]] = s["u"][s["nodes"]]
+        assert abs(sols[k][1] - u_sol @ Mo @ u_sol / (u_sol @ u_sol)) < 1e-9
+        Mw[np.ix_(s["nodes"], s["nodes"])] = 0.0
+    assert len(sols[0][0]) >= 5
+
+
+def test_full_size_properties_cfg2_cfg3(ctx):
+    """BASELINE configs 2/3 shape (n=m=200, d=512, semanticgrav): properties that need no oracle."""
+    reg = registration_for("semanticgrav", semantics_dim=512); reg.set_context(ctx)
+    B = 12
+    prs = [synth.make_pair(200, 200, 512, 3000 + k) for k in range(B)]
+    res = reg.register_and_align_batch([(p.map1, p.map2) for p in prs])
+    for b, pr in enumerate(prs):
+        got = set(map(tuple, res.assoc[b].tolist())); truth = set(map(tuple, pr.inliers.tolist()))
+        assert res.status[b] == 0
+        assert len(got & truth) >= 0.9 * len(truth) and len(got - truth) <= 2          # planted clique
+        assert len(set(i for i, _ in got)) == len(got) == len(set(j for _, j in got))    # one-to-one
+        assert np.linalg.norm(res.T[b][:3, :3] - pr.T_gt[:3, :3]) < 0.02 and np.linalg.norm(res.T[b][:3, 3] - pr.T_gt[:3, 3]) < 0.1
+        R = res.T[b][:3, :3]
+        assert abs(np.linalg.det(R) - 1) < 1e-12 and np.allclose(R @ R.T, np.eye(3), atol=1e-12)
+        assert res.stats["n_assoc_in"][b] == 40000 and res.stats["n_live"][b] < 8000
+    # idempotence / determinism: a second run returns bit-identical results
+    res2 = reg.register_and_align_batch([(p.map1, p.map2) for p in prs])
+    for b in range(B):
+        assert np.array_equal(res.assoc[b], res2.assoc[b]) and np.array_equal(res.T[b], res2.T[b])
+    # batch composition does not matter: problem 0 alone == problem 0 in the batch
+    solo = reg.register_and_align_batch([(prs[0].map1, prs[0].map2)])
+    assert np.array_equal(solo.assoc[0], res.assoc[0]) and np.array_equal(solo.T[0], res.T[0])
+    # permuting the objects of map 2 permutes the associations and leaves the pose unchanged
+    perm = np.random.default_rng(1).permutation(200)
+    m2p = [prs[1].map2[k] for k in perm]
+    rp = reg.register_and_align_batch([(prs[1].map1, m2p)])
+    assert set((int(i), int(perm[j])) for i, j in rp.assoc[0]) == set(map(tuple, res.assoc[1].tolist()))
+    assert np.linalg.norm(rp.T[0] - res.T[1]) < 1e-9
+
+
+def test_large_live_set_uses_global_u_path(ctx, orc):
+    """L = 150*150 = 22500 live associations exceed the LDS-resident vectors: same results."""
+    reg = registration_for("clipper"); reg.set_context(ctx)
+    pr = synth.make_pair(150, 150, 0, 61)
+    res = reg.register_and_align_batch([(pr.map1, pr.map2)])
+    o = oracle_one(orc, reg, pr.map1, pr.map2)
+    assert np.array_equal(res.assoc[0], o["assoc"])
+    assert res.stats["n_pass"][0] == o["stats"].n_pass and res.stats["nnz_upper"][0] == o["stats"].nnz_upper

@@ -1,0 +1,61 @@
+"""HIP path against the committed golden fixtures made from the reference's own Python
+(tests/golden/make_golden.py): T_align outputs of the reference function, and register()/T_align()
+results of the reference's unmodified plugin classes."""
+import numpy as np
+import pytest
+
+from conftest import golden_pair, golden_register_cases, golden_t_align_cases, registration_for
+from roman_amd import _abi
+from roman_amd.align import InsufficientAssociationsException
+
+pytestmark = pytest.mark.gpu
+
+POSE_TOL = 1e-5
+TCASES = golden_t_align_cases()
+RCASES = golden_register_cases()
+
+
+def test_pose_kernel_matches_reference_t_align(ctx):
+    """roman_pose_batch on every golden case in ONE ragged batch (k from 1 to 200, 2-D and 3-D
+    batched separately), incl. reflection (det=-1 branch), planar clouds and k<dim."""
+    for dim in (2, 3):
+        cs = [c for c in TCASES if c["dim"] == dim]
+        off = np.zeros(len(cs) + 1, dtype=np.int64)
+        for i, c in enumerate(cs):
+            off[i + 1] = off[i] + len(c["p1"])
+        p1 = np.concatenate([c["p1"].reshape(-1, dim) for c in cs]); p2 = np.concatenate([c["p2"].reshape(-1, dim) for c in cs])
+        T, status = ctx.pose_batch(dim, p1, p2, off)
+        for i, c in enumerate(cs):
+            if c["ok"]:
+                assert status[i] == 0, c["tag"]
+                assert np.linalg.norm(T[i] - c["T"]) < POSE_TOL, (c["tag"], np.linalg.norm(T[i] - c["T"]))
+            else:
+                assert status[i] & _abi.ROMAN_ST_INSUFFICIENT and np.all(np.isnan(T[i])), c["tag"]
+
+
+def test_pose_kernel_accuracy_is_near_machine_precision(ctx):
+    worst = 0.0
+    for dim in (2, 3):
+        cs = [c for c in TCASES if c["dim"] == dim and c["ok"] and "planar" not in c["tag"]]
+        off = np.cumsum([0] + [len(c["p1"]) for c in cs]).astype(np.int64)
+        T, _ = ctx.pose_batch(dim, np.concatenate([c["p1"] for c in cs]), np.concatenate([c["p2"] for c in cs]), off)
+        worst = max(worst, max(np.linalg.norm(T[i] - c["T"]) for i, c in enumerate(cs)))
+    assert worst < 1e-11
+
+
+@pytest.mark.parametrize("case", RCASES, ids=[f"{i}-{c['method']}" for i, c in enumerate(RCASES)])
+def test_register_and_t_align_match_reference_plugins(ctx, case):
+    """Same calls the reference's caller makes (submap_align.py:156-166): register() then T_align()."""
+    reg = registration_for(case["method"], **case["kw"]); reg.set_context(ctx)
+    pr = golden_pair(case)
+    assert np.array_equal(reg.pack(pr.map1), case["pack1"])          # generator reproducibility guard
+    assoc = reg.register(pr.map1, pr.map2)
+    assert assoc.dtype.kind == "i" and assoc.shape[1] == 2
+    assert np.array_equal(assoc.astype(np.int64), case["assoc"])      # bit-exact association indices
+    if len(case["assoc"]) >= reg.dim:
+        T = reg.T_align(pr.map1, pr.map2, assoc)
+        assert T.shape == case["T"].shape and np.linalg.norm(T - case["T"]) < POSE_TOL
+        assert np.linalg.norm(reg.T_align(pr.map1, pr.map2) - case["T"]) < POSE_TOL   # correspondences=None path
+    else:
+        with pytest.raises(InsufficientAssociationsException):
+            reg.T_align(pr.map1, pr.map2, assoc)
