@@ -60,6 +60,9 @@ class CLIPPER:
         self._A = None
         self._scored = False
         self._u0 = None
+        self._inputs = None          # what was scored: re-sent if another object used the context since
+        self._solution = None        # cached at solve(): upstream keeps results per CLIPPER object
+        self._selected = None
 
     # -- plumbing ---------------------------------------------------------------------------------
     def _context(self):
@@ -83,11 +86,27 @@ class CLIPPER:
             A = None                     # upstream: an empty A means all-to-all
         if A is None:
             self._A = utils.create_all_to_all(D1.shape[0], D2.shape[0])
-            self._context().score(self._abi_params(), D1, D2, None)
+            self._inputs = ("score", D1, D2, None)
         else:
             self._A = np.ascontiguousarray(A, dtype=np.int32).reshape(-1, 2)
-            self._context().score(self._abi_params(), D1, D2, self._A)
+            self._inputs = ("score", D1, D2, self._A)
+        self._solution = self._selected = None
+        self._send()
         self._scored = True
+
+    def _send(self):
+        """(Re)load this object's matrices into the context: one context holds one problem."""
+        ctx = self._context()
+        kind = self._inputs[0]
+        if kind == "score":
+            ctx.score(self._abi_params(), self._inputs[1], self._inputs[2], self._inputs[3])
+        else:
+            ctx.set_matrix_data(self._abi_params(), self._inputs[1], self._inputs[2])
+        ctx._owner = id(self)
+
+    def _own(self):
+        if getattr(self._context(), "_owner", None) != id(self):
+            self._send()
 
     # -- clipperpy API ----------------------------------------------------------------------------
     def score_pairwise_consistency(self, D1, D2, A=None):
@@ -96,9 +115,10 @@ class CLIPPER:
 
     def set_matrix_data(self, M, C):
         """[REF roman/align/object_registration.py:64]"""
-        M = np.asarray(M, dtype=np.float64)
         self._A = None
-        self._context().set_matrix_data(self._abi_params(), M, np.asarray(C, dtype=np.float64))
+        self._inputs = ("dense", np.array(M, dtype=np.float64), np.array(C, dtype=np.float64))
+        self._solution = self._selected = None
+        self._send()
         self._scored = True
 
     def solve(self, u0=None):
@@ -106,23 +126,33 @@ class CLIPPER:
         if not self._scored:
             raise RuntimeError("solve() called before scoring / set_matrix_data")
         self._u0 = None if u0 is None else np.asarray(u0, dtype=np.float64)
-        self._context().solve(self._u0)
+        self._own()
+        ctx = self._context()
+        ctx.solve(self._u0)
+        nodes, u, score, st = ctx.solution()
+        self._solution = Solution(nodes, u, score, self._u0, st.outer_iters)
+        self._selected = ctx.selected_associations()
 
     def get_selected_associations(self):
         """[REF roman/align/object_registration.py:28] -> (k,2) int32 rows of A in `nodes` order."""
-        return self._context().selected_associations()
+        if self._selected is None:
+            raise RuntimeError("get_selected_associations() before solve()")
+        return self._selected.copy()
 
     def get_solution(self):
         """[REF roman/align/object_registration.py:67-71]"""
-        nodes, u, score, st = self._context().solution()
-        return Solution(nodes, u, score, self._u0, st.outer_iters)
+        if self._solution is None:
+            raise RuntimeError("get_solution() before solve()")
+        return self._solution
 
     def get_affinity_matrix(self):
         """[REF roman/align/object_registration.py:53]"""
+        self._own()
         return self._context().dense_matrices()[0]
 
     def get_constraint_matrix(self):
         """[REF roman/align/object_registration.py:54]"""
+        self._own()
         return self._context().dense_matrices()[1]
 
     def get_initial_associations(self):

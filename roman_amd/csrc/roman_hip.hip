@@ -221,9 +221,6 @@ int stage_score(roman_ctx* c, const DevParams& D, const BatchIn& in, std::vector
     const size_t pairLds = (size_t)wpb * ldsPerWave * sizeof(double);
     const int blocksPerCU = std::max(1, std::min(2048 / (wpb * 64), (int)(c->lds_max / pairLds)));
     const int pairGrid = c->num_cu * blocksPerCU;
-    *idx16 = true;
-    for (int b = 0; b < B; ++b) if (hd[b].nA > 32767) { *idx16 = false; break; }
-
     StageTimer t1(c, ROMAN_STAGE_COUNT_PASS);
     {
         auto kc = D.gravity ? k_pairs<false, true, uint32_t> : k_pairs<false, false, uint32_t>;
@@ -240,6 +237,7 @@ int stage_score(roman_ctx* c, const DevParams& D, const BatchIn& in, std::vector
     HIPCHK(c, hipStreamSynchronize(c->stream));
     const BatchTotals tot = *c->pinnedTotals;
     *totOut = tot;
+    *idx16 = tot.maxL <= 32767;        // column indices are LIVE indices; bit 15 is the C==0 flag
     const size_t nnz1 = (size_t)std::max<int64_t>(tot.nnzTotal, 1);
     HIPCHK(c, c->vals.ensure(sizeof(double) * nnz1));
     HIPCHK(c, c->cols.ensure((*idx16 ? sizeof(uint16_t) : sizeof(uint32_t)) * nnz1));

@@ -31,7 +31,13 @@ def test_ragged_batch_equals_individual_oracle_solves(ctx, orc):
             continue
         o = oracle_one(orc, reg, m1, m2)
         assert np.array_equal(res.assoc[b], o["assoc"]), b
-        assert res.stats["n_pass"][b] == o["stats"].n_pass and res.stats["nnz_upper"][b] == o["stats"].nnz_upper
+        assert res.stats["n_live"][b] == o["stats"].n_live and res.stats["nnz_upper"][b] == o["stats"].nnz_upper
+        # Trajectory statistics are compared when M has at least one edge.  Without any consistent pair
+        # the iteration normalises a vector that is zero up to rounding (a discontinuity of the
+        # published algorithm), so pass counts there depend on summation order; with no live
+        # association the device skips the solver outright.
+        if o["stats"].nnz_upper > 0:
+            assert res.stats["n_pass"][b] == o["stats"].n_pass
         if len(o["assoc"]) >= 3:
             p1 = np.array([m1[i].center.ravel() for i, _ in o["assoc"]]); p2 = np.array([m2[j].center.ravel() for _, j in o["assoc"]])
             assert res.status[b] == 0 and np.linalg.norm(res.T[b] - orc.t_align(p1, p2)) < POSE_TOL

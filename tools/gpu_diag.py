@@ -148,6 +148,31 @@ def compare_case(ctx, name):
     print(f"times: oracle build+solve {t_or*1e3:.1f} ms | gpu score {t_sc*1e3:.1f} ms solve {t_so*1e3:.1f} ms (first-call overheads included)")
 
 
+def ragged(ctx):
+    section("ragged batch: per-problem stats GPU vs oracle")
+    reg = SubmapAlignParams(method="semanticgrav", semantics_dim=24).get_object_registration(); reg.set_context(ctx)
+    sizes = [(30, 30), (12, 40), (40, 9), (3, 3), (0, 10), (10, 0), (1, 1), (25, 26), (2, 30)]
+    pairs = []
+    for k, (n, m) in enumerate(sizes):
+        pr = synth.make_pair(max(n, 1), max(m, 1), 24, 100 + k)
+        pairs.append((pr.map1[:n], pr.map2[:m]))
+    res = reg.register_and_align_batch(pairs)
+    P = reg._abi_params()
+    for b, (m1, m2) in enumerate(pairs):
+        if not len(m1) or not len(m2):
+            continue
+        D1, D2 = reg.pack(m1), reg.pack(m2)
+        o = orc.register(P, D1, D2)
+        so = o["stats"]; sg = res.stats[b]
+        print(f"b={b} sizes={sizes[b]} oracle: L={so.n_live} nnzU={so.nnz_upper} pass={so.n_pass} outer={so.outer_iters} inner={so.inner_iters} ls={so.ls_trials} F={so.score!r} d={so.d_final!r} k={len(o['assoc'])}")
+        print(f"      gpu   : L={sg['n_live']} nnzU={sg['nnz_upper']} pass={sg['n_pass']} outer={sg['outer_iters']} inner={sg['inner_iters']} ls={sg['ls_trials']} F={float(sg['score'])!r} d={float(sg['d_final'])!r} k={len(res.assoc[b])}")
+        # single-problem stepwise for u
+        ctx.score(P, D1, D2, None); ctx.solve(None)
+        nodes, u, score, st = ctx.solution()
+        live = np.nonzero(o['u'] > 0)[0]
+        print(f"      stepwise gpu pass={st.n_pass}; u_or[live]={o['u'][live][:8]!r} u_gpu[live]={u[live][:8]!r}")
+
+
 def timing(ctx):
     section("throughput probe: batch of cfg2-shaped pairs (semanticgrav, n=m=200, d=512)")
     reg = SubmapAlignParams(method="semanticgrav", semantics_dim=512).get_object_registration()
@@ -180,6 +205,8 @@ def main():
                 math_checks(ctx)
             elif w == "cos":
                 cosine_checks(ctx)
+            elif w == "ragged":
+                ragged(ctx)
             elif w == "timing":
                 timing(ctx)
             else:
