@@ -6,13 +6,17 @@
 //   k_tables  intra-map distance tables with NaN sentinels      (n1^2 + n2^2 entries)
 //   k_live    single scores + ordered compaction of live associations
 //   k_rowbase prefix of live counts over problems
-//   k_pairs<COUNT> / k_rowscan / k_probscan / k_pairs<FILL>     sparse affinity build
+//   k_rowmap  flattened row -> problem map
+//   k_count (pair tests -> candidate bit masks) / k_rowsort / k_probscan / k_fill   sparse affinity build
 //   k_solve   persistent per-problem projected-gradient solver + top-omega + Umeyama pose
 //
-// Numerics contract (tests/test_gpu_parity.py): every decision that shapes the sparsity
-// pattern of M uses only +,-,*,sqrt and comparisons, compiled with -ffp-contract=off, so the
-// pattern is bit-identical to oracle/clipper_oracle.c; transcendental values (exp, cbrt, pow)
-// may differ from glibc by an ulp.
+// Layout of M in HBM (sorted SELL-64): per problem the live rows are counting-sorted by
+// their number of entries (descending) and cut into slices of 64 rows; a slice is stored entry-index-
+// major and padded to its longest row:  entry e of the row in slot (slice s, lane l) sits at
+//      sliceBase[s] + e*64 + l .
+// A wave that owns a slice (lane = row) therefore reads 64 contiguous words per step with no
+// predicates, ballots or cross-lane reductions, and keeps 2*G independent loads in flight.  Padding
+// and filtered entries are "inert": value 0 with the C-flag set (they add exactly nothing).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -47,17 +51,24 @@ struct ProbDesc {
 struct ProbState {
     int32_t  L;            // live associations
     int32_t  rowBase;      // prefix of L over the batch
-    int64_t  nnzOff;       // offset of this problem's CSR segment
-    uint32_t nnzCap;       // candidate entries allocated for this problem
+    int64_t  nnzOff;       // offset of this problem's matrix segment
+    int64_t  maskOff;      // offset (in 64-bit words) of this problem's candidate bit matrix
+    uint32_t nnzCap;       // padded SELL slots allocated for this problem
     uint32_t pad;
     unsigned long long nnzUpper;   // stored strict-upper non-zeros (after the affinityeps filter)
 };
 
 struct BatchTotals {
     int64_t nnzTotal;      // sum of nnzCap
+    int64_t maskWords;     // sum over problems of L * ceil(L/64)
     int32_t R;             // sum of L
     int32_t maxL;
 };
+
+// column-index word of a stored entry: live column index + a flag bit "C_pq == 0"
+template <typename IdxT> struct IdxTraits;
+template <> struct IdxTraits<uint16_t> { static constexpr uint32_t CZ = 0x8000u; static constexpr uint32_t MASK = 0x7fffu; };
+template <> struct IdxTraits<uint32_t> { static constexpr uint32_t CZ = 0x80000000u; static constexpr uint32_t MASK = 0x7fffffffu; };
 
 // ---------------------------------------------------------------------------------------------
 // small helpers
@@ -295,47 +306,46 @@ __global__ void __launch_bounds__(1024) k_live(DevParams D, const ProbDesc* __re
     }
 }
 
-// k_rowbase: serial prefix of the live counts (B is small); also the batch maxima.
+// k_rowbase: serial prefix of the live counts (B is small); also the batch maxima and the offsets
+// of the per-problem candidate bit matrices (L rows of ceil(L/64) words).
 __global__ void k_rowbase(int B, ProbState* __restrict__ st, BatchTotals* __restrict__ tot)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    int acc = 0, mx = 0;
-    for (int b = 0; b < B; ++b) { st[b].rowBase = acc; acc += st[b].L; mx = max(mx, st[b].L); }
-    tot->R = acc; tot->maxL = mx; tot->nnzTotal = 0;
+    int acc = 0, mx = 0; int64_t mw = 0;
+    for (int b = 0; b < B; ++b) {
+        const int L = st[b].L;
+        st[b].rowBase = acc; st[b].maskOff = mw;
+        acc += L; mx = max(mx, L); mw += (int64_t)L * ((L + 63) >> 6);
+    }
+    tot->R = acc; tot->maxL = mx; tot->nnzTotal = 0; tot->maskWords = mw;
+}
+
+// k_rowmap: rowProb[r] = problem of flattened live row r (replaces a per-row binary search).
+__global__ void __launch_bounds__(256) k_rowmap(const ProbState* __restrict__ st, int32_t* __restrict__ rowProb)
+{
+    const int b = blockIdx.x;
+    const int L = st[b].L, rb = st[b].rowBase;
+    for (int k = threadIdx.x; k < L; k += blockDim.x) rowProb[rb + k] = b;
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_pairs: the O(L^2) affinity build.  One wave per live row k=(i,j); lanes sweep the live
-// columns q=(i',j').  The two table rows TA[i][:] and TB[j][:] are staged in this wave's slice
-// of LDS, so a pair costs two LDS gathers, two coalesced loads and ~10 f64 VALU ops.
-//   COUNT pass: candidates per row (pattern only: +,-,*,compare).
-//   FILL pass : candidates ballot-compacted in ascending column order into the row's CSR
-//               segment, then a dense sweep turns them into values (sqrt/exp/cbrt only on
-//               candidates) and drops the rare ones at or below affinityeps.
+// k_count: the O(L^2) pair tests of the affinity build, done ONCE.  One wave per live row k=(i,j);
+// lanes sweep the live columns q=(i',j') 64 at a time.  The two table rows TA[i][:] and TB[j][:] are
+// staged in this wave's slice of LDS, so a test costs two LDS gathers, a few coalesced loads and
+// ~15 f64 VALU ops, all exactly rounded (+,-,*,compare).  Output: the row's candidate count and its
+// candidate bit mask (one ballot word per 64 columns) — k_fill never repeats a test.
 // Rows are taken persistently (grid-stride over the batch's flattened row list).
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ int find_problem(const ProbState* __restrict__ st, int B, int r)
-{
-    int lo = 0, hi = B - 1;                  // last b with rowBase[b] <= r (L may be 0 for some b)
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (st[mid].rowBase <= r) lo = mid; else hi = mid - 1;
-    }
-    return lo;
-}
-
-template <bool FILL, bool GRAV, typename IdxT>
-__global__ void __launch_bounds__(1024) k_pairs(DevParams D, int B, const ProbDesc* __restrict__ probs,
-                                                ProbState* __restrict__ st,
+template <bool GRAV>
+__global__ void __launch_bounds__(1024) k_count(DevParams D, const ProbDesc* __restrict__ probs,
+                                                const ProbState* __restrict__ st,
                                                 const BatchTotals* __restrict__ tot,
+                                                const int32_t* __restrict__ rowProb,
                                                 const double* __restrict__ tabPool,
                                                 const int32_t* __restrict__ li, const int32_t* __restrict__ lj,
-                                                const double* __restrict__ ls,
                                                 const double* __restrict__ lza, const double* __restrict__ lzb,
                                                 uint32_t* __restrict__ rowCnt,
-                                                const uint32_t* __restrict__ rowStart,
-                                                uint32_t* __restrict__ rowLen,
-                                                IdxT* __restrict__ cols, double* __restrict__ vals,
+                                                unsigned long long* __restrict__ maskPool,
                                                 int ldsPerWave /* doubles */)
 {
     extern __shared__ __attribute__((aligned(16))) double s_tab[];
@@ -343,7 +353,7 @@ __global__ void __launch_bounds__(1024) k_pairs(DevParams D, int B, const ProbDe
     double* tA = s_tab + (size_t)w * ldsPerWave;
     const int R = tot->R;
     for (int r = blockIdx.x * wpb + w; r < R; r += gridDim.x * wpb) {
-        const int b = find_problem(st, B, r);
+        const int b = rowProb[r];
         const ProbDesc pd = probs[b];
         const int L = st[b].L, k = r - st[b].rowBase;
         const int64_t lo = pd.liveOff;
@@ -359,92 +369,107 @@ __global__ void __launch_bounds__(1024) k_pairs(DevParams D, int B, const ProbDe
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
+        const int W = (L + 63) >> 6;
+        unsigned long long* mrow = maskPool + st[b].maskOff + (int64_t)k * W;
         uint32_t cnt = 0;
-        const int64_t segBase = FILL ? st[b].nnzOff + rowStart[lo + k] : 0;
-        for (int q0 = 0; q0 < L; q0 += WAVE) {
-            const int q = q0 + lane;
-            bool is = false; double x = 0.0;
-            if (q < L) {
-                const double a = tA[li[lo + q]], bb = tB[lj[lo + q]];
+        constexpr int U = 4;                       // column chunks per step: 4*U loads in flight per lane
+        for (int q0 = 0; q0 < L; q0 += U * WAVE) {
+            int iq[U], jq[U]; double zq1[U], zq2[U]; bool vq[U];
+#pragma unroll
+            for (int t = 0; t < U; ++t) {
+                const int q = q0 + t * WAVE + lane;
+                vq[t] = q < L;
+                const int64_t qi = lo + (vq[t] ? q : 0);
+                iq[t] = li[qi]; jq[t] = lj[qi];
+                if (GRAV) { zq1[t] = lza[qi]; zq2[t] = lzb[qi]; }
+            }
+#pragma unroll
+            for (int t = 0; t < U; ++t) {
+                const double a = tA[iq[t]], bb = tB[jq[t]];
+                bool is;
                 if (GRAV) {
                     const double ch = fabs(a - bb);
                     const double hm = a > bb ? a : bb;
-                    double cv = fabs((zi - lza[lo + q]) - (zj - lzb[lo + q])) - D.sin_unc * hm;
+                    double cv = fabs((zi - zq1[t]) - (zj - zq2[t])) - D.sin_unc * hm;
                     if (cv < 0.0) cv = 0.0;
-                    x = ch * ch + cv * cv;
-                    is = x < D.x_eps;              // <=> sqrt(x) < epsilon ; NaN -> false
+                    const double x = ch * ch + cv * cv;
+                    is = vq[t] && (x < D.x_eps);   // <=> sqrt(x) < epsilon ; NaN -> false
                 } else {
-                    x = fabs(a - bb);
-                    is = x < D.p.epsilon;
+                    is = vq[t] && (fabs(a - bb) < D.p.epsilon);
+                }
+                const unsigned long long m = __ballot(is);
+                if (q0 + t * WAVE < L) {
+                    if (lane == 0) mrow[(q0 >> 6) + t] = m;
+                    cnt += __popcll(m);
                 }
             }
-            const unsigned long long m = __ballot(is);
-            if (FILL && is) {
-                const int64_t pos = segBase + cnt + __popcll(m & ((1ull << lane) - 1ull));
-                cols[pos] = (IdxT)q; vals[pos] = x;
-            }
-            cnt += __popcll(m);
         }
-        if (!FILL) {
-            if (lane == 0) rowCnt[lo + k] = cnt;
-            continue;
-        }
-        // make this wave's candidate writes visible to its own lanes before the value sweep
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const double sk = ls[lo + k];
-        uint32_t kept = 0, upper = 0;
-        for (uint32_t e0 = 0; e0 < cnt; e0 += WAVE) {
-            const uint32_t e = e0 + lane;
-            bool keep = false; double v = 0.0; IdxT q = 0;
-            if (e < cnt) {
-                q = cols[segBase + e];
-                const double x = vals[segBase + e];
-                const double c = GRAV ? sqrt(x) : x;
-                const double sa = exp(((-0.5 * c) * c) / D.sig2);
-                v = fuse_pair(D, sa, sk, ls[lo + (int64_t)q]);
-                keep = v > D.p.affinityeps;
-            }
-            const unsigned long long m = __ballot(keep);
-            if (keep) {
-                const int64_t pos = segBase + kept + __popcll(m & ((1ull << lane) - 1ull));
-                cols[pos] = q; vals[pos] = v;       // pos <= segBase+e: in-place forward compaction
-            }
-            kept += __popcll(m);
-            upper += __popcll(__ballot(keep && (int)q > k));
-        }
-        if (lane == 0) {
-            rowLen[lo + k] = kept;
-            if (upper) atomicAdd(&st[b].nnzUpper, (unsigned long long)upper);
-        }
+        if (lane == 0) rowCnt[lo + k] = cnt;
     }
 }
 
-// k_rowscan: per problem exclusive scan of the candidate counts -> row starts + total.
-__global__ void __launch_bounds__(1024) k_rowscan(const ProbDesc* __restrict__ probs,
-                                                  ProbState* __restrict__ st,
+// ---------------------------------------------------------------------------------------------
+// k_rowsort: per problem, counting sort of the live rows by candidate count (descending), then the
+// sorted SELL-64 geometry: rowPos[k] = sorted position of row k, perm[pos] = row, and per slice its
+// width (longest row) and base offset.  The order among rows of equal count is arbitrary (atomic
+// ranks) — it changes where a row is stored, never what is computed for it.
+// ---------------------------------------------------------------------------------------------
+constexpr int SORT_KEYS = 8192;
+
+__global__ void __launch_bounds__(1024) k_rowsort(const ProbDesc* __restrict__ probs, ProbState* __restrict__ st,
                                                   const uint32_t* __restrict__ rowCnt,
-                                                  uint32_t* __restrict__ rowStart)
+                                                  uint32_t* __restrict__ rowPos, uint32_t* __restrict__ perm,
+                                                  uint32_t* __restrict__ sliceWidth, uint32_t* __restrict__ sliceBase)
 {
+    __shared__ uint32_t hist[SORT_KEYS];         // indexed by SORT_KEYS-1-key: ascending index = descending count
     __shared__ uint32_t wsum[16];
     __shared__ uint32_t carry_s;
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nt = blockDim.x, nw = nt >> 6;
     const int L = st[b].L;
     const int64_t lo = probs[b].liveOff;
+    for (int t = tid; t < SORT_KEYS; t += nt) hist[t] = 0;
+    __syncthreads();
+    for (int k = tid; k < L; k += nt) atomicAdd(&hist[SORT_KEYS - 1 - min(rowCnt[lo + k], (uint32_t)(SORT_KEYS - 1))], 1u);
+    __syncthreads();
+    {   // exclusive scan of hist (8 consecutive bins per thread)
+        constexpr int PER = SORT_KEYS / 1024;
+        uint32_t loc[PER]; uint32_t sum = 0;
+        for (int t = 0; t < PER; ++t) { loc[t] = hist[tid * PER + t]; sum += loc[t]; }
+        uint32_t inc = sum;
+        for (int off = 1; off < WAVE; off <<= 1) { const uint32_t t = __shfl_up(inc, off); if (lane >= off) inc += t; }
+        if (lane == WAVE - 1) wsum[w] = inc;
+        __syncthreads();
+        uint32_t wbase = 0;
+        for (int t = 0; t < w; ++t) wbase += wsum[t];
+        uint32_t run = wbase + inc - sum;
+        for (int t = 0; t < PER; ++t) { hist[tid * PER + t] = run; run += loc[t]; }
+    }
+    __syncthreads();
+    for (int k = tid; k < L; k += nt) {
+        const uint32_t pos = atomicAdd(&hist[SORT_KEYS - 1 - min(rowCnt[lo + k], (uint32_t)(SORT_KEYS - 1))], 1u);
+        rowPos[lo + k] = pos; perm[lo + pos] = (uint32_t)k;
+    }
+    __syncthreads();       // block-scope: perm visible to the whole workgroup
+    const int nsl = (L + 63) >> 6;
     if (tid == 0) carry_s = 0;
     __syncthreads();
-    for (int k0 = 0; k0 < L; k0 += blockDim.x) {
-        const int k = k0 + tid;
-        const uint32_t v = (k < L) ? rowCnt[lo + k] : 0u;
-        uint32_t inc = v;                                  // inclusive wave scan
+    for (int s0 = 0; s0 < nsl; s0 += nt) {
+        const int s = s0 + tid;
+        uint32_t width = 0;
+        if (s < nsl) {
+            const int hi = min(L, (s << 6) + 64);
+            for (int p = s << 6; p < hi; ++p) width = max(width, rowCnt[lo + perm[lo + p]]);
+            sliceWidth[lo + s] = width;
+        }
+        const uint32_t v = width * 64u;
+        uint32_t inc = v;
         for (int off = 1; off < WAVE; off <<= 1) { const uint32_t t = __shfl_up(inc, off); if (lane >= off) inc += t; }
         if (lane == WAVE - 1) wsum[w] = inc;
         __syncthreads();
         uint32_t wbase = 0, tot = 0;
         for (int t = 0; t < nw; ++t) { if (t < w) wbase += wsum[t]; tot += wsum[t]; }
         const uint32_t carry = carry_s;
-        if (k < L) rowStart[lo + k] = carry + wbase + inc - v;
+        if (s < nsl) sliceBase[lo + s] = carry + wbase + inc - v;
         __syncthreads();
         if (tid == 0) carry_s = carry + tot;
         __syncthreads();
@@ -452,13 +477,114 @@ __global__ void __launch_bounds__(1024) k_rowscan(const ProbDesc* __restrict__ p
     if (tid == 0) st[b].nnzCap = carry_s;
 }
 
-// k_probscan: serial prefix of the per-problem candidate totals.
+// k_probscan: serial prefix of the per-problem slot totals.
 __global__ void k_probscan(int B, ProbState* __restrict__ st, BatchTotals* __restrict__ tot)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     int64_t acc = 0;
     for (int b = 0; b < B; ++b) { st[b].nnzOff = acc; acc += st[b].nnzCap; }
     tot->nnzTotal = acc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_fill: candidates -> values.  One wave per live row: it walks the row's mask words (uniform
+// loads), compacts the set bits into a 128-entry wave-private LDS queue and, whenever 64 candidates
+// are queued, evaluates them densely: x (recomputed bit-identically from the tables), sqrt/exp/cbrt,
+// fusion with the two single scores, the affinityeps filter, and the store into the row's SELL slot
+// column.  Finally the row's slot is padded to the slice width with inert entries.
+// ---------------------------------------------------------------------------------------------
+template <bool GRAV, typename IdxT>
+__global__ void __launch_bounds__(1024) k_fill(DevParams D, const ProbDesc* __restrict__ probs,
+                                               ProbState* __restrict__ st,
+                                               const BatchTotals* __restrict__ tot,
+                                               const int32_t* __restrict__ rowProb,
+                                               const double* __restrict__ tabPool,
+                                               const int32_t* __restrict__ li, const int32_t* __restrict__ lj,
+                                               const double* __restrict__ ls,
+                                               const double* __restrict__ lza, const double* __restrict__ lzb,
+                                               const uint32_t* __restrict__ rowCnt,
+                                               const unsigned long long* __restrict__ maskPool,
+                                               const uint32_t* __restrict__ rowPos,
+                                               const uint32_t* __restrict__ sliceWidth,
+                                               const uint32_t* __restrict__ sliceBase,
+                                               IdxT* __restrict__ cols, double* __restrict__ vals)
+{
+    __shared__ uint32_t s_q[16][128];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+    uint32_t* qbuf = s_q[w];
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const int R = tot->R;
+    for (int r = blockIdx.x * wpb + w; r < R; r += gridDim.x * wpb) {
+        const int b = rowProb[r];
+        const ProbDesc pd = probs[b];
+        const int L = st[b].L, k = r - st[b].rowBase;
+        const int64_t lo = pd.liveOff;
+        const int i = li[lo + k], j = lj[lo + k];
+        const double zi = lza[lo + k], zj = lzb[lo + k];
+        const double sk = ls[lo + k];
+        const double* gA = tabPool + pd.tabOff + (int64_t)i * pd.n1;
+        const double* gB = tabPool + pd.tabOff + (int64_t)pd.n1 * pd.n1 + (int64_t)j * pd.n2;
+        const uint32_t pos = rowPos[lo + k];
+        const uint32_t slot = pos & 63u, sl = pos >> 6;
+        const int64_t base = st[b].nnzOff + sliceBase[lo + sl] + slot;     // + e*64
+        const uint32_t width = sliceWidth[lo + sl];
+        const int W = (L + 63) >> 6;
+        const unsigned long long* mrow = maskPool + st[b].maskOff + (int64_t)k * W;
+        uint32_t queued = 0, done = 0, upper = 0;
+        unsigned long long mreg = 0ull;            // lane l holds mask word (wi0 + l) of the current block of 64 words
+        for (int wi = 0; wi <= W; ++wi) {
+            const bool last = (wi == W);
+            if (!last) {
+                if ((wi & 63) == 0) mreg = (wi + lane < W) ? mrow[wi + lane] : 0ull;
+                const unsigned int mlo = __builtin_amdgcn_readlane((unsigned int)mreg, wi & 63);
+                const unsigned int mhi = __builtin_amdgcn_readlane((unsigned int)(mreg >> 32), wi & 63);
+                const unsigned long long m = ((unsigned long long)mhi << 32) | mlo;
+                if (m != 0ull) {
+                    if ((m >> lane) & 1ull) qbuf[queued + __popcll(m & lt)] = (uint32_t)(wi * 64 + lane);
+                    queued += __popcll(m);
+                }
+            }
+            while (queued >= 64u || (last && queued > 0u)) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const uint32_t take = queued < 64u ? queued : 64u;
+                if ((uint32_t)lane < take) {
+                    const uint32_t q = qbuf[lane];
+                    const double a = gA[li[lo + q]], bb = gB[lj[lo + q]];
+                    double c;
+                    if (GRAV) {
+                        const double ch = fabs(a - bb);
+                        const double hm = a > bb ? a : bb;
+                        double cv = fabs((zi - lza[lo + q]) - (zj - lzb[lo + q])) - D.sin_unc * hm;
+                        if (cv < 0.0) cv = 0.0;
+                        c = sqrt(ch * ch + cv * cv);
+                    } else {
+                        c = fabs(a - bb);
+                    }
+                    const double sa = exp(((-0.5 * c) * c) / D.sig2);
+                    const double v = fuse_pair(D, sa, sk, ls[lo + (int64_t)q]);
+                    const bool keep = v > D.p.affinityeps;
+                    // an entry at or below affinityeps belongs neither to M nor to C: inert slot
+                    const int64_t p = base + (int64_t)(done + lane) * 64;
+                    cols[p] = keep ? (IdxT)q : (IdxT)((uint32_t)k | IdxTraits<IdxT>::CZ);
+                    vals[p] = keep ? v : 0.0;
+                    upper += (keep && (int)q > k) ? 1u : 0u;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (queued > 64u) { const uint32_t mv = qbuf[64 + lane]; qbuf[lane] = mv; }   // shift the overflow half down
+                queued -= take; done += take;
+            }
+        }
+        for (uint32_t e = done + lane; e < width; e += WAVE) {          // pad the slot column
+            const int64_t p = base + (int64_t)e * 64;
+            cols[p] = (IdxT)((uint32_t)k | IdxTraits<IdxT>::CZ); vals[p] = 0.0;
+        }
+        for (int off = 32; off > 0; off >>= 1) upper += __shfl_xor(upper, off);
+        if (lane == 0 && upper) atomicAdd(&st[b].nnzUpper, (unsigned long long)upper);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -473,50 +599,74 @@ struct SolveOut {           // device pointers of the batch outputs
     double*  uOut;          // row pool: final u over live associations
 };
 
-// Sum of (a, b) over the block, identical in every thread; fixed reduction tree.
-__device__ __forceinline__ void block_sum2(double& a, double& b, double* red, int tid, int nw)
+// Sum of (a, b) over the block, identical in every thread; fixed reduction tree.  `red` holds two
+// ping-pong scratch areas of 32 doubles (`par` flips on every call), so consecutive reductions need a
+// single barrier each: a buffer is rewritten only after the barrier of the following reduction.
+__device__ __forceinline__ void block_sum2(double& a, double& b, double* red, int& par, int tid, int nw)
 {
     for (int off = 32; off > 0; off >>= 1) { a += __shfl_xor(a, off); b += __shfl_xor(b, off); }
-    if ((tid & 63) == 0) { red[2 * (tid >> 6)] = a; red[2 * (tid >> 6) + 1] = b; }
+    double* rr = red + 32 * par;
+    par ^= 1;
+    if ((tid & 63) == 0) { rr[2 * (tid >> 6)] = a; rr[2 * (tid >> 6) + 1] = b; }
     __syncthreads();
     double ra = 0.0, rb = 0.0;
-    for (int i = 0; i < nw; ++i) { ra += red[2 * i]; rb += red[2 * i + 1]; }
-    __syncthreads();
+    for (int i = 0; i < nw; ++i) { ra += rr[2 * i]; rb += rr[2 * i + 1]; }
     a = ra; b = rb;
 }
 
-template <typename IdxT> struct IdxTraits;
-template <> struct IdxTraits<uint16_t> { static constexpr uint32_t CZ = 0x8000u; static constexpr uint32_t MASK = 0x7fffu; };
-template <> struct IdxTraits<uint32_t> { static constexpr uint32_t CZ = 0x80000000u; static constexpr uint32_t MASK = 0x7fffffffu; };
-
-// (M_off u)_r and (C_off u)_r for every row; T lanes cooperate on a row (T = power of two).
-template <typename IdxT>
-__device__ __forceinline__ void spmv_rows(const double* u, int L, const uint32_t* __restrict__ rowStart,
-                                          const uint32_t* __restrict__ rowLen,
+// (M_off u)_r and (C_off u)_r for every row from the sorted SELL-64 layout: a wave owns a slice (lane
+// = row slot) and walks the entry index e with stride 64.  The walk is software-pipelined in groups
+// of G steps: while group g is consumed (LDS gathers of u + FMAs) the 2G global loads of group g+1
+// are already in flight.  Padding entries are inert (value 0, C-flag), so there are no predicates.
+template <typename IdxT, int G>
+__device__ __forceinline__ void spmv_sell(const double* u, int L, const uint32_t* __restrict__ perm,
+                                          const uint32_t* __restrict__ sliceWidth, const uint32_t* __restrict__ sliceBase,
                                           const IdxT* __restrict__ cols, const double* __restrict__ vals,
-                                          double* __restrict__ Mu, double* __restrict__ Cu,
-                                          int T, int tid, int nt)
+                                          double* Mu, double* Cu, int tid, int nt)
 {
-    const int ng = nt / T, g = tid / T, lg = tid & (T - 1);
-    for (int r = g; r < L; r += ng) {
-        const uint32_t s = rowStart[r], n = rowLen[r];
+    const int lane = tid & 63, w = tid >> 6, nw = nt >> 6;
+    const int nsl = (L + 63) >> 6;
+    for (int s = w; s < nsl; s += nw) {
+        const int pos = (s << 6) + lane;
+        const bool valid = pos < L;
+        const uint32_t row = valid ? perm[pos] : 0u;
+        const uint32_t width = sliceWidth[s];
+        const IdxT* cp = cols + sliceBase[s] + lane;
+        const double* vp = vals + sliceBase[s] + lane;
+        const uint32_t ngroups = (width + G - 1) / G;
         double am = 0.0, ac = 0.0;
-        for (uint32_t e = lg; e < n; e += T) {
-            const uint32_t c = cols[s + e];
-            const double v = vals[s + e];
-            const double uq = u[c & IdxTraits<IdxT>::MASK];
-            am = fma(v, uq, am);
-            ac += (c & IdxTraits<IdxT>::CZ) ? 0.0 : uq;
+        uint32_t cA[G], cB[G]; double vA[G], vB[G];
+#define SELL_ISSUE(e0, C_, V_)                                                         \
+        _Pragma("unroll") for (int t = 0; t < G; ++t) {                                \
+            const bool a_ = valid && ((e0) + t < width);                               \
+            C_[t] = a_ ? (uint32_t)cp[((e0) + t) * 64u] : IdxTraits<IdxT>::CZ;         \
+            V_[t] = a_ ? vp[((e0) + t) * 64u] : 0.0;                                   \
         }
-        for (int off = T >> 1; off > 0; off >>= 1) { am += __shfl_xor(am, off); ac += __shfl_xor(ac, off); }
-        if (lg == 0) { Mu[r] = am; Cu[r] = ac; }
+#define SELL_CONSUME(C_, V_)                                                           \
+        _Pragma("unroll") for (int t = 0; t < G; ++t) {                                \
+            const double uq_ = u[C_[t] & IdxTraits<IdxT>::MASK];                       \
+            am = fma(V_[t], uq_, am);                                                  \
+            ac += (C_[t] & IdxTraits<IdxT>::CZ) ? 0.0 : uq_;                           \
+        }
+        if (ngroups > 0) { SELL_ISSUE(0u, cA, vA) }
+        for (uint32_t g = 0; g < ngroups; g += 2) {
+            if (g + 1 < ngroups) { SELL_ISSUE((g + 1) * G, cB, vB) }
+            SELL_CONSUME(cA, vA)
+            if (g + 1 < ngroups) {
+                if (g + 2 < ngroups) { SELL_ISSUE((g + 2) * G, cA, vA) }
+                SELL_CONSUME(cB, vB)
+            }
+        }
+#undef SELL_ISSUE
+#undef SELL_CONSUME
+        if (valid) { Mu[row] = am; Cu[row] = ac; }
     }
 }
 
 // One-sided Jacobi (Hestenes) SVD of a dxd matrix (d = 2 or 3), then the proper rotation
 // R = u1 v1' + u2 v2' + (u1 x u2)(v1 x v2)'   — equal to the reference's  U Vh  with the last
 // row of Vh negated when det = -1 ([REF roman/align/object_registration.py:121-126]).
-__device__ inline void kabsch_rotation(const double* H, int d, double* R)
+__device__ __noinline__ void kabsch_rotation(const double* H, int d, double* R)
 {
     double G[9], V[9];
     for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) {
@@ -570,7 +720,7 @@ __device__ inline void kabsch_rotation(const double* H, int d, double* R)
 }
 
 // T (row-major (d+1)x(d+1) in the leading entries of 16 doubles) from centred sums.
-__device__ inline void write_pose(double* T, int d, const double* H, const double* m1, const double* m2)
+__device__ __noinline__ void write_pose(double* T, int d, const double* H, const double* m1, const double* m2)
 {
     double R[9];
     kabsch_rotation(H, d, R);
@@ -588,7 +738,7 @@ __device__ inline void write_pose(double* T, int d, const double* H, const doubl
 // over the FULL association index space (dead associations have u == 0).  Single thread; only
 // runs when the k-th largest value is tied or fewer than omega entries are positive.
 __device__ inline bool hp_less(double va, int ia, double vb, int ib) { return va < vb || (va == vb && ia < ib); }
-__device__ void heap_select_serial(const double* u, const int32_t* lp, int L, int nA, int k,
+__device__ __noinline__ void heap_select_serial(const double* u, const int32_t* lp, int L, int nA, int k,
                                    double* hv, int32_t* hi /* capacity k */, int32_t* outNodesOrig)
 {
     int sz = 0, nl = 0;
@@ -625,32 +775,45 @@ __device__ void heap_select_serial(const double* u, const int32_t* lp, int L, in
 /*
  * solve_one: CLIPPER findDenseClique on one problem, by one workgroup.
  * Mirrors oracle_solve() step for step (see there for the restated upstream algorithm):
- * u and u_new live in LDS when they fit (ULDS), the per-row vectors Mu, Cu, Mu_new, Cu_new in
- * the L2-resident row pools; gradF is recombined on the fly from (u, Mu, Cu, d, sum u).
+ * gradF is never stored: it is recombined on the fly from (u, Mu, Cu, d, sum u), bitwise the same
+ * value the oracle keeps in its gradF vector.
  */
-template <typename IdxT, bool ULDS>
+// MODE 2: u, u_new, Mu, Cu, Mu_new, Cu_new and the diagonal all live in LDS (7 * Lcap doubles);
+// MODE 1: only u and u_new (the gathered vectors) do, the row vectors sit in the L2-resident pools;
+// MODE 0: nothing fits, everything is in the pools.
+template <typename IdxT, int MODE>
 __device__ void solve_one(const DevParams& D, int b, const ProbDesc& pd, ProbState* st,
                           const double* __restrict__ feats, const int32_t* __restrict__ assoc,
                           const int32_t* __restrict__ lp, const double* __restrict__ ls,
-                          const uint32_t* __restrict__ rowStart, const uint32_t* __restrict__ rowLen,
+                          const uint32_t* __restrict__ permPool, const uint32_t* __restrict__ sliceWidthPool,
+                          const uint32_t* __restrict__ sliceBasePool,
                           const IdxT* __restrict__ colsPool, const double* __restrict__ valsPool,
                           double* __restrict__ vMu, double* __restrict__ vCu,
                           double* __restrict__ vMun, double* __restrict__ vCun,
                           double* __restrict__ gU, double* __restrict__ gUn,
                           const double* __restrict__ u0, const SolveOut& O,
-                          double* su, double* sun, double* red, int* sint, int T)
+                          double* sv /* LDS vectors */, int Lcap, double* red, int* sint)
 {
     const roman_params_t& P = D.p;
     const int tid = threadIdx.x, nt = blockDim.x, nw = nt >> 6;
     const int L = st[b].L, rb = st[b].rowBase;
     const int64_t lo = pd.liveOff;
-    const uint32_t* rs = rowStart + lo; const uint32_t* rl = rowLen + lo;
+    const uint32_t* perm = permPool + lo; const uint32_t* swid = sliceWidthPool + lo; const uint32_t* sbase = sliceBasePool + lo;
     const IdxT* cols = colsPool + st[b].nnzOff; const double* vals = valsPool + st[b].nnzOff;
+    double* u = (MODE >= 1) ? sv : gU + rb;
+    double* un = (MODE >= 1) ? sv + Lcap : gUn + rb;
+    double* Mu = (MODE == 2) ? sv + 2 * Lcap : vMu + rb;
+    double* Cu = (MODE == 2) ? sv + 3 * Lcap : vCu + rb;
+    double* Mun = (MODE == 2) ? sv + 4 * Lcap : vMun + rb;
+    double* Cun = (MODE == 2) ? sv + 5 * Lcap : vCun + rb;
     const double* sd = ls + lo;                       // diagonal M_pp = single score
-    double* Mu = vMu + rb; double* Cu = vCu + rb; double* Mun = vMun + rb; double* Cun = vCun + rb;
-    double* u = ULDS ? su : gU + rb;
-    double* un = ULDS ? sun : gUn + rb;
+    if (MODE == 2) {
+        double* sdl = sv + 6 * Lcap;
+        for (int p = tid; p < L; p += nt) sdl[p] = ls[lo + p];
+        sd = sdl;
+    }
     const int dim = P.point_dim;
+    int par = 0;
 
     int status = ROMAN_ST_OK;
     roman_stats_t S;
@@ -665,7 +828,7 @@ __device__ void solve_one(const DevParams& D, int b, const ProbDesc& pd, ProbSta
         for (int p = tid; p < L; p += nt) u[p] = u0 ? u0[lo + lp[lo + p]] : 1.0;
         __syncthreads();
         if (P.rescale_u0) {
-            spmv_rows<IdxT>(u, L, rs, rl, cols, vals, Mu, Cu, T, tid, nt); ++S.n_pass;
+            spmv_sell<IdxT, 8>(u, L, perm, swid, sbase, cols, vals, Mu, Cu, tid, nt); ++S.n_pass;
             __syncthreads();
             for (int p = tid; p < L; p += nt) u[p] = Mu[p] + sd[p] * u[p];
             __syncthreads();
@@ -673,22 +836,22 @@ __device__ void solve_one(const DevParams& D, int b, const ProbDesc& pd, ProbSta
         {
             double ss = 0.0, dummy = 0.0;
             for (int p = tid; p < L; p += nt) ss += u[p] * u[p];
-            block_sum2(ss, dummy, red, tid, nw);
+            block_sum2(ss, dummy, red, par, tid, nw);
             const double nr = sqrt(ss);
             if (nr > 0.0) for (int p = tid; p < L; p += nt) u[p] /= nr;
             __syncthreads();
         }
-        spmv_rows<IdxT>(u, L, rs, rl, cols, vals, Mu, Cu, T, tid, nt); ++S.n_pass;
+        spmv_sell<IdxT, 8>(u, L, perm, swid, sbase, cols, vals, Mu, Cu, tid, nt); ++S.n_pass;
         double usum = 0.0;
-        { double dummy = 0.0; for (int p = tid; p < L; p += nt) usum += u[p]; block_sum2(usum, dummy, red, tid, nw); }
-        // block_sum2's barriers also order the Mu/Cu stores of spmv_rows before the reads below
+        { double dummy = 0.0; for (int p = tid; p < L; p += nt) usum += u[p]; block_sum2(usum, dummy, red, par, tid, nw); }
+        // the barrier inside block_sum2 also orders the Mu/Cu stores of spmv_sell before the reads below
         {   // initial d: signed mean of (Mu)_p / Cbu_p over the active set
             double acc = 0.0, cnt = 0.0;
             for (int p = tid; p < L; p += nt) {
                 const double up = u[p], Cbu = (usum - Cu[p]) - up;
                 if (Cbu > P.eps && up > P.eps) { acc += (Mu[p] + sd[p] * up) / Cbu; cnt += 1.0; }
             }
-            block_sum2(acc, cnt, red, tid, nw);
+            block_sum2(acc, cnt, red, par, tid, nw);
             d = (cnt > 0.0) ? acc / cnt : 0.0;
         }
         // ---- projected gradient ascent with homotopy on d ---------------------------------------
@@ -701,7 +864,7 @@ __device__ void solve_one(const DevParams& D, int b, const ProbDesc& pd, ProbSta
                     const double g = (((sd[p] + d) * up - d * usum) + Mu[p]) + Cu[p] * d;
                     f += up * g;
                 }
-                block_sum2(f, dummy, red, tid, nw);
+                block_sum2(f, dummy, red, par, tid, nw);
                 F = f;
             }
             for (int j = 0; j < P.maxiniters; ++j) {
@@ -715,7 +878,7 @@ __device__ void solve_one(const DevParams& D, int b, const ProbDesc& pd, ProbSta
                         t = t > 0.0 ? t : 0.0;
                         un[p] = t; ss += t * t;
                     }
-                    block_sum2(ss, dummy, red, tid, nw);
+                    block_sum2(ss, dummy, red, par, tid, nw);
                     const double nr = sqrt(ss);
                     double s1 = 0.0, dd = 0.0;
                     for (int p = tid; p < L; p += nt) {
@@ -724,9 +887,9 @@ __device__ void solve_one(const DevParams& D, int b, const ProbDesc& pd, ProbSta
                         s1 += t;
                         const double df = t - u[p]; dd += df * df;
                     }
-                    block_sum2(s1, dd, red, tid, nw);
+                    block_sum2(s1, dd, red, par, tid, nw);
                     unsum = s1; du2 = dd;
-                    spmv_rows<IdxT>(un, L, rs, rl, cols, vals, Mun, Cun, T, tid, nt); ++S.n_pass; ++S.ls_trials;
+                    spmv_sell<IdxT, 8>(un, L, perm, swid, sbase, cols, vals, Mun, Cun, tid, nt); ++S.n_pass; ++S.ls_trials;
                     __syncthreads();
                     double f = 0.0;
                     for (int p = tid; p < L; p += nt) {
@@ -734,7 +897,7 @@ __device__ void solve_one(const DevParams& D, int b, const ProbDesc& pd, ProbSta
                         const double g = (((sd[p] + d) * up - d * unsum) + Mun[p]) + Cun[p] * d;
                         f += up * g;
                     }
-                    block_sum2(f, dummy, red, tid, nw);
+                    block_sum2(f, dummy, red, par, tid, nw);
                     Fnew = f;
                     deltaF = Fnew - F;
                     if (deltaF < -P.eps) alpha *= P.beta; else break;
@@ -750,7 +913,7 @@ __device__ void solve_one(const DevParams& D, int b, const ProbDesc& pd, ProbSta
                 const double up = u[p], Cbu = (usum - Cu[p]) - up;
                 if (Cbu > P.eps && up > P.eps) { acc += fabs((Mu[p] + sd[p] * up) / Cbu); cnt += 1.0; }
             }
-            block_sum2(acc, cnt, red, tid, nw);
+            block_sum2(acc, cnt, red, par, tid, nw);
             if (cnt > 0.0) d += acc / cnt; else break;
         }
         if (i >= P.maxoliters) status |= ROMAN_ST_MAXITER;
@@ -785,10 +948,10 @@ __device__ void solve_one(const DevParams& D, int b, const ProbDesc& pd, ProbSta
                     int rank = 0;
                     for (int f2 = 0; f2 < Pn; ++f2) { const double vf = pv[f2]; rank += (vf > ve) || (vf == ve && pidx[f2] > ie); }
                     if (rank < omega) nodesLive[rank] = ie;
-                    if (rank == omega - 1) { red[40] = ve; }
+                    if (rank == omega - 1) { red[64] = ve; }
                 }
                 __syncthreads();
-                const double vstar = red[40];
+                const double vstar = red[64];
                 int tie = 0;
                 for (int e = tid; e < Pn; e += nt) {
                     if (pv[e] == vstar) {
@@ -841,7 +1004,7 @@ __device__ void solve_one(const DevParams& D, int b, const ProbDesc& pd, ProbSta
             const double* a = feats + (pd.off1 + i) * D.F; const double* bb = feats + (pd.off2 + j) * D.F;
             for (int c = 0; c < dim; ++c) { m1[c] += a[c]; m2[c] += bb[c]; }
         }
-        block_sum2(m1[0], m1[1], red, tid, nw); block_sum2(m1[2], m2[0], red, tid, nw); block_sum2(m2[1], m2[2], red, tid, nw);
+        block_sum2(m1[0], m1[1], red, par, tid, nw); block_sum2(m1[2], m2[0], red, par, tid, nw); block_sum2(m2[1], m2[2], red, par, tid, nw);
         for (int c = 0; c < 3; ++c) { m1[c] /= (double)nsel; m2[c] /= (double)nsel; }
         double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
         for (int t = tid; t < nsel; t += nt) {
@@ -853,8 +1016,8 @@ __device__ void solve_one(const DevParams& D, int b, const ProbDesc& pd, ProbSta
             for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) H[r * 3 + c] += q1[r] * q2[c];
         }
         double z = 0.0;
-        block_sum2(H[0], H[1], red, tid, nw); block_sum2(H[2], H[3], red, tid, nw); block_sum2(H[4], H[5], red, tid, nw);
-        block_sum2(H[6], H[7], red, tid, nw); block_sum2(H[8], z, red, tid, nw);
+        block_sum2(H[0], H[1], red, par, tid, nw); block_sum2(H[2], H[3], red, par, tid, nw); block_sum2(H[4], H[5], red, par, tid, nw);
+        block_sum2(H[6], H[7], red, par, tid, nw); block_sum2(H[8], z, red, par, tid, nw);
         if (tid == 0) write_pose(Tp, dim, H, m1, m2);
         have_pose = true;
     } else {
@@ -870,24 +1033,27 @@ __device__ void solve_one(const DevParams& D, int b, const ProbDesc& pd, ProbSta
     __syncthreads();
 }
 
-template <typename IdxT>
+template <typename IdxT, int MODE>
 __global__ void __launch_bounds__(1024) k_solve(DevParams D, int B, const ProbDesc* __restrict__ probs,
                                                 ProbState* __restrict__ st,
                                                 const double* __restrict__ feats, const int32_t* __restrict__ assoc,
                                                 const int32_t* __restrict__ lp, const double* __restrict__ ls,
-                                                const uint32_t* __restrict__ rowStart, const uint32_t* __restrict__ rowLen,
+                                                const uint32_t* __restrict__ perm, const uint32_t* __restrict__ sliceWidth,
+                                                const uint32_t* __restrict__ sliceBase,
                                                 const IdxT* __restrict__ cols, const double* __restrict__ vals,
                                                 double* __restrict__ vMu, double* __restrict__ vCu,
                                                 double* __restrict__ vMun, double* __restrict__ vCun,
                                                 double* __restrict__ gU, double* __restrict__ gUn,
                                                 const double* __restrict__ u0, SolveOut O,
-                                                int* __restrict__ queue, int Lcap, int T)
+                                                int* __restrict__ queue, int Lcap)
 {
+    // LDS: [MODE 2: 7 | MODE 1: 2 | MODE 0: 0] vectors of Lcap doubles, 72 doubles of reduction
+    // scratch (2 x 32 ping-pong + 8), 4 ints
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    double* su = reinterpret_cast<double*>(smem);
-    double* sun = su + Lcap;
-    double* red = sun + Lcap;                 // 48 doubles
-    int* sint = reinterpret_cast<int*>(red + 48);   // 4 ints
+    constexpr int NVEC = (MODE == 2) ? 7 : (MODE == 1 ? 2 : 0);
+    double* sv = reinterpret_cast<double*>(smem);
+    double* red = sv + (size_t)NVEC * Lcap;
+    int* sint = reinterpret_cast<int*>(red + 72);
     for (;;) {
         if (threadIdx.x == 0) sint[2] = atomicAdd(queue, 1);
         __syncthreads();
@@ -895,12 +1061,12 @@ __global__ void __launch_bounds__(1024) k_solve(DevParams D, int B, const ProbDe
         __syncthreads();
         if (b >= B) break;
         const ProbDesc pd = probs[b];
-        if (st[b].L <= Lcap)
-            solve_one<IdxT, true>(D, b, pd, st, feats, assoc, lp, ls, rowStart, rowLen, cols, vals,
-                                  vMu, vCu, vMun, vCun, gU, gUn, u0, O, su, sun, red, sint, T);
+        if (MODE > 0 && st[b].L <= Lcap)
+            solve_one<IdxT, MODE>(D, b, pd, st, feats, assoc, lp, ls, perm, sliceWidth, sliceBase, cols, vals,
+                                  vMu, vCu, vMun, vCun, gU, gUn, u0, O, sv, Lcap, red, sint);
         else
-            solve_one<IdxT, false>(D, b, pd, st, feats, assoc, lp, ls, rowStart, rowLen, cols, vals,
-                                   vMu, vCu, vMun, vCun, gU, gUn, u0, O, su, sun, red, sint, T);
+            solve_one<IdxT, 0>(D, b, pd, st, feats, assoc, lp, ls, perm, sliceWidth, sliceBase, cols, vals,
+                               vMu, vCu, vMun, vCun, gU, gUn, u0, O, sv, Lcap, red, sint);
     }
 }
 

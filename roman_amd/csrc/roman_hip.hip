@@ -49,7 +49,8 @@ struct roman_ctx {
     DevBuf probs, state, totals, queue;
     DevBuf cosPool, normPool, tabPool, sTmp;
     DevBuf lp, li, lj, ls, lza, lzb;
-    DevBuf rowCnt, rowStart, rowLen, vMu, vCu, vMun, vCun, gU, gUn, uOut, nodesOrig, nSel;
+    DevBuf rowCnt, rowPos, perm, sliceWidth, sliceBase, rowProb, maskPool;
+    DevBuf vMu, vCu, vMun, vCun, gU, gUn, uOut, nodesOrig, nSel;
     DevBuf cols, vals;
     // staging for the host-pointer entry points
     DevBuf hFeats, hAssoc, hU0, oAssoc, oN, oT, oStatus, oStats, hAux1, hAux2, hAux3;
@@ -192,7 +193,8 @@ int stage_score(roman_ctx* c, const DevParams& D, const BatchIn& in, std::vector
     HIPCHK(c, c->sTmp.ensure(sizeof(double) * nA1));
     HIPCHK(c, c->lp.ensure(sizeof(int32_t) * nA1)); HIPCHK(c, c->li.ensure(sizeof(int32_t) * nA1)); HIPCHK(c, c->lj.ensure(sizeof(int32_t) * nA1));
     HIPCHK(c, c->ls.ensure(sizeof(double) * nA1)); HIPCHK(c, c->lza.ensure(sizeof(double) * nA1)); HIPCHK(c, c->lzb.ensure(sizeof(double) * nA1));
-    HIPCHK(c, c->rowCnt.ensure(sizeof(uint32_t) * nA1)); HIPCHK(c, c->rowStart.ensure(sizeof(uint32_t) * nA1)); HIPCHK(c, c->rowLen.ensure(sizeof(uint32_t) * nA1));
+    HIPCHK(c, c->rowCnt.ensure(sizeof(uint32_t) * nA1)); HIPCHK(c, c->rowPos.ensure(sizeof(uint32_t) * nA1)); HIPCHK(c, c->perm.ensure(sizeof(uint32_t) * nA1));
+    HIPCHK(c, c->sliceWidth.ensure(sizeof(uint32_t) * nA1)); HIPCHK(c, c->sliceBase.ensure(sizeof(uint32_t) * nA1)); HIPCHK(c, c->rowProb.ensure(sizeof(int32_t) * nA1));
 
     HIPCHK(c, hipMemcpyAsync(c->probs.p, hd.data(), sizeof(ProbDesc) * (size_t)B, hipMemcpyHostToDevice, c->stream));
     const ProbDesc* dP = c->probs.as<ProbDesc>();
@@ -210,9 +212,16 @@ int stage_score(roman_ctx* c, const DevParams& D, const BatchIn& in, std::vector
     hipLaunchKernelGGL(k_live, dim3(B), dim3(1024), 0, c->stream, D, dP, dS, in.feats, in.assoc, c->cosPool.as<double>(), c->sTmp.as<double>(),
                        c->lp.as<int32_t>(), c->li.as<int32_t>(), c->lj.as<int32_t>(), c->ls.as<double>(), c->lza.as<double>(), c->lzb.as<double>());
     hipLaunchKernelGGL(k_rowbase, dim3(1), dim3(64), 0, c->stream, B, dS, dT);
+    hipLaunchKernelGGL(k_rowmap, dim3(B), dim3(256), 0, c->stream, dS, c->rowProb.as<int32_t>());
+    // read-back #1 (24 bytes): live totals -> size of the candidate bit matrices, index width
+    HIPCHK(c, hipMemcpyAsync(c->pinnedTotals, dT, sizeof(BatchTotals), hipMemcpyDeviceToHost, c->stream));
     t0.stop();
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    BatchTotals tot = *c->pinnedTotals;
+    *idx16 = tot.maxL <= 32767;        // column indices are LIVE indices; bit 15 is the C==0 flag
+    HIPCHK(c, c->maskPool.ensure(sizeof(unsigned long long) * (size_t)std::max<int64_t>(tot.maskWords, 1)));
 
-    // per-wave LDS slice for the two table rows of the pair kernels
+    // per-wave LDS slice for the two table rows of the pair-test kernel
     const int ldsPerWave = ((2 * std::max(maxN, 1) + 1) & ~1) + 2;
     int wpb = 16;
     while (wpb > 1 && (size_t)wpb * ldsPerWave * sizeof(double) > c->lds_max) wpb >>= 1;
@@ -221,42 +230,39 @@ int stage_score(roman_ctx* c, const DevParams& D, const BatchIn& in, std::vector
     const size_t pairLds = (size_t)wpb * ldsPerWave * sizeof(double);
     const int blocksPerCU = std::max(1, std::min(2048 / (wpb * 64), (int)(c->lds_max / pairLds)));
     const int pairGrid = c->num_cu * blocksPerCU;
+
     StageTimer t1(c, ROMAN_STAGE_COUNT_PASS);
-    {
-        auto kc = D.gravity ? k_pairs<false, true, uint32_t> : k_pairs<false, false, uint32_t>;
+    if (tot.R > 0) {
+        auto kc = D.gravity ? k_count<true> : k_count<false>;
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kc), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pairLds));
-        hipLaunchKernelGGL(kc, dim3(pairGrid), dim3(wpb * 64), pairLds, c->stream, D, B, dP, dS, dT, c->tabPool.as<double>(),
-                           c->li.as<int32_t>(), c->lj.as<int32_t>(), c->ls.as<double>(), c->lza.as<double>(), c->lzb.as<double>(),
-                           c->rowCnt.as<uint32_t>(), c->rowStart.as<uint32_t>(), c->rowLen.as<uint32_t>(), (uint32_t*)nullptr, (double*)nullptr, ldsPerWave);
+        hipLaunchKernelGGL(kc, dim3(pairGrid), dim3(wpb * 64), pairLds, c->stream, D, dP, dS, dT, c->rowProb.as<int32_t>(), c->tabPool.as<double>(),
+                           c->li.as<int32_t>(), c->lj.as<int32_t>(), c->lza.as<double>(), c->lzb.as<double>(),
+                           c->rowCnt.as<uint32_t>(), c->maskPool.as<unsigned long long>(), ldsPerWave);
     }
-    hipLaunchKernelGGL(k_rowscan, dim3(B), dim3(1024), 0, c->stream, dP, dS, c->rowCnt.as<uint32_t>(), c->rowStart.as<uint32_t>());
+    hipLaunchKernelGGL(k_rowsort, dim3(B), dim3(1024), 0, c->stream, dP, dS, c->rowCnt.as<uint32_t>(), c->rowPos.as<uint32_t>(), c->perm.as<uint32_t>(),
+                       c->sliceWidth.as<uint32_t>(), c->sliceBase.as<uint32_t>());
     hipLaunchKernelGGL(k_probscan, dim3(1), dim3(64), 0, c->stream, B, dS, dT);
-    // the one read-back of the pipeline: how many candidate entries to allocate
+    // read-back #2: padded slot total -> size of the matrix arrays
     HIPCHK(c, hipMemcpyAsync(c->pinnedTotals, dT, sizeof(BatchTotals), hipMemcpyDeviceToHost, c->stream));
     t1.stop();
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    const BatchTotals tot = *c->pinnedTotals;
+    tot = *c->pinnedTotals;
     *totOut = tot;
-    *idx16 = tot.maxL <= 32767;        // column indices are LIVE indices; bit 15 is the C==0 flag
     const size_t nnz1 = (size_t)std::max<int64_t>(tot.nnzTotal, 1);
     HIPCHK(c, c->vals.ensure(sizeof(double) * nnz1));
     HIPCHK(c, c->cols.ensure((*idx16 ? sizeof(uint16_t) : sizeof(uint32_t)) * nnz1));
 
     StageTimer t2(c, ROMAN_STAGE_FILL);
     if (tot.R > 0) {
-        if (*idx16) {
-            auto kf = D.gravity ? k_pairs<true, true, uint16_t> : k_pairs<true, false, uint16_t>;
-            HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pairLds));
-            hipLaunchKernelGGL(kf, dim3(pairGrid), dim3(wpb * 64), pairLds, c->stream, D, B, dP, dS, dT, c->tabPool.as<double>(),
-                               c->li.as<int32_t>(), c->lj.as<int32_t>(), c->ls.as<double>(), c->lza.as<double>(), c->lzb.as<double>(),
-                               c->rowCnt.as<uint32_t>(), c->rowStart.as<uint32_t>(), c->rowLen.as<uint32_t>(), c->cols.as<uint16_t>(), c->vals.as<double>(), ldsPerWave);
-        } else {
-            auto kf = D.gravity ? k_pairs<true, true, uint32_t> : k_pairs<true, false, uint32_t>;
-            HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pairLds));
-            hipLaunchKernelGGL(kf, dim3(pairGrid), dim3(wpb * 64), pairLds, c->stream, D, B, dP, dS, dT, c->tabPool.as<double>(),
-                               c->li.as<int32_t>(), c->lj.as<int32_t>(), c->ls.as<double>(), c->lza.as<double>(), c->lzb.as<double>(),
-                               c->rowCnt.as<uint32_t>(), c->rowStart.as<uint32_t>(), c->rowLen.as<uint32_t>(), c->cols.as<uint32_t>(), c->vals.as<double>(), ldsPerWave);
-        }
+        const int fillGrid = c->num_cu * 2;
+#define ROMAN_LAUNCH_FILL(GRAV_, IDX)                                                                                          \
+        hipLaunchKernelGGL((k_fill<GRAV_, IDX>), dim3(fillGrid), dim3(1024), 0, c->stream, D, dP, dS, dT, c->rowProb.as<int32_t>(), c->tabPool.as<double>(), \
+                           c->li.as<int32_t>(), c->lj.as<int32_t>(), c->ls.as<double>(), c->lza.as<double>(), c->lzb.as<double>(),          \
+                           c->rowCnt.as<uint32_t>(), c->maskPool.as<unsigned long long>(), c->rowPos.as<uint32_t>(),                          \
+                           c->sliceWidth.as<uint32_t>(), c->sliceBase.as<uint32_t>(), c->cols.as<IDX>(), c->vals.as<double>())
+        if (*idx16) { if (D.gravity) ROMAN_LAUNCH_FILL(true, uint16_t); else ROMAN_LAUNCH_FILL(false, uint16_t); }
+        else        { if (D.gravity) ROMAN_LAUNCH_FILL(true, uint32_t); else ROMAN_LAUNCH_FILL(false, uint32_t); }
+#undef ROMAN_LAUNCH_FILL
     }
     t2.stop();
     HIPCHK(c, hipGetLastError());
@@ -276,19 +282,17 @@ int stage_solve(roman_ctx* c, const DevParams& D, int B, const double* feats, co
     HIPCHK(c, c->uOut.ensure(sizeof(double) * R1)); HIPCHK(c, c->nodesOrig.ensure(sizeof(int32_t) * R1));
     HIPCHK(c, c->nSel.ensure(sizeof(int32_t) * (size_t)B));
 
-    // LDS: u and u_new (Lcap doubles each) + 48 doubles + 4 ints
-    const size_t fixed = 48 * sizeof(double) + 4 * sizeof(int);
+    // LDS: NVEC vectors of Lcap doubles + 72 doubles of reduction scratch + 4 ints
+    const size_t fixed = 72 * sizeof(double) + 4 * sizeof(int);
     int Lcap = (std::max(tot.maxL, 64) + 1) & ~1;
-    const size_t maxLcap = (c->lds_max - fixed) / (2 * sizeof(double));
-    bool spill = false;
-    if ((size_t)Lcap > maxLcap) { Lcap = (int)(maxLcap & ~(size_t)1); spill = true; }
-    HIPCHK(c, c->gU.ensure(sizeof(double) * (spill ? R1 : 1))); HIPCHK(c, c->gUn.ensure(sizeof(double) * (spill ? R1 : 1)));
-    const size_t lds = 2 * sizeof(double) * (size_t)Lcap + fixed;
-    const int perCU = (c->lds_max / lds >= 2) ? 2 : 1;
-    const int nt = (perCU >= 2) ? 512 : 1024;
-    const int grid = std::max(1, std::min(B, c->num_cu * perCU));
-    const double avgRow = tot.R > 0 ? (double)tot.nnzTotal / (double)tot.R : 1.0;
-    int T = 4; while (T < 64 && (double)T * 2.0 < avgRow) T <<= 1;
+    int mode = 2;
+    if (7 * sizeof(double) * (size_t)Lcap + fixed > c->lds_max) mode = 1;
+    if (mode == 1 && 2 * sizeof(double) * (size_t)Lcap + fixed > c->lds_max) { mode = 0; Lcap = 0; }
+    const int nvec = mode == 2 ? 7 : (mode == 1 ? 2 : 0);
+    HIPCHK(c, c->gU.ensure(sizeof(double) * (mode == 0 ? R1 : 1))); HIPCHK(c, c->gUn.ensure(sizeof(double) * (mode == 0 ? R1 : 1)));
+    const size_t lds = (size_t)nvec * sizeof(double) * (size_t)Lcap + fixed;
+    const int nt = 1024;
+    const int grid = std::max(1, std::min(B, c->num_cu));
 
     HIPCHK(c, hipMemsetAsync(c->queue.p, 0, sizeof(int) * 4, c->stream));
     SolveOut O;
@@ -296,19 +300,17 @@ int stage_solve(roman_ctx* c, const DevParams& D, int B, const double* feats, co
     O.nodesOrig = c->nodesOrig.as<int32_t>(); O.nSel = c->nSel.as<int32_t>(); O.uOut = c->uOut.as<double>();
 
     StageTimer t3(c, ROMAN_STAGE_SOLVE);
-    if (idx16) {
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve<uint16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_solve<uint16_t>, dim3(grid), dim3(nt), lds, c->stream, D, B, c->probs.as<ProbDesc>(), c->state.as<ProbState>(), feats, assoc,
-                           c->lp.as<int32_t>(), c->ls.as<double>(), c->rowStart.as<uint32_t>(), c->rowLen.as<uint32_t>(), c->cols.as<uint16_t>(), c->vals.as<double>(),
-                           c->vMu.as<double>(), c->vCu.as<double>(), c->vMun.as<double>(), c->vCun.as<double>(), c->gU.as<double>(), c->gUn.as<double>(),
-                           u0, O, c->queue.as<int>(), Lcap, T);
-    } else {
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve<uint32_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_solve<uint32_t>, dim3(grid), dim3(nt), lds, c->stream, D, B, c->probs.as<ProbDesc>(), c->state.as<ProbState>(), feats, assoc,
-                           c->lp.as<int32_t>(), c->ls.as<double>(), c->rowStart.as<uint32_t>(), c->rowLen.as<uint32_t>(), c->cols.as<uint32_t>(), c->vals.as<double>(),
-                           c->vMu.as<double>(), c->vCu.as<double>(), c->vMun.as<double>(), c->vCun.as<double>(), c->gU.as<double>(), c->gUn.as<double>(),
-                           u0, O, c->queue.as<int>(), Lcap, T);
-    }
+#define ROMAN_LAUNCH_SOLVE(IDX, MODE_)                                                                                        \
+    do {                                                                                                                      \
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve<IDX, MODE_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((k_solve<IDX, MODE_>), dim3(grid), dim3(nt), lds, c->stream, D, B, c->probs.as<ProbDesc>(), c->state.as<ProbState>(), feats, assoc, \
+                           c->lp.as<int32_t>(), c->ls.as<double>(), c->perm.as<uint32_t>(), c->sliceWidth.as<uint32_t>(), c->sliceBase.as<uint32_t>(), c->cols.as<IDX>(), c->vals.as<double>(), \
+                           c->vMu.as<double>(), c->vCu.as<double>(), c->vMun.as<double>(), c->vCun.as<double>(), c->gU.as<double>(), c->gUn.as<double>(), \
+                           u0, O, c->queue.as<int>(), Lcap);                                                                   \
+    } while (0)
+    if (idx16) { if (mode == 2) ROMAN_LAUNCH_SOLVE(uint16_t, 2); else if (mode == 1) ROMAN_LAUNCH_SOLVE(uint16_t, 1); else ROMAN_LAUNCH_SOLVE(uint16_t, 0); }
+    else       { if (mode == 2) ROMAN_LAUNCH_SOLVE(uint32_t, 2); else if (mode == 1) ROMAN_LAUNCH_SOLVE(uint32_t, 1); else ROMAN_LAUNCH_SOLVE(uint32_t, 0); }
+#undef ROMAN_LAUNCH_SOLVE
     t3.stop();
     HIPCHK(c, hipGetLastError());
     return ROMAN_OK;
@@ -365,32 +367,70 @@ int solve_last(roman_ctx* c, const double* u0_host)
     return ROMAN_OK;
 }
 
-// download the CSR of the last single problem as full-symmetric host arrays over live indices
+// Host twin of k_rowsort: sorted SELL-64 geometry from the row lengths (stable descending sort).
+void sell_geometry(const std::vector<uint32_t>& cnt, int L, std::vector<uint32_t>& rowPos, std::vector<uint32_t>& perm,
+                   std::vector<uint32_t>& sliceWidth, std::vector<uint32_t>& sliceBase, uint64_t* total)
+{
+    perm.resize((size_t)std::max(L, 1)); rowPos.assign((size_t)std::max(L, 1), 0);
+    for (int k = 0; k < L; ++k) perm[(size_t)k] = (uint32_t)k;
+    std::stable_sort(perm.begin(), perm.begin() + L, [&](uint32_t a, uint32_t b) { return cnt[a] > cnt[b]; });
+    for (int p = 0; p < L; ++p) rowPos[perm[(size_t)p]] = (uint32_t)p;
+    const int nsl = (L + 63) / 64;
+    sliceWidth.assign((size_t)std::max(nsl, 1), 0); sliceBase.assign((size_t)std::max(nsl, 1), 0);
+    uint64_t acc = 0;
+    for (int sl = 0; sl < nsl; ++sl) {
+        uint32_t wmax = 0;
+        for (int p = sl * 64; p < std::min(L, sl * 64 + 64); ++p) wmax = std::max(wmax, cnt[perm[(size_t)p]]);
+        sliceWidth[(size_t)sl] = wmax; sliceBase[(size_t)sl] = (uint32_t)acc; acc += (uint64_t)wmax * 64u;
+    }
+    *total = acc;
+}
+
+// download the matrix of the last single problem and decode the sorted SELL-64 layout into per-row
+// lists over live indices: rs/rl index into cols/vals (row-contiguous on return); inert slots
+// (value 0 with the C flag and the row's own index) are dropped.
 int fetch_last_csr(const roman_ctx* cc, std::vector<uint32_t>& rs, std::vector<uint32_t>& rl, std::vector<uint32_t>& cols,
                    std::vector<double>& vals, std::vector<int32_t>& lp, std::vector<double>& ls)
 {
     roman_ctx* c = const_cast<roman_ctx*>(cc);
     const roman_ctx::Last& Lst = c->last;
     const int L = Lst.tot.R; const int64_t cap = Lst.tot.nnzTotal;
-    rs.assign((size_t)std::max(L, 1), 0); rl.assign((size_t)std::max(L, 1), 0); lp.assign((size_t)std::max(L, 1), 0); ls.assign((size_t)std::max(L, 1), 0.0);
-    cols.assign((size_t)std::max<int64_t>(cap, 1), 0); vals.assign((size_t)std::max<int64_t>(cap, 1), 0.0);
+    const size_t L1 = (size_t)std::max(L, 1), cap1 = (size_t)std::max<int64_t>(cap, 1);
+    std::vector<uint32_t> jcnt(L1, 0), jpos(L1, 0), jsw(L1, 0), jsb(L1, 0), jcols(cap1, 0); std::vector<double> jvals(cap1, 0.0);
+    rs.assign(L1, 0); rl.assign(L1, 0); lp.assign(L1, 0); ls.assign(L1, 0.0);
     HIPCHK(c, hipSetDevice(c->device));
     if (L > 0) {
-        HIPCHK(c, hipMemcpy(rs.data(), c->rowStart.p, sizeof(uint32_t) * (size_t)L, hipMemcpyDeviceToHost));
-        HIPCHK(c, hipMemcpy(rl.data(), c->rowLen.p, sizeof(uint32_t) * (size_t)L, hipMemcpyDeviceToHost));
+        const int nsl = (L + 63) / 64;
+        HIPCHK(c, hipMemcpy(jcnt.data(), c->rowCnt.p, sizeof(uint32_t) * (size_t)L, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(jpos.data(), c->rowPos.p, sizeof(uint32_t) * (size_t)L, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(jsw.data(), c->sliceWidth.p, sizeof(uint32_t) * (size_t)nsl, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(jsb.data(), c->sliceBase.p, sizeof(uint32_t) * (size_t)nsl, hipMemcpyDeviceToHost));
         HIPCHK(c, hipMemcpy(lp.data(), c->lp.p, sizeof(int32_t) * (size_t)L, hipMemcpyDeviceToHost));
         HIPCHK(c, hipMemcpy(ls.data(), c->ls.p, sizeof(double) * (size_t)L, hipMemcpyDeviceToHost));
     }
     if (cap > 0) {
-        HIPCHK(c, hipMemcpy(vals.data(), c->vals.p, sizeof(double) * (size_t)cap, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(jvals.data(), c->vals.p, sizeof(double) * (size_t)cap, hipMemcpyDeviceToHost));
         if (Lst.idx16) {
             std::vector<uint16_t> c16((size_t)cap);
             HIPCHK(c, hipMemcpy(c16.data(), c->cols.p, sizeof(uint16_t) * (size_t)cap, hipMemcpyDeviceToHost));
-            for (int64_t k = 0; k < cap; ++k) cols[(size_t)k] = (c16[(size_t)k] & 0x8000u) ? (0x80000000u | (c16[(size_t)k] & 0x7fffu)) : c16[(size_t)k];
+            for (int64_t k = 0; k < cap; ++k) jcols[(size_t)k] = (c16[(size_t)k] & 0x8000u) ? (0x80000000u | (c16[(size_t)k] & 0x7fffu)) : c16[(size_t)k];
         } else {
-            HIPCHK(c, hipMemcpy(cols.data(), c->cols.p, sizeof(uint32_t) * (size_t)cap, hipMemcpyDeviceToHost));
+            HIPCHK(c, hipMemcpy(jcols.data(), c->cols.p, sizeof(uint32_t) * (size_t)cap, hipMemcpyDeviceToHost));
         }
     }
+    cols.clear(); vals.clear();
+    for (int k = 0; k < L; ++k) {
+        const uint32_t pos = jpos[(size_t)k], sl = pos >> 6, slot = pos & 63u;
+        rs[(size_t)k] = (uint32_t)cols.size();
+        for (uint32_t e = 0; e < jcnt[(size_t)k]; ++e) {
+            const size_t p = (size_t)jsb[sl] + (size_t)e * 64 + slot;
+            const uint32_t cq = jcols[p]; const double v = jvals[p];
+            if (v == 0.0 && (cq & 0x80000000u) && (int)(cq & 0x7fffffffu) == k) continue;     // inert slot
+            cols.push_back(cq); vals.push_back(v);
+        }
+        rl[(size_t)k] = (uint32_t)cols.size() - rs[(size_t)k];
+    }
+    if (cols.empty()) { cols.push_back(0); vals.push_back(0.0); }
     return ROMAN_OK;
 }
 
@@ -453,7 +493,7 @@ int roman_ctx_destroy(roman_ctx_t* c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     DevBuf* all[] = {&c->probs, &c->state, &c->totals, &c->queue, &c->cosPool, &c->normPool, &c->tabPool, &c->sTmp, &c->lp, &c->li, &c->lj, &c->ls, &c->lza, &c->lzb,
-                     &c->rowCnt, &c->rowStart, &c->rowLen, &c->vMu, &c->vCu, &c->vMun, &c->vCun, &c->gU, &c->gUn, &c->uOut, &c->nodesOrig, &c->nSel, &c->cols, &c->vals,
+                     &c->rowCnt, &c->rowPos, &c->perm, &c->sliceWidth, &c->sliceBase, &c->rowProb, &c->maskPool, &c->vMu, &c->vCu, &c->vMun, &c->vCun, &c->gU, &c->gUn, &c->uOut, &c->nodesOrig, &c->nSel, &c->cols, &c->vals,
                      &c->hFeats, &c->hAssoc, &c->hU0, &c->oAssoc, &c->oN, &c->oT, &c->oStatus, &c->oStats, &c->hAux1, &c->hAux2, &c->hAux3};
     for (DevBuf* b : all) b->release();
     if (c->pinnedTotals) (void)hipHostFree(c->pinnedTotals);
@@ -628,10 +668,11 @@ int roman_set_matrix_data(roman_ctx_t* c, const roman_params_t* params, const do
     int rc = make_dev_params(c, &p, p.point_dim, &Lst.D);
     if (rc) return rc;
     Lst.idx16 = n <= 32767;
-    // full-symmetric CSR over the union pattern of the strict upper triangles of M and C
-    std::vector<uint32_t> rs((size_t)std::max(n, 1)), rl((size_t)std::max(n, 1), 0);
+    // full-symmetric rows over the union pattern of the strict upper triangles of M and C
+    std::vector<uint32_t> rs((size_t)std::max(n, 1)), rl((size_t)std::max(n, 1) + 64, 0);
     std::vector<uint32_t> cols; std::vector<double> vals;
     int64_t upper = 0;
+    const uint32_t czflag = Lst.idx16 ? 0x8000u : 0x80000000u;
     for (int p_ = 0; p_ < n; ++p_) {
         rs[(size_t)p_] = (uint32_t)cols.size();
         for (int q = 0; q < n; ++q) {
@@ -639,7 +680,7 @@ int roman_set_matrix_data(roman_ctx_t* c, const roman_params_t* params, const do
             const int a = std::min(p_, q), b = std::max(p_, q);
             const double mv = M[(int64_t)a * n + b], cv = Cm[(int64_t)a * n + b];
             if (mv != 0.0 || cv != 0.0) {
-                cols.push_back((uint32_t)q | ((cv == 0.0) ? (Lst.idx16 ? 0x8000u : 0x80000000u) : 0u));
+                cols.push_back((uint32_t)q | ((cv == 0.0) ? czflag : 0u));
                 vals.push_back(mv);
                 if (q > p_) ++upper;
             }
@@ -647,13 +688,32 @@ int roman_set_matrix_data(roman_ctx_t* c, const roman_params_t* params, const do
         rl[(size_t)p_] = (uint32_t)cols.size() - rs[(size_t)p_];
         if (cols.size() > 4000000000ull) return fail(c, ROMAN_E_TOO_LARGE, "dense matrix has too many non-zeros");
     }
-    const size_t n1_ = (size_t)std::max(n, 1), nnz1 = std::max<size_t>(cols.size(), 1);
+    // re-order into the device's sorted SELL-64 layout
+    std::vector<uint32_t> rowPos, perm, sliceWidth, sliceBase; uint64_t total = 0;
+    std::vector<uint32_t> cntv(rl.begin(), rl.begin() + std::max(n, 1));
+    sell_geometry(cntv, n, rowPos, perm, sliceWidth, sliceBase, &total);
+    if (total > 4000000000ull) return fail(c, ROMAN_E_TOO_LARGE, "dense matrix has too many non-zeros");
+    std::vector<uint32_t> jcols((size_t)std::max<uint64_t>(total, 1), 0); std::vector<double> jvals((size_t)std::max<uint64_t>(total, 1), 0.0);
+    for (int k = 0; k < n; ++k) {
+        const uint32_t pos = rowPos[(size_t)k], sl = pos >> 6, slot = pos & 63u;
+        for (uint32_t e = 0; e < sliceWidth[sl]; ++e) {
+            const size_t p = (size_t)sliceBase[sl] + (size_t)e * 64 + slot;
+            if (e < rl[(size_t)k]) { jcols[p] = cols[(size_t)rs[(size_t)k] + e]; jvals[p] = vals[(size_t)rs[(size_t)k] + e]; }
+            else { jcols[p] = (uint32_t)k | czflag; jvals[p] = 0.0; }
+        }
+    }
+    for (int sl = 0; sl < (n + 63) / 64; ++sl)                        // empty lanes of the last slice
+        for (int slot = 0; slot < 64; ++slot)
+            if (sl * 64 + slot >= n)
+                for (uint32_t e = 0; e < sliceWidth[(size_t)sl]; ++e) { jcols[(size_t)sliceBase[(size_t)sl] + (size_t)e * 64 + slot] = czflag; }
+    const size_t n1_ = (size_t)std::max(n, 1), nnz1 = (size_t)std::max<uint64_t>(total, 1), nsl1 = (size_t)std::max((n + 63) / 64, 1);
     HIPCHK(c, c->probs.ensure(sizeof(ProbDesc))); HIPCHK(c, c->state.ensure(sizeof(ProbState))); HIPCHK(c, c->queue.ensure(sizeof(int) * 4));
     HIPCHK(c, c->lp.ensure(sizeof(int32_t) * n1_)); HIPCHK(c, c->ls.ensure(sizeof(double) * n1_));
-    HIPCHK(c, c->rowStart.ensure(sizeof(uint32_t) * n1_)); HIPCHK(c, c->rowLen.ensure(sizeof(uint32_t) * n1_));
+    HIPCHK(c, c->rowCnt.ensure(sizeof(uint32_t) * n1_)); HIPCHK(c, c->rowPos.ensure(sizeof(uint32_t) * n1_)); HIPCHK(c, c->perm.ensure(sizeof(uint32_t) * n1_));
+    HIPCHK(c, c->sliceWidth.ensure(sizeof(uint32_t) * n1_)); HIPCHK(c, c->sliceBase.ensure(sizeof(uint32_t) * n1_));
     HIPCHK(c, c->vals.ensure(sizeof(double) * nnz1)); HIPCHK(c, c->cols.ensure((Lst.idx16 ? 2 : 4) * nnz1));
     ProbDesc pd{}; pd.off1 = 0; pd.off2 = 0; pd.assocOff = -1; pd.liveOff = 0; pd.n1 = n; pd.n2 = 1; pd.nA = n;
-    ProbState ps{}; ps.L = n; ps.rowBase = 0; ps.nnzOff = 0; ps.nnzCap = (uint32_t)cols.size(); ps.nnzUpper = (unsigned long long)upper;
+    ProbState ps{}; ps.L = n; ps.rowBase = 0; ps.nnzOff = 0; ps.maskOff = 0; ps.nnzCap = (uint32_t)total; ps.nnzUpper = (unsigned long long)upper;
     std::vector<int32_t> ident((size_t)std::max(n, 1)); std::vector<double> ones((size_t)std::max(n, 1), 1.0);
     for (int k = 0; k < n; ++k) ident[(size_t)k] = k;
     HIPCHK(c, hipMemcpy(c->probs.p, &pd, sizeof(pd), hipMemcpyHostToDevice));
@@ -661,21 +721,24 @@ int roman_set_matrix_data(roman_ctx_t* c, const roman_params_t* params, const do
     if (n > 0) {
         HIPCHK(c, hipMemcpy(c->lp.p, ident.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice));
         HIPCHK(c, hipMemcpy(c->ls.p, ones.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
-        HIPCHK(c, hipMemcpy(c->rowStart.p, rs.data(), sizeof(uint32_t) * (size_t)n, hipMemcpyHostToDevice));
-        HIPCHK(c, hipMemcpy(c->rowLen.p, rl.data(), sizeof(uint32_t) * (size_t)n, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(c->rowCnt.p, rl.data(), sizeof(uint32_t) * (size_t)n, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(c->rowPos.p, rowPos.data(), sizeof(uint32_t) * (size_t)n, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(c->perm.p, perm.data(), sizeof(uint32_t) * (size_t)n, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(c->sliceWidth.p, sliceWidth.data(), sizeof(uint32_t) * nsl1, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(c->sliceBase.p, sliceBase.data(), sizeof(uint32_t) * nsl1, hipMemcpyHostToDevice));
     }
-    if (!cols.empty()) {
-        HIPCHK(c, hipMemcpy(c->vals.p, vals.data(), sizeof(double) * vals.size(), hipMemcpyHostToDevice));
+    if (total > 0) {
+        HIPCHK(c, hipMemcpy(c->vals.p, jvals.data(), sizeof(double) * (size_t)total, hipMemcpyHostToDevice));
         if (Lst.idx16) {
-            std::vector<uint16_t> c16(cols.size());
-            for (size_t k = 0; k < cols.size(); ++k) c16[k] = (uint16_t)cols[k];
+            std::vector<uint16_t> c16((size_t)total);
+            for (size_t k = 0; k < (size_t)total; ++k) c16[k] = (uint16_t)jcols[k];
             HIPCHK(c, hipMemcpy(c->cols.p, c16.data(), sizeof(uint16_t) * c16.size(), hipMemcpyHostToDevice));
         } else {
-            HIPCHK(c, hipMemcpy(c->cols.p, cols.data(), sizeof(uint32_t) * cols.size(), hipMemcpyHostToDevice));
+            HIPCHK(c, hipMemcpy(c->cols.p, jcols.data(), sizeof(uint32_t) * (size_t)total, hipMemcpyHostToDevice));
         }
     }
     Lst.pd = pd; Lst.nA = n; Lst.L = n;
-    Lst.tot.nnzTotal = (int64_t)cols.size(); Lst.tot.R = n; Lst.tot.maxL = n;
+    Lst.tot.nnzTotal = (int64_t)total; Lst.tot.R = n; Lst.tot.maxL = n; Lst.tot.maskWords = 0;
     Lst.scored = true;
     return ROMAN_OK;
 }
