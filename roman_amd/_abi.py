@@ -112,7 +112,8 @@ STATS_NBYTES = C.sizeof(RomanStats)
 PARAMS_NBYTES = C.sizeof(RomanParams)
 
 _LIB = None
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libroman_hip.so")
+# in-tree build product (roman_amd/csrc/Makefile); ROMAN_HIP_LIBRARY overrides the location
+_LIB_PATH = os.environ.get("ROMAN_HIP_LIBRARY") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libroman_hip.so")
 
 
 class RomanHipError(RuntimeError):
