@@ -54,7 +54,7 @@ struct ProbState {
     int64_t  nnzOff;       // offset of this problem's matrix segment
     int64_t  maskOff;      // offset (in 64-bit words) of this problem's candidate bit matrix
     uint32_t nnzCap;       // padded SELL slots allocated for this problem
-    uint32_t pad;
+    int32_t  itemBase;     // first work item (row block) of this problem
     unsigned long long nnzUpper;   // stored strict-upper non-zeros (after the affinityeps filter)
 };
 
@@ -63,7 +63,11 @@ struct BatchTotals {
     int64_t maskWords;     // sum over problems of L * ceil(L/64)
     int32_t R;             // sum of L
     int32_t maxL;
+    int32_t items;         // work items (row blocks) of the pair-test / fill kernels
+    int32_t pad;
 };
+
+struct ItemDesc { int32_t b, row0; };   // a block of consecutive live rows of problem b
 
 // column-index word of a stored entry: live column index + a flag bit "C_pq == 0"
 template <typename IdxT> struct IdxTraits;
@@ -306,82 +310,81 @@ __global__ void __launch_bounds__(1024) k_live(DevParams D, const ProbDesc* __re
     }
 }
 
-// k_rowbase: serial prefix of the live counts (B is small); also the batch maxima and the offsets
-// of the per-problem candidate bit matrices (L rows of ceil(L/64) words).
-__global__ void k_rowbase(int B, ProbState* __restrict__ st, BatchTotals* __restrict__ tot)
+// k_rowbase: serial prefix of the live counts (B is small); also the batch maxima, the offsets of
+// the per-problem candidate bit matrices (L rows of ceil(L/64) words) and the work-item prefix
+// (a work item = a block of up to RPB consecutive live rows of one problem).
+__global__ void k_rowbase(int B, int RPB, ProbState* __restrict__ st, BatchTotals* __restrict__ tot)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    int acc = 0, mx = 0; int64_t mw = 0;
+    int acc = 0, mx = 0, items = 0; int64_t mw = 0;
     for (int b = 0; b < B; ++b) {
         const int L = st[b].L;
-        st[b].rowBase = acc; st[b].maskOff = mw;
+        st[b].rowBase = acc; st[b].maskOff = mw; st[b].itemBase = items;
         acc += L; mx = max(mx, L); mw += (int64_t)L * ((L + 63) >> 6);
+        items += (L + RPB - 1) / RPB;
     }
-    tot->R = acc; tot->maxL = mx; tot->nnzTotal = 0; tot->maskWords = mw;
+    tot->R = acc; tot->maxL = mx; tot->nnzTotal = 0; tot->maskWords = mw; tot->items = items;
 }
 
-// k_rowmap: rowProb[r] = problem of flattened live row r (replaces a per-row binary search).
-__global__ void __launch_bounds__(256) k_rowmap(const ProbState* __restrict__ st, int32_t* __restrict__ rowProb)
+// k_items: the work-item list of the pair-test and fill kernels.
+__global__ void __launch_bounds__(256) k_items(int RPB, const ProbState* __restrict__ st, ItemDesc* __restrict__ items)
 {
     const int b = blockIdx.x;
-    const int L = st[b].L, rb = st[b].rowBase;
-    for (int k = threadIdx.x; k < L; k += blockDim.x) rowProb[rb + k] = b;
+    const int L = st[b].L, ib = st[b].itemBase;
+    const int n = (L + RPB - 1) / RPB;
+    for (int t = threadIdx.x; t < n; t += blockDim.x) { ItemDesc d; d.b = b; d.row0 = t * RPB; items[ib + t] = d; }
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_count: the O(L^2) pair tests of the affinity build, done ONCE.  One wave per live row k=(i,j);
-// lanes sweep the live columns q=(i',j') 64 at a time.  The two table rows TA[i][:] and TB[j][:] are
-// staged in this wave's slice of LDS, so a test costs two LDS gathers, a few coalesced loads and
-// ~15 f64 VALU ops, all exactly rounded (+,-,*,compare).  Output: the row's candidate count and its
-// candidate bit mask (one ballot word per 64 columns) — k_fill never repeats a test.
-// Rows are taken persistently (grid-stride over the batch's flattened row list).
+// k_count: the O(L^2) pair tests of the affinity build, done ONCE.  A workgroup takes a work item
+// (RPB consecutive live rows of one problem) and stages the problem's COLUMN data (map-1/map-2
+// object and the two z coordinates of every live association) in LDS once; each wave then owns a
+// row k=(i,j) at a time: it stages the two table rows TA[i][:] and TB[j][:] in its private LDS
+// slice and sweeps the live columns 64 at a time.  A test costs three coalesced LDS reads, two LDS
+// gathers and ~12 f64 VALU ops, all exactly rounded (+,-,*,compare).  Output per row: the candidate
+// bit mask (one ballot word per 64 columns), the running candidate count in front of every word
+// (k_fill turns it into the entry index without another scan) and the row total.
+// Problems whose live set does not fit the LDS column tile read the columns from HBM/L2 instead.
 // ---------------------------------------------------------------------------------------------
-template <bool GRAV>
-__global__ void __launch_bounds__(1024) k_count(DevParams D, const ProbDesc* __restrict__ probs,
-                                                const ProbState* __restrict__ st,
-                                                const BatchTotals* __restrict__ tot,
-                                                const int32_t* __restrict__ rowProb,
-                                                const double* __restrict__ tabPool,
-                                                const int32_t* __restrict__ li, const int32_t* __restrict__ lj,
-                                                const double* __restrict__ lza, const double* __restrict__ lzb,
-                                                uint32_t* __restrict__ rowCnt,
-                                                unsigned long long* __restrict__ maskPool,
-                                                int ldsPerWave /* doubles */)
+template <bool GRAV, bool LDSCOL>
+__device__ __forceinline__ void count_rows(const DevParams& D, const ProbDesc& pd, int L, int row0, int nrows,
+                                           int w, int wpb, int lane,
+                                           const int32_t* cI, const int32_t* cJ, const double* cZa, const double* cZb,
+                                           const int32_t* __restrict__ gI, const int32_t* __restrict__ gJ,
+                                           const double* __restrict__ gZa, const double* __restrict__ gZb,
+                                           const double* __restrict__ TA, const double* __restrict__ TB, double* tA,
+                                           uint32_t* __restrict__ rowCnt, unsigned long long* __restrict__ mbase,
+                                           uint32_t* __restrict__ pbase)
 {
-    extern __shared__ __attribute__((aligned(16))) double s_tab[];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, wpb = blockDim.x >> 6;
-    double* tA = s_tab + (size_t)w * ldsPerWave;
-    const int R = tot->R;
-    for (int r = blockIdx.x * wpb + w; r < R; r += gridDim.x * wpb) {
-        const int b = rowProb[r];
-        const ProbDesc pd = probs[b];
-        const int L = st[b].L, k = r - st[b].rowBase;
-        const int64_t lo = pd.liveOff;
-        const int i = li[lo + k], j = lj[lo + k];
-        const double zi = lza[lo + k], zj = lzb[lo + k];
-        double* tB = tA + pd.n1;
+    const int W = (L + 63) >> 6;
+    double* tB = tA + pd.n1;
+    for (int r = w; r < nrows; r += wpb) {
+        const int k = row0 + r;
+        const int i = gI[k], j = gJ[k];
+        const double zi = GRAV ? gZa[k] : 0.0, zj = GRAV ? gZb[k] : 0.0;
+        const double* gA = TA + (int64_t)i * pd.n1;
+        const double* gB = TB + (int64_t)j * pd.n2;
         // stage the two table rows (wave-private slice; LDS ops of one wave execute in order)
-        const double* gA = tabPool + pd.tabOff + (int64_t)i * pd.n1;
-        const double* gB = tabPool + pd.tabOff + (int64_t)pd.n1 * pd.n1 + (int64_t)j * pd.n2;
         for (int t = lane; t < pd.n1; t += WAVE) tA[t] = gA[t];
         for (int t = lane; t < pd.n2; t += WAVE) tB[t] = gB[t];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-        const int W = (L + 63) >> 6;
-        unsigned long long* mrow = maskPool + st[b].maskOff + (int64_t)k * W;
+        unsigned long long* mrow = mbase + (int64_t)k * W;
+        uint32_t* prow = pbase + (int64_t)k * W;
         uint32_t cnt = 0;
-        constexpr int U = 4;                       // column chunks per step: 4*U loads in flight per lane
+        unsigned long long mreg = 0ull; uint32_t preg = 0u;     // lane l: word (block*64 + l) of the current 64-word block
+        constexpr int U = 4;                                    // column chunks per step
         for (int q0 = 0; q0 < L; q0 += U * WAVE) {
             int iq[U], jq[U]; double zq1[U], zq2[U]; bool vq[U];
 #pragma unroll
             for (int t = 0; t < U; ++t) {
                 const int q = q0 + t * WAVE + lane;
                 vq[t] = q < L;
-                const int64_t qi = lo + (vq[t] ? q : 0);
-                iq[t] = li[qi]; jq[t] = lj[qi];
-                if (GRAV) { zq1[t] = lza[qi]; zq2[t] = lzb[qi]; }
+                const int qi = vq[t] ? q : 0;
+                iq[t] = cI[qi]; jq[t] = cJ[qi];
+                if (GRAV) { zq1[t] = cZa[qi]; zq2[t] = cZb[qi]; }
             }
 #pragma unroll
             for (int t = 0; t < U; ++t) {
@@ -398,13 +401,73 @@ __global__ void __launch_bounds__(1024) k_count(DevParams D, const ProbDesc* __r
                     is = vq[t] && (fabs(a - bb) < D.p.epsilon);
                 }
                 const unsigned long long m = __ballot(is);
-                if (q0 + t * WAVE < L) {
-                    if (lane == 0) mrow[(q0 >> 6) + t] = m;
+                const int widx = (q0 >> 6) + t;
+                if (widx < W) {
+                    if (lane == (widx & 63)) { mreg = m; preg = cnt; }
                     cnt += __popcll(m);
                 }
             }
+            const int wend = min(W, (q0 >> 6) + U);             // words [.., wend) are complete
+            if ((wend & 63) == 0 || wend == W) {                // flush the block of <= 64 words, coalesced
+                const int wb = (wend - 1) & ~63;
+                if (wb + lane < wend) { mrow[wb + lane] = mreg; prow[wb + lane] = preg; }
+            }
         }
-        if (lane == 0) rowCnt[lo + k] = cnt;
+        if (lane == 0) rowCnt[k] = cnt;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();                        // table slice is rewritten by the next row
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
+template <bool GRAV>
+__global__ void __launch_bounds__(1024) k_count(DevParams D, const ProbDesc* __restrict__ probs,
+                                                const ProbState* __restrict__ st,
+                                                const BatchTotals* __restrict__ tot,
+                                                const ItemDesc* __restrict__ items,
+                                                const double* __restrict__ tabPool,
+                                                const int32_t* __restrict__ li, const int32_t* __restrict__ lj,
+                                                const double* __restrict__ lza, const double* __restrict__ lzb,
+                                                uint32_t* __restrict__ rowCnt,
+                                                unsigned long long* __restrict__ maskPool,
+                                                uint32_t* __restrict__ prefPool,
+                                                int TC /* LDS column tile (multiple of 64) */, int ldsPerWave /* doubles */, int RPB)
+{
+    // LDS: [GRAV: cZa[TC] cZb[TC]] cI[TC] cJ[TC] | per-wave table slices
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double* cZa = reinterpret_cast<double*>(smem);
+    double* cZb = cZa + (GRAV ? TC : 0);
+    int32_t* cI = reinterpret_cast<int32_t*>(cZb + (GRAV ? TC : 0));
+    int32_t* cJ = cI + TC;
+    double* tabs = reinterpret_cast<double*>(cJ + TC);
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int lane = tid & 63, w = tid >> 6, wpb = nt >> 6;
+    double* tA = tabs + (size_t)w * ldsPerWave;
+    const int nItems = tot->items;
+    for (int t = blockIdx.x; t < nItems; t += gridDim.x) {
+        const ItemDesc it = items[t];
+        const int b = it.b;
+        const ProbDesc pd = probs[b];
+        const int L = st[b].L;
+        const int64_t lo = pd.liveOff, mo = st[b].maskOff;
+        const int nrows = min(RPB, L - it.row0);
+        const double* TA = tabPool + pd.tabOff;
+        const double* TB = TA + (int64_t)pd.n1 * pd.n1;
+        const bool ldscol = L <= TC;
+        __syncthreads();                        // every wave is done with the previous item's columns
+        if (ldscol) {
+            for (int q = tid; q < L; q += nt) {
+                cI[q] = li[lo + q]; cJ[q] = lj[lo + q];
+                if (GRAV) { cZa[q] = lza[lo + q]; cZb[q] = lzb[lo + q]; }
+            }
+        }
+        __syncthreads();
+        if (ldscol)
+            count_rows<GRAV, true>(D, pd, L, it.row0, nrows, w, wpb, lane, cI, cJ, cZa, cZb, li + lo, lj + lo, lza + lo, lzb + lo,
+                                   TA, TB, tA, rowCnt + lo, maskPool + mo, prefPool + mo);
+        else
+            count_rows<GRAV, false>(D, pd, L, it.row0, nrows, w, wpb, lane, li + lo, lj + lo, lza + lo, lzb + lo, li + lo, lj + lo, lza + lo, lzb + lo,
+                                    TA, TB, tA, rowCnt + lo, maskPool + mo, prefPool + mo);
     }
 }
 
@@ -487,100 +550,176 @@ __global__ void k_probscan(int B, ProbState* __restrict__ st, BatchTotals* __res
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_fill: candidates -> values.  One wave per live row: it walks the row's mask words (uniform
-// loads), compacts the set bits into a 128-entry wave-private LDS queue and, whenever 64 candidates
-// are queued, evaluates them densely: x (recomputed bit-identically from the tables), sqrt/exp/cbrt,
-// fusion with the two single scores, the affinityeps filter, and the store into the row's SELL slot
-// column.  Finally the row's slot is padded to the slice width with inert entries.
+// k_fill: candidates -> values, as ONE flat stream over the mask words of a work item (RPB rows x
+// ceil(L/64) words, contiguous in HBM).  Each lane takes a mask word together with the candidate
+// count in front of it; in every "bit step" each lane that still has set bits emits one candidate
+// (row, column, entry index) into the wave's LDS ring.  Whenever 64 candidates are queued the wave
+// evaluates them densely, whatever rows they belong to: x (recomputed bit-identically from the
+// tables), sqrt/exp/cbrt, fusion with the two single scores, the affinityeps filter, and the store
+// into the row's SELL slot column.  The problem's per-association data (objects, z, single score,
+// SELL slot base) is staged in LDS once per work item.  Finally every row's slot column is padded
+// to the slice width with inert entries.
 // ---------------------------------------------------------------------------------------------
+constexpr int FILL_Q = 256;          // ring capacity per wave (>= 64 queued + 64 emitted per bit step)
+
+template <bool GRAV, typename IdxT, bool LDSCOL>
+__device__ __forceinline__ uint32_t fill_item(const DevParams& D, const ProbDesc& pd, int L, int row0, int nrows,
+                                              int w, int wpb, int lane,
+                                              const int32_t* cI, const int32_t* cJ, const double* cS,
+                                              const double* cZa, const double* cZb, const uint32_t* cBase,
+                                              const double* __restrict__ TA, const double* __restrict__ TB,
+                                              const unsigned long long* __restrict__ mbase, const uint32_t* __restrict__ pbase,
+                                              const uint32_t* __restrict__ rowPos, const uint32_t* __restrict__ sliceBase,
+                                              uint32_t* qK, uint32_t* qQ, uint32_t* qE,
+                                              IdxT* __restrict__ cols, double* __restrict__ vals)
+{
+    const int W = (L + 63) >> 6;
+    const int64_t nwords = (int64_t)nrows * W;
+    const unsigned long long* mw = mbase + (int64_t)row0 * W;
+    const uint32_t* pw = pbase + (int64_t)row0 * W;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    uint32_t head = 0, queued = 0, upper = 0;
+
+    auto evaluate = [&](uint32_t take) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if ((uint32_t)lane < take) {
+            const uint32_t s = (head + lane) & (FILL_Q - 1);
+            const int k = row0 + (int)qK[s];
+            const int q = (int)qQ[s];
+            const uint32_t e = qE[s];
+            const int i = cI[k], j = cJ[k], iq = cI[q], jq = cJ[q];
+            const double a = TA[(int64_t)i * pd.n1 + iq], bb = TB[(int64_t)j * pd.n2 + jq];
+            double c;
+            if (GRAV) {
+                const double ch = fabs(a - bb);
+                const double hm = a > bb ? a : bb;
+                double cv = fabs((cZa[k] - cZa[q]) - (cZb[k] - cZb[q])) - D.sin_unc * hm;
+                if (cv < 0.0) cv = 0.0;
+                c = sqrt(ch * ch + cv * cv);
+            } else {
+                c = fabs(a - bb);
+            }
+            const double sa = exp(((-0.5 * c) * c) / D.sig2);
+            const double v = fuse_pair(D, sa, cS[k], cS[q]);
+            const bool keep = v > D.p.affinityeps;
+            // an entry at or below affinityeps belongs neither to M nor to C: inert slot
+            uint32_t base;
+            if (LDSCOL) base = cBase[k];
+            else { const uint32_t pos = rowPos[k]; base = sliceBase[pos >> 6] + (pos & 63u); }
+            const int64_t p = (int64_t)base + (int64_t)e * 64;
+            cols[p] = keep ? (IdxT)q : (IdxT)((uint32_t)k | IdxTraits<IdxT>::CZ);
+            vals[p] = keep ? v : 0.0;
+            upper += (keep && q > k) ? 1u : 0u;
+        }
+        head = (head + take) & (FILL_Q - 1); queued -= take;
+    };
+
+    const int64_t nblk = (nwords + 63) >> 6;
+    unsigned long long m_next = 0ull; uint32_t p_next = 0u;
+    {   // prefetch the wave's first block
+        const int64_t x = (int64_t)w * 64 + lane;
+        if (w < nblk && x < nwords) { m_next = mw[x]; p_next = pw[x]; }
+    }
+    for (int64_t blk = w; blk < nblk; blk += wpb) {
+        unsigned long long m = m_next; uint32_t e = p_next;
+        const int64_t x = blk * 64 + lane;
+        {   // prefetch the next block while this one is expanded / evaluated
+            const int64_t xn = x + (int64_t)wpb * 64;
+            m_next = 0ull; p_next = 0u;
+            if (blk + wpb < nblk && xn < nwords) { m_next = mw[xn]; p_next = pw[xn]; }
+        }
+        const uint32_t kl = (uint32_t)((int)x / W);             // row of this word (local to the item; RPB*W < 2^31)
+        const uint32_t qb = (uint32_t)((int)x - (int)kl * W) << 6;  // first column of this word
+        for (;;) {                                              // bit steps
+            const bool has = m != 0ull;
+            const unsigned long long act = __ballot(has);
+            if (act == 0ull) break;
+            if (has) {
+                const int bit = __builtin_ctzll(m);
+                m &= m - 1ull;
+                const uint32_t s = (head + queued + (uint32_t)__popcll(act & lt)) & (FILL_Q - 1);
+                qK[s] = kl; qQ[s] = qb + (uint32_t)bit; qE[s] = e;
+                ++e;
+            }
+            queued += (uint32_t)__popcll(act);
+            while (queued >= 64u) evaluate(64u);
+        }
+    }
+    if (queued > 0u) evaluate(queued);
+    return upper;
+}
+
 template <bool GRAV, typename IdxT>
 __global__ void __launch_bounds__(1024) k_fill(DevParams D, const ProbDesc* __restrict__ probs,
                                                ProbState* __restrict__ st,
                                                const BatchTotals* __restrict__ tot,
-                                               const int32_t* __restrict__ rowProb,
+                                               const ItemDesc* __restrict__ items,
                                                const double* __restrict__ tabPool,
                                                const int32_t* __restrict__ li, const int32_t* __restrict__ lj,
                                                const double* __restrict__ ls,
                                                const double* __restrict__ lza, const double* __restrict__ lzb,
                                                const uint32_t* __restrict__ rowCnt,
                                                const unsigned long long* __restrict__ maskPool,
+                                               const uint32_t* __restrict__ prefPool,
                                                const uint32_t* __restrict__ rowPos,
                                                const uint32_t* __restrict__ sliceWidth,
                                                const uint32_t* __restrict__ sliceBase,
-                                               IdxT* __restrict__ cols, double* __restrict__ vals)
+                                               IdxT* __restrict__ cols, double* __restrict__ vals, int TC, int RPB)
 {
-    __shared__ uint32_t s_q[16][128];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, wpb = blockDim.x >> 6;
-    uint32_t* qbuf = s_q[w];
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    const int R = tot->R;
-    for (int r = blockIdx.x * wpb + w; r < R; r += gridDim.x * wpb) {
-        const int b = rowProb[r];
+    // LDS: cS[TC] [GRAV: cZa[TC] cZb[TC]] cI[TC] cJ[TC] cBase[TC] | per-wave rings qK qQ qE
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double* cS = reinterpret_cast<double*>(smem);
+    double* cZa = cS + TC;
+    double* cZb = cZa + (GRAV ? TC : 0);
+    int32_t* cI = reinterpret_cast<int32_t*>(cZb + (GRAV ? TC : 0));
+    int32_t* cJ = cI + TC;
+    uint32_t* cBase = reinterpret_cast<uint32_t*>(cJ + TC);
+    uint32_t* rings = cBase + TC;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int lane = tid & 63, w = tid >> 6, wpb = nt >> 6;
+    uint32_t* qK = rings + (size_t)w * 3 * FILL_Q;
+    uint32_t* qQ = qK + FILL_Q;
+    uint32_t* qE = qQ + FILL_Q;
+    const int nItems = tot->items;
+    for (int t = blockIdx.x; t < nItems; t += gridDim.x) {
+        const ItemDesc it = items[t];
+        const int b = it.b;
         const ProbDesc pd = probs[b];
-        const int L = st[b].L, k = r - st[b].rowBase;
-        const int64_t lo = pd.liveOff;
-        const int i = li[lo + k], j = lj[lo + k];
-        const double zi = lza[lo + k], zj = lzb[lo + k];
-        const double sk = ls[lo + k];
-        const double* gA = tabPool + pd.tabOff + (int64_t)i * pd.n1;
-        const double* gB = tabPool + pd.tabOff + (int64_t)pd.n1 * pd.n1 + (int64_t)j * pd.n2;
-        const uint32_t pos = rowPos[lo + k];
-        const uint32_t slot = pos & 63u, sl = pos >> 6;
-        const int64_t base = st[b].nnzOff + sliceBase[lo + sl] + slot;     // + e*64
-        const uint32_t width = sliceWidth[lo + sl];
-        const int W = (L + 63) >> 6;
-        const unsigned long long* mrow = maskPool + st[b].maskOff + (int64_t)k * W;
-        uint32_t queued = 0, done = 0, upper = 0;
-        unsigned long long mreg = 0ull;            // lane l holds mask word (wi0 + l) of the current block of 64 words
-        for (int wi = 0; wi <= W; ++wi) {
-            const bool last = (wi == W);
-            if (!last) {
-                if ((wi & 63) == 0) mreg = (wi + lane < W) ? mrow[wi + lane] : 0ull;
-                const unsigned int mlo = __builtin_amdgcn_readlane((unsigned int)mreg, wi & 63);
-                const unsigned int mhi = __builtin_amdgcn_readlane((unsigned int)(mreg >> 32), wi & 63);
-                const unsigned long long m = ((unsigned long long)mhi << 32) | mlo;
-                if (m != 0ull) {
-                    if ((m >> lane) & 1ull) qbuf[queued + __popcll(m & lt)] = (uint32_t)(wi * 64 + lane);
-                    queued += __popcll(m);
-                }
-            }
-            while (queued >= 64u || (last && queued > 0u)) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                const uint32_t take = queued < 64u ? queued : 64u;
-                if ((uint32_t)lane < take) {
-                    const uint32_t q = qbuf[lane];
-                    const double a = gA[li[lo + q]], bb = gB[lj[lo + q]];
-                    double c;
-                    if (GRAV) {
-                        const double ch = fabs(a - bb);
-                        const double hm = a > bb ? a : bb;
-                        double cv = fabs((zi - lza[lo + q]) - (zj - lzb[lo + q])) - D.sin_unc * hm;
-                        if (cv < 0.0) cv = 0.0;
-                        c = sqrt(ch * ch + cv * cv);
-                    } else {
-                        c = fabs(a - bb);
-                    }
-                    const double sa = exp(((-0.5 * c) * c) / D.sig2);
-                    const double v = fuse_pair(D, sa, sk, ls[lo + (int64_t)q]);
-                    const bool keep = v > D.p.affinityeps;
-                    // an entry at or below affinityeps belongs neither to M nor to C: inert slot
-                    const int64_t p = base + (int64_t)(done + lane) * 64;
-                    cols[p] = keep ? (IdxT)q : (IdxT)((uint32_t)k | IdxTraits<IdxT>::CZ);
-                    vals[p] = keep ? v : 0.0;
-                    upper += (keep && (int)q > k) ? 1u : 0u;
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                if (queued > 64u) { const uint32_t mv = qbuf[64 + lane]; qbuf[lane] = mv; }   // shift the overflow half down
-                queued -= take; done += take;
+        const int L = st[b].L;
+        const int64_t lo = pd.liveOff, mo = st[b].maskOff, no = st[b].nnzOff;
+        const int nrows = min(RPB, L - it.row0);
+        const double* TA = tabPool + pd.tabOff;
+        const double* TB = TA + (int64_t)pd.n1 * pd.n1;
+        const bool ldscol = L <= TC;
+        __syncthreads();                        // every wave is done with the previous item's columns
+        if (ldscol) {
+            for (int q = tid; q < L; q += nt) {
+                cI[q] = li[lo + q]; cJ[q] = lj[lo + q]; cS[q] = ls[lo + q];
+                if (GRAV) { cZa[q] = lza[lo + q]; cZb[q] = lzb[lo + q]; }
+                const uint32_t pos = rowPos[lo + q];
+                cBase[q] = sliceBase[lo + (pos >> 6)] + (pos & 63u);
             }
         }
-        for (uint32_t e = done + lane; e < width; e += WAVE) {          // pad the slot column
-            const int64_t p = base + (int64_t)e * 64;
-            cols[p] = (IdxT)((uint32_t)k | IdxTraits<IdxT>::CZ); vals[p] = 0.0;
+        __syncthreads();
+        uint32_t upper;
+        if (ldscol)
+            upper = fill_item<GRAV, IdxT, true>(D, pd, L, it.row0, nrows, w, wpb, lane, cI, cJ, cS, cZa, cZb, cBase, TA, TB,
+                                                maskPool + mo, prefPool + mo, rowPos + lo, sliceBase + lo, qK, qQ, qE, cols + no, vals + no);
+        else
+            upper = fill_item<GRAV, IdxT, false>(D, pd, L, it.row0, nrows, w, wpb, lane, li + lo, lj + lo, ls + lo, lza + lo, lzb + lo, nullptr, TA, TB,
+                                                 maskPool + mo, prefPool + mo, rowPos + lo, sliceBase + lo, qK, qQ, qE, cols + no, vals + no);
+        // pad every row's slot column up to its slice width with inert entries
+        for (int r = w; r < nrows; r += wpb) {
+            const int k = it.row0 + r;
+            const uint32_t pos = rowPos[lo + k];
+            const uint32_t width = sliceWidth[lo + (pos >> 6)];
+            const int64_t base = no + sliceBase[lo + (pos >> 6)] + (pos & 63u);
+            for (uint32_t e = rowCnt[lo + k] + lane; e < width; e += WAVE) {
+                const int64_t p = base + (int64_t)e * 64;
+                cols[p] = (IdxT)((uint32_t)k | IdxTraits<IdxT>::CZ); vals[p] = 0.0;
+            }
         }
         for (int off = 32; off > 0; off >>= 1) upper += __shfl_xor(upper, off);
         if (lane == 0 && upper) atomicAdd(&st[b].nnzUpper, (unsigned long long)upper);

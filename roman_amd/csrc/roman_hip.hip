@@ -49,7 +49,7 @@ struct roman_ctx {
     DevBuf probs, state, totals, queue;
     DevBuf cosPool, normPool, tabPool, sTmp;
     DevBuf lp, li, lj, ls, lza, lzb;
-    DevBuf rowCnt, rowPos, perm, sliceWidth, sliceBase, rowProb, maskPool;
+    DevBuf rowCnt, rowPos, perm, sliceWidth, sliceBase, items, maskPool, prefPool;
     DevBuf vMu, vCu, vMun, vCun, gU, gUn, uOut, nodesOrig, nSel;
     DevBuf cols, vals;
     // staging for the host-pointer entry points
@@ -194,7 +194,12 @@ int stage_score(roman_ctx* c, const DevParams& D, const BatchIn& in, std::vector
     HIPCHK(c, c->lp.ensure(sizeof(int32_t) * nA1)); HIPCHK(c, c->li.ensure(sizeof(int32_t) * nA1)); HIPCHK(c, c->lj.ensure(sizeof(int32_t) * nA1));
     HIPCHK(c, c->ls.ensure(sizeof(double) * nA1)); HIPCHK(c, c->lza.ensure(sizeof(double) * nA1)); HIPCHK(c, c->lzb.ensure(sizeof(double) * nA1));
     HIPCHK(c, c->rowCnt.ensure(sizeof(uint32_t) * nA1)); HIPCHK(c, c->rowPos.ensure(sizeof(uint32_t) * nA1)); HIPCHK(c, c->perm.ensure(sizeof(uint32_t) * nA1));
-    HIPCHK(c, c->sliceWidth.ensure(sizeof(uint32_t) * nA1)); HIPCHK(c, c->sliceBase.ensure(sizeof(uint32_t) * nA1)); HIPCHK(c, c->rowProb.ensure(sizeof(int32_t) * nA1));
+    HIPCHK(c, c->sliceWidth.ensure(sizeof(uint32_t) * nA1)); HIPCHK(c, c->sliceBase.ensure(sizeof(uint32_t) * nA1));
+    // work items: blocks of RPB consecutive live rows of one problem (more, smaller items for small batches)
+    int RPB = 32;
+    while (RPB < 256 && (int64_t)RPB * c->num_cu * 64 < sumA) RPB <<= 1;
+    const size_t maxItems = (size_t)(sumA / RPB) + (size_t)B + 1;
+    HIPCHK(c, c->items.ensure(sizeof(ItemDesc) * maxItems));
 
     HIPCHK(c, hipMemcpyAsync(c->probs.p, hd.data(), sizeof(ProbDesc) * (size_t)B, hipMemcpyHostToDevice, c->stream));
     const ProbDesc* dP = c->probs.as<ProbDesc>();
@@ -211,8 +216,8 @@ int stage_score(roman_ctx* c, const DevParams& D, const BatchIn& in, std::vector
         hipLaunchKernelGGL(k_tables, dim3((unsigned)((maxTab + 255) / 256), B), dim3(256), 0, c->stream, D, dP, in.feats, c->tabPool.as<double>());
     hipLaunchKernelGGL(k_live, dim3(B), dim3(1024), 0, c->stream, D, dP, dS, in.feats, in.assoc, c->cosPool.as<double>(), c->sTmp.as<double>(),
                        c->lp.as<int32_t>(), c->li.as<int32_t>(), c->lj.as<int32_t>(), c->ls.as<double>(), c->lza.as<double>(), c->lzb.as<double>());
-    hipLaunchKernelGGL(k_rowbase, dim3(1), dim3(64), 0, c->stream, B, dS, dT);
-    hipLaunchKernelGGL(k_rowmap, dim3(B), dim3(256), 0, c->stream, dS, c->rowProb.as<int32_t>());
+    hipLaunchKernelGGL(k_rowbase, dim3(1), dim3(64), 0, c->stream, B, RPB, dS, dT);
+    hipLaunchKernelGGL(k_items, dim3(B), dim3(256), 0, c->stream, RPB, dS, c->items.as<ItemDesc>());
     // read-back #1 (24 bytes): live totals -> size of the candidate bit matrices, index width
     HIPCHK(c, hipMemcpyAsync(c->pinnedTotals, dT, sizeof(BatchTotals), hipMemcpyDeviceToHost, c->stream));
     t0.stop();
@@ -220,24 +225,29 @@ int stage_score(roman_ctx* c, const DevParams& D, const BatchIn& in, std::vector
     BatchTotals tot = *c->pinnedTotals;
     *idx16 = tot.maxL <= 32767;        // column indices are LIVE indices; bit 15 is the C==0 flag
     HIPCHK(c, c->maskPool.ensure(sizeof(unsigned long long) * (size_t)std::max<int64_t>(tot.maskWords, 1)));
+    HIPCHK(c, c->prefPool.ensure(sizeof(uint32_t) * (size_t)std::max<int64_t>(tot.maskWords, 1)));
 
-    // per-wave LDS slice for the two table rows of the pair-test kernel
+    // pair-test kernel LDS: a column tile (objects [+ z] of every live association) + per-wave table rows
     const int ldsPerWave = ((2 * std::max(maxN, 1) + 1) & ~1) + 2;
+    const int colBytesC = D.gravity ? 24 : 8;
+    const int Lneed = (std::max(tot.maxL, 1) + 63) & ~63;
     int wpb = 16;
-    while (wpb > 1 && (size_t)wpb * ldsPerWave * sizeof(double) > c->lds_max) wpb >>= 1;
-    if ((size_t)wpb * ldsPerWave * sizeof(double) > c->lds_max)
+    while (wpb > 1 && (size_t)wpb * ldsPerWave * sizeof(double) + 64 * colBytesC > c->lds_max) wpb >>= 1;
+    if ((size_t)wpb * ldsPerWave * sizeof(double) + 64 * colBytesC > c->lds_max)
         return fail(c, ROMAN_E_TOO_LARGE, "maps of %d objects exceed the LDS table staging of this build", maxN);
-    const size_t pairLds = (size_t)wpb * ldsPerWave * sizeof(double);
-    const int blocksPerCU = std::max(1, std::min(2048 / (wpb * 64), (int)(c->lds_max / pairLds)));
-    const int pairGrid = c->num_cu * blocksPerCU;
+    const size_t tabLds = (size_t)wpb * ldsPerWave * sizeof(double);
+    int TCc = (int)std::min<size_t>((c->lds_max - tabLds) / colBytesC, 32768) & ~63;
+    TCc = std::min(TCc, Lneed);
+    const size_t pairLds = tabLds + (size_t)TCc * colBytesC;
+    const int pairGrid = c->num_cu * std::max(1, std::min(2048 / (wpb * 64), (int)(c->lds_max / pairLds)));
 
     StageTimer t1(c, ROMAN_STAGE_COUNT_PASS);
     if (tot.R > 0) {
         auto kc = D.gravity ? k_count<true> : k_count<false>;
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kc), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pairLds));
-        hipLaunchKernelGGL(kc, dim3(pairGrid), dim3(wpb * 64), pairLds, c->stream, D, dP, dS, dT, c->rowProb.as<int32_t>(), c->tabPool.as<double>(),
+        hipLaunchKernelGGL(kc, dim3(pairGrid), dim3(wpb * 64), pairLds, c->stream, D, dP, dS, dT, c->items.as<ItemDesc>(), c->tabPool.as<double>(),
                            c->li.as<int32_t>(), c->lj.as<int32_t>(), c->lza.as<double>(), c->lzb.as<double>(),
-                           c->rowCnt.as<uint32_t>(), c->maskPool.as<unsigned long long>(), ldsPerWave);
+                           c->rowCnt.as<uint32_t>(), c->maskPool.as<unsigned long long>(), c->prefPool.as<uint32_t>(), TCc, ldsPerWave, RPB);
     }
     hipLaunchKernelGGL(k_rowsort, dim3(B), dim3(1024), 0, c->stream, dP, dS, c->rowCnt.as<uint32_t>(), c->rowPos.as<uint32_t>(), c->perm.as<uint32_t>(),
                        c->sliceWidth.as<uint32_t>(), c->sliceBase.as<uint32_t>());
@@ -254,12 +264,21 @@ int stage_score(roman_ctx* c, const DevParams& D, const BatchIn& in, std::vector
 
     StageTimer t2(c, ROMAN_STAGE_FILL);
     if (tot.R > 0) {
-        const int fillGrid = c->num_cu * 2;
+        // fill kernel LDS: column tile (objects, single score, [z,] SELL slot base) + per-wave candidate rings
+        const int colBytesF = D.gravity ? 36 : 20;
+        const size_t ringLds = (size_t)16 * 3 * FILL_Q * sizeof(uint32_t);
+        int TCf = (int)std::min<size_t>((c->lds_max - ringLds) / colBytesF, 32768) & ~63;
+        TCf = std::min(TCf, Lneed);
+        const size_t fillLds = ringLds + (size_t)TCf * colBytesF;
+        const int fillGrid = c->num_cu * std::max(1, std::min(2, (int)(c->lds_max / fillLds)));
 #define ROMAN_LAUNCH_FILL(GRAV_, IDX)                                                                                          \
-        hipLaunchKernelGGL((k_fill<GRAV_, IDX>), dim3(fillGrid), dim3(1024), 0, c->stream, D, dP, dS, dT, c->rowProb.as<int32_t>(), c->tabPool.as<double>(), \
+        do {                                                                                                                   \
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_fill<GRAV_, IDX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fillLds)); \
+        hipLaunchKernelGGL((k_fill<GRAV_, IDX>), dim3(fillGrid), dim3(1024), fillLds, c->stream, D, dP, dS, dT, c->items.as<ItemDesc>(), c->tabPool.as<double>(), \
                            c->li.as<int32_t>(), c->lj.as<int32_t>(), c->ls.as<double>(), c->lza.as<double>(), c->lzb.as<double>(),          \
-                           c->rowCnt.as<uint32_t>(), c->maskPool.as<unsigned long long>(), c->rowPos.as<uint32_t>(),                          \
-                           c->sliceWidth.as<uint32_t>(), c->sliceBase.as<uint32_t>(), c->cols.as<IDX>(), c->vals.as<double>())
+                           c->rowCnt.as<uint32_t>(), c->maskPool.as<unsigned long long>(), c->prefPool.as<uint32_t>(), c->rowPos.as<uint32_t>(), \
+                           c->sliceWidth.as<uint32_t>(), c->sliceBase.as<uint32_t>(), c->cols.as<IDX>(), c->vals.as<double>(), TCf, RPB);        \
+        } while (0)
         if (*idx16) { if (D.gravity) ROMAN_LAUNCH_FILL(true, uint16_t); else ROMAN_LAUNCH_FILL(false, uint16_t); }
         else        { if (D.gravity) ROMAN_LAUNCH_FILL(true, uint32_t); else ROMAN_LAUNCH_FILL(false, uint32_t); }
 #undef ROMAN_LAUNCH_FILL
@@ -493,7 +512,7 @@ int roman_ctx_destroy(roman_ctx_t* c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     DevBuf* all[] = {&c->probs, &c->state, &c->totals, &c->queue, &c->cosPool, &c->normPool, &c->tabPool, &c->sTmp, &c->lp, &c->li, &c->lj, &c->ls, &c->lza, &c->lzb,
-                     &c->rowCnt, &c->rowPos, &c->perm, &c->sliceWidth, &c->sliceBase, &c->rowProb, &c->maskPool, &c->vMu, &c->vCu, &c->vMun, &c->vCun, &c->gU, &c->gUn, &c->uOut, &c->nodesOrig, &c->nSel, &c->cols, &c->vals,
+                     &c->rowCnt, &c->rowPos, &c->perm, &c->sliceWidth, &c->sliceBase, &c->items, &c->maskPool, &c->prefPool, &c->vMu, &c->vCu, &c->vMun, &c->vCun, &c->gU, &c->gUn, &c->uOut, &c->nodesOrig, &c->nSel, &c->cols, &c->vals,
                      &c->hFeats, &c->hAssoc, &c->hU0, &c->oAssoc, &c->oN, &c->oT, &c->oStatus, &c->oStats, &c->hAux1, &c->hAux2, &c->hAux3};
     for (DevBuf* b : all) b->release();
     if (c->pinnedTotals) (void)hipHostFree(c->pinnedTotals);
