@@ -163,11 +163,18 @@ __global__ void __launch_bounds__(256) k_norms(DevParams D, const ProbDesc* __re
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_cos: cos[i][j] = <d1_i, d2_j> / (|d1_i| |d2_j|), one 16x16 tile per wave on the f64 matrix
-// core (v_mfma_f64_16x16x4_f64).  Operand layout: lane l supplies A[i = l&15][k = l>>4] and
-// B[k = l>>4][j = l&15]; result reg r of lane l is C[row = (l>>4) + 4r][col = l&15].
+// k_cos: cos[i][j] = <d1_i, d2_j> / (|d1_i| |d2_j|) on the f64 matrix core (v_mfma_f64_16x16x4_f64).
+// One wave owns a 32x32 output tile (2x2 MFMA tiles).  Operand layout of one MFMA: lane l supplies
+// A[i = l&15][k = l>>4] and B[k = l>>4][j = l&15]; result reg r of lane l is C[row = (l>>4) + 4r][col = l&15].
+// Per 16 descriptor elements a lane loads 4 CONSECUTIVE doubles of each of its 2+2 rows (32-byte
+// loads) and feeds element t of every load to MFMA t: MFMA t contracts k = k0 + 4*(l>>4) + t — any
+// bijection k <-> (MFMA, l>>4) is a valid contraction order as long as A and B use the same one.
+// 16 MFMAs per 4 wide loads (the previous 16x16 tile issued 1 MFMA per 2 scalar loads).
 // ---------------------------------------------------------------------------------------------
 typedef double double4_t __attribute__((ext_vector_type(4)));
+struct __attribute__((packed, aligned(8))) d4u_t { double v[4]; };     // 8-byte aligned 32-byte load
+
+constexpr int COS_TILE = 32;
 
 __global__ void __launch_bounds__(256) k_cos(DevParams D, const ProbDesc* __restrict__ probs,
                                              const double* __restrict__ feats,
@@ -175,43 +182,78 @@ __global__ void __launch_bounds__(256) k_cos(DevParams D, const ProbDesc* __rest
                                              double* __restrict__ cosPool)
 {
     const ProbDesc pd = probs[blockIdx.y];
-    const int tj_n = (pd.n2 + 15) >> 4, ti_n = (pd.n1 + 15) >> 4;
+    const int tj_n = (pd.n2 + COS_TILE - 1) / COS_TILE, ti_n = (pd.n1 + COS_TILE - 1) / COS_TILE;
     const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (tile >= ti_n * tj_n) return;
     const int lane = threadIdx.x & 63;
-    const int i0 = (tile / tj_n) << 4, j0 = (tile % tj_n) << 4;
+    const int i0 = (tile / tj_n) * COS_TILE, j0 = (tile % tj_n) * COS_TILE;
     const int Fc = D.p.cos_feature_dim, coff = D.p.point_dim + D.p.ratio_feature_dim;
-    const int ia = i0 + (lane & 15), jb = j0 + (lane & 15), kq = lane >> 4;
-    const bool va = ia < pd.n1, vb = jb < pd.n2;
-    const double* fa = feats + (pd.off1 + (va ? ia : 0)) * D.F + coff;
-    const double* fb = feats + (pd.off2 + (vb ? jb : 0)) * D.F + coff;
-    double4_t acc = {0.0, 0.0, 0.0, 0.0};
-    int k0 = 0;
-    for (; k0 + 4 <= Fc; k0 += 4) {
-        const double a = va ? fa[k0 + kq] : 0.0;
-        const double b = vb ? fb[k0 + kq] : 0.0;
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    const int lr = lane & 15, kq = lane >> 4;
+    const double* fa[2]; const double* fb[2]; bool va[2], vb[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int ia = i0 + 16 * h + lr, jb = j0 + 16 * h + lr;
+        va[h] = ia < pd.n1; vb[h] = jb < pd.n2;
+        fa[h] = feats + (pd.off1 + (va[h] ? ia : 0)) * D.F + coff + 4 * kq;
+        fb[h] = feats + (pd.off2 + (vb[h] ? jb : 0)) * D.F + coff + 4 * kq;
     }
-    if (k0 < Fc) {                                   // ragged tail of the descriptor
-        const bool vk = (k0 + kq) < Fc;
-        const double a = (va && vk) ? fa[k0 + kq] : 0.0;
-        const double b = (vb && vk) ? fb[k0 + kq] : 0.0;
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    double4_t acc[2][2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) acc[x][y] = double4_t{0.0, 0.0, 0.0, 0.0};
+    int k0 = 0;
+    for (; k0 + 16 <= Fc; k0 += 16) {
+        d4u_t a[2], b[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            a[h] = *reinterpret_cast<const d4u_t*>(fa[h] + k0);
+            b[h] = *reinterpret_cast<const d4u_t*>(fb[h] + k0);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int y = 0; y < 2; ++y)
+                    acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(va[x] ? a[x].v[t] : 0.0, vb[y] ? b[y].v[t] : 0.0, acc[x][y], 0, 0, 0);
+    }
+    if (k0 < Fc) {                                   // ragged tail of the descriptor (< 16 elements)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int kk = k0 + 4 * kq + t;
+            const bool vk = kk < Fc;
+            double av[2], bv[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                av[h] = (va[h] && vk) ? fa[h][k0 + t] : 0.0;
+                bv[h] = (vb[h] && vk) ? fb[h][k0 + t] : 0.0;
+            }
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int y = 0; y < 2; ++y)
+                    acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[x], bv[y], acc[x][y], 0, 0, 0);
+        }
     }
     const double* nr1 = normPool + pd.normOff;
     const double* nr2 = nr1 + pd.n1;
-    const int col = j0 + (lane & 15);
-    if (col < pd.n2) {
+#pragma unroll
+    for (int y = 0; y < 2; ++y) {
+        const int col = j0 + 16 * y + lr;
+        if (col >= pd.n2) continue;
         const double nb = nr2[col];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = i0 + (lane >> 4) + 4 * r;
-            if (row < pd.n1) {
-                const double na = nr1[row];
-                cosPool[pd.cosOff + (int64_t)row * pd.n2 + col] =
-                    (na > 0.0 && nb > 0.0) ? acc[r] / (na * nb) : 0.0;
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = i0 + 16 * x + kq + 4 * r;
+                if (row < pd.n1) {
+                    const double na = nr1[row];
+                    cosPool[pd.cosOff + (int64_t)row * pd.n2 + col] =
+                        (na > 0.0 && nb > 0.0) ? acc[x][y][r] / (na * nb) : 0.0;
+                }
             }
-        }
     }
 }
 

@@ -176,7 +176,7 @@ int stage_score(roman_ctx* c, const DevParams& D, const BatchIn& in, std::vector
         d.liveOff = sumA; d.cosOff = sumCos; d.tabOff = sumTab; d.normOff = sumN;
         sumA += d.nA; sumCos += (int64_t)d.n1 * d.n2; sumTab += (int64_t)d.n1 * d.n1 + (int64_t)d.n2 * d.n2; sumN += d.n1 + d.n2;
         maxN12 = std::max(maxN12, d.n1 + d.n2); maxN = std::max(maxN, std::max(d.n1, d.n2));
-        maxTiles = std::max(maxTiles, ((d.n1 + 15) / 16) * ((d.n2 + 15) / 16));
+        maxTiles = std::max(maxTiles, ((d.n1 + COS_TILE - 1) / COS_TILE) * ((d.n2 + COS_TILE - 1) / COS_TILE));
         maxTab = std::max(maxTab, (int64_t)d.n1 * d.n1 + (int64_t)d.n2 * d.n2);
     }
     if (sumA > 2000000000LL) return fail(c, ROMAN_E_TOO_LARGE, "batch has %lld associations; split it (limit 2e9 per call)", (long long)sumA);
@@ -934,7 +934,7 @@ int roman_debug_cosine(roman_ctx_t* c, const roman_params_t* params, const doubl
     HIPCHK(c, c->cosPool.ensure(sizeof(double) * (size_t)n1 * n2)); HIPCHK(c, c->normPool.ensure(sizeof(double) * (size_t)(n1 + n2)));
     HIPCHK(c, hipMemcpyAsync(c->probs.p, &pd, sizeof(pd), hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(k_norms, dim3((n1 + n2 + 3) / 4, 1), dim3(256), 0, c->stream, D, c->probs.as<ProbDesc>(), c->hFeats.as<double>(), c->normPool.as<double>());
-    const int tiles = ((n1 + 15) / 16) * ((n2 + 15) / 16);
+    const int tiles = ((n1 + COS_TILE - 1) / COS_TILE) * ((n2 + COS_TILE - 1) / COS_TILE);
     hipLaunchKernelGGL(k_cos, dim3((tiles + 3) / 4, 1), dim3(256), 0, c->stream, D, c->probs.as<ProbDesc>(), c->hFeats.as<double>(), c->normPool.as<double>(), c->cosPool.as<double>());
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(out, c->cosPool.p, sizeof(double) * (size_t)n1 * n2, hipMemcpyDeviceToHost, c->stream));
