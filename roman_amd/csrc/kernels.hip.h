@@ -388,18 +388,87 @@ __global__ void __launch_bounds__(256) k_items(int RPB, const ProbState* __restr
 // (k_fill turns it into the entry index without another scan) and the row total.
 // Problems whose live set does not fit the LDS column tile read the columns from HBM/L2 instead.
 // ---------------------------------------------------------------------------------------------
-template <bool GRAV, bool LDSCOL>
-__device__ __forceinline__ void count_rows(const DevParams& D, const ProbDesc& pd, int L, int row0, int nrows,
-                                           int w, int wpb, int lane,
-                                           const int32_t* cI, const int32_t* cJ, const double* cZa, const double* cZb,
-                                           const int32_t* __restrict__ gI, const int32_t* __restrict__ gJ,
-                                           const double* __restrict__ gZa, const double* __restrict__ gZb,
-                                           const double* __restrict__ TA, const double* __restrict__ TB, double* tA,
-                                           uint32_t* __restrict__ rowCnt, unsigned long long* __restrict__ mbase,
-                                           uint32_t* __restrict__ pbase)
+// exclusive prefix sum over the 64 lanes of a wave
+__device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, int lane)
+{
+    uint32_t inc = v;
+#pragma unroll
+    for (int off = 1; off < WAVE; off <<= 1) { const uint32_t t = __shfl_up(inc, off); if (lane >= off) inc += t; }
+    return inc - v;
+}
+
+// Generic sweep (columns read from HBM/L2): used when the live set does not fit the LDS column tile.
+template <bool GRAV>
+__device__ __forceinline__ void count_rows_global(const DevParams& D, const ProbDesc& pd, int L, int row0, int nrows,
+                                                  int w, int wpb, int lane,
+                                                  const int32_t* __restrict__ gI, const int32_t* __restrict__ gJ,
+                                                  const double* __restrict__ gZa, const double* __restrict__ gZb,
+                                                  const double* __restrict__ TA, const double* __restrict__ TB, double* tA,
+                                                  uint32_t* __restrict__ rowCnt, unsigned long long* __restrict__ mbase,
+                                                  uint32_t* __restrict__ pbase)
 {
     const int W = (L + 63) >> 6;
-    double* tB = tA + pd.n1;
+    double* tB = tA + pd.n1 + 1;
+    for (int r = w; r < nrows; r += wpb) {
+        const int k = row0 + r;
+        const int i = gI[k], j = gJ[k];
+        const double zi = GRAV ? gZa[k] : 0.0, zj = GRAV ? gZb[k] : 0.0;
+        const double* gA = TA + (int64_t)i * pd.n1;
+        const double* gB = TB + (int64_t)j * pd.n2;
+        for (int t = lane; t < pd.n1; t += WAVE) tA[t] = gA[t];
+        for (int t = lane; t < pd.n2; t += WAVE) tB[t] = gB[t];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        unsigned long long* mrow = mbase + (int64_t)k * W;
+        uint32_t* prow = pbase + (int64_t)k * W;
+        uint32_t cnt = 0;
+        for (int q0 = 0; q0 < L; q0 += WAVE) {
+            const int q = q0 + lane;
+            const bool vq = q < L;
+            const int qi = vq ? q : 0;
+            const double a = tA[gI[qi]], bb = tB[gJ[qi]];
+            bool is;
+            if (GRAV) {
+                const double ch = fabs(a - bb);
+                const double hm = a > bb ? a : bb;
+                double cv = fabs((zi - gZa[qi]) - (zj - gZb[qi])) - D.sin_unc * hm;
+                if (cv < 0.0) cv = 0.0;
+                const double x = ch * ch + cv * cv;
+                is = vq && (x < D.x_eps);          // <=> sqrt(x) < epsilon ; NaN -> false
+            } else {
+                is = vq && (fabs(a - bb) < D.p.epsilon);
+            }
+            const unsigned long long m = __ballot(is);
+            if (lane == 0) { mrow[q0 >> 6] = m; prow[q0 >> 6] = cnt; }
+            cnt += __popcll(m);
+        }
+        if (lane == 0) rowCnt[k] = cnt;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
+// Fast sweep: columns in LDS as {8*i_q, 8*(n1+1+j_q)} byte offsets into the wave's table slice (+ the
+// two z coordinates), padded to a multiple of 256 columns with a sentinel whose table entry is NaN
+// (fails every test), so the inner loop has no bounds logic at all.  Per 64 tests: 2 coalesced LDS
+// reads, 2 LDS gathers, 12 f64 VALU ops, 2 address adds, 2 v_writelane.
+template <bool GRAV>
+__device__ __forceinline__ void count_rows_lds(const DevParams& D, const ProbDesc& pd, int L, int row0, int nrows,
+                                               int w, int wpb, int lane,
+                                               const int2* cIJ, const double2* cZZ,
+                                               const int32_t* __restrict__ gI, const int32_t* __restrict__ gJ,
+                                               const double* __restrict__ gZa, const double* __restrict__ gZb,
+                                               const double* __restrict__ TA, const double* __restrict__ TB, double* tA,
+                                               uint32_t* __restrict__ rowCnt, unsigned long long* __restrict__ mbase,
+                                               uint32_t* __restrict__ pbase)
+{
+    const int W = (L + 63) >> 6;
+    double* tB = tA + pd.n1 + 1;
+    const char* tbytes = reinterpret_cast<const char*>(tA);
+    constexpr int U = 4;                                        // column chunks per step
+    const int Lpad = (L + U * WAVE - 1) & ~(U * WAVE - 1);
     for (int r = w; r < nrows; r += wpb) {
         const int k = row0 + r;
         const int i = gI[k], j = gJ[k];
@@ -409,50 +478,53 @@ __device__ __forceinline__ void count_rows(const DevParams& D, const ProbDesc& p
         // stage the two table rows (wave-private slice; LDS ops of one wave execute in order)
         for (int t = lane; t < pd.n1; t += WAVE) tA[t] = gA[t];
         for (int t = lane; t < pd.n2; t += WAVE) tB[t] = gB[t];
+        if (lane == 0) tA[pd.n1] = d_nan();                     // sentinel entry of the padding columns
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
         unsigned long long* mrow = mbase + (int64_t)k * W;
         uint32_t* prow = pbase + (int64_t)k * W;
-        uint32_t cnt = 0;
-        unsigned long long mreg = 0ull; uint32_t preg = 0u;     // lane l: word (block*64 + l) of the current 64-word block
-        constexpr int U = 4;                                    // column chunks per step
-        for (int q0 = 0; q0 < L; q0 += U * WAVE) {
-            int iq[U], jq[U]; double zq1[U], zq2[U]; bool vq[U];
+        uint32_t cnt = 0, cntBlk = 0;
+        uint32_t mlo = 0u, mhi = 0u;                            // lane l: word (block*64 + l) of the current 64-word block
+        for (int q0 = 0; q0 < Lpad; q0 += U * WAVE) {
+            int2 ij[U]; double2 zz[U];
 #pragma unroll
             for (int t = 0; t < U; ++t) {
-                const int q = q0 + t * WAVE + lane;
-                vq[t] = q < L;
-                const int qi = vq[t] ? q : 0;
-                iq[t] = cI[qi]; jq[t] = cJ[qi];
-                if (GRAV) { zq1[t] = cZa[qi]; zq2[t] = cZb[qi]; }
+                ij[t] = cIJ[q0 + t * WAVE + lane];
+                if (GRAV) zz[t] = cZZ[q0 + t * WAVE + lane];
             }
 #pragma unroll
             for (int t = 0; t < U; ++t) {
-                const double a = tA[iq[t]], bb = tB[jq[t]];
+                const double a = *reinterpret_cast<const double*>(tbytes + ij[t].x);
+                const double bb = *reinterpret_cast<const double*>(tbytes + ij[t].y);
                 bool is;
                 if (GRAV) {
                     const double ch = fabs(a - bb);
-                    const double hm = a > bb ? a : bb;
-                    double cv = fabs((zi - zq1[t]) - (zj - zq2[t])) - D.sin_unc * hm;
-                    if (cv < 0.0) cv = 0.0;
+                    double hm;                                  // max(a,bb) in ONE instruction (fmax() would first
+                    asm("v_max_f64 %0, %1, %2" : "=v"(hm) : "v"(a), "v"(bb));   // canonicalise both); NaN operands: x is NaN through ch anyway
+                    const double cv = __builtin_fmax(fabs((zi - zz[t].x) - (zj - zz[t].y)) - D.sin_unc * hm, 0.0);
                     const double x = ch * ch + cv * cv;
-                    is = vq[t] && (x < D.x_eps);   // <=> sqrt(x) < epsilon ; NaN -> false
+                    is = x < D.x_eps;                           // <=> sqrt(x) < epsilon ; NaN -> false
                 } else {
-                    is = vq[t] && (fabs(a - bb) < D.p.epsilon);
+                    is = fabs(a - bb) < D.p.epsilon;
                 }
                 const unsigned long long m = __ballot(is);
-                const int widx = (q0 >> 6) + t;
-                if (widx < W) {
-                    if (lane == (widx & 63)) { mreg = m; preg = cnt; }
-                    cnt += __popcll(m);
+                const int widx = (q0 >> 6) + t;                 // words >= W are all-zero (sentinel columns)
+                {   // lane (widx & 63) of (mhi:mlo) <- m  (v_writelane_b32: uniform value, uniform lane select)
+                    const uint32_t ml_ = (uint32_t)m, mh_ = (uint32_t)(m >> 32), sel_ = (uint32_t)(widx & 63);
+                    asm("s_mov_b32 m0, %3\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %4, m0"
+                        : "+v"(mlo), "+v"(mhi) : "s"(ml_), "s"(sel_), "s"(mh_) : "m0");
                 }
+                cnt += __popcll(m);
             }
             const int wend = min(W, (q0 >> 6) + U);             // words [.., wend) are complete
             if ((wend & 63) == 0 || wend == W) {                // flush the block of <= 64 words, coalesced
                 const int wb = (wend - 1) & ~63;
-                if (wb + lane < wend) { mrow[wb + lane] = mreg; prow[wb + lane] = preg; }
+                const unsigned long long mreg = ((unsigned long long)mhi << 32) | mlo;
+                const uint32_t pref = cntBlk + wave_excl_scan((wb + lane < wend) ? (uint32_t)__popcll(mreg) : 0u, lane);
+                if (wb + lane < wend) { mrow[wb + lane] = mreg; prow[wb + lane] = pref; }
+                cntBlk = cnt;
             }
         }
         if (lane == 0) rowCnt[k] = cnt;
@@ -473,15 +545,13 @@ __global__ void __launch_bounds__(1024) k_count(DevParams D, const ProbDesc* __r
                                                 uint32_t* __restrict__ rowCnt,
                                                 unsigned long long* __restrict__ maskPool,
                                                 uint32_t* __restrict__ prefPool,
-                                                int TC /* LDS column tile (multiple of 64) */, int ldsPerWave /* doubles */, int RPB)
+                                                int TC /* LDS column tile (multiple of 256) */, int ldsPerWave /* doubles */, int RPB)
 {
-    // LDS: [GRAV: cZa[TC] cZb[TC]] cI[TC] cJ[TC] | per-wave table slices
+    // LDS: [GRAV: cZZ[TC]] cIJ[TC] | per-wave table slices (n1 + 1 + n2 doubles each)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    double* cZa = reinterpret_cast<double*>(smem);
-    double* cZb = cZa + (GRAV ? TC : 0);
-    int32_t* cI = reinterpret_cast<int32_t*>(cZb + (GRAV ? TC : 0));
-    int32_t* cJ = cI + TC;
-    double* tabs = reinterpret_cast<double*>(cJ + TC);
+    double2* cZZ = reinterpret_cast<double2*>(smem);
+    int2* cIJ = reinterpret_cast<int2*>(cZZ + (GRAV ? TC : 0));
+    double* tabs = reinterpret_cast<double*>(cIJ + TC);
     const int tid = threadIdx.x, nt = blockDim.x;
     const int lane = tid & 63, w = tid >> 6, wpb = nt >> 6;
     double* tA = tabs + (size_t)w * ldsPerWave;
@@ -495,20 +565,22 @@ __global__ void __launch_bounds__(1024) k_count(DevParams D, const ProbDesc* __r
         const int nrows = min(RPB, L - it.row0);
         const double* TA = tabPool + pd.tabOff;
         const double* TB = TA + (int64_t)pd.n1 * pd.n1;
-        const bool ldscol = L <= TC;
+        const int Lpad = (L + 255) & ~255;
+        const bool ldscol = Lpad <= TC;
         __syncthreads();                        // every wave is done with the previous item's columns
         if (ldscol) {
-            for (int q = tid; q < L; q += nt) {
-                cI[q] = li[lo + q]; cJ[q] = lj[lo + q];
-                if (GRAV) { cZa[q] = lza[lo + q]; cZb[q] = lzb[lo + q]; }
+            for (int q = tid; q < Lpad; q += nt) {
+                const bool v = q < L;
+                cIJ[q] = v ? make_int2(8 * li[lo + q], 8 * (pd.n1 + 1 + lj[lo + q])) : make_int2(8 * pd.n1, 8 * (pd.n1 + 1));
+                if (GRAV) cZZ[q] = v ? make_double2(lza[lo + q], lzb[lo + q]) : make_double2(0.0, 0.0);
             }
         }
         __syncthreads();
         if (ldscol)
-            count_rows<GRAV, true>(D, pd, L, it.row0, nrows, w, wpb, lane, cI, cJ, cZa, cZb, li + lo, lj + lo, lza + lo, lzb + lo,
-                                   TA, TB, tA, rowCnt + lo, maskPool + mo, prefPool + mo);
+            count_rows_lds<GRAV>(D, pd, L, it.row0, nrows, w, wpb, lane, cIJ, cZZ, li + lo, lj + lo, lza + lo, lzb + lo,
+                                 TA, TB, tA, rowCnt + lo, maskPool + mo, prefPool + mo);
         else
-            count_rows<GRAV, false>(D, pd, L, it.row0, nrows, w, wpb, lane, li + lo, lj + lo, lza + lo, lzb + lo, li + lo, lj + lo, lza + lo, lzb + lo,
+            count_rows_global<GRAV>(D, pd, L, it.row0, nrows, w, wpb, lane, li + lo, lj + lo, lza + lo, lzb + lo,
                                     TA, TB, tA, rowCnt + lo, maskPool + mo, prefPool + mo);
     }
 }

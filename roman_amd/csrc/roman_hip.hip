@@ -228,15 +228,15 @@ int stage_score(roman_ctx* c, const DevParams& D, const BatchIn& in, std::vector
     HIPCHK(c, c->prefPool.ensure(sizeof(uint32_t) * (size_t)std::max<int64_t>(tot.maskWords, 1)));
 
     // pair-test kernel LDS: a column tile (objects [+ z] of every live association) + per-wave table rows
-    const int ldsPerWave = ((2 * std::max(maxN, 1) + 1) & ~1) + 2;
+    const int ldsPerWave = ((2 * std::max(maxN, 1) + 1 + 1) & ~1) + 2;    // n1 + sentinel + n2 doubles
     const int colBytesC = D.gravity ? 24 : 8;
-    const int Lneed = (std::max(tot.maxL, 1) + 63) & ~63;
+    const int Lneed = (std::max(tot.maxL, 1) + 255) & ~255;
     int wpb = 16;
-    while (wpb > 1 && (size_t)wpb * ldsPerWave * sizeof(double) + 64 * colBytesC > c->lds_max) wpb >>= 1;
-    if ((size_t)wpb * ldsPerWave * sizeof(double) + 64 * colBytesC > c->lds_max)
+    while (wpb > 1 && (size_t)wpb * ldsPerWave * sizeof(double) + 256 * colBytesC > c->lds_max) wpb >>= 1;
+    if ((size_t)wpb * ldsPerWave * sizeof(double) + 256 * colBytesC > c->lds_max)
         return fail(c, ROMAN_E_TOO_LARGE, "maps of %d objects exceed the LDS table staging of this build", maxN);
     const size_t tabLds = (size_t)wpb * ldsPerWave * sizeof(double);
-    int TCc = (int)std::min<size_t>((c->lds_max - tabLds) / colBytesC, 32768) & ~63;
+    int TCc = (int)std::min<size_t>((c->lds_max - tabLds) / colBytesC, 32768) & ~255;
     TCc = std::min(TCc, Lneed);
     const size_t pairLds = tabLds + (size_t)TCc * colBytesC;
     const int pairGrid = c->num_cu * std::max(1, std::min(2048 / (wpb * 64), (int)(c->lds_max / pairLds)));
