@@ -1025,6 +1025,134 @@ __device__ __noinline__ void heap_select_serial(const double* u, const int32_t* 
     }
 }
 
+// Tail shared by every solver variant: final u to the row pool, top-omega rounding (with the exact
+// heap emulation on ties), selected associations, Umeyama pose, statistics.  `u` is indexed by live
+// association (LDS or global); pv / pidx / nodesLive are scratch arrays of capacity L.
+__device__ __noinline__ void finish_one(const DevParams& D, int b, const ProbDesc& pd, const double* __restrict__ feats,
+                                        const int32_t* __restrict__ assoc, const int32_t* __restrict__ lp, const SolveOut& O,
+                                        const double* u, double* pv, int32_t* pidx, int32_t* nodesLive,
+                                        int L, int rb, int64_t lo, double F, int status, roman_stats_t S,
+                                        double* red, int* sint)
+{
+    const roman_params_t& P = D.p;
+    const int tid = threadIdx.x, nt = blockDim.x, nw = nt >> 6;
+    const int dim = P.point_dim;
+    int par = 0;
+    int nsel = 0;
+    __syncthreads();
+    if (L > 0) {
+        // final u to the row pool (stepwise API, tests)
+        for (int p = tid; p < L; p += nt) O.uOut[rb + p] = u[p];
+
+        // ---- top-omega rounding --------------------------------------------------------------
+        const double om = round(F);
+        int omega = (om >= 2147483647.0) ? 2147483647 : (om < 1.0 ? 0 : (int)om);
+        if (omega > pd.nA) omega = pd.nA;
+        int32_t* nodesOrig = O.nodesOrig + rb;        // capacity L
+        if (tid == 0) { sint[0] = 0; sint[1] = 0; }
+        __syncthreads();
+        if (omega > 0) {
+            // compact the positive entries (order irrelevant: ranks below are order-free)
+            for (int p = tid; p < L; p += nt) {
+                const double up = u[p];
+                if (up > 0.0) { const int pos = atomicAdd(&sint[0], 1); pv[pos] = up; pidx[pos] = p; }
+            }
+            __syncthreads();
+            const int Pn = sint[0];
+            bool fallback = (Pn < omega) || (omega > L);
+            if (!fallback) {
+                // rank of e = number of entries greater in (value, index) order
+                for (int e = tid; e < Pn; e += nt) {
+                    const double ve = pv[e]; const int ie = pidx[e];
+                    int rank = 0;
+                    for (int f2 = 0; f2 < Pn; ++f2) { const double vf = pv[f2]; rank += (vf > ve) || (vf == ve && pidx[f2] > ie); }
+                    if (rank < omega) nodesLive[rank] = ie;
+                    if (rank == omega - 1) { red[64] = ve; }
+                }
+                __syncthreads();
+                const double vstar = red[64];
+                int tie = 0;
+                for (int e = tid; e < Pn; e += nt) {
+                    if (pv[e] == vstar) {
+                        const double ve = pv[e]; const int ie = pidx[e];
+                        int rank = 0;
+                        for (int f2 = 0; f2 < Pn; ++f2) { const double vf = pv[f2]; rank += (vf > ve) || (vf == ve && pidx[f2] > ie); }
+                        if (rank >= omega) tie = 1;
+                    }
+                }
+                if (tie) atomicOr(&sint[1], 1);
+                __syncthreads();
+                fallback = sint[1] != 0;
+            }
+            if (fallback) {
+                status |= ROMAN_ST_TIE_FALLBACK;
+                __syncthreads();
+                if (tid == 0) {
+                    const int kk = min(omega, L);      // heap capacity bounded by the scratch size
+                    heap_select_serial(u, lp + lo, L, pd.nA, kk, pv, pidx, nodesOrig);
+                    sint[0] = kk;
+                }
+                __syncthreads();
+                nsel = sint[0];
+            } else {
+                nsel = omega;
+                for (int t = tid; t < nsel; t += nt) nodesOrig[t] = lp[lo + nodesLive[t]];
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- outputs: associations, pose, stats ------------------------------------------------------
+    const int32_t* nodesOrigR = O.nodesOrig + rb;
+    const int kout = min(nsel, O.kmax);
+    if (nsel > O.kmax) status |= ROMAN_ST_ASSOC_TRUNCATED;
+    for (int t = tid; t < kout; t += nt) {
+        int i, j;
+        decode_assoc(pd, assoc, nodesOrigR[t], i, j);
+        O.assoc_out[((int64_t)b * O.kmax + t) * 2 + 0] = i;
+        O.assoc_out[((int64_t)b * O.kmax + t) * 2 + 1] = j;
+    }
+    // pose from ALL selected associations ([REF object_registration.py:110-128], unit weights)
+    double Tp[16];
+    bool have_pose = false;
+    if (nsel >= dim && feats != nullptr && !(status & ROMAN_ST_EMPTY_MAP)) {
+        double m1[3] = {0, 0, 0}, m2[3] = {0, 0, 0};
+        for (int t = tid; t < nsel; t += nt) {
+            int i, j;
+            decode_assoc(pd, assoc, nodesOrigR[t], i, j);
+            const double* a = feats + (pd.off1 + i) * D.F; const double* bb = feats + (pd.off2 + j) * D.F;
+            for (int c = 0; c < dim; ++c) { m1[c] += a[c]; m2[c] += bb[c]; }
+        }
+        block_sum2(m1[0], m1[1], red, par, tid, nw); block_sum2(m1[2], m2[0], red, par, tid, nw); block_sum2(m2[1], m2[2], red, par, tid, nw);
+        for (int c = 0; c < 3; ++c) { m1[c] /= (double)nsel; m2[c] /= (double)nsel; }
+        double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (int t = tid; t < nsel; t += nt) {
+            int i, j;
+            decode_assoc(pd, assoc, nodesOrigR[t], i, j);
+            const double* a = feats + (pd.off1 + i) * D.F; const double* bb = feats + (pd.off2 + j) * D.F;
+            double q1[3] = {0, 0, 0}, q2[3] = {0, 0, 0};
+            for (int c = 0; c < dim; ++c) { q1[c] = a[c] - m1[c]; q2[c] = bb[c] - m2[c]; }
+            for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) H[r * 3 + c] += q1[r] * q2[c];
+        }
+        double z = 0.0;
+        block_sum2(H[0], H[1], red, par, tid, nw); block_sum2(H[2], H[3], red, par, tid, nw); block_sum2(H[4], H[5], red, par, tid, nw);
+        block_sum2(H[6], H[7], red, par, tid, nw); block_sum2(H[8], z, red, par, tid, nw);
+        if (tid == 0) write_pose(Tp, dim, H, m1, m2);
+        have_pose = true;
+    } else {
+        status |= ROMAN_ST_INSUFFICIENT;
+    }
+    if (tid == 0) {
+        for (int t = 0; t < 16; ++t) O.T_out[(int64_t)b * 16 + t] = have_pose ? Tp[t] : d_nan();
+        O.n_assoc_out[b] = kout;
+        O.status_out[b] = status;
+        O.nSel[b] = nsel;
+        if (O.stats_out) O.stats_out[b] = S;
+    }
+    __syncthreads();
+}
+
+
 /*
  * solve_one: CLIPPER findDenseClique on one problem, by one workgroup.
  * Mirrors oracle_solve() step for step (see there for the restated upstream algorithm):
@@ -1172,118 +1300,10 @@ __device__ void solve_one(const DevParams& D, int b, const ProbDesc& pd, ProbSta
         if (i >= P.maxoliters) status |= ROMAN_ST_MAXITER;
         S.outer_iters = i; S.score = F; S.d_final = d;
 
-        // final u to the row pool (stepwise API, tests)
-        for (int p = tid; p < L; p += nt) O.uOut[rb + p] = u[p];
-
-        // ---- top-omega rounding --------------------------------------------------------------
-        const double om = round(F);
-        int omega = (om >= 2147483647.0) ? 2147483647 : (om < 1.0 ? 0 : (int)om);
-        if (omega > pd.nA) omega = pd.nA;
-        int32_t* nodesOrig = O.nodesOrig + rb;        // capacity L
-        int32_t* nodesLive = (int32_t*)Cun;           // scratch (capacity L ints)
-        double*  pv = Mun;                            // scratch: positive values
-        int32_t* pidx = (int32_t*)un;                 // scratch: their live indices (un is free now)
-        if (tid == 0) { sint[0] = 0; sint[1] = 0; }
-        __syncthreads();
-        if (omega > 0) {
-            // compact the positive entries (order irrelevant: ranks below are order-free)
-            for (int p = tid; p < L; p += nt) {
-                const double up = u[p];
-                if (up > 0.0) { const int pos = atomicAdd(&sint[0], 1); pv[pos] = up; pidx[pos] = p; }
-            }
-            __syncthreads();
-            const int Pn = sint[0];
-            bool fallback = (Pn < omega) || (omega > L);
-            if (!fallback) {
-                // rank of e = number of entries greater in (value, index) order
-                for (int e = tid; e < Pn; e += nt) {
-                    const double ve = pv[e]; const int ie = pidx[e];
-                    int rank = 0;
-                    for (int f2 = 0; f2 < Pn; ++f2) { const double vf = pv[f2]; rank += (vf > ve) || (vf == ve && pidx[f2] > ie); }
-                    if (rank < omega) nodesLive[rank] = ie;
-                    if (rank == omega - 1) { red[64] = ve; }
-                }
-                __syncthreads();
-                const double vstar = red[64];
-                int tie = 0;
-                for (int e = tid; e < Pn; e += nt) {
-                    if (pv[e] == vstar) {
-                        const double ve = pv[e]; const int ie = pidx[e];
-                        int rank = 0;
-                        for (int f2 = 0; f2 < Pn; ++f2) { const double vf = pv[f2]; rank += (vf > ve) || (vf == ve && pidx[f2] > ie); }
-                        if (rank >= omega) tie = 1;
-                    }
-                }
-                if (tie) atomicOr(&sint[1], 1);
-                __syncthreads();
-                fallback = sint[1] != 0;
-            }
-            if (fallback) {
-                status |= ROMAN_ST_TIE_FALLBACK;
-                __syncthreads();
-                if (tid == 0) {
-                    const int kk = min(omega, L);      // heap capacity bounded by the scratch size
-                    heap_select_serial(u, lp + lo, L, pd.nA, kk, pv, pidx, nodesOrig);
-                    sint[0] = kk;
-                }
-                __syncthreads();
-                nsel = sint[0];
-            } else {
-                nsel = omega;
-                for (int t = tid; t < nsel; t += nt) nodesOrig[t] = lp[lo + nodesLive[t]];
-            }
-            __syncthreads();
-        }
+        finish_one(D, b, pd, feats, assoc, lp, O, u, Mun, (int32_t*)un, (int32_t*)Cun, L, rb, lo, F, status, S, red, sint);
+        return;
     }
-
-    // ---- outputs: associations, pose, stats ------------------------------------------------------
-    const int32_t* nodesOrigR = O.nodesOrig + rb;
-    const int kout = min(nsel, O.kmax);
-    if (nsel > O.kmax) status |= ROMAN_ST_ASSOC_TRUNCATED;
-    for (int t = tid; t < kout; t += nt) {
-        int i, j;
-        decode_assoc(pd, assoc, nodesOrigR[t], i, j);
-        O.assoc_out[((int64_t)b * O.kmax + t) * 2 + 0] = i;
-        O.assoc_out[((int64_t)b * O.kmax + t) * 2 + 1] = j;
-    }
-    // pose from ALL selected associations ([REF object_registration.py:110-128], unit weights)
-    double Tp[16];
-    bool have_pose = false;
-    if (nsel >= dim && feats != nullptr && !(status & ROMAN_ST_EMPTY_MAP)) {
-        double m1[3] = {0, 0, 0}, m2[3] = {0, 0, 0};
-        for (int t = tid; t < nsel; t += nt) {
-            int i, j;
-            decode_assoc(pd, assoc, nodesOrigR[t], i, j);
-            const double* a = feats + (pd.off1 + i) * D.F; const double* bb = feats + (pd.off2 + j) * D.F;
-            for (int c = 0; c < dim; ++c) { m1[c] += a[c]; m2[c] += bb[c]; }
-        }
-        block_sum2(m1[0], m1[1], red, par, tid, nw); block_sum2(m1[2], m2[0], red, par, tid, nw); block_sum2(m2[1], m2[2], red, par, tid, nw);
-        for (int c = 0; c < 3; ++c) { m1[c] /= (double)nsel; m2[c] /= (double)nsel; }
-        double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-        for (int t = tid; t < nsel; t += nt) {
-            int i, j;
-            decode_assoc(pd, assoc, nodesOrigR[t], i, j);
-            const double* a = feats + (pd.off1 + i) * D.F; const double* bb = feats + (pd.off2 + j) * D.F;
-            double q1[3] = {0, 0, 0}, q2[3] = {0, 0, 0};
-            for (int c = 0; c < dim; ++c) { q1[c] = a[c] - m1[c]; q2[c] = bb[c] - m2[c]; }
-            for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) H[r * 3 + c] += q1[r] * q2[c];
-        }
-        double z = 0.0;
-        block_sum2(H[0], H[1], red, par, tid, nw); block_sum2(H[2], H[3], red, par, tid, nw); block_sum2(H[4], H[5], red, par, tid, nw);
-        block_sum2(H[6], H[7], red, par, tid, nw); block_sum2(H[8], z, red, par, tid, nw);
-        if (tid == 0) write_pose(Tp, dim, H, m1, m2);
-        have_pose = true;
-    } else {
-        status |= ROMAN_ST_INSUFFICIENT;
-    }
-    if (tid == 0) {
-        for (int t = 0; t < 16; ++t) O.T_out[(int64_t)b * 16 + t] = have_pose ? Tp[t] : d_nan();
-        O.n_assoc_out[b] = kout;
-        O.status_out[b] = status;
-        O.nSel[b] = nsel;
-        if (O.stats_out) O.stats_out[b] = S;
-    }
-    __syncthreads();
+    finish_one(D, b, pd, feats, assoc, lp, O, nullptr, nullptr, nullptr, nullptr, L, rb, lo, F, status, S, red, sint);
 }
 
 template <typename IdxT, int MODE>
@@ -1320,6 +1340,390 @@ __global__ void __launch_bounds__(1024) k_solve(DevParams D, int B, const ProbDe
         else
             solve_one<IdxT, 0>(D, b, pd, st, feats, assoc, lp, ls, perm, sliceWidth, sliceBase, cols, vals,
                                vMu, vCu, vMun, vCun, gU, gUn, u0, O, sv, Lcap, red, sint);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Register-resident solver (L <= REG_NW*REG_NS*64 = 3072): the fast path.
+//
+// Thread (wave w, lane l) OWNS the rows in slot l of the wave's slices (slice_of(w, k), k < REG_NS;
+// boustrophedon over the length-sorted slices so every wave gets long and short ones).  Everything that
+// is per-row — u, M u, C u, the diagonal, the trial vector and its products — lives in that thread's
+// registers; only the two vectors that are GATHERED by the SpMV (u and the trial u') are in LDS, indexed
+// by live association.  A pass therefore costs three block reductions and no vector traffic.
+//
+// Column-compacted copies of the matrix ("levels").  The support of u collapses quickly (typically
+// L -> ~L/3 after two steps, -> the clique after the first homotopy update) and a column q with
+// u_q == 0 contributes exactly nothing to M u and C u.  Level 1 ("mid") and level 2 ("small") hold the
+// same rows as the full matrix (level 0) restricted to a column set K (a bitmap in LDS), in the same
+// slice geometry.  A pass over vector x may use a level iff supp(x) is a subset of its K — tested for
+// every trial vector while it is formed — so the result is bit-identical to the full pass (the kept
+// entries are accumulated in the same order); otherwise the pass falls back to the next larger level.
+// Levels are (re)built by the owning waves from the accepted u when the support has at least halved
+// and no association re-entered in the last step (twice in a row before the expensive build from the
+// full matrix).  Compaction is a single walk of the source level and can run in place.
+// ---------------------------------------------------------------------------------------------
+constexpr int REG_NW = 8;            // waves per problem (512 threads: 256 VGPRs per lane, two problems per CU)
+constexpr int REG_NS = 6;            // slices per wave held in registers: L <= REG_NW * REG_NS * 64
+
+__device__ __forceinline__ int slice_of(int w, int k) { return k * REG_NW + ((k & 1) ? REG_NW - 1 - w : w); }
+
+// Sum of N values over the block, identical in every thread; fixed reduction tree.  `red`: two
+// ping-pong areas of 64 doubles.
+template <int N>
+__device__ __forceinline__ void block_sumN(double (&v)[N], double* red, int& par, int tid)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+        for (int i = 0; i < N; ++i) v[i] += __shfl_xor(v[i], off);
+    double* rr = red + 64 * par;
+    par ^= 1;
+    if ((tid & 63) == 0) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) rr[N * (tid >> 6) + i] = v[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = 0.0;
+    for (int w = 0; w < REG_NW; ++w)
+#pragma unroll
+        for (int i = 0; i < N; ++i) v[i] += rr[N * w + i];
+}
+
+// (M_off x)_r and (C_off x)_r of the row in this lane's slot of one slice; x gathered from LDS.
+template <typename IdxT, int G>
+__device__ __noinline__ double2 spmv_slot(const double* x, uint32_t width, const IdxT* cp, const double* vp)
+{
+    const uint32_t ngroups = (width + G - 1) / G;
+    double am = 0.0, ac = 0.0;
+    uint32_t cA[G], cB[G]; double vA[G], vB[G];
+#define SLOT_ISSUE(e0, C_, V_)                                                         \
+    _Pragma("unroll") for (int t = 0; t < G; ++t) {                                    \
+        const bool a_ = ((e0) + t < width);                                            \
+        C_[t] = a_ ? (uint32_t)cp[((e0) + t) * 64u] : IdxTraits<IdxT>::CZ;             \
+        V_[t] = a_ ? vp[((e0) + t) * 64u] : 0.0;                                       \
+    }
+#define SLOT_CONSUME(C_, V_)                                                           \
+    _Pragma("unroll") for (int t = 0; t < G; ++t) {                                    \
+        const double xq_ = x[C_[t] & IdxTraits<IdxT>::MASK];                           \
+        am = fma(V_[t], xq_, am);                                                      \
+        ac += (C_[t] & IdxTraits<IdxT>::CZ) ? 0.0 : xq_;                               \
+    }
+    if (ngroups > 0) { SLOT_ISSUE(0u, cA, vA) }
+    for (uint32_t g = 0; g < ngroups; g += 2) {
+        if (g + 1 < ngroups) { SLOT_ISSUE((g + 1) * G, cB, vB) }
+        SLOT_CONSUME(cA, vA)
+        if (g + 1 < ngroups) {
+            if (g + 2 < ngroups) { SLOT_ISSUE((g + 2) * G, cA, vA) }
+            SLOT_CONSUME(cB, vB)
+        }
+    }
+#undef SLOT_ISSUE
+#undef SLOT_CONSUME
+    return make_double2(am, ac);
+}
+
+// One slice of the column compaction: keep the entries of this lane's row whose column is in the
+// support of x (and drop inert padding); returns the number kept.  Safe in place (write index <= read index).
+template <typename IdxT>
+__device__ __noinline__ uint32_t compact_slot(const double* x, uint32_t width, const IdxT* cs, const double* vs, IdxT* cd, double* vd)
+{
+    uint32_t cnt = 0;
+    constexpr int G = 8;
+    for (uint32_t e0 = 0; e0 < width; e0 += G) {
+        uint32_t c_[G]; double v_[G];
+#pragma unroll
+        for (int t = 0; t < G; ++t) {
+            const bool a_ = e0 + t < width;
+            c_[t] = a_ ? (uint32_t)cs[(e0 + t) * 64u] : IdxTraits<IdxT>::CZ;
+            v_[t] = a_ ? vs[(e0 + t) * 64u] : 0.0;
+        }
+#pragma unroll
+        for (int t = 0; t < G; ++t) {
+            const bool inert = (c_[t] & IdxTraits<IdxT>::CZ) && v_[t] == 0.0;
+            if (!inert && x[c_[t] & IdxTraits<IdxT>::MASK] > 0.0) {
+                cd[cnt * 64u] = (IdxT)c_[t]; vd[cnt * 64u] = v_[t]; ++cnt;
+            }
+        }
+    }
+    return cnt;
+}
+
+template <typename IdxT>
+struct RegLevels {
+    IdxT* cols[3]; double* vals[3];     // level 0 (full), 1 (mid), 2 (small): this problem's segment
+};
+
+template <typename IdxT>
+__device__ void solve_reg(const DevParams& D, int b, const ProbDesc& pd, ProbState* st,
+                          const double* __restrict__ feats, const int32_t* __restrict__ assoc,
+                          const int32_t* __restrict__ lp, const double* __restrict__ ls,
+                          const uint32_t* __restrict__ permPool, const uint32_t* __restrict__ sliceWidthPool,
+                          const uint32_t* __restrict__ sliceBasePool, const RegLevels<IdxT>& LV,
+                          const double* __restrict__ u0, const SolveOut& O,
+                          double* sU, double* sUn, int32_t* sScratch /* 2*Lcap ints */,
+                          uint32_t* sWid /* [3][48] */, uint32_t* sBase /* [48] */, unsigned long long* sK /* [2][48] */,
+                          double* red, int* sint)
+{
+    const roman_params_t& P = D.p;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int L = st[b].L, rb = st[b].rowBase;
+    const int64_t lo = pd.liveOff;
+    const int nsl = (L + 63) >> 6;
+    int par = 0;
+
+    int status = ROMAN_ST_OK;
+    roman_stats_t S;
+    S.n_assoc_in = pd.nA; S.n_live = L; S.nnz_upper = (int64_t)st[b].nnzUpper;
+    S.n_pass = 0; S.outer_iters = 0; S.inner_iters = 0; S.ls_trials = 0; S.score = 0.0; S.d_final = 0.0;
+    double F = 0.0, d = 0.0;
+    if (pd.n1 == 0 || pd.n2 == 0) status |= ROMAN_ST_EMPTY_MAP;
+    if (L <= 0) {
+        finish_one(D, b, pd, feats, assoc, lp, O, nullptr, nullptr, nullptr, nullptr, L, rb, lo, F, status, S, red, sint);
+        return;
+    }
+
+    // ---- slice geometry to LDS; this thread's rows -------------------------------------------------
+    __syncthreads();
+    for (int s = tid; s < nsl; s += blockDim.x) { sWid[s] = sliceWidthPool[lo + s]; sBase[s] = sliceBasePool[lo + s]; }
+    int row[REG_NS]; bool val[REG_NS]; int sl[REG_NS];
+    double u[REG_NS], sd[REG_NS], Mu[REG_NS], Cu[REG_NS], un[REG_NS], Mun[REG_NS], Cun[REG_NS];
+#pragma unroll
+    for (int k = 0; k < REG_NS; ++k) {
+        sl[k] = slice_of(w, k);
+        const int pos = (sl[k] << 6) + lane;
+        val[k] = sl[k] < nsl && pos < L;
+        row[k] = val[k] ? (int)permPool[lo + pos] : 0;
+        sd[k] = val[k] ? ls[lo + row[k]] : 0.0;
+        u[k] = val[k] ? (u0 ? u0[lo + lp[lo + row[k]]] : 1.0) : 0.0;
+        Mu[k] = Cu[k] = un[k] = Mun[k] = Cun[k] = 0.0;
+        if (val[k]) sU[row[k]] = u[k];
+    }
+    __syncthreads();
+
+    bool hasMid = false, hasSmall = false;
+    int nKmid = L, nKsmall = L, calm = 0;
+
+    // SpMV of the vector in `x` on level `lvl` into (am[], ac[])
+    auto spmv = [&](const double* x, int lvl, double (&am)[REG_NS], double (&ac)[REG_NS]) {
+#pragma unroll
+        for (int k = 0; k < REG_NS; ++k) {
+            if (sl[k] < nsl) {
+                const uint32_t width = sWid[lvl * 48 + sl[k]];
+                // lanes without a row (tail of the last slice) own no initialised slots: they walk nothing
+                const double2 r_ = spmv_slot<IdxT, 8>(x, val[k] ? width : 0u, LV.cols[lvl] + sBase[sl[k]] + lane, LV.vals[lvl] + sBase[sl[k]] + lane);
+                am[k] = r_.x; ac[k] = r_.y;
+            }
+        }
+        ++S.n_pass;
+    };
+    // level dst <- rows of level src restricted to the columns in supp(sU); K bitmap of dst; |K| = nS
+    auto compact = [&](int src, int dst, int nS) {
+#pragma unroll
+        for (int k = 0; k < REG_NS; ++k) {
+            if (sl[k] < nsl) {
+                const uint32_t width = sWid[src * 48 + sl[k]];
+                const IdxT* cs = LV.cols[src] + sBase[sl[k]] + lane; const double* vs = LV.vals[src] + sBase[sl[k]] + lane;
+                IdxT* cd = LV.cols[dst] + sBase[sl[k]] + lane; double* vd = LV.vals[dst] + sBase[sl[k]] + lane;
+                const uint32_t cnt = compact_slot<IdxT>(sU, val[k] ? width : 0u, cs, vs, cd, vd);
+                uint32_t wmax = cnt;
+                for (int off = 32; off > 0; off >>= 1) wmax = max(wmax, (uint32_t)__shfl_xor((int)wmax, off));
+                for (uint32_t e = cnt; e < wmax; ++e) { cd[e * 64u] = (IdxT)((uint32_t)row[k] | IdxTraits<IdxT>::CZ); vd[e * 64u] = 0.0; }
+                if (lane == 0) sWid[dst * 48 + sl[k]] = wmax;
+            }
+        }
+        for (int wd = w; wd < nsl; wd += REG_NW) {
+            const int p = (wd << 6) + lane;
+            const unsigned long long m = __ballot(p < L && sU[p] > 0.0);
+            if (lane == 0) sK[(dst - 1) * 48 + wd] = m;
+        }
+        if (dst == 1) { hasMid = true; nKmid = nS; hasSmall = false; } else { hasSmall = true; nKsmall = nS; }
+        __syncthreads();
+    };
+
+    // ---- initialisation: u = normalize(M u0 + diag u0) ---------------------------------------------
+    if (P.rescale_u0) {
+        spmv(sU, 0, Mu, Cu);
+        __syncthreads();                                        // every gather of the old u is done
+#pragma unroll
+        for (int k = 0; k < REG_NS; ++k) { u[k] = Mu[k] + sd[k] * u[k]; }
+    }
+    {
+        double r[1] = {0.0};
+#pragma unroll
+        for (int k = 0; k < REG_NS; ++k) r[0] += u[k] * u[k];
+        block_sumN<1>(r, red, par, tid);
+        const double nr = sqrt(r[0]);
+#pragma unroll
+        for (int k = 0; k < REG_NS; ++k) { if (nr > 0.0) u[k] /= nr; if (val[k]) sU[row[k]] = u[k]; }
+        __syncthreads();
+    }
+    spmv(sU, 0, Mu, Cu);
+    double usum;
+    {
+        double r[1] = {0.0};
+#pragma unroll
+        for (int k = 0; k < REG_NS; ++k) r[0] += u[k];
+        block_sumN<1>(r, red, par, tid);
+        usum = r[0];
+    }
+    {   // initial d: signed mean of (Mu)_p / Cbu_p over the active set
+        double r[2] = {0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < REG_NS; ++k) {
+            const double Cbu = (usum - Cu[k]) - u[k];
+            if (val[k] && Cbu > P.eps && u[k] > P.eps) { r[0] += (Mu[k] + sd[k] * u[k]) / Cbu; r[1] += 1.0; }
+        }
+        block_sumN<2>(r, red, par, tid);
+        d = (r[1] > 0.0) ? r[0] / r[1] : 0.0;
+    }
+    // ---- projected gradient ascent with homotopy on d -----------------------------------------------
+    double* xU = sU; double* xUn = sUn;                         // LDS: accepted vector / trial vector
+    int i;
+    for (i = 0; i < P.maxoliters; ++i) {
+        {
+            double r[1] = {0.0};
+#pragma unroll
+            for (int k = 0; k < REG_NS; ++k) {
+                const double g = (((sd[k] + d) * u[k] - d * usum) + Mu[k]) + Cu[k] * d;
+                r[0] += u[k] * g;
+            }
+            block_sumN<1>(r, red, par, tid);
+            F = r[0];
+        }
+        for (int j = 0; j < P.maxiniters; ++j) {
+            double alpha = 1.0, Fnew = 0.0, deltaF = 0.0, unsum = 0.0, du2 = 0.0;
+            double nS = 0.0, born = 0.0, vm = 0.0, vs = 0.0;
+            for (int kk = 0; kk < P.maxlsiters; ++kk) {
+                double t_[REG_NS];
+                {
+                    double r[1] = {0.0};
+#pragma unroll
+                    for (int k = 0; k < REG_NS; ++k) {
+                        const double g = (((sd[k] + d) * u[k] - d * usum) + Mu[k]) + Cu[k] * d;
+                        double t = u[k] + alpha * g;
+                        t = t > 0.0 ? t : 0.0;
+                        t_[k] = val[k] ? t : 0.0; r[0] += t_[k] * t_[k];
+                    }
+                    block_sumN<1>(r, red, par, tid);
+                    const double nr = sqrt(r[0]);
+                    double q[4] = {0.0, 0.0, 0.0, 0.0};         // sum u', |u'-u|^2, support/birth counts, level violations
+#pragma unroll
+                    for (int k = 0; k < REG_NS; ++k) {
+                        double t = t_[k];
+                        if (nr > 0.0) t /= nr;
+                        un[k] = t;
+                        q[0] += t;
+                        const double df = t - u[k]; q[1] += df * df;
+                        if (val[k]) {
+                            xUn[row[k]] = t;
+                            if (t > 0.0) {
+                                q[2] += 1.0;
+                                if (!(u[k] > 0.0)) q[2] += 4096.0;
+                                if (hasMid && !((sK[row[k] >> 6] >> (row[k] & 63)) & 1ull)) q[3] += 1.0;
+                                if (hasSmall && !((sK[48 + (row[k] >> 6)] >> (row[k] & 63)) & 1ull)) q[3] += 4096.0;
+                            }
+                        }
+                    }
+                    block_sumN<4>(q, red, par, tid);           // its barrier also publishes the trial vector
+                    unsum = q[0]; du2 = q[1];
+                    born = floor(q[2] / 4096.0); nS = q[2] - 4096.0 * born;
+                    vs = floor(q[3] / 4096.0); vm = q[3] - 4096.0 * vs;
+                }
+                const int lvl = (hasSmall && vs == 0.0) ? 2 : ((hasMid && vm == 0.0) ? 1 : 0);
+                spmv(xUn, lvl, Mun, Cun); ++S.ls_trials;
+                {
+                    double r[1] = {0.0};
+#pragma unroll
+                    for (int k = 0; k < REG_NS; ++k) {
+                        const double g = (((sd[k] + d) * un[k] - d * unsum) + Mun[k]) + Cun[k] * d;
+                        r[0] += un[k] * g;
+                    }
+                    block_sumN<1>(r, red, par, tid);
+                    Fnew = r[0];
+                }
+                deltaF = Fnew - F;
+                if (deltaF < -P.eps) alpha *= P.beta; else break;
+            }
+            const double du = sqrt(du2);
+            F = Fnew; usum = unsum;
+#pragma unroll
+            for (int k = 0; k < REG_NS; ++k) { u[k] = un[k]; Mu[k] = Mun[k]; Cu[k] = Cun[k]; }
+            { double* t = xU; xU = xUn; xUn = t; }
+            ++S.inner_iters;
+            const bool stop = du < P.tol_u || fabs(deltaF) < P.tol_F;
+            // ---- level maintenance (speed only: every level pass is exact) ---------------------------
+            calm = (born == 0.0) ? calm + 1 : 0;
+            if (!stop && calm > 0) {
+                const int ns = (int)nS;
+                const bool validMid = hasMid && vm == 0.0, validSmall = hasSmall && vs == 0.0;
+                // compaction reads the accepted vector from sU: make sure it is there
+                bool doit = false; int src = 0, dst = 1;
+                if (!validMid) { if (calm >= 2 && 2 * ns <= L) { doit = true; src = 0; dst = 1; } }
+                else if (validSmall) { if (2 * ns <= nKsmall) { doit = true; src = 2; dst = 2; } }
+                else if (2 * ns <= nKmid) { doit = true; src = 1; dst = 2; }
+                if (doit) {
+                    if (xU != sU) {                             // keep the accepted vector in sU (compaction and the K bitmap read sU)
+#pragma unroll
+                        for (int k = 0; k < REG_NS; ++k) if (val[k]) sU[row[k]] = u[k];
+                        xU = sU; xUn = sUn;
+                        __syncthreads();
+                    }
+                    compact(src, dst, ns);
+                }
+            }
+            if (stop) break;
+        }
+        double r[2] = {0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < REG_NS; ++k) {
+            const double Cbu = (usum - Cu[k]) - u[k];
+            if (val[k] && Cbu > P.eps && u[k] > P.eps) { r[0] += fabs((Mu[k] + sd[k] * u[k]) / Cbu); r[1] += 1.0; }
+        }
+        block_sumN<2>(r, red, par, tid);
+        if (r[1] > 0.0) d += r[0] / r[1]; else break;
+    }
+    if (i >= P.maxoliters) status |= ROMAN_ST_MAXITER;
+    S.outer_iters = i; S.score = F; S.d_final = d;
+    // finish_one starts with a barrier; the accepted vector is complete in xU; scratch: the other vector + ints
+    finish_one(D, b, pd, feats, assoc, lp, O, xU, xUn, sScratch, sScratch + ((L + 1) & ~1), L, rb, lo, F, status, S, red, sint);
+}
+
+template <typename IdxT>
+__global__ void __launch_bounds__(REG_NW * 64) k_solve_reg(DevParams D, int B, const ProbDesc* __restrict__ probs,
+                                                    ProbState* __restrict__ st,
+                                                    const double* __restrict__ feats, const int32_t* __restrict__ assoc,
+                                                    const int32_t* __restrict__ lp, const double* __restrict__ ls,
+                                                    const uint32_t* __restrict__ perm, const uint32_t* __restrict__ sliceWidth,
+                                                    const uint32_t* __restrict__ sliceBase,
+                                                    IdxT* cols0, double* vals0, IdxT* cols1, double* vals1, IdxT* cols2, double* vals2,
+                                                    const double* __restrict__ u0, SolveOut O,
+                                                    int* __restrict__ queue, int Lcap)
+{
+    // LDS: sU[Lcap] sUn[Lcap] | red[136] | sK[2][48] u64 | scratch ints[2*Lcap] | sWid[3][48] sBase[48] | sint[4]
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double* sU = reinterpret_cast<double*>(smem);
+    double* sUn = sU + Lcap;
+    double* red = sUn + Lcap;
+    unsigned long long* sK = reinterpret_cast<unsigned long long*>(red + 136);
+    int32_t* sScratch = reinterpret_cast<int32_t*>(sK + 96);
+    uint32_t* sWid = reinterpret_cast<uint32_t*>(sScratch + 2 * Lcap);
+    uint32_t* sBase = sWid + 144;
+    int* sint = reinterpret_cast<int*>(sBase + 48);
+    for (;;) {
+        if (threadIdx.x == 0) sint[2] = atomicAdd(queue, 1);
+        __syncthreads();
+        const int b = sint[2];
+        __syncthreads();
+        if (b >= B) break;
+        const ProbDesc pd = probs[b];
+        RegLevels<IdxT> LV;
+        const int64_t no = st[b].nnzOff;
+        LV.cols[0] = cols0 + no; LV.vals[0] = vals0 + no; LV.cols[1] = cols1 + no; LV.vals[1] = vals1 + no;
+        LV.cols[2] = cols2 + no; LV.vals[2] = vals2 + no;
+        solve_reg<IdxT>(D, b, pd, st, feats, assoc, lp, ls, perm, sliceWidth, sliceBase, LV, u0, O,
+                        sU, sUn, sScratch, sWid, sBase, sK, red, sint);
     }
 }
 

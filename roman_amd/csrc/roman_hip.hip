@@ -52,6 +52,7 @@ struct roman_ctx {
     DevBuf rowCnt, rowPos, perm, sliceWidth, sliceBase, items, maskPool, prefPool;
     DevBuf vMu, vCu, vMun, vCun, gU, gUn, uOut, nodesOrig, nSel;
     DevBuf cols, vals;
+    DevBuf cols1, vals1, cols2, vals2;      // column-compacted copies of the matrix (solver levels)
     // staging for the host-pointer entry points
     DevBuf hFeats, hAssoc, hU0, oAssoc, oN, oT, oStatus, oStats, hAux1, hAux2, hAux3;
     BatchTotals* pinnedTotals = nullptr;
@@ -301,17 +302,27 @@ int stage_solve(roman_ctx* c, const DevParams& D, int B, const double* feats, co
     HIPCHK(c, c->uOut.ensure(sizeof(double) * R1)); HIPCHK(c, c->nodesOrig.ensure(sizeof(int32_t) * R1));
     HIPCHK(c, c->nSel.ensure(sizeof(int32_t) * (size_t)B));
 
+    // fast path: register-resident solver with column-compacted levels (L <= 16 waves x REG_NS slices x 64)
+    const bool regPath = tot.maxL <= REG_NW * REG_NS * 64;
     // LDS: NVEC vectors of Lcap doubles + 72 doubles of reduction scratch + 4 ints
     const size_t fixed = 72 * sizeof(double) + 4 * sizeof(int);
     int Lcap = (std::max(tot.maxL, 64) + 1) & ~1;
-    int mode = 2;
-    if (7 * sizeof(double) * (size_t)Lcap + fixed > c->lds_max) mode = 1;
-    if (mode == 1 && 2 * sizeof(double) * (size_t)Lcap + fixed > c->lds_max) { mode = 0; Lcap = 0; }
-    const int nvec = mode == 2 ? 7 : (mode == 1 ? 2 : 0);
-    HIPCHK(c, c->gU.ensure(sizeof(double) * (mode == 0 ? R1 : 1))); HIPCHK(c, c->gUn.ensure(sizeof(double) * (mode == 0 ? R1 : 1)));
-    const size_t lds = (size_t)nvec * sizeof(double) * (size_t)Lcap + fixed;
-    const int nt = 1024;
-    const int grid = std::max(1, std::min(B, c->num_cu));
+    int mode = 1;
+    if (2 * sizeof(double) * (size_t)Lcap + fixed > c->lds_max) { mode = 0; Lcap = 0; }
+    if (regPath) Lcap = (std::max(tot.maxL, 64) + 1) & ~1;
+    const int nvec = mode == 1 ? 2 : 0;
+    HIPCHK(c, c->gU.ensure(sizeof(double) * ((mode == 0 && !regPath) ? R1 : 1))); HIPCHK(c, c->gUn.ensure(sizeof(double) * ((mode == 0 && !regPath) ? R1 : 1)));
+    size_t lds = (size_t)nvec * sizeof(double) * (size_t)Lcap + fixed;
+    if (regPath) {
+        lds = 2 * sizeof(double) * (size_t)Lcap + 136 * sizeof(double) + 96 * sizeof(unsigned long long) + 2 * sizeof(int32_t) * (size_t)Lcap
+              + (144 + 48) * sizeof(uint32_t) + 4 * sizeof(int);
+        const size_t nnz1 = (size_t)std::max<int64_t>(tot.nnzTotal, 1);
+        const size_t isz = idx16 ? sizeof(uint16_t) : sizeof(uint32_t);
+        HIPCHK(c, c->vals1.ensure(sizeof(double) * nnz1)); HIPCHK(c, c->cols1.ensure(isz * nnz1));
+        HIPCHK(c, c->vals2.ensure(sizeof(double) * nnz1)); HIPCHK(c, c->cols2.ensure(isz * nnz1));
+    }
+    const int nt = regPath ? REG_NW * 64 : 1024;
+    const int grid = std::max(1, std::min(B, c->num_cu * (regPath ? std::max(1, (int)std::min<size_t>(2, c->lds_max / lds)) : 1)));
 
     HIPCHK(c, hipMemsetAsync(c->queue.p, 0, sizeof(int) * 4, c->stream));
     SolveOut O;
@@ -327,8 +338,18 @@ int stage_solve(roman_ctx* c, const DevParams& D, int B, const double* feats, co
                            c->vMu.as<double>(), c->vCu.as<double>(), c->vMun.as<double>(), c->vCun.as<double>(), c->gU.as<double>(), c->gUn.as<double>(), \
                            u0, O, c->queue.as<int>(), Lcap);                                                                   \
     } while (0)
-    if (idx16) { if (mode == 2) ROMAN_LAUNCH_SOLVE(uint16_t, 2); else if (mode == 1) ROMAN_LAUNCH_SOLVE(uint16_t, 1); else ROMAN_LAUNCH_SOLVE(uint16_t, 0); }
-    else       { if (mode == 2) ROMAN_LAUNCH_SOLVE(uint32_t, 2); else if (mode == 1) ROMAN_LAUNCH_SOLVE(uint32_t, 1); else ROMAN_LAUNCH_SOLVE(uint32_t, 0); }
+#define ROMAN_LAUNCH_SOLVE_REG(IDX)                                                                                          \
+    do {                                                                                                                      \
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve_reg<IDX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((k_solve_reg<IDX>), dim3(grid), dim3(nt), lds, c->stream, D, B, c->probs.as<ProbDesc>(), c->state.as<ProbState>(), feats, assoc, \
+                           c->lp.as<int32_t>(), c->ls.as<double>(), c->perm.as<uint32_t>(), c->sliceWidth.as<uint32_t>(), c->sliceBase.as<uint32_t>(), \
+                           c->cols.as<IDX>(), c->vals.as<double>(), c->cols1.as<IDX>(), c->vals1.as<double>(), c->cols2.as<IDX>(), c->vals2.as<double>(), \
+                           u0, O, c->queue.as<int>(), Lcap);                                                                   \
+    } while (0)
+    if (regPath) { if (idx16) ROMAN_LAUNCH_SOLVE_REG(uint16_t); else ROMAN_LAUNCH_SOLVE_REG(uint32_t); }
+    else if (idx16) { if (mode == 1) ROMAN_LAUNCH_SOLVE(uint16_t, 1); else ROMAN_LAUNCH_SOLVE(uint16_t, 0); }
+    else            { if (mode == 1) ROMAN_LAUNCH_SOLVE(uint32_t, 1); else ROMAN_LAUNCH_SOLVE(uint32_t, 0); }
+#undef ROMAN_LAUNCH_SOLVE_REG
 #undef ROMAN_LAUNCH_SOLVE
     t3.stop();
     HIPCHK(c, hipGetLastError());
@@ -512,7 +533,7 @@ int roman_ctx_destroy(roman_ctx_t* c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     DevBuf* all[] = {&c->probs, &c->state, &c->totals, &c->queue, &c->cosPool, &c->normPool, &c->tabPool, &c->sTmp, &c->lp, &c->li, &c->lj, &c->ls, &c->lza, &c->lzb,
-                     &c->rowCnt, &c->rowPos, &c->perm, &c->sliceWidth, &c->sliceBase, &c->items, &c->maskPool, &c->prefPool, &c->vMu, &c->vCu, &c->vMun, &c->vCun, &c->gU, &c->gUn, &c->uOut, &c->nodesOrig, &c->nSel, &c->cols, &c->vals,
+                     &c->rowCnt, &c->rowPos, &c->perm, &c->sliceWidth, &c->sliceBase, &c->items, &c->maskPool, &c->prefPool, &c->vMu, &c->vCu, &c->vMun, &c->vCun, &c->gU, &c->gUn, &c->uOut, &c->nodesOrig, &c->nSel, &c->cols, &c->vals, &c->cols1, &c->vals1, &c->cols2, &c->vals2,
                      &c->hFeats, &c->hAssoc, &c->hU0, &c->oAssoc, &c->oN, &c->oT, &c->oStatus, &c->oStats, &c->hAux1, &c->hAux2, &c->hAux3};
     for (DevBuf* b : all) b->release();
     if (c->pinnedTotals) (void)hipHostFree(c->pinnedTotals);
