@@ -74,6 +74,21 @@ template <typename IdxT> struct IdxTraits;
 template <> struct IdxTraits<uint16_t> { static constexpr uint32_t CZ = 0x8000u; static constexpr uint32_t MASK = 0x7fffu; };
 template <> struct IdxTraits<uint32_t> { static constexpr uint32_t CZ = 0x80000000u; static constexpr uint32_t MASK = 0x7fffffffu; };
 
+// Position of entry e of the row in lane-slot `slot` of a slice that starts at element `sbase` of the
+// problem's matrix segment (sbase is a multiple of 256 in the quad layout, of 64 otherwise).
+//  - SELL-64 (QUAD == false):  sbase + e*64 + slot  for both arrays.
+//  - quad layout (QUAD == true, 16-bit indices, widths multiples of 4): the 4 column indices of entries
+//    4g..4g+3 of a lane are contiguous (one 8-byte load), the values of entries 2h, 2h+1 are contiguous
+//    (one 16-byte load): 3 wide loads per 4 entries instead of 8 narrow ones.
+template <bool QUAD> __device__ __forceinline__ int64_t col_pos(int64_t sbase, uint32_t slot, uint32_t e)
+{
+    return QUAD ? sbase + (int64_t)(e >> 2) * 256 + slot * 4 + (e & 3u) : sbase + (int64_t)e * 64 + slot;
+}
+template <bool QUAD> __device__ __forceinline__ int64_t val_pos(int64_t sbase, uint32_t slot, uint32_t e)
+{
+    return QUAD ? sbase + (int64_t)(e >> 1) * 128 + slot * 2 + (e & 1u) : sbase + (int64_t)e * 64 + slot;
+}
+
 // ---------------------------------------------------------------------------------------------
 // small helpers
 // ---------------------------------------------------------------------------------------------
@@ -593,7 +608,8 @@ __global__ void __launch_bounds__(1024) k_count(DevParams D, const ProbDesc* __r
 // ---------------------------------------------------------------------------------------------
 constexpr int SORT_KEYS = 8192;
 
-__global__ void __launch_bounds__(1024) k_rowsort(const ProbDesc* __restrict__ probs, ProbState* __restrict__ st,
+__global__ void __launch_bounds__(1024) k_rowsort(int widthPad /* 1, or 4 for the quad layout */,
+                                                  const ProbDesc* __restrict__ probs, ProbState* __restrict__ st,
                                                   const uint32_t* __restrict__ rowCnt,
                                                   uint32_t* __restrict__ rowPos, uint32_t* __restrict__ perm,
                                                   uint32_t* __restrict__ sliceWidth, uint32_t* __restrict__ sliceBase)
@@ -636,6 +652,7 @@ __global__ void __launch_bounds__(1024) k_rowsort(const ProbDesc* __restrict__ p
         if (s < nsl) {
             const int hi = min(L, (s << 6) + 64);
             for (int p = s << 6; p < hi; ++p) width = max(width, rowCnt[lo + perm[lo + p]]);
+            width = (width + (uint32_t)widthPad - 1u) / (uint32_t)widthPad * (uint32_t)widthPad;
             sliceWidth[lo + s] = width;
         }
         const uint32_t v = width * 64u;
@@ -676,7 +693,7 @@ __global__ void k_probscan(int B, ProbState* __restrict__ st, BatchTotals* __res
 // ---------------------------------------------------------------------------------------------
 constexpr int FILL_Q = 256;          // ring capacity per wave (>= 64 queued + 64 emitted per bit step)
 
-template <bool GRAV, typename IdxT, bool LDSCOL>
+template <bool GRAV, typename IdxT, bool LDSCOL, bool QUAD>
 __device__ __forceinline__ uint32_t fill_item(const DevParams& D, const ProbDesc& pd, int L, int row0, int nrows,
                                               int w, int wpb, int lane,
                                               const int32_t* cI, const int32_t* cJ, const double* cS,
@@ -719,12 +736,11 @@ __device__ __forceinline__ uint32_t fill_item(const DevParams& D, const ProbDesc
             const double v = fuse_pair(D, sa, cS[k], cS[q]);
             const bool keep = v > D.p.affinityeps;
             // an entry at or below affinityeps belongs neither to M nor to C: inert slot
-            uint32_t base;
+            uint32_t base;                                      // slice base + lane slot (base is a multiple of 64)
             if (LDSCOL) base = cBase[k];
             else { const uint32_t pos = rowPos[k]; base = sliceBase[pos >> 6] + (pos & 63u); }
-            const int64_t p = (int64_t)base + (int64_t)e * 64;
-            cols[p] = keep ? (IdxT)q : (IdxT)((uint32_t)k | IdxTraits<IdxT>::CZ);
-            vals[p] = keep ? v : 0.0;
+            cols[col_pos<QUAD>(base & ~63u, base & 63u, e)] = keep ? (IdxT)q : (IdxT)((QUAD ? (uint32_t)L : (uint32_t)k) | IdxTraits<IdxT>::CZ);
+            vals[val_pos<QUAD>(base & ~63u, base & 63u, e)] = keep ? v : 0.0;
             upper += (keep && q > k) ? 1u : 0u;
         }
         head = (head + take) & (FILL_Q - 1); queued -= take;
@@ -765,7 +781,7 @@ __device__ __forceinline__ uint32_t fill_item(const DevParams& D, const ProbDesc
     return upper;
 }
 
-template <bool GRAV, typename IdxT>
+template <bool GRAV, typename IdxT, bool QUAD>
 __global__ void __launch_bounds__(1024) k_fill(DevParams D, const ProbDesc* __restrict__ probs,
                                                ProbState* __restrict__ st,
                                                const BatchTotals* __restrict__ tot,
@@ -819,20 +835,32 @@ __global__ void __launch_bounds__(1024) k_fill(DevParams D, const ProbDesc* __re
         __syncthreads();
         uint32_t upper;
         if (ldscol)
-            upper = fill_item<GRAV, IdxT, true>(D, pd, L, it.row0, nrows, w, wpb, lane, cI, cJ, cS, cZa, cZb, cBase, TA, TB,
+            upper = fill_item<GRAV, IdxT, true, QUAD>(D, pd, L, it.row0, nrows, w, wpb, lane, cI, cJ, cS, cZa, cZb, cBase, TA, TB,
                                                 maskPool + mo, prefPool + mo, rowPos + lo, sliceBase + lo, qK, qQ, qE, cols + no, vals + no);
         else
-            upper = fill_item<GRAV, IdxT, false>(D, pd, L, it.row0, nrows, w, wpb, lane, li + lo, lj + lo, ls + lo, lza + lo, lzb + lo, nullptr, TA, TB,
+            upper = fill_item<GRAV, IdxT, false, QUAD>(D, pd, L, it.row0, nrows, w, wpb, lane, li + lo, lj + lo, ls + lo, lza + lo, lzb + lo, nullptr, TA, TB,
                                                  maskPool + mo, prefPool + mo, rowPos + lo, sliceBase + lo, qK, qQ, qE, cols + no, vals + no);
-        // pad every row's slot column up to its slice width with inert entries
+        // pad every row's slot column up to its slice width with inert entries (value 0, C-flag; the
+        // column is the row itself, or in the quad layout the dummy vector element L, which is always 0)
         for (int r = w; r < nrows; r += wpb) {
             const int k = it.row0 + r;
             const uint32_t pos = rowPos[lo + k];
             const uint32_t width = sliceWidth[lo + (pos >> 6)];
-            const int64_t base = no + sliceBase[lo + (pos >> 6)] + (pos & 63u);
+            const int64_t sb = no + sliceBase[lo + (pos >> 6)];
             for (uint32_t e = rowCnt[lo + k] + lane; e < width; e += WAVE) {
-                const int64_t p = base + (int64_t)e * 64;
-                cols[p] = (IdxT)((uint32_t)k | IdxTraits<IdxT>::CZ); vals[p] = 0.0;
+                cols[col_pos<QUAD>(sb, pos & 63u, e)] = (IdxT)((QUAD ? (uint32_t)L : (uint32_t)k) | IdxTraits<IdxT>::CZ);
+                vals[val_pos<QUAD>(sb, pos & 63u, e)] = 0.0;
+            }
+        }
+        if (QUAD && it.row0 + nrows == L && (L & 63)) {         // lane slots of the last slice that hold no row
+            const uint32_t sl = (uint32_t)(L >> 6);
+            const uint32_t width = sliceWidth[lo + sl];
+            const int64_t sb = no + sliceBase[lo + sl];
+            const uint32_t nfree = 64u - (uint32_t)(L & 63);
+            for (uint32_t x = tid; x < nfree * width; x += nt) {
+                const uint32_t slot = (uint32_t)(L & 63) + x / width, e = x % width;
+                cols[col_pos<QUAD>(sb, slot, e)] = (IdxT)((uint32_t)L | IdxTraits<IdxT>::CZ);
+                vals[val_pos<QUAD>(sb, slot, e)] = 0.0;
             }
         }
         for (int off = 32; off > 0; off >>= 1) upper += __shfl_xor(upper, off);
@@ -850,6 +878,7 @@ struct SolveOut {           // device pointers of the batch outputs
     int32_t* nodesOrig;     // row pool: selected nodes as original association indices
     int32_t* nSel;          // per problem: number of selected nodes (untruncated)
     double*  uOut;          // row pool: final u over live associations
+    unsigned long long* dbg;   // timing build only: 16 counters per problem
 };
 
 // Sum of (a, b) over the block, identical in every thread; fixed reduction tree.  `red` holds two
@@ -1343,128 +1372,160 @@ __global__ void __launch_bounds__(1024) k_solve(DevParams D, int B, const ProbDe
     }
 }
 
+#ifdef ROMAN_SOLVE_TIMING
+#define TMARK(slot) do { const unsigned long long t__ = __builtin_readcyclecounter(); tacc[slot] += t__ - tlast; tcnt[slot] += 1; tlast = t__; } while (0)
+#else
+#define TMARK(slot) do { } while (0)
+#endif
+
 // ---------------------------------------------------------------------------------------------
-// Register-resident solver (L <= REG_NW*REG_NS*64 = 3072): the fast path.
+// Streaming solver (L <= ST_NW*ST_NS*64 = 3072, 16-bit indices, quad layout): the fast path.
 //
-// Thread (wave w, lane l) OWNS the rows in slot l of the wave's slices (slice_of(w, k), k < REG_NS;
-// boustrophedon over the length-sorted slices so every wave gets long and short ones).  Everything that
-// is per-row — u, M u, C u, the diagonal, the trial vector and its products — lives in that thread's
-// registers; only the two vectors that are GATHERED by the SpMV (u and the trial u') are in LDS, indexed
-// by live association.  A pass therefore costs three block reductions and no vector traffic.
+// One 512-thread workgroup per problem.  Thread (wave w, lane l) OWNS the rows in lane-slot l of the
+// slices s = k*ST_NW + w: everything per-row (u, M u, C u, the diagonal, the trial products) lives in
+// that thread's registers; only the two vectors the SpMV GATHERS (u and the trial u') are in LDS,
+// indexed by live association, with a dummy element [L] == 0 that inert padding entries point to.
+//
+// SpMV as ONE balanced stream.  In the quad layout the slices of a level are contiguous in memory, so
+// the whole matrix is a sequence of T "quads" (4 entries x 64 lanes, 3 wide loads).  Wave w streams the
+// contiguous range [w*T/8, (w+1)*T/8) with ST_D quads in flight per lane, whatever slices it covers
+// (lane = row slot of the current slice); when the range crosses a slice boundary the running sums are
+// flushed to an LDS partial slot.  After a barrier the row owners add the partials of their slice in
+// stream order (fixed tree: deterministic).  Perfect balance although a few slices (the rows of the
+// consensus set have ~4x the average degree) hold a large share of the entries.
 //
 // Column-compacted copies of the matrix ("levels").  The support of u collapses quickly (typically
 // L -> ~L/3 after two steps, -> the clique after the first homotopy update) and a column q with
-// u_q == 0 contributes exactly nothing to M u and C u.  Level 1 ("mid") and level 2 ("small") hold the
-// same rows as the full matrix (level 0) restricted to a column set K (a bitmap in LDS), in the same
-// slice geometry.  A pass over vector x may use a level iff supp(x) is a subset of its K — tested for
-// every trial vector while it is formed — so the result is bit-identical to the full pass (the kept
-// entries are accumulated in the same order); otherwise the pass falls back to the next larger level.
-// Levels are (re)built by the owning waves from the accepted u when the support has at least halved
-// and no association re-entered in the last step (twice in a row before the expensive build from the
-// full matrix).  Compaction is a single walk of the source level and can run in place.
+// u_q == 0 contributes exactly nothing to M u and C u.  A level holds the rows of the full matrix
+// (level 0) restricted to a column set K (a bitmap in LDS), re-packed contiguously.  A pass over vector
+// x may use a level iff supp(x) is a subset of its K — tested for every trial vector while it is
+// formed — and then yields the same sums over the same non-zero terms in the same order; otherwise the
+// pass falls back to the next larger level.  Levels are (re)built from the accepted u when the support
+// has at least halved and no association re-entered in the last step (twice in a row before the
+// expensive build from the full matrix).
 // ---------------------------------------------------------------------------------------------
-constexpr int REG_NW = 8;            // waves per problem (512 threads: 256 VGPRs per lane, two problems per CU)
-constexpr int REG_NS = 6;            // slices per wave held in registers: L <= REG_NW * REG_NS * 64
+constexpr int ST_NW = 8;                 // waves per problem
+constexpr int ST_NS = 6;                 // row slots (slices) per wave
+constexpr int ST_D = 8;                  // quads in flight per lane
+constexpr int ST_MAXSL = ST_NW * ST_NS;  // 48 slices -> L <= 3072
+constexpr int ST_PB = ST_MAXSL + ST_NW;  // LDS partial slots
+constexpr int ST_CQ = ST_MAXSL + 1;      // entries of a quad-prefix row
+constexpr uint32_t ST_CZ = 0x8000u, ST_MASK = 0x7fffu;
 
-__device__ __forceinline__ int slice_of(int w, int k) { return k * REG_NW + ((k & 1) ? REG_NW - 1 - w : w); }
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double dpp_mov(double v)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, ROWMASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROWMASK, 0xf, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+// sum over the 64 lanes, valid in lane 63 (fixed tree: pairs, quads, rows of 16, then across rows)
+__device__ __forceinline__ double wave_sum63(double v)
+{
+    v += dpp_mov<0xB1, 0xf>(v);          // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E, 0xf>(v);          // quad_perm [2,3,0,1]
+    v += dpp_mov<0x124, 0xf>(v);         // row_ror:4
+    v += dpp_mov<0x128, 0xf>(v);         // row_ror:8
+    v += dpp_mov<0x142, 0xa>(v);         // row_bcast:15 -> rows 1,3
+    v += dpp_mov<0x143, 0xc>(v);         // row_bcast:31 -> rows 2,3
+    return v;
+}
+__device__ __forceinline__ double readlane63(double v)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)b, 63), hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
 
-// Sum of N values over the block, identical in every thread; fixed reduction tree.  `red`: two
-// ping-pong areas of 64 doubles.
+// Sum of N values over the 8 waves of the block, identical in every thread; fixed reduction tree.
+// `red`: two ping-pong areas of 64 doubles (a buffer is rewritten only after the barrier of the next call).
 template <int N>
 __device__ __forceinline__ void block_sumN(double (&v)[N], double* red, int& par, int tid)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1)
-#pragma unroll
-        for (int i = 0; i < N; ++i) v[i] += __shfl_xor(v[i], off);
     double* rr = red + 64 * par;
     par ^= 1;
-    if ((tid & 63) == 0) {
 #pragma unroll
-        for (int i = 0; i < N; ++i) rr[N * (tid >> 6) + i] = v[i];
+    for (int i = 0; i < N; ++i) {
+        const double s = readlane63(wave_sum63(v[i]));
+        if ((tid & 63) == 0) rr[N * (tid >> 6) + i] = s;
     }
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < N; ++i) v[i] = 0.0;
-    for (int w = 0; w < REG_NW; ++w)
+#pragma unroll
+    for (int w = 0; w < ST_NW; ++w)
 #pragma unroll
         for (int i = 0; i < N; ++i) v[i] += rr[N * w + i];
 }
 
-// (M_off x)_r and (C_off x)_r of the row in this lane's slot of one slice; x gathered from LDS.
-template <typename IdxT, int G>
-__device__ __noinline__ double2 spmv_slot(const double* x, uint32_t width, const IdxT* cp, const double* vp)
-{
-    const uint32_t ngroups = (width + G - 1) / G;
-    double am = 0.0, ac = 0.0;
-    uint32_t cA[G], cB[G]; double vA[G], vB[G];
-#define SLOT_ISSUE(e0, C_, V_)                                                         \
-    _Pragma("unroll") for (int t = 0; t < G; ++t) {                                    \
-        const bool a_ = ((e0) + t < width);                                            \
-        C_[t] = a_ ? (uint32_t)cp[((e0) + t) * 64u] : IdxTraits<IdxT>::CZ;             \
-        V_[t] = a_ ? vp[((e0) + t) * 64u] : 0.0;                                       \
-    }
-#define SLOT_CONSUME(C_, V_)                                                           \
-    _Pragma("unroll") for (int t = 0; t < G; ++t) {                                    \
-        const double xq_ = x[C_[t] & IdxTraits<IdxT>::MASK];                           \
-        am = fma(V_[t], xq_, am);                                                      \
-        ac += (C_[t] & IdxTraits<IdxT>::CZ) ? 0.0 : xq_;                               \
-    }
-    if (ngroups > 0) { SLOT_ISSUE(0u, cA, vA) }
-    for (uint32_t g = 0; g < ngroups; g += 2) {
-        if (g + 1 < ngroups) { SLOT_ISSUE((g + 1) * G, cB, vB) }
-        SLOT_CONSUME(cA, vA)
-        if (g + 1 < ngroups) {
-            if (g + 2 < ngroups) { SLOT_ISSUE((g + 2) * G, cA, vA) }
-            SLOT_CONSUME(cB, vB)
-        }
-    }
-#undef SLOT_ISSUE
-#undef SLOT_CONSUME
-    return make_double2(am, ac);
-}
+struct StreamLevels { uint16_t* cols[4]; double* vals[4]; };   // level 0 (full) + three compact buffers
 
-// One slice of the column compaction: keep the entries of this lane's row whose column is in the
-// support of x (and drop inert padding); returns the number kept.  Safe in place (write index <= read index).
-template <typename IdxT>
-__device__ __noinline__ uint32_t compact_slot(const double* x, uint32_t width, const IdxT* cs, const double* vs, IdxT* cd, double* vd)
+// Compaction, phase 1: number of entries of this lane's row (quads [qa,qb) of a slice) whose column is in
+// the support of x.  Inert padding points at the dummy element x[L] == 0 and is never kept.
+__device__ __noinline__ uint32_t level_count_slot(const double* x, const uint16_t* cols, uint32_t qa, uint32_t qb, int lane)
 {
+    const unsigned long long* cp = reinterpret_cast<const unsigned long long*>(cols) + lane;
     uint32_t cnt = 0;
-    constexpr int G = 8;
-    for (uint32_t e0 = 0; e0 < width; e0 += G) {
-        uint32_t c_[G]; double v_[G];
+    for (uint32_t q0 = qa; q0 < qb; q0 += 4) {
+        unsigned long long c[4];
 #pragma unroll
-        for (int t = 0; t < G; ++t) {
-            const bool a_ = e0 + t < width;
-            c_[t] = a_ ? (uint32_t)cs[(e0 + t) * 64u] : IdxTraits<IdxT>::CZ;
-            v_[t] = a_ ? vs[(e0 + t) * 64u] : 0.0;
-        }
+        for (int t = 0; t < 4; ++t) c[t] = (q0 + t < qb) ? cp[(size_t)(q0 + t) * 64] : 0xffffffffffffffffull;
 #pragma unroll
-        for (int t = 0; t < G; ++t) {
-            const bool inert = (c_[t] & IdxTraits<IdxT>::CZ) && v_[t] == 0.0;
-            if (!inert && x[c_[t] & IdxTraits<IdxT>::MASK] > 0.0) {
-                cd[cnt * 64u] = (IdxT)c_[t]; vd[cnt * 64u] = v_[t]; ++cnt;
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t cw = (uint32_t)(c[t] >> (16 * j)) & 0xffffu;
+                if (q0 + t < qb && x[cw & ST_MASK] > 0.0) ++cnt;
             }
-        }
     }
     return cnt;
 }
+// Compaction, phase 2: copy the kept entries of this lane's row to the quads starting at `qd` of the
+// destination level and pad up to `newWq` quads with inert entries.
+__device__ __noinline__ void level_copy_slot(const double* x, const uint16_t* cols, const double* vals, uint32_t qa, uint32_t qb,
+                                             uint16_t* dcols, double* dvals, uint32_t qd, uint32_t newWq, uint32_t inert, int lane)
+{
+    const unsigned long long* cp = reinterpret_cast<const unsigned long long*>(cols) + lane;
+    const double2* vp = reinterpret_cast<const double2*>(vals) + lane;
+    const int64_t db = (int64_t)qd * 256;
+    uint32_t cnt = 0;
+    for (uint32_t q0 = qa; q0 < qb; q0 += 2) {
+        unsigned long long c[2]; double2 v[2][2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const bool a_ = q0 + t < qb;
+            c[t] = a_ ? cp[(size_t)(q0 + t) * 64] : 0ull;
+            v[t][0] = a_ ? vp[(size_t)(2 * (q0 + t)) * 64] : make_double2(0.0, 0.0);
+            v[t][1] = a_ ? vp[(size_t)(2 * (q0 + t) + 1) * 64] : make_double2(0.0, 0.0);
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t cw = (uint32_t)(c[t] >> (16 * j)) & 0xffffu;
+                const double vv = (j == 0) ? v[t][0].x : (j == 1) ? v[t][0].y : (j == 2) ? v[t][1].x : v[t][1].y;
+                if (q0 + t < qb && x[cw & ST_MASK] > 0.0) {
+                    dcols[col_pos<true>(db, (uint32_t)lane, cnt)] = (uint16_t)cw;
+                    dvals[val_pos<true>(db, (uint32_t)lane, cnt)] = vv;
+                    ++cnt;
+                }
+            }
+    }
+    for (uint32_t e = cnt; e < newWq * 4; ++e) {
+        dcols[col_pos<true>(db, (uint32_t)lane, e)] = (uint16_t)inert;
+        dvals[val_pos<true>(db, (uint32_t)lane, e)] = 0.0;
+    }
+}
 
-template <typename IdxT>
-struct RegLevels {
-    IdxT* cols[3]; double* vals[3];     // level 0 (full), 1 (mid), 2 (small): this problem's segment
-};
-
-template <typename IdxT>
-__device__ void solve_reg(const DevParams& D, int b, const ProbDesc& pd, ProbState* st,
-                          const double* __restrict__ feats, const int32_t* __restrict__ assoc,
-                          const int32_t* __restrict__ lp, const double* __restrict__ ls,
-                          const uint32_t* __restrict__ permPool, const uint32_t* __restrict__ sliceWidthPool,
-                          const uint32_t* __restrict__ sliceBasePool, const RegLevels<IdxT>& LV,
-                          const double* __restrict__ u0, const SolveOut& O,
-                          double* sU, double* sUn, int32_t* sScratch /* 2*Lcap ints */,
-                          uint32_t* sWid /* [3][48] */, uint32_t* sBase /* [48] */, unsigned long long* sK /* [2][48] */,
-                          double* red, int* sint)
+template <bool HASCZ>
+__device__ void solve_stream(const DevParams& D, int b, const ProbDesc& pd, ProbState* st,
+                             const double* __restrict__ feats, const int32_t* __restrict__ assoc,
+                             const int32_t* __restrict__ lp, const double* __restrict__ ls,
+                             const uint32_t* __restrict__ permPool, const uint32_t* __restrict__ sliceBasePool,
+                             const StreamLevels& LV, const double* __restrict__ u0, const SolveOut& O,
+                             double* sU, double* sUn, double2* pbuf, unsigned long long* sK /* [2][48] */,
+                             uint32_t* cumQ /* [4][ST_CQ] */, uint32_t* tmpW /* [48] */, double* red, int* sint)
 {
     const roman_params_t& P = D.p;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -1483,234 +1544,337 @@ __device__ void solve_reg(const DevParams& D, int b, const ProbDesc& pd, ProbSta
         finish_one(D, b, pd, feats, assoc, lp, O, nullptr, nullptr, nullptr, nullptr, L, rb, lo, F, status, S, red, sint);
         return;
     }
+#ifdef ROMAN_SOLVE_TIMING
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tcnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tlast = __builtin_readcyclecounter();
+    const unsigned long long tstart = tlast;
+#endif
 
-    // ---- slice geometry to LDS; this thread's rows -------------------------------------------------
+    // ---- slice geometry of level 0 to LDS; this thread's rows ------------------------------------------
     __syncthreads();
-    for (int s = tid; s < nsl; s += blockDim.x) { sWid[s] = sliceWidthPool[lo + s]; sBase[s] = sliceBasePool[lo + s]; }
-    int row[REG_NS]; bool val[REG_NS]; int sl[REG_NS];
-    double u[REG_NS], sd[REG_NS], Mu[REG_NS], Cu[REG_NS], un[REG_NS], Mun[REG_NS], Cun[REG_NS];
+    for (int s = tid; s <= nsl; s += blockDim.x)
+        cumQ[s] = (s < nsl) ? (sliceBasePool[lo + s] >> 8) : (st[b].nnzCap >> 8);
+    int row[ST_NS]; bool val[ST_NS];
+    double u[ST_NS], sd[ST_NS], Mu[ST_NS], Cu[ST_NS], Mun[ST_NS], Cun[ST_NS];
 #pragma unroll
-    for (int k = 0; k < REG_NS; ++k) {
-        sl[k] = slice_of(w, k);
-        const int pos = (sl[k] << 6) + lane;
-        val[k] = sl[k] < nsl && pos < L;
-        row[k] = val[k] ? (int)permPool[lo + pos] : 0;
+    for (int k = 0; k < ST_NS; ++k) {
+        const int s = k * ST_NW + w;
+        const int pos = (s << 6) + lane;
+        val[k] = s < nsl && pos < L;
+        row[k] = val[k] ? (int)permPool[lo + pos] : L;            // rows that do not exist alias the dummy element
         sd[k] = val[k] ? ls[lo + row[k]] : 0.0;
         u[k] = val[k] ? (u0 ? u0[lo + lp[lo + row[k]]] : 1.0) : 0.0;
-        Mu[k] = Cu[k] = un[k] = Mun[k] = Cun[k] = 0.0;
+        Mu[k] = Cu[k] = Mun[k] = Cun[k] = 0.0;
         if (val[k]) sU[row[k]] = u[k];
     }
+    if (tid == 0) { sU[L] = 0.0; sUn[L] = 0.0; }
     __syncthreads();
 
     bool hasMid = false, hasSmall = false;
     int nKmid = L, nKsmall = L, calm = 0;
+    int lvMid = 1, lvSmall = 2, lvSpare = 3;
 
-    // SpMV of the vector in `x` on level `lvl` into (am[], ac[])
-    auto spmv = [&](const double* x, int lvl, double (&am)[REG_NS], double (&ac)[REG_NS]) {
+    // ---- one balanced SpMV stream over level `lvl`; results (am[], ac[]) for the owned rows ---------
+    auto spmv = [&](const double* x, int lvl, double (&am)[ST_NS], double (&ac)[ST_NS]) {
+        TMARK(3);
+        const uint32_t* cq = cumQ + lvl * ST_CQ;
+        const uint32_t T4 = cq[nsl];
+        const uint32_t qs = (uint32_t)(((unsigned long long)T4 * (unsigned)w) / ST_NW);
+        const uint32_t qe = (uint32_t)(((unsigned long long)T4 * (unsigned)(w + 1)) / ST_NW);
+        if (qs < qe) {
+            int s = 0;
+            while (cq[s + 1] <= qs) ++s;
+            uint32_t nextB = cq[s + 1];
+            const unsigned long long* cp = reinterpret_cast<const unsigned long long*>(LV.cols[lvl]) + lane;
+            const double2* vp = reinterpret_cast<const double2*>(LV.vals[lvl]) + lane;
+            unsigned long long rc[ST_D]; double2 rv0[ST_D], rv1[ST_D];
 #pragma unroll
-        for (int k = 0; k < REG_NS; ++k) {
-            if (sl[k] < nsl) {
-                const uint32_t width = sWid[lvl * 48 + sl[k]];
-                // lanes without a row (tail of the last slice) own no initialised slots: they walk nothing
-                const double2 r_ = spmv_slot<IdxT, 8>(x, val[k] ? width : 0u, LV.cols[lvl] + sBase[sl[k]] + lane, LV.vals[lvl] + sBase[sl[k]] + lane);
-                am[k] = r_.x; ac[k] = r_.y;
+            for (int t = 0; t < ST_D; ++t) {
+                if (qs + t < qe) {
+                    rc[t] = cp[(size_t)(qs + t) * 64];
+                    rv0[t] = vp[(size_t)(2 * (qs + t)) * 64]; rv1[t] = vp[(size_t)(2 * (qs + t) + 1) * 64];
+                }
             }
+            double sm = 0.0, sc = 0.0;
+            for (uint32_t q0 = qs; q0 < qe; q0 += ST_D) {
+#pragma unroll
+                for (int t = 0; t < ST_D; ++t) {
+                    const uint32_t q = q0 + t;
+                    if (q < qe) {
+                        const unsigned long long c = rc[t];
+                        const double2 v0 = rv0[t], v1 = rv1[t];
+                        if (q + ST_D < qe) {
+                            rc[t] = cp[(size_t)(q + ST_D) * 64];
+                            rv0[t] = vp[(size_t)(2 * (q + ST_D)) * 64]; rv1[t] = vp[(size_t)(2 * (q + ST_D) + 1) * 64];
+                        }
+                        const uint32_t clo = (uint32_t)c, chi = (uint32_t)(c >> 32);
+                        const double x0 = x[clo & ST_MASK], x1 = x[(clo >> 16) & ST_MASK];
+                        const double x2 = x[chi & ST_MASK], x3 = x[(chi >> 16) & ST_MASK];
+                        sm = fma(v0.x, x0, sm); sm = fma(v0.y, x1, sm); sm = fma(v1.x, x2, sm); sm = fma(v1.y, x3, sm);
+                        if (HASCZ) {
+                            sc += (clo & ST_CZ) ? 0.0 : x0; sc += (clo & (ST_CZ << 16)) ? 0.0 : x1;
+                            sc += (chi & ST_CZ) ? 0.0 : x2; sc += (chi & (ST_CZ << 16)) ? 0.0 : x3;
+                        } else {                                  // the only C-flagged entries are inert: they gather x[L] == 0
+                            sc += x0; sc += x1; sc += x2; sc += x3;
+                        }
+                        if (q + 1 == nextB || q + 1 == qe) {      // end of this slice's part of the range
+                            pbuf[(s + w) * 64 + lane] = make_double2(sm, sc);
+                            sm = 0.0; sc = 0.0;
+                            if (q + 1 < qe) { do { ++s; } while (cq[s + 1] <= q + 1); nextB = cq[s + 1]; }
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < ST_NS; ++k) {
+            const int s = k * ST_NW + w;
+            double a_ = 0.0, c_ = 0.0;
+            if (s < nsl) {
+                const uint32_t a0 = cq[s], a1 = cq[s + 1];
+                if (a1 > a0) {
+#pragma unroll
+                    for (int w2 = 0; w2 < ST_NW; ++w2) {
+                        const uint32_t s2 = (uint32_t)(((unsigned long long)T4 * (unsigned)w2) / ST_NW);
+                        const uint32_t e2 = (uint32_t)(((unsigned long long)T4 * (unsigned)(w2 + 1)) / ST_NW);
+                        if (s2 < e2 && s2 < a1 && e2 > a0) { const double2 p_ = pbuf[(s + w2) * 64 + lane]; a_ += p_.x; c_ += p_.y; }
+                    }
+                }
+            }
+            am[k] = val[k] ? a_ : 0.0; ac[k] = val[k] ? c_ : 0.0;
         }
         ++S.n_pass;
-    };
-    // level dst <- rows of level src restricted to the columns in supp(sU); K bitmap of dst; |K| = nS
-    auto compact = [&](int src, int dst, int nS) {
-#pragma unroll
-        for (int k = 0; k < REG_NS; ++k) {
-            if (sl[k] < nsl) {
-                const uint32_t width = sWid[src * 48 + sl[k]];
-                const IdxT* cs = LV.cols[src] + sBase[sl[k]] + lane; const double* vs = LV.vals[src] + sBase[sl[k]] + lane;
-                IdxT* cd = LV.cols[dst] + sBase[sl[k]] + lane; double* vd = LV.vals[dst] + sBase[sl[k]] + lane;
-                const uint32_t cnt = compact_slot<IdxT>(sU, val[k] ? width : 0u, cs, vs, cd, vd);
-                uint32_t wmax = cnt;
-                for (int off = 32; off > 0; off >>= 1) wmax = max(wmax, (uint32_t)__shfl_xor((int)wmax, off));
-                for (uint32_t e = cnt; e < wmax; ++e) { cd[e * 64u] = (IdxT)((uint32_t)row[k] | IdxTraits<IdxT>::CZ); vd[e * 64u] = 0.0; }
-                if (lane == 0) sWid[dst * 48 + sl[k]] = wmax;
-            }
-        }
-        for (int wd = w; wd < nsl; wd += REG_NW) {
-            const int p = (wd << 6) + lane;
-            const unsigned long long m = __ballot(p < L && sU[p] > 0.0);
-            if (lane == 0) sK[(dst - 1) * 48 + wd] = m;
-        }
-        if (dst == 1) { hasMid = true; nKmid = nS; hasSmall = false; } else { hasSmall = true; nKsmall = nS; }
-        __syncthreads();
+        TMARK(lvl == 0 ? 0 : (lvl == lvMid ? 1 : 2));
     };
 
-    // ---- initialisation: u = normalize(M u0 + diag u0) ---------------------------------------------
-    if (P.rescale_u0) {
-        spmv(sU, 0, Mu, Cu);
-        __syncthreads();                                        // every gather of the old u is done
-#pragma unroll
-        for (int k = 0; k < REG_NS; ++k) { u[k] = Mu[k] + sd[k] * u[k]; }
-    }
-    {
+    // ---- level dst <- rows of level src restricted to the columns in supp(sU) ---------------------------
+    auto compact = [&](int src, int dst, bool asMid, int nS) {
+        TMARK(3);
+        const uint32_t* cqs = cumQ + src * ST_CQ; uint32_t* cqd = cumQ + dst * ST_CQ;
+#pragma unroll 1
+        for (int k = 0; k < ST_NS; ++k) {
+            const int s = k * ST_NW + w;
+            if (s < nsl) {
+                uint32_t cnt = level_count_slot(sU, LV.cols[src], cqs[s], cqs[s + 1], lane);
+                for (int off = 32; off > 0; off >>= 1) cnt = max(cnt, (uint32_t)__shfl_xor((int)cnt, off));
+                if (lane == 0) tmpW[s] = (cnt + 3u) >> 2;
+            }
+        }
+        __syncthreads();
+        if (tid == 0) { uint32_t acc = 0; for (int s = 0; s < nsl; ++s) { cqd[s] = acc; acc += tmpW[s]; } cqd[nsl] = acc; }
+        __syncthreads();
+#pragma unroll 1
+        for (int k = 0; k < ST_NS; ++k) {
+            const int s = k * ST_NW + w;
+            if (s < nsl)
+                level_copy_slot(sU, LV.cols[src], LV.vals[src], cqs[s], cqs[s + 1], LV.cols[dst], LV.vals[dst], cqd[s], tmpW[s],
+                                (uint32_t)L | ST_CZ, lane);
+        }
+        for (int wd = w; wd < nsl; wd += ST_NW) {
+            const int p = (wd << 6) + lane;
+            const unsigned long long m = __ballot(p < L && sU[p] > 0.0);
+            if (lane == 0) sK[(asMid ? 0 : 1) * ST_MAXSL + wd] = m;
+        }
+        if (asMid) { hasMid = true; nKmid = nS; hasSmall = false; } else { hasSmall = true; nKsmall = nS; }
+        __syncthreads();
+        TMARK(4 + (src == 0 ? 0 : 1));
+    };
+
+    // ---- the iteration as a state machine around ONE SpMV call site ------------------------------------
+    double* xU = sU; double* xUn = sUn;                         // LDS: accepted vector / trial vector
+    enum { PH_RESCALE, PH_INIT, PH_TRIAL };
+    int phase = P.rescale_u0 ? PH_RESCALE : PH_INIT;
+    if (phase == PH_INIT) {                                     // no rescale: normalise u0 first
         double r[1] = {0.0};
 #pragma unroll
-        for (int k = 0; k < REG_NS; ++k) r[0] += u[k] * u[k];
+        for (int k = 0; k < ST_NS; ++k) r[0] += u[k] * u[k];
         block_sumN<1>(r, red, par, tid);
         const double nr = sqrt(r[0]);
 #pragma unroll
-        for (int k = 0; k < REG_NS; ++k) { if (nr > 0.0) u[k] /= nr; if (val[k]) sU[row[k]] = u[k]; }
+        for (int k = 0; k < ST_NS; ++k) { if (nr > 0.0) u[k] /= nr; if (val[k]) sU[row[k]] = u[k]; }
         __syncthreads();
     }
-    spmv(sU, 0, Mu, Cu);
-    double usum;
-    {
+    double usum = 0.0, alpha = 1.0, unsum = 0.0, du2 = 0.0, nS = 0.0, born = 0.0, vm = 0.0, vs = 0.0;
+    int i = 0, j = 0, kk = 0, lvlTrial = 0;
+
+    // trial vector u' = normalize(max(u + alpha g, 0)) into xUn (+ its sums, support and level tests)
+    auto build_trial = [&]() {
+        double t_[ST_NS];
         double r[1] = {0.0};
 #pragma unroll
-        for (int k = 0; k < REG_NS; ++k) r[0] += u[k];
-        block_sumN<1>(r, red, par, tid);
-        usum = r[0];
-    }
-    {   // initial d: signed mean of (Mu)_p / Cbu_p over the active set
-        double r[2] = {0.0, 0.0};
-#pragma unroll
-        for (int k = 0; k < REG_NS; ++k) {
-            const double Cbu = (usum - Cu[k]) - u[k];
-            if (val[k] && Cbu > P.eps && u[k] > P.eps) { r[0] += (Mu[k] + sd[k] * u[k]) / Cbu; r[1] += 1.0; }
+        for (int k = 0; k < ST_NS; ++k) {
+            const double g = (((sd[k] + d) * u[k] - d * usum) + Mu[k]) + Cu[k] * d;
+            double t = u[k] + alpha * g;
+            t = t > 0.0 ? t : 0.0;
+            t_[k] = val[k] ? t : 0.0; r[0] += t_[k] * t_[k];
         }
-        block_sumN<2>(r, red, par, tid);
-        d = (r[1] > 0.0) ? r[0] / r[1] : 0.0;
-    }
-    // ---- projected gradient ascent with homotopy on d -----------------------------------------------
-    double* xU = sU; double* xUn = sUn;                         // LDS: accepted vector / trial vector
-    int i;
-    for (i = 0; i < P.maxoliters; ++i) {
-        {
+        block_sumN<1>(r, red, par, tid);
+        const double nr = sqrt(r[0]);
+        double q[4] = {0.0, 0.0, 0.0, 0.0};                     // sum u', |u'-u|^2, support/birth counts, level violations
+#pragma unroll
+        for (int k = 0; k < ST_NS; ++k) {
+            double t = t_[k];
+            if (nr > 0.0) t /= nr;
+            q[0] += t;
+            const double df = t - u[k]; q[1] += df * df;
+            if (val[k]) {
+                xUn[row[k]] = t;
+                if (t > 0.0) {
+                    q[2] += 1.0;
+                    if (!(u[k] > 0.0)) q[2] += 4096.0;
+                    if (hasMid && !((sK[row[k] >> 6] >> (row[k] & 63)) & 1ull)) q[3] += 1.0;
+                    if (hasSmall && !((sK[ST_MAXSL + (row[k] >> 6)] >> (row[k] & 63)) & 1ull)) q[3] += 4096.0;
+                }
+            }
+        }
+        block_sumN<4>(q, red, par, tid);                       // its barrier also publishes the trial vector
+        unsum = q[0]; du2 = q[1];
+        born = floor(q[2] / 4096.0); nS = q[2] - 4096.0 * born;
+        vs = floor(q[3] / 4096.0); vm = q[3] - 4096.0 * vs;
+        lvlTrial = (hasSmall && vs == 0.0) ? lvSmall : ((hasMid && vm == 0.0) ? lvMid : 0);
+    };
+    auto objective = [&](const double (&uu)[ST_NS], const double (&mm)[ST_NS], const double (&cc)[ST_NS], double us) -> double {
+        double r[1] = {0.0};
+#pragma unroll
+        for (int k = 0; k < ST_NS; ++k) {
+            const double g = (((sd[k] + d) * uu[k] - d * us) + mm[k]) + cc[k] * d;
+            r[0] += uu[k] * g;
+        }
+        block_sumN<1>(r, red, par, tid);
+        return r[0];
+    };
+
+    for (;;) {
+        double am[ST_NS], ac[ST_NS];
+        spmv(phase == PH_TRIAL ? xUn : xU, phase == PH_TRIAL ? lvlTrial : 0, am, ac);
+        if (phase == PH_RESCALE) {                              // u = normalize(M u0 + diag u0)
             double r[1] = {0.0};
 #pragma unroll
-            for (int k = 0; k < REG_NS; ++k) {
-                const double g = (((sd[k] + d) * u[k] - d * usum) + Mu[k]) + Cu[k] * d;
-                r[0] += u[k] * g;
-            }
-            block_sumN<1>(r, red, par, tid);
-            F = r[0];
+            for (int k = 0; k < ST_NS; ++k) { u[k] = am[k] + sd[k] * u[k]; r[0] += u[k] * u[k]; }
+            block_sumN<1>(r, red, par, tid);                    // barrier: every gather of the old u is done
+            const double nr = sqrt(r[0]);
+#pragma unroll
+            for (int k = 0; k < ST_NS; ++k) { if (nr > 0.0) u[k] /= nr; if (val[k]) sU[row[k]] = u[k]; }
+            __syncthreads();
+            phase = PH_INIT;
+            continue;
         }
-        for (int j = 0; j < P.maxiniters; ++j) {
-            double alpha = 1.0, Fnew = 0.0, deltaF = 0.0, unsum = 0.0, du2 = 0.0;
-            double nS = 0.0, born = 0.0, vm = 0.0, vs = 0.0;
-            for (int kk = 0; kk < P.maxlsiters; ++kk) {
-                double t_[REG_NS];
-                {
-                    double r[1] = {0.0};
+        bool new_outer = false;
+        if (phase == PH_INIT) {
 #pragma unroll
-                    for (int k = 0; k < REG_NS; ++k) {
-                        const double g = (((sd[k] + d) * u[k] - d * usum) + Mu[k]) + Cu[k] * d;
-                        double t = u[k] + alpha * g;
-                        t = t > 0.0 ? t : 0.0;
-                        t_[k] = val[k] ? t : 0.0; r[0] += t_[k] * t_[k];
-                    }
-                    block_sumN<1>(r, red, par, tid);
-                    const double nr = sqrt(r[0]);
-                    double q[4] = {0.0, 0.0, 0.0, 0.0};         // sum u', |u'-u|^2, support/birth counts, level violations
+            for (int k = 0; k < ST_NS; ++k) { Mu[k] = am[k]; Cu[k] = ac[k]; }
+            double r1[1] = {0.0};
 #pragma unroll
-                    for (int k = 0; k < REG_NS; ++k) {
-                        double t = t_[k];
-                        if (nr > 0.0) t /= nr;
-                        un[k] = t;
-                        q[0] += t;
-                        const double df = t - u[k]; q[1] += df * df;
-                        if (val[k]) {
-                            xUn[row[k]] = t;
-                            if (t > 0.0) {
-                                q[2] += 1.0;
-                                if (!(u[k] > 0.0)) q[2] += 4096.0;
-                                if (hasMid && !((sK[row[k] >> 6] >> (row[k] & 63)) & 1ull)) q[3] += 1.0;
-                                if (hasSmall && !((sK[48 + (row[k] >> 6)] >> (row[k] & 63)) & 1ull)) q[3] += 4096.0;
-                            }
-                        }
-                    }
-                    block_sumN<4>(q, red, par, tid);           // its barrier also publishes the trial vector
-                    unsum = q[0]; du2 = q[1];
-                    born = floor(q[2] / 4096.0); nS = q[2] - 4096.0 * born;
-                    vs = floor(q[3] / 4096.0); vm = q[3] - 4096.0 * vs;
-                }
-                const int lvl = (hasSmall && vs == 0.0) ? 2 : ((hasMid && vm == 0.0) ? 1 : 0);
-                spmv(xUn, lvl, Mun, Cun); ++S.ls_trials;
-                {
-                    double r[1] = {0.0};
+            for (int k = 0; k < ST_NS; ++k) r1[0] += u[k];
+            block_sumN<1>(r1, red, par, tid);
+            usum = r1[0];
+            double r2[2] = {0.0, 0.0};                          // initial d: signed mean of (Mu)_p / Cbu_p over the active set
 #pragma unroll
-                    for (int k = 0; k < REG_NS; ++k) {
-                        const double g = (((sd[k] + d) * un[k] - d * unsum) + Mun[k]) + Cun[k] * d;
-                        r[0] += un[k] * g;
-                    }
-                    block_sumN<1>(r, red, par, tid);
-                    Fnew = r[0];
-                }
-                deltaF = Fnew - F;
-                if (deltaF < -P.eps) alpha *= P.beta; else break;
+            for (int k = 0; k < ST_NS; ++k) {
+                const double Cbu = (usum - Cu[k]) - u[k];
+                if (val[k] && Cbu > P.eps && u[k] > P.eps) { r2[0] += (Mu[k] + sd[k] * u[k]) / Cbu; r2[1] += 1.0; }
             }
+            block_sumN<2>(r2, red, par, tid);
+            d = (r2[1] > 0.0) ? r2[0] / r2[1] : 0.0;
+            i = 0;
+            if (i >= P.maxoliters) break;
+            new_outer = true;
+        } else {                                                // PH_TRIAL: products of the trial vector
+            ++S.ls_trials;
+            double un[ST_NS];
+#pragma unroll
+            for (int k = 0; k < ST_NS; ++k) un[k] = val[k] ? xUn[row[k]] : 0.0;
+            const double Fnew = objective(un, am, ac, unsum);
+            const double deltaF = Fnew - F;
+            if (deltaF < -P.eps && kk + 1 < P.maxlsiters) {     // backtrack
+                alpha *= P.beta; ++kk;
+                build_trial();
+                continue;
+            }
+            // accept
             const double du = sqrt(du2);
             F = Fnew; usum = unsum;
 #pragma unroll
-            for (int k = 0; k < REG_NS; ++k) { u[k] = un[k]; Mu[k] = Mun[k]; Cu[k] = Cun[k]; }
+            for (int k = 0; k < ST_NS; ++k) { u[k] = un[k]; Mu[k] = am[k]; Cu[k] = ac[k]; }
             { double* t = xU; xU = xUn; xUn = t; }
-            ++S.inner_iters;
+            ++S.inner_iters; ++j;
             const bool stop = du < P.tol_u || fabs(deltaF) < P.tol_F;
             // ---- level maintenance (speed only: every level pass is exact) ---------------------------
             calm = (born == 0.0) ? calm + 1 : 0;
-            if (!stop && calm > 0) {
+            if (!stop && j < P.maxiniters && calm > 0) {
                 const int ns = (int)nS;
                 const bool validMid = hasMid && vm == 0.0, validSmall = hasSmall && vs == 0.0;
-                // compaction reads the accepted vector from sU: make sure it is there
-                bool doit = false; int src = 0, dst = 1;
-                if (!validMid) { if (calm >= 2 && 2 * ns <= L) { doit = true; src = 0; dst = 1; } }
-                else if (validSmall) { if (2 * ns <= nKsmall) { doit = true; src = 2; dst = 2; } }
-                else if (2 * ns <= nKmid) { doit = true; src = 1; dst = 2; }
-                if (doit) {
-                    if (xU != sU) {                             // keep the accepted vector in sU (compaction and the K bitmap read sU)
+                int src = -1, dst = 0; bool asMid = false;
+                if (!validMid) { if (calm >= 2 && 2 * ns <= L) { src = 0; dst = lvMid; asMid = true; } }
+                else if (validSmall) { if (2 * ns <= nKsmall) { src = lvSmall; dst = lvSpare; } }
+                else if (2 * ns <= nKmid) { src = lvMid; dst = lvSmall; }
+                if (src >= 0) {
+                    if (xU != sU) {                             // compaction and the K bitmap read the accepted vector from sU
 #pragma unroll
-                        for (int k = 0; k < REG_NS; ++k) if (val[k]) sU[row[k]] = u[k];
+                        for (int k = 0; k < ST_NS; ++k) if (val[k]) sU[row[k]] = u[k];
                         xU = sU; xUn = sUn;
                         __syncthreads();
                     }
-                    compact(src, dst, ns);
+                    compact(src, dst, asMid, ns);
+                    if (src == lvSmall) { const int t = lvSmall; lvSmall = lvSpare; lvSpare = t; }
                 }
             }
-            if (stop) break;
-        }
-        double r[2] = {0.0, 0.0};
+            if (stop || j >= P.maxiniters) {                    // end of the inner loop: homotopy update of d
+                double r2[2] = {0.0, 0.0};
 #pragma unroll
-        for (int k = 0; k < REG_NS; ++k) {
-            const double Cbu = (usum - Cu[k]) - u[k];
-            if (val[k] && Cbu > P.eps && u[k] > P.eps) { r[0] += fabs((Mu[k] + sd[k] * u[k]) / Cbu); r[1] += 1.0; }
+                for (int k = 0; k < ST_NS; ++k) {
+                    const double Cbu = (usum - Cu[k]) - u[k];
+                    if (val[k] && Cbu > P.eps && u[k] > P.eps) { r2[0] += fabs((Mu[k] + sd[k] * u[k]) / Cbu); r2[1] += 1.0; }
+                }
+                block_sumN<2>(r2, red, par, tid);
+                if (r2[1] > 0.0) d += r2[0] / r2[1]; else break;
+                ++i;
+                if (i >= P.maxoliters) break;
+                new_outer = true;
+            }
         }
-        block_sumN<2>(r, red, par, tid);
-        if (r[1] > 0.0) d += r[0] / r[1]; else break;
+        if (new_outer) { F = objective(u, Mu, Cu, usum); j = 0; }
+        alpha = 1.0; kk = 0;
+        build_trial();
+        phase = PH_TRIAL;
     }
     if (i >= P.maxoliters) status |= ROMAN_ST_MAXITER;
     S.outer_iters = i; S.score = F; S.d_final = d;
-    // finish_one starts with a barrier; the accepted vector is complete in xU; scratch: the other vector + ints
-    finish_one(D, b, pd, feats, assoc, lp, O, xU, xUn, sScratch, sScratch + ((L + 1) & ~1), L, rb, lo, F, status, S, red, sint);
+#ifdef ROMAN_SOLVE_TIMING
+    TMARK(3);
+    if (tid == 0 && O.dbg) {
+        unsigned long long* dg = O.dbg + (size_t)b * 16;
+        for (int t = 0; t < 6; ++t) { dg[t] = tacc[t]; dg[8 + t] = tcnt[t]; }
+        dg[6] = __builtin_readcyclecounter() - tstart;
+    }
+#endif
+    // finish_one starts with a barrier; the accepted vector is complete in xU; scratch: the other vector + the partial buffer
+    int32_t* isc = reinterpret_cast<int32_t*>(pbuf);
+    finish_one(D, b, pd, feats, assoc, lp, O, xU, xUn, isc, isc + ((L + 1) & ~1), L, rb, lo, F, status, S, red, sint);
 }
 
-template <typename IdxT>
-__global__ void __launch_bounds__(REG_NW * 64) k_solve_reg(DevParams D, int B, const ProbDesc* __restrict__ probs,
-                                                    ProbState* __restrict__ st,
-                                                    const double* __restrict__ feats, const int32_t* __restrict__ assoc,
-                                                    const int32_t* __restrict__ lp, const double* __restrict__ ls,
-                                                    const uint32_t* __restrict__ perm, const uint32_t* __restrict__ sliceWidth,
-                                                    const uint32_t* __restrict__ sliceBase,
-                                                    IdxT* cols0, double* vals0, IdxT* cols1, double* vals1, IdxT* cols2, double* vals2,
-                                                    const double* __restrict__ u0, SolveOut O,
-                                                    int* __restrict__ queue, int Lcap)
+template <bool HASCZ>
+__global__ void __launch_bounds__(ST_NW * 64) k_solve_stream(DevParams D, int B, const ProbDesc* __restrict__ probs,
+                                                             ProbState* __restrict__ st,
+                                                             const double* __restrict__ feats, const int32_t* __restrict__ assoc,
+                                                             const int32_t* __restrict__ lp, const double* __restrict__ ls,
+                                                             const uint32_t* __restrict__ perm, const uint32_t* __restrict__ sliceBase,
+                                                             uint16_t* cols0, double* vals0, uint16_t* cols1, double* vals1,
+                                                             uint16_t* cols2, double* vals2, uint16_t* cols3, double* vals3,
+                                                             const double* __restrict__ u0, SolveOut O,
+                                                             int* __restrict__ queue, int Lcap)
 {
-    // LDS: sU[Lcap] sUn[Lcap] | red[136] | sK[2][48] u64 | scratch ints[2*Lcap] | sWid[3][48] sBase[48] | sint[4]
+    // LDS: sU[Lcap+2] sUn[Lcap+2] | pbuf[ST_PB][64] double2 | red[136] | sK[2][48] u64 | cumQ[4][49] (+4 pad) tmpW[48] | sint[4]
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* sU = reinterpret_cast<double*>(smem);
-    double* sUn = sU + Lcap;
-    double* red = sUn + Lcap;
+    double* sUn = sU + (Lcap + 2);
+    double2* pbuf = reinterpret_cast<double2*>(sUn + (Lcap + 2));
+    double* red = reinterpret_cast<double*>(pbuf + ST_PB * 64);
     unsigned long long* sK = reinterpret_cast<unsigned long long*>(red + 136);
-    int32_t* sScratch = reinterpret_cast<int32_t*>(sK + 96);
-    uint32_t* sWid = reinterpret_cast<uint32_t*>(sScratch + 2 * Lcap);
-    uint32_t* sBase = sWid + 144;
-    int* sint = reinterpret_cast<int*>(sBase + 48);
+    uint32_t* cumQ = reinterpret_cast<uint32_t*>(sK + 2 * ST_MAXSL);
+    uint32_t* tmpW = cumQ + 4 * ST_CQ + 4;
+    int* sint = reinterpret_cast<int*>(tmpW + ST_MAXSL);
     for (;;) {
         if (threadIdx.x == 0) sint[2] = atomicAdd(queue, 1);
         __syncthreads();
@@ -1718,12 +1882,12 @@ __global__ void __launch_bounds__(REG_NW * 64) k_solve_reg(DevParams D, int B, c
         __syncthreads();
         if (b >= B) break;
         const ProbDesc pd = probs[b];
-        RegLevels<IdxT> LV;
+        StreamLevels LV;
         const int64_t no = st[b].nnzOff;
         LV.cols[0] = cols0 + no; LV.vals[0] = vals0 + no; LV.cols[1] = cols1 + no; LV.vals[1] = vals1 + no;
-        LV.cols[2] = cols2 + no; LV.vals[2] = vals2 + no;
-        solve_reg<IdxT>(D, b, pd, st, feats, assoc, lp, ls, perm, sliceWidth, sliceBase, LV, u0, O,
-                        sU, sUn, sScratch, sWid, sBase, sK, red, sint);
+        LV.cols[2] = cols2 + no; LV.vals[2] = vals2 + no; LV.cols[3] = cols3 + no; LV.vals[3] = vals3 + no;
+        solve_stream<HASCZ>(D, b, pd, st, feats, assoc, lp, ls, perm, sliceBase, LV, u0, O,
+                            sU, sUn, pbuf, sK, cumQ, tmpW, red, sint);
     }
 }
 

@@ -52,7 +52,7 @@ struct roman_ctx {
     DevBuf rowCnt, rowPos, perm, sliceWidth, sliceBase, items, maskPool, prefPool;
     DevBuf vMu, vCu, vMun, vCun, gU, gUn, uOut, nodesOrig, nSel;
     DevBuf cols, vals;
-    DevBuf cols1, vals1, cols2, vals2;      // column-compacted copies of the matrix (solver levels)
+    DevBuf cols1, vals1, cols2, vals2, cols3, vals3;      // column-compacted copies of the matrix (solver levels)
     // staging for the host-pointer entry points
     DevBuf hFeats, hAssoc, hU0, oAssoc, oN, oT, oStatus, oStats, hAux1, hAux2, hAux3;
     BatchTotals* pinnedTotals = nullptr;
@@ -67,7 +67,7 @@ struct roman_ctx {
 
     // state of the last single-problem call (stepwise API for the clipperpy shim)
     struct Last {
-        bool scored = false, solved = false, idx16 = true, dense = false;
+        bool scored = false, solved = false, idx16 = true, dense = false, hascz = false;
         DevParams D;
         ProbDesc pd;
         BatchTotals tot;
@@ -103,6 +103,16 @@ double sqrt_threshold(double t)
     while (std::sqrt(x) < t) x = std::nextafter(x, INFINITY);
     return x;
 }
+
+// The streaming solver (k_solve_stream) and its quad matrix layout serve problems of up to ST_MAXSL*64
+// live associations; larger ones use the SELL-64 layout and the LDS/HBM-vector solver.
+bool use_quad(const DevParams& D, int maxL)
+{
+    return maxL <= ST_MAXSL * 64 && D.p.maxiniters >= 1 && D.p.maxlsiters >= 1;
+}
+// host twins of col_pos / val_pos (kernels.hip.h)
+inline size_t h_col_pos(bool quad, size_t sbase, uint32_t slot, uint32_t e) { return quad ? sbase + (size_t)(e >> 2) * 256 + slot * 4 + (e & 3u) : sbase + (size_t)e * 64 + slot; }
+inline size_t h_val_pos(bool quad, size_t sbase, uint32_t slot, uint32_t e) { return quad ? sbase + (size_t)(e >> 1) * 128 + slot * 2 + (e & 1u) : sbase + (size_t)e * 64 + slot; }
 
 int make_dev_params(roman_ctx* c, const roman_params_t* p, int32_t F, DevParams* D)
 {
@@ -250,7 +260,8 @@ int stage_score(roman_ctx* c, const DevParams& D, const BatchIn& in, std::vector
                            c->li.as<int32_t>(), c->lj.as<int32_t>(), c->lza.as<double>(), c->lzb.as<double>(),
                            c->rowCnt.as<uint32_t>(), c->maskPool.as<unsigned long long>(), c->prefPool.as<uint32_t>(), TCc, ldsPerWave, RPB);
     }
-    hipLaunchKernelGGL(k_rowsort, dim3(B), dim3(1024), 0, c->stream, dP, dS, c->rowCnt.as<uint32_t>(), c->rowPos.as<uint32_t>(), c->perm.as<uint32_t>(),
+    const bool quad = use_quad(D, tot.maxL);
+    hipLaunchKernelGGL(k_rowsort, dim3(B), dim3(1024), 0, c->stream, quad ? 4 : 1, dP, dS, c->rowCnt.as<uint32_t>(), c->rowPos.as<uint32_t>(), c->perm.as<uint32_t>(),
                        c->sliceWidth.as<uint32_t>(), c->sliceBase.as<uint32_t>());
     hipLaunchKernelGGL(k_probscan, dim3(1), dim3(64), 0, c->stream, B, dS, dT);
     // read-back #2: padded slot total -> size of the matrix arrays
@@ -272,16 +283,17 @@ int stage_score(roman_ctx* c, const DevParams& D, const BatchIn& in, std::vector
         TCf = std::min(TCf, Lneed);
         const size_t fillLds = ringLds + (size_t)TCf * colBytesF;
         const int fillGrid = c->num_cu * std::max(1, std::min(2, (int)(c->lds_max / fillLds)));
-#define ROMAN_LAUNCH_FILL(GRAV_, IDX)                                                                                          \
+#define ROMAN_LAUNCH_FILL(GRAV_, IDX, QUAD_)                                                                                          \
         do {                                                                                                                   \
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_fill<GRAV_, IDX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fillLds)); \
-        hipLaunchKernelGGL((k_fill<GRAV_, IDX>), dim3(fillGrid), dim3(1024), fillLds, c->stream, D, dP, dS, dT, c->items.as<ItemDesc>(), c->tabPool.as<double>(), \
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_fill<GRAV_, IDX, QUAD_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fillLds)); \
+        hipLaunchKernelGGL((k_fill<GRAV_, IDX, QUAD_>), dim3(fillGrid), dim3(1024), fillLds, c->stream, D, dP, dS, dT, c->items.as<ItemDesc>(), c->tabPool.as<double>(), \
                            c->li.as<int32_t>(), c->lj.as<int32_t>(), c->ls.as<double>(), c->lza.as<double>(), c->lzb.as<double>(),          \
                            c->rowCnt.as<uint32_t>(), c->maskPool.as<unsigned long long>(), c->prefPool.as<uint32_t>(), c->rowPos.as<uint32_t>(), \
                            c->sliceWidth.as<uint32_t>(), c->sliceBase.as<uint32_t>(), c->cols.as<IDX>(), c->vals.as<double>(), TCf, RPB);        \
         } while (0)
-        if (*idx16) { if (D.gravity) ROMAN_LAUNCH_FILL(true, uint16_t); else ROMAN_LAUNCH_FILL(false, uint16_t); }
-        else        { if (D.gravity) ROMAN_LAUNCH_FILL(true, uint32_t); else ROMAN_LAUNCH_FILL(false, uint32_t); }
+        if (quad)        { if (D.gravity) ROMAN_LAUNCH_FILL(true, uint16_t, true); else ROMAN_LAUNCH_FILL(false, uint16_t, true); }
+        else if (*idx16) { if (D.gravity) ROMAN_LAUNCH_FILL(true, uint16_t, false); else ROMAN_LAUNCH_FILL(false, uint16_t, false); }
+        else             { if (D.gravity) ROMAN_LAUNCH_FILL(true, uint32_t, false); else ROMAN_LAUNCH_FILL(false, uint32_t, false); }
 #undef ROMAN_LAUNCH_FILL
     }
     t2.stop();
@@ -292,7 +304,7 @@ int stage_score(roman_ctx* c, const DevParams& D, const BatchIn& in, std::vector
 // Stage B: solver + rounding + pose on the CSR held by the context.  `feats` may be NULL (dense
 // matrix problems have no points: the pose is skipped).
 int stage_solve(roman_ctx* c, const DevParams& D, int B, const double* feats, const int32_t* assoc,
-                const double* u0, const BatchTotals& tot, bool idx16, int32_t kmax,
+                const double* u0, const BatchTotals& tot, bool idx16, bool hascz, int32_t kmax,
                 int32_t* assoc_out, int32_t* n_assoc_out, double* T_out, int32_t* status_out,
                 roman_stats_t* stats_out)
 {
@@ -302,9 +314,9 @@ int stage_solve(roman_ctx* c, const DevParams& D, int B, const double* feats, co
     HIPCHK(c, c->uOut.ensure(sizeof(double) * R1)); HIPCHK(c, c->nodesOrig.ensure(sizeof(int32_t) * R1));
     HIPCHK(c, c->nSel.ensure(sizeof(int32_t) * (size_t)B));
 
-    // fast path: register-resident solver with column-compacted levels (L <= 16 waves x REG_NS slices x 64)
-    const bool regPath = tot.maxL <= REG_NW * REG_NS * 64;
-    // LDS: NVEC vectors of Lcap doubles + 72 doubles of reduction scratch + 4 ints
+    // fast path: streaming solver on the quad layout with column-compacted levels
+    const bool regPath = use_quad(D, tot.maxL);
+    // LDS of the fallback solver: NVEC vectors of Lcap doubles + 72 doubles of reduction scratch + 4 ints
     const size_t fixed = 72 * sizeof(double) + 4 * sizeof(int);
     int Lcap = (std::max(tot.maxL, 64) + 1) & ~1;
     int mode = 1;
@@ -314,20 +326,26 @@ int stage_solve(roman_ctx* c, const DevParams& D, int B, const double* feats, co
     HIPCHK(c, c->gU.ensure(sizeof(double) * ((mode == 0 && !regPath) ? R1 : 1))); HIPCHK(c, c->gUn.ensure(sizeof(double) * ((mode == 0 && !regPath) ? R1 : 1)));
     size_t lds = (size_t)nvec * sizeof(double) * (size_t)Lcap + fixed;
     if (regPath) {
-        lds = 2 * sizeof(double) * (size_t)Lcap + 136 * sizeof(double) + 96 * sizeof(unsigned long long) + 2 * sizeof(int32_t) * (size_t)Lcap
-              + (144 + 48) * sizeof(uint32_t) + 4 * sizeof(int);
+        lds = 2 * sizeof(double) * (size_t)(Lcap + 2) + (size_t)ST_PB * 64 * 2 * sizeof(double) + 136 * sizeof(double)
+              + 2 * ST_MAXSL * sizeof(unsigned long long) + (4 * ST_CQ + 4 + ST_MAXSL) * sizeof(uint32_t) + 4 * sizeof(int);
         const size_t nnz1 = (size_t)std::max<int64_t>(tot.nnzTotal, 1);
-        const size_t isz = idx16 ? sizeof(uint16_t) : sizeof(uint32_t);
-        HIPCHK(c, c->vals1.ensure(sizeof(double) * nnz1)); HIPCHK(c, c->cols1.ensure(isz * nnz1));
-        HIPCHK(c, c->vals2.ensure(sizeof(double) * nnz1)); HIPCHK(c, c->cols2.ensure(isz * nnz1));
+        HIPCHK(c, c->vals1.ensure(sizeof(double) * nnz1)); HIPCHK(c, c->cols1.ensure(sizeof(uint16_t) * nnz1));
+        HIPCHK(c, c->vals2.ensure(sizeof(double) * nnz1)); HIPCHK(c, c->cols2.ensure(sizeof(uint16_t) * nnz1));
+        HIPCHK(c, c->vals3.ensure(sizeof(double) * nnz1)); HIPCHK(c, c->cols3.ensure(sizeof(uint16_t) * nnz1));
     }
-    const int nt = regPath ? REG_NW * 64 : 1024;
-    const int grid = std::max(1, std::min(B, c->num_cu * (regPath ? std::max(1, (int)std::min<size_t>(2, c->lds_max / lds)) : 1)));
+    const int nt = regPath ? ST_NW * 64 : 1024;
+    const int grid = std::max(1, std::min(B, c->num_cu));
 
     HIPCHK(c, hipMemsetAsync(c->queue.p, 0, sizeof(int) * 4, c->stream));
     SolveOut O;
     O.assoc_out = assoc_out; O.n_assoc_out = n_assoc_out; O.T_out = T_out; O.status_out = status_out; O.stats_out = stats_out; O.kmax = kmax;
     O.nodesOrig = c->nodesOrig.as<int32_t>(); O.nSel = c->nSel.as<int32_t>(); O.uOut = c->uOut.as<double>();
+    O.dbg = nullptr;
+#ifdef ROMAN_SOLVE_TIMING
+    HIPCHK(c, c->hAux3.ensure(sizeof(unsigned long long) * 16 * (size_t)B));
+    HIPCHK(c, hipMemsetAsync(c->hAux3.p, 0, sizeof(unsigned long long) * 16 * (size_t)B, c->stream));
+    O.dbg = c->hAux3.as<unsigned long long>();
+#endif
 
     StageTimer t3(c, ROMAN_STAGE_SOLVE);
 #define ROMAN_LAUNCH_SOLVE(IDX, MODE_)                                                                                        \
@@ -338,21 +356,32 @@ int stage_solve(roman_ctx* c, const DevParams& D, int B, const double* feats, co
                            c->vMu.as<double>(), c->vCu.as<double>(), c->vMun.as<double>(), c->vCun.as<double>(), c->gU.as<double>(), c->gUn.as<double>(), \
                            u0, O, c->queue.as<int>(), Lcap);                                                                   \
     } while (0)
-#define ROMAN_LAUNCH_SOLVE_REG(IDX)                                                                                          \
+#define ROMAN_LAUNCH_SOLVE_STREAM(CZ_)                                                                                        \
     do {                                                                                                                      \
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve_reg<IDX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL((k_solve_reg<IDX>), dim3(grid), dim3(nt), lds, c->stream, D, B, c->probs.as<ProbDesc>(), c->state.as<ProbState>(), feats, assoc, \
-                           c->lp.as<int32_t>(), c->ls.as<double>(), c->perm.as<uint32_t>(), c->sliceWidth.as<uint32_t>(), c->sliceBase.as<uint32_t>(), \
-                           c->cols.as<IDX>(), c->vals.as<double>(), c->cols1.as<IDX>(), c->vals1.as<double>(), c->cols2.as<IDX>(), c->vals2.as<double>(), \
-                           u0, O, c->queue.as<int>(), Lcap);                                                                   \
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve_stream<CZ_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((k_solve_stream<CZ_>), dim3(grid), dim3(nt), lds, c->stream, D, B, c->probs.as<ProbDesc>(), c->state.as<ProbState>(), feats, assoc, \
+                           c->lp.as<int32_t>(), c->ls.as<double>(), c->perm.as<uint32_t>(), c->sliceBase.as<uint32_t>(), \
+                           c->cols.as<uint16_t>(), c->vals.as<double>(), c->cols1.as<uint16_t>(), c->vals1.as<double>(), c->cols2.as<uint16_t>(), c->vals2.as<double>(), \
+                           c->cols3.as<uint16_t>(), c->vals3.as<double>(), u0, O, c->queue.as<int>(), Lcap);                    \
     } while (0)
-    if (regPath) { if (idx16) ROMAN_LAUNCH_SOLVE_REG(uint16_t); else ROMAN_LAUNCH_SOLVE_REG(uint32_t); }
+    if (regPath) { if (hascz) ROMAN_LAUNCH_SOLVE_STREAM(true); else ROMAN_LAUNCH_SOLVE_STREAM(false); }
     else if (idx16) { if (mode == 1) ROMAN_LAUNCH_SOLVE(uint16_t, 1); else ROMAN_LAUNCH_SOLVE(uint16_t, 0); }
     else            { if (mode == 1) ROMAN_LAUNCH_SOLVE(uint32_t, 1); else ROMAN_LAUNCH_SOLVE(uint32_t, 0); }
-#undef ROMAN_LAUNCH_SOLVE_REG
+#undef ROMAN_LAUNCH_SOLVE_STREAM
 #undef ROMAN_LAUNCH_SOLVE
     t3.stop();
     HIPCHK(c, hipGetLastError());
+#ifdef ROMAN_SOLVE_TIMING
+    if (regPath) {
+        std::vector<unsigned long long> h((size_t)B * 16);
+        HIPCHK(c, hipMemcpyAsync(h.data(), c->hAux3.p, sizeof(unsigned long long) * 16 * (size_t)B, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        double acc[16] = {0}; double mx = 0;
+        for (int b = 0; b < B; ++b) { for (int t = 0; t < 16; ++t) acc[t] += (double)h[(size_t)b * 16 + t]; mx = std::max(mx, (double)h[(size_t)b * 16 + 6]); }
+        fprintf(stderr, "[solve timing] B=%d mean cycles/problem: spmv L0 %.0f (n=%.1f) L1 %.0f (n=%.1f) L2 %.0f (n=%.1f) other %.0f (n=%.1f) compact0 %.0f (n=%.2f) compactN %.0f (n=%.2f) total %.0f max %.0f\n",
+                B, acc[0] / B, acc[8] / B, acc[1] / B, acc[9] / B, acc[2] / B, acc[10] / B, acc[3] / B, acc[11] / B, acc[4] / B, acc[12] / B, acc[5] / B, acc[13] / B, acc[6] / B, mx);
+    }
+#endif
     return ROMAN_OK;
 }
 
@@ -382,7 +411,7 @@ int solve_last(roman_ctx* c, const double* u0_host)
     HIPCHK(c, c->oT.ensure(sizeof(double) * 16)); HIPCHK(c, c->oStatus.ensure(sizeof(int32_t))); HIPCHK(c, c->oStats.ensure(sizeof(roman_stats_t)));
     const double* feats = Lst.dense ? nullptr : c->hFeats.as<double>();
     const int32_t* assoc = (Lst.pd.assocOff >= 0) ? c->hAssoc.as<int32_t>() : nullptr;
-    int rc = stage_solve(c, Lst.D, 1, feats, assoc, dU0, Lst.tot, Lst.idx16, kmax, c->oAssoc.as<int32_t>(), c->oN.as<int32_t>(),
+    int rc = stage_solve(c, Lst.D, 1, feats, assoc, dU0, Lst.tot, Lst.idx16, Lst.hascz, kmax, c->oAssoc.as<int32_t>(), c->oN.as<int32_t>(),
                          c->oT.as<double>(), c->oStatus.as<int32_t>(), c->oStats.as<roman_stats_t>());
     if (rc) return rc;
     int32_t nsel = 0;
@@ -408,7 +437,7 @@ int solve_last(roman_ctx* c, const double* u0_host)
 }
 
 // Host twin of k_rowsort: sorted SELL-64 geometry from the row lengths (stable descending sort).
-void sell_geometry(const std::vector<uint32_t>& cnt, int L, std::vector<uint32_t>& rowPos, std::vector<uint32_t>& perm,
+void sell_geometry(const std::vector<uint32_t>& cnt, int L, int widthPad, std::vector<uint32_t>& rowPos, std::vector<uint32_t>& perm,
                    std::vector<uint32_t>& sliceWidth, std::vector<uint32_t>& sliceBase, uint64_t* total)
 {
     perm.resize((size_t)std::max(L, 1)); rowPos.assign((size_t)std::max(L, 1), 0);
@@ -421,6 +450,7 @@ void sell_geometry(const std::vector<uint32_t>& cnt, int L, std::vector<uint32_t
     for (int sl = 0; sl < nsl; ++sl) {
         uint32_t wmax = 0;
         for (int p = sl * 64; p < std::min(L, sl * 64 + 64); ++p) wmax = std::max(wmax, cnt[perm[(size_t)p]]);
+        wmax = (wmax + (uint32_t)widthPad - 1u) / (uint32_t)widthPad * (uint32_t)widthPad;
         sliceWidth[(size_t)sl] = wmax; sliceBase[(size_t)sl] = (uint32_t)acc; acc += (uint64_t)wmax * 64u;
     }
     *total = acc;
@@ -459,13 +489,13 @@ int fetch_last_csr(const roman_ctx* cc, std::vector<uint32_t>& rs, std::vector<u
         }
     }
     cols.clear(); vals.clear();
+    const bool quad = use_quad(Lst.D, Lst.tot.maxL);
     for (int k = 0; k < L; ++k) {
         const uint32_t pos = jpos[(size_t)k], sl = pos >> 6, slot = pos & 63u;
         rs[(size_t)k] = (uint32_t)cols.size();
         for (uint32_t e = 0; e < jcnt[(size_t)k]; ++e) {
-            const size_t p = (size_t)jsb[sl] + (size_t)e * 64 + slot;
-            const uint32_t cq = jcols[p]; const double v = jvals[p];
-            if (v == 0.0 && (cq & 0x80000000u) && (int)(cq & 0x7fffffffu) == k) continue;     // inert slot
+            const uint32_t cq = jcols[h_col_pos(quad, jsb[sl], slot, e)]; const double v = jvals[h_val_pos(quad, jsb[sl], slot, e)];
+            if (v == 0.0 && (cq & 0x80000000u) && (int)(cq & 0x7fffffffu) == (quad ? L : k)) continue;     // inert slot
             cols.push_back(cq); vals.push_back(v);
         }
         rl[(size_t)k] = (uint32_t)cols.size() - rs[(size_t)k];
@@ -533,7 +563,7 @@ int roman_ctx_destroy(roman_ctx_t* c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     DevBuf* all[] = {&c->probs, &c->state, &c->totals, &c->queue, &c->cosPool, &c->normPool, &c->tabPool, &c->sTmp, &c->lp, &c->li, &c->lj, &c->ls, &c->lza, &c->lzb,
-                     &c->rowCnt, &c->rowPos, &c->perm, &c->sliceWidth, &c->sliceBase, &c->items, &c->maskPool, &c->prefPool, &c->vMu, &c->vCu, &c->vMun, &c->vCun, &c->gU, &c->gUn, &c->uOut, &c->nodesOrig, &c->nSel, &c->cols, &c->vals, &c->cols1, &c->vals1, &c->cols2, &c->vals2,
+                     &c->rowCnt, &c->rowPos, &c->perm, &c->sliceWidth, &c->sliceBase, &c->items, &c->maskPool, &c->prefPool, &c->vMu, &c->vCu, &c->vMun, &c->vCun, &c->gU, &c->gUn, &c->uOut, &c->nodesOrig, &c->nSel, &c->cols, &c->vals, &c->cols1, &c->vals1, &c->cols2, &c->vals2, &c->cols3, &c->vals3,
                      &c->hFeats, &c->hAssoc, &c->hU0, &c->oAssoc, &c->oN, &c->oT, &c->oStatus, &c->oStats, &c->hAux1, &c->hAux2, &c->hAux3};
     for (DevBuf* b : all) b->release();
     if (c->pinnedTotals) (void)hipHostFree(c->pinnedTotals);
@@ -594,7 +624,7 @@ int roman_align_batch_dev(roman_ctx_t* c, const roman_params_t* params, int32_t 
     BatchTotals tot{}; bool idx16 = true;
     rc = stage_score(c, D, in, hd, &tot, &idx16);
     if (rc) return rc;
-    rc = stage_solve(c, D, B, feats, assoc, u0, tot, idx16, kmax, assoc_out, n_assoc_out, T_out, status_out, stats_out);
+    rc = stage_solve(c, D, B, feats, assoc, u0, tot, idx16, false, kmax, assoc_out, n_assoc_out, T_out, status_out, stats_out);
     if (rc) return rc;
     c->last.scored = false; c->last.solved = false;
     return ROMAN_OK;
@@ -668,7 +698,7 @@ int roman_score(roman_ctx_t* c, const roman_params_t* params, const double* D1, 
     if ((n1 > 0 && !D1) || (n2 > 0 && !D2)) return fail(c, ROMAN_E_INVALID, "NULL feature matrix");
     HIPCHK(c, hipSetDevice(c->device));
     roman_ctx::Last& Lst = c->last;
-    Lst.scored = false; Lst.solved = false; Lst.dense = false;
+    Lst.scored = false; Lst.solved = false; Lst.dense = false; Lst.hascz = false;
     int rc = make_dev_params(c, params, F, &Lst.D);
     if (rc) return rc;
     const int64_t nobj = (int64_t)n1 + n2;
@@ -728,24 +758,29 @@ int roman_set_matrix_data(roman_ctx_t* c, const roman_params_t* params, const do
         rl[(size_t)p_] = (uint32_t)cols.size() - rs[(size_t)p_];
         if (cols.size() > 4000000000ull) return fail(c, ROMAN_E_TOO_LARGE, "dense matrix has too many non-zeros");
     }
-    // re-order into the device's sorted SELL-64 layout
+    // re-order into the device's layout: sorted SELL-64, or the quad layout of the streaming solver
+    Lst.tot.maxL = n; Lst.tot.R = n;
+    const bool quad = use_quad(Lst.D, n);
     std::vector<uint32_t> rowPos, perm, sliceWidth, sliceBase; uint64_t total = 0;
     std::vector<uint32_t> cntv(rl.begin(), rl.begin() + std::max(n, 1));
-    sell_geometry(cntv, n, rowPos, perm, sliceWidth, sliceBase, &total);
+    sell_geometry(cntv, n, quad ? 4 : 1, rowPos, perm, sliceWidth, sliceBase, &total);
     if (total > 4000000000ull) return fail(c, ROMAN_E_TOO_LARGE, "dense matrix has too many non-zeros");
     std::vector<uint32_t> jcols((size_t)std::max<uint64_t>(total, 1), 0); std::vector<double> jvals((size_t)std::max<uint64_t>(total, 1), 0.0);
-    for (int k = 0; k < n; ++k) {
-        const uint32_t pos = rowPos[(size_t)k], sl = pos >> 6, slot = pos & 63u;
-        for (uint32_t e = 0; e < sliceWidth[sl]; ++e) {
-            const size_t p = (size_t)sliceBase[sl] + (size_t)e * 64 + slot;
-            if (e < rl[(size_t)k]) { jcols[p] = cols[(size_t)rs[(size_t)k] + e]; jvals[p] = vals[(size_t)rs[(size_t)k] + e]; }
-            else { jcols[p] = (uint32_t)k | czflag; jvals[p] = 0.0; }
+    bool anycz = false;
+    for (int sl = 0; sl < (n + 63) / 64; ++sl)
+        for (uint32_t slot = 0; slot < 64; ++slot) {
+            const int pos = sl * 64 + (int)slot;
+            const int k = pos < n ? (int)perm[(size_t)pos] : -1;                 // -1: lane slot without a row
+            const uint32_t inert = (quad ? (uint32_t)n : (uint32_t)std::max(k, 0)) | czflag;
+            for (uint32_t e = 0; e < sliceWidth[(size_t)sl]; ++e) {
+                const size_t pc = h_col_pos(quad, sliceBase[(size_t)sl], slot, e), pv = h_val_pos(quad, sliceBase[(size_t)sl], slot, e);
+                if (k >= 0 && e < rl[(size_t)k]) {
+                    jcols[pc] = cols[(size_t)rs[(size_t)k] + e]; jvals[pv] = vals[(size_t)rs[(size_t)k] + e];
+                    anycz = anycz || (jcols[pc] & czflag);
+                } else { jcols[pc] = inert; jvals[pv] = 0.0; }
+            }
         }
-    }
-    for (int sl = 0; sl < (n + 63) / 64; ++sl)                        // empty lanes of the last slice
-        for (int slot = 0; slot < 64; ++slot)
-            if (sl * 64 + slot >= n)
-                for (uint32_t e = 0; e < sliceWidth[(size_t)sl]; ++e) { jcols[(size_t)sliceBase[(size_t)sl] + (size_t)e * 64 + slot] = czflag; }
+    Lst.hascz = anycz;
     const size_t n1_ = (size_t)std::max(n, 1), nnz1 = (size_t)std::max<uint64_t>(total, 1), nsl1 = (size_t)std::max((n + 63) / 64, 1);
     HIPCHK(c, c->probs.ensure(sizeof(ProbDesc))); HIPCHK(c, c->state.ensure(sizeof(ProbState))); HIPCHK(c, c->queue.ensure(sizeof(int) * 4));
     HIPCHK(c, c->lp.ensure(sizeof(int32_t) * n1_)); HIPCHK(c, c->ls.ensure(sizeof(double) * n1_));
