@@ -1405,12 +1405,34 @@ __global__ void __launch_bounds__(1024) k_solve(DevParams D, int B, const ProbDe
 // expensive build from the full matrix).
 // ---------------------------------------------------------------------------------------------
 constexpr int ST_NW = 8;                 // waves per problem
-constexpr int ST_NS = 6;                 // row slots (slices) per wave
-constexpr int ST_D = 8;                  // quads in flight per lane
+constexpr int ST_NS = 6;                 // max row slots (slices) per wave; the kernel is instantiated for 4, 5 and 6
+constexpr int ST_D = 6;                  // quads in flight per lane
 constexpr int ST_MAXSL = ST_NW * ST_NS;  // 48 slices -> L <= 3072
 constexpr int ST_PB = ST_MAXSL + ST_NW;  // LDS partial slots
 constexpr int ST_CQ = ST_MAXSL + 1;      // entries of a quad-prefix row
 constexpr uint32_t ST_CZ = 0x8000u, ST_MASK = 0x7fffu;
+
+// Explicit address spaces for the hot pointers of the streaming solver: pointers that reach the loops
+// through run-time selected level tables would otherwise be compiled to FLAT accesses, whose results
+// count against lgkmcnt as well — every wait for an LDS gather would then drain the prefetched matrix
+// loads and serialise the stream.
+#define ROMAN_GLOBAL __attribute__((address_space(1)))
+#define ROMAN_LDS __attribute__((address_space(3)))
+typedef double dbl2_t __attribute__((ext_vector_type(2)));
+typedef const ROMAN_GLOBAL unsigned long long* g_quad_cp;    // 4 x u16 column indices of one lane
+typedef const ROMAN_GLOBAL dbl2_t* g_pair_cp;                // 2 x f64 values of one lane
+typedef const ROMAN_LDS double* l_vec_cp;                    // gathered vector in LDS
+
+// wave-uniform values that the compiler cannot prove uniform (read from LDS, derived from threadIdx):
+// force them into SGPRs so that loop control and matrix addressing run on the scalar unit
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ double uni(double v)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readfirstlane((int)b), hi = __builtin_amdgcn_readfirstlane((int)(b >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
 
 template <int CTRL, int ROWMASK>
 __device__ __forceinline__ double dpp_mov(double v)
@@ -1448,7 +1470,7 @@ __device__ __forceinline__ void block_sumN(double (&v)[N], double* red, int& par
 #pragma unroll
     for (int i = 0; i < N; ++i) {
         const double s = readlane63(wave_sum63(v[i]));
-        if ((tid & 63) == 0) rr[N * (tid >> 6) + i] = s;
+        if ((tid & 63) == 0) rr[N * uni(tid >> 6) + i] = s;
     }
     __syncthreads();
 #pragma unroll
@@ -1457,6 +1479,8 @@ __device__ __forceinline__ void block_sumN(double (&v)[N], double* red, int& par
     for (int w = 0; w < ST_NW; ++w)
 #pragma unroll
         for (int i = 0; i < N; ++i) v[i] += rr[N * w + i];
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = uni(v[i]);                // every lane holds the same value: keep it in SGPRs
 }
 
 struct StreamLevels { uint16_t* cols[4]; double* vals[4]; };   // level 0 (full) + three compact buffers
@@ -1465,19 +1489,27 @@ struct StreamLevels { uint16_t* cols[4]; double* vals[4]; };   // level 0 (full)
 // the support of x.  Inert padding points at the dummy element x[L] == 0 and is never kept.
 __device__ __noinline__ uint32_t level_count_slot(const double* x, const uint16_t* cols, uint32_t qa, uint32_t qb, int lane)
 {
-    const unsigned long long* cp = reinterpret_cast<const unsigned long long*>(cols) + lane;
+    g_quad_cp cp = (g_quad_cp)cols + lane;
+    l_vec_cp xl = (l_vec_cp)x;
     uint32_t cnt = 0;
-    for (uint32_t q0 = qa; q0 < qb; q0 += 4) {
-        unsigned long long c[4];
+    constexpr int DC = 8;
+    unsigned long long c[DC];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) c[t] = (q0 + t < qb) ? cp[(size_t)(q0 + t) * 64] : 0xffffffffffffffffull;
+    for (int t = 0; t < DC; ++t) c[t] = (qa + t < qb) ? cp[(size_t)(qa + t) * 64] : 0ull;
+    for (uint32_t q0 = qa; q0 < qb; q0 += DC) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < DC; ++t) {
+            const uint32_t q = q0 + t;
+            if (q < qb) {
+                const unsigned long long cc = c[t];
+                if (q + DC < qb) c[t] = cp[(size_t)(q + DC) * 64];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint32_t cw = (uint32_t)(c[t] >> (16 * j)) & 0xffffu;
-                if (q0 + t < qb && x[cw & ST_MASK] > 0.0) ++cnt;
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t cw = (uint32_t)(cc >> (16 * j)) & 0xffffu;
+                    cnt += (xl[cw & ST_MASK] > 0.0) ? 1u : 0u;
+                }
             }
+        }
     }
     return cnt;
 }
@@ -1486,50 +1518,59 @@ __device__ __noinline__ uint32_t level_count_slot(const double* x, const uint16_
 __device__ __noinline__ void level_copy_slot(const double* x, const uint16_t* cols, const double* vals, uint32_t qa, uint32_t qb,
                                              uint16_t* dcols, double* dvals, uint32_t qd, uint32_t newWq, uint32_t inert, int lane)
 {
-    const unsigned long long* cp = reinterpret_cast<const unsigned long long*>(cols) + lane;
-    const double2* vp = reinterpret_cast<const double2*>(vals) + lane;
+    g_quad_cp cp = (g_quad_cp)cols + lane;
+    g_pair_cp vp = (g_pair_cp)vals + lane;
+    l_vec_cp xl = (l_vec_cp)x;
+    ROMAN_GLOBAL uint16_t* dc = (ROMAN_GLOBAL uint16_t*)dcols;
+    ROMAN_GLOBAL double* dv = (ROMAN_GLOBAL double*)dvals;
     const int64_t db = (int64_t)qd * 256;
     uint32_t cnt = 0;
-    for (uint32_t q0 = qa; q0 < qb; q0 += 2) {
-        unsigned long long c[2]; double2 v[2][2];
+    constexpr int DC = 6;
+    unsigned long long c[DC]; dbl2_t v0[DC], v1[DC];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const bool a_ = q0 + t < qb;
-            c[t] = a_ ? cp[(size_t)(q0 + t) * 64] : 0ull;
-            v[t][0] = a_ ? vp[(size_t)(2 * (q0 + t)) * 64] : make_double2(0.0, 0.0);
-            v[t][1] = a_ ? vp[(size_t)(2 * (q0 + t) + 1) * 64] : make_double2(0.0, 0.0);
-        }
+    for (int t = 0; t < DC; ++t) {
+        if (qa + t < qb) { c[t] = cp[(size_t)(qa + t) * 64]; v0[t] = vp[(size_t)(2 * (qa + t)) * 64]; v1[t] = vp[(size_t)(2 * (qa + t) + 1) * 64]; }
+    }
+    for (uint32_t q0 = qa; q0 < qb; q0 += DC) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < DC; ++t) {
+            const uint32_t q = q0 + t;
+            if (q < qb) {
+                const unsigned long long cc = c[t];
+                const dbl2_t a0 = v0[t], a1 = v1[t];
+                if (q + DC < qb) { c[t] = cp[(size_t)(q + DC) * 64]; v0[t] = vp[(size_t)(2 * (q + DC)) * 64]; v1[t] = vp[(size_t)(2 * (q + DC) + 1) * 64]; }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint32_t cw = (uint32_t)(c[t] >> (16 * j)) & 0xffffu;
-                const double vv = (j == 0) ? v[t][0].x : (j == 1) ? v[t][0].y : (j == 2) ? v[t][1].x : v[t][1].y;
-                if (q0 + t < qb && x[cw & ST_MASK] > 0.0) {
-                    dcols[col_pos<true>(db, (uint32_t)lane, cnt)] = (uint16_t)cw;
-                    dvals[val_pos<true>(db, (uint32_t)lane, cnt)] = vv;
-                    ++cnt;
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t cw = (uint32_t)(cc >> (16 * j)) & 0xffffu;
+                    const double vv = (j == 0) ? a0.x : (j == 1) ? a0.y : (j == 2) ? a1.x : a1.y;
+                    if (xl[cw & ST_MASK] > 0.0) {
+                        dc[col_pos<true>(db, (uint32_t)lane, cnt)] = (uint16_t)cw;
+                        dv[val_pos<true>(db, (uint32_t)lane, cnt)] = vv;
+                        ++cnt;
+                    }
                 }
             }
+        }
     }
     for (uint32_t e = cnt; e < newWq * 4; ++e) {
-        dcols[col_pos<true>(db, (uint32_t)lane, e)] = (uint16_t)inert;
-        dvals[val_pos<true>(db, (uint32_t)lane, e)] = 0.0;
+        dc[col_pos<true>(db, (uint32_t)lane, e)] = (uint16_t)inert;
+        dv[val_pos<true>(db, (uint32_t)lane, e)] = 0.0;
     }
 }
 
-template <bool HASCZ>
+template <bool HASCZ, int NS>
 __device__ void solve_stream(const DevParams& D, int b, const ProbDesc& pd, ProbState* st,
                              const double* __restrict__ feats, const int32_t* __restrict__ assoc,
                              const int32_t* __restrict__ lp, const double* __restrict__ ls,
                              const uint32_t* __restrict__ permPool, const uint32_t* __restrict__ sliceBasePool,
                              const StreamLevels& LV, const double* __restrict__ u0, const SolveOut& O,
                              double* sU, double* sUn, double2* pbuf, unsigned long long* sK /* [2][48] */,
-                             uint32_t* cumQ /* [4][ST_CQ] */, uint32_t* tmpW /* [48] */, double* red, int* sint)
+                             uint32_t* cumQ /* [4][ST_CQ] */, uint32_t* tmpW /* [48] */, uint32_t* wQ /* [4][ST_NW+1] quad range starts */,
+                             uint32_t* wS /* [4][ST_NW] first slice of every wave's range */, double* red, int* sint)
 {
     const roman_params_t& P = D.p;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int L = st[b].L, rb = st[b].rowBase;
+    const int tid = threadIdx.x, lane = tid & 63, w = uni(tid >> 6);
+    const int L = uni(st[b].L), rb = uni(st[b].rowBase);
     const int64_t lo = pd.liveOff;
     const int nsl = (L + 63) >> 6;
     int par = 0;
@@ -1554,40 +1595,60 @@ __device__ void solve_stream(const DevParams& D, int b, const ProbDesc& pd, Prob
     __syncthreads();
     for (int s = tid; s <= nsl; s += blockDim.x)
         cumQ[s] = (s < nsl) ? (sliceBasePool[lo + s] >> 8) : (st[b].nnzCap >> 8);
-    int row[ST_NS]; bool val[ST_NS];
-    double u[ST_NS], sd[ST_NS], Mu[ST_NS], Cu[ST_NS], Mun[ST_NS], Cun[ST_NS];
+    // per-row state in registers: the diagonal and the products of the accepted vector; u itself is re-read
+    // from LDS (it has to be there for the gathers anyway) at the start of every element-wise phase
+    int row[NS]; bool val[NS];
+    double sd[NS], Mu[NS], Cu[NS];
 #pragma unroll
-    for (int k = 0; k < ST_NS; ++k) {
+    for (int k = 0; k < NS; ++k) {
         const int s = k * ST_NW + w;
         const int pos = (s << 6) + lane;
         val[k] = s < nsl && pos < L;
         row[k] = val[k] ? (int)permPool[lo + pos] : L;            // rows that do not exist alias the dummy element
         sd[k] = val[k] ? ls[lo + row[k]] : 0.0;
-        u[k] = val[k] ? (u0 ? u0[lo + lp[lo + row[k]]] : 1.0) : 0.0;
-        Mu[k] = Cu[k] = Mun[k] = Cun[k] = 0.0;
-        if (val[k]) sU[row[k]] = u[k];
+        Mu[k] = Cu[k] = 0.0;
+        if (val[k]) sU[row[k]] = u0 ? u0[lo + lp[lo + row[k]]] : 1.0;
     }
     if (tid == 0) { sU[L] = 0.0; sUn[L] = 0.0; }
     __syncthreads();
+    auto load_vec = [&](const double* x, double (&v)[NS]) {
+#pragma unroll
+        for (int k = 0; k < NS; ++k) v[k] = x[row[k]];         // row == L (dummy, always 0) for rows that do not exist
+    };
 
     bool hasMid = false, hasSmall = false;
     int nKmid = L, nKsmall = L, calm = 0;
     int lvMid = 1, lvSmall = 2, lvSpare = 3;
+    // per level: the balanced quad range of every wave and the slice its range starts in (cumQ[lvl] must be final)
+    auto index_level = [&](int lvl) {
+        if (tid <= ST_NW) {
+            const uint32_t* cq = cumQ + lvl * ST_CQ;
+            const uint32_t T4 = cq[nsl];
+            const uint32_t qs = (uint32_t)(((unsigned long long)T4 * (unsigned)tid) / ST_NW);
+            wQ[lvl * (ST_NW + 1) + tid] = qs;
+            if (tid < ST_NW) {
+                int lo_ = 0, hi_ = nsl;                         // largest s with cq[s] <= qs, skipping empty slices (cq[s+1] > qs)
+                while (hi_ - lo_ > 1) { const int mid_ = (lo_ + hi_) >> 1; if (cq[mid_] <= qs) lo_ = mid_; else hi_ = mid_; }
+                wS[lvl * ST_NW + tid] = (uint32_t)lo_;
+            }
+        }
+    };
+    index_level(0);
+    __syncthreads();
 
     // ---- one balanced SpMV stream over level `lvl`; results (am[], ac[]) for the owned rows ---------
-    auto spmv = [&](const double* x, int lvl, double (&am)[ST_NS], double (&ac)[ST_NS]) {
+    auto spmv = [&](const double* x, int lvl, double (&am)[NS], double (&ac)[NS]) {
         TMARK(3);
         const uint32_t* cq = cumQ + lvl * ST_CQ;
-        const uint32_t T4 = cq[nsl];
-        const uint32_t qs = (uint32_t)(((unsigned long long)T4 * (unsigned)w) / ST_NW);
-        const uint32_t qe = (uint32_t)(((unsigned long long)T4 * (unsigned)(w + 1)) / ST_NW);
+        const uint32_t* wq = wQ + lvl * (ST_NW + 1);
+        const uint32_t qs = uni(wq[w]), qe = uni(wq[w + 1]);
         if (qs < qe) {
-            int s = 0;
-            while (cq[s + 1] <= qs) ++s;
-            uint32_t nextB = cq[s + 1];
-            const unsigned long long* cp = reinterpret_cast<const unsigned long long*>(LV.cols[lvl]) + lane;
-            const double2* vp = reinterpret_cast<const double2*>(LV.vals[lvl]) + lane;
-            unsigned long long rc[ST_D]; double2 rv0[ST_D], rv1[ST_D];
+            int s = uni((int)wS[lvl * ST_NW + w]);
+            uint32_t nextB = uni(cq[s + 1]);
+            g_quad_cp cp = (g_quad_cp)LV.cols[lvl] + lane;
+            g_pair_cp vp = (g_pair_cp)LV.vals[lvl] + lane;
+            l_vec_cp xl = (l_vec_cp)x;
+            unsigned long long rc[ST_D]; dbl2_t rv0[ST_D], rv1[ST_D];
 #pragma unroll
             for (int t = 0; t < ST_D; ++t) {
                 if (qs + t < qe) {
@@ -1602,14 +1663,14 @@ __device__ void solve_stream(const DevParams& D, int b, const ProbDesc& pd, Prob
                     const uint32_t q = q0 + t;
                     if (q < qe) {
                         const unsigned long long c = rc[t];
-                        const double2 v0 = rv0[t], v1 = rv1[t];
+                        const dbl2_t v0 = rv0[t], v1 = rv1[t];
                         if (q + ST_D < qe) {
                             rc[t] = cp[(size_t)(q + ST_D) * 64];
                             rv0[t] = vp[(size_t)(2 * (q + ST_D)) * 64]; rv1[t] = vp[(size_t)(2 * (q + ST_D) + 1) * 64];
                         }
                         const uint32_t clo = (uint32_t)c, chi = (uint32_t)(c >> 32);
-                        const double x0 = x[clo & ST_MASK], x1 = x[(clo >> 16) & ST_MASK];
-                        const double x2 = x[chi & ST_MASK], x3 = x[(chi >> 16) & ST_MASK];
+                        const double x0 = xl[clo & ST_MASK], x1 = xl[(clo >> 16) & ST_MASK];
+                        const double x2 = xl[chi & ST_MASK], x3 = xl[(chi >> 16) & ST_MASK];
                         sm = fma(v0.x, x0, sm); sm = fma(v0.y, x1, sm); sm = fma(v1.x, x2, sm); sm = fma(v1.y, x3, sm);
                         if (HASCZ) {
                             sc += (clo & ST_CZ) ? 0.0 : x0; sc += (clo & (ST_CZ << 16)) ? 0.0 : x1;
@@ -1620,32 +1681,41 @@ __device__ void solve_stream(const DevParams& D, int b, const ProbDesc& pd, Prob
                         if (q + 1 == nextB || q + 1 == qe) {      // end of this slice's part of the range
                             pbuf[(s + w) * 64 + lane] = make_double2(sm, sc);
                             sm = 0.0; sc = 0.0;
-                            if (q + 1 < qe) { do { ++s; } while (cq[s + 1] <= q + 1); nextB = cq[s + 1]; }
+                            if (q + 1 < qe) { do { ++s; nextB = uni(cq[s + 1]); } while (nextB <= q + 1); }
                         }
                     }
                 }
             }
         }
+        TMARK(0);
         __syncthreads();
+        TMARK(1);
+        {   // add up the partials of every owned slice in stream (= wave) order
+            const uint32_t T4 = uni(cq[nsl]);
+            uint32_t a0[NS], a1[NS];
 #pragma unroll
-        for (int k = 0; k < ST_NS; ++k) {
-            const int s = k * ST_NW + w;
-            double a_ = 0.0, c_ = 0.0;
-            if (s < nsl) {
-                const uint32_t a0 = cq[s], a1 = cq[s + 1];
-                if (a1 > a0) {
+            for (int k = 0; k < NS; ++k) {
+                const int s = k * ST_NW + w;
+                a0[k] = (s < nsl) ? cq[s] : 0u; a1[k] = (s < nsl) ? cq[s + 1] : 0u;
+            }
 #pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                const int s = k * ST_NW + w;
+                const uint32_t b0 = uni(a0[k]), b1 = uni(a1[k]);
+                double a_ = 0.0, c_ = 0.0;
+                if (b1 > b0) {
+#pragma unroll 1
                     for (int w2 = 0; w2 < ST_NW; ++w2) {
                         const uint32_t s2 = (uint32_t)(((unsigned long long)T4 * (unsigned)w2) / ST_NW);
                         const uint32_t e2 = (uint32_t)(((unsigned long long)T4 * (unsigned)(w2 + 1)) / ST_NW);
-                        if (s2 < e2 && s2 < a1 && e2 > a0) { const double2 p_ = pbuf[(s + w2) * 64 + lane]; a_ += p_.x; c_ += p_.y; }
+                        if (s2 < e2 && s2 < b1 && e2 > b0) { const double2 p_ = pbuf[(s + w2) * 64 + lane]; a_ += p_.x; c_ += p_.y; }
                     }
                 }
+                am[k] = val[k] ? a_ : 0.0; ac[k] = val[k] ? c_ : 0.0;
             }
-            am[k] = val[k] ? a_ : 0.0; ac[k] = val[k] ? c_ : 0.0;
         }
         ++S.n_pass;
-        TMARK(lvl == 0 ? 0 : (lvl == lvMid ? 1 : 2));
+        TMARK(2);
     };
 
     // ---- level dst <- rows of level src restricted to the columns in supp(sU) ---------------------------
@@ -1653,10 +1723,10 @@ __device__ void solve_stream(const DevParams& D, int b, const ProbDesc& pd, Prob
         TMARK(3);
         const uint32_t* cqs = cumQ + src * ST_CQ; uint32_t* cqd = cumQ + dst * ST_CQ;
 #pragma unroll 1
-        for (int k = 0; k < ST_NS; ++k) {
-            const int s = k * ST_NW + w;
+        for (int k = 0; k < NS; ++k) {
+            const int s = k * ST_NW + ((k & 1) ? ST_NW - 1 - w : w);   // snake over the length-sorted slices
             if (s < nsl) {
-                uint32_t cnt = level_count_slot(sU, LV.cols[src], cqs[s], cqs[s + 1], lane);
+                uint32_t cnt = level_count_slot(sU, LV.cols[src], uni(cqs[s]), uni(cqs[s + 1]), lane);
                 for (int off = 32; off > 0; off >>= 1) cnt = max(cnt, (uint32_t)__shfl_xor((int)cnt, off));
                 if (lane == 0) tmpW[s] = (cnt + 3u) >> 2;
             }
@@ -1664,11 +1734,12 @@ __device__ void solve_stream(const DevParams& D, int b, const ProbDesc& pd, Prob
         __syncthreads();
         if (tid == 0) { uint32_t acc = 0; for (int s = 0; s < nsl; ++s) { cqd[s] = acc; acc += tmpW[s]; } cqd[nsl] = acc; }
         __syncthreads();
+        index_level(dst);
 #pragma unroll 1
-        for (int k = 0; k < ST_NS; ++k) {
-            const int s = k * ST_NW + w;
+        for (int k = 0; k < NS; ++k) {
+            const int s = k * ST_NW + ((k & 1) ? ST_NW - 1 - w : w);
             if (s < nsl)
-                level_copy_slot(sU, LV.cols[src], LV.vals[src], cqs[s], cqs[s + 1], LV.cols[dst], LV.vals[dst], cqd[s], tmpW[s],
+                level_copy_slot(sU, LV.cols[src], LV.vals[src], uni(cqs[s]), uni(cqs[s + 1]), LV.cols[dst], LV.vals[dst], uni(cqd[s]), uni(tmpW[s]),
                                 (uint32_t)L | ST_CZ, lane);
         }
         for (int wd = w; wd < nsl; wd += ST_NW) {
@@ -1686,13 +1757,14 @@ __device__ void solve_stream(const DevParams& D, int b, const ProbDesc& pd, Prob
     enum { PH_RESCALE, PH_INIT, PH_TRIAL };
     int phase = P.rescale_u0 ? PH_RESCALE : PH_INIT;
     if (phase == PH_INIT) {                                     // no rescale: normalise u0 first
+        double u[NS]; load_vec(sU, u);
         double r[1] = {0.0};
 #pragma unroll
-        for (int k = 0; k < ST_NS; ++k) r[0] += u[k] * u[k];
+        for (int k = 0; k < NS; ++k) r[0] += u[k] * u[k];
         block_sumN<1>(r, red, par, tid);
         const double nr = sqrt(r[0]);
 #pragma unroll
-        for (int k = 0; k < ST_NS; ++k) { if (nr > 0.0) u[k] /= nr; if (val[k]) sU[row[k]] = u[k]; }
+        for (int k = 0; k < NS; ++k) { if (nr > 0.0) u[k] /= nr; if (val[k]) sU[row[k]] = u[k]; }
         __syncthreads();
     }
     double usum = 0.0, alpha = 1.0, unsum = 0.0, du2 = 0.0, nS = 0.0, born = 0.0, vm = 0.0, vs = 0.0;
@@ -1700,20 +1772,23 @@ __device__ void solve_stream(const DevParams& D, int b, const ProbDesc& pd, Prob
 
     // trial vector u' = normalize(max(u + alpha g, 0)) into xUn (+ its sums, support and level tests)
     auto build_trial = [&]() {
-        double t_[ST_NS];
+        double u[NS]; load_vec(xU, u);
+        double t_[NS];
         double r[1] = {0.0};
 #pragma unroll
-        for (int k = 0; k < ST_NS; ++k) {
+        for (int k = 0; k < NS; ++k) {
             const double g = (((sd[k] + d) * u[k] - d * usum) + Mu[k]) + Cu[k] * d;
             double t = u[k] + alpha * g;
             t = t > 0.0 ? t : 0.0;
             t_[k] = val[k] ? t : 0.0; r[0] += t_[k] * t_[k];
         }
+        TMARK(3);
         block_sumN<1>(r, red, par, tid);
+        TMARK(6);
         const double nr = sqrt(r[0]);
         double q[4] = {0.0, 0.0, 0.0, 0.0};                     // sum u', |u'-u|^2, support/birth counts, level violations
 #pragma unroll
-        for (int k = 0; k < ST_NS; ++k) {
+        for (int k = 0; k < NS; ++k) {
             double t = t_[k];
             if (nr > 0.0) t /= nr;
             q[0] += t;
@@ -1728,16 +1803,18 @@ __device__ void solve_stream(const DevParams& D, int b, const ProbDesc& pd, Prob
                 }
             }
         }
+        TMARK(3);
         block_sumN<4>(q, red, par, tid);                       // its barrier also publishes the trial vector
+        TMARK(7);
         unsum = q[0]; du2 = q[1];
         born = floor(q[2] / 4096.0); nS = q[2] - 4096.0 * born;
         vs = floor(q[3] / 4096.0); vm = q[3] - 4096.0 * vs;
         lvlTrial = (hasSmall && vs == 0.0) ? lvSmall : ((hasMid && vm == 0.0) ? lvMid : 0);
     };
-    auto objective = [&](const double (&uu)[ST_NS], const double (&mm)[ST_NS], const double (&cc)[ST_NS], double us) -> double {
+    auto objective = [&](const double (&uu)[NS], const double (&mm)[NS], const double (&cc)[NS], double us) -> double {
         double r[1] = {0.0};
 #pragma unroll
-        for (int k = 0; k < ST_NS; ++k) {
+        for (int k = 0; k < NS; ++k) {
             const double g = (((sd[k] + d) * uu[k] - d * us) + mm[k]) + cc[k] * d;
             r[0] += uu[k] * g;
         }
@@ -1746,16 +1823,17 @@ __device__ void solve_stream(const DevParams& D, int b, const ProbDesc& pd, Prob
     };
 
     for (;;) {
-        double am[ST_NS], ac[ST_NS];
+        double am[NS], ac[NS];
         spmv(phase == PH_TRIAL ? xUn : xU, phase == PH_TRIAL ? lvlTrial : 0, am, ac);
         if (phase == PH_RESCALE) {                              // u = normalize(M u0 + diag u0)
+            double u[NS]; load_vec(sU, u);
             double r[1] = {0.0};
 #pragma unroll
-            for (int k = 0; k < ST_NS; ++k) { u[k] = am[k] + sd[k] * u[k]; r[0] += u[k] * u[k]; }
+            for (int k = 0; k < NS; ++k) { u[k] = am[k] + sd[k] * u[k]; r[0] += u[k] * u[k]; }
             block_sumN<1>(r, red, par, tid);                    // barrier: every gather of the old u is done
             const double nr = sqrt(r[0]);
 #pragma unroll
-            for (int k = 0; k < ST_NS; ++k) { if (nr > 0.0) u[k] /= nr; if (val[k]) sU[row[k]] = u[k]; }
+            for (int k = 0; k < NS; ++k) { if (nr > 0.0) u[k] /= nr; if (val[k]) sU[row[k]] = u[k]; }
             __syncthreads();
             phase = PH_INIT;
             continue;
@@ -1763,15 +1841,16 @@ __device__ void solve_stream(const DevParams& D, int b, const ProbDesc& pd, Prob
         bool new_outer = false;
         if (phase == PH_INIT) {
 #pragma unroll
-            for (int k = 0; k < ST_NS; ++k) { Mu[k] = am[k]; Cu[k] = ac[k]; }
+            for (int k = 0; k < NS; ++k) { Mu[k] = am[k]; Cu[k] = ac[k]; }
+            double u[NS]; load_vec(xU, u);
             double r1[1] = {0.0};
 #pragma unroll
-            for (int k = 0; k < ST_NS; ++k) r1[0] += u[k];
+            for (int k = 0; k < NS; ++k) r1[0] += u[k];
             block_sumN<1>(r1, red, par, tid);
             usum = r1[0];
             double r2[2] = {0.0, 0.0};                          // initial d: signed mean of (Mu)_p / Cbu_p over the active set
 #pragma unroll
-            for (int k = 0; k < ST_NS; ++k) {
+            for (int k = 0; k < NS; ++k) {
                 const double Cbu = (usum - Cu[k]) - u[k];
                 if (val[k] && Cbu > P.eps && u[k] > P.eps) { r2[0] += (Mu[k] + sd[k] * u[k]) / Cbu; r2[1] += 1.0; }
             }
@@ -1782,9 +1861,7 @@ __device__ void solve_stream(const DevParams& D, int b, const ProbDesc& pd, Prob
             new_outer = true;
         } else {                                                // PH_TRIAL: products of the trial vector
             ++S.ls_trials;
-            double un[ST_NS];
-#pragma unroll
-            for (int k = 0; k < ST_NS; ++k) un[k] = val[k] ? xUn[row[k]] : 0.0;
+            double un[NS]; load_vec(xUn, un);
             const double Fnew = objective(un, am, ac, unsum);
             const double deltaF = Fnew - F;
             if (deltaF < -P.eps && kk + 1 < P.maxlsiters) {     // backtrack
@@ -1796,8 +1873,8 @@ __device__ void solve_stream(const DevParams& D, int b, const ProbDesc& pd, Prob
             const double du = sqrt(du2);
             F = Fnew; usum = unsum;
 #pragma unroll
-            for (int k = 0; k < ST_NS; ++k) { u[k] = un[k]; Mu[k] = am[k]; Cu[k] = ac[k]; }
-            { double* t = xU; xU = xUn; xUn = t; }
+            for (int k = 0; k < NS; ++k) { Mu[k] = am[k]; Cu[k] = ac[k]; }
+            { double* t = xU; xU = xUn; xUn = t; }                  // the trial vector (LDS) is the accepted one now
             ++S.inner_iters; ++j;
             const bool stop = du < P.tol_u || fabs(deltaF) < P.tol_F;
             // ---- level maintenance (speed only: every level pass is exact) ---------------------------
@@ -1812,7 +1889,7 @@ __device__ void solve_stream(const DevParams& D, int b, const ProbDesc& pd, Prob
                 if (src >= 0) {
                     if (xU != sU) {                             // compaction and the K bitmap read the accepted vector from sU
 #pragma unroll
-                        for (int k = 0; k < ST_NS; ++k) if (val[k]) sU[row[k]] = u[k];
+                        for (int k = 0; k < NS; ++k) if (val[k]) sU[row[k]] = un[k];
                         xU = sU; xUn = sUn;
                         __syncthreads();
                     }
@@ -1823,9 +1900,9 @@ __device__ void solve_stream(const DevParams& D, int b, const ProbDesc& pd, Prob
             if (stop || j >= P.maxiniters) {                    // end of the inner loop: homotopy update of d
                 double r2[2] = {0.0, 0.0};
 #pragma unroll
-                for (int k = 0; k < ST_NS; ++k) {
-                    const double Cbu = (usum - Cu[k]) - u[k];
-                    if (val[k] && Cbu > P.eps && u[k] > P.eps) { r2[0] += fabs((Mu[k] + sd[k] * u[k]) / Cbu); r2[1] += 1.0; }
+                for (int k = 0; k < NS; ++k) {
+                    const double Cbu = (usum - Cu[k]) - un[k];
+                    if (val[k] && Cbu > P.eps && un[k] > P.eps) { r2[0] += fabs((Mu[k] + sd[k] * un[k]) / Cbu); r2[1] += 1.0; }
                 }
                 block_sumN<2>(r2, red, par, tid);
                 if (r2[1] > 0.0) d += r2[0] / r2[1]; else break;
@@ -1834,7 +1911,7 @@ __device__ void solve_stream(const DevParams& D, int b, const ProbDesc& pd, Prob
                 new_outer = true;
             }
         }
-        if (new_outer) { F = objective(u, Mu, Cu, usum); j = 0; }
+        if (new_outer) { double u[NS]; load_vec(xU, u); F = objective(u, Mu, Cu, usum); j = 0; }
         alpha = 1.0; kk = 0;
         build_trial();
         phase = PH_TRIAL;
@@ -1845,8 +1922,7 @@ __device__ void solve_stream(const DevParams& D, int b, const ProbDesc& pd, Prob
     TMARK(3);
     if (tid == 0 && O.dbg) {
         unsigned long long* dg = O.dbg + (size_t)b * 16;
-        for (int t = 0; t < 6; ++t) { dg[t] = tacc[t]; dg[8 + t] = tcnt[t]; }
-        dg[6] = __builtin_readcyclecounter() - tstart;
+        for (int t = 0; t < 8; ++t) { dg[t] = tacc[t]; dg[8 + t] = tcnt[t]; }
     }
 #endif
     // finish_one starts with a barrier; the accepted vector is complete in xU; scratch: the other vector + the partial buffer
@@ -1854,7 +1930,7 @@ __device__ void solve_stream(const DevParams& D, int b, const ProbDesc& pd, Prob
     finish_one(D, b, pd, feats, assoc, lp, O, xU, xUn, isc, isc + ((L + 1) & ~1), L, rb, lo, F, status, S, red, sint);
 }
 
-template <bool HASCZ>
+template <bool HASCZ, int NS>
 __global__ void __launch_bounds__(ST_NW * 64) k_solve_stream(DevParams D, int B, const ProbDesc* __restrict__ probs,
                                                              ProbState* __restrict__ st,
                                                              const double* __restrict__ feats, const int32_t* __restrict__ assoc,
@@ -1865,7 +1941,7 @@ __global__ void __launch_bounds__(ST_NW * 64) k_solve_stream(DevParams D, int B,
                                                              const double* __restrict__ u0, SolveOut O,
                                                              int* __restrict__ queue, int Lcap)
 {
-    // LDS: sU[Lcap+2] sUn[Lcap+2] | pbuf[ST_PB][64] double2 | red[136] | sK[2][48] u64 | cumQ[4][49] (+4 pad) tmpW[48] | sint[4]
+    // LDS: sU[Lcap+2] sUn[Lcap+2] | pbuf[ST_PB][64] double2 | red[136] | sK[2][48] u64 | cumQ[4][49] (+4 pad) tmpW[48] wQ[4][9] wS[4][8] | sint[4]
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* sU = reinterpret_cast<double*>(smem);
     double* sUn = sU + (Lcap + 2);
@@ -1874,7 +1950,9 @@ __global__ void __launch_bounds__(ST_NW * 64) k_solve_stream(DevParams D, int B,
     unsigned long long* sK = reinterpret_cast<unsigned long long*>(red + 136);
     uint32_t* cumQ = reinterpret_cast<uint32_t*>(sK + 2 * ST_MAXSL);
     uint32_t* tmpW = cumQ + 4 * ST_CQ + 4;
-    int* sint = reinterpret_cast<int*>(tmpW + ST_MAXSL);
+    uint32_t* wQ = tmpW + ST_MAXSL;
+    uint32_t* wS = wQ + 4 * (ST_NW + 1);
+    int* sint = reinterpret_cast<int*>(wS + 4 * ST_NW);
     for (;;) {
         if (threadIdx.x == 0) sint[2] = atomicAdd(queue, 1);
         __syncthreads();
@@ -1886,8 +1964,8 @@ __global__ void __launch_bounds__(ST_NW * 64) k_solve_stream(DevParams D, int B,
         const int64_t no = st[b].nnzOff;
         LV.cols[0] = cols0 + no; LV.vals[0] = vals0 + no; LV.cols[1] = cols1 + no; LV.vals[1] = vals1 + no;
         LV.cols[2] = cols2 + no; LV.vals[2] = vals2 + no; LV.cols[3] = cols3 + no; LV.vals[3] = vals3 + no;
-        solve_stream<HASCZ>(D, b, pd, st, feats, assoc, lp, ls, perm, sliceBase, LV, u0, O,
-                            sU, sUn, pbuf, sK, cumQ, tmpW, red, sint);
+        solve_stream<HASCZ, NS>(D, b, pd, st, feats, assoc, lp, ls, perm, sliceBase, LV, u0, O,
+                            sU, sUn, pbuf, sK, cumQ, tmpW, wQ, wS, red, sint);
     }
 }
 

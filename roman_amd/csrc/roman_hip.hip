@@ -327,7 +327,7 @@ int stage_solve(roman_ctx* c, const DevParams& D, int B, const double* feats, co
     size_t lds = (size_t)nvec * sizeof(double) * (size_t)Lcap + fixed;
     if (regPath) {
         lds = 2 * sizeof(double) * (size_t)(Lcap + 2) + (size_t)ST_PB * 64 * 2 * sizeof(double) + 136 * sizeof(double)
-              + 2 * ST_MAXSL * sizeof(unsigned long long) + (4 * ST_CQ + 4 + ST_MAXSL) * sizeof(uint32_t) + 4 * sizeof(int);
+              + 2 * ST_MAXSL * sizeof(unsigned long long) + (4 * ST_CQ + 4 + ST_MAXSL + 4 * (ST_NW + 1) + 4 * ST_NW) * sizeof(uint32_t) + 4 * sizeof(int);
         const size_t nnz1 = (size_t)std::max<int64_t>(tot.nnzTotal, 1);
         HIPCHK(c, c->vals1.ensure(sizeof(double) * nnz1)); HIPCHK(c, c->cols1.ensure(sizeof(uint16_t) * nnz1));
         HIPCHK(c, c->vals2.ensure(sizeof(double) * nnz1)); HIPCHK(c, c->cols2.ensure(sizeof(uint16_t) * nnz1));
@@ -356,15 +356,21 @@ int stage_solve(roman_ctx* c, const DevParams& D, int B, const double* feats, co
                            c->vMu.as<double>(), c->vCu.as<double>(), c->vMun.as<double>(), c->vCun.as<double>(), c->gU.as<double>(), c->gUn.as<double>(), \
                            u0, O, c->queue.as<int>(), Lcap);                                                                   \
     } while (0)
-#define ROMAN_LAUNCH_SOLVE_STREAM(CZ_)                                                                                        \
+#define ROMAN_LAUNCH_SOLVE_STREAM(CZ_, NS_)                                                                                   \
     do {                                                                                                                      \
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve_stream<CZ_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL((k_solve_stream<CZ_>), dim3(grid), dim3(nt), lds, c->stream, D, B, c->probs.as<ProbDesc>(), c->state.as<ProbState>(), feats, assoc, \
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve_stream<CZ_, NS_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((k_solve_stream<CZ_, NS_>), dim3(grid), dim3(nt), lds, c->stream, D, B, c->probs.as<ProbDesc>(), c->state.as<ProbState>(), feats, assoc, \
                            c->lp.as<int32_t>(), c->ls.as<double>(), c->perm.as<uint32_t>(), c->sliceBase.as<uint32_t>(), \
                            c->cols.as<uint16_t>(), c->vals.as<double>(), c->cols1.as<uint16_t>(), c->vals1.as<double>(), c->cols2.as<uint16_t>(), c->vals2.as<double>(), \
                            c->cols3.as<uint16_t>(), c->vals3.as<double>(), u0, O, c->queue.as<int>(), Lcap);                    \
     } while (0)
-    if (regPath) { if (hascz) ROMAN_LAUNCH_SOLVE_STREAM(true); else ROMAN_LAUNCH_SOLVE_STREAM(false); }
+    if (regPath) {
+        const int nsNeed = ((std::max(tot.maxL, 1) + 63) / 64 + ST_NW - 1) / ST_NW;      // row slots per wave
+        if (hascz)            ROMAN_LAUNCH_SOLVE_STREAM(true, 6);                         // dense-matrix problems: one variant
+        else if (nsNeed <= 4) ROMAN_LAUNCH_SOLVE_STREAM(false, 4);
+        else if (nsNeed == 5) ROMAN_LAUNCH_SOLVE_STREAM(false, 5);
+        else                  ROMAN_LAUNCH_SOLVE_STREAM(false, 6);
+    }
     else if (idx16) { if (mode == 1) ROMAN_LAUNCH_SOLVE(uint16_t, 1); else ROMAN_LAUNCH_SOLVE(uint16_t, 0); }
     else            { if (mode == 1) ROMAN_LAUNCH_SOLVE(uint32_t, 1); else ROMAN_LAUNCH_SOLVE(uint32_t, 0); }
 #undef ROMAN_LAUNCH_SOLVE_STREAM
@@ -376,10 +382,13 @@ int stage_solve(roman_ctx* c, const DevParams& D, int B, const double* feats, co
         std::vector<unsigned long long> h((size_t)B * 16);
         HIPCHK(c, hipMemcpyAsync(h.data(), c->hAux3.p, sizeof(unsigned long long) * 16 * (size_t)B, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        double acc[16] = {0}; double mx = 0;
-        for (int b = 0; b < B; ++b) { for (int t = 0; t < 16; ++t) acc[t] += (double)h[(size_t)b * 16 + t]; mx = std::max(mx, (double)h[(size_t)b * 16 + 6]); }
-        fprintf(stderr, "[solve timing] B=%d mean cycles/problem: spmv L0 %.0f (n=%.1f) L1 %.0f (n=%.1f) L2 %.0f (n=%.1f) other %.0f (n=%.1f) compact0 %.0f (n=%.2f) compactN %.0f (n=%.2f) total %.0f max %.0f\n",
-                B, acc[0] / B, acc[8] / B, acc[1] / B, acc[9] / B, acc[2] / B, acc[10] / B, acc[3] / B, acc[11] / B, acc[4] / B, acc[12] / B, acc[5] / B, acc[13] / B, acc[6] / B, mx);
+        double acc[16] = {0};
+        for (int b = 0; b < B; ++b) for (int t = 0; t < 16; ++t) acc[t] += (double)h[(size_t)b * 16 + t];
+        const char* nm[8] = {"stream", "spmv-barrier", "combine", "other", "compact0", "compactN", "red-norm", "red-sums"};
+        fprintf(stderr, "[solve timing] B=%d cycles/problem:", B);
+        double tot_ = 0; for (int t = 0; t < 8; ++t) tot_ += acc[t] / B;
+        for (int t = 0; t < 8; ++t) fprintf(stderr, " %s %.0f (n=%.1f)", nm[t], acc[t] / B, acc[8 + t] / B);
+        fprintf(stderr, " total %.0f\n", tot_);
     }
 #endif
     return ROMAN_OK;
