@@ -1558,18 +1558,20 @@ __device__ __noinline__ void level_copy_slot(const double* x, const uint16_t* co
     }
 }
 
-template <bool HASCZ, int NS>
+template <bool HASCZ>
 __device__ void solve_stream(const DevParams& D, int b, const ProbDesc& pd, ProbState* st,
                              const double* __restrict__ feats, const int32_t* __restrict__ assoc,
                              const int32_t* __restrict__ lp, const double* __restrict__ ls,
                              const uint32_t* __restrict__ permPool, const uint32_t* __restrict__ sliceBasePool,
                              const StreamLevels& LV, const double* __restrict__ u0, const SolveOut& O,
-                             double* sU, double* sUn, double2* pbuf, unsigned long long* sK /* [2][48] */,
+                             double* vec /* 7 vectors of Lc doubles */, int Lc, uint16_t* permS /* [nsl*64] */,
+                             double2* pbuf /* [2*ST_NW][64] */, unsigned long long* sK /* [2][48] */,
                              uint32_t* cumQ /* [4][ST_CQ] */, uint32_t* tmpW /* [48] */, uint32_t* wQ /* [4][ST_NW+1] quad range starts */,
-                             uint32_t* wS /* [4][ST_NW] first slice of every wave's range */, double* red, int* sint)
+                             uint32_t* wS /* [4][ST_NW] first slice of every wave's range */, uint32_t* cutS /* [4][ST_NW] */, double* red, int* sint)
 {
     const roman_params_t& P = D.p;
     const int tid = threadIdx.x, lane = tid & 63, w = uni(tid >> 6);
+    constexpr int NT = ST_NW * 64;
     const int L = uni(st[b].L), rb = uni(st[b].rowBase);
     const int64_t lo = pd.liveOff;
     const int nsl = (L + 63) >> 6;
@@ -1579,6 +1581,7 @@ __device__ void solve_stream(const DevParams& D, int b, const ProbDesc& pd, Prob
     roman_stats_t S;
     S.n_assoc_in = pd.nA; S.n_live = L; S.nnz_upper = (int64_t)st[b].nnzUpper;
     S.n_pass = 0; S.outer_iters = 0; S.inner_iters = 0; S.ls_trials = 0; S.score = 0.0; S.d_final = 0.0;
+    int n_pass = 0, ls_trials = 0, inner_iters = 0;
     double F = 0.0, d = 0.0;
     if (pd.n1 == 0 || pd.n2 == 0) status |= ROMAN_ST_EMPTY_MAP;
     if (L <= 0) {
@@ -1588,33 +1591,19 @@ __device__ void solve_stream(const DevParams& D, int b, const ProbDesc& pd, Prob
 #ifdef ROMAN_SOLVE_TIMING
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tcnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tlast = __builtin_readcyclecounter();
-    const unsigned long long tstart = tlast;
 #endif
+    // LDS vectors, indexed by live association; element [L] of the gathered ones is a dummy that stays 0
+    double* xU = vec; double* xUn = vec + Lc;
+    double* Mu = vec + 2 * Lc; double* Cu = vec + 3 * Lc; double* Mun = vec + 4 * Lc; double* Cun = vec + 5 * Lc;
+    double* sd = vec + 6 * Lc;
 
-    // ---- slice geometry of level 0 to LDS; this thread's rows ------------------------------------------
+    // ---- slice geometry of level 0, rows of the slice slots, initial vector --------------------------
     __syncthreads();
-    for (int s = tid; s <= nsl; s += blockDim.x)
+    for (int s = tid; s <= nsl; s += NT)
         cumQ[s] = (s < nsl) ? (sliceBasePool[lo + s] >> 8) : (st[b].nnzCap >> 8);
-    // per-row state in registers: the diagonal and the products of the accepted vector; u itself is re-read
-    // from LDS (it has to be there for the gathers anyway) at the start of every element-wise phase
-    int row[NS]; bool val[NS];
-    double sd[NS], Mu[NS], Cu[NS];
-#pragma unroll
-    for (int k = 0; k < NS; ++k) {
-        const int s = k * ST_NW + w;
-        const int pos = (s << 6) + lane;
-        val[k] = s < nsl && pos < L;
-        row[k] = val[k] ? (int)permPool[lo + pos] : L;            // rows that do not exist alias the dummy element
-        sd[k] = val[k] ? ls[lo + row[k]] : 0.0;
-        Mu[k] = Cu[k] = 0.0;
-        if (val[k]) sU[row[k]] = u0 ? u0[lo + lp[lo + row[k]]] : 1.0;
-    }
-    if (tid == 0) { sU[L] = 0.0; sUn[L] = 0.0; }
-    __syncthreads();
-    auto load_vec = [&](const double* x, double (&v)[NS]) {
-#pragma unroll
-        for (int k = 0; k < NS; ++k) v[k] = x[row[k]];         // row == L (dummy, always 0) for rows that do not exist
-    };
+    for (int pos = tid; pos < nsl * 64; pos += NT) permS[pos] = (pos < L) ? (uint16_t)permPool[lo + pos] : (uint16_t)L;
+    for (int p = tid; p < L; p += NT) { sd[p] = ls[lo + p]; xU[p] = u0 ? u0[lo + lp[lo + p]] : 1.0; }
+    if (tid == 0) { xU[L] = 0.0; xUn[L] = 0.0; }
 
     bool hasMid = false, hasSmall = false;
     int nKmid = L, nKsmall = L, calm = 0;
@@ -1627,106 +1616,128 @@ __device__ void solve_stream(const DevParams& D, int b, const ProbDesc& pd, Prob
             const uint32_t qs = (uint32_t)(((unsigned long long)T4 * (unsigned)tid) / ST_NW);
             wQ[lvl * (ST_NW + 1) + tid] = qs;
             if (tid < ST_NW) {
-                int lo_ = 0, hi_ = nsl;                         // largest s with cq[s] <= qs, skipping empty slices (cq[s+1] > qs)
+                int lo_ = 0, hi_ = nsl;                         // largest s with cq[s] <= qs (skips empty slices)
                 while (hi_ - lo_ > 1) { const int mid_ = (lo_ + hi_) >> 1; if (cq[mid_] <= qs) lo_ = mid_; else hi_ = mid_; }
                 wS[lvl * ST_NW + tid] = (uint32_t)lo_;
+                // the range boundary qs cuts slice lo_ iff it lies strictly inside it; the FIRST cut inside a
+                // slice (the previous boundary is not inside) is the one that adds up the slice's partial sums
+                const uint32_t pq = tid > 0 ? (uint32_t)(((unsigned long long)T4 * (unsigned)(tid - 1)) / ST_NW) : 0u;
+                const bool cut = tid > 0 && qs < T4 && cq[lo_] < qs;
+                cutS[lvl * ST_NW + tid] = (cut && pq <= cq[lo_]) ? (uint32_t)lo_ : 0xffffffffu;
             }
         }
     };
+    __syncthreads();
     index_level(0);
     __syncthreads();
 
-    // ---- one balanced SpMV stream over level `lvl`; results (am[], ac[]) for the owned rows ---------
-    auto spmv = [&](const double* x, int lvl, double (&am)[NS], double (&ac)[NS]) {
+    // ---- one balanced SpMV stream over level `lvl`: (M x, C x) -> (mo, co) ------------------------------
+    // Wave w streams the quads [wQ[w], wQ[w+1]) of the level; a piece that covers a whole slice stores its
+    // row sums directly, a piece cut by a range boundary goes to a partial slot (2w: the piece that starts
+    // the wave's range, 2w+1: the piece that ends it) and is added up in wave order after the barrier.
+    auto spmv = [&](const double* x, int lvl, double* mo, double* co) {
         TMARK(3);
         const uint32_t* cq = cumQ + lvl * ST_CQ;
         const uint32_t* wq = wQ + lvl * (ST_NW + 1);
         const uint32_t qs = uni(wq[w]), qe = uni(wq[w + 1]);
         if (qs < qe) {
             int s = uni((int)wS[lvl * ST_NW + w]);
-            uint32_t nextB = uni(cq[s + 1]);
+            uint32_t sliceB = uni(cq[s]), nextB = uni(cq[s + 1]);
             g_quad_cp cp = (g_quad_cp)LV.cols[lvl] + lane;
             g_pair_cp vp = (g_pair_cp)LV.vals[lvl] + lane;
             l_vec_cp xl = (l_vec_cp)x;
+            // ring of ST_D quads in flight per lane.  Loads are issued unconditionally (the index is clamped to
+            // the last quad of the range) so that the wait counters stay exact: no branch ever separates a
+            // load from its use.
             unsigned long long rc[ST_D]; dbl2_t rv0[ST_D], rv1[ST_D];
 #pragma unroll
             for (int t = 0; t < ST_D; ++t) {
-                if (qs + t < qe) {
-                    rc[t] = cp[(size_t)(qs + t) * 64];
-                    rv0[t] = vp[(size_t)(2 * (qs + t)) * 64]; rv1[t] = vp[(size_t)(2 * (qs + t) + 1) * 64];
-                }
+                const uint32_t qq = min(qs + (uint32_t)t, qe - 1u);
+                rc[t] = cp[(size_t)qq * 64];
+                rv0[t] = vp[(size_t)(2 * qq) * 64]; rv1[t] = vp[(size_t)(2 * qq + 1) * 64];
             }
             double sm = 0.0, sc = 0.0;
-            for (uint32_t q0 = qs; q0 < qe; q0 += ST_D) {
+#define STREAM_CONSUME(Q_, C_, V0_, V1_)                                                                    \
+            {                                                                                               \
+                const uint32_t clo = (uint32_t)(C_), chi = (uint32_t)((C_) >> 32);                          \
+                const double x0 = xl[clo & ST_MASK], x1 = xl[(clo >> 16) & ST_MASK];                        \
+                const double x2 = xl[chi & ST_MASK], x3 = xl[(chi >> 16) & ST_MASK];                        \
+                sm = fma((V0_).x, x0, sm); sm = fma((V0_).y, x1, sm); sm = fma((V1_).x, x2, sm); sm = fma((V1_).y, x3, sm); \
+                if (HASCZ) {                                                                                \
+                    sc += (clo & ST_CZ) ? 0.0 : x0; sc += (clo & (ST_CZ << 16)) ? 0.0 : x1;                 \
+                    sc += (chi & ST_CZ) ? 0.0 : x2; sc += (chi & (ST_CZ << 16)) ? 0.0 : x3;                 \
+                } else {              /* the only C-flagged entries are inert: they gather x[L] == 0 */     \
+                    sc += x0; sc += x1; sc += x2; sc += x3;                                                 \
+                }                                                                                           \
+                if ((Q_) + 1 == nextB || (Q_) + 1 == qe) {            /* end of this slice's piece */        \
+                    const uint32_t p0 = sliceB > qs ? sliceB : qs;    /* the piece is [p0, Q_+1) */           \
+                    if (p0 == sliceB && (Q_) + 1 == nextB) {          /* whole slice: final sums */            \
+                        const int r_ = permS[s * 64 + lane];                                                \
+                        mo[r_] = sm; co[r_] = sc;                     /* rows that do not exist alias element [L] */ \
+                    } else {                                                                                \
+                        pbuf[(2 * w + (p0 == qs ? 0 : 1)) * 64 + lane] = make_double2(sm, sc);              \
+                    }                                                                                       \
+                    sm = 0.0; sc = 0.0;                                                                     \
+                    if ((Q_) + 1 < qe) { do { ++s; sliceB = nextB; nextB = uni(cq[s + 1]); } while (nextB <= (Q_) + 1); } \
+                }                                                                                           \
+            }
+            uint32_t q0 = qs;
+            for (; q0 + ST_D <= qe; q0 += ST_D) {
 #pragma unroll
                 for (int t = 0; t < ST_D; ++t) {
                     const uint32_t q = q0 + t;
-                    if (q < qe) {
-                        const unsigned long long c = rc[t];
-                        const dbl2_t v0 = rv0[t], v1 = rv1[t];
-                        if (q + ST_D < qe) {
-                            rc[t] = cp[(size_t)(q + ST_D) * 64];
-                            rv0[t] = vp[(size_t)(2 * (q + ST_D)) * 64]; rv1[t] = vp[(size_t)(2 * (q + ST_D) + 1) * 64];
-                        }
-                        const uint32_t clo = (uint32_t)c, chi = (uint32_t)(c >> 32);
-                        const double x0 = xl[clo & ST_MASK], x1 = xl[(clo >> 16) & ST_MASK];
-                        const double x2 = xl[chi & ST_MASK], x3 = xl[(chi >> 16) & ST_MASK];
-                        sm = fma(v0.x, x0, sm); sm = fma(v0.y, x1, sm); sm = fma(v1.x, x2, sm); sm = fma(v1.y, x3, sm);
-                        if (HASCZ) {
-                            sc += (clo & ST_CZ) ? 0.0 : x0; sc += (clo & (ST_CZ << 16)) ? 0.0 : x1;
-                            sc += (chi & ST_CZ) ? 0.0 : x2; sc += (chi & (ST_CZ << 16)) ? 0.0 : x3;
-                        } else {                                  // the only C-flagged entries are inert: they gather x[L] == 0
-                            sc += x0; sc += x1; sc += x2; sc += x3;
-                        }
-                        if (q + 1 == nextB || q + 1 == qe) {      // end of this slice's part of the range
-                            pbuf[(s + w) * 64 + lane] = make_double2(sm, sc);
-                            sm = 0.0; sc = 0.0;
-                            if (q + 1 < qe) { do { ++s; nextB = uni(cq[s + 1]); } while (nextB <= q + 1); }
-                        }
-                    }
+                    const unsigned long long c = rc[t];
+                    const dbl2_t v0 = rv0[t], v1 = rv1[t];
+                    const uint32_t qn = min(q + (uint32_t)ST_D, qe - 1u);
+                    rc[t] = cp[(size_t)qn * 64];
+                    rv0[t] = vp[(size_t)(2 * qn) * 64]; rv1[t] = vp[(size_t)(2 * qn + 1) * 64];
+                    STREAM_CONSUME(q, c, v0, v1)
                 }
             }
+#pragma unroll
+            for (int t = 0; t < ST_D; ++t) {                    // tail: fewer than ST_D quads, already in the ring
+                const uint32_t q = q0 + t;
+                if (q < qe) { STREAM_CONSUME(q, rc[t], rv0[t], rv1[t]) }
+            }
+#undef STREAM_CONSUME
         }
         TMARK(0);
         __syncthreads();
         TMARK(1);
-        {   // add up the partials of every owned slice in stream (= wave) order
-            const uint32_t T4 = uni(cq[nsl]);
-            uint32_t a0[NS], a1[NS];
-#pragma unroll
-            for (int k = 0; k < NS; ++k) {
-                const int s = k * ST_NW + w;
-                a0[k] = (s < nsl) ? cq[s] : 0u; a1[k] = (s < nsl) ? cq[s + 1] : 0u;
-            }
-#pragma unroll
-            for (int k = 0; k < NS; ++k) {
-                const int s = k * ST_NW + w;
-                const uint32_t b0 = uni(a0[k]), b1 = uni(a1[k]);
-                double a_ = 0.0, c_ = 0.0;
-                if (b1 > b0) {
+        for (int s = w; s < nsl; s += ST_NW)                    // rows of slices that are empty at this level
+            if (uni(cq[s + 1]) == uni(cq[s])) { const int r_ = permS[s * 64 + lane]; mo[r_] = 0.0; co[r_] = 0.0; }
+        // slices cut by a range boundary: the wave behind the first cut adds the partial sums in stream order
+        const uint32_t cs = uni(cutS[lvl * ST_NW + w]);
+        if (cs != 0xffffffffu) {
+            const int s = (int)cs;
+            const uint32_t a0 = uni(cq[s]), a1 = uni(cq[s + 1]);
+            double a_ = 0.0, c_ = 0.0;
 #pragma unroll 1
-                    for (int w2 = 0; w2 < ST_NW; ++w2) {
-                        const uint32_t s2 = (uint32_t)(((unsigned long long)T4 * (unsigned)w2) / ST_NW);
-                        const uint32_t e2 = (uint32_t)(((unsigned long long)T4 * (unsigned)(w2 + 1)) / ST_NW);
-                        if (s2 < e2 && s2 < b1 && e2 > b0) { const double2 p_ = pbuf[(s + w2) * 64 + lane]; a_ += p_.x; c_ += p_.y; }
-                    }
+            for (int w3 = 0; w3 < ST_NW; ++w3) {
+                const uint32_t s3 = uni(wq[w3]), e3 = uni(wq[w3 + 1]);
+                if (s3 < e3 && s3 < a1 && e3 > a0) {
+                    const uint32_t p0 = a0 > s3 ? a0 : s3;
+                    const double2 p_ = pbuf[(2 * w3 + (p0 == s3 ? 0 : 1)) * 64 + lane];
+                    a_ += p_.x; c_ += p_.y;
                 }
-                am[k] = val[k] ? a_ : 0.0; ac[k] = val[k] ? c_ : 0.0;
             }
+            const int r_ = permS[s * 64 + lane];
+            mo[r_] = a_; co[r_] = c_;
         }
-        ++S.n_pass;
+        __syncthreads();
+        ++n_pass;
         TMARK(2);
     };
 
-    // ---- level dst <- rows of level src restricted to the columns in supp(sU) ---------------------------
-    auto compact = [&](int src, int dst, bool asMid, int nS) {
+    // ---- level dst <- rows of level src restricted to the columns in supp(x) ---------------------------
+    auto compact = [&](const double* x, int src, int dst, bool asMid, int nS) {
         TMARK(3);
         const uint32_t* cqs = cumQ + src * ST_CQ; uint32_t* cqd = cumQ + dst * ST_CQ;
 #pragma unroll 1
-        for (int k = 0; k < NS; ++k) {
+        for (int k = 0; k * ST_NW < nsl; ++k) {
             const int s = k * ST_NW + ((k & 1) ? ST_NW - 1 - w : w);   // snake over the length-sorted slices
             if (s < nsl) {
-                uint32_t cnt = level_count_slot(sU, LV.cols[src], uni(cqs[s]), uni(cqs[s + 1]), lane);
+                uint32_t cnt = level_count_slot(x, LV.cols[src], uni(cqs[s]), uni(cqs[s + 1]), lane);
                 for (int off = 32; off > 0; off >>= 1) cnt = max(cnt, (uint32_t)__shfl_xor((int)cnt, off));
                 if (lane == 0) tmpW[s] = (cnt + 3u) >> 2;
             }
@@ -1736,15 +1747,15 @@ __device__ void solve_stream(const DevParams& D, int b, const ProbDesc& pd, Prob
         __syncthreads();
         index_level(dst);
 #pragma unroll 1
-        for (int k = 0; k < NS; ++k) {
+        for (int k = 0; k * ST_NW < nsl; ++k) {
             const int s = k * ST_NW + ((k & 1) ? ST_NW - 1 - w : w);
             if (s < nsl)
-                level_copy_slot(sU, LV.cols[src], LV.vals[src], uni(cqs[s]), uni(cqs[s + 1]), LV.cols[dst], LV.vals[dst], uni(cqd[s]), uni(tmpW[s]),
+                level_copy_slot(x, LV.cols[src], LV.vals[src], uni(cqs[s]), uni(cqs[s + 1]), LV.cols[dst], LV.vals[dst], uni(cqd[s]), uni(tmpW[s]),
                                 (uint32_t)L | ST_CZ, lane);
         }
         for (int wd = w; wd < nsl; wd += ST_NW) {
             const int p = (wd << 6) + lane;
-            const unsigned long long m = __ballot(p < L && sU[p] > 0.0);
+            const unsigned long long m = __ballot(p < L && x[p] > 0.0);
             if (lane == 0) sK[(asMid ? 0 : 1) * ST_MAXSL + wd] = m;
         }
         if (asMid) { hasMid = true; nKmid = nS; hasSmall = false; } else { hasSmall = true; nKsmall = nS; }
@@ -1753,54 +1764,46 @@ __device__ void solve_stream(const DevParams& D, int b, const ProbDesc& pd, Prob
     };
 
     // ---- the iteration as a state machine around ONE SpMV call site ------------------------------------
-    double* xU = sU; double* xUn = sUn;                         // LDS: accepted vector / trial vector
     enum { PH_RESCALE, PH_INIT, PH_TRIAL };
     int phase = P.rescale_u0 ? PH_RESCALE : PH_INIT;
-    if (phase == PH_INIT) {                                     // no rescale: normalise u0 first
-        double u[NS]; load_vec(sU, u);
+    auto normalize_u = [&]() {                                  // xU /= |xU|
         double r[1] = {0.0};
-#pragma unroll
-        for (int k = 0; k < NS; ++k) r[0] += u[k] * u[k];
+        for (int p = tid; p < L; p += NT) r[0] += xU[p] * xU[p];
         block_sumN<1>(r, red, par, tid);
         const double nr = sqrt(r[0]);
-#pragma unroll
-        for (int k = 0; k < NS; ++k) { if (nr > 0.0) u[k] /= nr; if (val[k]) sU[row[k]] = u[k]; }
+        if (nr > 0.0) for (int p = tid; p < L; p += NT) xU[p] /= nr;
         __syncthreads();
-    }
+    };
+    if (phase == PH_INIT) normalize_u();
     double usum = 0.0, alpha = 1.0, unsum = 0.0, du2 = 0.0, nS = 0.0, born = 0.0, vm = 0.0, vs = 0.0;
     int i = 0, j = 0, kk = 0, lvlTrial = 0;
 
     // trial vector u' = normalize(max(u + alpha g, 0)) into xUn (+ its sums, support and level tests)
     auto build_trial = [&]() {
-        double u[NS]; load_vec(xU, u);
-        double t_[NS];
         double r[1] = {0.0};
-#pragma unroll
-        for (int k = 0; k < NS; ++k) {
-            const double g = (((sd[k] + d) * u[k] - d * usum) + Mu[k]) + Cu[k] * d;
-            double t = u[k] + alpha * g;
+        for (int p = tid; p < L; p += NT) {
+            const double up = xU[p];
+            const double g = (((sd[p] + d) * up - d * usum) + Mu[p]) + Cu[p] * d;
+            double t = up + alpha * g;
             t = t > 0.0 ? t : 0.0;
-            t_[k] = val[k] ? t : 0.0; r[0] += t_[k] * t_[k];
+            xUn[p] = t; r[0] += t * t;
         }
         TMARK(3);
         block_sumN<1>(r, red, par, tid);
         TMARK(6);
         const double nr = sqrt(r[0]);
         double q[4] = {0.0, 0.0, 0.0, 0.0};                     // sum u', |u'-u|^2, support/birth counts, level violations
-#pragma unroll
-        for (int k = 0; k < NS; ++k) {
-            double t = t_[k];
-            if (nr > 0.0) t /= nr;
+        for (int p = tid; p < L; p += NT) {
+            double t = xUn[p];
+            if (nr > 0.0) { t /= nr; xUn[p] = t; }
             q[0] += t;
-            const double df = t - u[k]; q[1] += df * df;
-            if (val[k]) {
-                xUn[row[k]] = t;
-                if (t > 0.0) {
-                    q[2] += 1.0;
-                    if (!(u[k] > 0.0)) q[2] += 4096.0;
-                    if (hasMid && !((sK[row[k] >> 6] >> (row[k] & 63)) & 1ull)) q[3] += 1.0;
-                    if (hasSmall && !((sK[ST_MAXSL + (row[k] >> 6)] >> (row[k] & 63)) & 1ull)) q[3] += 4096.0;
-                }
+            const double up = xU[p];
+            const double df = t - up; q[1] += df * df;
+            if (t > 0.0) {
+                q[2] += 1.0;
+                if (!(up > 0.0)) q[2] += 4096.0;
+                if (hasMid && !((sK[p >> 6] >> (p & 63)) & 1ull)) q[3] += 1.0;
+                if (hasSmall && !((sK[ST_MAXSL + (p >> 6)] >> (p & 63)) & 1ull)) q[3] += 4096.0;
             }
         }
         TMARK(3);
@@ -1811,71 +1814,61 @@ __device__ void solve_stream(const DevParams& D, int b, const ProbDesc& pd, Prob
         vs = floor(q[3] / 4096.0); vm = q[3] - 4096.0 * vs;
         lvlTrial = (hasSmall && vs == 0.0) ? lvSmall : ((hasMid && vm == 0.0) ? lvMid : 0);
     };
-    auto objective = [&](const double (&uu)[NS], const double (&mm)[NS], const double (&cc)[NS], double us) -> double {
+    auto objective = [&](const double* uu, const double* mm, const double* cc, double us) -> double {
         double r[1] = {0.0};
-#pragma unroll
-        for (int k = 0; k < NS; ++k) {
-            const double g = (((sd[k] + d) * uu[k] - d * us) + mm[k]) + cc[k] * d;
-            r[0] += uu[k] * g;
+        for (int p = tid; p < L; p += NT) {
+            const double up = uu[p];
+            const double g = (((sd[p] + d) * up - d * us) + mm[p]) + cc[p] * d;
+            r[0] += up * g;
         }
         block_sumN<1>(r, red, par, tid);
         return r[0];
     };
+    auto d_ratio = [&](bool absval, double& acc, double& cnt) { // mean of (M u)_p / Cbu_p over the active set
+        double r2[2] = {0.0, 0.0};
+        for (int p = tid; p < L; p += NT) {
+            const double up = xU[p], Cbu = (usum - Cu[p]) - up;
+            if (Cbu > P.eps && up > P.eps) { const double r_ = (Mu[p] + sd[p] * up) / Cbu; r2[0] += absval ? fabs(r_) : r_; r2[1] += 1.0; }
+        }
+        block_sumN<2>(r2, red, par, tid);
+        acc = r2[0]; cnt = r2[1];
+    };
 
     for (;;) {
-        double am[NS], ac[NS];
-        spmv(phase == PH_TRIAL ? xUn : xU, phase == PH_TRIAL ? lvlTrial : 0, am, ac);
+        if (phase == PH_TRIAL) spmv(xUn, lvlTrial, Mun, Cun); else spmv(xU, 0, Mu, Cu);
         if (phase == PH_RESCALE) {                              // u = normalize(M u0 + diag u0)
-            double u[NS]; load_vec(sU, u);
-            double r[1] = {0.0};
-#pragma unroll
-            for (int k = 0; k < NS; ++k) { u[k] = am[k] + sd[k] * u[k]; r[0] += u[k] * u[k]; }
-            block_sumN<1>(r, red, par, tid);                    // barrier: every gather of the old u is done
-            const double nr = sqrt(r[0]);
-#pragma unroll
-            for (int k = 0; k < NS; ++k) { if (nr > 0.0) u[k] /= nr; if (val[k]) sU[row[k]] = u[k]; }
+            for (int p = tid; p < L; p += NT) xU[p] = Mu[p] + sd[p] * xU[p];
             __syncthreads();
+            normalize_u();
             phase = PH_INIT;
             continue;
         }
         bool new_outer = false;
         if (phase == PH_INIT) {
-#pragma unroll
-            for (int k = 0; k < NS; ++k) { Mu[k] = am[k]; Cu[k] = ac[k]; }
-            double u[NS]; load_vec(xU, u);
             double r1[1] = {0.0};
-#pragma unroll
-            for (int k = 0; k < NS; ++k) r1[0] += u[k];
+            for (int p = tid; p < L; p += NT) r1[0] += xU[p];
             block_sumN<1>(r1, red, par, tid);
             usum = r1[0];
-            double r2[2] = {0.0, 0.0};                          // initial d: signed mean of (Mu)_p / Cbu_p over the active set
-#pragma unroll
-            for (int k = 0; k < NS; ++k) {
-                const double Cbu = (usum - Cu[k]) - u[k];
-                if (val[k] && Cbu > P.eps && u[k] > P.eps) { r2[0] += (Mu[k] + sd[k] * u[k]) / Cbu; r2[1] += 1.0; }
-            }
-            block_sumN<2>(r2, red, par, tid);
-            d = (r2[1] > 0.0) ? r2[0] / r2[1] : 0.0;
+            double acc, cnt;
+            d_ratio(false, acc, cnt);
+            d = (cnt > 0.0) ? acc / cnt : 0.0;
             i = 0;
             if (i >= P.maxoliters) break;
             new_outer = true;
         } else {                                                // PH_TRIAL: products of the trial vector
-            ++S.ls_trials;
-            double un[NS]; load_vec(xUn, un);
-            const double Fnew = objective(un, am, ac, unsum);
+            ++ls_trials;
+            const double Fnew = objective(xUn, Mun, Cun, unsum);
             const double deltaF = Fnew - F;
             if (deltaF < -P.eps && kk + 1 < P.maxlsiters) {     // backtrack
                 alpha *= P.beta; ++kk;
                 build_trial();
                 continue;
             }
-            // accept
+            // accept: the trial vector and its products become the current ones
             const double du = sqrt(du2);
             F = Fnew; usum = unsum;
-#pragma unroll
-            for (int k = 0; k < NS; ++k) { Mu[k] = am[k]; Cu[k] = ac[k]; }
-            { double* t = xU; xU = xUn; xUn = t; }                  // the trial vector (LDS) is the accepted one now
-            ++S.inner_iters; ++j;
+            { double* t; t = xU; xU = xUn; xUn = t; t = Mu; Mu = Mun; Mun = t; t = Cu; Cu = Cun; Cun = t; }
+            ++inner_iters; ++j;
             const bool stop = du < P.tol_u || fabs(deltaF) < P.tol_F;
             // ---- level maintenance (speed only: every level pass is exact) ---------------------------
             calm = (born == 0.0) ? calm + 1 : 0;
@@ -1887,36 +1880,26 @@ __device__ void solve_stream(const DevParams& D, int b, const ProbDesc& pd, Prob
                 else if (validSmall) { if (2 * ns <= nKsmall) { src = lvSmall; dst = lvSpare; } }
                 else if (2 * ns <= nKmid) { src = lvMid; dst = lvSmall; }
                 if (src >= 0) {
-                    if (xU != sU) {                             // compaction and the K bitmap read the accepted vector from sU
-#pragma unroll
-                        for (int k = 0; k < NS; ++k) if (val[k]) sU[row[k]] = un[k];
-                        xU = sU; xUn = sUn;
-                        __syncthreads();
-                    }
-                    compact(src, dst, asMid, ns);
+                    compact(xU, src, dst, asMid, ns);
                     if (src == lvSmall) { const int t = lvSmall; lvSmall = lvSpare; lvSpare = t; }
                 }
             }
             if (stop || j >= P.maxiniters) {                    // end of the inner loop: homotopy update of d
-                double r2[2] = {0.0, 0.0};
-#pragma unroll
-                for (int k = 0; k < NS; ++k) {
-                    const double Cbu = (usum - Cu[k]) - un[k];
-                    if (val[k] && Cbu > P.eps && un[k] > P.eps) { r2[0] += fabs((Mu[k] + sd[k] * un[k]) / Cbu); r2[1] += 1.0; }
-                }
-                block_sumN<2>(r2, red, par, tid);
-                if (r2[1] > 0.0) d += r2[0] / r2[1]; else break;
+                double acc, cnt;
+                d_ratio(true, acc, cnt);
+                if (cnt > 0.0) d += acc / cnt; else break;
                 ++i;
                 if (i >= P.maxoliters) break;
                 new_outer = true;
             }
         }
-        if (new_outer) { double u[NS]; load_vec(xU, u); F = objective(u, Mu, Cu, usum); j = 0; }
+        if (new_outer) { F = objective(xU, Mu, Cu, usum); j = 0; }
         alpha = 1.0; kk = 0;
         build_trial();
         phase = PH_TRIAL;
     }
     if (i >= P.maxoliters) status |= ROMAN_ST_MAXITER;
+    S.n_pass = n_pass; S.ls_trials = ls_trials; S.inner_iters = inner_iters;
     S.outer_iters = i; S.score = F; S.d_final = d;
 #ifdef ROMAN_SOLVE_TIMING
     TMARK(3);
@@ -1925,12 +1908,11 @@ __device__ void solve_stream(const DevParams& D, int b, const ProbDesc& pd, Prob
         for (int t = 0; t < 8; ++t) { dg[t] = tacc[t]; dg[8 + t] = tcnt[t]; }
     }
 #endif
-    // finish_one starts with a barrier; the accepted vector is complete in xU; scratch: the other vector + the partial buffer
-    int32_t* isc = reinterpret_cast<int32_t*>(pbuf);
-    finish_one(D, b, pd, feats, assoc, lp, O, xU, xUn, isc, isc + ((L + 1) & ~1), L, rb, lo, F, status, S, red, sint);
+    // finish_one starts with a barrier; scratch: the trial vector and its products
+    finish_one(D, b, pd, feats, assoc, lp, O, xU, Mun, reinterpret_cast<int32_t*>(xUn), reinterpret_cast<int32_t*>(Cun), L, rb, lo, F, status, S, red, sint);
 }
 
-template <bool HASCZ, int NS>
+template <bool HASCZ>
 __global__ void __launch_bounds__(ST_NW * 64) k_solve_stream(DevParams D, int B, const ProbDesc* __restrict__ probs,
                                                              ProbState* __restrict__ st,
                                                              const double* __restrict__ feats, const int32_t* __restrict__ assoc,
@@ -1939,20 +1921,22 @@ __global__ void __launch_bounds__(ST_NW * 64) k_solve_stream(DevParams D, int B,
                                                              uint16_t* cols0, double* vals0, uint16_t* cols1, double* vals1,
                                                              uint16_t* cols2, double* vals2, uint16_t* cols3, double* vals3,
                                                              const double* __restrict__ u0, SolveOut O,
-                                                             int* __restrict__ queue, int Lcap)
+                                                             int* __restrict__ queue, int Lc)
 {
-    // LDS: sU[Lcap+2] sUn[Lcap+2] | pbuf[ST_PB][64] double2 | red[136] | sK[2][48] u64 | cumQ[4][49] (+4 pad) tmpW[48] wQ[4][9] wS[4][8] | sint[4]
+    // LDS: 7 vectors of Lc doubles | pbuf[2*ST_NW][64] double2 | red[136] | sK[2][48] u64 |
+    //      cumQ[4][49] (+4 pad) tmpW[48] wQ[4][9] wS[4][8] cutS[4][8] sint[4] | permS[ST_MAXSL*64] u16
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    double* sU = reinterpret_cast<double*>(smem);
-    double* sUn = sU + (Lcap + 2);
-    double2* pbuf = reinterpret_cast<double2*>(sUn + (Lcap + 2));
-    double* red = reinterpret_cast<double*>(pbuf + ST_PB * 64);
+    double* vec = reinterpret_cast<double*>(smem);
+    double2* pbuf = reinterpret_cast<double2*>(vec + 7 * (size_t)Lc);
+    double* red = reinterpret_cast<double*>(pbuf + 2 * ST_NW * 64);
     unsigned long long* sK = reinterpret_cast<unsigned long long*>(red + 136);
     uint32_t* cumQ = reinterpret_cast<uint32_t*>(sK + 2 * ST_MAXSL);
     uint32_t* tmpW = cumQ + 4 * ST_CQ + 4;
     uint32_t* wQ = tmpW + ST_MAXSL;
     uint32_t* wS = wQ + 4 * (ST_NW + 1);
-    int* sint = reinterpret_cast<int*>(wS + 4 * ST_NW);
+    uint32_t* cutS = wS + 4 * ST_NW;
+    int* sint = reinterpret_cast<int*>(cutS + 4 * ST_NW);
+    uint16_t* permS = reinterpret_cast<uint16_t*>(sint + 4);
     for (;;) {
         if (threadIdx.x == 0) sint[2] = atomicAdd(queue, 1);
         __syncthreads();
@@ -1964,8 +1948,8 @@ __global__ void __launch_bounds__(ST_NW * 64) k_solve_stream(DevParams D, int B,
         const int64_t no = st[b].nnzOff;
         LV.cols[0] = cols0 + no; LV.vals[0] = vals0 + no; LV.cols[1] = cols1 + no; LV.vals[1] = vals1 + no;
         LV.cols[2] = cols2 + no; LV.vals[2] = vals2 + no; LV.cols[3] = cols3 + no; LV.vals[3] = vals3 + no;
-        solve_stream<HASCZ, NS>(D, b, pd, st, feats, assoc, lp, ls, perm, sliceBase, LV, u0, O,
-                            sU, sUn, pbuf, sK, cumQ, tmpW, wQ, wS, red, sint);
+        solve_stream<HASCZ>(D, b, pd, st, feats, assoc, lp, ls, perm, sliceBase, LV, u0, O,
+                            vec, Lc, permS, pbuf, sK, cumQ, tmpW, wQ, wS, cutS, red, sint);
     }
 }
 

@@ -106,9 +106,19 @@ double sqrt_threshold(double t)
 
 // The streaming solver (k_solve_stream) and its quad matrix layout serve problems of up to ST_MAXSL*64
 // live associations; larger ones use the SELL-64 layout and the LDS/HBM-vector solver.
+// LDS of k_solve_stream for problems of up to maxL live associations (layout: see the kernel)
+size_t stream_lds_bytes(int maxL)
+{
+    const size_t Lc = (size_t)((maxL + 2 + 1) & ~1);
+    const size_t nsl = (size_t)(maxL + 63) / 64;
+    return 7 * sizeof(double) * Lc + (size_t)2 * ST_NW * 64 * 2 * sizeof(double) + 136 * sizeof(double)
+           + 2 * ST_MAXSL * sizeof(unsigned long long)
+           + (4 * ST_CQ + 4 + ST_MAXSL + 4 * (ST_NW + 1) + 4 * ST_NW + 4 * ST_NW) * sizeof(uint32_t) + 4 * sizeof(int)
+           + nsl * 64 * sizeof(uint16_t) + 64;
+}
 bool use_quad(const DevParams& D, int maxL)
 {
-    return maxL <= ST_MAXSL * 64 && D.p.maxiniters >= 1 && D.p.maxlsiters >= 1;
+    return maxL <= ST_MAXSL * 64 && stream_lds_bytes(maxL) <= (size_t)(160 * 1024 - 4096) && D.p.maxiniters >= 1 && D.p.maxlsiters >= 1;
 }
 // host twins of col_pos / val_pos (kernels.hip.h)
 inline size_t h_col_pos(bool quad, size_t sbase, uint32_t slot, uint32_t e) { return quad ? sbase + (size_t)(e >> 2) * 256 + slot * 4 + (e & 3u) : sbase + (size_t)e * 64 + slot; }
@@ -326,8 +336,8 @@ int stage_solve(roman_ctx* c, const DevParams& D, int B, const double* feats, co
     HIPCHK(c, c->gU.ensure(sizeof(double) * ((mode == 0 && !regPath) ? R1 : 1))); HIPCHK(c, c->gUn.ensure(sizeof(double) * ((mode == 0 && !regPath) ? R1 : 1)));
     size_t lds = (size_t)nvec * sizeof(double) * (size_t)Lcap + fixed;
     if (regPath) {
-        lds = 2 * sizeof(double) * (size_t)(Lcap + 2) + (size_t)ST_PB * 64 * 2 * sizeof(double) + 136 * sizeof(double)
-              + 2 * ST_MAXSL * sizeof(unsigned long long) + (4 * ST_CQ + 4 + ST_MAXSL + 4 * (ST_NW + 1) + 4 * ST_NW) * sizeof(uint32_t) + 4 * sizeof(int);
+        Lcap = (tot.maxL + 2 + 1) & ~1;                            // vector length incl. the dummy element [L]
+        lds = stream_lds_bytes(tot.maxL);
         const size_t nnz1 = (size_t)std::max<int64_t>(tot.nnzTotal, 1);
         HIPCHK(c, c->vals1.ensure(sizeof(double) * nnz1)); HIPCHK(c, c->cols1.ensure(sizeof(uint16_t) * nnz1));
         HIPCHK(c, c->vals2.ensure(sizeof(double) * nnz1)); HIPCHK(c, c->cols2.ensure(sizeof(uint16_t) * nnz1));
@@ -356,21 +366,15 @@ int stage_solve(roman_ctx* c, const DevParams& D, int B, const double* feats, co
                            c->vMu.as<double>(), c->vCu.as<double>(), c->vMun.as<double>(), c->vCun.as<double>(), c->gU.as<double>(), c->gUn.as<double>(), \
                            u0, O, c->queue.as<int>(), Lcap);                                                                   \
     } while (0)
-#define ROMAN_LAUNCH_SOLVE_STREAM(CZ_, NS_)                                                                                   \
+#define ROMAN_LAUNCH_SOLVE_STREAM(CZ_)                                                                                        \
     do {                                                                                                                      \
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve_stream<CZ_, NS_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL((k_solve_stream<CZ_, NS_>), dim3(grid), dim3(nt), lds, c->stream, D, B, c->probs.as<ProbDesc>(), c->state.as<ProbState>(), feats, assoc, \
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve_stream<CZ_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((k_solve_stream<CZ_>), dim3(grid), dim3(nt), lds, c->stream, D, B, c->probs.as<ProbDesc>(), c->state.as<ProbState>(), feats, assoc, \
                            c->lp.as<int32_t>(), c->ls.as<double>(), c->perm.as<uint32_t>(), c->sliceBase.as<uint32_t>(), \
                            c->cols.as<uint16_t>(), c->vals.as<double>(), c->cols1.as<uint16_t>(), c->vals1.as<double>(), c->cols2.as<uint16_t>(), c->vals2.as<double>(), \
                            c->cols3.as<uint16_t>(), c->vals3.as<double>(), u0, O, c->queue.as<int>(), Lcap);                    \
     } while (0)
-    if (regPath) {
-        const int nsNeed = ((std::max(tot.maxL, 1) + 63) / 64 + ST_NW - 1) / ST_NW;      // row slots per wave
-        if (hascz)            ROMAN_LAUNCH_SOLVE_STREAM(true, 6);                         // dense-matrix problems: one variant
-        else if (nsNeed <= 4) ROMAN_LAUNCH_SOLVE_STREAM(false, 4);
-        else if (nsNeed == 5) ROMAN_LAUNCH_SOLVE_STREAM(false, 5);
-        else                  ROMAN_LAUNCH_SOLVE_STREAM(false, 6);
-    }
+    if (regPath) { if (hascz) ROMAN_LAUNCH_SOLVE_STREAM(true); else ROMAN_LAUNCH_SOLVE_STREAM(false); }
     else if (idx16) { if (mode == 1) ROMAN_LAUNCH_SOLVE(uint16_t, 1); else ROMAN_LAUNCH_SOLVE(uint16_t, 0); }
     else            { if (mode == 1) ROMAN_LAUNCH_SOLVE(uint32_t, 1); else ROMAN_LAUNCH_SOLVE(uint32_t, 0); }
 #undef ROMAN_LAUNCH_SOLVE_STREAM
