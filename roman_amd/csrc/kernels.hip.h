@@ -1410,6 +1410,7 @@ constexpr int ST_D = 6;                  // quads in flight per lane
 constexpr int ST_MAXSL = ST_NW * ST_NS;  // 48 slices -> L <= 3072
 constexpr int ST_PB = ST_MAXSL + ST_NW;  // LDS partial slots
 constexpr int ST_CQ = ST_MAXSL + 1;      // entries of a quad-prefix row
+constexpr int ST_KMAX = 5;               // per-element loops cover ST_KMAX * 512 = 2560 associations
 constexpr uint32_t ST_CZ = 0x8000u, ST_MASK = 0x7fffu;
 
 // Explicit address spaces for the hot pointers of the streaming solver: pointers that reach the loops
@@ -1514,22 +1515,27 @@ __device__ __noinline__ uint32_t level_count_slot(const double* x, const uint16_
     return cnt;
 }
 // Compaction, phase 2: copy the kept entries of this lane's row to the quads starting at `qd` of the
-// destination level and pad up to `newWq` quads with inert entries.
+// destination level and pad up to `newWq` quads with inert entries.  Kept entries are assembled into whole
+// quads (column indices in a 64-bit shift register, values in a per-wave LDS stage of 4 x 64 doubles) and
+// stored with the same three wide stores the stream loads them with.
 __device__ __noinline__ void level_copy_slot(const double* x, const uint16_t* cols, const double* vals, uint32_t qa, uint32_t qb,
-                                             uint16_t* dcols, double* dvals, uint32_t qd, uint32_t newWq, uint32_t inert, int lane)
+                                             uint16_t* dcols, double* dvals, uint32_t qd, uint32_t newWq, uint32_t inert,
+                                             double* stage, int lane)
 {
     g_quad_cp cp = (g_quad_cp)cols + lane;
     g_pair_cp vp = (g_pair_cp)vals + lane;
     l_vec_cp xl = (l_vec_cp)x;
-    ROMAN_GLOBAL uint16_t* dc = (ROMAN_GLOBAL uint16_t*)dcols;
-    ROMAN_GLOBAL double* dv = (ROMAN_GLOBAL double*)dvals;
-    const int64_t db = (int64_t)qd * 256;
-    uint32_t cnt = 0;
+    ROMAN_LDS double* sg = (ROMAN_LDS double*)stage + lane;                                                    // value j of the open quad: sg[j*64]
+    ROMAN_GLOBAL unsigned long long* dc = (ROMAN_GLOBAL unsigned long long*)dcols + (size_t)qd * 64 + lane;     // quad g: dc[g*64]
+    ROMAN_GLOBAL dbl2_t* dv = (ROMAN_GLOBAL dbl2_t*)dvals + (size_t)qd * 128 + lane;                           // pairs 2g, 2g+1: dv[2g*64], dv[(2g+1)*64]
+    uint32_t gq = 0, nb = 0;                                    // quads written, entries in the open quad
+    unsigned long long cacc = 0ull;                             // the open quad's indices, newest in the top 16 bits
     constexpr int DC = 6;
     unsigned long long c[DC]; dbl2_t v0[DC], v1[DC];
 #pragma unroll
     for (int t = 0; t < DC; ++t) {
-        if (qa + t < qb) { c[t] = cp[(size_t)(qa + t) * 64]; v0[t] = vp[(size_t)(2 * (qa + t)) * 64]; v1[t] = vp[(size_t)(2 * (qa + t) + 1) * 64]; }
+        const uint32_t qq = min(qa + (uint32_t)t, qb > qa ? qb - 1u : qa);
+        c[t] = cp[(size_t)qq * 64]; v0[t] = vp[(size_t)(2 * qq) * 64]; v1[t] = vp[(size_t)(2 * qq + 1) * 64];
     }
     for (uint32_t q0 = qa; q0 < qb; q0 += DC) {
 #pragma unroll
@@ -1537,25 +1543,34 @@ __device__ __noinline__ void level_copy_slot(const double* x, const uint16_t* co
             const uint32_t q = q0 + t;
             if (q < qb) {
                 const unsigned long long cc = c[t];
-                const dbl2_t a0 = v0[t], a1 = v1[t];
-                if (q + DC < qb) { c[t] = cp[(size_t)(q + DC) * 64]; v0[t] = vp[(size_t)(2 * (q + DC)) * 64]; v1[t] = vp[(size_t)(2 * (q + DC) + 1) * 64]; }
+                const dbl2_t b0 = v0[t], b1 = v1[t];
+                const uint32_t qn = min(q + (uint32_t)DC, qb - 1u);
+                c[t] = cp[(size_t)qn * 64]; v0[t] = vp[(size_t)(2 * qn) * 64]; v1[t] = vp[(size_t)(2 * qn + 1) * 64];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const uint32_t cw = (uint32_t)(cc >> (16 * j)) & 0xffffu;
-                    const double vv = (j == 0) ? a0.x : (j == 1) ? a0.y : (j == 2) ? a1.x : a1.y;
+                    const double vv = (j == 0) ? b0.x : (j == 1) ? b0.y : (j == 2) ? b1.x : b1.y;
                     if (xl[cw & ST_MASK] > 0.0) {
-                        dc[col_pos<true>(db, (uint32_t)lane, cnt)] = (uint16_t)cw;
-                        dv[val_pos<true>(db, (uint32_t)lane, cnt)] = vv;
-                        ++cnt;
+                        sg[nb * 64] = vv;
+                        cacc = (cacc >> 16) | ((unsigned long long)cw << 48);
+                        if (++nb == 4) {
+                            dc[(size_t)gq * 64] = cacc;
+                            dv[(size_t)(2 * gq) * 64] = dbl2_t{sg[0], sg[64]}; dv[(size_t)(2 * gq + 1) * 64] = dbl2_t{sg[128], sg[192]};
+                            ++gq; nb = 0;
+                        }
                     }
                 }
             }
         }
     }
-    for (uint32_t e = cnt; e < newWq * 4; ++e) {
-        dc[col_pos<true>(db, (uint32_t)lane, e)] = (uint16_t)inert;
-        dv[val_pos<true>(db, (uint32_t)lane, e)] = 0.0;
+    const unsigned long long iq = (unsigned long long)inert * 0x0001000100010001ull;
+    if (nb > 0) {                                               // close the open quad with inert entries
+        cacc = (cacc >> (16 * (4 - nb))) | (iq << (16 * nb));
+        const double a0 = sg[0], a1 = nb > 1 ? sg[64] : 0.0, a2 = nb > 2 ? sg[128] : 0.0;
+        dc[(size_t)gq * 64] = cacc; dv[(size_t)(2 * gq) * 64] = dbl2_t{a0, a1}; dv[(size_t)(2 * gq + 1) * 64] = dbl2_t{a2, 0.0};
+        ++gq;
     }
+    for (; gq < newWq; ++gq) { dc[(size_t)gq * 64] = iq; dv[(size_t)(2 * gq) * 64] = dbl2_t{0.0, 0.0}; dv[(size_t)(2 * gq + 1) * 64] = dbl2_t{0.0, 0.0}; }
 }
 
 template <bool HASCZ>
@@ -1567,11 +1582,13 @@ __device__ void solve_stream(const DevParams& D, int b, const ProbDesc& pd, Prob
                              double* vec /* 7 vectors of Lc doubles */, int Lc, uint16_t* permS /* [nsl*64] */,
                              double2* pbuf /* [2*ST_NW][64] */, unsigned long long* sK /* [2][48] */,
                              uint32_t* cumQ /* [4][ST_CQ] */, uint32_t* tmpW /* [48] */, uint32_t* wQ /* [4][ST_NW+1] quad range starts */,
-                             uint32_t* wS /* [4][ST_NW] first slice of every wave's range */, uint32_t* cutS /* [4][ST_NW] */, double* red, int* sint)
+                             uint32_t* wS /* [4][ST_NW] first slice of every wave's range */, uint32_t* cutS /* [4][ST_NW] */, unsigned long long* emptyM /* [4] */, double* red, int* sint)
 {
     const roman_params_t& P = D.p;
     const int tid = threadIdx.x, lane = tid & 63, w = uni(tid >> 6);
     constexpr int NT = ST_NW * 64;
+    // per-element loops: fully unrolled (ST_KMAX * NT >= L) so that the LDS reads of all iterations overlap
+#define FOR_P(p) _Pragma("unroll") for (int k_ = 0; k_ < ST_KMAX; ++k_) if (const int p = tid + k_ * NT; p < L)
     const int L = uni(st[b].L), rb = uni(st[b].rowBase);
     const int64_t lo = pd.liveOff;
     const int nsl = (L + 63) >> 6;
@@ -1624,6 +1641,11 @@ __device__ void solve_stream(const DevParams& D, int b, const ProbDesc& pd, Prob
                 const uint32_t pq = tid > 0 ? (uint32_t)(((unsigned long long)T4 * (unsigned)(tid - 1)) / ST_NW) : 0u;
                 const bool cut = tid > 0 && qs < T4 && cq[lo_] < qs;
                 cutS[lvl * ST_NW + tid] = (cut && pq <= cq[lo_]) ? (uint32_t)lo_ : 0xffffffffu;
+            }
+            if (tid == ST_NW) {                                 // slices without entries at this level
+                unsigned long long em = 0ull;
+                for (int s = 0; s < nsl; ++s) if (cq[s + 1] == cq[s]) em |= 1ull << s;
+                emptyM[lvl] = em;
             }
         }
     };
@@ -1704,8 +1726,14 @@ __device__ void solve_stream(const DevParams& D, int b, const ProbDesc& pd, Prob
         TMARK(0);
         __syncthreads();
         TMARK(1);
-        for (int s = w; s < nsl; s += ST_NW)                    // rows of slices that are empty at this level
-            if (uni(cq[s + 1]) == uni(cq[s])) { const int r_ = permS[s * 64 + lane]; mo[r_] = 0.0; co[r_] = 0.0; }
+        {   // rows of slices that are empty at this level
+            unsigned long long em = emptyM[lvl];
+            em = ((unsigned long long)uni((uint32_t)(em >> 32)) << 32) | uni((uint32_t)em);
+            while (em) {
+                const int s = __builtin_ctzll(em); em &= em - 1ull;
+                if ((s & (ST_NW - 1)) == w) { const int r_ = permS[s * 64 + lane]; mo[r_] = 0.0; co[r_] = 0.0; }
+            }
+        }
         // slices cut by a range boundary: the wave behind the first cut adds the partial sums in stream order
         const uint32_t cs = uni(cutS[lvl * ST_NW + w]);
         if (cs != 0xffffffffu) {
@@ -1751,7 +1779,7 @@ __device__ void solve_stream(const DevParams& D, int b, const ProbDesc& pd, Prob
             const int s = k * ST_NW + ((k & 1) ? ST_NW - 1 - w : w);
             if (s < nsl)
                 level_copy_slot(x, LV.cols[src], LV.vals[src], uni(cqs[s]), uni(cqs[s + 1]), LV.cols[dst], LV.vals[dst], uni(cqd[s]), uni(tmpW[s]),
-                                (uint32_t)L | ST_CZ, lane);
+                                (uint32_t)L | ST_CZ, reinterpret_cast<double*>(pbuf) + w * 256, lane);   // stage: the (idle) partial-sum buffer
         }
         for (int wd = w; wd < nsl; wd += ST_NW) {
             const int p = (wd << 6) + lane;
@@ -1768,10 +1796,10 @@ __device__ void solve_stream(const DevParams& D, int b, const ProbDesc& pd, Prob
     int phase = P.rescale_u0 ? PH_RESCALE : PH_INIT;
     auto normalize_u = [&]() {                                  // xU /= |xU|
         double r[1] = {0.0};
-        for (int p = tid; p < L; p += NT) r[0] += xU[p] * xU[p];
+        FOR_P(p) r[0] += xU[p] * xU[p];
         block_sumN<1>(r, red, par, tid);
         const double nr = sqrt(r[0]);
-        if (nr > 0.0) for (int p = tid; p < L; p += NT) xU[p] /= nr;
+        if (nr > 0.0) FOR_P(p) xU[p] /= nr;
         __syncthreads();
     };
     if (phase == PH_INIT) normalize_u();
@@ -1781,7 +1809,7 @@ __device__ void solve_stream(const DevParams& D, int b, const ProbDesc& pd, Prob
     // trial vector u' = normalize(max(u + alpha g, 0)) into xUn (+ its sums, support and level tests)
     auto build_trial = [&]() {
         double r[1] = {0.0};
-        for (int p = tid; p < L; p += NT) {
+        FOR_P(p) {
             const double up = xU[p];
             const double g = (((sd[p] + d) * up - d * usum) + Mu[p]) + Cu[p] * d;
             double t = up + alpha * g;
@@ -1793,7 +1821,7 @@ __device__ void solve_stream(const DevParams& D, int b, const ProbDesc& pd, Prob
         TMARK(6);
         const double nr = sqrt(r[0]);
         double q[4] = {0.0, 0.0, 0.0, 0.0};                     // sum u', |u'-u|^2, support/birth counts, level violations
-        for (int p = tid; p < L; p += NT) {
+        FOR_P(p) {
             double t = xUn[p];
             if (nr > 0.0) { t /= nr; xUn[p] = t; }
             q[0] += t;
@@ -1816,7 +1844,7 @@ __device__ void solve_stream(const DevParams& D, int b, const ProbDesc& pd, Prob
     };
     auto objective = [&](const double* uu, const double* mm, const double* cc, double us) -> double {
         double r[1] = {0.0};
-        for (int p = tid; p < L; p += NT) {
+        FOR_P(p) {
             const double up = uu[p];
             const double g = (((sd[p] + d) * up - d * us) + mm[p]) + cc[p] * d;
             r[0] += up * g;
@@ -1826,7 +1854,7 @@ __device__ void solve_stream(const DevParams& D, int b, const ProbDesc& pd, Prob
     };
     auto d_ratio = [&](bool absval, double& acc, double& cnt) { // mean of (M u)_p / Cbu_p over the active set
         double r2[2] = {0.0, 0.0};
-        for (int p = tid; p < L; p += NT) {
+        FOR_P(p) {
             const double up = xU[p], Cbu = (usum - Cu[p]) - up;
             if (Cbu > P.eps && up > P.eps) { const double r_ = (Mu[p] + sd[p] * up) / Cbu; r2[0] += absval ? fabs(r_) : r_; r2[1] += 1.0; }
         }
@@ -1837,7 +1865,7 @@ __device__ void solve_stream(const DevParams& D, int b, const ProbDesc& pd, Prob
     for (;;) {
         if (phase == PH_TRIAL) spmv(xUn, lvlTrial, Mun, Cun); else spmv(xU, 0, Mu, Cu);
         if (phase == PH_RESCALE) {                              // u = normalize(M u0 + diag u0)
-            for (int p = tid; p < L; p += NT) xU[p] = Mu[p] + sd[p] * xU[p];
+            FOR_P(p) xU[p] = Mu[p] + sd[p] * xU[p];
             __syncthreads();
             normalize_u();
             phase = PH_INIT;
@@ -1846,7 +1874,7 @@ __device__ void solve_stream(const DevParams& D, int b, const ProbDesc& pd, Prob
         bool new_outer = false;
         if (phase == PH_INIT) {
             double r1[1] = {0.0};
-            for (int p = tid; p < L; p += NT) r1[0] += xU[p];
+            FOR_P(p) r1[0] += xU[p];
             block_sumN<1>(r1, red, par, tid);
             usum = r1[0];
             double acc, cnt;
@@ -1910,6 +1938,7 @@ __device__ void solve_stream(const DevParams& D, int b, const ProbDesc& pd, Prob
 #endif
     // finish_one starts with a barrier; scratch: the trial vector and its products
     finish_one(D, b, pd, feats, assoc, lp, O, xU, Mun, reinterpret_cast<int32_t*>(xUn), reinterpret_cast<int32_t*>(Cun), L, rb, lo, F, status, S, red, sint);
+#undef FOR_P
 }
 
 template <bool HASCZ>
@@ -1923,14 +1952,15 @@ __global__ void __launch_bounds__(ST_NW * 64) k_solve_stream(DevParams D, int B,
                                                              const double* __restrict__ u0, SolveOut O,
                                                              int* __restrict__ queue, int Lc)
 {
-    // LDS: 7 vectors of Lc doubles | pbuf[2*ST_NW][64] double2 | red[136] | sK[2][48] u64 |
+    // LDS: 7 vectors of Lc doubles | pbuf[2*ST_NW][64] double2 | red[136] | sK[2][48] u64 | emptyM[4] u64 |
     //      cumQ[4][49] (+4 pad) tmpW[48] wQ[4][9] wS[4][8] cutS[4][8] sint[4] | permS[ST_MAXSL*64] u16
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* vec = reinterpret_cast<double*>(smem);
     double2* pbuf = reinterpret_cast<double2*>(vec + 7 * (size_t)Lc);
     double* red = reinterpret_cast<double*>(pbuf + 2 * ST_NW * 64);
     unsigned long long* sK = reinterpret_cast<unsigned long long*>(red + 136);
-    uint32_t* cumQ = reinterpret_cast<uint32_t*>(sK + 2 * ST_MAXSL);
+    unsigned long long* emptyM = sK + 2 * ST_MAXSL;
+    uint32_t* cumQ = reinterpret_cast<uint32_t*>(emptyM + 4);
     uint32_t* tmpW = cumQ + 4 * ST_CQ + 4;
     uint32_t* wQ = tmpW + ST_MAXSL;
     uint32_t* wS = wQ + 4 * (ST_NW + 1);
@@ -1949,7 +1979,7 @@ __global__ void __launch_bounds__(ST_NW * 64) k_solve_stream(DevParams D, int B,
         LV.cols[0] = cols0 + no; LV.vals[0] = vals0 + no; LV.cols[1] = cols1 + no; LV.vals[1] = vals1 + no;
         LV.cols[2] = cols2 + no; LV.vals[2] = vals2 + no; LV.cols[3] = cols3 + no; LV.vals[3] = vals3 + no;
         solve_stream<HASCZ>(D, b, pd, st, feats, assoc, lp, ls, perm, sliceBase, LV, u0, O,
-                            vec, Lc, permS, pbuf, sK, cumQ, tmpW, wQ, wS, cutS, red, sint);
+                            vec, Lc, permS, pbuf, sK, cumQ, tmpW, wQ, wS, cutS, emptyM, red, sint);
     }
 }
 

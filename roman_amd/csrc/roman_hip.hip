@@ -112,13 +112,13 @@ size_t stream_lds_bytes(int maxL)
     const size_t Lc = (size_t)((maxL + 2 + 1) & ~1);
     const size_t nsl = (size_t)(maxL + 63) / 64;
     return 7 * sizeof(double) * Lc + (size_t)2 * ST_NW * 64 * 2 * sizeof(double) + 136 * sizeof(double)
-           + 2 * ST_MAXSL * sizeof(unsigned long long)
+           + (2 * ST_MAXSL + 4) * sizeof(unsigned long long)
            + (4 * ST_CQ + 4 + ST_MAXSL + 4 * (ST_NW + 1) + 4 * ST_NW + 4 * ST_NW) * sizeof(uint32_t) + 4 * sizeof(int)
            + nsl * 64 * sizeof(uint16_t) + 64;
 }
 bool use_quad(const DevParams& D, int maxL)
 {
-    return maxL <= ST_MAXSL * 64 && stream_lds_bytes(maxL) <= (size_t)(160 * 1024 - 4096) && D.p.maxiniters >= 1 && D.p.maxlsiters >= 1;
+    return maxL <= ST_MAXSL * 64 && maxL <= ST_KMAX * ST_NW * 64 && stream_lds_bytes(maxL) <= (size_t)(160 * 1024 - 256) && D.p.maxiniters >= 1 && D.p.maxlsiters >= 1;
 }
 // host twins of col_pos / val_pos (kernels.hip.h)
 inline size_t h_col_pos(bool quad, size_t sbase, uint32_t slot, uint32_t e) { return quad ? sbase + (size_t)(e >> 2) * 256 + slot * 4 + (e & 3u) : sbase + (size_t)e * 64 + slot; }
@@ -393,6 +393,18 @@ int stage_solve(roman_ctx* c, const DevParams& D, int B, const double* feats, co
         double tot_ = 0; for (int t = 0; t < 8; ++t) tot_ += acc[t] / B;
         for (int t = 0; t < 8; ++t) fprintf(stderr, " %s %.0f (n=%.1f)", nm[t], acc[t] / B, acc[8 + t] / B);
         fprintf(stderr, " total %.0f\n", tot_);
+        if (B > 1) {   // the slowest problems
+            std::vector<std::pair<double, int>> tt;
+            for (int b = 0; b < B; ++b) { double t_ = 0; for (int t = 0; t < 8; ++t) t_ += (double)h[(size_t)b * 16 + t]; tt.push_back({t_, b}); }
+            std::sort(tt.begin(), tt.end());
+            for (int r = 0; r < 4; ++r) {
+                const int b = tt[(size_t)(B - 1 - r)].second;
+                fprintf(stderr, "   slow #%d (b=%d, %.0f cyc):", r, b, tt[(size_t)(B - 1 - r)].first);
+                for (int t = 0; t < 8; ++t) fprintf(stderr, " %s %.0f (n=%.0f)", nm[t], (double)h[(size_t)b * 16 + t], (double)h[(size_t)b * 16 + 8 + t]);
+                fprintf(stderr, "\n");
+            }
+            fprintf(stderr, "   median problem: %.0f cyc\n", tt[(size_t)B / 2].first);
+        }
     }
 #endif
     return ROMAN_OK;
@@ -556,7 +568,7 @@ int roman_ctx_create(roman_ctx_t** out, int device, void* stream)
     if (!c) return fail(nullptr, ROMAN_E_NOMEM, "out of host memory");
     c->device = device;
     c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    c->lds_max = prop.sharedMemPerBlock >= 163840 ? (size_t)(160 * 1024 - 4096) : (size_t)prop.sharedMemPerBlock;
+    c->lds_max = prop.sharedMemPerBlock >= 163840 ? (size_t)(160 * 1024 - 256) : (size_t)prop.sharedMemPerBlock;
     if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
     else {
         if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return fail(nullptr, ROMAN_E_HIP, "hipStreamCreate failed"); }
