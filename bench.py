@@ -45,6 +45,9 @@ def parse():
     ap.add_argument("--cpu-sample", type=int, default=4, help="pairs timed on the CPU oracle (rank 0, N=1 only); 0 = skip")
     ap.add_argument("--latency-reps", type=int, default=30)
     ap.add_argument("--no-profile", action="store_true", help="do not bracket stages with hipEvents")
+    ap.add_argument("--pipeline", type=int, default=2, choices=[1, 2],
+                    help="batches in flight per GPU (roman_ctx_set_pipeline): 2 overlaps the straggler tail of one step's kernels "
+                         "with the next step's affinity build; results are complete at the closing device-wide synchronise")
     return ap.parse_args()
 
 
@@ -80,13 +83,17 @@ def main():
     batch = batch_from_pairs(reg, [(p.map1, p.map2) for p in pairs])
     kmax = batch.kmax()
     feats = torch.from_numpy(batch.feats).to(dev)
-    assoc_out = torch.zeros((B, kmax, 2), dtype=torch.int32, device=dev)
-    n_out = torch.zeros(B, dtype=torch.int32, device=dev)
-    T_out = torch.zeros((B, 16), dtype=torch.float64, device=dev)
-    status = torch.zeros(B, dtype=torch.int32, device=dev)
-    stats = torch.zeros(B * _abi.STATS_NBYTES, dtype=torch.uint8, device=dev)
-    stream = torch.cuda.current_stream(dev)
-    ctx = Context(local_rank, stream=stream.cuda_stream)       # library launches on torch's current stream
+    # two output sets: with two batches in flight, step k writes set k&1 while step k-1's set is gathered
+    NSET = 2
+    assoc_o = [torch.zeros((B, kmax, 2), dtype=torch.int32, device=dev) for _ in range(NSET)]
+    n_o = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(NSET)]
+    T_o = [torch.zeros((B, 16), dtype=torch.float64, device=dev) for _ in range(NSET)]
+    status_o = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(NSET)]
+    stats_o = [torch.zeros(B * _abi.STATS_NBYTES, dtype=torch.uint8, device=dev) for _ in range(NSET)]
+    assoc_out, n_out, T_out, status, stats = assoc_o[0], n_o[0], T_o[0], status_o[0], stats_o[0]
+    stream = torch.cuda.Stream(dev)                             # an explicit stream shared by torch (RCCL) and the library:
+    torch.cuda.set_stream(stream)                              # the legacy default stream would not order against it
+    ctx = Context(local_rank, stream=stream.cuda_stream)       # library launches on / behind torch's current stream
     reg.set_context(ctx)
 
     if world > 1:
@@ -94,13 +101,31 @@ def main():
         gat_i = torch.empty((world * B, 2 + 2 * kmax), dtype=torch.int32, device=dev)
         gat_T = torch.empty((world * B, 16), dtype=torch.float64, device=dev)
 
+    def gather(k):                                             # collect inlier sets + poses of output set k on every rank
+        rec_i[:, 0] = n_o[k]; rec_i[:, 1] = status_o[k]; rec_i[:, 2:] = assoc_o[k].view(B, -1)
+        dist.all_gather_into_tensor(gat_i, rec_i)
+        dist.all_gather_into_tensor(gat_T, T_o[k])
+
+    step_no = [0]
+
     def step():
+        k = step_no[0] & 1
+        step_no[0] += 1
         ctx.align_batch_dev(P, feats.data_ptr(), F, batch.off1, batch.n1, batch.off2, batch.n2, kmax,
-                            assoc_out.data_ptr(), n_out.data_ptr(), T_out.data_ptr(), status.data_ptr(), stats.data_ptr())
-        if world > 1:                                          # collect inlier sets + poses on every rank
-            rec_i[:, 0] = n_out; rec_i[:, 1] = status; rec_i[:, 2:] = assoc_out.view(B, -1)
-            dist.all_gather_into_tensor(gat_i, rec_i)
-            dist.all_gather_into_tensor(gat_T, T_out)
+                            assoc_o[k].data_ptr(), n_o[k].data_ptr(), T_o[k].data_ptr(), status_o[k].data_ptr(), stats_o[k].data_ptr())
+        if world > 1:
+            if args.pipeline == 2:
+                if step_no[0] > 1:
+                    ctx.join(skip_latest=True)                 # torch's stream waits for the PREVIOUS batch only
+                    gather(k ^ 1)
+            else:
+                gather(k)
+
+    def drain():                                               # results of the last batch
+        if args.pipeline == 2:
+            ctx.join(skip_latest=False)
+            if world > 1 and step_no[0] > 0:
+                gather((step_no[0] - 1) & 1)
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -108,19 +133,24 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    ctx.set_pipeline(args.pipeline)
     for _ in range(args.warmup):
         step()
-    fence()
+    drain(); fence()
+    step_no[0] = 0
     if not args.no_profile:
         ctx.profile_enable(True); ctx.profile_reset()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    fence()
+    drain(); fence()
     dt = time.perf_counter() - t0
     prof = ctx.profile_get() if not args.no_profile else None
     if not args.no_profile:
         ctx.profile_enable(False)
+    ctx.set_pipeline(1)                                         # the latency probe and the checks below are single calls
+    last = (args.steps - 1) & 1
+    assoc_out, n_out, T_out, status, stats = assoc_o[last], n_o[last], T_o[last], status_o[last], stats_o[last]
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -164,7 +194,8 @@ def main():
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"config 3: batch of {B} submap pairs per GPU, n={args.n} m={args.m} d={args.d}, method={args.method} "
                                f"(xyz + {args.d}-d descriptors + gravity prior); p50 latency measured on config 2 (single pair)",
-                   "pairs_per_gpu": B, "n": args.n, "m": args.m, "d": args.d, "method": args.method, "sharding": f"pairs x{world}, all_gather of records" if world > 1 else "single GPU"},
+                   "pairs_per_gpu": B, "n": args.n, "m": args.m, "d": args.d, "method": args.method, "sharding": f"pairs x{world}, all_gather of records" if world > 1 else "single GPU",
+                   "batches_in_flight": args.pipeline},
         "p50_latency_ms": p50,
         "alignments_per_s_batch1": (1e3 / p50) if p50 else None,
         "result_check": {"status_ok_frac": ok_frac, "planted_inlier_recall_mean": float(np.mean(rec)),

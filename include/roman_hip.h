@@ -141,6 +141,23 @@ ROMAN_API int roman_params_default(roman_params_t* p);
 ROMAN_API int roman_ctx_create(roman_ctx_t** ctx, int device, void* stream);
 ROMAN_API int roman_ctx_destroy(roman_ctx_t* ctx);
 
+/* Batches in flight.  depth 1 (default): every call runs on the context's stream and its results are
+   complete once that stream is synchronised.  depth 2: consecutive roman_align_batch_dev calls alternate
+   between two internal workspaces, each on an internal stream that starts behind the work already queued
+   on the context's stream, so the straggler tail of one batch's kernels overlaps the next batch's
+   affinity build (the reference's loop [REF roman/align/submap_align.py:93-200] has no dependency
+   between pairs).  With depth 2 the results of a batch call are complete after roman_ctx_sync() (or a
+   device-wide synchronisation), NOT after synchronising the context's stream alone; the caller must give
+   batches that may be in flight together distinct output buffers if it needs both results.  The
+   host-pointer and stepwise entry points always drain the pipeline first and run synchronously. */
+ROMAN_API int roman_ctx_set_pipeline(roman_ctx_t* ctx, int depth);
+/* Enqueue on the context's stream (no host blocking) a wait for the pipelined batches issued so far: all of
+   them, or — skip_latest != 0 — all but the most recent one, so that work queued on the caller's stream
+   afterwards (e.g. the all_gather of batch k-1's records) sees their results while batch k keeps running. */
+ROMAN_API int roman_ctx_join(roman_ctx_t* ctx, int skip_latest);
+/* Wait for every batch in flight on this context (all internal streams and the context's stream). */
+ROMAN_API int roman_ctx_sync(roman_ctx_t* ctx);
+
 /* Human-readable text of the last error on this context (or of the last context-less error
    when ctx == NULL).  The pointer stays valid until the next call on the same context. */
 ROMAN_API const char* roman_last_error(const roman_ctx_t* ctx);

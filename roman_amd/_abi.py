@@ -141,6 +141,9 @@ def load_library():
         "roman_params_default": (C.c_int, [P(RomanParams)]),
         "roman_ctx_create": (C.c_int, [P(ctxp), C.c_int, vp]),
         "roman_ctx_destroy": (C.c_int, [ctxp]),
+        "roman_ctx_set_pipeline": (C.c_int, [ctxp, C.c_int]),
+        "roman_ctx_sync": (C.c_int, [ctxp]),
+        "roman_ctx_join": (C.c_int, [ctxp, C.c_int]),
         "roman_last_error": (C.c_char_p, [ctxp]),
         "roman_align_batch_dev": (C.c_int, [ctxp, P(RomanParams), i32, vp, vp, vp, vp, vp, i32,
                                             vp, vp, vp, i32, vp, vp, vp, vp, vp]),
@@ -175,7 +178,8 @@ def load_library():
 
 
 EXPORTED_SYMBOLS = (
-    "roman_params_default", "roman_ctx_create", "roman_ctx_destroy", "roman_last_error",
+    "roman_params_default", "roman_ctx_create", "roman_ctx_destroy", "roman_ctx_set_pipeline", "roman_ctx_sync", "roman_ctx_join",
+    "roman_last_error",
     "roman_align_batch_dev", "roman_align_batch", "roman_create_all_to_all", "roman_score",
     "roman_set_matrix_data", "roman_solve", "roman_num_associations", "roman_num_selected",
     "roman_get_selected_associations", "roman_get_solution", "roman_get_dense_matrices",

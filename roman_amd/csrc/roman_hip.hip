@@ -45,23 +45,39 @@ struct roman_ctx {
     size_t lds_max = 65536;
     std::string err;
 
-    // workspace pools (see DESIGN.md "Data layout in HBM")
-    DevBuf probs, state, totals, queue;
-    DevBuf cosPool, normPool, tabPool, sTmp;
-    DevBuf lp, li, lj, ls, lza, lzb;
-    DevBuf rowCnt, rowPos, perm, sliceWidth, sliceBase, items, maskPool, prefPool;
-    DevBuf vMu, vCu, vMun, vCun, gU, gUn, uOut, nodesOrig, nSel;
-    DevBuf cols, vals;
-    DevBuf cols1, vals1, cols2, vals2, cols3, vals3;      // column-compacted copies of the matrix (solver levels)
-    // staging for the host-pointer entry points
-    DevBuf hFeats, hAssoc, hU0, oAssoc, oN, oT, oStatus, oStats, hAux1, hAux2, hAux3;
-    BatchTotals* pinnedTotals = nullptr;
+    // Workspace: every device pool of one batch in flight, its stream and its profiling events.  The
+    // context owns two of them: with roman_ctx_set_pipeline(ctx, 2) consecutive batch calls alternate
+    // between the two (each on its own internal stream), so the straggler tail of one batch's kernels
+    // overlaps the next batch's build.  Set 0 also serves the stepwise API.
+    struct Workspace {
+        hipStream_t stream = nullptr;          // set 0: the context's stream; set 1: internal
+        hipEvent_t done = nullptr;             // recorded after the last kernel of a batch call
+        bool issued = false;
+        // pools (see DESIGN.md "Data layout in HBM")
+        DevBuf probs, state, totals, queue;
+        DevBuf cosPool, normPool, tabPool, sTmp;
+        DevBuf lp, li, lj, ls, lza, lzb;
+        DevBuf rowCnt, rowPos, perm, sliceWidth, sliceBase, items, maskPool, prefPool;
+        DevBuf vMu, vCu, vMun, vCun, gU, gUn, uOut, nodesOrig, nSel;
+        DevBuf cols, vals;
+        DevBuf cols1, vals1, cols2, vals2, cols3, vals3;      // column-compacted copies of the matrix (solver levels)
+        // staging for the host-pointer entry points
+        DevBuf hFeats, hAssoc, hU0, oAssoc, oN, oT, oStatus, oStats, hAux1, hAux2, hAux3;
+        BatchTotals* pinnedTotals = nullptr;
+        // per-stage hipEvent pairs on `stream`
+        hipEvent_t evA[ROMAN_STAGE_COUNT] = {nullptr, nullptr, nullptr, nullptr};
+        hipEvent_t evB[ROMAN_STAGE_COUNT] = {nullptr, nullptr, nullptr, nullptr};
+        bool pending[ROMAN_STAGE_COUNT] = {false, false, false, false};
+    } ws[2];
+    int wsel = 0;                              // workspace of the call in progress
+    bool in_host_batch = false;                // roman_align_batch (host pointers) is driving roman_align_batch_dev
+    int pipeline = 1;                          // batches in flight (1 or 2)
+    int next_ws = 0;
+    hipStream_t stream2 = nullptr;             // internal stream of workspace 1 (pipeline == 2)
+    hipStream_t stream1 = nullptr;             // internal stream of workspace 0 while pipelining
+    hipEvent_t evIn = nullptr;                 // inputs ready on the caller's stream
 
-    // per-stage hipEvent pairs on `stream`
     bool profile = false;
-    hipEvent_t evA[ROMAN_STAGE_COUNT] = {nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t evB[ROMAN_STAGE_COUNT] = {nullptr, nullptr, nullptr, nullptr};
-    bool pending[ROMAN_STAGE_COUNT] = {false, false, false, false};
     double prof_ms[ROMAN_STAGE_COUNT] = {0, 0, 0, 0};
     int64_t prof_n[ROMAN_STAGE_COUNT] = {0, 0, 0, 0};
 
@@ -80,6 +96,8 @@ struct roman_ctx {
     } last;
 };
 
+#define WS (c->ws[c->wsel])
+
 namespace {
 
 int fail(roman_ctx* c, int code, const char* fmt, ...)
@@ -90,8 +108,22 @@ int fail(roman_ctx* c, int code, const char* fmt, ...)
     return code;
 }
 
+// The stepwise / host-pointer entry points run on workspace 0 and the context's own stream; work that
+// pipelined batch calls still have in flight is drained first.
+int use_ws0(roman_ctx* c);
+
 #define HIPCHK(c, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { (void)hipGetLastError(); \
     return fail((c), (e_ == hipErrorOutOfMemory) ? ROMAN_E_NOMEM : ROMAN_E_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); } } while (0)
+
+int use_ws0(roman_ctx* c)
+{
+    if (c->pipeline == 2) {
+        if (c->stream1) HIPCHK(c, hipStreamSynchronize(c->stream1));
+        if (c->stream2) HIPCHK(c, hipStreamSynchronize(c->stream2));
+    }
+    c->wsel = 0; c->ws[0].stream = c->stream;
+    return ROMAN_OK;
+}
 
 // smallest x with sqrt(x) >= t  (so  sqrt(x) < t  <=>  x < result ; sqrt is monotone and correctly
 // rounded on host and device)
@@ -150,19 +182,20 @@ int make_dev_params(roman_ctx* c, const roman_params_t* p, int32_t F, DevParams*
     return ROMAN_OK;
 }
 
-void prof_flush(roman_ctx* c, int s)
+void prof_flush(roman_ctx* c, int k, int s)
 {
-    if (!c->pending[s]) return;
+    roman_ctx::Workspace& W = c->ws[k];
+    if (!W.pending[s]) return;
     float ms = 0.f;
-    if (hipEventSynchronize(c->evB[s]) == hipSuccess && hipEventElapsedTime(&ms, c->evA[s], c->evB[s]) == hipSuccess) {
+    if (hipEventSynchronize(W.evB[s]) == hipSuccess && hipEventElapsedTime(&ms, W.evA[s], W.evB[s]) == hipSuccess) {
         c->prof_ms[s] += (double)ms; c->prof_n[s] += 1;
     }
-    c->pending[s] = false;
+    W.pending[s] = false;
 }
 struct StageTimer {
     roman_ctx* c; int s;
-    StageTimer(roman_ctx* c_, int s_) : c(c_), s(s_) { if (c->profile) { prof_flush(c, s); (void)hipEventRecord(c->evA[s], c->stream); } }
-    void stop() { if (c->profile) { (void)hipEventRecord(c->evB[s], c->stream); c->pending[s] = true; } }
+    StageTimer(roman_ctx* c_, int s_) : c(c_), s(s_) { if (c->profile) { prof_flush(c, c->wsel, s); (void)hipEventRecord(WS.evA[s], WS.stream); } }
+    void stop() { if (c->profile) { (void)hipEventRecord(WS.evB[s], WS.stream); WS.pending[s] = true; } }
 };
 
 struct BatchIn {
@@ -204,49 +237,49 @@ int stage_score(roman_ctx* c, const DevParams& D, const BatchIn& in, std::vector
     const size_t nA1 = (size_t)std::max<int64_t>(sumA, 1);
     const bool cosOn = D.p.cos_feature_dim > 0;
 
-    HIPCHK(c, c->probs.ensure(sizeof(ProbDesc) * (size_t)B));
-    HIPCHK(c, c->state.ensure(sizeof(ProbState) * (size_t)B));
-    HIPCHK(c, c->totals.ensure(sizeof(BatchTotals)));
-    HIPCHK(c, c->queue.ensure(sizeof(int) * 4));
-    HIPCHK(c, c->cosPool.ensure(sizeof(double) * (size_t)(cosOn ? std::max<int64_t>(sumCos, 1) : 1)));
-    HIPCHK(c, c->normPool.ensure(sizeof(double) * (size_t)(cosOn ? std::max<int64_t>(sumN, 1) : 1)));
-    HIPCHK(c, c->tabPool.ensure(sizeof(double) * (size_t)std::max<int64_t>(sumTab, 1)));
-    HIPCHK(c, c->sTmp.ensure(sizeof(double) * nA1));
-    HIPCHK(c, c->lp.ensure(sizeof(int32_t) * nA1)); HIPCHK(c, c->li.ensure(sizeof(int32_t) * nA1)); HIPCHK(c, c->lj.ensure(sizeof(int32_t) * nA1));
-    HIPCHK(c, c->ls.ensure(sizeof(double) * nA1)); HIPCHK(c, c->lza.ensure(sizeof(double) * nA1)); HIPCHK(c, c->lzb.ensure(sizeof(double) * nA1));
-    HIPCHK(c, c->rowCnt.ensure(sizeof(uint32_t) * nA1)); HIPCHK(c, c->rowPos.ensure(sizeof(uint32_t) * nA1)); HIPCHK(c, c->perm.ensure(sizeof(uint32_t) * nA1));
-    HIPCHK(c, c->sliceWidth.ensure(sizeof(uint32_t) * nA1)); HIPCHK(c, c->sliceBase.ensure(sizeof(uint32_t) * nA1));
+    HIPCHK(c, WS.probs.ensure(sizeof(ProbDesc) * (size_t)B));
+    HIPCHK(c, WS.state.ensure(sizeof(ProbState) * (size_t)B));
+    HIPCHK(c, WS.totals.ensure(sizeof(BatchTotals)));
+    HIPCHK(c, WS.queue.ensure(sizeof(int) * 4));
+    HIPCHK(c, WS.cosPool.ensure(sizeof(double) * (size_t)(cosOn ? std::max<int64_t>(sumCos, 1) : 1)));
+    HIPCHK(c, WS.normPool.ensure(sizeof(double) * (size_t)(cosOn ? std::max<int64_t>(sumN, 1) : 1)));
+    HIPCHK(c, WS.tabPool.ensure(sizeof(double) * (size_t)std::max<int64_t>(sumTab, 1)));
+    HIPCHK(c, WS.sTmp.ensure(sizeof(double) * nA1));
+    HIPCHK(c, WS.lp.ensure(sizeof(int32_t) * nA1)); HIPCHK(c, WS.li.ensure(sizeof(int32_t) * nA1)); HIPCHK(c, WS.lj.ensure(sizeof(int32_t) * nA1));
+    HIPCHK(c, WS.ls.ensure(sizeof(double) * nA1)); HIPCHK(c, WS.lza.ensure(sizeof(double) * nA1)); HIPCHK(c, WS.lzb.ensure(sizeof(double) * nA1));
+    HIPCHK(c, WS.rowCnt.ensure(sizeof(uint32_t) * nA1)); HIPCHK(c, WS.rowPos.ensure(sizeof(uint32_t) * nA1)); HIPCHK(c, WS.perm.ensure(sizeof(uint32_t) * nA1));
+    HIPCHK(c, WS.sliceWidth.ensure(sizeof(uint32_t) * nA1)); HIPCHK(c, WS.sliceBase.ensure(sizeof(uint32_t) * nA1));
     // work items: blocks of RPB consecutive live rows of one problem (more, smaller items for small batches)
     int RPB = 32;
     while (RPB < 256 && (int64_t)RPB * c->num_cu * 64 < sumA) RPB <<= 1;
     const size_t maxItems = (size_t)(sumA / RPB) + (size_t)B + 1;
-    HIPCHK(c, c->items.ensure(sizeof(ItemDesc) * maxItems));
+    HIPCHK(c, WS.items.ensure(sizeof(ItemDesc) * maxItems));
 
-    HIPCHK(c, hipMemcpyAsync(c->probs.p, hd.data(), sizeof(ProbDesc) * (size_t)B, hipMemcpyHostToDevice, c->stream));
-    const ProbDesc* dP = c->probs.as<ProbDesc>();
-    ProbState* dS = c->state.as<ProbState>();
-    BatchTotals* dT = c->totals.as<BatchTotals>();
+    HIPCHK(c, hipMemcpyAsync(WS.probs.p, hd.data(), sizeof(ProbDesc) * (size_t)B, hipMemcpyHostToDevice, WS.stream));
+    const ProbDesc* dP = WS.probs.as<ProbDesc>();
+    ProbState* dS = WS.state.as<ProbState>();
+    BatchTotals* dT = WS.totals.as<BatchTotals>();
 
     StageTimer t0(c, ROMAN_STAGE_SINGLE);
     if (cosOn && maxN12 > 0) {
-        hipLaunchKernelGGL(k_norms, dim3((maxN12 + 3) / 4, B), dim3(256), 0, c->stream, D, dP, in.feats, c->normPool.as<double>());
+        hipLaunchKernelGGL(k_norms, dim3((maxN12 + 3) / 4, B), dim3(256), 0, WS.stream, D, dP, in.feats, WS.normPool.as<double>());
         if (maxTiles > 0)
-            hipLaunchKernelGGL(k_cos, dim3((maxTiles + 3) / 4, B), dim3(256), 0, c->stream, D, dP, in.feats, c->normPool.as<double>(), c->cosPool.as<double>());
+            hipLaunchKernelGGL(k_cos, dim3((maxTiles + 3) / 4, B), dim3(256), 0, WS.stream, D, dP, in.feats, WS.normPool.as<double>(), WS.cosPool.as<double>());
     }
     if (maxTab > 0)
-        hipLaunchKernelGGL(k_tables, dim3((unsigned)((maxTab + 255) / 256), B), dim3(256), 0, c->stream, D, dP, in.feats, c->tabPool.as<double>());
-    hipLaunchKernelGGL(k_live, dim3(B), dim3(1024), 0, c->stream, D, dP, dS, in.feats, in.assoc, c->cosPool.as<double>(), c->sTmp.as<double>(),
-                       c->lp.as<int32_t>(), c->li.as<int32_t>(), c->lj.as<int32_t>(), c->ls.as<double>(), c->lza.as<double>(), c->lzb.as<double>());
-    hipLaunchKernelGGL(k_rowbase, dim3(1), dim3(64), 0, c->stream, B, RPB, dS, dT);
-    hipLaunchKernelGGL(k_items, dim3(B), dim3(256), 0, c->stream, RPB, dS, c->items.as<ItemDesc>());
+        hipLaunchKernelGGL(k_tables, dim3((unsigned)((maxTab + 255) / 256), B), dim3(256), 0, WS.stream, D, dP, in.feats, WS.tabPool.as<double>());
+    hipLaunchKernelGGL(k_live, dim3(B), dim3(1024), 0, WS.stream, D, dP, dS, in.feats, in.assoc, WS.cosPool.as<double>(), WS.sTmp.as<double>(),
+                       WS.lp.as<int32_t>(), WS.li.as<int32_t>(), WS.lj.as<int32_t>(), WS.ls.as<double>(), WS.lza.as<double>(), WS.lzb.as<double>());
+    hipLaunchKernelGGL(k_rowbase, dim3(1), dim3(64), 0, WS.stream, B, RPB, dS, dT);
+    hipLaunchKernelGGL(k_items, dim3(B), dim3(256), 0, WS.stream, RPB, dS, WS.items.as<ItemDesc>());
     // read-back #1 (24 bytes): live totals -> size of the candidate bit matrices, index width
-    HIPCHK(c, hipMemcpyAsync(c->pinnedTotals, dT, sizeof(BatchTotals), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(WS.pinnedTotals, dT, sizeof(BatchTotals), hipMemcpyDeviceToHost, WS.stream));
     t0.stop();
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    BatchTotals tot = *c->pinnedTotals;
+    HIPCHK(c, hipStreamSynchronize(WS.stream));
+    BatchTotals tot = *WS.pinnedTotals;
     *idx16 = tot.maxL <= 32767;        // column indices are LIVE indices; bit 15 is the C==0 flag
-    HIPCHK(c, c->maskPool.ensure(sizeof(unsigned long long) * (size_t)std::max<int64_t>(tot.maskWords, 1)));
-    HIPCHK(c, c->prefPool.ensure(sizeof(uint32_t) * (size_t)std::max<int64_t>(tot.maskWords, 1)));
+    HIPCHK(c, WS.maskPool.ensure(sizeof(unsigned long long) * (size_t)std::max<int64_t>(tot.maskWords, 1)));
+    HIPCHK(c, WS.prefPool.ensure(sizeof(uint32_t) * (size_t)std::max<int64_t>(tot.maskWords, 1)));
 
     // pair-test kernel LDS: a column tile (objects [+ z] of every live association) + per-wave table rows
     const int ldsPerWave = ((2 * std::max(maxN, 1) + 1 + 1) & ~1) + 2;    // n1 + sentinel + n2 doubles
@@ -266,23 +299,23 @@ int stage_score(roman_ctx* c, const DevParams& D, const BatchIn& in, std::vector
     if (tot.R > 0) {
         auto kc = D.gravity ? k_count<true> : k_count<false>;
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kc), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pairLds));
-        hipLaunchKernelGGL(kc, dim3(pairGrid), dim3(wpb * 64), pairLds, c->stream, D, dP, dS, dT, c->items.as<ItemDesc>(), c->tabPool.as<double>(),
-                           c->li.as<int32_t>(), c->lj.as<int32_t>(), c->lza.as<double>(), c->lzb.as<double>(),
-                           c->rowCnt.as<uint32_t>(), c->maskPool.as<unsigned long long>(), c->prefPool.as<uint32_t>(), TCc, ldsPerWave, RPB);
+        hipLaunchKernelGGL(kc, dim3(pairGrid), dim3(wpb * 64), pairLds, WS.stream, D, dP, dS, dT, WS.items.as<ItemDesc>(), WS.tabPool.as<double>(),
+                           WS.li.as<int32_t>(), WS.lj.as<int32_t>(), WS.lza.as<double>(), WS.lzb.as<double>(),
+                           WS.rowCnt.as<uint32_t>(), WS.maskPool.as<unsigned long long>(), WS.prefPool.as<uint32_t>(), TCc, ldsPerWave, RPB);
     }
     const bool quad = use_quad(D, tot.maxL);
-    hipLaunchKernelGGL(k_rowsort, dim3(B), dim3(1024), 0, c->stream, quad ? 4 : 1, dP, dS, c->rowCnt.as<uint32_t>(), c->rowPos.as<uint32_t>(), c->perm.as<uint32_t>(),
-                       c->sliceWidth.as<uint32_t>(), c->sliceBase.as<uint32_t>());
-    hipLaunchKernelGGL(k_probscan, dim3(1), dim3(64), 0, c->stream, B, dS, dT);
+    hipLaunchKernelGGL(k_rowsort, dim3(B), dim3(1024), 0, WS.stream, quad ? 4 : 1, dP, dS, WS.rowCnt.as<uint32_t>(), WS.rowPos.as<uint32_t>(), WS.perm.as<uint32_t>(),
+                       WS.sliceWidth.as<uint32_t>(), WS.sliceBase.as<uint32_t>());
+    hipLaunchKernelGGL(k_probscan, dim3(1), dim3(64), 0, WS.stream, B, dS, dT);
     // read-back #2: padded slot total -> size of the matrix arrays
-    HIPCHK(c, hipMemcpyAsync(c->pinnedTotals, dT, sizeof(BatchTotals), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(WS.pinnedTotals, dT, sizeof(BatchTotals), hipMemcpyDeviceToHost, WS.stream));
     t1.stop();
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    tot = *c->pinnedTotals;
+    HIPCHK(c, hipStreamSynchronize(WS.stream));
+    tot = *WS.pinnedTotals;
     *totOut = tot;
     const size_t nnz1 = (size_t)std::max<int64_t>(tot.nnzTotal, 1);
-    HIPCHK(c, c->vals.ensure(sizeof(double) * nnz1));
-    HIPCHK(c, c->cols.ensure((*idx16 ? sizeof(uint16_t) : sizeof(uint32_t)) * nnz1));
+    HIPCHK(c, WS.vals.ensure(sizeof(double) * nnz1));
+    HIPCHK(c, WS.cols.ensure((*idx16 ? sizeof(uint16_t) : sizeof(uint32_t)) * nnz1));
 
     StageTimer t2(c, ROMAN_STAGE_FILL);
     if (tot.R > 0) {
@@ -296,10 +329,10 @@ int stage_score(roman_ctx* c, const DevParams& D, const BatchIn& in, std::vector
 #define ROMAN_LAUNCH_FILL(GRAV_, IDX, QUAD_)                                                                                          \
         do {                                                                                                                   \
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_fill<GRAV_, IDX, QUAD_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fillLds)); \
-        hipLaunchKernelGGL((k_fill<GRAV_, IDX, QUAD_>), dim3(fillGrid), dim3(1024), fillLds, c->stream, D, dP, dS, dT, c->items.as<ItemDesc>(), c->tabPool.as<double>(), \
-                           c->li.as<int32_t>(), c->lj.as<int32_t>(), c->ls.as<double>(), c->lza.as<double>(), c->lzb.as<double>(),          \
-                           c->rowCnt.as<uint32_t>(), c->maskPool.as<unsigned long long>(), c->prefPool.as<uint32_t>(), c->rowPos.as<uint32_t>(), \
-                           c->sliceWidth.as<uint32_t>(), c->sliceBase.as<uint32_t>(), c->cols.as<IDX>(), c->vals.as<double>(), TCf, RPB);        \
+        hipLaunchKernelGGL((k_fill<GRAV_, IDX, QUAD_>), dim3(fillGrid), dim3(1024), fillLds, WS.stream, D, dP, dS, dT, WS.items.as<ItemDesc>(), WS.tabPool.as<double>(), \
+                           WS.li.as<int32_t>(), WS.lj.as<int32_t>(), WS.ls.as<double>(), WS.lza.as<double>(), WS.lzb.as<double>(),          \
+                           WS.rowCnt.as<uint32_t>(), WS.maskPool.as<unsigned long long>(), WS.prefPool.as<uint32_t>(), WS.rowPos.as<uint32_t>(), \
+                           WS.sliceWidth.as<uint32_t>(), WS.sliceBase.as<uint32_t>(), WS.cols.as<IDX>(), WS.vals.as<double>(), TCf, RPB);        \
         } while (0)
         if (quad)        { if (D.gravity) ROMAN_LAUNCH_FILL(true, uint16_t, true); else ROMAN_LAUNCH_FILL(false, uint16_t, true); }
         else if (*idx16) { if (D.gravity) ROMAN_LAUNCH_FILL(true, uint16_t, false); else ROMAN_LAUNCH_FILL(false, uint16_t, false); }
@@ -319,10 +352,10 @@ int stage_solve(roman_ctx* c, const DevParams& D, int B, const double* feats, co
                 roman_stats_t* stats_out)
 {
     const size_t R1 = (size_t)std::max(tot.R, 1);
-    HIPCHK(c, c->vMu.ensure(sizeof(double) * R1)); HIPCHK(c, c->vCu.ensure(sizeof(double) * R1));
-    HIPCHK(c, c->vMun.ensure(sizeof(double) * R1)); HIPCHK(c, c->vCun.ensure(sizeof(double) * R1));
-    HIPCHK(c, c->uOut.ensure(sizeof(double) * R1)); HIPCHK(c, c->nodesOrig.ensure(sizeof(int32_t) * R1));
-    HIPCHK(c, c->nSel.ensure(sizeof(int32_t) * (size_t)B));
+    HIPCHK(c, WS.vMu.ensure(sizeof(double) * R1)); HIPCHK(c, WS.vCu.ensure(sizeof(double) * R1));
+    HIPCHK(c, WS.vMun.ensure(sizeof(double) * R1)); HIPCHK(c, WS.vCun.ensure(sizeof(double) * R1));
+    HIPCHK(c, WS.uOut.ensure(sizeof(double) * R1)); HIPCHK(c, WS.nodesOrig.ensure(sizeof(int32_t) * R1));
+    HIPCHK(c, WS.nSel.ensure(sizeof(int32_t) * (size_t)B));
 
     // fast path: streaming solver on the quad layout with column-compacted levels
     const bool regPath = use_quad(D, tot.maxL);
@@ -333,46 +366,46 @@ int stage_solve(roman_ctx* c, const DevParams& D, int B, const double* feats, co
     if (2 * sizeof(double) * (size_t)Lcap + fixed > c->lds_max) { mode = 0; Lcap = 0; }
     if (regPath) Lcap = (std::max(tot.maxL, 64) + 1) & ~1;
     const int nvec = mode == 1 ? 2 : 0;
-    HIPCHK(c, c->gU.ensure(sizeof(double) * ((mode == 0 && !regPath) ? R1 : 1))); HIPCHK(c, c->gUn.ensure(sizeof(double) * ((mode == 0 && !regPath) ? R1 : 1)));
+    HIPCHK(c, WS.gU.ensure(sizeof(double) * ((mode == 0 && !regPath) ? R1 : 1))); HIPCHK(c, WS.gUn.ensure(sizeof(double) * ((mode == 0 && !regPath) ? R1 : 1)));
     size_t lds = (size_t)nvec * sizeof(double) * (size_t)Lcap + fixed;
     if (regPath) {
         Lcap = (tot.maxL + 2 + 1) & ~1;                            // vector length incl. the dummy element [L]
         lds = stream_lds_bytes(tot.maxL);
         const size_t nnz1 = (size_t)std::max<int64_t>(tot.nnzTotal, 1);
-        HIPCHK(c, c->vals1.ensure(sizeof(double) * nnz1)); HIPCHK(c, c->cols1.ensure(sizeof(uint16_t) * nnz1));
-        HIPCHK(c, c->vals2.ensure(sizeof(double) * nnz1)); HIPCHK(c, c->cols2.ensure(sizeof(uint16_t) * nnz1));
-        HIPCHK(c, c->vals3.ensure(sizeof(double) * nnz1)); HIPCHK(c, c->cols3.ensure(sizeof(uint16_t) * nnz1));
+        HIPCHK(c, WS.vals1.ensure(sizeof(double) * nnz1)); HIPCHK(c, WS.cols1.ensure(sizeof(uint16_t) * nnz1));
+        HIPCHK(c, WS.vals2.ensure(sizeof(double) * nnz1)); HIPCHK(c, WS.cols2.ensure(sizeof(uint16_t) * nnz1));
+        HIPCHK(c, WS.vals3.ensure(sizeof(double) * nnz1)); HIPCHK(c, WS.cols3.ensure(sizeof(uint16_t) * nnz1));
     }
     const int nt = regPath ? ST_NW * 64 : 1024;
     const int grid = std::max(1, std::min(B, c->num_cu));
 
-    HIPCHK(c, hipMemsetAsync(c->queue.p, 0, sizeof(int) * 4, c->stream));
+    HIPCHK(c, hipMemsetAsync(WS.queue.p, 0, sizeof(int) * 4, WS.stream));
     SolveOut O;
     O.assoc_out = assoc_out; O.n_assoc_out = n_assoc_out; O.T_out = T_out; O.status_out = status_out; O.stats_out = stats_out; O.kmax = kmax;
-    O.nodesOrig = c->nodesOrig.as<int32_t>(); O.nSel = c->nSel.as<int32_t>(); O.uOut = c->uOut.as<double>();
+    O.nodesOrig = WS.nodesOrig.as<int32_t>(); O.nSel = WS.nSel.as<int32_t>(); O.uOut = WS.uOut.as<double>();
     O.dbg = nullptr;
 #ifdef ROMAN_SOLVE_TIMING
-    HIPCHK(c, c->hAux3.ensure(sizeof(unsigned long long) * 16 * (size_t)B));
-    HIPCHK(c, hipMemsetAsync(c->hAux3.p, 0, sizeof(unsigned long long) * 16 * (size_t)B, c->stream));
-    O.dbg = c->hAux3.as<unsigned long long>();
+    HIPCHK(c, WS.hAux3.ensure(sizeof(unsigned long long) * 16 * (size_t)B));
+    HIPCHK(c, hipMemsetAsync(WS.hAux3.p, 0, sizeof(unsigned long long) * 16 * (size_t)B, WS.stream));
+    O.dbg = WS.hAux3.as<unsigned long long>();
 #endif
 
     StageTimer t3(c, ROMAN_STAGE_SOLVE);
 #define ROMAN_LAUNCH_SOLVE(IDX, MODE_)                                                                                        \
     do {                                                                                                                      \
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve<IDX, MODE_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL((k_solve<IDX, MODE_>), dim3(grid), dim3(nt), lds, c->stream, D, B, c->probs.as<ProbDesc>(), c->state.as<ProbState>(), feats, assoc, \
-                           c->lp.as<int32_t>(), c->ls.as<double>(), c->perm.as<uint32_t>(), c->sliceWidth.as<uint32_t>(), c->sliceBase.as<uint32_t>(), c->cols.as<IDX>(), c->vals.as<double>(), \
-                           c->vMu.as<double>(), c->vCu.as<double>(), c->vMun.as<double>(), c->vCun.as<double>(), c->gU.as<double>(), c->gUn.as<double>(), \
-                           u0, O, c->queue.as<int>(), Lcap);                                                                   \
+        hipLaunchKernelGGL((k_solve<IDX, MODE_>), dim3(grid), dim3(nt), lds, WS.stream, D, B, WS.probs.as<ProbDesc>(), WS.state.as<ProbState>(), feats, assoc, \
+                           WS.lp.as<int32_t>(), WS.ls.as<double>(), WS.perm.as<uint32_t>(), WS.sliceWidth.as<uint32_t>(), WS.sliceBase.as<uint32_t>(), WS.cols.as<IDX>(), WS.vals.as<double>(), \
+                           WS.vMu.as<double>(), WS.vCu.as<double>(), WS.vMun.as<double>(), WS.vCun.as<double>(), WS.gU.as<double>(), WS.gUn.as<double>(), \
+                           u0, O, WS.queue.as<int>(), Lcap);                                                                   \
     } while (0)
 #define ROMAN_LAUNCH_SOLVE_STREAM(CZ_)                                                                                        \
     do {                                                                                                                      \
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve_stream<CZ_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL((k_solve_stream<CZ_>), dim3(grid), dim3(nt), lds, c->stream, D, B, c->probs.as<ProbDesc>(), c->state.as<ProbState>(), feats, assoc, \
-                           c->lp.as<int32_t>(), c->ls.as<double>(), c->perm.as<uint32_t>(), c->sliceBase.as<uint32_t>(), \
-                           c->cols.as<uint16_t>(), c->vals.as<double>(), c->cols1.as<uint16_t>(), c->vals1.as<double>(), c->cols2.as<uint16_t>(), c->vals2.as<double>(), \
-                           c->cols3.as<uint16_t>(), c->vals3.as<double>(), u0, O, c->queue.as<int>(), Lcap);                    \
+        hipLaunchKernelGGL((k_solve_stream<CZ_>), dim3(grid), dim3(nt), lds, WS.stream, D, B, WS.probs.as<ProbDesc>(), WS.state.as<ProbState>(), feats, assoc, \
+                           WS.lp.as<int32_t>(), WS.ls.as<double>(), WS.perm.as<uint32_t>(), WS.sliceBase.as<uint32_t>(), \
+                           WS.cols.as<uint16_t>(), WS.vals.as<double>(), WS.cols1.as<uint16_t>(), WS.vals1.as<double>(), WS.cols2.as<uint16_t>(), WS.vals2.as<double>(), \
+                           WS.cols3.as<uint16_t>(), WS.vals3.as<double>(), u0, O, WS.queue.as<int>(), Lcap);                    \
     } while (0)
     if (regPath) { if (hascz) ROMAN_LAUNCH_SOLVE_STREAM(true); else ROMAN_LAUNCH_SOLVE_STREAM(false); }
     else if (idx16) { if (mode == 1) ROMAN_LAUNCH_SOLVE(uint16_t, 1); else ROMAN_LAUNCH_SOLVE(uint16_t, 0); }
@@ -384,8 +417,8 @@ int stage_solve(roman_ctx* c, const DevParams& D, int B, const double* feats, co
 #ifdef ROMAN_SOLVE_TIMING
     if (regPath) {
         std::vector<unsigned long long> h((size_t)B * 16);
-        HIPCHK(c, hipMemcpyAsync(h.data(), c->hAux3.p, sizeof(unsigned long long) * 16 * (size_t)B, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipMemcpyAsync(h.data(), WS.hAux3.p, sizeof(unsigned long long) * 16 * (size_t)B, hipMemcpyDeviceToHost, WS.stream));
+        HIPCHK(c, hipStreamSynchronize(WS.stream));
         double acc[16] = {0};
         for (int b = 0; b < B; ++b) for (int t = 0; t < 16; ++t) acc[t] += (double)h[(size_t)b * 16 + t];
         const char* nm[8] = {"stream", "spmv-barrier", "combine", "other", "compact0", "compactN", "red-norm", "red-sums"};
@@ -412,10 +445,11 @@ int stage_solve(roman_ctx* c, const DevParams& D, int B, const double* feats, co
 
 int ensure_events(roman_ctx* c)
 {
-    for (int s = 0; s < ROMAN_STAGE_COUNT; ++s) {
-        if (!c->evA[s]) HIPCHK(c, hipEventCreate(&c->evA[s]));
-        if (!c->evB[s]) HIPCHK(c, hipEventCreate(&c->evB[s]));
-    }
+    for (int k = 0; k < 2; ++k)
+        for (int s = 0; s < ROMAN_STAGE_COUNT; ++s) {
+            if (!c->ws[k].evA[s]) HIPCHK(c, hipEventCreate(&c->ws[k].evA[s]));
+            if (!c->ws[k].evB[s]) HIPCHK(c, hipEventCreate(&c->ws[k].evB[s]));
+        }
     return ROMAN_OK;
 }
 
@@ -427,33 +461,33 @@ int solve_last(roman_ctx* c, const double* u0_host)
     const size_t nA1 = (size_t)std::max(nA, 1);
     const double* dU0 = nullptr;
     if (u0_host) {
-        HIPCHK(c, c->hU0.ensure(sizeof(double) * nA1));
-        HIPCHK(c, hipMemcpyAsync(c->hU0.p, u0_host, sizeof(double) * (size_t)nA, hipMemcpyHostToDevice, c->stream));
-        dU0 = c->hU0.as<double>();
+        HIPCHK(c, WS.hU0.ensure(sizeof(double) * nA1));
+        HIPCHK(c, hipMemcpyAsync(WS.hU0.p, u0_host, sizeof(double) * (size_t)nA, hipMemcpyHostToDevice, WS.stream));
+        dU0 = WS.hU0.as<double>();
     }
     const int32_t kmax = std::max(nA, 1);
-    HIPCHK(c, c->oAssoc.ensure(sizeof(int32_t) * 2 * (size_t)kmax)); HIPCHK(c, c->oN.ensure(sizeof(int32_t)));
-    HIPCHK(c, c->oT.ensure(sizeof(double) * 16)); HIPCHK(c, c->oStatus.ensure(sizeof(int32_t))); HIPCHK(c, c->oStats.ensure(sizeof(roman_stats_t)));
-    const double* feats = Lst.dense ? nullptr : c->hFeats.as<double>();
-    const int32_t* assoc = (Lst.pd.assocOff >= 0) ? c->hAssoc.as<int32_t>() : nullptr;
-    int rc = stage_solve(c, Lst.D, 1, feats, assoc, dU0, Lst.tot, Lst.idx16, Lst.hascz, kmax, c->oAssoc.as<int32_t>(), c->oN.as<int32_t>(),
-                         c->oT.as<double>(), c->oStatus.as<int32_t>(), c->oStats.as<roman_stats_t>());
+    HIPCHK(c, WS.oAssoc.ensure(sizeof(int32_t) * 2 * (size_t)kmax)); HIPCHK(c, WS.oN.ensure(sizeof(int32_t)));
+    HIPCHK(c, WS.oT.ensure(sizeof(double) * 16)); HIPCHK(c, WS.oStatus.ensure(sizeof(int32_t))); HIPCHK(c, WS.oStats.ensure(sizeof(roman_stats_t)));
+    const double* feats = Lst.dense ? nullptr : WS.hFeats.as<double>();
+    const int32_t* assoc = (Lst.pd.assocOff >= 0) ? WS.hAssoc.as<int32_t>() : nullptr;
+    int rc = stage_solve(c, Lst.D, 1, feats, assoc, dU0, Lst.tot, Lst.idx16, Lst.hascz, kmax, WS.oAssoc.as<int32_t>(), WS.oN.as<int32_t>(),
+                         WS.oT.as<double>(), WS.oStatus.as<int32_t>(), WS.oStats.as<roman_stats_t>());
     if (rc) return rc;
     int32_t nsel = 0;
-    HIPCHK(c, hipMemcpyAsync(&nsel, c->nSel.p, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(&Lst.stats, c->oStats.p, sizeof(roman_stats_t), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(&Lst.status, c->oStatus.p, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpyAsync(&nsel, WS.nSel.p, sizeof(int32_t), hipMemcpyDeviceToHost, WS.stream));
+    HIPCHK(c, hipMemcpyAsync(&Lst.stats, WS.oStats.p, sizeof(roman_stats_t), hipMemcpyDeviceToHost, WS.stream));
+    HIPCHK(c, hipMemcpyAsync(&Lst.status, WS.oStatus.p, sizeof(int32_t), hipMemcpyDeviceToHost, WS.stream));
+    HIPCHK(c, hipStreamSynchronize(WS.stream));
     Lst.nsel = nsel;
     Lst.nodes.assign((size_t)std::max(nsel, 0), 0);
     const int L = Lst.tot.R;
     std::vector<double> ul((size_t)std::max(L, 1)); std::vector<int32_t> lpv((size_t)std::max(L, 1));
-    if (nsel > 0) HIPCHK(c, hipMemcpyAsync(Lst.nodes.data(), c->nodesOrig.p, sizeof(int32_t) * (size_t)nsel, hipMemcpyDeviceToHost, c->stream));
+    if (nsel > 0) HIPCHK(c, hipMemcpyAsync(Lst.nodes.data(), WS.nodesOrig.p, sizeof(int32_t) * (size_t)nsel, hipMemcpyDeviceToHost, WS.stream));
     if (L > 0) {
-        HIPCHK(c, hipMemcpyAsync(ul.data(), c->uOut.p, sizeof(double) * (size_t)L, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(lpv.data(), c->lp.p, sizeof(int32_t) * (size_t)L, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(ul.data(), WS.uOut.p, sizeof(double) * (size_t)L, hipMemcpyDeviceToHost, WS.stream));
+        HIPCHK(c, hipMemcpyAsync(lpv.data(), WS.lp.p, sizeof(int32_t) * (size_t)L, hipMemcpyDeviceToHost, WS.stream));
     }
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipStreamSynchronize(WS.stream));
     Lst.u.assign((size_t)nA, 0.0);
     for (int k = 0; k < L; ++k) Lst.u[(size_t)lpv[k]] = ul[k];
     Lst.L = L;
@@ -496,21 +530,21 @@ int fetch_last_csr(const roman_ctx* cc, std::vector<uint32_t>& rs, std::vector<u
     HIPCHK(c, hipSetDevice(c->device));
     if (L > 0) {
         const int nsl = (L + 63) / 64;
-        HIPCHK(c, hipMemcpy(jcnt.data(), c->rowCnt.p, sizeof(uint32_t) * (size_t)L, hipMemcpyDeviceToHost));
-        HIPCHK(c, hipMemcpy(jpos.data(), c->rowPos.p, sizeof(uint32_t) * (size_t)L, hipMemcpyDeviceToHost));
-        HIPCHK(c, hipMemcpy(jsw.data(), c->sliceWidth.p, sizeof(uint32_t) * (size_t)nsl, hipMemcpyDeviceToHost));
-        HIPCHK(c, hipMemcpy(jsb.data(), c->sliceBase.p, sizeof(uint32_t) * (size_t)nsl, hipMemcpyDeviceToHost));
-        HIPCHK(c, hipMemcpy(lp.data(), c->lp.p, sizeof(int32_t) * (size_t)L, hipMemcpyDeviceToHost));
-        HIPCHK(c, hipMemcpy(ls.data(), c->ls.p, sizeof(double) * (size_t)L, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(jcnt.data(), WS.rowCnt.p, sizeof(uint32_t) * (size_t)L, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(jpos.data(), WS.rowPos.p, sizeof(uint32_t) * (size_t)L, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(jsw.data(), WS.sliceWidth.p, sizeof(uint32_t) * (size_t)nsl, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(jsb.data(), WS.sliceBase.p, sizeof(uint32_t) * (size_t)nsl, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(lp.data(), WS.lp.p, sizeof(int32_t) * (size_t)L, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(ls.data(), WS.ls.p, sizeof(double) * (size_t)L, hipMemcpyDeviceToHost));
     }
     if (cap > 0) {
-        HIPCHK(c, hipMemcpy(jvals.data(), c->vals.p, sizeof(double) * (size_t)cap, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(jvals.data(), WS.vals.p, sizeof(double) * (size_t)cap, hipMemcpyDeviceToHost));
         if (Lst.idx16) {
             std::vector<uint16_t> c16((size_t)cap);
-            HIPCHK(c, hipMemcpy(c16.data(), c->cols.p, sizeof(uint16_t) * (size_t)cap, hipMemcpyDeviceToHost));
+            HIPCHK(c, hipMemcpy(c16.data(), WS.cols.p, sizeof(uint16_t) * (size_t)cap, hipMemcpyDeviceToHost));
             for (int64_t k = 0; k < cap; ++k) jcols[(size_t)k] = (c16[(size_t)k] & 0x8000u) ? (0x80000000u | (c16[(size_t)k] & 0x7fffu)) : c16[(size_t)k];
         } else {
-            HIPCHK(c, hipMemcpy(jcols.data(), c->cols.p, sizeof(uint32_t) * (size_t)cap, hipMemcpyDeviceToHost));
+            HIPCHK(c, hipMemcpy(jcols.data(), WS.cols.p, sizeof(uint32_t) * (size_t)cap, hipMemcpyDeviceToHost));
         }
     }
     cols.clear(); vals.clear();
@@ -574,9 +608,11 @@ int roman_ctx_create(roman_ctx_t** out, int device, void* stream)
         if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return fail(nullptr, ROMAN_E_HIP, "hipStreamCreate failed"); }
         c->own_stream = true;
     }
-    if (hipHostMalloc((void**)&c->pinnedTotals, sizeof(BatchTotals), hipHostMallocDefault) != hipSuccess) {
-        if (c->own_stream) (void)hipStreamDestroy(c->stream);
-        delete c; return fail(nullptr, ROMAN_E_NOMEM, "hipHostMalloc failed");
+    c->ws[0].stream = c->stream; c->ws[1].stream = c->stream;
+    for (int k = 0; k < 2; ++k) {
+        if (hipHostMalloc((void**)&c->ws[k].pinnedTotals, sizeof(BatchTotals), hipHostMallocDefault) != hipSuccess) {
+            roman_ctx_destroy(c); return fail(nullptr, ROMAN_E_NOMEM, "hipHostMalloc failed");
+        }
     }
     *out = c;
     return ROMAN_OK;
@@ -586,15 +622,72 @@ int roman_ctx_destroy(roman_ctx_t* c)
 {
     if (!c) return ROMAN_OK;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
-    DevBuf* all[] = {&c->probs, &c->state, &c->totals, &c->queue, &c->cosPool, &c->normPool, &c->tabPool, &c->sTmp, &c->lp, &c->li, &c->lj, &c->ls, &c->lza, &c->lzb,
-                     &c->rowCnt, &c->rowPos, &c->perm, &c->sliceWidth, &c->sliceBase, &c->items, &c->maskPool, &c->prefPool, &c->vMu, &c->vCu, &c->vMun, &c->vCun, &c->gU, &c->gUn, &c->uOut, &c->nodesOrig, &c->nSel, &c->cols, &c->vals, &c->cols1, &c->vals1, &c->cols2, &c->vals2, &c->cols3, &c->vals3,
-                     &c->hFeats, &c->hAssoc, &c->hU0, &c->oAssoc, &c->oN, &c->oT, &c->oStatus, &c->oStats, &c->hAux1, &c->hAux2, &c->hAux3};
-    for (DevBuf* b : all) b->release();
-    if (c->pinnedTotals) (void)hipHostFree(c->pinnedTotals);
-    for (int s = 0; s < ROMAN_STAGE_COUNT; ++s) { if (c->evA[s]) (void)hipEventDestroy(c->evA[s]); if (c->evB[s]) (void)hipEventDestroy(c->evB[s]); }
-    if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    (void)roman_ctx_sync(c);
+    for (int k = 0; k < 2; ++k) {
+        roman_ctx::Workspace& W = c->ws[k];
+        DevBuf* all[] = {&W.probs, &W.state, &W.totals, &W.queue, &W.cosPool, &W.normPool, &W.tabPool, &W.sTmp, &W.lp, &W.li, &W.lj, &W.ls, &W.lza, &W.lzb,
+                         &W.rowCnt, &W.rowPos, &W.perm, &W.sliceWidth, &W.sliceBase, &W.items, &W.maskPool, &W.prefPool, &W.vMu, &W.vCu, &W.vMun, &W.vCun, &W.gU, &W.gUn,
+                         &W.uOut, &W.nodesOrig, &W.nSel, &W.cols, &W.vals, &W.cols1, &W.vals1, &W.cols2, &W.vals2, &W.cols3, &W.vals3,
+                         &W.hFeats, &W.hAssoc, &W.hU0, &W.oAssoc, &W.oN, &W.oT, &W.oStatus, &W.oStats, &W.hAux1, &W.hAux2, &W.hAux3};
+        for (DevBuf* b : all) b->release();
+        if (W.pinnedTotals) (void)hipHostFree(W.pinnedTotals);
+        for (int s = 0; s < ROMAN_STAGE_COUNT; ++s) { if (W.evA[s]) (void)hipEventDestroy(W.evA[s]); if (W.evB[s]) (void)hipEventDestroy(W.evB[s]); }
+        if (W.done) (void)hipEventDestroy(W.done);
+    }
+    if (c->evIn) (void)hipEventDestroy(c->evIn);
+    if (c->stream1) (void)hipStreamDestroy(c->stream1);
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
+    return ROMAN_OK;
+}
+
+// Two batches in flight.  depth 1 (default): every call runs on the context's stream.  depth 2: batch calls
+// (roman_align_batch_dev) alternate between two workspaces, each with an internal stream that starts after
+// the work already queued on the context's stream; their results are complete after roman_ctx_sync (or a
+// device-wide synchronisation), NOT after synchronising the context's stream alone.
+int roman_ctx_set_pipeline(roman_ctx_t* c, int depth)
+{
+    if (!c) return fail(nullptr, ROMAN_E_INVALID, "ctx is NULL");
+    if (depth != 1 && depth != 2) return fail(c, ROMAN_E_INVALID, "pipeline depth must be 1 or 2");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = roman_ctx_sync(c);
+    if (rc) return rc;
+    if (depth == 2) {
+        if (!c->stream1) HIPCHK(c, hipStreamCreateWithFlags(&c->stream1, hipStreamNonBlocking));
+        if (!c->stream2) HIPCHK(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+        if (!c->evIn) HIPCHK(c, hipEventCreateWithFlags(&c->evIn, hipEventDisableTiming));
+        for (int k = 0; k < 2; ++k) if (!c->ws[k].done) HIPCHK(c, hipEventCreateWithFlags(&c->ws[k].done, hipEventDisableTiming));
+    }
+    c->pipeline = depth; c->next_ws = 0; c->wsel = 0; c->ws[0].issued = c->ws[1].issued = false;
+    c->ws[0].stream = c->stream; c->ws[1].stream = c->stream;
+    return ROMAN_OK;
+}
+
+// Make the context's (caller's) stream wait — without blocking the host — for the pipelined batches issued so
+// far: all of them (skip_latest == 0) or all but the most recent one (skip_latest != 0), so that work queued on
+// the caller's stream afterwards (e.g. the RCCL all_gather of batch k-1's records) sees their results while the
+// latest batch keeps running.
+int roman_ctx_join(roman_ctx_t* c, int skip_latest)
+{
+    if (!c) return fail(nullptr, ROMAN_E_INVALID, "ctx is NULL");
+    if (c->pipeline != 2) return ROMAN_OK;                      // everything already runs on the caller's stream
+    HIPCHK(c, hipSetDevice(c->device));
+    const int latest = c->next_ws ^ 1;                          // workspace of the most recent batch call
+    for (int k = 0; k < 2; ++k) {
+        if (skip_latest && k == latest) continue;
+        if (c->ws[k].done && c->ws[k].issued) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ws[k].done, 0));
+    }
+    return ROMAN_OK;
+}
+
+int roman_ctx_sync(roman_ctx_t* c)
+{
+    if (!c) return fail(nullptr, ROMAN_E_INVALID, "ctx is NULL");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->stream1) HIPCHK(c, hipStreamSynchronize(c->stream1));
+    if (c->stream2) HIPCHK(c, hipStreamSynchronize(c->stream2));
+    if (c->stream) HIPCHK(c, hipStreamSynchronize(c->stream));
     return ROMAN_OK;
 }
 
@@ -604,20 +697,22 @@ int roman_profile_enable(roman_ctx_t* c, int on)
     if (!c) return fail(nullptr, ROMAN_E_INVALID, "ctx is NULL");
     HIPCHK(c, hipSetDevice(c->device));
     if (on) { int rc = ensure_events(c); if (rc) return rc; }
-    else for (int s = 0; s < ROMAN_STAGE_COUNT; ++s) prof_flush(c, s);
+    else for (int k = 0; k < 2; ++k) for (int s = 0; s < ROMAN_STAGE_COUNT; ++s) prof_flush(c, k, s);
     c->profile = on != 0;
     return ROMAN_OK;
 }
 int roman_profile_reset(roman_ctx_t* c)
 {
     if (!c) return fail(nullptr, ROMAN_E_INVALID, "ctx is NULL");
-    for (int s = 0; s < ROMAN_STAGE_COUNT; ++s) { prof_flush(c, s); c->prof_ms[s] = 0.0; c->prof_n[s] = 0; }
+    for (int k = 0; k < 2; ++k) for (int s = 0; s < ROMAN_STAGE_COUNT; ++s) prof_flush(c, k, s);
+    for (int s = 0; s < ROMAN_STAGE_COUNT; ++s) { c->prof_ms[s] = 0.0; c->prof_n[s] = 0; }
     return ROMAN_OK;
 }
 int roman_profile_get(roman_ctx_t* c, double ms[ROMAN_STAGE_COUNT], int64_t launches[ROMAN_STAGE_COUNT])
 {
     if (!c) return fail(nullptr, ROMAN_E_INVALID, "ctx is NULL");
-    for (int s = 0; s < ROMAN_STAGE_COUNT; ++s) { prof_flush(c, s); if (ms) ms[s] = c->prof_ms[s]; if (launches) launches[s] = c->prof_n[s]; }
+    for (int k = 0; k < 2; ++k) for (int s = 0; s < ROMAN_STAGE_COUNT; ++s) prof_flush(c, k, s);
+    for (int s = 0; s < ROMAN_STAGE_COUNT; ++s) { if (ms) ms[s] = c->prof_ms[s]; if (launches) launches[s] = c->prof_n[s]; }
     return ROMAN_OK;
 }
 
@@ -639,6 +734,14 @@ int roman_align_batch_dev(roman_ctx_t* c, const roman_params_t* params, int32_t 
     DevParams D;
     int rc = make_dev_params(c, params, F, &D);
     if (rc) return rc;
+    if (c->pipeline == 2 && !c->in_host_batch) {                // next workspace, on its internal stream, behind the caller's stream
+        c->wsel = c->next_ws; c->next_ws ^= 1;
+        WS.stream = c->wsel == 0 ? c->stream1 : c->stream2;
+        HIPCHK(c, hipEventRecord(c->evIn, c->stream));
+        HIPCHK(c, hipStreamWaitEvent(WS.stream, c->evIn, 0));
+    } else if (!c->in_host_batch) {
+        c->wsel = 0; WS.stream = c->stream;
+    }
     if (!feats) {
         bool any = false;
         for (int b = 0; b < B; ++b) any = any || (n1[b] > 0 || n2[b] > 0);
@@ -651,7 +754,8 @@ int roman_align_batch_dev(roman_ctx_t* c, const roman_params_t* params, int32_t 
     if (rc) return rc;
     rc = stage_solve(c, D, B, feats, assoc, u0, tot, idx16, false, kmax, assoc_out, n_assoc_out, T_out, status_out, stats_out);
     if (rc) return rc;
-    c->last.scored = false; c->last.solved = false;
+    if (c->pipeline == 2 && !c->in_host_batch) { HIPCHK(c, hipEventRecord(WS.done, WS.stream)); WS.issued = true; }
+    if (c->wsel == 0) { c->last.scored = false; c->last.solved = false; }
     return ROMAN_OK;
 }
 
@@ -669,6 +773,8 @@ int roman_align_batch(roman_ctx_t* c, const roman_params_t* params, int32_t B,
         return fail(c, ROMAN_E_INVALID, "NULL metadata/output pointer or kmax < 0");
     if (assoc && !assoc_off) return fail(c, ROMAN_E_INVALID, "assoc given without assoc_off");
     HIPCHK(c, hipSetDevice(c->device));
+    { int rc0 = use_ws0(c); if (rc0) return rc0; }
+    struct HostBatchGuard { roman_ctx* c; HostBatchGuard(roman_ctx* c_) : c(c_) { c->in_host_batch = true; } ~HostBatchGuard() { c->in_host_batch = false; } } guard(c);
     int64_t sumA = 0;
     for (int b = 0; b < B; ++b) {
         if (off1[b] < 0 || off2[b] < 0 || off1[b] + n1[b] > n_objects || off2[b] + n2[b] > n_objects)
@@ -676,34 +782,34 @@ int roman_align_batch(roman_ctx_t* c, const roman_params_t* params, int32_t B,
         sumA += assoc ? (assoc_off[b + 1] - assoc_off[b]) : (int64_t)n1[b] * n2[b];
     }
     const size_t fbytes = sizeof(double) * (size_t)std::max<int64_t>(n_objects * F, 1);
-    HIPCHK(c, c->hFeats.ensure(fbytes));
-    if (n_objects * F > 0) HIPCHK(c, hipMemcpyAsync(c->hFeats.p, feats, sizeof(double) * (size_t)(n_objects * F), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, WS.hFeats.ensure(fbytes));
+    if (n_objects * F > 0) HIPCHK(c, hipMemcpyAsync(WS.hFeats.p, feats, sizeof(double) * (size_t)(n_objects * F), hipMemcpyHostToDevice, WS.stream));
     const int32_t* dA = nullptr;
     if (assoc) {
         const int64_t rows = assoc_off[B];
-        HIPCHK(c, c->hAssoc.ensure(sizeof(int32_t) * 2 * (size_t)std::max<int64_t>(rows, 1)));
-        if (rows > 0) HIPCHK(c, hipMemcpyAsync(c->hAssoc.p, assoc, sizeof(int32_t) * 2 * (size_t)rows, hipMemcpyHostToDevice, c->stream));
-        dA = c->hAssoc.as<int32_t>();
+        HIPCHK(c, WS.hAssoc.ensure(sizeof(int32_t) * 2 * (size_t)std::max<int64_t>(rows, 1)));
+        if (rows > 0) HIPCHK(c, hipMemcpyAsync(WS.hAssoc.p, assoc, sizeof(int32_t) * 2 * (size_t)rows, hipMemcpyHostToDevice, WS.stream));
+        dA = WS.hAssoc.as<int32_t>();
     }
     const double* dU0 = nullptr;
     if (u0) {
-        HIPCHK(c, c->hU0.ensure(sizeof(double) * (size_t)std::max<int64_t>(sumA, 1)));
-        if (sumA > 0) HIPCHK(c, hipMemcpyAsync(c->hU0.p, u0, sizeof(double) * (size_t)sumA, hipMemcpyHostToDevice, c->stream));
-        dU0 = c->hU0.as<double>();
+        HIPCHK(c, WS.hU0.ensure(sizeof(double) * (size_t)std::max<int64_t>(sumA, 1)));
+        if (sumA > 0) HIPCHK(c, hipMemcpyAsync(WS.hU0.p, u0, sizeof(double) * (size_t)sumA, hipMemcpyHostToDevice, WS.stream));
+        dU0 = WS.hU0.as<double>();
     }
     const size_t kb = (size_t)B * (size_t)std::max(kmax, 1);
-    HIPCHK(c, c->oAssoc.ensure(sizeof(int32_t) * 2 * kb)); HIPCHK(c, c->oN.ensure(sizeof(int32_t) * (size_t)B));
-    HIPCHK(c, c->oT.ensure(sizeof(double) * 16 * (size_t)B)); HIPCHK(c, c->oStatus.ensure(sizeof(int32_t) * (size_t)B));
-    HIPCHK(c, c->oStats.ensure(sizeof(roman_stats_t) * (size_t)B));
-    int rc = roman_align_batch_dev(c, params, B, c->hFeats.as<double>(), off1, n1, off2, n2, F, dA, assoc_off, dU0, kmax,
-                                   c->oAssoc.as<int32_t>(), c->oN.as<int32_t>(), c->oT.as<double>(), c->oStatus.as<int32_t>(), c->oStats.as<roman_stats_t>());
+    HIPCHK(c, WS.oAssoc.ensure(sizeof(int32_t) * 2 * kb)); HIPCHK(c, WS.oN.ensure(sizeof(int32_t) * (size_t)B));
+    HIPCHK(c, WS.oT.ensure(sizeof(double) * 16 * (size_t)B)); HIPCHK(c, WS.oStatus.ensure(sizeof(int32_t) * (size_t)B));
+    HIPCHK(c, WS.oStats.ensure(sizeof(roman_stats_t) * (size_t)B));
+    int rc = roman_align_batch_dev(c, params, B, WS.hFeats.as<double>(), off1, n1, off2, n2, F, dA, assoc_off, dU0, kmax,
+                                   WS.oAssoc.as<int32_t>(), WS.oN.as<int32_t>(), WS.oT.as<double>(), WS.oStatus.as<int32_t>(), WS.oStats.as<roman_stats_t>());
     if (rc) return rc;
-    if (kmax > 0) HIPCHK(c, hipMemcpyAsync(assoc_out, c->oAssoc.p, sizeof(int32_t) * 2 * (size_t)B * (size_t)kmax, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(n_assoc_out, c->oN.p, sizeof(int32_t) * (size_t)B, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(T_out, c->oT.p, sizeof(double) * 16 * (size_t)B, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(status_out, c->oStatus.p, sizeof(int32_t) * (size_t)B, hipMemcpyDeviceToHost, c->stream));
-    if (stats_out) HIPCHK(c, hipMemcpyAsync(stats_out, c->oStats.p, sizeof(roman_stats_t) * (size_t)B, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (kmax > 0) HIPCHK(c, hipMemcpyAsync(assoc_out, WS.oAssoc.p, sizeof(int32_t) * 2 * (size_t)B * (size_t)kmax, hipMemcpyDeviceToHost, WS.stream));
+    HIPCHK(c, hipMemcpyAsync(n_assoc_out, WS.oN.p, sizeof(int32_t) * (size_t)B, hipMemcpyDeviceToHost, WS.stream));
+    HIPCHK(c, hipMemcpyAsync(T_out, WS.oT.p, sizeof(double) * 16 * (size_t)B, hipMemcpyDeviceToHost, WS.stream));
+    HIPCHK(c, hipMemcpyAsync(status_out, WS.oStatus.p, sizeof(int32_t) * (size_t)B, hipMemcpyDeviceToHost, WS.stream));
+    if (stats_out) HIPCHK(c, hipMemcpyAsync(stats_out, WS.oStats.p, sizeof(roman_stats_t) * (size_t)B, hipMemcpyDeviceToHost, WS.stream));
+    HIPCHK(c, hipStreamSynchronize(WS.stream));
     return ROMAN_OK;
 }
 
@@ -722,14 +828,15 @@ int roman_score(roman_ctx_t* c, const roman_params_t* params, const double* D1, 
     if (n1 < 0 || n2 < 0 || F < 0 || (assoc && n_assoc < 0)) return fail(c, ROMAN_E_INVALID, "negative size");
     if ((n1 > 0 && !D1) || (n2 > 0 && !D2)) return fail(c, ROMAN_E_INVALID, "NULL feature matrix");
     HIPCHK(c, hipSetDevice(c->device));
+    { int rc0 = use_ws0(c); if (rc0) return rc0; }
     roman_ctx::Last& Lst = c->last;
     Lst.scored = false; Lst.solved = false; Lst.dense = false; Lst.hascz = false;
     int rc = make_dev_params(c, params, F, &Lst.D);
     if (rc) return rc;
     const int64_t nobj = (int64_t)n1 + n2;
-    HIPCHK(c, c->hFeats.ensure(sizeof(double) * (size_t)std::max<int64_t>(nobj * F, 1)));
-    if ((int64_t)n1 * F > 0) HIPCHK(c, hipMemcpyAsync(c->hFeats.p, D1, sizeof(double) * (size_t)n1 * F, hipMemcpyHostToDevice, c->stream));
-    if ((int64_t)n2 * F > 0) HIPCHK(c, hipMemcpyAsync(c->hFeats.as<double>() + (size_t)n1 * F, D2, sizeof(double) * (size_t)n2 * F, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, WS.hFeats.ensure(sizeof(double) * (size_t)std::max<int64_t>(nobj * F, 1)));
+    if ((int64_t)n1 * F > 0) HIPCHK(c, hipMemcpyAsync(WS.hFeats.p, D1, sizeof(double) * (size_t)n1 * F, hipMemcpyHostToDevice, WS.stream));
+    if ((int64_t)n2 * F > 0) HIPCHK(c, hipMemcpyAsync(WS.hFeats.as<double>() + (size_t)n1 * F, D2, sizeof(double) * (size_t)n2 * F, hipMemcpyHostToDevice, WS.stream));
     const int32_t* dA = nullptr;
     int64_t aoff[2] = {0, n_assoc};
     Lst.assoc.clear();
@@ -738,16 +845,16 @@ int roman_score(roman_ctx_t* c, const roman_params_t* params, const double* D1, 
             if (assoc[2 * k] < 0 || assoc[2 * k] >= n1 || assoc[2 * k + 1] < 0 || assoc[2 * k + 1] >= n2)
                 return fail(c, ROMAN_E_INVALID, "association %d = (%d,%d) out of range", k, assoc[2 * k], assoc[2 * k + 1]);
         Lst.assoc.assign(assoc, assoc + 2 * (size_t)n_assoc);
-        HIPCHK(c, c->hAssoc.ensure(sizeof(int32_t) * 2 * (size_t)std::max(n_assoc, 1)));
-        if (n_assoc > 0) HIPCHK(c, hipMemcpyAsync(c->hAssoc.p, assoc, sizeof(int32_t) * 2 * (size_t)n_assoc, hipMemcpyHostToDevice, c->stream));
-        dA = c->hAssoc.as<int32_t>();
+        HIPCHK(c, WS.hAssoc.ensure(sizeof(int32_t) * 2 * (size_t)std::max(n_assoc, 1)));
+        if (n_assoc > 0) HIPCHK(c, hipMemcpyAsync(WS.hAssoc.p, assoc, sizeof(int32_t) * 2 * (size_t)n_assoc, hipMemcpyHostToDevice, WS.stream));
+        dA = WS.hAssoc.as<int32_t>();
     }
     const int64_t o1 = 0, o2 = n1;
-    BatchIn in{1, c->hFeats.as<double>(), &o1, &n1, &o2, &n2, F, dA, aoff};
+    BatchIn in{1, WS.hFeats.as<double>(), &o1, &n1, &o2, &n2, F, dA, aoff};
     std::vector<ProbDesc> hd;
     rc = stage_score(c, Lst.D, in, hd, &Lst.tot, &Lst.idx16);
     if (rc) return rc;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipStreamSynchronize(WS.stream));
     Lst.pd = hd[0]; Lst.nA = hd[0].nA; Lst.L = Lst.tot.R; Lst.scored = true;
     return ROMAN_OK;
 }
@@ -757,6 +864,7 @@ int roman_set_matrix_data(roman_ctx_t* c, const roman_params_t* params, const do
     if (!c) return fail(nullptr, ROMAN_E_INVALID, "ctx is NULL");
     if (n < 0 || (n > 0 && (!M || !Cm))) return fail(c, ROMAN_E_INVALID, "bad matrix arguments");
     HIPCHK(c, hipSetDevice(c->device));
+    { int rc0 = use_ws0(c); if (rc0) return rc0; }
     roman_ctx::Last& Lst = c->last;
     Lst.scored = false; Lst.solved = false; Lst.dense = true; Lst.assoc.clear();
     roman_params_t p = *params; p.invariant = ROMAN_INV_EUCLIDEAN;          // implicit identity diagonal
@@ -807,34 +915,34 @@ int roman_set_matrix_data(roman_ctx_t* c, const roman_params_t* params, const do
         }
     Lst.hascz = anycz;
     const size_t n1_ = (size_t)std::max(n, 1), nnz1 = (size_t)std::max<uint64_t>(total, 1), nsl1 = (size_t)std::max((n + 63) / 64, 1);
-    HIPCHK(c, c->probs.ensure(sizeof(ProbDesc))); HIPCHK(c, c->state.ensure(sizeof(ProbState))); HIPCHK(c, c->queue.ensure(sizeof(int) * 4));
-    HIPCHK(c, c->lp.ensure(sizeof(int32_t) * n1_)); HIPCHK(c, c->ls.ensure(sizeof(double) * n1_));
-    HIPCHK(c, c->rowCnt.ensure(sizeof(uint32_t) * n1_)); HIPCHK(c, c->rowPos.ensure(sizeof(uint32_t) * n1_)); HIPCHK(c, c->perm.ensure(sizeof(uint32_t) * n1_));
-    HIPCHK(c, c->sliceWidth.ensure(sizeof(uint32_t) * n1_)); HIPCHK(c, c->sliceBase.ensure(sizeof(uint32_t) * n1_));
-    HIPCHK(c, c->vals.ensure(sizeof(double) * nnz1)); HIPCHK(c, c->cols.ensure((Lst.idx16 ? 2 : 4) * nnz1));
+    HIPCHK(c, WS.probs.ensure(sizeof(ProbDesc))); HIPCHK(c, WS.state.ensure(sizeof(ProbState))); HIPCHK(c, WS.queue.ensure(sizeof(int) * 4));
+    HIPCHK(c, WS.lp.ensure(sizeof(int32_t) * n1_)); HIPCHK(c, WS.ls.ensure(sizeof(double) * n1_));
+    HIPCHK(c, WS.rowCnt.ensure(sizeof(uint32_t) * n1_)); HIPCHK(c, WS.rowPos.ensure(sizeof(uint32_t) * n1_)); HIPCHK(c, WS.perm.ensure(sizeof(uint32_t) * n1_));
+    HIPCHK(c, WS.sliceWidth.ensure(sizeof(uint32_t) * n1_)); HIPCHK(c, WS.sliceBase.ensure(sizeof(uint32_t) * n1_));
+    HIPCHK(c, WS.vals.ensure(sizeof(double) * nnz1)); HIPCHK(c, WS.cols.ensure((Lst.idx16 ? 2 : 4) * nnz1));
     ProbDesc pd{}; pd.off1 = 0; pd.off2 = 0; pd.assocOff = -1; pd.liveOff = 0; pd.n1 = n; pd.n2 = 1; pd.nA = n;
     ProbState ps{}; ps.L = n; ps.rowBase = 0; ps.nnzOff = 0; ps.maskOff = 0; ps.nnzCap = (uint32_t)total; ps.nnzUpper = (unsigned long long)upper;
     std::vector<int32_t> ident((size_t)std::max(n, 1)); std::vector<double> ones((size_t)std::max(n, 1), 1.0);
     for (int k = 0; k < n; ++k) ident[(size_t)k] = k;
-    HIPCHK(c, hipMemcpy(c->probs.p, &pd, sizeof(pd), hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(c->state.p, &ps, sizeof(ps), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(WS.probs.p, &pd, sizeof(pd), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(WS.state.p, &ps, sizeof(ps), hipMemcpyHostToDevice));
     if (n > 0) {
-        HIPCHK(c, hipMemcpy(c->lp.p, ident.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice));
-        HIPCHK(c, hipMemcpy(c->ls.p, ones.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
-        HIPCHK(c, hipMemcpy(c->rowCnt.p, rl.data(), sizeof(uint32_t) * (size_t)n, hipMemcpyHostToDevice));
-        HIPCHK(c, hipMemcpy(c->rowPos.p, rowPos.data(), sizeof(uint32_t) * (size_t)n, hipMemcpyHostToDevice));
-        HIPCHK(c, hipMemcpy(c->perm.p, perm.data(), sizeof(uint32_t) * (size_t)n, hipMemcpyHostToDevice));
-        HIPCHK(c, hipMemcpy(c->sliceWidth.p, sliceWidth.data(), sizeof(uint32_t) * nsl1, hipMemcpyHostToDevice));
-        HIPCHK(c, hipMemcpy(c->sliceBase.p, sliceBase.data(), sizeof(uint32_t) * nsl1, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(WS.lp.p, ident.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(WS.ls.p, ones.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(WS.rowCnt.p, rl.data(), sizeof(uint32_t) * (size_t)n, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(WS.rowPos.p, rowPos.data(), sizeof(uint32_t) * (size_t)n, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(WS.perm.p, perm.data(), sizeof(uint32_t) * (size_t)n, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(WS.sliceWidth.p, sliceWidth.data(), sizeof(uint32_t) * nsl1, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(WS.sliceBase.p, sliceBase.data(), sizeof(uint32_t) * nsl1, hipMemcpyHostToDevice));
     }
     if (total > 0) {
-        HIPCHK(c, hipMemcpy(c->vals.p, jvals.data(), sizeof(double) * (size_t)total, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(WS.vals.p, jvals.data(), sizeof(double) * (size_t)total, hipMemcpyHostToDevice));
         if (Lst.idx16) {
             std::vector<uint16_t> c16((size_t)total);
             for (size_t k = 0; k < (size_t)total; ++k) c16[k] = (uint16_t)jcols[k];
-            HIPCHK(c, hipMemcpy(c->cols.p, c16.data(), sizeof(uint16_t) * c16.size(), hipMemcpyHostToDevice));
+            HIPCHK(c, hipMemcpy(WS.cols.p, c16.data(), sizeof(uint16_t) * c16.size(), hipMemcpyHostToDevice));
         } else {
-            HIPCHK(c, hipMemcpy(c->cols.p, jcols.data(), sizeof(uint32_t) * (size_t)total, hipMemcpyHostToDevice));
+            HIPCHK(c, hipMemcpy(WS.cols.p, jcols.data(), sizeof(uint32_t) * (size_t)total, hipMemcpyHostToDevice));
         }
     }
     Lst.pd = pd; Lst.nA = n; Lst.L = n;
@@ -848,6 +956,7 @@ int roman_solve(roman_ctx_t* c, const double* u0)
     if (!c) return fail(nullptr, ROMAN_E_INVALID, "ctx is NULL");
     if (!c->last.scored) return fail(c, ROMAN_E_INVALID, "roman_solve: no matrices (call roman_score or roman_set_matrix_data first)");
     HIPCHK(c, hipSetDevice(c->device));
+    { int rc0 = use_ws0(c); if (rc0) return rc0; }
     return solve_last(c, u0);
 }
 
@@ -959,23 +1068,24 @@ int roman_pose_batch(roman_ctx_t* c, int32_t dim, int32_t B, const double* pts1,
     if (B < 0 || !corr_off || !T_out || !status_out) return fail(c, ROMAN_E_INVALID, "bad arguments");
     if (B == 0) return ROMAN_OK;
     HIPCHK(c, hipSetDevice(c->device));
+    { int rc0 = use_ws0(c); if (rc0) return rc0; }
     const int64_t K = corr_off[B];
     if (K < 0 || (K > 0 && (!pts1 || !pts2))) return fail(c, ROMAN_E_INVALID, "bad correspondence arrays");
-    HIPCHK(c, c->hAux1.ensure(sizeof(double) * (size_t)std::max<int64_t>(K * dim, 1)));
-    HIPCHK(c, c->hAux2.ensure(sizeof(double) * (size_t)std::max<int64_t>(K * dim, 1)));
-    HIPCHK(c, c->hAux3.ensure(sizeof(int64_t) * ((size_t)B + 1)));
-    HIPCHK(c, c->oT.ensure(sizeof(double) * 16 * (size_t)B)); HIPCHK(c, c->oStatus.ensure(sizeof(int32_t) * (size_t)B));
+    HIPCHK(c, WS.hAux1.ensure(sizeof(double) * (size_t)std::max<int64_t>(K * dim, 1)));
+    HIPCHK(c, WS.hAux2.ensure(sizeof(double) * (size_t)std::max<int64_t>(K * dim, 1)));
+    HIPCHK(c, WS.hAux3.ensure(sizeof(int64_t) * ((size_t)B + 1)));
+    HIPCHK(c, WS.oT.ensure(sizeof(double) * 16 * (size_t)B)); HIPCHK(c, WS.oStatus.ensure(sizeof(int32_t) * (size_t)B));
     if (K > 0) {
-        HIPCHK(c, hipMemcpyAsync(c->hAux1.p, pts1, sizeof(double) * (size_t)(K * dim), hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipMemcpyAsync(c->hAux2.p, pts2, sizeof(double) * (size_t)(K * dim), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(WS.hAux1.p, pts1, sizeof(double) * (size_t)(K * dim), hipMemcpyHostToDevice, WS.stream));
+        HIPCHK(c, hipMemcpyAsync(WS.hAux2.p, pts2, sizeof(double) * (size_t)(K * dim), hipMemcpyHostToDevice, WS.stream));
     }
-    HIPCHK(c, hipMemcpyAsync(c->hAux3.p, corr_off, sizeof(int64_t) * ((size_t)B + 1), hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(k_pose, dim3(B), dim3(64), 0, c->stream, dim, c->hAux1.as<double>(), c->hAux2.as<double>(), c->hAux3.as<int64_t>(),
-                       c->oT.as<double>(), c->oStatus.as<int32_t>());
+    HIPCHK(c, hipMemcpyAsync(WS.hAux3.p, corr_off, sizeof(int64_t) * ((size_t)B + 1), hipMemcpyHostToDevice, WS.stream));
+    hipLaunchKernelGGL(k_pose, dim3(B), dim3(64), 0, WS.stream, dim, WS.hAux1.as<double>(), WS.hAux2.as<double>(), WS.hAux3.as<int64_t>(),
+                       WS.oT.as<double>(), WS.oStatus.as<int32_t>());
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(T_out, c->oT.p, sizeof(double) * 16 * (size_t)B, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(status_out, c->oStatus.p, sizeof(int32_t) * (size_t)B, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpyAsync(T_out, WS.oT.p, sizeof(double) * 16 * (size_t)B, hipMemcpyDeviceToHost, WS.stream));
+    HIPCHK(c, hipMemcpyAsync(status_out, WS.oStatus.p, sizeof(int32_t) * (size_t)B, hipMemcpyDeviceToHost, WS.stream));
+    HIPCHK(c, hipStreamSynchronize(WS.stream));
     return ROMAN_OK;
 }
 
@@ -986,14 +1096,15 @@ int roman_debug_math(roman_ctx_t* c, int kind, const double* in1, const double* 
     if (n < 0 || (n > 0 && (!in1 || !out))) return fail(c, ROMAN_E_INVALID, "bad arguments");
     if (n == 0) return ROMAN_OK;
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, c->hAux1.ensure(sizeof(double) * (size_t)n)); HIPCHK(c, c->hAux2.ensure(sizeof(double) * (size_t)n)); HIPCHK(c, c->hAux3.ensure(sizeof(double) * (size_t)n));
-    HIPCHK(c, hipMemcpyAsync(c->hAux1.p, in1, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, c->stream));
-    if (in2) HIPCHK(c, hipMemcpyAsync(c->hAux2.p, in2, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(k_debug_math, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, kind, c->hAux1.as<double>(),
-                       in2 ? c->hAux2.as<double>() : (const double*)nullptr, n, c->hAux3.as<double>());
+    { int rc0 = use_ws0(c); if (rc0) return rc0; }
+    HIPCHK(c, WS.hAux1.ensure(sizeof(double) * (size_t)n)); HIPCHK(c, WS.hAux2.ensure(sizeof(double) * (size_t)n)); HIPCHK(c, WS.hAux3.ensure(sizeof(double) * (size_t)n));
+    HIPCHK(c, hipMemcpyAsync(WS.hAux1.p, in1, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, WS.stream));
+    if (in2) HIPCHK(c, hipMemcpyAsync(WS.hAux2.p, in2, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, WS.stream));
+    hipLaunchKernelGGL(k_debug_math, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, WS.stream, kind, WS.hAux1.as<double>(),
+                       in2 ? WS.hAux2.as<double>() : (const double*)nullptr, n, WS.hAux3.as<double>());
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(out, c->hAux3.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpyAsync(out, WS.hAux3.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, WS.stream));
+    HIPCHK(c, hipStreamSynchronize(WS.stream));
     return ROMAN_OK;
 }
 
@@ -1003,23 +1114,24 @@ int roman_debug_cosine(roman_ctx_t* c, const roman_params_t* params, const doubl
     if (!c) return fail(nullptr, ROMAN_E_INVALID, "ctx is NULL");
     if (n1 <= 0 || n2 <= 0 || !D1 || !D2 || !out) return fail(c, ROMAN_E_INVALID, "bad arguments");
     HIPCHK(c, hipSetDevice(c->device));
+    { int rc0 = use_ws0(c); if (rc0) return rc0; }
     DevParams D;
     int rc = make_dev_params(c, params, F, &D);
     if (rc) return rc;
     if (D.p.cos_feature_dim <= 0) return fail(c, ROMAN_E_INVALID, "cos_feature_dim is 0");
-    HIPCHK(c, c->hFeats.ensure(sizeof(double) * (size_t)(n1 + n2) * F));
-    HIPCHK(c, hipMemcpyAsync(c->hFeats.p, D1, sizeof(double) * (size_t)n1 * F, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->hFeats.as<double>() + (size_t)n1 * F, D2, sizeof(double) * (size_t)n2 * F, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, WS.hFeats.ensure(sizeof(double) * (size_t)(n1 + n2) * F));
+    HIPCHK(c, hipMemcpyAsync(WS.hFeats.p, D1, sizeof(double) * (size_t)n1 * F, hipMemcpyHostToDevice, WS.stream));
+    HIPCHK(c, hipMemcpyAsync(WS.hFeats.as<double>() + (size_t)n1 * F, D2, sizeof(double) * (size_t)n2 * F, hipMemcpyHostToDevice, WS.stream));
     ProbDesc pd{}; pd.off1 = 0; pd.off2 = n1; pd.assocOff = -1; pd.n1 = n1; pd.n2 = n2; pd.nA = n1 * n2;
-    HIPCHK(c, c->probs.ensure(sizeof(ProbDesc)));
-    HIPCHK(c, c->cosPool.ensure(sizeof(double) * (size_t)n1 * n2)); HIPCHK(c, c->normPool.ensure(sizeof(double) * (size_t)(n1 + n2)));
-    HIPCHK(c, hipMemcpyAsync(c->probs.p, &pd, sizeof(pd), hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(k_norms, dim3((n1 + n2 + 3) / 4, 1), dim3(256), 0, c->stream, D, c->probs.as<ProbDesc>(), c->hFeats.as<double>(), c->normPool.as<double>());
+    HIPCHK(c, WS.probs.ensure(sizeof(ProbDesc)));
+    HIPCHK(c, WS.cosPool.ensure(sizeof(double) * (size_t)n1 * n2)); HIPCHK(c, WS.normPool.ensure(sizeof(double) * (size_t)(n1 + n2)));
+    HIPCHK(c, hipMemcpyAsync(WS.probs.p, &pd, sizeof(pd), hipMemcpyHostToDevice, WS.stream));
+    hipLaunchKernelGGL(k_norms, dim3((n1 + n2 + 3) / 4, 1), dim3(256), 0, WS.stream, D, WS.probs.as<ProbDesc>(), WS.hFeats.as<double>(), WS.normPool.as<double>());
     const int tiles = ((n1 + COS_TILE - 1) / COS_TILE) * ((n2 + COS_TILE - 1) / COS_TILE);
-    hipLaunchKernelGGL(k_cos, dim3((tiles + 3) / 4, 1), dim3(256), 0, c->stream, D, c->probs.as<ProbDesc>(), c->hFeats.as<double>(), c->normPool.as<double>(), c->cosPool.as<double>());
+    hipLaunchKernelGGL(k_cos, dim3((tiles + 3) / 4, 1), dim3(256), 0, WS.stream, D, WS.probs.as<ProbDesc>(), WS.hFeats.as<double>(), WS.normPool.as<double>(), WS.cosPool.as<double>());
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(out, c->cosPool.p, sizeof(double) * (size_t)n1 * n2, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpyAsync(out, WS.cosPool.p, sizeof(double) * (size_t)n1 * n2, hipMemcpyDeviceToHost, WS.stream));
+    HIPCHK(c, hipStreamSynchronize(WS.stream));
     c->last.scored = false; c->last.solved = false;
     return ROMAN_OK;
 }
@@ -1032,8 +1144,8 @@ int roman_debug_live(const roman_ctx_t* cc, int32_t* n_live, int32_t* idx, doubl
     const int L = c->last.tot.R;
     if (n_live) *n_live = L;
     HIPCHK(c, hipSetDevice(c->device));
-    if (idx && L > 0) HIPCHK(c, hipMemcpy(idx, c->lp.p, sizeof(int32_t) * (size_t)L, hipMemcpyDeviceToHost));
-    if (score && L > 0) HIPCHK(c, hipMemcpy(score, c->ls.p, sizeof(double) * (size_t)L, hipMemcpyDeviceToHost));
+    if (idx && L > 0) HIPCHK(c, hipMemcpy(idx, WS.lp.p, sizeof(int32_t) * (size_t)L, hipMemcpyDeviceToHost));
+    if (score && L > 0) HIPCHK(c, hipMemcpy(score, WS.ls.p, sizeof(double) * (size_t)L, hipMemcpyDeviceToHost));
     return ROMAN_OK;
 }
 

@@ -59,6 +59,18 @@ class Context:
         except Exception:
             pass
 
+    def set_pipeline(self, depth):
+        """Batches in flight (1 or 2), see roman_ctx_set_pipeline in include/roman_hip.h.  With depth 2 the
+        results of align_batch_dev calls are complete after sync() (or a device-wide synchronise)."""
+        self._check(self._lib.roman_ctx_set_pipeline(self._h, int(depth)), "roman_ctx_set_pipeline")
+
+    def sync(self):
+        self._check(self._lib.roman_ctx_sync(self._h), "roman_ctx_sync")
+
+    def join(self, skip_latest=False):
+        """Make the context's stream wait for the pipelined batches issued so far (optionally all but the latest)."""
+        self._check(self._lib.roman_ctx_join(self._h, int(bool(skip_latest))), "roman_ctx_join")
+
     def _check(self, rc, what):
         if rc != 0:
             msg = self._lib.roman_last_error(self._h)
