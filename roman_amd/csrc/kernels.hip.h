@@ -1,8 +1,7 @@
 // kernels.hip.h — gfx950 (CDNA4, wave64) device code of libroman_hip.so.
 //
 // Pipeline for a batch of B independent submap pairs (one "problem" each):
-//   k_norms   per-object descriptor norms                       (cos_feature_dim > 0)
-//   k_cos     normalised cosine matrix, f64 MFMA 16x16x4        (cos_feature_dim > 0)
+//   k_cos     normalised cosine matrix (+ descriptor norms), f64 MFMA 16x16x4   (cos_feature_dim > 0)
 //   k_tables  intra-map distance tables with NaN sentinels      (n1^2 + n2^2 entries)
 //   k_live    single scores + ordered compaction of live associations
 //   k_rowbase prefix of live counts over problems
@@ -159,25 +158,6 @@ __device__ __forceinline__ double fuse_pair(const DevParams& D, double sa, doubl
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_norms: one wave per object, Euclidean norm of its cosine-feature block
-// ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_norms(DevParams D, const ProbDesc* __restrict__ probs,
-                                               const double* __restrict__ feats,
-                                               double* __restrict__ normPool)
-{
-    const ProbDesc pd = probs[blockIdx.y];
-    const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (o >= pd.n1 + pd.n2) return;
-    const int64_t obj = (o < pd.n1) ? pd.off1 + o : pd.off2 + (o - pd.n1);
-    const double* f = feats + obj * D.F + D.p.point_dim + D.p.ratio_feature_dim;
-    double s = 0.0;
-    for (int k = lane; k < D.p.cos_feature_dim; k += WAVE) s = fma(f[k], f[k], s);
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-    if (lane == 0) normPool[pd.normOff + o] = sqrt(s);
-}
-
-// ---------------------------------------------------------------------------------------------
 // k_cos: cos[i][j] = <d1_i, d2_j> / (|d1_i| |d2_j|) on the f64 matrix core (v_mfma_f64_16x16x4_f64).
 // One wave owns a 32x32 output tile (2x2 MFMA tiles).  Operand layout of one MFMA: lane l supplies
 // A[i = l&15][k = l>>4] and B[k = l>>4][j = l&15]; result reg r of lane l is C[row = (l>>4) + 4r][col = l&15].
@@ -193,7 +173,6 @@ constexpr int COS_TILE = 32;
 
 __global__ void __launch_bounds__(256) k_cos(DevParams D, const ProbDesc* __restrict__ probs,
                                              const double* __restrict__ feats,
-                                             const double* __restrict__ normPool,
                                              double* __restrict__ cosPool)
 {
     const ProbDesc pd = probs[blockIdx.y];
@@ -217,6 +196,9 @@ __global__ void __launch_bounds__(256) k_cos(DevParams D, const ProbDesc* __rest
     for (int x = 0; x < 2; ++x)
 #pragma unroll
         for (int y = 0; y < 2; ++y) acc[x][y] = double4_t{0.0, 0.0, 0.0, 0.0};
+    // squared norms of the tile's 32 + 32 descriptors ride along on the VALU (the operands are in registers
+    // anyway): lane (lr, kq) accumulates the elements it holds, the four kq-lanes of a row are added at the end
+    double sa[2] = {0.0, 0.0}, sb[2] = {0.0, 0.0};
     int k0 = 0;
     for (; k0 + 16 <= Fc; k0 += 16) {
         d4u_t a[2], b[2];
@@ -226,12 +208,15 @@ __global__ void __launch_bounds__(256) k_cos(DevParams D, const ProbDesc* __rest
             b[h] = *reinterpret_cast<const d4u_t*>(fb[h] + k0);
         }
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < 4; ++t) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) { sa[h] = fma(a[h].v[t], a[h].v[t], sa[h]); sb[h] = fma(b[h].v[t], b[h].v[t], sb[h]); }
 #pragma unroll
             for (int x = 0; x < 2; ++x)
 #pragma unroll
                 for (int y = 0; y < 2; ++y)
                     acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(va[x] ? a[x].v[t] : 0.0, vb[y] ? b[y].v[t] : 0.0, acc[x][y], 0, 0, 0);
+        }
     }
     if (k0 < Fc) {                                   // ragged tail of the descriptor (< 16 elements)
 #pragma unroll
@@ -243,6 +228,7 @@ __global__ void __launch_bounds__(256) k_cos(DevParams D, const ProbDesc* __rest
             for (int h = 0; h < 2; ++h) {
                 av[h] = (va[h] && vk) ? fa[h][k0 + t] : 0.0;
                 bv[h] = (vb[h] && vk) ? fb[h][k0 + t] : 0.0;
+                sa[h] = fma(av[h], av[h], sa[h]); sb[h] = fma(bv[h], bv[h], sb[h]);
             }
 #pragma unroll
             for (int x = 0; x < 2; ++x)
@@ -251,23 +237,24 @@ __global__ void __launch_bounds__(256) k_cos(DevParams D, const ProbDesc* __rest
                     acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[x], bv[y], acc[x][y], 0, 0, 0);
         }
     }
-    const double* nr1 = normPool + pd.normOff;
-    const double* nr2 = nr1 + pd.n1;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {                    // every lane (lr, *) ends with the norm of row 16h + lr
+        sa[h] += __shfl_xor(sa[h], 16); sa[h] += __shfl_xor(sa[h], 32);
+        sb[h] += __shfl_xor(sb[h], 16); sb[h] += __shfl_xor(sb[h], 32);
+        sa[h] = sqrt(sa[h]); sb[h] = sqrt(sb[h]);
+    }
 #pragma unroll
     for (int y = 0; y < 2; ++y) {
         const int col = j0 + 16 * y + lr;
-        if (col >= pd.n2) continue;
-        const double nb = nr2[col];
+        const double nb = sb[y];
 #pragma unroll
         for (int x = 0; x < 2; ++x)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = i0 + 16 * x + kq + 4 * r;
-                if (row < pd.n1) {
-                    const double na = nr1[row];
-                    cosPool[pd.cosOff + (int64_t)row * pd.n2 + col] =
-                        (na > 0.0 && nb > 0.0) ? acc[x][y][r] / (na * nb) : 0.0;
-                }
+                const double na = __shfl(sa[x], kq + 4 * r);       // norm of row 16x + (kq + 4r): held by lanes with lr == kq + 4r
+                if (row < pd.n1 && col < pd.n2)
+                    cosPool[pd.cosOff + (int64_t)row * pd.n2 + col] = (na > 0.0 && nb > 0.0) ? acc[x][y][r] / (na * nb) : 0.0;
             }
     }
 }
@@ -282,22 +269,36 @@ __global__ void __launch_bounds__(256) k_tables(DevParams D, const ProbDesc* __r
                                                 const double* __restrict__ feats,
                                                 double* __restrict__ tabPool)
 {
-    const ProbDesc pd = probs[blockIdx.y];
-    const int64_t nA2 = (int64_t)pd.n1 * pd.n1, nB2 = (int64_t)pd.n2 * pd.n2;
-    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= nA2 + nB2) return;
-    int64_t base; int n, a, b;
-    if (e < nA2) { n = pd.n1; a = (int)(e / n); b = (int)(e % n); base = pd.off1; }
-    else { const int64_t e2 = e - nA2; n = pd.n2; a = (int)(e2 / n); b = (int)(e2 % n); base = pd.off2; }
-    const double* pa = feats + (base + a) * D.F;
-    const double* pb = feats + (base + b) * D.F;
-    const double dx = pa[0] - pb[0], dy = pa[1] - pb[1];
-    const double dz = (D.p.point_dim == 3) ? pa[2] - pb[2] : 0.0;
-    const double h2 = dx * dx + dy * dy;
-    const double l2 = h2 + dz * dz;
-    const bool bad = (a == b) || (D.p.mindist > 0.0 && l2 < D.x_mindist);
-    const double v = D.gravity ? sqrt(h2) : sqrt(l2);
-    tabPool[pd.tabOff + e] = bad ? d_nan() : v;
+    // grid: (row bands of 8 rows over max(n1,n2), 2 maps, B).  The map's points are staged in LDS once per
+    // block (3 doubles per object); a wave writes table rows with lanes along the row (coalesced).
+    extern __shared__ __attribute__((aligned(16))) double s_xyz[];
+    const ProbDesc pd = probs[blockIdx.z];
+    const int which = blockIdx.y;
+    const int n = which == 0 ? pd.n1 : pd.n2;
+    const int r0 = blockIdx.x * 8;
+    if (r0 >= n) return;
+    const int64_t base = which == 0 ? pd.off1 : pd.off2;
+    const int pdim = D.p.point_dim;
+    for (int t = threadIdx.x; t < n * 3; t += blockDim.x) {
+        const int o = t / 3, c = t - o * 3;
+        s_xyz[t] = (c < pdim) ? feats[(base + o) * D.F + c] : 0.0;
+    }
+    __syncthreads();
+    double* tab = tabPool + pd.tabOff + (which == 0 ? 0 : (int64_t)pd.n1 * pd.n1);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int rr = w; rr < 8; rr += 4) {
+        const int a = r0 + rr;
+        if (a >= n) break;
+        const double ax = s_xyz[3 * a], ay = s_xyz[3 * a + 1], az = s_xyz[3 * a + 2];
+        for (int b = lane; b < n; b += WAVE) {
+            const double dx = ax - s_xyz[3 * b], dy = ay - s_xyz[3 * b + 1], dz = az - s_xyz[3 * b + 2];
+            const double h2 = dx * dx + dy * dy;
+            const double l2 = h2 + dz * dz;
+            const bool bad = (a == b) || (D.p.mindist > 0.0 && l2 < D.x_mindist);
+            const double v = D.gravity ? sqrt(h2) : sqrt(l2);
+            tab[(int64_t)a * n + b] = bad ? d_nan() : v;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -370,17 +371,28 @@ __global__ void __launch_bounds__(1024) k_live(DevParams D, const ProbDesc* __re
 // k_rowbase: serial prefix of the live counts (B is small); also the batch maxima, the offsets of
 // the per-problem candidate bit matrices (L rows of ceil(L/64) words) and the work-item prefix
 // (a work item = a block of up to RPB consecutive live rows of one problem).
-__global__ void k_rowbase(int B, int RPB, ProbState* __restrict__ st, BatchTotals* __restrict__ tot)
+__global__ void __launch_bounds__(64) k_rowbase(int B, int RPB, ProbState* __restrict__ st, BatchTotals* __restrict__ tot)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    int acc = 0, mx = 0, items = 0; int64_t mw = 0;
-    for (int b = 0; b < B; ++b) {
-        const int L = st[b].L;
-        st[b].rowBase = acc; st[b].maskOff = mw; st[b].itemBase = items;
-        acc += L; mx = max(mx, L); mw += (int64_t)L * ((L + 63) >> 6);
-        items += (L + RPB - 1) / RPB;
+    // one wave; lane-strided blocks of 64 problems with a running carry (B is small)
+    const int lane = threadIdx.x;
+    int accR = 0, accI = 0, mx = 0; long long accM = 0;
+    for (int b0 = 0; b0 < B; b0 += WAVE) {
+        const int b = b0 + lane;
+        const int L = b < B ? st[b].L : 0;
+        const int it = (L + RPB - 1) / RPB;
+        const long long mw = (long long)L * ((L + 63) >> 6);
+        int pr = L, pi = it; long long pm = mw;               // inclusive scans over the lanes
+        for (int off = 1; off < WAVE; off <<= 1) {
+            const int tr = __shfl_up(pr, off), ti = __shfl_up(pi, off); const long long tm = __shfl_up(pm, off);
+            if (lane >= off) { pr += tr; pi += ti; pm += tm; }
+        }
+        if (b < B) { st[b].rowBase = accR + pr - L; st[b].itemBase = accI + pi - it; st[b].maskOff = accM + pm - mw; }
+        int m = L;
+        for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off));
+        mx = max(mx, m);
+        accR += __shfl(pr, WAVE - 1); accI += __shfl(pi, WAVE - 1); accM += __shfl(pm, WAVE - 1);
     }
-    tot->R = acc; tot->maxL = mx; tot->nnzTotal = 0; tot->maskWords = mw; tot->items = items;
+    if (lane == 0) { tot->R = accR; tot->maxL = mx; tot->nnzTotal = 0; tot->maskWords = accM; tot->items = accI; }
 }
 
 // k_items: the work-item list of the pair-test and fill kernels.
@@ -672,12 +684,19 @@ __global__ void __launch_bounds__(1024) k_rowsort(int widthPad /* 1, or 4 for th
 }
 
 // k_probscan: serial prefix of the per-problem slot totals.
-__global__ void k_probscan(int B, ProbState* __restrict__ st, BatchTotals* __restrict__ tot)
+__global__ void __launch_bounds__(64) k_probscan(int B, ProbState* __restrict__ st, BatchTotals* __restrict__ tot)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    int64_t acc = 0;
-    for (int b = 0; b < B; ++b) { st[b].nnzOff = acc; acc += st[b].nnzCap; }
-    tot->nnzTotal = acc;
+    const int lane = threadIdx.x;
+    long long acc = 0;
+    for (int b0 = 0; b0 < B; b0 += WAVE) {
+        const int b = b0 + lane;
+        const long long cap = b < B ? (long long)st[b].nnzCap : 0;
+        long long pc = cap;
+        for (int off = 1; off < WAVE; off <<= 1) { const long long t = __shfl_up(pc, off); if (lane >= off) pc += t; }
+        if (b < B) st[b].nnzOff = acc + pc - cap;
+        acc += __shfl(pc, WAVE - 1);
+    }
+    if (lane == 0) tot->nnzTotal = acc;
 }
 
 // ---------------------------------------------------------------------------------------------

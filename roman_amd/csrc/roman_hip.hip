@@ -262,12 +262,15 @@ int stage_score(roman_ctx* c, const DevParams& D, const BatchIn& in, std::vector
 
     StageTimer t0(c, ROMAN_STAGE_SINGLE);
     if (cosOn && maxN12 > 0) {
-        hipLaunchKernelGGL(k_norms, dim3((maxN12 + 3) / 4, B), dim3(256), 0, WS.stream, D, dP, in.feats, WS.normPool.as<double>());
         if (maxTiles > 0)
-            hipLaunchKernelGGL(k_cos, dim3((maxTiles + 3) / 4, B), dim3(256), 0, WS.stream, D, dP, in.feats, WS.normPool.as<double>(), WS.cosPool.as<double>());
+            hipLaunchKernelGGL(k_cos, dim3((maxTiles + 3) / 4, B), dim3(256), 0, WS.stream, D, dP, in.feats, WS.cosPool.as<double>());
     }
-    if (maxTab > 0)
-        hipLaunchKernelGGL(k_tables, dim3((unsigned)((maxTab + 255) / 256), B), dim3(256), 0, WS.stream, D, dP, in.feats, WS.tabPool.as<double>());
+    if (maxTab > 0) {
+        const size_t tabLds = sizeof(double) * 3 * (size_t)std::max(maxN, 1);
+        if (tabLds > c->lds_max) return fail(c, ROMAN_E_TOO_LARGE, "maps of %d objects exceed the LDS point staging of this build", maxN);
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_tables), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tabLds));
+        hipLaunchKernelGGL(k_tables, dim3((unsigned)((maxN + 7) / 8), 2, B), dim3(256), tabLds, WS.stream, D, dP, in.feats, WS.tabPool.as<double>());
+    }
     hipLaunchKernelGGL(k_live, dim3(B), dim3(1024), 0, WS.stream, D, dP, dS, in.feats, in.assoc, WS.cosPool.as<double>(), WS.sTmp.as<double>(),
                        WS.lp.as<int32_t>(), WS.li.as<int32_t>(), WS.lj.as<int32_t>(), WS.ls.as<double>(), WS.lza.as<double>(), WS.lzb.as<double>());
     hipLaunchKernelGGL(k_rowbase, dim3(1), dim3(64), 0, WS.stream, B, RPB, dS, dT);
@@ -1126,9 +1129,8 @@ int roman_debug_cosine(roman_ctx_t* c, const roman_params_t* params, const doubl
     HIPCHK(c, WS.probs.ensure(sizeof(ProbDesc)));
     HIPCHK(c, WS.cosPool.ensure(sizeof(double) * (size_t)n1 * n2)); HIPCHK(c, WS.normPool.ensure(sizeof(double) * (size_t)(n1 + n2)));
     HIPCHK(c, hipMemcpyAsync(WS.probs.p, &pd, sizeof(pd), hipMemcpyHostToDevice, WS.stream));
-    hipLaunchKernelGGL(k_norms, dim3((n1 + n2 + 3) / 4, 1), dim3(256), 0, WS.stream, D, WS.probs.as<ProbDesc>(), WS.hFeats.as<double>(), WS.normPool.as<double>());
     const int tiles = ((n1 + COS_TILE - 1) / COS_TILE) * ((n2 + COS_TILE - 1) / COS_TILE);
-    hipLaunchKernelGGL(k_cos, dim3((tiles + 3) / 4, 1), dim3(256), 0, WS.stream, D, WS.probs.as<ProbDesc>(), WS.hFeats.as<double>(), WS.normPool.as<double>(), WS.cosPool.as<double>());
+    hipLaunchKernelGGL(k_cos, dim3((tiles + 3) / 4, 1), dim3(256), 0, WS.stream, D, WS.probs.as<ProbDesc>(), WS.hFeats.as<double>(), WS.cosPool.as<double>());
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(out, WS.cosPool.p, sizeof(double) * (size_t)n1 * n2, hipMemcpyDeviceToHost, WS.stream));
     HIPCHK(c, hipStreamSynchronize(WS.stream));
