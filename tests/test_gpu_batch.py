@@ -155,3 +155,78 @@ def test_large_live_set_uses_global_u_path(ctx, orc):
     o = oracle_one(orc, reg, pr.map1, pr.map2)
     assert np.array_equal(res.assoc[0], o["assoc"])
     assert res.stats["n_pass"][0] == o["stats"].n_pass and res.stats["nnz_upper"][0] == o["stats"].nnz_upper
+
+
+class _Hip:
+    """Minimal device-memory helper on the HIP runtime the library already loaded (no torch in this process:
+    torch bundles its own HIP runtime, and two runtimes in one process do not share the device)."""
+
+    def __init__(self):
+        import ctypes as C
+        self.C = C
+        self.lib = C.CDLL("libamdhip64.so")
+        self.lib.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+        self.lib.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        self.lib.hipFree.argtypes = [C.c_void_p]
+        self.bufs = []
+
+    def alloc(self, nbytes):
+        p = self.C.c_void_p()
+        assert self.lib.hipMalloc(self.C.byref(p), max(int(nbytes), 8)) == 0
+        self.bufs.append(p)
+        return p.value
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        p = self.alloc(arr.nbytes)
+        assert self.lib.hipMemcpy(p, arr.ctypes.data, arr.nbytes, 1) == 0      # hipMemcpyHostToDevice
+        return p
+
+    def download(self, ptr, shape, dtype):
+        out = np.zeros(shape, dtype=dtype)
+        assert self.lib.hipMemcpy(out.ctypes.data, ptr, out.nbytes, 2) == 0    # hipMemcpyDeviceToHost
+        return out
+
+    def free_all(self):
+        for p in self.bufs:
+            self.lib.hipFree(p)
+        self.bufs = []
+
+
+def test_two_batches_in_flight_equal_sequential_calls(ctx):
+    """roman_ctx_set_pipeline(2): consecutive device-pointer batch calls alternate between two workspaces on
+    internal streams; after roman_ctx_sync every batch's results equal the ones of plain sequential calls."""
+    from roman_amd.runtime import stats_dtype
+    reg = registration_for("semanticgrav", semantics_dim=32); reg.set_context(ctx)
+    P = reg._abi_params(); F = P.feature_dim()
+    hip = _Hip()
+    batches = []
+    for g in range(4):                                          # four different batches (different sizes and seeds)
+        pairs = [synth.make_pair(40 + 5 * g, 35 + 3 * k, 32, 700 + 10 * g + k) for k in range(3 + g)]
+        batches.append(rb.batch_from_pairs(reg, [(p.map1, p.map2) for p in pairs]))
+    ref = [rb.run_batch(reg, b) for b in batches]               # sequential host-pointer calls
+    outs = []
+    for b in batches:
+        B, kmax = len(b), b.kmax()
+        outs.append(dict(feats=hip.upload(b.feats), kmax=kmax, assoc=hip.alloc(B * kmax * 2 * 4), n=hip.alloc(B * 4),
+                         T=hip.alloc(B * 16 * 8), status=hip.alloc(B * 4), stats=hip.alloc(B * _abi.STATS_NBYTES)))
+    ctx.set_pipeline(2)
+    try:
+        for b, o in zip(batches, outs):                         # issue all four without waiting in between
+            ctx.align_batch_dev(P, o["feats"], F, b.off1, b.n1, b.off2, b.n2, o["kmax"], o["assoc"], o["n"], o["T"], o["status"], o["stats"])
+        ctx.sync()
+    finally:
+        ctx.set_pipeline(1)
+    try:
+        for b, o, r in zip(batches, outs, ref):
+            B, kmax = len(b), o["kmax"]
+            n = hip.download(o["n"], (B,), np.int32); a = hip.download(o["assoc"], (B, kmax, 2), np.int32)
+            T = hip.download(o["T"], (B, 16), np.float64); st = hip.download(o["status"], (B,), np.int32)
+            stt = hip.download(o["stats"], (B,), stats_dtype())
+            for k in range(B):
+                assert np.array_equal(a[k, :n[k]], r.assoc[k]) and st[k] == r.status[k]
+                assert stt["n_pass"][k] == r.stats["n_pass"][k] and stt["nnz_upper"][k] == r.stats["nnz_upper"][k]
+                if st[k] == 0:
+                    assert np.array_equal(T[k].reshape(4, 4), r.T[k])       # same kernels, same order: bit-identical pose
+    finally:
+        hip.free_all()
