@@ -448,8 +448,6 @@ __device__ __forceinline__ void count_rows_global(const DevParams& D, const Prob
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         unsigned long long* mrow = mbase + (int64_t)k * W;
-        uint32_t* prow = pbase + (int64_t)k * W;
-        uint32_t cnt = 0;
         for (int q0 = 0; q0 < L; q0 += WAVE) {
             const int q = q0 + lane;
             const bool vq = q < L;
@@ -467,10 +465,8 @@ __device__ __forceinline__ void count_rows_global(const DevParams& D, const Prob
                 is = vq && (fabs(a - bb) < D.p.epsilon);
             }
             const unsigned long long m = __ballot(is);
-            if (lane == 0) { mrow[q0 >> 6] = m; prow[q0 >> 6] = cnt; }
-            cnt += __popcll(m);
+            if (lane == 0) mrow[q0 >> 6] = m;
         }
-        if (lane == 0) rowCnt[k] = cnt;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -496,25 +492,55 @@ __device__ __forceinline__ void count_rows_lds(const DevParams& D, const ProbDes
     const char* tbytes = reinterpret_cast<const char*>(tA);
     constexpr int U = 4;                                        // column chunks per step
     const int Lpad = (L + U * WAVE - 1) & ~(U * WAVE - 1);
+    // Rows are columns too: their objects and z come from the LDS column tile.  The two table rows of the NEXT
+    // row are fetched into registers while the current row is swept (maps of up to 256 objects; larger ones
+    // load directly), so no global-memory latency sits between two sweeps.
+    constexpr int TR = 4;
+    const bool pre = pd.n1 <= TR * WAVE && pd.n2 <= TR * WAVE;
+    double ra[TR], rb[TR];
+    auto fetch_tab = [&](int k_) {
+        const int i_ = cIJ[k_].x >> 3, j_ = (cIJ[k_].y >> 3) - (pd.n1 + 1);
+        const double* gA_ = TA + (int64_t)i_ * pd.n1;
+        const double* gB_ = TB + (int64_t)j_ * pd.n2;
+#pragma unroll
+        for (int m_ = 0; m_ < TR; ++m_) {
+            ra[m_] = (lane + m_ * WAVE < pd.n1) ? gA_[lane + m_ * WAVE] : 0.0;
+            rb[m_] = (lane + m_ * WAVE < pd.n2) ? gB_[lane + m_ * WAVE] : 0.0;
+        }
+    };
+    if (pre && w < nrows) fetch_tab(__builtin_amdgcn_readfirstlane(row0 + w));
     for (int r = w; r < nrows; r += wpb) {
-        const int k = row0 + r;
-        const int i = gI[k], j = gJ[k];
-        const double zi = GRAV ? gZa[k] : 0.0, zj = GRAV ? gZb[k] : 0.0;
-        const double* gA = TA + (int64_t)i * pd.n1;
-        const double* gB = TB + (int64_t)j * pd.n2;
+        const int k = __builtin_amdgcn_readfirstlane(row0 + r);      // wave-uniform: loop bounds and lane selects in SGPRs
+        const double zi = GRAV ? cZZ[k].x : 0.0, zj = GRAV ? cZZ[k].y : 0.0;
         // stage the two table rows (wave-private slice; LDS ops of one wave execute in order)
-        for (int t = lane; t < pd.n1; t += WAVE) tA[t] = gA[t];
-        for (int t = lane; t < pd.n2; t += WAVE) tB[t] = gB[t];
+        if (pre) {
+#pragma unroll
+            for (int m_ = 0; m_ < TR; ++m_) {
+                if (lane + m_ * WAVE < pd.n1) tA[lane + m_ * WAVE] = ra[m_];
+                if (lane + m_ * WAVE < pd.n2) tB[lane + m_ * WAVE] = rb[m_];
+            }
+        } else {
+            const int i = cIJ[k].x >> 3, j = (cIJ[k].y >> 3) - (pd.n1 + 1);
+            const double* gA = TA + (int64_t)i * pd.n1;
+            const double* gB = TB + (int64_t)j * pd.n2;
+            for (int t = lane; t < pd.n1; t += WAVE) tA[t] = gA[t];
+            for (int t = lane; t < pd.n2; t += WAVE) tB[t] = gB[t];
+        }
         if (lane == 0) tA[pd.n1] = d_nan();                     // sentinel entry of the padding columns
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (pre && r + wpb < nrows) fetch_tab(__builtin_amdgcn_readfirstlane(row0 + r + wpb));
 
+        // The pair test is symmetric: row k computes only the 64-column words c >= R = k/64 (the diagonal word
+        // completely, both of its triangles) and mirrors every hit (k, q) of the words c > R into row q with one
+        // 8-byte atomic OR on word (q, R) — integer OR: any order gives the same bits.  The mask pool is zeroed
+        // before this kernel; prefix counts and row totals are taken afterwards by k_rowprefix.
         unsigned long long* mrow = mbase + (int64_t)k * W;
-        uint32_t* prow = pbase + (int64_t)k * W;
-        uint32_t cnt = 0, cntBlk = 0;
+        const int R = k >> 6;
+        const unsigned long long kbit = 1ull << (k & 63);
         uint32_t mlo = 0u, mhi = 0u;                            // lane l: word (block*64 + l) of the current 64-word block
-        for (int q0 = 0; q0 < Lpad; q0 += U * WAVE) {
+        for (int q0 = (R << 6) & ~(U * WAVE - 1); q0 < Lpad; q0 += U * WAVE) {
             int2 ij[U]; double2 zz[U];
 #pragma unroll
             for (int t = 0; t < U; ++t) {
@@ -543,18 +569,17 @@ __device__ __forceinline__ void count_rows_lds(const DevParams& D, const ProbDes
                     asm("s_mov_b32 m0, %3\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %4, m0"
                         : "+v"(mlo), "+v"(mhi) : "s"(ml_), "s"(sel_), "s"(mh_) : "m0");
                 }
-                cnt += __popcll(m);
+                if (m != 0ull && widx > R) {                    // mirror the hits into the rows of the columns
+                    if (is) atomicOr(mbase + (int64_t)((widx << 6) + lane) * W + R, kbit);
+                }
             }
             const int wend = min(W, (q0 >> 6) + U);             // words [.., wend) are complete
             if ((wend & 63) == 0 || wend == W) {                // flush the block of <= 64 words, coalesced
                 const int wb = (wend - 1) & ~63;
                 const unsigned long long mreg = ((unsigned long long)mhi << 32) | mlo;
-                const uint32_t pref = cntBlk + wave_excl_scan((wb + lane < wend) ? (uint32_t)__popcll(mreg) : 0u, lane);
-                if (wb + lane < wend) { mrow[wb + lane] = mreg; prow[wb + lane] = pref; }
-                cntBlk = cnt;
+                if (wb + lane < wend && wb + lane >= R) mrow[wb + lane] = mreg;
             }
         }
-        if (lane == 0) rowCnt[k] = cnt;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();                        // table slice is rewritten by the next row
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -609,6 +634,41 @@ __global__ void __launch_bounds__(1024) k_count(DevParams D, const ProbDesc* __r
         else
             count_rows_global<GRAV>(D, pd, L, it.row0, nrows, w, wpb, lane, li + lo, lj + lo, lza + lo, lzb + lo,
                                     TA, TB, tA, rowCnt + lo, maskPool + mo, prefPool + mo);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_rowprefix: per live row, the number of candidates in front of every 64-column mask word (the entry
+// index of the word's first candidate in k_fill) and the row total.  One wave per row, lanes = words.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) k_rowprefix(const ProbDesc* __restrict__ probs, const ProbState* __restrict__ st,
+                                                    const BatchTotals* __restrict__ tot, const ItemDesc* __restrict__ items,
+                                                    const unsigned long long* __restrict__ maskPool, uint32_t* __restrict__ prefPool,
+                                                    uint32_t* __restrict__ rowCnt, int RPB)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+    const int nItems = tot->items;
+    for (int t = blockIdx.x; t < nItems; t += gridDim.x) {
+        const ItemDesc it = items[t];
+        const int b = it.b;
+        const int L = st[b].L;
+        const int W = (L + 63) >> 6;
+        const int64_t lo = probs[b].liveOff, mo = st[b].maskOff;
+        const int nrows = min(RPB, L - it.row0);
+        for (int r = w; r < nrows; r += wpb) {
+            const int k = it.row0 + r;
+            const unsigned long long* mrow = maskPool + mo + (int64_t)k * W;
+            uint32_t* prow = prefPool + mo + (int64_t)k * W;
+            uint32_t carry = 0;
+            for (int wb = 0; wb < W; wb += WAVE) {
+                const bool v = wb + lane < W;
+                const uint32_t c = v ? (uint32_t)__popcll(mrow[wb + lane]) : 0u;
+                const uint32_t ex = wave_excl_scan(c, lane);
+                if (v) prow[wb + lane] = carry + ex;
+                carry += __shfl(ex + c, WAVE - 1);
+            }
+            if (lane == 0) rowCnt[lo + k] = carry;
+        }
     }
 }
 
