@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--cpu-sample", type=int, default=4, help="pairs timed on the CPU oracle (rank 0, N=1 only); 0 = skip")
     ap.add_argument("--latency-reps", type=int, default=30)
     ap.add_argument("--no-profile", action="store_true", help="do not bracket stages with hipEvents")
-    ap.add_argument("--pipeline", type=int, default=2, choices=[1, 2],
+    ap.add_argument("--pipeline", type=int, default=2, choices=[1, 2, 3],
                     help="batches in flight per GPU (roman_ctx_set_pipeline): 2 overlaps the straggler tail of one step's kernels "
                          "with the next step's affinity build; results are complete at the closing device-wide synchronise")
     return ap.parse_args()
@@ -83,8 +83,8 @@ def main():
     batch = batch_from_pairs(reg, [(p.map1, p.map2) for p in pairs])
     kmax = batch.kmax()
     feats = torch.from_numpy(batch.feats).to(dev)
-    # two output sets: with two batches in flight, step k writes set k&1 while step k-1's set is gathered
-    NSET = 2
+    # one output set per batch in flight: step k writes set k % NSET while older sets are gathered
+    NSET = max(args.pipeline, 2)
     assoc_o = [torch.zeros((B, kmax, 2), dtype=torch.int32, device=dev) for _ in range(NSET)]
     n_o = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(NSET)]
     T_o = [torch.zeros((B, 16), dtype=torch.float64, device=dev) for _ in range(NSET)]
@@ -109,23 +109,23 @@ def main():
     step_no = [0]
 
     def step():
-        k = step_no[0] & 1
+        k = step_no[0] % NSET
         step_no[0] += 1
         ctx.align_batch_dev(P, feats.data_ptr(), F, batch.off1, batch.n1, batch.off2, batch.n2, kmax,
                             assoc_o[k].data_ptr(), n_o[k].data_ptr(), T_o[k].data_ptr(), status_o[k].data_ptr(), stats_o[k].data_ptr())
         if world > 1:
-            if args.pipeline == 2:
+            if args.pipeline >= 2:
                 if step_no[0] > 1:
-                    ctx.join(skip_latest=True)                 # torch's stream waits for the PREVIOUS batch only
-                    gather(k ^ 1)
+                    ctx.join(skip_latest=True)                 # torch's stream waits for the OLDER batches only
+                    gather((k - 1) % NSET)                     # (with 3 in flight this is conservative: it also waits for k-1)
             else:
                 gather(k)
 
     def drain():                                               # results of the last batch
-        if args.pipeline == 2:
+        if args.pipeline >= 2:
             ctx.join(skip_latest=False)
             if world > 1 and step_no[0] > 0:
-                gather((step_no[0] - 1) & 1)
+                gather((step_no[0] - 1) % NSET)
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -149,7 +149,7 @@ def main():
     if not args.no_profile:
         ctx.profile_enable(False)
     ctx.set_pipeline(1)                                         # the latency probe and the checks below are single calls
-    last = (args.steps - 1) & 1
+    last = (args.steps - 1) % NSET
     assoc_out, n_out, T_out, status, stats = assoc_o[last], n_o[last], T_o[last], status_o[last], stats_o[last]
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)

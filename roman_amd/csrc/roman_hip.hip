@@ -37,6 +37,8 @@ struct DevBuf {
 
 }  // namespace
 
+constexpr int ROMAN_MAX_PIPELINE = 3;        // workspaces (batches in flight) a context can hold
+
 struct roman_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -68,13 +70,13 @@ struct roman_ctx {
         hipEvent_t evA[ROMAN_STAGE_COUNT] = {nullptr, nullptr, nullptr, nullptr};
         hipEvent_t evB[ROMAN_STAGE_COUNT] = {nullptr, nullptr, nullptr, nullptr};
         bool pending[ROMAN_STAGE_COUNT] = {false, false, false, false};
-    } ws[2];
+    } ws[ROMAN_MAX_PIPELINE];
     int wsel = 0;                              // workspace of the call in progress
     bool in_host_batch = false;                // roman_align_batch (host pointers) is driving roman_align_batch_dev
     int pipeline = 1;                          // batches in flight (1 or 2)
     int next_ws = 0;
-    hipStream_t stream2 = nullptr;             // internal stream of workspace 1 (pipeline == 2)
-    hipStream_t stream1 = nullptr;             // internal stream of workspace 0 while pipelining
+    hipStream_t istream[ROMAN_MAX_PIPELINE] = {nullptr, nullptr, nullptr};   // internal streams of the workspaces while pipelining
+    int latest_ws = -1;                        // workspace of the most recent pipelined batch call
     hipEvent_t evIn = nullptr;                 // inputs ready on the caller's stream
 
     bool profile = false;
@@ -117,9 +119,8 @@ int use_ws0(roman_ctx* c);
 
 int use_ws0(roman_ctx* c)
 {
-    if (c->pipeline == 2) {
-        if (c->stream1) HIPCHK(c, hipStreamSynchronize(c->stream1));
-        if (c->stream2) HIPCHK(c, hipStreamSynchronize(c->stream2));
+    if (c->pipeline >= 2) {
+        for (int k = 0; k < ROMAN_MAX_PIPELINE; ++k) if (c->istream[k]) HIPCHK(c, hipStreamSynchronize(c->istream[k]));
     }
     c->wsel = 0; c->ws[0].stream = c->stream;
     return ROMAN_OK;
@@ -452,7 +453,7 @@ int stage_solve(roman_ctx* c, const DevParams& D, int B, const double* feats, co
 
 int ensure_events(roman_ctx* c)
 {
-    for (int k = 0; k < 2; ++k)
+    for (int k = 0; k < ROMAN_MAX_PIPELINE; ++k)
         for (int s = 0; s < ROMAN_STAGE_COUNT; ++s) {
             if (!c->ws[k].evA[s]) HIPCHK(c, hipEventCreate(&c->ws[k].evA[s]));
             if (!c->ws[k].evB[s]) HIPCHK(c, hipEventCreate(&c->ws[k].evB[s]));
@@ -615,8 +616,8 @@ int roman_ctx_create(roman_ctx_t** out, int device, void* stream)
         if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return fail(nullptr, ROMAN_E_HIP, "hipStreamCreate failed"); }
         c->own_stream = true;
     }
-    c->ws[0].stream = c->stream; c->ws[1].stream = c->stream;
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < ROMAN_MAX_PIPELINE; ++k) c->ws[k].stream = c->stream;
+    for (int k = 0; k < ROMAN_MAX_PIPELINE; ++k) {
         if (hipHostMalloc((void**)&c->ws[k].pinnedTotals, sizeof(BatchTotals), hipHostMallocDefault) != hipSuccess) {
             roman_ctx_destroy(c); return fail(nullptr, ROMAN_E_NOMEM, "hipHostMalloc failed");
         }
@@ -630,7 +631,7 @@ int roman_ctx_destroy(roman_ctx_t* c)
     if (!c) return ROMAN_OK;
     (void)hipSetDevice(c->device);
     (void)roman_ctx_sync(c);
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < ROMAN_MAX_PIPELINE; ++k) {
         roman_ctx::Workspace& W = c->ws[k];
         DevBuf* all[] = {&W.probs, &W.state, &W.totals, &W.queue, &W.cosPool, &W.normPool, &W.tabPool, &W.sTmp, &W.lp, &W.li, &W.lj, &W.ls, &W.lza, &W.lzb,
                          &W.rowCnt, &W.rowPos, &W.perm, &W.sliceWidth, &W.sliceBase, &W.items, &W.maskPool, &W.prefPool, &W.vMu, &W.vCu, &W.vMun, &W.vCun, &W.gU, &W.gUn,
@@ -642,32 +643,32 @@ int roman_ctx_destroy(roman_ctx_t* c)
         if (W.done) (void)hipEventDestroy(W.done);
     }
     if (c->evIn) (void)hipEventDestroy(c->evIn);
-    if (c->stream1) (void)hipStreamDestroy(c->stream1);
-    if (c->stream2) (void)hipStreamDestroy(c->stream2);
+    for (int k = 0; k < ROMAN_MAX_PIPELINE; ++k) if (c->istream[k]) (void)hipStreamDestroy(c->istream[k]);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return ROMAN_OK;
 }
 
-// Two batches in flight.  depth 1 (default): every call runs on the context's stream.  depth 2: batch calls
-// (roman_align_batch_dev) alternate between two workspaces, each with an internal stream that starts after
+// Batches in flight.  depth 1 (default): every call runs on the context's stream.  depth 2 or 3: batch calls
+// (roman_align_batch_dev) rotate over that many workspaces, each with an internal stream that starts after
 // the work already queued on the context's stream; their results are complete after roman_ctx_sync (or a
 // device-wide synchronisation), NOT after synchronising the context's stream alone.
 int roman_ctx_set_pipeline(roman_ctx_t* c, int depth)
 {
     if (!c) return fail(nullptr, ROMAN_E_INVALID, "ctx is NULL");
-    if (depth != 1 && depth != 2) return fail(c, ROMAN_E_INVALID, "pipeline depth must be 1 or 2");
+    if (depth < 1 || depth > ROMAN_MAX_PIPELINE) return fail(c, ROMAN_E_INVALID, "pipeline depth must be 1..%d", ROMAN_MAX_PIPELINE);
     HIPCHK(c, hipSetDevice(c->device));
     int rc = roman_ctx_sync(c);
     if (rc) return rc;
-    if (depth == 2) {
-        if (!c->stream1) HIPCHK(c, hipStreamCreateWithFlags(&c->stream1, hipStreamNonBlocking));
-        if (!c->stream2) HIPCHK(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    if (depth >= 2) {
+        for (int k = 0; k < depth; ++k) {
+            if (!c->istream[k]) HIPCHK(c, hipStreamCreateWithFlags(&c->istream[k], hipStreamNonBlocking));
+            if (!c->ws[k].done) HIPCHK(c, hipEventCreateWithFlags(&c->ws[k].done, hipEventDisableTiming));
+        }
         if (!c->evIn) HIPCHK(c, hipEventCreateWithFlags(&c->evIn, hipEventDisableTiming));
-        for (int k = 0; k < 2; ++k) if (!c->ws[k].done) HIPCHK(c, hipEventCreateWithFlags(&c->ws[k].done, hipEventDisableTiming));
     }
-    c->pipeline = depth; c->next_ws = 0; c->wsel = 0; c->ws[0].issued = c->ws[1].issued = false;
-    c->ws[0].stream = c->stream; c->ws[1].stream = c->stream;
+    c->pipeline = depth; c->next_ws = 0; c->wsel = 0; c->latest_ws = -1;
+    for (int k = 0; k < ROMAN_MAX_PIPELINE; ++k) { c->ws[k].issued = false; c->ws[k].stream = c->stream; }
     return ROMAN_OK;
 }
 
@@ -678,10 +679,10 @@ int roman_ctx_set_pipeline(roman_ctx_t* c, int depth)
 int roman_ctx_join(roman_ctx_t* c, int skip_latest)
 {
     if (!c) return fail(nullptr, ROMAN_E_INVALID, "ctx is NULL");
-    if (c->pipeline != 2) return ROMAN_OK;                      // everything already runs on the caller's stream
+    if (c->pipeline < 2) return ROMAN_OK;                       // everything already runs on the caller's stream
     HIPCHK(c, hipSetDevice(c->device));
-    const int latest = c->next_ws ^ 1;                          // workspace of the most recent batch call
-    for (int k = 0; k < 2; ++k) {
+    const int latest = c->latest_ws;                            // workspace of the most recent batch call
+    for (int k = 0; k < c->pipeline; ++k) {
         if (skip_latest && k == latest) continue;
         if (c->ws[k].done && c->ws[k].issued) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ws[k].done, 0));
     }
@@ -692,8 +693,7 @@ int roman_ctx_sync(roman_ctx_t* c)
 {
     if (!c) return fail(nullptr, ROMAN_E_INVALID, "ctx is NULL");
     HIPCHK(c, hipSetDevice(c->device));
-    if (c->stream1) HIPCHK(c, hipStreamSynchronize(c->stream1));
-    if (c->stream2) HIPCHK(c, hipStreamSynchronize(c->stream2));
+    for (int k = 0; k < ROMAN_MAX_PIPELINE; ++k) if (c->istream[k]) HIPCHK(c, hipStreamSynchronize(c->istream[k]));
     if (c->stream) HIPCHK(c, hipStreamSynchronize(c->stream));
     return ROMAN_OK;
 }
@@ -704,21 +704,21 @@ int roman_profile_enable(roman_ctx_t* c, int on)
     if (!c) return fail(nullptr, ROMAN_E_INVALID, "ctx is NULL");
     HIPCHK(c, hipSetDevice(c->device));
     if (on) { int rc = ensure_events(c); if (rc) return rc; }
-    else for (int k = 0; k < 2; ++k) for (int s = 0; s < ROMAN_STAGE_COUNT; ++s) prof_flush(c, k, s);
+    else for (int k = 0; k < ROMAN_MAX_PIPELINE; ++k) for (int s = 0; s < ROMAN_STAGE_COUNT; ++s) prof_flush(c, k, s);
     c->profile = on != 0;
     return ROMAN_OK;
 }
 int roman_profile_reset(roman_ctx_t* c)
 {
     if (!c) return fail(nullptr, ROMAN_E_INVALID, "ctx is NULL");
-    for (int k = 0; k < 2; ++k) for (int s = 0; s < ROMAN_STAGE_COUNT; ++s) prof_flush(c, k, s);
+    for (int k = 0; k < ROMAN_MAX_PIPELINE; ++k) for (int s = 0; s < ROMAN_STAGE_COUNT; ++s) prof_flush(c, k, s);
     for (int s = 0; s < ROMAN_STAGE_COUNT; ++s) { c->prof_ms[s] = 0.0; c->prof_n[s] = 0; }
     return ROMAN_OK;
 }
 int roman_profile_get(roman_ctx_t* c, double ms[ROMAN_STAGE_COUNT], int64_t launches[ROMAN_STAGE_COUNT])
 {
     if (!c) return fail(nullptr, ROMAN_E_INVALID, "ctx is NULL");
-    for (int k = 0; k < 2; ++k) for (int s = 0; s < ROMAN_STAGE_COUNT; ++s) prof_flush(c, k, s);
+    for (int k = 0; k < ROMAN_MAX_PIPELINE; ++k) for (int s = 0; s < ROMAN_STAGE_COUNT; ++s) prof_flush(c, k, s);
     for (int s = 0; s < ROMAN_STAGE_COUNT; ++s) { if (ms) ms[s] = c->prof_ms[s]; if (launches) launches[s] = c->prof_n[s]; }
     return ROMAN_OK;
 }
@@ -741,9 +741,9 @@ int roman_align_batch_dev(roman_ctx_t* c, const roman_params_t* params, int32_t 
     DevParams D;
     int rc = make_dev_params(c, params, F, &D);
     if (rc) return rc;
-    if (c->pipeline == 2 && !c->in_host_batch) {                // next workspace, on its internal stream, behind the caller's stream
-        c->wsel = c->next_ws; c->next_ws ^= 1;
-        WS.stream = c->wsel == 0 ? c->stream1 : c->stream2;
+    if (c->pipeline >= 2 && !c->in_host_batch) {                // next workspace, on its internal stream, behind the caller's stream
+        c->wsel = c->next_ws; c->next_ws = (c->next_ws + 1) % c->pipeline; c->latest_ws = c->wsel;
+        WS.stream = c->istream[c->wsel];
         HIPCHK(c, hipEventRecord(c->evIn, c->stream));
         HIPCHK(c, hipStreamWaitEvent(WS.stream, c->evIn, 0));
     } else if (!c->in_host_batch) {
@@ -761,7 +761,7 @@ int roman_align_batch_dev(roman_ctx_t* c, const roman_params_t* params, int32_t 
     if (rc) return rc;
     rc = stage_solve(c, D, B, feats, assoc, u0, tot, idx16, false, kmax, assoc_out, n_assoc_out, T_out, status_out, stats_out);
     if (rc) return rc;
-    if (c->pipeline == 2 && !c->in_host_batch) { HIPCHK(c, hipEventRecord(WS.done, WS.stream)); WS.issued = true; }
+    if (c->pipeline >= 2 && !c->in_host_batch) { HIPCHK(c, hipEventRecord(WS.done, WS.stream)); WS.issued = true; }
     if (c->wsel == 0) { c->last.scored = false; c->last.solved = false; }
     return ROMAN_OK;
 }
