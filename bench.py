@@ -12,7 +12,7 @@ scaling, no data-path collective) and one RCCL all_gather of the fixed-size resu
 (inlier sets + poses) closes each step.
 
 The printed JSON line also carries
-  roofline      — the dominant kernel (k_solve, HBM-bound SpMV passes): algorithmic bytes per launch
+  roofline      — the dominant kernel (k_solve_stream, HBM-bound SpMV passes): algorithmic bytes per launch
                   (sum_b N_pass,b * (12*nnz_upper,b + 24*L_b)) / its hipEvent time,
                   against the 8 TB/s HBM3E peak;
   cpu_baseline  — the CPU oracle (a restatement of the absent clipperpy, kind "port") timed on this
@@ -210,8 +210,16 @@ def main():
         if solve_n > 0 and solve_ms > 0:
             avg_s = solve_ms / solve_n * 1e-3
             ach = alg_bytes / avg_s / 1e9
-            out["roofline"] = {"kernel": "k_solve", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": ach / HBM_PEAK_GBS, "traffic": None,
+            traffic = None                                      # HBM bytes per launch from the committed PMC pass (same workload)
+            try:
+                with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
+                    pj = json.load(fh)
+                if pj.get("kernel") == "k_solve_stream" and B == 256 and (args.n, args.m, args.d) == (200, 200, 512):
+                    traffic = pj["traffic_bytes_per_launch"]
+            except (OSError, ValueError, KeyError):
+                pass
+            out["roofline"] = {"kernel": "k_solve_stream", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/pmc_traffic.json)",
                                "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": solve_ms / solve_n,
                                "dominant_stage_by_time": dom}
     # ---- CPU baseline: the oracle on this box's host cores, bounded sample ----------------------------
