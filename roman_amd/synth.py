@@ -190,3 +190,75 @@ def make_submap_grid(n_submaps, n=200, d=512, seed0=4000, overlap=0.5, noise=0.1
         submaps.append(objs)
         poses.append(T_ws)
     return submaps, poses
+
+
+# --------------------------------------------------------------------------------------------------
+# scenarios for the submap-pair loop: two robots' submaps with odometry and
+# ground-truth poses, timestamps and submap descriptors
+# --------------------------------------------------------------------------------------------------
+ALIGN_SCENARIOS = {
+    # name: (params kwargs, io kwargs, generator options)
+    "gravity_gt": (dict(method="gravity"), dict(gt_available=(True, True)),
+                   dict(d=0, n=24, empty=True, far=True)),
+    "roman_descriptor": (dict(method="roman", semantics_dim=16, submap_descriptor="mean_semantic", submap_descriptor_thresh=0.55),
+                         dict(skip_distance=25.0, lc_association_thresh=5), dict(d=16, n=28, far=True)),
+    "single_robot_fill": (dict(method="pcavolgrav", single_robot_lc=True, single_robot_lc_time_thresh=50.0,
+                               force_fill_submaps=True, epsilon_shape=0.1, force_rm_lc_roll_pitch=False),
+                          dict(), dict(d=0, n=26, shared_ids=True)),
+    "prune": (dict(method="clipper+prune", cosine_min=0.5, epsilon_shape=0.05), dict(), dict(d=24, n=22)),
+}
+
+
+def make_align_scenario(name, seed0=7100):
+    """-> (params_kwargs, io_kwargs, robots, trajectories): robots[r] is a list of dicts with the fields of the
+    reference's Submap ([REF roman/map/map.py:94-103]: id, time, segments, pose_flu, pose_flu_gt, descriptor),
+    trajectories[r] the (times, poses) of robot r's odometry that the `.g2o` writer indexes into."""
+    pk, iok, opt = ALIGN_SCENARIOS[name]
+    n_sub = (3, 3)
+    subs, poses = make_submap_grid(sum(n_sub), n=opt["n"], d=opt["d"], seed0=seed0)
+    rng = np.random.default_rng(seed0 + 999)
+    robots, trajectories = [], []
+    place = rng.standard_normal(max(opt["d"], 1)); place /= np.linalg.norm(place)
+    s = 0
+    for r in range(2):
+        rob = []
+        for k in range(n_sub[r]):
+            T_gt = poses[s].copy()
+            if opt.get("far") and r == 1 and k == 2:
+                T_gt[:3, 3] += np.array([60.0, -45.0, 0.0])           # beyond 2 x submap_radius and skip_distance
+            T_odom = T_gt @ yaw_transform(rng.normal(0, 0.05), rng.normal(0, 0.3, 3))      # drifted odometry
+            tilt = yaw_transform(0.0, [0, 0, 0], roll=rng.normal(0, 0.03), pitch=rng.normal(0, 0.03))
+            segs = subs[s]
+            if opt.get("empty") and r == 1 and k == 1:
+                segs = []
+            if opt.get("shared_ids"):                                  # one robot revisiting: overlapping id ranges
+                for q, sg in enumerate(segs):
+                    sg.id = 10 * (3 * r + k) + q                       # neighbours share ids 10..(n-1) apart
+            desc = None
+            if opt["d"] > 0:                                           # same place seen twice: place vector + noise
+                desc = place + 0.45 * rng.standard_normal(opt["d"]) / np.sqrt(opt["d"])
+                if r == 1 and k == 0:
+                    desc = rng.standard_normal(opt["d"])               # an unrelated place: the descriptor gate fires
+            rob.append(dict(id=k, time=100.0 * r + 30.0 * k + 0.25 * (k + 1), segments=segs,
+                            pose_flu=T_odom @ tilt, pose_flu_gt=T_gt @ tilt, descriptor=desc))
+            s += 1
+        robots.append(rob)
+        times = np.arange(0.0, 400.0, 0.5) + 0.01 * r
+        trajectories.append((times, [np.eye(4) for _ in times]))
+    return dict(pk), dict(iok), robots, trajectories
+
+
+def map_segments_of(submap_segment_lists):
+    """The robot's whole-map segment list for the `sm.json` writer: every distinct segment of its submaps; every
+    third one carries a small point cloud (`points`), the others do not (minimal data) and are skipped by the writer."""
+    seen, out = set(), []
+    for segs in submap_segment_lists:
+        for sg in segs:
+            if id(sg) in seen:
+                continue
+            seen.add(id(sg))
+            if len(out) % 3 == 0:
+                c = sg.center.reshape(-1)
+                sg.points = c + 0.1 * np.array([[1, 0, 0], [0, 1, 0], [0, 0, 1], [-1, -1, -1.0]])
+            out.append(sg)
+    return out

@@ -30,18 +30,61 @@ REF = "/root/reference"
 def install_reference_stubs():
     import _oracle_clipperpy
     _oracle_clipperpy.install()
-    for name in ["robotdatapy", "robotdatapy.transform", "open3d"]:
+    for name in ["robotdatapy", "robotdatapy.transform", "robotdatapy.data", "robotdatapy.data.pose_data", "open3d"]:
         sys.modules[name] = types.ModuleType(name)
-    sys.modules["robotdatapy.transform"].transform = lambda T, x, **k: x
+    install_robotdatapy_restatement(sys.modules["robotdatapy.transform"], sys.modules["robotdatapy.data.pose_data"])
     sys.modules["robotdatapy"].transform = sys.modules["robotdatapy.transform"]
     # roman.object.segment / pointcloud_object pull cv2, shapely, ... : the plugins only use them
     # for type hints, so give dist_reg_with_pruning importable placeholders.
-    for name, attrs in [("roman.object.pointcloud_object", ["PointCloudObject"]), ("roman.object.segment", ["Segment"])]:
+    for name, attrs in [("roman.object.pointcloud_object", ["PointCloudObject"]), ("roman.object.segment", ["Segment", "SegmentMinimalData"])]:
         m = types.ModuleType(name)
         for a in attrs:
             setattr(m, a, type(a, (), {}))
         sys.modules[name] = m
     sys.path.insert(0, REF)
+
+
+def install_robotdatapy_restatement(tf, pd):
+    """robotdatapy (pip dependency of the reference, [REF setup.py], absent here and not vendored) — the five
+    helpers the pair loop and the writers call, restated from its published behaviour:
+    transform(T, pts) applies a homogeneous transform to row-vector points; transform_to_xyzrpy = translation +
+    scipy 'xyz' Euler angles; transform_to_xyz_quat = translation + scipy xyzw quaternion; transform_to_xytheta
+    = planar pose; PoseData.idx(t, force_single=True) = index of the sample closest in time."""
+    from scipy.spatial.transform import Rotation as Rot
+
+    def transform(T, pts, **kw):
+        pts = np.asarray(pts, dtype=np.float64)
+        d = T.shape[0] - 1
+        return pts @ T[:d, :d].T + T[:d, d]
+
+    def transform_to_xyzrpy(T, degrees=False):
+        return np.concatenate([T[:3, 3], Rot.from_matrix(T[:3, :3]).as_euler('xyz', degrees=degrees)])
+
+    def transform_to_xyz_quat(T, separate=False):
+        t, q = T[:3, 3].copy(), Rot.from_matrix(T[:3, :3]).as_quat()
+        return (t, q) if separate else np.concatenate([t, q])
+
+    def transform_to_xytheta(T):
+        return T[0, -1], T[1, -1], np.arctan2(T[1, 0], T[0, 0])
+
+    class PoseData:
+        def __init__(self, times, poses):
+            self.times = np.asarray(times, dtype=np.float64); self.poses = poses
+
+        @classmethod
+        def from_times_and_poses(cls, times, poses, **kw):
+            return cls(times, poses)
+
+        @classmethod
+        def from_csv(cls, **kw):                         # only `is not None` is tested on the ground-truth source
+            return cls([], [])
+
+        def idx(self, t, force_single=False):
+            return int(np.argmin(np.abs(self.times - t)))
+
+    tf.transform, tf.transform_to_xyzrpy, tf.transform_to_xyz_quat, tf.transform_to_xytheta = \
+        transform, transform_to_xyzrpy, transform_to_xyz_quat, transform_to_xytheta
+    pd.PoseData = PoseData
 
 
 class Pt:
@@ -161,9 +204,95 @@ def gen_register():
     print(f"register_golden.npz: {len(cases)} cases")
 
 
+def gen_submap_align():
+    """submap_align_golden.npz — PINS rows f1/f3: the reference's unmodified pair loop
+    (/root/reference/roman/align/submap_align.py:28-220) and result writers (roman/align/results.py:122-198)
+    run over the scenarios of roman_amd.synth.make_align_scenario, with the map loader replaced by the
+    synthetic submaps (reference `Submap` instances) and the oracle-backed clipperpy underneath."""
+    import tempfile
+    import pickle
+    import yaml
+    import matplotlib
+    matplotlib.use("Agg")
+    import roman.align.submap_align as ref_sa
+    import roman.align.results as ref_res
+    from roman.map.map import Submap as RefSubmap
+    from roman.params.submap_align_params import SubmapAlignParams as RefParams, SubmapAlignInputOutput as RefIO
+    from roman_amd import synth
+
+    class FakeMap:                                       # what load_roman_map would have returned
+        def __init__(self, submaps, times, traj):
+            self.submaps, self.times, self.trajectory = submaps, list(times), traj
+            self.segments = synth.map_segments_of([s.segments for s in submaps])
+
+    ref_sa.load_roman_map = lambda m: m
+    ref_sa.submaps_from_roman_map = lambda rm, sp, gt: rm.submaps
+    ref_res.plot_align_results = lambda *a, **k: None
+    ref_res.plt.savefig = lambda *a, **k: None
+    out = {"names": np.array(list(synth.ALIGN_SCENARIOS))}
+    for name in synth.ALIGN_SCENARIOS:
+        pk, iok, robots, trajs = synth.make_align_scenario(name)
+        tmp = tempfile.mkdtemp()
+        gt = iok.pop("gt_available", (False, False))
+        yamls = [None, None]
+        for r in range(2):
+            if gt[r]:
+                yamls[r] = os.path.join(tmp, f"gt{r}.yaml")
+                with open(yamls[r], "w") as f:
+                    yaml.safe_dump({"type": "csv"}, f)
+        maps = [FakeMap([RefSubmap(id=s["id"], time=s["time"], segments=s["segments"], pose_flu=s["pose_flu"],
+                                   pose_flu_gt=s["pose_flu_gt"], descriptor=s["descriptor"]) for s in robots[r]],
+                        *trajs[r]) for r in range(2)]
+        io = RefIO(inputs=maps, output_dir=tmp, run_name="run", input_gt_pose_yaml=yamls, **iok)
+        sp = RefParams(**pk)
+        captured = {}
+        real_save = ref_res.save_submap_align_results
+
+        def save(results, submaps, roman_maps):
+            captured["r"] = results
+            # the results pickle embeds reference classes and the fake maps: not part of the fixture
+            orig_dump = pickle.dump
+            ref_res.pickle.dump = lambda obj, f: orig_dump(obj, f) if isinstance(obj, list) else None
+            try:
+                real_save(results, submaps, roman_maps)
+            finally:
+                ref_res.pickle.dump = orig_dump
+        ref_sa.save_submap_align_results = save
+        ref_sa.submap_align(sp, io)
+        R = captured["r"]
+        for k in ["robots_nearby_mat", "clipper_angle_mat", "clipper_dist_mat", "clipper_num_associations",
+                  "submap_yaw_diff_mat", "T_ij_mat", "T_ij_hat_mat"]:
+            out[f"{name}/{k}"] = getattr(R, k)
+        out[f"{name}/similarity_mat"] = R.similarity_mat if R.similarity_mat is not None else np.zeros(0)
+        out[f"{name}/has_similarity"] = R.similarity_mat is not None
+        n0, n1 = R.clipper_num_associations.shape
+        for i in range(n0):
+            for j in range(n1):
+                out[f"{name}/assoc_{i}_{j}"] = np.asarray(R.associated_objs_mat[i][j], dtype=np.int64).reshape(-1, 2) \
+                    if np.size(R.associated_objs_mat[i][j]) else np.zeros((0, 2), np.int64)
+        out[f"{name}/n_timed"] = len(R.timing_list)
+        out[f"{name}/g2o"] = open(io.output_g2o).read()
+        out[f"{name}/json"] = open(io.output_lc_json).read()
+        out[f"{name}/timing"] = open(io.output_timing).read()
+        for r in range(2):
+            out[f"{name}/sm_json_{r}"] = open(io.output_submaps[r]).read()
+        with open(io.output_matrix, "rb") as f:
+            mats = pickle.load(f)
+        out[f"{name}/matrix_pkl_len"] = len(mats)
+        print(f"  {name:20s} pairs registered={len(R.timing_list)} edges={out[f'{name}/g2o'].count('EDGE_SE3')}"
+              f" assoc counts={R.clipper_num_associations.astype(int).ravel().tolist()}")
+    np.savez_compressed(os.path.join(HERE, "submap_align_golden.npz"), **out)
+    print("submap_align_golden.npz written")
+
+
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         sys.exit("reference checkout not present: golden fixtures can only be regenerated where /root/reference exists")
     install_reference_stubs()
-    gen_t_align()
-    gen_register()
+    which = sys.argv[1:] or ["t_align", "register", "submap_align"]
+    if "t_align" in which:
+        gen_t_align()
+    if "register" in which:
+        gen_register()
+    if "submap_align" in which:
+        gen_submap_align()
