@@ -11,4 +11,4 @@ from .roman_registration import FusionMethod, ROMANParams, ROMANRegistration  # 
 from .dist_reg_with_pruning import DistRegWithPruning, GravityConstraintError  # noqa: F401
 from .submap_align_params import SubmapAlignParams  # noqa: F401
 from .batch import AlignmentBatch, align_pairs, all_pairs_problems  # noqa: F401
-from .submap_align import Submap, SubmapAlignIO, SubmapAlignResults, submap_align  # noqa: F401
+from .submap_align import Submap, SubmapAlignIO, SubmapAlignResults  # noqa: F401  (the loop: roman_amd.align.submap_align.submap_align)
