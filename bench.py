@@ -167,7 +167,7 @@ def main():
 
     # ---- p50 single-pair latency (config 2: B=1) ----------------------------------------------------
     p50 = None
-    if rank == 0:
+    if rank == 0 and args.latency_reps >= 0:          # --latency-reps -1: B=256 launches only (counter passes)
         b1 = batch.subset(0, 1)
         lat = []
         for r in range(args.latency_reps + 3):

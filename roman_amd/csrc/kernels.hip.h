@@ -54,6 +54,8 @@ struct ProbState {
     int64_t  maskOff;      // offset (in 64-bit words) of this problem's candidate bit matrix
     uint32_t nnzCap;       // padded SELL slots allocated for this problem
     int32_t  itemBase;     // first work item (row block) of this problem
+    int32_t  sgBase;       // first slice group (k_fill_slice work item) of this problem
+    int32_t  pad0;
     unsigned long long nnzUpper;   // stored strict-upper non-zeros (after the affinityeps filter)
 };
 
@@ -63,7 +65,7 @@ struct BatchTotals {
     int32_t R;             // sum of L
     int32_t maxL;
     int32_t items;         // work items (row blocks) of the pair-test / fill kernels
-    int32_t pad;
+    int32_t sliceGroups;   // work items (groups of SPI slices) of k_fill_slice
 };
 
 struct ItemDesc { int32_t b, row0; };   // a block of consecutive live rows of problem b
@@ -743,20 +745,27 @@ __global__ void __launch_bounds__(1024) k_rowsort(int widthPad /* 1, or 4 for th
     if (tid == 0) st[b].nnzCap = carry_s;
 }
 
-// k_probscan: serial prefix of the per-problem slot totals.
-__global__ void __launch_bounds__(64) k_probscan(int B, ProbState* __restrict__ st, BatchTotals* __restrict__ tot)
+// k_probscan: serial prefix of the per-problem slot totals and of the slice-group counts (SPI slices per group).
+__global__ void __launch_bounds__(64) k_probscan(int B, int SPI, ProbState* __restrict__ st, BatchTotals* __restrict__ tot)
 {
     const int lane = threadIdx.x;
     long long acc = 0;
+    int gacc = 0;
     for (int b0 = 0; b0 < B; b0 += WAVE) {
         const int b = b0 + lane;
         const long long cap = b < B ? (long long)st[b].nnzCap : 0;
+        const int ng = b < B ? (((st[b].L + 63) >> 6) + SPI - 1) / SPI : 0;
         long long pc = cap;
-        for (int off = 1; off < WAVE; off <<= 1) { const long long t = __shfl_up(pc, off); if (lane >= off) pc += t; }
-        if (b < B) st[b].nnzOff = acc + pc - cap;
+        int pg = ng;
+        for (int off = 1; off < WAVE; off <<= 1) {
+            const long long t = __shfl_up(pc, off); const int tg = __shfl_up(pg, off);
+            if (lane >= off) { pc += t; pg += tg; }
+        }
+        if (b < B) { st[b].nnzOff = acc + pc - cap; st[b].sgBase = gacc + pg - ng; }
         acc += __shfl(pc, WAVE - 1);
+        gacc += __shfl(pg, WAVE - 1);
     }
-    if (lane == 0) tot->nnzTotal = acc;
+    if (lane == 0) { tot->nnzTotal = acc; tot->sliceGroups = gacc; }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -940,6 +949,185 @@ __global__ void __launch_bounds__(1024) k_fill(DevParams D, const ProbDesc* __re
                 const uint32_t slot = (uint32_t)(L & 63) + x / width, e = x % width;
                 cols[col_pos<QUAD>(sb, slot, e)] = (IdxT)((uint32_t)L | IdxTraits<IdxT>::CZ);
                 vals[val_pos<QUAD>(sb, slot, e)] = 0.0;
+            }
+        }
+        for (int off = 32; off > 0; off >>= 1) upper += __shfl_xor(upper, off);
+        if (lane == 0 && upper) atomicAdd(&st[b].nnzUpper, (unsigned long long)upper);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_fill_slice (quad layout): the same candidates -> values work as k_fill, organised by OUTPUT: a
+// workgroup builds one 64-row slice of the sorted matrix at a time as an exact image of its HBM block
+// in LDS (entries [e0, e0+EC) of every lane slot: EC*64 values + EC*64 column words) and writes the
+// image out with full-width coalesced stores.  k_fill's per-entry stores land in 64 different cache
+// lines per wave store (a row's entries are 1 KiB apart in the lane-major layout); they cost more
+// than the arithmetic.  Each of the 16 waves expands the masks of 4 lane slots (rows of one slice
+// have similar lengths: the rows are sorted) through the same LDS ring and evaluates 64 candidates
+// at a time.  Slices wider than EC take several passes over their masks.  Work items are groups of
+// SPI consecutive slices of one problem, so the column tile is staged once per group.
+// ---------------------------------------------------------------------------------------------
+constexpr int FILLS_Q = 128;         // ring capacity per wave (< 64 queued + <= 64 emitted per bit step)
+
+template <bool GRAV>
+__global__ void __launch_bounds__(1024) k_fill_slice(DevParams D, int B, const ProbDesc* __restrict__ probs,
+                                                     ProbState* __restrict__ st, const BatchTotals* __restrict__ tot,
+                                                     const double* __restrict__ tabPool,
+                                                     const int32_t* __restrict__ li, const int32_t* __restrict__ lj,
+                                                     const double* __restrict__ ls,
+                                                     const double* __restrict__ lza, const double* __restrict__ lzb,
+                                                     const unsigned long long* __restrict__ maskPool,
+                                                     const uint32_t* __restrict__ prefPool,
+                                                     const uint32_t* __restrict__ perm,
+                                                     const uint32_t* __restrict__ sliceWidth,
+                                                     const uint32_t* __restrict__ sliceBase,
+                                                     uint16_t* __restrict__ cols, double* __restrict__ vals,
+                                                     int TC, int EC /* multiple of 4 */, int SPI)
+{
+    // LDS: cS[TC] [GRAV: cZa[TC] cZb[TC]] cI[TC] cJ[TC] | image values [EC*64] | image columns [EC*64] | rings | sK[64]
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double* cS = reinterpret_cast<double*>(smem);
+    double* cZa = cS + TC;
+    double* cZb = cZa + (GRAV ? TC : 0);
+    int32_t* cI = reinterpret_cast<int32_t*>(cZb + (GRAV ? TC : 0));
+    int32_t* cJ = cI + TC;
+    double* imgV = reinterpret_cast<double*>(cJ + TC);
+    uint16_t* imgC = reinterpret_cast<uint16_t*>(imgV + (size_t)EC * 64);
+    uint32_t* rings = reinterpret_cast<uint32_t*>(imgC + (size_t)EC * 64);
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int lane = tid & 63, w = tid >> 6, nw = nt >> 6;
+    uint32_t* qK = rings + (size_t)w * 3 * FILLS_Q;
+    uint32_t* qQ = qK + FILLS_Q;
+    uint32_t* qE = qQ + FILLS_Q;
+    uint32_t* sK = rings + (size_t)nw * 3 * FILLS_Q;
+    const int SPW = 64 / nw;                                    // lane slots per wave
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const int nGroups = tot->sliceGroups;
+    for (int t = blockIdx.x; t < nGroups; t += gridDim.x) {
+        int b = 0;                                              // last problem with sgBase <= t and at least one group
+        {
+            int lo_ = 0, hi_ = B - 1;
+            while (lo_ < hi_) { const int mid = (lo_ + hi_ + 1) >> 1; if (st[mid].sgBase <= t) lo_ = mid; else hi_ = mid - 1; }
+            b = lo_;
+        }
+        const ProbDesc pd = probs[b];
+        const int L = st[b].L;
+        const int W = (L + 63) >> 6;
+        const int64_t lo = pd.liveOff, mo = st[b].maskOff, no = st[b].nnzOff;
+        const int s_begin = (t - st[b].sgBase) * SPI, s_end = min(W, s_begin + SPI);
+        const double* TA = tabPool + pd.tabOff;
+        const double* TB = TA + (int64_t)pd.n1 * pd.n1;
+        __syncthreads();                        // every wave is done with the previous group's columns
+        for (int q = tid; q < L; q += nt) {
+            cI[q] = li[lo + q]; cJ[q] = lj[lo + q]; cS[q] = ls[lo + q];
+            if (GRAV) { cZa[q] = lza[lo + q]; cZb[q] = lzb[lo + q]; }
+        }
+        uint32_t upper = 0;
+        for (int sl = s_begin; sl < s_end; ++sl) {
+            const uint32_t width = sliceWidth[lo + sl];
+            const int64_t sb = no + sliceBase[lo + sl];         // first element of the slice (multiple of 256)
+            for (uint32_t e0 = 0; e0 < width; e0 += (uint32_t)EC) {
+                const uint32_t ew = min((uint32_t)EC, width - e0);
+                __syncthreads();                                // previous image written out, previous sK consumed
+                if (tid < 64) sK[tid] = (sl * 64 + tid < L) ? perm[lo + sl * 64 + tid] : 0xffffffffu;
+                {   // inert image: value 0, column = dummy vector element L with the C-flag
+                    double2* v2 = reinterpret_cast<double2*>(imgV);
+                    for (uint32_t x = tid; x < ew * 32u; x += nt) v2[x] = make_double2(0.0, 0.0);
+                    const uint32_t inert = ((uint32_t)L | 0x8000u) * 0x10001u;
+                    uint2* c2 = reinterpret_cast<uint2*>(imgC);
+                    for (uint32_t x = tid; x < ew * 16u; x += nt) c2[x] = make_uint2(inert, inert);
+                }
+                __syncthreads();
+
+                uint32_t head = 0, queued = 0;
+                auto evaluate = [&](uint32_t take) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    if ((uint32_t)lane < take) {
+                        const uint32_t s = (head + lane) & (FILLS_Q - 1);
+                        const uint32_t ks = qK[s];
+                        const int k = (int)(ks & 0xffffu);
+                        const uint32_t slot = ks >> 16;
+                        const int q = (int)qQ[s];
+                        const uint32_t e = qE[s] - e0;
+                        const int i = cI[k], j = cJ[k], iq = cI[q], jq = cJ[q];
+                        const double a = TA[(int64_t)i * pd.n1 + iq], bb = TB[(int64_t)j * pd.n2 + jq];
+                        double c;
+                        if (GRAV) {
+                            const double ch = fabs(a - bb);
+                            const double hm = a > bb ? a : bb;
+                            double cv = fabs((cZa[k] - cZa[q]) - (cZb[k] - cZb[q])) - D.sin_unc * hm;
+                            if (cv < 0.0) cv = 0.0;
+                            c = sqrt(ch * ch + cv * cv);
+                        } else {
+                            c = fabs(a - bb);
+                        }
+                        const double sa = exp(((-0.5 * c) * c) / D.sig2);
+                        const double v = fuse_pair(D, sa, cS[k], cS[q]);
+                        if (v > D.p.affinityeps) {              // otherwise the slot stays inert: neither in M nor in C
+                            imgC[(e >> 2) * 256u + slot * 4u + (e & 3u)] = (uint16_t)q;
+                            imgV[(e >> 1) * 128u + slot * 2u + (e & 1u)] = v;
+                            upper += (q > k) ? 1u : 0u;
+                        }
+                    }
+                    head = (head + take) & (FILLS_Q - 1); queued -= take;
+                };
+
+                // this wave's lane slots [w*SPW, w*SPW + SPW): one flat stream over their mask words; the words of
+                // the next block of 64 are fetched while the current block is expanded and evaluated
+                const int nwords = SPW * W;
+                unsigned long long m_next = 0ull; uint32_t e_next = 0u;
+                auto fetch = [&](int x) {
+                    m_next = 0ull; e_next = 0u;
+                    if (x < nwords) {
+                        const int r = x / W, word = x - r * W;
+                        const uint32_t k = sK[w * SPW + r];
+                        if (k != 0xffffffffu) {
+                            m_next = maskPool[mo + (int64_t)k * W + word];
+                            e_next = prefPool[mo + (int64_t)k * W + word];
+                        }
+                    }
+                };
+                fetch(lane);
+                for (int x0 = 0; x0 < nwords; x0 += WAVE) {
+                    const int x = x0 + lane;
+                    unsigned long long m = m_next; uint32_t e = e_next;
+                    fetch(x + WAVE);
+                    const uint32_t slot_ = (uint32_t)(w * SPW + min(x / W, SPW - 1));
+                    const uint32_t ks = (sK[slot_] & 0xffffu) | (slot_ << 16);
+                    const uint32_t qb = (uint32_t)((x < nwords) ? (x - (x / W) * W) : 0) << 6;
+                    if (e >= e0 + ew) m = 0ull;                 // the whole word lies behind this pass
+                    for (;;) {                                  // bit steps
+                        const bool has = m != 0ull;
+                        if (__ballot(has) == 0ull) break;
+                        bool push = false; int bit = 0;
+                        if (has) {
+                            bit = __builtin_ctzll(m);
+                            m &= m - 1ull;
+                            push = e >= e0 && e < e0 + ew;
+                            if (e + 1u >= e0 + ew) m = 0ull;    // the rest of the word belongs to a later pass
+                        }
+                        const unsigned long long act = __ballot(push);
+                        if (push) {
+                            const uint32_t s = (head + queued + (uint32_t)__popcll(act & lt)) & (FILLS_Q - 1);
+                            qK[s] = ks; qQ[s] = qb + (uint32_t)bit; qE[s] = e;
+                        }
+                        if (has) ++e;
+                        queued += (uint32_t)__popcll(act);
+                        while (queued >= 64u) evaluate(64u);
+                    }
+                }
+                if (queued > 0u) evaluate(queued);
+                __syncthreads();
+                {   // image -> HBM: entries [e0, e0+ew) of the slice are one contiguous block in both arrays
+                    const double2* v2 = reinterpret_cast<const double2*>(imgV);
+                    double2* gv = reinterpret_cast<double2*>(vals + sb + (int64_t)e0 * 64);
+                    for (uint32_t x = tid; x < ew * 32u; x += nt) gv[x] = v2[x];
+                    const uint2* c2 = reinterpret_cast<const uint2*>(imgC);
+                    uint2* gc = reinterpret_cast<uint2*>(cols + sb + (int64_t)e0 * 64);
+                    for (uint32_t x = tid; x < ew * 16u; x += nt) gc[x] = c2[x];
+                }
             }
         }
         for (int off = 32; off > 0; off >>= 1) upper += __shfl_xor(upper, off);

@@ -314,7 +314,9 @@ int stage_score(roman_ctx* c, const DevParams& D, const BatchIn& in, std::vector
     const bool quad = use_quad(D, tot.maxL);
     hipLaunchKernelGGL(k_rowsort, dim3(B), dim3(1024), 0, WS.stream, quad ? 4 : 1, dP, dS, WS.rowCnt.as<uint32_t>(), WS.rowPos.as<uint32_t>(), WS.perm.as<uint32_t>(),
                        WS.sliceWidth.as<uint32_t>(), WS.sliceBase.as<uint32_t>());
-    hipLaunchKernelGGL(k_probscan, dim3(1), dim3(64), 0, WS.stream, B, dS, dT);
+    // k_fill_slice work items: groups of SPI slices of one problem (one slice each for small batches)
+    const int SPI = std::max(1, RPB / 64);
+    hipLaunchKernelGGL(k_probscan, dim3(1), dim3(64), 0, WS.stream, B, SPI, dS, dT);
     // read-back #2: padded slot total -> size of the matrix arrays
     HIPCHK(c, hipMemcpyAsync(WS.pinnedTotals, dT, sizeof(BatchTotals), hipMemcpyDeviceToHost, WS.stream));
     t1.stop();
@@ -326,7 +328,26 @@ int stage_score(roman_ctx* c, const DevParams& D, const BatchIn& in, std::vector
     HIPCHK(c, WS.cols.ensure((*idx16 ? sizeof(uint16_t) : sizeof(uint32_t)) * nnz1));
 
     StageTimer t2(c, ROMAN_STAGE_FILL);
-    if (tot.R > 0) {
+    bool sliceFill = false;
+    if (tot.R > 0 && quad) {
+        // slice-image fill: column tile + one slice image (640 bytes per entry column) + 16 candidate rings
+        const int colBytesF = D.gravity ? 32 : 16;
+        const int TCs = (std::max(tot.maxL, 1) + 63) & ~63;
+        const size_t fixedLds = (size_t)TCs * colBytesF + (size_t)16 * 3 * FILLS_Q * sizeof(uint32_t) + 64 * sizeof(uint32_t);
+        if (fixedLds + 640 * 8 <= c->lds_max) {
+            const int EC = (int)std::min<size_t>((c->lds_max - fixedLds) / 640, 4096) & ~3;
+            const size_t sliceLds = fixedLds + (size_t)EC * 640;
+            auto kf = D.gravity ? k_fill_slice<true> : k_fill_slice<false>;
+            HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sliceLds));
+            hipLaunchKernelGGL(kf, dim3(std::min<int64_t>(c->num_cu, std::max<int64_t>(tot.sliceGroups, 1))), dim3(1024), sliceLds, WS.stream,
+                               D, B, dP, dS, dT, WS.tabPool.as<double>(),
+                               WS.li.as<int32_t>(), WS.lj.as<int32_t>(), WS.ls.as<double>(), WS.lza.as<double>(), WS.lzb.as<double>(),
+                               WS.maskPool.as<unsigned long long>(), WS.prefPool.as<uint32_t>(), WS.perm.as<uint32_t>(),
+                               WS.sliceWidth.as<uint32_t>(), WS.sliceBase.as<uint32_t>(), WS.cols.as<uint16_t>(), WS.vals.as<double>(), TCs, EC, SPI);
+            sliceFill = true;
+        }
+    }
+    if (tot.R > 0 && !sliceFill) {
         // fill kernel LDS: column tile (objects, single score, [z,] SELL slot base) + per-wave candidate rings
         const int colBytesF = D.gravity ? 36 : 20;
         const size_t ringLds = (size_t)16 * 3 * FILL_Q * sizeof(uint32_t);

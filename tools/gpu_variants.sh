@@ -2,7 +2,7 @@
 # Time bench.py stages with alternative builds of the library (timing experiments only).
 OUT=$PWD/gpurun_out; mkdir -p $OUT
 for f in "$@"; do
-  ROMAN_HIP_LIBRARY=$PWD/$f timeout 300 python bench.py --steps 10 --warmup 2 --cpu-sample 0 --latency-reps 3 > $OUT/var.txt 2>$OUT/var.err
+  ROMAN_HIP_LIBRARY=$PWD/$f timeout 300 python bench.py --steps 10 --warmup 2 --cpu-sample 0 --latency-reps 3 --pipeline ${PIPE:-1} > $OUT/var.txt 2>$OUT/var.err
   python - "$f" <<PY
 import json,sys
 try:
