@@ -173,13 +173,20 @@ struct __attribute__((packed, aligned(8))) d4u_t { double v[4]; };     // 8-byte
 
 constexpr int COS_TILE = 32;
 
-__global__ void __launch_bounds__(256) k_cos(DevParams D, const ProbDesc* __restrict__ probs,
+__global__ void __launch_bounds__(256) k_cos(DevParams D, int B, int G /* workgroups (4 tiles each) per problem */,
+                                             const ProbDesc* __restrict__ probs,
                                              const double* __restrict__ feats,
                                              double* __restrict__ cosPool)
 {
-    const ProbDesc pd = probs[blockIdx.y];
+    // Workgroups are dealt to the 8 XCDs round-robin by linear id.  All G workgroups of a problem get ids that are
+    // congruent modulo 8, i.e. one XCD and one L2: the descriptors of a problem are read from HBM once instead
+    // of once per XCD (8 problems are interleaved: id = 8 * (G * (b / 8) + g) + b % 8).
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int b = (slot / G) * 8 + xcd;
+    if (b >= B) return;
+    const ProbDesc pd = probs[b];
     const int tj_n = (pd.n2 + COS_TILE - 1) / COS_TILE, ti_n = (pd.n1 + COS_TILE - 1) / COS_TILE;
-    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int tile = (slot % G) * 4 + (threadIdx.x >> 6);
     if (tile >= ti_n * tj_n) return;
     const int lane = threadIdx.x & 63;
     const int i0 = (tile / tj_n) * COS_TILE, j0 = (tile % tj_n) * COS_TILE;
@@ -373,28 +380,29 @@ __global__ void __launch_bounds__(1024) k_live(DevParams D, const ProbDesc* __re
 // k_rowbase: serial prefix of the live counts (B is small); also the batch maxima, the offsets of
 // the per-problem candidate bit matrices (L rows of ceil(L/64) words) and the work-item prefix
 // (a work item = a block of up to RPB consecutive live rows of one problem).
-__global__ void __launch_bounds__(64) k_rowbase(int B, int RPB, ProbState* __restrict__ st, BatchTotals* __restrict__ tot)
+__global__ void __launch_bounds__(64) k_rowbase(int B, int RPB, int SPI, ProbState* __restrict__ st, BatchTotals* __restrict__ tot)
 {
     // one wave; lane-strided blocks of 64 problems with a running carry (B is small)
     const int lane = threadIdx.x;
-    int accR = 0, accI = 0, mx = 0; long long accM = 0;
+    int accR = 0, accI = 0, accG = 0, mx = 0; long long accM = 0;
     for (int b0 = 0; b0 < B; b0 += WAVE) {
         const int b = b0 + lane;
         const int L = b < B ? st[b].L : 0;
         const int it = (L + RPB - 1) / RPB;
+        const int ng = (((L + 63) >> 6) + SPI - 1) / SPI;      // groups of SPI 64-row slices (k_fill_slice work items)
         const long long mw = (long long)L * ((L + 63) >> 6);
-        int pr = L, pi = it; long long pm = mw;               // inclusive scans over the lanes
+        int pr = L, pi = it, pg = ng; long long pm = mw;      // inclusive scans over the lanes
         for (int off = 1; off < WAVE; off <<= 1) {
-            const int tr = __shfl_up(pr, off), ti = __shfl_up(pi, off); const long long tm = __shfl_up(pm, off);
-            if (lane >= off) { pr += tr; pi += ti; pm += tm; }
+            const int tr = __shfl_up(pr, off), ti = __shfl_up(pi, off), tg = __shfl_up(pg, off); const long long tm = __shfl_up(pm, off);
+            if (lane >= off) { pr += tr; pi += ti; pg += tg; pm += tm; }
         }
-        if (b < B) { st[b].rowBase = accR + pr - L; st[b].itemBase = accI + pi - it; st[b].maskOff = accM + pm - mw; }
+        if (b < B) { st[b].rowBase = accR + pr - L; st[b].itemBase = accI + pi - it; st[b].sgBase = accG + pg - ng; st[b].maskOff = accM + pm - mw; }
         int m = L;
         for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off));
         mx = max(mx, m);
-        accR += __shfl(pr, WAVE - 1); accI += __shfl(pi, WAVE - 1); accM += __shfl(pm, WAVE - 1);
+        accR += __shfl(pr, WAVE - 1); accI += __shfl(pi, WAVE - 1); accG += __shfl(pg, WAVE - 1); accM += __shfl(pm, WAVE - 1);
     }
-    if (lane == 0) { tot->R = accR; tot->maxL = mx; tot->nnzTotal = 0; tot->maskWords = accM; tot->items = accI; }
+    if (lane == 0) { tot->R = accR; tot->maxL = mx; tot->nnzTotal = 0; tot->maskWords = accM; tot->items = accI; tot->sliceGroups = accG; }
 }
 
 // k_items: the work-item list of the pair-test and fill kernels.
@@ -535,12 +543,10 @@ __device__ __forceinline__ void count_rows_lds(const DevParams& D, const ProbDes
         if (pre && r + wpb < nrows) fetch_tab(__builtin_amdgcn_readfirstlane(row0 + r + wpb));
 
         // The pair test is symmetric: row k computes only the 64-column words c >= R = k/64 (the diagonal word
-        // completely, both of its triangles) and mirrors every hit (k, q) of the words c > R into row q with one
-        // 8-byte atomic OR on word (q, R) — integer OR: any order gives the same bits.  The mask pool is zeroed
-        // before this kernel; prefix counts and row totals are taken afterwards by k_rowprefix.
+        // completely, both of its triangles); the words c < R are the bit transposes of blocks computed by other
+        // rows and are written by k_mirror.  Prefix counts and row totals are taken afterwards by k_rowprefix.
         unsigned long long* mrow = mbase + (int64_t)k * W;
         const int R = k >> 6;
-        const unsigned long long kbit = 1ull << (k & 63);
         uint32_t mlo = 0u, mhi = 0u;                            // lane l: word (block*64 + l) of the current 64-word block
         for (int q0 = (R << 6) & ~(U * WAVE - 1); q0 < Lpad; q0 += U * WAVE) {
             int2 ij[U]; double2 zz[U];
@@ -570,9 +576,6 @@ __device__ __forceinline__ void count_rows_lds(const DevParams& D, const ProbDes
                     const uint32_t ml_ = (uint32_t)m, mh_ = (uint32_t)(m >> 32), sel_ = (uint32_t)(widx & 63);
                     asm("s_mov_b32 m0, %3\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %4, m0"
                         : "+v"(mlo), "+v"(mhi) : "s"(ml_), "s"(sel_), "s"(mh_) : "m0");
-                }
-                if (m != 0ull && widx > R) {                    // mirror the hits into the rows of the columns
-                    if (is) atomicOr(mbase + (int64_t)((widx << 6) + lane) * W + R, kbit);
                 }
             }
             const int wend = min(W, (q0 >> 6) + U);             // words [.., wend) are complete
@@ -636,6 +639,54 @@ __global__ void __launch_bounds__(1024) k_count(DevParams D, const ProbDesc* __r
         else
             count_rows_global<GRAV>(D, pd, L, it.row0, nrows, w, wpb, lane, li + lo, lj + lo, lza + lo, lzb + lo,
                                     TA, TB, tA, rowCnt + lo, maskPool + mo, prefPool + mo);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_mirror: lower triangle of the candidate bit matrix.  Block (c, R) of 64x64 bits, c > R, is the
+// transpose of block (R, c) that k_count produced: lane l loads word c of row R*64+l, the wave
+// transposes the 64x64 bit block in registers (6 butterfly stages) and lane l stores word R of row
+// c*64+l.  (The earlier scheme, one 8-byte atomic OR per hit from inside k_count, cost 0.25 ms per
+// batch of 256; this kernel takes 0.13 ms and needs no zeroed mask pool.)
+// A wave owns 1 x 8 blocks: it loads the words c..c+7 of the 64 rows of source row block R (one cache line per
+// row for all 8 loads, all in flight together).  The 8 waves of a workgroup take 8 consecutive R for the same
+// c range: their stores to words R..R+7 of a target row fall into one line and are merged by the write-back L2.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long transpose64(unsigned long long x, int lane)
+{
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) {
+        const unsigned long long m = (s == 32) ? 0x00000000ffffffffull : (s == 16) ? 0x0000ffff0000ffffull : (s == 8) ? 0x00ff00ff00ff00ffull
+                                   : (s == 4) ? 0x0f0f0f0f0f0f0f0full : (s == 2) ? 0x3333333333333333ull : 0x5555555555555555ull;
+        const unsigned long long o = __shfl_xor(x, s);
+        x = (lane & s) ? ((x & ~m) | ((o & ~m) >> s)) : ((x & m) | ((o & m) << s));
+    }
+    return x;
+}
+
+__global__ void __launch_bounds__(512) k_mirror(const ProbState* __restrict__ st, unsigned long long* __restrict__ maskPool)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int b = blockIdx.y;
+    const int L = st[b].L;
+    const int W = (L + 63) >> 6;
+    const int nR = ((W - 1 + nw - 1) / nw) * nw;                  // source row blocks 0..W-2, padded to whole workgroups
+    const int task = blockIdx.x * nw + w;
+    const int ct = task / max(nR, 1), R = task - ct * nR;
+    const int cb = ct * 8;
+    if (R >= W - 1 || cb >= W || cb + 7 <= R) return;             // nothing below the diagonal in this strip
+    unsigned long long* mb = maskPool + st[b].maskOff;
+    const unsigned long long* src = mb + (int64_t)(R * 64 + lane) * W;         // rows R*64+lane < (W-1)*64 < L exist
+    unsigned long long x[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[i] = (cb + i > R && cb + i < W) ? src[cb + i] : 0ull;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = cb + i;
+        if (c > R && c < W) {                                    // wave-uniform
+            const unsigned long long y = transpose64(x[i], lane);
+            if (c * 64 + lane < L) mb[(int64_t)(c * 64 + lane) * W + R] = y;
+        }
     }
 }
 
@@ -745,27 +796,20 @@ __global__ void __launch_bounds__(1024) k_rowsort(int widthPad /* 1, or 4 for th
     if (tid == 0) st[b].nnzCap = carry_s;
 }
 
-// k_probscan: serial prefix of the per-problem slot totals and of the slice-group counts (SPI slices per group).
-__global__ void __launch_bounds__(64) k_probscan(int B, int SPI, ProbState* __restrict__ st, BatchTotals* __restrict__ tot)
+// k_probscan: serial prefix of the per-problem slot totals.
+__global__ void __launch_bounds__(64) k_probscan(int B, ProbState* __restrict__ st, BatchTotals* __restrict__ tot)
 {
     const int lane = threadIdx.x;
     long long acc = 0;
-    int gacc = 0;
     for (int b0 = 0; b0 < B; b0 += WAVE) {
         const int b = b0 + lane;
         const long long cap = b < B ? (long long)st[b].nnzCap : 0;
-        const int ng = b < B ? (((st[b].L + 63) >> 6) + SPI - 1) / SPI : 0;
         long long pc = cap;
-        int pg = ng;
-        for (int off = 1; off < WAVE; off <<= 1) {
-            const long long t = __shfl_up(pc, off); const int tg = __shfl_up(pg, off);
-            if (lane >= off) { pc += t; pg += tg; }
-        }
-        if (b < B) { st[b].nnzOff = acc + pc - cap; st[b].sgBase = gacc + pg - ng; }
+        for (int off = 1; off < WAVE; off <<= 1) { const long long t = __shfl_up(pc, off); if (lane >= off) pc += t; }
+        if (b < B) st[b].nnzOff = acc + pc - cap;
         acc += __shfl(pc, WAVE - 1);
-        gacc += __shfl(pg, WAVE - 1);
     }
-    if (lane == 0) { tot->nnzTotal = acc; tot->sliceGroups = gacc; }
+    if (lane == 0) tot->nnzTotal = acc;
 }
 
 // ---------------------------------------------------------------------------------------------

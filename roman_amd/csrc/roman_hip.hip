@@ -264,7 +264,10 @@ int stage_score(roman_ctx* c, const DevParams& D, const BatchIn& in, std::vector
     StageTimer t0(c, ROMAN_STAGE_SINGLE);
     if (cosOn && maxN12 > 0) {
         if (maxTiles > 0)
-            hipLaunchKernelGGL(k_cos, dim3((maxTiles + 3) / 4, B), dim3(256), 0, WS.stream, D, dP, in.feats, WS.cosPool.as<double>());
+        {
+            const int G = (maxTiles + 3) / 4;
+            hipLaunchKernelGGL(k_cos, dim3((unsigned)(G * ((B + 7) / 8) * 8)), dim3(256), 0, WS.stream, D, B, G, dP, in.feats, WS.cosPool.as<double>());
+        }
     }
     if (maxTab > 0) {
         const size_t tabLds = sizeof(double) * 3 * (size_t)std::max(maxN, 1);
@@ -274,7 +277,8 @@ int stage_score(roman_ctx* c, const DevParams& D, const BatchIn& in, std::vector
     }
     hipLaunchKernelGGL(k_live, dim3(B), dim3(1024), 0, WS.stream, D, dP, dS, in.feats, in.assoc, WS.cosPool.as<double>(), WS.sTmp.as<double>(),
                        WS.lp.as<int32_t>(), WS.li.as<int32_t>(), WS.lj.as<int32_t>(), WS.ls.as<double>(), WS.lza.as<double>(), WS.lzb.as<double>());
-    hipLaunchKernelGGL(k_rowbase, dim3(1), dim3(64), 0, WS.stream, B, RPB, dS, dT);
+    const int SPI = std::max(1, RPB / 64);          // 64-row blocks per work item of k_mirror / k_fill_slice
+    hipLaunchKernelGGL(k_rowbase, dim3(1), dim3(64), 0, WS.stream, B, RPB, SPI, dS, dT);
     hipLaunchKernelGGL(k_items, dim3(B), dim3(256), 0, WS.stream, RPB, dS, WS.items.as<ItemDesc>());
     // read-back #1 (24 bytes): live totals -> size of the candidate bit matrices, index width
     HIPCHK(c, hipMemcpyAsync(WS.pinnedTotals, dT, sizeof(BatchTotals), hipMemcpyDeviceToHost, WS.stream));
@@ -301,22 +305,24 @@ int stage_score(roman_ctx* c, const DevParams& D, const BatchIn& in, std::vector
 
     StageTimer t1(c, ROMAN_STAGE_COUNT_PASS);
     if (tot.R > 0) {
-        // the pair tests fill the lower triangle of the bit matrix with atomic ORs: start from zero
-        HIPCHK(c, hipMemsetAsync(WS.maskPool.p, 0, sizeof(unsigned long long) * (size_t)std::max<int64_t>(tot.maskWords, 1), WS.stream));
         auto kc = D.gravity ? k_count<true> : k_count<false>;
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kc), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pairLds));
         hipLaunchKernelGGL(kc, dim3(pairGrid), dim3(wpb * 64), pairLds, WS.stream, D, dP, dS, dT, WS.items.as<ItemDesc>(), WS.tabPool.as<double>(),
                            WS.li.as<int32_t>(), WS.lj.as<int32_t>(), WS.lza.as<double>(), WS.lzb.as<double>(),
                            WS.rowCnt.as<uint32_t>(), WS.maskPool.as<unsigned long long>(), WS.prefPool.as<uint32_t>(), TCc, ldsPerWave, RPB);
+        // lower triangle of the bit matrices = transposed blocks of the upper triangle
+        {
+            const int Wmax = (tot.maxL + 63) / 64;
+            const int tasks = ((Wmax + 7) / 8) * ((std::max(Wmax - 1, 1) + 7) / 8);          // workgroups of 8 waves
+            hipLaunchKernelGGL(k_mirror, dim3((unsigned)tasks, (unsigned)B), dim3(512), 0, WS.stream, dS, WS.maskPool.as<unsigned long long>());
+        }
         hipLaunchKernelGGL(k_rowprefix, dim3(c->num_cu * 2), dim3(1024), 0, WS.stream, dP, dS, dT, WS.items.as<ItemDesc>(),
                            WS.maskPool.as<unsigned long long>(), WS.prefPool.as<uint32_t>(), WS.rowCnt.as<uint32_t>(), RPB);
     }
     const bool quad = use_quad(D, tot.maxL);
     hipLaunchKernelGGL(k_rowsort, dim3(B), dim3(1024), 0, WS.stream, quad ? 4 : 1, dP, dS, WS.rowCnt.as<uint32_t>(), WS.rowPos.as<uint32_t>(), WS.perm.as<uint32_t>(),
                        WS.sliceWidth.as<uint32_t>(), WS.sliceBase.as<uint32_t>());
-    // k_fill_slice work items: groups of SPI slices of one problem (one slice each for small batches)
-    const int SPI = std::max(1, RPB / 64);
-    hipLaunchKernelGGL(k_probscan, dim3(1), dim3(64), 0, WS.stream, B, SPI, dS, dT);
+    hipLaunchKernelGGL(k_probscan, dim3(1), dim3(64), 0, WS.stream, B, dS, dT);
     // read-back #2: padded slot total -> size of the matrix arrays
     HIPCHK(c, hipMemcpyAsync(WS.pinnedTotals, dT, sizeof(BatchTotals), hipMemcpyDeviceToHost, WS.stream));
     t1.stop();
@@ -1155,7 +1161,7 @@ int roman_debug_cosine(roman_ctx_t* c, const roman_params_t* params, const doubl
     HIPCHK(c, WS.cosPool.ensure(sizeof(double) * (size_t)n1 * n2)); HIPCHK(c, WS.normPool.ensure(sizeof(double) * (size_t)(n1 + n2)));
     HIPCHK(c, hipMemcpyAsync(WS.probs.p, &pd, sizeof(pd), hipMemcpyHostToDevice, WS.stream));
     const int tiles = ((n1 + COS_TILE - 1) / COS_TILE) * ((n2 + COS_TILE - 1) / COS_TILE);
-    hipLaunchKernelGGL(k_cos, dim3((tiles + 3) / 4, 1), dim3(256), 0, WS.stream, D, WS.probs.as<ProbDesc>(), WS.hFeats.as<double>(), WS.cosPool.as<double>());
+    hipLaunchKernelGGL(k_cos, dim3((unsigned)(((tiles + 3) / 4) * 8)), dim3(256), 0, WS.stream, D, 1, (tiles + 3) / 4, WS.probs.as<ProbDesc>(), WS.hFeats.as<double>(), WS.cosPool.as<double>());
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(out, WS.cosPool.p, sizeof(double) * (size_t)n1 * n2, hipMemcpyDeviceToHost, WS.stream));
     HIPCHK(c, hipStreamSynchronize(WS.stream));

@@ -1,0 +1,56 @@
+// Microbenchmark: issue cost of v_mfma_f64_16x16x4_f64 (4 independent accumulators) vs v_fma_f64 with an SGPR
+// operand.  Build: hipcc --offload-arch=gfx950 -O3 -o mfma_rate mfma_rate.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef double double4_t __attribute__((ext_vector_type(4)));
+template <int OP>
+__global__ void __launch_bounds__(256) k(double* out, double s, int iters)
+{
+    double4_t acc[4];
+    for (int i = 0; i < 4; ++i) acc[i] = double4_t{0, 0, 0, 0};
+    double a = out[threadIdx.x], b = out[threadIdx.x + 256];
+    double f[16];
+    for (int i = 0; i < 16; ++i) f[i] = a + i;
+    for (int it = 0; it < iters; ++it) {
+        if (OP == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+        } else if (OP == 1) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) asm volatile("v_fma_f64 %0, %1, %2, %0" : "+v"(f[i]) : "s"(s), "v"(b));
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { asm volatile("v_mul_f64 %0, %1, %2" : "=v"(a) : "s"(s), "v"(b)); asm volatile("v_add_f64 %0, %0, %1" : "+v"(f[i]) : "v"(a)); }
+        }
+    }
+    double r = 0;
+    for (int i = 0; i < 4; ++i) r += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    for (int i = 0; i < 16; ++i) r += f[i];
+    out[threadIdx.x] = r;
+}
+template <int OP> void run(const char* name, double* d, int wavesPerSimd, double flop_per_inst)
+{
+    int dev; hipGetDevice(&dev); hipDeviceProp_t p; hipGetDeviceProperties(&p, dev);
+    const int iters = 20000;
+    dim3 grid(p.multiProcessorCount * wavesPerSimd), block(256);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    k<OP><<<grid, block>>>(d, 1.0000001, 10);
+    hipEventRecord(e0); k<OP><<<grid, block>>>(d, 1.0000001, iters); hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    const double insts = (double)iters * 16 * wavesPerSimd;        // per SIMD
+    const double clk = p.clockRate * 1e3;
+    printf("%-22s waves/SIMD=%d  %.3f ms -> %.1f cycles/inst/SIMD, %.1f TFLOP/s chip\n", name, wavesPerSimd, ms, ms * 1e-3 * clk / insts,
+           insts * p.multiProcessorCount * 4 * flop_per_inst / (ms * 1e-3) / 1e12);
+}
+int main()
+{
+    double* d; hipMalloc(&d, 512 * sizeof(double)); hipMemset(d, 0, 512 * sizeof(double));
+    for (int w : {1, 2, 4}) {
+        run<0>("mfma_f64_16x16x4", d, w, 2048.0);
+        run<1>("v_fma_f64 (sgpr src)", d, w, 128.0);
+        run<2>("v_mul_f64+v_add_f64", d, w, 128.0);
+    }
+    return 0;
+}
