@@ -380,29 +380,28 @@ __global__ void __launch_bounds__(1024) k_live(DevParams D, const ProbDesc* __re
 // k_rowbase: serial prefix of the live counts (B is small); also the batch maxima, the offsets of
 // the per-problem candidate bit matrices (L rows of ceil(L/64) words) and the work-item prefix
 // (a work item = a block of up to RPB consecutive live rows of one problem).
-__global__ void __launch_bounds__(64) k_rowbase(int B, int RPB, int SPI, ProbState* __restrict__ st, BatchTotals* __restrict__ tot)
+__global__ void __launch_bounds__(64) k_rowbase(int B, int RPB, ProbState* __restrict__ st, BatchTotals* __restrict__ tot)
 {
     // one wave; lane-strided blocks of 64 problems with a running carry (B is small)
     const int lane = threadIdx.x;
-    int accR = 0, accI = 0, accG = 0, mx = 0; long long accM = 0;
+    int accR = 0, accI = 0, mx = 0; long long accM = 0;
     for (int b0 = 0; b0 < B; b0 += WAVE) {
         const int b = b0 + lane;
         const int L = b < B ? st[b].L : 0;
         const int it = (L + RPB - 1) / RPB;
-        const int ng = (((L + 63) >> 6) + SPI - 1) / SPI;      // groups of SPI 64-row slices (k_fill_slice work items)
         const long long mw = (long long)L * ((L + 63) >> 6);
-        int pr = L, pi = it, pg = ng; long long pm = mw;      // inclusive scans over the lanes
+        int pr = L, pi = it; long long pm = mw;               // inclusive scans over the lanes
         for (int off = 1; off < WAVE; off <<= 1) {
-            const int tr = __shfl_up(pr, off), ti = __shfl_up(pi, off), tg = __shfl_up(pg, off); const long long tm = __shfl_up(pm, off);
-            if (lane >= off) { pr += tr; pi += ti; pg += tg; pm += tm; }
+            const int tr = __shfl_up(pr, off), ti = __shfl_up(pi, off); const long long tm = __shfl_up(pm, off);
+            if (lane >= off) { pr += tr; pi += ti; pm += tm; }
         }
-        if (b < B) { st[b].rowBase = accR + pr - L; st[b].itemBase = accI + pi - it; st[b].sgBase = accG + pg - ng; st[b].maskOff = accM + pm - mw; }
+        if (b < B) { st[b].rowBase = accR + pr - L; st[b].itemBase = accI + pi - it; st[b].maskOff = accM + pm - mw; }
         int m = L;
         for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off));
         mx = max(mx, m);
-        accR += __shfl(pr, WAVE - 1); accI += __shfl(pi, WAVE - 1); accG += __shfl(pg, WAVE - 1); accM += __shfl(pm, WAVE - 1);
+        accR += __shfl(pr, WAVE - 1); accI += __shfl(pi, WAVE - 1); accM += __shfl(pm, WAVE - 1);
     }
-    if (lane == 0) { tot->R = accR; tot->maxL = mx; tot->nnzTotal = 0; tot->maskWords = accM; tot->items = accI; tot->sliceGroups = accG; }
+    if (lane == 0) { tot->R = accR; tot->maxL = mx; tot->nnzTotal = 0; tot->maskWords = accM; tot->items = accI; tot->sliceGroups = 0; }
 }
 
 // k_items: the work-item list of the pair-test and fill kernels.
@@ -796,20 +795,28 @@ __global__ void __launch_bounds__(1024) k_rowsort(int widthPad /* 1, or 4 for th
     if (tid == 0) st[b].nnzCap = carry_s;
 }
 
-// k_probscan: serial prefix of the per-problem slot totals.
-__global__ void __launch_bounds__(64) k_probscan(int B, ProbState* __restrict__ st, BatchTotals* __restrict__ tot)
+// k_probscan: serial prefix of the per-problem slot totals and of the slice-group counts (k_fill_slice work items:
+// groups of SPI consecutive slices of one problem).
+__global__ void __launch_bounds__(64) k_probscan(int B, int SPI, ProbState* __restrict__ st, BatchTotals* __restrict__ tot)
 {
     const int lane = threadIdx.x;
     long long acc = 0;
+    int gacc = 0;
     for (int b0 = 0; b0 < B; b0 += WAVE) {
         const int b = b0 + lane;
         const long long cap = b < B ? (long long)st[b].nnzCap : 0;
+        const int ng = b < B ? (((st[b].L + 63) >> 6) + SPI - 1) / SPI : 0;
         long long pc = cap;
-        for (int off = 1; off < WAVE; off <<= 1) { const long long t = __shfl_up(pc, off); if (lane >= off) pc += t; }
-        if (b < B) st[b].nnzOff = acc + pc - cap;
+        int pg = ng;
+        for (int off = 1; off < WAVE; off <<= 1) {
+            const long long t = __shfl_up(pc, off); const int tg = __shfl_up(pg, off);
+            if (lane >= off) { pc += t; pg += tg; }
+        }
+        if (b < B) { st[b].nnzOff = acc + pc - cap; st[b].sgBase = gacc + pg - ng; }
         acc += __shfl(pc, WAVE - 1);
+        gacc += __shfl(pg, WAVE - 1);
     }
-    if (lane == 0) tot->nnzTotal = acc;
+    if (lane == 0) { tot->nnzTotal = acc; tot->sliceGroups = gacc; }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1011,6 +1018,12 @@ __global__ void __launch_bounds__(1024) k_fill(DevParams D, const ProbDesc* __re
 // at a time.  Slices wider than EC take several passes over their masks.  Work items are groups of
 // SPI consecutive slices of one problem, so the column tile is staged once per group.
 // ---------------------------------------------------------------------------------------------
+#ifdef ROMAN_FILL_TIMING
+#define FMARK(slot) do { const unsigned long long t__ = __builtin_readcyclecounter(); facc[slot] += t__ - flast; flast = t__; } while (0)
+#else
+#define FMARK(slot) do { } while (0)
+#endif
+constexpr int FILLS_MAXSPI = 16;     // slices per work item (group)
 constexpr int FILLS_Q = 128;         // ring capacity per wave (< 64 queued + <= 64 emitted per bit step)
 
 template <bool GRAV>
@@ -1026,8 +1039,12 @@ __global__ void __launch_bounds__(1024) k_fill_slice(DevParams D, int B, const P
                                                      const uint32_t* __restrict__ sliceWidth,
                                                      const uint32_t* __restrict__ sliceBase,
                                                      uint16_t* __restrict__ cols, double* __restrict__ vals,
-                                                     int TC, int EC /* multiple of 4 */, int SPI)
+                                                     int TC, int EC /* multiple of 4 */, int SPI, unsigned long long* fdbg)
 {
+#ifdef ROMAN_FILL_TIMING
+    unsigned long long facc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long flast = __builtin_readcyclecounter();
+#endif
     // LDS: cS[TC] [GRAV: cZa[TC] cZb[TC]] cI[TC] cJ[TC] | image values [EC*64] | image columns [EC*64] | rings | sK[64]
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* cS = reinterpret_cast<double*>(smem);
@@ -1043,7 +1060,7 @@ __global__ void __launch_bounds__(1024) k_fill_slice(DevParams D, int B, const P
     uint32_t* qK = rings + (size_t)w * 3 * FILLS_Q;
     uint32_t* qQ = qK + FILLS_Q;
     uint32_t* qE = qQ + FILLS_Q;
-    uint32_t* sK = rings + (size_t)nw * 3 * FILLS_Q;
+    uint32_t* sKall = rings + (size_t)nw * 3 * FILLS_Q;         // rows of the group's slices: FILLS_MAXSPI * 64 entries
     const int SPW = 64 / nw;                                    // lane slots per wave
     const unsigned long long lt = (1ull << lane) - 1ull;
     const int nGroups = tot->sliceGroups;
@@ -1066,14 +1083,17 @@ __global__ void __launch_bounds__(1024) k_fill_slice(DevParams D, int B, const P
             cI[q] = li[lo + q]; cJ[q] = lj[lo + q]; cS[q] = ls[lo + q];
             if (GRAV) { cZa[q] = lza[lo + q]; cZb[q] = lzb[lo + q]; }
         }
+        for (int x = tid; x < (s_end - s_begin) * 64; x += nt)
+            sKall[x] = (s_begin * 64 + x < L) ? perm[lo + s_begin * 64 + x] : 0xffffffffu;
         uint32_t upper = 0;
+        FMARK(0);
         for (int sl = s_begin; sl < s_end; ++sl) {
             const uint32_t width = sliceWidth[lo + sl];
             const int64_t sb = no + sliceBase[lo + sl];         // first element of the slice (multiple of 256)
+            const uint32_t* sK = sKall + (sl - s_begin) * 64;
             for (uint32_t e0 = 0; e0 < width; e0 += (uint32_t)EC) {
                 const uint32_t ew = min((uint32_t)EC, width - e0);
-                __syncthreads();                                // previous image written out, previous sK consumed
-                if (tid < 64) sK[tid] = (sl * 64 + tid < L) ? perm[lo + sl * 64 + tid] : 0xffffffffu;
+                __syncthreads();                                // previous image written out (first pass: tile and rows staged)
                 {   // inert image: value 0, column = dummy vector element L with the C-flag
                     double2* v2 = reinterpret_cast<double2*>(imgV);
                     for (uint32_t x = tid; x < ew * 32u; x += nt) v2[x] = make_double2(0.0, 0.0);
@@ -1082,9 +1102,11 @@ __global__ void __launch_bounds__(1024) k_fill_slice(DevParams D, int B, const P
                     for (uint32_t x = tid; x < ew * 16u; x += nt) c2[x] = make_uint2(inert, inert);
                 }
                 __syncthreads();
+                FMARK(1);
 
                 uint32_t head = 0, queued = 0;
                 auto evaluate = [&](uint32_t take) {
+                    FMARK(2);
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1097,6 +1119,10 @@ __global__ void __launch_bounds__(1024) k_fill_slice(DevParams D, int B, const P
                         const uint32_t e = qE[s] - e0;
                         const int i = cI[k], j = cJ[k], iq = cI[q], jq = cJ[q];
                         const double a = TA[(int64_t)i * pd.n1 + iq], bb = TB[(int64_t)j * pd.n2 + jq];
+#ifdef ROMAN_FILL_TIMING
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        FMARK(3);
+#endif
                         double c;
                         if (GRAV) {
                             const double ch = fabs(a - bb);
@@ -1116,9 +1142,11 @@ __global__ void __launch_bounds__(1024) k_fill_slice(DevParams D, int B, const P
                         }
                     }
                     head = (head + take) & (FILLS_Q - 1); queued -= take;
+                    FMARK(4);
                 };
 
-                // this wave's lane slots [w*SPW, w*SPW + SPW): one flat stream over their mask words; the words of
+                // this wave's lane slots w, w+nw, w+2nw, .. (rows are sorted by length: interleaving balances the waves):
+                // one flat stream over their mask words; the words of
                 // the next block of 64 are fetched while the current block is expanded and evaluated
                 const int nwords = SPW * W;
                 unsigned long long m_next = 0ull; uint32_t e_next = 0u;
@@ -1126,7 +1154,7 @@ __global__ void __launch_bounds__(1024) k_fill_slice(DevParams D, int B, const P
                     m_next = 0ull; e_next = 0u;
                     if (x < nwords) {
                         const int r = x / W, word = x - r * W;
-                        const uint32_t k = sK[w * SPW + r];
+                        const uint32_t k = sK[r * nw + w];
                         if (k != 0xffffffffu) {
                             m_next = maskPool[mo + (int64_t)k * W + word];
                             e_next = prefPool[mo + (int64_t)k * W + word];
@@ -1138,7 +1166,7 @@ __global__ void __launch_bounds__(1024) k_fill_slice(DevParams D, int B, const P
                     const int x = x0 + lane;
                     unsigned long long m = m_next; uint32_t e = e_next;
                     fetch(x + WAVE);
-                    const uint32_t slot_ = (uint32_t)(w * SPW + min(x / W, SPW - 1));
+                    const uint32_t slot_ = (uint32_t)(min(x / W, SPW - 1) * nw + w);
                     const uint32_t ks = (sK[slot_] & 0xffffu) | (slot_ << 16);
                     const uint32_t qb = (uint32_t)((x < nwords) ? (x - (x / W) * W) : 0) << 6;
                     if (e >= e0 + ew) m = 0ull;                 // the whole word lies behind this pass
@@ -1163,7 +1191,9 @@ __global__ void __launch_bounds__(1024) k_fill_slice(DevParams D, int B, const P
                     }
                 }
                 if (queued > 0u) evaluate(queued);
+                FMARK(2);
                 __syncthreads();
+                FMARK(5);
                 {   // image -> HBM: entries [e0, e0+ew) of the slice are one contiguous block in both arrays
                     const double2* v2 = reinterpret_cast<const double2*>(imgV);
                     double2* gv = reinterpret_cast<double2*>(vals + sb + (int64_t)e0 * 64);
@@ -1172,11 +1202,16 @@ __global__ void __launch_bounds__(1024) k_fill_slice(DevParams D, int B, const P
                     uint2* gc = reinterpret_cast<uint2*>(cols + sb + (int64_t)e0 * 64);
                     for (uint32_t x = tid; x < ew * 16u; x += nt) gc[x] = c2[x];
                 }
+                FMARK(6);
             }
         }
         for (int off = 32; off > 0; off >>= 1) upper += __shfl_xor(upper, off);
         if (lane == 0 && upper) atomicAdd(&st[b].nnzUpper, (unsigned long long)upper);
     }
+#ifdef ROMAN_FILL_TIMING
+    FMARK(7);
+    if (lane == 0 && fdbg) for (int t_ = 0; t_ < 8; ++t_) atomicAdd(&fdbg[t_], facc[t_]);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------

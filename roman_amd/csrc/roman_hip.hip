@@ -277,8 +277,7 @@ int stage_score(roman_ctx* c, const DevParams& D, const BatchIn& in, std::vector
     }
     hipLaunchKernelGGL(k_live, dim3(B), dim3(1024), 0, WS.stream, D, dP, dS, in.feats, in.assoc, WS.cosPool.as<double>(), WS.sTmp.as<double>(),
                        WS.lp.as<int32_t>(), WS.li.as<int32_t>(), WS.lj.as<int32_t>(), WS.ls.as<double>(), WS.lza.as<double>(), WS.lzb.as<double>());
-    const int SPI = std::max(1, RPB / 64);          // 64-row blocks per work item of k_mirror / k_fill_slice
-    hipLaunchKernelGGL(k_rowbase, dim3(1), dim3(64), 0, WS.stream, B, RPB, SPI, dS, dT);
+    hipLaunchKernelGGL(k_rowbase, dim3(1), dim3(64), 0, WS.stream, B, RPB, dS, dT);
     hipLaunchKernelGGL(k_items, dim3(B), dim3(256), 0, WS.stream, RPB, dS, WS.items.as<ItemDesc>());
     // read-back #1 (24 bytes): live totals -> size of the candidate bit matrices, index width
     HIPCHK(c, hipMemcpyAsync(WS.pinnedTotals, dT, sizeof(BatchTotals), hipMemcpyDeviceToHost, WS.stream));
@@ -322,7 +321,9 @@ int stage_score(roman_ctx* c, const DevParams& D, const BatchIn& in, std::vector
     const bool quad = use_quad(D, tot.maxL);
     hipLaunchKernelGGL(k_rowsort, dim3(B), dim3(1024), 0, WS.stream, quad ? 4 : 1, dP, dS, WS.rowCnt.as<uint32_t>(), WS.rowPos.as<uint32_t>(), WS.perm.as<uint32_t>(),
                        WS.sliceWidth.as<uint32_t>(), WS.sliceBase.as<uint32_t>());
-    hipLaunchKernelGGL(k_probscan, dim3(1), dim3(64), 0, WS.stream, B, dS, dT);
+    // k_fill_slice work items: groups of SPI consecutive slices of one problem, about 3 per CU for the whole batch
+    const int SPI = (int)std::min<int64_t>(FILLS_MAXSPI, std::max<int64_t>(1, ((int64_t)tot.R / 64 + B + 3 * c->num_cu - 1) / (3 * (int64_t)c->num_cu)));
+    hipLaunchKernelGGL(k_probscan, dim3(1), dim3(64), 0, WS.stream, B, SPI, dS, dT);
     // read-back #2: padded slot total -> size of the matrix arrays
     HIPCHK(c, hipMemcpyAsync(WS.pinnedTotals, dT, sizeof(BatchTotals), hipMemcpyDeviceToHost, WS.stream));
     t1.stop();
@@ -339,18 +340,37 @@ int stage_score(roman_ctx* c, const DevParams& D, const BatchIn& in, std::vector
         // slice-image fill: column tile + one slice image (640 bytes per entry column) + 16 candidate rings
         const int colBytesF = D.gravity ? 32 : 16;
         const int TCs = (std::max(tot.maxL, 1) + 63) & ~63;
-        const size_t fixedLds = (size_t)TCs * colBytesF + (size_t)16 * 3 * FILLS_Q * sizeof(uint32_t) + 64 * sizeof(uint32_t);
+        const size_t fixedLds = (size_t)TCs * colBytesF + (size_t)16 * 3 * FILLS_Q * sizeof(uint32_t) + (size_t)FILLS_MAXSPI * 64 * sizeof(uint32_t);
         if (fixedLds + 640 * 8 <= c->lds_max) {
             const int EC = (int)std::min<size_t>((c->lds_max - fixedLds) / 640, 4096) & ~3;
             const size_t sliceLds = fixedLds + (size_t)EC * 640;
             auto kf = D.gravity ? k_fill_slice<true> : k_fill_slice<false>;
+            unsigned long long* fdbg = nullptr;
+#ifdef ROMAN_FILL_TIMING
+            HIPCHK(c, WS.hAux3.ensure(sizeof(unsigned long long) * 8));
+            HIPCHK(c, hipMemsetAsync(WS.hAux3.p, 0, sizeof(unsigned long long) * 8, WS.stream));
+            fdbg = WS.hAux3.as<unsigned long long>();
+#endif
             HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sliceLds));
             hipLaunchKernelGGL(kf, dim3(std::min<int64_t>(c->num_cu, std::max<int64_t>(tot.sliceGroups, 1))), dim3(1024), sliceLds, WS.stream,
                                D, B, dP, dS, dT, WS.tabPool.as<double>(),
                                WS.li.as<int32_t>(), WS.lj.as<int32_t>(), WS.ls.as<double>(), WS.lza.as<double>(), WS.lzb.as<double>(),
                                WS.maskPool.as<unsigned long long>(), WS.prefPool.as<uint32_t>(), WS.perm.as<uint32_t>(),
-                               WS.sliceWidth.as<uint32_t>(), WS.sliceBase.as<uint32_t>(), WS.cols.as<uint16_t>(), WS.vals.as<double>(), TCs, EC, SPI);
+                               WS.sliceWidth.as<uint32_t>(), WS.sliceBase.as<uint32_t>(), WS.cols.as<uint16_t>(), WS.vals.as<double>(), TCs, EC, SPI, fdbg);
             sliceFill = true;
+#ifdef ROMAN_FILL_TIMING
+            {
+                unsigned long long h[8];
+                HIPCHK(c, hipMemcpyAsync(h, fdbg, sizeof(h), hipMemcpyDeviceToHost, WS.stream));
+                HIPCHK(c, hipStreamSynchronize(WS.stream));
+                const double nwaves = 16.0 * std::min<int64_t>(c->num_cu, std::max<int64_t>(tot.sliceGroups, 1));
+                const char* nm[8] = {"stage", "init+barrier", "bitsteps", "gather-wait", "math+store", "end-barrier", "write-out", "tail"};
+                fprintf(stderr, "[fill timing] B=%d cycles/wave:", B);
+                double tt = 0; for (int t = 0; t < 8; ++t) tt += (double)h[t] / nwaves;
+                for (int t = 0; t < 8; ++t) fprintf(stderr, " %s %.0f", nm[t], (double)h[t] / nwaves);
+                fprintf(stderr, " total %.0f\n", tt);
+            }
+#endif
         }
     }
     if (tot.R > 0 && !sliceFill) {
