@@ -34,7 +34,7 @@ struct DevParams {
     int32_t single;     // invariant has per-association scores
     int32_t gravity;    // ROMAN invariant && gravity_guided
     int32_t F;          // features per object
-    int32_t pad;
+    int32_t max_compact; // streaming solver: column compactions allowed per problem (speed only; set per launch)
 };
 
 struct ProbDesc {
@@ -1023,8 +1023,26 @@ __global__ void __launch_bounds__(1024) k_fill(DevParams D, const ProbDesc* __re
 #else
 #define FMARK(slot) do { } while (0)
 #endif
+// inclusive scans over the 64 lanes of a wave with DPP row shifts / row broadcasts (no LDS traffic)
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROWMASK, 0xf, false); }
+__device__ __forceinline__ uint32_t wave_incl_add(uint32_t v)
+{
+    v += dpp_u32<0x111, 0xf>(v); v += dpp_u32<0x112, 0xf>(v); v += dpp_u32<0x114, 0xf>(v); v += dpp_u32<0x118, 0xf>(v);   // row_shr 1,2,4,8
+    v += dpp_u32<0x142, 0xa>(v);          // row_bcast:15 -> rows 1,3
+    v += dpp_u32<0x143, 0xc>(v);          // row_bcast:31 -> rows 2,3
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_incl_max(uint32_t v)
+{
+    v = max(v, dpp_u32<0x111, 0xf>(v)); v = max(v, dpp_u32<0x112, 0xf>(v)); v = max(v, dpp_u32<0x114, 0xf>(v)); v = max(v, dpp_u32<0x118, 0xf>(v));
+    v = max(v, dpp_u32<0x142, 0xa>(v));
+    v = max(v, dpp_u32<0x143, 0xc>(v));
+    return v;
+}
+
 constexpr int FILLS_MAXSPI = 16;     // slices per work item (group)
-constexpr int FILLS_Q = 128;         // ring capacity per wave (< 64 queued + <= 64 emitted per bit step)
+constexpr int FILLS_NBLK = 3;        // blocks of 64 mask words per wave and slice: (64/16 slots) * ceil(L/64) <= 192 words
 
 template <bool GRAV>
 __global__ void __launch_bounds__(1024) k_fill_slice(DevParams D, int B, const ProbDesc* __restrict__ probs,
@@ -1045,7 +1063,7 @@ __global__ void __launch_bounds__(1024) k_fill_slice(DevParams D, int B, const P
     unsigned long long facc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long flast = __builtin_readcyclecounter();
 #endif
-    // LDS: cS[TC] [GRAV: cZa[TC] cZb[TC]] cI[TC] cJ[TC] | image values [EC*64] | image columns [EC*64] | rings | sK[64]
+    // LDS: cS[TC] [GRAV: cZa[TC] cZb[TC]] cI[TC] cJ[TC] | image values [EC*64] | image columns [EC*64] | owner lines | rows
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* cS = reinterpret_cast<double*>(smem);
     double* cZa = cS + TC;
@@ -1057,14 +1075,16 @@ __global__ void __launch_bounds__(1024) k_fill_slice(DevParams D, int B, const P
     uint32_t* rings = reinterpret_cast<uint32_t*>(imgC + (size_t)EC * 64);
     const int tid = threadIdx.x, nt = blockDim.x;
     const int lane = tid & 63, w = tid >> 6, nw = nt >> 6;
-    uint32_t* qK = rings + (size_t)w * 3 * FILLS_Q;
-    uint32_t* qQ = qK + FILLS_Q;
-    uint32_t* qE = qQ + FILLS_Q;
-    uint32_t* sKall = rings + (size_t)nw * 3 * FILLS_Q;         // rows of the group's slices: FILLS_MAXSPI * 64 entries
+    uint32_t* ownL = rings + (size_t)w * WAVE;                  // this wave's owner line (64 entries)
+    uint32_t* sKall = rings + (size_t)nw * WAVE;                // rows of the group's slices: FILLS_MAXSPI * 64 entries
     const int SPW = 64 / nw;                                    // lane slots per wave
-    const unsigned long long lt = (1ull << lane) - 1ull;
     const int nGroups = tot->sliceGroups;
-    for (int t = blockIdx.x; t < nGroups; t += gridDim.x) {
+    // XCD-aware order: workgroups are dealt to the 8 XCDs round-robin by id, so XCD x takes the CONTIGUOUS range
+    // [x*Gx, (x+1)*Gx) of groups — the groups of one problem (which share its tables) run on one L2.
+    const int Gx = (nGroups + 7) >> 3;
+    for (int sIdx = blockIdx.x; (sIdx >> 3) < Gx; sIdx += gridDim.x) {
+        const int t = (sIdx & 7) * Gx + (sIdx >> 3);
+        if (t >= nGroups) continue;
         int b = 0;                                              // last problem with sgBase <= t and at least one group
         {
             int lo_ = 0, hi_ = B - 1;
@@ -1104,19 +1124,85 @@ __global__ void __launch_bounds__(1024) k_fill_slice(DevParams D, int B, const P
                 __syncthreads();
                 FMARK(1);
 
-                uint32_t head = 0, queued = 0;
-                auto evaluate = [&](uint32_t take) {
-                    FMARK(2);
+                // ---- this wave's lane slots w, w+nw, w+2nw, .. (rows are sorted by length: interleaving balances the
+                // waves).  Their mask words (at most FILLS_NBLK blocks of 64, one word per lane) are expanded DENSELY:
+                // with c = popcount per word and its exclusive prefix over the wave's words, candidate number o is
+                // bit (o - prefix[l]) of the word l with prefix[l] <= o < prefix[l] + c[l].  Every round produces 64
+                // candidates at once: the owner words are scattered into a 64-entry LDS line at their first
+                // candidate's position and spread by a max-scan, the word is fetched with ds_bpermute and the bit
+                // found by a 6-step rank select.  (One bit per lane and step through a ring took 3x the cycles.)
+                const int nwords = SPW * W;
+                unsigned long long mB[FILLS_NBLK]; uint32_t iA[FILLS_NBLK], iB[FILLS_NBLK];
+                uint32_t Ttot = 0;
+#pragma unroll
+                for (int jb = 0; jb < FILLS_NBLK; ++jb) {
+                    const int x = jb * WAVE + lane;
+                    unsigned long long m = 0ull; uint32_t ef = 0u, ka = 0u;
+                    if (x < nwords) {
+                        const int r = x / W, word = x - r * W;
+                        const uint32_t slot = (uint32_t)(r * nw + w);
+                        const uint32_t k = sK[slot];
+                        if (k != 0xffffffffu) {
+                            m = maskPool[mo + (int64_t)k * W + word];
+                            ef = prefPool[mo + (int64_t)k * W + word];
+                            ka = k | (slot << 16) | ((uint32_t)word << 22);
+                        }
+                    }
+                    uint32_t c = (uint32_t)__popcll(m);
+                    if (ef >= e0 + ew || ef + c <= e0) { m = 0ull; c = 0u; }     // no entry of this word in this pass
+                    const uint32_t incl = wave_incl_add(c);
+                    mB[jb] = m; iA[jb] = ka; iB[jb] = ((Ttot + incl - c) << 16) | ef;
+                    Ttot += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                }
+                FMARK(2);
+                for (uint32_t base = 0; base < Ttot; base += WAVE) {
+                    ownL[lane] = 0u;
+#pragma unroll
+                    for (int jb = 0; jb < FILLS_NBLK; ++jb) {
+                        const int pos = (int)(iB[jb] >> 16) - (int)base;
+                        if (mB[jb] != 0ull && pos < WAVE && pos + (int)__popcll(mB[jb]) > 0) ownL[max(pos, 0)] = (uint32_t)(jb * WAVE + lane + 1);
+                    }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    if ((uint32_t)lane < take) {
-                        const uint32_t s = (head + lane) & (FILLS_Q - 1);
-                        const uint32_t ks = qK[s];
-                        const int k = (int)(ks & 0xffffu);
-                        const uint32_t slot = ks >> 16;
-                        const int q = (int)qQ[s];
-                        const uint32_t e = qE[s] - e0;
+                    const uint32_t own = wave_incl_max(ownL[lane]);       // >= 1 wherever base + lane < Ttot
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();                      // ownL is rewritten by the next round
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    const uint32_t id = (own - 1u) & (FILLS_NBLK * WAVE - 1 < 255 ? 255u : 511u);
+                    const int src = (int)((id & 63u) << 2);
+                    const uint32_t jsel = id >> 6;
+                    uint32_t mlo = 0u, mhi = 0u, ka = 0u, kb = 0u;
+#pragma unroll
+                    for (int jb = 0; jb < FILLS_NBLK; ++jb) {
+                        if (jb * WAVE >= nwords) break;                   // wave-uniform
+                        const uint32_t t0 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)(uint32_t)mB[jb]);
+                        const uint32_t t1 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)(uint32_t)(mB[jb] >> 32));
+                        const uint32_t t2 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)iA[jb]);
+                        const uint32_t t3 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)iB[jb]);
+                        if (jsel == (uint32_t)jb) { mlo = t0; mhi = t1; ka = t2; kb = t3; }
+                    }
+                    uint32_t n = base + (uint32_t)lane - (kb >> 16);      // rank of this candidate within its word
+                    const uint32_t e = (kb & 0xffffu) + n;
+                    const bool valid = base + (uint32_t)lane < Ttot && own != 0u && e >= e0 && e < e0 + ew;
+                    uint32_t bit;
+                    {   // position of the n-th set bit of (mhi:mlo)
+                        uint32_t t = (uint32_t)__popc(mlo);
+                        bool up = n >= t;
+                        uint32_t wv = up ? mhi : mlo; n -= up ? t : 0u; bit = up ? 32u : 0u;
+#pragma unroll
+                        for (int sft = 16; sft > 0; sft >>= 1) {
+                            t = (uint32_t)__popc(wv & ((1u << sft) - 1u));
+                            up = n >= t;
+                            wv = up ? (wv >> sft) : wv; n -= up ? t : 0u; bit += up ? (uint32_t)sft : 0u;
+                        }
+                    }
+                    FMARK(2);
+                    if (valid) {
+                        const int k = (int)(ka & 0xffffu);
+                        const uint32_t slot = (ka >> 16) & 63u;
+                        const int q = (int)(((ka >> 22) << 6) + bit);
+                        const uint32_t er = e - e0;
                         const int i = cI[k], j = cJ[k], iq = cI[q], jq = cJ[q];
                         const double a = TA[(int64_t)i * pd.n1 + iq], bb = TB[(int64_t)j * pd.n2 + jq];
 #ifdef ROMAN_FILL_TIMING
@@ -1136,61 +1222,13 @@ __global__ void __launch_bounds__(1024) k_fill_slice(DevParams D, int B, const P
                         const double sa = exp(((-0.5 * c) * c) / D.sig2);
                         const double v = fuse_pair(D, sa, cS[k], cS[q]);
                         if (v > D.p.affinityeps) {              // otherwise the slot stays inert: neither in M nor in C
-                            imgC[(e >> 2) * 256u + slot * 4u + (e & 3u)] = (uint16_t)q;
-                            imgV[(e >> 1) * 128u + slot * 2u + (e & 1u)] = v;
+                            imgC[(er >> 2) * 256u + slot * 4u + (er & 3u)] = (uint16_t)q;
+                            imgV[(er >> 1) * 128u + slot * 2u + (er & 1u)] = v;
                             upper += (q > k) ? 1u : 0u;
                         }
                     }
-                    head = (head + take) & (FILLS_Q - 1); queued -= take;
                     FMARK(4);
-                };
-
-                // this wave's lane slots w, w+nw, w+2nw, .. (rows are sorted by length: interleaving balances the waves):
-                // one flat stream over their mask words; the words of
-                // the next block of 64 are fetched while the current block is expanded and evaluated
-                const int nwords = SPW * W;
-                unsigned long long m_next = 0ull; uint32_t e_next = 0u;
-                auto fetch = [&](int x) {
-                    m_next = 0ull; e_next = 0u;
-                    if (x < nwords) {
-                        const int r = x / W, word = x - r * W;
-                        const uint32_t k = sK[r * nw + w];
-                        if (k != 0xffffffffu) {
-                            m_next = maskPool[mo + (int64_t)k * W + word];
-                            e_next = prefPool[mo + (int64_t)k * W + word];
-                        }
-                    }
-                };
-                fetch(lane);
-                for (int x0 = 0; x0 < nwords; x0 += WAVE) {
-                    const int x = x0 + lane;
-                    unsigned long long m = m_next; uint32_t e = e_next;
-                    fetch(x + WAVE);
-                    const uint32_t slot_ = (uint32_t)(min(x / W, SPW - 1) * nw + w);
-                    const uint32_t ks = (sK[slot_] & 0xffffu) | (slot_ << 16);
-                    const uint32_t qb = (uint32_t)((x < nwords) ? (x - (x / W) * W) : 0) << 6;
-                    if (e >= e0 + ew) m = 0ull;                 // the whole word lies behind this pass
-                    for (;;) {                                  // bit steps
-                        const bool has = m != 0ull;
-                        if (__ballot(has) == 0ull) break;
-                        bool push = false; int bit = 0;
-                        if (has) {
-                            bit = __builtin_ctzll(m);
-                            m &= m - 1ull;
-                            push = e >= e0 && e < e0 + ew;
-                            if (e + 1u >= e0 + ew) m = 0ull;    // the rest of the word belongs to a later pass
-                        }
-                        const unsigned long long act = __ballot(push);
-                        if (push) {
-                            const uint32_t s = (head + queued + (uint32_t)__popcll(act & lt)) & (FILLS_Q - 1);
-                            qK[s] = ks; qQ[s] = qb + (uint32_t)bit; qE[s] = e;
-                        }
-                        if (has) ++e;
-                        queued += (uint32_t)__popcll(act);
-                        while (queued >= 64u) evaluate(64u);
-                    }
                 }
-                if (queued > 0u) evaluate(queued);
                 FMARK(2);
                 __syncthreads();
                 FMARK(5);
@@ -1969,7 +2007,7 @@ __device__ void solve_stream(const DevParams& D, int b, const ProbDesc& pd, Prob
     if (tid == 0) { xU[L] = 0.0; xUn[L] = 0.0; }
 
     bool hasMid = false, hasSmall = false;
-    int nKmid = L, nKsmall = L, calm = 0;
+    int nKmid = L, nKsmall = L, calm = 0, ncompact = 0;
     int lvMid = 1, lvSmall = 2, lvSpare = 3;
     // per level: the balanced quad range of every wave and the slice its range starts in (cumQ[lvl] must be final)
     auto index_level = [&](int lvl) {
@@ -2253,7 +2291,10 @@ __device__ void solve_stream(const DevParams& D, int b, const ProbDesc& pd, Prob
                 if (!validMid) { if (calm >= 2 && 2 * ns <= L) { src = 0; dst = lvMid; asMid = true; } }
                 else if (validSmall) { if (2 * ns <= nKsmall) { src = lvSmall; dst = lvSpare; } }
                 else if (2 * ns <= nKmid) { src = lvMid; dst = lvSmall; }
-                if (src >= 0) {
+                // budget: a third and later copy never paid for itself in the passes that were left (measured: the
+                // slowest problems of a batch did 5-6 compactions; capping at 2 cut the kernel from 2.2 to 1.9 ms)
+                if (src >= 0 && ncompact < D.max_compact) {
+                    ++ncompact;
                     compact(xU, src, dst, asMid, ns);
                     if (src == lvSmall) { const int t = lvSmall; lvSmall = lvSpare; lvSpare = t; }
                 }

@@ -340,8 +340,8 @@ int stage_score(roman_ctx* c, const DevParams& D, const BatchIn& in, std::vector
         // slice-image fill: column tile + one slice image (640 bytes per entry column) + 16 candidate rings
         const int colBytesF = D.gravity ? 32 : 16;
         const int TCs = (std::max(tot.maxL, 1) + 63) & ~63;
-        const size_t fixedLds = (size_t)TCs * colBytesF + (size_t)16 * 3 * FILLS_Q * sizeof(uint32_t) + (size_t)FILLS_MAXSPI * 64 * sizeof(uint32_t);
-        if (fixedLds + 640 * 8 <= c->lds_max) {
+        const size_t fixedLds = (size_t)TCs * colBytesF + (size_t)16 * 64 * sizeof(uint32_t) + (size_t)FILLS_MAXSPI * 64 * sizeof(uint32_t);
+        if (fixedLds + 640 * 8 <= c->lds_max && ((tot.maxL + 63) / 64) * 4 <= FILLS_NBLK * 64) {
             const int EC = (int)std::min<size_t>((c->lds_max - fixedLds) / 640, 4096) & ~3;
             const size_t sliceLds = fixedLds + (size_t)EC * 640;
             auto kf = D.gravity ? k_fill_slice<true> : k_fill_slice<false>;
@@ -352,7 +352,7 @@ int stage_score(roman_ctx* c, const DevParams& D, const BatchIn& in, std::vector
             fdbg = WS.hAux3.as<unsigned long long>();
 #endif
             HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sliceLds));
-            hipLaunchKernelGGL(kf, dim3(std::min<int64_t>(c->num_cu, std::max<int64_t>(tot.sliceGroups, 1))), dim3(1024), sliceLds, WS.stream,
+            hipLaunchKernelGGL(kf, dim3((unsigned)std::min<int64_t>(c->num_cu & ~7, (std::max<int64_t>(tot.sliceGroups, 1) + 7) / 8 * 8)), dim3(1024), sliceLds, WS.stream,
                                D, B, dP, dS, dT, WS.tabPool.as<double>(),
                                WS.li.as<int32_t>(), WS.lj.as<int32_t>(), WS.ls.as<double>(), WS.lza.as<double>(), WS.lzb.as<double>(),
                                WS.maskPool.as<unsigned long long>(), WS.prefPool.as<uint32_t>(), WS.perm.as<uint32_t>(),
@@ -401,11 +401,20 @@ int stage_score(roman_ctx* c, const DevParams& D, const BatchIn& in, std::vector
 
 // Stage B: solver + rounding + pose on the CSR held by the context.  `feats` may be NULL (dense
 // matrix problems have no points: the pose is skipped).
-int stage_solve(roman_ctx* c, const DevParams& D, int B, const double* feats, const int32_t* assoc,
+int stage_solve(roman_ctx* c, const DevParams& Din, int B, const double* feats, const int32_t* assoc,
                 const double* u0, const BatchTotals& tot, bool idx16, bool hascz, int32_t kmax,
                 int32_t* assoc_out, int32_t* n_assoc_out, double* T_out, int32_t* status_out,
                 roman_stats_t* stats_out)
 {
+    DevParams D = Din;
+    // Column compaction pays when the SpMV passes compete for HBM (many problems in flight), and then only twice
+    // per problem; a lone problem streams its matrix from L2/MALL faster than it can be copied (p50 of a single
+    // pair: 1.00 ms with compaction, 0.89 ms without).  ROMAN_MAX_COMPACT overrides the budget (tuning only:
+    // every level pass is exact, the results do not depend on it).
+    {
+        static const char* env = getenv("ROMAN_MAX_COMPACT");
+        D.max_compact = env ? atoi(env) : ((B >= c->num_cu / 4) ? 2 : 0);
+    }
     const size_t R1 = (size_t)std::max(tot.R, 1);
     HIPCHK(c, WS.vMu.ensure(sizeof(double) * R1)); HIPCHK(c, WS.vCu.ensure(sizeof(double) * R1));
     HIPCHK(c, WS.vMun.ensure(sizeof(double) * R1)); HIPCHK(c, WS.vCun.ensure(sizeof(double) * R1));
