@@ -482,71 +482,85 @@ __device__ __forceinline__ void count_rows_global(const DevParams& D, const Prob
     }
 }
 
-// Fast sweep: columns in LDS as {8*i_q, 8*(n1+1+j_q)} byte offsets into the wave's table slice (+ the
-// two z coordinates), padded to a multiple of 256 columns with a sentinel whose table entry is NaN
-// (fails every test), so the inner loop has no bounds logic at all.  Per 64 tests: 2 coalesced LDS
-// reads, 2 LDS gathers, 12 f64 VALU ops, 2 address adds, 2 v_writelane.
-template <bool GRAV>
+// Fast sweep: columns in LDS as {8*i_q, 8*(n1+1+j_q)} byte offsets into a table slice (+ the two z
+// coordinates), padded to a multiple of 256 columns with a sentinel whose table entry is NaN (fails every
+// test), so the inner loop has no bounds logic at all.  A wave sweeps NR ADJACENT rows at once (NR = 2 when
+// the table slices fit): the column data is read once for both, the two rows' instruction streams are
+// independent (the kernel is bound by LDS/VALU/scalar latency, not by any one pipe), and the loop overhead
+// is shared.  Per 64 columns and row: 2 LDS gathers, 12 f64 VALU ops, 2 address adds, 2 v_writelane.
+template <bool GRAV, int NR>
 __device__ __forceinline__ void count_rows_lds(const DevParams& D, const ProbDesc& pd, int L, int row0, int nrows,
                                                int w, int wpb, int lane,
                                                const int2* cIJ, const double2* cZZ,
-                                               const int32_t* __restrict__ gI, const int32_t* __restrict__ gJ,
-                                               const double* __restrict__ gZa, const double* __restrict__ gZb,
-                                               const double* __restrict__ TA, const double* __restrict__ TB, double* tA,
-                                               uint32_t* __restrict__ rowCnt, unsigned long long* __restrict__ mbase,
-                                               uint32_t* __restrict__ pbase)
+                                               const double* __restrict__ TA, const double* __restrict__ TB,
+                                               double* tA /* NR slices of ldsPerRow doubles */, int ldsPerRow,
+                                               unsigned long long* __restrict__ mbase)
 {
     const int W = (L + 63) >> 6;
-    double* tB = tA + pd.n1 + 1;
     const char* tbytes = reinterpret_cast<const char*>(tA);
+    const int sliceBytes = ldsPerRow * 8;
     constexpr int U = 4;                                        // column chunks per step
     const int Lpad = (L + U * WAVE - 1) & ~(U * WAVE - 1);
-    // Rows are columns too: their objects and z come from the LDS column tile.  The two table rows of the NEXT
-    // row are fetched into registers while the current row is swept (maps of up to 256 objects; larger ones
+    // Rows are columns too: their objects and z come from the LDS column tile.  The table rows of the NEXT
+    // rows are fetched into registers while the current ones are swept (maps of up to 256 objects; larger ones
     // load directly), so no global-memory latency sits between two sweeps.
     constexpr int TR = 4;
     const bool pre = pd.n1 <= TR * WAVE && pd.n2 <= TR * WAVE;
-    double ra[TR], rb[TR];
-    auto fetch_tab = [&](int k_) {
-        const int i_ = cIJ[k_].x >> 3, j_ = (cIJ[k_].y >> 3) - (pd.n1 + 1);
-        const double* gA_ = TA + (int64_t)i_ * pd.n1;
-        const double* gB_ = TB + (int64_t)j_ * pd.n2;
+    double ra[NR][TR], rb[NR][TR];
+    auto fetch_tab = [&](int r_) {
 #pragma unroll
-        for (int m_ = 0; m_ < TR; ++m_) {
-            ra[m_] = (lane + m_ * WAVE < pd.n1) ? gA_[lane + m_ * WAVE] : 0.0;
-            rb[m_] = (lane + m_ * WAVE < pd.n2) ? gB_[lane + m_ * WAVE] : 0.0;
-        }
-    };
-    if (pre && w < nrows) fetch_tab(__builtin_amdgcn_readfirstlane(row0 + w));
-    for (int r = w; r < nrows; r += wpb) {
-        const int k = __builtin_amdgcn_readfirstlane(row0 + r);      // wave-uniform: loop bounds and lane selects in SGPRs
-        const double zi = GRAV ? cZZ[k].x : 0.0, zj = GRAV ? cZZ[k].y : 0.0;
-        // stage the two table rows (wave-private slice; LDS ops of one wave execute in order)
-        if (pre) {
+        for (int x = 0; x < NR; ++x) {
+            const int k_ = row0 + min(r_ + x, nrows - 1);
+            const int i_ = cIJ[k_].x >> 3, j_ = (cIJ[k_].y >> 3) - (pd.n1 + 1);
+            const double* gA_ = TA + (int64_t)i_ * pd.n1;
+            const double* gB_ = TB + (int64_t)j_ * pd.n2;
 #pragma unroll
             for (int m_ = 0; m_ < TR; ++m_) {
-                if (lane + m_ * WAVE < pd.n1) tA[lane + m_ * WAVE] = ra[m_];
-                if (lane + m_ * WAVE < pd.n2) tB[lane + m_ * WAVE] = rb[m_];
+                ra[x][m_] = (lane + m_ * WAVE < pd.n1) ? gA_[lane + m_ * WAVE] : 0.0;
+                rb[x][m_] = (lane + m_ * WAVE < pd.n2) ? gB_[lane + m_ * WAVE] : 0.0;
             }
-        } else {
-            const int i = cIJ[k].x >> 3, j = (cIJ[k].y >> 3) - (pd.n1 + 1);
-            const double* gA = TA + (int64_t)i * pd.n1;
-            const double* gB = TB + (int64_t)j * pd.n2;
-            for (int t = lane; t < pd.n1; t += WAVE) tA[t] = gA[t];
-            for (int t = lane; t < pd.n2; t += WAVE) tB[t] = gB[t];
         }
-        if (lane == 0) tA[pd.n1] = d_nan();                     // sentinel entry of the padding columns
+    };
+    if (pre && NR * w < nrows) fetch_tab(__builtin_amdgcn_readfirstlane(NR * w));
+    for (int r = NR * w; r < nrows; r += NR * wpb) {
+        int k[NR]; double zi[NR], zj[NR];
+#pragma unroll
+        for (int x = 0; x < NR; ++x) {
+            k[x] = __builtin_amdgcn_readfirstlane(row0 + min(r + x, nrows - 1));   // wave-uniform: loop bounds and lane selects in SGPRs
+            zi[x] = GRAV ? cZZ[k[x]].x : 0.0; zj[x] = GRAV ? cZZ[k[x]].y : 0.0;
+        }
+        // stage the table rows (wave-private slices; LDS ops of one wave execute in order)
+#pragma unroll
+        for (int x = 0; x < NR; ++x) {
+            double* sA = tA + x * ldsPerRow; double* sB = sA + pd.n1 + 1;
+            if (pre) {
+#pragma unroll
+                for (int m_ = 0; m_ < TR; ++m_) {
+                    if (lane + m_ * WAVE < pd.n1) sA[lane + m_ * WAVE] = ra[x][m_];
+                    if (lane + m_ * WAVE < pd.n2) sB[lane + m_ * WAVE] = rb[x][m_];
+                }
+            } else {
+                const int i = cIJ[k[x]].x >> 3, j = (cIJ[k[x]].y >> 3) - (pd.n1 + 1);
+                const double* gA = TA + (int64_t)i * pd.n1;
+                const double* gB = TB + (int64_t)j * pd.n2;
+                for (int t = lane; t < pd.n1; t += WAVE) sA[t] = gA[t];
+                for (int t = lane; t < pd.n2; t += WAVE) sB[t] = gB[t];
+            }
+            if (lane == 0) sA[pd.n1] = d_nan();                 // sentinel entry of the padding columns
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (pre && r + wpb < nrows) fetch_tab(__builtin_amdgcn_readfirstlane(row0 + r + wpb));
+        if (pre && r + NR * wpb < nrows) fetch_tab(__builtin_amdgcn_readfirstlane(r + NR * wpb));
 
         // The pair test is symmetric: row k computes only the 64-column words c >= R = k/64 (the diagonal word
         // completely, both of its triangles); the words c < R are the bit transposes of blocks computed by other
         // rows and are written by k_mirror.  Prefix counts and row totals are taken afterwards by k_rowprefix.
-        unsigned long long* mrow = mbase + (int64_t)k * W;
-        const int R = k >> 6;
-        uint32_t mlo = 0u, mhi = 0u;                            // lane l: word (block*64 + l) of the current 64-word block
+        // The NR rows of a wave are adjacent and start at a multiple of NR: they lie in the same 64-row block.
+        const int R = k[0] >> 6;
+        uint32_t mlo[NR], mhi[NR];                              // lane l: word (block*64 + l) of the current 64-word block
+#pragma unroll
+        for (int x = 0; x < NR; ++x) { mlo[x] = 0u; mhi[x] = 0u; }
         for (int q0 = (R << 6) & ~(U * WAVE - 1); q0 < Lpad; q0 += U * WAVE) {
             int2 ij[U]; double2 zz[U];
 #pragma unroll
@@ -556,41 +570,47 @@ __device__ __forceinline__ void count_rows_lds(const DevParams& D, const ProbDes
             }
 #pragma unroll
             for (int t = 0; t < U; ++t) {
-                const double a = *reinterpret_cast<const double*>(tbytes + ij[t].x);
-                const double bb = *reinterpret_cast<const double*>(tbytes + ij[t].y);
-                bool is;
-                if (GRAV) {
-                    const double ch = fabs(a - bb);
-                    double hm;                                  // max(a,bb) in ONE instruction (fmax() would first
-                    asm("v_max_f64 %0, %1, %2" : "=v"(hm) : "v"(a), "v"(bb));   // canonicalise both); NaN operands: x is NaN through ch anyway
-                    const double cv = __builtin_fmax(fabs((zi - zz[t].x) - (zj - zz[t].y)) - D.sin_unc * hm, 0.0);
-                    const double x = ch * ch + cv * cv;
-                    is = x < D.x_eps;                           // <=> sqrt(x) < epsilon ; NaN -> false
-                } else {
-                    is = fabs(a - bb) < D.p.epsilon;
-                }
-                const unsigned long long m = __ballot(is);
                 const int widx = (q0 >> 6) + t;                 // words >= W are all-zero (sentinel columns)
-                {   // lane (widx & 63) of (mhi:mlo) <- m  (v_writelane_b32: uniform value, uniform lane select)
-                    const uint32_t ml_ = (uint32_t)m, mh_ = (uint32_t)(m >> 32), sel_ = (uint32_t)(widx & 63);
-                    asm("s_mov_b32 m0, %3\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %4, m0"
-                        : "+v"(mlo), "+v"(mhi) : "s"(ml_), "s"(sel_), "s"(mh_) : "m0");
+#pragma unroll
+                for (int x = 0; x < NR; ++x) {
+                    const double a = *reinterpret_cast<const double*>(tbytes + x * sliceBytes + ij[t].x);
+                    const double bb = *reinterpret_cast<const double*>(tbytes + x * sliceBytes + ij[t].y);
+                    bool is;
+                    if (GRAV) {
+                        const double ch = fabs(a - bb);
+                        double hm;                              // max(a,bb) in ONE instruction (fmax() would first
+                        asm("v_max_f64 %0, %1, %2" : "=v"(hm) : "v"(a), "v"(bb));   // canonicalise both); NaN operands: x is NaN through ch anyway
+                        const double cv = __builtin_fmax(fabs((zi[x] - zz[t].x) - (zj[x] - zz[t].y)) - D.sin_unc * hm, 0.0);
+                        const double xx = ch * ch + cv * cv;
+                        is = xx < D.x_eps;                      // <=> sqrt(x) < epsilon ; NaN -> false
+                    } else {
+                        is = fabs(a - bb) < D.p.epsilon;
+                    }
+                    const unsigned long long m = __ballot(is);
+                    {   // lane (widx & 63) of (mhi:mlo) <- m  (v_writelane_b32: uniform value, uniform lane select)
+                        const uint32_t ml_ = (uint32_t)m, mh_ = (uint32_t)(m >> 32), sel_ = (uint32_t)(widx & 63);
+                        asm("s_mov_b32 m0, %3\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %4, m0"
+                            : "+v"(mlo[x]), "+v"(mhi[x]) : "s"(ml_), "s"(sel_), "s"(mh_) : "m0");
+                    }
                 }
             }
             const int wend = min(W, (q0 >> 6) + U);             // words [.., wend) are complete
             if ((wend & 63) == 0 || wend == W) {                // flush the block of <= 64 words, coalesced
                 const int wb = (wend - 1) & ~63;
-                const unsigned long long mreg = ((unsigned long long)mhi << 32) | mlo;
-                if (wb + lane < wend && wb + lane >= R) mrow[wb + lane] = mreg;
+#pragma unroll
+                for (int x = 0; x < NR; ++x) {
+                    const unsigned long long mreg = ((unsigned long long)mhi[x] << 32) | mlo[x];
+                    if (r + x < nrows && wb + lane < wend && wb + lane >= R) mbase[(int64_t)k[x] * W + wb + lane] = mreg;
+                }
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();                        // table slice is rewritten by the next row
+        __builtin_amdgcn_wave_barrier();                        // table slices are rewritten by the next rows
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
 }
 
-template <bool GRAV>
+template <bool GRAV, int NR>
 __global__ void __launch_bounds__(1024) k_count(DevParams D, const ProbDesc* __restrict__ probs,
                                                 const ProbState* __restrict__ st,
                                                 const BatchTotals* __restrict__ tot,
@@ -601,9 +621,9 @@ __global__ void __launch_bounds__(1024) k_count(DevParams D, const ProbDesc* __r
                                                 uint32_t* __restrict__ rowCnt,
                                                 unsigned long long* __restrict__ maskPool,
                                                 uint32_t* __restrict__ prefPool,
-                                                int TC /* LDS column tile (multiple of 256) */, int ldsPerWave /* doubles */, int RPB)
+                                                int TC /* LDS column tile (multiple of 256) */, int ldsPerWave /* doubles: NR table slices */, int RPB)
 {
-    // LDS: [GRAV: cZZ[TC]] cIJ[TC] | per-wave table slices (n1 + 1 + n2 doubles each)
+    // LDS: [GRAV: cZZ[TC]] cIJ[TC] | per wave NR table slices (n1 + 1 + n2 doubles each)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double2* cZZ = reinterpret_cast<double2*>(smem);
     int2* cIJ = reinterpret_cast<int2*>(cZZ + (GRAV ? TC : 0));
@@ -633,8 +653,7 @@ __global__ void __launch_bounds__(1024) k_count(DevParams D, const ProbDesc* __r
         }
         __syncthreads();
         if (ldscol)
-            count_rows_lds<GRAV>(D, pd, L, it.row0, nrows, w, wpb, lane, cIJ, cZZ, li + lo, lj + lo, lza + lo, lzb + lo,
-                                 TA, TB, tA, rowCnt + lo, maskPool + mo, prefPool + mo);
+            count_rows_lds<GRAV, NR>(D, pd, L, it.row0, nrows, w, wpb, lane, cIJ, cZZ, TA, TB, tA, ldsPerWave / NR, maskPool + mo);
         else
             count_rows_global<GRAV>(D, pd, L, it.row0, nrows, w, wpb, lane, li + lo, lj + lo, lza + lo, lzb + lo,
                                     TA, TB, tA, rowCnt + lo, maskPool + mo, prefPool + mo);

@@ -288,14 +288,17 @@ int stage_score(roman_ctx* c, const DevParams& D, const BatchIn& in, std::vector
     HIPCHK(c, WS.maskPool.ensure(sizeof(unsigned long long) * (size_t)std::max<int64_t>(tot.maskWords, 1)));
     HIPCHK(c, WS.prefPool.ensure(sizeof(uint32_t) * (size_t)std::max<int64_t>(tot.maskWords, 1)));
 
-    // pair-test kernel LDS: a column tile (objects [+ z] of every live association) + per-wave table rows
-    const int ldsPerWave = ((2 * std::max(maxN, 1) + 1 + 1) & ~1) + 2;    // n1 + sentinel + n2 doubles
+    // pair-test kernel LDS: a column tile (objects [+ z] of every live association) + per wave the table rows of
+    // the NR rows it sweeps together (NR = 2 if that fits beside the whole column tile, else 1)
+    const int ldsPerRow = ((2 * std::max(maxN, 1) + 1 + 1) & ~1) + 2;     // n1 + sentinel + n2 doubles
     const int colBytesC = D.gravity ? 24 : 8;
     const int Lneed = (std::max(tot.maxL, 1) + 255) & ~255;
+    int NRc = ((size_t)16 * 2 * ldsPerRow * sizeof(double) + (size_t)Lneed * colBytesC <= c->lds_max) ? 2 : 1;
     int wpb = 16;
-    while (wpb > 1 && (size_t)wpb * ldsPerWave * sizeof(double) + 256 * colBytesC > c->lds_max) wpb >>= 1;
-    if ((size_t)wpb * ldsPerWave * sizeof(double) + 256 * colBytesC > c->lds_max)
+    while (wpb > 1 && (size_t)wpb * NRc * ldsPerRow * sizeof(double) + 256 * colBytesC > c->lds_max) wpb >>= 1;
+    if ((size_t)wpb * NRc * ldsPerRow * sizeof(double) + 256 * colBytesC > c->lds_max)
         return fail(c, ROMAN_E_TOO_LARGE, "maps of %d objects exceed the LDS table staging of this build", maxN);
+    const int ldsPerWave = NRc * ldsPerRow;
     const size_t tabLds = (size_t)wpb * ldsPerWave * sizeof(double);
     int TCc = (int)std::min<size_t>((c->lds_max - tabLds) / colBytesC, 32768) & ~255;
     TCc = std::min(TCc, Lneed);
@@ -304,7 +307,7 @@ int stage_score(roman_ctx* c, const DevParams& D, const BatchIn& in, std::vector
 
     StageTimer t1(c, ROMAN_STAGE_COUNT_PASS);
     if (tot.R > 0) {
-        auto kc = D.gravity ? k_count<true> : k_count<false>;
+        auto kc = D.gravity ? (NRc == 2 ? k_count<true, 2> : k_count<true, 1>) : (NRc == 2 ? k_count<false, 2> : k_count<false, 1>);
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kc), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pairLds));
         hipLaunchKernelGGL(kc, dim3(pairGrid), dim3(wpb * 64), pairLds, WS.stream, D, dP, dS, dT, WS.items.as<ItemDesc>(), WS.tabPool.as<double>(),
                            WS.li.as<int32_t>(), WS.lj.as<int32_t>(), WS.lza.as<double>(), WS.lzb.as<double>(),
