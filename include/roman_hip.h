@@ -149,11 +149,19 @@ ROMAN_API int roman_ctx_destroy(roman_ctx_t* ctx);
    between pairs).  With depth >= 2 the results of a batch call are complete after roman_ctx_sync() (or a
    device-wide synchronisation), NOT after synchronising the context's stream alone; the caller must give
    batches that may be in flight together distinct output buffers if it needs both results.  The
-   host-pointer and stepwise entry points always drain the pipeline first and run synchronously. */
+   host-pointer and stepwise entry points always drain the pipeline first and run synchronously.
+   With depth >= 2 roman_align_batch_dev is ASYNCHRONOUS for the host as well: it validates and copies its
+   host-side arguments (params, off1/n1/off2/n2, assoc_off) and returns; a worker thread of the workspace
+   issues the kernels (the sequence blocks twice on a small size read-back, and only a second host thread
+   lets the next batch's first kernels queue up meanwhile).  Device buffers must stay valid until
+   roman_ctx_sync().  A failure inside a queued batch is reported by the next call that touches its
+   workspace (the batch call `depth` calls later, roman_ctx_join or roman_ctx_sync), with its text in
+   roman_last_error(). */
 ROMAN_API int roman_ctx_set_pipeline(roman_ctx_t* ctx, int depth);
-/* Enqueue on the context's stream (no host blocking) a wait for the pipelined batches issued so far: all of
-   them, or — skip_latest != 0 — all but the most recent one, so that work queued on the caller's stream
-   afterwards (e.g. the all_gather of batch k-1's records) sees their results while batch k keeps running. */
+/* Enqueue on the context's stream a wait for the pipelined batches issued so far: all of them, or —
+   skip_latest != 0 — all but the most recent one, so that work queued on the caller's stream afterwards
+   (e.g. the all_gather of batch k-1's records) sees their results while batch k keeps running.  The host
+   blocks only until the worker threads have QUEUED those batches (not until the GPU has finished them). */
 ROMAN_API int roman_ctx_join(roman_ctx_t* ctx, int skip_latest);
 /* Wait for every batch in flight on this context (all internal streams and the context's stream). */
 ROMAN_API int roman_ctx_sync(roman_ctx_t* ctx);

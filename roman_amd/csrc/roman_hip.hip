@@ -3,12 +3,15 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cmath>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "kernels.hip.h"
@@ -18,6 +21,8 @@ using namespace roman;
 namespace {
 
 thread_local std::string g_last_error;
+thread_local int t_wsel = 0;                  // workspace the calling thread works on (pipeline workers: their own)
+thread_local std::string* t_err = nullptr;     // pipeline workers collect their error text here instead of in the context
 
 // grow-only device buffer
 struct DevBuf {
@@ -71,13 +76,30 @@ struct roman_ctx {
         hipEvent_t evB[ROMAN_STAGE_COUNT] = {nullptr, nullptr, nullptr, nullptr};
         bool pending[ROMAN_STAGE_COUNT] = {false, false, false, false};
     } ws[ROMAN_MAX_PIPELINE];
-    int wsel = 0;                              // workspace of the call in progress
     bool in_host_batch = false;                // roman_align_batch (host pointers) is driving roman_align_batch_dev
     int pipeline = 1;                          // batches in flight (1 or 2)
     int next_ws = 0;
     hipStream_t istream[ROMAN_MAX_PIPELINE] = {nullptr, nullptr, nullptr};   // internal streams of the workspaces while pipelining
     int latest_ws = -1;                        // workspace of the most recent pipelined batch call
     hipEvent_t evIn = nullptr;                 // inputs ready on the caller's stream
+
+    // Pipelined batch calls are executed by one worker thread per workspace: the call sequence of a batch blocks
+    // twice on a 32-byte read-back (sizes of the sparse build), and only a second host thread lets the next
+    // batch's first kernels be queued meanwhile.  roman_align_batch_dev copies its host-side arguments into
+    // the job and returns; errors of a job surface at the next call that touches its workspace.
+    struct Job {
+        roman_params_t params; int32_t B = 0, F = 0, kmax = 0;
+        const double* feats = nullptr; const int32_t* assoc = nullptr; const double* u0 = nullptr;
+        std::vector<int64_t> off1, off2, assoc_off; std::vector<int32_t> n1, n2;
+        int32_t* assoc_out = nullptr; int32_t* n_assoc_out = nullptr; double* T_out = nullptr; int32_t* status_out = nullptr;
+        roman_stats_t* stats_out = nullptr;
+    };
+    struct Worker {
+        std::thread th; std::mutex m; std::condition_variable cv;
+        bool started = false, has_job = false, busy = false, quit = false;
+        Job job; int rc = 0; std::string err;
+    } wk[ROMAN_MAX_PIPELINE];
+    std::mutex prof_mu;
 
     bool profile = false;
     double prof_ms[ROMAN_STAGE_COUNT] = {0, 0, 0, 0};
@@ -98,7 +120,7 @@ struct roman_ctx {
     } last;
 };
 
-#define WS (c->ws[c->wsel])
+#define WS (c->ws[t_wsel])
 
 namespace {
 
@@ -106,7 +128,7 @@ int fail(roman_ctx* c, int code, const char* fmt, ...)
 {
     char buf[640];
     va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap);
-    if (c) c->err = buf; else g_last_error = buf;
+    if (t_err) *t_err = buf; else if (c) c->err = buf; else g_last_error = buf;
     return code;
 }
 
@@ -117,12 +139,19 @@ int use_ws0(roman_ctx* c);
 #define HIPCHK(c, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { (void)hipGetLastError(); \
     return fail((c), (e_ == hipErrorOutOfMemory) ? ROMAN_E_NOMEM : ROMAN_E_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); } } while (0)
 
+int workers_wait_all(roman_ctx* c);
+int worker_wait_idle(roman_ctx* c, int k);
+void workers_stop(roman_ctx* c);
+void worker_main(roman_ctx* c, int k);
+
 int use_ws0(roman_ctx* c)
 {
     if (c->pipeline >= 2) {
+        const int rc = workers_wait_all(c);
         for (int k = 0; k < ROMAN_MAX_PIPELINE; ++k) if (c->istream[k]) HIPCHK(c, hipStreamSynchronize(c->istream[k]));
+        if (rc) return rc;
     }
-    c->wsel = 0; c->ws[0].stream = c->stream;
+    t_wsel = 0; c->ws[0].stream = c->stream;
     return ROMAN_OK;
 }
 
@@ -189,13 +218,14 @@ void prof_flush(roman_ctx* c, int k, int s)
     if (!W.pending[s]) return;
     float ms = 0.f;
     if (hipEventSynchronize(W.evB[s]) == hipSuccess && hipEventElapsedTime(&ms, W.evA[s], W.evB[s]) == hipSuccess) {
+        std::lock_guard<std::mutex> lk(c->prof_mu);
         c->prof_ms[s] += (double)ms; c->prof_n[s] += 1;
     }
     W.pending[s] = false;
 }
 struct StageTimer {
     roman_ctx* c; int s;
-    StageTimer(roman_ctx* c_, int s_) : c(c_), s(s_) { if (c->profile) { prof_flush(c, c->wsel, s); (void)hipEventRecord(WS.evA[s], WS.stream); } }
+    StageTimer(roman_ctx* c_, int s_) : c(c_), s(s_) { if (c->profile) { prof_flush(c, t_wsel, s); (void)hipEventRecord(WS.evA[s], WS.stream); } }
     void stop() { if (c->profile) { (void)hipEventRecord(WS.evB[s], WS.stream); WS.pending[s] = true; } }
 };
 
@@ -690,6 +720,7 @@ int roman_ctx_destroy(roman_ctx_t* c)
     if (!c) return ROMAN_OK;
     (void)hipSetDevice(c->device);
     (void)roman_ctx_sync(c);
+    workers_stop(c);
     for (int k = 0; k < ROMAN_MAX_PIPELINE; ++k) {
         roman_ctx::Workspace& W = c->ws[k];
         DevBuf* all[] = {&W.probs, &W.state, &W.totals, &W.queue, &W.cosPool, &W.normPool, &W.tabPool, &W.sTmp, &W.lp, &W.li, &W.lj, &W.ls, &W.lza, &W.lzb,
@@ -707,6 +738,87 @@ int roman_ctx_destroy(roman_ctx_t* c)
     delete c;
     return ROMAN_OK;
 }
+
+namespace {
+
+// one batch through the stages, on workspace t_wsel and its stream
+int run_batch(roman_ctx* c, const DevParams& D, const BatchIn& in, const double* u0, int32_t kmax,
+              int32_t* assoc_out, int32_t* n_assoc_out, double* T_out, int32_t* status_out, roman_stats_t* stats_out)
+{
+    std::vector<ProbDesc> hd;
+    BatchTotals tot{}; bool idx16 = true;
+    int rc = stage_score(c, D, in, hd, &tot, &idx16);
+    if (rc) return rc;
+    return stage_solve(c, D, in.B, in.feats, in.assoc, u0, tot, idx16, false, kmax, assoc_out, n_assoc_out, T_out, status_out, stats_out);
+}
+
+void worker_main(roman_ctx* c, int k)
+{
+    roman_ctx::Worker& Wk = c->wk[k];
+    t_wsel = k;
+    t_err = &Wk.err;
+    (void)hipSetDevice(c->device);
+    for (;;) {
+        {
+            std::unique_lock<std::mutex> lk(Wk.m);
+            Wk.cv.wait(lk, [&] { return Wk.has_job || Wk.quit; });
+            if (Wk.quit) return;
+            Wk.has_job = false;
+        }
+        const roman_ctx::Job& J = Wk.job;                       // not touched by the caller while busy
+        int rc = ROMAN_OK;
+        DevParams D;
+        rc = make_dev_params(c, &J.params, J.F, &D);
+        if (!rc) {
+            c->ws[k].stream = c->istream[k];
+            BatchIn in{J.B, J.feats, J.off1.data(), J.n1.data(), J.off2.data(), J.n2.data(), J.F, J.assoc, J.assoc ? J.assoc_off.data() : nullptr};
+            rc = run_batch(c, D, in, J.u0, J.kmax, J.assoc_out, J.n_assoc_out, J.T_out, J.status_out, J.stats_out);
+            if (!rc) {
+                if (hipEventRecord(c->ws[k].done, c->ws[k].stream) != hipSuccess) { (void)hipGetLastError(); rc = fail(c, ROMAN_E_HIP, "hipEventRecord failed in the pipeline worker"); }
+                else c->ws[k].issued = true;
+            }
+        }
+        {
+            std::lock_guard<std::mutex> lk(Wk.m);
+            Wk.rc = rc; Wk.busy = false;
+        }
+        Wk.cv.notify_all();
+    }
+}
+
+// Block until the worker of workspace k has queued everything of its current batch; returns (once) the error
+// of that batch, with its text in the context.
+int worker_wait_idle(roman_ctx* c, int k)
+{
+    roman_ctx::Worker& Wk = c->wk[k];
+    if (!Wk.started) return ROMAN_OK;
+    std::unique_lock<std::mutex> lk(Wk.m);
+    Wk.cv.wait(lk, [&] { return !Wk.busy; });
+    const int rc = Wk.rc;
+    if (rc) { c->err = Wk.err; Wk.rc = ROMAN_OK; }
+    return rc;
+}
+
+int workers_wait_all(roman_ctx* c)
+{
+    int first = ROMAN_OK;
+    for (int k = 0; k < ROMAN_MAX_PIPELINE; ++k) { const int rc = worker_wait_idle(c, k); if (rc && !first) first = rc; }
+    return first;
+}
+
+void workers_stop(roman_ctx* c)
+{
+    for (int k = 0; k < ROMAN_MAX_PIPELINE; ++k) {
+        roman_ctx::Worker& Wk = c->wk[k];
+        if (!Wk.started) continue;
+        { std::unique_lock<std::mutex> lk(Wk.m); Wk.cv.wait(lk, [&] { return !Wk.busy; }); Wk.quit = true; }
+        Wk.cv.notify_all();
+        Wk.th.join();
+        Wk.started = false; Wk.quit = false;
+    }
+}
+
+}  // namespace
 
 // Batches in flight.  depth 1 (default): every call runs on the context's stream.  depth 2 or 3: batch calls
 // (roman_align_batch_dev) rotate over that many workspaces, each with an internal stream that starts after
@@ -726,7 +838,7 @@ int roman_ctx_set_pipeline(roman_ctx_t* c, int depth)
         }
         if (!c->evIn) HIPCHK(c, hipEventCreateWithFlags(&c->evIn, hipEventDisableTiming));
     }
-    c->pipeline = depth; c->next_ws = 0; c->wsel = 0; c->latest_ws = -1;
+    c->pipeline = depth; c->next_ws = 0; t_wsel = 0; c->latest_ws = -1;
     for (int k = 0; k < ROMAN_MAX_PIPELINE; ++k) { c->ws[k].issued = false; c->ws[k].stream = c->stream; }
     return ROMAN_OK;
 }
@@ -741,20 +853,24 @@ int roman_ctx_join(roman_ctx_t* c, int skip_latest)
     if (c->pipeline < 2) return ROMAN_OK;                       // everything already runs on the caller's stream
     HIPCHK(c, hipSetDevice(c->device));
     const int latest = c->latest_ws;                            // workspace of the most recent batch call
+    int first = ROMAN_OK;
     for (int k = 0; k < c->pipeline; ++k) {
         if (skip_latest && k == latest) continue;
+        const int rc = worker_wait_idle(c, k);                  // the batch must be queued completely before its event exists
+        if (rc && !first) first = rc;
         if (c->ws[k].done && c->ws[k].issued) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ws[k].done, 0));
     }
-    return ROMAN_OK;
+    return first;
 }
 
 int roman_ctx_sync(roman_ctx_t* c)
 {
     if (!c) return fail(nullptr, ROMAN_E_INVALID, "ctx is NULL");
     HIPCHK(c, hipSetDevice(c->device));
+    const int rcw = workers_wait_all(c);
     for (int k = 0; k < ROMAN_MAX_PIPELINE; ++k) if (c->istream[k]) HIPCHK(c, hipStreamSynchronize(c->istream[k]));
     if (c->stream) HIPCHK(c, hipStreamSynchronize(c->stream));
-    return ROMAN_OK;
+    return rcw;
 }
 
 // --- instrumentation -----------------------------------------------------------------------------
@@ -800,28 +916,39 @@ int roman_align_batch_dev(roman_ctx_t* c, const roman_params_t* params, int32_t 
     DevParams D;
     int rc = make_dev_params(c, params, F, &D);
     if (rc) return rc;
-    if (c->pipeline >= 2 && !c->in_host_batch) {                // next workspace, on its internal stream, behind the caller's stream
-        c->wsel = c->next_ws; c->next_ws = (c->next_ws + 1) % c->pipeline; c->latest_ws = c->wsel;
-        WS.stream = c->istream[c->wsel];
-        HIPCHK(c, hipEventRecord(c->evIn, c->stream));
-        HIPCHK(c, hipStreamWaitEvent(WS.stream, c->evIn, 0));
-    } else if (!c->in_host_batch) {
-        c->wsel = 0; WS.stream = c->stream;
-    }
     if (!feats) {
         bool any = false;
         for (int b = 0; b < B; ++b) any = any || (n1[b] > 0 || n2[b] > 0);
         if (any) return fail(c, ROMAN_E_INVALID, "feats is NULL");
     }
+    if (c->pipeline >= 2 && !c->in_host_batch) {
+        // next workspace: its worker thread runs the launch sequence on the workspace's internal stream, which
+        // starts behind the work already queued on the caller's stream
+        const int k = c->next_ws;
+        c->next_ws = (c->next_ws + 1) % c->pipeline; c->latest_ws = k;
+        rc = worker_wait_idle(c, k);                            // also reports a failure of the batch it ran before
+        if (rc) return rc;
+        HIPCHK(c, hipEventRecord(c->evIn, c->stream));
+        HIPCHK(c, hipStreamWaitEvent(c->istream[k], c->evIn, 0));
+        roman_ctx::Worker& Wk = c->wk[k];
+        {
+            std::lock_guard<std::mutex> lk(Wk.m);
+            roman_ctx::Job& J = Wk.job;
+            J.params = *params; J.B = B; J.F = F; J.kmax = kmax; J.feats = feats; J.assoc = assoc; J.u0 = u0;
+            J.off1.assign(off1, off1 + B); J.off2.assign(off2, off2 + B); J.n1.assign(n1, n1 + B); J.n2.assign(n2, n2 + B);
+            if (assoc) J.assoc_off.assign(assoc_off, assoc_off + B + 1); else J.assoc_off.clear();
+            J.assoc_out = assoc_out; J.n_assoc_out = n_assoc_out; J.T_out = T_out; J.status_out = status_out; J.stats_out = stats_out;
+            if (!Wk.started) { Wk.started = true; Wk.th = std::thread(worker_main, c, k); }
+            Wk.has_job = true; Wk.busy = true;
+        }
+        Wk.cv.notify_all();
+        return ROMAN_OK;
+    }
+    if (!c->in_host_batch) { t_wsel = 0; WS.stream = c->stream; }
     BatchIn in{B, feats, off1, n1, off2, n2, F, assoc, assoc_off};
-    std::vector<ProbDesc> hd;
-    BatchTotals tot{}; bool idx16 = true;
-    rc = stage_score(c, D, in, hd, &tot, &idx16);
+    rc = run_batch(c, D, in, u0, kmax, assoc_out, n_assoc_out, T_out, status_out, stats_out);
     if (rc) return rc;
-    rc = stage_solve(c, D, B, feats, assoc, u0, tot, idx16, false, kmax, assoc_out, n_assoc_out, T_out, status_out, stats_out);
-    if (rc) return rc;
-    if (c->pipeline >= 2 && !c->in_host_batch) { HIPCHK(c, hipEventRecord(WS.done, WS.stream)); WS.issued = true; }
-    if (c->wsel == 0) { c->last.scored = false; c->last.solved = false; }
+    if (t_wsel == 0) { c->last.scored = false; c->last.solved = false; }
     return ROMAN_OK;
 }
 
