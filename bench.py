@@ -149,6 +149,14 @@ def main():
     if not args.no_profile:
         ctx.profile_enable(False)
     ctx.set_pipeline(1)                                         # the latency probe and the checks below are single calls
+    iso = None
+    if prof is not None and args.pipeline >= 2 and rank == 0:   # the same kernels without a second batch beside them
+        ctx.profile_enable(True); ctx.profile_reset()
+        for _ in range(3):
+            ctx.align_batch_dev(P, feats.data_ptr(), F, batch.off1, batch.n1, batch.off2, batch.n2, kmax,
+                                assoc_o[0].data_ptr(), n_o[0].data_ptr(), T_o[0].data_ptr(), status_o[0].data_ptr(), stats_o[0].data_ptr())
+        torch.cuda.synchronize(dev)
+        iso = ctx.profile_get(); ctx.profile_enable(False)
     last = (args.steps - 1) % NSET
     assoc_out, n_out, T_out, status, stats = assoc_o[last], n_o[last], T_o[last], status_o[last], stats_o[last]
     if world > 1:
@@ -222,6 +230,11 @@ def main():
                                "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/pmc_traffic.json)",
                                "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": solve_ms / solve_n,
                                "dominant_stage_by_time": dom}
+            if iso is not None and iso["solve"][1] > 0:         # launch duration with no other batch in flight (3 extra untimed steps)
+                iso_ms = iso["solve"][0] / iso["solve"][1]
+                out["roofline"]["isolated"] = {"avg_launch_ms": iso_ms, "achieved": alg_bytes / (iso_ms * 1e-3) / 1e9,
+                                               "frac": alg_bytes / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                               "stage_ms_per_step": {k: v[0] / max(v[1], 1) for k, v in iso.items()}}
     # ---- CPU baseline: the oracle on this box's host cores, bounded sample ----------------------------
     if world == 1 and args.cpu_sample > 0:
         from oracle import oracle as orc
