@@ -28,6 +28,12 @@ LADDER = [  # (id, method, kwargs, n, m, d, seed)
     ("cfg2", "semanticgrav", {"semantics_dim": 512}, 200, 200, 512, 2000),
     ("roman_d768", "roman", {}, 40, 40, 768, 27),
     ("gravity100", "gravity", {}, 100, 100, 0, 7),
+    # edge shapes of the sparse build: one mask word per row (no lower-triangle blocks), two to three words, and
+    # rows with several hundred candidates (slices wider than one LDS image pass of the fill kernel)
+    ("tiny_4x5", "clipper", {}, 4, 5, 0, 32),
+    ("words2_9x10", "gravity", {}, 9, 10, 0, 33),
+    ("words3_12x14", "clipper", {}, 12, 14, 0, 34),
+    ("dense45", "clipper", {"epsilon": 1.5, "sigma": 0.8}, 45, 45, 0, 31),
 ]
 
 
@@ -90,8 +96,9 @@ def test_stagewise_parity(ctx, orc, case):
         assert np.linalg.norm(res.T[0] - T_o) < POSE_TOL
         assert np.linalg.norm(reg.T_align(pr.map1, pr.map2, sel) - T_o) < POSE_TOL
     # the planted inliers come back
-    got = set(map(tuple, sel.tolist())); truth = set(map(tuple, pr.inliers.tolist()))
-    assert len(got & truth) >= 0.85 * len(truth)
+    if case[3] >= 20 and "epsilon" not in case[2]:              # (edge shapes are about parity, not about recall)
+        got = set(map(tuple, sel.tolist())); truth = set(map(tuple, pr.inliers.tolist()))
+        assert len(got & truth) >= 0.85 * len(truth)
 
 
 def test_device_arithmetic_is_bit_exact(ctx):
