@@ -35,8 +35,8 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI35
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--batch", type=int, default=256, help="submap pairs per GPU per step (config 3: 256)")
     ap.add_argument("--n", type=int, default=200)
     ap.add_argument("--m", type=int, default=200)
