@@ -311,52 +311,87 @@ __global__ void __launch_bounds__(256) k_tables(DevParams D, const ProbDesc* __r
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_live: per problem, single score of every association and ordered (ascending association
-// index) compaction of the live ones.  1024 threads; wave w owns a contiguous segment so the
-// compaction needs a single cross-wave prefix.
+// k_live<PHASE>: single score of every association and ordered (ascending association index)
+// compaction of the live ones, in two launches over chunks of LIVE_CHUNK associations (grid:
+// chunks x problems, so a single problem is spread over many CUs as well):
+//   PHASE 0  scores -> sTmp, number of live associations of the chunk -> chunkCnt
+//   PHASE 1  chunk base = sum of the counts in front of it (fixed order), ordered compaction; the
+//            workgroup of chunk 0 also publishes L.
+// Wave w of a workgroup owns a contiguous quarter of the chunk, so the order needs one cross-wave prefix.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(1024) k_live(DevParams D, const ProbDesc* __restrict__ probs,
-                                               ProbState* __restrict__ st,
-                                               const double* __restrict__ feats,
-                                               const int32_t* __restrict__ assoc,
-                                               const double* __restrict__ cosPool,
-                                               double* __restrict__ sTmp,
-                                               int32_t* __restrict__ lp, int32_t* __restrict__ li,
-                                               int32_t* __restrict__ lj, double* __restrict__ ls,
-                                               double* __restrict__ lza, double* __restrict__ lzb)
+constexpr int LIVE_CHUNK = 4096;
+
+template <int PHASE>
+__global__ void __launch_bounds__(256) k_live(DevParams D, const ProbDesc* __restrict__ probs,
+                                              ProbState* __restrict__ st,
+                                              const double* __restrict__ feats,
+                                              const int32_t* __restrict__ assoc,
+                                              const double* __restrict__ cosPool,
+                                              double* __restrict__ sTmp, int32_t* __restrict__ chunkCnt, int maxChunks,
+                                              int32_t* __restrict__ lp, int32_t* __restrict__ li,
+                                              int32_t* __restrict__ lj, double* __restrict__ ls,
+                                              double* __restrict__ lza, double* __restrict__ lzb)
 {
-    __shared__ int wtot[16];
-    const int b = blockIdx.x;
+    __shared__ int wtot[4];
+    __shared__ int cbase[2];
+    const int b = blockIdx.y, c = blockIdx.x;
     const ProbDesc pd = probs[b];
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, nw = blockDim.x >> 6;
     const int nA = pd.nA;
-    const int seg = (((nA + nw - 1) / nw) + 63) & ~63;
-    const int p_beg = w * seg, p_end = min(nA, p_beg + seg);
+    const int nChunks = (nA + LIVE_CHUNK - 1) / LIVE_CHUNK;
+    if (c >= nChunks && !(PHASE == 1 && c == 0)) return;
+    const int seg = LIVE_CHUNK / 4;                              // per wave (blockDim.x == 256)
+    const int p_beg = min(nA, c * LIVE_CHUNK + w * seg), p_end = min(nA, p_beg + seg);
     const int Fc = D.p.cos_feature_dim;
     double* sT = sTmp + pd.liveOff;
+    int32_t* cc = chunkCnt + (int64_t)b * maxChunks;
 
+    if (PHASE == 0) {
+        int cnt = 0;
+        for (int p0 = p_beg; p0 < p_end; p0 += WAVE) {
+            const int p = p0 + lane;
+            double s = 0.0;
+            if (p < p_end) {
+                int i, j;
+                decode_assoc(pd, assoc, p, i, j);
+                if (D.single) {
+                    const double cosv = (Fc > 0) ? cosPool[pd.cosOff + (int64_t)i * pd.n2 + j] : 0.0;
+                    s = single_score(D, feats + (pd.off1 + i) * D.F, feats + (pd.off2 + j) * D.F, cosv);
+                } else {
+                    s = 1.0;
+                }
+                sT[p] = s;
+            }
+            cnt += __popcll(__ballot(s > 0.0));
+        }
+        if (lane == 0) wtot[w] = cnt;
+        __syncthreads();
+        if (tid == 0) { int t = 0; for (int k = 0; k < nw; ++k) t += wtot[k]; cc[c] = t; }
+        return;
+    }
+
+    // PHASE 1
+    if (w == 0) {                                               // counts in front of this chunk, and the problem total
+        int front = 0, total = 0;
+        for (int k0 = 0; k0 < nChunks; k0 += WAVE) {
+            const int k = k0 + lane;
+            const int v = k < nChunks ? cc[k] : 0;
+            int f = k < c ? v : 0, t = v;
+            for (int off = 32; off > 0; off >>= 1) { f += __shfl_xor(f, off); t += __shfl_xor(t, off); }
+            front += f; total += t;
+        }
+        if (lane == 0) { cbase[0] = front; cbase[1] = total; }
+    }
     int cnt = 0;
     for (int p0 = p_beg; p0 < p_end; p0 += WAVE) {
         const int p = p0 + lane;
-        double s = 0.0;
-        if (p < p_end) {
-            int i, j;
-            decode_assoc(pd, assoc, p, i, j);
-            if (D.single) {
-                const double cosv = (Fc > 0) ? cosPool[pd.cosOff + (int64_t)i * pd.n2 + j] : 0.0;
-                s = single_score(D, feats + (pd.off1 + i) * D.F, feats + (pd.off2 + j) * D.F, cosv);
-            } else {
-                s = 1.0;
-            }
-            sT[p] = s;
-        }
-        cnt += __popcll(__ballot(s > 0.0));
+        cnt += __popcll(__ballot(p < p_end && sT[p] > 0.0));
     }
     if (lane == 0) wtot[w] = cnt;
     __syncthreads();
-    int base = 0, total = 0;
-    for (int k = 0; k < nw; ++k) { if (k < w) base += wtot[k]; total += wtot[k]; }
-    if (tid == 0) { st[b].L = total; st[b].nnzUpper = 0ull; }
+    int base = cbase[0];
+    for (int k = 0; k < w; ++k) base += wtot[k];
+    if (c == 0 && tid == 0) { st[b].L = cbase[1]; st[b].nnzUpper = 0ull; }
 
     const int64_t lo = pd.liveOff;
     for (int p0 = p_beg; p0 < p_end; p0 += WAVE) {

@@ -62,7 +62,7 @@ struct roman_ctx {
         bool issued = false;
         // pools (see DESIGN.md "Data layout in HBM")
         DevBuf probs, state, totals, queue;
-        DevBuf cosPool, normPool, tabPool, sTmp;
+        DevBuf cosPool, normPool, tabPool, sTmp, chunkCnt;
         DevBuf lp, li, lj, ls, lza, lzb;
         DevBuf rowCnt, rowPos, perm, sliceWidth, sliceBase, items, maskPool, prefPool;
         DevBuf vMu, vCu, vMun, vCun, gU, gUn, uOut, nodesOrig, nSel;
@@ -242,7 +242,7 @@ int stage_score(roman_ctx* c, const DevParams& D, const BatchIn& in, std::vector
     const int B = in.B;
     hd.assign(B, ProbDesc{});
     int64_t sumA = 0, sumCos = 0, sumTab = 0, sumN = 0;
-    int maxN12 = 0, maxTiles = 0, maxN = 0; int64_t maxTab = 0;
+    int maxN12 = 0, maxTiles = 0, maxN = 0, maxA = 0; int64_t maxTab = 0;
     for (int b = 0; b < B; ++b) {
         ProbDesc& d = hd[b];
         d.off1 = in.off1[b]; d.off2 = in.off2[b]; d.n1 = in.n1[b]; d.n2 = in.n2[b];
@@ -259,6 +259,7 @@ int stage_score(roman_ctx* c, const DevParams& D, const BatchIn& in, std::vector
             d.nA = (int32_t)na;
         }
         d.liveOff = sumA; d.cosOff = sumCos; d.tabOff = sumTab; d.normOff = sumN;
+        maxA = std::max(maxA, d.nA);
         sumA += d.nA; sumCos += (int64_t)d.n1 * d.n2; sumTab += (int64_t)d.n1 * d.n1 + (int64_t)d.n2 * d.n2; sumN += d.n1 + d.n2;
         maxN12 = std::max(maxN12, d.n1 + d.n2); maxN = std::max(maxN, std::max(d.n1, d.n2));
         maxTiles = std::max(maxTiles, ((d.n1 + COS_TILE - 1) / COS_TILE) * ((d.n2 + COS_TILE - 1) / COS_TILE));
@@ -305,8 +306,16 @@ int stage_score(roman_ctx* c, const DevParams& D, const BatchIn& in, std::vector
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_tables), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tabLds));
         hipLaunchKernelGGL(k_tables, dim3((unsigned)((maxN + 7) / 8), 2, B), dim3(256), tabLds, WS.stream, D, dP, in.feats, WS.tabPool.as<double>());
     }
-    hipLaunchKernelGGL(k_live, dim3(B), dim3(1024), 0, WS.stream, D, dP, dS, in.feats, in.assoc, WS.cosPool.as<double>(), WS.sTmp.as<double>(),
-                       WS.lp.as<int32_t>(), WS.li.as<int32_t>(), WS.lj.as<int32_t>(), WS.ls.as<double>(), WS.lza.as<double>(), WS.lzb.as<double>());
+    {   // single scores, then the ordered compaction of the live associations: chunks x problems
+        const int maxChunks = std::max(1, (maxA + LIVE_CHUNK - 1) / LIVE_CHUNK);
+        HIPCHK(c, WS.chunkCnt.ensure(sizeof(int32_t) * (size_t)B * (size_t)maxChunks));
+        hipLaunchKernelGGL(k_live<0>, dim3((unsigned)maxChunks, (unsigned)B), dim3(256), 0, WS.stream, D, dP, dS, in.feats, in.assoc, WS.cosPool.as<double>(), WS.sTmp.as<double>(),
+                           WS.chunkCnt.as<int32_t>(), maxChunks,
+                           WS.lp.as<int32_t>(), WS.li.as<int32_t>(), WS.lj.as<int32_t>(), WS.ls.as<double>(), WS.lza.as<double>(), WS.lzb.as<double>());
+        hipLaunchKernelGGL(k_live<1>, dim3((unsigned)maxChunks, (unsigned)B), dim3(256), 0, WS.stream, D, dP, dS, in.feats, in.assoc, WS.cosPool.as<double>(), WS.sTmp.as<double>(),
+                           WS.chunkCnt.as<int32_t>(), maxChunks,
+                           WS.lp.as<int32_t>(), WS.li.as<int32_t>(), WS.lj.as<int32_t>(), WS.ls.as<double>(), WS.lza.as<double>(), WS.lzb.as<double>());
+    }
     hipLaunchKernelGGL(k_rowbase, dim3(1), dim3(64), 0, WS.stream, B, RPB, dS, dT);
     hipLaunchKernelGGL(k_items, dim3(B), dim3(256), 0, WS.stream, RPB, dS, WS.items.as<ItemDesc>());
     // read-back #1 (24 bytes): live totals -> size of the candidate bit matrices, index width
@@ -726,7 +735,7 @@ int roman_ctx_destroy(roman_ctx_t* c)
         DevBuf* all[] = {&W.probs, &W.state, &W.totals, &W.queue, &W.cosPool, &W.normPool, &W.tabPool, &W.sTmp, &W.lp, &W.li, &W.lj, &W.ls, &W.lza, &W.lzb,
                          &W.rowCnt, &W.rowPos, &W.perm, &W.sliceWidth, &W.sliceBase, &W.items, &W.maskPool, &W.prefPool, &W.vMu, &W.vCu, &W.vMun, &W.vCun, &W.gU, &W.gUn,
                          &W.uOut, &W.nodesOrig, &W.nSel, &W.cols, &W.vals, &W.cols1, &W.vals1, &W.cols2, &W.vals2, &W.cols3, &W.vals3,
-                         &W.hFeats, &W.hAssoc, &W.hU0, &W.oAssoc, &W.oN, &W.oT, &W.oStatus, &W.oStats, &W.hAux1, &W.hAux2, &W.hAux3};
+                         &W.hFeats, &W.hAssoc, &W.hU0, &W.oAssoc, &W.oN, &W.oT, &W.oStatus, &W.oStats, &W.hAux1, &W.hAux2, &W.hAux3, &W.chunkCnt};
         for (DevBuf* b : all) b->release();
         if (W.pinnedTotals) (void)hipHostFree(W.pinnedTotals);
         for (int s = 0; s < ROMAN_STAGE_COUNT; ++s) { if (W.evA[s]) (void)hipEventDestroy(W.evA[s]); if (W.evB[s]) (void)hipEventDestroy(W.evB[s]); }
