@@ -161,6 +161,14 @@ def submap_align(sm_params, submaps, sm_io: Optional[SubmapAlignIO] = None, regi
     associated_objs_mat = [[[] for _ in range(n1)] for _ in range(n0)]
     total_time_t0 = time.time()
 
+    # ---- submap-descriptor gate: all S0 x S1 cosines in one device call when the descriptors are plain vectors
+    # (row f2; stacked descriptors and the CPU test double use the per-pair numpy form below) --------------------
+    sim_all = None
+    if sm_params.submap_descriptor is not None and compute is run_batch and n0 and n1:
+        descs = [[np.asarray(sm.descriptor) for sm in submaps[r]] for r in range(2)]
+        if all(d.ndim == 1 for r in range(2) for d in descs[r]):
+            sim_all = registration._context().cosine_matrix(np.stack(descs[0]), np.stack(descs[1]))
+
     # ---- pass 1: gating, reference transforms, the list of pairs to register ([REF :93-149]) -------------------
     todo = []                                            # (i, j, segs_i, segs_j)
     skipped_sim = []
@@ -184,7 +192,7 @@ def submap_align(sm_params, submaps, sm_io: Optional[SubmapAlignIO] = None, regi
             T_ij = np.linalg.inv(T_wi) @ T_wj
             if not np.isnan(robots_nearby_mat[i, j]):
                 submap_yaw_diff_mat[i, j] = np.abs(np.rad2deg(transform_to_xyzrpy(T_ij)[5]))
-            submap_sim = Submap.similarity(si, sj) if sm_params.submap_descriptor is not None else np.inf
+            submap_sim = np.inf if sm_params.submap_descriptor is None else (sim_all[i, j] if sim_all is not None else Submap.similarity(si, sj))
             T_ij_mat[i, j] = T_ij
             if submap_distance > sm_io.skip_distance:
                 clipper_num_associations[i, j] = 0

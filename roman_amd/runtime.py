@@ -240,6 +240,20 @@ class Context:
         return out
 
 
+    def cosine_matrix(self, A, B):
+        """Normalised cosine of every row of A (n1, d) with every row of B (n2, d) on the f64 matrix core (k_cos);
+        0 where a row has zero norm.  Used for the submap-descriptor gate of the pair loop."""
+        A, B = _f64(A), _f64(B)
+        if A.ndim != 2 or B.ndim != 2 or A.shape[1] != B.shape[1]:
+            raise ValueError("cosine_matrix needs two (n, d) matrices of the same d")
+        P = _abi.RomanParams.default()
+        P.cos_feature_dim = A.shape[1]
+        pad = lambda M: np.ascontiguousarray(np.hstack([np.zeros((M.shape[0], P.point_dim)), M]))     # [xyz | descriptor]
+        if A.shape[0] == 0 or B.shape[0] == 0:
+            return np.zeros((A.shape[0], B.shape[0]))
+        return self.debug_cosine(P, pad(A), pad(B))
+
+
 _DEFAULT_CTX = None
 
 

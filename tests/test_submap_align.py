@@ -173,3 +173,17 @@ def test_similarity_and_helpers():
     assert sa.aabb_intersects(np.array([[0, 0, 0], [1, 1, 1.0]]), np.array([[1, 1, 1], [2, 2, 2.0]]))
     assert not sa.aabb_intersects(np.array([[0, 0, 0], [1, 1, 1.0]]), np.array([[1.1, 0, 0], [2, 2, 2.0]]))
     assert sa.nearest_index([0.0, 0.5, 1.0], 0.7) == 1
+
+
+@pytest.mark.gpu
+def test_device_descriptor_gate_matches_pairwise_similarity():
+    """Row f2: the S0 x S1 submap-descriptor cosines of one device call against Submap.similarity per pair."""
+    from roman_amd.runtime import default_context
+    rng = np.random.default_rng(5)
+    A = rng.standard_normal((7, 48)); B = rng.standard_normal((5, 48))
+    A[3] = 0.0                                           # a zero descriptor: similarity 0 by the guard
+    S = default_context().cosine_matrix(A, B)
+    for i in range(7):
+        for j in range(5):
+            ref = sa.Submap.similarity(sa.Submap(0, 0.0, [], np.eye(4), descriptor=A[i]), sa.Submap(1, 0.0, [], np.eye(4), descriptor=B[j]))
+            assert abs(S[i, j] - ref) < 1e-12
