@@ -147,6 +147,34 @@ def test_full_size_properties_cfg2_cfg3(ctx):
     assert np.linalg.norm(rp.T[0] - res.T[1]) < 1e-9
 
 
+def test_full_size_properties_cfg4_submap_grid(ctx):
+    """BASELINE config 4 shape (cross pairs of two robots' submaps, n=200, d=512, one shared feature pool):
+    poses agree with the generator's ground truth and compose consistently, T_ij = T_ik T_kj^-1... checked as
+    T(a,c) ~ T(a,b) T(b,c) through a third submap; every submap is packed once."""
+    reg = registration_for("semanticgrav", semantics_dim=512); reg.set_context(ctx)
+    S = 6
+    subs, poses = synth.make_submap_grid(2 * S, n=200, d=512, seed0=4000)
+    batch = rb.batch_from_submap_grid(reg, subs[:S], subs[S:])
+    assert len(batch) == S * S and batch.feats.shape[0] == 2 * S * 200
+    res = rb.run_batch(reg, batch)
+    T = {}
+    for b, (i, j) in enumerate(batch.pair_index):
+        assert res.status[b] == 0
+        a = res.assoc[b]
+        assert len(a) >= 60 and len(set(a[:, 0].tolist())) == len(a) == len(set(a[:, 1].tolist()))
+        T_gt = np.linalg.inv(poses[i]) @ poses[S + j]                     # map 2 (robot-1 submap j) -> map 1 (robot-0 submap i)
+        assert np.linalg.norm(res.T[b][:3, :3] - T_gt[:3, :3]) < 0.03 and np.linalg.norm(res.T[b][:3, 3] - T_gt[:3, 3]) < 0.15
+        T[(int(i), int(j))] = res.T[b]
+    # composition through another pair of submaps: T(i,j) T(i',j)^-1 T(i',j') ~ T(i,j')
+    for (i, j, i2, j2) in [(0, 0, 1, 1), (2, 3, 4, 5), (5, 1, 0, 4)]:
+        lhs = T[(i, j)] @ np.linalg.inv(T[(i2, j)]) @ T[(i2, j2)]
+        assert np.linalg.norm(lhs - T[(i, j2)]) < 0.3
+    # the same pairs as independent problems (each submap packed per pair) give bit-identical results
+    solo = reg.register_and_align_batch([(subs[0], subs[S + 1]), (subs[3], subs[S + 2])])
+    assert np.array_equal(solo.assoc[0], res.assoc[0 * S + 1]) and np.array_equal(solo.T[0], res.T[0 * S + 1])
+    assert np.array_equal(solo.assoc[1], res.assoc[3 * S + 2]) and np.array_equal(solo.T[1], res.T[3 * S + 2])
+
+
 def test_large_live_set_uses_global_u_path(ctx, orc):
     """L = 150*150 = 22500 live associations exceed the LDS-resident vectors: same results."""
     reg = registration_for("clipper"); reg.set_context(ctx)
