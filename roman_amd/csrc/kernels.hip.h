@@ -1844,7 +1844,7 @@ __global__ void __launch_bounds__(1024) k_solve(DevParams D, int B, const ProbDe
 // ---------------------------------------------------------------------------------------------
 constexpr int ST_NW = 8;                 // waves per problem
 constexpr int ST_NS = 6;                 // max row slots (slices) per wave; the kernel is instantiated for 4, 5 and 6
-constexpr int ST_D = 6;                  // quads in flight per lane
+constexpr int ST_D = 3;                  // quads in flight per lane (measured: 2-4 beat 6-8, for a lone problem as well as for 256)
 constexpr int ST_MAXSL = ST_NW * ST_NS;  // 48 slices -> L <= 3072
 constexpr int ST_PB = ST_MAXSL + ST_NW;  // LDS partial slots
 constexpr int ST_CQ = ST_MAXSL + 1;      // entries of a quad-prefix row
