@@ -283,7 +283,7 @@ int stage_score(roman_ctx* c, const DevParams& D, const BatchIn& in, std::vector
     HIPCHK(c, WS.sliceWidth.ensure(sizeof(uint32_t) * nA1)); HIPCHK(c, WS.sliceBase.ensure(sizeof(uint32_t) * nA1));
     // work items: blocks of RPB consecutive live rows of one problem (more, smaller items for small batches)
     int RPB = 32;
-    while (RPB < 256 && (int64_t)RPB * c->num_cu * 64 < sumA) RPB <<= 1;
+    while (RPB < 128 && (int64_t)RPB * c->num_cu * 64 < sumA) RPB <<= 1;     // 128: ~17 items per problem balance the static item loop best (measured 32..1024)
     const size_t maxItems = (size_t)(sumA / RPB) + (size_t)B + 1;
     HIPCHK(c, WS.items.ensure(sizeof(ItemDesc) * maxItems));
 
