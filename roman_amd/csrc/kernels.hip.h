@@ -534,7 +534,7 @@ __device__ __forceinline__ void count_rows_lds(const DevParams& D, const ProbDes
     const int W = (L + 63) >> 6;
     const char* tbytes = reinterpret_cast<const char*>(tA);
     const int sliceBytes = ldsPerRow * 8;
-    constexpr int U = 4;                                        // column chunks per step
+    constexpr int U = 2;                                        // column chunks per step (with 2 rows per wave: 2 beats 1 and 4)
     const int Lpad = (L + U * WAVE - 1) & ~(U * WAVE - 1);
     // Rows are columns too: their objects and z come from the LDS column tile.  The table rows of the NEXT
     // rows are fetched into registers while the current ones are swept (maps of up to 256 objects; larger ones
