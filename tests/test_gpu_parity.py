@@ -34,6 +34,9 @@ LADDER = [  # (id, method, kwargs, n, m, d, seed)
     ("words2_9x10", "gravity", {}, 9, 10, 0, 33),
     ("words3_12x14", "clipper", {}, 12, 14, 0, 34),
     ("dense45", "clipper", {"epsilon": 1.5, "sigma": 0.8}, 45, 45, 0, 31),
+    # maps of more than 256 objects: one table slice per wave in the pair tests (no second row), table rows loaded
+    # without the register prefetch, and a live set beyond the streaming solver's size (SELL-64 fill and solver)
+    ("maps300", "semanticgrav", {"semantics_dim": 32, "cosine_min": 0.6, "cosine_max": 0.8}, 300, 300, 32, 41),
 ]
 
 
