@@ -92,5 +92,29 @@ class ROMANRegistration(ObjectRegistration):
             object_as_list += np.array(object.semantic_descriptor).tolist()
         return object_as_list
 
+    def pack(self, object_map):
+        """Same (n, F) matrix as the per-object lists above, assembled column block by column block (the list form
+        costs ~60 us per object with a 512-d descriptor: 1.5 s for the 128 submaps of a 64 x 64 grid, 30x the device
+        time of its 4096 alignments)."""
+        n = len(object_map)
+        if n == 0:
+            return super().pack(object_map)
+        try:
+            blocks = [np.stack([np.asarray(o.center, dtype=np.float64).reshape(-1)[:self.dim] for o in object_map])]
+            if self.pca:
+                blocks.append(np.array([[o.linearity, o.planarity, o.scattering] for o in object_map], dtype=np.float64))
+            if self.volume:
+                blocks.append(np.array([[o.volume] for o in object_map], dtype=np.float64))
+            if self.extent:
+                blocks.append(np.array([sorted(o.extent) for o in object_map], dtype=np.float64))
+            if self.semantics:
+                blocks.append(np.stack([np.asarray(o.semantic_descriptor, dtype=np.float64).reshape(-1) for o in object_map]))
+            out = np.ascontiguousarray(np.hstack(blocks))
+            if out.shape != (n, self._abi_params().feature_dim()):
+                raise ValueError("feature width")
+            return out
+        except (ValueError, TypeError):
+            return super().pack(object_map)          # ragged input: let the generic path raise what it always raised
+
     def _check_clipper_arrays(self, map1_cl, map2_cl):
         assert map1_cl.shape[1] == map2_cl.shape[1]

@@ -127,3 +127,20 @@ def test_synthetic_generator_is_deterministic_and_well_formed():
     assert abs(np.linalg.norm(a.map1[0].semantic_descriptor) - 1.0) < 1e-12
     subs, poses = synth.make_submap_grid(3, n=20, d=4, seed0=5)
     assert len(subs) == 3 and all(len(s) == 20 for s in subs) and poses[0].shape == (4, 4)
+
+
+def test_vectorised_pack_equals_the_per_object_lists():
+    """ROMANRegistration.pack assembles column blocks; it must be the very matrix the reference builds row by row."""
+    from conftest import registration_for
+    from roman_amd.align.object_registration import ObjectRegistration
+    for method, kw, d in [("semanticgrav", {"semantics_dim": 40}, 40), ("roman", {"semantics_dim": 24}, 24),
+                          ("sevg", {"semantics_dim": 16}, 16), ("pcavolgrav", {}, 0), ("clipper", {"dim": 2}, 0)]:
+        reg = registration_for(method, **kw)
+        subs, _ = synth.make_submap_grid(3, n=17, d=d, seed0=77)
+        if kw.get("dim") == 2:
+            for sm in subs:
+                for o in sm:
+                    o.centroid = o.centroid[:2]; o.dim = 2
+        for sm in subs + [[]]:
+            a, b = reg.pack(sm), ObjectRegistration.pack(reg, sm)
+            assert a.dtype == b.dtype and a.shape == b.shape and np.array_equal(a, b) and a.flags.c_contiguous
