@@ -147,6 +147,24 @@ def test_full_size_properties_cfg2_cfg3(ctx):
     assert np.linalg.norm(rp.T[0] - res.T[1]) < 1e-9
 
 
+def test_rigid_motion_of_map2_composes_with_the_pose(ctx):
+    """Full size (n=m=200, d=512): a gravity-preserving rigid motion G of map 2 (yaw + translation) leaves every
+    intra-map distance and height difference unchanged up to rounding, so the inlier set stays (almost) the same
+    and the estimated pose composes: T(map1 <- G map2) = T(map1 <- map2) G^-1."""
+    import copy
+    reg = registration_for("semanticgrav", semantics_dim=512); reg.set_context(ctx)
+    pr = synth.make_pair(200, 200, 512, 3001)
+    G = synth.yaw_transform(1.1, [4.0, -7.0, 0.8])
+    moved = copy.deepcopy(pr.map2)
+    for o in moved:
+        o.centroid = (G[:3, :3] @ o.centroid.reshape(3, 1) + G[:3, 3:4])
+    res = reg.register_and_align_batch([(pr.map1, pr.map2), (pr.map1, moved)])
+    assert res.status[0] == 0 and res.status[1] == 0
+    a0, a1 = set(map(tuple, res.assoc[0].tolist())), set(map(tuple, res.assoc[1].tolist()))
+    assert len(a0 ^ a1) <= 2
+    assert np.linalg.norm(res.T[1] @ G - res.T[0]) < 1e-6 + 0.05 * (len(a0 ^ a1) > 0)
+
+
 def test_full_size_properties_cfg4_submap_grid(ctx):
     """BASELINE config 4 shape (cross pairs of two robots' submaps, n=200, d=512, one shared feature pool):
     poses agree with the generator's ground truth and compose consistently, T_ij = T_ik T_kj^-1... checked as
