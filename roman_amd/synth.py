@@ -206,6 +206,8 @@ ALIGN_SCENARIOS = {
                                force_fill_submaps=True, epsilon_shape=0.1, force_rm_lc_roll_pitch=False),
                           dict(), dict(d=0, n=26, shared_ids=True)),
     "prune": (dict(method="clipper+prune", cosine_min=0.5, epsilon_shape=0.05), dict(), dict(d=24, n=22)),
+    "stacked_descriptors": (dict(method="semanticgrav", semantics_dim=12, submap_descriptor="stacked_frame_descriptors",
+                                 submap_descriptor_thresh=0.6), dict(), dict(d=12, n=20, stacked=True)),
 }
 
 
@@ -239,6 +241,11 @@ def make_align_scenario(name, seed0=7100):
                 desc = place + 0.45 * rng.standard_normal(opt["d"]) / np.sqrt(opt["d"])
                 if r == 1 and k == 0:
                     desc = rng.standard_normal(opt["d"])               # an unrelated place: the descriptor gate fires
+                if opt.get("stacked"):                                 # several frame descriptors per submap: best pairwise cosine
+                    rows = [desc] + [rng.standard_normal(opt["d"]) for _ in range(1 + (k + r) % 3)]
+                    if k == 2:
+                        rows.append(np.zeros(opt["d"]))                # a zero row is ignored by the similarity
+                    desc = np.stack(rows)
             rob.append(dict(id=k, time=100.0 * r + 30.0 * k + 0.25 * (k + 1), segments=segs,
                             pose_flu=T_odom @ tilt, pose_flu_gt=T_gt @ tilt, descriptor=desc))
             s += 1
