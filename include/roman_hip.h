@@ -69,6 +69,27 @@ extern "C" {
 #define ROMAN_FUSE_ARITHMETIC_MEAN 1
 #define ROMAN_FUSE_PRODUCT         2
 
+/* The two formulas of the ROMAN invariant that live only in the absent clipperpy sources (SURVEY.md
+   Appendix B7, DESIGN.md decisions H2 and H3) are SWITCHES, not hard-wired guesses: 0 is the pinned
+   default, the other values are the alternative readings.  The reference never sets them
+   ([REF roman/align/roman_registration.py:55-78] lists every attribute it assigns); they exist so that a
+   build that can import the real clipperpy can find the reading that reproduces it
+   (tests/test_real_clipperpy.py).  With d = displacement between the two objects of a map, h = its
+   horizontal length, v = its signed vertical component, l = its full length, unc = gravity_unc_ang_rad:
+     ROMAN_GRAV_COMBINED  ch=|h1-h2|, cv=max(0,|v1-v2|-sin(unc)*max(h1,h2)), c=sqrt(ch^2+cv^2); c<epsilon; exp(-c^2/2sigma^2)
+     ROMAN_GRAV_SEPARATE  same ch, cv, c; each part gated on its own: ch<epsilon AND cv<epsilon
+     ROMAN_GRAV_ZGATE     c=|l1-l2| as for EuclideanDistance, plus the hard gate |v1-v2| < epsilon+sin(unc)*max(l1,l2) */
+#define ROMAN_GRAV_COMBINED 0
+#define ROMAN_GRAV_SEPARATE 1
+#define ROMAN_GRAV_ZGATE    2
+/*   ROMAN_SINGLE_BOTH     M_pq = fuse(s_a(p,q), s_o(p), s_o(q)), M_pp = s_o(p)
+     ROMAN_SINGLE_OFFDIAG  M_pq fused as above, M_pp = 1 (plain CLIPPER's implicit identity)
+     ROMAN_SINGLE_DIAG     M_pq = s_a(p,q), M_pp = s_o(p)
+   In every mode an association whose single score is 0 is removed from the problem. */
+#define ROMAN_SINGLE_BOTH    0
+#define ROMAN_SINGLE_OFFDIAG 1
+#define ROMAN_SINGLE_DIAG    2
+
 /*
  * Invariant + solver parameters.  Replaces clipperpy.invariants.ROMANParams /
  * EuclideanDistanceParams (attributes set at [REF roman/align/roman_registration.py:55-78],
@@ -105,7 +126,10 @@ typedef struct roman_params {
     int32_t maxiniters;           /* 200   */
     int32_t maxoliters;           /* 1000  */
     int32_t maxlsiters;           /* 99    */
-    int32_t reserved;
+    /* decision switches (see ROMAN_GRAV_*, ROMAN_SINGLE_* above); 0 = the pinned default */
+    int32_t gravity_mode;         /* ROMAN_GRAV_*   : reading of the gravity-guided pair score (H2)   */
+    int32_t single_mode;          /* ROMAN_SINGLE_* : where single scores enter M (H3)                */
+    int32_t reserved;             /* must be 0                                                        */
 } roman_params_t;
 
 /* per-problem statistics (the quantities SURVEY.md §8(d) builds the roofline from) */
@@ -191,7 +215,11 @@ ROMAN_API const char* roman_last_error(const roman_ctx_t* ctx);
  *   n1/n2      HOST, int32[B]: objects in map 1 / map 2 of problem b
  *   F          features per object = point_dim + ratio_feature_dim + cos_feature_dim
  *   assoc      DEVICE, int32 (sum A_b, 2) or NULL (= all-to-all for every problem)
- *   assoc_off  HOST, int64[B+1] row offsets into assoc (ignored when assoc == NULL)
+ *   assoc_off  HOST, int64[B+1] row offsets into assoc (ignored when assoc == NULL), non-decreasing from 0;
+ *              a problem whose list is EMPTY is scored all-to-all, as clipperpy does with an empty A
+ *              (the reference reaches that case when its prefilter prunes everything,
+ *              [REF roman/align/dist_reg_with_pruning.py:94-96]).  Rows must satisfy 0 <= i < n1, 0 <= j < n2:
+ *              the host-pointer entry below checks them, this one cannot (device memory) and trusts the caller
  *   u0         DEVICE, float64 initial vectors, concatenated per problem in association order,
  *              or NULL (= all ones; DESIGN.md decision H1)
  *   kmax       capacity (rows) of each problem's slot in assoc_out
@@ -240,7 +268,7 @@ ROMAN_API int roman_create_all_to_all(int32_t n1, int32_t n2, int32_t* out);
 /* score_pairwise_consistency / score_pairwise_and_single_consistency
    [REF roman/align/object_registration.py:47], [REF roman/align/roman_registration.py:95]:
    builds M (and C, which has M's pattern) for ONE problem on the device and keeps it in the
-   context.  assoc may be NULL (all-to-all). */
+   context.  assoc may be NULL, or n_assoc 0 (all-to-all). */
 ROMAN_API int roman_score(roman_ctx_t* ctx, const roman_params_t* params,
                 const double* D1, int32_t n1, const double* D2, int32_t n2, int32_t F,
                 const int32_t* assoc, int32_t n_assoc);
@@ -302,9 +330,10 @@ ROMAN_API int roman_profile_get(roman_ctx_t* ctx, double ms[ROMAN_STAGE_COUNT],
                       int64_t launches[ROMAN_STAGE_COUNT]);
 
 /* Diagnostics for tests: evaluate a device math primitive elementwise (host pointers).
-   kind 0: sqrt(x)  1: exp(x)  2: cbrt(x)  3: x/y (y = in2)  4: pow(x,y).  Used to check that
-   the device's +,-,*,/,sqrt are bit-identical to the host's (pattern parity) and to measure
-   the ulp distance of the transcendental functions. */
+   kind 0: sqrt(x)  1: exp(x)  2: cbrt(x)  3: x/y (y = in2)  4: pow(x,y)  5: the library's fixed-sequence
+   exp  6: its fixed-sequence cbrt  7: fma(x,y,x).  Used to check that the device's +,-,*,/,sqrt,fma and the
+   two fixed-sequence functions are bit-identical to the host's (pattern parity) and to
+   measure the ulp distance of the device's libm. */
 ROMAN_API int roman_debug_math(roman_ctx_t* ctx, int kind, const double* in1, const double* in2,
                      int64_t n, double* out);
 /* Diagnostics for tests: normalised cosine matrix (n1 x n2, row-major) of the cosine-feature

@@ -27,9 +27,16 @@
  * restatement that IS pinned against the reference's own function (tests/golden/).
  *
  * Build: see oracle/Makefile (gcc -O2 -fopenmp -ffp-contract=off).  -ffp-contract=off matters:
- * the sparsity pattern of M is decided by +,-,*,sqrt and comparisons only, which are exactly
- * rounded on both CPU and gfx950, so the HIP path can (and is tested to) reproduce the pattern
- * bit for bit.
+ * every quantity a threshold is applied to is produced by +,-,*,/,sqrt,fma and comparisons only,
+ * which are correctly rounded on both the host and gfx950, IN A STATED ORDER:
+ *   - the descriptor dot product and norms are accumulated in the fixed order documented at
+ *     dot_fixed()/norm_fixed() (any fixed order is as legitimate as the sequential one: upstream's
+ *     Eigen reductions are vectorised in an order this tree does not record);
+ *   - exp and cbrt are evaluated by the explicit algorithms oracle_exp()/oracle_cbrt() (< 1 ulp,
+ *     checked against glibc in tests/test_oracle_math.py) instead of libm, because the
+ *     `score > affinityeps` gate is applied AFTER them.
+ * oracle_set_arith(1) switches to the plain restatement (sequential dot, glibc exp/cbrt) so that
+ * tests can show that no fixture's pattern or selection depends on the choice.
  */
 #include <math.h>
 #include <stdint.h>
@@ -43,6 +50,119 @@
 #include "../include/roman_hip.h"   /* roman_params_t / roman_stats_t only (interface structs) */
 
 #define ORACLE_API __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------------------------------ */
+/* stated-order arithmetic                                                                    */
+/* ------------------------------------------------------------------------------------------ */
+static int g_plain_arith = 0;     /* 0: stated-order dot + oracle_exp/oracle_cbrt; 1: sequential dot + libm */
+ORACLE_API void oracle_set_arith(int plain) { g_plain_arith = plain ? 1 : 0; }
+ORACLE_API int oracle_get_arith(void) { return g_plain_arith; }
+
+static inline double from_bits(uint64_t b) { double d; memcpy(&d, &b, 8); return d; }
+static inline uint64_t to_bits(double d) { uint64_t b; memcpy(&b, &d, 8); return b; }
+
+/*
+ * exp(y), |error| < 1 ulp.  Fixed sequence of correctly-rounded operations:
+ *   k = rint(y*log2e); r1 = fma(-k, ln2_hi, y) (exact); rl = -k*ln2_lo; r = r1 + rl; r_err = (r1 - r) + rl     |r| <= 0.347
+ *   q = Horner in r of 1/2!, 1/3!, ..., 1/13! (fma chain, highest degree first)
+ *   a = 1 + r; a_err = (r - (a - 1)) + r_err;  result = (a + fma(r*r, q, a_err)) * 2^k
+ * Outside (-700, 700) (never produced by the path: y = -c^2/(2 sigma^2), c < epsilon) libm answers.
+ */
+ORACLE_API double oracle_exp(double y)
+{
+    if (!(y > -700.0 && y < 700.0)) return exp(y);
+    static const double LOG2E = 0x1.71547652b82fep+0, LN2_HI = 0x1.62e42fee00000p-1, LN2_LO = 0x1.a39ef35793c76p-33;
+    static const double INVFACT[12] = {          /* 1/2! .. 1/13! */
+        0.5, 0x1.5555555555555p-3, 0x1.5555555555555p-5, 0x1.1111111111111p-7, 0x1.6c16c16c16c17p-10,
+        0x1.a01a01a01a01ap-13, 0x1.a01a01a01a01ap-16, 0x1.71de3a556c734p-19, 0x1.27e4fb7789f5cp-22,
+        0x1.ae64567f544e4p-26, 0x1.1eed8eff8d898p-29, 0x1.6124613a86d09p-33 };
+    const double k = rint(y * LOG2E);
+    const double r1 = fma(-k, LN2_HI, y);              /* exact */
+    const double rl = -k * LN2_LO;
+    const double r = r1 + rl;
+    const double r_err = (r1 - r) + rl;                 /* what the rounding of r dropped */
+    double q = INVFACT[11];
+    for (int i = 10; i >= 0; --i) q = fma(q, r, INVFACT[i]);
+    const double a = 1.0 + r;
+    const double a_err = (r - (a - 1.0)) + r_err;       /* 1 + r1 + rl == a + a_err (to ~2^-105) */
+    const double p = a + fma(r * r, q, a_err);
+    return p * from_bits((uint64_t)(1023 + (int)k) << 52);
+}
+
+/*
+ * cbrt(x) for normal x > 0, |error| < 1 ulp.  Fixed sequence of correctly-rounded operations:
+ *   x = m * 2^(3q), m in [1,8)                                  (exponent arithmetic, exact)
+ *   y ~ m^(-1/3): cubic initial guess, 4 Newton steps y <- (y * (4 - m y^3)) * (1/3)   (no division)
+ *   t = m*(y*y); residual r = m - t^3 with the square's rounding error carried (two fma);
+ *   t <- fma(r, (y*y)*(1/3), t); result = t * 2^q
+ * Other arguments (zero, negative, subnormal, non-finite: never produced by the path) go to libm.
+ */
+ORACLE_API double oracle_cbrt(double x)
+{
+    const uint64_t b = to_bits(x);
+    const int E = (int)((b >> 52) & 0x7ff);
+    if (!(x > 0.0) || E == 0 || E == 0x7ff) return cbrt(x);
+    static const double C0 = 0x1.331e76e38c2bfp+0, C1 = -0x1.142641324f5d9p-2, C2 = 0x1.49dcf893faf42p-5, C3 = -0x1.2190c96665e59p-9;
+    static const double THIRD = 0x1.5555555555555p-2;
+    const int e = E - 1023;
+    const int q = (e >= 0) ? e / 3 : -((2 - e) / 3);       /* floor(e/3) */
+    const int rem = e - 3 * q;                              /* 0, 1, 2    */
+    const double m = from_bits((b & 0x000fffffffffffffULL) | ((uint64_t)(1023 + rem) << 52));
+    double y = fma(fma(fma(C3, m, C2), m, C1), m, C0);
+    for (int it = 0; it < 4; ++it) {
+        const double y2 = y * y, y3 = y2 * y;
+        const double w = fma(-m, y3, 4.0);
+        y = (y * w) * THIRD;
+    }
+    const double yy = y * y;
+    double t = m * yy;
+    const double t2 = t * t, e2 = fma(t, t, -t2);
+    const double r = fma(-e2, t, fma(-t2, t, m));
+    t = fma(r, yy * THIRD, t);
+    return t * from_bits((uint64_t)(1023 + q) << 52);
+}
+
+static inline double x_exp(double y) { return g_plain_arith ? exp(y) : oracle_exp(y); }
+static inline double x_cbrt(double x) { return g_plain_arith ? cbrt(x) : oracle_cbrt(x); }
+
+/*
+ * Stated-order dot product of two descriptors of length d (the order the device's f64 matrix-core
+ * contraction uses): one accumulator, elements visited chunk by chunk of 16, inside a
+ * chunk in the order k = k0 + 4*g + t for t = 0..3 (outer), g = 0..3 (inner), each step one fma.
+ * Plain mode: the sequential order k = 0..d-1 with a rounded product and a rounded add.
+ */
+static double dot_fixed(const double* a, const double* b, int d)
+{
+    double acc = 0.0;
+    if (g_plain_arith) { for (int k = 0; k < d; ++k) acc += a[k] * b[k]; return acc; }
+    for (int k0 = 0; k0 < d; k0 += 16)
+        for (int t = 0; t < 4; ++t)
+            for (int g = 0; g < 4; ++g) {
+                const int k = k0 + 4 * g + t;
+                if (k < d) acc = fma(a[k], b[k], acc);
+            }
+    return acc;
+}
+/* Stated-order squared norm: four fma chains (chain g takes the elements k0 + 4g + t, t = 0..3, of every
+ * chunk of 16, in ascending order), combined as (s0 + s1) + (s2 + s3). */
+static double norm_fixed(const double* a, int d)
+{
+    if (g_plain_arith) { double s = 0.0; for (int k = 0; k < d; ++k) s += a[k] * a[k]; return sqrt(s); }
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int k0 = 0; k0 < d; k0 += 16)
+        for (int g = 0; g < 4; ++g)
+            for (int t = 0; t < 4; ++t) {
+                const int k = k0 + 4 * g + t;
+                if (k < d) s[g] = fma(a[k], a[k], s[g]);
+            }
+    return sqrt((s[0] + s[1]) + (s[2] + s[3]));
+}
+/* test hook: the normalised cosine of two descriptors exactly as oracle_single_scores computes it */
+ORACLE_API double oracle_cosine(const double* a, const double* b, int d)
+{
+    const double na = norm_fixed(a, d), nb = norm_fixed(b, d);
+    return (na > 0.0 && nb > 0.0) ? dot_fixed(a, b, d) / (na * nb) : 0.0;
+}
 
 /* ------------------------------------------------------------------------------------------ */
 /* utils                                                                                      */
@@ -84,21 +204,13 @@ static double root_w(double x, double w)
 {
     if (w == 1.0) return x;
     if (w == 2.0) return sqrt(x);
-    if (w == 3.0) return cbrt(x);
-    return pow(x, 1.0 / w);
+    if (w == 3.0) return x_cbrt(x);
+    return pow(x, 1.0 / w);        /* non-integer weights: libm pow (values then agree with the device to a few ulp only) */
 }
 static double pow_w(double x, double w)
 {
     if (w == 1.0) return x;
     return pow(x, w);
-}
-
-/* Euclidean norm of the cosine-feature block of one object (sequential sum). */
-static double desc_norm(const double* f, int off, int d)
-{
-    double s = 0.0;
-    for (int k = 0; k < d; ++k) s += f[off + k] * f[off + k];
-    return sqrt(s);
 }
 
 /*
@@ -160,8 +272,8 @@ ORACLE_API int oracle_single_scores(const roman_params_t* P, const double* D1, i
     if (Fc > 0) {
         nr1 = (double*)malloc(sizeof(double) * (n1 > 0 ? n1 : 1));
         nr2 = (double*)malloc(sizeof(double) * (n2 > 0 ? n2 : 1));
-        for (int32_t i = 0; i < n1; ++i) nr1[i] = desc_norm(D1 + (int64_t)i * F, off, Fc);
-        for (int32_t j = 0; j < n2; ++j) nr2[j] = desc_norm(D2 + (int64_t)j * F, off, Fc);
+        for (int32_t i = 0; i < n1; ++i) nr1[i] = norm_fixed(D1 + (int64_t)i * F + off, Fc);
+        for (int32_t j = 0; j < n2; ++j) nr2[j] = norm_fixed(D2 + (int64_t)j * F + off, Fc);
     }
 #pragma omp parallel for schedule(static)
     for (int32_t p = 0; p < nA; ++p) {
@@ -169,8 +281,7 @@ ORACLE_API int oracle_single_scores(const roman_params_t* P, const double* D1, i
         const double* fi = D1 + (int64_t)i * F; const double* fj = D2 + (int64_t)j * F;
         double cosv = 0.0;
         if (Fc > 0) {
-            double dot = 0.0;
-            for (int k = 0; k < Fc; ++k) dot += fi[off + k] * fj[off + k];
+            const double dot = dot_fixed(fi + off, fj + off, Fc);
             cosv = (nr1[i] > 0.0 && nr2[j] > 0.0) ? dot / (nr1[i] * nr2[j]) : 0.0;
         }
         s_out[p] = single_score(P, fi, fj, cosv);
@@ -208,17 +319,30 @@ static double pair_score(const roman_params_t* P, const pair_consts_t* K,
     if (P->mindist > 0.0 && (l1 < P->mindist || l2 < P->mindist)) return 0.0;
     double c;
     if (P->invariant == ROMAN_INV_ROMAN && P->gravity_guided) {
-        const double h1 = sqrt(ha2), h2 = sqrt(hb2);
-        const double ch = fabs(h1 - h2);
-        const double hm = h1 > h2 ? h1 : h2;
-        double cv = fabs(dza - dzb) - K->sin_unc * hm;
-        if (cv < 0.0) cv = 0.0;
-        c = sqrt(ch * ch + cv * cv);
+        if (P->gravity_mode == ROMAN_GRAV_ZGATE) {
+            /* reading 2: the EuclideanDistance score on the full lengths plus a hard gate on the vertical offsets */
+            c = fabs(l1 - l2);
+            const double lm = l1 > l2 ? l1 : l2;
+            if (!(c < P->epsilon)) return 0.0;
+            if (!(fabs(dza - dzb) < P->epsilon + K->sin_unc * lm)) return 0.0;
+        } else {
+            const double h1 = sqrt(ha2), h2 = sqrt(hb2);
+            const double ch = fabs(h1 - h2);
+            const double hm = h1 > h2 ? h1 : h2;
+            double cv = fabs(dza - dzb) - K->sin_unc * hm;
+            if (cv < 0.0) cv = 0.0;
+            c = sqrt(ch * ch + cv * cv);
+            if (P->gravity_mode == ROMAN_GRAV_SEPARATE) {          /* reading 1: each part gated on its own */
+                if (!(ch < P->epsilon && cv < P->epsilon)) return 0.0;
+            } else {                                               /* reading 0 (default): one gate on c    */
+                if (!(c < P->epsilon)) return 0.0;
+            }
+        }
     } else {
         c = fabs(l1 - l2);
+        if (!(c < P->epsilon)) return 0.0;
     }
-    if (!(c < P->epsilon)) return 0.0;
-    return exp(((-0.5 * c) * c) / K->sig2);
+    return x_exp(((-0.5 * c) * c) / K->sig2);
 }
 
 /* DECISION H3 (fusion of pair and single scores): off-diagonal
@@ -226,11 +350,14 @@ static double pair_score(const roman_params_t* P, const pair_consts_t* K,
  *   (s_a^wd * (s_o(p)*s_o(q)))^(1/(wd+2));  ARITHMETIC_MEAN: (wd*s_a + s_o(p)+s_o(q))/(wd+2)
  *   with any zero factor forcing 0;  PRODUCT: s_a*(s_o(p)*s_o(q)).
  *   When the invariant has no single features (method 'clipper'/'gravity') M_pq = s_a.
- *   The product s_o(p)*s_o(q) is formed first so the result is bitwise symmetric in (p,q). */
+ *   The product s_o(p)*s_o(q) is formed first so the result is bitwise symmetric in (p,q).
+ *   single_mode (roman_hip.h) selects the alternative readings: OFFDIAG keeps this fusion but an identity
+ *   diagonal, DIAG keeps M_pq = s_a and puts the single scores on the diagonal only. */
 static double fuse_pair(const roman_params_t* P, int single, double sa, double sp, double sq)
 {
     if (!single) return sa;
     if (sa == 0.0 || sp == 0.0 || sq == 0.0) return 0.0;
+    if (P->single_mode == ROMAN_SINGLE_DIAG) return sa;       /* single scores on the diagonal only */
     const double ss = sp * sq, wd = P->distance_weight;
     switch (P->fusion_method) {
     case ROMAN_FUSE_ARITHMETIC_MEAN: return (wd * sa + (sp + sq)) / (wd + 2.0);
@@ -251,12 +378,13 @@ typedef struct {
     double*  vals;     /* nnz                                                   */
     uint8_t* czero;    /* nnz or NULL: 1 where C_pq == 0 although stored (set_matrix_data only) */
     double*  diag;     /* n: M_pp (1 = implicit identity for EUCLIDEAN)         */
+    uint8_t* live;     /* n: 0 where the single score is 0 (association removed) */
 } oracle_mat_t;
 
 ORACLE_API void oracle_mat_free(oracle_mat_t* m)
 {
     if (!m) return;
-    free(m->rowptr); free(m->cols); free(m->vals); free(m->czero); free(m->diag); free(m);
+    free(m->rowptr); free(m->cols); free(m->vals); free(m->czero); free(m->diag); free(m->live); free(m);
 }
 ORACLE_API int32_t oracle_mat_n(const oracle_mat_t* m) { return m->n; }
 ORACLE_API int64_t oracle_mat_nnz(const oracle_mat_t* m) { return m->nnz; }
@@ -291,8 +419,13 @@ ORACLE_API oracle_mat_t* oracle_build(const roman_params_t* P, const double* D1,
     m->rowptr = (int64_t*)calloc((size_t)nA + 1, sizeof(int64_t));
     m->diag = (double*)malloc(sizeof(double) * (nA > 0 ? nA : 1));
     const int single = has_single(P);
-    oracle_single_scores(P, D1, n1, D2, n2, F, A, nA, m->diag);
-    const double* s = m->diag;
+    double* s = (double*)malloc(sizeof(double) * (nA > 0 ? nA : 1));
+    m->live = (uint8_t*)malloc((size_t)(nA > 0 ? nA : 1));
+    oracle_single_scores(P, D1, n1, D2, n2, F, A, nA, s);
+    for (int32_t p = 0; p < nA; ++p) {
+        m->live[p] = s[p] > 0.0;
+        m->diag[p] = (single && P->single_mode == ROMAN_SINGLE_OFFDIAG) ? (m->live[p] ? 1.0 : 0.0) : s[p];
+    }
     pair_consts_t K; K.sig2 = P->sigma * P->sigma; K.sin_unc = sin(P->gravity_unc_ang_rad);
 
     int32_t** rcols = (int32_t**)calloc((size_t)(nA > 0 ? nA : 1), sizeof(int32_t*));
@@ -332,7 +465,7 @@ ORACLE_API oracle_mat_t* oracle_build(const roman_params_t* P, const double* D1,
         }
         free(rcols[p]); free(rvals[p]);
     }
-    free(rcols); free(rvals); free(rcnt);
+    free(rcols); free(rvals); free(rcnt); free(s);
     return m;
 }
 
@@ -345,8 +478,9 @@ ORACLE_API oracle_mat_t* oracle_from_dense(const double* M, const double* C, int
     m->n = n;
     m->rowptr = (int64_t*)calloc((size_t)n + 1, sizeof(int64_t));
     m->diag = (double*)malloc(sizeof(double) * (n > 0 ? n : 1));
+    m->live = (uint8_t*)malloc((size_t)(n > 0 ? n : 1));
     for (int32_t p = 0; p < n; ++p) {
-        m->diag[p] = 1.0;
+        m->diag[p] = 1.0; m->live[p] = 1;
         int64_t c = 0;
         for (int32_t q = p + 1; q < n; ++q)
             if (M[(int64_t)p * n + q] != 0.0 || C[(int64_t)p * n + q] != 0.0) ++c;
@@ -476,7 +610,7 @@ ORACLE_API int oracle_solve(const roman_params_t* P, const oracle_mat_t* m, cons
     const int32_t n = m->n;
     roman_stats_t S; memset(&S, 0, sizeof(S));
     S.n_assoc_in = n; S.nnz_upper = m->nnz;
-    { int32_t live = 0; for (int32_t p = 0; p < n; ++p) live += (m->diag[p] != 0.0); S.n_live = live; }
+    { int32_t live = 0; for (int32_t p = 0; p < n; ++p) live += m->live[p]; S.n_live = live; }
     if (n <= 0) { *n_nodes = 0; if (st) *st = S; return 0; }
 
     double* u   = (double*)calloc((size_t)n, sizeof(double));
@@ -493,7 +627,8 @@ ORACLE_API int oracle_solve(const roman_params_t* P, const oracle_mat_t* m, cons
         for (int32_t p_ = 0; p_ < n; ++p_) { c_ += ((vec)[p_] > 0.0); } \
         support_trace[npass] = c_; } } while (0)
 
-    for (int32_t p = 0; p < n; ++p) u[p] = u0_in ? u0_in[p] : 1.0;
+    /* removed associations (zero single score) take no part: their u is 0 whatever u0 says */
+    for (int32_t p = 0; p < n; ++p) u[p] = m->live[p] ? (u0_in ? u0_in[p] : 1.0) : 0.0;
     if (P->rescale_u0) {                       /* u = M u0 (+ diag u0): one power-method step */
         TRACE(u); spmv_sym(m, u, Mu, Cu); ++npass;
         for (int32_t p = 0; p < n; ++p) un[p] = Mu[p] + m->diag[p] * u[p];

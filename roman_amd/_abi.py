@@ -25,6 +25,13 @@ ROMAN_FUSE_GEOMETRIC_MEAN = 0
 ROMAN_FUSE_ARITHMETIC_MEAN = 1
 ROMAN_FUSE_PRODUCT = 2
 
+ROMAN_GRAV_COMBINED = 0
+ROMAN_GRAV_SEPARATE = 1
+ROMAN_GRAV_ZGATE = 2
+ROMAN_SINGLE_BOTH = 0
+ROMAN_SINGLE_OFFDIAG = 1
+ROMAN_SINGLE_DIAG = 2
+
 ROMAN_STAGE_SINGLE = 0
 ROMAN_STAGE_COUNT_PASS = 1
 ROMAN_STAGE_FILL = 2
@@ -62,6 +69,8 @@ class RomanParams(C.Structure):
         ("maxiniters", C.c_int32),
         ("maxoliters", C.c_int32),
         ("maxlsiters", C.c_int32),
+        ("gravity_mode", C.c_int32),
+        ("single_mode", C.c_int32),
         ("reserved", C.c_int32),
     ]
 

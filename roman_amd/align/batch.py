@@ -81,7 +81,7 @@ def batch_from_pairs(registration, pairs) -> AlignmentBatch:
     n1 = (offs[1:2 * B + 1:2] - offs[0:2 * B:2]).astype(np.int32)
     n2 = (offs[2:2 * B + 2:2] - offs[1:2 * B:2]).astype(np.int32)
     assoc, assoc_off = None, None
-    lists = [registration._associations_to_score(m1, m2) if (len(m1) and len(m2)) else None for m1, m2 in pairs]
+    lists = [registration._association_list(m1, m2) if (len(m1) and len(m2)) else None for m1, m2 in pairs]
     if any(a is not None for a in lists):
         from ..clipperpy.utils import create_all_to_all
         lists = [a if a is not None else create_all_to_all(len(m1), len(m2)) for a, (m1, m2) in zip(lists, pairs)]

@@ -63,6 +63,14 @@ class ObjectRegistration:
         """None = all-to-all ([REF roman/align/object_registration.py:41]); subclasses may prune."""
         return None
 
+    def _association_list(self, map1, map2):
+        """The list handed to the scorer.  An EMPTY pruned list means all-to-all, as it does for
+        clipperpy's `score_pairwise_consistency(D1, D2, A)` (an empty A is replaced by the all-to-all
+        list), which is what the reference's pruning plugin ends up calling when every association
+        was pruned ([REF roman/align/dist_reg_with_pruning.py:94-96])."""
+        A = self._associations_to_score(map1, map2)
+        return None if (A is None or len(A) == 0) else A
+
     # ------------------------------------------------------------------ reference API
     def register(self, map1: List, map2: List):
         """[REF roman/align/object_registration.py:22-29]"""
@@ -70,7 +78,7 @@ class ObjectRegistration:
             return np.array([[]])                                # (1,0) float64, as the reference
         m1, m2 = self.pack(map1), self.pack(map2)
         self._check_clipper_arrays(m1, m2)
-        A = self._associations_to_score(map1, map2)
+        A = self._association_list(map1, map2)
         ctx = self._context()
         ctx.score(self._abi_params(), m1, m2, A)
         ctx.solve(None)
@@ -79,7 +87,7 @@ class ObjectRegistration:
     def get_MCA(self, map1: List, map2: List):
         """[REF roman/align/object_registration.py:50-55]: dense M, C and the association list."""
         m1, m2 = self.pack(map1), self.pack(map2)
-        A = self._associations_to_score(map1, map2)
+        A = self._association_list(map1, map2)
         ctx = self._context()
         ctx.score(self._abi_params(), m1, m2, A)
         M, C = ctx.dense_matrices()
@@ -93,7 +101,9 @@ class ObjectRegistration:
         Rayleigh quotient of the selected nodes on the original M, zero their block, repeat."""
         M, C, A = self.get_MCA(map1, map2)
         M_orig = M.copy()
-        params = self._abi_params()
+        # a COPY: the reference builds a separate CLIPPER(PairwiseInvariant) for this loop
+        # ([REF roman/align/object_registration.py:60]) and never touches the registration's own parameters
+        params = _abi.RomanParams.from_buffer_copy(self._abi_params())
         params.invariant = _abi.ROMAN_INV_EUCLIDEAN
         ctx = self._context()
         solutions = []

@@ -219,7 +219,7 @@ def submap_align(sm_params, submaps, sm_io: Optional[SubmapAlignIO] = None, regi
         feats, offs = pack_submaps(registration, pool)
         lens = np.diff(offs).astype(np.int32)
         batch = AlignmentBatch(feats, offs[ii].astype(np.int64), lens[ii], offs[jj].astype(np.int64), lens[jj])
-        lists = [registration._associations_to_score(a, b) if (len(a) and len(b)) else None for (_, _, a, b) in todo]
+        lists = [registration._association_list(a, b) if (len(a) and len(b)) else None for (_, _, a, b) in todo]
         if any(l is not None for l in lists):            # pruning plugins score explicit association lists
             from ..clipperpy.utils import create_all_to_all
             lists = [l if l is not None else create_all_to_all(len(a), len(b)) for l, (_, _, a, b) in zip(lists, todo)]

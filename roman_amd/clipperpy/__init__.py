@@ -63,6 +63,7 @@ class CLIPPER:
         self._inputs = None          # what was scored: re-sent if another object used the context since
         self._solution = None        # cached at solve(): upstream keeps results per CLIPPER object
         self._selected = None
+        self._gen = None             # Context._generation right after this object's inputs were loaded
 
     # -- plumbing ---------------------------------------------------------------------------------
     def _context(self):
@@ -102,10 +103,12 @@ class CLIPPER:
             ctx.score(self._abi_params(), self._inputs[1], self._inputs[2], self._inputs[3])
         else:
             ctx.set_matrix_data(self._abi_params(), self._inputs[1], self._inputs[2])
-        ctx._owner = id(self)
+        self._gen = ctx._generation
 
     def _own(self):
-        if getattr(self._context(), "_owner", None) != id(self):
+        """Anything else that used the context since (another CLIPPER object, a registration plugin, a batch
+        call) moved its generation on: reload this object's problem before operating on it."""
+        if self._context()._generation != self._gen:
             self._send()
 
     # -- clipperpy API ----------------------------------------------------------------------------

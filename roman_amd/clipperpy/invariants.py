@@ -57,6 +57,10 @@ class ROMANParams:
         self.drift_aware = False
         self.gravity_unc_ang_rad = 0.0
         self.fusion_method = 0
+        # NOT upstream attributes: switches of the two formulas pinned by decision (include/roman_hip.h
+        # ROMAN_GRAV_*, ROMAN_SINGLE_*); the reference never sets them, 0 = the pinned default
+        self.gravity_mode = 0
+        self.single_mode = 0
 
 
 class ROMAN(PairwiseInvariant):
@@ -91,4 +95,6 @@ class ROMAN(PairwiseInvariant):
         p.drift_aware = int(bool(ip.drift_aware))
         p.gravity_unc_ang_rad = float(ip.gravity_unc_ang_rad)
         p.fusion_method = int(getattr(ip, "fusion_method", 0))
+        p.gravity_mode = int(getattr(ip, "gravity_mode", 0))
+        p.single_mode = int(getattr(ip, "single_mode", 0))
         return p

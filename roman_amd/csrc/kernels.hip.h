@@ -35,6 +35,8 @@ struct DevParams {
     int32_t gravity;    // ROMAN invariant && gravity_guided
     int32_t F;          // features per object
     int32_t max_compact; // streaming solver: column compactions allowed per problem (speed only; set per launch)
+    int32_t gmode;      // 0: no gravity; 1 + ROMAN_GRAV_* otherwise (1 combined, 2 separate gates, 3 z gate on full lengths)
+    int32_t diag_one;   // single scores present but the diagonal is the identity (ROMAN_SINGLE_OFFDIAG)
 };
 
 struct ProbDesc {
@@ -104,11 +106,60 @@ __device__ __forceinline__ void decode_assoc(const ProbDesc& pd, const int32_t* 
     else { i = p / pd.n2; j = p - i * pd.n2; }
 }
 
+// exp and cbrt as FIXED sequences of correctly-rounded operations: the `score > affinityeps`
+// gate is applied after them, so they must produce the same bits as the oracle's oracle_exp()/oracle_cbrt()
+// (oracle/clipper_oracle.c states the same sequences; tests/test_gpu_parity.py compares the bits).  < 1 ulp.
+__device__ __forceinline__ double bits_f64(unsigned long long b) { return __longlong_as_double((long long)b); }
+__device__ __forceinline__ double fx_exp(double y)
+{
+    if (!(y > -700.0 && y < 700.0)) return exp(y);
+    constexpr double LOG2E = 0x1.71547652b82fep+0, LN2_HI = 0x1.62e42fee00000p-1, LN2_LO = 0x1.a39ef35793c76p-33;
+    const double k = rint(y * LOG2E);
+    const double r1 = fma(-k, LN2_HI, y);
+    const double rl = -k * LN2_LO;
+    const double r = r1 + rl;
+    const double r_err = (r1 - r) + rl;
+    double q = 0x1.6124613a86d09p-33;                              // 1/13!
+    q = fma(q, r, 0x1.1eed8eff8d898p-29); q = fma(q, r, 0x1.ae64567f544e4p-26); q = fma(q, r, 0x1.27e4fb7789f5cp-22);
+    q = fma(q, r, 0x1.71de3a556c734p-19); q = fma(q, r, 0x1.a01a01a01a01ap-16); q = fma(q, r, 0x1.a01a01a01a01ap-13);
+    q = fma(q, r, 0x1.6c16c16c16c17p-10); q = fma(q, r, 0x1.1111111111111p-7);  q = fma(q, r, 0x1.5555555555555p-5);
+    q = fma(q, r, 0x1.5555555555555p-3);  q = fma(q, r, 0.5);     // ... 1/2!
+    const double a = 1.0 + r;
+    const double a_err = (r - (a - 1.0)) + r_err;
+    const double p = a + fma(r * r, q, a_err);
+    return p * bits_f64((unsigned long long)(1023 + (int)k) << 52);
+}
+__device__ __forceinline__ double fx_cbrt(double x)
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+    const int E = (int)((b >> 52) & 0x7ffull);
+    if (!(x > 0.0) || E == 0 || E == 0x7ff) return cbrt(x);
+    constexpr double C0 = 0x1.331e76e38c2bfp+0, C1 = -0x1.142641324f5d9p-2, C2 = 0x1.49dcf893faf42p-5, C3 = -0x1.2190c96665e59p-9;
+    constexpr double THIRD = 0x1.5555555555555p-2;
+    const int e = E - 1023;
+    const int q = (e >= 0) ? e / 3 : -((2 - e) / 3);
+    const int rem = e - 3 * q;
+    const double m = bits_f64((b & 0x000fffffffffffffull) | ((unsigned long long)(1023 + rem) << 52));
+    double y = fma(fma(fma(C3, m, C2), m, C1), m, C0);
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const double y2 = y * y, y3 = y2 * y;
+        const double w = fma(-m, y3, 4.0);
+        y = (y * w) * THIRD;
+    }
+    const double yy = y * y;
+    double t = m * yy;
+    const double t2 = t * t, e2 = fma(t, t, -t2);
+    const double r = fma(-e2, t, fma(-t2, t, m));
+    t = fma(r, yy * THIRD, t);
+    return t * bits_f64((unsigned long long)(1023 + q) << 52);
+}
+
 __device__ __forceinline__ double root_w(double x, double w)
 {
     if (w == 1.0) return x;
     if (w == 2.0) return sqrt(x);
-    if (w == 3.0) return cbrt(x);
+    if (w == 3.0) return fx_cbrt(x);
     return pow(x, 1.0 / w);
 }
 __device__ __forceinline__ double pow_w(double x, double w) { return (w == 1.0) ? x : pow(x, w); }
@@ -151,6 +202,7 @@ __device__ __forceinline__ double fuse_pair(const DevParams& D, double sa, doubl
 {
     if (!D.single) return sa;
     if (sa == 0.0 || sp == 0.0 || sq == 0.0) return 0.0;
+    if (D.p.single_mode == ROMAN_SINGLE_DIAG) return sa;
     const double ss = sp * sq, wd = D.p.distance_weight;
     switch (D.p.fusion_method) {
     case ROMAN_FUSE_ARITHMETIC_MEAN: return (wd * sa + (sp + sq)) / (wd + 2.0);
@@ -304,7 +356,7 @@ __global__ void __launch_bounds__(256) k_tables(DevParams D, const ProbDesc* __r
             const double h2 = dx * dx + dy * dy;
             const double l2 = h2 + dz * dz;
             const bool bad = (a == b) || (D.p.mindist > 0.0 && l2 < D.x_mindist);
-            const double v = D.gravity ? sqrt(h2) : sqrt(l2);
+            const double v = (D.gmode == 1 || D.gmode == 2) ? sqrt(h2) : sqrt(l2);     // z-gate mode compares full lengths
             tab[(int64_t)a * n + b] = bad ? d_nan() : v;
         }
     }
@@ -329,7 +381,7 @@ __global__ void __launch_bounds__(256) k_live(DevParams D, const ProbDesc* __res
                                               const double* __restrict__ cosPool,
                                               double* __restrict__ sTmp, int32_t* __restrict__ chunkCnt, int maxChunks,
                                               int32_t* __restrict__ lp, int32_t* __restrict__ li,
-                                              int32_t* __restrict__ lj, double* __restrict__ ls,
+                                              int32_t* __restrict__ lj, double* __restrict__ ls, double* __restrict__ ld,
                                               double* __restrict__ lza, double* __restrict__ lzb)
 {
     __shared__ int wtot[4];
@@ -404,6 +456,7 @@ __global__ void __launch_bounds__(256) k_live(DevParams D, const ProbDesc* __res
             int i, j;
             decode_assoc(pd, assoc, p, i, j);
             lp[lo + pos] = p; li[lo + pos] = i; lj[lo + pos] = j; ls[lo + pos] = s;
+            ld[lo + pos] = D.diag_one ? 1.0 : s;               // M_pp: the single score, or the identity (ROMAN_SINGLE_OFFDIAG)
             const bool has_z = D.p.point_dim == 3;
             lza[lo + pos] = has_z ? feats[(pd.off1 + i) * D.F + 2] : 0.0;
             lzb[lo + pos] = has_z ? feats[(pd.off2 + j) * D.F + 2] : 0.0;
@@ -469,7 +522,34 @@ __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, int lane)
 }
 
 // Generic sweep (columns read from HBM/L2): used when the live set does not fit the LDS column tile.
-template <bool GRAV>
+// GM: 0 no gravity prior, 1 ROMAN_GRAV_COMBINED, 2 ROMAN_GRAV_SEPARATE, 3 ROMAN_GRAV_ZGATE (tables then hold full lengths)
+template <int GM>
+__device__ __forceinline__ bool pair_gate(const DevParams& D, double a, double bb, double dz)
+{
+    if (GM == 1) {
+        const double ch = fabs(a - bb);
+        double hm;                              // max(a,bb) in ONE instruction (fmax() would first
+        asm("v_max_f64 %0, %1, %2" : "=v"(hm) : "v"(a), "v"(bb));   // canonicalise both); NaN operands: x is NaN through ch anyway
+        const double cv = __builtin_fmax(dz - D.sin_unc * hm, 0.0);
+        const double xx = ch * ch + cv * cv;
+        return xx < D.x_eps;                    // <=> sqrt(x) < epsilon ; NaN -> false
+    } else if (GM == 2) {
+        const double ch = fabs(a - bb);
+        double hm;
+        asm("v_max_f64 %0, %1, %2" : "=v"(hm) : "v"(a), "v"(bb));
+        const double cv = __builtin_fmax(dz - D.sin_unc * hm, 0.0);
+        return (ch < D.p.epsilon) & (cv < D.p.epsilon);             // a NaN table entry fails through ch
+    } else if (GM == 3) {
+        const double c = fabs(a - bb);
+        double lm;
+        asm("v_max_f64 %0, %1, %2" : "=v"(lm) : "v"(a), "v"(bb));
+        return (c < D.p.epsilon) & (dz < D.p.epsilon + D.sin_unc * lm);
+    } else {
+        return fabs(a - bb) < D.p.epsilon;
+    }
+}
+
+template <int GM>
 __device__ __forceinline__ void count_rows_global(const DevParams& D, const ProbDesc& pd, int L, int row0, int nrows,
                                                   int w, int wpb, int lane,
                                                   const int32_t* __restrict__ gI, const int32_t* __restrict__ gJ,
@@ -483,7 +563,7 @@ __device__ __forceinline__ void count_rows_global(const DevParams& D, const Prob
     for (int r = w; r < nrows; r += wpb) {
         const int k = row0 + r;
         const int i = gI[k], j = gJ[k];
-        const double zi = GRAV ? gZa[k] : 0.0, zj = GRAV ? gZb[k] : 0.0;
+        const double zi = GM ? gZa[k] : 0.0, zj = GM ? gZb[k] : 0.0;
         const double* gA = TA + (int64_t)i * pd.n1;
         const double* gB = TB + (int64_t)j * pd.n2;
         for (int t = lane; t < pd.n1; t += WAVE) tA[t] = gA[t];
@@ -497,17 +577,8 @@ __device__ __forceinline__ void count_rows_global(const DevParams& D, const Prob
             const bool vq = q < L;
             const int qi = vq ? q : 0;
             const double a = tA[gI[qi]], bb = tB[gJ[qi]];
-            bool is;
-            if (GRAV) {
-                const double ch = fabs(a - bb);
-                const double hm = a > bb ? a : bb;
-                double cv = fabs((zi - gZa[qi]) - (zj - gZb[qi])) - D.sin_unc * hm;
-                if (cv < 0.0) cv = 0.0;
-                const double x = ch * ch + cv * cv;
-                is = vq && (x < D.x_eps);          // <=> sqrt(x) < epsilon ; NaN -> false
-            } else {
-                is = vq && (fabs(a - bb) < D.p.epsilon);
-            }
+            const double dz = GM ? fabs((zi - gZa[qi]) - (zj - gZb[qi])) : 0.0;
+            const bool is = vq && pair_gate<GM>(D, a, bb, dz);
             const unsigned long long m = __ballot(is);
             if (lane == 0) mrow[q0 >> 6] = m;
         }
@@ -523,7 +594,7 @@ __device__ __forceinline__ void count_rows_global(const DevParams& D, const Prob
 // the table slices fit): the column data is read once for both, the two rows' instruction streams are
 // independent (the kernel is bound by LDS/VALU/scalar latency, not by any one pipe), and the loop overhead
 // is shared.  Per 64 columns and row: 2 LDS gathers, 12 f64 VALU ops, 2 address adds, 2 v_writelane.
-template <bool GRAV, int NR>
+template <int GM, int NR>
 __device__ __forceinline__ void count_rows_lds(const DevParams& D, const ProbDesc& pd, int L, int row0, int nrows,
                                                int w, int wpb, int lane,
                                                const int2* cIJ, const double2* cZZ,
@@ -562,7 +633,7 @@ __device__ __forceinline__ void count_rows_lds(const DevParams& D, const ProbDes
 #pragma unroll
         for (int x = 0; x < NR; ++x) {
             k[x] = __builtin_amdgcn_readfirstlane(row0 + min(r + x, nrows - 1));   // wave-uniform: loop bounds and lane selects in SGPRs
-            zi[x] = GRAV ? cZZ[k[x]].x : 0.0; zj[x] = GRAV ? cZZ[k[x]].y : 0.0;
+            zi[x] = GM ? cZZ[k[x]].x : 0.0; zj[x] = GM ? cZZ[k[x]].y : 0.0;
         }
         // stage the table rows (wave-private slices; LDS ops of one wave execute in order)
 #pragma unroll
@@ -601,7 +672,7 @@ __device__ __forceinline__ void count_rows_lds(const DevParams& D, const ProbDes
 #pragma unroll
             for (int t = 0; t < U; ++t) {
                 ij[t] = cIJ[q0 + t * WAVE + lane];
-                if (GRAV) zz[t] = cZZ[q0 + t * WAVE + lane];
+                if (GM) zz[t] = cZZ[q0 + t * WAVE + lane];
             }
 #pragma unroll
             for (int t = 0; t < U; ++t) {
@@ -610,17 +681,8 @@ __device__ __forceinline__ void count_rows_lds(const DevParams& D, const ProbDes
                 for (int x = 0; x < NR; ++x) {
                     const double a = *reinterpret_cast<const double*>(tbytes + x * sliceBytes + ij[t].x);
                     const double bb = *reinterpret_cast<const double*>(tbytes + x * sliceBytes + ij[t].y);
-                    bool is;
-                    if (GRAV) {
-                        const double ch = fabs(a - bb);
-                        double hm;                              // max(a,bb) in ONE instruction (fmax() would first
-                        asm("v_max_f64 %0, %1, %2" : "=v"(hm) : "v"(a), "v"(bb));   // canonicalise both); NaN operands: x is NaN through ch anyway
-                        const double cv = __builtin_fmax(fabs((zi[x] - zz[t].x) - (zj[x] - zz[t].y)) - D.sin_unc * hm, 0.0);
-                        const double xx = ch * ch + cv * cv;
-                        is = xx < D.x_eps;                      // <=> sqrt(x) < epsilon ; NaN -> false
-                    } else {
-                        is = fabs(a - bb) < D.p.epsilon;
-                    }
+                    const double dz = GM ? fabs((zi[x] - zz[t].x) - (zj[x] - zz[t].y)) : 0.0;
+                    const bool is = pair_gate<GM>(D, a, bb, dz);
                     const unsigned long long m = __ballot(is);
                     {   // lane (widx & 63) of (mhi:mlo) <- m  (v_writelane_b32: uniform value, uniform lane select)
                         const uint32_t ml_ = (uint32_t)m, mh_ = (uint32_t)(m >> 32), sel_ = (uint32_t)(widx & 63);
@@ -645,7 +707,7 @@ __device__ __forceinline__ void count_rows_lds(const DevParams& D, const ProbDes
     }
 }
 
-template <bool GRAV, int NR>
+template <int GM, int NR>
 __global__ void __launch_bounds__(1024) k_count(DevParams D, const ProbDesc* __restrict__ probs,
                                                 const ProbState* __restrict__ st,
                                                 const BatchTotals* __restrict__ tot,
@@ -658,10 +720,10 @@ __global__ void __launch_bounds__(1024) k_count(DevParams D, const ProbDesc* __r
                                                 uint32_t* __restrict__ prefPool,
                                                 int TC /* LDS column tile (multiple of 256) */, int ldsPerWave /* doubles: NR table slices */, int RPB)
 {
-    // LDS: [GRAV: cZZ[TC]] cIJ[TC] | per wave NR table slices (n1 + 1 + n2 doubles each)
+    // LDS: [GM: cZZ[TC]] cIJ[TC] | per wave NR table slices (n1 + 1 + n2 doubles each)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double2* cZZ = reinterpret_cast<double2*>(smem);
-    int2* cIJ = reinterpret_cast<int2*>(cZZ + (GRAV ? TC : 0));
+    int2* cIJ = reinterpret_cast<int2*>(cZZ + (GM ? TC : 0));
     double* tabs = reinterpret_cast<double*>(cIJ + TC);
     const int tid = threadIdx.x, nt = blockDim.x;
     const int lane = tid & 63, w = tid >> 6, wpb = nt >> 6;
@@ -683,14 +745,14 @@ __global__ void __launch_bounds__(1024) k_count(DevParams D, const ProbDesc* __r
             for (int q = tid; q < Lpad; q += nt) {
                 const bool v = q < L;
                 cIJ[q] = v ? make_int2(8 * li[lo + q], 8 * (pd.n1 + 1 + lj[lo + q])) : make_int2(8 * pd.n1, 8 * (pd.n1 + 1));
-                if (GRAV) cZZ[q] = v ? make_double2(lza[lo + q], lzb[lo + q]) : make_double2(0.0, 0.0);
+                if (GM) cZZ[q] = v ? make_double2(lza[lo + q], lzb[lo + q]) : make_double2(0.0, 0.0);
             }
         }
         __syncthreads();
         if (ldscol)
-            count_rows_lds<GRAV, NR>(D, pd, L, it.row0, nrows, w, wpb, lane, cIJ, cZZ, TA, TB, tA, ldsPerWave / NR, maskPool + mo);
+            count_rows_lds<GM, NR>(D, pd, L, it.row0, nrows, w, wpb, lane, cIJ, cZZ, TA, TB, tA, ldsPerWave / NR, maskPool + mo);
         else
-            count_rows_global<GRAV>(D, pd, L, it.row0, nrows, w, wpb, lane, li + lo, lj + lo, lza + lo, lzb + lo,
+            count_rows_global<GM>(D, pd, L, it.row0, nrows, w, wpb, lane, li + lo, lj + lo, lza + lo, lzb + lo,
                                     TA, TB, tA, rowCnt + lo, maskPool + mo, prefPool + mo);
     }
 }
@@ -916,16 +978,16 @@ __device__ __forceinline__ uint32_t fill_item(const DevParams& D, const ProbDesc
             const int i = cI[k], j = cJ[k], iq = cI[q], jq = cJ[q];
             const double a = TA[(int64_t)i * pd.n1 + iq], bb = TB[(int64_t)j * pd.n2 + jq];
             double c;
-            if (GRAV) {
+            if (GRAV && D.gmode != 3) {
                 const double ch = fabs(a - bb);
                 const double hm = a > bb ? a : bb;
                 double cv = fabs((cZa[k] - cZa[q]) - (cZb[k] - cZb[q])) - D.sin_unc * hm;
                 if (cv < 0.0) cv = 0.0;
                 c = sqrt(ch * ch + cv * cv);
             } else {
-                c = fabs(a - bb);
+                c = fabs(a - bb);                               // no gravity prior, or the z-gate reading (full lengths)
             }
-            const double sa = exp(((-0.5 * c) * c) / D.sig2);
+            const double sa = fx_exp(((-0.5 * c) * c) / D.sig2);
             const double v = fuse_pair(D, sa, cS[k], cS[q]);
             const bool keep = v > D.p.affinityeps;
             // an entry at or below affinityeps belongs neither to M nor to C: inert slot
@@ -1264,16 +1326,16 @@ __global__ void __launch_bounds__(1024) k_fill_slice(DevParams D, int B, const P
                         FMARK(3);
 #endif
                         double c;
-                        if (GRAV) {
+                        if (GRAV && D.gmode != 3) {
                             const double ch = fabs(a - bb);
                             const double hm = a > bb ? a : bb;
                             double cv = fabs((cZa[k] - cZa[q]) - (cZb[k] - cZb[q])) - D.sin_unc * hm;
                             if (cv < 0.0) cv = 0.0;
                             c = sqrt(ch * ch + cv * cv);
                         } else {
-                            c = fabs(a - bb);
+                            c = fabs(a - bb);                   // no gravity prior, or the z-gate reading (full lengths)
                         }
-                        const double sa = exp(((-0.5 * c) * c) / D.sig2);
+                        const double sa = fx_exp(((-0.5 * c) * c) / D.sig2);
                         const double v = fuse_pair(D, sa, cS[k], cS[q]);
                         if (v > D.p.affinityeps) {              // otherwise the slot stays inert: neither in M nor in C
                             imgC[(er >> 2) * 256u + slot * 4u + (er & 3u)] = (uint16_t)q;
@@ -1660,6 +1722,7 @@ __device__ void solve_one(const DevParams& D, int b, const ProbDesc& pd, ProbSta
         for (int p = tid; p < L; p += nt) sdl[p] = ls[lo + p];
         sd = sdl;
     }
+
     const int dim = P.point_dim;
     int par = 0;
 
@@ -2465,7 +2528,10 @@ __global__ void k_debug_math(int kind, const double* __restrict__ a, const doubl
     case 1: r = exp(x); break;
     case 2: r = cbrt(x); break;
     case 3: r = x / y; break;
-    default: r = pow(x, y); break;
+    case 4: r = pow(x, y); break;
+    case 5: r = fx_exp(x); break;
+    case 6: r = fx_cbrt(x); break;
+    default: r = fma(x, y, x); break;
     }
     out[i] = r;
 }

@@ -63,7 +63,7 @@ struct roman_ctx {
         // pools (see DESIGN.md "Data layout in HBM")
         DevBuf probs, state, totals, queue;
         DevBuf cosPool, normPool, tabPool, sTmp, chunkCnt;
-        DevBuf lp, li, lj, ls, lza, lzb;
+        DevBuf lp, li, lj, ls, ld, lza, lzb;
         DevBuf rowCnt, rowPos, perm, sliceWidth, sliceBase, items, maskPool, prefPool;
         DevBuf vMu, vCu, vMun, vCun, gU, gUn, uOut, nodesOrig, nSel;
         DevBuf cols, vals;
@@ -196,18 +196,23 @@ int make_dev_params(roman_ctx* c, const roman_params_t* p, int32_t F, DevParams*
     if (p->drift_aware) return fail(c, ROMAN_E_UNSUPPORTED, "drift_aware is not defined by the reference call sites (always False)");
     if (p->invariant == ROMAN_INV_ROMAN && p->gravity_guided && p->point_dim != 3) return fail(c, ROMAN_E_UNSUPPORTED, "gravity_guided requires point_dim == 3");
     if (p->fusion_method < 0 || p->fusion_method > 2) return fail(c, ROMAN_E_INVALID, "unknown fusion_method");
+    if (p->gravity_mode < 0 || p->gravity_mode > 2) return fail(c, ROMAN_E_INVALID, "unknown gravity_mode %d", p->gravity_mode);
+    if (p->single_mode < 0 || p->single_mode > 2) return fail(c, ROMAN_E_INVALID, "unknown single_mode %d", p->single_mode);
+    if (p->reserved != 0) return fail(c, ROMAN_E_INVALID, "roman_params_t.reserved must be 0");
     if (!(p->sigma > 0.0)) return fail(c, ROMAN_E_INVALID, "sigma must be > 0");
     const int need = (p->invariant == ROMAN_INV_ROMAN) ? p->point_dim + p->ratio_feature_dim + p->cos_feature_dim : p->point_dim;
     if (F < need) return fail(c, ROMAN_E_INVALID, "F=%d smaller than the %d features the invariant reads", F, need);
     memset(D, 0, sizeof(*D));
     D->p = *p;
-    if (p->invariant == ROMAN_INV_EUCLIDEAN) { D->p.ratio_feature_dim = 0; D->p.cos_feature_dim = 0; D->p.gravity_guided = 0; }
+    if (p->invariant == ROMAN_INV_EUCLIDEAN) { D->p.ratio_feature_dim = 0; D->p.cos_feature_dim = 0; D->p.gravity_guided = 0; D->p.gravity_mode = 0; D->p.single_mode = 0; }
     D->sig2 = p->sigma * p->sigma;
     D->sin_unc = std::sin(p->gravity_unc_ang_rad);
     D->x_eps = sqrt_threshold(p->epsilon);
     D->x_mindist = sqrt_threshold(p->mindist);
     D->single = (p->invariant == ROMAN_INV_ROMAN) && (p->ratio_feature_dim > 0 || p->cos_feature_dim > 0);
     D->gravity = (p->invariant == ROMAN_INV_ROMAN) && p->gravity_guided;
+    D->gmode = D->gravity ? 1 + p->gravity_mode : 0;
+    D->diag_one = D->single && p->single_mode == ROMAN_SINGLE_OFFDIAG;
     D->F = F;
     return ROMAN_OK;
 }
@@ -247,12 +252,12 @@ int stage_score(roman_ctx* c, const DevParams& D, const BatchIn& in, std::vector
         ProbDesc& d = hd[b];
         d.off1 = in.off1[b]; d.off2 = in.off2[b]; d.n1 = in.n1[b]; d.n2 = in.n2[b];
         if (d.n1 < 0 || d.n2 < 0) return fail(c, ROMAN_E_INVALID, "negative map size in problem %d", b);
-        if (in.assoc) {
+        const int64_t na_list = in.assoc ? in.assoc_off[b + 1] - in.assoc_off[b] : 0;
+        if (in.assoc && (na_list < 0 || na_list > 2147483647LL || in.assoc_off[b] < 0)) return fail(c, ROMAN_E_INVALID, "bad assoc_off at problem %d", b);
+        if (in.assoc && na_list > 0) {
             d.assocOff = in.assoc_off[b];
-            const int64_t na = in.assoc_off[b + 1] - in.assoc_off[b];
-            if (na < 0 || na > 2147483647LL) return fail(c, ROMAN_E_INVALID, "bad assoc_off at problem %d", b);
-            d.nA = (int32_t)na;
-        } else {
+            d.nA = (int32_t)na_list;
+        } else {                                       // no list, or an EMPTY one: all-to-all (clipperpy replaces an empty A likewise)
             d.assocOff = -1;
             const int64_t na = (int64_t)d.n1 * d.n2;
             if (na > 2147483647LL) return fail(c, ROMAN_E_TOO_LARGE, "n1*n2 overflows int32 in problem %d", b);
@@ -278,7 +283,7 @@ int stage_score(roman_ctx* c, const DevParams& D, const BatchIn& in, std::vector
     HIPCHK(c, WS.tabPool.ensure(sizeof(double) * (size_t)std::max<int64_t>(sumTab, 1)));
     HIPCHK(c, WS.sTmp.ensure(sizeof(double) * nA1));
     HIPCHK(c, WS.lp.ensure(sizeof(int32_t) * nA1)); HIPCHK(c, WS.li.ensure(sizeof(int32_t) * nA1)); HIPCHK(c, WS.lj.ensure(sizeof(int32_t) * nA1));
-    HIPCHK(c, WS.ls.ensure(sizeof(double) * nA1)); HIPCHK(c, WS.lza.ensure(sizeof(double) * nA1)); HIPCHK(c, WS.lzb.ensure(sizeof(double) * nA1));
+    HIPCHK(c, WS.ls.ensure(sizeof(double) * nA1)); HIPCHK(c, WS.ld.ensure(sizeof(double) * nA1)); HIPCHK(c, WS.lza.ensure(sizeof(double) * nA1)); HIPCHK(c, WS.lzb.ensure(sizeof(double) * nA1));
     HIPCHK(c, WS.rowCnt.ensure(sizeof(uint32_t) * nA1)); HIPCHK(c, WS.rowPos.ensure(sizeof(uint32_t) * nA1)); HIPCHK(c, WS.perm.ensure(sizeof(uint32_t) * nA1));
     HIPCHK(c, WS.sliceWidth.ensure(sizeof(uint32_t) * nA1)); HIPCHK(c, WS.sliceBase.ensure(sizeof(uint32_t) * nA1));
     // work items: blocks of RPB consecutive live rows of one problem (more, smaller items for small batches)
@@ -311,10 +316,10 @@ int stage_score(roman_ctx* c, const DevParams& D, const BatchIn& in, std::vector
         HIPCHK(c, WS.chunkCnt.ensure(sizeof(int32_t) * (size_t)B * (size_t)maxChunks));
         hipLaunchKernelGGL(k_live<0>, dim3((unsigned)maxChunks, (unsigned)B), dim3(256), 0, WS.stream, D, dP, dS, in.feats, in.assoc, WS.cosPool.as<double>(), WS.sTmp.as<double>(),
                            WS.chunkCnt.as<int32_t>(), maxChunks,
-                           WS.lp.as<int32_t>(), WS.li.as<int32_t>(), WS.lj.as<int32_t>(), WS.ls.as<double>(), WS.lza.as<double>(), WS.lzb.as<double>());
+                           WS.lp.as<int32_t>(), WS.li.as<int32_t>(), WS.lj.as<int32_t>(), WS.ls.as<double>(), WS.ld.as<double>(), WS.lza.as<double>(), WS.lzb.as<double>());
         hipLaunchKernelGGL(k_live<1>, dim3((unsigned)maxChunks, (unsigned)B), dim3(256), 0, WS.stream, D, dP, dS, in.feats, in.assoc, WS.cosPool.as<double>(), WS.sTmp.as<double>(),
                            WS.chunkCnt.as<int32_t>(), maxChunks,
-                           WS.lp.as<int32_t>(), WS.li.as<int32_t>(), WS.lj.as<int32_t>(), WS.ls.as<double>(), WS.lza.as<double>(), WS.lzb.as<double>());
+                           WS.lp.as<int32_t>(), WS.li.as<int32_t>(), WS.lj.as<int32_t>(), WS.ls.as<double>(), WS.ld.as<double>(), WS.lza.as<double>(), WS.lzb.as<double>());
     }
     hipLaunchKernelGGL(k_rowbase, dim3(1), dim3(64), 0, WS.stream, B, RPB, dS, dT);
     hipLaunchKernelGGL(k_items, dim3(B), dim3(256), 0, WS.stream, RPB, dS, WS.items.as<ItemDesc>());
@@ -346,7 +351,13 @@ int stage_score(roman_ctx* c, const DevParams& D, const BatchIn& in, std::vector
 
     StageTimer t1(c, ROMAN_STAGE_COUNT_PASS);
     if (tot.R > 0) {
-        auto kc = D.gravity ? (NRc == 2 ? k_count<true, 2> : k_count<true, 1>) : (NRc == 2 ? k_count<false, 2> : k_count<false, 1>);
+        auto kc = NRc == 2 ? k_count<0, 2> : k_count<0, 1>;
+        switch (D.gmode) {
+        case 1: kc = NRc == 2 ? k_count<1, 2> : k_count<1, 1>; break;
+        case 2: kc = NRc == 2 ? k_count<2, 2> : k_count<2, 1>; break;
+        case 3: kc = NRc == 2 ? k_count<3, 2> : k_count<3, 1>; break;
+        default: break;
+        }
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kc), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pairLds));
         hipLaunchKernelGGL(kc, dim3(pairGrid), dim3(wpb * 64), pairLds, WS.stream, D, dP, dS, dT, WS.items.as<ItemDesc>(), WS.tabPool.as<double>(),
                            WS.li.as<int32_t>(), WS.lj.as<int32_t>(), WS.lza.as<double>(), WS.lzb.as<double>(),
@@ -501,7 +512,7 @@ int stage_solve(roman_ctx* c, const DevParams& Din, int B, const double* feats, 
     do {                                                                                                                      \
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve<IDX, MODE_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         hipLaunchKernelGGL((k_solve<IDX, MODE_>), dim3(grid), dim3(nt), lds, WS.stream, D, B, WS.probs.as<ProbDesc>(), WS.state.as<ProbState>(), feats, assoc, \
-                           WS.lp.as<int32_t>(), WS.ls.as<double>(), WS.perm.as<uint32_t>(), WS.sliceWidth.as<uint32_t>(), WS.sliceBase.as<uint32_t>(), WS.cols.as<IDX>(), WS.vals.as<double>(), \
+                           WS.lp.as<int32_t>(), WS.ld.as<double>(), WS.perm.as<uint32_t>(), WS.sliceWidth.as<uint32_t>(), WS.sliceBase.as<uint32_t>(), WS.cols.as<IDX>(), WS.vals.as<double>(), \
                            WS.vMu.as<double>(), WS.vCu.as<double>(), WS.vMun.as<double>(), WS.vCun.as<double>(), WS.gU.as<double>(), WS.gUn.as<double>(), \
                            u0, O, WS.queue.as<int>(), Lcap);                                                                   \
     } while (0)
@@ -509,7 +520,7 @@ int stage_solve(roman_ctx* c, const DevParams& Din, int B, const double* feats, 
     do {                                                                                                                      \
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve_stream<CZ_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         hipLaunchKernelGGL((k_solve_stream<CZ_>), dim3(grid), dim3(nt), lds, WS.stream, D, B, WS.probs.as<ProbDesc>(), WS.state.as<ProbState>(), feats, assoc, \
-                           WS.lp.as<int32_t>(), WS.ls.as<double>(), WS.perm.as<uint32_t>(), WS.sliceBase.as<uint32_t>(), \
+                           WS.lp.as<int32_t>(), WS.ld.as<double>(), WS.perm.as<uint32_t>(), WS.sliceBase.as<uint32_t>(), \
                            WS.cols.as<uint16_t>(), WS.vals.as<double>(), WS.cols1.as<uint16_t>(), WS.vals1.as<double>(), WS.cols2.as<uint16_t>(), WS.vals2.as<double>(), \
                            WS.cols3.as<uint16_t>(), WS.vals3.as<double>(), u0, O, WS.queue.as<int>(), Lcap);                    \
     } while (0)
@@ -641,7 +652,7 @@ int fetch_last_csr(const roman_ctx* cc, std::vector<uint32_t>& rs, std::vector<u
         HIPCHK(c, hipMemcpy(jsw.data(), WS.sliceWidth.p, sizeof(uint32_t) * (size_t)nsl, hipMemcpyDeviceToHost));
         HIPCHK(c, hipMemcpy(jsb.data(), WS.sliceBase.p, sizeof(uint32_t) * (size_t)nsl, hipMemcpyDeviceToHost));
         HIPCHK(c, hipMemcpy(lp.data(), WS.lp.p, sizeof(int32_t) * (size_t)L, hipMemcpyDeviceToHost));
-        HIPCHK(c, hipMemcpy(ls.data(), WS.ls.p, sizeof(double) * (size_t)L, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(ls.data(), WS.ld.p, sizeof(double) * (size_t)L, hipMemcpyDeviceToHost));   // diagonal values
     }
     if (cap > 0) {
         HIPCHK(c, hipMemcpy(jvals.data(), WS.vals.p, sizeof(double) * (size_t)cap, hipMemcpyDeviceToHost));
@@ -732,7 +743,7 @@ int roman_ctx_destroy(roman_ctx_t* c)
     workers_stop(c);
     for (int k = 0; k < ROMAN_MAX_PIPELINE; ++k) {
         roman_ctx::Workspace& W = c->ws[k];
-        DevBuf* all[] = {&W.probs, &W.state, &W.totals, &W.queue, &W.cosPool, &W.normPool, &W.tabPool, &W.sTmp, &W.lp, &W.li, &W.lj, &W.ls, &W.lza, &W.lzb,
+        DevBuf* all[] = {&W.probs, &W.state, &W.totals, &W.queue, &W.cosPool, &W.normPool, &W.tabPool, &W.sTmp, &W.lp, &W.li, &W.lj, &W.ls, &W.ld, &W.lza, &W.lzb,
                          &W.rowCnt, &W.rowPos, &W.perm, &W.sliceWidth, &W.sliceBase, &W.items, &W.maskPool, &W.prefPool, &W.vMu, &W.vCu, &W.vMun, &W.vCun, &W.gU, &W.gUn,
                          &W.uOut, &W.nodesOrig, &W.nSel, &W.cols, &W.vals, &W.cols1, &W.vals1, &W.cols2, &W.vals2, &W.cols3, &W.vals3,
                          &W.hFeats, &W.hAssoc, &W.hU0, &W.oAssoc, &W.oN, &W.oT, &W.oStatus, &W.oStats, &W.hAux1, &W.hAux2, &W.hAux3, &W.chunkCnt};
@@ -978,10 +989,18 @@ int roman_align_batch(roman_ctx_t* c, const roman_params_t* params, int32_t B,
     { int rc0 = use_ws0(c); if (rc0) return rc0; }
     struct HostBatchGuard { roman_ctx* c; HostBatchGuard(roman_ctx* c_) : c(c_) { c->in_host_batch = true; } ~HostBatchGuard() { c->in_host_batch = false; } } guard(c);
     int64_t sumA = 0;
+    if (assoc && assoc_off[0] != 0) return fail(c, ROMAN_E_INVALID, "assoc_off[0] must be 0");
     for (int b = 0; b < B; ++b) {
-        if (off1[b] < 0 || off2[b] < 0 || off1[b] + n1[b] > n_objects || off2[b] + n2[b] > n_objects)
+        if (n1[b] < 0 || n2[b] < 0 || off1[b] < 0 || off2[b] < 0 || off1[b] + n1[b] > n_objects || off2[b] + n2[b] > n_objects)
             return fail(c, ROMAN_E_INVALID, "problem %d reads objects outside feats[0..%lld)", b, (long long)n_objects);
-        sumA += assoc ? (assoc_off[b + 1] - assoc_off[b]) : (int64_t)n1[b] * n2[b];
+        if (assoc) {
+            if (assoc_off[b + 1] < assoc_off[b]) return fail(c, ROMAN_E_INVALID, "assoc_off is not non-decreasing at problem %d", b);
+            for (int64_t k = assoc_off[b]; k < assoc_off[b + 1]; ++k)
+                if (assoc[2 * k] < 0 || assoc[2 * k] >= n1[b] || assoc[2 * k + 1] < 0 || assoc[2 * k + 1] >= n2[b])
+                    return fail(c, ROMAN_E_INVALID, "problem %d: association %lld = (%d,%d) out of range", b, (long long)(k - assoc_off[b]), assoc[2 * k], assoc[2 * k + 1]);
+        }
+        const int64_t na = assoc ? (assoc_off[b + 1] - assoc_off[b]) : 0;
+        sumA += na > 0 ? na : (int64_t)n1[b] * n2[b];      // an empty list means all-to-all
     }
     const size_t fbytes = sizeof(double) * (size_t)std::max<int64_t>(n_objects * F, 1);
     HIPCHK(c, WS.hFeats.ensure(fbytes));
@@ -1040,6 +1059,7 @@ int roman_score(roman_ctx_t* c, const roman_params_t* params, const double* D1, 
     if ((int64_t)n1 * F > 0) HIPCHK(c, hipMemcpyAsync(WS.hFeats.p, D1, sizeof(double) * (size_t)n1 * F, hipMemcpyHostToDevice, WS.stream));
     if ((int64_t)n2 * F > 0) HIPCHK(c, hipMemcpyAsync(WS.hFeats.as<double>() + (size_t)n1 * F, D2, sizeof(double) * (size_t)n2 * F, hipMemcpyHostToDevice, WS.stream));
     const int32_t* dA = nullptr;
+    if (assoc && n_assoc == 0) assoc = nullptr;        // clipperpy: an empty A is replaced by the all-to-all list
     int64_t aoff[2] = {0, n_assoc};
     Lst.assoc.clear();
     if (assoc) {
@@ -1118,7 +1138,7 @@ int roman_set_matrix_data(roman_ctx_t* c, const roman_params_t* params, const do
     Lst.hascz = anycz;
     const size_t n1_ = (size_t)std::max(n, 1), nnz1 = (size_t)std::max<uint64_t>(total, 1), nsl1 = (size_t)std::max((n + 63) / 64, 1);
     HIPCHK(c, WS.probs.ensure(sizeof(ProbDesc))); HIPCHK(c, WS.state.ensure(sizeof(ProbState))); HIPCHK(c, WS.queue.ensure(sizeof(int) * 4));
-    HIPCHK(c, WS.lp.ensure(sizeof(int32_t) * n1_)); HIPCHK(c, WS.ls.ensure(sizeof(double) * n1_));
+    HIPCHK(c, WS.lp.ensure(sizeof(int32_t) * n1_)); HIPCHK(c, WS.ls.ensure(sizeof(double) * n1_)); HIPCHK(c, WS.ld.ensure(sizeof(double) * n1_));
     HIPCHK(c, WS.rowCnt.ensure(sizeof(uint32_t) * n1_)); HIPCHK(c, WS.rowPos.ensure(sizeof(uint32_t) * n1_)); HIPCHK(c, WS.perm.ensure(sizeof(uint32_t) * n1_));
     HIPCHK(c, WS.sliceWidth.ensure(sizeof(uint32_t) * n1_)); HIPCHK(c, WS.sliceBase.ensure(sizeof(uint32_t) * n1_));
     HIPCHK(c, WS.vals.ensure(sizeof(double) * nnz1)); HIPCHK(c, WS.cols.ensure((Lst.idx16 ? 2 : 4) * nnz1));
@@ -1131,6 +1151,7 @@ int roman_set_matrix_data(roman_ctx_t* c, const roman_params_t* params, const do
     if (n > 0) {
         HIPCHK(c, hipMemcpy(WS.lp.p, ident.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice));
         HIPCHK(c, hipMemcpy(WS.ls.p, ones.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(WS.ld.p, ones.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
         HIPCHK(c, hipMemcpy(WS.rowCnt.p, rl.data(), sizeof(uint32_t) * (size_t)n, hipMemcpyHostToDevice));
         HIPCHK(c, hipMemcpy(WS.rowPos.p, rowPos.data(), sizeof(uint32_t) * (size_t)n, hipMemcpyHostToDevice));
         HIPCHK(c, hipMemcpy(WS.perm.p, perm.data(), sizeof(uint32_t) * (size_t)n, hipMemcpyHostToDevice));

@@ -47,6 +47,10 @@ class Context:
             msg = self._lib.roman_last_error(None)
             raise RomanHipError(f"roman_ctx_create failed ({rc}): {msg.decode() if msg else ''}")
         self.device = int(device)
+        # One context holds ONE stepwise problem (the matrices of the last score()/set_matrix_data()).  Every call
+        # that replaces or invalidates it bumps this counter; holders of a problem (the clipperpy shim's CLIPPER
+        # objects) remember the value they loaded at and re-send their inputs when it has moved on.
+        self._generation = 0
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
@@ -101,6 +105,7 @@ class Context:
         status = np.zeros(B, dtype=np.int32)
         stats = np.zeros(B, dtype=stats_dtype())
         assert stats.dtype.itemsize == _abi.STATS_NBYTES
+        self._generation += 1
         rc = self._lib.roman_align_batch(self._h, C.byref(params), B, _ptr(feats), n_obj, _ptr(off1), _ptr(n1),
                                          _ptr(off2), _ptr(n2), F, _ptr(assoc), _ptr(assoc_off), _ptr(u0), kmax,
                                          _ptr(a_out), _ptr(n_out), _ptr(T), _ptr(status), _ptr(stats))
@@ -120,6 +125,7 @@ class Context:
         if assoc_off is not None:
             assoc_off = np.ascontiguousarray(assoc_off, dtype=np.int64)
         vp = lambda x: C.c_void_p(int(x)) if x else None
+        self._generation += 1
         rc = self._lib.roman_align_batch_dev(self._h, C.byref(params), int(n1.shape[0]), vp(feats_ptr), _ptr(off1),
                                              _ptr(n1), _ptr(off2), _ptr(n2), int(F), vp(assoc_ptr), _ptr(assoc_off),
                                              vp(u0_ptr), int(kmax), vp(assoc_out_ptr), vp(n_assoc_out_ptr),
@@ -139,6 +145,7 @@ class Context:
         if assoc is not None:
             assoc = np.ascontiguousarray(assoc, dtype=np.int32).reshape(-1, 2)
             na = assoc.shape[0]
+        self._generation += 1
         rc = self._lib.roman_score(self._h, C.byref(params), _ptr(D1), n1, _ptr(D2), n2, F, _ptr(assoc), na)
         self._check(rc, "roman_score")
 
@@ -146,6 +153,7 @@ class Context:
         M, Cm = _f64(M), _f64(Cm)
         if M.shape != Cm.shape or M.ndim != 2 or M.shape[0] != M.shape[1]:
             raise ValueError("M and C must be square matrices of the same shape")
+        self._generation += 1
         self._check(self._lib.roman_set_matrix_data(self._h, C.byref(params), _ptr(M), _ptr(Cm), M.shape[0]),
                     "roman_set_matrix_data")
 
@@ -235,6 +243,7 @@ class Context:
     def debug_cosine(self, params, D1, D2):
         D1, D2 = _f64(D1), _f64(D2)
         out = np.zeros((D1.shape[0], D2.shape[0]), dtype=np.float64)
+        self._generation += 1
         self._check(self._lib.roman_debug_cosine(self._h, C.byref(params), _ptr(D1), D1.shape[0], _ptr(D2), D2.shape[0],
                                                  D1.shape[1], _ptr(out)), "roman_debug_cosine")
         return out

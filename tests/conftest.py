@@ -1,3 +1,4 @@
+import ast
 import os
 import sys
 
@@ -50,7 +51,7 @@ def golden_register_cases():
     out = []
     for i in range(int(z["n"])):
         out.append(dict(method=str(z[f"method_{i}"]), n=int(z[f"n_{i}"]), m=int(z[f"m_{i}"]), d=int(z[f"d_{i}"]),
-                        seed=int(z[f"seed_{i}"]), kw=eval(str(z[f"kw_{i}"])), assoc=z[f"assoc_{i}"], T=z[f"T_{i}"],
+                        seed=int(z[f"seed_{i}"]), kw=ast.literal_eval(str(z[f"kw_{i}"])), assoc=z[f"assoc_{i}"], T=z[f"T_{i}"],
                         status=str(z[f"status_{i}"]), pack1=z[f"pack1_{i}"], pack2=z[f"pack2_{i}"],
                         A_scored=z[f"A_scored_{i}"], tilt=float(z[f"tilt_{i}"])))
     return out

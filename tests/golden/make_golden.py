@@ -172,6 +172,8 @@ def gen_register():
         ("clipper+prune", 50, 50, 64, 1012, {"cosine_min": 0.5, "epsilon_shape": 0.1}),
         ("clipper+prune", 40, 30, 32, 1013, {"cosine_min": 0.6}),
         ("clipper", 20, 20, 0, 1014, {"dim": 2}),
+        # the prefilter prunes EVERY association: the reference then hands clipperpy an empty list, which means all-to-all
+        ("clipper+prune", 24, 24, 16, 1015, {"cosine_min": 0.9999}),
     ]
     for method, n, m, d, seed, kw in specs:
         sp = RefParams(method=method, **kw)

@@ -13,7 +13,7 @@ POSE_TOL = 1e-5
 
 def oracle_one(orc, reg, m1, m2):
     D1, D2 = reg.pack(m1), reg.pack(m2)
-    A = reg._associations_to_score(m1, m2) if len(m1) and len(m2) else None
+    A = reg._association_list(m1, m2) if len(m1) and len(m2) else None
     return orc.register(reg._abi_params(), D1, D2, A)
 
 
@@ -115,6 +115,44 @@ def test_dense_matrix_path_and_mno_clipper(ctx, orc):
         assert abs(sols[k][1] - u_sol @ Mo @ u_sol / (u_sol @ u_sol)) < 1e-9
         Mw[np.ix_(s["nodes"], s["nodes"])] = 0.0
     assert len(sols[0][0]) >= 5
+
+
+def test_mno_clipper_leaves_the_registration_untouched(ctx, orc):
+    """mno_clipper() solves on a separate plain-CLIPPER problem ([REF roman/align/object_registration.py:60]); the
+    registration's own invariant parameters must not change: register() before == register() after."""
+    reg = registration_for("roman", semantics_dim=16); reg.set_context(ctx)
+    pr = synth.make_pair(16, 15, 16, 35, tilt_deg=1.0)
+    before = reg.register(pr.map1, pr.map2)
+    inv0 = reg._abi_params().invariant
+    sols = reg.mno_clipper(pr.map1, pr.map2, num_solutions=2)
+    assert reg._abi_params().invariant == inv0 == _abi.ROMAN_INV_ROMAN
+    after = reg.register(pr.map1, pr.map2)
+    assert np.array_equal(before, after) and np.array_equal(after, oracle_one(orc, reg, pr.map1, pr.map2)["assoc"])
+    assert len(sols) == 2 and len(sols[0][0]) >= 3
+    res = reg.register_and_align_batch([(pr.map1, pr.map2)])
+    assert np.array_equal(res.assoc[0], before)
+
+
+def test_batch_entry_rejects_malformed_association_lists(ctx):
+    """roman_align_batch range-checks explicit lists like roman_score does (ROMAN_E_INVALID, no device reads)."""
+    from roman_amd import RomanHipError
+    reg = registration_for("clipper"); reg.set_context(ctx)
+    pr = synth.make_pair(6, 5, 0, 36)
+    b = rb.batch_from_pairs(reg, [(pr.map1, pr.map2), (pr.map1, pr.map2)])
+    P = reg._abi_params()
+    ok_list = np.array([[0, 0], [1, 1], [2, 2], [3, 3]], dtype=np.int32)
+    good = ctx.align_batch(P, b.feats, b.off1, b.n1, b.off2, b.n2, assoc=np.concatenate([ok_list, ok_list]), assoc_off=[0, 4, 8])
+    assert len(good.assoc) == 2
+    for assoc, off in [(np.concatenate([ok_list, [[6, 0]]]), [0, 4, 5]),          # i == n1
+                       (np.concatenate([ok_list, [[0, -1]]]), [0, 4, 5]),         # negative j
+                       (np.concatenate([ok_list, ok_list]), [0, 5, 4]),           # decreasing offsets
+                       (np.concatenate([ok_list, ok_list]), [1, 4, 8])]:          # does not start at 0
+        with pytest.raises(RomanHipError, match="out of range|non-decreasing|must be 0|bad assoc_off"):
+            ctx.align_batch(P, b.feats, b.off1, b.n1, b.off2, b.n2, assoc=assoc, assoc_off=off)
+    # an EMPTY list for one problem means all-to-all for that problem (clipperpy's convention)
+    mixed = ctx.align_batch(P, b.feats, b.off1, b.n1, b.off2, b.n2, assoc=ok_list, assoc_off=[0, 0, 4])
+    alltoall = ctx.align_batch(P, b.feats, b.off1, b.n1, b.off2, b.n2)
+    assert np.array_equal(mixed.assoc[0], alltoall.assoc[0]) and mixed.stats["n_assoc_in"].tolist() == [30, 4]
 
 
 def test_full_size_properties_cfg2_cfg3(ctx):

@@ -1,0 +1,82 @@
+"""Oracle parity at BASELINE.json's OWN configurations (n = m = 200 objects, d = 512, method 'semanticgrav'):
+EVERY problem of config 3 (the 256 pairs the benchmark times, seeds 3000..3255) and a 16 x 16 config-4 grid
+(32 submaps packed once, 256 cross pairs) is compared with the CPU oracle — identical association arrays
+(indices and order), identical n_live / nnz_upper / n_pass, pose within 1e-5 Frobenius of the oracle's
+T_align on the oracle's associations.  The hot call these replace: [REF roman/align/submap_align.py:155-166]."""
+import numpy as np
+import pytest
+
+from conftest import registration_for
+from roman_amd import _abi, synth
+from roman_amd.align import batch as rb
+
+pytestmark = pytest.mark.gpu
+POSE_TOL = 1e-5
+
+
+def _compare(orc, reg, res, problems):
+    """problems: list of (D1, D2) packed feature matrices, in batch order."""
+    P = reg._abi_params()
+    bad = []
+    worst = 0.0
+    for b, (D1, D2) in enumerate(problems):
+        o = orc.register(P, D1, D2, faithful=False)
+        st = o["stats"]
+        same = (np.array_equal(res.assoc[b], o["assoc"]) and res.stats["n_live"][b] == st.n_live
+                and res.stats["nnz_upper"][b] == st.nnz_upper and res.stats["n_pass"][b] == st.n_pass
+                and res.stats["inner_iters"][b] == st.inner_iters and res.stats["outer_iters"][b] == st.outer_iters)
+        if len(o["assoc"]) >= 3:
+            T_o = orc.t_align(D1[o["assoc"][:, 0], :3], D2[o["assoc"][:, 1], :3])
+            err = float(np.linalg.norm(res.T[b] - T_o))
+            worst = max(worst, err)
+            same = same and res.status[b] == _abi.ROMAN_ST_OK and err < POSE_TOL
+        else:
+            same = same and bool(res.status[b] & _abi.ROMAN_ST_INSUFFICIENT)
+        if not same:
+            bad.append(b)
+    return bad, worst
+
+
+def test_config3_every_one_of_the_256_pairs_matches_the_oracle(ctx, orc):
+    reg = registration_for("semanticgrav", semantics_dim=512); reg.set_context(ctx)
+    pairs = [synth.make_pair(200, 200, 512, 3000 + k) for k in range(256)]
+    batch = rb.batch_from_pairs(reg, [(p.map1, p.map2) for p in pairs])
+    res = rb.run_batch(reg, batch)
+    F = batch.feats.shape[1]
+    problems = [(batch.feats[batch.off1[b]:batch.off1[b] + 200], batch.feats[batch.off2[b]:batch.off2[b] + 200]) for b in range(256)]
+    assert problems[0][0].shape == (200, F)
+    bad, worst = _compare(orc, reg, res, problems)
+    assert not bad, f"{len(bad)} of 256 problems differ from the oracle: {bad[:10]}"
+    assert worst < POSE_TOL
+    assert (res.stats["n_assoc_in"] == 40000).all()
+
+
+def test_config4_grid_16x16_every_pair_matches_the_oracle(ctx, orc):
+    reg = registration_for("semanticgrav", semantics_dim=512); reg.set_context(ctx)
+    S = 16
+    subs, poses = synth.make_submap_grid(2 * S, n=200, d=512, seed0=4000)
+    batch = rb.batch_from_submap_grid(reg, subs[:S], subs[S:])
+    assert len(batch) == S * S and batch.feats.shape[0] == 2 * S * 200        # every submap packed once
+    res = rb.run_batch(reg, batch)
+    problems = [(batch.feats[batch.off1[b]:batch.off1[b] + batch.n1[b]], batch.feats[batch.off2[b]:batch.off2[b] + batch.n2[b]])
+                for b in range(len(batch))]
+    bad, worst = _compare(orc, reg, res, problems)
+    assert not bad, f"{len(bad)} of {S * S} grid problems differ from the oracle: {bad[:10]}"
+    assert worst < POSE_TOL
+    ok = sum(int(res.status[b] == 0 and len(res.assoc[b]) >= 20) for b in range(len(batch)))
+    assert ok >= 0.9 * len(batch)                                            # overlapping submaps do align
+
+
+def test_mixed_batch_large_and_small_live_sets(ctx, orc):
+    """One problem whose live set exceeds the streaming solver's capacity next to ordinary ones: each problem
+    takes the layout / solver that fits it, results equal the oracle's for all of them."""
+    reg = registration_for("gravity"); reg.set_context(ctx)
+    sizes = [(40, 40), (75, 80), (35, 30), (20, 20)]                           # L = n*m: 1600, 6000, 1050, 400
+    pairs = [synth.make_pair(n, m, 0, 900 + k, tilt_deg=1.0) for k, (n, m) in enumerate(sizes)]
+    batch = rb.batch_from_pairs(reg, [(p.map1, p.map2) for p in pairs])
+    res = rb.run_batch(reg, batch)
+    problems = [(batch.feats[batch.off1[b]:batch.off1[b] + batch.n1[b]], batch.feats[batch.off2[b]:batch.off2[b] + batch.n2[b]])
+                for b in range(len(batch))]
+    bad, worst = _compare(orc, reg, res, problems)
+    assert not bad and worst < POSE_TOL
+    assert res.stats["n_live"].tolist() == [1600, 6000, 1050, 400]

@@ -37,12 +37,22 @@ LADDER = [  # (id, method, kwargs, n, m, d, seed)
     # maps of more than 256 objects: one table slice per wave in the pair tests (no second row), table rows loaded
     # without the register prefetch, and a live set beyond the streaming solver's size (SELL-64 fill and solver)
     ("maps300", "semanticgrav", {"semantics_dim": 32, "cosine_min": 0.6, "cosine_max": 0.8}, 300, 300, 32, 41),
+    # the alternative readings of the two formulas pinned by decision (include/roman_hip.h ROMAN_GRAV_*, ROMAN_SINGLE_*)
+    ("grav_separate", "gravity", {"_gravity_mode": 1}, 45, 45, 0, 31),
+    ("grav_zgate", "gravity", {"_gravity_mode": 2}, 45, 45, 0, 31),
+    ("semgrav_separate", "semanticgrav", {"semantics_dim": 64, "_gravity_mode": 1}, 60, 50, 64, 12),
+    ("semgrav_zgate_200", "semanticgrav", {"semantics_dim": 128, "_gravity_mode": 2}, 200, 200, 128, 2001),
+    ("roman_offdiag", "roman", {"semantics_dim": 32, "_single_mode": 1}, 50, 50, 32, 13),
+    ("roman_diagonly", "roman", {"semantics_dim": 32, "_single_mode": 2}, 50, 50, 32, 13),
+    ("sevg_offdiag_sep", "sevg", {"semantics_dim": 16, "epsilon_shape": 0.3, "_single_mode": 1, "_gravity_mode": 1}, 45, 40, 16, 14),
 ]
 
 
 def make(case):
     _, method, kw, n, m, d, seed = case
-    reg = registration_for(method, **kw)
+    reg = registration_for(method, **{k: v for k, v in kw.items() if not k.startswith("_")})
+    reg._abi_params().gravity_mode = kw.get("_gravity_mode", 0)        # decision switches: not part of the reference's
+    reg._abi_params().single_mode = kw.get("_single_mode", 0)          # parameter set, set on the ABI block directly
     pr = synth.make_pair(n, m, d, seed, tilt_deg=1.0 if reg._abi_params().gravity_guided else 0.0)
     if kw.get("dim") == 2:
         for o in pr.map1 + pr.map2:
@@ -56,7 +66,7 @@ def test_stagewise_parity(ctx, orc, case):
     reg.set_context(ctx)
     P = reg._abi_params()
     D1, D2 = reg.pack(pr.map1), reg.pack(pr.map2)
-    A = reg._associations_to_score(pr.map1, pr.map2)
+    A = reg._association_list(pr.map1, pr.map2)
     mat, Ao = orc.build_matrix(P, D1, D2, A)
     sol = orc.solve(P, mat)
     ctx.score(P, D1, D2, A)
@@ -66,15 +76,14 @@ def test_stagewise_parity(ctx, orc, case):
     live_o = np.nonzero(s_o > 0)[0]
     idx, sc = ctx.live()
     assert np.array_equal(idx, live_o)
-    assert np.allclose(sc, s_o[live_o], rtol=1e-12, atol=0)
+    assert np.array_equal(sc, s_o[live_o])          # bit-identical: stated-order dot / norms, exact ops otherwise
 
     # (2) affinity matrix: bit-identical sparsity pattern, values within a few ulp
     rp_o, c_o, v_o, d_o = mat.export()
     rp, cc, vv, dd = ctx.upper_csr()
     assert np.array_equal(rp, rp_o) and np.array_equal(cc, c_o)
-    if v_o.size:
-        assert np.max(np.abs(vv - v_o) / np.abs(v_o)) < 1e-13
-    assert np.allclose(dd, d_o, rtol=1e-12, atol=0)
+    assert np.array_equal(vv, v_o)                  # bit-identical values: fixed-sequence exp / cbrt on both sides
+    assert np.array_equal(dd, d_o)
 
     # (3) solver: same selected nodes in the same order, same trajectory
     ctx.solve(None)
@@ -104,9 +113,10 @@ def test_stagewise_parity(ctx, orc, case):
         assert len(got & truth) >= 0.85 * len(truth)
 
 
-def test_device_arithmetic_is_bit_exact(ctx):
-    """The ops that shape the sparsity pattern (+,-,*,/,sqrt) are IEEE-exact on gfx950; the
-    transcendental ones stay within 2 ulp of glibc."""
+def test_device_arithmetic_is_bit_exact(ctx, orc):
+    """The ops every threshold is applied to (+,-,*,/,sqrt,fma and the two fixed-sequence functions) give the
+    host's bits on gfx950; the device's own libm stays within 2 ulp of glibc (it is only used for pow with
+    non-integer weights)."""
     rng = np.random.default_rng(0)
     x = np.concatenate([rng.uniform(0, 1000, 200000), rng.uniform(0, 1e-3, 50000), 10.0 ** rng.uniform(-300, 300, 50000)])
     assert np.array_equal(ctx.debug_math(0, x), np.sqrt(x))
@@ -117,6 +127,16 @@ def test_device_arithmetic_is_bit_exact(ctx):
     c = rng.uniform(1e-12, 1, 200000)
     assert ulp_diff(ctx.debug_math(2, c), np.cbrt(c)).max() <= 2
     assert ulp_diff(ctx.debug_math(4, c, np.full_like(c, 0.25)), np.power(c, 0.25)).max() <= 2
+    # fma, and the fixed sequences of exact operations that replace exp / cbrt on the scoring path
+    a, b = rng.standard_normal(100000), rng.standard_normal(100000)
+    from fractions import Fraction
+    got = ctx.debug_math(7, a, b)
+    for k in range(0, 100000, 997):
+        assert got[k] == float(Fraction(a[k]) * Fraction(b[k]) + Fraction(a[k]))
+    e2 = np.concatenate([-rng.uniform(0, 2, 200000), rng.uniform(-40, 40, 50000), [0.0, -1.125, -650.0]])
+    assert np.array_equal(ctx.debug_math(5, e2), orc.fixed_exp(e2))
+    c2 = np.concatenate([rng.uniform(0, 1, 200000), 10.0 ** rng.uniform(-30, 3, 50000), [1.0, 0.125, 1e-12]])
+    assert np.array_equal(ctx.debug_math(6, c2), orc.fixed_cbrt(c2))
 
 
 @pytest.mark.parametrize("n1,n2,d", [(16, 16, 4), (37, 53, 70), (200, 200, 512), (5, 3, 1), (1, 1, 9)])
@@ -134,6 +154,100 @@ def test_mfma_cosine_kernel(ctx, n1, n2, d):
         ref = (a @ b.T) / np.outer(np.linalg.norm(a, axis=1), np.linalg.norm(b, axis=1))
     ref[~np.isfinite(ref)] = 0.0
     assert np.max(np.abs(got - ref)) < 1e-14
+
+
+@pytest.mark.parametrize("n1,n2,d", [(16, 16, 4), (20, 24, 16), (37, 53, 70), (64, 64, 512), (9, 7, 768), (5, 3, 1)])
+def test_cosine_bits_equal_the_oracles_stated_order(ctx, orc, n1, n2, d):
+    """The f64 matrix-core contraction accumulates in the order the oracle states (dot_fixed / norm_fixed in
+    oracle/clipper_oracle.c): the cosine matrix is BIT-identical, so the cosine gate decides on the same value."""
+    rng = np.random.default_rng(n1 * 977 + n2 * 13 + d)
+    P = _abi.RomanParams.default(); P.cos_feature_dim = d
+    D1 = rng.standard_normal((n1, 3 + d)); D2 = rng.standard_normal((n2, 3 + d))
+    got = ctx.debug_cosine(P, D1, D2)
+    ref = np.array([[orc.cosine(D1[i, 3:], D2[j, 3:]) for j in range(n2)] for i in range(n1)])
+    assert np.array_equal(got, ref)
+
+
+def _nudge(x, k):
+    for _ in range(abs(k)):
+        x = np.nextafter(x, np.inf if k > 0 else -np.inf)
+    return float(x)
+
+
+def test_associations_on_the_cosine_threshold(ctx, orc):
+    """Associations whose cosine sits exactly ON cos_min, one ulp below and one ulp above it: the live set is the
+    oracle's in every case and flips where it must (`c > 0` after the rescaling, strict)."""
+    rng = np.random.default_rng(3)
+    n, d = 24, 96
+    reg = registration_for("semanticgrav", semantics_dim=d); reg.set_context(ctx)
+    pr = synth.make_pair(n, n, d, 77, tilt_deg=1.0)
+    D1, D2 = reg.pack(pr.map1), reg.pack(pr.map2)
+    cos = np.array([[orc.cosine(D1[i, 3:], D2[j, 3:]) for j in range(n)] for i in range(n)])
+    flat = np.sort(cos.ravel())
+    targets = [flat[len(flat) // 2], flat[int(0.9 * len(flat))], flat[int(0.97 * len(flat))]]   # three distinct on-threshold cases
+    seen_flip = 0
+    for t in targets:
+        lives = []
+        for k in (-1, 0, 1):
+            P = type(reg._abi_params()).from_buffer_copy(reg._abi_params())
+            P.cosine_min = _nudge(t, k); P.cosine_max = P.cosine_min + 0.2
+            s_o = orc.single_scores(P, D1, D2)
+            ctx.score(P, D1, D2, None)
+            idx, sc = ctx.live()
+            assert np.array_equal(idx, np.nonzero(s_o > 0)[0]) and np.array_equal(sc, s_o[idx])
+            mat, _ = orc.build_matrix(P, D1, D2)
+            rp_o, c_o, v_o, _ = mat.export()
+            rp, cc, vv, _ = ctx.upper_csr()
+            assert np.array_equal(rp, rp_o) and np.array_equal(cc, c_o) and np.array_equal(vv, v_o)
+            lives.append(len(idx))
+        on = int((cos == t).sum())
+        assert lives[0] - lives[1] == on and lives[1] >= lives[2]     # cos == cos_min is dead, one ulp below cos_min it is live
+        seen_flip += on
+    assert seen_flip >= 3
+
+
+@pytest.mark.parametrize("method", ["clipper", "gravity"])
+def test_pairs_on_the_epsilon_threshold(ctx, orc, method):
+    """Object pairs whose length difference is exactly epsilon, and epsilon moved by +-1 and +-2 ulp around it:
+    the sparsity pattern is the oracle's in every case (`c < epsilon`, strict) and changes where it must."""
+    reg = registration_for(method); reg.set_context(ctx)
+    # map 1: points on the x axis 3 apart; map 2: points 2.4 apart -> |3 - fl(2.4)| is exactly one ulp above fl(0.6)
+    xs1 = [0.0, 3.0, 6.0, 9.0, 12.5]; xs2 = [0.0, 2.4, 4.8, 7.2, 12.5]
+    D1 = np.array([[x, 0.0, 0.0] for x in xs1]); D2 = np.array([[x, 0.0, 0.0] for x in xs2])
+    c_exact = 3.0 - 2.4
+    sizes = []
+    for k in (-2, -1, 0, 1, 2):
+        P = type(reg._abi_params()).from_buffer_copy(reg._abi_params())
+        P.epsilon = _nudge(c_exact, k); P.mindist = 0.0
+        mat, _ = orc.build_matrix(P, D1, D2)
+        rp_o, c_o, v_o, _ = mat.export()
+        ctx.score(P, D1, D2, None)
+        rp, cc, vv, _ = ctx.upper_csr()
+        assert np.array_equal(rp, rp_o) and np.array_equal(cc, c_o) and np.array_equal(vv, v_o)
+        sizes.append(len(c_o))
+    assert sizes[0] == sizes[1] == sizes[2] < sizes[3] == sizes[4]    # c == epsilon is rejected, epsilon one ulp larger accepts it
+
+
+def test_entries_on_the_affinityeps_threshold(ctx, orc):
+    """Single scores small enough that fused entries straddle affinityeps: kept and dropped entries are the
+    oracle's (the gate is applied to values both sides compute with the same fixed operation sequences)."""
+    n, d = 30, 48
+    reg = registration_for("semanticgrav", semantics_dim=d); reg.set_context(ctx)
+    pr = synth.make_pair(n, n, d, 78, tilt_deg=1.0)
+    D1, D2 = reg.pack(pr.map1), reg.pack(pr.map2)
+    P0 = reg._abi_params()
+    mat, _ = orc.build_matrix(P0, D1, D2)
+    vals = np.sort(mat.export()[2])
+    assert vals.size > 50
+    for t in (vals[3], vals[len(vals) // 3], vals[len(vals) // 2]):
+        for k in (-1, 0, 1):
+            P = type(P0).from_buffer_copy(P0); P.affinityeps = _nudge(t, k)
+            m2, _ = orc.build_matrix(P, D1, D2)
+            rp_o, c_o, v_o, _ = m2.export()
+            ctx.score(P, D1, D2, None)
+            rp, cc, vv, _ = ctx.upper_csr()
+            assert np.array_equal(rp, rp_o) and np.array_equal(cc, c_o) and np.array_equal(vv, v_o)
+            assert (v_o > P.affinityeps).all()
 
 
 def test_explicit_u0_and_no_rescale(ctx, orc):

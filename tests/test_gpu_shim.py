@@ -53,3 +53,29 @@ def test_reference_call_sequence_through_shim(ctx, orc):
     Md = c2.get_affinity_matrix(); Cd = c2.get_constraint_matrix()
     c3.set_matrix_data(M=Md, C=Cd); c3.solve()
     assert np.array_equal(A_put[c3.get_solution().nodes], c2.get_selected_associations())
+
+
+def test_context_sharing_between_shim_objects_and_plugins(ctx, orc):
+    """One context holds ONE stepwise problem.  A shim CLIPPER object whose problem was displaced — by another
+    CLIPPER object, by a registration plugin's register(), or by a batch call on the same context — reloads its
+    own inputs before solve() / get_*_matrix() instead of silently operating on the newcomer's problem."""
+    clipperpy = roman_amd.install_clipperpy_shim(force=True)
+    ep = clipperpy.invariants.EuclideanDistanceParams(); ep.sigma, ep.epsilon, ep.mindist = 0.4, 0.6, 0.2
+    prA, prB = synth.make_pair(20, 22, 0, 801), synth.make_pair(26, 18, 0, 802)
+    reg = registration_for("clipper"); reg.set_context(ctx)
+    ptsA = (reg.pack(prA.map1), reg.pack(prA.map2)); ptsB = (reg.pack(prB.map1), reg.pack(prB.map2))
+    refA = orc.register(reg._abi_params(), *ptsA)["assoc"]; refB = orc.register(reg._abi_params(), *ptsB)["assoc"]
+    assert not np.array_equal(refA, refB)
+    cA = clipperpy.CLIPPER(clipperpy.invariants.EuclideanDistance(ep), clipperpy.Params()); cA._ctx = ctx
+    cB = clipperpy.CLIPPER(clipperpy.invariants.EuclideanDistance(ep), clipperpy.Params()); cB._ctx = ctx
+    cA.score_pairwise_consistency(ptsA[0].T, ptsA[1].T)
+    cB.score_pairwise_consistency(ptsB[0].T, ptsB[1].T)            # displaces A's problem
+    cA.solve()
+    assert np.array_equal(cA.get_selected_associations(), refA)
+    assert np.array_equal(reg.register(prB.map1, prB.map2), refB)   # a plugin call on the same context ...
+    assert cA.get_affinity_matrix().shape == (20 * 22,) * 2         # ... and A still answers for its own problem
+    reg.register_and_align_batch([(prB.map1, prB.map2)])            # so does a batch call
+    cA.solve()
+    assert np.array_equal(cA.get_selected_associations(), refA)
+    cB.solve()
+    assert np.array_equal(cB.get_selected_associations(), refB)

@@ -69,6 +69,18 @@ def test_empty_map_and_exception_protocol():
     assert issubclass(GravityConstraintError, Exception) and ObjectRegistration(dim=2).dim == 2
 
 
+def test_fully_pruned_list_means_all_to_all():
+    """Every association pruned -> the reference hands clipperpy an empty A, which it replaces by the all-to-all
+    list ([REF roman/align/dist_reg_with_pruning.py:94-96]); the mirror maps the empty list to None likewise
+    (pinned by the last register_golden case, generated through the reference's own class)."""
+    reg = DistRegWithPruning(0.4, 0.6, 0.2, shape_epsilon=0.0, cos_min=0.9999, use_gravity=True)
+    pr = synth.make_pair(12, 10, 16, 5)
+    assert reg._associations_to_score(pr.map1, pr.map2).shape == (0, 2)
+    assert reg._association_list(pr.map1, pr.map2) is None
+    from roman_amd.align.batch import batch_from_pairs
+    assert batch_from_pairs(reg, [(pr.map1, pr.map2)]).assoc is None
+
+
 def test_prune_prefilter_matches_formula():
     reg = DistRegWithPruning(0.4, 0.6, 0.2, shape_epsilon=0.3, cos_min=0.5, use_gravity=True)
     pr = synth.make_pair(12, 10, 16, 5)

@@ -190,7 +190,7 @@ def test_reference_python_through_oracle_is_reproduced_by_the_mirror(orc, case):
     pr = golden_pair(case)
     D1, D2 = reg.pack(pr.map1), reg.pack(pr.map2)
     assert np.array_equal(D1, case["pack1"]) and np.array_equal(D2, case["pack2"])      # feature rows (a1)
-    A = reg._associations_to_score(pr.map1, pr.map2)
+    A = reg._association_list(pr.map1, pr.map2)          # an empty pruned list means all-to-all (as for clipperpy)
     A_eff = orc.create_all_to_all(len(pr.map1), len(pr.map2)) if A is None else A
     assert np.array_equal(A_eff, case["A_scored"])                                      # a3 / a9
     res = orc.register(reg._abi_params(), D1, D2, A)
