@@ -205,7 +205,9 @@ static double root_w(double x, double w)
     if (w == 1.0) return x;
     if (w == 2.0) return sqrt(x);
     if (w == 3.0) return x_cbrt(x);
-    return pow(x, 1.0 / w);        /* non-integer weights: libm pow (values then agree with the device to a few ulp only) */
+    if (w == 4.0) return sqrt(sqrt(x));   /* four ratio features (every method of the factory that has any): exact operations */
+    if (w == 6.0) return x_cbrt(sqrt(x));
+    return pow(x, 1.0 / w);        /* other weights: libm pow (values then agree with the device to a few ulp only) */
 }
 static double pow_w(double x, double w)
 {

@@ -160,6 +160,8 @@ __device__ __forceinline__ double root_w(double x, double w)
     if (w == 1.0) return x;
     if (w == 2.0) return sqrt(x);
     if (w == 3.0) return fx_cbrt(x);
+    if (w == 4.0) return sqrt(sqrt(x));
+    if (w == 6.0) return fx_cbrt(sqrt(x));
     return pow(x, 1.0 / w);
 }
 __device__ __forceinline__ double pow_w(double x, double w) { return (w == 1.0) ? x : pow(x, w); }
