@@ -704,6 +704,15 @@ ORACLE_API int32_t oracle_register(const roman_params_t* P, const double* D1, in
     return k;
 }
 
+ORACLE_API void oracle_set_threads(int n)
+{
+#ifdef _OPENMP
+    if (n >= 1) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 ORACLE_API int oracle_num_threads(void)
 {
 #ifdef _OPENMP

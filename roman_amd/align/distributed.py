@@ -1,9 +1,11 @@
 """Multi-GPU sharding of a batch of independent alignments.
 
 One process per GPU (torch.distributed; backend "nccl" is RCCL on ROCm).  Problems are independent
-([REF roman/align/submap_align.py:93-200] carries no state across iterations), so each rank aligns a
-contiguous shard of the flattened pair list and ONE all_gather of fixed-size result records
-collects the inlier sets and poses.  No other collective.
+([REF roman/align/submap_align.py:93-200] carries no state across iterations), so every rank aligns its share of the
+flattened pair list and ONE all_gather of fixed-size result records collects the inlier sets and poses.  No other
+collective.  The share is cost-balanced: problems are dealt longest-first (cost = number of associations to score,
+n1*n2 for all-to-all) to the rank with the least work so far — the deal is a pure function of the batch, identical on
+every rank.  On GPUs the records never leave the device before the gather.
 """
 import numpy as np
 
@@ -17,39 +19,114 @@ def shard_bounds(n_items, rank, world_size):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+def problem_costs(batch: AlignmentBatch):
+    """Associations each problem scores (the O(A^2) build and the solver both grow with it)."""
+    if batch.assoc_off is not None:
+        a = np.diff(batch.assoc_off).astype(np.int64)
+        full = batch.n1.astype(np.int64) * batch.n2.astype(np.int64)
+        return np.where(a > 0, a, full)                       # an empty list means all-to-all
+    return batch.n1.astype(np.int64) * batch.n2.astype(np.int64)
+
+
+def deal_by_cost(costs, world_size):
+    """Longest-processing-time deal -> list of ascending index arrays, one per rank.  Deterministic: ties in cost keep
+    problem order, ties in load go to the lowest rank."""
+    costs = np.asarray(costs, dtype=np.int64)
+    order = np.argsort(-costs, kind="stable")
+    load = np.zeros(world_size, dtype=np.int64)
+    count = np.zeros(world_size, dtype=np.int64)
+    shards = [[] for _ in range(world_size)]
+    for i in order:
+        # lightest rank; among equally light ones the one holding fewer problems, then the lowest rank
+        r = int(np.lexsort((np.arange(world_size), count, load))[0])
+        shards[r].append(int(i)); load[r] += max(int(costs[i]), 1); count[r] += 1
+    return [np.array(sorted(s), dtype=np.int64) for s in shards]
+
+
+def take(batch: AlignmentBatch, idx) -> AlignmentBatch:
+    """The problems `idx` of a batch over the same feature pool."""
+    idx = np.asarray(idx, dtype=np.int64)
+    a, ao = None, None
+    if batch.assoc is not None:
+        lens = np.diff(batch.assoc_off)[idx]
+        ao = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        a = np.concatenate([batch.assoc[batch.assoc_off[i]:batch.assoc_off[i + 1]] for i in idx], axis=0) if len(idx) else np.zeros((0, 2), np.int32)
+    return AlignmentBatch(batch.feats, batch.off1[idx], batch.n1[idx], batch.off2[idx], batch.n2[idx], a, ao,
+                          None if batch.pair_index is None else batch.pair_index[idx])
+
+
+def _device_records(registration, sub: AlignmentBatch, kmax, per, dev):
+    """Align `sub` with device-resident inputs and outputs; -> (ints (per, 2+2*kmax) int32, poses (per,16) f64) torch
+    tensors on `dev`, rows beyond len(sub) padded with -1 / NaN."""
+    import torch
+    from .. import _abi
+    ctx = registration._context()
+    B = len(sub)
+    ints = torch.full((per, 2 + 2 * kmax), -1, dtype=torch.int32, device=dev)
+    poses = torch.full((per, 16), float("nan"), dtype=torch.float64, device=dev)
+    if B == 0:
+        return ints, poses
+    P = registration._abi_params()
+    F = sub.feats.shape[1]
+    feats = torch.from_numpy(sub.feats).to(dev)
+    assoc = None if sub.assoc is None else torch.from_numpy(np.ascontiguousarray(sub.assoc, dtype=np.int32)).to(dev)
+    a_out = torch.full((B, kmax, 2), -1, dtype=torch.int32, device=dev)
+    n_out = torch.zeros(B, dtype=torch.int32, device=dev)
+    T_out = torch.zeros((B, 16), dtype=torch.float64, device=dev)
+    st_out = torch.zeros(B, dtype=torch.int32, device=dev)
+    torch.cuda.current_stream(dev).synchronize()               # inputs are in place before the library's stream reads them
+    for attempt in range(4):                                   # the device-pointer entry sizes its pools speculatively
+        ctx.align_batch_dev(P, feats.data_ptr(), F, sub.off1, sub.n1, sub.off2, sub.n2, kmax, a_out.data_ptr(), n_out.data_ptr(),
+                            T_out.data_ptr(), st_out.data_ptr(), None,
+                            assoc_ptr=None if assoc is None else assoc.data_ptr(), assoc_off=sub.assoc_off)
+        ctx.sync()
+        if not bool((st_out & _abi.ROMAN_ST_WORKSPACE).any()):
+            break
+    ints[:B, 0] = n_out; ints[:B, 1] = st_out
+    valid = torch.arange(kmax, device=dev)[None, :] < n_out[:, None]
+    ints[:B, 2:] = torch.where(valid[:, :, None], a_out, torch.full_like(a_out, -1)).reshape(B, -1)
+    poses[:B] = T_out
+    return ints, poses
+
+
 def align_sharded(registration, batch: AlignmentBatch, group=None, compute=None, device=None):
     """Align `batch` across the ranks of `group` (default: WORLD); every rank returns the full result
     (assoc list, T, status) in problem order.
 
-    compute(registration, sub_batch) -> runtime.BatchResult defaults to the HIP path (run_batch).
-    `device`: torch device for the gathered tensors (cuda:<local rank> under RCCL, cpu under gloo).
+    compute(registration, sub_batch) -> runtime.BatchResult: a CPU double for tests; by default the HIP path runs with
+    device-resident records (`device`: torch device of this rank, default cuda:<current device>).
     """
     import torch
     import torch.distributed as dist
-    compute = compute or run_batch
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     B = len(batch)
     kmax = batch.kmax()
-    lo, hi = shard_bounds(B, rank, world)
-    res = compute(registration, batch.subset(lo, hi))
-    ints, poses = pack_records(res, kmax)
-    if world == 1:
-        return unpack_records(ints, poses, registration.dim)
-    # pad every shard to the largest shard so all_gather sees equal shapes
-    per = (B + world - 1) // world
-    ints_p = np.full((per, ints.shape[1]), -1, dtype=np.int32); ints_p[:ints.shape[0]] = ints
-    poses_p = np.full((per, 16), np.nan, dtype=np.float64); poses_p[:poses.shape[0]] = poses
-    dev = device if device is not None else (torch.device("cuda", torch.cuda.current_device())
-                                             if dist.get_backend(group) == "nccl" else torch.device("cpu"))
-    ti = torch.from_numpy(ints_p).to(dev); tp = torch.from_numpy(poses_p).to(dev)
-    gi = torch.empty((world * per, ti.shape[1]), dtype=ti.dtype, device=dev)    # concatenated along dim 0
-    gp = torch.empty((world * per, tp.shape[1]), dtype=tp.dtype, device=dev)
-    dist.all_gather_into_tensor(gi, ti, group=group)
-    dist.all_gather_into_tensor(gp, tp, group=group)
+    shards = deal_by_cost(problem_costs(batch), world)
+    mine = shards[rank]
+    per = max(1, max(len(s) for s in shards))                  # every rank gathers equal shapes
+    sub = take(batch, mine)
+    on_device = compute is None
+    if on_device:
+        dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        ti, tp = _device_records(registration, sub, kmax, per, dev)
+    else:
+        res = compute(registration, sub)
+        ints, poses = pack_records(res, kmax)
+        ints_p = np.full((per, ints.shape[1]), -1, dtype=np.int32); ints_p[:ints.shape[0]] = ints
+        poses_p = np.full((per, 16), np.nan, dtype=np.float64); poses_p[:poses.shape[0]] = poses
+        dev = device if device is not None else (torch.device("cuda", torch.cuda.current_device())
+                                                 if dist.is_initialized() and dist.get_backend(group) == "nccl" else torch.device("cpu"))
+        ti = torch.from_numpy(ints_p).to(dev); tp = torch.from_numpy(poses_p).to(dev)
+    if world > 1:
+        gi = torch.empty((world * per, ti.shape[1]), dtype=ti.dtype, device=ti.device)    # concatenated along dim 0
+        gp = torch.empty((world * per, tp.shape[1]), dtype=tp.dtype, device=tp.device)
+        dist.all_gather_into_tensor(gi, ti, group=group)
+        dist.all_gather_into_tensor(gp, tp, group=group)
+    else:
+        gi, gp = ti, tp
     gi = gi.cpu().numpy().reshape(world, per, -1); gp = gp.cpu().numpy().reshape(world, per, -1)
-    rows_i, rows_p = [], []
+    out_i = np.full((B, gi.shape[2]), -1, dtype=np.int32); out_p = np.full((B, 16), np.nan)
     for r in range(world):
-        rlo, rhi = shard_bounds(B, r, world)
-        rows_i.append(gi[r, :rhi - rlo]); rows_p.append(gp[r, :rhi - rlo])
-    return unpack_records(np.concatenate(rows_i, axis=0), np.concatenate(rows_p, axis=0), registration.dim)
+        out_i[shards[r]] = gi[r, :len(shards[r])]; out_p[shards[r]] = gp[r, :len(shards[r])]
+    return unpack_records(out_i, out_p, registration.dim)

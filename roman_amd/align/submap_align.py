@@ -112,6 +112,15 @@ class Submap:
         return np.max(sims)
 
 
+def stacked_similarity(ctx, descs0, descs1):
+    """Best pairwise cosine between the frame descriptors of every submap of robot 0 and every submap of robot 1
+    ([REF roman/map/map.py:152-162]) -> (S0, S1).  One cosine kernel over all frames, then a segmented maximum."""
+    o0 = np.concatenate([[0], np.cumsum([d.shape[0] for d in descs0])]).astype(np.int64)
+    o1 = np.concatenate([[0], np.cumsum([d.shape[0] for d in descs1])]).astype(np.int64)
+    frames = ctx.cosine_matrix(np.concatenate(descs0, axis=0), np.concatenate(descs1, axis=0))     # zero-norm frames: 0
+    return np.maximum.reduceat(np.maximum.reduceat(frames, o0[:-1], axis=0), o1[:-1], axis=1)
+
+
 @dataclass
 class SubmapAlignIO:
     """The fields of SubmapAlignInputOutput [REF roman/params/submap_align_params.py:153-198] the loop and the
@@ -161,13 +170,19 @@ def submap_align(sm_params, submaps, sm_io: Optional[SubmapAlignIO] = None, regi
     associated_objs_mat = [[[] for _ in range(n1)] for _ in range(n0)]
     total_time_t0 = time.time()
 
-    # ---- submap-descriptor gate: all S0 x S1 cosines in one device call when the descriptors are plain vectors
-    # (row f2; stacked descriptors and the CPU test double use the per-pair numpy form below) --------------------
+    # ---- submap-descriptor gate (row f2): every cosine of the S0 x S1 gate in ONE device call (k_cos, f64 matrix
+    # core).  Plain vector descriptors: the S0 x S1 cosine matrix itself.  Stacked per-frame descriptors
+    # ([REF roman/map/map.py:152-162]: the best cosine over all frame pairs, zero-norm frames scoring 0): all frames
+    # of all submaps go through the same kernel at once and the per-pair maximum is a segmented reduction of its
+    # output.  (The CPU test double uses the per-pair numpy form below.) -----------------------------------------
     sim_all = None
     if sm_params.submap_descriptor is not None and compute is run_batch and n0 and n1:
         descs = [[np.asarray(sm.descriptor) for sm in submaps[r]] for r in range(2)]
-        if all(d.ndim == 1 for r in range(2) for d in descs[r]):
+        flat = [d for r in range(2) for d in descs[r]]
+        if all(d.ndim == 1 for d in flat):
             sim_all = registration._context().cosine_matrix(np.stack(descs[0]), np.stack(descs[1]))
+        elif all(d.ndim == 2 and d.shape[0] > 0 and d.shape[1] == flat[0].shape[1] for d in flat):
+            sim_all = stacked_similarity(registration._context(), descs[0], descs[1])
 
     # ---- pass 1: gating, reference transforms, the list of pairs to register ([REF :93-149]) -------------------
     todo = []                                            # (i, j, segs_i, segs_j)

@@ -1,21 +1,27 @@
 // kernels.hip.h — gfx950 (CDNA4, wave64) device code of libroman_hip.so.
 //
 // Pipeline for a batch of B independent submap pairs (one "problem" each):
-//   k_cos     normalised cosine matrix (+ descriptor norms), f64 MFMA 16x16x4   (cos_feature_dim > 0)
-//   k_tables  intra-map distance tables with NaN sentinels      (n1^2 + n2^2 entries)
-//   k_live    single scores + ordered compaction of live associations
-//   k_rowbase prefix of live counts over problems
-//   k_rowmap  flattened row -> problem map
-//   k_count (pair tests -> candidate bit masks) / k_rowsort / k_probscan / k_fill   sparse affinity build
-//   k_solve   persistent per-problem projected-gradient solver + top-omega + Umeyama pose
+//   k_cos        normalised cosine matrix (+ descriptor norms), f64 MFMA 16x16x4   (cos_feature_dim > 0)
+//   k_tables     intra-map distance tables with NaN sentinels      (n1^2 + n2^2 entries)
+//   k_live       single scores + ordered compaction of live associations; picks the problem's KIND
+//   k_rowbase / k_items   prefix of live counts over problems, work-item list
+//   k_count      the O(L^2) pair tests -> candidate bit matrix (upper 64-bit words), k_mirror the lower ones
+//   k_rowprefix  row degrees (+ per-word prefix counts for the fallback layout)
+//   k_rowsort    rows by descending degree
+//   kind 0 ("stream", L <= STREAM_MAXL):
+//     k_permute    bit matrix into POSITION numbering (position = rank by degree), strict upper triangle only
+//     k_slicegeom  slice widths / bases of the quad layout
+//     k_fill_slice candidates -> values, one 64-row slice image at a time
+//     k_solve_up   persistent per-problem CLIPPER solve on the upper triangle (pull + push SpMV)
+//   kind 1 (fallback, any L): symmetric sorted SELL-64 in live numbering: k_fill, k_solve
 //
-// Layout of M in HBM (sorted SELL-64): per problem the live rows are counting-sorted by
-// their number of entries (descending) and cut into slices of 64 rows; a slice is stored entry-index-
-// major and padded to its longest row:  entry e of the row in slot (slice s, lane l) sits at
+// Matrix layout of kind 0: only the strict upper triangle of M in position numbering is stored
+// (entry (p,q), p < q, in row p) — 10 bytes per non-zero of the upper triangle.  Rows are cut into slices of 64
+// consecutive positions, a slice is padded to its longest row (multiple of 4 entries) and stored as "quads":
+// the 4 column indices of entries 4g..4g+3 of a lane are one 8-byte word, the values of entries 2h,2h+1 one
+// 16-byte pair: 3 wide, fully coalesced loads per 4 entries.  Padding is inert (value 0, column L, C-flag).
+// Layout of kind 1 (sorted SELL-64, both triangles): entry e of the row in slot (slice s, lane l) sits at
 //      sliceBase[s] + e*64 + l .
-// A wave that owns a slice (lane = row) therefore reads 64 contiguous words per step with no
-// predicates, ballots or cross-lane reductions, and keeps 2*G independent loads in flight.  Padding
-// and filtered entries are "inert": value 0 with the C-flag set (they add exactly nothing).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -24,6 +30,7 @@
 namespace roman {
 
 constexpr int WAVE = 64;
+constexpr int STREAM_MAXL = 3072;        // live associations the stream layout / solver serve (48 slices of 64 rows)
 
 struct DevParams {
     roman_params_t p;
@@ -37,6 +44,8 @@ struct DevParams {
     int32_t max_compact; // streaming solver: column compactions allowed per problem (speed only; set per launch)
     int32_t gmode;      // 0: no gravity; 1 + ROMAN_GRAV_* otherwise (1 combined, 2 separate gates, 3 z gate on full lengths)
     int32_t diag_one;   // single scores present but the diagonal is the identity (ROMAN_SINGLE_OFFDIAG)
+    int32_t stream_maxL;     // problems of up to this many live associations take the stream layout (<= STREAM_MAXL; set per launch:
+                             // it is also the column capacity of k_fill_slice's LDS tile and of the stream solver's LDS vectors)
 };
 
 struct ProbDesc {
@@ -57,17 +66,23 @@ struct ProbState {
     uint32_t nnzCap;       // padded SELL slots allocated for this problem
     int32_t  itemBase;     // first work item (row block) of this problem
     int32_t  sgBase;       // first slice group (k_fill_slice work item) of this problem
-    int32_t  pad0;
+    int32_t  kind;         // 0: stream layout + k_solve_up (L <= STREAM_MAXL), 1: symmetric SELL-64 fallback
     unsigned long long nnzUpper;   // stored strict-upper non-zeros (after the affinityeps filter)
 };
 
 struct BatchTotals {
-    int64_t nnzTotal;      // sum of nnzCap
-    int64_t maskWords;     // sum over problems of L * ceil(L/64)
+    int64_t nnzTotal;      // sum of nnzCap over the problems that fit
+    int64_t maskWords;     // sum over the problems that fit of L * ceil(L/64)
     int32_t R;             // sum of L
     int32_t maxL;
     int32_t items;         // work items (row blocks) of the pair-test / fill kernels
     int32_t sliceGroups;   // work items (groups of SPI slices) of k_fill_slice
+    // what the whole batch WOULD need (the pools are sized before the live counts are known: problems that do not fit
+    // are skipped with ROMAN_ST_WORKSPACE and the host grows the pools from these numbers)
+    int64_t needMaskWords;
+    int64_t needNnz;
+    int32_t overflow;      // problems skipped for lack of workspace
+    int32_t maxStreamL;    // largest L among stream-layout problems
 };
 
 struct ItemDesc { int32_t b, row0; };   // a block of consecutive live rows of problem b
@@ -97,6 +112,7 @@ template <bool QUAD> __device__ __forceinline__ int64_t val_pos(int64_t sbase, u
 // ---------------------------------------------------------------------------------------------
 
 __device__ __forceinline__ double d_nan() { return __longlong_as_double(0x7ff8000000000000LL); }
+__device__ __forceinline__ int uni_i(int v) { return __builtin_amdgcn_readfirstlane(v); }    // wave-uniform value into an SGPR
 
 // association index p of problem pd -> (map-1 object, map-2 object)
 __device__ __forceinline__ void decode_assoc(const ProbDesc& pd, const int32_t* __restrict__ assoc,
@@ -445,7 +461,10 @@ __global__ void __launch_bounds__(256) k_live(DevParams D, const ProbDesc* __res
     __syncthreads();
     int base = cbase[0];
     for (int k = 0; k < w; ++k) base += wtot[k];
-    if (c == 0 && tid == 0) { st[b].L = cbase[1]; st[b].nnzUpper = 0ull; }
+    if (c == 0 && tid == 0) {
+        st[b].L = cbase[1]; st[b].nnzUpper = 0ull;
+        st[b].kind = (cbase[1] <= D.stream_maxL && D.p.maxiniters >= 1 && D.p.maxlsiters >= 1) ? 0 : 1;
+    }
 
     const int64_t lo = pd.liveOff;
     for (int p0 = p_beg; p0 < p_end; p0 += WAVE) {
@@ -469,29 +488,39 @@ __global__ void __launch_bounds__(256) k_live(DevParams D, const ProbDesc* __res
 
 // k_rowbase: serial prefix of the live counts (B is small); also the batch maxima, the offsets of
 // the per-problem candidate bit matrices (L rows of ceil(L/64) words) and the work-item prefix
-// (a work item = a block of up to RPB consecutive live rows of one problem).
-__global__ void __launch_bounds__(64) k_rowbase(int B, int RPB, ProbState* __restrict__ st, BatchTotals* __restrict__ tot)
+// (a work item = a block of up to RPB consecutive live rows of one problem).  The bit-matrix pools were sized
+// before L was known: a problem whose matrix would end beyond `capMaskWords` becomes kind 2 (skipped).
+__global__ void __launch_bounds__(64) k_rowbase(int B, int RPB, long long capMaskWords, ProbState* __restrict__ st, BatchTotals* __restrict__ tot)
 {
     // one wave; lane-strided blocks of 64 problems with a running carry (B is small)
     const int lane = threadIdx.x;
-    int accR = 0, accI = 0, mx = 0; long long accM = 0;
+    int accR = 0, accI = 0, mx = 0, mxs = 0, nover = 0; long long accM = 0;
     for (int b0 = 0; b0 < B; b0 += WAVE) {
         const int b = b0 + lane;
         const int L = b < B ? st[b].L : 0;
-        const int it = (L + RPB - 1) / RPB;
         const long long mw = (long long)L * ((L + 63) >> 6);
-        int pr = L, pi = it; long long pm = mw;               // inclusive scans over the lanes
+        long long pm = mw;
+        for (int off = 1; off < WAVE; off <<= 1) { const long long tm = __shfl_up(pm, off); if (lane >= off) pm += tm; }
+        const bool fits = accM + pm <= capMaskWords;           // the prefix is monotone: once a problem does not fit, none behind it does
+        const int it = fits ? (L + RPB - 1) / RPB : 0;
+        int pr = L, pi = it;
         for (int off = 1; off < WAVE; off <<= 1) {
-            const int tr = __shfl_up(pr, off), ti = __shfl_up(pi, off); const long long tm = __shfl_up(pm, off);
-            if (lane >= off) { pr += tr; pi += ti; pm += tm; }
+            const int tr = __shfl_up(pr, off), ti = __shfl_up(pi, off);
+            if (lane >= off) { pr += tr; pi += ti; }
         }
-        if (b < B) { st[b].rowBase = accR + pr - L; st[b].itemBase = accI + pi - it; st[b].maskOff = accM + pm - mw; }
-        int m = L;
-        for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off));
-        mx = max(mx, m);
+        if (b < B) {
+            st[b].rowBase = accR + pr - L; st[b].itemBase = accI + pi - it; st[b].maskOff = fits ? accM + pm - mw : 0;
+            if (!fits) st[b].kind = 2;
+        }
+        int m = L, ms = (b < B && st[b].kind == 0) ? L : 0, ov = (b < B && !fits) ? 1 : 0;
+        for (int off = 32; off > 0; off >>= 1) { m = max(m, __shfl_xor(m, off)); ms = max(ms, __shfl_xor(ms, off)); ov += __shfl_xor(ov, off); }
+        mx = max(mx, m); mxs = max(mxs, ms); nover += ov;
         accR += __shfl(pr, WAVE - 1); accI += __shfl(pi, WAVE - 1); accM += __shfl(pm, WAVE - 1);
     }
-    if (lane == 0) { tot->R = accR; tot->maxL = mx; tot->nnzTotal = 0; tot->maskWords = accM; tot->items = accI; tot->sliceGroups = 0; }
+    if (lane == 0) {
+        tot->R = accR; tot->maxL = mx; tot->nnzTotal = 0; tot->maskWords = accM < capMaskWords ? accM : capMaskWords; tot->items = accI; tot->sliceGroups = 0;
+        tot->needMaskWords = accM; tot->needNnz = 0; tot->overflow = nover; tot->maxStreamL = mxs;
+    }
 }
 
 // k_items: the work-item list of the pair-test and fill kernels.
@@ -499,7 +528,7 @@ __global__ void __launch_bounds__(256) k_items(int RPB, const ProbState* __restr
 {
     const int b = blockIdx.x;
     const int L = st[b].L, ib = st[b].itemBase;
-    const int n = (L + RPB - 1) / RPB;
+    const int n = (st[b].kind == 2) ? 0 : (L + RPB - 1) / RPB;
     for (int t = threadIdx.x; t < n; t += blockDim.x) { ItemDesc d; d.b = b; d.row0 = t * RPB; items[ib + t] = d; }
 }
 
@@ -785,24 +814,28 @@ __global__ void __launch_bounds__(512) k_mirror(const ProbState* __restrict__ st
 {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int b = blockIdx.y;
+    if (st[b].kind == 2) return;
     const int L = st[b].L;
     const int W = (L + 63) >> 6;
     const int nR = ((W - 1 + nw - 1) / nw) * nw;                  // source row blocks 0..W-2, padded to whole workgroups
-    const int task = blockIdx.x * nw + w;
-    const int ct = task / max(nR, 1), R = task - ct * nR;
-    const int cb = ct * 8;
-    if (R >= W - 1 || cb >= W || cb + 7 <= R) return;             // nothing below the diagonal in this strip
+    const int nTasks = ((W + 7) / 8) * max(nR, 1);                // (column strip of 8 words) x (source row block)
     unsigned long long* mb = maskPool + st[b].maskOff;
-    const unsigned long long* src = mb + (int64_t)(R * 64 + lane) * W;         // rows R*64+lane < (W-1)*64 < L exist
-    unsigned long long x[8];
+    // the grid was sized from an ESTIMATE of the largest live set: a larger problem takes several rounds
+    for (int task = blockIdx.x * nw + w; task < nTasks; task += gridDim.x * nw) {
+        const int ct = task / max(nR, 1), R = task - ct * nR;
+        const int cb = ct * 8;
+        if (R >= W - 1 || cb >= W || cb + 7 <= R) continue;       // nothing below the diagonal in this strip
+        const unsigned long long* src = mb + (int64_t)(R * 64 + lane) * W;         // rows R*64+lane < (W-1)*64 < L exist
+        unsigned long long x[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) x[i] = (cb + i > R && cb + i < W) ? src[cb + i] : 0ull;
+        for (int i = 0; i < 8; ++i) x[i] = (cb + i > R && cb + i < W) ? src[cb + i] : 0ull;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int c = cb + i;
-        if (c > R && c < W) {                                    // wave-uniform
-            const unsigned long long y = transpose64(x[i], lane);
-            if (c * 64 + lane < L) mb[(int64_t)(c * 64 + lane) * W + R] = y;
+        for (int i = 0; i < 8; ++i) {
+            const int c = cb + i;
+            if (c > R && c < W) {                                // wave-uniform
+                const unsigned long long y = transpose64(x[i], lane);
+                if (c * 64 + lane < L) mb[(int64_t)(c * 64 + lane) * W + R] = y;
+            }
         }
     }
 }
@@ -825,6 +858,7 @@ __global__ void __launch_bounds__(1024) k_rowprefix(const ProbDesc* __restrict__
         const int W = (L + 63) >> 6;
         const int64_t lo = probs[b].liveOff, mo = st[b].maskOff;
         const int nrows = min(RPB, L - it.row0);
+        const bool wantPrefix = st[b].kind != 0;               // the stream layout takes its prefix counts in k_permute
         for (int r = w; r < nrows; r += wpb) {
             const int k = it.row0 + r;
             const unsigned long long* mrow = maskPool + mo + (int64_t)k * W;
@@ -834,7 +868,7 @@ __global__ void __launch_bounds__(1024) k_rowprefix(const ProbDesc* __restrict__
                 const bool v = wb + lane < W;
                 const uint32_t c = v ? (uint32_t)__popcll(mrow[wb + lane]) : 0u;
                 const uint32_t ex = wave_excl_scan(c, lane);
-                if (v) prow[wb + lane] = carry + ex;
+                if (v && wantPrefix) prow[wb + lane] = carry + ex;
                 carry += __shfl(ex + c, WAVE - 1);
             }
             if (lane == 0) rowCnt[lo + k] = carry;
@@ -843,15 +877,19 @@ __global__ void __launch_bounds__(1024) k_rowprefix(const ProbDesc* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_rowsort: per problem, counting sort of the live rows by candidate count (descending), then the
-// sorted SELL-64 geometry: rowPos[k] = sorted position of row k, perm[pos] = row, and per slice its
-// width (longest row) and base offset.  The order among rows of equal count is arbitrary (atomic
-// ranks) — it changes where a row is stored, never what is computed for it.
+// k_rowsort: per problem, the live rows ordered by descending candidate count (degree).
+//  kind 0 (stream layout): a STABLE, deterministic order — rank(k) = #{rows with a larger degree} + #{rows k' < k with
+//    the same degree} — because the rank becomes the association's POSITION, the numbering of the stored matrix
+//    (it fixes the order inside every row).  Counting sort; the ranks inside a group of equal degree are taken by ONE
+//    wave that walks the rows in index order.  Slice geometry follows in k_slicegeom, once k_permute knows the upper
+//    degrees.
+//  kind 1 (fallback): counting sort with atomic ranks (the order among rows of equal degree is arbitrary — it
+//    changes where a row is stored, never what is computed for it), then the sorted SELL-64 geometry:
+//    rowPos[k] = sorted position of row k, perm[pos] = row, per slice its width (longest row) and base offset.
 // ---------------------------------------------------------------------------------------------
 constexpr int SORT_KEYS = 8192;
 
-__global__ void __launch_bounds__(1024) k_rowsort(int widthPad /* 1, or 4 for the quad layout */,
-                                                  const ProbDesc* __restrict__ probs, ProbState* __restrict__ st,
+__global__ void __launch_bounds__(1024) k_rowsort(const ProbDesc* __restrict__ probs, ProbState* __restrict__ st,
                                                   const uint32_t* __restrict__ rowCnt,
                                                   uint32_t* __restrict__ rowPos, uint32_t* __restrict__ perm,
                                                   uint32_t* __restrict__ sliceWidth, uint32_t* __restrict__ sliceBase)
@@ -862,6 +900,8 @@ __global__ void __launch_bounds__(1024) k_rowsort(int widthPad /* 1, or 4 for th
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nt = blockDim.x, nw = nt >> 6;
     const int L = st[b].L;
     const int64_t lo = probs[b].liveOff;
+    if (st[b].kind == 2) return;
+    const bool stable = st[b].kind == 0;
     for (int t = tid; t < SORT_KEYS; t += nt) hist[t] = 0;
     __syncthreads();
     for (int k = tid; k < L; k += nt) atomicAdd(&hist[SORT_KEYS - 1 - min(rowCnt[lo + k], (uint32_t)(SORT_KEYS - 1))], 1u);
@@ -880,6 +920,36 @@ __global__ void __launch_bounds__(1024) k_rowsort(int widthPad /* 1, or 4 for th
         for (int t = 0; t < PER; ++t) { hist[tid * PER + t] = run; run += loc[t]; }
     }
     __syncthreads();
+    if (stable) {
+        // rank inside a group of equal degree = number of EARLIER rows of that degree.  One wave walks the rows in
+        // index order, 64 at a time: a lane's rank is the group's running counter (hist holds base + rows seen so far)
+        // plus the number of lower lanes of this chunk with the same key; the last lane of every key advances the
+        // counter.  Equal keys inside a chunk are found key by key (readfirstlane + ballot): a chunk of neighbouring
+        // rows holds few distinct degrees.
+        if (w == 0) {
+            for (int k0 = 0; k0 < L; k0 += WAVE) {
+                const int k = k0 + lane;
+                const bool v = k < L;
+                const uint32_t key = v ? SORT_KEYS - 1 - min(rowCnt[lo + k], (uint32_t)(SORT_KEYS - 1)) : 0xffffffffu;
+                unsigned long long todo = __ballot(v);
+                uint32_t pos = 0;
+                while (todo) {
+                    const int leader = __builtin_ctzll(todo);
+                    const uint32_t kk = (uint32_t)__builtin_amdgcn_readlane((int)key, leader);
+                    const unsigned long long same = __ballot(v && key == kk);
+                    if (v && key == kk) pos = hist[kk] + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane == leader) hist[kk] += (uint32_t)__popcll(same);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    todo &= ~same;
+                }
+                if (v) { rowPos[lo + k] = pos; perm[lo + pos] = (uint32_t)k; }
+            }
+        }
+        return;                                                 // slice geometry of the stream layout: k_slicegeom
+    }
     for (int k = tid; k < L; k += nt) {
         const uint32_t pos = atomicAdd(&hist[SORT_KEYS - 1 - min(rowCnt[lo + k], (uint32_t)(SORT_KEYS - 1))], 1u);
         rowPos[lo + k] = pos; perm[lo + pos] = (uint32_t)k;
@@ -894,7 +964,6 @@ __global__ void __launch_bounds__(1024) k_rowsort(int widthPad /* 1, or 4 for th
         if (s < nsl) {
             const int hi = min(L, (s << 6) + 64);
             for (int p = s << 6; p < hi; ++p) width = max(width, rowCnt[lo + perm[lo + p]]);
-            width = (width + (uint32_t)widthPad - 1u) / (uint32_t)widthPad * (uint32_t)widthPad;
             sliceWidth[lo + s] = width;
         }
         const uint32_t v = width * 64u;
@@ -913,28 +982,131 @@ __global__ void __launch_bounds__(1024) k_rowsort(int widthPad /* 1, or 4 for th
     if (tid == 0) st[b].nnzCap = carry_s;
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_permute (kind 0): the candidate bit matrix in POSITION numbering, strict upper triangle only.
+// Row p of the result is row perm[p] of the symmetric live-order matrix with its columns permuted the same way
+// and everything at or below the diagonal dropped: bit q' (q' > p) = bit perm[q'] of the source row.  One wave
+// per row: the source row (<= 48 words) sits in a wave-private LDS line, the problem's perm table in LDS; for
+// every 64-column word at or right of the diagonal each lane looks up its column's bit and the ballot is the
+// word.  The wave then has the whole row in its lanes (lane = word) and takes the per-word prefix counts (the
+// entry index of a word's first candidate in k_fill_slice) and the row's upper degree with one scan.  The
+// per-association pools are copied into position order on the way.
+// ---------------------------------------------------------------------------------------------
+struct LivePools { int32_t* lp; int32_t* li; int32_t* lj; double* ls; double* ld; double* lza; double* lzb; };
+
+__global__ void __launch_bounds__(1024) k_permute(const ProbDesc* __restrict__ probs, const ProbState* __restrict__ st,
+                                                  const BatchTotals* __restrict__ tot, const ItemDesc* __restrict__ items,
+                                                  const unsigned long long* __restrict__ maskPool,
+                                                  unsigned long long* __restrict__ umaskPool, uint32_t* __restrict__ prefPool,
+                                                  uint32_t* __restrict__ rowCnt, const uint32_t* __restrict__ perm,
+                                                  LivePools src, LivePools dst, int RPB)
+{
+    __shared__ uint16_t permS[STREAM_MAXL];
+    __shared__ unsigned long long srow[16][WAVE];
+    const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, w = tid >> 6, wpb = nt >> 6;
+    const int nItems = tot->items;
+    int staged = -1;
+    for (int t = blockIdx.x; t < nItems; t += gridDim.x) {
+        const ItemDesc it = items[t];
+        const int b = it.b;
+        if (uni_i(st[b].kind) == 0) {                       // (no `continue` around the barriers below)
+        const int L = st[b].L;
+        const int W = (L + 63) >> 6;
+        const int64_t lo = probs[b].liveOff, mo = st[b].maskOff;
+        const int nrows = min(RPB, L - it.row0);
+        if (staged != b) {                                       // consecutive items of a workgroup often share the problem
+            __syncthreads();
+            for (int q = tid; q < L; q += nt) permS[q] = (uint16_t)perm[lo + q];
+            __syncthreads();
+            staged = b;
+        }
+        for (int r = w; r < nrows; r += wpb) {
+            const int p = it.row0 + r;
+            const int k = permS[p];
+            srow[w][lane] = (lane < W) ? maskPool[mo + (int64_t)k * W + lane] : 0ull;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            uint32_t mlo = 0u, mhi = 0u;                          // lane l: word l of the permuted row
+            for (int wd = p >> 6; wd < W; ++wd) {
+                const int q = (wd << 6) + lane;
+                const int kq = permS[min(q, L - 1)];
+                const unsigned long long word = srow[w][kq >> 6];
+                const bool is = (q < L) && (q > p) && ((word >> (kq & 63)) & 1ull);
+                const unsigned long long m = __ballot(is);
+                const uint32_t ml_ = (uint32_t)m, mh_ = (uint32_t)(m >> 32), sel_ = (uint32_t)__builtin_amdgcn_readfirstlane(wd);
+                asm("s_mov_b32 m0, %3\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %4, m0"
+                    : "+v"(mlo), "+v"(mhi) : "s"(ml_), "s"(sel_), "s"(mh_) : "m0");
+            }
+            const unsigned long long mine = ((unsigned long long)mhi << 32) | mlo;
+            const uint32_t c = (uint32_t)__popcll(mine);
+            const uint32_t ex = wave_excl_scan(c, lane);
+            if (lane < W) { umaskPool[mo + (int64_t)p * W + lane] = mine; prefPool[mo + (int64_t)p * W + lane] = ex; }
+            if (lane == WAVE - 1) rowCnt[lo + p] = ex + c;       // upper degree of position p (the live-order degrees are spent)
+            if (lane == 0) { dst.lp[lo + p] = src.lp[lo + k]; dst.li[lo + p] = src.li[lo + k]; dst.lj[lo + p] = src.lj[lo + k]; }
+            if (lane == 1) { dst.ls[lo + p] = src.ls[lo + k]; dst.ld[lo + p] = src.ld[lo + k]; }
+            if (lane == 2) { dst.lza[lo + p] = src.lza[lo + k]; dst.lzb[lo + p] = src.lzb[lo + k]; }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();                      // srow[w] is rewritten by the next row
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        }
+    }
+}
+
+// k_slicegeom (kind 0): slice widths (longest upper row of the slice, rounded up to whole quads), slice bases and the
+// problem's slot total.  One wave per problem, lane = slice.
+__global__ void __launch_bounds__(64) k_slicegeom(const ProbDesc* __restrict__ probs, ProbState* __restrict__ st,
+                                                  const uint32_t* __restrict__ rowCnt,
+                                                  uint32_t* __restrict__ sliceWidth, uint32_t* __restrict__ sliceBase)
+{
+    const int b = blockIdx.x, lane = threadIdx.x;
+    if (st[b].kind != 0) return;
+    const int L = st[b].L;
+    const int64_t lo = probs[b].liveOff;
+    const int nsl = (L + 63) >> 6;                                // <= STREAM_MAXL / 64 <= 64
+    uint32_t width = 0;
+    if (lane < nsl) {
+        const int hi = min(L, (lane << 6) + 64);
+        for (int p = lane << 6; p < hi; ++p) width = max(width, rowCnt[lo + p]);
+        width = (width + 3u) & ~3u;
+        sliceWidth[lo + lane] = width;
+    }
+    const uint32_t v = width * 64u;
+    const uint32_t ex = wave_excl_scan(v, lane);
+    if (lane < nsl) sliceBase[lo + lane] = ex;
+    if (lane == WAVE - 1) st[b].nnzCap = ex + v;
+}
+
 // k_probscan: serial prefix of the per-problem slot totals and of the slice-group counts (k_fill_slice work items:
-// groups of SPI consecutive slices of one problem).
-__global__ void __launch_bounds__(64) k_probscan(int B, int SPI, ProbState* __restrict__ st, BatchTotals* __restrict__ tot)
+// groups of SPI consecutive slices of one stream-layout problem).  A problem whose matrix segment would end beyond
+// `capNnz` slots becomes kind 2 (skipped; nothing has been written for it yet).
+__global__ void __launch_bounds__(64) k_probscan(int B, int SPI, long long capNnz, ProbState* __restrict__ st, BatchTotals* __restrict__ tot)
 {
     const int lane = threadIdx.x;
     long long acc = 0;
-    int gacc = 0;
+    int gacc = 0, nover = 0;
     for (int b0 = 0; b0 < B; b0 += WAVE) {
         const int b = b0 + lane;
-        const long long cap = b < B ? (long long)st[b].nnzCap : 0;
-        const int ng = b < B ? (((st[b].L + 63) >> 6) + SPI - 1) / SPI : 0;
+        const int kind = b < B ? st[b].kind : 2;
+        const long long cap = (b < B && kind != 2) ? (long long)st[b].nnzCap : 0;
         long long pc = cap;
+        for (int off = 1; off < WAVE; off <<= 1) { const long long t = __shfl_up(pc, off); if (lane >= off) pc += t; }
+        const bool fits = acc + pc <= capNnz;
+        const int ng = (b < B && kind == 0 && fits) ? (((st[b].L + 63) >> 6) + SPI - 1) / SPI : 0;
         int pg = ng;
-        for (int off = 1; off < WAVE; off <<= 1) {
-            const long long t = __shfl_up(pc, off); const int tg = __shfl_up(pg, off);
-            if (lane >= off) { pc += t; pg += tg; }
+        for (int off = 1; off < WAVE; off <<= 1) { const int tg = __shfl_up(pg, off); if (lane >= off) pg += tg; }
+        if (b < B) {
+            st[b].nnzOff = fits ? acc + pc - cap : 0; st[b].sgBase = gacc + pg - ng;
+            if (!fits && kind != 2) st[b].kind = 2;
         }
-        if (b < B) { st[b].nnzOff = acc + pc - cap; st[b].sgBase = gacc + pg - ng; }
+        int ov = (b < B && kind != 2 && !fits) ? 1 : 0;
+        for (int off = 32; off > 0; off >>= 1) ov += __shfl_xor(ov, off);
+        nover += ov;
         acc += __shfl(pc, WAVE - 1);
         gacc += __shfl(pg, WAVE - 1);
     }
-    if (lane == 0) { tot->nnzTotal = acc; tot->sliceGroups = gacc; }
+    if (lane == 0) { tot->nnzTotal = acc < capNnz ? acc : capNnz; tot->sliceGroups = gacc; tot->needNnz = acc; tot->overflow += nover; }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1073,6 +1245,7 @@ __global__ void __launch_bounds__(1024) k_fill(DevParams D, const ProbDesc* __re
     for (int t = blockIdx.x; t < nItems; t += gridDim.x) {
         const ItemDesc it = items[t];
         const int b = it.b;
+        if (uni_i(st[b].kind) == 1) {           // stream-layout problems are filled by k_fill_slice, skipped ones not at all
         const ProbDesc pd = probs[b];
         const int L = st[b].L;
         const int64_t lo = pd.liveOff, mo = st[b].maskOff, no = st[b].nnzOff;
@@ -1122,6 +1295,7 @@ __global__ void __launch_bounds__(1024) k_fill(DevParams D, const ProbDesc* __re
         }
         for (int off = 32; off > 0; off >>= 1) upper += __shfl_xor(upper, off);
         if (lane == 0 && upper) atomicAdd(&st[b].nnzUpper, (unsigned long long)upper);
+        }
     }
 }
 
@@ -1171,7 +1345,6 @@ __global__ void __launch_bounds__(1024) k_fill_slice(DevParams D, int B, const P
                                                      const double* __restrict__ lza, const double* __restrict__ lzb,
                                                      const unsigned long long* __restrict__ maskPool,
                                                      const uint32_t* __restrict__ prefPool,
-                                                     const uint32_t* __restrict__ perm,
                                                      const uint32_t* __restrict__ sliceWidth,
                                                      const uint32_t* __restrict__ sliceBase,
                                                      uint16_t* __restrict__ cols, double* __restrict__ vals,
@@ -1181,7 +1354,8 @@ __global__ void __launch_bounds__(1024) k_fill_slice(DevParams D, int B, const P
     unsigned long long facc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long flast = __builtin_readcyclecounter();
 #endif
-    // LDS: cS[TC] [GRAV: cZa[TC] cZb[TC]] cI[TC] cJ[TC] | image values [EC*64] | image columns [EC*64] | owner lines | rows
+    // LDS: cS[TC] [GRAV: cZa[TC] cZb[TC]] cI[TC] cJ[TC] | image values [EC*64] | image columns [EC*64] | owner lines
+    // (li, lj, ls, lza, lzb, maskPool, prefPool: the POSITION-ordered pools and upper-triangle masks k_permute wrote)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* cS = reinterpret_cast<double*>(smem);
     double* cZa = cS + TC;
@@ -1194,7 +1368,6 @@ __global__ void __launch_bounds__(1024) k_fill_slice(DevParams D, int B, const P
     const int tid = threadIdx.x, nt = blockDim.x;
     const int lane = tid & 63, w = tid >> 6, nw = nt >> 6;
     uint32_t* ownL = rings + (size_t)w * WAVE;                  // this wave's owner line (64 entries)
-    uint32_t* sKall = rings + (size_t)nw * WAVE;                // rows of the group's slices: FILLS_MAXSPI * 64 entries
     const int SPW = 64 / nw;                                    // lane slots per wave
     const int nGroups = tot->sliceGroups;
     // XCD-aware order: workgroups are dealt to the 8 XCDs round-robin by id, so XCD x takes the CONTIGUOUS range
@@ -1221,23 +1394,24 @@ __global__ void __launch_bounds__(1024) k_fill_slice(DevParams D, int B, const P
             cI[q] = li[lo + q]; cJ[q] = lj[lo + q]; cS[q] = ls[lo + q];
             if (GRAV) { cZa[q] = lza[lo + q]; cZb[q] = lzb[lo + q]; }
         }
-        for (int x = tid; x < (s_end - s_begin) * 64; x += nt)
-            sKall[x] = (s_begin * 64 + x < L) ? perm[lo + s_begin * 64 + x] : 0xffffffffu;
         uint32_t upper = 0;
         FMARK(0);
         for (int sl = s_begin; sl < s_end; ++sl) {
             const uint32_t width = sliceWidth[lo + sl];
             const int64_t sb = no + sliceBase[lo + sl];         // first element of the slice (multiple of 256)
-            const uint32_t* sK = sKall + (sl - s_begin) * 64;
             for (uint32_t e0 = 0; e0 < width; e0 += (uint32_t)EC) {
                 const uint32_t ew = min((uint32_t)EC, width - e0);
                 __syncthreads();                                // previous image written out (first pass: tile and rows staged)
-                {   // inert image: value 0, column = dummy vector element L with the C-flag
+                {   // inert image: value 0, column = the lane slot's own dummy vector element L + slot, with the C-flag
+                    // (one dummy per slot: the solver pushes into the column's accumulator, and 64 lanes hitting
+                    // ONE dummy address would serialise in the LDS)
                     double2* v2 = reinterpret_cast<double2*>(imgV);
                     for (uint32_t x = tid; x < ew * 32u; x += nt) v2[x] = make_double2(0.0, 0.0);
-                    const uint32_t inert = ((uint32_t)L | 0x8000u) * 0x10001u;
                     uint2* c2 = reinterpret_cast<uint2*>(imgC);
-                    for (uint32_t x = tid; x < ew * 16u; x += nt) c2[x] = make_uint2(inert, inert);
+                    for (uint32_t x = tid; x < ew * 16u; x += nt) {
+                        const uint32_t inert = (((uint32_t)L + (x & 63u)) | 0x8000u) * 0x10001u;
+                        c2[x] = make_uint2(inert, inert);
+                    }
                 }
                 __syncthreads();
                 FMARK(1);
@@ -1249,7 +1423,10 @@ __global__ void __launch_bounds__(1024) k_fill_slice(DevParams D, int B, const P
                 // candidates at once: the owner words are scattered into a 64-entry LDS line at their first
                 // candidate's position and spread by a max-scan, the word is fetched with ds_bpermute and the bit
                 // found by a 6-step rank select.  (One bit per lane and step through a ring took 3x the cycles.)
-                const int nwords = SPW * W;
+                // (rows of slice sl are the positions 64 sl .. 64 sl + 63; a row's candidates lie in the words at or right
+                // of the diagonal: words sl .. W-1)
+                const int Wr = W - sl;
+                const int nwords = SPW * Wr;
                 unsigned long long mB[FILLS_NBLK]; uint32_t iA[FILLS_NBLK], iB[FILLS_NBLK];
                 uint32_t Ttot = 0;
 #pragma unroll
@@ -1257,10 +1434,10 @@ __global__ void __launch_bounds__(1024) k_fill_slice(DevParams D, int B, const P
                     const int x = jb * WAVE + lane;
                     unsigned long long m = 0ull; uint32_t ef = 0u, ka = 0u;
                     if (x < nwords) {
-                        const int r = x / W, word = x - r * W;
+                        const int r = x / Wr, word = sl + (x - r * Wr);
                         const uint32_t slot = (uint32_t)(r * nw + w);
-                        const uint32_t k = sK[slot];
-                        if (k != 0xffffffffu) {
+                        const uint32_t k = (uint32_t)(sl * 64) + slot;
+                        if (k < (uint32_t)L) {
                             m = maskPool[mo + (int64_t)k * W + word];
                             ef = prefPool[mo + (int64_t)k * W + word];
                             ka = k | (slot << 16) | ((uint32_t)word << 22);
@@ -1342,7 +1519,7 @@ __global__ void __launch_bounds__(1024) k_fill_slice(DevParams D, int B, const P
                         if (v > D.p.affinityeps) {              // otherwise the slot stays inert: neither in M nor in C
                             imgC[(er >> 2) * 256u + slot * 4u + (er & 3u)] = (uint16_t)q;
                             imgV[(er >> 1) * 128u + slot * 2u + (er & 1u)] = v;
-                            upper += (q > k) ? 1u : 0u;
+                            upper += 1u;                        // every stored entry is a strict-upper one
                         }
                     }
                     FMARK(4);
@@ -1522,13 +1699,15 @@ __device__ __noinline__ void write_pose(double* T, int d, const double* H, const
 // over the FULL association index space (dead associations have u == 0).  Single thread; only
 // runs when the k-th largest value is tied or fewer than omega entries are positive.
 __device__ inline bool hp_less(double va, int ia, double vb, int ib) { return va < vb || (va == vb && ia < ib); }
-__device__ __noinline__ void heap_select_serial(const double* u, const int32_t* lp, int L, int nA, int k,
+__device__ __noinline__ void heap_select_serial(const double* u, const int32_t* lp /* ascending: live order */,
+                                   const uint32_t* vecOfLive /* live index -> index into u, or nullptr = identity */,
+                                   int L, int nA, int k,
                                    double* hv, int32_t* hi /* capacity k */, int32_t* outNodesOrig)
 {
     int sz = 0, nl = 0;
     for (int p = 0; p < nA; ++p) {
         double x = 0.0;
-        if (nl < L && lp[nl] == p) { x = u[nl]; ++nl; }
+        if (nl < L && lp[nl] == p) { x = u[vecOfLive ? (int)vecOfLive[nl] : nl]; ++nl; }
         if (sz < k) {
             int c = sz++; hv[c] = x; hi[c] = p;
             while (c > 0) { const int par = (c - 1) >> 1; if (!hp_less(hv[c], hi[c], hv[par], hi[par])) break;
@@ -1557,10 +1736,14 @@ __device__ __noinline__ void heap_select_serial(const double* u, const int32_t* 
 }
 
 // Tail shared by every solver variant: final u to the row pool, top-omega rounding (with the exact
-// heap emulation on ties), selected associations, Umeyama pose, statistics.  `u` is indexed by live
-// association (LDS or global); pv / pidx / nodesLive are scratch arrays of capacity L.
+// heap emulation on ties), selected associations, Umeyama pose, statistics.  `u` is indexed by "vector index":
+// the live index (fallback solver) or the position (stream solver); lp[lo + v] is the association index of
+// vector index v.  lpAsc is the ascending association list in live order and vecOfLive the live -> vector index
+// map (nullptr: identity) — only the sequential heap emulation needs them.  pv / pidx / nodesLive are scratch
+// arrays of capacity L.
 __device__ __noinline__ void finish_one(const DevParams& D, int b, const ProbDesc& pd, const double* __restrict__ feats,
-                                        const int32_t* __restrict__ assoc, const int32_t* __restrict__ lp, const SolveOut& O,
+                                        const int32_t* __restrict__ assoc, const int32_t* __restrict__ lp,
+                                        const int32_t* __restrict__ lpAsc, const uint32_t* __restrict__ vecOfLive, const SolveOut& O,
                                         const double* u, double* pv, int32_t* pidx, int32_t* nodesLive,
                                         int L, int rb, int64_t lo, double F, int status, roman_stats_t S,
                                         double* red, int* sint)
@@ -1592,11 +1775,11 @@ __device__ __noinline__ void finish_one(const DevParams& D, int b, const ProbDes
             const int Pn = sint[0];
             bool fallback = (Pn < omega) || (omega > L);
             if (!fallback) {
-                // rank of e = number of entries greater in (value, index) order
+                // rank of e = number of entries greater in (value, association index) order
                 for (int e = tid; e < Pn; e += nt) {
-                    const double ve = pv[e]; const int ie = pidx[e];
+                    const double ve = pv[e]; const int ie = pidx[e]; const int ae = lp[lo + ie];
                     int rank = 0;
-                    for (int f2 = 0; f2 < Pn; ++f2) { const double vf = pv[f2]; rank += (vf > ve) || (vf == ve && pidx[f2] > ie); }
+                    for (int f2 = 0; f2 < Pn; ++f2) { const double vf = pv[f2]; rank += (vf > ve) || (vf == ve && lp[lo + pidx[f2]] > ae); }
                     if (rank < omega) nodesLive[rank] = ie;
                     if (rank == omega - 1) { red[64] = ve; }
                 }
@@ -1605,9 +1788,9 @@ __device__ __noinline__ void finish_one(const DevParams& D, int b, const ProbDes
                 int tie = 0;
                 for (int e = tid; e < Pn; e += nt) {
                     if (pv[e] == vstar) {
-                        const double ve = pv[e]; const int ie = pidx[e];
+                        const double ve = pv[e]; const int ae = lp[lo + pidx[e]];
                         int rank = 0;
-                        for (int f2 = 0; f2 < Pn; ++f2) { const double vf = pv[f2]; rank += (vf > ve) || (vf == ve && pidx[f2] > ie); }
+                        for (int f2 = 0; f2 < Pn; ++f2) { const double vf = pv[f2]; rank += (vf > ve) || (vf == ve && lp[lo + pidx[f2]] > ae); }
                         if (rank >= omega) tie = 1;
                     }
                 }
@@ -1620,7 +1803,7 @@ __device__ __noinline__ void finish_one(const DevParams& D, int b, const ProbDes
                 __syncthreads();
                 if (tid == 0) {
                     const int kk = min(omega, L);      // heap capacity bounded by the scratch size
-                    heap_select_serial(u, lp + lo, L, pd.nA, kk, pv, pidx, nodesOrig);
+                    heap_select_serial(u, lpAsc + lo, vecOfLive ? vecOfLive + lo : nullptr, L, pd.nA, kk, pv, pidx, nodesOrig);
                     sint[0] = kk;
                 }
                 __syncthreads();
@@ -1832,10 +2015,10 @@ __device__ void solve_one(const DevParams& D, int b, const ProbDesc& pd, ProbSta
         if (i >= P.maxoliters) status |= ROMAN_ST_MAXITER;
         S.outer_iters = i; S.score = F; S.d_final = d;
 
-        finish_one(D, b, pd, feats, assoc, lp, O, u, Mun, (int32_t*)un, (int32_t*)Cun, L, rb, lo, F, status, S, red, sint);
+        finish_one(D, b, pd, feats, assoc, lp, lp, nullptr, O, u, Mun, (int32_t*)un, (int32_t*)Cun, L, rb, lo, F, status, S, red, sint);
         return;
     }
-    finish_one(D, b, pd, feats, assoc, lp, O, nullptr, nullptr, nullptr, nullptr, L, rb, lo, F, status, S, red, sint);
+    finish_one(D, b, pd, feats, assoc, lp, lp, nullptr, O, nullptr, nullptr, nullptr, nullptr, L, rb, lo, F, status, S, red, sint);
 }
 
 template <typename IdxT, int MODE>
@@ -1862,16 +2045,18 @@ __global__ void __launch_bounds__(1024) k_solve(DevParams D, int B, const ProbDe
     for (;;) {
         if (threadIdx.x == 0) sint[2] = atomicAdd(queue, 1);
         __syncthreads();
-        const int b = sint[2];
+        const int b = __builtin_amdgcn_readfirstlane(sint[2]);
         __syncthreads();
         if (b >= B) break;
-        const ProbDesc pd = probs[b];
-        if (MODE > 0 && st[b].L <= Lcap)
-            solve_one<IdxT, MODE>(D, b, pd, st, feats, assoc, lp, ls, perm, sliceWidth, sliceBase, cols, vals,
-                                  vMu, vCu, vMun, vCun, gU, gUn, u0, O, sv, Lcap, red, sint);
-        else
-            solve_one<IdxT, 0>(D, b, pd, st, feats, assoc, lp, ls, perm, sliceWidth, sliceBase, cols, vals,
-                               vMu, vCu, vMun, vCun, gU, gUn, u0, O, sv, Lcap, red, sint);
+        if (__builtin_amdgcn_readfirstlane(st[b].kind) == 1) {   // (else: the stream solver's problem, or a skipped one)
+            const ProbDesc pd = probs[b];
+            if (MODE > 0 && st[b].L <= Lcap)
+                solve_one<IdxT, MODE>(D, b, pd, st, feats, assoc, lp, ls, perm, sliceWidth, sliceBase, cols, vals,
+                                      vMu, vCu, vMun, vCun, gU, gUn, u0, O, sv, Lcap, red, sint);
+            else
+                solve_one<IdxT, 0>(D, b, pd, st, feats, assoc, lp, ls, perm, sliceWidth, sliceBase, cols, vals,
+                                   vMu, vCu, vMun, vCun, gU, gUn, u0, O, sv, Lcap, red, sint);
+        }
     }
 }
 
@@ -1882,50 +2067,51 @@ __global__ void __launch_bounds__(1024) k_solve(DevParams D, int B, const ProbDe
 #endif
 
 // ---------------------------------------------------------------------------------------------
-// Streaming solver (L <= ST_NW*ST_NS*64 = 3072, 16-bit indices, quad layout): the fast path.
+// Stream solver (kind 0: L <= STREAM_MAXL, 16-bit position indices, upper-triangle quad layout).
 //
-// One 512-thread workgroup per problem.  Thread (wave w, lane l) OWNS the rows in lane-slot l of the
-// slices s = k*ST_NW + w: everything per-row (u, M u, C u, the diagonal, the trial products) lives in
-// that thread's registers; only the two vectors the SpMV GATHERS (u and the trial u') are in LDS,
-// indexed by live association, with a dummy element [L] == 0 that inert padding entries point to.
+// One workgroup of NW waves per problem.  Thread t OWNS the vector elements p = t, t + NT, t + 2 NT (positions):
+// u, M u, C u, the diagonal and the trial vector with its products live in that thread's registers.  LDS holds
+// only what the SpMV touches by index: the vector being multiplied (xg) and two accumulator arrays.
 //
-// SpMV as ONE balanced stream.  In the quad layout the slices of a level are contiguous in memory, so
-// the whole matrix is a sequence of T "quads" (4 entries x 64 lanes, 3 wide loads).  Wave w streams the
-// contiguous range [w*T/8, (w+1)*T/8) with ST_D quads in flight per lane, whatever slices it covers
-// (lane = row slot of the current slice); when the range crosses a slice boundary the running sums are
-// flushed to an LDS partial slot.  After a barrier the row owners add the partials of their slice in
-// stream order (fixed tree: deterministic).  Perfect balance although a few slices (the rows of the
-// consensus set have ~4x the average degree) hold a large share of the entries.
+// SpMV on the upper triangle, pull + push.  A stored entry (p, q, v), p < q, serves both triangles:
+//      (M x)_p += v x_q      pulled: the row's lane gathers x_q from LDS and accumulates in registers,
+//      (M x)_q += v x_p      pushed: an LDS atomic add into the accumulator of q,
+// and likewise (C x) with v replaced by 1.  Every pass therefore moves 10 bytes per non-zero of the UPPER
+// triangle, and — positions being ranks by degree — a vector whose support lies in the first S slices needs only
+// those S slices: rows beyond have x_p = 0 (nothing to push) and only columns q > p beyond the support (nothing
+// to pull).  The solver's long tail runs on the clique found so far, i.e. on the first one or two slices; no
+// column-compacted copies of the matrix are needed.
 //
-// Column-compacted copies of the matrix ("levels").  The support of u collapses quickly (typically
-// L -> ~L/3 after two steps, -> the clique after the first homotopy update) and a column q with
-// u_q == 0 contributes exactly nothing to M u and C u.  A level holds the rows of the full matrix
-// (level 0) restricted to a column set K (a bitmap in LDS), re-packed contiguously.  A pass over vector
-// x may use a level iff supp(x) is a subset of its K — tested for every trial vector while it is
-// formed — and then yields the same sums over the same non-zero terms in the same order; otherwise the
-// pass falls back to the next larger level.  Levels are (re)built from the accepted u when the support
-// has at least halved and no association re-entered in the last step (twice in a row before the
-// expensive build from the full matrix).
+// Exact accumulation.  Atomic floating-point adds would make the sums depend on the order in which waves reach
+// the LDS.  Every term is instead rounded ONCE to a fixed-point integer, rint(v x 2^s) (s chosen per pass from
+// max x so that a term is below 2^49 and any sum below 2^62), and integers are added — in registers for the
+// pulled part, with ds_add_u64 for the pushed part and for the flush of a row's pulled sum.  Integer addition is
+// associative: the result does not depend on the order, on the number of waves, or on how the stream is split.
+// The rounding unit 2^-s is 2^-48 relative to the largest element of x, the same order as the rounding of an f64
+// summation.  The conversion is one fma against 2^52 + 2^51 (the integer appears in the low mantissa bits).
+//
+// One balanced stream: the S slices of a pass are contiguous in memory (quads); wave w streams the quads
+// [w T / NW, (w+1) T / NW) with ST_D quads (9 wide loads) in flight per lane, whatever slices the range covers
+// (lane = row slot of the current slice) and flushes its pulled sums when it leaves a slice or its range.
 // ---------------------------------------------------------------------------------------------
-constexpr int ST_NW = 8;                 // waves per problem
-constexpr int ST_NS = 6;                 // max row slots (slices) per wave; the kernel is instantiated for 4, 5 and 6
-constexpr int ST_D = 3;                  // quads in flight per lane (measured: 2-4 beat 6-8, for a lone problem as well as for 256)
-constexpr int ST_MAXSL = ST_NW * ST_NS;  // 48 slices -> L <= 3072
-constexpr int ST_PB = ST_MAXSL + ST_NW;  // LDS partial slots
-constexpr int ST_CQ = ST_MAXSL + 1;      // entries of a quad-prefix row
-constexpr int ST_KMAX = 5;               // per-element loops cover ST_KMAX * 512 = 2560 associations
+#ifndef ROMAN_SOLVE_WAVES
+#define ROMAN_SOLVE_WAVES 16             // waves of the stream solver's workgroup (one problem per workgroup)
+#endif
+constexpr int ST_D = 3;                  // quads in flight per lane
+constexpr int ST_MAXSL = STREAM_MAXL / 64;
 constexpr uint32_t ST_CZ = 0x8000u, ST_MASK = 0x7fffu;
+constexpr unsigned long long FX_MAGIC_BITS = 0x4338000000000000ull;     // 2^52 + 2^51
+#define FX_MAGIC 6755399441055744.0
 
-// Explicit address spaces for the hot pointers of the streaming solver: pointers that reach the loops
-// through run-time selected level tables would otherwise be compiled to FLAT accesses, whose results
-// count against lgkmcnt as well — every wait for an LDS gather would then drain the prefetched matrix
-// loads and serialise the stream.
+// Explicit address spaces for the hot pointers of the stream: FLAT accesses would count against lgkmcnt as well and
+// every wait for an LDS gather would drain the prefetched matrix loads.
 #define ROMAN_GLOBAL __attribute__((address_space(1)))
 #define ROMAN_LDS __attribute__((address_space(3)))
 typedef double dbl2_t __attribute__((ext_vector_type(2)));
 typedef const ROMAN_GLOBAL unsigned long long* g_quad_cp;    // 4 x u16 column indices of one lane
 typedef const ROMAN_GLOBAL dbl2_t* g_pair_cp;                // 2 x f64 values of one lane
 typedef const ROMAN_LDS double* l_vec_cp;                    // gathered vector in LDS
+typedef ROMAN_LDS unsigned long long* l_acc_p;               // fixed-point accumulators in LDS
 
 // wave-uniform values that the compiler cannot prove uniform (read from LDS, derived from threadIdx):
 // force them into SGPRs so that loop control and matrix addressing run on the scalar unit
@@ -1946,7 +2132,8 @@ __device__ __forceinline__ double dpp_mov(double v)
     const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROWMASK, 0xf, false);
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
-// sum over the 64 lanes, valid in lane 63 (fixed tree: pairs, quads, rows of 16, then across rows)
+// sum / maximum (of non-negative values) over the 64 lanes, valid in lane 63 (fixed tree: pairs, quads, rows of 16,
+// then across rows; rows a row_bcast does not reach receive 0, the neutral element of both)
 __device__ __forceinline__ double wave_sum63(double v)
 {
     v += dpp_mov<0xB1, 0xf>(v);          // quad_perm [1,0,3,2]
@@ -1957,6 +2144,16 @@ __device__ __forceinline__ double wave_sum63(double v)
     v += dpp_mov<0x143, 0xc>(v);         // row_bcast:31 -> rows 2,3
     return v;
 }
+__device__ __forceinline__ double wave_max63(double v)
+{
+    v = fmax(v, dpp_mov<0xB1, 0xf>(v));
+    v = fmax(v, dpp_mov<0x4E, 0xf>(v));
+    v = fmax(v, dpp_mov<0x124, 0xf>(v));
+    v = fmax(v, dpp_mov<0x128, 0xf>(v));
+    v = fmax(v, dpp_mov<0x142, 0xa>(v));
+    v = fmax(v, dpp_mov<0x143, 0xc>(v));
+    return v;
+}
 __device__ __forceinline__ double readlane63(double v)
 {
     const long long b = __double_as_longlong(v);
@@ -1964,134 +2161,74 @@ __device__ __forceinline__ double readlane63(double v)
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
-// Sum of N values over the 8 waves of the block, identical in every thread; fixed reduction tree.
-// `red`: two ping-pong areas of 64 doubles (a buffer is rewritten only after the barrier of the next call).
-template <int N>
-__device__ __forceinline__ void block_sumN(double (&v)[N], double* red, int& par, int tid)
+// NS sums and NM maxima (of non-negative values) over the NW waves of the block, identical in every thread; fixed
+// reduction tree.  `red`: two ping-pong areas of NW*8 doubles (a buffer is rewritten only after the barrier of the
+// next call).  The barrier inside also publishes whatever the caller wrote to LDS before the call.
+constexpr int RED_STRIDE = 8;
+template <int NW, int NS, int NM>
+__device__ __forceinline__ void block_red(double (&sv)[NS > 0 ? NS : 1], double (&mv)[NM > 0 ? NM : 1], double* red, int& par, int tid)
 {
-    double* rr = red + 64 * par;
+    static_assert(NS + NM <= RED_STRIDE, "reduction scratch");
+    static_assert(NW == 8 || NW == 16, "cross-wave butterfly");
+    double* rr = red + NW * RED_STRIDE * par;
     par ^= 1;
+    const int w = uni(tid >> 6);
 #pragma unroll
-    for (int i = 0; i < N; ++i) {
-        const double s = readlane63(wave_sum63(v[i]));
-        if ((tid & 63) == 0) rr[N * uni(tid >> 6) + i] = s;
+    for (int i = 0; i < NS; ++i) {
+        const double s = readlane63(wave_sum63(sv[i]));
+        if ((tid & 63) == 0) rr[RED_STRIDE * w + i] = s;
+    }
+#pragma unroll
+    for (int i = 0; i < NM; ++i) {
+        const double m = readlane63(wave_max63(mv[i]));
+        if ((tid & 63) == 0) rr[RED_STRIDE * w + NS + i] = m;
     }
     __syncthreads();
+    // cross-wave step: lane l takes the partial of wave l % NW; the NW lanes of a DPP row are combined with a fixed
+    // butterfly (every lane ends with the total), the result moves to an SGPR
+    const int src = (tid & 63) & (NW - 1);
 #pragma unroll
-    for (int i = 0; i < N; ++i) v[i] = 0.0;
+    for (int i = 0; i < NS; ++i) {
+        double v = rr[RED_STRIDE * src + i];
+        v += dpp_mov<0xB1, 0xf>(v);          // quad_perm [1,0,3,2]
+        v += dpp_mov<0x4E, 0xf>(v);          // quad_perm [2,3,0,1]
+        v += dpp_mov<0x124, 0xf>(v);         // row_ror:4
+        if (NW > 8) v += dpp_mov<0x128, 0xf>(v);     // row_ror:8
+        sv[i] = uni(v);
+    }
 #pragma unroll
-    for (int w = 0; w < ST_NW; ++w)
-#pragma unroll
-        for (int i = 0; i < N; ++i) v[i] += rr[N * w + i];
-#pragma unroll
-    for (int i = 0; i < N; ++i) v[i] = uni(v[i]);                // every lane holds the same value: keep it in SGPRs
+    for (int i = 0; i < NM; ++i) {
+        double v = rr[RED_STRIDE * src + NS + i];
+        v = fmax(v, dpp_mov<0xB1, 0xf>(v));
+        v = fmax(v, dpp_mov<0x4E, 0xf>(v));
+        v = fmax(v, dpp_mov<0x124, 0xf>(v));
+        if (NW > 8) v = fmax(v, dpp_mov<0x128, 0xf>(v));
+        mv[i] = uni(v);
+    }
 }
 
-struct StreamLevels { uint16_t* cols[4]; double* vals[4]; };   // level 0 (full) + three compact buffers
-
-// Compaction, phase 1: number of entries of this lane's row (quads [qa,qb) of a slice) whose column is in
-// the support of x.  Inert padding points at the dummy element x[L] == 0 and is never kept.
-__device__ __noinline__ uint32_t level_count_slot(const double* x, const uint16_t* cols, uint32_t qa, uint32_t qb, int lane)
+// fixed-point accumulator -> double (the accumulated integer is below 2^62)
+__device__ __forceinline__ double fx_decode(unsigned long long a, double inv)
 {
-    g_quad_cp cp = (g_quad_cp)cols + lane;
-    l_vec_cp xl = (l_vec_cp)x;
-    uint32_t cnt = 0;
-    constexpr int DC = 8;
-    unsigned long long c[DC];
-#pragma unroll
-    for (int t = 0; t < DC; ++t) c[t] = (qa + t < qb) ? cp[(size_t)(qa + t) * 64] : 0ull;
-    for (uint32_t q0 = qa; q0 < qb; q0 += DC) {
-#pragma unroll
-        for (int t = 0; t < DC; ++t) {
-            const uint32_t q = q0 + t;
-            if (q < qb) {
-                const unsigned long long cc = c[t];
-                if (q + DC < qb) c[t] = cp[(size_t)(q + DC) * 64];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const uint32_t cw = (uint32_t)(cc >> (16 * j)) & 0xffffu;
-                    cnt += (xl[cw & ST_MASK] > 0.0) ? 1u : 0u;
-                }
-            }
-        }
-    }
-    return cnt;
-}
-// Compaction, phase 2: copy the kept entries of this lane's row to the quads starting at `qd` of the
-// destination level and pad up to `newWq` quads with inert entries.  Kept entries are assembled into whole
-// quads (column indices in a 64-bit shift register, values in a per-wave LDS stage of 4 x 64 doubles) and
-// stored with the same three wide stores the stream loads them with.
-__device__ __noinline__ void level_copy_slot(const double* x, const uint16_t* cols, const double* vals, uint32_t qa, uint32_t qb,
-                                             uint16_t* dcols, double* dvals, uint32_t qd, uint32_t newWq, uint32_t inert,
-                                             double* stage, int lane)
-{
-    g_quad_cp cp = (g_quad_cp)cols + lane;
-    g_pair_cp vp = (g_pair_cp)vals + lane;
-    l_vec_cp xl = (l_vec_cp)x;
-    ROMAN_LDS double* sg = (ROMAN_LDS double*)stage + lane;                                                    // value j of the open quad: sg[j*64]
-    ROMAN_GLOBAL unsigned long long* dc = (ROMAN_GLOBAL unsigned long long*)dcols + (size_t)qd * 64 + lane;     // quad g: dc[g*64]
-    ROMAN_GLOBAL dbl2_t* dv = (ROMAN_GLOBAL dbl2_t*)dvals + (size_t)qd * 128 + lane;                           // pairs 2g, 2g+1: dv[2g*64], dv[(2g+1)*64]
-    uint32_t gq = 0, nb = 0;                                    // quads written, entries in the open quad
-    unsigned long long cacc = 0ull;                             // the open quad's indices, newest in the top 16 bits
-    constexpr int DC = 6;
-    unsigned long long c[DC]; dbl2_t v0[DC], v1[DC];
-#pragma unroll
-    for (int t = 0; t < DC; ++t) {
-        const uint32_t qq = min(qa + (uint32_t)t, qb > qa ? qb - 1u : qa);
-        c[t] = cp[(size_t)qq * 64]; v0[t] = vp[(size_t)(2 * qq) * 64]; v1[t] = vp[(size_t)(2 * qq + 1) * 64];
-    }
-    for (uint32_t q0 = qa; q0 < qb; q0 += DC) {
-#pragma unroll
-        for (int t = 0; t < DC; ++t) {
-            const uint32_t q = q0 + t;
-            if (q < qb) {
-                const unsigned long long cc = c[t];
-                const dbl2_t b0 = v0[t], b1 = v1[t];
-                const uint32_t qn = min(q + (uint32_t)DC, qb - 1u);
-                c[t] = cp[(size_t)qn * 64]; v0[t] = vp[(size_t)(2 * qn) * 64]; v1[t] = vp[(size_t)(2 * qn + 1) * 64];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const uint32_t cw = (uint32_t)(cc >> (16 * j)) & 0xffffu;
-                    const double vv = (j == 0) ? b0.x : (j == 1) ? b0.y : (j == 2) ? b1.x : b1.y;
-                    if (xl[cw & ST_MASK] > 0.0) {
-                        sg[nb * 64] = vv;
-                        cacc = (cacc >> 16) | ((unsigned long long)cw << 48);
-                        if (++nb == 4) {
-                            dc[(size_t)gq * 64] = cacc;
-                            dv[(size_t)(2 * gq) * 64] = dbl2_t{sg[0], sg[64]}; dv[(size_t)(2 * gq + 1) * 64] = dbl2_t{sg[128], sg[192]};
-                            ++gq; nb = 0;
-                        }
-                    }
-                }
-            }
-        }
-    }
-    const unsigned long long iq = (unsigned long long)inert * 0x0001000100010001ull;
-    if (nb > 0) {                                               // close the open quad with inert entries
-        cacc = (cacc >> (16 * (4 - nb))) | (iq << (16 * nb));
-        const double a0 = sg[0], a1 = nb > 1 ? sg[64] : 0.0, a2 = nb > 2 ? sg[128] : 0.0;
-        dc[(size_t)gq * 64] = cacc; dv[(size_t)(2 * gq) * 64] = dbl2_t{a0, a1}; dv[(size_t)(2 * gq + 1) * 64] = dbl2_t{a2, 0.0};
-        ++gq;
-    }
-    for (; gq < newWq; ++gq) { dc[(size_t)gq * 64] = iq; dv[(size_t)(2 * gq) * 64] = dbl2_t{0.0, 0.0}; dv[(size_t)(2 * gq + 1) * 64] = dbl2_t{0.0, 0.0}; }
+    return fma((double)(uint32_t)(a >> 32), 4294967296.0, (double)(uint32_t)a) * inv;
 }
 
-template <bool HASCZ>
-__device__ void solve_stream(const DevParams& D, int b, const ProbDesc& pd, ProbState* st,
-                             const double* __restrict__ feats, const int32_t* __restrict__ assoc,
-                             const int32_t* __restrict__ lp, const double* __restrict__ ls,
-                             const uint32_t* __restrict__ permPool, const uint32_t* __restrict__ sliceBasePool,
-                             const StreamLevels& LV, const double* __restrict__ u0, const SolveOut& O,
-                             double* vec /* 7 vectors of Lc doubles */, int Lc, uint16_t* permS /* [nsl*64] */,
-                             double2* pbuf /* [2*ST_NW][64] */, unsigned long long* sK /* [2][48] */,
-                             uint32_t* cumQ /* [4][ST_CQ] */, uint32_t* tmpW /* [48] */, uint32_t* wQ /* [4][ST_NW+1] quad range starts */,
-                             uint32_t* wS /* [4][ST_NW] first slice of every wave's range */, uint32_t* cutS /* [4][ST_NW] */, unsigned long long* emptyM /* [4] */, double* red, int* sint)
+template <int NW, bool HASCZ>
+__device__ void solve_up(const DevParams& D, int b, const ProbDesc& pd, ProbState* st,
+                         const double* __restrict__ feats, const int32_t* __restrict__ assoc,
+                         const int32_t* __restrict__ plp /* position -> association index */, const int32_t* __restrict__ lpAsc,
+                         const uint32_t* __restrict__ rowPosPool, const double* __restrict__ pld /* diagonal, position order */,
+                         const uint32_t* __restrict__ sliceBasePool,
+                         const uint16_t* __restrict__ colsPool, const double* __restrict__ valsPool,
+                         const double* __restrict__ u0, const SolveOut& O,
+                         double* xg /* [Lc] */, unsigned long long* accM /* [Lc] */, unsigned long long* accC /* [Lc] */, int Lc,
+                         uint32_t* cumQ /* [ST_MAXSL + 1] */, double* red, int* sint)
 {
+    constexpr int NT = NW * 64;
+    constexpr int KMAX = (STREAM_MAXL + NT - 1) / NT;          // elements per thread
     const roman_params_t& P = D.p;
     const int tid = threadIdx.x, lane = tid & 63, w = uni(tid >> 6);
-    constexpr int NT = ST_NW * 64;
-    // per-element loops: fully unrolled (ST_KMAX * NT >= L) so that the LDS reads of all iterations overlap
-#define FOR_P(p) _Pragma("unroll") for (int k_ = 0; k_ < ST_KMAX; ++k_) if (const int p = tid + k_ * NT; p < L)
+#define FOR_K(k_, p_) _Pragma("unroll") for (int k_ = 0; k_ < KMAX; ++k_) if ([[maybe_unused]] const int p_ = tid + k_ * NT; true)
     const int L = uni(st[b].L), rb = uni(st[b].rowBase);
     const int64_t lo = pd.liveOff;
     const int nsl = (L + 63) >> 6;
@@ -2105,105 +2242,112 @@ __device__ void solve_stream(const DevParams& D, int b, const ProbDesc& pd, Prob
     double F = 0.0, d = 0.0;
     if (pd.n1 == 0 || pd.n2 == 0) status |= ROMAN_ST_EMPTY_MAP;
     if (L <= 0) {
-        finish_one(D, b, pd, feats, assoc, lp, O, nullptr, nullptr, nullptr, nullptr, L, rb, lo, F, status, S, red, sint);
+        finish_one(D, b, pd, feats, assoc, plp, lpAsc, rowPosPool, O, nullptr, nullptr, nullptr, nullptr, L, rb, lo, F, status, S, red, sint);
         return;
     }
 #ifdef ROMAN_SOLVE_TIMING
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tcnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tlast = __builtin_readcyclecounter();
 #endif
-    // LDS vectors, indexed by live association; element [L] of the gathered ones is a dummy that stays 0
-    double* xU = vec; double* xUn = vec + Lc;
-    double* Mu = vec + 2 * Lc; double* Cu = vec + 3 * Lc; double* Mun = vec + 4 * Lc; double* Cun = vec + 5 * Lc;
-    double* sd = vec + 6 * Lc;
+    g_quad_cp cbase = (g_quad_cp)(colsPool + st[b].nnzOff) + lane;
+    g_pair_cp vbase = (g_pair_cp)(valsPool + st[b].nnzOff) + lane;
+    l_vec_cp xl = (l_vec_cp)xg;
+    l_acc_p aM = (l_acc_p)accM; l_acc_p aC = (l_acc_p)accC;
 
-    // ---- slice geometry of level 0, rows of the slice slots, initial vector --------------------------
+    // ---- per-problem set-up: quad prefix of the slices, owned elements, clean LDS --------------------------
     __syncthreads();
-    for (int s = tid; s <= nsl; s += NT)
-        cumQ[s] = (s < nsl) ? (sliceBasePool[lo + s] >> 8) : (st[b].nnzCap >> 8);
-    for (int pos = tid; pos < nsl * 64; pos += NT) permS[pos] = (pos < L) ? (uint16_t)permPool[lo + pos] : (uint16_t)L;
-    for (int p = tid; p < L; p += NT) { sd[p] = ls[lo + p]; xU[p] = u0 ? u0[lo + lp[lo + p]] : 1.0; }
-    if (tid == 0) { xU[L] = 0.0; xUn[L] = 0.0; }
-
-    bool hasMid = false, hasSmall = false;
-    int nKmid = L, nKsmall = L, calm = 0, ncompact = 0;
-    int lvMid = 1, lvSmall = 2, lvSpare = 3;
-    // per level: the balanced quad range of every wave and the slice its range starts in (cumQ[lvl] must be final)
-    auto index_level = [&](int lvl) {
-        if (tid <= ST_NW) {
-            const uint32_t* cq = cumQ + lvl * ST_CQ;
-            const uint32_t T4 = cq[nsl];
-            const uint32_t qs = (uint32_t)(((unsigned long long)T4 * (unsigned)tid) / ST_NW);
-            wQ[lvl * (ST_NW + 1) + tid] = qs;
-            if (tid < ST_NW) {
-                int lo_ = 0, hi_ = nsl;                         // largest s with cq[s] <= qs (skips empty slices)
-                while (hi_ - lo_ > 1) { const int mid_ = (lo_ + hi_) >> 1; if (cq[mid_] <= qs) lo_ = mid_; else hi_ = mid_; }
-                wS[lvl * ST_NW + tid] = (uint32_t)lo_;
-                // the range boundary qs cuts slice lo_ iff it lies strictly inside it; the FIRST cut inside a
-                // slice (the previous boundary is not inside) is the one that adds up the slice's partial sums
-                const uint32_t pq = tid > 0 ? (uint32_t)(((unsigned long long)T4 * (unsigned)(tid - 1)) / ST_NW) : 0u;
-                const bool cut = tid > 0 && qs < T4 && cq[lo_] < qs;
-                cutS[lvl * ST_NW + tid] = (cut && pq <= cq[lo_]) ? (uint32_t)lo_ : 0xffffffffu;
-            }
-            if (tid == ST_NW) {                                 // slices without entries at this level
-                unsigned long long em = 0ull;
-                for (int s = 0; s < nsl; ++s) if (cq[s + 1] == cq[s]) em |= 1ull << s;
-                emptyM[lvl] = em;
-            }
-        }
-    };
-    __syncthreads();
-    index_level(0);
+    for (int s = tid; s <= nsl; s += NT) cumQ[s] = (s < nsl) ? (sliceBasePool[lo + s] >> 8) : (st[b].nnzCap >> 8);
+    for (int p = tid; p < Lc; p += NT) { xg[p] = 0.0; accM[p] = 0ull; accC[p] = 0ull; }
+    double u[KMAX], Mu[KMAX], Cu[KMAX], sd[KMAX], tk[KMAX], Mn[KMAX], Cn[KMAX];
+    FOR_K(k, p) {
+        const bool in = p < L;
+        sd[k] = in ? pld[lo + p] : 0.0;
+        u[k] = in ? (u0 ? u0[lo + plp[lo + p]] : 1.0) : 0.0;
+        Mu[k] = Cu[k] = tk[k] = Mn[k] = Cn[k] = 0.0;
+    }
     __syncthreads();
 
-    // ---- one balanced SpMV stream over level `lvl`: (M x, C x) -> (mo, co) ------------------------------
-    // Wave w streams the quads [wQ[w], wQ[w+1]) of the level; a piece that covers a whole slice stores its
-    // row sums directly, a piece cut by a range boundary goes to a partial slot (2w: the piece that starts
-    // the wave's range, 2w+1: the piece that ends it) and is added up in wave order after the barrier.
-    auto spmv = [&](const double* x, int lvl, double* mo, double* co) {
+    // ---- (M x, C x) -> (Mn, Cn) for the vector x held in tk[] (elements >= 0), with xmax = max x and
+    //      mp1 = 1 + the largest position with x > 0 (0: x is the zero vector) --------------------------------
+    auto spmv = [&](double xmax, int mp1) {
         TMARK(3);
-        const uint32_t* cq = cumQ + lvl * ST_CQ;
-        const uint32_t* wq = wQ + lvl * (ST_NW + 1);
-        const uint32_t qs = uni(wq[w]), qe = uni(wq[w + 1]);
+        if (!(xmax > 0.0) || mp1 <= 0) {                       // zero vector: zero products, nothing to publish
+            FOR_K(k, p) { Mn[k] = 0.0; Cn[k] = 0.0; }
+            ++n_pass;
+            return;
+        }
+        // scale: x_max * 2^s in [2^48, 2^49)
+        int e_ = (int)((__double_as_longlong(xmax) >> 52) & 0x7ff) - 1023;
+        int s_ = 48 - e_;
+        s_ = s_ > 960 ? 960 : (s_ < -960 ? -960 : s_);
+        const double sc = bits_f64((unsigned long long)(1023 + s_) << 52), inv = bits_f64((unsigned long long)(1023 - s_) << 52);
+        FOR_K(k, p) if (p < L) xg[p] = tk[k] * sc;
+        __syncthreads();                                        // the scaled vector is published; accumulators are clean
+        TMARK(6);
+        const int Sx = min(nsl, (mp1 + 63) >> 6);
+        const uint32_t T = uni(cumQ[Sx]);
+        const uint32_t qs = (uint32_t)(((unsigned long long)T * (unsigned)w) / NW), qe = (uint32_t)(((unsigned long long)T * (unsigned)(w + 1)) / NW);
         if (qs < qe) {
-            int s = uni((int)wS[lvl * ST_NW + w]);
-            uint32_t sliceB = uni(cq[s]), nextB = uni(cq[s + 1]);
-            g_quad_cp cp = (g_quad_cp)LV.cols[lvl] + lane;
-            g_pair_cp vp = (g_pair_cp)LV.vals[lvl] + lane;
-            l_vec_cp xl = (l_vec_cp)x;
-            // ring of ST_D quads in flight per lane.  Loads are issued unconditionally (the index is clamped to
-            // the last quad of the range) so that the wait counters stay exact: no branch ever separates a
-            // load from its use.
+            int s = 0;
+            {   // largest s with cumQ[s] <= qs (skips empty slices)
+                int lo_ = 0, hi_ = Sx;
+                while (hi_ - lo_ > 1) { const int mid_ = (lo_ + hi_) >> 1; if (uni(cumQ[mid_]) <= qs) lo_ = mid_; else hi_ = mid_; }
+                s = lo_;
+            }
+            uint32_t nextB = uni(cumQ[s + 1]);
+            // ring of ST_D quads in flight per lane; loads are issued unconditionally (clamped index) so that the wait
+            // counters stay exact
             unsigned long long rc[ST_D]; dbl2_t rv0[ST_D], rv1[ST_D];
 #pragma unroll
             for (int t = 0; t < ST_D; ++t) {
                 const uint32_t qq = min(qs + (uint32_t)t, qe - 1u);
-                rc[t] = cp[(size_t)qq * 64];
-                rv0[t] = vp[(size_t)(2 * qq) * 64]; rv1[t] = vp[(size_t)(2 * qq + 1) * 64];
+                rc[t] = cbase[(size_t)qq * 64];
+                rv0[t] = vbase[(size_t)(2 * qq) * 64]; rv1[t] = vbase[(size_t)(2 * qq + 1) * 64];
             }
-            double sm = 0.0, sc = 0.0;
-#define STREAM_CONSUME(Q_, C_, V0_, V1_)                                                                    \
+            unsigned long long smI = 0ull, scI = 0ull;          // pulled sums of this lane's row: sum of bits(MAGIC + term)
+            uint32_t pieceQ = qs;                               // first quad of the current piece
+            double xp = xl[s * 64 + lane];                      // this lane's row element (scaled); rows >= L read zeros
+            unsigned long long iCp = (unsigned long long)__double_as_longlong(xp + FX_MAGIC) - FX_MAGIC_BITS;
+#define UP_CONSUME(Q_, C_, V0_, V1_)                                                                        \
             {                                                                                               \
                 const uint32_t clo = (uint32_t)(C_), chi = (uint32_t)((C_) >> 32);                          \
-                const double x0 = xl[clo & ST_MASK], x1 = xl[(clo >> 16) & ST_MASK];                        \
-                const double x2 = xl[chi & ST_MASK], x3 = xl[(chi >> 16) & ST_MASK];                        \
-                sm = fma((V0_).x, x0, sm); sm = fma((V0_).y, x1, sm); sm = fma((V1_).x, x2, sm); sm = fma((V1_).y, x3, sm); \
+                const uint32_t c0 = clo & ST_MASK, c1 = (clo >> 16) & ST_MASK, c2 = chi & ST_MASK, c3 = (chi >> 16) & ST_MASK; \
+                const double x0 = xl[c0], x1 = xl[c1], x2 = xl[c2], x3 = xl[c3];                            \
+                smI += (unsigned long long)__double_as_longlong(fma((V0_).x, x0, FX_MAGIC));                \
+                smI += (unsigned long long)__double_as_longlong(fma((V0_).y, x1, FX_MAGIC));                \
+                smI += (unsigned long long)__double_as_longlong(fma((V1_).x, x2, FX_MAGIC));                \
+                smI += (unsigned long long)__double_as_longlong(fma((V1_).y, x3, FX_MAGIC));                \
                 if (HASCZ) {                                                                                \
-                    sc += (clo & ST_CZ) ? 0.0 : x0; sc += (clo & (ST_CZ << 16)) ? 0.0 : x1;                 \
-                    sc += (chi & ST_CZ) ? 0.0 : x2; sc += (chi & (ST_CZ << 16)) ? 0.0 : x3;                 \
-                } else {              /* the only C-flagged entries are inert: they gather x[L] == 0 */     \
-                    sc += x0; sc += x1; sc += x2; sc += x3;                                                 \
+                    scI += (unsigned long long)__double_as_longlong(((clo & ST_CZ) ? 0.0 : x0) + FX_MAGIC); \
+                    scI += (unsigned long long)__double_as_longlong(((clo & (ST_CZ << 16)) ? 0.0 : x1) + FX_MAGIC); \
+                    scI += (unsigned long long)__double_as_longlong(((chi & ST_CZ) ? 0.0 : x2) + FX_MAGIC); \
+                    scI += (unsigned long long)__double_as_longlong(((chi & (ST_CZ << 16)) ? 0.0 : x3) + FX_MAGIC); \
+                } else {              /* the only C-flagged entries are inert: they gather a zero */        \
+                    scI += (unsigned long long)__double_as_longlong(x0 + FX_MAGIC);                         \
+                    scI += (unsigned long long)__double_as_longlong(x1 + FX_MAGIC);                         \
+                    scI += (unsigned long long)__double_as_longlong(x2 + FX_MAGIC);                         \
+                    scI += (unsigned long long)__double_as_longlong(x3 + FX_MAGIC);                         \
                 }                                                                                           \
-                if ((Q_) + 1 == nextB || (Q_) + 1 == qe) {            /* end of this slice's piece */        \
-                    const uint32_t p0 = sliceB > qs ? sliceB : qs;    /* the piece is [p0, Q_+1) */           \
-                    if (p0 == sliceB && (Q_) + 1 == nextB) {          /* whole slice: final sums */            \
-                        const int r_ = permS[s * 64 + lane];                                                \
-                        mo[r_] = sm; co[r_] = sc;                     /* rows that do not exist alias element [L] */ \
-                    } else {                                                                                \
-                        pbuf[(2 * w + (p0 == qs ? 0 : 1)) * 64 + lane] = make_double2(sm, sc);              \
+                if (xp != 0.0) {                      /* push this row's element to the columns */          \
+                    __hip_atomic_fetch_add(aM + c0, (unsigned long long)__double_as_longlong(fma((V0_).x, xp, FX_MAGIC)) - FX_MAGIC_BITS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+                    __hip_atomic_fetch_add(aM + c1, (unsigned long long)__double_as_longlong(fma((V0_).y, xp, FX_MAGIC)) - FX_MAGIC_BITS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+                    __hip_atomic_fetch_add(aM + c2, (unsigned long long)__double_as_longlong(fma((V1_).x, xp, FX_MAGIC)) - FX_MAGIC_BITS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+                    __hip_atomic_fetch_add(aM + c3, (unsigned long long)__double_as_longlong(fma((V1_).y, xp, FX_MAGIC)) - FX_MAGIC_BITS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+                    if (!HASCZ || !(clo & ST_CZ)) __hip_atomic_fetch_add(aC + c0, iCp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+                    if (!HASCZ || !(clo & (ST_CZ << 16))) __hip_atomic_fetch_add(aC + c1, iCp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+                    if (!HASCZ || !(chi & ST_CZ)) __hip_atomic_fetch_add(aC + c2, iCp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+                    if (!HASCZ || !(chi & (ST_CZ << 16))) __hip_atomic_fetch_add(aC + c3, iCp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+                }                                                                                           \
+                if ((Q_) + 1 == nextB || (Q_) + 1 == qe) {            /* end of this slice's piece: flush the pulled sums */ \
+                    const unsigned long long nterm = (unsigned long long)(((Q_) + 1 - pieceQ) * 4u) * FX_MAGIC_BITS; \
+                    __hip_atomic_fetch_add(aM + (s * 64 + lane), smI - nterm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+                    __hip_atomic_fetch_add(aC + (s * 64 + lane), scI - nterm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+                    smI = 0ull; scI = 0ull; pieceQ = (Q_) + 1;                                              \
+                    if ((Q_) + 1 < qe) {                                                                    \
+                        do { ++s; nextB = uni(cumQ[s + 1]); } while (nextB <= (Q_) + 1);                    \
+                        xp = xl[s * 64 + lane];                                                             \
+                        iCp = (unsigned long long)__double_as_longlong(xp + FX_MAGIC) - FX_MAGIC_BITS;      \
                     }                                                                                       \
-                    sm = 0.0; sc = 0.0;                                                                     \
-                    if ((Q_) + 1 < qe) { do { ++s; sliceB = nextB; nextB = uni(cq[s + 1]); } while (nextB <= (Q_) + 1); } \
                 }                                                                                           \
             }
             uint32_t q0 = qs;
@@ -2214,171 +2358,117 @@ __device__ void solve_stream(const DevParams& D, int b, const ProbDesc& pd, Prob
                     const unsigned long long c = rc[t];
                     const dbl2_t v0 = rv0[t], v1 = rv1[t];
                     const uint32_t qn = min(q + (uint32_t)ST_D, qe - 1u);
-                    rc[t] = cp[(size_t)qn * 64];
-                    rv0[t] = vp[(size_t)(2 * qn) * 64]; rv1[t] = vp[(size_t)(2 * qn + 1) * 64];
-                    STREAM_CONSUME(q, c, v0, v1)
+                    rc[t] = cbase[(size_t)qn * 64];
+                    rv0[t] = vbase[(size_t)(2 * qn) * 64]; rv1[t] = vbase[(size_t)(2 * qn + 1) * 64];
+                    UP_CONSUME(q, c, v0, v1)
                 }
             }
 #pragma unroll
             for (int t = 0; t < ST_D; ++t) {                    // tail: fewer than ST_D quads, already in the ring
                 const uint32_t q = q0 + t;
-                if (q < qe) { STREAM_CONSUME(q, rc[t], rv0[t], rv1[t]) }
+                if (q < qe) { UP_CONSUME(q, rc[t], rv0[t], rv1[t]) }
             }
-#undef STREAM_CONSUME
+#undef UP_CONSUME
         }
         TMARK(0);
-        __syncthreads();
+        __syncthreads();                                        // every contribution has landed
         TMARK(1);
-        {   // rows of slices that are empty at this level
-            unsigned long long em = emptyM[lvl];
-            em = ((unsigned long long)uni((uint32_t)(em >> 32)) << 32) | uni((uint32_t)em);
-            while (em) {
-                const int s = __builtin_ctzll(em); em &= em - 1ull;
-                if ((s & (ST_NW - 1)) == w) { const int r_ = permS[s * 64 + lane]; mo[r_] = 0.0; co[r_] = 0.0; }
-            }
+        FOR_K(k, p) {
+            if (p < L) {
+                Mn[k] = fx_decode(accM[p], inv); Cn[k] = fx_decode(accC[p], inv);
+                accM[p] = 0ull; accC[p] = 0ull;                 // clean for the next pass (published by its barrier)
+            } else { Mn[k] = 0.0; Cn[k] = 0.0; }
         }
-        // slices cut by a range boundary: the wave behind the first cut adds the partial sums in stream order
-        const uint32_t cs = uni(cutS[lvl * ST_NW + w]);
-        if (cs != 0xffffffffu) {
-            const int s = (int)cs;
-            const uint32_t a0 = uni(cq[s]), a1 = uni(cq[s + 1]);
-            double a_ = 0.0, c_ = 0.0;
-#pragma unroll 1
-            for (int w3 = 0; w3 < ST_NW; ++w3) {
-                const uint32_t s3 = uni(wq[w3]), e3 = uni(wq[w3 + 1]);
-                if (s3 < e3 && s3 < a1 && e3 > a0) {
-                    const uint32_t p0 = a0 > s3 ? a0 : s3;
-                    const double2 p_ = pbuf[(2 * w3 + (p0 == s3 ? 0 : 1)) * 64 + lane];
-                    a_ += p_.x; c_ += p_.y;
-                }
-            }
-            const int r_ = permS[s * 64 + lane];
-            mo[r_] = a_; co[r_] = c_;
-        }
-        __syncthreads();
         ++n_pass;
         TMARK(2);
-    };
-
-    // ---- level dst <- rows of level src restricted to the columns in supp(x) ---------------------------
-    auto compact = [&](const double* x, int src, int dst, bool asMid, int nS) {
-        TMARK(3);
-        const uint32_t* cqs = cumQ + src * ST_CQ; uint32_t* cqd = cumQ + dst * ST_CQ;
-#pragma unroll 1
-        for (int k = 0; k * ST_NW < nsl; ++k) {
-            const int s = k * ST_NW + ((k & 1) ? ST_NW - 1 - w : w);   // snake over the length-sorted slices
-            if (s < nsl) {
-                uint32_t cnt = level_count_slot(x, LV.cols[src], uni(cqs[s]), uni(cqs[s + 1]), lane);
-                for (int off = 32; off > 0; off >>= 1) cnt = max(cnt, (uint32_t)__shfl_xor((int)cnt, off));
-                if (lane == 0) tmpW[s] = (cnt + 3u) >> 2;
-            }
-        }
-        __syncthreads();
-        if (tid == 0) { uint32_t acc = 0; for (int s = 0; s < nsl; ++s) { cqd[s] = acc; acc += tmpW[s]; } cqd[nsl] = acc; }
-        __syncthreads();
-        index_level(dst);
-#pragma unroll 1
-        for (int k = 0; k * ST_NW < nsl; ++k) {
-            const int s = k * ST_NW + ((k & 1) ? ST_NW - 1 - w : w);
-            if (s < nsl)
-                level_copy_slot(x, LV.cols[src], LV.vals[src], uni(cqs[s]), uni(cqs[s + 1]), LV.cols[dst], LV.vals[dst], uni(cqd[s]), uni(tmpW[s]),
-                                (uint32_t)L | ST_CZ, reinterpret_cast<double*>(pbuf) + w * 256, lane);   // stage: the (idle) partial-sum buffer
-        }
-        for (int wd = w; wd < nsl; wd += ST_NW) {
-            const int p = (wd << 6) + lane;
-            const unsigned long long m = __ballot(p < L && x[p] > 0.0);
-            if (lane == 0) sK[(asMid ? 0 : 1) * ST_MAXSL + wd] = m;
-        }
-        if (asMid) { hasMid = true; nKmid = nS; hasSmall = false; } else { hasSmall = true; nKsmall = nS; }
-        __syncthreads();
-        TMARK(4 + (src == 0 ? 0 : 1));
     };
 
     // ---- the iteration as a state machine around ONE SpMV call site ------------------------------------
     enum { PH_RESCALE, PH_INIT, PH_TRIAL };
     int phase = P.rescale_u0 ? PH_RESCALE : PH_INIT;
-    auto normalize_u = [&]() {                                  // xU /= |xU|
-        double r[1] = {0.0};
-        FOR_P(p) r[0] += xU[p] * xU[p];
-        block_sumN<1>(r, red, par, tid);
-        const double nr = sqrt(r[0]);
-        if (nr > 0.0) FOR_P(p) xU[p] /= nr;
-        __syncthreads();
-    };
-    if (phase == PH_INIT) normalize_u();
-    double usum = 0.0, alpha = 1.0, unsum = 0.0, du2 = 0.0, nS = 0.0, born = 0.0, vm = 0.0, vs = 0.0;
-    int i = 0, j = 0, kk = 0, lvlTrial = 0;
+    double usum = 0.0, alpha = 1.0, unsum = 0.0, du2 = 0.0, xmaxT = 0.0;
+    int mp1T = 0;
+    int i = 0, j = 0, kk = 0;
 
-    // trial vector u' = normalize(max(u + alpha g, 0)) into xUn (+ its sums, support and level tests)
+    auto normalize_u = [&]() {                                  // u /= |u|
+        double r[1] = {0.0}, m0[1] = {0.0};
+        FOR_K(k, p) r[0] += u[k] * u[k];
+        block_red<NW, 1, 0>(r, m0, red, par, tid);
+        const double nr = sqrt(r[0]);
+        if (nr > 0.0) FOR_K(k, p) u[k] /= nr;                   // (three passes per problem: the exact division stays)
+    };
+    auto load_u_as_x = [&]() {                                  // x = u (initial passes): tk, its maximum and support bound
+        double r0[1] = {0.0}, m2[2] = {0.0, 0.0};
+        FOR_K(k, p) { tk[k] = u[k]; m2[0] = fmax(m2[0], u[k]); if (u[k] > 0.0) m2[1] = (double)(p + 1); }
+        block_red<NW, 0, 2>(r0, m2, red, par, tid);             // NS == 0: r0 is not touched
+        xmaxT = m2[0]; mp1T = (int)m2[1];
+    };
+    // trial vector u' = normalize(max(u + alpha g, 0)) into tk (+ its sums and support)
     auto build_trial = [&]() {
-        double r[1] = {0.0};
-        FOR_P(p) {
-            const double up = xU[p];
-            const double g = (((sd[p] + d) * up - d * usum) + Mu[p]) + Cu[p] * d;
+        double r[1] = {0.0}, m2[2] = {0.0, 0.0};
+        FOR_K(k, p) {
+            const double up = u[k];
+            const double g = (((sd[k] + d) * up - d * usum) + Mu[k]) + Cu[k] * d;
             double t = up + alpha * g;
-            t = t > 0.0 ? t : 0.0;
-            xUn[p] = t; r[0] += t * t;
+            t = (p < L && t > 0.0) ? t : 0.0;
+            tk[k] = t; r[0] += t * t;
+            m2[0] = fmax(m2[0], t);
+            if (t > 0.0) m2[1] = (double)(p + 1);               // ascending p: the last one stays
         }
         TMARK(3);
-        block_sumN<1>(r, red, par, tid);
+        block_red<NW, 1, 2>(r, m2, red, par, tid);
         TMARK(6);
         const double nr = sqrt(r[0]);
-        double q[4] = {0.0, 0.0, 0.0, 0.0};                     // sum u', |u'-u|^2, support/birth counts, level violations
-        FOR_P(p) {
-            double t = xUn[p];
-            if (nr > 0.0) { t /= nr; xUn[p] = t; }
+        double q[2] = {0.0, 0.0}, m0[1] = {0.0};                // sum u', |u'-u|^2
+        FOR_K(k, p) {
+            double t = tk[k];
+            if (nr > 0.0) { t /= nr; tk[k] = t; }
             q[0] += t;
-            const double up = xU[p];
-            const double df = t - up; q[1] += df * df;
-            if (t > 0.0) {
-                q[2] += 1.0;
-                if (!(up > 0.0)) q[2] += 4096.0;
-                if (hasMid && !((sK[p >> 6] >> (p & 63)) & 1ull)) q[3] += 1.0;
-                if (hasSmall && !((sK[ST_MAXSL + (p >> 6)] >> (p & 63)) & 1ull)) q[3] += 4096.0;
-            }
+            const double df = t - u[k]; q[1] += df * df;
         }
         TMARK(3);
-        block_sumN<4>(q, red, par, tid);                       // its barrier also publishes the trial vector
+        block_red<NW, 2, 0>(q, m0, red, par, tid);
         TMARK(7);
         unsum = q[0]; du2 = q[1];
-        born = floor(q[2] / 4096.0); nS = q[2] - 4096.0 * born;
-        vs = floor(q[3] / 4096.0); vm = q[3] - 4096.0 * vs;
-        lvlTrial = (hasSmall && vs == 0.0) ? lvSmall : ((hasMid && vm == 0.0) ? lvMid : 0);
+        xmaxT = (nr > 0.0) ? m2[0] / nr : m2[0]; mp1T = (int)m2[1];
     };
-    auto objective = [&](const double* uu, const double* mm, const double* cc, double us) -> double {
-        double r[1] = {0.0};
-        FOR_P(p) {
-            const double up = uu[p];
-            const double g = (((sd[p] + d) * up - d * us) + mm[p]) + cc[p] * d;
+    auto objective = [&](const double (&uu)[KMAX], const double (&mm)[KMAX], const double (&cc)[KMAX], double us) -> double {
+        double r[1] = {0.0}, m0[1] = {0.0};
+        FOR_K(k, p) {
+            const double up = uu[k];
+            const double g = (((sd[k] + d) * up - d * us) + mm[k]) + cc[k] * d;
             r[0] += up * g;
         }
-        block_sumN<1>(r, red, par, tid);
+        block_red<NW, 1, 0>(r, m0, red, par, tid);
         return r[0];
     };
     auto d_ratio = [&](bool absval, double& acc, double& cnt) { // mean of (M u)_p / Cbu_p over the active set
-        double r2[2] = {0.0, 0.0};
-        FOR_P(p) {
-            const double up = xU[p], Cbu = (usum - Cu[p]) - up;
-            if (Cbu > P.eps && up > P.eps) { const double r_ = (Mu[p] + sd[p] * up) / Cbu; r2[0] += absval ? fabs(r_) : r_; r2[1] += 1.0; }
+        double r2[2] = {0.0, 0.0}, m0[1] = {0.0};
+        FOR_K(k, p) {
+            const double up = u[k], Cbu = (usum - Cu[k]) - up;
+            if (p < L && Cbu > P.eps && up > P.eps) { const double r_ = (Mu[k] + sd[k] * up) / Cbu; r2[0] += absval ? fabs(r_) : r_; r2[1] += 1.0; }
         }
-        block_sumN<2>(r2, red, par, tid);
+        block_red<NW, 2, 0>(r2, m0, red, par, tid);
         acc = r2[0]; cnt = r2[1];
     };
 
+    if (phase == PH_INIT) normalize_u();
+    load_u_as_x();
     for (;;) {
-        if (phase == PH_TRIAL) spmv(xUn, lvlTrial, Mun, Cun); else spmv(xU, 0, Mu, Cu);
+        spmv(xmaxT, mp1T);
         if (phase == PH_RESCALE) {                              // u = normalize(M u0 + diag u0)
-            FOR_P(p) xU[p] = Mu[p] + sd[p] * xU[p];
-            __syncthreads();
+            FOR_K(k, p) u[k] = (p < L) ? Mn[k] + sd[k] * u[k] : 0.0;
             normalize_u();
+            load_u_as_x();
             phase = PH_INIT;
             continue;
         }
         bool new_outer = false;
         if (phase == PH_INIT) {
-            double r1[1] = {0.0};
-            FOR_P(p) r1[0] += xU[p];
-            block_sumN<1>(r1, red, par, tid);
+            FOR_K(k, p) { Mu[k] = Mn[k]; Cu[k] = Cn[k]; }
+            double r1[1] = {0.0}, m0[1] = {0.0};
+            FOR_K(k, p) r1[0] += u[k];
+            block_red<NW, 1, 0>(r1, m0, red, par, tid);
             usum = r1[0];
             double acc, cnt;
             d_ratio(false, acc, cnt);
@@ -2388,7 +2478,7 @@ __device__ void solve_stream(const DevParams& D, int b, const ProbDesc& pd, Prob
             new_outer = true;
         } else {                                                // PH_TRIAL: products of the trial vector
             ++ls_trials;
-            const double Fnew = objective(xUn, Mun, Cun, unsum);
+            const double Fnew = objective(tk, Mn, Cn, unsum);
             const double deltaF = Fnew - F;
             if (deltaF < -P.eps && kk + 1 < P.maxlsiters) {     // backtrack
                 alpha *= P.beta; ++kk;
@@ -2398,26 +2488,9 @@ __device__ void solve_stream(const DevParams& D, int b, const ProbDesc& pd, Prob
             // accept: the trial vector and its products become the current ones
             const double du = sqrt(du2);
             F = Fnew; usum = unsum;
-            { double* t; t = xU; xU = xUn; xUn = t; t = Mu; Mu = Mun; Mun = t; t = Cu; Cu = Cun; Cun = t; }
+            FOR_K(k, p) { u[k] = tk[k]; Mu[k] = Mn[k]; Cu[k] = Cn[k]; }
             ++inner_iters; ++j;
             const bool stop = du < P.tol_u || fabs(deltaF) < P.tol_F;
-            // ---- level maintenance (speed only: every level pass is exact) ---------------------------
-            calm = (born == 0.0) ? calm + 1 : 0;
-            if (!stop && j < P.maxiniters && calm > 0) {
-                const int ns = (int)nS;
-                const bool validMid = hasMid && vm == 0.0, validSmall = hasSmall && vs == 0.0;
-                int src = -1, dst = 0; bool asMid = false;
-                if (!validMid) { if (calm >= 2 && 2 * ns <= L) { src = 0; dst = lvMid; asMid = true; } }
-                else if (validSmall) { if (2 * ns <= nKsmall) { src = lvSmall; dst = lvSpare; } }
-                else if (2 * ns <= nKmid) { src = lvMid; dst = lvSmall; }
-                // budget: a third and later copy never paid for itself in the passes that were left (measured: the
-                // slowest problems of a batch did 5-6 compactions; capping at 2 cut the kernel from 2.2 to 1.9 ms)
-                if (src >= 0 && ncompact < D.max_compact) {
-                    ++ncompact;
-                    compact(xU, src, dst, asMid, ns);
-                    if (src == lvSmall) { const int t = lvSmall; lvSmall = lvSpare; lvSpare = t; }
-                }
-            }
             if (stop || j >= P.maxiniters) {                    // end of the inner loop: homotopy update of d
                 double acc, cnt;
                 d_ratio(true, acc, cnt);
@@ -2427,7 +2500,7 @@ __device__ void solve_stream(const DevParams& D, int b, const ProbDesc& pd, Prob
                 new_outer = true;
             }
         }
-        if (new_outer) { F = objective(xU, Mu, Cu, usum); j = 0; }
+        if (new_outer) { F = objective(u, Mu, Cu, usum); j = 0; }
         alpha = 1.0; kk = 0;
         build_trial();
         phase = PH_TRIAL;
@@ -2442,51 +2515,59 @@ __device__ void solve_stream(const DevParams& D, int b, const ProbDesc& pd, Prob
         for (int t = 0; t < 8; ++t) { dg[t] = tacc[t]; dg[8 + t] = tcnt[t]; }
     }
 #endif
-    // finish_one starts with a barrier; scratch: the trial vector and its products
-    finish_one(D, b, pd, feats, assoc, lp, O, xU, Mun, reinterpret_cast<int32_t*>(xUn), reinterpret_cast<int32_t*>(Cun), L, rb, lo, F, status, S, red, sint);
-#undef FOR_P
+    // final u (unscaled) to LDS for the shared tail; scratch: the two accumulator arrays
+    __syncthreads();
+    FOR_K(k, p) if (p < L) xg[p] = u[k];
+    finish_one(D, b, pd, feats, assoc, plp, lpAsc, rowPosPool, O, xg, reinterpret_cast<double*>(accM),
+               reinterpret_cast<int32_t*>(accC), reinterpret_cast<int32_t*>(accC) + Lc, L, rb, lo, F, status, S, red, sint);
+#undef FOR_K
 }
 
-template <bool HASCZ>
-__global__ void __launch_bounds__(ST_NW * 64) k_solve_stream(DevParams D, int B, const ProbDesc* __restrict__ probs,
-                                                             ProbState* __restrict__ st,
-                                                             const double* __restrict__ feats, const int32_t* __restrict__ assoc,
-                                                             const int32_t* __restrict__ lp, const double* __restrict__ ls,
-                                                             const uint32_t* __restrict__ perm, const uint32_t* __restrict__ sliceBase,
-                                                             uint16_t* cols0, double* vals0, uint16_t* cols1, double* vals1,
-                                                             uint16_t* cols2, double* vals2, uint16_t* cols3, double* vals3,
-                                                             const double* __restrict__ u0, SolveOut O,
-                                                             int* __restrict__ queue, int Lc)
+template <int NW, bool HASCZ>
+__global__ void __launch_bounds__(NW * 64) k_solve_up(DevParams D, int B, const ProbDesc* __restrict__ probs,
+                                                      ProbState* __restrict__ st,
+                                                      const double* __restrict__ feats, const int32_t* __restrict__ assoc,
+                                                      const int32_t* __restrict__ plp, const int32_t* __restrict__ lpAsc,
+                                                      const uint32_t* __restrict__ rowPos, const double* __restrict__ pld,
+                                                      const uint32_t* __restrict__ sliceBase,
+                                                      const uint16_t* __restrict__ cols, const double* __restrict__ vals,
+                                                      const double* __restrict__ u0, SolveOut O,
+                                                      int* __restrict__ queue, int Lc)
 {
-    // LDS: 7 vectors of Lc doubles | pbuf[2*ST_NW][64] double2 | red[136] | sK[2][48] u64 | emptyM[4] u64 |
-    //      cumQ[4][49] (+4 pad) tmpW[48] wQ[4][9] wS[4][8] cutS[4][8] sint[4] | permS[ST_MAXSL*64] u16
+    // LDS: xg[Lc] f64 | accM[Lc] u64 | accC[Lc] u64 | red[2 * NW * RED_STRIDE + 8] | cumQ[ST_MAXSL + 2] u32 | sint[4]
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    double* vec = reinterpret_cast<double*>(smem);
-    double2* pbuf = reinterpret_cast<double2*>(vec + 7 * (size_t)Lc);
-    double* red = reinterpret_cast<double*>(pbuf + 2 * ST_NW * 64);
-    unsigned long long* sK = reinterpret_cast<unsigned long long*>(red + 136);
-    unsigned long long* emptyM = sK + 2 * ST_MAXSL;
-    uint32_t* cumQ = reinterpret_cast<uint32_t*>(emptyM + 4);
-    uint32_t* tmpW = cumQ + 4 * ST_CQ + 4;
-    uint32_t* wQ = tmpW + ST_MAXSL;
-    uint32_t* wS = wQ + 4 * (ST_NW + 1);
-    uint32_t* cutS = wS + 4 * ST_NW;
-    int* sint = reinterpret_cast<int*>(cutS + 4 * ST_NW);
-    uint16_t* permS = reinterpret_cast<uint16_t*>(sint + 4);
+    double* xg = reinterpret_cast<double*>(smem);
+    unsigned long long* accM = reinterpret_cast<unsigned long long*>(xg + Lc);
+    unsigned long long* accC = accM + Lc;
+    double* red = reinterpret_cast<double*>(accC + Lc);
+    uint32_t* cumQ = reinterpret_cast<uint32_t*>(red + 2 * NW * RED_STRIDE + 8);
+    int* sint = reinterpret_cast<int*>(cumQ + ST_MAXSL + 2);
     for (;;) {
         if (threadIdx.x == 0) sint[2] = atomicAdd(queue, 1);
         __syncthreads();
-        const int b = sint[2];
+        const int b = uni(sint[2]);
         __syncthreads();
         if (b >= B) break;
-        const ProbDesc pd = probs[b];
-        StreamLevels LV;
-        const int64_t no = st[b].nnzOff;
-        LV.cols[0] = cols0 + no; LV.vals[0] = vals0 + no; LV.cols[1] = cols1 + no; LV.vals[1] = vals1 + no;
-        LV.cols[2] = cols2 + no; LV.vals[2] = vals2 + no; LV.cols[3] = cols3 + no; LV.vals[3] = vals3 + no;
-        solve_stream<HASCZ>(D, b, pd, st, feats, assoc, lp, ls, perm, sliceBase, LV, u0, O,
-                            vec, Lc, permS, pbuf, sK, cumQ, tmpW, wQ, wS, cutS, emptyM, red, sint);
+        // (plain if / else on a scalar, no `continue`: every wave must reach the two barriers above the same number of
+        // times, and a `continue` out of a branch only thread 0 works in was compiled into a loop that did not)
+        const int kind = uni(st[b].kind);
+        if (kind == 0) {
+            const ProbDesc pd = probs[b];
+            solve_up<NW, HASCZ>(D, b, pd, st, feats, assoc, plp, lpAsc, rowPos, pld, sliceBase, cols, vals, u0, O,
+                                xg, accM, accC, Lc, cumQ, red, sint);
+        }                                                       // kind 1: the fallback solver's problem; kind 2: skipped (k_skipped)
     }
+}
+
+// k_skipped: result records of the problems that found no workspace (kind 2): ROMAN_ST_WORKSPACE, no associations,
+// NaN pose.  One thread per problem.
+__global__ void __launch_bounds__(256) k_skipped(int B, const ProbDesc* __restrict__ probs, const ProbState* __restrict__ st, SolveOut O)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B || st[b].kind != 2) return;
+    for (int t = 0; t < 16; ++t) O.T_out[(int64_t)b * 16 + t] = d_nan();
+    O.n_assoc_out[b] = 0; O.status_out[b] = ROMAN_ST_WORKSPACE; O.nSel[b] = 0;
+    if (O.stats_out) { roman_stats_t S{}; S.n_assoc_in = probs[b].nA; S.n_live = st[b].L; O.stats_out[b] = S; }
 }
 
 // ---------------------------------------------------------------------------------------------

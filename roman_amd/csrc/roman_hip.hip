@@ -1,17 +1,22 @@
 // roman_hip.hip — host side of libroman_hip.so: context, HBM workspace, launch sequence and the
 // C ABI declared in include/roman_hip.h.  gfx950 only; no CPU fallback.
+//
+// A batch is a pure ENQUEUE: the launch sequence never waits for the GPU.  The sizes of the sparse
+// pools (candidate bit matrices, matrix entries) depend on the data; they are allocated from estimates —
+// exact where the invariant has no single scores (every association is live), otherwise from the ratios
+// seen in earlier batches with the same parameters (read back lazily, never waited for), otherwise from a
+// heuristic — and the device checks every problem against the capacity it was given: a problem that does
+// not fit is skipped with ROMAN_ST_WORKSPACE and the recorded need sizes the next attempt.  The entry
+// points that are synchronous anyway (host pointers, stepwise API) retry by themselves.
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cmath>
-#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <mutex>
 #include <new>
 #include <string>
-#include <thread>
 #include <vector>
 
 #include "kernels.hip.h"
@@ -21,8 +26,6 @@ using namespace roman;
 namespace {
 
 thread_local std::string g_last_error;
-thread_local int t_wsel = 0;                  // workspace the calling thread works on (pipeline workers: their own)
-thread_local std::string* t_err = nullptr;     // pipeline workers collect their error text here instead of in the context
 
 // grow-only device buffer
 struct DevBuf {
@@ -52,54 +55,50 @@ struct roman_ctx {
     size_t lds_max = 65536;
     std::string err;
 
-    // Workspace: every device pool of one batch in flight, its stream and its profiling events.  The
-    // context owns two of them: with roman_ctx_set_pipeline(ctx, 2) consecutive batch calls alternate
-    // between the two (each on its own internal stream), so the straggler tail of one batch's kernels
-    // overlaps the next batch's build.  Set 0 also serves the stepwise API.
+    // Workspace: every device pool of one batch in flight, its stream and its profiling events.  With
+    // roman_ctx_set_pipeline(ctx, 2) consecutive batch calls alternate between two of them (each on its own
+    // internal stream), so the straggler tail of one batch's kernels overlaps the next batch's build.  Set 0 also
+    // serves the stepwise API.
     struct Workspace {
-        hipStream_t stream = nullptr;          // set 0: the context's stream; set 1: internal
+        hipStream_t stream = nullptr;          // set 0 at depth 1: the context's stream; otherwise internal
         hipEvent_t done = nullptr;             // recorded after the last kernel of a batch call
         bool issued = false;
         // pools (see DESIGN.md "Data layout in HBM")
         DevBuf probs, state, totals, queue;
-        DevBuf cosPool, normPool, tabPool, sTmp, chunkCnt;
-        DevBuf lp, li, lj, ls, ld, lza, lzb;
-        DevBuf rowCnt, rowPos, perm, sliceWidth, sliceBase, items, maskPool, prefPool;
+        DevBuf cosPool, tabPool, sTmp, chunkCnt;
+        DevBuf lp, li, lj, ls, ld, lza, lzb;                       // per live association, live order
+        DevBuf plp, pli, plj, pls, pld, plza, plzb;                // the same in position order (stream layout)
+        DevBuf rowCnt, rowPos, perm, sliceWidth, sliceBase, items, maskPool, umaskPool, prefPool;
         DevBuf vMu, vCu, vMun, vCun, gU, gUn, uOut, nodesOrig, nSel;
-        DevBuf cols, vals;
-        DevBuf cols1, vals1, cols2, vals2, cols3, vals3;      // column-compacted copies of the matrix (solver levels)
+        DevBuf cols16, cols32, vals;
+        long long capMaskWords = 0, capNnz = 0;                    // what the sparse pools hold (elements)
         // staging for the host-pointer entry points
         DevBuf hFeats, hAssoc, hU0, oAssoc, oN, oT, oStatus, oStats, hAux1, hAux2, hAux3;
+        // totals of the most recent batch on this workspace, copied back without waiting
         BatchTotals* pinnedTotals = nullptr;
+        hipEvent_t totEvent = nullptr;
+        bool totPending = false;
+        double totMaskBound = 0.0, totSumA = 0.0, totMaxA = 0.0;   // the bounds the pending totals relate to
         // per-stage hipEvent pairs on `stream`
         hipEvent_t evA[ROMAN_STAGE_COUNT] = {nullptr, nullptr, nullptr, nullptr};
         hipEvent_t evB[ROMAN_STAGE_COUNT] = {nullptr, nullptr, nullptr, nullptr};
         bool pending[ROMAN_STAGE_COUNT] = {false, false, false, false};
     } ws[ROMAN_MAX_PIPELINE];
-    bool in_host_batch = false;                // roman_align_batch (host pointers) is driving roman_align_batch_dev
-    int pipeline = 1;                          // batches in flight (1 or 2)
+    int cur = 0;                               // workspace the current call works on
+    int pipeline = 1;                          // batches in flight (1..3)
     int next_ws = 0;
     hipStream_t istream[ROMAN_MAX_PIPELINE] = {nullptr, nullptr, nullptr};   // internal streams of the workspaces while pipelining
     int latest_ws = -1;                        // workspace of the most recent pipelined batch call
     hipEvent_t evIn = nullptr;                 // inputs ready on the caller's stream
 
-    // Pipelined batch calls are executed by one worker thread per workspace: the call sequence of a batch blocks
-    // twice on a 32-byte read-back (sizes of the sparse build), and only a second host thread lets the next
-    // batch's first kernels be queued meanwhile.  roman_align_batch_dev copies its host-side arguments into
-    // the job and returns; errors of a job surface at the next call that touches its workspace.
-    struct Job {
-        roman_params_t params; int32_t B = 0, F = 0, kmax = 0;
-        const double* feats = nullptr; const int32_t* assoc = nullptr; const double* u0 = nullptr;
-        std::vector<int64_t> off1, off2, assoc_off; std::vector<int32_t> n1, n2;
-        int32_t* assoc_out = nullptr; int32_t* n_assoc_out = nullptr; double* T_out = nullptr; int32_t* status_out = nullptr;
-        roman_stats_t* stats_out = nullptr;
-    };
-    struct Worker {
-        std::thread th; std::mutex m; std::condition_variable cv;
-        bool started = false, has_job = false, busy = false, quit = false;
-        Job job; int rc = 0; std::string err;
-    } wk[ROMAN_MAX_PIPELINE];
-    std::mutex prof_mu;
+    // sizing history: largest observed need relative to what the host can bound before the launch
+    struct Hist {
+        bool valid = false;
+        roman_params_t params; int32_t F = 0;  // the ratios belong to this parameter block
+        double rMaxL = 0.0;                    // largest live set / largest association list
+        double rMask = 0.0;                    // bit-matrix words / sum of nA * ceil(nA / 64)
+        double rNnz = 0.0;                     // matrix slots / sum of nA
+    } hist;
 
     bool profile = false;
     double prof_ms[ROMAN_STAGE_COUNT] = {0, 0, 0, 0};
@@ -107,11 +106,12 @@ struct roman_ctx {
 
     // state of the last single-problem call (stepwise API for the clipperpy shim)
     struct Last {
-        bool scored = false, solved = false, idx16 = true, dense = false, hascz = false;
+        bool scored = false, solved = false, dense = false, hascz = false;
+        int kind = 1;                      // layout of the problem held by workspace 0 (ProbState.kind)
         DevParams D;
         ProbDesc pd;
-        BatchTotals tot;
         int32_t nA = 0, L = 0, nsel = 0;
+        int64_t nnzCap = 0;
         std::vector<int32_t> assoc;        // (nA,2) host copy (explicit list) — empty for all-to-all
         std::vector<int32_t> nodes;        // selected nodes (original association indices)
         std::vector<double> u;             // length nA
@@ -120,7 +120,7 @@ struct roman_ctx {
     } last;
 };
 
-#define WS (c->ws[t_wsel])
+#define WS (c->ws[c->cur])
 
 namespace {
 
@@ -128,30 +128,20 @@ int fail(roman_ctx* c, int code, const char* fmt, ...)
 {
     char buf[640];
     va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap);
-    if (t_err) *t_err = buf; else if (c) c->err = buf; else g_last_error = buf;
+    if (c) c->err = buf; else g_last_error = buf;
     return code;
 }
-
-// The stepwise / host-pointer entry points run on workspace 0 and the context's own stream; work that
-// pipelined batch calls still have in flight is drained first.
-int use_ws0(roman_ctx* c);
 
 #define HIPCHK(c, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { (void)hipGetLastError(); \
     return fail((c), (e_ == hipErrorOutOfMemory) ? ROMAN_E_NOMEM : ROMAN_E_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); } } while (0)
 
-int workers_wait_all(roman_ctx* c);
-int worker_wait_idle(roman_ctx* c, int k);
-void workers_stop(roman_ctx* c);
-void worker_main(roman_ctx* c, int k);
-
+// The stepwise / host-pointer entry points run on workspace 0 and the context's own stream; work that
+// pipelined batch calls still have in flight is drained first.
 int use_ws0(roman_ctx* c)
 {
-    if (c->pipeline >= 2) {
-        const int rc = workers_wait_all(c);
+    if (c->pipeline >= 2)
         for (int k = 0; k < ROMAN_MAX_PIPELINE; ++k) if (c->istream[k]) HIPCHK(c, hipStreamSynchronize(c->istream[k]));
-        if (rc) return rc;
-    }
-    t_wsel = 0; c->ws[0].stream = c->stream;
+    c->cur = 0; c->ws[0].stream = c->stream;
     return ROMAN_OK;
 }
 
@@ -166,22 +156,6 @@ double sqrt_threshold(double t)
     return x;
 }
 
-// The streaming solver (k_solve_stream) and its quad matrix layout serve problems of up to ST_MAXSL*64
-// live associations; larger ones use the SELL-64 layout and the LDS/HBM-vector solver.
-// LDS of k_solve_stream for problems of up to maxL live associations (layout: see the kernel)
-size_t stream_lds_bytes(int maxL)
-{
-    const size_t Lc = (size_t)((maxL + 2 + 1) & ~1);
-    const size_t nsl = (size_t)(maxL + 63) / 64;
-    return 7 * sizeof(double) * Lc + (size_t)2 * ST_NW * 64 * 2 * sizeof(double) + 136 * sizeof(double)
-           + (2 * ST_MAXSL + 4) * sizeof(unsigned long long)
-           + (4 * ST_CQ + 4 + ST_MAXSL + 4 * (ST_NW + 1) + 4 * ST_NW + 4 * ST_NW) * sizeof(uint32_t) + 4 * sizeof(int)
-           + nsl * 64 * sizeof(uint16_t) + 64;
-}
-bool use_quad(const DevParams& D, int maxL)
-{
-    return maxL <= ST_MAXSL * 64 && maxL <= ST_KMAX * ST_NW * 64 && stream_lds_bytes(maxL) <= (size_t)(160 * 1024 - 256) && D.p.maxiniters >= 1 && D.p.maxlsiters >= 1;
-}
 // host twins of col_pos / val_pos (kernels.hip.h)
 inline size_t h_col_pos(bool quad, size_t sbase, uint32_t slot, uint32_t e) { return quad ? sbase + (size_t)(e >> 2) * 256 + slot * 4 + (e & 3u) : sbase + (size_t)e * 64 + slot; }
 inline size_t h_val_pos(bool quad, size_t sbase, uint32_t slot, uint32_t e) { return quad ? sbase + (size_t)(e >> 1) * 128 + slot * 2 + (e & 1u) : sbase + (size_t)e * 64 + slot; }
@@ -214,6 +188,7 @@ int make_dev_params(roman_ctx* c, const roman_params_t* p, int32_t F, DevParams*
     D->gmode = D->gravity ? 1 + p->gravity_mode : 0;
     D->diag_one = D->single && p->single_mode == ROMAN_SINGLE_OFFDIAG;
     D->F = F;
+    D->stream_maxL = STREAM_MAXL;
     return ROMAN_OK;
 }
 
@@ -223,30 +198,97 @@ void prof_flush(roman_ctx* c, int k, int s)
     if (!W.pending[s]) return;
     float ms = 0.f;
     if (hipEventSynchronize(W.evB[s]) == hipSuccess && hipEventElapsedTime(&ms, W.evA[s], W.evB[s]) == hipSuccess) {
-        std::lock_guard<std::mutex> lk(c->prof_mu);
         c->prof_ms[s] += (double)ms; c->prof_n[s] += 1;
     }
     W.pending[s] = false;
 }
 struct StageTimer {
     roman_ctx* c; int s;
-    StageTimer(roman_ctx* c_, int s_) : c(c_), s(s_) { if (c->profile) { prof_flush(c, t_wsel, s); (void)hipEventRecord(WS.evA[s], WS.stream); } }
+    StageTimer(roman_ctx* c_, int s_) : c(c_), s(s_) { if (c->profile) { prof_flush(c, c->cur, s); (void)hipEventRecord(WS.evA[s], WS.stream); } }
     void stop() { if (c->profile) { (void)hipEventRecord(WS.evB[s], WS.stream); WS.pending[s] = true; } }
 };
+
+// ROMAN_DEBUG=1: synchronise after every launch and say which one it was (locating a kernel that does not return)
+int dbg_stage(roman_ctx* c, const char* what)
+{
+    static const bool dbg = getenv("ROMAN_DEBUG") != nullptr;
+    if (!dbg) return ROMAN_OK;
+    const hipError_t e = hipStreamSynchronize(WS.stream);
+    fprintf(stderr, "[roman] %-14s %s\n", what, e == hipSuccess ? "ok" : hipGetErrorString(e));
+    fflush(stderr);
+    return e == hipSuccess ? ROMAN_OK : fail(c, ROMAN_E_HIP, "%s failed: %s", what, hipGetErrorString(e));
+}
+#define DBG(c, what) do { int rc_ = dbg_stage((c), (what)); if (rc_) return rc_; } while (0)
 
 struct BatchIn {
     int32_t B; const double* feats; const int64_t* off1; const int32_t* n1; const int64_t* off2; const int32_t* n2;
     int32_t F; const int32_t* assoc; const int64_t* assoc_off;
 };
 
-// Stage A: scoring — norms, cosine, tables, live list, sparse affinity build.  Leaves the CSR and
-// the live pools in the context; returns the host copy of the problem descriptors and totals.
-int stage_score(roman_ctx* c, const DevParams& D, const BatchIn& in, std::vector<ProbDesc>& hd,
-                BatchTotals* totOut, bool* idx16)
+// ---- sizing -----------------------------------------------------------------------------------------------------
+// What the host can bound before the launch, and the estimates derived from it.
+struct Sizing {
+    double sumA = 0, maxA = 0, maskBound = 0;      // sum / max of the association list lengths, sum of nA * ceil(nA/64)
+    int expectMaxL = 0;                            // estimate of the largest live set
+    long long capMaskWords = 0, capNnz = 0;        // capacities to allocate (elements)
+};
+
+// Fold the totals a finished batch left in pinned memory into the history (never waits: only completed copies count).
+void harvest_totals(roman_ctx* c, bool wait)
+{
+    for (int k = 0; k < ROMAN_MAX_PIPELINE; ++k) {
+        roman_ctx::Workspace& W = c->ws[k];
+        if (!W.totPending || !W.totEvent) continue;
+        if (wait) { if (hipEventSynchronize(W.totEvent) != hipSuccess) { (void)hipGetLastError(); continue; } }
+        else if (hipEventQuery(W.totEvent) != hipSuccess) { (void)hipGetLastError(); continue; }
+        W.totPending = false;
+        const BatchTotals& t = *W.pinnedTotals;
+        roman_ctx::Hist& H = c->hist;
+        if (W.totMaxA > 0) H.rMaxL = std::max(H.rMaxL, (double)t.maxL / W.totMaxA);
+        if (W.totMaskBound > 0) H.rMask = std::max(H.rMask, (double)t.needMaskWords / W.totMaskBound);
+        if (W.totSumA > 0) H.rNnz = std::max(H.rNnz, (double)t.needNnz / W.totSumA);
+        H.valid = true;
+    }
+}
+
+void estimate_sizes(roman_ctx* c, const DevParams& D, const roman_params_t* params, int32_t F, const std::vector<ProbDesc>& hd, Sizing* S)
+{
+    roman_ctx::Hist& H = c->hist;
+    if (!H.valid || H.F != F || memcmp(&H.params, params, sizeof(roman_params_t)) != 0) {   // other parameters: other ratios
+        H = roman_ctx::Hist{}; H.params = *params; H.F = F;
+    }
+    harvest_totals(c, false);
+    double heurMask = 0, heurNnz = 0; int heurMaxL = 0;
+    for (const ProbDesc& d : hd) {
+        const double nA = d.nA;
+        S->sumA += nA; S->maxA = std::max(S->maxA, nA); S->maskBound += nA * std::ceil(nA / 64.0);
+        // first-call heuristic: without single scores every association is live; with them a fraction is
+        const double capL = D.single ? std::min(nA, std::max(4096.0, nA / 8.0)) : nA;
+        heurMaxL = std::max(heurMaxL, (int)capL);
+        heurMask += capL * std::ceil(capL / 64.0);
+        heurNnz += capL * std::min(capL, 96.0);
+    }
+    if (H.valid) {
+        S->expectMaxL = D.single ? (int)std::min(S->maxA, std::ceil(H.rMaxL * S->maxA * 1.15) + 64.0) : (int)S->maxA;
+        S->capMaskWords = (long long)(D.single ? H.rMask * S->maskBound * 1.3 + 4096.0 : S->maskBound);
+        S->capNnz = (long long)(H.rNnz * S->sumA * 1.3 + 65536.0);
+    } else {
+        S->expectMaxL = heurMaxL; S->capMaskWords = (long long)heurMask; S->capNnz = (long long)heurNnz + 65536;
+    }
+    S->capMaskWords = std::max<long long>(S->capMaskWords, 64);
+    // tests: force the first attempt of a batch to overflow (exercises the skip / retry path)
+    static const char* tcap = getenv("ROMAN_TEST_CAPNNZ");
+    if (tcap && !H.valid) S->capNnz = atoll(tcap);
+}
+
+// ---- the launch sequence of one batch (score + solve), on workspace c->cur and its stream; never waits -------------
+struct BatchOut { int32_t kmax; int32_t* assoc_out; int32_t* n_assoc_out; double* T_out; int32_t* status_out; roman_stats_t* stats_out; };
+
+int enqueue_score(roman_ctx* c, const DevParams& Din, const roman_params_t* params, const BatchIn& in, std::vector<ProbDesc>& hd, DevParams* Dout)
 {
     const int B = in.B;
     hd.assign(B, ProbDesc{});
-    int64_t sumA = 0, sumCos = 0, sumTab = 0, sumN = 0;
+    int64_t sumA = 0, sumCos = 0, sumTab = 0;
     int maxN12 = 0, maxTiles = 0, maxN = 0, maxA = 0; int64_t maxTab = 0;
     for (int b = 0; b < B; ++b) {
         ProbDesc& d = hd[b];
@@ -263,29 +305,46 @@ int stage_score(roman_ctx* c, const DevParams& D, const BatchIn& in, std::vector
             if (na > 2147483647LL) return fail(c, ROMAN_E_TOO_LARGE, "n1*n2 overflows int32 in problem %d", b);
             d.nA = (int32_t)na;
         }
-        d.liveOff = sumA; d.cosOff = sumCos; d.tabOff = sumTab; d.normOff = sumN;
+        d.liveOff = sumA; d.cosOff = sumCos; d.tabOff = sumTab; d.normOff = 0;
         maxA = std::max(maxA, d.nA);
-        sumA += d.nA; sumCos += (int64_t)d.n1 * d.n2; sumTab += (int64_t)d.n1 * d.n1 + (int64_t)d.n2 * d.n2; sumN += d.n1 + d.n2;
+        sumA += d.nA; sumCos += (int64_t)d.n1 * d.n2; sumTab += (int64_t)d.n1 * d.n1 + (int64_t)d.n2 * d.n2;
         maxN12 = std::max(maxN12, d.n1 + d.n2); maxN = std::max(maxN, std::max(d.n1, d.n2));
         maxTiles = std::max(maxTiles, ((d.n1 + COS_TILE - 1) / COS_TILE) * ((d.n2 + COS_TILE - 1) / COS_TILE));
         maxTab = std::max(maxTab, (int64_t)d.n1 * d.n1 + (int64_t)d.n2 * d.n2);
     }
     if (sumA > 2000000000LL) return fail(c, ROMAN_E_TOO_LARGE, "batch has %lld associations; split it (limit 2e9 per call)", (long long)sumA);
     const size_t nA1 = (size_t)std::max<int64_t>(sumA, 1);
+    DevParams D = Din;
     const bool cosOn = D.p.cos_feature_dim > 0;
+
+    Sizing SZ;
+    estimate_sizes(c, D, params, in.F, hd, &SZ);
+    // a workspace never shrinks: keep what earlier (larger) batches made it hold
+    SZ.capMaskWords = std::max(SZ.capMaskWords, WS.capMaskWords); SZ.capNnz = std::max(SZ.capNnz, WS.capNnz);
+    // stream layout: as many live associations as the LDS tiles of this launch are sized for
+    D.stream_maxL = std::min(STREAM_MAXL, std::max(64, (SZ.expectMaxL + 63) & ~63));
+    *Dout = D;
 
     HIPCHK(c, WS.probs.ensure(sizeof(ProbDesc) * (size_t)B));
     HIPCHK(c, WS.state.ensure(sizeof(ProbState) * (size_t)B));
     HIPCHK(c, WS.totals.ensure(sizeof(BatchTotals)));
-    HIPCHK(c, WS.queue.ensure(sizeof(int) * 4));
+    HIPCHK(c, WS.queue.ensure(sizeof(int) * 8));
     HIPCHK(c, WS.cosPool.ensure(sizeof(double) * (size_t)(cosOn ? std::max<int64_t>(sumCos, 1) : 1)));
-    HIPCHK(c, WS.normPool.ensure(sizeof(double) * (size_t)(cosOn ? std::max<int64_t>(sumN, 1) : 1)));
     HIPCHK(c, WS.tabPool.ensure(sizeof(double) * (size_t)std::max<int64_t>(sumTab, 1)));
     HIPCHK(c, WS.sTmp.ensure(sizeof(double) * nA1));
-    HIPCHK(c, WS.lp.ensure(sizeof(int32_t) * nA1)); HIPCHK(c, WS.li.ensure(sizeof(int32_t) * nA1)); HIPCHK(c, WS.lj.ensure(sizeof(int32_t) * nA1));
-    HIPCHK(c, WS.ls.ensure(sizeof(double) * nA1)); HIPCHK(c, WS.ld.ensure(sizeof(double) * nA1)); HIPCHK(c, WS.lza.ensure(sizeof(double) * nA1)); HIPCHK(c, WS.lzb.ensure(sizeof(double) * nA1));
-    HIPCHK(c, WS.rowCnt.ensure(sizeof(uint32_t) * nA1)); HIPCHK(c, WS.rowPos.ensure(sizeof(uint32_t) * nA1)); HIPCHK(c, WS.perm.ensure(sizeof(uint32_t) * nA1));
-    HIPCHK(c, WS.sliceWidth.ensure(sizeof(uint32_t) * nA1)); HIPCHK(c, WS.sliceBase.ensure(sizeof(uint32_t) * nA1));
+    {
+        DevBuf* i32s[] = {&WS.lp, &WS.li, &WS.lj, &WS.plp, &WS.pli, &WS.plj, &WS.rowCnt, &WS.rowPos, &WS.perm, &WS.sliceWidth, &WS.sliceBase};
+        for (DevBuf* b_ : i32s) HIPCHK(c, b_->ensure(sizeof(int32_t) * nA1));
+        DevBuf* f64s[] = {&WS.ls, &WS.ld, &WS.lza, &WS.lzb, &WS.pls, &WS.pld, &WS.plza, &WS.plzb};
+        for (DevBuf* b_ : f64s) HIPCHK(c, b_->ensure(sizeof(double) * nA1));
+    }
+    HIPCHK(c, WS.maskPool.ensure(sizeof(unsigned long long) * (size_t)SZ.capMaskWords));
+    HIPCHK(c, WS.umaskPool.ensure(sizeof(unsigned long long) * (size_t)SZ.capMaskWords));
+    HIPCHK(c, WS.prefPool.ensure(sizeof(uint32_t) * (size_t)SZ.capMaskWords));
+    HIPCHK(c, WS.vals.ensure(sizeof(double) * (size_t)SZ.capNnz));
+    HIPCHK(c, WS.cols16.ensure(sizeof(uint16_t) * (size_t)SZ.capNnz));
+    HIPCHK(c, WS.cols32.ensure(sizeof(uint32_t) * (size_t)SZ.capNnz));
+    WS.capMaskWords = SZ.capMaskWords; WS.capNnz = SZ.capNnz;
     // work items: blocks of RPB consecutive live rows of one problem (more, smaller items for small batches)
     int RPB = 32;
     while (RPB < 128 && (int64_t)RPB * c->num_cu * 64 < sumA) RPB <<= 1;     // 128: ~17 items per problem balance the static item loop best (measured 32..1024)
@@ -296,47 +355,44 @@ int stage_score(roman_ctx* c, const DevParams& D, const BatchIn& in, std::vector
     const ProbDesc* dP = WS.probs.as<ProbDesc>();
     ProbState* dS = WS.state.as<ProbState>();
     BatchTotals* dT = WS.totals.as<BatchTotals>();
+    const LivePools LP{WS.lp.as<int32_t>(), WS.li.as<int32_t>(), WS.lj.as<int32_t>(), WS.ls.as<double>(), WS.ld.as<double>(), WS.lza.as<double>(), WS.lzb.as<double>()};
+    const LivePools PP{WS.plp.as<int32_t>(), WS.pli.as<int32_t>(), WS.plj.as<int32_t>(), WS.pls.as<double>(), WS.pld.as<double>(), WS.plza.as<double>(), WS.plzb.as<double>()};
 
     StageTimer t0(c, ROMAN_STAGE_SINGLE);
-    if (cosOn && maxN12 > 0) {
-        if (maxTiles > 0)
-        {
-            const int G = (maxTiles + 3) / 4;
-            hipLaunchKernelGGL(k_cos, dim3((unsigned)(G * ((B + 7) / 8) * 8)), dim3(256), 0, WS.stream, D, B, G, dP, in.feats, WS.cosPool.as<double>());
-        }
+    if (cosOn && maxN12 > 0 && maxTiles > 0) {
+        const int G = (maxTiles + 3) / 4;
+        hipLaunchKernelGGL(k_cos, dim3((unsigned)(G * ((B + 7) / 8) * 8)), dim3(256), 0, WS.stream, D, B, G, dP, in.feats, WS.cosPool.as<double>());
+    DBG(c, "k_cos");
     }
     if (maxTab > 0) {
         const size_t tabLds = sizeof(double) * 3 * (size_t)std::max(maxN, 1);
         if (tabLds > c->lds_max) return fail(c, ROMAN_E_TOO_LARGE, "maps of %d objects exceed the LDS point staging of this build", maxN);
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_tables), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tabLds));
         hipLaunchKernelGGL(k_tables, dim3((unsigned)((maxN + 7) / 8), 2, B), dim3(256), tabLds, WS.stream, D, dP, in.feats, WS.tabPool.as<double>());
+    DBG(c, "k_tables");
     }
     {   // single scores, then the ordered compaction of the live associations: chunks x problems
         const int maxChunks = std::max(1, (maxA + LIVE_CHUNK - 1) / LIVE_CHUNK);
         HIPCHK(c, WS.chunkCnt.ensure(sizeof(int32_t) * (size_t)B * (size_t)maxChunks));
         hipLaunchKernelGGL(k_live<0>, dim3((unsigned)maxChunks, (unsigned)B), dim3(256), 0, WS.stream, D, dP, dS, in.feats, in.assoc, WS.cosPool.as<double>(), WS.sTmp.as<double>(),
-                           WS.chunkCnt.as<int32_t>(), maxChunks,
-                           WS.lp.as<int32_t>(), WS.li.as<int32_t>(), WS.lj.as<int32_t>(), WS.ls.as<double>(), WS.ld.as<double>(), WS.lza.as<double>(), WS.lzb.as<double>());
+                           WS.chunkCnt.as<int32_t>(), maxChunks, LP.lp, LP.li, LP.lj, LP.ls, LP.ld, LP.lza, LP.lzb);
         hipLaunchKernelGGL(k_live<1>, dim3((unsigned)maxChunks, (unsigned)B), dim3(256), 0, WS.stream, D, dP, dS, in.feats, in.assoc, WS.cosPool.as<double>(), WS.sTmp.as<double>(),
-                           WS.chunkCnt.as<int32_t>(), maxChunks,
-                           WS.lp.as<int32_t>(), WS.li.as<int32_t>(), WS.lj.as<int32_t>(), WS.ls.as<double>(), WS.ld.as<double>(), WS.lza.as<double>(), WS.lzb.as<double>());
+                           WS.chunkCnt.as<int32_t>(), maxChunks, LP.lp, LP.li, LP.lj, LP.ls, LP.ld, LP.lza, LP.lzb);
+    DBG(c, "k_live");
     }
-    hipLaunchKernelGGL(k_rowbase, dim3(1), dim3(64), 0, WS.stream, B, RPB, dS, dT);
+    hipLaunchKernelGGL(k_rowbase, dim3(1), dim3(64), 0, WS.stream, B, RPB, SZ.capMaskWords, dS, dT);
+    DBG(c, "k_rowbase");
     hipLaunchKernelGGL(k_items, dim3(B), dim3(256), 0, WS.stream, RPB, dS, WS.items.as<ItemDesc>());
-    // read-back #1 (24 bytes): live totals -> size of the candidate bit matrices, index width
-    HIPCHK(c, hipMemcpyAsync(WS.pinnedTotals, dT, sizeof(BatchTotals), hipMemcpyDeviceToHost, WS.stream));
+    DBG(c, "k_items");
     t0.stop();
-    HIPCHK(c, hipStreamSynchronize(WS.stream));
-    BatchTotals tot = *WS.pinnedTotals;
-    *idx16 = tot.maxL <= 32767;        // column indices are LIVE indices; bit 15 is the C==0 flag
-    HIPCHK(c, WS.maskPool.ensure(sizeof(unsigned long long) * (size_t)std::max<int64_t>(tot.maskWords, 1)));
-    HIPCHK(c, WS.prefPool.ensure(sizeof(uint32_t) * (size_t)std::max<int64_t>(tot.maskWords, 1)));
 
     // pair-test kernel LDS: a column tile (objects [+ z] of every live association) + per wave the table rows of
-    // the NR rows it sweeps together (NR = 2 if that fits beside the whole column tile, else 1)
+    // the NR rows it sweeps together (NR = 2 if that fits beside the whole column tile, else 1).  The tile is sized
+    // for the EXPECTED largest live set; a problem that exceeds it reads its columns from memory instead.
+    const int expL = std::max(SZ.expectMaxL, 1);
     const int ldsPerRow = ((2 * std::max(maxN, 1) + 1 + 1) & ~1) + 2;     // n1 + sentinel + n2 doubles
     const int colBytesC = D.gravity ? 24 : 8;
-    const int Lneed = (std::max(tot.maxL, 1) + 255) & ~255;
+    const int Lneed = (expL + 255) & ~255;
     int NRc = ((size_t)16 * 2 * ldsPerRow * sizeof(double) + (size_t)Lneed * colBytesC <= c->lds_max) ? 2 : 1;
     int wpb = 16;
     while (wpb > 1 && (size_t)wpb * NRc * ldsPerRow * sizeof(double) + 256 * colBytesC > c->lds_max) wpb >>= 1;
@@ -350,7 +406,7 @@ int stage_score(roman_ctx* c, const DevParams& D, const BatchIn& in, std::vector
     const int pairGrid = c->num_cu * std::max(1, std::min(2048 / (wpb * 64), (int)(c->lds_max / pairLds)));
 
     StageTimer t1(c, ROMAN_STAGE_COUNT_PASS);
-    if (tot.R > 0) {
+    if (sumA > 0) {
         auto kc = NRc == 2 ? k_count<0, 2> : k_count<0, 1>;
         switch (D.gmode) {
         case 1: kc = NRc == 2 ? k_count<1, 2> : k_count<1, 1>; break;
@@ -360,145 +416,91 @@ int stage_score(roman_ctx* c, const DevParams& D, const BatchIn& in, std::vector
         }
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kc), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pairLds));
         hipLaunchKernelGGL(kc, dim3(pairGrid), dim3(wpb * 64), pairLds, WS.stream, D, dP, dS, dT, WS.items.as<ItemDesc>(), WS.tabPool.as<double>(),
-                           WS.li.as<int32_t>(), WS.lj.as<int32_t>(), WS.lza.as<double>(), WS.lzb.as<double>(),
+                           LP.li, LP.lj, LP.lza, LP.lzb,
                            WS.rowCnt.as<uint32_t>(), WS.maskPool.as<unsigned long long>(), WS.prefPool.as<uint32_t>(), TCc, ldsPerWave, RPB);
-        // lower triangle of the bit matrices = transposed blocks of the upper triangle
-        {
-            const int Wmax = (tot.maxL + 63) / 64;
-            const int tasks = ((Wmax + 7) / 8) * ((std::max(Wmax - 1, 1) + 7) / 8);          // workgroups of 8 waves
-            hipLaunchKernelGGL(k_mirror, dim3((unsigned)tasks, (unsigned)B), dim3(512), 0, WS.stream, dS, WS.maskPool.as<unsigned long long>());
+    DBG(c, "k_count");
+        {   // lower triangle of the bit matrices = transposed blocks of the upper triangle (grid for the expected size;
+            // the kernel loops when a problem is larger)
+            const int Wexp = (expL + 63) / 64;
+            const int tasks = ((Wexp + 7) / 8) * ((std::max(Wexp - 1, 1) + 7) / 8);          // workgroups of 8 waves
+            hipLaunchKernelGGL(k_mirror, dim3((unsigned)std::max(tasks, 1), (unsigned)B), dim3(512), 0, WS.stream, dS, WS.maskPool.as<unsigned long long>());
+    DBG(c, "k_mirror");
         }
         hipLaunchKernelGGL(k_rowprefix, dim3(c->num_cu * 2), dim3(1024), 0, WS.stream, dP, dS, dT, WS.items.as<ItemDesc>(),
                            WS.maskPool.as<unsigned long long>(), WS.prefPool.as<uint32_t>(), WS.rowCnt.as<uint32_t>(), RPB);
+    DBG(c, "k_rowprefix");
+        hipLaunchKernelGGL(k_rowsort, dim3(B), dim3(1024), 0, WS.stream, dP, dS, WS.rowCnt.as<uint32_t>(), WS.rowPos.as<uint32_t>(), WS.perm.as<uint32_t>(),
+                           WS.sliceWidth.as<uint32_t>(), WS.sliceBase.as<uint32_t>());
+    DBG(c, "k_rowsort");
+        hipLaunchKernelGGL(k_permute, dim3(c->num_cu * 2), dim3(1024), 0, WS.stream, dP, dS, dT, WS.items.as<ItemDesc>(),
+                           WS.maskPool.as<unsigned long long>(), WS.umaskPool.as<unsigned long long>(), WS.prefPool.as<uint32_t>(),
+                           WS.rowCnt.as<uint32_t>(), WS.perm.as<uint32_t>(), LP, PP, RPB);
+    DBG(c, "k_permute");
+        hipLaunchKernelGGL(k_slicegeom, dim3(B), dim3(64), 0, WS.stream, dP, dS, WS.rowCnt.as<uint32_t>(), WS.sliceWidth.as<uint32_t>(), WS.sliceBase.as<uint32_t>());
+    DBG(c, "k_slicegeom");
     }
-    const bool quad = use_quad(D, tot.maxL);
-    hipLaunchKernelGGL(k_rowsort, dim3(B), dim3(1024), 0, WS.stream, quad ? 4 : 1, dP, dS, WS.rowCnt.as<uint32_t>(), WS.rowPos.as<uint32_t>(), WS.perm.as<uint32_t>(),
-                       WS.sliceWidth.as<uint32_t>(), WS.sliceBase.as<uint32_t>());
     // k_fill_slice work items: groups of SPI consecutive slices of one problem, about 3 per CU for the whole batch
-    const int SPI = (int)std::min<int64_t>(FILLS_MAXSPI, std::max<int64_t>(1, ((int64_t)tot.R / 64 + B + 3 * c->num_cu - 1) / (3 * (int64_t)c->num_cu)));
-    hipLaunchKernelGGL(k_probscan, dim3(1), dim3(64), 0, WS.stream, B, SPI, dS, dT);
-    // read-back #2: padded slot total -> size of the matrix arrays
-    HIPCHK(c, hipMemcpyAsync(WS.pinnedTotals, dT, sizeof(BatchTotals), hipMemcpyDeviceToHost, WS.stream));
+    const double expR = c->hist.valid && D.single ? std::min<double>((double)sumA, c->hist.rMaxL * (double)sumA * 1.2) : (double)sumA;
+    const int SPI = (int)std::min<int64_t>(FILLS_MAXSPI, std::max<int64_t>(1, ((int64_t)(expR / 64.0) + B + 3 * c->num_cu - 1) / (3 * (int64_t)c->num_cu)));
+    hipLaunchKernelGGL(k_probscan, dim3(1), dim3(64), 0, WS.stream, B, SPI, SZ.capNnz, dS, dT);
+    DBG(c, "k_probscan");
     t1.stop();
-    HIPCHK(c, hipStreamSynchronize(WS.stream));
-    tot = *WS.pinnedTotals;
-    *totOut = tot;
-    const size_t nnz1 = (size_t)std::max<int64_t>(tot.nnzTotal, 1);
-    HIPCHK(c, WS.vals.ensure(sizeof(double) * nnz1));
-    HIPCHK(c, WS.cols.ensure((*idx16 ? sizeof(uint16_t) : sizeof(uint32_t)) * nnz1));
 
     StageTimer t2(c, ROMAN_STAGE_FILL);
-    bool sliceFill = false;
-    if (tot.R > 0 && quad) {
-        // slice-image fill: column tile + one slice image (640 bytes per entry column) + 16 candidate rings
+    if (sumA > 0) {
+        // slice-image fill (stream layout): column tile + one slice image (640 bytes per entry column) + 16 owner lines
         const int colBytesF = D.gravity ? 32 : 16;
-        const int TCs = (std::max(tot.maxL, 1) + 63) & ~63;
-        const size_t fixedLds = (size_t)TCs * colBytesF + (size_t)16 * 64 * sizeof(uint32_t) + (size_t)FILLS_MAXSPI * 64 * sizeof(uint32_t);
-        if (fixedLds + 640 * 8 <= c->lds_max && ((tot.maxL + 63) / 64) * 4 <= FILLS_NBLK * 64) {
-            const int EC = (int)std::min<size_t>((c->lds_max - fixedLds) / 640, 4096) & ~3;
-            const size_t sliceLds = fixedLds + (size_t)EC * 640;
-            auto kf = D.gravity ? k_fill_slice<true> : k_fill_slice<false>;
-            unsigned long long* fdbg = nullptr;
-#ifdef ROMAN_FILL_TIMING
-            HIPCHK(c, WS.hAux3.ensure(sizeof(unsigned long long) * 8));
-            HIPCHK(c, hipMemsetAsync(WS.hAux3.p, 0, sizeof(unsigned long long) * 8, WS.stream));
-            fdbg = WS.hAux3.as<unsigned long long>();
-#endif
-            HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sliceLds));
-            hipLaunchKernelGGL(kf, dim3((unsigned)std::min<int64_t>(c->num_cu & ~7, (std::max<int64_t>(tot.sliceGroups, 1) + 7) / 8 * 8)), dim3(1024), sliceLds, WS.stream,
-                               D, B, dP, dS, dT, WS.tabPool.as<double>(),
-                               WS.li.as<int32_t>(), WS.lj.as<int32_t>(), WS.ls.as<double>(), WS.lza.as<double>(), WS.lzb.as<double>(),
-                               WS.maskPool.as<unsigned long long>(), WS.prefPool.as<uint32_t>(), WS.perm.as<uint32_t>(),
-                               WS.sliceWidth.as<uint32_t>(), WS.sliceBase.as<uint32_t>(), WS.cols.as<uint16_t>(), WS.vals.as<double>(), TCs, EC, SPI, fdbg);
-            sliceFill = true;
-#ifdef ROMAN_FILL_TIMING
-            {
-                unsigned long long h[8];
-                HIPCHK(c, hipMemcpyAsync(h, fdbg, sizeof(h), hipMemcpyDeviceToHost, WS.stream));
-                HIPCHK(c, hipStreamSynchronize(WS.stream));
-                const double nwaves = 16.0 * std::min<int64_t>(c->num_cu, std::max<int64_t>(tot.sliceGroups, 1));
-                const char* nm[8] = {"stage", "init+barrier", "bitsteps", "gather-wait", "math+store", "end-barrier", "write-out", "tail"};
-                fprintf(stderr, "[fill timing] B=%d cycles/wave:", B);
-                double tt = 0; for (int t = 0; t < 8; ++t) tt += (double)h[t] / nwaves;
-                for (int t = 0; t < 8; ++t) fprintf(stderr, " %s %.0f", nm[t], (double)h[t] / nwaves);
-                fprintf(stderr, " total %.0f\n", tt);
-            }
-#endif
+        const int TCs = D.stream_maxL;
+        const size_t fixedLds = (size_t)TCs * colBytesF + (size_t)16 * 64 * sizeof(uint32_t);
+        if (fixedLds + 640 * 8 > c->lds_max) return fail(c, ROMAN_E_TOO_LARGE, "internal: stream column tile does not fit the LDS");
+        const int EC = (int)std::min<size_t>((c->lds_max - fixedLds) / 640, 4096) & ~3;
+        const size_t sliceLds = fixedLds + (size_t)EC * 640;
+        auto kf = D.gravity ? k_fill_slice<true> : k_fill_slice<false>;
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sliceLds));
+        hipLaunchKernelGGL(kf, dim3((unsigned)(c->num_cu & ~7)), dim3(1024), sliceLds, WS.stream,
+                           D, B, dP, dS, dT, WS.tabPool.as<double>(), PP.li, PP.lj, PP.ls, PP.lza, PP.lzb,
+                           WS.umaskPool.as<unsigned long long>(), WS.prefPool.as<uint32_t>(),
+                           WS.sliceWidth.as<uint32_t>(), WS.sliceBase.as<uint32_t>(), WS.cols16.as<uint16_t>(), WS.vals.as<double>(), TCs, EC, SPI,
+                           (unsigned long long*)nullptr);
+    DBG(c, "k_fill_slice");
+        // fallback layout (symmetric SELL-64, 32-bit indices) for the problems the stream layout does not take: only when
+        // one can exist (the kernel would find no work otherwise)
+        if (SZ.maxA > D.stream_maxL) {
+            const int colBytesG = D.gravity ? 36 : 20;
+            const size_t ringLds = (size_t)16 * 3 * FILL_Q * sizeof(uint32_t);
+            int TCf = (int)std::min<size_t>((c->lds_max - ringLds) / colBytesG, 32768) & ~63;
+            TCf = std::min(TCf, Lneed);
+            const size_t fillLds = ringLds + (size_t)TCf * colBytesG;
+            const int fillGrid = c->num_cu * std::max(1, std::min(2, (int)(c->lds_max / fillLds)));
+            auto kg = D.gravity ? k_fill<true, uint32_t, false> : k_fill<false, uint32_t, false>;
+            HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kg), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fillLds));
+            hipLaunchKernelGGL(kg, dim3(fillGrid), dim3(1024), fillLds, WS.stream, D, dP, dS, dT, WS.items.as<ItemDesc>(), WS.tabPool.as<double>(),
+                               LP.li, LP.lj, LP.ls, LP.lza, LP.lzb,
+                               WS.rowCnt.as<uint32_t>(), WS.maskPool.as<unsigned long long>(), WS.prefPool.as<uint32_t>(), WS.rowPos.as<uint32_t>(),
+                               WS.sliceWidth.as<uint32_t>(), WS.sliceBase.as<uint32_t>(), WS.cols32.as<uint32_t>(), WS.vals.as<double>(), TCf, RPB);
+    DBG(c, "k_fill");
         }
     }
-    if (tot.R > 0 && !sliceFill) {
-        // fill kernel LDS: column tile (objects, single score, [z,] SELL slot base) + per-wave candidate rings
-        const int colBytesF = D.gravity ? 36 : 20;
-        const size_t ringLds = (size_t)16 * 3 * FILL_Q * sizeof(uint32_t);
-        int TCf = (int)std::min<size_t>((c->lds_max - ringLds) / colBytesF, 32768) & ~63;
-        TCf = std::min(TCf, Lneed);
-        const size_t fillLds = ringLds + (size_t)TCf * colBytesF;
-        const int fillGrid = c->num_cu * std::max(1, std::min(2, (int)(c->lds_max / fillLds)));
-#define ROMAN_LAUNCH_FILL(GRAV_, IDX, QUAD_)                                                                                          \
-        do {                                                                                                                   \
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_fill<GRAV_, IDX, QUAD_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fillLds)); \
-        hipLaunchKernelGGL((k_fill<GRAV_, IDX, QUAD_>), dim3(fillGrid), dim3(1024), fillLds, WS.stream, D, dP, dS, dT, WS.items.as<ItemDesc>(), WS.tabPool.as<double>(), \
-                           WS.li.as<int32_t>(), WS.lj.as<int32_t>(), WS.ls.as<double>(), WS.lza.as<double>(), WS.lzb.as<double>(),          \
-                           WS.rowCnt.as<uint32_t>(), WS.maskPool.as<unsigned long long>(), WS.prefPool.as<uint32_t>(), WS.rowPos.as<uint32_t>(), \
-                           WS.sliceWidth.as<uint32_t>(), WS.sliceBase.as<uint32_t>(), WS.cols.as<IDX>(), WS.vals.as<double>(), TCf, RPB);        \
-        } while (0)
-        if (quad)        { if (D.gravity) ROMAN_LAUNCH_FILL(true, uint16_t, true); else ROMAN_LAUNCH_FILL(false, uint16_t, true); }
-        else if (*idx16) { if (D.gravity) ROMAN_LAUNCH_FILL(true, uint16_t, false); else ROMAN_LAUNCH_FILL(false, uint16_t, false); }
-        else             { if (D.gravity) ROMAN_LAUNCH_FILL(true, uint32_t, false); else ROMAN_LAUNCH_FILL(false, uint32_t, false); }
-#undef ROMAN_LAUNCH_FILL
-    }
     t2.stop();
+    // the totals travel back on their own: whoever sizes a later batch picks them up once they have arrived
+    HIPCHK(c, hipMemcpyAsync(WS.pinnedTotals, dT, sizeof(BatchTotals), hipMemcpyDeviceToHost, WS.stream));
+    HIPCHK(c, hipEventRecord(WS.totEvent, WS.stream));
+    WS.totPending = true; WS.totMaskBound = SZ.maskBound; WS.totSumA = SZ.sumA; WS.totMaxA = SZ.maxA;
     HIPCHK(c, hipGetLastError());
     return ROMAN_OK;
 }
 
-// Stage B: solver + rounding + pose on the CSR held by the context.  `feats` may be NULL (dense
-// matrix problems have no points: the pose is skipped).
-int stage_solve(roman_ctx* c, const DevParams& Din, int B, const double* feats, const int32_t* assoc,
-                const double* u0, const BatchTotals& tot, bool idx16, bool hascz, int32_t kmax,
-                int32_t* assoc_out, int32_t* n_assoc_out, double* T_out, int32_t* status_out,
-                roman_stats_t* stats_out)
+// Solver + rounding + pose on the matrices held by the workspace.  `feats` may be NULL (dense
+// matrix problems have no points: the pose is skipped).  mayFallback: a problem of the fallback kind can exist.
+int enqueue_solve(roman_ctx* c, const DevParams& D, int B, int64_t sumA, const double* feats, const int32_t* assoc,
+                  const double* u0, bool hascz, bool mayFallback, const BatchOut& out)
 {
-    DevParams D = Din;
-    // Column compaction pays when the SpMV passes compete for HBM (many problems in flight), and then only twice
-    // per problem; a lone problem streams its matrix from L2/MALL faster than it can be copied (p50 of a single
-    // pair: 1.00 ms with compaction, 0.89 ms without).  ROMAN_MAX_COMPACT overrides the budget (tuning only:
-    // every level pass is exact, the results do not depend on it).
-    {
-        static const char* env = getenv("ROMAN_MAX_COMPACT");
-        D.max_compact = env ? atoi(env) : ((B >= c->num_cu / 4) ? 2 : 0);
-    }
-    const size_t R1 = (size_t)std::max(tot.R, 1);
-    HIPCHK(c, WS.vMu.ensure(sizeof(double) * R1)); HIPCHK(c, WS.vCu.ensure(sizeof(double) * R1));
-    HIPCHK(c, WS.vMun.ensure(sizeof(double) * R1)); HIPCHK(c, WS.vCun.ensure(sizeof(double) * R1));
+    const size_t R1 = (size_t)std::max<int64_t>(sumA, 1);
     HIPCHK(c, WS.uOut.ensure(sizeof(double) * R1)); HIPCHK(c, WS.nodesOrig.ensure(sizeof(int32_t) * R1));
     HIPCHK(c, WS.nSel.ensure(sizeof(int32_t) * (size_t)B));
-
-    // fast path: streaming solver on the quad layout with column-compacted levels
-    const bool regPath = use_quad(D, tot.maxL);
-    // LDS of the fallback solver: NVEC vectors of Lcap doubles + 72 doubles of reduction scratch + 4 ints
-    const size_t fixed = 72 * sizeof(double) + 4 * sizeof(int);
-    int Lcap = (std::max(tot.maxL, 64) + 1) & ~1;
-    int mode = 1;
-    if (2 * sizeof(double) * (size_t)Lcap + fixed > c->lds_max) { mode = 0; Lcap = 0; }
-    if (regPath) Lcap = (std::max(tot.maxL, 64) + 1) & ~1;
-    const int nvec = mode == 1 ? 2 : 0;
-    HIPCHK(c, WS.gU.ensure(sizeof(double) * ((mode == 0 && !regPath) ? R1 : 1))); HIPCHK(c, WS.gUn.ensure(sizeof(double) * ((mode == 0 && !regPath) ? R1 : 1)));
-    size_t lds = (size_t)nvec * sizeof(double) * (size_t)Lcap + fixed;
-    if (regPath) {
-        Lcap = (tot.maxL + 2 + 1) & ~1;                            // vector length incl. the dummy element [L]
-        lds = stream_lds_bytes(tot.maxL);
-        const size_t nnz1 = (size_t)std::max<int64_t>(tot.nnzTotal, 1);
-        HIPCHK(c, WS.vals1.ensure(sizeof(double) * nnz1)); HIPCHK(c, WS.cols1.ensure(sizeof(uint16_t) * nnz1));
-        HIPCHK(c, WS.vals2.ensure(sizeof(double) * nnz1)); HIPCHK(c, WS.cols2.ensure(sizeof(uint16_t) * nnz1));
-        HIPCHK(c, WS.vals3.ensure(sizeof(double) * nnz1)); HIPCHK(c, WS.cols3.ensure(sizeof(uint16_t) * nnz1));
-    }
-    const int nt = regPath ? ST_NW * 64 : 1024;
-    const int grid = std::max(1, std::min(B, c->num_cu));
-
-    HIPCHK(c, hipMemsetAsync(WS.queue.p, 0, sizeof(int) * 4, WS.stream));
+    HIPCHK(c, hipMemsetAsync(WS.queue.p, 0, sizeof(int) * 8, WS.stream));
     SolveOut O;
-    O.assoc_out = assoc_out; O.n_assoc_out = n_assoc_out; O.T_out = T_out; O.status_out = status_out; O.stats_out = stats_out; O.kmax = kmax;
+    O.assoc_out = out.assoc_out; O.n_assoc_out = out.n_assoc_out; O.T_out = out.T_out; O.status_out = out.status_out; O.stats_out = out.stats_out; O.kmax = out.kmax;
     O.nodesOrig = WS.nodesOrig.as<int32_t>(); O.nSel = WS.nSel.as<int32_t>(); O.uOut = WS.uOut.as<double>();
     O.dbg = nullptr;
 #ifdef ROMAN_SOLVE_TIMING
@@ -506,39 +508,53 @@ int stage_solve(roman_ctx* c, const DevParams& Din, int B, const double* feats, 
     HIPCHK(c, hipMemsetAsync(WS.hAux3.p, 0, sizeof(unsigned long long) * 16 * (size_t)B, WS.stream));
     O.dbg = WS.hAux3.as<unsigned long long>();
 #endif
+    // stream solver: LDS = three vectors of Lc elements (Lc: whole slices of stream_maxL + the 64 dummy elements the
+    // inert padding entries point at) + reduction scratch + slice table
+    constexpr int NW = ROMAN_SOLVE_WAVES;
+    const int Lc = ((D.stream_maxL + 63) & ~63) + 64;
+    const size_t ldsUp = (size_t)3 * 8 * Lc + sizeof(double) * (2 * NW * RED_STRIDE + 8) + sizeof(uint32_t) * (ST_MAXSL + 2) + sizeof(int) * 4 + 16;
+    const int wgPerCu = std::max(1, std::min((int)(c->lds_max / ldsUp), 2048 / (NW * 64)));
+    const int gridUp = std::max(1, std::min(B, c->num_cu * wgPerCu));
 
     StageTimer t3(c, ROMAN_STAGE_SOLVE);
-#define ROMAN_LAUNCH_SOLVE(IDX, MODE_)                                                                                        \
+    hipLaunchKernelGGL(k_skipped, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, WS.stream, B, WS.probs.as<ProbDesc>(), WS.state.as<ProbState>(), O);
+    DBG(c, "k_skipped");
+#define ROMAN_LAUNCH_UP(CZ_)                                                                                                  \
     do {                                                                                                                      \
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve<IDX, MODE_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL((k_solve<IDX, MODE_>), dim3(grid), dim3(nt), lds, WS.stream, D, B, WS.probs.as<ProbDesc>(), WS.state.as<ProbState>(), feats, assoc, \
-                           WS.lp.as<int32_t>(), WS.ld.as<double>(), WS.perm.as<uint32_t>(), WS.sliceWidth.as<uint32_t>(), WS.sliceBase.as<uint32_t>(), WS.cols.as<IDX>(), WS.vals.as<double>(), \
-                           WS.vMu.as<double>(), WS.vCu.as<double>(), WS.vMun.as<double>(), WS.vCun.as<double>(), WS.gU.as<double>(), WS.gUn.as<double>(), \
-                           u0, O, WS.queue.as<int>(), Lcap);                                                                   \
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve_up<NW, CZ_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsUp)); \
+        hipLaunchKernelGGL((k_solve_up<NW, CZ_>), dim3(gridUp), dim3(NW * 64), ldsUp, WS.stream, D, B, WS.probs.as<ProbDesc>(), WS.state.as<ProbState>(), feats, assoc, \
+                           WS.plp.as<int32_t>(), WS.lp.as<int32_t>(), WS.rowPos.as<uint32_t>(), WS.pld.as<double>(), WS.sliceBase.as<uint32_t>(), \
+                           WS.cols16.as<uint16_t>(), WS.vals.as<double>(), u0, O, WS.queue.as<int>(), Lc);                     \
     } while (0)
-#define ROMAN_LAUNCH_SOLVE_STREAM(CZ_)                                                                                        \
-    do {                                                                                                                      \
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve_stream<CZ_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL((k_solve_stream<CZ_>), dim3(grid), dim3(nt), lds, WS.stream, D, B, WS.probs.as<ProbDesc>(), WS.state.as<ProbState>(), feats, assoc, \
-                           WS.lp.as<int32_t>(), WS.ld.as<double>(), WS.perm.as<uint32_t>(), WS.sliceBase.as<uint32_t>(), \
-                           WS.cols.as<uint16_t>(), WS.vals.as<double>(), WS.cols1.as<uint16_t>(), WS.vals1.as<double>(), WS.cols2.as<uint16_t>(), WS.vals2.as<double>(), \
-                           WS.cols3.as<uint16_t>(), WS.vals3.as<double>(), u0, O, WS.queue.as<int>(), Lcap);                    \
-    } while (0)
-    if (regPath) { if (hascz) ROMAN_LAUNCH_SOLVE_STREAM(true); else ROMAN_LAUNCH_SOLVE_STREAM(false); }
-    else if (idx16) { if (mode == 1) ROMAN_LAUNCH_SOLVE(uint16_t, 1); else ROMAN_LAUNCH_SOLVE(uint16_t, 0); }
-    else            { if (mode == 1) ROMAN_LAUNCH_SOLVE(uint32_t, 1); else ROMAN_LAUNCH_SOLVE(uint32_t, 0); }
-#undef ROMAN_LAUNCH_SOLVE_STREAM
-#undef ROMAN_LAUNCH_SOLVE
+    if (hascz) ROMAN_LAUNCH_UP(true); else ROMAN_LAUNCH_UP(false);
+#undef ROMAN_LAUNCH_UP
+    DBG(c, "k_solve_up");
+    if (mayFallback) {
+        // fallback solver (symmetric SELL-64, 32-bit indices): u and u' in LDS when they fit, everything in HBM otherwise
+        HIPCHK(c, WS.vMu.ensure(sizeof(double) * R1)); HIPCHK(c, WS.vCu.ensure(sizeof(double) * R1));
+        HIPCHK(c, WS.vMun.ensure(sizeof(double) * R1)); HIPCHK(c, WS.vCun.ensure(sizeof(double) * R1));
+        HIPCHK(c, WS.gU.ensure(sizeof(double) * R1)); HIPCHK(c, WS.gUn.ensure(sizeof(double) * R1));
+        const size_t fixed = 72 * sizeof(double) + 4 * sizeof(int);
+        const int Lcap = (int)(((c->lds_max - fixed) / (2 * sizeof(double))) & ~(size_t)1);
+        const size_t lds = (size_t)2 * sizeof(double) * (size_t)Lcap + fixed;
+        const int grid = std::max(1, std::min(B, c->num_cu));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve<uint32_t, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((k_solve<uint32_t, 1>), dim3(grid), dim3(1024), lds, WS.stream, D, B, WS.probs.as<ProbDesc>(), WS.state.as<ProbState>(), feats, assoc,
+                           WS.lp.as<int32_t>(), WS.ld.as<double>(), WS.perm.as<uint32_t>(), WS.sliceWidth.as<uint32_t>(), WS.sliceBase.as<uint32_t>(), WS.cols32.as<uint32_t>(), WS.vals.as<double>(),
+                           WS.vMu.as<double>(), WS.vCu.as<double>(), WS.vMun.as<double>(), WS.vCun.as<double>(), WS.gU.as<double>(), WS.gUn.as<double>(),
+                           u0, O, WS.queue.as<int>() + 4, Lcap);
+    DBG(c, "k_solve");
+    }
     t3.stop();
     HIPCHK(c, hipGetLastError());
 #ifdef ROMAN_SOLVE_TIMING
-    if (regPath) {
+    {
         std::vector<unsigned long long> h((size_t)B * 16);
         HIPCHK(c, hipMemcpyAsync(h.data(), WS.hAux3.p, sizeof(unsigned long long) * 16 * (size_t)B, hipMemcpyDeviceToHost, WS.stream));
         HIPCHK(c, hipStreamSynchronize(WS.stream));
         double acc[16] = {0};
         for (int b = 0; b < B; ++b) for (int t = 0; t < 16; ++t) acc[t] += (double)h[(size_t)b * 16 + t];
-        const char* nm[8] = {"stream", "spmv-barrier", "combine", "other", "compact0", "compactN", "red-norm", "red-sums"};
+        const char* nm[8] = {"stream", "spmv-barrier", "decode", "elementwise", "-", "-", "publish", "red-sums"};
         fprintf(stderr, "[solve timing] B=%d cycles/problem:", B);
         double tot_ = 0; for (int t = 0; t < 8; ++t) tot_ += acc[t] / B;
         for (int t = 0; t < 8; ++t) fprintf(stderr, " %s %.0f (n=%.1f)", nm[t], acc[t] / B, acc[8 + t] / B);
@@ -547,7 +563,7 @@ int stage_solve(roman_ctx* c, const DevParams& Din, int B, const double* feats, 
             std::vector<std::pair<double, int>> tt;
             for (int b = 0; b < B; ++b) { double t_ = 0; for (int t = 0; t < 8; ++t) t_ += (double)h[(size_t)b * 16 + t]; tt.push_back({t_, b}); }
             std::sort(tt.begin(), tt.end());
-            for (int r = 0; r < 4; ++r) {
+            for (int r = 0; r < 3; ++r) {
                 const int b = tt[(size_t)(B - 1 - r)].second;
                 fprintf(stderr, "   slow #%d (b=%d, %.0f cyc):", r, b, tt[(size_t)(B - 1 - r)].first);
                 for (int t = 0; t < 8; ++t) fprintf(stderr, " %s %.0f (n=%.0f)", nm[t], (double)h[(size_t)b * 16 + t], (double)h[(size_t)b * 16 + 8 + t]);
@@ -560,6 +576,13 @@ int stage_solve(roman_ctx* c, const DevParams& Din, int B, const double* feats, 
     return ROMAN_OK;
 }
 
+bool may_fallback(const DevParams& D, const std::vector<ProbDesc>& hd)
+{
+    if (D.p.maxiniters < 1 || D.p.maxlsiters < 1) return true;
+    for (const ProbDesc& d : hd) if (d.nA > D.stream_maxL) return true;
+    return false;
+}
+
 int ensure_events(roman_ctx* c)
 {
     for (int k = 0; k < ROMAN_MAX_PIPELINE; ++k)
@@ -568,6 +591,29 @@ int ensure_events(roman_ctx* c)
             if (!c->ws[k].evB[s]) HIPCHK(c, hipEventCreate(&c->ws[k].evB[s]));
         }
     return ROMAN_OK;
+}
+
+// one batch through the stages, on workspace c->cur and its stream (pure enqueue)
+int run_batch(roman_ctx* c, const DevParams& D0, const roman_params_t* params, const BatchIn& in, const double* u0, const BatchOut& out)
+{
+    std::vector<ProbDesc> hd;
+    DevParams D;
+    int rc = enqueue_score(c, D0, params, in, hd, &D);
+    if (rc) return rc;
+    int64_t sumA = 0; for (const ProbDesc& d : hd) sumA += d.nA;
+    return enqueue_solve(c, D, in.B, sumA, in.feats, in.assoc, u0, false, may_fallback(D, hd), out);
+}
+
+// After a synchronous run: did every problem fit its workspace?  (reads the totals the batch copied back; the stream
+// has been synchronised by the caller).  On overflow the history now holds the need: the caller runs the batch again.
+bool batch_overflowed(roman_ctx* c)
+{
+    harvest_totals(c, true);
+    static const bool dbg = getenv("ROMAN_DEBUG") != nullptr;
+    const BatchTotals& t = *WS.pinnedTotals;
+    if (dbg) fprintf(stderr, "[roman] batch totals: R=%d maxL=%d items=%d maskWords need %lld cap %lld, nnz need %lld cap %lld, overflow=%d sliceGroups=%d\n",
+                     t.R, t.maxL, t.items, (long long)t.needMaskWords, WS.capMaskWords, (long long)t.needNnz, WS.capNnz, t.overflow, t.sliceGroups);
+    return t.overflow > 0;
 }
 
 // run a B=1 solve on the matrices held by the context and pull the solution to the host
@@ -587,8 +633,8 @@ int solve_last(roman_ctx* c, const double* u0_host)
     HIPCHK(c, WS.oT.ensure(sizeof(double) * 16)); HIPCHK(c, WS.oStatus.ensure(sizeof(int32_t))); HIPCHK(c, WS.oStats.ensure(sizeof(roman_stats_t)));
     const double* feats = Lst.dense ? nullptr : WS.hFeats.as<double>();
     const int32_t* assoc = (Lst.pd.assocOff >= 0) ? WS.hAssoc.as<int32_t>() : nullptr;
-    int rc = stage_solve(c, Lst.D, 1, feats, assoc, dU0, Lst.tot, Lst.idx16, Lst.hascz, kmax, WS.oAssoc.as<int32_t>(), WS.oN.as<int32_t>(),
-                         WS.oT.as<double>(), WS.oStatus.as<int32_t>(), WS.oStats.as<roman_stats_t>());
+    const BatchOut out{kmax, WS.oAssoc.as<int32_t>(), WS.oN.as<int32_t>(), WS.oT.as<double>(), WS.oStatus.as<int32_t>(), WS.oStats.as<roman_stats_t>()};
+    int rc = enqueue_solve(c, Lst.D, 1, nA, feats, assoc, dU0, Lst.hascz, Lst.kind == 1, out);
     if (rc) return rc;
     int32_t nsel = 0;
     HIPCHK(c, hipMemcpyAsync(&nsel, WS.nSel.p, sizeof(int32_t), hipMemcpyDeviceToHost, WS.stream));
@@ -597,23 +643,24 @@ int solve_last(roman_ctx* c, const double* u0_host)
     HIPCHK(c, hipStreamSynchronize(WS.stream));
     Lst.nsel = nsel;
     Lst.nodes.assign((size_t)std::max(nsel, 0), 0);
-    const int L = Lst.tot.R;
+    const int L = Lst.L;
     std::vector<double> ul((size_t)std::max(L, 1)); std::vector<int32_t> lpv((size_t)std::max(L, 1));
     if (nsel > 0) HIPCHK(c, hipMemcpyAsync(Lst.nodes.data(), WS.nodesOrig.p, sizeof(int32_t) * (size_t)nsel, hipMemcpyDeviceToHost, WS.stream));
     if (L > 0) {
+        // u comes back indexed like the solver's vectors: by position (stream layout) or by live index (fallback);
+        // the matching association-index pool maps either to the caller's association order
         HIPCHK(c, hipMemcpyAsync(ul.data(), WS.uOut.p, sizeof(double) * (size_t)L, hipMemcpyDeviceToHost, WS.stream));
-        HIPCHK(c, hipMemcpyAsync(lpv.data(), WS.lp.p, sizeof(int32_t) * (size_t)L, hipMemcpyDeviceToHost, WS.stream));
+        HIPCHK(c, hipMemcpyAsync(lpv.data(), Lst.kind == 0 ? WS.plp.p : WS.lp.p, sizeof(int32_t) * (size_t)L, hipMemcpyDeviceToHost, WS.stream));
     }
     HIPCHK(c, hipStreamSynchronize(WS.stream));
     Lst.u.assign((size_t)nA, 0.0);
     for (int k = 0; k < L; ++k) Lst.u[(size_t)lpv[k]] = ul[k];
-    Lst.L = L;
     Lst.solved = true;
     return ROMAN_OK;
 }
 
-// Host twin of k_rowsort: sorted SELL-64 geometry from the row lengths (stable descending sort).
-void sell_geometry(const std::vector<uint32_t>& cnt, int L, int widthPad, std::vector<uint32_t>& rowPos, std::vector<uint32_t>& perm,
+// Host twin of the fallback branch of k_rowsort: sorted SELL-64 geometry from the row lengths (stable descending sort).
+void sell_geometry(const std::vector<uint32_t>& cnt, int L, std::vector<uint32_t>& rowPos, std::vector<uint32_t>& perm,
                    std::vector<uint32_t>& sliceWidth, std::vector<uint32_t>& sliceBase, uint64_t* total)
 {
     perm.resize((size_t)std::max(L, 1)); rowPos.assign((size_t)std::max(L, 1), 0);
@@ -626,55 +673,77 @@ void sell_geometry(const std::vector<uint32_t>& cnt, int L, int widthPad, std::v
     for (int sl = 0; sl < nsl; ++sl) {
         uint32_t wmax = 0;
         for (int p = sl * 64; p < std::min(L, sl * 64 + 64); ++p) wmax = std::max(wmax, cnt[perm[(size_t)p]]);
-        wmax = (wmax + (uint32_t)widthPad - 1u) / (uint32_t)widthPad * (uint32_t)widthPad;
         sliceWidth[(size_t)sl] = wmax; sliceBase[(size_t)sl] = (uint32_t)acc; acc += (uint64_t)wmax * 64u;
     }
     *total = acc;
 }
 
-// download the matrix of the last single problem and decode the sorted SELL-64 layout into per-row
-// lists over live indices: rs/rl index into cols/vals (row-contiguous on return); inert slots
-// (value 0 with the C flag and the row's own index) are dropped.
+// Download the matrix of the last single problem and decode it into per-row lists over LIVE indices, both triangles,
+// ascending columns: rs/rl index into cols/vals (row-contiguous on return; bit 31 of a column = "C_pq == 0"); inert
+// slots are dropped.  lp / diag: association index and diagonal value per live index.
 int fetch_last_csr(const roman_ctx* cc, std::vector<uint32_t>& rs, std::vector<uint32_t>& rl, std::vector<uint32_t>& cols,
                    std::vector<double>& vals, std::vector<int32_t>& lp, std::vector<double>& ls)
 {
     roman_ctx* c = const_cast<roman_ctx*>(cc);
     const roman_ctx::Last& Lst = c->last;
-    const int L = Lst.tot.R; const int64_t cap = Lst.tot.nnzTotal;
+    const int L = Lst.L; const int64_t cap = Lst.nnzCap;
     const size_t L1 = (size_t)std::max(L, 1), cap1 = (size_t)std::max<int64_t>(cap, 1);
-    std::vector<uint32_t> jcnt(L1, 0), jpos(L1, 0), jsw(L1, 0), jsb(L1, 0), jcols(cap1, 0); std::vector<double> jvals(cap1, 0.0);
+    std::vector<uint32_t> jcnt(L1, 0), jpos(L1, 0), jperm(L1, 0), jsw(L1, 0), jsb(L1, 0), jcols(cap1, 0); std::vector<double> jvals(cap1, 0.0);
     rs.assign(L1, 0); rl.assign(L1, 0); lp.assign(L1, 0); ls.assign(L1, 0.0);
     HIPCHK(c, hipSetDevice(c->device));
+    roman_ctx::Workspace& W0 = c->ws[0];
+    const bool up = Lst.kind == 0;
     if (L > 0) {
         const int nsl = (L + 63) / 64;
-        HIPCHK(c, hipMemcpy(jcnt.data(), WS.rowCnt.p, sizeof(uint32_t) * (size_t)L, hipMemcpyDeviceToHost));
-        HIPCHK(c, hipMemcpy(jpos.data(), WS.rowPos.p, sizeof(uint32_t) * (size_t)L, hipMemcpyDeviceToHost));
-        HIPCHK(c, hipMemcpy(jsw.data(), WS.sliceWidth.p, sizeof(uint32_t) * (size_t)nsl, hipMemcpyDeviceToHost));
-        HIPCHK(c, hipMemcpy(jsb.data(), WS.sliceBase.p, sizeof(uint32_t) * (size_t)nsl, hipMemcpyDeviceToHost));
-        HIPCHK(c, hipMemcpy(lp.data(), WS.lp.p, sizeof(int32_t) * (size_t)L, hipMemcpyDeviceToHost));
-        HIPCHK(c, hipMemcpy(ls.data(), WS.ld.p, sizeof(double) * (size_t)L, hipMemcpyDeviceToHost));   // diagonal values
+        HIPCHK(c, hipMemcpy(jcnt.data(), W0.rowCnt.p, sizeof(uint32_t) * (size_t)L, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(jpos.data(), W0.rowPos.p, sizeof(uint32_t) * (size_t)L, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(jperm.data(), W0.perm.p, sizeof(uint32_t) * (size_t)L, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(jsw.data(), W0.sliceWidth.p, sizeof(uint32_t) * (size_t)nsl, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(jsb.data(), W0.sliceBase.p, sizeof(uint32_t) * (size_t)nsl, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(lp.data(), W0.lp.p, sizeof(int32_t) * (size_t)L, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(ls.data(), W0.ld.p, sizeof(double) * (size_t)L, hipMemcpyDeviceToHost));   // diagonal values
     }
     if (cap > 0) {
-        HIPCHK(c, hipMemcpy(jvals.data(), WS.vals.p, sizeof(double) * (size_t)cap, hipMemcpyDeviceToHost));
-        if (Lst.idx16) {
+        HIPCHK(c, hipMemcpy(jvals.data(), W0.vals.p, sizeof(double) * (size_t)cap, hipMemcpyDeviceToHost));
+        if (up) {
             std::vector<uint16_t> c16((size_t)cap);
-            HIPCHK(c, hipMemcpy(c16.data(), WS.cols.p, sizeof(uint16_t) * (size_t)cap, hipMemcpyDeviceToHost));
+            HIPCHK(c, hipMemcpy(c16.data(), W0.cols16.p, sizeof(uint16_t) * (size_t)cap, hipMemcpyDeviceToHost));
             for (int64_t k = 0; k < cap; ++k) jcols[(size_t)k] = (c16[(size_t)k] & 0x8000u) ? (0x80000000u | (c16[(size_t)k] & 0x7fffu)) : c16[(size_t)k];
         } else {
-            HIPCHK(c, hipMemcpy(jcols.data(), WS.cols.p, sizeof(uint32_t) * (size_t)cap, hipMemcpyDeviceToHost));
+            HIPCHK(c, hipMemcpy(jcols.data(), W0.cols32.p, sizeof(uint32_t) * (size_t)cap, hipMemcpyDeviceToHost));
+        }
+    }
+    std::vector<std::vector<std::pair<uint32_t, double>>> rows(L1);
+    if (up) {
+        // stream layout: row p (POSITION) holds its strict-upper entries (p, q), q a position; rowCnt[p] slots are in use
+        for (int p = 0; p < L; ++p) {
+            const uint32_t sl = (uint32_t)p >> 6, slot = (uint32_t)p & 63u;
+            const uint32_t kp = jperm[(size_t)p];
+            for (uint32_t e = 0; e < jcnt[(size_t)p]; ++e) {
+                const uint32_t cq = jcols[h_col_pos(true, jsb[sl], slot, e)]; const double v = jvals[h_val_pos(true, jsb[sl], slot, e)];
+                const uint32_t q = cq & 0x7fffffffu;
+                if (q >= (uint32_t)L) continue;                                                      // inert slot (dummy column L + slot)
+                const uint32_t kq = jperm[(size_t)q], flag = cq & 0x80000000u;
+                rows[kp].push_back({kq | flag, v}); rows[kq].push_back({kp | flag, v});
+            }
+        }
+    } else {
+        for (int k = 0; k < L; ++k) {
+            const uint32_t pos = jpos[(size_t)k], sl = pos >> 6, slot = pos & 63u;
+            for (uint32_t e = 0; e < jcnt[(size_t)k]; ++e) {
+                const uint32_t cq = jcols[h_col_pos(false, jsb[sl], slot, e)]; const double v = jvals[h_val_pos(false, jsb[sl], slot, e)];
+                if (v == 0.0 && (cq & 0x80000000u) && (int)(cq & 0x7fffffffu) == k) continue;      // inert slot
+                rows[(size_t)k].push_back({cq, v});
+            }
         }
     }
     cols.clear(); vals.clear();
-    const bool quad = use_quad(Lst.D, Lst.tot.maxL);
     for (int k = 0; k < L; ++k) {
-        const uint32_t pos = jpos[(size_t)k], sl = pos >> 6, slot = pos & 63u;
+        auto& r = rows[(size_t)k];
+        std::sort(r.begin(), r.end(), [](const std::pair<uint32_t, double>& a, const std::pair<uint32_t, double>& b) { return (a.first & 0x7fffffffu) < (b.first & 0x7fffffffu); });
         rs[(size_t)k] = (uint32_t)cols.size();
-        for (uint32_t e = 0; e < jcnt[(size_t)k]; ++e) {
-            const uint32_t cq = jcols[h_col_pos(quad, jsb[sl], slot, e)]; const double v = jvals[h_val_pos(quad, jsb[sl], slot, e)];
-            if (v == 0.0 && (cq & 0x80000000u) && (int)(cq & 0x7fffffffu) == (quad ? L : k)) continue;     // inert slot
-            cols.push_back(cq); vals.push_back(v);
-        }
-        rl[(size_t)k] = (uint32_t)cols.size() - rs[(size_t)k];
+        for (auto& e : r) { cols.push_back(e.first); vals.push_back(e.second); }
+        rl[(size_t)k] = (uint32_t)r.size();
     }
     if (cols.empty()) { cols.push_back(0); vals.push_back(0.0); }
     return ROMAN_OK;
@@ -687,7 +756,7 @@ int fetch_last_csr(const roman_ctx* cc, std::vector<uint32_t>& rs, std::vector<u
 // =============================================================================================
 extern "C" {
 
-const char* roman_version(void) { return "roman_hip 0.1.0 gfx950 (HIP, wave64, f64)"; }
+const char* roman_version(void) { return "roman_hip 0.2.0 gfx950 (HIP, wave64, f64)"; }
 
 int roman_params_default(roman_params_t* p)
 {
@@ -727,9 +796,11 @@ int roman_ctx_create(roman_ctx_t** out, int device, void* stream)
     }
     for (int k = 0; k < ROMAN_MAX_PIPELINE; ++k) c->ws[k].stream = c->stream;
     for (int k = 0; k < ROMAN_MAX_PIPELINE; ++k) {
-        if (hipHostMalloc((void**)&c->ws[k].pinnedTotals, sizeof(BatchTotals), hipHostMallocDefault) != hipSuccess) {
-            roman_ctx_destroy(c); return fail(nullptr, ROMAN_E_NOMEM, "hipHostMalloc failed");
+        if (hipHostMalloc((void**)&c->ws[k].pinnedTotals, sizeof(BatchTotals), hipHostMallocDefault) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ws[k].totEvent, hipEventDisableTiming) != hipSuccess) {
+            roman_ctx_destroy(c); return fail(nullptr, ROMAN_E_NOMEM, "hipHostMalloc / hipEventCreate failed");
         }
+        memset(c->ws[k].pinnedTotals, 0, sizeof(BatchTotals));
     }
     *out = c;
     return ROMAN_OK;
@@ -740,15 +811,16 @@ int roman_ctx_destroy(roman_ctx_t* c)
     if (!c) return ROMAN_OK;
     (void)hipSetDevice(c->device);
     (void)roman_ctx_sync(c);
-    workers_stop(c);
     for (int k = 0; k < ROMAN_MAX_PIPELINE; ++k) {
         roman_ctx::Workspace& W = c->ws[k];
-        DevBuf* all[] = {&W.probs, &W.state, &W.totals, &W.queue, &W.cosPool, &W.normPool, &W.tabPool, &W.sTmp, &W.lp, &W.li, &W.lj, &W.ls, &W.ld, &W.lza, &W.lzb,
-                         &W.rowCnt, &W.rowPos, &W.perm, &W.sliceWidth, &W.sliceBase, &W.items, &W.maskPool, &W.prefPool, &W.vMu, &W.vCu, &W.vMun, &W.vCun, &W.gU, &W.gUn,
-                         &W.uOut, &W.nodesOrig, &W.nSel, &W.cols, &W.vals, &W.cols1, &W.vals1, &W.cols2, &W.vals2, &W.cols3, &W.vals3,
-                         &W.hFeats, &W.hAssoc, &W.hU0, &W.oAssoc, &W.oN, &W.oT, &W.oStatus, &W.oStats, &W.hAux1, &W.hAux2, &W.hAux3, &W.chunkCnt};
+        DevBuf* all[] = {&W.probs, &W.state, &W.totals, &W.queue, &W.cosPool, &W.tabPool, &W.sTmp, &W.chunkCnt,
+                         &W.lp, &W.li, &W.lj, &W.ls, &W.ld, &W.lza, &W.lzb, &W.plp, &W.pli, &W.plj, &W.pls, &W.pld, &W.plza, &W.plzb,
+                         &W.rowCnt, &W.rowPos, &W.perm, &W.sliceWidth, &W.sliceBase, &W.items, &W.maskPool, &W.umaskPool, &W.prefPool,
+                         &W.vMu, &W.vCu, &W.vMun, &W.vCun, &W.gU, &W.gUn, &W.uOut, &W.nodesOrig, &W.nSel, &W.cols16, &W.cols32, &W.vals,
+                         &W.hFeats, &W.hAssoc, &W.hU0, &W.oAssoc, &W.oN, &W.oT, &W.oStatus, &W.oStats, &W.hAux1, &W.hAux2, &W.hAux3};
         for (DevBuf* b : all) b->release();
         if (W.pinnedTotals) (void)hipHostFree(W.pinnedTotals);
+        if (W.totEvent) (void)hipEventDestroy(W.totEvent);
         for (int s = 0; s < ROMAN_STAGE_COUNT; ++s) { if (W.evA[s]) (void)hipEventDestroy(W.evA[s]); if (W.evB[s]) (void)hipEventDestroy(W.evB[s]); }
         if (W.done) (void)hipEventDestroy(W.done);
     }
@@ -758,87 +830,6 @@ int roman_ctx_destroy(roman_ctx_t* c)
     delete c;
     return ROMAN_OK;
 }
-
-namespace {
-
-// one batch through the stages, on workspace t_wsel and its stream
-int run_batch(roman_ctx* c, const DevParams& D, const BatchIn& in, const double* u0, int32_t kmax,
-              int32_t* assoc_out, int32_t* n_assoc_out, double* T_out, int32_t* status_out, roman_stats_t* stats_out)
-{
-    std::vector<ProbDesc> hd;
-    BatchTotals tot{}; bool idx16 = true;
-    int rc = stage_score(c, D, in, hd, &tot, &idx16);
-    if (rc) return rc;
-    return stage_solve(c, D, in.B, in.feats, in.assoc, u0, tot, idx16, false, kmax, assoc_out, n_assoc_out, T_out, status_out, stats_out);
-}
-
-void worker_main(roman_ctx* c, int k)
-{
-    roman_ctx::Worker& Wk = c->wk[k];
-    t_wsel = k;
-    t_err = &Wk.err;
-    (void)hipSetDevice(c->device);
-    for (;;) {
-        {
-            std::unique_lock<std::mutex> lk(Wk.m);
-            Wk.cv.wait(lk, [&] { return Wk.has_job || Wk.quit; });
-            if (Wk.quit) return;
-            Wk.has_job = false;
-        }
-        const roman_ctx::Job& J = Wk.job;                       // not touched by the caller while busy
-        int rc = ROMAN_OK;
-        DevParams D;
-        rc = make_dev_params(c, &J.params, J.F, &D);
-        if (!rc) {
-            c->ws[k].stream = c->istream[k];
-            BatchIn in{J.B, J.feats, J.off1.data(), J.n1.data(), J.off2.data(), J.n2.data(), J.F, J.assoc, J.assoc ? J.assoc_off.data() : nullptr};
-            rc = run_batch(c, D, in, J.u0, J.kmax, J.assoc_out, J.n_assoc_out, J.T_out, J.status_out, J.stats_out);
-            if (!rc) {
-                if (hipEventRecord(c->ws[k].done, c->ws[k].stream) != hipSuccess) { (void)hipGetLastError(); rc = fail(c, ROMAN_E_HIP, "hipEventRecord failed in the pipeline worker"); }
-                else c->ws[k].issued = true;
-            }
-        }
-        {
-            std::lock_guard<std::mutex> lk(Wk.m);
-            Wk.rc = rc; Wk.busy = false;
-        }
-        Wk.cv.notify_all();
-    }
-}
-
-// Block until the worker of workspace k has queued everything of its current batch; returns (once) the error
-// of that batch, with its text in the context.
-int worker_wait_idle(roman_ctx* c, int k)
-{
-    roman_ctx::Worker& Wk = c->wk[k];
-    if (!Wk.started) return ROMAN_OK;
-    std::unique_lock<std::mutex> lk(Wk.m);
-    Wk.cv.wait(lk, [&] { return !Wk.busy; });
-    const int rc = Wk.rc;
-    if (rc) { c->err = Wk.err; Wk.rc = ROMAN_OK; }
-    return rc;
-}
-
-int workers_wait_all(roman_ctx* c)
-{
-    int first = ROMAN_OK;
-    for (int k = 0; k < ROMAN_MAX_PIPELINE; ++k) { const int rc = worker_wait_idle(c, k); if (rc && !first) first = rc; }
-    return first;
-}
-
-void workers_stop(roman_ctx* c)
-{
-    for (int k = 0; k < ROMAN_MAX_PIPELINE; ++k) {
-        roman_ctx::Worker& Wk = c->wk[k];
-        if (!Wk.started) continue;
-        { std::unique_lock<std::mutex> lk(Wk.m); Wk.cv.wait(lk, [&] { return !Wk.busy; }); Wk.quit = true; }
-        Wk.cv.notify_all();
-        Wk.th.join();
-        Wk.started = false; Wk.quit = false;
-    }
-}
-
-}  // namespace
 
 // Batches in flight.  depth 1 (default): every call runs on the context's stream.  depth 2 or 3: batch calls
 // (roman_align_batch_dev) rotate over that many workspaces, each with an internal stream that starts after
@@ -858,7 +849,7 @@ int roman_ctx_set_pipeline(roman_ctx_t* c, int depth)
         }
         if (!c->evIn) HIPCHK(c, hipEventCreateWithFlags(&c->evIn, hipEventDisableTiming));
     }
-    c->pipeline = depth; c->next_ws = 0; t_wsel = 0; c->latest_ws = -1;
+    c->pipeline = depth; c->next_ws = 0; c->cur = 0; c->latest_ws = -1;
     for (int k = 0; k < ROMAN_MAX_PIPELINE; ++k) { c->ws[k].issued = false; c->ws[k].stream = c->stream; }
     return ROMAN_OK;
 }
@@ -872,25 +863,20 @@ int roman_ctx_join(roman_ctx_t* c, int skip_latest)
     if (!c) return fail(nullptr, ROMAN_E_INVALID, "ctx is NULL");
     if (c->pipeline < 2) return ROMAN_OK;                       // everything already runs on the caller's stream
     HIPCHK(c, hipSetDevice(c->device));
-    const int latest = c->latest_ws;                            // workspace of the most recent batch call
-    int first = ROMAN_OK;
     for (int k = 0; k < c->pipeline; ++k) {
-        if (skip_latest && k == latest) continue;
-        const int rc = worker_wait_idle(c, k);                  // the batch must be queued completely before its event exists
-        if (rc && !first) first = rc;
+        if (skip_latest && k == c->latest_ws) continue;
         if (c->ws[k].done && c->ws[k].issued) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ws[k].done, 0));
     }
-    return first;
+    return ROMAN_OK;
 }
 
 int roman_ctx_sync(roman_ctx_t* c)
 {
     if (!c) return fail(nullptr, ROMAN_E_INVALID, "ctx is NULL");
     HIPCHK(c, hipSetDevice(c->device));
-    const int rcw = workers_wait_all(c);
     for (int k = 0; k < ROMAN_MAX_PIPELINE; ++k) if (c->istream[k]) HIPCHK(c, hipStreamSynchronize(c->istream[k]));
     if (c->stream) HIPCHK(c, hipStreamSynchronize(c->stream));
-    return rcw;
+    return ROMAN_OK;
 }
 
 // --- instrumentation -----------------------------------------------------------------------------
@@ -941,34 +927,27 @@ int roman_align_batch_dev(roman_ctx_t* c, const roman_params_t* params, int32_t 
         for (int b = 0; b < B; ++b) any = any || (n1[b] > 0 || n2[b] > 0);
         if (any) return fail(c, ROMAN_E_INVALID, "feats is NULL");
     }
-    if (c->pipeline >= 2 && !c->in_host_batch) {
-        // next workspace: its worker thread runs the launch sequence on the workspace's internal stream, which
-        // starts behind the work already queued on the caller's stream
+    const BatchIn in{B, feats, off1, n1, off2, n2, F, assoc, assoc_off};
+    const BatchOut out{kmax, assoc_out, n_assoc_out, T_out, status_out, stats_out};
+    if (c->pipeline >= 2) {
+        // next workspace: its internal stream starts behind the work already queued on the caller's stream
         const int k = c->next_ws;
         c->next_ws = (c->next_ws + 1) % c->pipeline; c->latest_ws = k;
-        rc = worker_wait_idle(c, k);                            // also reports a failure of the batch it ran before
-        if (rc) return rc;
         HIPCHK(c, hipEventRecord(c->evIn, c->stream));
         HIPCHK(c, hipStreamWaitEvent(c->istream[k], c->evIn, 0));
-        roman_ctx::Worker& Wk = c->wk[k];
-        {
-            std::lock_guard<std::mutex> lk(Wk.m);
-            roman_ctx::Job& J = Wk.job;
-            J.params = *params; J.B = B; J.F = F; J.kmax = kmax; J.feats = feats; J.assoc = assoc; J.u0 = u0;
-            J.off1.assign(off1, off1 + B); J.off2.assign(off2, off2 + B); J.n1.assign(n1, n1 + B); J.n2.assign(n2, n2 + B);
-            if (assoc) J.assoc_off.assign(assoc_off, assoc_off + B + 1); else J.assoc_off.clear();
-            J.assoc_out = assoc_out; J.n_assoc_out = n_assoc_out; J.T_out = T_out; J.status_out = status_out; J.stats_out = stats_out;
-            if (!Wk.started) { Wk.started = true; Wk.th = std::thread(worker_main, c, k); }
-            Wk.has_job = true; Wk.busy = true;
+        c->cur = k; c->ws[k].stream = c->istream[k];
+        rc = run_batch(c, D, params, in, u0, out);
+        if (!rc) {
+            HIPCHK(c, hipEventRecord(c->ws[k].done, c->ws[k].stream));
+            c->ws[k].issued = true;
         }
-        Wk.cv.notify_all();
-        return ROMAN_OK;
+        c->cur = 0;
+        return rc;
     }
-    if (!c->in_host_batch) { t_wsel = 0; WS.stream = c->stream; }
-    BatchIn in{B, feats, off1, n1, off2, n2, F, assoc, assoc_off};
-    rc = run_batch(c, D, in, u0, kmax, assoc_out, n_assoc_out, T_out, status_out, stats_out);
+    c->cur = 0; WS.stream = c->stream;
+    rc = run_batch(c, D, params, in, u0, out);
     if (rc) return rc;
-    if (t_wsel == 0) { c->last.scored = false; c->last.solved = false; }
+    c->last.scored = false; c->last.solved = false;
     return ROMAN_OK;
 }
 
@@ -987,7 +966,9 @@ int roman_align_batch(roman_ctx_t* c, const roman_params_t* params, int32_t B,
     if (assoc && !assoc_off) return fail(c, ROMAN_E_INVALID, "assoc given without assoc_off");
     HIPCHK(c, hipSetDevice(c->device));
     { int rc0 = use_ws0(c); if (rc0) return rc0; }
-    struct HostBatchGuard { roman_ctx* c; HostBatchGuard(roman_ctx* c_) : c(c_) { c->in_host_batch = true; } ~HostBatchGuard() { c->in_host_batch = false; } } guard(c);
+    DevParams D;
+    int rc = make_dev_params(c, params, F, &D);
+    if (rc) return rc;
     int64_t sumA = 0;
     if (assoc && assoc_off[0] != 0) return fail(c, ROMAN_E_INVALID, "assoc_off[0] must be 0");
     for (int b = 0; b < B; ++b) {
@@ -1022,15 +1003,24 @@ int roman_align_batch(roman_ctx_t* c, const roman_params_t* params, int32_t B,
     HIPCHK(c, WS.oAssoc.ensure(sizeof(int32_t) * 2 * kb)); HIPCHK(c, WS.oN.ensure(sizeof(int32_t) * (size_t)B));
     HIPCHK(c, WS.oT.ensure(sizeof(double) * 16 * (size_t)B)); HIPCHK(c, WS.oStatus.ensure(sizeof(int32_t) * (size_t)B));
     HIPCHK(c, WS.oStats.ensure(sizeof(roman_stats_t) * (size_t)B));
-    int rc = roman_align_batch_dev(c, params, B, WS.hFeats.as<double>(), off1, n1, off2, n2, F, dA, assoc_off, dU0, kmax,
-                                   WS.oAssoc.as<int32_t>(), WS.oN.as<int32_t>(), WS.oT.as<double>(), WS.oStatus.as<int32_t>(), WS.oStats.as<roman_stats_t>());
-    if (rc) return rc;
+    const BatchIn in{B, WS.hFeats.as<double>(), off1, n1, off2, n2, F, dA, assoc_off};
+    const BatchOut out{kmax, WS.oAssoc.as<int32_t>(), WS.oN.as<int32_t>(), WS.oT.as<double>(), WS.oStatus.as<int32_t>(), WS.oStats.as<roman_stats_t>()};
+    // this entry point is synchronous anyway: when a problem did not fit the speculatively sized pools, run again
+    // with the need the first attempt recorded
+    for (int attempt = 0; ; ++attempt) {
+        rc = run_batch(c, D, params, in, dU0, out);
+        if (rc) return rc;
+        HIPCHK(c, hipStreamSynchronize(WS.stream));
+        if (!batch_overflowed(c)) break;
+        if (attempt >= 3) return fail(c, ROMAN_E_NOMEM, "the sparse workspace still does not fit after %d attempts", attempt + 1);
+    }
     if (kmax > 0) HIPCHK(c, hipMemcpyAsync(assoc_out, WS.oAssoc.p, sizeof(int32_t) * 2 * (size_t)B * (size_t)kmax, hipMemcpyDeviceToHost, WS.stream));
     HIPCHK(c, hipMemcpyAsync(n_assoc_out, WS.oN.p, sizeof(int32_t) * (size_t)B, hipMemcpyDeviceToHost, WS.stream));
     HIPCHK(c, hipMemcpyAsync(T_out, WS.oT.p, sizeof(double) * 16 * (size_t)B, hipMemcpyDeviceToHost, WS.stream));
     HIPCHK(c, hipMemcpyAsync(status_out, WS.oStatus.p, sizeof(int32_t) * (size_t)B, hipMemcpyDeviceToHost, WS.stream));
     if (stats_out) HIPCHK(c, hipMemcpyAsync(stats_out, WS.oStats.p, sizeof(roman_stats_t) * (size_t)B, hipMemcpyDeviceToHost, WS.stream));
     HIPCHK(c, hipStreamSynchronize(WS.stream));
+    c->last.scored = false; c->last.solved = false;
     return ROMAN_OK;
 }
 
@@ -1052,7 +1042,8 @@ int roman_score(roman_ctx_t* c, const roman_params_t* params, const double* D1, 
     { int rc0 = use_ws0(c); if (rc0) return rc0; }
     roman_ctx::Last& Lst = c->last;
     Lst.scored = false; Lst.solved = false; Lst.dense = false; Lst.hascz = false;
-    int rc = make_dev_params(c, params, F, &Lst.D);
+    DevParams D0;
+    int rc = make_dev_params(c, params, F, &D0);
     if (rc) return rc;
     const int64_t nobj = (int64_t)n1 + n2;
     HIPCHK(c, WS.hFeats.ensure(sizeof(double) * (size_t)std::max<int64_t>(nobj * F, 1)));
@@ -1072,12 +1063,18 @@ int roman_score(roman_ctx_t* c, const roman_params_t* params, const double* D1, 
         dA = WS.hAssoc.as<int32_t>();
     }
     const int64_t o1 = 0, o2 = n1;
-    BatchIn in{1, WS.hFeats.as<double>(), &o1, &n1, &o2, &n2, F, dA, aoff};
+    const BatchIn in{1, WS.hFeats.as<double>(), &o1, &n1, &o2, &n2, F, dA, aoff};
     std::vector<ProbDesc> hd;
-    rc = stage_score(c, Lst.D, in, hd, &Lst.tot, &Lst.idx16);
-    if (rc) return rc;
-    HIPCHK(c, hipStreamSynchronize(WS.stream));
-    Lst.pd = hd[0]; Lst.nA = hd[0].nA; Lst.L = Lst.tot.R; Lst.scored = true;
+    ProbState ps{};
+    for (int attempt = 0; ; ++attempt) {
+        rc = enqueue_score(c, D0, params, in, hd, &Lst.D);
+        if (rc) return rc;
+        HIPCHK(c, hipMemcpyAsync(&ps, WS.state.p, sizeof(ProbState), hipMemcpyDeviceToHost, WS.stream));
+        HIPCHK(c, hipStreamSynchronize(WS.stream));
+        if (!batch_overflowed(c)) break;
+        if (attempt >= 3) return fail(c, ROMAN_E_NOMEM, "the sparse workspace still does not fit after %d attempts", attempt + 1);
+    }
+    Lst.pd = hd[0]; Lst.nA = hd[0].nA; Lst.L = ps.L; Lst.kind = ps.kind; Lst.nnzCap = ps.nnzCap; Lst.scored = true;
     return ROMAN_OK;
 }
 
@@ -1092,67 +1089,105 @@ int roman_set_matrix_data(roman_ctx_t* c, const roman_params_t* params, const do
     roman_params_t p = *params; p.invariant = ROMAN_INV_EUCLIDEAN;          // implicit identity diagonal
     int rc = make_dev_params(c, &p, p.point_dim, &Lst.D);
     if (rc) return rc;
-    Lst.idx16 = n <= 32767;
-    // full-symmetric rows over the union pattern of the strict upper triangles of M and C
-    std::vector<uint32_t> rs((size_t)std::max(n, 1)), rl((size_t)std::max(n, 1) + 64, 0);
-    std::vector<uint32_t> cols; std::vector<double> vals;
-    int64_t upper = 0;
-    const uint32_t czflag = Lst.idx16 ? 0x8000u : 0x80000000u;
-    for (int p_ = 0; p_ < n; ++p_) {
-        rs[(size_t)p_] = (uint32_t)cols.size();
-        for (int q = 0; q < n; ++q) {
-            if (q == p_) continue;
-            const int a = std::min(p_, q), b = std::max(p_, q);
+    const bool up = n <= STREAM_MAXL && Lst.D.p.maxiniters >= 1 && Lst.D.p.maxlsiters >= 1;
+    Lst.D.stream_maxL = up ? std::max(64, (n + 63) & ~63) : 64;
+    // full-symmetric rows over the union pattern of the strict upper triangles of M and C (like upstream only the
+    // strict upper triangles are read)
+    const size_t n1_ = (size_t)std::max(n, 1);
+    std::vector<std::vector<std::pair<uint32_t, double>>> rows(n1_);       // (column | flag in bit 31, value)
+    int64_t upper = 0; bool anycz = false;
+    for (int a = 0; a < n; ++a)
+        for (int b = a + 1; b < n; ++b) {
             const double mv = M[(int64_t)a * n + b], cv = Cm[(int64_t)a * n + b];
             if (mv != 0.0 || cv != 0.0) {
-                cols.push_back((uint32_t)q | ((cv == 0.0) ? czflag : 0u));
-                vals.push_back(mv);
-                if (q > p_) ++upper;
+                const uint32_t flag = (cv == 0.0) ? 0x80000000u : 0u;
+                anycz = anycz || flag;
+                rows[(size_t)a].push_back({(uint32_t)b | flag, mv}); rows[(size_t)b].push_back({(uint32_t)a | flag, mv});
+                ++upper;
+                if (upper > 1500000000LL) return fail(c, ROMAN_E_TOO_LARGE, "dense matrix has too many non-zeros");
             }
         }
-        rl[(size_t)p_] = (uint32_t)cols.size() - rs[(size_t)p_];
-        if (cols.size() > 4000000000ull) return fail(c, ROMAN_E_TOO_LARGE, "dense matrix has too many non-zeros");
-    }
-    // re-order into the device's layout: sorted SELL-64, or the quad layout of the streaming solver
-    Lst.tot.maxL = n; Lst.tot.R = n;
-    const bool quad = use_quad(Lst.D, n);
-    std::vector<uint32_t> rowPos, perm, sliceWidth, sliceBase; uint64_t total = 0;
-    std::vector<uint32_t> cntv(rl.begin(), rl.begin() + std::max(n, 1));
-    sell_geometry(cntv, n, quad ? 4 : 1, rowPos, perm, sliceWidth, sliceBase, &total);
-    if (total > 4000000000ull) return fail(c, ROMAN_E_TOO_LARGE, "dense matrix has too many non-zeros");
-    std::vector<uint32_t> jcols((size_t)std::max<uint64_t>(total, 1), 0); std::vector<double> jvals((size_t)std::max<uint64_t>(total, 1), 0.0);
-    bool anycz = false;
-    for (int sl = 0; sl < (n + 63) / 64; ++sl)
-        for (uint32_t slot = 0; slot < 64; ++slot) {
-            const int pos = sl * 64 + (int)slot;
-            const int k = pos < n ? (int)perm[(size_t)pos] : -1;                 // -1: lane slot without a row
-            const uint32_t inert = (quad ? (uint32_t)n : (uint32_t)std::max(k, 0)) | czflag;
-            for (uint32_t e = 0; e < sliceWidth[(size_t)sl]; ++e) {
-                const size_t pc = h_col_pos(quad, sliceBase[(size_t)sl], slot, e), pv = h_val_pos(quad, sliceBase[(size_t)sl], slot, e);
-                if (k >= 0 && e < rl[(size_t)k]) {
-                    jcols[pc] = cols[(size_t)rs[(size_t)k] + e]; jvals[pv] = vals[(size_t)rs[(size_t)k] + e];
-                    anycz = anycz || (jcols[pc] & czflag);
-                } else { jcols[pc] = inert; jvals[pv] = 0.0; }
-            }
-        }
+    for (auto& r : rows) std::sort(r.begin(), r.end(), [](const std::pair<uint32_t, double>& x, const std::pair<uint32_t, double>& y) { return (x.first & 0x7fffffffu) < (y.first & 0x7fffffffu); });
     Lst.hascz = anycz;
-    const size_t n1_ = (size_t)std::max(n, 1), nnz1 = (size_t)std::max<uint64_t>(total, 1), nsl1 = (size_t)std::max((n + 63) / 64, 1);
-    HIPCHK(c, WS.probs.ensure(sizeof(ProbDesc))); HIPCHK(c, WS.state.ensure(sizeof(ProbState))); HIPCHK(c, WS.queue.ensure(sizeof(int) * 4));
-    HIPCHK(c, WS.lp.ensure(sizeof(int32_t) * n1_)); HIPCHK(c, WS.ls.ensure(sizeof(double) * n1_)); HIPCHK(c, WS.ld.ensure(sizeof(double) * n1_));
+    std::vector<uint32_t> deg(n1_, 0), rowPos, perm, sliceWidth, sliceBase, rowCnt(n1_, 0);
+    for (int k = 0; k < n; ++k) deg[(size_t)k] = (uint32_t)rows[(size_t)k].size();
+    uint64_t total = 0;
+    std::vector<uint16_t> c16; std::vector<uint32_t> c32; std::vector<double> jvals;
+    if (up) {
+        // stream layout: positions = stable rank by descending degree; row p keeps its strict-upper entries (p, q > p)
+        // in ascending q; slices padded to whole quads; inert entries point at the dummy elements n + slot
+        perm.resize(n1_); rowPos.assign(n1_, 0);
+        for (int k = 0; k < n; ++k) perm[(size_t)k] = (uint32_t)k;
+        std::stable_sort(perm.begin(), perm.begin() + n, [&](uint32_t a, uint32_t b) { return deg[a] > deg[b]; });
+        for (int q = 0; q < n; ++q) rowPos[perm[(size_t)q]] = (uint32_t)q;
+        std::vector<std::vector<std::pair<uint32_t, double>>> urows(n1_);
+        for (int q = 0; q < n; ++q) {
+            for (auto& e : rows[perm[(size_t)q]]) {
+                const uint32_t qq = rowPos[e.first & 0x7fffffffu];
+                if ((int)qq > q) urows[(size_t)q].push_back({qq | (e.first & 0x80000000u), e.second});
+            }
+            std::sort(urows[(size_t)q].begin(), urows[(size_t)q].end(), [](const std::pair<uint32_t, double>& x, const std::pair<uint32_t, double>& y) { return (x.first & 0x7fffffffu) < (y.first & 0x7fffffffu); });
+            rowCnt[(size_t)q] = (uint32_t)urows[(size_t)q].size();
+        }
+        const int nsl = (n + 63) / 64;
+        sliceWidth.assign((size_t)std::max(nsl, 1), 0); sliceBase.assign((size_t)std::max(nsl, 1), 0);
+        for (int sl = 0; sl < nsl; ++sl) {
+            uint32_t wmax = 0;
+            for (int q = sl * 64; q < std::min(n, sl * 64 + 64); ++q) wmax = std::max(wmax, rowCnt[(size_t)q]);
+            wmax = (wmax + 3u) & ~3u;
+            sliceWidth[(size_t)sl] = wmax; sliceBase[(size_t)sl] = (uint32_t)total; total += (uint64_t)wmax * 64u;
+        }
+        c16.assign((size_t)std::max<uint64_t>(total, 1), 0); jvals.assign((size_t)std::max<uint64_t>(total, 1), 0.0);
+        for (int sl = 0; sl < nsl; ++sl)
+            for (uint32_t slot = 0; slot < 64; ++slot) {
+                const int q = sl * 64 + (int)slot;
+                for (uint32_t e = 0; e < sliceWidth[(size_t)sl]; ++e) {
+                    const size_t pc = h_col_pos(true, sliceBase[(size_t)sl], slot, e), pv = h_val_pos(true, sliceBase[(size_t)sl], slot, e);
+                    if (q < n && e < rowCnt[(size_t)q]) {
+                        const auto& en = urows[(size_t)q][e];
+                        c16[pc] = (uint16_t)((en.first & 0x7fffu) | ((en.first & 0x80000000u) ? 0x8000u : 0u)); jvals[pv] = en.second;
+                    } else { c16[pc] = (uint16_t)(((uint32_t)n + slot) | 0x8000u); jvals[pv] = 0.0; }
+                }
+            }
+    } else {
+        // fallback layout: symmetric sorted SELL-64 in the caller's numbering, 32-bit indices
+        sell_geometry(deg, n, rowPos, perm, sliceWidth, sliceBase, &total);
+        if (total > 4000000000ull) return fail(c, ROMAN_E_TOO_LARGE, "dense matrix has too many non-zeros");
+        c32.assign((size_t)std::max<uint64_t>(total, 1), 0); jvals.assign((size_t)std::max<uint64_t>(total, 1), 0.0);
+        for (int sl = 0; sl < (n + 63) / 64; ++sl)
+            for (uint32_t slot = 0; slot < 64; ++slot) {
+                const int pos = sl * 64 + (int)slot;
+                const int k = pos < n ? (int)perm[(size_t)pos] : -1;                 // -1: lane slot without a row
+                const uint32_t inert = (uint32_t)std::max(k, 0) | 0x80000000u;
+                for (uint32_t e = 0; e < sliceWidth[(size_t)sl]; ++e) {
+                    const size_t pc = h_col_pos(false, sliceBase[(size_t)sl], slot, e), pv = h_val_pos(false, sliceBase[(size_t)sl], slot, e);
+                    if (k >= 0 && e < deg[(size_t)k]) { c32[pc] = rows[(size_t)k][e].first; jvals[pv] = rows[(size_t)k][e].second; }
+                    else { c32[pc] = inert; jvals[pv] = 0.0; }
+                }
+            }
+        for (int k = 0; k < n; ++k) rowCnt[(size_t)k] = deg[(size_t)k];
+    }
+    const size_t nnz1 = (size_t)std::max<uint64_t>(total, 1), nsl1 = (size_t)std::max((n + 63) / 64, 1);
+    HIPCHK(c, WS.probs.ensure(sizeof(ProbDesc))); HIPCHK(c, WS.state.ensure(sizeof(ProbState))); HIPCHK(c, WS.queue.ensure(sizeof(int) * 8));
+    HIPCHK(c, WS.lp.ensure(sizeof(int32_t) * n1_)); HIPCHK(c, WS.plp.ensure(sizeof(int32_t) * n1_));
+    HIPCHK(c, WS.ls.ensure(sizeof(double) * n1_)); HIPCHK(c, WS.ld.ensure(sizeof(double) * n1_)); HIPCHK(c, WS.pld.ensure(sizeof(double) * n1_));
     HIPCHK(c, WS.rowCnt.ensure(sizeof(uint32_t) * n1_)); HIPCHK(c, WS.rowPos.ensure(sizeof(uint32_t) * n1_)); HIPCHK(c, WS.perm.ensure(sizeof(uint32_t) * n1_));
     HIPCHK(c, WS.sliceWidth.ensure(sizeof(uint32_t) * n1_)); HIPCHK(c, WS.sliceBase.ensure(sizeof(uint32_t) * n1_));
-    HIPCHK(c, WS.vals.ensure(sizeof(double) * nnz1)); HIPCHK(c, WS.cols.ensure((Lst.idx16 ? 2 : 4) * nnz1));
+    HIPCHK(c, WS.vals.ensure(sizeof(double) * nnz1)); HIPCHK(c, WS.cols16.ensure(sizeof(uint16_t) * nnz1)); HIPCHK(c, WS.cols32.ensure(sizeof(uint32_t) * nnz1));
+    WS.capNnz = std::max<long long>(WS.capNnz, (long long)nnz1);
     ProbDesc pd{}; pd.off1 = 0; pd.off2 = 0; pd.assocOff = -1; pd.liveOff = 0; pd.n1 = n; pd.n2 = 1; pd.nA = n;
-    ProbState ps{}; ps.L = n; ps.rowBase = 0; ps.nnzOff = 0; ps.maskOff = 0; ps.nnzCap = (uint32_t)total; ps.nnzUpper = (unsigned long long)upper;
-    std::vector<int32_t> ident((size_t)std::max(n, 1)); std::vector<double> ones((size_t)std::max(n, 1), 1.0);
-    for (int k = 0; k < n; ++k) ident[(size_t)k] = k;
+    ProbState ps{}; ps.L = n; ps.rowBase = 0; ps.nnzOff = 0; ps.maskOff = 0; ps.nnzCap = (uint32_t)total; ps.nnzUpper = (unsigned long long)upper; ps.kind = up ? 0 : 1;
+    std::vector<int32_t> ident(n1_), plp(n1_); std::vector<double> ones(n1_, 1.0);
+    for (int k = 0; k < n; ++k) { ident[(size_t)k] = k; plp[(size_t)k] = up ? (int32_t)perm[(size_t)k] : k; }
     HIPCHK(c, hipMemcpy(WS.probs.p, &pd, sizeof(pd), hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(WS.state.p, &ps, sizeof(ps), hipMemcpyHostToDevice));
     if (n > 0) {
         HIPCHK(c, hipMemcpy(WS.lp.p, ident.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(WS.plp.p, plp.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice));
         HIPCHK(c, hipMemcpy(WS.ls.p, ones.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
         HIPCHK(c, hipMemcpy(WS.ld.p, ones.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
-        HIPCHK(c, hipMemcpy(WS.rowCnt.p, rl.data(), sizeof(uint32_t) * (size_t)n, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(WS.pld.p, ones.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(WS.rowCnt.p, rowCnt.data(), sizeof(uint32_t) * (size_t)n, hipMemcpyHostToDevice));
         HIPCHK(c, hipMemcpy(WS.rowPos.p, rowPos.data(), sizeof(uint32_t) * (size_t)n, hipMemcpyHostToDevice));
         HIPCHK(c, hipMemcpy(WS.perm.p, perm.data(), sizeof(uint32_t) * (size_t)n, hipMemcpyHostToDevice));
         HIPCHK(c, hipMemcpy(WS.sliceWidth.p, sliceWidth.data(), sizeof(uint32_t) * nsl1, hipMemcpyHostToDevice));
@@ -1160,16 +1195,10 @@ int roman_set_matrix_data(roman_ctx_t* c, const roman_params_t* params, const do
     }
     if (total > 0) {
         HIPCHK(c, hipMemcpy(WS.vals.p, jvals.data(), sizeof(double) * (size_t)total, hipMemcpyHostToDevice));
-        if (Lst.idx16) {
-            std::vector<uint16_t> c16((size_t)total);
-            for (size_t k = 0; k < (size_t)total; ++k) c16[k] = (uint16_t)jcols[k];
-            HIPCHK(c, hipMemcpy(WS.cols.p, c16.data(), sizeof(uint16_t) * c16.size(), hipMemcpyHostToDevice));
-        } else {
-            HIPCHK(c, hipMemcpy(WS.cols.p, jcols.data(), sizeof(uint32_t) * (size_t)total, hipMemcpyHostToDevice));
-        }
+        if (up) HIPCHK(c, hipMemcpy(WS.cols16.p, c16.data(), sizeof(uint16_t) * (size_t)total, hipMemcpyHostToDevice));
+        else    HIPCHK(c, hipMemcpy(WS.cols32.p, c32.data(), sizeof(uint32_t) * (size_t)total, hipMemcpyHostToDevice));
     }
-    Lst.pd = pd; Lst.nA = n; Lst.L = n;
-    Lst.tot.nnzTotal = (int64_t)total; Lst.tot.R = n; Lst.tot.maxL = n; Lst.tot.maskWords = 0;
+    Lst.pd = pd; Lst.nA = n; Lst.L = n; Lst.kind = ps.kind; Lst.nnzCap = (int64_t)total;
     Lst.scored = true;
     return ROMAN_OK;
 }
@@ -1228,7 +1257,7 @@ int roman_get_upper_csr(const roman_ctx_t* c, int64_t* nnz, int64_t* rowptr, int
     std::vector<uint32_t> rs, rl, cols; std::vector<double> vals, ls; std::vector<int32_t> lp;
     int rc = fetch_last_csr(c, rs, rl, cols, vals, lp, ls);
     if (rc) return rc;
-    const int L = Lst.tot.R, nA = Lst.nA;
+    const int L = Lst.L, nA = Lst.nA;
     int64_t cnt = 0;
     std::vector<int64_t> rp((size_t)nA + 1, 0);
     for (int k = 0; k < L; ++k) {
@@ -1264,7 +1293,7 @@ int roman_get_dense_matrices(const roman_ctx_t* c, double* M, double* Cm)
     std::vector<uint32_t> rs, rl, cols; std::vector<double> vals, ls; std::vector<int32_t> lp;
     int rc = fetch_last_csr(c, rs, rl, cols, vals, lp, ls);
     if (rc) return rc;
-    const int L = Lst.tot.R; const int64_t nA = Lst.nA;
+    const int L = Lst.L; const int64_t nA = Lst.nA;
     if (M) memset(M, 0, sizeof(double) * (size_t)(nA * nA));
     if (Cm) memset(Cm, 0, sizeof(double) * (size_t)(nA * nA));
     const bool single = Lst.D.single && !Lst.dense;
@@ -1347,7 +1376,7 @@ int roman_debug_cosine(roman_ctx_t* c, const roman_params_t* params, const doubl
     HIPCHK(c, hipMemcpyAsync(WS.hFeats.as<double>() + (size_t)n1 * F, D2, sizeof(double) * (size_t)n2 * F, hipMemcpyHostToDevice, WS.stream));
     ProbDesc pd{}; pd.off1 = 0; pd.off2 = n1; pd.assocOff = -1; pd.n1 = n1; pd.n2 = n2; pd.nA = n1 * n2;
     HIPCHK(c, WS.probs.ensure(sizeof(ProbDesc)));
-    HIPCHK(c, WS.cosPool.ensure(sizeof(double) * (size_t)n1 * n2)); HIPCHK(c, WS.normPool.ensure(sizeof(double) * (size_t)(n1 + n2)));
+    HIPCHK(c, WS.cosPool.ensure(sizeof(double) * (size_t)n1 * n2));
     HIPCHK(c, hipMemcpyAsync(WS.probs.p, &pd, sizeof(pd), hipMemcpyHostToDevice, WS.stream));
     const int tiles = ((n1 + COS_TILE - 1) / COS_TILE) * ((n2 + COS_TILE - 1) / COS_TILE);
     hipLaunchKernelGGL(k_cos, dim3((unsigned)(((tiles + 3) / 4) * 8)), dim3(256), 0, WS.stream, D, 1, (tiles + 3) / 4, WS.probs.as<ProbDesc>(), WS.hFeats.as<double>(), WS.cosPool.as<double>());
@@ -1363,7 +1392,7 @@ int roman_debug_live(const roman_ctx_t* cc, int32_t* n_live, int32_t* idx, doubl
     if (!cc) return fail(nullptr, ROMAN_E_INVALID, "ctx is NULL");
     roman_ctx* c = const_cast<roman_ctx*>(cc);
     if (!c->last.scored) return fail(c, ROMAN_E_INVALID, "nothing scored yet");
-    const int L = c->last.tot.R;
+    const int L = c->last.L;
     if (n_live) *n_live = L;
     HIPCHK(c, hipSetDevice(c->device));
     if (idx && L > 0) HIPCHK(c, hipMemcpy(idx, WS.lp.p, sizeof(int32_t) * (size_t)L, hipMemcpyDeviceToHost));

@@ -10,7 +10,7 @@ import pytest
 from conftest import registration_for
 from roman_amd import synth
 from roman_amd.align import batch as rb
-from roman_amd.align.distributed import align_sharded, shard_bounds
+from roman_amd.align.distributed import align_sharded, deal_by_cost, problem_costs, shard_bounds, take
 from roman_amd.runtime import BatchResult, stats_dtype
 
 
@@ -39,13 +39,20 @@ def make_batch(reg):
     return rb.batch_from_submap_grid(reg, subs[:2], subs[2:])      # 2x2 = 4 problems... plus ragged sizes
 
 
-def _worker(rank, world, port, q):
+def make_grid_batch(reg):
+    """A small all-pairs grid (config 4's shape: S x S submaps of two robots over one shared pool) with ragged sizes."""
+    subs, _ = synth.make_submap_grid(6, n=20, d=0, seed0=43)
+    subs[1] = subs[1][:11]; subs[4] = subs[4][:15]
+    return rb.batch_from_submap_grid(reg, subs[:3], subs[3:])      # 3 x 3 = 9 problems dealt to 2 ranks
+
+
+def _worker(rank, world, port, q, which="pairs"):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         reg = registration_for("gravity")
-        batch = make_batch(reg)
+        batch = make_batch(reg) if which == "pairs" else make_grid_batch(reg)
         assoc, T, status = align_sharded(reg, batch, compute=oracle_compute)
         q.put((rank, [a.tolist() for a in assoc], T.tolist(), status.tolist()))
     finally:
@@ -60,6 +67,36 @@ def test_shard_bounds_partition():
             assert all(b[r][1] == b[r + 1][0] for r in range(w - 1))
             sizes = [hi - lo for lo, hi in b]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_cost_balanced_deal_is_a_partition_and_deterministic():
+    rng = np.random.default_rng(3)
+    for n, w in [(0, 2), (1, 4), (7, 2), (64, 8), (4096, 8), (4096, 3)]:
+        costs = rng.integers(1, 40000, size=n)
+        shards = deal_by_cost(costs, w)
+        assert len(shards) == w and sorted(np.concatenate(shards).tolist() if n else []) == list(range(n))
+        assert all(np.all(np.diff(s) > 0) for s in shards if len(s) > 1)          # ascending inside a shard
+        again = deal_by_cost(costs.copy(), w)
+        assert all(np.array_equal(a, b) for a, b in zip(shards, again))
+        if n >= 8 * w:
+            loads = np.array([costs[s].sum() for s in shards], dtype=np.float64)
+            assert loads.max() <= 1.05 * loads.mean() + costs.max()                # longest-first keeps the ranks level
+    # equal costs (the all-pairs grid of equal-sized submaps): every rank gets the same number of problems
+    shards = deal_by_cost(np.full(4096, 40000), 8)
+    assert [len(s) for s in shards] == [512] * 8
+
+
+def test_take_keeps_problem_semantics():
+    reg = registration_for("clipper+prune", cosine_min=0.5)
+    pairs = [(p.map1, p.map2) for p in (synth.make_pair(12 + k, 10, 16, 300 + k) for k in range(5))]
+    b = rb.batch_from_pairs(reg, pairs)
+    assert b.assoc is not None
+    sub = take(b, [4, 1, 2])
+    assert sub.feats is b.feats and len(sub) == 3 and sub.assoc_off[-1] == len(sub.assoc)
+    for k, i in enumerate([4, 1, 2]):
+        assert np.array_equal(sub.assoc[sub.assoc_off[k]:sub.assoc_off[k + 1]], b.assoc[b.assoc_off[i]:b.assoc_off[i + 1]])
+        assert (sub.off1[k], sub.n1[k], sub.off2[k], sub.n2[k]) == (b.off1[i], b.n1[i], b.off2[i], b.n2[i])
+    assert np.array_equal(problem_costs(b), np.diff(b.assoc_off))
 
 
 def test_record_roundtrip():
@@ -86,12 +123,13 @@ def test_batch_layout_shares_the_feature_pool():
     assert bp.n1.tolist() == [10, 10] and bp.n2.tolist() == [10, 0] and bp.assoc is None
 
 
-def test_world_size_2_gloo_matches_serial():
+@pytest.mark.parametrize("which", ["pairs", "grid"])
+def test_world_size_2_gloo_matches_serial(which):
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, which)) for r in range(2)]
     for p in procs:
         p.start()
     outs = [q.get(timeout=240) for _ in procs]
@@ -99,7 +137,7 @@ def test_world_size_2_gloo_matches_serial():
         p.join(timeout=60)
         assert p.exitcode == 0
     reg = registration_for("gravity")
-    batch = make_batch(reg)
+    batch = make_batch(reg) if which == "pairs" else make_grid_batch(reg)
     serial = oracle_compute(reg, batch)
     for rank, assoc, T, status in outs:
         assert len(assoc) == len(batch)

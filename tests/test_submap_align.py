@@ -187,3 +187,22 @@ def test_device_descriptor_gate_matches_pairwise_similarity():
         for j in range(5):
             ref = sa.Submap.similarity(sa.Submap(0, 0.0, [], np.eye(4), descriptor=A[i]), sa.Submap(1, 0.0, [], np.eye(4), descriptor=B[j]))
             assert abs(S[i, j] - ref) < 1e-12
+
+
+@pytest.mark.gpu
+def test_device_stacked_descriptor_gate_matches_pairwise_similarity():
+    """Stacked per-frame descriptors ([REF roman/map/map.py:152-162]): one cosine kernel over all frames of all
+    submaps + a segmented maximum equals Submap.similarity pair by pair (zero frames score 0)."""
+    from roman_amd.runtime import default_context
+    rng = np.random.default_rng(6)
+    d0 = [rng.standard_normal((k, 24)) for k in (3, 1, 5, 2)]
+    d1 = [rng.standard_normal((k, 24)) for k in (2, 4, 1)]
+    d0[2][1] = 0.0; d1[1][3] = 0.0                       # zero frames
+    d0[1][:] = 0.0                                       # a submap with only zero frames: similarity 0 with everything
+    S = sa.stacked_similarity(default_context(), d0, d1)
+    assert S.shape == (4, 3)
+    for i, a in enumerate(d0):
+        for j, b in enumerate(d1):
+            ref = sa.Submap.similarity(sa.Submap(0, 0.0, [], np.eye(4), descriptor=a), sa.Submap(1, 0.0, [], np.eye(4), descriptor=b))
+            assert abs(S[i, j] - ref) < 1e-12
+    assert np.all(S[1] == 0.0)
