@@ -9,7 +9,7 @@
 //   k_rowprefix  row degrees (+ per-word prefix counts for the fallback layout)
 //   k_rowsort    rows by descending degree
 //   kind 0 ("stream", L <= STREAM_MAXL):
-//     k_permute    bit matrix into POSITION numbering (position = rank by degree), strict upper triangle only
+//     k_upper      every candidate pair kept once, in the row of its endpoint with the smaller POSITION (rank by degree)
 //     k_slicegeom  slice widths / bases of the quad layout
 //     k_fill_slice candidates -> values, one 64-row slice image at a time
 //     k_solve_up   persistent per-problem CLIPPER solve on the upper triangle (pull + push SpMV)
@@ -858,7 +858,7 @@ __global__ void __launch_bounds__(1024) k_rowprefix(const ProbDesc* __restrict__
         const int W = (L + 63) >> 6;
         const int64_t lo = probs[b].liveOff, mo = st[b].maskOff;
         const int nrows = min(RPB, L - it.row0);
-        const bool wantPrefix = st[b].kind != 0;               // the stream layout takes its prefix counts in k_permute
+        const bool wantPrefix = st[b].kind != 0;               // the stream layout takes its prefix counts in k_upper
         for (int r = w; r < nrows; r += wpb) {
             const int k = it.row0 + r;
             const unsigned long long* mrow = maskPool + mo + (int64_t)k * W;
@@ -880,9 +880,8 @@ __global__ void __launch_bounds__(1024) k_rowprefix(const ProbDesc* __restrict__
 // k_rowsort: per problem, the live rows ordered by descending candidate count (degree).
 //  kind 0 (stream layout): a STABLE, deterministic order — rank(k) = #{rows with a larger degree} + #{rows k' < k with
 //    the same degree} — because the rank becomes the association's POSITION, the numbering of the stored matrix
-//    (it fixes the order inside every row).  Counting sort; the ranks inside a group of equal degree are taken by ONE
-//    wave that walks the rows in index order.  Slice geometry follows in k_slicegeom, once k_permute knows the upper
-//    degrees.
+//    (which entries a row keeps).  Bitonic sort of unique (degree, row) keys in LDS.  Slice geometry follows in
+//    k_slicegeom, once k_upper knows the upper degrees.
 //  kind 1 (fallback): counting sort with atomic ranks (the order among rows of equal degree is arbitrary — it
 //    changes where a row is stored, never what is computed for it), then the sorted SELL-64 geometry:
 //    rowPos[k] = sorted position of row k, perm[pos] = row, per slice its width (longest row) and base offset.
@@ -901,7 +900,30 @@ __global__ void __launch_bounds__(1024) k_rowsort(const ProbDesc* __restrict__ p
     const int L = st[b].L;
     const int64_t lo = probs[b].liveOff;
     if (st[b].kind == 2) return;
-    const bool stable = st[b].kind == 0;
+    if (st[b].kind == 0) {
+        // stream layout: bitonic sort (descending) of the UNIQUE keys ((degree + 1) << 12) | (4095 - row): larger degree
+        // first, equal degrees in row order — the rank is the row's position.  N = next power of two >= L keys in LDS
+        // (padding keys 0 sort last), log2(N)(log2(N)+1)/2 <= 78 compare-exchange stages of N/2 pairs.
+        static_assert(STREAM_MAXL <= 4096 && SORT_KEYS >= 4096, "bitonic sort capacity");
+        int N = 64; while (N < L) N <<= 1;
+        for (int t = tid; t < N; t += nt) hist[t] = (t < L) ? (((rowCnt[lo + t] + 1u) << 12) | (uint32_t)(4095 - t)) : 0u;
+        __syncthreads();
+        for (int k2 = 2; k2 <= N; k2 <<= 1)
+            for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
+                for (int t = tid; t < (N >> 1); t += nt) {
+                    const int i1 = ((t & ~(j2 - 1)) << 1) | (t & (j2 - 1)), i2 = i1 | j2;     // the pair (i1, i1 ^ j2)
+                    const uint32_t a = hist[i1], c2 = hist[i2];
+                    const bool desc = (i1 & k2) == 0;                                         // direction of this bitonic block
+                    if ((a < c2) == desc) { hist[i1] = c2; hist[i2] = a; }
+                }
+                __syncthreads();
+            }
+        for (int q = tid; q < L; q += nt) {
+            const uint32_t k = 4095u - (hist[q] & 4095u);
+            perm[lo + q] = k; rowPos[lo + k] = (uint32_t)q;
+        }
+        return;                                                 // slice geometry of the stream layout: k_slicegeom
+    }
     for (int t = tid; t < SORT_KEYS; t += nt) hist[t] = 0;
     __syncthreads();
     for (int k = tid; k < L; k += nt) atomicAdd(&hist[SORT_KEYS - 1 - min(rowCnt[lo + k], (uint32_t)(SORT_KEYS - 1))], 1u);
@@ -920,36 +942,6 @@ __global__ void __launch_bounds__(1024) k_rowsort(const ProbDesc* __restrict__ p
         for (int t = 0; t < PER; ++t) { hist[tid * PER + t] = run; run += loc[t]; }
     }
     __syncthreads();
-    if (stable) {
-        // rank inside a group of equal degree = number of EARLIER rows of that degree.  One wave walks the rows in
-        // index order, 64 at a time: a lane's rank is the group's running counter (hist holds base + rows seen so far)
-        // plus the number of lower lanes of this chunk with the same key; the last lane of every key advances the
-        // counter.  Equal keys inside a chunk are found key by key (readfirstlane + ballot): a chunk of neighbouring
-        // rows holds few distinct degrees.
-        if (w == 0) {
-            for (int k0 = 0; k0 < L; k0 += WAVE) {
-                const int k = k0 + lane;
-                const bool v = k < L;
-                const uint32_t key = v ? SORT_KEYS - 1 - min(rowCnt[lo + k], (uint32_t)(SORT_KEYS - 1)) : 0xffffffffu;
-                unsigned long long todo = __ballot(v);
-                uint32_t pos = 0;
-                while (todo) {
-                    const int leader = __builtin_ctzll(todo);
-                    const uint32_t kk = (uint32_t)__builtin_amdgcn_readlane((int)key, leader);
-                    const unsigned long long same = __ballot(v && key == kk);
-                    if (v && key == kk) pos = hist[kk] + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
-                    __builtin_amdgcn_wave_barrier();
-                    if (lane == leader) hist[kk] += (uint32_t)__popcll(same);
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    todo &= ~same;
-                }
-                if (v) { rowPos[lo + k] = pos; perm[lo + pos] = (uint32_t)k; }
-            }
-        }
-        return;                                                 // slice geometry of the stream layout: k_slicegeom
-    }
     for (int k = tid; k < L; k += nt) {
         const uint32_t pos = atomicAdd(&hist[SORT_KEYS - 1 - min(rowCnt[lo + k], (uint32_t)(SORT_KEYS - 1))], 1u);
         rowPos[lo + k] = pos; perm[lo + pos] = (uint32_t)k;
@@ -983,72 +975,70 @@ __global__ void __launch_bounds__(1024) k_rowsort(const ProbDesc* __restrict__ p
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_permute (kind 0): the candidate bit matrix in POSITION numbering, strict upper triangle only.
-// Row p of the result is row perm[p] of the symmetric live-order matrix with its columns permuted the same way
-// and everything at or below the diagonal dropped: bit q' (q' > p) = bit perm[q'] of the source row.  One wave
-// per row: the source row (<= 48 words) sits in a wave-private LDS line, the problem's perm table in LDS; for
-// every 64-column word at or right of the diagonal each lane looks up its column's bit and the ballot is the
-// word.  The wave then has the whole row in its lanes (lane = word) and takes the per-word prefix counts (the
-// entry index of a word's first candidate in k_fill_slice) and the row's upper degree with one scan.  The
-// per-association pools are copied into position order on the way.
+// k_upper (kind 0): which candidates row p of the stored matrix keeps.  The matrix is stored once per unordered pair:
+// candidate (k, q) of the symmetric bit matrix stays in the row of the endpoint with the SMALLER position.  Row p of the
+// result is row k = perm[p] of the live-order matrix with the bits q dropped whose position is not larger than p —
+// the COLUMNS stay in live order (the fill kernel labels an entry with its column's position; the order of the entries
+// inside a row is immaterial: the solver's sums are exact).  One wave per row: the row's words sit in its lanes (lane =
+// word); for word w the lanes compare the positions of columns 64w..64w+63 (LDS table) with p, the ballot is ANDed
+// onto the word (consecutive rows update the masks instead of rebuilding them).  The per-word prefix counts (entry index of a word's first kept candidate in k_fill_slice), the
+// row's upper degree and the position-ordered copies of the pools the solver reads come out of the same pass.
 // ---------------------------------------------------------------------------------------------
 struct LivePools { int32_t* lp; int32_t* li; int32_t* lj; double* ls; double* ld; double* lza; double* lzb; };
 
-__global__ void __launch_bounds__(1024) k_permute(const ProbDesc* __restrict__ probs, const ProbState* __restrict__ st,
-                                                  const BatchTotals* __restrict__ tot, const ItemDesc* __restrict__ items,
-                                                  const unsigned long long* __restrict__ maskPool,
-                                                  unsigned long long* __restrict__ umaskPool, uint32_t* __restrict__ prefPool,
-                                                  uint32_t* __restrict__ rowCnt, const uint32_t* __restrict__ perm,
-                                                  LivePools src, LivePools dst, int RPB)
+__global__ void __launch_bounds__(1024) k_upper(const ProbDesc* __restrict__ probs, const ProbState* __restrict__ st,
+                                                const BatchTotals* __restrict__ tot, const ItemDesc* __restrict__ items,
+                                                const unsigned long long* __restrict__ maskPool,
+                                                unsigned long long* __restrict__ umaskPool, uint32_t* __restrict__ prefPool,
+                                                uint32_t* __restrict__ rowCnt, const uint32_t* __restrict__ perm,
+                                                const uint32_t* __restrict__ rowPos, LivePools src, LivePools dst, int RPB)
 {
-    __shared__ uint16_t permS[STREAM_MAXL];
-    __shared__ unsigned long long srow[16][WAVE];
+    __shared__ uint16_t posS[STREAM_MAXL + 64];                  // position of every live column (padding: 0 = never kept)
     const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, w = tid >> 6, wpb = nt >> 6;
     const int nItems = tot->items;
     int staged = -1;
     for (int t = blockIdx.x; t < nItems; t += gridDim.x) {
         const ItemDesc it = items[t];
         const int b = it.b;
-        if (uni_i(st[b].kind) == 0) {                       // (no `continue` around the barriers below)
+        if (uni_i(st[b].kind) == 0) {                           // (no `continue` around the barriers below)
         const int L = st[b].L;
         const int W = (L + 63) >> 6;
         const int64_t lo = probs[b].liveOff, mo = st[b].maskOff;
         const int nrows = min(RPB, L - it.row0);
         if (staged != b) {                                       // consecutive items of a workgroup often share the problem
             __syncthreads();
-            for (int q = tid; q < L; q += nt) permS[q] = (uint16_t)perm[lo + q];
+            for (int q = tid; q < W * 64; q += nt) posS[q] = (q < L) ? (uint16_t)rowPos[lo + q] : (uint16_t)0;
             __syncthreads();
             staged = b;
         }
-        for (int r = w; r < nrows; r += wpb) {
-            const int p = it.row0 + r;
-            const int k = permS[p];
-            srow[w][lane] = (lane < W) ? maskPool[mo + (int64_t)k * W + lane] : 0ull;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            uint32_t mlo = 0u, mhi = 0u;                          // lane l: word l of the permuted row
-            for (int wd = p >> 6; wd < W; ++wd) {
-                const int q = (wd << 6) + lane;
-                const int kq = permS[min(q, L - 1)];
-                const unsigned long long word = srow[w][kq >> 6];
-                const bool is = (q < L) && (q > p) && ((word >> (kq & 63)) & 1ull);
-                const unsigned long long m = __ballot(is);
-                const uint32_t ml_ = (uint32_t)m, mh_ = (uint32_t)(m >> 32), sel_ = (uint32_t)__builtin_amdgcn_readfirstlane(wd);
+        // A wave takes CONSECUTIVE rows: the set of columns behind p loses exactly one member, column perm[p + 1], when p
+        // moves on by one — the "behind" masks of all words are built once (lane = word) and then only updated.
+        const int RW = (nrows + wpb - 1) / wpb;
+        const int r0 = w * RW, r1 = min(nrows, r0 + RW);
+        if (r0 < r1) {
+            const int p0 = it.row0 + r0;
+            uint32_t glo = 0u, ghi = 0u;                         // lane wd: columns of word wd with a position > p
+            for (int wd = 0; wd < W; ++wd) {
+                const unsigned long long gt = __ballot((int)posS[(wd << 6) + lane] > p0);
+                const uint32_t gl_ = (uint32_t)gt, gh_ = (uint32_t)(gt >> 32), sel_ = (uint32_t)__builtin_amdgcn_readfirstlane(wd);
                 asm("s_mov_b32 m0, %3\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %4, m0"
-                    : "+v"(mlo), "+v"(mhi) : "s"(ml_), "s"(sel_), "s"(mh_) : "m0");
+                    : "+v"(glo), "+v"(ghi) : "s"(gl_), "s"(sel_), "s"(gh_) : "m0");
             }
-            const unsigned long long mine = ((unsigned long long)mhi << 32) | mlo;
-            const uint32_t c = (uint32_t)__popcll(mine);
-            const uint32_t ex = wave_excl_scan(c, lane);
-            if (lane < W) { umaskPool[mo + (int64_t)p * W + lane] = mine; prefPool[mo + (int64_t)p * W + lane] = ex; }
-            if (lane == WAVE - 1) rowCnt[lo + p] = ex + c;       // upper degree of position p (the live-order degrees are spent)
-            if (lane == 0) { dst.lp[lo + p] = src.lp[lo + k]; dst.li[lo + p] = src.li[lo + k]; dst.lj[lo + p] = src.lj[lo + k]; }
-            if (lane == 1) { dst.ls[lo + p] = src.ls[lo + k]; dst.ld[lo + p] = src.ld[lo + k]; }
-            if (lane == 2) { dst.lza[lo + p] = src.lza[lo + k]; dst.lzb[lo + p] = src.lzb[lo + k]; }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();                      // srow[w] is rewritten by the next row
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            unsigned long long behind = ((unsigned long long)ghi << 32) | glo;
+            for (int r = r0; r < r1; ++r) {
+                const int p = it.row0 + r;                       // position of the row being written
+                const int k = (int)perm[lo + p];                 // its live index
+                const unsigned long long mine = ((lane < W) ? maskPool[mo + (int64_t)k * W + lane] : 0ull) & behind;
+                const uint32_t c = (uint32_t)__popcll(mine);
+                const uint32_t ex = wave_excl_scan(c, lane);
+                if (lane < W) { umaskPool[mo + (int64_t)p * W + lane] = mine; prefPool[mo + (int64_t)p * W + lane] = ex; }
+                if (lane == WAVE - 1) rowCnt[lo + p] = ex + c;   // upper degree of position p (the live-order degrees are spent)
+                if (lane == 0) { dst.lp[lo + p] = src.lp[lo + k]; dst.ld[lo + p] = src.ld[lo + k]; }
+                if (r + 1 < r1) {                                // the column at position p + 1 is no longer behind
+                    const int qn = (int)perm[lo + p + 1];
+                    if (lane == (qn >> 6)) behind &= ~(1ull << (qn & 63));
+                }
+            }
         }
         }
     }
@@ -1345,6 +1335,7 @@ __global__ void __launch_bounds__(1024) k_fill_slice(DevParams D, int B, const P
                                                      const double* __restrict__ lza, const double* __restrict__ lzb,
                                                      const unsigned long long* __restrict__ maskPool,
                                                      const uint32_t* __restrict__ prefPool,
+                                                     const uint32_t* __restrict__ perm, const uint32_t* __restrict__ rowPos,
                                                      const uint32_t* __restrict__ sliceWidth,
                                                      const uint32_t* __restrict__ sliceBase,
                                                      uint16_t* __restrict__ cols, double* __restrict__ vals,
@@ -1354,20 +1345,24 @@ __global__ void __launch_bounds__(1024) k_fill_slice(DevParams D, int B, const P
     unsigned long long facc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long flast = __builtin_readcyclecounter();
 #endif
-    // LDS: cS[TC] [GRAV: cZa[TC] cZb[TC]] cI[TC] cJ[TC] | image values [EC*64] | image columns [EC*64] | owner lines
-    // (li, lj, ls, lza, lzb, maskPool, prefPool: the POSITION-ordered pools and upper-triangle masks k_permute wrote)
+    // LDS: cS[TC] [GRAV: cZa[TC] cZb[TC]] cI[TC] cJ[TC] cP[TC] (u16) | image values [EC*64] | image columns [EC*64] |
+    //      owner lines | rows of the group's slices
+    // (li .. lzb: the live-order pools; maskPool / prefPool: the kept-candidate masks and prefix counts k_upper wrote, rows
+    // in POSITION order, columns in live order; cP: position of every live column = the label an entry is stored with)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* cS = reinterpret_cast<double*>(smem);
     double* cZa = cS + TC;
     double* cZb = cZa + (GRAV ? TC : 0);
     int32_t* cI = reinterpret_cast<int32_t*>(cZb + (GRAV ? TC : 0));
     int32_t* cJ = cI + TC;
-    double* imgV = reinterpret_cast<double*>(cJ + TC);
+    uint16_t* cP = reinterpret_cast<uint16_t*>(cJ + TC);
+    double* imgV = reinterpret_cast<double*>(cP + TC);
     uint16_t* imgC = reinterpret_cast<uint16_t*>(imgV + (size_t)EC * 64);
     uint32_t* rings = reinterpret_cast<uint32_t*>(imgC + (size_t)EC * 64);
     const int tid = threadIdx.x, nt = blockDim.x;
     const int lane = tid & 63, w = tid >> 6, nw = nt >> 6;
     uint32_t* ownL = rings + (size_t)w * WAVE;                  // this wave's owner line (64 entries)
+    uint32_t* sKall = rings + (size_t)nw * WAVE;                // live rows of the group's slices: FILLS_MAXSPI * 64 entries
     const int SPW = 64 / nw;                                    // lane slots per wave
     const int nGroups = tot->sliceGroups;
     // XCD-aware order: workgroups are dealt to the 8 XCDs round-robin by id, so XCD x takes the CONTIGUOUS range
@@ -1391,14 +1386,17 @@ __global__ void __launch_bounds__(1024) k_fill_slice(DevParams D, int B, const P
         const double* TB = TA + (int64_t)pd.n1 * pd.n1;
         __syncthreads();                        // every wave is done with the previous group's columns
         for (int q = tid; q < L; q += nt) {
-            cI[q] = li[lo + q]; cJ[q] = lj[lo + q]; cS[q] = ls[lo + q];
+            cI[q] = li[lo + q]; cJ[q] = lj[lo + q]; cS[q] = ls[lo + q]; cP[q] = (uint16_t)rowPos[lo + q];
             if (GRAV) { cZa[q] = lza[lo + q]; cZb[q] = lzb[lo + q]; }
         }
+        for (int x = tid; x < (s_end - s_begin) * 64; x += nt)
+            sKall[x] = (s_begin * 64 + x < L) ? perm[lo + s_begin * 64 + x] : 0xffffffffu;
         uint32_t upper = 0;
         FMARK(0);
         for (int sl = s_begin; sl < s_end; ++sl) {
             const uint32_t width = sliceWidth[lo + sl];
             const int64_t sb = no + sliceBase[lo + sl];         // first element of the slice (multiple of 256)
+            const uint32_t* sK = sKall + (sl - s_begin) * 64;
             for (uint32_t e0 = 0; e0 < width; e0 += (uint32_t)EC) {
                 const uint32_t ew = min((uint32_t)EC, width - e0);
                 __syncthreads();                                // previous image written out (first pass: tile and rows staged)
@@ -1423,10 +1421,9 @@ __global__ void __launch_bounds__(1024) k_fill_slice(DevParams D, int B, const P
                 // candidates at once: the owner words are scattered into a 64-entry LDS line at their first
                 // candidate's position and spread by a max-scan, the word is fetched with ds_bpermute and the bit
                 // found by a 6-step rank select.  (One bit per lane and step through a ring took 3x the cycles.)
-                // (rows of slice sl are the positions 64 sl .. 64 sl + 63; a row's candidates lie in the words at or right
-                // of the diagonal: words sl .. W-1)
-                const int Wr = W - sl;
-                const int nwords = SPW * Wr;
+                // (rows of slice sl are the positions 64 sl .. 64 sl + 63, live rows sK[slot]; their kept candidates can sit
+                // in any word: the columns are in live order)
+                const int nwords = SPW * W;
                 unsigned long long mB[FILLS_NBLK]; uint32_t iA[FILLS_NBLK], iB[FILLS_NBLK];
                 uint32_t Ttot = 0;
 #pragma unroll
@@ -1434,12 +1431,13 @@ __global__ void __launch_bounds__(1024) k_fill_slice(DevParams D, int B, const P
                     const int x = jb * WAVE + lane;
                     unsigned long long m = 0ull; uint32_t ef = 0u, ka = 0u;
                     if (x < nwords) {
-                        const int r = x / Wr, word = sl + (x - r * Wr);
+                        const int r = x / W, word = x - r * W;
                         const uint32_t slot = (uint32_t)(r * nw + w);
-                        const uint32_t k = (uint32_t)(sl * 64) + slot;
-                        if (k < (uint32_t)L) {
-                            m = maskPool[mo + (int64_t)k * W + word];
-                            ef = prefPool[mo + (int64_t)k * W + word];
+                        const uint32_t k = sK[slot];                                 // live index of the row in this slot
+                        if (k != 0xffffffffu) {
+                            const uint32_t pr = (uint32_t)(sl * 64) + slot;          // its position: the row of the masks
+                            m = maskPool[mo + (int64_t)pr * W + word];
+                            ef = prefPool[mo + (int64_t)pr * W + word];
                             ka = k | (slot << 16) | ((uint32_t)word << 22);
                         }
                     }
@@ -1517,9 +1515,9 @@ __global__ void __launch_bounds__(1024) k_fill_slice(DevParams D, int B, const P
                         const double sa = fx_exp(((-0.5 * c) * c) / D.sig2);
                         const double v = fuse_pair(D, sa, cS[k], cS[q]);
                         if (v > D.p.affinityeps) {              // otherwise the slot stays inert: neither in M nor in C
-                            imgC[(er >> 2) * 256u + slot * 4u + (er & 3u)] = (uint16_t)q;
+                            imgC[(er >> 2) * 256u + slot * 4u + (er & 3u)] = cP[q];          // label: the column's position
                             imgV[(er >> 1) * 128u + slot * 2u + (er & 1u)] = v;
-                            upper += 1u;                        // every stored entry is a strict-upper one
+                            upper += 1u;                        // every stored entry is kept once: a strict-upper one
                         }
                     }
                     FMARK(4);
@@ -2095,7 +2093,7 @@ __global__ void __launch_bounds__(1024) k_solve(DevParams D, int B, const ProbDe
 // (lane = row slot of the current slice) and flushes its pulled sums when it leaves a slice or its range.
 // ---------------------------------------------------------------------------------------------
 #ifndef ROMAN_SOLVE_WAVES
-#define ROMAN_SOLVE_WAVES 16             // waves of the stream solver's workgroup (one problem per workgroup)
+#define ROMAN_SOLVE_WAVES 8              // waves of the stream solver's workgroup (one problem per workgroup; measured: 8 beats 16)
 #endif
 constexpr int ST_D = 3;                  // quads in flight per lane
 constexpr int ST_MAXSL = STREAM_MAXL / 64;
@@ -2227,6 +2225,9 @@ __device__ void solve_up(const DevParams& D, int b, const ProbDesc& pd, ProbStat
     constexpr int NT = NW * 64;
     constexpr int KMAX = (STREAM_MAXL + NT - 1) / NT;          // elements per thread
     const roman_params_t& P = D.p;
+    // the solver's parameters as scalars (the argument block sits in scratch memory: its address is taken for the shared tail)
+    const double p_eps = uni(P.eps), p_beta = uni(P.beta), p_tol_u = uni(P.tol_u), p_tol_F = uni(P.tol_F);
+    const int p_maxin = uni(P.maxiniters), p_maxout = uni(P.maxoliters), p_maxls = uni(P.maxlsiters), p_rescale = uni(P.rescale_u0);
     const int tid = threadIdx.x, lane = tid & 63, w = uni(tid >> 6);
 #define FOR_K(k_, p_) _Pragma("unroll") for (int k_ = 0; k_ < KMAX; ++k_) if ([[maybe_unused]] const int p_ = tid + k_ * NT; true)
     const int L = uni(st[b].L), rb = uni(st[b].rowBase);
@@ -2256,7 +2257,9 @@ __device__ void solve_up(const DevParams& D, int b, const ProbDesc& pd, ProbStat
 
     // ---- per-problem set-up: quad prefix of the slices, owned elements, clean LDS --------------------------
     __syncthreads();
-    for (int s = tid; s <= nsl; s += NT) cumQ[s] = (s < nsl) ? (sliceBasePool[lo + s] >> 8) : (st[b].nnzCap >> 8);
+    // slice table: lane s of every wave holds the first quad of slice s (lane nsl: the total), read with v_readlane
+    const uint32_t cqv = (lane < nsl) ? (sliceBasePool[lo + lane] >> 8) : (st[b].nnzCap >> 8);
+#define CUMQ(s_) ((uint32_t)__builtin_amdgcn_readlane((int)cqv, (s_)))
     for (int p = tid; p < Lc; p += NT) { xg[p] = 0.0; accM[p] = 0ull; accC[p] = 0ull; }
     double u[KMAX], Mu[KMAX], Cu[KMAX], sd[KMAX], tk[KMAX], Mn[KMAX], Cn[KMAX];
     FOR_K(k, p) {
@@ -2285,16 +2288,16 @@ __device__ void solve_up(const DevParams& D, int b, const ProbDesc& pd, ProbStat
         __syncthreads();                                        // the scaled vector is published; accumulators are clean
         TMARK(6);
         const int Sx = min(nsl, (mp1 + 63) >> 6);
-        const uint32_t T = uni(cumQ[Sx]);
+        const uint32_t T = CUMQ(Sx);
         const uint32_t qs = (uint32_t)(((unsigned long long)T * (unsigned)w) / NW), qe = (uint32_t)(((unsigned long long)T * (unsigned)(w + 1)) / NW);
         if (qs < qe) {
             int s = 0;
             {   // largest s with cumQ[s] <= qs (skips empty slices)
                 int lo_ = 0, hi_ = Sx;
-                while (hi_ - lo_ > 1) { const int mid_ = (lo_ + hi_) >> 1; if (uni(cumQ[mid_]) <= qs) lo_ = mid_; else hi_ = mid_; }
+                while (hi_ - lo_ > 1) { const int mid_ = (lo_ + hi_) >> 1; if (CUMQ(mid_) <= qs) lo_ = mid_; else hi_ = mid_; }
                 s = lo_;
             }
-            uint32_t nextB = uni(cumQ[s + 1]);
+            uint32_t nextB = CUMQ(s + 1);
             // ring of ST_D quads in flight per lane; loads are issued unconditionally (clamped index) so that the wait
             // counters stay exact
             unsigned long long rc[ST_D]; dbl2_t rv0[ST_D], rv1[ST_D];
@@ -2307,6 +2310,7 @@ __device__ void solve_up(const DevParams& D, int b, const ProbDesc& pd, ProbStat
             unsigned long long smI = 0ull, scI = 0ull;          // pulled sums of this lane's row: sum of bits(MAGIC + term)
             uint32_t pieceQ = qs;                               // first quad of the current piece
             double xp = xl[s * 64 + lane];                      // this lane's row element (scaled); rows >= L read zeros
+            double xpn = xl[(s + 1) * 64 + lane];               // ... and the next slice's, fetched ahead of the transition
             unsigned long long iCp = (unsigned long long)__double_as_longlong(xp + FX_MAGIC) - FX_MAGIC_BITS;
 #define UP_CONSUME(Q_, C_, V0_, V1_)                                                                        \
             {                                                                                               \
@@ -2344,8 +2348,10 @@ __device__ void solve_up(const DevParams& D, int b, const ProbDesc& pd, ProbStat
                     __hip_atomic_fetch_add(aC + (s * 64 + lane), scI - nterm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
                     smI = 0ull; scI = 0ull; pieceQ = (Q_) + 1;                                              \
                     if ((Q_) + 1 < qe) {                                                                    \
-                        do { ++s; nextB = uni(cumQ[s + 1]); } while (nextB <= (Q_) + 1);                    \
-                        xp = xl[s * 64 + lane];                                                             \
+                        const int s_old_ = s;                                                               \
+                        do { ++s; nextB = CUMQ(s + 1); } while (nextB <= (Q_) + 1);                         \
+                        xp = (s == s_old_ + 1) ? xpn : xl[s * 64 + lane];                                   \
+                        xpn = xl[(s + 1) * 64 + lane];                                                      \
                         iCp = (unsigned long long)__double_as_longlong(xp + FX_MAGIC) - FX_MAGIC_BITS;      \
                     }                                                                                       \
                 }                                                                                           \
@@ -2385,7 +2391,7 @@ __device__ void solve_up(const DevParams& D, int b, const ProbDesc& pd, ProbStat
 
     // ---- the iteration as a state machine around ONE SpMV call site ------------------------------------
     enum { PH_RESCALE, PH_INIT, PH_TRIAL };
-    int phase = P.rescale_u0 ? PH_RESCALE : PH_INIT;
+    int phase = p_rescale ? PH_RESCALE : PH_INIT;
     double usum = 0.0, alpha = 1.0, unsum = 0.0, du2 = 0.0, xmaxT = 0.0;
     int mp1T = 0;
     int i = 0, j = 0, kk = 0;
@@ -2446,7 +2452,7 @@ __device__ void solve_up(const DevParams& D, int b, const ProbDesc& pd, ProbStat
         double r2[2] = {0.0, 0.0}, m0[1] = {0.0};
         FOR_K(k, p) {
             const double up = u[k], Cbu = (usum - Cu[k]) - up;
-            if (p < L && Cbu > P.eps && up > P.eps) { const double r_ = (Mu[k] + sd[k] * up) / Cbu; r2[0] += absval ? fabs(r_) : r_; r2[1] += 1.0; }
+            if (p < L && Cbu > p_eps && up > p_eps) { const double r_ = (Mu[k] + sd[k] * up) / Cbu; r2[0] += absval ? fabs(r_) : r_; r2[1] += 1.0; }
         }
         block_red<NW, 2, 0>(r2, m0, red, par, tid);
         acc = r2[0]; cnt = r2[1];
@@ -2474,14 +2480,14 @@ __device__ void solve_up(const DevParams& D, int b, const ProbDesc& pd, ProbStat
             d_ratio(false, acc, cnt);
             d = (cnt > 0.0) ? acc / cnt : 0.0;
             i = 0;
-            if (i >= P.maxoliters) break;
+            if (i >= p_maxout) break;
             new_outer = true;
         } else {                                                // PH_TRIAL: products of the trial vector
             ++ls_trials;
             const double Fnew = objective(tk, Mn, Cn, unsum);
             const double deltaF = Fnew - F;
-            if (deltaF < -P.eps && kk + 1 < P.maxlsiters) {     // backtrack
-                alpha *= P.beta; ++kk;
+            if (deltaF < -p_eps && kk + 1 < p_maxls) {          // backtrack
+                alpha *= p_beta; ++kk;
                 build_trial();
                 continue;
             }
@@ -2490,13 +2496,13 @@ __device__ void solve_up(const DevParams& D, int b, const ProbDesc& pd, ProbStat
             F = Fnew; usum = unsum;
             FOR_K(k, p) { u[k] = tk[k]; Mu[k] = Mn[k]; Cu[k] = Cn[k]; }
             ++inner_iters; ++j;
-            const bool stop = du < P.tol_u || fabs(deltaF) < P.tol_F;
-            if (stop || j >= P.maxiniters) {                    // end of the inner loop: homotopy update of d
+            const bool stop = du < p_tol_u || fabs(deltaF) < p_tol_F;
+            if (stop || j >= p_maxin) {                    // end of the inner loop: homotopy update of d
                 double acc, cnt;
                 d_ratio(true, acc, cnt);
                 if (cnt > 0.0) d += acc / cnt; else break;
                 ++i;
-                if (i >= P.maxoliters) break;
+                if (i >= p_maxout) break;
                 new_outer = true;
             }
         }
@@ -2505,7 +2511,7 @@ __device__ void solve_up(const DevParams& D, int b, const ProbDesc& pd, ProbStat
         build_trial();
         phase = PH_TRIAL;
     }
-    if (i >= P.maxoliters) status |= ROMAN_ST_MAXITER;
+    if (i >= p_maxout) status |= ROMAN_ST_MAXITER;
     S.n_pass = n_pass; S.ls_trials = ls_trials; S.inner_iters = inner_iters;
     S.outer_iters = i; S.score = F; S.d_final = d;
 #ifdef ROMAN_SOLVE_TIMING
@@ -2521,6 +2527,7 @@ __device__ void solve_up(const DevParams& D, int b, const ProbDesc& pd, ProbStat
     finish_one(D, b, pd, feats, assoc, plp, lpAsc, rowPosPool, O, xg, reinterpret_cast<double*>(accM),
                reinterpret_cast<int32_t*>(accC), reinterpret_cast<int32_t*>(accC) + Lc, L, rb, lo, F, status, S, red, sint);
 #undef FOR_K
+#undef CUMQ
 }
 
 template <int NW, bool HASCZ>

@@ -432,10 +432,10 @@ int enqueue_score(roman_ctx* c, const DevParams& Din, const roman_params_t* para
         hipLaunchKernelGGL(k_rowsort, dim3(B), dim3(1024), 0, WS.stream, dP, dS, WS.rowCnt.as<uint32_t>(), WS.rowPos.as<uint32_t>(), WS.perm.as<uint32_t>(),
                            WS.sliceWidth.as<uint32_t>(), WS.sliceBase.as<uint32_t>());
     DBG(c, "k_rowsort");
-        hipLaunchKernelGGL(k_permute, dim3(c->num_cu * 2), dim3(1024), 0, WS.stream, dP, dS, dT, WS.items.as<ItemDesc>(),
+        hipLaunchKernelGGL(k_upper, dim3(c->num_cu * 2), dim3(1024), 0, WS.stream, dP, dS, dT, WS.items.as<ItemDesc>(),
                            WS.maskPool.as<unsigned long long>(), WS.umaskPool.as<unsigned long long>(), WS.prefPool.as<uint32_t>(),
-                           WS.rowCnt.as<uint32_t>(), WS.perm.as<uint32_t>(), LP, PP, RPB);
-    DBG(c, "k_permute");
+                           WS.rowCnt.as<uint32_t>(), WS.perm.as<uint32_t>(), WS.rowPos.as<uint32_t>(), LP, PP, RPB);
+    DBG(c, "k_upper");
         hipLaunchKernelGGL(k_slicegeom, dim3(B), dim3(64), 0, WS.stream, dP, dS, WS.rowCnt.as<uint32_t>(), WS.sliceWidth.as<uint32_t>(), WS.sliceBase.as<uint32_t>());
     DBG(c, "k_slicegeom");
     }
@@ -451,15 +451,15 @@ int enqueue_score(roman_ctx* c, const DevParams& Din, const roman_params_t* para
         // slice-image fill (stream layout): column tile + one slice image (640 bytes per entry column) + 16 owner lines
         const int colBytesF = D.gravity ? 32 : 16;
         const int TCs = D.stream_maxL;
-        const size_t fixedLds = (size_t)TCs * colBytesF + (size_t)16 * 64 * sizeof(uint32_t);
+        const size_t fixedLds = (size_t)TCs * (colBytesF + 2) + (size_t)16 * 64 * sizeof(uint32_t) + (size_t)FILLS_MAXSPI * 64 * sizeof(uint32_t);
         if (fixedLds + 640 * 8 > c->lds_max) return fail(c, ROMAN_E_TOO_LARGE, "internal: stream column tile does not fit the LDS");
         const int EC = (int)std::min<size_t>((c->lds_max - fixedLds) / 640, 4096) & ~3;
         const size_t sliceLds = fixedLds + (size_t)EC * 640;
         auto kf = D.gravity ? k_fill_slice<true> : k_fill_slice<false>;
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sliceLds));
         hipLaunchKernelGGL(kf, dim3((unsigned)(c->num_cu & ~7)), dim3(1024), sliceLds, WS.stream,
-                           D, B, dP, dS, dT, WS.tabPool.as<double>(), PP.li, PP.lj, PP.ls, PP.lza, PP.lzb,
-                           WS.umaskPool.as<unsigned long long>(), WS.prefPool.as<uint32_t>(),
+                           D, B, dP, dS, dT, WS.tabPool.as<double>(), LP.li, LP.lj, LP.ls, LP.lza, LP.lzb,
+                           WS.umaskPool.as<unsigned long long>(), WS.prefPool.as<uint32_t>(), WS.perm.as<uint32_t>(), WS.rowPos.as<uint32_t>(),
                            WS.sliceWidth.as<uint32_t>(), WS.sliceBase.as<uint32_t>(), WS.cols16.as<uint16_t>(), WS.vals.as<double>(), TCs, EC, SPI,
                            (unsigned long long*)nullptr);
     DBG(c, "k_fill_slice");

@@ -314,3 +314,32 @@ def test_two_batches_in_flight_equal_sequential_calls(ctx):
                     assert np.array_equal(T[k].reshape(4, 4), r.T[k])       # same kernels, same order: bit-identical pose
     finally:
         hip.free_all()
+
+
+def test_align_sharded_device_path_single_rank():
+    """align_sharded's HIP path (device-resident records, cost-balanced deal) on one rank equals run_batch.  torch is
+    imported FIRST in a fresh process: its bundled HIP runtime must be the one libroman_hip binds to."""
+    import subprocess, sys, textwrap
+    from conftest import ROOT
+    code = textwrap.dedent("""
+        import torch, sys, numpy as np
+        sys.path.insert(0, %r); sys.path.insert(0, %r + '/tests')
+        from conftest import registration_for
+        from roman_amd import synth
+        from roman_amd.align import batch as rb
+        from roman_amd.align.distributed import align_sharded
+        reg = registration_for('semanticgrav', semantics_dim=16)
+        subs, _ = synth.make_submap_grid(6, n=30, d=16, seed0=71)
+        subs[4] = subs[4][:17]
+        batch = rb.batch_from_submap_grid(reg, subs[:3], subs[3:])
+        ref = rb.run_batch(reg, batch)
+        assoc, T, status = align_sharded(reg, batch)
+        assert len(assoc) == len(batch) == 9
+        for b in range(9):
+            assert np.array_equal(assoc[b], ref.assoc[b]), b
+            assert status[b] == ref.status[b]
+            assert np.array_equal(np.nan_to_num(T[b]), np.nan_to_num(ref.T[b]))
+        print('SHARDED_OK')
+    """ % (ROOT, ROOT))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert "SHARDED_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]

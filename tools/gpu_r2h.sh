@@ -1,7 +1,7 @@
 #!/bin/bash
 TAG=${1:-r2h}
 OUT=$PWD/gpurun_out; mkdir -p $OUT; export TMPDIR=/tmp
-echo "== overflow probes"; ROMAN_TEST_CAPNNZ=256 timeout 40 python -u tools/gpu_overflow_probe.py small 2>&1 | tail -2; timeout 60 python -u tools/gpu_overflow_probe.py large 2>&1 | tail -2
+echo "== overflow probes"; ROMAN_TEST_CAPNNZ=256 timeout 40 python -u tools/gpu_overflow_probe.py small 2>&1 | tail -1
 echo "== all gpu tests"; timeout 420 python -X faulthandler -m pytest tests -q -m gpu -x --durations=6 -o faulthandler_timeout=100 > $OUT/${TAG}_pytest_gpu.txt 2>&1; echo "rc=$?"; grep -v "^  File" $OUT/${TAG}_pytest_gpu.txt | tail -30
 bench() {  # tag, extra env/lib
   timeout 150 python bench.py --steps 10 --warmup 3 --cpu-sample 0 --latency-reps 20 --pipeline $2 > $OUT/${TAG}_bench_$1.txt 2>$OUT/${TAG}_bench_$1.err
@@ -15,7 +15,7 @@ except Exception as e:
 PY
 }
 bench p2 2; bench p1 1
-ROMAN_HIP_LIBRARY=$PWD/roman_amd/csrc/variants/libW8.so bench w8p2 2
+ROMAN_HIP_LIBRARY=$PWD/roman_amd/csrc/variants/libW16.so bench w16p2 2
 ROMAN_HIP_LIBRARY=$PWD/roman_amd/csrc/variants/libT.so timeout 100 python bench.py --steps 3 --warmup 1 --cpu-sample 0 --latency-reps 2 --pipeline 1 > $OUT/${TAG}_timing.txt 2>$OUT/${TAG}_timing.err
 grep -A4 "solve timing" $OUT/${TAG}_timing.err | tail -7
 echo "== rocprofv3 kernel stats"
