@@ -247,6 +247,7 @@ def main():
 
     # ---- p50 single-pair latency (config 2: B=1) ----------------------------------------------------
     p50 = None
+    lat_break = None
     if rank == 0 and args.latency_reps >= 0:          # --latency-reps -1: batched launches only (counter passes)
         lat = []
         for r in range(args.latency_reps + 3):
@@ -257,6 +258,20 @@ def main():
             if r >= 3:
                 lat.append(time.perf_counter() - t1)
         p50 = float(np.median(lat) * 1e3)
+        # where a single pair's time goes: host enqueue time of the call, and the stages' device time (hipEvents)
+        enq = []; stg = []
+        for r in range(5):
+            ctx.profile_enable(True); ctx.profile_reset()
+            torch.cuda.synchronize(dev); t1 = time.perf_counter()
+            ctx.align_batch_dev(P, feats.data_ptr(), F, o1[:1], a1[:1], o2[:1], a2[:1], kmax,
+                                assoc_o[1].data_ptr(), n_o[1].data_ptr(), T_o[1].data_ptr(), status_o[1].data_ptr(), stats_o[1].data_ptr())
+            enq.append(time.perf_counter() - t1)
+            torch.cuda.synchronize(dev)
+            g = ctx.profile_get(); ctx.profile_enable(False)
+            stg.append({k: v[0] for k, v in g.items()})
+        lat_break = {"host_enqueue_ms": float(np.median(enq) * 1e3),
+                     "stage_ms": {k: float(np.median([x[k] for x in stg])) for k in stg[0]},
+                     "note": "B=1, stage timers on (they add event records to the call)"}
     if world > 1:
         dist.barrier()
 
@@ -277,6 +292,7 @@ def main():
                    "sharding": f"pairs x{world}, all_gather of records" if world > 1 else "single GPU",
                    "batches_in_flight": args.pipeline},
         "p50_latency_ms": p50,
+        "latency_breakdown": lat_break,
         "alignments_per_s_batch1": (1e3 / p50) if p50 else None,
         "register_only": {"note": "the reference times register() alone; the pose is fused into the solver kernel's tail here, so the split is "
                                   "measured as the stand-alone pose entry on the same correspondences (host-pointer call, copies included: an upper bound)",

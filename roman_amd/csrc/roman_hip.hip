@@ -456,13 +456,31 @@ int enqueue_score(roman_ctx* c, const DevParams& Din, const roman_params_t* para
         const int EC = (int)std::min<size_t>((c->lds_max - fixedLds) / 640, 4096) & ~3;
         const size_t sliceLds = fixedLds + (size_t)EC * 640;
         auto kf = D.gravity ? k_fill_slice<true> : k_fill_slice<false>;
+        unsigned long long* fdbg = nullptr;
+#ifdef ROMAN_FILL_TIMING
+        HIPCHK(c, WS.hAux3.ensure(sizeof(unsigned long long) * 8));
+        HIPCHK(c, hipMemsetAsync(WS.hAux3.p, 0, sizeof(unsigned long long) * 8, WS.stream));
+        fdbg = WS.hAux3.as<unsigned long long>();
+#endif
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sliceLds));
         hipLaunchKernelGGL(kf, dim3((unsigned)(c->num_cu & ~7)), dim3(1024), sliceLds, WS.stream,
                            D, B, dP, dS, dT, WS.tabPool.as<double>(), LP.li, LP.lj, LP.ls, LP.lza, LP.lzb,
                            WS.umaskPool.as<unsigned long long>(), WS.prefPool.as<uint32_t>(), WS.perm.as<uint32_t>(), WS.rowPos.as<uint32_t>(),
                            WS.sliceWidth.as<uint32_t>(), WS.sliceBase.as<uint32_t>(), WS.cols16.as<uint16_t>(), WS.vals.as<double>(), TCs, EC, SPI,
-                           (unsigned long long*)nullptr);
+                           fdbg);
     DBG(c, "k_fill_slice");
+#ifdef ROMAN_FILL_TIMING
+        {
+            unsigned long long h[8];
+            HIPCHK(c, hipMemcpyAsync(h, fdbg, sizeof(h), hipMemcpyDeviceToHost, WS.stream));
+            HIPCHK(c, hipStreamSynchronize(WS.stream));
+            const char* nm[8] = {"stage-columns", "zero-image", "expand", "gather-wait", "evaluate", "barrier", "write-out", "tail"};
+            const double nwv = (double)(c->num_cu & ~7) * 16.0;
+            fprintf(stderr, "[fill timing] B=%d SPI=%d EC=%d cycles/wave:", B, SPI, EC);
+            for (int t = 0; t < 8; ++t) fprintf(stderr, " %s %.0f", nm[t], (double)h[t] / nwv);
+            fprintf(stderr, "\n");
+        }
+#endif
         // fallback layout (symmetric SELL-64, 32-bit indices) for the problems the stream layout does not take: only when
         // one can exist (the kernel would find no work otherwise)
         if (SZ.maxA > D.stream_maxL) {
