@@ -68,6 +68,7 @@ struct ProbState {
     int32_t  sgBase;       // first slice group (k_fill_slice work item) of this problem
     int32_t  kind;         // 0: stream layout + k_solve_up (L <= STREAM_MAXL), 1: symmetric SELL-64 fallback
     unsigned long long nnzUpper;   // stored strict-upper non-zeros (after the affinityeps filter)
+    int64_t  listOff;      // stream layout: first element of this problem's candidate lists in the list pool
 };
 
 struct BatchTotals {
@@ -83,6 +84,7 @@ struct BatchTotals {
     int64_t needNnz;
     int32_t overflow;      // problems skipped for lack of workspace
     int32_t maxStreamL;    // largest L among stream-layout problems
+    unsigned long long listTop;    // bump pointer of the candidate-list pool = what the whole batch needs of it
 };
 
 struct ItemDesc { int32_t b, row0; };   // a block of consecutive live rows of problem b
@@ -519,7 +521,7 @@ __global__ void __launch_bounds__(64) k_rowbase(int B, int RPB, long long capMas
     }
     if (lane == 0) {
         tot->R = accR; tot->maxL = mx; tot->nnzTotal = 0; tot->maskWords = accM < capMaskWords ? accM : capMaskWords; tot->items = accI; tot->sliceGroups = 0;
-        tot->needMaskWords = accM; tot->needNnz = 0; tot->overflow = nover; tot->maxStreamL = mxs;
+        tot->needMaskWords = accM; tot->needNnz = 0; tot->overflow = nover; tot->maxStreamL = mxs; tot->listTop = 0ull;
     }
 }
 
@@ -889,13 +891,16 @@ __global__ void __launch_bounds__(1024) k_rowprefix(const ProbDesc* __restrict__
 constexpr int SORT_KEYS = 8192;
 
 __global__ void __launch_bounds__(1024) k_rowsort(const ProbDesc* __restrict__ probs, ProbState* __restrict__ st,
+                                                  BatchTotals* __restrict__ tot,
                                                   const uint32_t* __restrict__ rowCnt,
                                                   uint32_t* __restrict__ rowPos, uint32_t* __restrict__ perm,
-                                                  uint32_t* __restrict__ sliceWidth, uint32_t* __restrict__ sliceBase)
+                                                  uint32_t* __restrict__ sliceWidth, uint32_t* __restrict__ sliceBase,
+                                                  uint32_t* __restrict__ listOff, long long capList)
 {
     __shared__ uint32_t hist[SORT_KEYS];         // indexed by SORT_KEYS-1-key: ascending index = descending count
     __shared__ uint32_t wsum[16];
     __shared__ uint32_t carry_s;
+    __shared__ unsigned long long lbase_s;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nt = blockDim.x, nw = nt >> 6;
     const int L = st[b].L;
     const int64_t lo = probs[b].liveOff;
@@ -921,6 +926,35 @@ __global__ void __launch_bounds__(1024) k_rowsort(const ProbDesc* __restrict__ p
         for (int q = tid; q < L; q += nt) {
             const uint32_t k = 4095u - (hist[q] & 4095u);
             perm[lo + q] = k; rowPos[lo + k] = (uint32_t)q;
+        }
+        // Candidate lists (k_upper writes them, k_fill_list reads them): position q keeps at most
+        // min(degree, L - 1 - q) of its candidates — room for that many 16-bit column indices, rounded up to whole
+        // quads, at listOff[q] behind the problem's base.  The base comes from a bump pointer shared by the batch (where
+        // a problem's lists lie is immaterial); a problem whose lists would end beyond the pool becomes kind 2.
+        {
+            const int PER = (L + nt - 1) / nt;                  // consecutive positions per thread (<= 3)
+            uint32_t sum = 0;
+            for (int t = 0; t < PER; ++t) {
+                const int q = tid * PER + t;
+                if (q < L) sum += (min((hist[q] >> 12) - 1u, (uint32_t)(L - 1 - q)) + 3u) & ~3u;
+            }
+            uint32_t inc = sum;
+            for (int off = 1; off < WAVE; off <<= 1) { const uint32_t t = __shfl_up(inc, off); if (lane >= off) inc += t; }
+            if (lane == WAVE - 1) wsum[w] = inc;
+            __syncthreads();
+            uint32_t wbase = 0, total = 0;
+            for (int t = 0; t < nw; ++t) { if (t < w) wbase += wsum[t]; total += wsum[t]; }
+            if (tid == 0) {
+                const unsigned long long base = atomicAdd(&tot->listTop, (unsigned long long)total);
+                lbase_s = base;
+                st[b].listOff = (int64_t)base;
+                if ((long long)(base + total) > capList) { st[b].kind = 2; atomicAdd(&tot->overflow, 1); }
+            }
+            uint32_t run = wbase + inc - sum;
+            for (int t = 0; t < PER; ++t) {
+                const int q = tid * PER + t;
+                if (q < L) { listOff[lo + q] = run; run += (min((hist[q] >> 12) - 1u, (uint32_t)(L - 1 - q)) + 3u) & ~3u; }
+            }
         }
         return;                                                 // slice geometry of the stream layout: k_slicegeom
     }
@@ -989,7 +1023,7 @@ struct LivePools { int32_t* lp; int32_t* li; int32_t* lj; double* ls; double* ld
 __global__ void __launch_bounds__(1024) k_upper(const ProbDesc* __restrict__ probs, const ProbState* __restrict__ st,
                                                 const BatchTotals* __restrict__ tot, const ItemDesc* __restrict__ items,
                                                 const unsigned long long* __restrict__ maskPool,
-                                                unsigned long long* __restrict__ umaskPool, uint32_t* __restrict__ prefPool,
+                                                uint16_t* __restrict__ listPool, const uint32_t* __restrict__ listOff,
                                                 uint32_t* __restrict__ rowCnt, const uint32_t* __restrict__ perm,
                                                 const uint32_t* __restrict__ rowPos, LivePools src, LivePools dst, int RPB)
 {
@@ -1004,6 +1038,7 @@ __global__ void __launch_bounds__(1024) k_upper(const ProbDesc* __restrict__ pro
         const int L = st[b].L;
         const int W = (L + 63) >> 6;
         const int64_t lo = probs[b].liveOff, mo = st[b].maskOff;
+        uint16_t* const lists = listPool + st[b].listOff;
         const int nrows = min(RPB, L - it.row0);
         if (staged != b) {                                       // consecutive items of a workgroup often share the problem
             __syncthreads();
@@ -1031,8 +1066,14 @@ __global__ void __launch_bounds__(1024) k_upper(const ProbDesc* __restrict__ pro
                 const unsigned long long mine = ((lane < W) ? maskPool[mo + (int64_t)k * W + lane] : 0ull) & behind;
                 const uint32_t c = (uint32_t)__popcll(mine);
                 const uint32_t ex = wave_excl_scan(c, lane);
-                if (lane < W) { umaskPool[mo + (int64_t)p * W + lane] = mine; prefPool[mo + (int64_t)p * W + lane] = ex; }
-                if (lane == WAVE - 1) rowCnt[lo + p] = ex + c;   // upper degree of position p (the live-order degrees are spent)
+                const uint32_t cnt = (uint32_t)__shfl((int)(ex + c), WAVE - 1);
+                {   // the row's candidate list: live column indices in ascending order, padded to a whole quad
+                    uint16_t* lst = lists + listOff[lo + p];
+                    unsigned long long m = mine; uint32_t e = ex;
+                    while (m) { lst[e++] = (uint16_t)((lane << 6) + __builtin_ctzll(m)); m &= m - 1ull; }
+                    if (lane < 4 && cnt + (uint32_t)lane < ((cnt + 3u) & ~3u)) lst[cnt + lane] = (uint16_t)0xffffu;
+                }
+                if (lane == 0) rowCnt[lo + p] = cnt;             // upper degree of position p (the live-order degrees are spent)
                 if (lane == 0) { dst.lp[lo + p] = src.lp[lo + k]; dst.ld[lo + p] = src.ld[lo + k]; }
                 if (r + 1 < r1) {                                // the column at position p + 1 is no longer behind
                     const int qn = (int)perm[lo + p + 1];
@@ -1290,87 +1331,74 @@ __global__ void __launch_bounds__(1024) k_fill(DevParams D, const ProbDesc* __re
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_fill_slice (quad layout): the same candidates -> values work as k_fill, organised by OUTPUT: a
-// workgroup builds one 64-row slice of the sorted matrix at a time as an exact image of its HBM block
-// in LDS (entries [e0, e0+EC) of every lane slot: EC*64 values + EC*64 column words) and writes the
-// image out with full-width coalesced stores.  k_fill's per-entry stores land in 64 different cache
-// lines per wave store (a row's entries are 1 KiB apart in the lane-major layout); they cost more
-// than the arithmetic.  Each of the 16 waves expands the masks of 4 lane slots (rows of one slice
-// have similar lengths: the rows are sorted) through the same LDS ring and evaluates 64 candidates
-// at a time.  Slices wider than EC take several passes over their masks.  Work items are groups of
-// SPI consecutive slices of one problem, so the column tile is staged once per group.
+// k_fill_list (stream layout): candidates -> values, written straight into the quad layout.  k_upper left every
+// position row's kept candidates as a list of live column indices (ascending, padded to whole quads), so entry e of a
+// row is simply element e of its list.  A wave takes one QUAD of one slice at a time — lane = lane slot = row, 4
+// consecutive entries per lane: one 8-byte list read, four independent evaluation chains (two LDS column lookups, two
+// table gathers, sqrt / exp / cbrt, fusion, affinityeps filter), then one 8-byte column store and two 16-byte value
+// stores that are contiguous over the wave — the layout's own order, no staging image, no barriers inside a work
+// item.  Entries beyond a row's count (slice padding) and filtered entries are written inert (value 0, the lane
+// slot's dummy column with the C-flag).  Work items are groups of SPI consecutive slices of one problem: the
+// problem's column tile (objects, z, single score, position of every live association) is staged in LDS once per
+// item, as are the rows of the group (live index, count, list offset); the quads of the group are dealt to the waves
+// round-robin.  Items are ordered so that the groups of one problem run on one XCD (its tables stay in that L2).
 // ---------------------------------------------------------------------------------------------
-#ifdef ROMAN_FILL_TIMING
-#define FMARK(slot) do { const unsigned long long t__ = __builtin_readcyclecounter(); facc[slot] += t__ - flast; flast = t__; } while (0)
-#else
-#define FMARK(slot) do { } while (0)
-#endif
-// inclusive scans over the 64 lanes of a wave with DPP row shifts / row broadcasts (no LDS traffic)
-template <int CTRL, int ROWMASK>
-__device__ __forceinline__ uint32_t dpp_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROWMASK, 0xf, false); }
-__device__ __forceinline__ uint32_t wave_incl_add(uint32_t v)
-{
-    v += dpp_u32<0x111, 0xf>(v); v += dpp_u32<0x112, 0xf>(v); v += dpp_u32<0x114, 0xf>(v); v += dpp_u32<0x118, 0xf>(v);   // row_shr 1,2,4,8
-    v += dpp_u32<0x142, 0xa>(v);          // row_bcast:15 -> rows 1,3
-    v += dpp_u32<0x143, 0xc>(v);          // row_bcast:31 -> rows 2,3
-    return v;
-}
-__device__ __forceinline__ uint32_t wave_incl_max(uint32_t v)
-{
-    v = max(v, dpp_u32<0x111, 0xf>(v)); v = max(v, dpp_u32<0x112, 0xf>(v)); v = max(v, dpp_u32<0x114, 0xf>(v)); v = max(v, dpp_u32<0x118, 0xf>(v));
-    v = max(v, dpp_u32<0x142, 0xa>(v));
-    v = max(v, dpp_u32<0x143, 0xc>(v));
-    return v;
-}
-
 constexpr int FILLS_MAXSPI = 16;     // slices per work item (group)
-constexpr int FILLS_NBLK = 3;        // blocks of 64 mask words per wave and slice: (64/16 slots) * ceil(L/64) <= 192 words
 
-template <bool GRAV>
-__global__ void __launch_bounds__(1024) k_fill_slice(DevParams D, int B, const ProbDesc* __restrict__ probs,
-                                                     ProbState* __restrict__ st, const BatchTotals* __restrict__ tot,
-                                                     const double* __restrict__ tabPool,
-                                                     const int32_t* __restrict__ li, const int32_t* __restrict__ lj,
-                                                     const double* __restrict__ ls,
-                                                     const double* __restrict__ lza, const double* __restrict__ lzb,
-                                                     const unsigned long long* __restrict__ maskPool,
-                                                     const uint32_t* __restrict__ prefPool,
-                                                     const uint32_t* __restrict__ perm, const uint32_t* __restrict__ rowPos,
-                                                     const uint32_t* __restrict__ sliceWidth,
-                                                     const uint32_t* __restrict__ sliceBase,
-                                                     uint16_t* __restrict__ cols, double* __restrict__ vals,
-                                                     int TC, int EC /* multiple of 4 */, int SPI, unsigned long long* fdbg)
+template <bool GRAV, bool FAST>
+__device__ __forceinline__ double fill_value(const DevParams& D, double a, double bb, double dza, double dzb, double ss, double sk, double sq)
 {
-#ifdef ROMAN_FILL_TIMING
-    unsigned long long facc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned long long flast = __builtin_readcyclecounter();
-#endif
-    // LDS: cS[TC] [GRAV: cZa[TC] cZb[TC]] cI[TC] cJ[TC] cP[TC] (u16) | image values [EC*64] | image columns [EC*64] |
-    //      owner lines | rows of the group's slices
-    // (li .. lzb: the live-order pools; maskPool / prefPool: the kept-candidate masks and prefix counts k_upper wrote, rows
-    // in POSITION order, columns in live order; cP: position of every live column = the label an entry is stored with)
+    double c;
+    if (GRAV && D.gmode != 3) {
+        const double ch = fabs(a - bb);
+        const double hm = a > bb ? a : bb;
+        double cv = fabs(dza - dzb) - D.sin_unc * hm;
+        if (cv < 0.0) cv = 0.0;
+        c = sqrt(ch * ch + cv * cv);
+    } else {
+        c = fabs(a - bb);                   // no gravity prior, or the z-gate reading (full lengths)
+    }
+    const double sa = fx_exp(((-0.5 * c) * c) / D.sig2);
+    if (FAST) return (sa == 0.0) ? 0.0 : fx_cbrt(sa * ss);      // geometric mean, distance weight 1: fuse_pair()'s default branch
+    return fuse_pair(D, sa, sk, sq);
+}
+
+template <bool GRAV, bool FAST>
+__global__ void __launch_bounds__(1024) k_fill_list(DevParams D, int B, const ProbDesc* __restrict__ probs,
+                                                    ProbState* __restrict__ st, const BatchTotals* __restrict__ tot,
+                                                    const double* __restrict__ tabPool,
+                                                    const int32_t* __restrict__ li, const int32_t* __restrict__ lj,
+                                                    const double* __restrict__ ls,
+                                                    const double* __restrict__ lza, const double* __restrict__ lzb,
+                                                    const uint16_t* __restrict__ listPool, const uint32_t* __restrict__ listOff,
+                                                    const uint32_t* __restrict__ rowCnt,
+                                                    const uint32_t* __restrict__ perm, const uint32_t* __restrict__ rowPos,
+                                                    const uint32_t* __restrict__ sliceWidth,
+                                                    const uint32_t* __restrict__ sliceBase,
+                                                    uint16_t* __restrict__ cols, double* __restrict__ vals, int TC, int SPI)
+{
+    // LDS: cS[TC] [GRAV: cZa[TC] cZb[TC]] cI[TC] cJ[TC] | gK gCnt gOff [FILLS_MAXSPI*64] | gQ[FILLS_MAXSPI+1] gSB[FILLS_MAXSPI] | cP[TC] (u16)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* cS = reinterpret_cast<double*>(smem);
     double* cZa = cS + TC;
     double* cZb = cZa + (GRAV ? TC : 0);
     int32_t* cI = reinterpret_cast<int32_t*>(cZb + (GRAV ? TC : 0));
     int32_t* cJ = cI + TC;
-    uint16_t* cP = reinterpret_cast<uint16_t*>(cJ + TC);
-    double* imgV = reinterpret_cast<double*>(cP + TC);
-    uint16_t* imgC = reinterpret_cast<uint16_t*>(imgV + (size_t)EC * 64);
-    uint32_t* rings = reinterpret_cast<uint32_t*>(imgC + (size_t)EC * 64);
+    uint32_t* gK = reinterpret_cast<uint32_t*>(cJ + TC);         // rows of the group's slices: live index (~0: no row)
+    uint32_t* gCnt = gK + FILLS_MAXSPI * 64;                     //   kept candidates
+    uint32_t* gOff = gCnt + FILLS_MAXSPI * 64;                   //   list offset
+    uint32_t* gQ = gOff + FILLS_MAXSPI * 64;                     // quads in front of every slice of the group (+ total)
+    uint32_t* gSB = gQ + FILLS_MAXSPI + 1;                       // slice bases
+    uint16_t* cP = reinterpret_cast<uint16_t*>(gSB + FILLS_MAXSPI + 1);
     const int tid = threadIdx.x, nt = blockDim.x;
     const int lane = tid & 63, w = tid >> 6, nw = nt >> 6;
-    uint32_t* ownL = rings + (size_t)w * WAVE;                  // this wave's owner line (64 entries)
-    uint32_t* sKall = rings + (size_t)nw * WAVE;                // live rows of the group's slices: FILLS_MAXSPI * 64 entries
-    const int SPW = 64 / nw;                                    // lane slots per wave
     const int nGroups = tot->sliceGroups;
     // XCD-aware order: workgroups are dealt to the 8 XCDs round-robin by id, so XCD x takes the CONTIGUOUS range
     // [x*Gx, (x+1)*Gx) of groups — the groups of one problem (which share its tables) run on one L2.
     const int Gx = (nGroups + 7) >> 3;
     for (int sIdx = blockIdx.x; (sIdx >> 3) < Gx; sIdx += gridDim.x) {
         const int t = (sIdx & 7) * Gx + (sIdx >> 3);
-        if (t >= nGroups) continue;
+        if (t < nGroups) {
         int b = 0;                                              // last problem with sgBase <= t and at least one group
         {
             int lo_ = 0, hi_ = B - 1;
@@ -1380,169 +1408,69 @@ __global__ void __launch_bounds__(1024) k_fill_slice(DevParams D, int B, const P
         const ProbDesc pd = probs[b];
         const int L = st[b].L;
         const int W = (L + 63) >> 6;
-        const int64_t lo = pd.liveOff, mo = st[b].maskOff, no = st[b].nnzOff;
-        const int s_begin = (t - st[b].sgBase) * SPI, s_end = min(W, s_begin + SPI);
+        const int64_t lo = pd.liveOff, no = st[b].nnzOff;
+        const uint16_t* lists = listPool + st[b].listOff;
+        const int s_begin = (t - st[b].sgBase) * SPI, s_end = min(W, s_begin + SPI), ns = s_end - s_begin;
         const double* TA = tabPool + pd.tabOff;
         const double* TB = TA + (int64_t)pd.n1 * pd.n1;
-        __syncthreads();                        // every wave is done with the previous group's columns
+        __syncthreads();                        // every wave is done with the previous group's tile
         for (int q = tid; q < L; q += nt) {
             cI[q] = li[lo + q]; cJ[q] = lj[lo + q]; cS[q] = ls[lo + q]; cP[q] = (uint16_t)rowPos[lo + q];
             if (GRAV) { cZa[q] = lza[lo + q]; cZb[q] = lzb[lo + q]; }
         }
-        for (int x = tid; x < (s_end - s_begin) * 64; x += nt)
-            sKall[x] = (s_begin * 64 + x < L) ? perm[lo + s_begin * 64 + x] : 0xffffffffu;
+        for (int x = tid; x < ns * 64; x += nt) {
+            const int p = s_begin * 64 + x;
+            const bool row = p < L;
+            gK[x] = row ? perm[lo + p] : 0xffffffffu; gCnt[x] = row ? rowCnt[lo + p] : 0u; gOff[x] = row ? listOff[lo + p] : 0u;
+        }
+        if (w == 0) {                           // quads in front of every slice of the group
+            const uint32_t wq = (lane < ns) ? (sliceWidth[lo + s_begin + lane] >> 2) : 0u;
+            const uint32_t ex = wave_excl_scan(wq, lane);
+            if (lane < ns) { gQ[lane] = ex; gSB[lane] = sliceBase[lo + s_begin + lane]; }
+            if (lane == ns) gQ[ns] = ex;        // ns <= 16 < 64
+        }
+        __syncthreads();
+        const uint32_t Q = gQ[ns];
         uint32_t upper = 0;
-        FMARK(0);
-        for (int sl = s_begin; sl < s_end; ++sl) {
-            const uint32_t width = sliceWidth[lo + sl];
-            const int64_t sb = no + sliceBase[lo + sl];         // first element of the slice (multiple of 256)
-            const uint32_t* sK = sKall + (sl - s_begin) * 64;
-            for (uint32_t e0 = 0; e0 < width; e0 += (uint32_t)EC) {
-                const uint32_t ew = min((uint32_t)EC, width - e0);
-                __syncthreads();                                // previous image written out (first pass: tile and rows staged)
-                {   // inert image: value 0, column = the lane slot's own dummy vector element L + slot, with the C-flag
-                    // (one dummy per slot: the solver pushes into the column's accumulator, and 64 lanes hitting
-                    // ONE dummy address would serialise in the LDS)
-                    double2* v2 = reinterpret_cast<double2*>(imgV);
-                    for (uint32_t x = tid; x < ew * 32u; x += nt) v2[x] = make_double2(0.0, 0.0);
-                    uint2* c2 = reinterpret_cast<uint2*>(imgC);
-                    for (uint32_t x = tid; x < ew * 16u; x += nt) {
-                        const uint32_t inert = (((uint32_t)L + (x & 63u)) | 0x8000u) * 0x10001u;
-                        c2[x] = make_uint2(inert, inert);
-                    }
-                }
-                __syncthreads();
-                FMARK(1);
-
-                // ---- this wave's lane slots w, w+nw, w+2nw, .. (rows are sorted by length: interleaving balances the
-                // waves).  Their mask words (at most FILLS_NBLK blocks of 64, one word per lane) are expanded DENSELY:
-                // with c = popcount per word and its exclusive prefix over the wave's words, candidate number o is
-                // bit (o - prefix[l]) of the word l with prefix[l] <= o < prefix[l] + c[l].  Every round produces 64
-                // candidates at once: the owner words are scattered into a 64-entry LDS line at their first
-                // candidate's position and spread by a max-scan, the word is fetched with ds_bpermute and the bit
-                // found by a 6-step rank select.  (One bit per lane and step through a ring took 3x the cycles.)
-                // (rows of slice sl are the positions 64 sl .. 64 sl + 63, live rows sK[slot]; their kept candidates can sit
-                // in any word: the columns are in live order)
-                const int nwords = SPW * W;
-                unsigned long long mB[FILLS_NBLK]; uint32_t iA[FILLS_NBLK], iB[FILLS_NBLK];
-                uint32_t Ttot = 0;
+        int si = 0;
+        for (uint32_t u = (uint32_t)w; u < Q; u += (uint32_t)nw) {
+            while (u >= gQ[si + 1]) ++si;                       // wave-uniform
+            const uint32_t g = u - gQ[si];
+            const int64_t sb = no + gSB[si];                    // first element of the slice (multiple of 256)
+            const int x = si * 64 + lane;
+            const uint32_t kraw = gK[x], cnt = gCnt[x];
+            const uint32_t e0 = g << 2;
+            uint2 qq = make_uint2(0u, 0u);
+            if (e0 < cnt) qq = *reinterpret_cast<const uint2*>(lists + gOff[x] + e0);
+            const int k = (kraw == 0xffffffffu) ? 0 : (int)kraw;
+            const double sk = cS[k];
+            const double* TAr = TA + (int64_t)cI[k] * pd.n1;
+            const double* TBr = TB + (int64_t)cJ[k] * pd.n2;
+            const double zak = GRAV ? cZa[k] : 0.0, zbk = GRAV ? cZb[k] : 0.0;
+            const uint32_t inert = ((uint32_t)L + (uint32_t)lane) | 0x8000u;     // the lane slot's own dummy column
+            uint32_t cw[4]; double vv[4];
 #pragma unroll
-                for (int jb = 0; jb < FILLS_NBLK; ++jb) {
-                    const int x = jb * WAVE + lane;
-                    unsigned long long m = 0ull; uint32_t ef = 0u, ka = 0u;
-                    if (x < nwords) {
-                        const int r = x / W, word = x - r * W;
-                        const uint32_t slot = (uint32_t)(r * nw + w);
-                        const uint32_t k = sK[slot];                                 // live index of the row in this slot
-                        if (k != 0xffffffffu) {
-                            const uint32_t pr = (uint32_t)(sl * 64) + slot;          // its position: the row of the masks
-                            m = maskPool[mo + (int64_t)pr * W + word];
-                            ef = prefPool[mo + (int64_t)pr * W + word];
-                            ka = k | (slot << 16) | ((uint32_t)word << 22);
-                        }
-                    }
-                    uint32_t c = (uint32_t)__popcll(m);
-                    if (ef >= e0 + ew || ef + c <= e0) { m = 0ull; c = 0u; }     // no entry of this word in this pass
-                    const uint32_t incl = wave_incl_add(c);
-                    mB[jb] = m; iA[jb] = ka; iB[jb] = ((Ttot + incl - c) << 16) | ef;
-                    Ttot += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-                }
-                FMARK(2);
-                for (uint32_t base = 0; base < Ttot; base += WAVE) {
-                    ownL[lane] = 0u;
-#pragma unroll
-                    for (int jb = 0; jb < FILLS_NBLK; ++jb) {
-                        const int pos = (int)(iB[jb] >> 16) - (int)base;
-                        if (mB[jb] != 0ull && pos < WAVE && pos + (int)__popcll(mB[jb]) > 0) ownL[max(pos, 0)] = (uint32_t)(jb * WAVE + lane + 1);
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    const uint32_t own = wave_incl_max(ownL[lane]);       // >= 1 wherever base + lane < Ttot
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();                      // ownL is rewritten by the next round
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    const uint32_t id = (own - 1u) & (FILLS_NBLK * WAVE - 1 < 255 ? 255u : 511u);
-                    const int src = (int)((id & 63u) << 2);
-                    const uint32_t jsel = id >> 6;
-                    uint32_t mlo = 0u, mhi = 0u, ka = 0u, kb = 0u;
-#pragma unroll
-                    for (int jb = 0; jb < FILLS_NBLK; ++jb) {
-                        if (jb * WAVE >= nwords) break;                   // wave-uniform
-                        const uint32_t t0 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)(uint32_t)mB[jb]);
-                        const uint32_t t1 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)(uint32_t)(mB[jb] >> 32));
-                        const uint32_t t2 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)iA[jb]);
-                        const uint32_t t3 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)iB[jb]);
-                        if (jsel == (uint32_t)jb) { mlo = t0; mhi = t1; ka = t2; kb = t3; }
-                    }
-                    uint32_t n = base + (uint32_t)lane - (kb >> 16);      // rank of this candidate within its word
-                    const uint32_t e = (kb & 0xffffu) + n;
-                    const bool valid = base + (uint32_t)lane < Ttot && own != 0u && e >= e0 && e < e0 + ew;
-                    uint32_t bit;
-                    {   // position of the n-th set bit of (mhi:mlo)
-                        uint32_t t = (uint32_t)__popc(mlo);
-                        bool up = n >= t;
-                        uint32_t wv = up ? mhi : mlo; n -= up ? t : 0u; bit = up ? 32u : 0u;
-#pragma unroll
-                        for (int sft = 16; sft > 0; sft >>= 1) {
-                            t = (uint32_t)__popc(wv & ((1u << sft) - 1u));
-                            up = n >= t;
-                            wv = up ? (wv >> sft) : wv; n -= up ? t : 0u; bit += up ? (uint32_t)sft : 0u;
-                        }
-                    }
-                    FMARK(2);
-                    if (valid) {
-                        const int k = (int)(ka & 0xffffu);
-                        const uint32_t slot = (ka >> 16) & 63u;
-                        const int q = (int)(((ka >> 22) << 6) + bit);
-                        const uint32_t er = e - e0;
-                        const int i = cI[k], j = cJ[k], iq = cI[q], jq = cJ[q];
-                        const double a = TA[(int64_t)i * pd.n1 + iq], bb = TB[(int64_t)j * pd.n2 + jq];
-#ifdef ROMAN_FILL_TIMING
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        FMARK(3);
-#endif
-                        double c;
-                        if (GRAV && D.gmode != 3) {
-                            const double ch = fabs(a - bb);
-                            const double hm = a > bb ? a : bb;
-                            double cv = fabs((cZa[k] - cZa[q]) - (cZb[k] - cZb[q])) - D.sin_unc * hm;
-                            if (cv < 0.0) cv = 0.0;
-                            c = sqrt(ch * ch + cv * cv);
-                        } else {
-                            c = fabs(a - bb);                   // no gravity prior, or the z-gate reading (full lengths)
-                        }
-                        const double sa = fx_exp(((-0.5 * c) * c) / D.sig2);
-                        const double v = fuse_pair(D, sa, cS[k], cS[q]);
-                        if (v > D.p.affinityeps) {              // otherwise the slot stays inert: neither in M nor in C
-                            imgC[(er >> 2) * 256u + slot * 4u + (er & 3u)] = cP[q];          // label: the column's position
-                            imgV[(er >> 1) * 128u + slot * 2u + (er & 1u)] = v;
-                            upper += 1u;                        // every stored entry is kept once: a strict-upper one
-                        }
-                    }
-                    FMARK(4);
-                }
-                FMARK(2);
-                __syncthreads();
-                FMARK(5);
-                {   // image -> HBM: entries [e0, e0+ew) of the slice are one contiguous block in both arrays
-                    const double2* v2 = reinterpret_cast<const double2*>(imgV);
-                    double2* gv = reinterpret_cast<double2*>(vals + sb + (int64_t)e0 * 64);
-                    for (uint32_t x = tid; x < ew * 32u; x += nt) gv[x] = v2[x];
-                    const uint2* c2 = reinterpret_cast<const uint2*>(imgC);
-                    uint2* gc = reinterpret_cast<uint2*>(cols + sb + (int64_t)e0 * 64);
-                    for (uint32_t x = tid; x < ew * 16u; x += nt) gc[x] = c2[x];
-                }
-                FMARK(6);
+            for (int j = 0; j < 4; ++j) {
+                const bool have = e0 + (uint32_t)j < cnt;
+                const uint32_t qr = ((j < 2 ? qq.x : qq.y) >> (16 * (j & 1))) & 0xffffu;
+                const int q = have ? (int)qr : k;               // (a padding entry evaluates the row against itself: discarded)
+                double a = TAr[cI[q]], bb = TBr[cJ[q]];
+                if (!have) { a = 0.0; bb = 0.0; }
+                const double sq = cS[q];
+                const double v = fill_value<GRAV, FAST>(D, a, bb, GRAV ? zak - cZa[q] : 0.0, GRAV ? zbk - cZb[q] : 0.0, sk * sq, sk, sq);
+                const bool keep = have && v > D.p.affinityeps;  // otherwise the slot stays inert: neither in M nor in C
+                cw[j] = keep ? (uint32_t)cP[q] : inert;
+                vv[j] = keep ? v : 0.0;
+                upper += keep ? 1u : 0u;                        // every stored entry is kept once: a strict-upper one
             }
+            *reinterpret_cast<uint2*>(cols + sb + (int64_t)g * 256 + lane * 4) = make_uint2(cw[0] | (cw[1] << 16), cw[2] | (cw[3] << 16));
+            *reinterpret_cast<double2*>(vals + sb + (int64_t)(2 * g) * 128 + lane * 2) = make_double2(vv[0], vv[1]);
+            *reinterpret_cast<double2*>(vals + sb + (int64_t)(2 * g + 1) * 128 + lane * 2) = make_double2(vv[2], vv[3]);
         }
         for (int off = 32; off > 0; off >>= 1) upper += __shfl_xor(upper, off);
         if (lane == 0 && upper) atomicAdd(&st[b].nnzUpper, (unsigned long long)upper);
+        }
     }
-#ifdef ROMAN_FILL_TIMING
-    FMARK(7);
-    if (lane == 0 && fdbg) for (int t_ = 0; t_ < 8; ++t_) atomicAdd(&fdbg[t_], facc[t_]);
-#endif
 }
 
 // ---------------------------------------------------------------------------------------------

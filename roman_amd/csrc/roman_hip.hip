@@ -68,10 +68,10 @@ struct roman_ctx {
         DevBuf cosPool, tabPool, sTmp, chunkCnt;
         DevBuf lp, li, lj, ls, ld, lza, lzb;                       // per live association, live order
         DevBuf plp, pli, plj, pls, pld, plza, plzb;                // the same in position order (stream layout)
-        DevBuf rowCnt, rowPos, perm, sliceWidth, sliceBase, items, maskPool, umaskPool, prefPool;
+        DevBuf rowCnt, rowPos, perm, sliceWidth, sliceBase, items, maskPool, prefPool, listPool, listOff;
         DevBuf vMu, vCu, vMun, vCun, gU, gUn, uOut, nodesOrig, nSel;
         DevBuf cols16, cols32, vals;
-        long long capMaskWords = 0, capNnz = 0;                    // what the sparse pools hold (elements)
+        long long capMaskWords = 0, capNnz = 0, capList = 0;       // what the sparse pools hold (elements)
         // staging for the host-pointer entry points
         DevBuf hFeats, hAssoc, hU0, oAssoc, oN, oT, oStatus, oStats, hAux1, hAux2, hAux3;
         // totals of the most recent batch on this workspace, copied back without waiting
@@ -98,6 +98,7 @@ struct roman_ctx {
         double rMaxL = 0.0;                    // largest live set / largest association list
         double rMask = 0.0;                    // bit-matrix words / sum of nA * ceil(nA / 64)
         double rNnz = 0.0;                     // matrix slots / sum of nA
+        double rList = 0.0;                    // candidate-list elements / sum of nA
     } hist;
 
     bool profile = false;
@@ -230,7 +231,7 @@ struct BatchIn {
 struct Sizing {
     double sumA = 0, maxA = 0, maskBound = 0;      // sum / max of the association list lengths, sum of nA * ceil(nA/64)
     int expectMaxL = 0;                            // estimate of the largest live set
-    long long capMaskWords = 0, capNnz = 0;        // capacities to allocate (elements)
+    long long capMaskWords = 0, capNnz = 0, capList = 0;        // capacities to allocate (elements)
 };
 
 // Fold the totals a finished batch left in pinned memory into the history (never waits: only completed copies count).
@@ -247,6 +248,7 @@ void harvest_totals(roman_ctx* c, bool wait)
         if (W.totMaxA > 0) H.rMaxL = std::max(H.rMaxL, (double)t.maxL / W.totMaxA);
         if (W.totMaskBound > 0) H.rMask = std::max(H.rMask, (double)t.needMaskWords / W.totMaskBound);
         if (W.totSumA > 0) H.rNnz = std::max(H.rNnz, (double)t.needNnz / W.totSumA);
+        if (W.totSumA > 0) H.rList = std::max(H.rList, (double)t.listTop / W.totSumA);
         H.valid = true;
     }
 }
@@ -272,8 +274,10 @@ void estimate_sizes(roman_ctx* c, const DevParams& D, const roman_params_t* para
         S->expectMaxL = D.single ? (int)std::min(S->maxA, std::ceil(H.rMaxL * S->maxA * 1.15) + 64.0) : (int)S->maxA;
         S->capMaskWords = (long long)(D.single ? H.rMask * S->maskBound * 1.3 + 4096.0 : S->maskBound);
         S->capNnz = (long long)(H.rNnz * S->sumA * 1.3 + 65536.0);
+        S->capList = (long long)(H.rList * S->sumA * 1.3 + 65536.0);
     } else {
         S->expectMaxL = heurMaxL; S->capMaskWords = (long long)heurMask; S->capNnz = (long long)heurNnz + 65536;
+        S->capList = (long long)(2.5 * heurNnz) + 65536;
     }
     S->capMaskWords = std::max<long long>(S->capMaskWords, 64);
     // tests: force the first attempt of a batch to overflow (exercises the skip / retry path)
@@ -320,7 +324,7 @@ int enqueue_score(roman_ctx* c, const DevParams& Din, const roman_params_t* para
     Sizing SZ;
     estimate_sizes(c, D, params, in.F, hd, &SZ);
     // a workspace never shrinks: keep what earlier (larger) batches made it hold
-    SZ.capMaskWords = std::max(SZ.capMaskWords, WS.capMaskWords); SZ.capNnz = std::max(SZ.capNnz, WS.capNnz);
+    SZ.capMaskWords = std::max(SZ.capMaskWords, WS.capMaskWords); SZ.capNnz = std::max(SZ.capNnz, WS.capNnz); SZ.capList = std::max(SZ.capList, WS.capList);
     // stream layout: as many live associations as the LDS tiles of this launch are sized for
     D.stream_maxL = std::min(STREAM_MAXL, std::max(64, (SZ.expectMaxL + 63) & ~63));
     *Dout = D;
@@ -333,18 +337,18 @@ int enqueue_score(roman_ctx* c, const DevParams& Din, const roman_params_t* para
     HIPCHK(c, WS.tabPool.ensure(sizeof(double) * (size_t)std::max<int64_t>(sumTab, 1)));
     HIPCHK(c, WS.sTmp.ensure(sizeof(double) * nA1));
     {
-        DevBuf* i32s[] = {&WS.lp, &WS.li, &WS.lj, &WS.plp, &WS.pli, &WS.plj, &WS.rowCnt, &WS.rowPos, &WS.perm, &WS.sliceWidth, &WS.sliceBase};
+        DevBuf* i32s[] = {&WS.lp, &WS.li, &WS.lj, &WS.plp, &WS.pli, &WS.plj, &WS.rowCnt, &WS.rowPos, &WS.perm, &WS.sliceWidth, &WS.sliceBase, &WS.listOff};
         for (DevBuf* b_ : i32s) HIPCHK(c, b_->ensure(sizeof(int32_t) * nA1));
         DevBuf* f64s[] = {&WS.ls, &WS.ld, &WS.lza, &WS.lzb, &WS.pls, &WS.pld, &WS.plza, &WS.plzb};
         for (DevBuf* b_ : f64s) HIPCHK(c, b_->ensure(sizeof(double) * nA1));
     }
     HIPCHK(c, WS.maskPool.ensure(sizeof(unsigned long long) * (size_t)SZ.capMaskWords));
-    HIPCHK(c, WS.umaskPool.ensure(sizeof(unsigned long long) * (size_t)SZ.capMaskWords));
+    HIPCHK(c, WS.listPool.ensure(sizeof(uint16_t) * (size_t)std::max<long long>(SZ.capList, 4)));
     HIPCHK(c, WS.prefPool.ensure(sizeof(uint32_t) * (size_t)SZ.capMaskWords));
     HIPCHK(c, WS.vals.ensure(sizeof(double) * (size_t)SZ.capNnz));
     HIPCHK(c, WS.cols16.ensure(sizeof(uint16_t) * (size_t)SZ.capNnz));
     HIPCHK(c, WS.cols32.ensure(sizeof(uint32_t) * (size_t)SZ.capNnz));
-    WS.capMaskWords = SZ.capMaskWords; WS.capNnz = SZ.capNnz;
+    WS.capMaskWords = SZ.capMaskWords; WS.capNnz = SZ.capNnz; WS.capList = SZ.capList;
     // work items: blocks of RPB consecutive live rows of one problem (more, smaller items for small batches)
     int RPB = 32;
     while (RPB < 128 && (int64_t)RPB * c->num_cu * 64 < sumA) RPB <<= 1;     // 128: ~17 items per problem balance the static item loop best (measured 32..1024)
@@ -429,17 +433,17 @@ int enqueue_score(roman_ctx* c, const DevParams& Din, const roman_params_t* para
         hipLaunchKernelGGL(k_rowprefix, dim3(c->num_cu * 2), dim3(1024), 0, WS.stream, dP, dS, dT, WS.items.as<ItemDesc>(),
                            WS.maskPool.as<unsigned long long>(), WS.prefPool.as<uint32_t>(), WS.rowCnt.as<uint32_t>(), RPB);
     DBG(c, "k_rowprefix");
-        hipLaunchKernelGGL(k_rowsort, dim3(B), dim3(1024), 0, WS.stream, dP, dS, WS.rowCnt.as<uint32_t>(), WS.rowPos.as<uint32_t>(), WS.perm.as<uint32_t>(),
-                           WS.sliceWidth.as<uint32_t>(), WS.sliceBase.as<uint32_t>());
+        hipLaunchKernelGGL(k_rowsort, dim3(B), dim3(1024), 0, WS.stream, dP, dS, dT, WS.rowCnt.as<uint32_t>(), WS.rowPos.as<uint32_t>(), WS.perm.as<uint32_t>(),
+                           WS.sliceWidth.as<uint32_t>(), WS.sliceBase.as<uint32_t>(), WS.listOff.as<uint32_t>(), SZ.capList);
     DBG(c, "k_rowsort");
         hipLaunchKernelGGL(k_upper, dim3(c->num_cu * 2), dim3(1024), 0, WS.stream, dP, dS, dT, WS.items.as<ItemDesc>(),
-                           WS.maskPool.as<unsigned long long>(), WS.umaskPool.as<unsigned long long>(), WS.prefPool.as<uint32_t>(),
+                           WS.maskPool.as<unsigned long long>(), WS.listPool.as<uint16_t>(), WS.listOff.as<uint32_t>(),
                            WS.rowCnt.as<uint32_t>(), WS.perm.as<uint32_t>(), WS.rowPos.as<uint32_t>(), LP, PP, RPB);
     DBG(c, "k_upper");
         hipLaunchKernelGGL(k_slicegeom, dim3(B), dim3(64), 0, WS.stream, dP, dS, WS.rowCnt.as<uint32_t>(), WS.sliceWidth.as<uint32_t>(), WS.sliceBase.as<uint32_t>());
     DBG(c, "k_slicegeom");
     }
-    // k_fill_slice work items: groups of SPI consecutive slices of one problem, about 3 per CU for the whole batch
+    // k_fill_list work items: groups of SPI consecutive slices of one problem, about 3 per CU for the whole batch
     const double expR = c->hist.valid && D.single ? std::min<double>((double)sumA, c->hist.rMaxL * (double)sumA * 1.2) : (double)sumA;
     const int SPI = (int)std::min<int64_t>(FILLS_MAXSPI, std::max<int64_t>(1, ((int64_t)(expR / 64.0) + B + 3 * c->num_cu - 1) / (3 * (int64_t)c->num_cu)));
     hipLaunchKernelGGL(k_probscan, dim3(1), dim3(64), 0, WS.stream, B, SPI, SZ.capNnz, dS, dT);
@@ -448,39 +452,20 @@ int enqueue_score(roman_ctx* c, const DevParams& Din, const roman_params_t* para
 
     StageTimer t2(c, ROMAN_STAGE_FILL);
     if (sumA > 0) {
-        // slice-image fill (stream layout): column tile + one slice image (640 bytes per entry column) + 16 owner lines
+        // list fill (stream layout): column tile + the rows and slice tables of one group
         const int colBytesF = D.gravity ? 32 : 16;
         const int TCs = D.stream_maxL;
-        const size_t fixedLds = (size_t)TCs * (colBytesF + 2) + (size_t)16 * 64 * sizeof(uint32_t) + (size_t)FILLS_MAXSPI * 64 * sizeof(uint32_t);
-        if (fixedLds + 640 * 8 > c->lds_max) return fail(c, ROMAN_E_TOO_LARGE, "internal: stream column tile does not fit the LDS");
-        const int EC = (int)std::min<size_t>((c->lds_max - fixedLds) / 640, 4096) & ~3;
-        const size_t sliceLds = fixedLds + (size_t)EC * 640;
-        auto kf = D.gravity ? k_fill_slice<true> : k_fill_slice<false>;
-        unsigned long long* fdbg = nullptr;
-#ifdef ROMAN_FILL_TIMING
-        HIPCHK(c, WS.hAux3.ensure(sizeof(unsigned long long) * 8));
-        HIPCHK(c, hipMemsetAsync(WS.hAux3.p, 0, sizeof(unsigned long long) * 8, WS.stream));
-        fdbg = WS.hAux3.as<unsigned long long>();
-#endif
+        const size_t sliceLds = (size_t)TCs * (colBytesF + 2) + sizeof(uint32_t) * (size_t)(3 * FILLS_MAXSPI * 64 + 2 * (FILLS_MAXSPI + 1));
+        if (sliceLds > c->lds_max) return fail(c, ROMAN_E_TOO_LARGE, "internal: stream column tile does not fit the LDS");
+        const bool fast = D.single && D.p.single_mode != ROMAN_SINGLE_DIAG && D.p.distance_weight == 1.0 &&
+                          D.p.fusion_method != ROMAN_FUSE_ARITHMETIC_MEAN && D.p.fusion_method != ROMAN_FUSE_PRODUCT;
+        auto kf = D.gravity ? (fast ? k_fill_list<true, true> : k_fill_list<true, false>) : (fast ? k_fill_list<false, true> : k_fill_list<false, false>);
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sliceLds));
         hipLaunchKernelGGL(kf, dim3((unsigned)(c->num_cu & ~7)), dim3(1024), sliceLds, WS.stream,
                            D, B, dP, dS, dT, WS.tabPool.as<double>(), LP.li, LP.lj, LP.ls, LP.lza, LP.lzb,
-                           WS.umaskPool.as<unsigned long long>(), WS.prefPool.as<uint32_t>(), WS.perm.as<uint32_t>(), WS.rowPos.as<uint32_t>(),
-                           WS.sliceWidth.as<uint32_t>(), WS.sliceBase.as<uint32_t>(), WS.cols16.as<uint16_t>(), WS.vals.as<double>(), TCs, EC, SPI,
-                           fdbg);
-    DBG(c, "k_fill_slice");
-#ifdef ROMAN_FILL_TIMING
-        {
-            unsigned long long h[8];
-            HIPCHK(c, hipMemcpyAsync(h, fdbg, sizeof(h), hipMemcpyDeviceToHost, WS.stream));
-            HIPCHK(c, hipStreamSynchronize(WS.stream));
-            const char* nm[8] = {"stage-columns", "zero-image", "expand", "gather-wait", "evaluate", "barrier", "write-out", "tail"};
-            const double nwv = (double)(c->num_cu & ~7) * 16.0;
-            fprintf(stderr, "[fill timing] B=%d SPI=%d EC=%d cycles/wave:", B, SPI, EC);
-            for (int t = 0; t < 8; ++t) fprintf(stderr, " %s %.0f", nm[t], (double)h[t] / nwv);
-            fprintf(stderr, "\n");
-        }
-#endif
+                           WS.listPool.as<uint16_t>(), WS.listOff.as<uint32_t>(), WS.rowCnt.as<uint32_t>(), WS.perm.as<uint32_t>(), WS.rowPos.as<uint32_t>(),
+                           WS.sliceWidth.as<uint32_t>(), WS.sliceBase.as<uint32_t>(), WS.cols16.as<uint16_t>(), WS.vals.as<double>(), TCs, SPI);
+    DBG(c, "k_fill_list");
         // fallback layout (symmetric SELL-64, 32-bit indices) for the problems the stream layout does not take: only when
         // one can exist (the kernel would find no work otherwise)
         if (SZ.maxA > D.stream_maxL) {
@@ -629,8 +614,8 @@ bool batch_overflowed(roman_ctx* c)
     harvest_totals(c, true);
     static const bool dbg = getenv("ROMAN_DEBUG") != nullptr;
     const BatchTotals& t = *WS.pinnedTotals;
-    if (dbg) fprintf(stderr, "[roman] batch totals: R=%d maxL=%d items=%d maskWords need %lld cap %lld, nnz need %lld cap %lld, overflow=%d sliceGroups=%d\n",
-                     t.R, t.maxL, t.items, (long long)t.needMaskWords, WS.capMaskWords, (long long)t.needNnz, WS.capNnz, t.overflow, t.sliceGroups);
+    if (dbg) fprintf(stderr, "[roman] batch totals: R=%d maxL=%d items=%d maskWords need %lld cap %lld, nnz need %lld cap %lld, list need %llu cap %lld, overflow=%d sliceGroups=%d\n",
+                     t.R, t.maxL, t.items, (long long)t.needMaskWords, WS.capMaskWords, (long long)t.needNnz, WS.capNnz, t.listTop, WS.capList, t.overflow, t.sliceGroups);
     return t.overflow > 0;
 }
 
@@ -833,7 +818,7 @@ int roman_ctx_destroy(roman_ctx_t* c)
         roman_ctx::Workspace& W = c->ws[k];
         DevBuf* all[] = {&W.probs, &W.state, &W.totals, &W.queue, &W.cosPool, &W.tabPool, &W.sTmp, &W.chunkCnt,
                          &W.lp, &W.li, &W.lj, &W.ls, &W.ld, &W.lza, &W.lzb, &W.plp, &W.pli, &W.plj, &W.pls, &W.pld, &W.plza, &W.plzb,
-                         &W.rowCnt, &W.rowPos, &W.perm, &W.sliceWidth, &W.sliceBase, &W.items, &W.maskPool, &W.umaskPool, &W.prefPool,
+                         &W.rowCnt, &W.rowPos, &W.perm, &W.sliceWidth, &W.sliceBase, &W.items, &W.maskPool, &W.prefPool, &W.listPool, &W.listOff,
                          &W.vMu, &W.vCu, &W.vMun, &W.vCun, &W.gU, &W.gUn, &W.uOut, &W.nodesOrig, &W.nSel, &W.cols16, &W.cols32, &W.vals,
                          &W.hFeats, &W.hAssoc, &W.hU0, &W.oAssoc, &W.oN, &W.oT, &W.oStatus, &W.oStats, &W.hAux1, &W.hAux2, &W.hAux3};
         for (DevBuf* b : all) b->release();
