@@ -23,6 +23,7 @@
 // Layout of kind 1 (sorted SELL-64, both triangles): entry e of the row in slot (slice s, lane l) sits at
 //      sliceBase[s] + e*64 + l .
 #pragma once
+#include <hip/hip_cooperative_groups.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/roman_hip.h"
@@ -900,7 +901,6 @@ __global__ void __launch_bounds__(1024) k_rowsort(const ProbDesc* __restrict__ p
     __shared__ uint32_t hist[SORT_KEYS];         // indexed by SORT_KEYS-1-key: ascending index = descending count
     __shared__ uint32_t wsum[16];
     __shared__ uint32_t carry_s;
-    __shared__ unsigned long long lbase_s;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nt = blockDim.x, nw = nt >> 6;
     const int L = st[b].L;
     const int64_t lo = probs[b].liveOff;
@@ -946,7 +946,6 @@ __global__ void __launch_bounds__(1024) k_rowsort(const ProbDesc* __restrict__ p
             for (int t = 0; t < nw; ++t) { if (t < w) wbase += wsum[t]; total += wsum[t]; }
             if (tid == 0) {
                 const unsigned long long base = atomicAdd(&tot->listTop, (unsigned long long)total);
-                lbase_s = base;
                 st[b].listOff = (int64_t)base;
                 if ((long long)(base + total) > capList) { st[b].kind = 2; atomicAdd(&tot->overflow, 1); }
             }
@@ -1793,8 +1792,33 @@ __device__ __noinline__ void finish_one(const DevParams& D, int b, const ProbDes
 }
 
 
+// ---- whole-grid variants of the barrier and of block_sum2, for the cooperative launch of the fallback solver ----
+template <bool COOP> __device__ __forceinline__ void sync_all()
+{
+    if (COOP) cooperative_groups::this_grid().sync(); else __syncthreads();
+}
+// Sums of (a, b) over every thread of the grid, identical in all of them: block partials (block_sum2) into a ping-pong
+// slot array (one slot per workgroup; a slot array is rewritten two reductions later, behind the barrier of the one in
+// between), grid barrier, then every wave adds the partials in ONE fixed order.
+__device__ __forceinline__ void grid_sum2(double& a, double& b, double* red, int& par, int ltid, int nw, double* part, int& gpar)
+{
+    block_sum2(a, b, red, par, ltid, nw);
+    const int G = (int)gridDim.x;
+    double* slot = part + (size_t)gpar * 2 * (size_t)G;
+    gpar ^= 1;
+    if (ltid == 0) { slot[2 * blockIdx.x] = a; slot[2 * blockIdx.x + 1] = b; }
+    cooperative_groups::this_grid().sync();
+    double sa = 0.0, sb = 0.0;
+    for (int i = (ltid & 63); i < G; i += WAVE) { sa += slot[2 * i]; sb += slot[2 * i + 1]; }
+    for (int off = 32; off > 0; off >>= 1) { sa += __shfl_xor(sa, off); sb += __shfl_xor(sb, off); }
+    a = sa; b = sb;
+}
+
 /*
- * solve_one: CLIPPER findDenseClique on one problem, by one workgroup.
+ * solve_one: CLIPPER findDenseClique on one problem, by one workgroup — or, COOP, by every workgroup of a
+ * cooperative launch together (the large-problem path: all vectors in the pools, the SELL slices and the vector
+ * elements dealt over the whole grid, grid barriers where the single workgroup has block barriers; only workgroup
+ * 0 runs the shared tail).
  * Mirrors oracle_solve() step for step (see there for the restated upstream algorithm):
  * gradF is never stored: it is recombined on the fly from (u, Mu, Cu, d, sum u), bitwise the same
  * value the oracle keeps in its gradF vector.
@@ -1802,7 +1826,7 @@ __device__ __noinline__ void finish_one(const DevParams& D, int b, const ProbDes
 // MODE 2: u, u_new, Mu, Cu, Mu_new, Cu_new and the diagonal all live in LDS (7 * Lcap doubles);
 // MODE 1: only u and u_new (the gathered vectors) do, the row vectors sit in the L2-resident pools;
 // MODE 0: nothing fits, everything is in the pools.
-template <typename IdxT, int MODE>
+template <typename IdxT, int MODE, bool COOP = false>
 __device__ void solve_one(const DevParams& D, int b, const ProbDesc& pd, ProbState* st,
                           const double* __restrict__ feats, const int32_t* __restrict__ assoc,
                           const int32_t* __restrict__ lp, const double* __restrict__ ls,
@@ -1813,10 +1837,19 @@ __device__ void solve_one(const DevParams& D, int b, const ProbDesc& pd, ProbSta
                           double* __restrict__ vMun, double* __restrict__ vCun,
                           double* __restrict__ gU, double* __restrict__ gUn,
                           const double* __restrict__ u0, const SolveOut& O,
-                          double* sv /* LDS vectors */, int Lcap, double* red, int* sint)
+                          double* sv /* LDS vectors */, int Lcap, double* red, int* sint,
+                          double* part = nullptr /* COOP: 2 x gridDim.x x 2 doubles */, int* gparp = nullptr)
 {
+    static_assert(!COOP || MODE == 0, "the cooperative solver keeps every vector in the pools");
     const roman_params_t& P = D.p;
-    const int tid = threadIdx.x, nt = blockDim.x, nw = nt >> 6;
+    const int ltid = threadIdx.x, nw = blockDim.x >> 6;
+    // COOP: the element / slice owner index runs over the whole grid, wave-interleaved over the workgroups (consecutive
+    // SELL slices — the rows are sorted by length — go to different compute units)
+    const int nt = COOP ? (int)(blockDim.x * gridDim.x) : (int)blockDim.x;
+    const int tid = COOP ? ((((ltid >> 6) * (int)gridDim.x + (int)blockIdx.x) << 6) | (ltid & 63)) : ltid;
+    int gpar_local = 0;
+    int& gpar = gparp ? *gparp : gpar_local;
+#define SUM2(a_, b_) do { if (COOP) grid_sum2(a_, b_, red, par, ltid, nw, part, gpar); else block_sum2(a_, b_, red, par, ltid, nw); } while (0)
     const int L = st[b].L, rb = st[b].rowBase;
     const int64_t lo = pd.liveOff;
     const uint32_t* perm = permPool + lo; const uint32_t* swid = sliceWidthPool + lo; const uint32_t* sbase = sliceBasePool + lo;
@@ -1848,24 +1881,24 @@ __device__ void solve_one(const DevParams& D, int b, const ProbDesc& pd, ProbSta
     if (L > 0) {
         // ---- initialisation: u = normalize(M u0 + diag u0) ------------------------------------
         for (int p = tid; p < L; p += nt) u[p] = u0 ? u0[lo + lp[lo + p]] : 1.0;
-        __syncthreads();
+        sync_all<COOP>();
         if (P.rescale_u0) {
             spmv_sell<IdxT, 8>(u, L, perm, swid, sbase, cols, vals, Mu, Cu, tid, nt); ++S.n_pass;
-            __syncthreads();
+            sync_all<COOP>();
             for (int p = tid; p < L; p += nt) u[p] = Mu[p] + sd[p] * u[p];
-            __syncthreads();
+            sync_all<COOP>();
         }
         {
             double ss = 0.0, dummy = 0.0;
             for (int p = tid; p < L; p += nt) ss += u[p] * u[p];
-            block_sum2(ss, dummy, red, par, tid, nw);
+            SUM2(ss, dummy);
             const double nr = sqrt(ss);
             if (nr > 0.0) for (int p = tid; p < L; p += nt) u[p] /= nr;
-            __syncthreads();
+            sync_all<COOP>();
         }
         spmv_sell<IdxT, 8>(u, L, perm, swid, sbase, cols, vals, Mu, Cu, tid, nt); ++S.n_pass;
         double usum = 0.0;
-        { double dummy = 0.0; for (int p = tid; p < L; p += nt) usum += u[p]; block_sum2(usum, dummy, red, par, tid, nw); }
+        { double dummy = 0.0; for (int p = tid; p < L; p += nt) usum += u[p]; SUM2(usum, dummy); }
         // the barrier inside block_sum2 also orders the Mu/Cu stores of spmv_sell before the reads below
         {   // initial d: signed mean of (Mu)_p / Cbu_p over the active set
             double acc = 0.0, cnt = 0.0;
@@ -1873,7 +1906,7 @@ __device__ void solve_one(const DevParams& D, int b, const ProbDesc& pd, ProbSta
                 const double up = u[p], Cbu = (usum - Cu[p]) - up;
                 if (Cbu > P.eps && up > P.eps) { acc += (Mu[p] + sd[p] * up) / Cbu; cnt += 1.0; }
             }
-            block_sum2(acc, cnt, red, par, tid, nw);
+            SUM2(acc, cnt);
             d = (cnt > 0.0) ? acc / cnt : 0.0;
         }
         // ---- projected gradient ascent with homotopy on d ---------------------------------------
@@ -1886,7 +1919,7 @@ __device__ void solve_one(const DevParams& D, int b, const ProbDesc& pd, ProbSta
                     const double g = (((sd[p] + d) * up - d * usum) + Mu[p]) + Cu[p] * d;
                     f += up * g;
                 }
-                block_sum2(f, dummy, red, par, tid, nw);
+                SUM2(f, dummy);
                 F = f;
             }
             for (int j = 0; j < P.maxiniters; ++j) {
@@ -1900,7 +1933,7 @@ __device__ void solve_one(const DevParams& D, int b, const ProbDesc& pd, ProbSta
                         t = t > 0.0 ? t : 0.0;
                         un[p] = t; ss += t * t;
                     }
-                    block_sum2(ss, dummy, red, par, tid, nw);
+                    SUM2(ss, dummy);
                     const double nr = sqrt(ss);
                     double s1 = 0.0, dd = 0.0;
                     for (int p = tid; p < L; p += nt) {
@@ -1909,17 +1942,17 @@ __device__ void solve_one(const DevParams& D, int b, const ProbDesc& pd, ProbSta
                         s1 += t;
                         const double df = t - u[p]; dd += df * df;
                     }
-                    block_sum2(s1, dd, red, par, tid, nw);
+                    SUM2(s1, dd);
                     unsum = s1; du2 = dd;
                     spmv_sell<IdxT, 8>(un, L, perm, swid, sbase, cols, vals, Mun, Cun, tid, nt); ++S.n_pass; ++S.ls_trials;
-                    __syncthreads();
+                    sync_all<COOP>();
                     double f = 0.0;
                     for (int p = tid; p < L; p += nt) {
                         const double up = un[p];
                         const double g = (((sd[p] + d) * up - d * unsum) + Mun[p]) + Cun[p] * d;
                         f += up * g;
                     }
-                    block_sum2(f, dummy, red, par, tid, nw);
+                    SUM2(f, dummy);
                     Fnew = f;
                     deltaF = Fnew - F;
                     if (deltaF < -P.eps) alpha *= P.beta; else break;
@@ -1935,17 +1968,22 @@ __device__ void solve_one(const DevParams& D, int b, const ProbDesc& pd, ProbSta
                 const double up = u[p], Cbu = (usum - Cu[p]) - up;
                 if (Cbu > P.eps && up > P.eps) { acc += fabs((Mu[p] + sd[p] * up) / Cbu); cnt += 1.0; }
             }
-            block_sum2(acc, cnt, red, par, tid, nw);
+            SUM2(acc, cnt);
             if (cnt > 0.0) d += acc / cnt; else break;
         }
         if (i >= P.maxoliters) status |= ROMAN_ST_MAXITER;
         S.outer_iters = i; S.score = F; S.d_final = d;
 
-        finish_one(D, b, pd, feats, assoc, lp, lp, nullptr, O, u, Mun, (int32_t*)un, (int32_t*)Cun, L, rb, lo, F, status, S, red, sint);
+        sync_all<COOP>();                         // every element of the final u is in memory
+        if (!COOP || blockIdx.x == 0)
+            finish_one(D, b, pd, feats, assoc, lp, lp, nullptr, O, u, Mun, (int32_t*)un, (int32_t*)Cun, L, rb, lo, F, status, S, red, sint);
         return;
     }
-    finish_one(D, b, pd, feats, assoc, lp, lp, nullptr, O, nullptr, nullptr, nullptr, nullptr, L, rb, lo, F, status, S, red, sint);
+    if (!COOP || blockIdx.x == 0)
+        finish_one(D, b, pd, feats, assoc, lp, lp, nullptr, O, nullptr, nullptr, nullptr, nullptr, L, rb, lo, F, status, S, red, sint);
+#undef SUM2
 }
+
 
 template <typename IdxT, int MODE>
 __global__ void __launch_bounds__(1024) k_solve(DevParams D, int B, const ProbDesc* __restrict__ probs,
@@ -1982,6 +2020,34 @@ __global__ void __launch_bounds__(1024) k_solve(DevParams D, int B, const ProbDe
             else
                 solve_one<IdxT, 0>(D, b, pd, st, feats, assoc, lp, ls, perm, sliceWidth, sliceBase, cols, vals,
                                    vMu, vCu, vMun, vCun, gU, gUn, u0, O, sv, Lcap, red, sint);
+        }
+    }
+}
+
+// k_solve_coop: the fallback solver for FEW, LARGE problems — launched cooperatively (hipLaunchCooperativeKernel: every
+// workgroup resident), all workgroups solve the kind-1 problems of the batch one after the other TOGETHER: the SpMV of a
+// 40 000-row problem is 0.5 GB per pass, which one compute unit streams at a few GB/s and the whole device at TB/s.
+template <typename IdxT>
+__global__ void __launch_bounds__(1024) k_solve_coop(DevParams D, int B, const ProbDesc* __restrict__ probs,
+                                                     ProbState* __restrict__ st,
+                                                     const double* __restrict__ feats, const int32_t* __restrict__ assoc,
+                                                     const int32_t* __restrict__ lp, const double* __restrict__ ls,
+                                                     const uint32_t* __restrict__ perm, const uint32_t* __restrict__ sliceWidth,
+                                                     const uint32_t* __restrict__ sliceBase,
+                                                     const IdxT* __restrict__ cols, const double* __restrict__ vals,
+                                                     double* __restrict__ vMu, double* __restrict__ vCu,
+                                                     double* __restrict__ vMun, double* __restrict__ vCun,
+                                                     double* __restrict__ gU, double* __restrict__ gUn,
+                                                     const double* __restrict__ u0, SolveOut O, double* __restrict__ part)
+{
+    __shared__ double red[72];
+    __shared__ int sint[4];
+    int gpar = 0;
+    for (int b = 0; b < B; ++b) {
+        if (__builtin_amdgcn_readfirstlane(st[b].kind) == 1) {
+            const ProbDesc pd = probs[b];
+            solve_one<IdxT, 0, true>(D, b, pd, st, feats, assoc, lp, ls, perm, sliceWidth, sliceBase, cols, vals,
+                                     vMu, vCu, vMun, vCun, gU, gUn, u0, O, nullptr, 0, red, sint, part, &gpar);
         }
     }
 }
@@ -2495,9 +2561,11 @@ __global__ void __launch_bounds__(NW * 64) k_solve_up(DevParams D, int B, const 
 }
 
 // k_skipped: result records of the problems that found no workspace (kind 2): ROMAN_ST_WORKSPACE, no associations,
-// NaN pose.  One thread per problem.
-__global__ void __launch_bounds__(256) k_skipped(int B, const ProbDesc* __restrict__ probs, const ProbState* __restrict__ st, SolveOut O)
+// NaN pose.  One thread per problem.  Runs right before the solver kernels and also resets their problem queues.
+__global__ void __launch_bounds__(256) k_skipped(int B, const ProbDesc* __restrict__ probs, const ProbState* __restrict__ st, SolveOut O,
+                                                 int* __restrict__ queue /* the solvers' problem queues (8 ints): cleared here */)
 {
+    if (blockIdx.x == 0 && threadIdx.x < 8) queue[threadIdx.x] = 0;
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B || st[b].kind != 2) return;
     for (int t = 0; t < 16; ++t) O.T_out[(int64_t)b * 16 + t] = d_nan();

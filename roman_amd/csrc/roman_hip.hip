@@ -53,6 +53,7 @@ struct roman_ctx {
     bool own_stream = false;
     int num_cu = 256;
     size_t lds_max = 65536;
+    bool coop_ok = false;                      // hipLaunchCooperativeKernel available (large-problem solver)
     std::string err;
 
     // Workspace: every device pool of one batch in flight, its stream and its profiling events.  With
@@ -69,13 +70,15 @@ struct roman_ctx {
         DevBuf lp, li, lj, ls, ld, lza, lzb;                       // per live association, live order
         DevBuf plp, pli, plj, pls, pld, plza, plzb;                // the same in position order (stream layout)
         DevBuf rowCnt, rowPos, perm, sliceWidth, sliceBase, items, maskPool, prefPool, listPool, listOff;
-        DevBuf vMu, vCu, vMun, vCun, gU, gUn, uOut, nodesOrig, nSel;
+        DevBuf vMu, vCu, vMun, vCun, gU, gUn, uOut, nodesOrig, nSel, coopPart;
         DevBuf cols16, cols32, vals;
         long long capMaskWords = 0, capNnz = 0, capList = 0;       // what the sparse pools hold (elements)
         // staging for the host-pointer entry points
         DevBuf hFeats, hAssoc, hU0, oAssoc, oN, oT, oStatus, oStats, hAux1, hAux2, hAux3;
         // totals of the most recent batch on this workspace, copied back without waiting
         BatchTotals* pinnedTotals = nullptr;
+        ProbDesc* pinnedProbs = nullptr; size_t pinnedProbsCap = 0;   // staging of the problem descriptors (truly asynchronous upload)
+        hipEvent_t probsEvent = nullptr; bool probsPending = false;
         hipEvent_t totEvent = nullptr;
         bool totPending = false;
         double totMaskBound = 0.0, totSumA = 0.0, totMaxA = 0.0;   // the bounds the pending totals relate to
@@ -101,6 +104,8 @@ struct roman_ctx {
         double rList = 0.0;                    // candidate-list elements / sum of nA
     } hist;
 
+    std::vector<std::pair<const void*, int>> ldsAttr;   // dynamic-LDS limits already set (per kernel function)
+
     bool profile = false;
     double prof_ms[ROMAN_STAGE_COUNT] = {0, 0, 0, 0};
     int64_t prof_n[ROMAN_STAGE_COUNT] = {0, 0, 0, 0};
@@ -122,6 +127,18 @@ struct roman_ctx {
 };
 
 #define WS (c->ws[c->cur])
+
+// hipFuncAttributeMaxDynamicSharedMemorySize, raised only when a launch needs more than the function already has
+static hipError_t dyn_lds(roman_ctx* c, const void* fn, size_t bytes)
+{
+    for (auto& e : c->ldsAttr) if (e.first == fn) {
+        if ((size_t)e.second >= bytes) return hipSuccess;
+        e.second = (int)bytes;
+        return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    }
+    c->ldsAttr.emplace_back(fn, (int)bytes);
+    return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
 
 namespace {
 
@@ -355,7 +372,20 @@ int enqueue_score(roman_ctx* c, const DevParams& Din, const roman_params_t* para
     const size_t maxItems = (size_t)(sumA / RPB) + (size_t)B + 1;
     HIPCHK(c, WS.items.ensure(sizeof(ItemDesc) * maxItems));
 
-    HIPCHK(c, hipMemcpyAsync(WS.probs.p, hd.data(), sizeof(ProbDesc) * (size_t)B, hipMemcpyHostToDevice, WS.stream));
+    {   // descriptors: through pinned staging (a pageable source makes the runtime stage the copy itself, at several times the cost)
+        if (WS.probsPending) { HIPCHK(c, hipEventSynchronize(WS.probsEvent)); WS.probsPending = false; }   // the previous upload has left the staging
+        if (WS.pinnedProbsCap < (size_t)B) {
+            if (WS.pinnedProbs) (void)hipHostFree(WS.pinnedProbs);
+            WS.pinnedProbs = nullptr; WS.pinnedProbsCap = 0;
+            const size_t cap = std::max<size_t>((size_t)B * 2, 64);
+            HIPCHK(c, hipHostMalloc((void**)&WS.pinnedProbs, sizeof(ProbDesc) * cap, hipHostMallocDefault));
+            WS.pinnedProbsCap = cap;
+        }
+        memcpy(WS.pinnedProbs, hd.data(), sizeof(ProbDesc) * (size_t)B);
+        HIPCHK(c, hipMemcpyAsync(WS.probs.p, WS.pinnedProbs, sizeof(ProbDesc) * (size_t)B, hipMemcpyHostToDevice, WS.stream));
+        HIPCHK(c, hipEventRecord(WS.probsEvent, WS.stream));
+        WS.probsPending = true;
+    }
     const ProbDesc* dP = WS.probs.as<ProbDesc>();
     ProbState* dS = WS.state.as<ProbState>();
     BatchTotals* dT = WS.totals.as<BatchTotals>();
@@ -371,7 +401,7 @@ int enqueue_score(roman_ctx* c, const DevParams& Din, const roman_params_t* para
     if (maxTab > 0) {
         const size_t tabLds = sizeof(double) * 3 * (size_t)std::max(maxN, 1);
         if (tabLds > c->lds_max) return fail(c, ROMAN_E_TOO_LARGE, "maps of %d objects exceed the LDS point staging of this build", maxN);
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_tables), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tabLds));
+        HIPCHK(c, dyn_lds(c, reinterpret_cast<const void*>(k_tables), tabLds));
         hipLaunchKernelGGL(k_tables, dim3((unsigned)((maxN + 7) / 8), 2, B), dim3(256), tabLds, WS.stream, D, dP, in.feats, WS.tabPool.as<double>());
     DBG(c, "k_tables");
     }
@@ -418,7 +448,7 @@ int enqueue_score(roman_ctx* c, const DevParams& Din, const roman_params_t* para
         case 3: kc = NRc == 2 ? k_count<3, 2> : k_count<3, 1>; break;
         default: break;
         }
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kc), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pairLds));
+        HIPCHK(c, dyn_lds(c, reinterpret_cast<const void*>(kc), pairLds));
         hipLaunchKernelGGL(kc, dim3(pairGrid), dim3(wpb * 64), pairLds, WS.stream, D, dP, dS, dT, WS.items.as<ItemDesc>(), WS.tabPool.as<double>(),
                            LP.li, LP.lj, LP.lza, LP.lzb,
                            WS.rowCnt.as<uint32_t>(), WS.maskPool.as<unsigned long long>(), WS.prefPool.as<uint32_t>(), TCc, ldsPerWave, RPB);
@@ -460,7 +490,7 @@ int enqueue_score(roman_ctx* c, const DevParams& Din, const roman_params_t* para
         const bool fast = D.single && D.p.single_mode != ROMAN_SINGLE_DIAG && D.p.distance_weight == 1.0 &&
                           D.p.fusion_method != ROMAN_FUSE_ARITHMETIC_MEAN && D.p.fusion_method != ROMAN_FUSE_PRODUCT;
         auto kf = D.gravity ? (fast ? k_fill_list<true, true> : k_fill_list<true, false>) : (fast ? k_fill_list<false, true> : k_fill_list<false, false>);
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sliceLds));
+        HIPCHK(c, dyn_lds(c, reinterpret_cast<const void*>(kf), sliceLds));
         hipLaunchKernelGGL(kf, dim3((unsigned)(c->num_cu & ~7)), dim3(1024), sliceLds, WS.stream,
                            D, B, dP, dS, dT, WS.tabPool.as<double>(), LP.li, LP.lj, LP.ls, LP.lza, LP.lzb,
                            WS.listPool.as<uint16_t>(), WS.listOff.as<uint32_t>(), WS.rowCnt.as<uint32_t>(), WS.perm.as<uint32_t>(), WS.rowPos.as<uint32_t>(),
@@ -476,7 +506,7 @@ int enqueue_score(roman_ctx* c, const DevParams& Din, const roman_params_t* para
             const size_t fillLds = ringLds + (size_t)TCf * colBytesG;
             const int fillGrid = c->num_cu * std::max(1, std::min(2, (int)(c->lds_max / fillLds)));
             auto kg = D.gravity ? k_fill<true, uint32_t, false> : k_fill<false, uint32_t, false>;
-            HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kg), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fillLds));
+            HIPCHK(c, dyn_lds(c, reinterpret_cast<const void*>(kg), fillLds));
             hipLaunchKernelGGL(kg, dim3(fillGrid), dim3(1024), fillLds, WS.stream, D, dP, dS, dT, WS.items.as<ItemDesc>(), WS.tabPool.as<double>(),
                                LP.li, LP.lj, LP.ls, LP.lza, LP.lzb,
                                WS.rowCnt.as<uint32_t>(), WS.maskPool.as<unsigned long long>(), WS.prefPool.as<uint32_t>(), WS.rowPos.as<uint32_t>(),
@@ -496,12 +526,11 @@ int enqueue_score(roman_ctx* c, const DevParams& Din, const roman_params_t* para
 // Solver + rounding + pose on the matrices held by the workspace.  `feats` may be NULL (dense
 // matrix problems have no points: the pose is skipped).  mayFallback: a problem of the fallback kind can exist.
 int enqueue_solve(roman_ctx* c, const DevParams& D, int B, int64_t sumA, const double* feats, const int32_t* assoc,
-                  const double* u0, bool hascz, bool mayFallback, const BatchOut& out)
+                  const double* u0, bool hascz, int mayFallback /* problems that can be of the fallback kind */, const BatchOut& out)
 {
     const size_t R1 = (size_t)std::max<int64_t>(sumA, 1);
     HIPCHK(c, WS.uOut.ensure(sizeof(double) * R1)); HIPCHK(c, WS.nodesOrig.ensure(sizeof(int32_t) * R1));
     HIPCHK(c, WS.nSel.ensure(sizeof(int32_t) * (size_t)B));
-    HIPCHK(c, hipMemsetAsync(WS.queue.p, 0, sizeof(int) * 8, WS.stream));
     SolveOut O;
     O.assoc_out = out.assoc_out; O.n_assoc_out = out.n_assoc_out; O.T_out = out.T_out; O.status_out = out.status_out; O.stats_out = out.stats_out; O.kmax = out.kmax;
     O.nodesOrig = WS.nodesOrig.as<int32_t>(); O.nSel = WS.nSel.as<int32_t>(); O.uOut = WS.uOut.as<double>();
@@ -520,11 +549,11 @@ int enqueue_solve(roman_ctx* c, const DevParams& D, int B, int64_t sumA, const d
     const int gridUp = std::max(1, std::min(B, c->num_cu * wgPerCu));
 
     StageTimer t3(c, ROMAN_STAGE_SOLVE);
-    hipLaunchKernelGGL(k_skipped, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, WS.stream, B, WS.probs.as<ProbDesc>(), WS.state.as<ProbState>(), O);
+    hipLaunchKernelGGL(k_skipped, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, WS.stream, B, WS.probs.as<ProbDesc>(), WS.state.as<ProbState>(), O, WS.queue.as<int>());
     DBG(c, "k_skipped");
 #define ROMAN_LAUNCH_UP(CZ_)                                                                                                  \
     do {                                                                                                                      \
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve_up<NW, CZ_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsUp)); \
+        HIPCHK(c, dyn_lds(c, reinterpret_cast<const void*>(k_solve_up<NW, CZ_>), ldsUp)); \
         hipLaunchKernelGGL((k_solve_up<NW, CZ_>), dim3(gridUp), dim3(NW * 64), ldsUp, WS.stream, D, B, WS.probs.as<ProbDesc>(), WS.state.as<ProbState>(), feats, assoc, \
                            WS.plp.as<int32_t>(), WS.lp.as<int32_t>(), WS.rowPos.as<uint32_t>(), WS.pld.as<double>(), WS.sliceBase.as<uint32_t>(), \
                            WS.cols16.as<uint16_t>(), WS.vals.as<double>(), u0, O, WS.queue.as<int>(), Lc);                     \
@@ -537,15 +566,43 @@ int enqueue_solve(roman_ctx* c, const DevParams& D, int B, int64_t sumA, const d
         HIPCHK(c, WS.vMu.ensure(sizeof(double) * R1)); HIPCHK(c, WS.vCu.ensure(sizeof(double) * R1));
         HIPCHK(c, WS.vMun.ensure(sizeof(double) * R1)); HIPCHK(c, WS.vCun.ensure(sizeof(double) * R1));
         HIPCHK(c, WS.gU.ensure(sizeof(double) * R1)); HIPCHK(c, WS.gUn.ensure(sizeof(double) * R1));
+        // Few (large) problems: all compute units solve them together, one after the other (cooperative launch); many:
+        // one workgroup per problem, u and u' in LDS when they fit.
+        static const char* coopEnv = getenv("ROMAN_COOP");      // "0": never, "1": whenever a fallback problem can exist
+        bool coop = c->coop_ok && (coopEnv ? coopEnv[0] == '1' : mayFallback <= std::max(1, c->num_cu / 16));
+        if (coop) {
+            const int G = c->num_cu;
+            HIPCHK(c, WS.coopPart.ensure(sizeof(double) * 4 * (size_t)G));
+            DevParams Dv = D; int Bv = B;
+            const ProbDesc* a_probs = WS.probs.as<ProbDesc>(); ProbState* a_state = WS.state.as<ProbState>();
+            const double* a_feats = feats; const int32_t* a_assoc = assoc;
+            const int32_t* a_lp = WS.lp.as<int32_t>(); const double* a_ld = WS.ld.as<double>();
+            const uint32_t* a_perm = WS.perm.as<uint32_t>(); const uint32_t* a_sw = WS.sliceWidth.as<uint32_t>(); const uint32_t* a_sb = WS.sliceBase.as<uint32_t>();
+            const uint32_t* a_cols = WS.cols32.as<uint32_t>(); const double* a_vals = WS.vals.as<double>();
+            double* a_vMu = WS.vMu.as<double>(); double* a_vCu = WS.vCu.as<double>(); double* a_vMun = WS.vMun.as<double>(); double* a_vCun = WS.vCun.as<double>();
+            double* a_gU = WS.gU.as<double>(); double* a_gUn = WS.gUn.as<double>();
+            const double* a_u0 = u0; SolveOut a_O = O; double* a_part = WS.coopPart.as<double>();
+            void* args[] = {&Dv, &Bv, &a_probs, &a_state, &a_feats, &a_assoc, &a_lp, &a_ld, &a_perm, &a_sw, &a_sb, &a_cols, &a_vals,
+                            &a_vMu, &a_vCu, &a_vMun, &a_vCun, &a_gU, &a_gUn, &a_u0, &a_O, &a_part};
+            const hipError_t e = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(k_solve_coop<uint32_t>), dim3((unsigned)G), dim3(1024), args, 0, WS.stream);
+            if (e != hipSuccess) {                              // not available here: the one-workgroup solver does the same work
+                (void)hipGetLastError();
+                fprintf(stderr, "[roman_hip] cooperative launch failed (%s); large problems use the single-workgroup solver\n", hipGetErrorString(e));
+                c->coop_ok = false; coop = false;
+            }
+    DBG(c, "k_solve_coop");
+        }
+        if (!coop) {
         const size_t fixed = 72 * sizeof(double) + 4 * sizeof(int);
         const int Lcap = (int)(((c->lds_max - fixed) / (2 * sizeof(double))) & ~(size_t)1);
         const size_t lds = (size_t)2 * sizeof(double) * (size_t)Lcap + fixed;
         const int grid = std::max(1, std::min(B, c->num_cu));
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve<uint32_t, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(c, dyn_lds(c, reinterpret_cast<const void*>(k_solve<uint32_t, 1>), lds));
         hipLaunchKernelGGL((k_solve<uint32_t, 1>), dim3(grid), dim3(1024), lds, WS.stream, D, B, WS.probs.as<ProbDesc>(), WS.state.as<ProbState>(), feats, assoc,
                            WS.lp.as<int32_t>(), WS.ld.as<double>(), WS.perm.as<uint32_t>(), WS.sliceWidth.as<uint32_t>(), WS.sliceBase.as<uint32_t>(), WS.cols32.as<uint32_t>(), WS.vals.as<double>(),
                            WS.vMu.as<double>(), WS.vCu.as<double>(), WS.vMun.as<double>(), WS.vCun.as<double>(), WS.gU.as<double>(), WS.gUn.as<double>(),
                            u0, O, WS.queue.as<int>() + 4, Lcap);
+        }
     DBG(c, "k_solve");
     }
     t3.stop();
@@ -579,11 +636,13 @@ int enqueue_solve(roman_ctx* c, const DevParams& D, int B, int64_t sumA, const d
     return ROMAN_OK;
 }
 
-bool may_fallback(const DevParams& D, const std::vector<ProbDesc>& hd)
+// how many problems of the batch can be of the fallback kind (0: none, the fallback solver is not launched)
+int may_fallback(const DevParams& D, const std::vector<ProbDesc>& hd)
 {
-    if (D.p.maxiniters < 1 || D.p.maxlsiters < 1) return true;
-    for (const ProbDesc& d : hd) if (d.nA > D.stream_maxL) return true;
-    return false;
+    if (D.p.maxiniters < 1 || D.p.maxlsiters < 1) return (int)hd.size();
+    int n = 0;
+    for (const ProbDesc& d : hd) if (d.nA > D.stream_maxL) ++n;
+    return n;
 }
 
 int ensure_events(roman_ctx* c)
@@ -637,7 +696,7 @@ int solve_last(roman_ctx* c, const double* u0_host)
     const double* feats = Lst.dense ? nullptr : WS.hFeats.as<double>();
     const int32_t* assoc = (Lst.pd.assocOff >= 0) ? WS.hAssoc.as<int32_t>() : nullptr;
     const BatchOut out{kmax, WS.oAssoc.as<int32_t>(), WS.oN.as<int32_t>(), WS.oT.as<double>(), WS.oStatus.as<int32_t>(), WS.oStats.as<roman_stats_t>()};
-    int rc = enqueue_solve(c, Lst.D, 1, nA, feats, assoc, dU0, Lst.hascz, Lst.kind == 1, out);
+    int rc = enqueue_solve(c, Lst.D, 1, nA, feats, assoc, dU0, Lst.hascz, Lst.kind == 1 ? 1 : 0, out);
     if (rc) return rc;
     int32_t nsel = 0;
     HIPCHK(c, hipMemcpyAsync(&nsel, WS.nSel.p, sizeof(int32_t), hipMemcpyDeviceToHost, WS.stream));
@@ -792,6 +851,7 @@ int roman_ctx_create(roman_ctx_t** out, int device, void* stream)
     c->device = device;
     c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     c->lds_max = prop.sharedMemPerBlock >= 163840 ? (size_t)(160 * 1024 - 256) : (size_t)prop.sharedMemPerBlock;
+    { int coopAttr = 0; c->coop_ok = hipDeviceGetAttribute(&coopAttr, hipDeviceAttributeCooperativeLaunch, device) == hipSuccess && coopAttr != 0; (void)hipGetLastError(); }
     if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
     else {
         if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return fail(nullptr, ROMAN_E_HIP, "hipStreamCreate failed"); }
@@ -800,7 +860,8 @@ int roman_ctx_create(roman_ctx_t** out, int device, void* stream)
     for (int k = 0; k < ROMAN_MAX_PIPELINE; ++k) c->ws[k].stream = c->stream;
     for (int k = 0; k < ROMAN_MAX_PIPELINE; ++k) {
         if (hipHostMalloc((void**)&c->ws[k].pinnedTotals, sizeof(BatchTotals), hipHostMallocDefault) != hipSuccess ||
-            hipEventCreateWithFlags(&c->ws[k].totEvent, hipEventDisableTiming) != hipSuccess) {
+            hipEventCreateWithFlags(&c->ws[k].totEvent, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ws[k].probsEvent, hipEventDisableTiming) != hipSuccess) {
             roman_ctx_destroy(c); return fail(nullptr, ROMAN_E_NOMEM, "hipHostMalloc / hipEventCreate failed");
         }
         memset(c->ws[k].pinnedTotals, 0, sizeof(BatchTotals));
@@ -819,11 +880,13 @@ int roman_ctx_destroy(roman_ctx_t* c)
         DevBuf* all[] = {&W.probs, &W.state, &W.totals, &W.queue, &W.cosPool, &W.tabPool, &W.sTmp, &W.chunkCnt,
                          &W.lp, &W.li, &W.lj, &W.ls, &W.ld, &W.lza, &W.lzb, &W.plp, &W.pli, &W.plj, &W.pls, &W.pld, &W.plza, &W.plzb,
                          &W.rowCnt, &W.rowPos, &W.perm, &W.sliceWidth, &W.sliceBase, &W.items, &W.maskPool, &W.prefPool, &W.listPool, &W.listOff,
-                         &W.vMu, &W.vCu, &W.vMun, &W.vCun, &W.gU, &W.gUn, &W.uOut, &W.nodesOrig, &W.nSel, &W.cols16, &W.cols32, &W.vals,
+                         &W.vMu, &W.vCu, &W.vMun, &W.vCun, &W.gU, &W.gUn, &W.uOut, &W.nodesOrig, &W.nSel, &W.coopPart, &W.cols16, &W.cols32, &W.vals,
                          &W.hFeats, &W.hAssoc, &W.hU0, &W.oAssoc, &W.oN, &W.oT, &W.oStatus, &W.oStats, &W.hAux1, &W.hAux2, &W.hAux3};
         for (DevBuf* b : all) b->release();
         if (W.pinnedTotals) (void)hipHostFree(W.pinnedTotals);
         if (W.totEvent) (void)hipEventDestroy(W.totEvent);
+        if (W.pinnedProbs) (void)hipHostFree(W.pinnedProbs);
+        if (W.probsEvent) (void)hipEventDestroy(W.probsEvent);
         for (int s = 0; s < ROMAN_STAGE_COUNT; ++s) { if (W.evA[s]) (void)hipEventDestroy(W.evA[s]); if (W.evB[s]) (void)hipEventDestroy(W.evB[s]); }
         if (W.done) (void)hipEventDestroy(W.done);
     }

@@ -89,3 +89,18 @@ def test_mixed_batch_large_and_small_live_sets(ctx, orc):
     bad, worst, traj = _compare(orc, reg, res, problems)
     assert not bad and worst < POSE_TOL and not traj
     assert res.stats["n_live"].tolist() == [1600, 6000, 1050, 400]
+
+
+def test_gravity_200x200_all_associations_live(ctx, orc):
+    """method 'gravity' has no semantic gate: at n = m = 200 every one of the 40 000 associations is live — far beyond
+    the stream layout (L <= 3072).  The problem takes the symmetric SELL-64 layout and the COOPERATIVE fallback
+    solver (all compute units on one problem, grid barriers; k_solve_coop): results and pass counts equal the oracle's."""
+    reg = registration_for("gravity"); reg.set_context(ctx)
+    pr = synth.make_pair(200, 200, 0, 7001, tilt_deg=1.0)
+    res = reg.register_and_align_batch([(pr.map1, pr.map2)])
+    D1, D2 = reg.pack(pr.map1), reg.pack(pr.map2)
+    bad, worst, traj = _compare(orc, reg, res, [(D1, D2)])
+    assert not bad and worst < POSE_TOL
+    assert res.stats["n_live"][0] == 40000
+    truth = set(map(tuple, pr.inliers.tolist()))
+    assert len(truth & set(map(tuple, res.assoc[0].tolist()))) >= 0.9 * len(truth)
