@@ -179,18 +179,14 @@ ROMAN_API int roman_ctx_destroy(roman_ctx_t* ctx);
    device-wide synchronisation), NOT after synchronising the context's stream alone; the caller must give
    batches that may be in flight together distinct output buffers if it needs both results.  The
    host-pointer and stepwise entry points always drain the pipeline first and run synchronously.
-   With depth >= 2 roman_align_batch_dev is ASYNCHRONOUS for the host as well: it validates and copies its
-   host-side arguments (params, off1/n1/off2/n2, assoc_off) and returns; a worker thread of the workspace
-   issues the kernels (the sequence blocks twice on a small size read-back, and only a second host thread
-   lets the next batch's first kernels queue up meanwhile).  Device buffers must stay valid until
-   roman_ctx_sync().  A failure inside a queued batch is reported by the next call that touches its
-   workspace (the batch call `depth` calls later, roman_ctx_join or roman_ctx_sync), with its text in
-   roman_last_error(). */
+   roman_align_batch_dev is a pure enqueue at every depth (it never waits for the device and reads nothing
+   back), so one host thread keeps all the batches in flight fed; no library threads exist.  Device buffers
+   must stay valid until roman_ctx_sync(). */
 ROMAN_API int roman_ctx_set_pipeline(roman_ctx_t* ctx, int depth);
 /* Enqueue on the context's stream a wait for the pipelined batches issued so far: all of them, or —
    skip_latest != 0 — all but the most recent one, so that work queued on the caller's stream afterwards
    (e.g. the all_gather of batch k-1's records) sees their results while batch k keeps running.  The host
-   blocks only until the worker threads have QUEUED those batches (not until the GPU has finished them). */
+   does not block. */
 ROMAN_API int roman_ctx_join(roman_ctx_t* ctx, int skip_latest);
 /* Wait for every batch in flight on this context (all internal streams and the context's stream). */
 ROMAN_API int roman_ctx_sync(roman_ctx_t* ctx);
@@ -239,8 +235,12 @@ ROMAN_API const char* roman_last_error(const roman_ctx_t* ctx);
  *
  * The small per-problem metadata arrays are host memory (the library stages them itself);
  * all bulk data stays in HBM.
- * Asynchronous on the context's stream except for one internal 16-byte read-back that sizes
- * the sparse workspace.  Results are complete once the stream is synchronised.
+ * A PURE ENQUEUE: never synchronises a stream, never reads anything back.  The sparse workspace is sized before
+ * the live counts are known — from what earlier batches with the same parameter block needed (the totals of a
+ * finished batch are picked up from pinned memory without waiting), or from first-call heuristics; the device
+ * checks every capacity itself, and a problem that does not fit is SKIPPED: status ROMAN_ST_WORKSPACE, no
+ * associations, NaN pose.  Run those problems again (by then the context knows their sizes).  Results are
+ * complete once the stream is synchronised (depth 1) / after roman_ctx_sync() (depth >= 2).
  */
 ROMAN_API int roman_align_batch_dev(roman_ctx_t* ctx, const roman_params_t* params, int32_t B,
                           const double* feats, const int64_t* off1, const int32_t* n1,
@@ -325,9 +325,9 @@ ROMAN_API int roman_pose_batch(roman_ctx_t* ctx, int32_t dim, int32_t B,
    stream; roman_profile_get returns the accumulated per-stage milliseconds and launch counts
    since the last roman_profile_reset.  Stage ids: */
 #define ROMAN_STAGE_SINGLE   0   /* norms, cos-sim MFMA GEMM, distance tables, single scores + live compaction */
-#define ROMAN_STAGE_COUNT_PASS 1 /* affinity candidate count + row/problem scans (+ the 16-byte read-back)     */
-#define ROMAN_STAGE_FILL     2   /* affinity fill: candidates -> CSR values                                    */
-#define ROMAN_STAGE_SOLVE    3   /* persistent projected-gradient solver (+ select + pose): ONE kernel launch  */
+#define ROMAN_STAGE_COUNT_PASS 1 /* affinity pair tests, mirror, degree sort, candidate lists, problem scans   */
+#define ROMAN_STAGE_FILL     2   /* affinity fill: candidate lists -> matrix values                            */
+#define ROMAN_STAGE_SOLVE    3   /* persistent projected-gradient solvers (+ select + pose)                    */
 #define ROMAN_STAGE_COUNT    4
 ROMAN_API int roman_profile_enable(roman_ctx_t* ctx, int on);
 ROMAN_API int roman_profile_reset(roman_ctx_t* ctx);

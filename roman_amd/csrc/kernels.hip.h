@@ -1059,25 +1059,34 @@ __global__ void __launch_bounds__(1024) k_upper(const ProbDesc* __restrict__ pro
                     : "+v"(glo), "+v"(ghi) : "s"(gl_), "s"(sel_), "s"(gh_) : "m0");
             }
             unsigned long long behind = ((unsigned long long)ghi << 32) | glo;
-            for (int r = r0; r < r1; ++r) {
-                const int p = it.row0 + r;                       // position of the row being written
-                const int k = (int)perm[lo + p];                 // its live index
-                const unsigned long long mine = ((lane < W) ? maskPool[mo + (int64_t)k * W + lane] : 0ull) & behind;
+            // the wave's rows: live index and list offset of row r0 + l in lane l (read back with v_readlane), and the
+            // position-ordered copies of the pools the solver reads; the mask row of the NEXT row is requested before
+            // the current one is worked on, so no memory round trip sits between two rows
+            const int nr = r1 - r0;                              // <= RPB / waves per block <= 64
+            const int kv = (lane < nr) ? (int)perm[lo + p0 + lane] : 0;
+            const uint32_t ov = (lane < nr) ? listOff[lo + p0 + lane] : 0u;
+            if (lane < nr) { dst.lp[lo + p0 + lane] = src.lp[lo + kv]; dst.ld[lo + p0 + lane] = src.ld[lo + kv]; }
+            unsigned long long m_n = (lane < W) ? maskPool[mo + (int64_t)__builtin_amdgcn_readlane(kv, 0) * W + lane] : 0ull;
+            for (int i = 0; i < nr; ++i) {
+                const int p = p0 + i;                            // position of the row being written
+                const unsigned long long raw = m_n;
+                int kn = 0;
+                if (i + 1 < nr) {
+                    kn = __builtin_amdgcn_readlane(kv, i + 1);
+                    m_n = (lane < W) ? maskPool[mo + (int64_t)kn * W + lane] : 0ull;
+                }
+                const unsigned long long mine = raw & behind;
                 const uint32_t c = (uint32_t)__popcll(mine);
                 const uint32_t ex = wave_excl_scan(c, lane);
                 const uint32_t cnt = (uint32_t)__shfl((int)(ex + c), WAVE - 1);
                 {   // the row's candidate list: live column indices in ascending order, padded to a whole quad
-                    uint16_t* lst = lists + listOff[lo + p];
+                    uint16_t* lst = lists + (uint32_t)__builtin_amdgcn_readlane((int)ov, i);
                     unsigned long long m = mine; uint32_t e = ex;
                     while (m) { lst[e++] = (uint16_t)((lane << 6) + __builtin_ctzll(m)); m &= m - 1ull; }
                     if (lane < 4 && cnt + (uint32_t)lane < ((cnt + 3u) & ~3u)) lst[cnt + lane] = (uint16_t)0xffffu;
                 }
                 if (lane == 0) rowCnt[lo + p] = cnt;             // upper degree of position p (the live-order degrees are spent)
-                if (lane == 0) { dst.lp[lo + p] = src.lp[lo + k]; dst.ld[lo + p] = src.ld[lo + k]; }
-                if (r + 1 < r1) {                                // the column at position p + 1 is no longer behind
-                    const int qn = (int)perm[lo + p + 1];
-                    if (lane == (qn >> 6)) behind &= ~(1ull << (qn & 63));
-                }
+                if (i + 1 < nr && lane == (kn >> 6)) behind &= ~(1ull << (kn & 63));   // the column at position p + 1 is no longer behind
             }
         }
         }
@@ -1342,7 +1351,7 @@ __global__ void __launch_bounds__(1024) k_fill(DevParams D, const ProbDesc* __re
 // item, as are the rows of the group (live index, count, list offset); the quads of the group are dealt to the waves
 // round-robin.  Items are ordered so that the groups of one problem run on one XCD (its tables stay in that L2).
 // ---------------------------------------------------------------------------------------------
-constexpr int FILLS_MAXSPI = 16;     // slices per work item (group)
+constexpr int FILLS_MAXSPI = STREAM_MAXL / 64;     // slices per work item (group): up to a whole problem
 
 template <bool GRAV, bool FAST>
 __device__ __forceinline__ double fill_value(const DevParams& D, double a, double bb, double dza, double dzb, double ss, double sk, double sq)
@@ -1376,7 +1385,7 @@ __global__ void __launch_bounds__(1024) k_fill_list(DevParams D, int B, const Pr
                                                     const uint32_t* __restrict__ sliceBase,
                                                     uint16_t* __restrict__ cols, double* __restrict__ vals, int TC, int SPI)
 {
-    // LDS: cS[TC] [GRAV: cZa[TC] cZb[TC]] cI[TC] cJ[TC] | gK gCnt gOff [FILLS_MAXSPI*64] | gQ[FILLS_MAXSPI+1] gSB[FILLS_MAXSPI] | cP[TC] (u16)
+    // LDS: cS[TC] [GRAV: cZa[TC] cZb[TC]] cI[TC] cJ[TC] | gK gCnt gOff [SPI*64] | gQ[SPI+1] gSB[SPI+1] | cP[TC] (u16)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* cS = reinterpret_cast<double*>(smem);
     double* cZa = cS + TC;
@@ -1384,11 +1393,11 @@ __global__ void __launch_bounds__(1024) k_fill_list(DevParams D, int B, const Pr
     int32_t* cI = reinterpret_cast<int32_t*>(cZb + (GRAV ? TC : 0));
     int32_t* cJ = cI + TC;
     uint32_t* gK = reinterpret_cast<uint32_t*>(cJ + TC);         // rows of the group's slices: live index (~0: no row)
-    uint32_t* gCnt = gK + FILLS_MAXSPI * 64;                     //   kept candidates
-    uint32_t* gOff = gCnt + FILLS_MAXSPI * 64;                   //   list offset
-    uint32_t* gQ = gOff + FILLS_MAXSPI * 64;                     // quads in front of every slice of the group (+ total)
-    uint32_t* gSB = gQ + FILLS_MAXSPI + 1;                       // slice bases
-    uint16_t* cP = reinterpret_cast<uint16_t*>(gSB + FILLS_MAXSPI + 1);
+    uint32_t* gCnt = gK + SPI * 64;                     //   kept candidates
+    uint32_t* gOff = gCnt + SPI * 64;                   //   list offset
+    uint32_t* gQ = gOff + SPI * 64;                     // quads in front of every slice of the group (+ total)
+    uint32_t* gSB = gQ + SPI + 1;                       // slice bases
+    uint16_t* cP = reinterpret_cast<uint16_t*>(gSB + SPI + 1);
     const int tid = threadIdx.x, nt = blockDim.x;
     const int lane = tid & 63, w = tid >> 6, nw = nt >> 6;
     const int nGroups = tot->sliceGroups;
@@ -1426,7 +1435,7 @@ __global__ void __launch_bounds__(1024) k_fill_list(DevParams D, int B, const Pr
             const uint32_t wq = (lane < ns) ? (sliceWidth[lo + s_begin + lane] >> 2) : 0u;
             const uint32_t ex = wave_excl_scan(wq, lane);
             if (lane < ns) { gQ[lane] = ex; gSB[lane] = sliceBase[lo + s_begin + lane]; }
-            if (lane == ns) gQ[ns] = ex;        // ns <= 16 < 64
+            if (lane == ns) gQ[ns] = ex;        // ns <= STREAM_MAXL / 64 < 64
         }
         __syncthreads();
         const uint32_t Q = gQ[ns];

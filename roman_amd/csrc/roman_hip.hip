@@ -475,7 +475,13 @@ int enqueue_score(roman_ctx* c, const DevParams& Din, const roman_params_t* para
     }
     // k_fill_list work items: groups of SPI consecutive slices of one problem, about 3 per CU for the whole batch
     const double expR = c->hist.valid && D.single ? std::min<double>((double)sumA, c->hist.rMaxL * (double)sumA * 1.2) : (double)sumA;
-    const int SPI = (int)std::min<int64_t>(FILLS_MAXSPI, std::max<int64_t>(1, ((int64_t)(expR / 64.0) + B + 3 * c->num_cu - 1) / (3 * (int64_t)c->num_cu)));
+    // (about 3 groups per CU, every problem of a uniform batch cut into the same number of groups: the static deal of
+    // the groups to the workgroups then gives each one heavy and two light groups; whole problems per workgroup or an
+    // uneven cut measured 0.46-0.63 ms against 0.38-0.40)
+    static const char* spiEnv = getenv("ROMAN_FILL_SPI");
+    int SPI = (int)std::min<int64_t>(FILLS_MAXSPI, std::max<int64_t>(1, ((int64_t)(expR / 64.0) + B + 3 * c->num_cu - 1) / (3 * (int64_t)c->num_cu)));
+    if (spiEnv) SPI = std::max(1, std::min(FILLS_MAXSPI, atoi(spiEnv)));
+    SPI = std::min(SPI, std::max(1, D.stream_maxL / 64));
     hipLaunchKernelGGL(k_probscan, dim3(1), dim3(64), 0, WS.stream, B, SPI, SZ.capNnz, dS, dT);
     DBG(c, "k_probscan");
     t1.stop();
@@ -485,7 +491,7 @@ int enqueue_score(roman_ctx* c, const DevParams& Din, const roman_params_t* para
         // list fill (stream layout): column tile + the rows and slice tables of one group
         const int colBytesF = D.gravity ? 32 : 16;
         const int TCs = D.stream_maxL;
-        const size_t sliceLds = (size_t)TCs * (colBytesF + 2) + sizeof(uint32_t) * (size_t)(3 * FILLS_MAXSPI * 64 + 2 * (FILLS_MAXSPI + 1));
+        const size_t sliceLds = (size_t)TCs * (colBytesF + 2) + sizeof(uint32_t) * (size_t)(3 * SPI * 64 + 2 * (SPI + 1) + 2);
         if (sliceLds > c->lds_max) return fail(c, ROMAN_E_TOO_LARGE, "internal: stream column tile does not fit the LDS");
         const bool fast = D.single && D.p.single_mode != ROMAN_SINGLE_DIAG && D.p.distance_weight == 1.0 &&
                           D.p.fusion_method != ROMAN_FUSE_ARITHMETIC_MEAN && D.p.fusion_method != ROMAN_FUSE_PRODUCT;

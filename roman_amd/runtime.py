@@ -118,8 +118,9 @@ class Context:
                         T_out_ptr, status_out_ptr, stats_out_ptr=None, assoc_ptr=None, assoc_off=None,
                         u0_ptr=None):
         """Device-pointer batch call (roman_align_batch_dev).  Pointers are integers (e.g.
-        torch.Tensor.data_ptr()); metadata arrays are host NumPy arrays.  Asynchronous on the
-        context's stream apart from the library's one 16-byte read-back."""
+        torch.Tensor.data_ptr()); metadata arrays are host NumPy arrays.  A pure enqueue: nothing is
+        waited for or read back; problems that found no workspace come back with ROMAN_ST_WORKSPACE
+        (run them again)."""
         off1 = np.ascontiguousarray(off1, dtype=np.int64); off2 = np.ascontiguousarray(off2, dtype=np.int64)
         n1 = np.ascontiguousarray(n1, dtype=np.int32); n2 = np.ascontiguousarray(n2, dtype=np.int32)
         if assoc_off is not None:
