@@ -1118,9 +1118,9 @@ __global__ void __launch_bounds__(64) k_slicegeom(const ProbDesc* __restrict__ p
 }
 
 // k_probscan: serial prefix of the per-problem slot totals and of the slice-group counts (k_fill_slice work items:
-// groups of SPI consecutive slices of one stream-layout problem).  A problem whose matrix segment would end beyond
+// min(NG, slices) groups of consecutive slices per stream-layout problem).  A problem whose matrix segment would end beyond
 // `capNnz` slots becomes kind 2 (skipped; nothing has been written for it yet).
-__global__ void __launch_bounds__(64) k_probscan(int B, int SPI, long long capNnz, ProbState* __restrict__ st, BatchTotals* __restrict__ tot)
+__global__ void __launch_bounds__(64) k_probscan(int B, int NG /* fill groups per problem */, long long capNnz, ProbState* __restrict__ st, BatchTotals* __restrict__ tot)
 {
     const int lane = threadIdx.x;
     long long acc = 0;
@@ -1132,7 +1132,7 @@ __global__ void __launch_bounds__(64) k_probscan(int B, int SPI, long long capNn
         long long pc = cap;
         for (int off = 1; off < WAVE; off <<= 1) { const long long t = __shfl_up(pc, off); if (lane >= off) pc += t; }
         const bool fits = acc + pc <= capNnz;
-        const int ng = (b < B && kind == 0 && fits) ? (((st[b].L + 63) >> 6) + SPI - 1) / SPI : 0;
+        const int ng = (b < B && kind == 0 && fits) ? min(NG, (st[b].L + 63) >> 6) : 0;
         int pg = ng;
         for (int off = 1; off < WAVE; off <<= 1) { const int tg = __shfl_up(pg, off); if (lane >= off) pg += tg; }
         if (b < B) {
@@ -1346,7 +1346,7 @@ __global__ void __launch_bounds__(1024) k_fill(DevParams D, const ProbDesc* __re
 // table gathers, sqrt / exp / cbrt, fusion, affinityeps filter), then one 8-byte column store and two 16-byte value
 // stores that are contiguous over the wave — the layout's own order, no staging image, no barriers inside a work
 // item.  Entries beyond a row's count (slice padding) and filtered entries are written inert (value 0, the lane
-// slot's dummy column with the C-flag).  Work items are groups of SPI consecutive slices of one problem: the
+// slot's dummy column with the C-flag).  Work items are groups of consecutive slices of one problem (NG groups per problem): the
 // problem's column tile (objects, z, single score, position of every live association) is staged in LDS once per
 // item, as are the rows of the group (live index, count, list offset); the quads of the group are dealt to the waves
 // round-robin.  Items are ordered so that the groups of one problem run on one XCD (its tables stay in that L2).
@@ -1383,7 +1383,7 @@ __global__ void __launch_bounds__(1024) k_fill_list(DevParams D, int B, const Pr
                                                     const uint32_t* __restrict__ perm, const uint32_t* __restrict__ rowPos,
                                                     const uint32_t* __restrict__ sliceWidth,
                                                     const uint32_t* __restrict__ sliceBase,
-                                                    uint16_t* __restrict__ cols, double* __restrict__ vals, int TC, int SPI)
+                                                    uint16_t* __restrict__ cols, double* __restrict__ vals, int TC, int NG, int SPI /* LDS capacity: slices per group */)
 {
     // LDS: cS[TC] [GRAV: cZa[TC] cZb[TC]] cI[TC] cJ[TC] | gK gCnt gOff [SPI*64] | gQ[SPI+1] gSB[SPI+1] | cP[TC] (u16)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1418,7 +1418,10 @@ __global__ void __launch_bounds__(1024) k_fill_list(DevParams D, int B, const Pr
         const int W = (L + 63) >> 6;
         const int64_t lo = pd.liveOff, no = st[b].nnzOff;
         const uint16_t* lists = listPool + st[b].listOff;
-        const int s_begin = (t - st[b].sgBase) * SPI, s_end = min(W, s_begin + SPI), ns = s_end - s_begin;
+        // every problem is cut into the same number of groups (min(NG, W)) of ceil(W / groups) slices: with a uniform
+        // batch the static deal then hands every workgroup the same mix of heavy (first) and light (last) groups
+        const int ngb = min(NG, W), spib = (W + ngb - 1) / max(ngb, 1);
+        const int s_begin = (t - st[b].sgBase) * spib, s_end = min(W, s_begin + spib), ns = max(s_end - s_begin, 0);
         const double* TA = tabPool + pd.tabOff;
         const double* TB = TA + (int64_t)pd.n1 * pd.n1;
         __syncthreads();                        // every wave is done with the previous group's tile

@@ -473,16 +473,23 @@ int enqueue_score(roman_ctx* c, const DevParams& Din, const roman_params_t* para
         hipLaunchKernelGGL(k_slicegeom, dim3(B), dim3(64), 0, WS.stream, dP, dS, WS.rowCnt.as<uint32_t>(), WS.sliceWidth.as<uint32_t>(), WS.sliceBase.as<uint32_t>());
     DBG(c, "k_slicegeom");
     }
-    // k_fill_list work items: groups of SPI consecutive slices of one problem, about 3 per CU for the whole batch
-    const double expR = c->hist.valid && D.single ? std::min<double>((double)sumA, c->hist.rMaxL * (double)sumA * 1.2) : (double)sumA;
-    // (about 3 groups per CU, every problem of a uniform batch cut into the same number of groups: the static deal of
-    // the groups to the workgroups then gives each one heavy and two light groups; whole problems per workgroup or an
-    // uneven cut measured 0.46-0.63 ms against 0.38-0.40)
-    static const char* spiEnv = getenv("ROMAN_FILL_SPI");
-    int SPI = (int)std::min<int64_t>(FILLS_MAXSPI, std::max<int64_t>(1, ((int64_t)(expR / 64.0) + B + 3 * c->num_cu - 1) / (3 * (int64_t)c->num_cu)));
-    if (spiEnv) SPI = std::max(1, std::min(FILLS_MAXSPI, atoi(spiEnv)));
-    SPI = std::min(SPI, std::max(1, D.stream_maxL / 64));
-    hipLaunchKernelGGL(k_probscan, dim3(1), dim3(64), 0, WS.stream, B, SPI, SZ.capNnz, dS, dT);
+    // k_fill_list work items: groups of consecutive slices of one problem, about 3 per CU for the whole batch
+    // (about 3 groups per CU, EVERY problem cut into the same number NG of groups: the static deal of the groups to the
+    // workgroups then gives each one heavy (first slices) and two light groups; whole problems per workgroup or cuts
+    // that differ between problems measured 0.46-0.63 ms against 0.38-0.40)
+    static const char* ngEnv = getenv("ROMAN_FILL_NG");
+    int NG = (int)std::max<int64_t>(1, std::min<int64_t>(FILLS_MAXSPI, (3 * (int64_t)c->num_cu + B / 2) / std::max(B, 1)));
+    {   // a workgroup takes every (grid/8)-th group of its XCD's range: the residues it meets (which part of a problem
+        // a group is) rotate through all NG values only if that stride is coprime to NG — NG = 4 on 256 CUs (stride 32)
+        // hands some workgroups nothing but first, heavy groups (fill 0.59 ms against 0.38 with NG = 3)
+        const int stride = std::max(1, (c->num_cu & ~7) / 8);
+        auto gcd = [](int a, int b) { while (b) { const int t = a % b; a = b; b = t; } return a; };
+        while (NG > 1 && gcd(stride % NG, NG) != 1) --NG;
+    }
+    if (ngEnv) NG = std::max(1, std::min(FILLS_MAXSPI, atoi(ngEnv)));
+    const int Wmax = std::max(1, D.stream_maxL / 64);
+    const int SPI = (Wmax + std::min(NG, Wmax) - 1) / std::min(NG, Wmax);       // slices per group at most (LDS capacity)
+    hipLaunchKernelGGL(k_probscan, dim3(1), dim3(64), 0, WS.stream, B, NG, SZ.capNnz, dS, dT);
     DBG(c, "k_probscan");
     t1.stop();
 
@@ -500,7 +507,7 @@ int enqueue_score(roman_ctx* c, const DevParams& Din, const roman_params_t* para
         hipLaunchKernelGGL(kf, dim3((unsigned)(c->num_cu & ~7)), dim3(1024), sliceLds, WS.stream,
                            D, B, dP, dS, dT, WS.tabPool.as<double>(), LP.li, LP.lj, LP.ls, LP.lza, LP.lzb,
                            WS.listPool.as<uint16_t>(), WS.listOff.as<uint32_t>(), WS.rowCnt.as<uint32_t>(), WS.perm.as<uint32_t>(), WS.rowPos.as<uint32_t>(),
-                           WS.sliceWidth.as<uint32_t>(), WS.sliceBase.as<uint32_t>(), WS.cols16.as<uint16_t>(), WS.vals.as<double>(), TCs, SPI);
+                           WS.sliceWidth.as<uint32_t>(), WS.sliceBase.as<uint32_t>(), WS.cols16.as<uint16_t>(), WS.vals.as<double>(), TCs, NG, SPI);
     DBG(c, "k_fill_list");
         // fallback layout (symmetric SELL-64, 32-bit indices) for the problems the stream layout does not take: only when
         // one can exist (the kernel would find no work otherwise)
