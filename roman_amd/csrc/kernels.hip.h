@@ -45,6 +45,8 @@ struct DevParams {
     int32_t max_compact; // streaming solver: column compactions allowed per problem (speed only; set per launch)
     int32_t gmode;      // 0: no gravity; 1 + ROMAN_GRAV_* otherwise (1 combined, 2 separate gates, 3 z gate on full lengths)
     int32_t diag_one;   // single scores present but the diagonal is the identity (ROMAN_SINGLE_OFFDIAG)
+    int32_t allow_fallback;  // the fallback kernels are part of this launch; otherwise a problem that does not fit the stream layout is
+                             // SKIPPED (kind 2, ROMAN_ST_WORKSPACE) and runs again with them (set per launch, from the sizing history)
     int32_t stream_maxL;     // problems of up to this many live associations take the stream layout (<= STREAM_MAXL; set per launch:
                              // it is also the column capacity of k_fill_slice's LDS tile and of the stream solver's LDS vectors)
 };
@@ -466,7 +468,7 @@ __global__ void __launch_bounds__(256) k_live(DevParams D, const ProbDesc* __res
     for (int k = 0; k < w; ++k) base += wtot[k];
     if (c == 0 && tid == 0) {
         st[b].L = cbase[1]; st[b].nnzUpper = 0ull;
-        st[b].kind = (cbase[1] <= D.stream_maxL && D.p.maxiniters >= 1 && D.p.maxlsiters >= 1) ? 0 : 1;
+        st[b].kind = (cbase[1] <= D.stream_maxL && D.p.maxiniters >= 1 && D.p.maxlsiters >= 1) ? 0 : (D.allow_fallback ? 1 : 2);
     }
 
     const int64_t lo = pd.liveOff;
@@ -497,14 +499,19 @@ __global__ void __launch_bounds__(64) k_rowbase(int B, int RPB, long long capMas
 {
     // one wave; lane-strided blocks of 64 problems with a running carry (B is small)
     const int lane = threadIdx.x;
-    int accR = 0, accI = 0, mx = 0, mxs = 0, nover = 0; long long accM = 0;
+    int accR = 0, accI = 0, mx = 0, mxs = 0, nover = 0; long long accM = 0, needM = 0;
     for (int b0 = 0; b0 < B; b0 += WAVE) {
         const int b = b0 + lane;
         const int L = b < B ? st[b].L : 0;
-        const long long mw = (long long)L * ((L + 63) >> 6);
-        long long pm = mw;
-        for (int off = 1; off < WAVE; off <<= 1) { const long long tm = __shfl_up(pm, off); if (lane >= off) pm += tm; }
-        const bool fits = accM + pm <= capMaskWords;           // the prefix is monotone: once a problem does not fit, none behind it does
+        const bool skip = b < B && st[b].kind == 2;             // already skipped (k_live: no fallback kernels in this launch)
+        const long long mwAll = (long long)L * ((L + 63) >> 6);
+        const long long mw = skip ? 0 : mwAll;
+        long long pm = mw, pn = mwAll;
+        for (int off = 1; off < WAVE; off <<= 1) {
+            const long long tm = __shfl_up(pm, off), tn = __shfl_up(pn, off);
+            if (lane >= off) { pm += tm; pn += tn; }
+        }
+        const bool fits = !skip && accM + pm <= capMaskWords;  // the prefix is monotone: once a problem does not fit, none behind it does
         const int it = fits ? (L + RPB - 1) / RPB : 0;
         int pr = L, pi = it;
         for (int off = 1; off < WAVE; off <<= 1) {
@@ -518,11 +525,11 @@ __global__ void __launch_bounds__(64) k_rowbase(int B, int RPB, long long capMas
         int m = L, ms = (b < B && st[b].kind == 0) ? L : 0, ov = (b < B && !fits) ? 1 : 0;
         for (int off = 32; off > 0; off >>= 1) { m = max(m, __shfl_xor(m, off)); ms = max(ms, __shfl_xor(ms, off)); ov += __shfl_xor(ov, off); }
         mx = max(mx, m); mxs = max(mxs, ms); nover += ov;
-        accR += __shfl(pr, WAVE - 1); accI += __shfl(pi, WAVE - 1); accM += __shfl(pm, WAVE - 1);
+        accR += __shfl(pr, WAVE - 1); accI += __shfl(pi, WAVE - 1); accM += __shfl(pm, WAVE - 1); needM += __shfl(pn, WAVE - 1);
     }
     if (lane == 0) {
         tot->R = accR; tot->maxL = mx; tot->nnzTotal = 0; tot->maskWords = accM < capMaskWords ? accM : capMaskWords; tot->items = accI; tot->sliceGroups = 0;
-        tot->needMaskWords = accM; tot->needNnz = 0; tot->overflow = nover; tot->maxStreamL = mxs; tot->listTop = 0ull;
+        tot->needMaskWords = needM; tot->needNnz = 0; tot->overflow = nover; tot->maxStreamL = mxs; tot->listTop = 0ull;
     }
 }
 

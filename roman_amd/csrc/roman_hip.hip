@@ -207,6 +207,7 @@ int make_dev_params(roman_ctx* c, const roman_params_t* p, int32_t F, DevParams*
     D->diag_one = D->single && p->single_mode == ROMAN_SINGLE_OFFDIAG;
     D->F = F;
     D->stream_maxL = STREAM_MAXL;
+    D->allow_fallback = 1;
     return ROMAN_OK;
 }
 
@@ -344,6 +345,11 @@ int enqueue_score(roman_ctx* c, const DevParams& Din, const roman_params_t* para
     SZ.capMaskWords = std::max(SZ.capMaskWords, WS.capMaskWords); SZ.capNnz = std::max(SZ.capNnz, WS.capNnz); SZ.capList = std::max(SZ.capList, WS.capList);
     // stream layout: as many live associations as the LDS tiles of this launch are sized for
     D.stream_maxL = std::min(STREAM_MAXL, std::max(64, (SZ.expectMaxL + 63) & ~63));
+    // The fallback layout's kernels (symmetric SELL fill, k_solve / k_solve_coop) are launched only when a problem can
+    // need them: no history yet, a live set beyond the stream layout expected, or parameters only k_solve handles.  Else a
+    // problem that turns out too large for the LDS tiles of this launch is skipped (ROMAN_ST_WORKSPACE) and, the
+    // history corrected, takes them on its second run.
+    D.allow_fallback = (!c->hist.valid || SZ.expectMaxL > D.stream_maxL || D.p.maxiniters < 1 || D.p.maxlsiters < 1) ? 1 : 0;
     *Dout = D;
 
     HIPCHK(c, WS.probs.ensure(sizeof(ProbDesc) * (size_t)B));
@@ -511,7 +517,7 @@ int enqueue_score(roman_ctx* c, const DevParams& Din, const roman_params_t* para
     DBG(c, "k_fill_list");
         // fallback layout (symmetric SELL-64, 32-bit indices) for the problems the stream layout does not take: only when
         // one can exist (the kernel would find no work otherwise)
-        if (SZ.maxA > D.stream_maxL) {
+        if (D.allow_fallback && SZ.maxA > D.stream_maxL) {
             const int colBytesG = D.gravity ? 36 : 20;
             const size_t ringLds = (size_t)16 * 3 * FILL_Q * sizeof(uint32_t);
             int TCf = (int)std::min<size_t>((c->lds_max - ringLds) / colBytesG, 32768) & ~63;
@@ -652,6 +658,7 @@ int enqueue_solve(roman_ctx* c, const DevParams& D, int B, int64_t sumA, const d
 // how many problems of the batch can be of the fallback kind (0: none, the fallback solver is not launched)
 int may_fallback(const DevParams& D, const std::vector<ProbDesc>& hd)
 {
+    if (!D.allow_fallback) return 0;
     if (D.p.maxiniters < 1 || D.p.maxlsiters < 1) return (int)hd.size();
     int n = 0;
     for (const ProbDesc& d : hd) if (d.nA > D.stream_maxL) ++n;

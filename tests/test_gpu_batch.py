@@ -343,3 +343,29 @@ def test_align_sharded_device_path_single_rank():
     """ % (ROOT, ROOT))
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert "SHARDED_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
+def test_live_set_larger_than_the_history_expects_is_retried_with_the_fallback_kernels(orc):
+    """Once a context has seen batches of a parameter block it launches the fallback layout's kernels only when a live set
+    beyond the stream layout is expected.  A problem that then turns out larger (here: every descriptor identical, so
+    all 60 x 60 associations pass the cosine gate where earlier pairs kept 5 %) is skipped (ROMAN_ST_WORKSPACE on the
+    device-pointer entry) and run again by the host-pointer entry with the corrected history: same result as the oracle."""
+    from roman_amd.runtime import Context
+    c = Context(0)
+    try:
+        reg = registration_for("semanticgrav", semantics_dim=16); reg.set_context(c)
+        ordinary = [synth.make_pair(60, 60, 16, 5000 + k) for k in range(3)]
+        for _ in range(2):                                   # the second call finds the totals of the first
+            r0 = reg.register_and_align_batch([(p.map1, p.map2) for p in ordinary])
+        assert (r0.status == 0).all() and r0.stats["n_live"].max() < 1000
+        odd = synth.make_pair(60, 60, 16, 5100)
+        e = np.zeros(16); e[0] = 1.0
+        for o in list(odd.map1) + list(odd.map2):
+            o.semantic_descriptor = e.copy()
+        res = reg.register_and_align_batch([(ordinary[0].map1, ordinary[0].map2), (odd.map1, odd.map2)])
+        assert res.stats["n_live"].tolist()[1] == 3600 and (res.status == 0).all()
+        assert np.array_equal(res.assoc[0], r0.assoc[0])
+        o = oracle_one(orc, reg, odd.map1, odd.map2)
+        assert np.array_equal(res.assoc[1], o["assoc"]) and res.stats["nnz_upper"][1] == o["stats"].nnz_upper
+    finally:
+        c.close()
