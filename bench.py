@@ -4,7 +4,7 @@ MI355X, at BASELINE.json's shape n=m=200 objects, d=512 (`method='semanticgrav'`
 
   python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
 
-Workloads (`--workload`, default `auto`: `pairs` at N=1, `grid` at N>1):
+Workloads (`--workload`, default `pairs` at every N, so that the per-N values of a scaling sweep are one workload):
   pairs  BASELINE config 3: a batch of 256 independent synthetic submap pairs per GPU per step (config 2 is the
          same shape at B=1 and is what `p50_latency_ms` is measured on).  With N>1 every rank aligns its own 256
          pairs: weak scaling.
@@ -12,6 +12,8 @@ Workloads (`--workload`, default `auto`: `pairs` at N=1, `grid` at N>1):
          are packed ONCE into one feature pool that every rank holds; the 4096 pairs are dealt round-robin to the
          ranks (512 per rank at N=8) and aligned in calls of at most 512 pairs: strong scaling, a step = the whole
          grid.
+With N>1 (or `--also-grid`) the `pairs` run is followed by a short `grid` leg (`--grid-steps`, default 3) whose
+result is reported in the same line as `grid_config4` — config 4's strong-scaling number next to the weak one.
 A "step" is one pass of the hot path (score -> solve -> select -> pose; roman_align_batch_dev calls) over the
 workload.  Inputs are resident in HBM before the timed region.  There is no data-path collective; one RCCL
 all_gather of the fixed-size result records (inlier sets + poses) per call collects the results on every rank.
@@ -42,7 +44,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--workload", default="auto", choices=["auto", "pairs", "grid"])
+    ap.add_argument("--workload", default="auto", choices=["auto", "pairs", "grid"], help="auto = pairs")
+    ap.add_argument("--also-grid", action="store_true", help="N=1: run the config-4 grid leg too (always run at N>1)")
+    ap.add_argument("--grid-steps", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256, help="pairs workload: submap pairs per GPU per step (config 3: 256)")
     ap.add_argument("--grid", type=int, default=64, help="grid workload: submaps per robot (config 4: 64 -> 4096 alignments)")
     ap.add_argument("--chunk", type=int, default=512, help="grid workload: pairs per roman_align_batch_dev call")
@@ -91,117 +95,137 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    workload = args.workload if args.workload != "auto" else ("pairs" if world == 1 else "grid")
+    workload = args.workload if args.workload != "auto" else "pairs"
 
     sp = SubmapAlignParams(method=args.method, semantics_dim=args.d) if args.d > 0 else SubmapAlignParams(method=args.method)
     reg = sp.get_object_registration()
     P = reg._abi_params()
     F = P.feature_dim() if P.invariant == _abi.ROMAN_INV_ROMAN else reg.dim
 
-    # ---- synthetic workload, packed once, resident in HBM --------------------------------
-    truth = None
-    if workload == "pairs":
-        B = args.batch
-        pairs = [synth.make_pair(args.n, args.m, args.d, 3000 + rank * B + k) for k in range(B)]
-        batch = batch_from_pairs(reg, [(p.map1, p.map2) for p in pairs])
-        truth = [p.inliers for p in pairs]
-        mine = np.arange(B)                                    # every rank owns all problems of its own batch
-        total_per_step = world * B
-        chunk = B
-        scaling = "weak"
-        wl_text = (f"config 3: batch of {B} submap pairs per GPU, n={args.n} m={args.m} d={args.d}, method={args.method} "
-                   f"(xyz + {args.d}-d descriptors + gravity prior); p50 latency measured on config 2 (single pair)")
-    else:
-        S = args.grid
-        subs, _poses = synth.make_submap_grid(2 * S, n=args.n, d=args.d, seed0=4000)
-        batch = batch_from_submap_grid(reg, subs[:S], subs[S:])   # S*S problems over ONE pool of 2S submaps
-        mine = np.arange(rank, S * S, world)                     # dealt round-robin: every rank gets the same mix
-        total_per_step = S * S
-        chunk = min(args.chunk, len(mine))
-        scaling = "strong"
-        wl_text = (f"config 4: all-pairs grid of {S} x {S} submaps ({S * S} alignments), n={args.n} d={args.d}, method={args.method}; "
-                   f"{2 * S} submaps packed once and replicated, pairs dealt round-robin to {world} rank(s), {chunk} pairs per call")
-    kmax = batch.kmax()
-    feats = torch.from_numpy(batch.feats).to(dev)
-    calls = [mine[i:i + chunk] for i in range(0, len(mine), chunk)]          # problem indices of every call of a step
-    meta = [(batch.off1[ix], batch.n1[ix], batch.off2[ix], batch.n2[ix]) for ix in calls]
-    CB = max(len(ix) for ix in calls)
-
-    # one output set per call in flight: call k writes set k % NSET while older sets are gathered
-    NSET = max(args.pipeline, 2)
-    assoc_o = [torch.zeros((CB, kmax, 2), dtype=torch.int32, device=dev) for _ in range(NSET)]
-    n_o = [torch.zeros(CB, dtype=torch.int32, device=dev) for _ in range(NSET)]
-    T_o = [torch.zeros((CB, 16), dtype=torch.float64, device=dev) for _ in range(NSET)]
-    status_o = [torch.zeros(CB, dtype=torch.int32, device=dev) for _ in range(NSET)]
-    stats_o = [torch.zeros(CB * _abi.STATS_NBYTES, dtype=torch.uint8, device=dev) for _ in range(NSET)]
     stream = torch.cuda.Stream(dev)                             # an explicit stream shared by torch (RCCL) and the library:
     torch.cuda.set_stream(stream)                              # the legacy default stream would not order against it
     ctx = Context(local_rank, stream=stream.cuda_stream)       # library launches on / behind torch's current stream
     reg.set_context(ctx)
 
-    if world > 1:
-        rec_i = torch.empty((CB, 2 + 2 * kmax), dtype=torch.int32, device=dev)
-        gat_i = torch.empty((world * CB, 2 + 2 * kmax), dtype=torch.int32, device=dev)
-        gat_T = torch.empty((world * CB, 16), dtype=torch.float64, device=dev)
+    import types
 
-    def gather(k):                                             # collect inlier sets + poses of output set k on every rank
-        rec_i[:, 0] = n_o[k]; rec_i[:, 1] = status_o[k]; rec_i[:, 2:] = assoc_o[k].view(CB, -1)
-        dist.all_gather_into_tensor(gat_i, rec_i)
-        dist.all_gather_into_tensor(gat_T, T_o[k])
+    def measure(workload, steps, warmup, profile):
+        """Build one workload, keep it resident in HBM, run `warmup` untimed and `steps` timed steps (barrier +
+        device synchronise on both sides, MAX over ranks).  Returns everything the later sections look at."""
+        # ---- synthetic workload (SURVEY.md Appendix C), packed once, resident in HBM --------------------------------
+        truth = None
+        if workload == "pairs":
+            B = args.batch
+            pairs = [synth.make_pair(args.n, args.m, args.d, 3000 + rank * B + k) for k in range(B)]
+            batch = batch_from_pairs(reg, [(p.map1, p.map2) for p in pairs])
+            truth = [p.inliers for p in pairs]
+            mine = np.arange(B)                                    # every rank owns all problems of its own batch
+            total_per_step = world * B
+            chunk = B
+            scaling = "weak"
+            wl_text = (f"config 3: batch of {B} submap pairs per GPU, n={args.n} m={args.m} d={args.d}, method={args.method} "
+                       f"(xyz + {args.d}-d descriptors + gravity prior); p50 latency measured on config 2 (single pair)")
+        else:
+            S = args.grid
+            subs, _poses = synth.make_submap_grid(2 * S, n=args.n, d=args.d, seed0=4000)
+            batch = batch_from_submap_grid(reg, subs[:S], subs[S:])   # S*S problems over ONE pool of 2S submaps
+            mine = np.arange(rank, S * S, world)                     # dealt round-robin: every rank gets the same mix
+            total_per_step = S * S
+            chunk = min(args.chunk, -(-(S * S) // world))         # the same on every rank (the gathered records are fixed-size)
+            scaling = "strong"
+            wl_text = (f"config 4: all-pairs grid of {S} x {S} submaps ({S * S} alignments), n={args.n} d={args.d}, method={args.method}; "
+                       f"{2 * S} submaps packed once and replicated, pairs dealt round-robin to {world} rank(s), {chunk} pairs per call")
+        kmax = batch.kmax()
+        feats = torch.from_numpy(batch.feats).to(dev)
+        calls = [mine[i:i + chunk] for i in range(0, len(mine), chunk)]          # problem indices of every call of a step
+        meta = [(batch.off1[ix], batch.n1[ix], batch.off2[ix], batch.n2[ix]) for ix in calls]
+        CB = chunk                                                 # rows of the output sets / gathered records
 
-    call_no = [0]
+        # one output set per call in flight: call k writes set k % NSET while older sets are gathered
+        NSET = max(args.pipeline, 2)
+        assoc_o = [torch.zeros((CB, kmax, 2), dtype=torch.int32, device=dev) for _ in range(NSET)]
+        n_o = [torch.zeros(CB, dtype=torch.int32, device=dev) for _ in range(NSET)]
+        T_o = [torch.zeros((CB, 16), dtype=torch.float64, device=dev) for _ in range(NSET)]
+        status_o = [torch.zeros(CB, dtype=torch.int32, device=dev) for _ in range(NSET)]
+        stats_o = [torch.zeros(CB * _abi.STATS_NBYTES, dtype=torch.uint8, device=dev) for _ in range(NSET)]
 
-    def one_call(ci):
-        k = call_no[0] % NSET
-        call_no[0] += 1
-        o1, a1, o2, a2 = meta[ci]
-        ctx.align_batch_dev(P, feats.data_ptr(), F, o1, a1, o2, a2, kmax,
-                            assoc_o[k].data_ptr(), n_o[k].data_ptr(), T_o[k].data_ptr(), status_o[k].data_ptr(), stats_o[k].data_ptr())
         if world > 1:
+            rec_i = torch.empty((CB, 2 + 2 * kmax), dtype=torch.int32, device=dev)
+            gat_i = torch.empty((world * CB, 2 + 2 * kmax), dtype=torch.int32, device=dev)
+            gat_T = torch.empty((world * CB, 16), dtype=torch.float64, device=dev)
+
+        def gather(k):                                             # collect inlier sets + poses of output set k on every rank
+            rec_i[:, 0] = n_o[k]; rec_i[:, 1] = status_o[k]; rec_i[:, 2:] = assoc_o[k].view(CB, -1)
+            dist.all_gather_into_tensor(gat_i, rec_i)
+            dist.all_gather_into_tensor(gat_T, T_o[k])
+
+        call_no = [0]
+
+        def one_call(ci):
+            k = call_no[0] % NSET
+            call_no[0] += 1
+            o1, a1, o2, a2 = meta[ci]
+            ctx.align_batch_dev(P, feats.data_ptr(), F, o1, a1, o2, a2, kmax,
+                                assoc_o[k].data_ptr(), n_o[k].data_ptr(), T_o[k].data_ptr(), status_o[k].data_ptr(), stats_o[k].data_ptr())
+            if world > 1:
+                if args.pipeline >= 2:
+                    if call_no[0] > 1:
+                        ctx.join(skip_latest=True)                 # torch's stream waits for the OLDER calls only
+                        gather((k - 1) % NSET)
+                else:
+                    gather(k)
+            return k
+
+        def step():
+            for ci in range(len(calls)):
+                one_call(ci)
+
+        def drain():                                               # results of the last call
             if args.pipeline >= 2:
-                if call_no[0] > 1:
-                    ctx.join(skip_latest=True)                 # torch's stream waits for the OLDER calls only
-                    gather((k - 1) % NSET)
-            else:
-                gather(k)
-        return k
+                ctx.join(skip_latest=False)
+                if world > 1 and call_no[0] > 0:
+                    gather((call_no[0] - 1) % NSET)
 
-    def step():
-        for ci in range(len(calls)):
-            one_call(ci)
+        def fence():
+            torch.cuda.synchronize(dev)
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize(dev)
 
-    def drain():                                               # results of the last call
-        if args.pipeline >= 2:
-            ctx.join(skip_latest=False)
-            if world > 1 and call_no[0] > 0:
-                gather((call_no[0] - 1) % NSET)
-
-    def fence():
-        torch.cuda.synchronize(dev)
+        ctx.set_pipeline(args.pipeline)
+        for _ in range(warmup):
+            step()
+        drain(); fence()
+        call_no[0] = 0
+        if profile:
+            ctx.profile_enable(True); ctx.profile_reset()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        drain(); fence()
+        dt = time.perf_counter() - t0
+        prof = ctx.profile_get() if profile else None
+        if profile:
+            ctx.profile_enable(False)
+        ctx.set_pipeline(1)                                         # the latency probe and the checks below are single calls
         if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
+            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
 
-    ctx.set_pipeline(args.pipeline)
-    for _ in range(args.warmup):
-        step()
-    drain(); fence()
-    call_no[0] = 0
-    if not args.no_profile:
-        ctx.profile_enable(True); ctx.profile_reset()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    drain(); fence()
-    dt = time.perf_counter() - t0
-    prof = ctx.profile_get() if not args.no_profile else None
-    if not args.no_profile:
-        ctx.profile_enable(False)
-    ctx.set_pipeline(1)                                         # the latency probe and the checks below are single calls
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        return types.SimpleNamespace(workload=workload, batch=batch, truth=truth, calls=calls, meta=meta, feats=feats, kmax=kmax, CB=CB,
+                                     assoc_o=assoc_o, n_o=n_o, T_o=T_o, status_o=status_o, stats_o=stats_o, total_per_step=total_per_step,
+                                     scaling=scaling, wl_text=wl_text, dt=dt, prof=prof, steps=steps)
+
+    M = measure(workload, args.steps, args.warmup, not args.no_profile)
+    batch, truth, calls, meta, feats, kmax, CB = M.batch, M.truth, M.calls, M.meta, M.feats, M.kmax, M.CB
+    assoc_o, n_o, T_o, status_o, stats_o = M.assoc_o, M.n_o, M.T_o, M.status_o, M.stats_o
+    total_per_step, scaling, wl_text, dt, prof = M.total_per_step, M.scaling, M.wl_text, M.dt, M.prof
+    # N > 1 (or --also-grid): BASELINE config 4 as a second, short leg — the 4096-pair grid dealt over the ranks (strong
+    # scaling) next to the weak-scaling `value` above; reported in `grid_config4`
+    G = None
+    if workload == "pairs" and (world > 1 or args.also_grid):
+        G = measure("grid", args.grid_steps, 1, False)
 
     # ---- the first call once more, alone: its results are what the checks below look at, its kernels what
     #      `isolated` times (one untimed launch first: the first launch from this thread at depth 1 pays one-time costs)
@@ -292,6 +316,11 @@ def main():
                    "sharding": f"pairs x{world}, all_gather of records" if world > 1 else "single GPU",
                    "batches_in_flight": args.pipeline},
         "p50_latency_ms": p50,
+        "grid_config4": None if G is None else {
+            "value": G.total_per_step * G.steps / G.dt, "unit": "alignments/s", "scaling": "strong", "steps": G.steps, "warmup": 1,
+            "ms_per_step": G.dt / G.steps * 1e3, "workload": G.wl_text, "calls_per_step_per_gpu": len(G.calls),
+            "status_ok_frac": float(np.mean(np.concatenate([x.cpu().numpy() for x in G.status_o]) == 0)),     # the last calls' output sets
+            "note": "second leg of this run, same timing rules (barrier + device synchronise, MAX over ranks)"},
         "latency_breakdown": lat_break,
         "alignments_per_s_batch1": (1e3 / p50) if p50 else None,
         "register_only": {"note": "the reference times register() alone; the pose is fused into the solver kernel's tail here, so the split is "
