@@ -7,19 +7,22 @@
 //   k_rowbase / k_items   prefix of live counts over problems, work-item list
 //   k_count      the O(L^2) pair tests -> candidate bit matrix (upper 64-bit words), k_mirror the lower ones
 //   k_rowprefix  row degrees (+ per-word prefix counts for the fallback layout)
-//   k_rowsort    rows by descending degree
+//   k_rowsort    rows by descending degree (+ kind 0: offsets of the candidate lists)
 //   kind 0 ("stream", L <= STREAM_MAXL):
-//     k_upper      every candidate pair kept once, in the row of its endpoint with the smaller POSITION (rank by degree)
+//     k_upper      every candidate pair kept once, in the row of its endpoint with the smaller POSITION (rank by degree):
+//                  the row's kept candidates as a list of 16-bit live column indices
 //     k_slicegeom  slice widths / bases of the quad layout
-//     k_fill_slice candidates -> values, one 64-row slice image at a time
+//     k_fill_list  candidate lists -> values, one quad (4 entries per lane = row) at a time, straight into the layout
 //     k_solve_up   persistent per-problem CLIPPER solve on the upper triangle (pull + push SpMV)
-//   kind 1 (fallback, any L): symmetric sorted SELL-64 in live numbering: k_fill, k_solve
+//   kind 1 (fallback, any L): symmetric sorted SELL-64 in live numbering: k_fill, then k_solve (a workgroup per
+//     problem) or k_solve_coop (cooperative launch: the whole device on one large problem at a time)
+//   kind 2: skipped for lack of workspace (k_skipped writes ROMAN_ST_WORKSPACE)
 //
 // Matrix layout of kind 0: only the strict upper triangle of M in position numbering is stored
 // (entry (p,q), p < q, in row p) — 10 bytes per non-zero of the upper triangle.  Rows are cut into slices of 64
 // consecutive positions, a slice is padded to its longest row (multiple of 4 entries) and stored as "quads":
 // the 4 column indices of entries 4g..4g+3 of a lane are one 8-byte word, the values of entries 2h,2h+1 one
-// 16-byte pair: 3 wide, fully coalesced loads per 4 entries.  Padding is inert (value 0, column L, C-flag).
+// 16-byte pair: 3 wide, fully coalesced loads per 4 entries.  Padding is inert (value 0, column L + lane, C-flag).
 // Layout of kind 1 (sorted SELL-64, both triangles): entry e of the row in slot (slice s, lane l) sits at
 //      sliceBase[s] + e*64 + l .
 #pragma once
