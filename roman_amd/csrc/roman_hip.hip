@@ -54,6 +54,8 @@ struct roman_ctx {
     int num_cu = 256;
     size_t lds_max = 65536;
     bool coop_ok = false;                      // hipLaunchCooperativeKernel available (large-problem solver)
+    hipEvent_t coopDone = nullptr;             // behind the most recent cooperative launch of this context
+    bool coopIssued = false;
     std::string err;
 
     // Workspace: every device pool of one batch in flight, its stream and its profiling events.  With
@@ -603,7 +605,13 @@ int enqueue_solve(roman_ctx* c, const DevParams& D, int B, int64_t sumA, const d
             const double* a_u0 = u0; SolveOut a_O = O; double* a_part = WS.coopPart.as<double>();
             void* args[] = {&Dv, &Bv, &a_probs, &a_state, &a_feats, &a_assoc, &a_lp, &a_ld, &a_perm, &a_sw, &a_sb, &a_cols, &a_vals,
                             &a_vMu, &a_vCu, &a_vMun, &a_vCun, &a_gU, &a_gUn, &a_u0, &a_O, &a_part};
+            // Two cooperative kernels must never be resident together (each would hold compute units while waiting at a
+            // grid barrier for workgroups the other one keeps out): with batches in flight on several streams, a
+            // cooperative launch waits for the previous one of this context.
+            if (!c->coopDone) HIPCHK(c, hipEventCreateWithFlags(&c->coopDone, hipEventDisableTiming));
+            if (c->coopIssued) HIPCHK(c, hipStreamWaitEvent(WS.stream, c->coopDone, 0));
             const hipError_t e = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(k_solve_coop<uint32_t>), dim3((unsigned)G), dim3(1024), args, 0, WS.stream);
+            if (e == hipSuccess) { HIPCHK(c, hipEventRecord(c->coopDone, WS.stream)); c->coopIssued = true; }
             if (e != hipSuccess) {                              // not available here: the one-workgroup solver does the same work
                 (void)hipGetLastError();
                 fprintf(stderr, "[roman_hip] cooperative launch failed (%s); large problems use the single-workgroup solver\n", hipGetErrorString(e));
@@ -911,6 +919,7 @@ int roman_ctx_destroy(roman_ctx_t* c)
         if (W.done) (void)hipEventDestroy(W.done);
     }
     if (c->evIn) (void)hipEventDestroy(c->evIn);
+    if (c->coopDone) (void)hipEventDestroy(c->coopDone);
     for (int k = 0; k < ROMAN_MAX_PIPELINE; ++k) if (c->istream[k]) (void)hipStreamDestroy(c->istream[k]);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
