@@ -704,6 +704,42 @@ ORACLE_API int32_t oracle_register(const roman_params_t* P, const double* D1, in
     return k;
 }
 
+/*
+ * Throughput form of register() for the CPU baseline of bench.py: B independent all-to-all problems over one
+ * object-major feature pool, ONE OpenMP thread per problem (the parallel loops inside a problem then run on that
+ * thread: nested parallelism is off by default) — what a caller with many pairs and many cores would do.
+ * assoc_out: B x kmax x 2 (rows beyond n_out[b] untouched), n_out[b] = selected associations of problem b.
+ */
+ORACLE_API int oracle_register_many(const roman_params_t* P, int32_t B, const double* feats,
+                                    const int64_t* off1, const int32_t* n1, const int64_t* off2, const int32_t* n2,
+                                    int32_t F, int faithful, int32_t kmax, int32_t* assoc_out, int32_t* n_out)
+{
+    int bad = 0;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int32_t b = 0; b < B; ++b) {
+        const int32_t nA = n1[b] * n2[b];
+        int32_t* tmp = (int32_t*)malloc(sizeof(int32_t) * 2 * (size_t)(nA > 0 ? nA : 1));
+        double* u = (double*)malloc(sizeof(double) * (size_t)(nA > 0 ? nA : 1));
+        roman_stats_t st;
+        if (!tmp || !u) {
+#pragma omp atomic write
+            bad = 1;
+            free(tmp); free(u);
+            continue;
+        }
+        const int32_t k = oracle_register(P, feats + off1[b] * F, n1[b], feats + off2[b] * F, n2[b], F, NULL, nA, NULL,
+                                          faithful, tmp, u, &st);
+        const int32_t kk = k < kmax ? k : kmax;
+        for (int32_t t = 0; t < kk; ++t) {
+            assoc_out[((size_t)b * kmax + t) * 2] = tmp[2 * t];
+            assoc_out[((size_t)b * kmax + t) * 2 + 1] = tmp[2 * t + 1];
+        }
+        n_out[b] = k;
+        free(tmp); free(u);
+    }
+    return bad ? -1 : 0;
+}
+
 ORACLE_API void oracle_set_threads(int n)
 {
 #ifdef _OPENMP

@@ -199,3 +199,22 @@ def test_reference_python_through_oracle_is_reproduced_by_the_mirror(orc, case):
         d = reg.dim
         p1 = np.array([pr.map1[i].center.ravel()[:d] for i, _ in res["assoc"]]); p2 = np.array([pr.map2[j].center.ravel()[:d] for _, j in res["assoc"]])
         assert np.linalg.norm(orc.t_align(p1, p2, d) - case["T"]) < 1e-12               # a8
+
+
+def test_register_many_equals_register_per_problem(orc):
+    """The throughput form used for bench.py's pair-parallel CPU baseline (one OpenMP thread per problem) returns what
+    register() returns for every problem, empty maps included."""
+    reg = registration_for("semanticgrav", semantics_dim=16)
+    P = reg._abi_params()
+    prs = [synth.make_pair(n, m, 16, 8800 + k) for k, (n, m) in enumerate([(30, 30), (25, 40), (12, 9), (40, 33)])]
+    mats = [(reg.pack(p.map1), reg.pack(p.map2)) for p in prs]
+    mats.append((mats[0][0][:0], mats[0][1]))                      # an empty map
+    feats = np.vstack([np.vstack(m) for m in mats])
+    off1, n1, off2, n2, pos = [], [], [], [], 0
+    for D1, D2 in mats:
+        off1.append(pos); n1.append(len(D1)); pos += len(D1)
+        off2.append(pos); n2.append(len(D2)); pos += len(D2)
+    got = orc.register_many(P, feats, off1, n1, off2, n2, kmax=40)
+    for (D1, D2), g in zip(mats, got):
+        want = orc.register(P, D1, D2, faithful=False)["assoc"]
+        assert np.array_equal(g, want)
