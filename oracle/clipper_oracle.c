@@ -715,6 +715,10 @@ ORACLE_API int oracle_register_many(const roman_params_t* P, int32_t B, const do
                                     int32_t F, int faithful, int32_t kmax, int32_t* assoc_out, int32_t* n_out)
 {
     int bad = 0;
+#ifdef _OPENMP
+    const int levels_before = omp_get_max_active_levels();
+    omp_set_max_active_levels(1);                 /* the loops inside a problem stay on the problem's thread */
+#endif
 #pragma omp parallel for schedule(dynamic, 1)
     for (int32_t b = 0; b < B; ++b) {
         const int32_t nA = n1[b] * n2[b];
@@ -737,6 +741,9 @@ ORACLE_API int oracle_register_many(const roman_params_t* P, int32_t B, const do
         n_out[b] = k;
         free(tmp); free(u);
     }
+#ifdef _OPENMP
+    omp_set_max_active_levels(levels_before);
+#endif
     return bad ? -1 : 0;
 }
 
