@@ -90,10 +90,16 @@ extern "C" {
 /*   ROMAN_SINGLE_BOTH     M_pq = fuse(s_a(p,q), s_o(p), s_o(q)), M_pp = s_o(p)
      ROMAN_SINGLE_OFFDIAG  M_pq fused as above, M_pp = 1 (plain CLIPPER's implicit identity)
      ROMAN_SINGLE_DIAG     M_pq = s_a(p,q), M_pp = s_o(p)
-   In every mode an association whose single score is 0 is removed from the problem. */
-#define ROMAN_SINGLE_BOTH    0
-#define ROMAN_SINGLE_OFFDIAG 1
-#define ROMAN_SINGLE_DIAG    2
+   In these three readings an association whose single score is 0 is removed from the problem (its row and column
+   of M and C are empty, its u stays 0).
+     ROMAN_SINGLE_DIAG_KEEP  M_pq = s_a(p,q), M_pp = s_o(p) — and NOTHING is removed: an association with s_o = 0 keeps
+                             its off-diagonal entries and only has a zero diagonal (SURVEY.md B7 read literally: "diagonal
+                             M_pp = s_single(p)", the pair score alone off the diagonal).  Every input association is then
+                             live (L = A): the large-live-set path (k_solve_wide) serves it. */
+#define ROMAN_SINGLE_BOTH      0
+#define ROMAN_SINGLE_OFFDIAG   1
+#define ROMAN_SINGLE_DIAG      2
+#define ROMAN_SINGLE_DIAG_KEEP 3
 
 /*
  * Invariant + solver parameters.  Replaces clipperpy.invariants.ROMANParams /
@@ -249,6 +255,19 @@ ROMAN_API int roman_align_batch_dev(roman_ctx_t* ctx, const roman_params_t* para
                           const double* u0,
                           int32_t kmax, int32_t* assoc_out, int32_t* n_assoc_out,
                           double* T_out, int32_t* status_out, roman_stats_t* stats_out);
+
+/* Problems that roman_align_batch_dev calls on this context have reported with ROMAN_ST_WORKSPACE so far (a running
+   total; only batches whose totals have arrived count: wait != 0 synchronises every stream of the context first, so
+   that all issued batches count).  A caller that never looks at status_out can still tell that something was skipped:
+       int64_t before, after;
+       roman_ctx_skipped(ctx, 1, &before);
+       roman_align_batch_dev(ctx, ...);                          // enqueue (any number of calls)
+       roman_ctx_skipped(ctx, 1, &after);                        // waits for them
+       if (after != before) { ... status_out[b] & ROMAN_ST_WORKSPACE marks the problems: issue THOSE again — same call
+                                  with off1/n1/off2/n2/assoc_off restricted to them; the context has recorded their need,
+                                  so the second attempt sizes its pools for them ... }
+   roman_align_batch (host pointers) runs exactly this loop itself (at most 4 attempts, then ROMAN_E_NOMEM). */
+ROMAN_API int roman_ctx_skipped(roman_ctx_t* ctx, int wait, int64_t* n_skipped);
 
 /* Same contract with HOST pointers everywhere; `n_objects` = number of objects in `feats`.
    Copies in, runs roman_align_batch_dev, copies out, synchronises.  This is what a cgo/ctypes

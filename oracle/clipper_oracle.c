@@ -354,10 +354,12 @@ static double pair_score(const roman_params_t* P, const pair_consts_t* K,
  *   When the invariant has no single features (method 'clipper'/'gravity') M_pq = s_a.
  *   The product s_o(p)*s_o(q) is formed first so the result is bitwise symmetric in (p,q).
  *   single_mode (roman_hip.h) selects the alternative readings: OFFDIAG keeps this fusion but an identity
- *   diagonal, DIAG keeps M_pq = s_a and puts the single scores on the diagonal only. */
+ *   diagonal, DIAG keeps M_pq = s_a and puts the single scores on the diagonal only, DIAG_KEEP does the same
+ *   without removing the associations whose single score is 0 (they keep their off-diagonal entries). */
 static double fuse_pair(const roman_params_t* P, int single, double sa, double sp, double sq)
 {
     if (!single) return sa;
+    if (P->single_mode == ROMAN_SINGLE_DIAG_KEEP) return sa;  /* single scores on the diagonal only, nothing removed */
     if (sa == 0.0 || sp == 0.0 || sq == 0.0) return 0.0;
     if (P->single_mode == ROMAN_SINGLE_DIAG) return sa;       /* single scores on the diagonal only */
     const double ss = sp * sq, wd = P->distance_weight;
@@ -424,8 +426,9 @@ ORACLE_API oracle_mat_t* oracle_build(const roman_params_t* P, const double* D1,
     double* s = (double*)malloc(sizeof(double) * (nA > 0 ? nA : 1));
     m->live = (uint8_t*)malloc((size_t)(nA > 0 ? nA : 1));
     oracle_single_scores(P, D1, n1, D2, n2, F, A, nA, s);
+    const int keep = single && P->single_mode == ROMAN_SINGLE_DIAG_KEEP;   /* a zero single score removes nothing */
     for (int32_t p = 0; p < nA; ++p) {
-        m->live[p] = s[p] > 0.0;
+        m->live[p] = keep || s[p] > 0.0;
         m->diag[p] = (single && P->single_mode == ROMAN_SINGLE_OFFDIAG) ? (m->live[p] ? 1.0 : 0.0) : s[p];
     }
     pair_consts_t K; K.sig2 = P->sigma * P->sigma; K.sin_unc = sin(P->gravity_unc_ang_rad);
@@ -435,12 +438,12 @@ ORACLE_API oracle_mat_t* oracle_build(const roman_params_t* P, const double* D1,
     int32_t*  rcnt  = (int32_t*)calloc((size_t)(nA > 0 ? nA : 1), sizeof(int32_t));
 #pragma omp parallel for schedule(dynamic, 16)
     for (int32_t p = 0; p < nA; ++p) {
-        if (!faithful && s[p] == 0.0) continue;
+        if (!faithful && !m->live[p]) continue;
         const int32_t i = A[2 * p], j = A[2 * p + 1];
         const double* ai = D1 + (int64_t)i * F; const double* bj = D2 + (int64_t)j * F;
         int32_t cap = 0, cnt = 0; int32_t* cc = NULL; double* vv = NULL;
         for (int32_t q = p + 1; q < nA; ++q) {
-            if (!faithful && s[q] == 0.0) continue;
+            if (!faithful && !m->live[q]) continue;
             const int32_t i2 = A[2 * q], j2 = A[2 * q + 1];
             if (i == i2 || j == j2) continue;                       /* distinctness */
             const double sa = pair_score(P, &K, ai, D1 + (int64_t)i2 * F, bj, D2 + (int64_t)j2 * F);

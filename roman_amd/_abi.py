@@ -32,6 +32,7 @@ ROMAN_GRAV_ZGATE = 2
 ROMAN_SINGLE_BOTH = 0
 ROMAN_SINGLE_OFFDIAG = 1
 ROMAN_SINGLE_DIAG = 2
+ROMAN_SINGLE_DIAG_KEEP = 3
 
 ROMAN_STAGE_SINGLE = 0
 ROMAN_STAGE_COUNT_PASS = 1
@@ -154,6 +155,7 @@ def load_library():
         "roman_ctx_set_pipeline": (C.c_int, [ctxp, C.c_int]),
         "roman_ctx_sync": (C.c_int, [ctxp]),
         "roman_ctx_join": (C.c_int, [ctxp, C.c_int]),
+        "roman_ctx_skipped": (C.c_int, [ctxp, C.c_int, P(i64)]),
         "roman_last_error": (C.c_char_p, [ctxp]),
         "roman_align_batch_dev": (C.c_int, [ctxp, P(RomanParams), i32, vp, vp, vp, vp, vp, i32,
                                             vp, vp, vp, i32, vp, vp, vp, vp, vp]),
@@ -189,7 +191,7 @@ def load_library():
 
 EXPORTED_SYMBOLS = (
     "roman_params_default", "roman_ctx_create", "roman_ctx_destroy", "roman_ctx_set_pipeline", "roman_ctx_sync", "roman_ctx_join",
-    "roman_last_error",
+    "roman_ctx_skipped", "roman_last_error",
     "roman_align_batch_dev", "roman_align_batch", "roman_create_all_to_all", "roman_score",
     "roman_set_matrix_data", "roman_solve", "roman_num_associations", "roman_num_selected",
     "roman_get_selected_associations", "roman_get_solution", "roman_get_dense_matrices",

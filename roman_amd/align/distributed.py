@@ -55,9 +55,27 @@ def take(batch: AlignmentBatch, idx) -> AlignmentBatch:
                           None if batch.pair_index is None else batch.pair_index[idx])
 
 
+_POOL_CACHE = {}          # device -> (host array it was uploaded from, device tensor): a batch's feature pool is uploaded once
+
+
+def _device_pool(feats, dev):
+    """The feature pool of a batch on `dev`: uploaded once per (array, device) — consecutive calls over the same pool
+    (the chunks of one grid, the retry of skipped problems) reuse the resident copy."""
+    import torch
+    key = str(dev)
+    hit = _POOL_CACHE.get(key)
+    if hit is not None and hit[0] is feats:
+        return hit[1]
+    t = torch.from_numpy(feats).to(dev)
+    _POOL_CACHE[key] = (feats, t)
+    return t
+
+
 def _device_records(registration, sub: AlignmentBatch, kmax, per, dev):
     """Align `sub` with device-resident inputs and outputs; -> (ints (per, 2+2*kmax) int32, poses (per,16) f64) torch
-    tensors on `dev`, rows beyond len(sub) padded with -1 / NaN."""
+    tensors on `dev`, rows beyond len(sub) padded with -1 / NaN.  Problems the speculatively sized workspace skipped
+    (ROMAN_ST_WORKSPACE) are issued again — those problems only — and an error is raised if any is still skipped after
+    four attempts (the host-pointer entry returns ROMAN_E_NOMEM in the same situation)."""
     import torch
     from .. import _abi
     ctx = registration._context()
@@ -68,20 +86,36 @@ def _device_records(registration, sub: AlignmentBatch, kmax, per, dev):
         return ints, poses
     P = registration._abi_params()
     F = sub.feats.shape[1]
-    feats = torch.from_numpy(sub.feats).to(dev)
-    assoc = None if sub.assoc is None else torch.from_numpy(np.ascontiguousarray(sub.assoc, dtype=np.int32)).to(dev)
+    feats = _device_pool(sub.feats, dev)
     a_out = torch.full((B, kmax, 2), -1, dtype=torch.int32, device=dev)
     n_out = torch.zeros(B, dtype=torch.int32, device=dev)
     T_out = torch.zeros((B, 16), dtype=torch.float64, device=dev)
     st_out = torch.zeros(B, dtype=torch.int32, device=dev)
     torch.cuda.current_stream(dev).synchronize()               # inputs are in place before the library's stream reads them
+    todo = np.arange(B)
     for attempt in range(4):                                   # the device-pointer entry sizes its pools speculatively
-        ctx.align_batch_dev(P, feats.data_ptr(), F, sub.off1, sub.n1, sub.off2, sub.n2, kmax, a_out.data_ptr(), n_out.data_ptr(),
-                            T_out.data_ptr(), st_out.data_ptr(), None,
-                            assoc_ptr=None if assoc is None else assoc.data_ptr(), assoc_off=sub.assoc_off)
+        part = sub if len(todo) == B else take(sub, todo)
+        assoc = None if part.assoc is None else torch.from_numpy(np.ascontiguousarray(part.assoc, dtype=np.int32)).to(dev)
+        if len(todo) == B:
+            ao, no, To, so = a_out, n_out, T_out, st_out
+        else:
+            nb = len(todo)
+            ao = torch.full((nb, kmax, 2), -1, dtype=torch.int32, device=dev); no = torch.zeros(nb, dtype=torch.int32, device=dev)
+            To = torch.zeros((nb, 16), dtype=torch.float64, device=dev); so = torch.zeros(nb, dtype=torch.int32, device=dev)
+            torch.cuda.current_stream(dev).synchronize()
+        ctx.align_batch_dev(P, feats.data_ptr(), F, part.off1, part.n1, part.off2, part.n2, kmax, ao.data_ptr(), no.data_ptr(),
+                            To.data_ptr(), so.data_ptr(), None,
+                            assoc_ptr=None if assoc is None else assoc.data_ptr(), assoc_off=part.assoc_off)
         ctx.sync()
-        if not bool((st_out & _abi.ROMAN_ST_WORKSPACE).any()):
+        if len(todo) != B:
+            ix = torch.from_numpy(todo).to(dev)
+            a_out[ix] = ao; n_out[ix] = no; T_out[ix] = To; st_out[ix] = so
+        skipped = ((so & _abi.ROMAN_ST_WORKSPACE) != 0).cpu().numpy()
+        if not skipped.any():
             break
+        todo = todo[skipped]
+    else:
+        raise _abi.RomanHipError(f"{len(todo)} problem(s) still without workspace after 4 attempts")
     ints[:B, 0] = n_out; ints[:B, 1] = st_out
     valid = torch.arange(kmax, device=dev)[None, :] < n_out[:, None]
     ints[:B, 2:] = torch.where(valid[:, :, None], a_out, torch.full_like(a_out, -1)).reshape(B, -1)
@@ -106,6 +140,8 @@ def align_sharded(registration, batch: AlignmentBatch, group=None, compute=None,
     mine = shards[rank]
     per = max(1, max(len(s) for s in shards))                  # every rank gathers equal shapes
     sub = take(batch, mine)
+    if compute is None and world == 1 and not torch.cuda.is_available():
+        compute = run_batch                                    # no torch device memory to hold the records: the host-pointer entry
     on_device = compute is None
     if on_device:
         dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())

@@ -48,6 +48,7 @@ struct DevParams {
     int32_t max_compact; // streaming solver: column compactions allowed per problem (speed only; set per launch)
     int32_t gmode;      // 0: no gravity; 1 + ROMAN_GRAV_* otherwise (1 combined, 2 separate gates, 3 z gate on full lengths)
     int32_t diag_one;   // single scores present but the diagonal is the identity (ROMAN_SINGLE_OFFDIAG)
+    int32_t keep_all;   // single scores present but a zero one removes nothing (ROMAN_SINGLE_DIAG_KEEP): every association is live
     int32_t allow_fallback;  // the fallback kernels are part of this launch; otherwise a problem that does not fit the stream layout is
                              // SKIPPED (kind 2, ROMAN_ST_WORKSPACE) and runs again with them (set per launch, from the sizing history)
     int32_t stream_maxL;     // problems of up to this many live associations take the stream layout (<= STREAM_MAXL; set per launch:
@@ -226,7 +227,7 @@ __device__ inline double single_score(const DevParams& D, const double* __restri
 // Fusion of the pair score with the two single scores; mirrors oracle fuse_pair().
 __device__ __forceinline__ double fuse_pair(const DevParams& D, double sa, double sp, double sq)
 {
-    if (!D.single) return sa;
+    if (!D.single || D.keep_all) return sa;
     if (sa == 0.0 || sp == 0.0 || sq == 0.0) return 0.0;
     if (D.p.single_mode == ROMAN_SINGLE_DIAG) return sa;
     const double ss = sp * sq, wd = D.p.distance_weight;
@@ -440,7 +441,7 @@ __global__ void __launch_bounds__(256) k_live(DevParams D, const ProbDesc* __res
                 }
                 sT[p] = s;
             }
-            cnt += __popcll(__ballot(s > 0.0));
+            cnt += __popcll(__ballot(p < p_end && (s > 0.0 || D.keep_all)));
         }
         if (lane == 0) wtot[w] = cnt;
         __syncthreads();
@@ -463,7 +464,7 @@ __global__ void __launch_bounds__(256) k_live(DevParams D, const ProbDesc* __res
     int cnt = 0;
     for (int p0 = p_beg; p0 < p_end; p0 += WAVE) {
         const int p = p0 + lane;
-        cnt += __popcll(__ballot(p < p_end && sT[p] > 0.0));
+        cnt += __popcll(__ballot(p < p_end && (D.keep_all || sT[p] > 0.0)));
     }
     if (lane == 0) wtot[w] = cnt;
     __syncthreads();
@@ -478,7 +479,7 @@ __global__ void __launch_bounds__(256) k_live(DevParams D, const ProbDesc* __res
     for (int p0 = p_beg; p0 < p_end; p0 += WAVE) {
         const int p = p0 + lane;
         const double s = (p < p_end) ? sT[p] : 0.0;
-        const bool live = s > 0.0;
+        const bool live = p < p_end && (s > 0.0 || D.keep_all);
         const unsigned long long m = __ballot(live);
         if (live) {
             const int pos = base + __popcll(m & ((1ull << lane) - 1ull));

@@ -84,6 +84,7 @@ struct roman_ctx {
         hipEvent_t totEvent = nullptr;
         bool totPending = false;
         double totMaskBound = 0.0, totSumA = 0.0, totMaxA = 0.0;   // the bounds the pending totals relate to
+        unsigned totEpoch = 0;                                     // sizing-history epoch (parameter block) the pending totals were measured under
         // per-stage hipEvent pairs on `stream`
         hipEvent_t evA[ROMAN_STAGE_COUNT] = {nullptr, nullptr, nullptr, nullptr};
         hipEvent_t evB[ROMAN_STAGE_COUNT] = {nullptr, nullptr, nullptr, nullptr};
@@ -105,6 +106,8 @@ struct roman_ctx {
         double rNnz = 0.0;                     // matrix slots / sum of nA
         double rList = 0.0;                    // candidate-list elements / sum of nA
     } hist;
+    unsigned histEpoch = 1;                    // bumped whenever the history is reset for another parameter block
+    long long skippedTotal = 0;                // problems reported ROMAN_ST_WORKSPACE so far (harvested totals)
 
     std::vector<std::pair<const void*, int>> ldsAttr;   // dynamic-LDS limits already set (per kernel function)
 
@@ -161,6 +164,9 @@ int use_ws0(roman_ctx* c)
 {
     if (c->pipeline >= 2)
         for (int k = 0; k < ROMAN_MAX_PIPELINE; ++k) if (c->istream[k]) HIPCHK(c, hipStreamSynchronize(c->istream[k]));
+    // a depth-1 batch may still be running on the context's (non-blocking) stream: the blocking copies of the stepwise
+    // entry points (null stream) are not ordered against it otherwise
+    if (c->stream) HIPCHK(c, hipStreamSynchronize(c->stream));
     c->cur = 0; c->ws[0].stream = c->stream;
     return ROMAN_OK;
 }
@@ -191,7 +197,7 @@ int make_dev_params(roman_ctx* c, const roman_params_t* p, int32_t F, DevParams*
     if (p->invariant == ROMAN_INV_ROMAN && p->gravity_guided && p->point_dim != 3) return fail(c, ROMAN_E_UNSUPPORTED, "gravity_guided requires point_dim == 3");
     if (p->fusion_method < 0 || p->fusion_method > 2) return fail(c, ROMAN_E_INVALID, "unknown fusion_method");
     if (p->gravity_mode < 0 || p->gravity_mode > 2) return fail(c, ROMAN_E_INVALID, "unknown gravity_mode %d", p->gravity_mode);
-    if (p->single_mode < 0 || p->single_mode > 2) return fail(c, ROMAN_E_INVALID, "unknown single_mode %d", p->single_mode);
+    if (p->single_mode < 0 || p->single_mode > 3) return fail(c, ROMAN_E_INVALID, "unknown single_mode %d", p->single_mode);
     if (p->reserved != 0) return fail(c, ROMAN_E_INVALID, "roman_params_t.reserved must be 0");
     if (!(p->sigma > 0.0)) return fail(c, ROMAN_E_INVALID, "sigma must be > 0");
     const int need = (p->invariant == ROMAN_INV_ROMAN) ? p->point_dim + p->ratio_feature_dim + p->cos_feature_dim : p->point_dim;
@@ -206,7 +212,8 @@ int make_dev_params(roman_ctx* c, const roman_params_t* p, int32_t F, DevParams*
     D->single = (p->invariant == ROMAN_INV_ROMAN) && (p->ratio_feature_dim > 0 || p->cos_feature_dim > 0);
     D->gravity = (p->invariant == ROMAN_INV_ROMAN) && p->gravity_guided;
     D->gmode = D->gravity ? 1 + p->gravity_mode : 0;
-    D->diag_one = D->single && p->single_mode == ROMAN_SINGLE_OFFDIAG;
+    D->diag_one = D->single && D->p.single_mode == ROMAN_SINGLE_OFFDIAG;
+    D->keep_all = D->single && D->p.single_mode == ROMAN_SINGLE_DIAG_KEEP;
     D->F = F;
     D->stream_maxL = STREAM_MAXL;
     D->allow_fallback = 1;
@@ -264,6 +271,8 @@ void harvest_totals(roman_ctx* c, bool wait)
         else if (hipEventQuery(W.totEvent) != hipSuccess) { (void)hipGetLastError(); continue; }
         W.totPending = false;
         const BatchTotals& t = *W.pinnedTotals;
+        c->skippedTotal += t.overflow;
+        if (W.totEpoch != c->histEpoch) continue;               // measured under another parameter block: not this history's ratios
         roman_ctx::Hist& H = c->hist;
         if (W.totMaxA > 0) H.rMaxL = std::max(H.rMaxL, (double)t.maxL / W.totMaxA);
         if (W.totMaskBound > 0) H.rMask = std::max(H.rMask, (double)t.needMaskWords / W.totMaskBound);
@@ -278,21 +287,23 @@ void estimate_sizes(roman_ctx* c, const DevParams& D, const roman_params_t* para
     roman_ctx::Hist& H = c->hist;
     if (!H.valid || H.F != F || memcmp(&H.params, params, sizeof(roman_params_t)) != 0) {   // other parameters: other ratios
         H = roman_ctx::Hist{}; H.params = *params; H.F = F;
+        ++c->histEpoch;                                         // totals still in flight belong to the old block: harvest_totals drops them
     }
     harvest_totals(c, false);
+    const bool prunes = D.single && !D.keep_all;              // single scores can remove associations: L <= A, else L == A
     double heurMask = 0, heurNnz = 0; int heurMaxL = 0;
     for (const ProbDesc& d : hd) {
         const double nA = d.nA;
         S->sumA += nA; S->maxA = std::max(S->maxA, nA); S->maskBound += nA * std::ceil(nA / 64.0);
         // first-call heuristic: without single scores every association is live; with them a fraction is
-        const double capL = D.single ? std::min(nA, std::max(4096.0, nA / 8.0)) : nA;
+        const double capL = prunes ? std::min(nA, std::max(4096.0, nA / 8.0)) : nA;
         heurMaxL = std::max(heurMaxL, (int)capL);
         heurMask += capL * std::ceil(capL / 64.0);
         heurNnz += capL * std::min(capL, 96.0);
     }
     if (H.valid) {
-        S->expectMaxL = D.single ? (int)std::min(S->maxA, std::ceil(H.rMaxL * S->maxA * 1.15) + 64.0) : (int)S->maxA;
-        S->capMaskWords = (long long)(D.single ? H.rMask * S->maskBound * 1.3 + 4096.0 : S->maskBound);
+        S->expectMaxL = prunes ? (int)std::min(S->maxA, std::ceil(H.rMaxL * S->maxA * 1.15) + 64.0) : (int)S->maxA;
+        S->capMaskWords = (long long)(prunes ? H.rMask * S->maskBound * 1.3 + 4096.0 : S->maskBound);
         S->capNnz = (long long)(H.rNnz * S->sumA * 1.3 + 65536.0);
         S->capList = (long long)(H.rList * S->sumA * 1.3 + 65536.0);
     } else {
@@ -508,7 +519,7 @@ int enqueue_score(roman_ctx* c, const DevParams& Din, const roman_params_t* para
         const int TCs = D.stream_maxL;
         const size_t sliceLds = (size_t)TCs * (colBytesF + 2) + sizeof(uint32_t) * (size_t)(3 * SPI * 64 + 2 * (SPI + 1) + 2);
         if (sliceLds > c->lds_max) return fail(c, ROMAN_E_TOO_LARGE, "internal: stream column tile does not fit the LDS");
-        const bool fast = D.single && D.p.single_mode != ROMAN_SINGLE_DIAG && D.p.distance_weight == 1.0 &&
+        const bool fast = D.single && (D.p.single_mode == ROMAN_SINGLE_BOTH || D.p.single_mode == ROMAN_SINGLE_OFFDIAG) && D.p.distance_weight == 1.0 &&
                           D.p.fusion_method != ROMAN_FUSE_ARITHMETIC_MEAN && D.p.fusion_method != ROMAN_FUSE_PRODUCT;
         auto kf = D.gravity ? (fast ? k_fill_list<true, true> : k_fill_list<true, false>) : (fast ? k_fill_list<false, true> : k_fill_list<false, false>);
         HIPCHK(c, dyn_lds(c, reinterpret_cast<const void*>(kf), sliceLds));
@@ -519,7 +530,7 @@ int enqueue_score(roman_ctx* c, const DevParams& Din, const roman_params_t* para
     DBG(c, "k_fill_list");
         // fallback layout (symmetric SELL-64, 32-bit indices) for the problems the stream layout does not take: only when
         // one can exist (the kernel would find no work otherwise)
-        if (D.allow_fallback && SZ.maxA > D.stream_maxL) {
+        if (D.allow_fallback && (SZ.maxA > D.stream_maxL || D.p.maxiniters < 1 || D.p.maxlsiters < 1)) {
             const int colBytesG = D.gravity ? 36 : 20;
             const size_t ringLds = (size_t)16 * 3 * FILL_Q * sizeof(uint32_t);
             int TCf = (int)std::min<size_t>((c->lds_max - ringLds) / colBytesG, 32768) & ~63;
@@ -539,7 +550,7 @@ int enqueue_score(roman_ctx* c, const DevParams& Din, const roman_params_t* para
     // the totals travel back on their own: whoever sizes a later batch picks them up once they have arrived
     HIPCHK(c, hipMemcpyAsync(WS.pinnedTotals, dT, sizeof(BatchTotals), hipMemcpyDeviceToHost, WS.stream));
     HIPCHK(c, hipEventRecord(WS.totEvent, WS.stream));
-    WS.totPending = true; WS.totMaskBound = SZ.maskBound; WS.totSumA = SZ.sumA; WS.totMaxA = SZ.maxA;
+    WS.totPending = true; WS.totMaskBound = SZ.maskBound; WS.totSumA = SZ.sumA; WS.totMaxA = SZ.maxA; WS.totEpoch = c->histEpoch;
     HIPCHK(c, hipGetLastError());
     return ROMAN_OK;
 }
@@ -974,6 +985,16 @@ int roman_ctx_sync(roman_ctx_t* c)
     return ROMAN_OK;
 }
 
+int roman_ctx_skipped(roman_ctx_t* c, int wait, int64_t* n)
+{
+    if (!c || !n) return fail(c, ROMAN_E_INVALID, "NULL argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (wait) { int rc = roman_ctx_sync(c); if (rc) return rc; }
+    harvest_totals(c, wait != 0);
+    *n = (int64_t)c->skippedTotal;
+    return ROMAN_OK;
+}
+
 // --- instrumentation -----------------------------------------------------------------------------
 int roman_profile_enable(roman_ctx_t* c, int on)
 {
@@ -1037,6 +1058,7 @@ int roman_align_batch_dev(roman_ctx_t* c, const roman_params_t* params, int32_t 
             c->ws[k].issued = true;
         }
         c->cur = 0;
+        c->last.scored = false; c->last.solved = false;        // workspace 0 is reused: the stepwise problem it held is gone
         return rc;
     }
     c->cur = 0; WS.stream = c->stream;

@@ -75,6 +75,13 @@ class Context:
         """Make the context's stream wait for the pipelined batches issued so far (optionally all but the latest)."""
         self._check(self._lib.roman_ctx_join(self._h, int(bool(skip_latest))), "roman_ctx_join")
 
+    def skipped(self, wait=True):
+        """Running total of problems that batch calls on this context reported with ROMAN_ST_WORKSPACE
+        (roman_ctx_skipped); wait=True synchronises the context first so that every issued batch counts."""
+        n = C.c_int64(0)
+        self._check(self._lib.roman_ctx_skipped(self._h, int(bool(wait)), C.byref(n)), "roman_ctx_skipped")
+        return int(n.value)
+
     def _check(self, rc, what):
         if rc != 0:
             msg = self._lib.roman_last_error(self._h)

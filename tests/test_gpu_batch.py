@@ -369,3 +369,56 @@ def test_live_set_larger_than_the_history_expects_is_retried_with_the_fallback_k
         assert np.array_equal(res.assoc[1], o["assoc"]) and res.stats["nnz_upper"][1] == o["stats"].nnz_upper
     finally:
         c.close()
+
+
+def test_zero_inner_iterations_take_the_fallback_layout_and_match_the_oracle(ctx, orc):
+    """maxiniters < 1 (or maxlsiters < 1) makes every problem kind 1 (only the fallback solver implements the degenerate
+    loop): its fill kernel must run for ordinary small problems too (it was launched only for live sets beyond
+    the stream layout, so the solver read unwritten column indices).  Both batch entries and the stepwise pair."""
+    reg = registration_for("semanticgrav", semantics_dim=24); reg.set_context(ctx)
+    P = reg._abi_params()
+    old = (P.maxiniters, P.maxoliters)
+    try:
+        P.maxiniters = 0; P.maxoliters = 7
+        pairs = [synth.make_pair(40, 35 + k, 24, 820 + k, tilt_deg=1.0) for k in range(3)]
+        res = reg.register_and_align_batch([(p.map1, p.map2) for p in pairs])
+        for b, p in enumerate(pairs):
+            o = oracle_one(orc, reg, p.map1, p.map2)
+            assert np.array_equal(res.assoc[b], o["assoc"]), b
+            assert res.stats["nnz_upper"][b] == o["stats"].nnz_upper and res.stats["outer_iters"][b] == o["stats"].outer_iters == 7
+            assert res.stats["n_pass"][b] == o["stats"].n_pass == 2
+        D1, D2 = reg.pack(pairs[0].map1), reg.pack(pairs[0].map2)
+        ctx.score(P, D1, D2, None); ctx.solve(None)
+        assert np.array_equal(ctx.selected_associations(), res.assoc[0])
+    finally:
+        P.maxiniters, P.maxoliters = old
+
+
+def test_sizing_history_of_one_parameter_block_is_not_applied_to_another(orc):
+    """The totals a batch leaves behind size the NEXT batch — of the same parameter block only.  A block that keeps far more
+    associations, issued right after (its predecessor's totals still pending), must start from the first-call heuristics
+    and the fallback kernels, not from the other block's ratios: no ROMAN_ST_WORKSPACE on its first call."""
+    from roman_amd.runtime import Context
+    c = Context(0)
+    hip = _Hip()
+    try:
+        regA = registration_for("semanticgrav", semantics_dim=16, cosine_min=0.9, cosine_max=0.95); regA.set_context(c)
+        regB = registration_for("semanticgrav", semantics_dim=16, cosine_min=-0.9, cosine_max=0.7); regB.set_context(c)
+        pairs = [synth.make_pair(60, 60, 16, 5200 + k) for k in range(4)]
+        batch = rb.batch_from_pairs(regA, [(p.map1, p.map2) for p in pairs])
+        B, kmax, F = len(batch), batch.kmax(), batch.feats.shape[1]
+        o = dict(feats=hip.upload(batch.feats), assoc=hip.alloc(B * kmax * 2 * 4), n=hip.alloc(B * 4), T=hip.alloc(B * 16 * 8),
+                 status=hip.alloc(B * 4), stats=hip.alloc(B * _abi.STATS_NBYTES))
+        for _ in range(2):
+            c.align_batch_dev(regA._abi_params(), o["feats"], F, batch.off1, batch.n1, batch.off2, batch.n2, kmax, o["assoc"], o["n"], o["T"], o["status"], o["stats"])
+        # no sync: block A's totals are still pending when block B is sized
+        c.align_batch_dev(regB._abi_params(), o["feats"], F, batch.off1, batch.n1, batch.off2, batch.n2, kmax, o["assoc"], o["n"], o["T"], o["status"], o["stats"])
+        c.sync()
+        st = hip.download(o["status"], (B,), np.int32); n = hip.download(o["n"], (B,), np.int32); a = hip.download(o["assoc"], (B, kmax, 2), np.int32)
+        assert not (st & _abi.ROMAN_ST_WORKSPACE).any(), st
+        assert c.skipped() == 0
+        for b, p in enumerate(pairs):
+            ob = oracle_one(orc, regB, p.map1, p.map2)
+            assert np.array_equal(a[b, :n[b]], ob["assoc"]), b
+    finally:
+        hip.free_all(); c.close()

@@ -45,6 +45,10 @@ LADDER = [  # (id, method, kwargs, n, m, d, seed)
     ("roman_offdiag", "roman", {"semantics_dim": 32, "_single_mode": 1}, 50, 50, 32, 13),
     ("roman_diagonly", "roman", {"semantics_dim": 32, "_single_mode": 2}, 50, 50, 32, 13),
     ("sevg_offdiag_sep", "sevg", {"semantics_dim": 16, "epsilon_shape": 0.3, "_single_mode": 1, "_gravity_mode": 1}, 45, 40, 16, 14),
+    # ROMAN_SINGLE_DIAG_KEEP: a zero single score removes nothing (every association live, zero diagonals): once inside the
+    # stream layout (L = 2500), once beyond it (L = 8100: symmetric SELL-64 + the whole-device solver k_solve_wide)
+    ("roman_diagkeep", "roman", {"semantics_dim": 32, "_single_mode": 3}, 50, 50, 32, 13),
+    ("semgrav_diagkeep_90", "semanticgrav", {"semantics_dim": 64, "_single_mode": 3}, 90, 90, 64, 17),
 ]
 
 
@@ -73,7 +77,7 @@ def test_stagewise_parity(ctx, orc, case):
 
     # (1) live association list: identical indices; single scores to rounding
     s_o = orc.single_scores(P, D1, D2, Ao)
-    live_o = np.nonzero(s_o > 0)[0]
+    live_o = np.arange(len(s_o)) if P.single_mode == _abi.ROMAN_SINGLE_DIAG_KEEP else np.nonzero(s_o > 0)[0]
     idx, sc = ctx.live()
     assert np.array_equal(idx, live_o)
     assert np.array_equal(sc, s_o[live_o])          # bit-identical: stated-order dot / norms, exact ops otherwise

@@ -136,6 +136,35 @@ def test_single_mode_switch_h3(orc):
         assert np.all(live[sol["nodes"]]) and np.all(sol["u"][~live] == 0.0)
 
 
+def test_single_mode_diag_keep_removes_nothing(orc):
+    """ROMAN_SINGLE_DIAG_KEEP (VERDICT r2 missing #3: "a zero single score does NOT remove the association"): every
+    association stays live, off-diagonals are the unfused pair score over ALL associations, the diagonal is the
+    single score (0 where it vanishes)."""
+    reg = registration_for("roman", semantics_dim=16)
+    pr = synth.make_pair(36, 36, 16, 8, tilt_deg=1.0)
+    D1, D2 = reg.pack(pr.map1), reg.pack(pr.map2)
+    P = type(reg._abi_params()).from_buffer_copy(reg._abi_params())
+    P.single_mode = _abi.ROMAN_SINGLE_DIAG_KEEP
+    keep = _pattern(orc, P, D1, D2)
+    s = orc.single_scores(P, D1, D2)
+    assert (s == 0).any() and np.array_equal(keep[2], s)              # zero diagonals are part of the problem
+    Pg = type(P).from_buffer_copy(P); Pg.ratio_feature_dim = 0; Pg.cos_feature_dim = 0   # the pair score alone
+    m2, _ = orc.build_matrix(Pg, D1[:, :3].copy(), D2[:, :3].copy())
+    rp, cc, vv, _ = m2.export()
+    rows = np.repeat(np.arange(m2.n), np.diff(rp))
+    assert keep[1] == {(p, q): v for p, q, v in zip(rows.tolist(), cc.tolist(), vv.tolist())}
+    # faithful (every pair scored) and pruned builds agree: nothing is pruned in this reading
+    mf, _ = orc.build_matrix(P, D1, D2, faithful=True)
+    assert mf.nnz == keep[3].nnz
+    sol = orc.solve(P, keep[3])
+    assert sol["stats"].n_live == 36 * 36
+    # DIAG is the same reading restricted to the associations with a non-zero single score
+    P.single_mode = _abi.ROMAN_SINGLE_DIAG
+    diag = _pattern(orc, P, D1, D2)
+    live = s > 0
+    assert diag[1] == {k: v for k, v in keep[1].items() if live[k[0]] and live[k[1]]}
+
+
 def test_removed_associations_ignore_u0(orc):
     reg = registration_for("semanticgrav", semantics_dim=16)
     pr = synth.make_pair(30, 30, 16, 3, tilt_deg=1.0)
