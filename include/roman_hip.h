@@ -56,6 +56,8 @@ extern "C" {
 #define ROMAN_ST_MAXITER             4  /* solver stopped on maxoliters                          */
 #define ROMAN_ST_ASSOC_TRUNCATED     8  /* more selected associations than kmax (output clipped) */
 #define ROMAN_ST_TIE_FALLBACK       16  /* top-omega boundary tie: sequential heap emulation ran */
+#define ROMAN_ST_INTERNAL           64  /* internal error (a bounded device-side wait of the large-problem solver expired): the
+                                           problem has no result; never expected, reported instead of hanging the device */
 #define ROMAN_ST_WORKSPACE          32  /* the problem was SKIPPED: roman_align_batch_dev sizes its device pools before the
                                            sizes of the sparse matrices are known (from earlier batches; the call never
                                            waits for the GPU) and this problem did not fit.  The library has recorded the

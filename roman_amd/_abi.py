@@ -18,6 +18,7 @@ ROMAN_ST_MAXITER = 4
 ROMAN_ST_ASSOC_TRUNCATED = 8
 ROMAN_ST_TIE_FALLBACK = 16
 ROMAN_ST_WORKSPACE = 32
+ROMAN_ST_INTERNAL = 64
 
 ROMAN_INV_EUCLIDEAN = 0
 ROMAN_INV_ROMAN = 1

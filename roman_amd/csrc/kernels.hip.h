@@ -1691,7 +1691,8 @@ __device__ __noinline__ void heap_select_serial(const double* u, const int32_t* 
 // arrays of capacity L.
 __device__ __noinline__ void finish_one(const DevParams& D, int b, const ProbDesc& pd, const double* __restrict__ feats,
                                         const int32_t* __restrict__ assoc, const int32_t* __restrict__ lp,
-                                        const int32_t* __restrict__ lpAsc, const uint32_t* __restrict__ vecOfLive, const SolveOut& O,
+                                        const int32_t* __restrict__ lpAsc, const uint32_t* __restrict__ vecOfLive,
+                                        const uint32_t* __restrict__ outIdx /* vector index -> slot of uOut (nullptr: identity) */, const SolveOut& O,
                                         const double* u, double* pv, int32_t* pidx, int32_t* nodesLive,
                                         int L, int rb, int64_t lo, double F, int status, roman_stats_t S,
                                         double* red, int* sint)
@@ -1704,7 +1705,7 @@ __device__ __noinline__ void finish_one(const DevParams& D, int b, const ProbDes
     __syncthreads();
     if (L > 0) {
         // final u to the row pool (stepwise API, tests)
-        for (int p = tid; p < L; p += nt) O.uOut[rb + p] = u[p];
+        for (int p = tid; p < L; p += nt) O.uOut[rb + (outIdx ? (int)outIdx[lo + p] : p)] = u[p];
 
         // ---- top-omega rounding --------------------------------------------------------------
         const double om = round(F);
@@ -1815,33 +1816,9 @@ __device__ __noinline__ void finish_one(const DevParams& D, int b, const ProbDes
 }
 
 
-// ---- whole-grid variants of the barrier and of block_sum2, for the cooperative launch of the fallback solver ----
-template <bool COOP> __device__ __forceinline__ void sync_all()
-{
-    if (COOP) cooperative_groups::this_grid().sync(); else __syncthreads();
-}
-// Sums of (a, b) over every thread of the grid, identical in all of them: block partials (block_sum2) into a ping-pong
-// slot array (one slot per workgroup; a slot array is rewritten two reductions later, behind the barrier of the one in
-// between), grid barrier, then every wave adds the partials in ONE fixed order.
-__device__ __forceinline__ void grid_sum2(double& a, double& b, double* red, int& par, int ltid, int nw, double* part, int& gpar)
-{
-    block_sum2(a, b, red, par, ltid, nw);
-    const int G = (int)gridDim.x;
-    double* slot = part + (size_t)gpar * 2 * (size_t)G;
-    gpar ^= 1;
-    if (ltid == 0) { slot[2 * blockIdx.x] = a; slot[2 * blockIdx.x + 1] = b; }
-    cooperative_groups::this_grid().sync();
-    double sa = 0.0, sb = 0.0;
-    for (int i = (ltid & 63); i < G; i += WAVE) { sa += slot[2 * i]; sb += slot[2 * i + 1]; }
-    for (int off = 32; off > 0; off >>= 1) { sa += __shfl_xor(sa, off); sb += __shfl_xor(sb, off); }
-    a = sa; b = sb;
-}
-
 /*
- * solve_one: CLIPPER findDenseClique on one problem, by one workgroup — or, COOP, by every workgroup of a
- * cooperative launch together (the large-problem path: all vectors in the pools, the SELL slices and the vector
- * elements dealt over the whole grid, grid barriers where the single workgroup has block barriers; only workgroup
- * 0 runs the shared tail).
+ * solve_one: CLIPPER findDenseClique on one problem, by one workgroup (k_solve: many mid-size problems of the fallback
+ * kind; few large ones go to k_solve_wide, the whole device on one problem).
  * Mirrors oracle_solve() step for step (see there for the restated upstream algorithm):
  * gradF is never stored: it is recombined on the fly from (u, Mu, Cu, d, sum u), bitwise the same
  * value the oracle keeps in its gradF vector.
@@ -1849,7 +1826,7 @@ __device__ __forceinline__ void grid_sum2(double& a, double& b, double* red, int
 // MODE 2: u, u_new, Mu, Cu, Mu_new, Cu_new and the diagonal all live in LDS (7 * Lcap doubles);
 // MODE 1: only u and u_new (the gathered vectors) do, the row vectors sit in the L2-resident pools;
 // MODE 0: nothing fits, everything is in the pools.
-template <typename IdxT, int MODE, bool COOP = false>
+template <typename IdxT, int MODE>
 __device__ void solve_one(const DevParams& D, int b, const ProbDesc& pd, ProbState* st,
                           const double* __restrict__ feats, const int32_t* __restrict__ assoc,
                           const int32_t* __restrict__ lp, const double* __restrict__ ls,
@@ -1860,19 +1837,13 @@ __device__ void solve_one(const DevParams& D, int b, const ProbDesc& pd, ProbSta
                           double* __restrict__ vMun, double* __restrict__ vCun,
                           double* __restrict__ gU, double* __restrict__ gUn,
                           const double* __restrict__ u0, const SolveOut& O,
-                          double* sv /* LDS vectors */, int Lcap, double* red, int* sint,
-                          double* part = nullptr /* COOP: 2 x gridDim.x x 2 doubles */, int* gparp = nullptr)
+                          double* sv /* LDS vectors */, int Lcap, double* red, int* sint)
 {
-    static_assert(!COOP || MODE == 0, "the cooperative solver keeps every vector in the pools");
     const roman_params_t& P = D.p;
     const int ltid = threadIdx.x, nw = blockDim.x >> 6;
-    // COOP: the element / slice owner index runs over the whole grid, wave-interleaved over the workgroups (consecutive
-    // SELL slices — the rows are sorted by length — go to different compute units)
-    const int nt = COOP ? (int)(blockDim.x * gridDim.x) : (int)blockDim.x;
-    const int tid = COOP ? ((((ltid >> 6) * (int)gridDim.x + (int)blockIdx.x) << 6) | (ltid & 63)) : ltid;
-    int gpar_local = 0;
-    int& gpar = gparp ? *gparp : gpar_local;
-#define SUM2(a_, b_) do { if (COOP) grid_sum2(a_, b_, red, par, ltid, nw, part, gpar); else block_sum2(a_, b_, red, par, ltid, nw); } while (0)
+    const int nt = (int)blockDim.x;
+    const int tid = ltid;
+#define SUM2(a_, b_) block_sum2(a_, b_, red, par, ltid, nw)
     const int L = st[b].L, rb = st[b].rowBase;
     const int64_t lo = pd.liveOff;
     const uint32_t* perm = permPool + lo; const uint32_t* swid = sliceWidthPool + lo; const uint32_t* sbase = sliceBasePool + lo;
@@ -1890,26 +1861,24 @@ __device__ void solve_one(const DevParams& D, int b, const ProbDesc& pd, ProbSta
         sd = sdl;
     }
 
-    const int dim = P.point_dim;
     int par = 0;
 
     int status = ROMAN_ST_OK;
     roman_stats_t S;
     S.n_assoc_in = pd.nA; S.n_live = L; S.nnz_upper = (int64_t)st[b].nnzUpper;
     S.n_pass = 0; S.outer_iters = 0; S.inner_iters = 0; S.ls_trials = 0; S.score = 0.0; S.d_final = 0.0;
-    int nsel = 0;
     double F = 0.0, d = 0.0;
 
     if (pd.n1 == 0 || pd.n2 == 0) status |= ROMAN_ST_EMPTY_MAP;
     if (L > 0) {
         // ---- initialisation: u = normalize(M u0 + diag u0) ------------------------------------
         for (int p = tid; p < L; p += nt) u[p] = u0 ? u0[lo + lp[lo + p]] : 1.0;
-        sync_all<COOP>();
+        __syncthreads();
         if (P.rescale_u0) {
             spmv_sell<IdxT, 8>(u, L, perm, swid, sbase, cols, vals, Mu, Cu, tid, nt); ++S.n_pass;
-            sync_all<COOP>();
+            __syncthreads();
             for (int p = tid; p < L; p += nt) u[p] = Mu[p] + sd[p] * u[p];
-            sync_all<COOP>();
+            __syncthreads();
         }
         {
             double ss = 0.0, dummy = 0.0;
@@ -1917,7 +1886,7 @@ __device__ void solve_one(const DevParams& D, int b, const ProbDesc& pd, ProbSta
             SUM2(ss, dummy);
             const double nr = sqrt(ss);
             if (nr > 0.0) for (int p = tid; p < L; p += nt) u[p] /= nr;
-            sync_all<COOP>();
+            __syncthreads();
         }
         spmv_sell<IdxT, 8>(u, L, perm, swid, sbase, cols, vals, Mu, Cu, tid, nt); ++S.n_pass;
         double usum = 0.0;
@@ -1968,7 +1937,7 @@ __device__ void solve_one(const DevParams& D, int b, const ProbDesc& pd, ProbSta
                     SUM2(s1, dd);
                     unsum = s1; du2 = dd;
                     spmv_sell<IdxT, 8>(un, L, perm, swid, sbase, cols, vals, Mun, Cun, tid, nt); ++S.n_pass; ++S.ls_trials;
-                    sync_all<COOP>();
+                    __syncthreads();
                     double f = 0.0;
                     for (int p = tid; p < L; p += nt) {
                         const double up = un[p];
@@ -1997,13 +1966,11 @@ __device__ void solve_one(const DevParams& D, int b, const ProbDesc& pd, ProbSta
         if (i >= P.maxoliters) status |= ROMAN_ST_MAXITER;
         S.outer_iters = i; S.score = F; S.d_final = d;
 
-        sync_all<COOP>();                         // every element of the final u is in memory
-        if (!COOP || blockIdx.x == 0)
-            finish_one(D, b, pd, feats, assoc, lp, lp, nullptr, O, u, Mun, (int32_t*)un, (int32_t*)Cun, L, rb, lo, F, status, S, red, sint);
+        __syncthreads();                         // every element of the final u is in memory
+        finish_one(D, b, pd, feats, assoc, lp, lp, nullptr, nullptr, O, u, Mun, (int32_t*)un, (int32_t*)Cun, L, rb, lo, F, status, S, red, sint);
         return;
     }
-    if (!COOP || blockIdx.x == 0)
-        finish_one(D, b, pd, feats, assoc, lp, lp, nullptr, O, nullptr, nullptr, nullptr, nullptr, L, rb, lo, F, status, S, red, sint);
+    finish_one(D, b, pd, feats, assoc, lp, lp, nullptr, nullptr, O, nullptr, nullptr, nullptr, nullptr, L, rb, lo, F, status, S, red, sint);
 #undef SUM2
 }
 
@@ -2043,34 +2010,6 @@ __global__ void __launch_bounds__(1024) k_solve(DevParams D, int B, const ProbDe
             else
                 solve_one<IdxT, 0>(D, b, pd, st, feats, assoc, lp, ls, perm, sliceWidth, sliceBase, cols, vals,
                                    vMu, vCu, vMun, vCun, gU, gUn, u0, O, sv, Lcap, red, sint);
-        }
-    }
-}
-
-// k_solve_coop: the fallback solver for FEW, LARGE problems — launched cooperatively (hipLaunchCooperativeKernel: every
-// workgroup resident), all workgroups solve the kind-1 problems of the batch one after the other TOGETHER: the SpMV of a
-// 40 000-row problem is 0.5 GB per pass, which one compute unit streams at a few GB/s and the whole device at TB/s.
-template <typename IdxT>
-__global__ void __launch_bounds__(1024) k_solve_coop(DevParams D, int B, const ProbDesc* __restrict__ probs,
-                                                     ProbState* __restrict__ st,
-                                                     const double* __restrict__ feats, const int32_t* __restrict__ assoc,
-                                                     const int32_t* __restrict__ lp, const double* __restrict__ ls,
-                                                     const uint32_t* __restrict__ perm, const uint32_t* __restrict__ sliceWidth,
-                                                     const uint32_t* __restrict__ sliceBase,
-                                                     const IdxT* __restrict__ cols, const double* __restrict__ vals,
-                                                     double* __restrict__ vMu, double* __restrict__ vCu,
-                                                     double* __restrict__ vMun, double* __restrict__ vCun,
-                                                     double* __restrict__ gU, double* __restrict__ gUn,
-                                                     const double* __restrict__ u0, SolveOut O, double* __restrict__ part)
-{
-    __shared__ double red[72];
-    __shared__ int sint[4];
-    int gpar = 0;
-    for (int b = 0; b < B; ++b) {
-        if (__builtin_amdgcn_readfirstlane(st[b].kind) == 1) {
-            const ProbDesc pd = probs[b];
-            solve_one<IdxT, 0, true>(D, b, pd, st, feats, assoc, lp, ls, perm, sliceWidth, sliceBase, cols, vals,
-                                     vMu, vCu, vMun, vCun, gU, gUn, u0, O, nullptr, 0, red, sint, part, &gpar);
         }
     }
 }
@@ -2260,7 +2199,7 @@ __device__ void solve_up(const DevParams& D, int b, const ProbDesc& pd, ProbStat
     double F = 0.0, d = 0.0;
     if (pd.n1 == 0 || pd.n2 == 0) status |= ROMAN_ST_EMPTY_MAP;
     if (L <= 0) {
-        finish_one(D, b, pd, feats, assoc, plp, lpAsc, rowPosPool, O, nullptr, nullptr, nullptr, nullptr, L, rb, lo, F, status, S, red, sint);
+        finish_one(D, b, pd, feats, assoc, plp, lpAsc, rowPosPool, nullptr, O, nullptr, nullptr, nullptr, nullptr, L, rb, lo, F, status, S, red, sint);
         return;
     }
 #ifdef ROMAN_SOLVE_TIMING
@@ -2541,7 +2480,7 @@ __device__ void solve_up(const DevParams& D, int b, const ProbDesc& pd, ProbStat
     // final u (unscaled) to LDS for the shared tail; scratch: the two accumulator arrays
     __syncthreads();
     FOR_K(k, p) if (p < L) xg[p] = u[k];
-    finish_one(D, b, pd, feats, assoc, plp, lpAsc, rowPosPool, O, xg, reinterpret_cast<double*>(accM),
+    finish_one(D, b, pd, feats, assoc, plp, lpAsc, rowPosPool, nullptr, O, xg, reinterpret_cast<double*>(accM),
                reinterpret_cast<int32_t*>(accC), reinterpret_cast<int32_t*>(accC) + Lc, L, rb, lo, F, status, S, red, sint);
 #undef FOR_K
 #undef CUMQ
@@ -2580,6 +2519,358 @@ __global__ void __launch_bounds__(NW * 64) k_solve_up(DevParams D, int B, const 
             solve_up<NW, HASCZ>(D, b, pd, st, feats, assoc, plp, lpAsc, rowPos, pld, sliceBase, cols, vals, u0, O,
                                 xg, accM, accC, Lc, cumQ, red, sint);
         }                                                       // kind 1: the fallback solver's problem; kind 2: skipped (k_skipped)
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_solve_wide: the solver for FEW, LARGE problems of the fallback kind (symmetric sorted SELL-64): every compute unit
+// works on ONE problem at a time.  (`method='gravity'` / `'clipper'` at n = m = 200, or the ROMAN_SINGLE_DIAG_KEEP
+// reading: L = 40 000 live associations, 0.5 GB of matrix; one workgroup would stream that at a few GB/s.)
+//
+//  * One persistent launch, one 512-thread workgroup per compute unit (cooperative launch: all resident).
+//  * The matrix is ONE flat stream of T "steps" (a step = entry e of the 64 lanes of a slice: 64 column words + 64
+//    values, contiguous); wave g of the grid streams the steps [T g / NWG, T (g+1) / NWG) whatever slices they belong
+//    to, WIDE_U steps in flight, and leaves the partial row sums of every slice piece it covered in a partials buffer
+//    (piece id = g + slice).  The rows' owners add the pieces of their slice in ascending order — a fixed order, no
+//    atomics.  (The round-2 solver gave a whole slice to one wave: 625 waves of 4096 busy, each walking ~1000 dependent
+//    steps: 0.5 ms per pass of pure latency.)
+//  * Vector elements live in REGISTERS: thread (wave g, lane l) owns positions (g + k NWG) * 64 + l — the rows of the slices
+//    whose partials it adds.  Only the vector being multiplied is in memory (live order, gathered by column index).
+//  * The trial vector is published UNNORMALISED: t = max(u + alpha grad, 0) goes out together with the partials of
+//    sum t^2 and sum t under ONE grid barrier; M t, C t come back and are scaled by 1 / |t| in registers
+//    (M (t / |t|) = (M t) / |t| up to rounding).  A line-search trial costs three grid barriers: publish, products, objective.
+//  * Grid barrier: one monotone counter; everything other workgroups read is stored write-through (`sc1`), so an
+//    arrival is: every wave drains its stores, workgroup barrier, one relaxed atomic add; departure: relaxed poll,
+//    ONE agent-scope acquire, workgroup barrier (MI355X_MICROARCH.md "barrier-counter": 7 us against 26 us for
+//    cooperative_groups' grid.sync()).  Grid sums ride on it: workgroup partials into a ping-pong slot array before the
+//    arrival, every workgroup adds the slots in one fixed order afterwards.  Every spin is bounded (4 s): on a timeout the
+//    kernel gives up and reports ROMAN_ST_INTERNAL instead of hanging the device.
+//  Mirrors oracle_solve() like solve_one; the sums are plain doubles in a fixed (different) order.
+// ---------------------------------------------------------------------------------------------
+constexpr int WIDE_NT = 512;             // threads per workgroup (one workgroup per compute unit; 8 waves: 256 registers each)
+constexpr int WIDE_NW = WIDE_NT / 64;
+constexpr int WIDE_KW = 4;               // vector elements a thread can own: L <= WIDE_KW * 64 * (waves of the grid)
+constexpr int WIDE_NRED = 4;             // doubles per workgroup slot of a grid reduction
+constexpr int WIDE_U = 16;               // stream steps in flight per wave
+
+struct WideShared {
+    double wred[2][WIDE_NW][WIDE_NRED];  // wave partials of a reduction (ping-pong)
+    double bc[2][WIDE_NRED];             // reduced values for the whole workgroup (ping-pong)
+    double red[72];                      // finish_one scratch
+    int sint[4];
+    int abort_;
+};
+
+// write-through store of a value other workgroups will read (global_store ... sc1: no release fence needed later)
+__device__ __forceinline__ void st_pub(double* p, double v)
+{
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Grid barrier.  bar[0]: arrivals (monotone over the launch), bar[1]: abort flag.  RELEASE: plain stores issued before the
+// barrier must be visible behind it as well (one agent-scope release by the arriving lane).
+template <bool RELEASE>
+__device__ __forceinline__ bool wide_sync(WideShared& sh, unsigned* bar, unsigned& epoch, int G, int ltid)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // every wave: its stores have left the compute unit
+    __syncthreads();
+    ++epoch;
+    if (ltid == 0) {
+        if (RELEASE) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned target = epoch * (unsigned)G;
+        const unsigned long long t0 = wall_clock64();
+        unsigned n = 0; bool ok = true;
+        while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if ((++n & 255u) == 0u && (wall_clock64() - t0 > 400000000ull || __hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) { ok = false; break; }
+        }
+        if (!ok) { __hip_atomic_store(bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); sh.abort_ = 1; }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // this compute unit's L1 holds nothing older than the barrier
+    }
+    __syncthreads();
+    return sh.abort_ == 0;
+}
+
+// Grid barrier carrying N sums: v[i] <- sum over every thread of the grid, identical in all of them (fixed order: lanes by
+// butterfly, waves ascending, workgroups lane-strided then butterfly).  N == 0: the barrier alone.
+template <int N>
+__device__ __forceinline__ bool wide_reduce(double (&v)[N > 0 ? N : 1], WideShared& sh, double* slots, unsigned* bar, unsigned& epoch, int G, int ltid)
+{
+    static_assert(N <= WIDE_NRED, "slot width");
+    const int lane = ltid & 63, w = ltid >> 6, par = (int)(epoch & 1u);
+    if (N > 0) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            double x = v[i];
+            for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
+            if (lane == 0) sh.wred[par][w][i] = x;
+        }
+        __syncthreads();
+        if (ltid < N) {
+            double t = 0.0;
+            for (int ww = 0; ww < WIDE_NW; ++ww) t += sh.wred[par][ww][ltid];
+            st_pub(slots + ((size_t)par * G + blockIdx.x) * WIDE_NRED + ltid, t);
+        }
+    }
+    if (!wide_sync<false>(sh, bar, epoch, G, ltid)) return false;
+    if (N > 0) {
+        if (w == 0) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                double a = 0.0;
+                for (int g = lane; g < G; g += WAVE) a += slots[((size_t)par * G + g) * WIDE_NRED + i];
+                for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off);
+                if (lane == 0) sh.bc[par][i] = a;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < N; ++i) v[i] = sh.bc[par][i];
+    }
+    return true;
+}
+
+template <typename IdxT>
+__global__ void __launch_bounds__(WIDE_NT) k_solve_wide(DevParams D, int B, const ProbDesc* __restrict__ probs,
+                                                        ProbState* __restrict__ st,
+                                                        const double* __restrict__ feats, const int32_t* __restrict__ assoc,
+                                                        const int32_t* __restrict__ lp, const double* __restrict__ ld,
+                                                        const uint32_t* __restrict__ permPool, const uint32_t* __restrict__ rowPosPool,
+                                                        const uint32_t* __restrict__ sliceBasePool,
+                                                        const IdxT* __restrict__ colsPool, const double* __restrict__ valsPool,
+                                                        double* __restrict__ vU /* final u by position */, double* __restrict__ vX /* published vector, live order */,
+                                                        double* __restrict__ vS0, double* __restrict__ vS1, double* __restrict__ vS2 /* scratch of the shared tail */,
+                                                        int32_t* __restrict__ plp /* position -> association index (written here) */,
+                                                        const double* __restrict__ u0, SolveOut O,
+                                                        double* __restrict__ part /* [(waves + slices)][64][2] */,
+                                                        double* __restrict__ slots /* [2][G][WIDE_NRED] */, unsigned* __restrict__ bar)
+{
+    __shared__ WideShared sh;
+    const roman_params_t& P = D.p;
+    const int ltid = threadIdx.x, lane = ltid & 63, w = uni_i(ltid >> 6);
+    const int G = (int)gridDim.x, NWG = G * WIDE_NW;
+    const int gw = w * G + (int)blockIdx.x;                     // wave id in the grid: consecutive ids on different compute units
+    unsigned epoch = 0;
+    if (ltid == 0) sh.abort_ = 0;
+    __syncthreads();
+    for (int b = 0; b < B; ++b) {
+        if (uni_i(st[b].kind) != 1) continue;                   // (uniform over the grid)
+        const ProbDesc pd = probs[b];
+        const int L = uni_i(st[b].L), rb = uni_i(st[b].rowBase);
+        const int64_t lo = pd.liveOff;
+        const int nsl = (L + 63) >> 6;
+        const uint32_t T = st[b].nnzCap >> 6;                   // steps of the flat stream
+        const uint32_t* perm = permPool + lo; const uint32_t* sbase = sliceBasePool + lo;
+        const IdxT* cols = colsPool + st[b].nnzOff; const double* vals = valsPool + st[b].nnzOff;
+        double* xv = vX + rb;
+        const int kw = min(WIDE_KW, (nsl + NWG - 1) / NWG);     // element rounds in use (the host guarantees L <= WIDE_KW * NWG * 64)
+#define CUMW(s_) ((s_) < nsl ? (sbase[(s_)] >> 6) : T)
+#define WIDE_QS(g_) ((uint32_t)(((unsigned long long)T * (unsigned)(g_)) / (unsigned)NWG))
+#define FORK(k_) _Pragma("unroll") for (int k_ = 0; k_ < WIDE_KW; ++k_) if (k_ < kw)
+        const uint32_t qs = WIDE_QS(gw), qe = WIDE_QS(gw + 1);
+        int s0 = 0; uint32_t sEnd0 = 0;
+        if (qs < qe) {                                          // the slice that holds step qs (largest s with cumW[s] <= qs)
+            int lo_ = 0, hi_ = nsl;
+            while (hi_ - lo_ > 1) { const int mid_ = (lo_ + hi_) >> 1; if (CUMW(mid_) <= qs) lo_ = mid_; else hi_ = mid_; }
+            s0 = lo_; sEnd0 = CUMW(s0 + 1);
+        }
+
+        int status = ROMAN_ST_OK;
+        roman_stats_t S;
+        S.n_assoc_in = pd.nA; S.n_live = L; S.nnz_upper = (int64_t)st[b].nnzUpper;
+        S.n_pass = 0; S.outer_iters = 0; S.inner_iters = 0; S.ls_trials = 0; S.score = 0.0; S.d_final = 0.0;
+        if (pd.n1 == 0 || pd.n2 == 0) status |= ROMAN_ST_EMPTY_MAP;
+        double F = 0.0, d = 0.0, usum = 0.0;
+        int n_pass = 0, ls_trials = 0, inner_iters = 0, i = 0;
+
+        // owned elements
+        double u[WIDE_KW], Mu[WIDE_KW], Cu[WIDE_KW], sd[WIDE_KW], tt[WIDE_KW], Mn[WIDE_KW], Cn[WIDE_KW];
+        int kk[WIDE_KW]; bool in[WIDE_KW];
+#pragma unroll
+        for (int k = 0; k < WIDE_KW; ++k) {
+            const int pos = ((gw + k * NWG) << 6) + lane;
+            in[k] = k < kw && pos < L;
+            kk[k] = in[k] ? (int)perm[pos] : 0;
+            sd[k] = in[k] ? ld[lo + kk[k]] : 0.0;
+            const int a_ = in[k] ? lp[lo + kk[k]] : 0;
+            if (in[k]) plp[lo + pos] = a_;
+            u[k] = in[k] ? (u0 ? u0[lo + a_] : 1.0) : 0.0;
+            Mu[k] = Cu[k] = tt[k] = Mn[k] = Cn[k] = 0.0;
+        }
+        double dummy1[1] = {0.0};
+        bool alive = true;
+
+        // x (one value per owned element) -> the live-ordered vector other compute units gather from
+        auto publish = [&](const double (&x)[WIDE_KW]) { FORK(k) if (in[k]) st_pub(xv + kk[k], x[k]); };
+        // flat stream over this wave's steps: partial row sums of every slice piece -> partials buffer
+        auto stream = [&]() {
+            uint32_t t = qs; int s = s0; uint32_t sEnd = sEnd0;
+            while (t < qe) {
+                const uint32_t stop = min(sEnd, qe);
+                const bool valid = ((s << 6) + lane) < L;
+                double am = 0.0, ac = 0.0;
+                const IdxT* cp = cols + (size_t)t * 64 + lane; const double* vp = vals + (size_t)t * 64 + lane;
+                uint32_t n = stop - t;
+                for (; n >= (uint32_t)WIDE_U; n -= WIDE_U, cp += WIDE_U * 64, vp += WIDE_U * 64) {
+                    uint32_t c_[WIDE_U]; double v_[WIDE_U];
+#pragma unroll
+                    for (int e = 0; e < WIDE_U; ++e) { c_[e] = valid ? (uint32_t)cp[e * 64] : IdxTraits<IdxT>::CZ; v_[e] = valid ? vp[e * 64] : 0.0; }
+#pragma unroll
+                    for (int e = 0; e < WIDE_U; ++e) {
+                        const double uq = xv[c_[e] & IdxTraits<IdxT>::MASK];
+                        am = fma(v_[e], uq, am);
+                        ac += (c_[e] & IdxTraits<IdxT>::CZ) ? 0.0 : uq;
+                    }
+                }
+                {   // fewer than WIDE_U steps left in this piece: predicated, still all loads in flight together
+                    uint32_t c_[WIDE_U]; double v_[WIDE_U];
+#pragma unroll
+                    for (int e = 0; e < WIDE_U; ++e) {
+                        const bool a_ = valid && (uint32_t)e < n;
+                        c_[e] = a_ ? (uint32_t)cp[e * 64] : IdxTraits<IdxT>::CZ; v_[e] = a_ ? vp[e * 64] : 0.0;
+                    }
+#pragma unroll
+                    for (int e = 0; e < WIDE_U; ++e) {
+                        const double uq = xv[c_[e] & IdxTraits<IdxT>::MASK];
+                        am = fma(v_[e], uq, am);
+                        ac += (c_[e] & IdxTraits<IdxT>::CZ) ? 0.0 : uq;
+                    }
+                }
+                double* pp = part + ((size_t)(gw + s) * 64 + lane) * 2;
+                st_pub(pp, am); st_pub(pp + 1, ac);
+                t = stop;
+                if (t < qe) { do { ++s; sEnd = CUMW(s + 1); } while (sEnd <= t); }
+            }
+            ++n_pass;
+        };
+        // (M x, C x) of the owned rows: the pieces of their slice in ascending order
+        auto collect = [&](double (&om)[WIDE_KW], double (&oc)[WIDE_KW]) {
+            FORK(k) {
+                const int s = gw + k * NWG;
+                double m_ = 0.0, c_ = 0.0;
+                if (s < nsl) {
+                    const uint32_t a_ = CUMW(s), e_ = CUMW(s + 1);
+                    if (e_ > a_) {
+                        const int gf = (int)((((unsigned long long)a_ + 1ull) * (unsigned)NWG - 1ull) / T);
+                        const int gl = (int)(((unsigned long long)e_ * (unsigned)NWG - 1ull) / T);
+                        for (int g = gf; g <= gl; ++g) {
+                            if (WIDE_QS(g) < WIDE_QS(g + 1)) {      // (a wave with an empty range wrote nothing)
+                                const double* pp = part + ((size_t)(g + s) * 64 + lane) * 2;
+                                m_ += pp[0]; c_ += pp[1];
+                            }
+                        }
+                    }
+                }
+                om[k] = in[k] ? m_ : 0.0; oc[k] = in[k] ? c_ : 0.0;
+            }
+        };
+        // mean of (M u)_p / Cbu_p over the active set, and the two sums F = A + d B is made of — one grid reduction
+        auto d_ratio = [&](bool absval, double (&r4)[4]) -> bool {
+            r4[0] = r4[1] = r4[2] = r4[3] = 0.0;
+            FORK(k) if (in[k]) {
+                const double up = u[k], Cbu = (usum - Cu[k]) - up, mdu = Mu[k] + sd[k] * up;
+                if (Cbu > P.eps && up > P.eps) { const double r_ = mdu / Cbu; r4[0] += absval ? fabs(r_) : r_; r4[1] += 1.0; }
+                r4[2] += up * mdu; r4[3] += up * ((up - usum) + Cu[k]);
+            }
+            return wide_reduce<4>(r4, sh, slots, bar, epoch, G, ltid);
+        };
+
+        if (L > 0) do {
+            // ---- initialisation: u = normalize(M u0 + diag u0) -----------------------------------------------
+            if (P.rescale_u0) {
+                publish(u);
+                if (!(alive = wide_reduce<0>(dummy1, sh, slots, bar, epoch, G, ltid))) break;
+                stream();
+                if (!(alive = wide_reduce<0>(dummy1, sh, slots, bar, epoch, G, ltid))) break;
+                collect(Mn, Cn);
+                FORK(k) u[k] = in[k] ? Mn[k] + sd[k] * u[k] : 0.0;
+            }
+            {
+                double r1[1] = {0.0};
+                FORK(k) r1[0] += u[k] * u[k];
+                if (!(alive = wide_reduce<1>(r1, sh, slots, bar, epoch, G, ltid))) break;
+                const double nr = sqrt(r1[0]);
+                if (nr > 0.0) FORK(k) u[k] /= nr;
+            }
+            publish(u);
+            if (!(alive = wide_reduce<0>(dummy1, sh, slots, bar, epoch, G, ltid))) break;
+            stream();
+            {
+                double r1[1] = {0.0};
+                FORK(k) r1[0] += u[k];
+                if (!(alive = wide_reduce<1>(r1, sh, slots, bar, epoch, G, ltid))) break;
+                usum = r1[0];
+            }
+            collect(Mu, Cu);
+            double r4[4];
+            if (!(alive = d_ratio(false, r4))) break;
+            d = (r4[1] > 0.0) ? r4[0] / r4[1] : 0.0;
+            // ---- projected gradient ascent with homotopy on d ---------------------------------------------------
+            for (i = 0; i < P.maxoliters; ++i) {
+                F = r4[2] + d * r4[3];                              // u . gradF at the current d
+                for (int j = 0; j < P.maxiniters; ++j) {
+                    double alpha = 1.0, Fnew = 0.0, deltaF = 0.0, unsum = 0.0, du2 = 0.0;
+                    for (int k2 = 0; k2 < P.maxlsiters; ++k2) {
+                        double r2[2] = {0.0, 0.0};
+                        FORK(k) {
+                            const double up = u[k];
+                            const double g = (((sd[k] + d) * up - d * usum) + Mu[k]) + Cu[k] * d;
+                            double t = up + alpha * g;
+                            t = (in[k] && t > 0.0) ? t : 0.0;
+                            tt[k] = t; r2[0] += t * t; r2[1] += t;
+                        }
+                        publish(tt);
+                        if (!(alive = wide_reduce<2>(r2, sh, slots, bar, epoch, G, ltid))) break;
+                        const double nr = sqrt(r2[0]);
+                        stream(); ++ls_trials;
+                        if (!(alive = wide_reduce<0>(dummy1, sh, slots, bar, epoch, G, ltid))) break;
+                        collect(Mn, Cn);
+                        unsum = (nr > 0.0) ? r2[1] / nr : r2[1];
+                        double q2[2] = {0.0, 0.0};
+                        FORK(k) {
+                            if (nr > 0.0) { tt[k] /= nr; Mn[k] /= nr; Cn[k] /= nr; }
+                            const double up = tt[k];
+                            const double g = (((sd[k] + d) * up - d * unsum) + Mn[k]) + Cn[k] * d;
+                            q2[0] += up * g;
+                            const double df = up - u[k]; q2[1] += df * df;
+                        }
+                        if (!(alive = wide_reduce<2>(q2, sh, slots, bar, epoch, G, ltid))) break;
+                        Fnew = q2[0]; du2 = q2[1];
+                        deltaF = Fnew - F;
+                        if (deltaF < -P.eps) alpha *= P.beta; else break;
+                    }
+                    if (!alive) break;
+                    const double du = sqrt(du2);
+                    F = Fnew; usum = unsum;
+                    FORK(k) { u[k] = tt[k]; Mu[k] = Mn[k]; Cu[k] = Cn[k]; }
+                    ++inner_iters;
+                    if (du < P.tol_u || fabs(deltaF) < P.tol_F) break;
+                }
+                if (!alive) break;
+                if (!(alive = d_ratio(true, r4))) break;
+                if (r4[1] > 0.0) d += r4[0] / r4[1]; else break;
+            }
+        } while (false);
+        if (!alive) {                                            // a grid barrier timed out: give up, say so
+            if (blockIdx.x == 0 && ltid == 0) {
+                for (int t = 0; t < 16; ++t) O.T_out[(int64_t)b * 16 + t] = d_nan();
+                O.n_assoc_out[b] = 0; O.status_out[b] = ROMAN_ST_INTERNAL; O.nSel[b] = 0;
+            }
+            return;
+        }
+        if (i >= P.maxoliters) status |= ROMAN_ST_MAXITER;
+        S.n_pass = n_pass; S.ls_trials = ls_trials; S.inner_iters = inner_iters;
+        S.outer_iters = i; S.score = F; S.d_final = d;
+        // final u by position for the shared tail (plain stores + one release); workgroup 0 selects and writes the pose
+        FORK(k) if (in[k]) vU[rb + ((gw + k * NWG) << 6) + lane] = u[k];
+        if (!wide_sync<true>(sh, bar, epoch, G, ltid)) return;
+        if (blockIdx.x == 0)
+            finish_one(D, b, pd, feats, assoc, plp, lp, rowPosPool, permPool, O, L > 0 ? vU + rb : nullptr, vS0 + rb,
+                       reinterpret_cast<int32_t*>(vS1 + rb), reinterpret_cast<int32_t*>(vS2 + rb), L, rb, lo, F, status, S, sh.red, sh.sint);
+#undef CUMW
+#undef WIDE_QS
+#undef FORK
     }
 }
 

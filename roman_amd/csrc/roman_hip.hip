@@ -72,7 +72,7 @@ struct roman_ctx {
         DevBuf lp, li, lj, ls, ld, lza, lzb;                       // per live association, live order
         DevBuf plp, pli, plj, pls, pld, plza, plzb;                // the same in position order (stream layout)
         DevBuf rowCnt, rowPos, perm, sliceWidth, sliceBase, items, maskPool, prefPool, listPool, listOff;
-        DevBuf vMu, vCu, vMun, vCun, gU, gUn, uOut, nodesOrig, nSel, coopPart;
+        DevBuf vMu, vCu, vMun, vCun, gU, gUn, uOut, nodesOrig, nSel, widePart, wideSlots, wideBar;
         DevBuf cols16, cols32, vals;
         long long capMaskWords = 0, capNnz = 0, capList = 0;       // what the sparse pools hold (elements)
         // staging for the host-pointer entry points
@@ -557,7 +557,7 @@ int enqueue_score(roman_ctx* c, const DevParams& Din, const roman_params_t* para
 
 // Solver + rounding + pose on the matrices held by the workspace.  `feats` may be NULL (dense
 // matrix problems have no points: the pose is skipped).  mayFallback: a problem of the fallback kind can exist.
-int enqueue_solve(roman_ctx* c, const DevParams& D, int B, int64_t sumA, const double* feats, const int32_t* assoc,
+int enqueue_solve(roman_ctx* c, const DevParams& D, int B, int64_t sumA, int64_t maxA /* longest association list */, const double* feats, const int32_t* assoc,
                   const double* u0, bool hascz, int mayFallback /* problems that can be of the fallback kind */, const BatchOut& out)
 {
     const size_t R1 = (size_t)std::max<int64_t>(sumA, 1);
@@ -598,37 +598,44 @@ int enqueue_solve(roman_ctx* c, const DevParams& D, int B, int64_t sumA, const d
         HIPCHK(c, WS.vMu.ensure(sizeof(double) * R1)); HIPCHK(c, WS.vCu.ensure(sizeof(double) * R1));
         HIPCHK(c, WS.vMun.ensure(sizeof(double) * R1)); HIPCHK(c, WS.vCun.ensure(sizeof(double) * R1));
         HIPCHK(c, WS.gU.ensure(sizeof(double) * R1)); HIPCHK(c, WS.gUn.ensure(sizeof(double) * R1));
-        // Few (large) problems: all compute units solve them together, one after the other (cooperative launch); many:
-        // one workgroup per problem, u and u' in LDS when they fit.
-        static const char* coopEnv = getenv("ROMAN_COOP");      // "0": never, "1": whenever a fallback problem can exist
-        bool coop = c->coop_ok && (coopEnv ? coopEnv[0] == '1' : mayFallback <= std::max(1, c->num_cu / 16));
+        // Few (large) problems: all compute units solve them together, one after the other (k_solve_wide, cooperative
+        // launch so that every workgroup is resident); many: one workgroup per problem, u and u' in LDS when they fit.
+        static const char* wideEnv = getenv("ROMAN_WIDE");      // "0": never, "1": whenever a fallback problem can exist
+        bool coop = c->coop_ok && D.p.maxiniters >= 1 && D.p.maxlsiters >= 1 && maxA <= (int64_t)WIDE_KW * c->num_cu * WIDE_NW * 64 &&
+                    (wideEnv ? wideEnv[0] == '1' : mayFallback <= std::max(1, c->num_cu / 16));
         if (coop) {
-            const int G = c->num_cu;
-            HIPCHK(c, WS.coopPart.ensure(sizeof(double) * 4 * (size_t)G));
+            const int G = c->num_cu, NWG = G * WIDE_NW;
+            const size_t partDoubles = ((size_t)NWG + (size_t)(maxA + 63) / 64 + 2) * 64 * 2;
+            HIPCHK(c, WS.widePart.ensure(sizeof(double) * partDoubles));
+            HIPCHK(c, WS.wideSlots.ensure(sizeof(double) * 2 * (size_t)G * WIDE_NRED));
+            HIPCHK(c, WS.wideBar.ensure(sizeof(unsigned) * 4));
+            HIPCHK(c, hipMemsetAsync(WS.wideBar.p, 0, sizeof(unsigned) * 4, WS.stream));      // arrivals and the abort flag start at 0 in every launch
             DevParams Dv = D; int Bv = B;
             const ProbDesc* a_probs = WS.probs.as<ProbDesc>(); ProbState* a_state = WS.state.as<ProbState>();
             const double* a_feats = feats; const int32_t* a_assoc = assoc;
             const int32_t* a_lp = WS.lp.as<int32_t>(); const double* a_ld = WS.ld.as<double>();
-            const uint32_t* a_perm = WS.perm.as<uint32_t>(); const uint32_t* a_sw = WS.sliceWidth.as<uint32_t>(); const uint32_t* a_sb = WS.sliceBase.as<uint32_t>();
+            const uint32_t* a_perm = WS.perm.as<uint32_t>(); const uint32_t* a_rpos = WS.rowPos.as<uint32_t>(); const uint32_t* a_sb = WS.sliceBase.as<uint32_t>();
             const uint32_t* a_cols = WS.cols32.as<uint32_t>(); const double* a_vals = WS.vals.as<double>();
-            double* a_vMu = WS.vMu.as<double>(); double* a_vCu = WS.vCu.as<double>(); double* a_vMun = WS.vMun.as<double>(); double* a_vCun = WS.vCun.as<double>();
-            double* a_gU = WS.gU.as<double>(); double* a_gUn = WS.gUn.as<double>();
-            const double* a_u0 = u0; SolveOut a_O = O; double* a_part = WS.coopPart.as<double>();
-            void* args[] = {&Dv, &Bv, &a_probs, &a_state, &a_feats, &a_assoc, &a_lp, &a_ld, &a_perm, &a_sw, &a_sb, &a_cols, &a_vals,
-                            &a_vMu, &a_vCu, &a_vMun, &a_vCun, &a_gU, &a_gUn, &a_u0, &a_O, &a_part};
-            // Two cooperative kernels must never be resident together (each would hold compute units while waiting at a
+            double* a_vU = WS.gU.as<double>(); double* a_vX = WS.gUn.as<double>();
+            double* a_s0 = WS.vMu.as<double>(); double* a_s1 = WS.vCu.as<double>(); double* a_s2 = WS.vMun.as<double>();
+            int32_t* a_plp = WS.plp.as<int32_t>();
+            const double* a_u0 = u0; SolveOut a_O = O;
+            double* a_part = WS.widePart.as<double>(); double* a_slots = WS.wideSlots.as<double>(); unsigned* a_bar = WS.wideBar.as<unsigned>();
+            void* args[] = {&Dv, &Bv, &a_probs, &a_state, &a_feats, &a_assoc, &a_lp, &a_ld, &a_perm, &a_rpos, &a_sb, &a_cols, &a_vals,
+                            &a_vU, &a_vX, &a_s0, &a_s1, &a_s2, &a_plp, &a_u0, &a_O, &a_part, &a_slots, &a_bar};
+            // Two whole-device kernels must never be resident together (each would hold compute units while waiting at a
             // grid barrier for workgroups the other one keeps out): with batches in flight on several streams, a
-            // cooperative launch waits for the previous one of this context.
+            // launch waits for the previous one of this context.
             if (!c->coopDone) HIPCHK(c, hipEventCreateWithFlags(&c->coopDone, hipEventDisableTiming));
             if (c->coopIssued) HIPCHK(c, hipStreamWaitEvent(WS.stream, c->coopDone, 0));
-            const hipError_t e = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(k_solve_coop<uint32_t>), dim3((unsigned)G), dim3(1024), args, 0, WS.stream);
+            const hipError_t e = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(k_solve_wide<uint32_t>), dim3((unsigned)G), dim3(WIDE_NT), args, 0, WS.stream);
             if (e == hipSuccess) { HIPCHK(c, hipEventRecord(c->coopDone, WS.stream)); c->coopIssued = true; }
             if (e != hipSuccess) {                              // not available here: the one-workgroup solver does the same work
                 (void)hipGetLastError();
                 fprintf(stderr, "[roman_hip] cooperative launch failed (%s); large problems use the single-workgroup solver\n", hipGetErrorString(e));
                 c->coop_ok = false; coop = false;
             }
-    DBG(c, "k_solve_coop");
+    DBG(c, "k_solve_wide");
         }
         if (!coop) {
         const size_t fixed = 72 * sizeof(double) + 4 * sizeof(int);
@@ -701,8 +708,8 @@ int run_batch(roman_ctx* c, const DevParams& D0, const roman_params_t* params, c
     DevParams D;
     int rc = enqueue_score(c, D0, params, in, hd, &D);
     if (rc) return rc;
-    int64_t sumA = 0; for (const ProbDesc& d : hd) sumA += d.nA;
-    return enqueue_solve(c, D, in.B, sumA, in.feats, in.assoc, u0, false, may_fallback(D, hd), out);
+    int64_t sumA = 0, maxA = 0; for (const ProbDesc& d : hd) { sumA += d.nA; maxA = std::max<int64_t>(maxA, d.nA); }
+    return enqueue_solve(c, D, in.B, sumA, maxA, in.feats, in.assoc, u0, false, may_fallback(D, hd), out);
 }
 
 // After a synchronous run: did every problem fit its workspace?  (reads the totals the batch copied back; the stream
@@ -735,7 +742,7 @@ int solve_last(roman_ctx* c, const double* u0_host)
     const double* feats = Lst.dense ? nullptr : WS.hFeats.as<double>();
     const int32_t* assoc = (Lst.pd.assocOff >= 0) ? WS.hAssoc.as<int32_t>() : nullptr;
     const BatchOut out{kmax, WS.oAssoc.as<int32_t>(), WS.oN.as<int32_t>(), WS.oT.as<double>(), WS.oStatus.as<int32_t>(), WS.oStats.as<roman_stats_t>()};
-    int rc = enqueue_solve(c, Lst.D, 1, nA, feats, assoc, dU0, Lst.hascz, Lst.kind == 1 ? 1 : 0, out);
+    int rc = enqueue_solve(c, Lst.D, 1, nA, nA, feats, assoc, dU0, Lst.hascz, Lst.kind == 1 ? 1 : 0, out);
     if (rc) return rc;
     int32_t nsel = 0;
     HIPCHK(c, hipMemcpyAsync(&nsel, WS.nSel.p, sizeof(int32_t), hipMemcpyDeviceToHost, WS.stream));
@@ -919,7 +926,7 @@ int roman_ctx_destroy(roman_ctx_t* c)
         DevBuf* all[] = {&W.probs, &W.state, &W.totals, &W.queue, &W.cosPool, &W.tabPool, &W.sTmp, &W.chunkCnt,
                          &W.lp, &W.li, &W.lj, &W.ls, &W.ld, &W.lza, &W.lzb, &W.plp, &W.pli, &W.plj, &W.pls, &W.pld, &W.plza, &W.plzb,
                          &W.rowCnt, &W.rowPos, &W.perm, &W.sliceWidth, &W.sliceBase, &W.items, &W.maskPool, &W.prefPool, &W.listPool, &W.listOff,
-                         &W.vMu, &W.vCu, &W.vMun, &W.vCun, &W.gU, &W.gUn, &W.uOut, &W.nodesOrig, &W.nSel, &W.coopPart, &W.cols16, &W.cols32, &W.vals,
+                         &W.vMu, &W.vCu, &W.vMun, &W.vCun, &W.gU, &W.gUn, &W.uOut, &W.nodesOrig, &W.nSel, &W.widePart, &W.wideSlots, &W.wideBar, &W.cols16, &W.cols32, &W.vals,
                          &W.hFeats, &W.hAssoc, &W.hU0, &W.oAssoc, &W.oN, &W.oT, &W.oStatus, &W.oStats, &W.hAux1, &W.hAux2, &W.hAux3};
         for (DevBuf* b : all) b->release();
         if (W.pinnedTotals) (void)hipHostFree(W.pinnedTotals);
