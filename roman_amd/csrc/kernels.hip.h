@@ -29,6 +29,7 @@
 #include <hip/hip_cooperative_groups.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "../../include/roman_hip.h"
 
 namespace roman {
@@ -248,6 +249,7 @@ __device__ __forceinline__ double fuse_pair(const DevParams& D, double sa, doubl
 // 16 MFMAs per 4 wide loads (the previous 16x16 tile issued 1 MFMA per 2 scalar loads).
 // ---------------------------------------------------------------------------------------------
 typedef double double4_t __attribute__((ext_vector_type(4)));
+typedef double dbl2_t __attribute__((ext_vector_type(2)));
 struct __attribute__((packed, aligned(8))) d4u_t { double v[4]; };     // 8-byte aligned 32-byte load
 
 constexpr int COS_TILE = 32;
@@ -1000,6 +1002,7 @@ __global__ void __launch_bounds__(1024) k_rowsort(const ProbDesc* __restrict__ p
         if (s < nsl) {
             const int hi = min(L, (s << 6) + 64);
             for (int p = s << 6; p < hi; ++p) width = max(width, rowCnt[lo + perm[lo + p]]);
+            width = (width + 3u) & ~3u;                         // quad layout: 4 entries per lane and step
             sliceWidth[lo + s] = width;
         }
         const uint32_t v = width * 64u;
@@ -1176,7 +1179,7 @@ template <bool GRAV, typename IdxT, bool LDSCOL, bool QUAD>
 __device__ __forceinline__ uint32_t fill_item(const DevParams& D, const ProbDesc& pd, int L, int row0, int nrows,
                                               int w, int wpb, int lane,
                                               const int32_t* cI, const int32_t* cJ, const double* cS,
-                                              const double* cZa, const double* cZb, const uint32_t* cBase,
+                                              const double* cZa, const double* cZb, const uint32_t* cBase, const uint32_t* cPos,
                                               const double* __restrict__ TA, const double* __restrict__ TB,
                                               const unsigned long long* __restrict__ mbase, const uint32_t* __restrict__ pbase,
                                               const uint32_t* __restrict__ rowPos, const uint32_t* __restrict__ sliceBase,
@@ -1215,10 +1218,11 @@ __device__ __forceinline__ uint32_t fill_item(const DevParams& D, const ProbDesc
             const double v = fuse_pair(D, sa, cS[k], cS[q]);
             const bool keep = v > D.p.affinityeps;
             // an entry at or below affinityeps belongs neither to M nor to C: inert slot
-            uint32_t base;                                      // slice base + lane slot (base is a multiple of 64)
-            if (LDSCOL) base = cBase[k];
-            else { const uint32_t pos = rowPos[k]; base = sliceBase[pos >> 6] + (pos & 63u); }
-            cols[col_pos<QUAD>(base & ~63u, base & 63u, e)] = keep ? (IdxT)q : (IdxT)((QUAD ? (uint32_t)L : (uint32_t)k) | IdxTraits<IdxT>::CZ);
+            // column labels are POSITIONS (sorted row order): the solvers keep their vectors in that order
+            uint32_t base, pk, pq;                              // slice base + lane slot (base is a multiple of 64); positions of row and column
+            if (LDSCOL) { base = cBase[k]; pk = cPos[k]; pq = cPos[q]; }
+            else { pk = rowPos[k]; pq = rowPos[q]; base = sliceBase[pk >> 6] + (pk & 63u); }
+            cols[col_pos<QUAD>(base & ~63u, base & 63u, e)] = keep ? (IdxT)pq : (IdxT)(pk | IdxTraits<IdxT>::CZ);
             vals[val_pos<QUAD>(base & ~63u, base & 63u, e)] = keep ? v : 0.0;
             upper += (keep && q > k) ? 1u : 0u;
         }
@@ -1277,7 +1281,7 @@ __global__ void __launch_bounds__(1024) k_fill(DevParams D, const ProbDesc* __re
                                                const uint32_t* __restrict__ sliceBase,
                                                IdxT* __restrict__ cols, double* __restrict__ vals, int TC, int RPB)
 {
-    // LDS: cS[TC] [GRAV: cZa[TC] cZb[TC]] cI[TC] cJ[TC] cBase[TC] | per-wave rings qK qQ qE
+    // LDS: cS[TC] [GRAV: cZa[TC] cZb[TC]] cI[TC] cJ[TC] cBase[TC] cPos[TC] | per-wave rings qK qQ qE
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* cS = reinterpret_cast<double*>(smem);
     double* cZa = cS + TC;
@@ -1285,7 +1289,8 @@ __global__ void __launch_bounds__(1024) k_fill(DevParams D, const ProbDesc* __re
     int32_t* cI = reinterpret_cast<int32_t*>(cZb + (GRAV ? TC : 0));
     int32_t* cJ = cI + TC;
     uint32_t* cBase = reinterpret_cast<uint32_t*>(cJ + TC);
-    uint32_t* rings = cBase + TC;
+    uint32_t* cPos = cBase + TC;
+    uint32_t* rings = cPos + TC;
     const int tid = threadIdx.x, nt = blockDim.x;
     const int lane = tid & 63, w = tid >> 6, wpb = nt >> 6;
     uint32_t* qK = rings + (size_t)w * 3 * FILL_Q;
@@ -1309,26 +1314,26 @@ __global__ void __launch_bounds__(1024) k_fill(DevParams D, const ProbDesc* __re
                 cI[q] = li[lo + q]; cJ[q] = lj[lo + q]; cS[q] = ls[lo + q];
                 if (GRAV) { cZa[q] = lza[lo + q]; cZb[q] = lzb[lo + q]; }
                 const uint32_t pos = rowPos[lo + q];
-                cBase[q] = sliceBase[lo + (pos >> 6)] + (pos & 63u);
+                cBase[q] = sliceBase[lo + (pos >> 6)] + (pos & 63u); cPos[q] = pos;
             }
         }
         __syncthreads();
         uint32_t upper;
         if (ldscol)
-            upper = fill_item<GRAV, IdxT, true, QUAD>(D, pd, L, it.row0, nrows, w, wpb, lane, cI, cJ, cS, cZa, cZb, cBase, TA, TB,
+            upper = fill_item<GRAV, IdxT, true, QUAD>(D, pd, L, it.row0, nrows, w, wpb, lane, cI, cJ, cS, cZa, cZb, cBase, cPos, TA, TB,
                                                 maskPool + mo, prefPool + mo, rowPos + lo, sliceBase + lo, qK, qQ, qE, cols + no, vals + no);
         else
-            upper = fill_item<GRAV, IdxT, false, QUAD>(D, pd, L, it.row0, nrows, w, wpb, lane, li + lo, lj + lo, ls + lo, lza + lo, lzb + lo, nullptr, TA, TB,
+            upper = fill_item<GRAV, IdxT, false, QUAD>(D, pd, L, it.row0, nrows, w, wpb, lane, li + lo, lj + lo, ls + lo, lza + lo, lzb + lo, nullptr, nullptr, TA, TB,
                                                  maskPool + mo, prefPool + mo, rowPos + lo, sliceBase + lo, qK, qQ, qE, cols + no, vals + no);
         // pad every row's slot column up to its slice width with inert entries (value 0, C-flag; the
-        // column is the row itself, or in the quad layout the dummy vector element L, which is always 0)
+        // column is the row's own position: a real, finite vector element whatever the solver gathers from)
         for (int r = w; r < nrows; r += wpb) {
             const int k = it.row0 + r;
             const uint32_t pos = rowPos[lo + k];
             const uint32_t width = sliceWidth[lo + (pos >> 6)];
             const int64_t sb = no + sliceBase[lo + (pos >> 6)];
             for (uint32_t e = rowCnt[lo + k] + lane; e < width; e += WAVE) {
-                cols[col_pos<QUAD>(sb, pos & 63u, e)] = (IdxT)((QUAD ? (uint32_t)L : (uint32_t)k) | IdxTraits<IdxT>::CZ);
+                cols[col_pos<QUAD>(sb, pos & 63u, e)] = (IdxT)(pos | IdxTraits<IdxT>::CZ);
                 vals[val_pos<QUAD>(sb, pos & 63u, e)] = 0.0;
             }
         }
@@ -1339,7 +1344,7 @@ __global__ void __launch_bounds__(1024) k_fill(DevParams D, const ProbDesc* __re
             const uint32_t nfree = 64u - (uint32_t)(L & 63);
             for (uint32_t x = tid; x < nfree * width; x += nt) {
                 const uint32_t slot = (uint32_t)(L & 63) + x / width, e = x % width;
-                cols[col_pos<QUAD>(sb, slot, e)] = (IdxT)((uint32_t)L | IdxTraits<IdxT>::CZ);
+                cols[col_pos<QUAD>(sb, slot, e)] = (IdxT)(IdxTraits<IdxT>::CZ);          // (column 0, flagged: gathers a real element, adds nothing)
                 vals[val_pos<QUAD>(sb, slot, e)] = 0.0;
             }
         }
@@ -1523,52 +1528,49 @@ __device__ __forceinline__ void block_sum2(double& a, double& b, double* red, in
     a = ra; b = rb;
 }
 
-// (M_off u)_r and (C_off u)_r for every row from the sorted SELL-64 layout: a wave owns a slice (lane
-// = row slot) and walks the entry index e with stride 64.  The walk is software-pipelined in groups
-// of G steps: while group g is consumed (LDS gathers of u + FMAs) the 2G global loads of group g+1
-// are already in flight.  Padding entries are inert (value 0, C-flag), so there are no predicates.
+// (M_off u)_p and (C_off u)_p for every position p from the fallback layout (symmetric sorted SELL-64 in quads: the 4 column
+// words of entries 4g..4g+3 of a lane are one 16-byte load, the values two 16-byte loads): a wave owns a slice (lane = row
+// slot) and walks the quads, G quads in flight.  Padding entries — and the lane slots of the last slice that hold no
+// row — are inert (value 0, C-flag, a valid column), so there are no predicates.
+typedef unsigned int uint4_t __attribute__((ext_vector_type(4)));
 template <typename IdxT, int G>
 __device__ __forceinline__ void spmv_sell(const double* u, int L, const uint32_t* __restrict__ perm,
                                           const uint32_t* __restrict__ sliceWidth, const uint32_t* __restrict__ sliceBase,
                                           const IdxT* __restrict__ cols, const double* __restrict__ vals,
                                           double* Mu, double* Cu, int tid, int nt)
 {
+    static_assert(sizeof(IdxT) == 4, "fallback layout: 32-bit column words");
     const int lane = tid & 63, w = tid >> 6, nw = nt >> 6;
     const int nsl = (L + 63) >> 6;
     for (int s = w; s < nsl; s += nw) {
         const int pos = (s << 6) + lane;
         const bool valid = pos < L;
-        const uint32_t row = valid ? perm[pos] : 0u;
-        const uint32_t width = sliceWidth[s];
-        const IdxT* cp = cols + sliceBase[s] + lane;
-        const double* vp = vals + sliceBase[s] + lane;
-        const uint32_t ngroups = (width + G - 1) / G;
+        const uint32_t nq = sliceWidth[s] >> 2;
+        const uint4_t* cp = reinterpret_cast<const uint4_t*>(cols + sliceBase[s]) + lane;
+        const dbl2_t* vp = reinterpret_cast<const dbl2_t*>(vals + sliceBase[s]) + lane;
         double am = 0.0, ac = 0.0;
-        uint32_t cA[G], cB[G]; double vA[G], vB[G];
-#define SELL_ISSUE(e0, C_, V_)                                                         \
-        _Pragma("unroll") for (int t = 0; t < G; ++t) {                                \
-            const bool a_ = valid && ((e0) + t < width);                               \
-            C_[t] = a_ ? (uint32_t)cp[((e0) + t) * 64u] : IdxTraits<IdxT>::CZ;         \
-            V_[t] = a_ ? vp[((e0) + t) * 64u] : 0.0;                                   \
-        }
-#define SELL_CONSUME(C_, V_)                                                           \
-        _Pragma("unroll") for (int t = 0; t < G; ++t) {                                \
-            const double uq_ = u[C_[t] & IdxTraits<IdxT>::MASK];                       \
-            am = fma(V_[t], uq_, am);                                                  \
-            ac += (C_[t] & IdxTraits<IdxT>::CZ) ? 0.0 : uq_;                           \
-        }
-        if (ngroups > 0) { SELL_ISSUE(0u, cA, vA) }
-        for (uint32_t g = 0; g < ngroups; g += 2) {
-            if (g + 1 < ngroups) { SELL_ISSUE((g + 1) * G, cB, vB) }
-            SELL_CONSUME(cA, vA)
-            if (g + 1 < ngroups) {
-                if (g + 2 < ngroups) { SELL_ISSUE((g + 2) * G, cA, vA) }
-                SELL_CONSUME(cB, vB)
+        for (uint32_t g0 = 0; g0 < nq; g0 += G) {
+            uint4_t c_[G]; dbl2_t v0_[G], v1_[G];
+#pragma unroll
+            for (int t = 0; t < G; ++t) {
+                const uint32_t g = min(g0 + (uint32_t)t, nq - 1u);      // (clamped: a repeated quad is skipped below)
+                c_[t] = cp[(size_t)g * 64]; v0_[t] = vp[(size_t)(2 * g) * 64]; v1_[t] = vp[(size_t)(2 * g + 1) * 64];
+            }
+#pragma unroll
+            for (int t = 0; t < G; ++t) {
+                if (g0 + (uint32_t)t < nq) {
+                    const uint32_t c4[4] = {c_[t].x, c_[t].y, c_[t].z, c_[t].w};
+                    const double v4[4] = {v0_[t].x, v0_[t].y, v1_[t].x, v1_[t].y};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const double uq = u[c4[e] & IdxTraits<IdxT>::MASK];
+                        am = fma(v4[e], uq, am);
+                        ac += (c4[e] & IdxTraits<IdxT>::CZ) ? 0.0 : uq;
+                    }
+                }
             }
         }
-#undef SELL_ISSUE
-#undef SELL_CONSUME
-        if (valid) { Mu[row] = am; Cu[row] = ac; }
+        if (valid) { Mu[pos] = am; Cu[pos] = ac; }
     }
 }
 
@@ -1830,15 +1832,18 @@ template <typename IdxT, int MODE>
 __device__ void solve_one(const DevParams& D, int b, const ProbDesc& pd, ProbState* st,
                           const double* __restrict__ feats, const int32_t* __restrict__ assoc,
                           const int32_t* __restrict__ lp, const double* __restrict__ ls,
-                          const uint32_t* __restrict__ permPool, const uint32_t* __restrict__ sliceWidthPool,
-                          const uint32_t* __restrict__ sliceBasePool,
+                          const uint32_t* __restrict__ permPool, const uint32_t* __restrict__ rowPosPool,
+                          const uint32_t* __restrict__ sliceWidthPool, const uint32_t* __restrict__ sliceBasePool,
                           const IdxT* __restrict__ colsPool, const double* __restrict__ valsPool,
                           double* __restrict__ vMu, double* __restrict__ vCu,
                           double* __restrict__ vMun, double* __restrict__ vCun,
                           double* __restrict__ gU, double* __restrict__ gUn,
+                          int32_t* __restrict__ plpPool /* position -> association index */, double* __restrict__ pldPool /* diagonal by position */,
                           const double* __restrict__ u0, const SolveOut& O,
                           double* sv /* LDS vectors */, int Lcap, double* red, int* sint)
 {
+    // Every vector is indexed by POSITION (the sorted row order of the layout; the matrix's column labels are positions):
+    // element p belongs to the live association perm[p].
     const roman_params_t& P = D.p;
     const int ltid = threadIdx.x, nw = blockDim.x >> 6;
     const int nt = (int)blockDim.x;
@@ -1854,10 +1859,13 @@ __device__ void solve_one(const DevParams& D, int b, const ProbDesc& pd, ProbSta
     double* Cu = (MODE == 2) ? sv + 3 * Lcap : vCu + rb;
     double* Mun = (MODE == 2) ? sv + 4 * Lcap : vMun + rb;
     double* Cun = (MODE == 2) ? sv + 5 * Lcap : vCun + rb;
-    const double* sd = ls + lo;                       // diagonal M_pp = single score
+    int32_t* plp = plpPool + lo; double* pld = pldPool + lo;
+    for (int p = tid; p < L; p += nt) { const uint32_t k_ = perm[p]; plp[p] = lp[lo + k_]; pld[p] = ls[lo + k_]; }
+    __syncthreads();
+    const double* sd = pld;                           // diagonal M_pp = single score
     if (MODE == 2) {
         double* sdl = sv + 6 * Lcap;
-        for (int p = tid; p < L; p += nt) sdl[p] = ls[lo + p];
+        for (int p = tid; p < L; p += nt) sdl[p] = pld[p];
         sd = sdl;
     }
 
@@ -1872,10 +1880,10 @@ __device__ void solve_one(const DevParams& D, int b, const ProbDesc& pd, ProbSta
     if (pd.n1 == 0 || pd.n2 == 0) status |= ROMAN_ST_EMPTY_MAP;
     if (L > 0) {
         // ---- initialisation: u = normalize(M u0 + diag u0) ------------------------------------
-        for (int p = tid; p < L; p += nt) u[p] = u0 ? u0[lo + lp[lo + p]] : 1.0;
+        for (int p = tid; p < L; p += nt) u[p] = u0 ? u0[lo + plp[p]] : 1.0;
         __syncthreads();
         if (P.rescale_u0) {
-            spmv_sell<IdxT, 8>(u, L, perm, swid, sbase, cols, vals, Mu, Cu, tid, nt); ++S.n_pass;
+            spmv_sell<IdxT, 4>(u, L, perm, swid, sbase, cols, vals, Mu, Cu, tid, nt); ++S.n_pass;
             __syncthreads();
             for (int p = tid; p < L; p += nt) u[p] = Mu[p] + sd[p] * u[p];
             __syncthreads();
@@ -1888,7 +1896,7 @@ __device__ void solve_one(const DevParams& D, int b, const ProbDesc& pd, ProbSta
             if (nr > 0.0) for (int p = tid; p < L; p += nt) u[p] /= nr;
             __syncthreads();
         }
-        spmv_sell<IdxT, 8>(u, L, perm, swid, sbase, cols, vals, Mu, Cu, tid, nt); ++S.n_pass;
+        spmv_sell<IdxT, 4>(u, L, perm, swid, sbase, cols, vals, Mu, Cu, tid, nt); ++S.n_pass;
         double usum = 0.0;
         { double dummy = 0.0; for (int p = tid; p < L; p += nt) usum += u[p]; SUM2(usum, dummy); }
         // the barrier inside block_sum2 also orders the Mu/Cu stores of spmv_sell before the reads below
@@ -1936,7 +1944,7 @@ __device__ void solve_one(const DevParams& D, int b, const ProbDesc& pd, ProbSta
                     }
                     SUM2(s1, dd);
                     unsum = s1; du2 = dd;
-                    spmv_sell<IdxT, 8>(un, L, perm, swid, sbase, cols, vals, Mun, Cun, tid, nt); ++S.n_pass; ++S.ls_trials;
+                    spmv_sell<IdxT, 4>(un, L, perm, swid, sbase, cols, vals, Mun, Cun, tid, nt); ++S.n_pass; ++S.ls_trials;
                     __syncthreads();
                     double f = 0.0;
                     for (int p = tid; p < L; p += nt) {
@@ -1967,10 +1975,10 @@ __device__ void solve_one(const DevParams& D, int b, const ProbDesc& pd, ProbSta
         S.outer_iters = i; S.score = F; S.d_final = d;
 
         __syncthreads();                         // every element of the final u is in memory
-        finish_one(D, b, pd, feats, assoc, lp, lp, nullptr, nullptr, O, u, Mun, (int32_t*)un, (int32_t*)Cun, L, rb, lo, F, status, S, red, sint);
+        finish_one(D, b, pd, feats, assoc, plpPool, lp, rowPosPool, permPool, O, u, Mun, (int32_t*)un, (int32_t*)Cun, L, rb, lo, F, status, S, red, sint);
         return;
     }
-    finish_one(D, b, pd, feats, assoc, lp, lp, nullptr, nullptr, O, nullptr, nullptr, nullptr, nullptr, L, rb, lo, F, status, S, red, sint);
+    finish_one(D, b, pd, feats, assoc, plpPool, lp, rowPosPool, permPool, O, nullptr, nullptr, nullptr, nullptr, L, rb, lo, F, status, S, red, sint);
 #undef SUM2
 }
 
@@ -1980,12 +1988,13 @@ __global__ void __launch_bounds__(1024) k_solve(DevParams D, int B, const ProbDe
                                                 ProbState* __restrict__ st,
                                                 const double* __restrict__ feats, const int32_t* __restrict__ assoc,
                                                 const int32_t* __restrict__ lp, const double* __restrict__ ls,
-                                                const uint32_t* __restrict__ perm, const uint32_t* __restrict__ sliceWidth,
-                                                const uint32_t* __restrict__ sliceBase,
+                                                const uint32_t* __restrict__ perm, const uint32_t* __restrict__ rowPos,
+                                                const uint32_t* __restrict__ sliceWidth, const uint32_t* __restrict__ sliceBase,
                                                 const IdxT* __restrict__ cols, const double* __restrict__ vals,
                                                 double* __restrict__ vMu, double* __restrict__ vCu,
                                                 double* __restrict__ vMun, double* __restrict__ vCun,
                                                 double* __restrict__ gU, double* __restrict__ gUn,
+                                                int32_t* __restrict__ plp, double* __restrict__ pld,
                                                 const double* __restrict__ u0, SolveOut O,
                                                 int* __restrict__ queue, int Lcap)
 {
@@ -2005,11 +2014,11 @@ __global__ void __launch_bounds__(1024) k_solve(DevParams D, int B, const ProbDe
         if (__builtin_amdgcn_readfirstlane(st[b].kind) == 1) {   // (else: the stream solver's problem, or a skipped one)
             const ProbDesc pd = probs[b];
             if (MODE > 0 && st[b].L <= Lcap)
-                solve_one<IdxT, MODE>(D, b, pd, st, feats, assoc, lp, ls, perm, sliceWidth, sliceBase, cols, vals,
-                                      vMu, vCu, vMun, vCun, gU, gUn, u0, O, sv, Lcap, red, sint);
+                solve_one<IdxT, MODE>(D, b, pd, st, feats, assoc, lp, ls, perm, rowPos, sliceWidth, sliceBase, cols, vals,
+                                      vMu, vCu, vMun, vCun, gU, gUn, plp, pld, u0, O, sv, Lcap, red, sint);
             else
-                solve_one<IdxT, 0>(D, b, pd, st, feats, assoc, lp, ls, perm, sliceWidth, sliceBase, cols, vals,
-                                   vMu, vCu, vMun, vCun, gU, gUn, u0, O, sv, Lcap, red, sint);
+                solve_one<IdxT, 0>(D, b, pd, st, feats, assoc, lp, ls, perm, rowPos, sliceWidth, sliceBase, cols, vals,
+                                   vMu, vCu, vMun, vCun, gU, gUn, plp, pld, u0, O, sv, Lcap, red, sint);
         }
     }
 }
@@ -2061,7 +2070,6 @@ constexpr unsigned long long FX_MAGIC_BITS = 0x4338000000000000ull;     // 2^52 
 // every wait for an LDS gather would drain the prefetched matrix loads.
 #define ROMAN_GLOBAL __attribute__((address_space(1)))
 #define ROMAN_LDS __attribute__((address_space(3)))
-typedef double dbl2_t __attribute__((ext_vector_type(2)));
 typedef const ROMAN_GLOBAL unsigned long long* g_quad_cp;    // 4 x u16 column indices of one lane
 typedef const ROMAN_GLOBAL dbl2_t* g_pair_cp;                // 2 x f64 values of one lane
 typedef const ROMAN_LDS double* l_vec_cp;                    // gathered vector in LDS
@@ -2528,17 +2536,20 @@ __global__ void __launch_bounds__(NW * 64) k_solve_up(DevParams D, int B, const 
 // reading: L = 40 000 live associations, 0.5 GB of matrix; one workgroup would stream that at a few GB/s.)
 //
 //  * One persistent launch, one 512-thread workgroup per compute unit (cooperative launch: all resident).
-//  * The matrix is ONE flat stream of T "steps" (a step = entry e of the 64 lanes of a slice: 64 column words + 64
-//    values, contiguous); wave g of the grid streams the steps [T g / NWG, T (g+1) / NWG) whatever slices they belong
-//    to, WIDE_U steps in flight, and leaves the partial row sums of every slice piece it covered in a partials buffer
-//    (piece id = g + slice).  The rows' owners add the pieces of their slice in ascending order — a fixed order, no
-//    atomics.  (The round-2 solver gave a whole slice to one wave: 625 waves of 4096 busy, each walking ~1000 dependent
-//    steps: 0.5 ms per pass of pure latency.)
+//  * The matrix is ONE flat stream of T "steps" (a step = one quad of the 64 lanes of a slice: 4 column words and 4
+//    values per lane, three 16-byte loads), cut into chunks that are dealt round-robin to the waves of the grid (chunk c
+//    to wave c mod NWG: at any moment the grid reads one contiguous window of the matrix; every wave takes the same
+//    number of chunks) whatever slices they belong to; a wave keeps two blocks of WIDE_U quads in flight and leaves the partial row sums of every slice piece it
+//    covered in a partials buffer (piece id = chunk + slice).  The rows' owners add the pieces of their slice in
+//    ascending order — a fixed order, no atomics.  (The round-2 solver gave a whole slice to one wave: 625 waves of
+//    4096 busy, each walking ~1000 dependent steps: 0.5 ms per pass of pure latency.)
 //  * Vector elements live in REGISTERS: thread (wave g, lane l) owns positions (g + k NWG) * 64 + l — the rows of the slices
 //    whose partials it adds.  Only the vector being multiplied is in memory (live order, gathered by column index).
 //  * The trial vector is published UNNORMALISED: t = max(u + alpha grad, 0) goes out together with the partials of
 //    sum t^2 and sum t under ONE grid barrier; M t, C t come back and are scaled by 1 / |t| in registers
-//    (M (t / |t|) = (M t) / |t| up to rounding).  A line-search trial costs three grid barriers: publish, products, objective.
+//    (M (t / |t|) = (M t) / |t| up to rounding).  A line-search trial costs TWO grid barriers: behind the stream, and one
+//    that carries the trial's objective together with the sums of BOTH vectors that can come next (the backtracked
+//    trial and the first trial from the accepted vector are published speculatively before the objective is known).
 //  * Grid barrier: one monotone counter; everything other workgroups read is stored write-through (`sc1`), so an
 //    arrival is: every wave drains its stores, workgroup barrier, one relaxed atomic add; departure: relaxed poll,
 //    ONE agent-scope acquire, workgroup barrier (MI355X_MICROARCH.md "barrier-counter": 7 us against 26 us for
@@ -2549,9 +2560,10 @@ __global__ void __launch_bounds__(NW * 64) k_solve_up(DevParams D, int B, const 
 // ---------------------------------------------------------------------------------------------
 constexpr int WIDE_NT = 512;             // threads per workgroup (one workgroup per compute unit; 8 waves: 256 registers each)
 constexpr int WIDE_NW = WIDE_NT / 64;
-constexpr int WIDE_KW = 4;               // vector elements a thread can own: L <= WIDE_KW * 64 * (waves of the grid)
-constexpr int WIDE_NRED = 4;             // doubles per workgroup slot of a grid reduction
-constexpr int WIDE_U = 16;               // stream steps in flight per wave
+constexpr int WIDE_KW = 2;               // vector elements a thread can own: L <= WIDE_KW * 64 * (waves of the grid)
+constexpr int WIDE_NRED = 8;             // doubles per workgroup slot of a grid reduction
+constexpr int WIDE_U = 3;                // quads (of 4 entries per lane) per block of the stream; two blocks in flight per wave
+constexpr int WIDE_MAXCH = 8;            // chunks of the flat stream a wave takes per pass at most
 
 struct WideShared {
     double wred[2][WIDE_NW][WIDE_NRED];  // wave partials of a reduction (ping-pong)
@@ -2559,6 +2571,7 @@ struct WideShared {
     double red[72];                      // finish_one scratch
     int sint[4];
     int abort_;
+    int sS[WIDE_NT / 64][8];             // per wave: first slice of each of its chunks (-1: no such chunk)
 };
 
 // write-through store of a value other workgroups will read (global_store ... sc1: no release fence needed later)
@@ -2567,60 +2580,122 @@ __device__ __forceinline__ void st_pub(double* p, double v)
     __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Grid barrier.  bar[0]: arrivals (monotone over the launch), bar[1]: abort flag.  RELEASE: plain stores issued before the
-// barrier must be visible behind it as well (one agent-scope release by the arriving lane).
+// Grid barrier, XCD-hierarchical (MI355X_MICROARCH.md "barrier-xcd": 4-5 us against 7+ for one flat counter and 26 for
+// cooperative_groups' grid.sync()): a workgroup arrives at the counter of the XCD it runs on; the last arriver of an XCD
+// arrives at the top counter, waits for the other XCDs' leaders and then releases its own XCD through a generation word that
+// the others poll — 32 + 8 serialised atomics instead of 256, and nobody polls a line that arrivals are still hitting.
+// Which XCD a workgroup is on is read from the hardware (HW_REG_XCC_ID), how many workgroups each XCD holds is counted at
+// kernel start (wide_census): nothing is assumed about placement.  Words of `bar` (zeroed before every launch), one 128-byte
+// line each: [0] abort flag, [1+x] arrivals of XCD x, [9] top arrivals, [10+x] generation of XCD x, [18] census (8 words),
+// [19] flat counter of the census barrier.  RELEASE: plain stores issued before the barrier must be visible behind it as well.
+// Every spin is bounded (4 s): on a timeout the abort flag goes up and every workgroup leaves.
+constexpr int WIDE_BAR_WORDS = 20 * 32;
+struct WideBar { unsigned* bar; unsigned epoch; int G; int xcc; unsigned nX; unsigned nActive; };
+
+__device__ __forceinline__ bool wide_spin(const unsigned* word, unsigned target, unsigned* bar)
+{
+    const unsigned long long t0 = wall_clock64();
+    unsigned n = 0;
+    while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        __builtin_amdgcn_s_sleep(1);
+        if ((++n & 255u) == 0u && (wall_clock64() - t0 > 400000000ull || __hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+            __hip_atomic_store(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return false;
+        }
+    }
+    return true;
+}
+
 template <bool RELEASE>
-__device__ __forceinline__ bool wide_sync(WideShared& sh, unsigned* bar, unsigned& epoch, int G, int ltid)
+__device__ __forceinline__ bool wide_sync(WideShared& sh, WideBar& wb, int ltid)
 {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // every wave: its stores have left the compute unit
     __syncthreads();
-    ++epoch;
+    ++wb.epoch;
     if (ltid == 0) {
         if (RELEASE) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-        __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned target = epoch * (unsigned)G;
-        const unsigned long long t0 = wall_clock64();
-        unsigned n = 0; bool ok = true;
-        while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            __builtin_amdgcn_s_sleep(1);
-            if ((++n & 255u) == 0u && (wall_clock64() - t0 > 400000000ull || __hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) { ok = false; break; }
+        unsigned* bar = wb.bar;
+        bool ok;
+        const unsigned old = __hip_atomic_fetch_add(bar + 32 * (1 + wb.xcc), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old + 1u == wb.epoch * wb.nX) {                     // the last workgroup of this XCD: on to the top level
+            __hip_atomic_fetch_add(bar + 32 * 9, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ok = wide_spin(bar + 32 * 9, wb.epoch * wb.nActive, bar);
+            __hip_atomic_store(bar + 32 * (10 + wb.xcc), wb.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            ok = wide_spin(bar + 32 * (10 + wb.xcc), wb.epoch, bar);
         }
-        if (!ok) { __hip_atomic_store(bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); sh.abort_ = 1; }
+        if (!ok) sh.abort_ = 1;
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // this compute unit's L1 holds nothing older than the barrier
     }
     __syncthreads();
     return sh.abort_ == 0;
 }
 
-// Grid barrier carrying N sums: v[i] <- sum over every thread of the grid, identical in all of them (fixed order: lanes by
-// butterfly, waves ascending, workgroups lane-strided then butterfly).  N == 0: the barrier alone.
-template <int N>
-__device__ __forceinline__ bool wide_reduce(double (&v)[N > 0 ? N : 1], WideShared& sh, double* slots, unsigned* bar, unsigned& epoch, int G, int ltid)
+// Once per launch: which XCD am I on, how many workgroups does each XCD hold (one flat-counter barrier).
+__device__ __forceinline__ bool wide_census(WideShared& sh, WideBar& wb, int ltid)
 {
-    static_assert(N <= WIDE_NRED, "slot width");
-    const int lane = ltid & 63, w = ltid >> 6, par = (int)(epoch & 1u);
+    unsigned x;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+    wb.xcc = (int)(x & 7u);
+    if (ltid == 0) {
+        unsigned* bar = wb.bar;
+        __hip_atomic_fetch_add(bar + 32 * 18 + wb.xcc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(bar + 32 * 19, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool ok = wide_spin(bar + 32 * 19, (unsigned)wb.G, bar);
+        unsigned act = 0;
+        for (int t = 0; t < 8; ++t) {
+            const unsigned c_ = __hip_atomic_load(bar + 32 * 18 + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            act += c_ ? 1u : 0u;
+            if (t == wb.xcc) sh.sint[0] = (int)c_;
+        }
+        sh.sint[1] = (int)act;
+        if (!ok) sh.abort_ = 1;
+    }
+    __syncthreads();
+    wb.nX = (unsigned)sh.sint[0]; wb.nActive = (unsigned)sh.sint[1];
+    __syncthreads();
+    return sh.abort_ == 0;
+}
+
+// Grid barrier carrying N values: v[i] <- sum (i < N - NM) or maximum (the last NM, non-negative values) over every thread
+// of the grid, identical in all of them (fixed order: lanes by butterfly, waves ascending, workgroups lane-strided then
+// butterfly).  N == 0: the barrier alone.
+template <int N, int NM = 0>
+__device__ __forceinline__ bool wide_reduce(double (&v)[N > 0 ? N : 1], WideShared& sh, double* slots, WideBar& wb, int ltid)
+{
+    static_assert(N <= WIDE_NRED && NM <= N, "slot width");
+    const int lane = ltid & 63, w = ltid >> 6, par = (int)(wb.epoch & 1u);
+    const int G = wb.G;
     if (N > 0) {
 #pragma unroll
         for (int i = 0; i < N; ++i) {
             double x = v[i];
-            for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
+            if (i < N - NM) { for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off); }
+            else { for (int off = 32; off > 0; off >>= 1) x = fmax(x, __shfl_xor(x, off)); }
             if (lane == 0) sh.wred[par][w][i] = x;
         }
         __syncthreads();
         if (ltid < N) {
             double t = 0.0;
-            for (int ww = 0; ww < WIDE_NW; ++ww) t += sh.wred[par][ww][ltid];
+            if (ltid < N - NM) { for (int ww = 0; ww < WIDE_NW; ++ww) t += sh.wred[par][ww][ltid]; }
+            else { for (int ww = 0; ww < WIDE_NW; ++ww) t = fmax(t, sh.wred[par][ww][ltid]); }
             st_pub(slots + ((size_t)par * G + blockIdx.x) * WIDE_NRED + ltid, t);
         }
     }
-    if (!wide_sync<false>(sh, bar, epoch, G, ltid)) return false;
+    if (!wide_sync<false>(sh, wb, ltid)) return false;
     if (N > 0) {
         if (w == 0) {
 #pragma unroll
             for (int i = 0; i < N; ++i) {
                 double a = 0.0;
-                for (int g = lane; g < G; g += WAVE) a += slots[((size_t)par * G + g) * WIDE_NRED + i];
-                for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off);
+                if (i < N - NM) {
+                    for (int g = lane; g < G; g += WAVE) a += slots[((size_t)par * G + g) * WIDE_NRED + i];
+                    for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off);
+                } else {
+                    for (int g = lane; g < G; g += WAVE) a = fmax(a, slots[((size_t)par * G + g) * WIDE_NRED + i]);
+                    for (int off = 32; off > 0; off >>= 1) a = fmax(a, __shfl_xor(a, off));
+                }
                 if (lane == 0) sh.bc[par][i] = a;
             }
         }
@@ -2639,42 +2714,65 @@ __global__ void __launch_bounds__(WIDE_NT) k_solve_wide(DevParams D, int B, cons
                                                         const uint32_t* __restrict__ permPool, const uint32_t* __restrict__ rowPosPool,
                                                         const uint32_t* __restrict__ sliceBasePool,
                                                         const IdxT* __restrict__ colsPool, const double* __restrict__ valsPool,
-                                                        double* __restrict__ vU /* final u by position */, double* __restrict__ vX /* published vector, live order */,
+                                                        double* __restrict__ vU /* final u by position */,
+                                                        double* __restrict__ vXa, double* __restrict__ vXb /* published vectors, by position */,
                                                         double* __restrict__ vS0, double* __restrict__ vS1, double* __restrict__ vS2 /* scratch of the shared tail */,
                                                         int32_t* __restrict__ plp /* position -> association index (written here) */,
                                                         const double* __restrict__ u0, SolveOut O,
-                                                        double* __restrict__ part /* [(waves + slices)][64][2] */,
-                                                        double* __restrict__ slots /* [2][G][WIDE_NRED] */, unsigned* __restrict__ bar)
+                                                        double* __restrict__ part /* [(chunks + slices)][64][2] */,
+                                                        double* __restrict__ slots /* [2][G][WIDE_NRED] */, unsigned* __restrict__ bar,
+                                                        unsigned long long* __restrict__ bmPool /* [2][bmWords]: support bit maps of the two published vectors */,
+                                                        int bmWords /* 64-bit words of one bit map (and of its LDS copy) */,
+                                                        int xcap /* doubles of dynamic LDS behind the bit map: the gathered vector's leading part */,
+                                                        int tune /* experiments: bit 0 never gather from LDS, bit 1 non-temporal matrix loads, bits 8.. chunks per wave */)
 {
     __shared__ WideShared sh;
+    extern __shared__ __attribute__((aligned(16))) unsigned char wide_smem[];
+    unsigned long long* bml = reinterpret_cast<unsigned long long*>(wide_smem);      // support bit map of the vector being multiplied
+    double* xl = reinterpret_cast<double*>(bml + bmWords);                             // its leading xcap elements
     const roman_params_t& P = D.p;
     const int ltid = threadIdx.x, lane = ltid & 63, w = uni_i(ltid >> 6);
     const int G = (int)gridDim.x, NWG = G * WIDE_NW;
     const int gw = w * G + (int)blockIdx.x;                     // wave id in the grid: consecutive ids on different compute units
-    unsigned epoch = 0;
     if (ltid == 0) sh.abort_ = 0;
     __syncthreads();
+    WideBar wb{bar, 0u, G, 0, 1u, 1u};
+    if (!wide_census(sh, wb, ltid)) return;
     for (int b = 0; b < B; ++b) {
         if (uni_i(st[b].kind) != 1) continue;                   // (uniform over the grid)
         const ProbDesc pd = probs[b];
         const int L = uni_i(st[b].L), rb = uni_i(st[b].rowBase);
         const int64_t lo = pd.liveOff;
         const int nsl = (L + 63) >> 6;
-        const uint32_t T = st[b].nnzCap >> 6;                   // steps of the flat stream
+        const uint32_t T = st[b].nnzCap >> 8;                   // steps of the flat stream (a step = one quad of the 64 lanes of a slice: 256 entries)
         const uint32_t* perm = permPool + lo; const uint32_t* sbase = sliceBasePool + lo;
         const IdxT* cols = colsPool + st[b].nnzOff; const double* vals = valsPool + st[b].nnzOff;
-        double* xv = vX + rb;
+        double* xva = vXa + rb; double* xvb = vXb + rb;
+        unsigned long long* bma = bmPool; unsigned long long* bmb = bmPool + bmWords;
         const int kw = min(WIDE_KW, (nsl + NWG - 1) / NWG);     // element rounds in use (the host guarantees L <= WIDE_KW * NWG * 64)
-#define CUMW(s_) ((s_) < nsl ? (sbase[(s_)] >> 6) : T)
-#define WIDE_QS(g_) ((uint32_t)(((unsigned long long)T * (unsigned)(g_)) / (unsigned)NWG))
+#define CUMW(s_) ((s_) < nsl ? (sbase[(s_)] >> 8) : T)
 #define FORK(k_) _Pragma("unroll") for (int k_ = 0; k_ < WIDE_KW; ++k_) if (k_ < kw)
-        const uint32_t qs = WIDE_QS(gw), qe = WIDE_QS(gw + 1);
-        int s0 = 0; uint32_t sEnd0 = 0;
-        if (qs < qe) {                                          // the slice that holds step qs (largest s with cumW[s] <= qs)
-            int lo_ = 0, hi_ = nsl;
-            while (hi_ - lo_ > 1) { const int mid_ = (lo_ + hi_) >> 1; if (CUMW(mid_) <= qs) lo_ = mid_; else hi_ = mid_; }
-            s0 = lo_; sEnd0 = CUMW(s0 + 1);
+        // chunks of CS steps, dealt round-robin to the waves (chunk c to wave c % NWG): at any moment the waves of the grid
+        // read one contiguous window of the matrix.  Every wave takes the same number m <= WIDE_MAXCH of chunks (the last
+        // round may be short): about 16 steps (12 KB per lane-row... 48 KB per wave) per chunk, more when the matrix is larger.
+        uint32_t mch = max(1u, min((uint32_t)WIDE_MAXCH, (T + (uint32_t)NWG * 16u - 1u) / ((uint32_t)NWG * 16u)));
+        if ((tune >> 8) & 0xff) mch = min((uint32_t)WIDE_MAXCH, (uint32_t)((tune >> 8) & 0xff));
+        const uint32_t CS = max(1u, (T + (uint32_t)NWG * mch - 1u) / ((uint32_t)NWG * mch));
+        const uint32_t nCh = (T + CS - 1u) / CS;                // <= NWG * mch
+        static_assert(WIDE_MAXCH <= 8, "sS capacity");
+        __syncthreads();                                        // (the previous problem's stream is done with sS)
+        if (lane < WIDE_MAXCH) {                                // lane j: first slice of this wave's chunk j (-1: no such chunk)
+            const uint32_t c = (uint32_t)gw + (uint32_t)lane * (uint32_t)NWG;
+            int s_ = -1;
+            if (c < nCh) {                                      // largest s with cumW[s] <= first step of the chunk
+                const uint32_t t0 = c * CS;
+                int lo_ = 0, hi_ = nsl;
+                while (hi_ - lo_ > 1) { const int mid_ = (lo_ + hi_) >> 1; if (CUMW(mid_) <= t0) lo_ = mid_; else hi_ = mid_; }
+                s_ = lo_;
+            }
+            sh.sS[w][lane] = s_;
         }
+        __syncthreads();
 
         int status = ROMAN_ST_OK;
         roman_stats_t S;
@@ -2684,85 +2782,146 @@ __global__ void __launch_bounds__(WIDE_NT) k_solve_wide(DevParams D, int B, cons
         double F = 0.0, d = 0.0, usum = 0.0;
         int n_pass = 0, ls_trials = 0, inner_iters = 0, i = 0;
 
-        // owned elements
-        double u[WIDE_KW], Mu[WIDE_KW], Cu[WIDE_KW], sd[WIDE_KW], tt[WIDE_KW], Mn[WIDE_KW], Cn[WIDE_KW];
-        int kk[WIDE_KW]; bool in[WIDE_KW];
+        // owned elements (registers) and the pieces of their slices
+        double u[WIDE_KW], Mu[WIDE_KW], Cu[WIDE_KW], sd[WIDE_KW], tt[WIDE_KW], Mn[WIDE_KW], Cn[WIDE_KW], tb[WIDE_KW], ta[WIDE_KW];
+        int kk[WIDE_KW]; bool in[WIDE_KW]; uint32_t pcf[WIDE_KW], pcn[WIDE_KW];
 #pragma unroll
         for (int k = 0; k < WIDE_KW; ++k) {
-            const int pos = ((gw + k * NWG) << 6) + lane;
+            const int s_ = gw + k * NWG;
+            const int pos = (s_ << 6) + lane;
             in[k] = k < kw && pos < L;
             kk[k] = in[k] ? (int)perm[pos] : 0;
             sd[k] = in[k] ? ld[lo + kk[k]] : 0.0;
             const int a_ = in[k] ? lp[lo + kk[k]] : 0;
             if (in[k]) plp[lo + pos] = a_;
             u[k] = in[k] ? (u0 ? u0[lo + a_] : 1.0) : 0.0;
-            Mu[k] = Cu[k] = tt[k] = Mn[k] = Cn[k] = 0.0;
+            Mu[k] = Cu[k] = tt[k] = Mn[k] = Cn[k] = tb[k] = ta[k] = 0.0;
+            pcf[k] = 0u; pcn[k] = 0u;
+            if (k < kw && s_ < nsl) {                           // pieces (chunk c, slice s_) have id c + s_
+                const uint32_t a0 = CUMW(s_), e0 = CUMW(s_ + 1);
+                if (e0 > a0) { pcf[k] = a0 / CS + (uint32_t)s_; pcn[k] = (e0 - 1u) / CS - a0 / CS + 1u; }
+            }
         }
         double dummy1[1] = {0.0};
         bool alive = true;
+#ifdef ROMAN_SOLVE_TIMING
+        unsigned long long wacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, wcnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        unsigned long long wlast = wall_clock64();
+#define WMARK(slot) do { const unsigned long long t__ = wall_clock64(); wacc[slot] += t__ - wlast; wcnt[slot] += 1; wlast = t__; } while (0)
+#else
+#define WMARK(slot) do { } while (0)
+#endif
 
-        // x (one value per owned element) -> the live-ordered vector other compute units gather from
-        auto publish = [&](const double (&x)[WIDE_KW]) { FORK(k) if (in[k]) st_pub(xv + kk[k], x[k]); };
-        // flat stream over this wave's steps: partial row sums of every slice piece -> partials buffer
-        auto stream = [&]() {
-            uint32_t t = qs; int s = s0; uint32_t sEnd = sEnd0;
-            while (t < qe) {
-                const uint32_t stop = min(sEnd, qe);
-                const bool valid = ((s << 6) + lane) < L;
-                double am = 0.0, ac = 0.0;
-                const IdxT* cp = cols + (size_t)t * 64 + lane; const double* vp = vals + (size_t)t * 64 + lane;
-                uint32_t n = stop - t;
-                for (; n >= (uint32_t)WIDE_U; n -= WIDE_U, cp += WIDE_U * 64, vp += WIDE_U * 64) {
-                    uint32_t c_[WIDE_U]; double v_[WIDE_U];
-#pragma unroll
-                    for (int e = 0; e < WIDE_U; ++e) { c_[e] = valid ? (uint32_t)cp[e * 64] : IdxTraits<IdxT>::CZ; v_[e] = valid ? vp[e * 64] : 0.0; }
-#pragma unroll
-                    for (int e = 0; e < WIDE_U; ++e) {
-                        const double uq = xv[c_[e] & IdxTraits<IdxT>::MASK];
-                        am = fma(v_[e], uq, am);
-                        ac += (c_[e] & IdxTraits<IdxT>::CZ) ? 0.0 : uq;
+        // x (one value per owned element) -> the vector other compute units gather from (by position, like the column labels)
+        // together with its support bit map: one ballot word per wave and round (a wave owns 64 consecutive positions)
+        auto publish = [&](double* xv, unsigned long long* bm, const double (&x)[WIDE_KW]) {
+            FORK(k) {
+                if (in[k]) st_pub(xv + (((gw + k * NWG) << 6) + lane), x[k]);
+                const unsigned long long m_ = __ballot(in[k] && x[k] > 0.0);
+                if (lane == 0 && gw + k * NWG < nsl) __hip_atomic_store(bm + (gw + k * NWG), m_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        };
+        // one piece [t, stop) of slice s: partial row sums -> partials buffer.  Blocks of WIDE_U quads (three 16-byte loads
+        // per lane and quad), the next block's matrix loads in flight while the current block gathers and accumulates.
+        auto piece = [&](const double* xv, uint32_t nl, uint32_t t, uint32_t stop, uint32_t pid) {
+            double am = 0.0, ac = 0.0;
+            const uint4_t* cp = reinterpret_cast<const uint4_t*>(cols) + (size_t)t * 64 + lane;
+            const dbl2_t* vp = reinterpret_cast<const dbl2_t*>(vals) + (size_t)t * 128 + lane;
+            const uint32_t n = stop - t;
+            uint4_t cA[WIDE_U], cB[WIDE_U]; dbl2_t vA0[WIDE_U], vA1[WIDE_U], vB0[WIDE_U], vB1[WIDE_U];
+#define WIDE_ISSUE(C_, V0_, V1_, off_, n_)                                                                    \
+            _Pragma("unroll") for (int e = 0; e < WIDE_U; ++e) {                                              \
+                const uint32_t q_ = (off_) + min((uint32_t)e, (n_) - 1u);     /* clamped: a repeated quad is skipped by the consumer */ \
+                if (tune & 2) { C_[e] = __builtin_nontemporal_load(cp + (size_t)q_ * 64); V0_[e] = __builtin_nontemporal_load(vp + (size_t)(2u * q_) * 64); V1_[e] = __builtin_nontemporal_load(vp + (size_t)(2u * q_ + 1u) * 64); } \
+                else { C_[e] = cp[(size_t)q_ * 64]; V0_[e] = vp[(size_t)(2u * q_) * 64]; V1_[e] = vp[(size_t)(2u * q_ + 1u) * 64]; } \
+            }
+#define WIDE_CONSUME(C_, V0_, V1_, n_)                                                                        \
+            _Pragma("unroll") for (int e = 0; e < WIDE_U; ++e) {                                              \
+                if ((uint32_t)e < (n_)) {                                                                     \
+                    const uint32_t c4[4] = {C_[e].x, C_[e].y, C_[e].z, C_[e].w};                              \
+                    const double v4[4] = {V0_[e].x, V0_[e].y, V1_[e].x, V1_[e].y};                            \
+                    _Pragma("unroll") for (int h = 0; h < 4; ++h) {                                           \
+                        const uint32_t ci = c4[h] & IdxTraits<IdxT>::MASK;                                    \
+                        double uq = 0.0;                                                                      \
+                        if (ci < nl) uq = xl[ci];                                                             \
+                        else if ((bml[ci >> 6] >> (ci & 63u)) & 1ull) uq = xv[ci];                            \
+                        am = fma(v4[h], uq, am);                                                              \
+                        ac += (c4[h] & IdxTraits<IdxT>::CZ) ? 0.0 : uq;                                       \
+                    }                                                                                         \
+                }                                                                                             \
+            }
+            WIDE_ISSUE(cA, vA0, vA1, 0u, n)
+            for (uint32_t o = 0; o < n; o += 2 * WIDE_U) {
+                const uint32_t n1 = (n > o + WIDE_U) ? n - o - WIDE_U : 0u;
+                if (n1) { WIDE_ISSUE(cB, vB0, vB1, o + WIDE_U, n1) }
+                WIDE_CONSUME(cA, vA0, vA1, n - o)
+                if (n1) {
+                    const uint32_t n2 = (n > o + 2 * WIDE_U) ? n - o - 2 * WIDE_U : 0u;
+                    if (n2) { WIDE_ISSUE(cA, vA0, vA1, o + 2 * WIDE_U, n2) }
+                    WIDE_CONSUME(cB, vB0, vB1, n1)
+                }
+            }
+#undef WIDE_ISSUE
+#undef WIDE_CONSUME
+            double* pp = part + ((size_t)pid * 64 + lane) * 2;
+            st_pub(pp, am); st_pub(pp + 1, ac);
+        };
+        // Where the gathered values come from.  A 320 KB vector against a 32 KB L1 makes every gather an L2 access, and the
+        // whole device does 280 G of those per second: 150 us for the 42 M entries of the n = m = 200 problem, more than
+        // the matrix stream itself.  So every workgroup first copies into LDS (a) the support bit map of x (one bit per
+        // position) and (b) the leading min(mp1, xcap) elements of x — positions are ranks by degree, so the leading
+        // elements are the columns most entries point at, and the support collapses onto them within a few passes.  A
+        // gather is then an LDS read; only a column beyond the LDS part whose bit is set goes to L2.
+        auto stream = [&](const double* xv, const unsigned long long* bm, uint32_t mp1) {
+            const uint32_t nl = (tune & 1) ? 0u : min(mp1, (uint32_t)xcap);
+            for (uint32_t p = (uint32_t)ltid; p < (uint32_t)nsl; p += WIDE_NT) bml[p] = bm[p];
+            for (uint32_t p = (uint32_t)ltid; p < nl; p += WIDE_NT) xl[p] = xv[p];
+            __syncthreads();
+#ifdef ROMAN_SOLVE_TIMING
+            wcnt[7] += (mp1 <= (uint32_t)xcap) ? 1 : 0;
+#endif
+            for (int j = 0; j < WIDE_MAXCH; ++j) {
+                int s = uni_i(sh.sS[w][j]);
+                if (s >= 0) {
+                    const uint32_t c = (uint32_t)gw + (uint32_t)j * (uint32_t)NWG;
+                    uint32_t t = c * CS;
+                    const uint32_t tEnd = min(T, t + CS);
+                    uint32_t sEnd = CUMW(s + 1);
+                    while (t < tEnd) {
+                        const uint32_t stop = min(sEnd, tEnd);
+                        piece(xv, nl, t, stop, c + (uint32_t)s);
+                        t = stop;
+                        if (t < tEnd) { do { ++s; sEnd = CUMW(s + 1); } while (sEnd <= t); }
                     }
                 }
-                {   // fewer than WIDE_U steps left in this piece: predicated, still all loads in flight together
-                    uint32_t c_[WIDE_U]; double v_[WIDE_U];
-#pragma unroll
-                    for (int e = 0; e < WIDE_U; ++e) {
-                        const bool a_ = valid && (uint32_t)e < n;
-                        c_[e] = a_ ? (uint32_t)cp[e * 64] : IdxTraits<IdxT>::CZ; v_[e] = a_ ? vp[e * 64] : 0.0;
-                    }
-#pragma unroll
-                    for (int e = 0; e < WIDE_U; ++e) {
-                        const double uq = xv[c_[e] & IdxTraits<IdxT>::MASK];
-                        am = fma(v_[e], uq, am);
-                        ac += (c_[e] & IdxTraits<IdxT>::CZ) ? 0.0 : uq;
-                    }
-                }
-                double* pp = part + ((size_t)(gw + s) * 64 + lane) * 2;
-                st_pub(pp, am); st_pub(pp + 1, ac);
-                t = stop;
-                if (t < qe) { do { ++s; sEnd = CUMW(s + 1); } while (sEnd <= t); }
             }
             ++n_pass;
         };
         // (M x, C x) of the owned rows: the pieces of their slice in ascending order
         auto collect = [&](double (&om)[WIDE_KW], double (&oc)[WIDE_KW]) {
             FORK(k) {
-                const int s = gw + k * NWG;
                 double m_ = 0.0, c_ = 0.0;
-                if (s < nsl) {
-                    const uint32_t a_ = CUMW(s), e_ = CUMW(s + 1);
-                    if (e_ > a_) {
-                        const int gf = (int)((((unsigned long long)a_ + 1ull) * (unsigned)NWG - 1ull) / T);
-                        const int gl = (int)(((unsigned long long)e_ * (unsigned)NWG - 1ull) / T);
-                        for (int g = gf; g <= gl; ++g) {
-                            if (WIDE_QS(g) < WIDE_QS(g + 1)) {      // (a wave with an empty range wrote nothing)
-                                const double* pp = part + ((size_t)(g + s) * 64 + lane) * 2;
-                                m_ += pp[0]; c_ += pp[1];
-                            }
-                        }
-                    }
+                const dbl2_t* pp = reinterpret_cast<const dbl2_t*>(part) + (size_t)pcf[k] * 64 + lane;
+                for (uint32_t q0 = 0; q0 < pcn[k]; q0 += 8) {     // 8 pieces in flight, added in ascending order
+                    dbl2_t x_[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) x_[e] = pp[(size_t)min(q0 + (uint32_t)e, pcn[k] - 1u) * 64];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) if (q0 + (uint32_t)e < pcn[k]) { m_ += x_[e].x; c_ += x_[e].y; }
                 }
                 om[k] = in[k] ? m_ : 0.0; oc[k] = in[k] ? c_ : 0.0;
+            }
+        };
+        // trial vector max(base + alpha grad(base), 0) of the owned elements, with the partials of sum t^2 and sum t
+        auto trial = [&](const double (&ub)[WIDE_KW], const double (&mb)[WIDE_KW], const double (&cb)[WIDE_KW], double us, double alpha,
+                         double (&out)[WIDE_KW], double& ss, double& s1, double& mp) {
+            FORK(k) {
+                const double up = ub[k];
+                const double g = (((sd[k] + d) * up - d * us) + mb[k]) + cb[k] * d;
+                double t = up + alpha * g;
+                t = (in[k] && t > 0.0) ? t : 0.0;
+                out[k] = t; ss += t * t; s1 += t;
+                if (t > 0.0) mp = fmax(mp, (double)(((gw + k * NWG) << 6) + lane + 1));
             }
         };
         // mean of (M u)_p / Cbu_p over the active set, and the two sums F = A + d B is made of — one grid reduction
@@ -2773,85 +2932,110 @@ __global__ void __launch_bounds__(WIDE_NT) k_solve_wide(DevParams D, int B, cons
                 if (Cbu > P.eps && up > P.eps) { const double r_ = mdu / Cbu; r4[0] += absval ? fabs(r_) : r_; r4[1] += 1.0; }
                 r4[2] += up * mdu; r4[3] += up * ((up - usum) + Cu[k]);
             }
-            return wide_reduce<4>(r4, sh, slots, bar, epoch, G, ltid);
+            return wide_reduce<4>(r4, sh, slots, wb, ltid);
         };
 
-        if (L > 0) do {
-            // ---- initialisation: u = normalize(M u0 + diag u0) -----------------------------------------------
-            if (P.rescale_u0) {
-                publish(u);
-                if (!(alive = wide_reduce<0>(dummy1, sh, slots, bar, epoch, G, ltid))) break;
-                stream();
-                if (!(alive = wide_reduce<0>(dummy1, sh, slots, bar, epoch, G, ltid))) break;
+        // The iteration as a state machine around ONE stream call site (rescale pass / initial pass / line-search trial).
+        // A trial costs TWO grid barriers: the one behind the stream, and one that carries the objective of the trial just
+        // multiplied TOGETHER with the sums of both vectors that can come next — the backtracked trial from the same base
+        // (published to xva) and the first trial from the accepted vector (xvb): whichever the objective selects is
+        // already out when the barrier opens.  (The host sends problems with maxiniters < 1 or maxlsiters < 1 to k_solve.)
+        enum { PH_RESCALE, PH_INIT, PH_TRIAL };
+        if (L > 0) {
+            double r4[4] = {0.0, 0.0, 0.0, 0.0};
+            double alpha = 1.0, nr = 0.0, s1cur = 0.0;
+            int j = 0, k2 = 0;
+            const double* xcur = xva; const unsigned long long* bmcur = bma;
+            uint32_t mpcur = (uint32_t)L;                       // support bound of the vector in xcur
+            auto normalise = [&]() -> bool {                    // u /= |u|, usum = sum u
+                double r2[2] = {0.0, 0.0};
+                FORK(k) { r2[0] += u[k] * u[k]; r2[1] += u[k]; }
+                if (!wide_reduce<2>(r2, sh, slots, wb, ltid)) return false;
+                const double nr_ = sqrt(r2[0]);
+                if (nr_ > 0.0) FORK(k) u[k] /= nr_;
+                usum = (nr_ > 0.0) ? r2[1] / nr_ : r2[1];
+                return true;
+            };
+            int phase = P.rescale_u0 ? PH_RESCALE : PH_INIT;
+            if (phase == PH_INIT) alive = normalise();
+            if (alive) { publish(xva, bma, u); alive = wide_reduce<0>(dummy1, sh, slots, wb, ltid); }
+            while (alive) {
+                stream(xcur, bmcur, mpcur);
+                WMARK(2);
+                if (!(alive = wide_reduce<0>(dummy1, sh, slots, wb, ltid))) break;
+                WMARK(3);
                 collect(Mn, Cn);
-                FORK(k) u[k] = in[k] ? Mn[k] + sd[k] * u[k] : 0.0;
-            }
-            {
-                double r1[1] = {0.0};
-                FORK(k) r1[0] += u[k] * u[k];
-                if (!(alive = wide_reduce<1>(r1, sh, slots, bar, epoch, G, ltid))) break;
-                const double nr = sqrt(r1[0]);
-                if (nr > 0.0) FORK(k) u[k] /= nr;
-            }
-            publish(u);
-            if (!(alive = wide_reduce<0>(dummy1, sh, slots, bar, epoch, G, ltid))) break;
-            stream();
-            {
-                double r1[1] = {0.0};
-                FORK(k) r1[0] += u[k];
-                if (!(alive = wide_reduce<1>(r1, sh, slots, bar, epoch, G, ltid))) break;
-                usum = r1[0];
-            }
-            collect(Mu, Cu);
-            double r4[4];
-            if (!(alive = d_ratio(false, r4))) break;
-            d = (r4[1] > 0.0) ? r4[0] / r4[1] : 0.0;
-            // ---- projected gradient ascent with homotopy on d ---------------------------------------------------
-            for (i = 0; i < P.maxoliters; ++i) {
-                F = r4[2] + d * r4[3];                              // u . gradF at the current d
-                for (int j = 0; j < P.maxiniters; ++j) {
-                    double alpha = 1.0, Fnew = 0.0, deltaF = 0.0, unsum = 0.0, du2 = 0.0;
-                    for (int k2 = 0; k2 < P.maxlsiters; ++k2) {
-                        double r2[2] = {0.0, 0.0};
-                        FORK(k) {
-                            const double up = u[k];
-                            const double g = (((sd[k] + d) * up - d * usum) + Mu[k]) + Cu[k] * d;
-                            double t = up + alpha * g;
-                            t = (in[k] && t > 0.0) ? t : 0.0;
-                            tt[k] = t; r2[0] += t * t; r2[1] += t;
-                        }
-                        publish(tt);
-                        if (!(alive = wide_reduce<2>(r2, sh, slots, bar, epoch, G, ltid))) break;
-                        const double nr = sqrt(r2[0]);
-                        stream(); ++ls_trials;
-                        if (!(alive = wide_reduce<0>(dummy1, sh, slots, bar, epoch, G, ltid))) break;
-                        collect(Mn, Cn);
-                        unsum = (nr > 0.0) ? r2[1] / nr : r2[1];
-                        double q2[2] = {0.0, 0.0};
-                        FORK(k) {
-                            if (nr > 0.0) { tt[k] /= nr; Mn[k] /= nr; Cn[k] /= nr; }
-                            const double up = tt[k];
-                            const double g = (((sd[k] + d) * up - d * unsum) + Mn[k]) + Cn[k] * d;
-                            q2[0] += up * g;
-                            const double df = up - u[k]; q2[1] += df * df;
-                        }
-                        if (!(alive = wide_reduce<2>(q2, sh, slots, bar, epoch, G, ltid))) break;
-                        Fnew = q2[0]; du2 = q2[1];
-                        deltaF = Fnew - F;
-                        if (deltaF < -P.eps) alpha *= P.beta; else break;
+                if (phase == PH_RESCALE) {                      // u = normalize(M u0 + diag u0)
+                    FORK(k) u[k] = in[k] ? Mn[k] + sd[k] * u[k] : 0.0;
+                    if (!(alive = normalise())) break;
+                    publish(xva, bma, u);
+                    if (!(alive = wide_reduce<0>(dummy1, sh, slots, wb, ltid))) break;
+                    phase = PH_INIT;
+                    continue;
+                }
+                bool new_outer = false;
+                if (phase == PH_INIT) {
+                    FORK(k) { Mu[k] = Mn[k]; Cu[k] = Cn[k]; }
+                    if (!(alive = d_ratio(false, r4))) break;
+                    d = (r4[1] > 0.0) ? r4[0] / r4[1] : 0.0;
+                    i = 0;
+                    if (i >= P.maxoliters) break;
+                    new_outer = true;
+                } else {                                        // PH_TRIAL: products of the trial vector
+                    ++ls_trials;
+                    const double unsum = (nr > 0.0) ? s1cur / nr : s1cur;
+                    double r6[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};   // objective, |du|^2, sums of the two candidates, their support bounds
+                    FORK(k) {
+                        if (nr > 0.0) { tt[k] /= nr; Mn[k] /= nr; Cn[k] /= nr; }
+                        const double up = tt[k];
+                        const double g = (((sd[k] + d) * up - d * unsum) + Mn[k]) + Cn[k] * d;
+                        r6[0] += up * g;
+                        const double df = up - u[k]; r6[1] += df * df;
                     }
-                    if (!alive) break;
-                    const double du = sqrt(du2);
+                    const bool can_back = k2 + 1 < P.maxlsiters, can_next = j + 1 < P.maxiniters;
+                    if (can_back) { trial(u, Mu, Cu, usum, alpha * P.beta, tb, r6[2], r6[3], r6[6]); publish(xva, bma, tb); }
+                    if (can_next) { trial(tt, Mn, Cn, unsum, 1.0, ta, r6[4], r6[5], r6[7]); publish(xvb, bmb, ta); }
+                    WMARK(4);
+                    if (!(alive = (wide_reduce<8, 2>(r6, sh, slots, wb, ltid)))) break;
+                    WMARK(5);
+                    const double Fnew = r6[0], deltaF = Fnew - F;
+                    if (deltaF < -P.eps && can_back) {          // backtrack: the shorter step from the same base is already out
+                        alpha *= P.beta; ++k2;
+                        FORK(k) tt[k] = tb[k];
+                        nr = sqrt(r6[2]); s1cur = r6[3]; xcur = xva; bmcur = bma; mpcur = (uint32_t)r6[6];
+                        continue;
+                    }
+                    // accept: the trial vector and its products become the current ones
+                    const double du = sqrt(r6[1]);
                     F = Fnew; usum = unsum;
                     FORK(k) { u[k] = tt[k]; Mu[k] = Mn[k]; Cu[k] = Cn[k]; }
-                    ++inner_iters;
-                    if (du < P.tol_u || fabs(deltaF) < P.tol_F) break;
+                    ++inner_iters; ++j;
+                    if (!(du < P.tol_u || fabs(deltaF) < P.tol_F || !can_next)) {   // the inner loop goes on: its next trial is already out
+                        alpha = 1.0; k2 = 0;
+                        FORK(k) tt[k] = ta[k];
+                        nr = sqrt(r6[4]); s1cur = r6[5]; xcur = xvb; bmcur = bmb; mpcur = (uint32_t)r6[7];
+                        continue;
+                    }
+                    if (!(alive = d_ratio(true, r4))) break;    // end of the inner loop: homotopy update of d
+                    if (r4[1] > 0.0) d += r4[0] / r4[1]; else break;
+                    ++i;
+                    if (i >= P.maxoliters) break;
+                    new_outer = true;
                 }
-                if (!alive) break;
-                if (!(alive = d_ratio(true, r4))) break;
-                if (r4[1] > 0.0) d += r4[0] / r4[1]; else break;
+                if (new_outer) {                                // first trial of an inner loop: nothing to overlap it with
+                    F = r4[2] + d * r4[3];                      // u . gradF at the new d
+                    alpha = 1.0; j = 0; k2 = 0;
+                    double r2[3] = {0.0, 0.0, 0.0};
+                    trial(u, Mu, Cu, usum, alpha, tt, r2[0], r2[1], r2[2]);
+                    publish(xva, bma, tt);
+                    WMARK(0);
+                    if (!(alive = (wide_reduce<3, 1>(r2, sh, slots, wb, ltid)))) break;
+                    WMARK(1);
+                    nr = sqrt(r2[0]); s1cur = r2[1]; xcur = xva; bmcur = bma; mpcur = (uint32_t)r2[2];
+                    phase = PH_TRIAL;
+                }
             }
-        } while (false);
+        }
         if (!alive) {                                            // a grid barrier timed out: give up, say so
             if (blockIdx.x == 0 && ltid == 0) {
                 for (int t = 0; t < 16; ++t) O.T_out[(int64_t)b * 16 + t] = d_nan();
@@ -2862,14 +3046,21 @@ __global__ void __launch_bounds__(WIDE_NT) k_solve_wide(DevParams D, int B, cons
         if (i >= P.maxoliters) status |= ROMAN_ST_MAXITER;
         S.n_pass = n_pass; S.ls_trials = ls_trials; S.inner_iters = inner_iters;
         S.outer_iters = i; S.score = F; S.d_final = d;
+#ifdef ROMAN_SOLVE_TIMING
+        WMARK(6);
+        if (blockIdx.x == 0 && ltid == 0 && O.dbg) {            // 100 MHz ticks -> the host prints them as "cycles": x 10 ns
+            unsigned long long* dg = O.dbg + (size_t)b * 16;
+            for (int t = 0; t < 8; ++t) { dg[t] = wacc[t]; dg[8 + t] = wcnt[t]; }
+        }
+#endif
+#undef WMARK
         // final u by position for the shared tail (plain stores + one release); workgroup 0 selects and writes the pose
         FORK(k) if (in[k]) vU[rb + ((gw + k * NWG) << 6) + lane] = u[k];
-        if (!wide_sync<true>(sh, bar, epoch, G, ltid)) return;
+        if (!wide_sync<true>(sh, wb, ltid)) return;
         if (blockIdx.x == 0)
             finish_one(D, b, pd, feats, assoc, plp, lp, rowPosPool, permPool, O, L > 0 ? vU + rb : nullptr, vS0 + rb,
                        reinterpret_cast<int32_t*>(vS1 + rb), reinterpret_cast<int32_t*>(vS2 + rb), L, rb, lo, F, status, S, sh.red, sh.sint);
 #undef CUMW
-#undef WIDE_QS
 #undef FORK
     }
 }

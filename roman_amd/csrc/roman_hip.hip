@@ -72,7 +72,7 @@ struct roman_ctx {
         DevBuf lp, li, lj, ls, ld, lza, lzb;                       // per live association, live order
         DevBuf plp, pli, plj, pls, pld, plza, plzb;                // the same in position order (stream layout)
         DevBuf rowCnt, rowPos, perm, sliceWidth, sliceBase, items, maskPool, prefPool, listPool, listOff;
-        DevBuf vMu, vCu, vMun, vCun, gU, gUn, uOut, nodesOrig, nSel, widePart, wideSlots, wideBar;
+        DevBuf vMu, vCu, vMun, vCun, gU, gUn, uOut, nodesOrig, nSel, widePart, wideSlots, wideBar, wideBm;
         DevBuf cols16, cols32, vals;
         long long capMaskWords = 0, capNnz = 0, capList = 0;       // what the sparse pools hold (elements)
         // staging for the host-pointer entry points
@@ -531,13 +531,13 @@ int enqueue_score(roman_ctx* c, const DevParams& Din, const roman_params_t* para
         // fallback layout (symmetric SELL-64, 32-bit indices) for the problems the stream layout does not take: only when
         // one can exist (the kernel would find no work otherwise)
         if (D.allow_fallback && (SZ.maxA > D.stream_maxL || D.p.maxiniters < 1 || D.p.maxlsiters < 1)) {
-            const int colBytesG = D.gravity ? 36 : 20;
+            const int colBytesG = D.gravity ? 40 : 24;
             const size_t ringLds = (size_t)16 * 3 * FILL_Q * sizeof(uint32_t);
             int TCf = (int)std::min<size_t>((c->lds_max - ringLds) / colBytesG, 32768) & ~63;
             TCf = std::min(TCf, Lneed);
             const size_t fillLds = ringLds + (size_t)TCf * colBytesG;
             const int fillGrid = c->num_cu * std::max(1, std::min(2, (int)(c->lds_max / fillLds)));
-            auto kg = D.gravity ? k_fill<true, uint32_t, false> : k_fill<false, uint32_t, false>;
+            auto kg = D.gravity ? k_fill<true, uint32_t, true> : k_fill<false, uint32_t, true>;
             HIPCHK(c, dyn_lds(c, reinterpret_cast<const void*>(kg), fillLds));
             hipLaunchKernelGGL(kg, dim3(fillGrid), dim3(1024), fillLds, WS.stream, D, dP, dS, dT, WS.items.as<ItemDesc>(), WS.tabPool.as<double>(),
                                LP.li, LP.lj, LP.ls, LP.lza, LP.lzb,
@@ -605,30 +605,40 @@ int enqueue_solve(roman_ctx* c, const DevParams& D, int B, int64_t sumA, int64_t
                     (wideEnv ? wideEnv[0] == '1' : mayFallback <= std::max(1, c->num_cu / 16));
         if (coop) {
             const int G = c->num_cu, NWG = G * WIDE_NW;
-            const size_t partDoubles = ((size_t)NWG + (size_t)(maxA + 63) / 64 + 2) * 64 * 2;
+            const size_t partDoubles = ((size_t)NWG * WIDE_MAXCH + (size_t)(maxA + 63) / 64 + 4) * 64 * 2;    // pieces: chunks + slices
             HIPCHK(c, WS.widePart.ensure(sizeof(double) * partDoubles));
             HIPCHK(c, WS.wideSlots.ensure(sizeof(double) * 2 * (size_t)G * WIDE_NRED));
-            HIPCHK(c, WS.wideBar.ensure(sizeof(unsigned) * 4));
-            HIPCHK(c, hipMemsetAsync(WS.wideBar.p, 0, sizeof(unsigned) * 4, WS.stream));      // arrivals and the abort flag start at 0 in every launch
+            HIPCHK(c, WS.wideBar.ensure(sizeof(unsigned) * WIDE_BAR_WORDS));
+            HIPCHK(c, hipMemsetAsync(WS.wideBar.p, 0, sizeof(unsigned) * WIDE_BAR_WORDS, WS.stream));      // counters, generations and the abort flag start at 0 in every launch
             DevParams Dv = D; int Bv = B;
             const ProbDesc* a_probs = WS.probs.as<ProbDesc>(); ProbState* a_state = WS.state.as<ProbState>();
             const double* a_feats = feats; const int32_t* a_assoc = assoc;
             const int32_t* a_lp = WS.lp.as<int32_t>(); const double* a_ld = WS.ld.as<double>();
             const uint32_t* a_perm = WS.perm.as<uint32_t>(); const uint32_t* a_rpos = WS.rowPos.as<uint32_t>(); const uint32_t* a_sb = WS.sliceBase.as<uint32_t>();
             const uint32_t* a_cols = WS.cols32.as<uint32_t>(); const double* a_vals = WS.vals.as<double>();
-            double* a_vU = WS.gU.as<double>(); double* a_vX = WS.gUn.as<double>();
+            double* a_vU = WS.gU.as<double>(); double* a_vX = WS.gUn.as<double>(); double* a_vX2 = WS.vCun.as<double>();
             double* a_s0 = WS.vMu.as<double>(); double* a_s1 = WS.vCu.as<double>(); double* a_s2 = WS.vMun.as<double>();
             int32_t* a_plp = WS.plp.as<int32_t>();
             const double* a_u0 = u0; SolveOut a_O = O;
             double* a_part = WS.widePart.as<double>(); double* a_slots = WS.wideSlots.as<double>(); unsigned* a_bar = WS.wideBar.as<unsigned>();
+            // dynamic LDS: the support bit map of the gathered vector + its leading part (everything the static part leaves of the 160 KB)
+            int a_bmw = (int)((maxA + 63) / 64) + 1;
+            HIPCHK(c, WS.wideBm.ensure(sizeof(unsigned long long) * 2 * (size_t)a_bmw));
+            unsigned long long* a_bm = WS.wideBm.as<unsigned long long>();
+            int a_xcap = (int)(((int64_t)c->lds_max - 4096 - 8 * (int64_t)a_bmw) / (int64_t)sizeof(double)) & ~63;
+            if (a_xcap < 0) a_xcap = 0;
+            const size_t wideLds = sizeof(double) * (size_t)a_xcap + 8 * (size_t)a_bmw;
+            HIPCHK(c, dyn_lds(c, reinterpret_cast<const void*>(k_solve_wide<uint32_t>), wideLds));
+            static const char* tuneEnv = getenv("ROMAN_WIDE_TUNE");
+            int a_tune = tuneEnv ? (int)strtol(tuneEnv, nullptr, 0) : 0;
             void* args[] = {&Dv, &Bv, &a_probs, &a_state, &a_feats, &a_assoc, &a_lp, &a_ld, &a_perm, &a_rpos, &a_sb, &a_cols, &a_vals,
-                            &a_vU, &a_vX, &a_s0, &a_s1, &a_s2, &a_plp, &a_u0, &a_O, &a_part, &a_slots, &a_bar};
+                            &a_vU, &a_vX, &a_vX2, &a_s0, &a_s1, &a_s2, &a_plp, &a_u0, &a_O, &a_part, &a_slots, &a_bar, &a_bm, &a_bmw, &a_xcap, &a_tune};
             // Two whole-device kernels must never be resident together (each would hold compute units while waiting at a
             // grid barrier for workgroups the other one keeps out): with batches in flight on several streams, a
             // launch waits for the previous one of this context.
             if (!c->coopDone) HIPCHK(c, hipEventCreateWithFlags(&c->coopDone, hipEventDisableTiming));
             if (c->coopIssued) HIPCHK(c, hipStreamWaitEvent(WS.stream, c->coopDone, 0));
-            const hipError_t e = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(k_solve_wide<uint32_t>), dim3((unsigned)G), dim3(WIDE_NT), args, 0, WS.stream);
+            const hipError_t e = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(k_solve_wide<uint32_t>), dim3((unsigned)G), dim3(WIDE_NT), args, wideLds, WS.stream);
             if (e == hipSuccess) { HIPCHK(c, hipEventRecord(c->coopDone, WS.stream)); c->coopIssued = true; }
             if (e != hipSuccess) {                              // not available here: the one-workgroup solver does the same work
                 (void)hipGetLastError();
@@ -644,9 +654,9 @@ int enqueue_solve(roman_ctx* c, const DevParams& D, int B, int64_t sumA, int64_t
         const int grid = std::max(1, std::min(B, c->num_cu));
         HIPCHK(c, dyn_lds(c, reinterpret_cast<const void*>(k_solve<uint32_t, 1>), lds));
         hipLaunchKernelGGL((k_solve<uint32_t, 1>), dim3(grid), dim3(1024), lds, WS.stream, D, B, WS.probs.as<ProbDesc>(), WS.state.as<ProbState>(), feats, assoc,
-                           WS.lp.as<int32_t>(), WS.ld.as<double>(), WS.perm.as<uint32_t>(), WS.sliceWidth.as<uint32_t>(), WS.sliceBase.as<uint32_t>(), WS.cols32.as<uint32_t>(), WS.vals.as<double>(),
+                           WS.lp.as<int32_t>(), WS.ld.as<double>(), WS.perm.as<uint32_t>(), WS.rowPos.as<uint32_t>(), WS.sliceWidth.as<uint32_t>(), WS.sliceBase.as<uint32_t>(), WS.cols32.as<uint32_t>(), WS.vals.as<double>(),
                            WS.vMu.as<double>(), WS.vCu.as<double>(), WS.vMun.as<double>(), WS.vCun.as<double>(), WS.gU.as<double>(), WS.gUn.as<double>(),
-                           u0, O, WS.queue.as<int>() + 4, Lcap);
+                           WS.plp.as<int32_t>(), WS.pld.as<double>(), u0, O, WS.queue.as<int>() + 4, Lcap);
         }
     DBG(c, "k_solve");
     }
@@ -659,6 +669,8 @@ int enqueue_solve(roman_ctx* c, const DevParams& D, int B, int64_t sumA, int64_t
         HIPCHK(c, hipStreamSynchronize(WS.stream));
         double acc[16] = {0};
         for (int b = 0; b < B; ++b) for (int t = 0; t < 16; ++t) acc[t] += (double)h[(size_t)b * 16 + t];
+        // (k_solve_up: cycles of the phases named here; k_solve_wide: 10 ns ticks of trial+publish, barrier 1, stream, barrier 2,
+        //  collect+objective, barrier 3, everything else — in slots 0..6)
         const char* nm[8] = {"stream", "spmv-barrier", "decode", "elementwise", "-", "-", "publish", "red-sums"};
         fprintf(stderr, "[solve timing] B=%d cycles/problem:", B);
         double tot_ = 0; for (int t = 0; t < 8; ++t) tot_ += acc[t] / B;
@@ -767,7 +779,7 @@ int solve_last(roman_ctx* c, const double* u0_host)
     return ROMAN_OK;
 }
 
-// Host twin of the fallback branch of k_rowsort: sorted SELL-64 geometry from the row lengths (stable descending sort).
+// Host twin of the fallback branch of k_rowsort: sorted SELL-64 geometry (widths in whole quads) from the row lengths (stable descending sort).
 void sell_geometry(const std::vector<uint32_t>& cnt, int L, std::vector<uint32_t>& rowPos, std::vector<uint32_t>& perm,
                    std::vector<uint32_t>& sliceWidth, std::vector<uint32_t>& sliceBase, uint64_t* total)
 {
@@ -781,6 +793,7 @@ void sell_geometry(const std::vector<uint32_t>& cnt, int L, std::vector<uint32_t
     for (int sl = 0; sl < nsl; ++sl) {
         uint32_t wmax = 0;
         for (int p = sl * 64; p < std::min(L, sl * 64 + 64); ++p) wmax = std::max(wmax, cnt[perm[(size_t)p]]);
+        wmax = (wmax + 3u) & ~3u;                               // quad layout
         sliceWidth[(size_t)sl] = wmax; sliceBase[(size_t)sl] = (uint32_t)acc; acc += (uint64_t)wmax * 64u;
     }
     *total = acc;
@@ -839,9 +852,9 @@ int fetch_last_csr(const roman_ctx* cc, std::vector<uint32_t>& rs, std::vector<u
         for (int k = 0; k < L; ++k) {
             const uint32_t pos = jpos[(size_t)k], sl = pos >> 6, slot = pos & 63u;
             for (uint32_t e = 0; e < jcnt[(size_t)k]; ++e) {
-                const uint32_t cq = jcols[h_col_pos(false, jsb[sl], slot, e)]; const double v = jvals[h_val_pos(false, jsb[sl], slot, e)];
-                if (v == 0.0 && (cq & 0x80000000u) && (int)(cq & 0x7fffffffu) == k) continue;      // inert slot
-                rows[(size_t)k].push_back({cq, v});
+                const uint32_t cq = jcols[h_col_pos(true, jsb[sl], slot, e)]; const double v = jvals[h_val_pos(true, jsb[sl], slot, e)];
+                if (v == 0.0 && (cq & 0x80000000u) && (cq & 0x7fffffffu) == pos) continue;         // inert slot (the row's own position, flagged)
+                rows[(size_t)k].push_back({jperm[(size_t)(cq & 0x7fffffffu)] | (cq & 0x80000000u), v});     // column labels are positions
             }
         }
     }
@@ -926,7 +939,7 @@ int roman_ctx_destroy(roman_ctx_t* c)
         DevBuf* all[] = {&W.probs, &W.state, &W.totals, &W.queue, &W.cosPool, &W.tabPool, &W.sTmp, &W.chunkCnt,
                          &W.lp, &W.li, &W.lj, &W.ls, &W.ld, &W.lza, &W.lzb, &W.plp, &W.pli, &W.plj, &W.pls, &W.pld, &W.plza, &W.plzb,
                          &W.rowCnt, &W.rowPos, &W.perm, &W.sliceWidth, &W.sliceBase, &W.items, &W.maskPool, &W.prefPool, &W.listPool, &W.listOff,
-                         &W.vMu, &W.vCu, &W.vMun, &W.vCun, &W.gU, &W.gUn, &W.uOut, &W.nodesOrig, &W.nSel, &W.widePart, &W.wideSlots, &W.wideBar, &W.cols16, &W.cols32, &W.vals,
+                         &W.vMu, &W.vCu, &W.vMun, &W.vCun, &W.gU, &W.gUn, &W.uOut, &W.nodesOrig, &W.nSel, &W.widePart, &W.wideSlots, &W.wideBar, &W.wideBm, &W.cols16, &W.cols32, &W.vals,
                          &W.hFeats, &W.hAssoc, &W.hU0, &W.oAssoc, &W.oN, &W.oT, &W.oStatus, &W.oStats, &W.hAux1, &W.hAux2, &W.hAux3};
         for (DevBuf* b : all) b->release();
         if (W.pinnedTotals) (void)hipHostFree(W.pinnedTotals);
@@ -1274,7 +1287,7 @@ int roman_set_matrix_data(roman_ctx_t* c, const roman_params_t* params, const do
                 }
             }
     } else {
-        // fallback layout: symmetric sorted SELL-64 in the caller's numbering, 32-bit indices
+        // fallback layout: symmetric sorted SELL-64 in quads, the caller's numbering, 32-bit indices
         sell_geometry(deg, n, rowPos, perm, sliceWidth, sliceBase, &total);
         if (total > 4000000000ull) return fail(c, ROMAN_E_TOO_LARGE, "dense matrix has too many non-zeros");
         c32.assign((size_t)std::max<uint64_t>(total, 1), 0); jvals.assign((size_t)std::max<uint64_t>(total, 1), 0.0);
@@ -1282,11 +1295,13 @@ int roman_set_matrix_data(roman_ctx_t* c, const roman_params_t* params, const do
             for (uint32_t slot = 0; slot < 64; ++slot) {
                 const int pos = sl * 64 + (int)slot;
                 const int k = pos < n ? (int)perm[(size_t)pos] : -1;                 // -1: lane slot without a row
-                const uint32_t inert = (uint32_t)std::max(k, 0) | 0x80000000u;
+                const uint32_t inert = (uint32_t)(k >= 0 ? pos : 0) | 0x80000000u;       // the row's own position, flagged
                 for (uint32_t e = 0; e < sliceWidth[(size_t)sl]; ++e) {
-                    const size_t pc = h_col_pos(false, sliceBase[(size_t)sl], slot, e), pv = h_val_pos(false, sliceBase[(size_t)sl], slot, e);
-                    if (k >= 0 && e < deg[(size_t)k]) { c32[pc] = rows[(size_t)k][e].first; jvals[pv] = rows[(size_t)k][e].second; }
-                    else { c32[pc] = inert; jvals[pv] = 0.0; }
+                    const size_t pc = h_col_pos(true, sliceBase[(size_t)sl], slot, e), pv = h_val_pos(true, sliceBase[(size_t)sl], slot, e);
+                    if (k >= 0 && e < deg[(size_t)k]) {          // column label = POSITION of the column (+ the C flag)
+                        const uint32_t cw = rows[(size_t)k][e].first;
+                        c32[pc] = rowPos[cw & 0x7fffffffu] | (cw & 0x80000000u); jvals[pv] = rows[(size_t)k][e].second;
+                    } else { c32[pc] = inert; jvals[pv] = 0.0; }
                 }
             }
         for (int k = 0; k < n; ++k) rowCnt[(size_t)k] = deg[(size_t)k];

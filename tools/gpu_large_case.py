@@ -23,12 +23,18 @@ ctx = Context(0); reg.set_context(ctx)
 big = synth.make_pair(n, n, 0, 7001, tilt_deg=1.0)
 say("warm-up (small problem)")
 reg.register_and_align_batch([(synth.make_pair(20, 20, 0, 1).map1, synth.make_pair(20, 20, 0, 1).map2)])
-for rep in range(2):
+for rep in range(3):
+    ctx.profile_enable(True); ctx.profile_reset()
     t = time.perf_counter()
     res = reg.register_and_align_batch([(big.map1, big.map2)])
     dt = time.perf_counter() - t
-    say(f"(a) gravity n=m={n}: {dt*1e3:.1f} ms  status={res.status[0]} L={res.stats['n_live'][0]} nnz_upper={res.stats['nnz_upper'][0]} "
-        f"passes={res.stats['n_pass'][0]} selected={len(res.assoc[0])}")
+    prof = ctx.profile_get(); ctx.profile_enable(False)
+    npass = int(res.stats['n_pass'][0]); nnz = int(res.stats['nnz_upper'][0]); Lv = int(res.stats['n_live'][0])
+    solve_ms = prof["solve"][0]
+    alg = npass * (12.0 * nnz + 24.0 * Lv)
+    say(f"(a) gravity n=m={n}: {dt*1e3:.1f} ms  status={res.status[0]} L={Lv} nnz_upper={nnz} passes={npass} selected={len(res.assoc[0])}  "
+        f"stages ms: " + " ".join(f"{k}={v[0]:.2f}" for k, v in prof.items()) +
+        f" | solve {solve_ms*1e3/max(npass,1):.1f} us/pass, algorithmic {alg/1e9:.2f} GB -> {alg/max(solve_ms,1e-9)/1e6:.0f} GB/s = {alg/max(solve_ms,1e-9)/1e6/8000:.3f} of 8 TB/s")
 truth = set(map(tuple, big.inliers.tolist()))
 say("planted inliers recovered:", len(truth & set(map(tuple, res.assoc[0].tolist()))), "of", len(truth))
 if check:
