@@ -52,6 +52,8 @@ struct DevParams {
     int32_t keep_all;   // single scores present but a zero one removes nothing (ROMAN_SINGLE_DIAG_KEEP): every association is live
     int32_t allow_fallback;  // the fallback kernels are part of this launch; otherwise a problem that does not fit the stream layout is
                              // SKIPPED (kind 2, ROMAN_ST_WORKSPACE) and runs again with them (set per launch, from the sizing history)
+    int32_t wide;            // fallback problems of this launch go to k_solve_wide (few, large) instead of k_solve (set per launch)
+    int32_t idx16;           // ... and their column labels are 16 bits wide (no C flag; 0xffff = inert): 10 instead of 12 bytes per entry
     int32_t stream_maxL;     // problems of up to this many live associations take the stream layout (<= STREAM_MAXL; set per launch:
                              // it is also the column capacity of k_fill_slice's LDS tile and of the stream solver's LDS vectors)
 };
@@ -101,6 +103,13 @@ struct ItemDesc { int32_t b, row0; };   // a block of consecutive live rows of p
 template <typename IdxT> struct IdxTraits;
 template <> struct IdxTraits<uint16_t> { static constexpr uint32_t CZ = 0x8000u; static constexpr uint32_t MASK = 0x7fffu; };
 template <> struct IdxTraits<uint32_t> { static constexpr uint32_t CZ = 0x80000000u; static constexpr uint32_t MASK = 0x7fffffffu; };
+
+// Fallback layout, column word of an inert entry (padding / filtered): 32-bit words carry the row's own position with the C
+// flag (a real vector element, excluded from C); 16-bit words (k_solve_wide only, no flag bit) are 0xffff = "no column".
+template <typename IdxT> __device__ __forceinline__ IdxT fb_inert(uint32_t pos)
+{
+    return sizeof(IdxT) == 2 ? (IdxT)0xffffu : (IdxT)(pos | IdxTraits<IdxT>::CZ);
+}
 
 // Position of entry e of the row in lane-slot `slot` of a slice that starts at element `sbase` of the
 // problem's matrix segment (sbase is a multiple of 256 in the quad layout, of 64 otherwise).
@@ -1222,7 +1231,7 @@ __device__ __forceinline__ uint32_t fill_item(const DevParams& D, const ProbDesc
             uint32_t base, pk, pq;                              // slice base + lane slot (base is a multiple of 64); positions of row and column
             if (LDSCOL) { base = cBase[k]; pk = cPos[k]; pq = cPos[q]; }
             else { pk = rowPos[k]; pq = rowPos[q]; base = sliceBase[pk >> 6] + (pk & 63u); }
-            cols[col_pos<QUAD>(base & ~63u, base & 63u, e)] = keep ? (IdxT)pq : (IdxT)(pk | IdxTraits<IdxT>::CZ);
+            cols[col_pos<QUAD>(base & ~63u, base & 63u, e)] = keep ? (IdxT)pq : fb_inert<IdxT>(pk);
             vals[val_pos<QUAD>(base & ~63u, base & 63u, e)] = keep ? v : 0.0;
             upper += (keep && q > k) ? 1u : 0u;
         }
@@ -1333,7 +1342,7 @@ __global__ void __launch_bounds__(1024) k_fill(DevParams D, const ProbDesc* __re
             const uint32_t width = sliceWidth[lo + (pos >> 6)];
             const int64_t sb = no + sliceBase[lo + (pos >> 6)];
             for (uint32_t e = rowCnt[lo + k] + lane; e < width; e += WAVE) {
-                cols[col_pos<QUAD>(sb, pos & 63u, e)] = (IdxT)(pos | IdxTraits<IdxT>::CZ);
+                cols[col_pos<QUAD>(sb, pos & 63u, e)] = fb_inert<IdxT>(pos);
                 vals[val_pos<QUAD>(sb, pos & 63u, e)] = 0.0;
             }
         }
@@ -1344,7 +1353,7 @@ __global__ void __launch_bounds__(1024) k_fill(DevParams D, const ProbDesc* __re
             const uint32_t nfree = 64u - (uint32_t)(L & 63);
             for (uint32_t x = tid; x < nfree * width; x += nt) {
                 const uint32_t slot = (uint32_t)(L & 63) + x / width, e = x % width;
-                cols[col_pos<QUAD>(sb, slot, e)] = (IdxT)(IdxTraits<IdxT>::CZ);          // (column 0, flagged: gathers a real element, adds nothing)
+                cols[col_pos<QUAD>(sb, slot, e)] = fb_inert<IdxT>(0u);                   // (column 0, flagged: gathers a real element, adds nothing)
                 vals[val_pos<QUAD>(sb, slot, e)] = 0.0;
             }
         }
@@ -2825,10 +2834,12 @@ __global__ void __launch_bounds__(WIDE_NT) k_solve_wide(DevParams D, int B, cons
         // per lane and quad), the next block's matrix loads in flight while the current block gathers and accumulates.
         auto piece = [&](const double* xv, uint32_t nl, uint32_t t, uint32_t stop, uint32_t pid) {
             double am = 0.0, ac = 0.0;
-            const uint4_t* cp = reinterpret_cast<const uint4_t*>(cols) + (size_t)t * 64 + lane;
+            constexpr bool W16 = sizeof(IdxT) == 2;              // 16-bit column words: 8 bytes per lane and quad, no C flag, 0xffff = no column
+            typedef typename std::conditional<W16, unsigned long long, uint4_t>::type cword_t;
+            const cword_t* cp = reinterpret_cast<const cword_t*>(cols) + (size_t)t * 64 + lane;
             const dbl2_t* vp = reinterpret_cast<const dbl2_t*>(vals) + (size_t)t * 128 + lane;
             const uint32_t n = stop - t;
-            uint4_t cA[WIDE_U], cB[WIDE_U]; dbl2_t vA0[WIDE_U], vA1[WIDE_U], vB0[WIDE_U], vB1[WIDE_U];
+            cword_t cA[WIDE_U], cB[WIDE_U]; dbl2_t vA0[WIDE_U], vA1[WIDE_U], vB0[WIDE_U], vB1[WIDE_U];
 #define WIDE_ISSUE(C_, V0_, V1_, off_, n_)                                                                    \
             _Pragma("unroll") for (int e = 0; e < WIDE_U; ++e) {                                              \
                 const uint32_t q_ = (off_) + min((uint32_t)e, (n_) - 1u);     /* clamped: a repeated quad is skipped by the consumer */ \
@@ -2838,15 +2849,18 @@ __global__ void __launch_bounds__(WIDE_NT) k_solve_wide(DevParams D, int B, cons
 #define WIDE_CONSUME(C_, V0_, V1_, n_)                                                                        \
             _Pragma("unroll") for (int e = 0; e < WIDE_U; ++e) {                                              \
                 if ((uint32_t)e < (n_)) {                                                                     \
-                    const uint32_t c4[4] = {C_[e].x, C_[e].y, C_[e].z, C_[e].w};                              \
+                    uint32_t c4[4];                                                                           \
+                    if constexpr (W16) { const unsigned long long cw_ = *reinterpret_cast<const unsigned long long*>(&C_[e]); \
+                        c4[0] = (uint32_t)(cw_ & 0xffffu); c4[1] = (uint32_t)((cw_ >> 16) & 0xffffu); c4[2] = (uint32_t)((cw_ >> 32) & 0xffffu); c4[3] = (uint32_t)(cw_ >> 48); } \
+                    else { const uint4_t cw_ = *reinterpret_cast<const uint4_t*>(&C_[e]); c4[0] = cw_.x; c4[1] = cw_.y; c4[2] = cw_.z; c4[3] = cw_.w; } \
                     const double v4[4] = {V0_[e].x, V0_[e].y, V1_[e].x, V1_[e].y};                            \
                     _Pragma("unroll") for (int h = 0; h < 4; ++h) {                                           \
-                        const uint32_t ci = c4[h] & IdxTraits<IdxT>::MASK;                                    \
+                        const uint32_t ci = W16 ? c4[h] : (c4[h] & 0x7fffffffu);                              \
                         double uq = 0.0;                                                                      \
                         if (ci < nl) uq = xl[ci];                                                             \
-                        else if ((bml[ci >> 6] >> (ci & 63u)) & 1ull) uq = xv[ci];                            \
+                        else if (ci < (uint32_t)L && ((bml[ci >> 6] >> (ci & 63u)) & 1ull)) uq = xv[ci];     \
                         am = fma(v4[h], uq, am);                                                              \
-                        ac += (c4[h] & IdxTraits<IdxT>::CZ) ? 0.0 : uq;                                       \
+                        ac += (!W16 && (c4[h] & 0x80000000u)) ? 0.0 : uq;                                     \
                     }                                                                                         \
                 }                                                                                             \
             }

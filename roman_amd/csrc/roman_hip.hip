@@ -316,6 +316,8 @@ void estimate_sizes(roman_ctx* c, const DevParams& D, const roman_params_t* para
     if (tcap && !H.valid) S->capNnz = atoll(tcap);
 }
 
+int may_fallback(const DevParams& D, const std::vector<ProbDesc>& hd);
+
 // ---- the launch sequence of one batch (score + solve), on workspace c->cur and its stream; never waits -------------
 struct BatchOut { int32_t kmax; int32_t* assoc_out; int32_t* n_assoc_out; double* T_out; int32_t* status_out; roman_stats_t* stats_out; };
 
@@ -363,6 +365,16 @@ int enqueue_score(roman_ctx* c, const DevParams& Din, const roman_params_t* para
     // problem that turns out too large for the LDS tiles of this launch is skipped (ROMAN_ST_WORKSPACE) and, the
     // history corrected, takes them on its second run.
     D.allow_fallback = (!c->hist.valid || SZ.expectMaxL > D.stream_maxL || D.p.maxiniters < 1 || D.p.maxlsiters < 1) ? 1 : 0;
+    {   // Which solver takes the fallback problems: few (large) ones -> k_solve_wide, every compute unit on one problem at a
+        // time; many -> k_solve, one workgroup per problem.  Decided here because the fill writes 16-bit column labels for
+        // the wide solver when every position fits (10 instead of 12 bytes per entry of the stream it is bound by).
+        static const char* wideEnv = getenv("ROMAN_WIDE");      // "0": never, "1": whenever a fallback problem can exist
+        const int mayFb = may_fallback(D, hd);
+        D.wide = (c->coop_ok && mayFb > 0 && D.p.maxiniters >= 1 && D.p.maxlsiters >= 1 && maxA <= (int64_t)WIDE_KW * c->num_cu * WIDE_NW * 64 &&
+                  (wideEnv ? wideEnv[0] == '1' : mayFb <= std::max(1, c->num_cu / 16))) ? 1 : 0;
+        static const char* i16Env = getenv("ROMAN_WIDE_IDX16");  // "0": 32-bit labels always
+        D.idx16 = (D.wide && maxA <= 65534 && !(i16Env && i16Env[0] == '0')) ? 1 : 0;
+    }
     *Dout = D;
 
     HIPCHK(c, WS.probs.ensure(sizeof(ProbDesc) * (size_t)B));
@@ -537,12 +549,21 @@ int enqueue_score(roman_ctx* c, const DevParams& Din, const roman_params_t* para
             TCf = std::min(TCf, Lneed);
             const size_t fillLds = ringLds + (size_t)TCf * colBytesG;
             const int fillGrid = c->num_cu * std::max(1, std::min(2, (int)(c->lds_max / fillLds)));
-            auto kg = D.gravity ? k_fill<true, uint32_t, true> : k_fill<false, uint32_t, true>;
-            HIPCHK(c, dyn_lds(c, reinterpret_cast<const void*>(kg), fillLds));
-            hipLaunchKernelGGL(kg, dim3(fillGrid), dim3(1024), fillLds, WS.stream, D, dP, dS, dT, WS.items.as<ItemDesc>(), WS.tabPool.as<double>(),
-                               LP.li, LP.lj, LP.ls, LP.lza, LP.lzb,
-                               WS.rowCnt.as<uint32_t>(), WS.maskPool.as<unsigned long long>(), WS.prefPool.as<uint32_t>(), WS.rowPos.as<uint32_t>(),
-                               WS.sliceWidth.as<uint32_t>(), WS.sliceBase.as<uint32_t>(), WS.cols32.as<uint32_t>(), WS.vals.as<double>(), TCf, RPB);
+            if (D.idx16) {                                      // 16-bit column labels for k_solve_wide
+                auto kg = D.gravity ? k_fill<true, uint16_t, true> : k_fill<false, uint16_t, true>;
+                HIPCHK(c, dyn_lds(c, reinterpret_cast<const void*>(kg), fillLds));
+                hipLaunchKernelGGL(kg, dim3(fillGrid), dim3(1024), fillLds, WS.stream, D, dP, dS, dT, WS.items.as<ItemDesc>(), WS.tabPool.as<double>(),
+                                   LP.li, LP.lj, LP.ls, LP.lza, LP.lzb,
+                                   WS.rowCnt.as<uint32_t>(), WS.maskPool.as<unsigned long long>(), WS.prefPool.as<uint32_t>(), WS.rowPos.as<uint32_t>(),
+                                   WS.sliceWidth.as<uint32_t>(), WS.sliceBase.as<uint32_t>(), WS.cols16.as<uint16_t>(), WS.vals.as<double>(), TCf, RPB);
+            } else {
+                auto kg = D.gravity ? k_fill<true, uint32_t, true> : k_fill<false, uint32_t, true>;
+                HIPCHK(c, dyn_lds(c, reinterpret_cast<const void*>(kg), fillLds));
+                hipLaunchKernelGGL(kg, dim3(fillGrid), dim3(1024), fillLds, WS.stream, D, dP, dS, dT, WS.items.as<ItemDesc>(), WS.tabPool.as<double>(),
+                                   LP.li, LP.lj, LP.ls, LP.lza, LP.lzb,
+                                   WS.rowCnt.as<uint32_t>(), WS.maskPool.as<unsigned long long>(), WS.prefPool.as<uint32_t>(), WS.rowPos.as<uint32_t>(),
+                                   WS.sliceWidth.as<uint32_t>(), WS.sliceBase.as<uint32_t>(), WS.cols32.as<uint32_t>(), WS.vals.as<double>(), TCf, RPB);
+            }
     DBG(c, "k_fill");
         }
     }
@@ -600,9 +621,7 @@ int enqueue_solve(roman_ctx* c, const DevParams& D, int B, int64_t sumA, int64_t
         HIPCHK(c, WS.gU.ensure(sizeof(double) * R1)); HIPCHK(c, WS.gUn.ensure(sizeof(double) * R1));
         // Few (large) problems: all compute units solve them together, one after the other (k_solve_wide, cooperative
         // launch so that every workgroup is resident); many: one workgroup per problem, u and u' in LDS when they fit.
-        static const char* wideEnv = getenv("ROMAN_WIDE");      // "0": never, "1": whenever a fallback problem can exist
-        bool coop = c->coop_ok && D.p.maxiniters >= 1 && D.p.maxlsiters >= 1 && maxA <= (int64_t)WIDE_KW * c->num_cu * WIDE_NW * 64 &&
-                    (wideEnv ? wideEnv[0] == '1' : mayFallback <= std::max(1, c->num_cu / 16));
+        bool coop = D.wide != 0 && c->coop_ok;                  // decided when the batch was scored (enqueue_score / roman_set_matrix_data)
         if (coop) {
             const int G = c->num_cu, NWG = G * WIDE_NW;
             const size_t partDoubles = ((size_t)NWG * WIDE_MAXCH + (size_t)(maxA + 63) / 64 + 4) * 64 * 2;    // pieces: chunks + slices
@@ -615,7 +634,7 @@ int enqueue_solve(roman_ctx* c, const DevParams& D, int B, int64_t sumA, int64_t
             const double* a_feats = feats; const int32_t* a_assoc = assoc;
             const int32_t* a_lp = WS.lp.as<int32_t>(); const double* a_ld = WS.ld.as<double>();
             const uint32_t* a_perm = WS.perm.as<uint32_t>(); const uint32_t* a_rpos = WS.rowPos.as<uint32_t>(); const uint32_t* a_sb = WS.sliceBase.as<uint32_t>();
-            const uint32_t* a_cols = WS.cols32.as<uint32_t>(); const double* a_vals = WS.vals.as<double>();
+            const void* a_cols = D.idx16 ? (const void*)WS.cols16.as<uint16_t>() : (const void*)WS.cols32.as<uint32_t>(); const double* a_vals = WS.vals.as<double>();
             double* a_vU = WS.gU.as<double>(); double* a_vX = WS.gUn.as<double>(); double* a_vX2 = WS.vCun.as<double>();
             double* a_s0 = WS.vMu.as<double>(); double* a_s1 = WS.vCu.as<double>(); double* a_s2 = WS.vMun.as<double>();
             int32_t* a_plp = WS.plp.as<int32_t>();
@@ -628,7 +647,8 @@ int enqueue_solve(roman_ctx* c, const DevParams& D, int B, int64_t sumA, int64_t
             int a_xcap = (int)(((int64_t)c->lds_max - 4096 - 8 * (int64_t)a_bmw) / (int64_t)sizeof(double)) & ~63;
             if (a_xcap < 0) a_xcap = 0;
             const size_t wideLds = sizeof(double) * (size_t)a_xcap + 8 * (size_t)a_bmw;
-            HIPCHK(c, dyn_lds(c, reinterpret_cast<const void*>(k_solve_wide<uint32_t>), wideLds));
+            const void* wideFn = D.idx16 ? reinterpret_cast<const void*>(k_solve_wide<uint16_t>) : reinterpret_cast<const void*>(k_solve_wide<uint32_t>);
+            HIPCHK(c, dyn_lds(c, wideFn, wideLds));
             static const char* tuneEnv = getenv("ROMAN_WIDE_TUNE");
             int a_tune = tuneEnv ? (int)strtol(tuneEnv, nullptr, 0) : 0;
             void* args[] = {&Dv, &Bv, &a_probs, &a_state, &a_feats, &a_assoc, &a_lp, &a_ld, &a_perm, &a_rpos, &a_sb, &a_cols, &a_vals,
@@ -638,12 +658,13 @@ int enqueue_solve(roman_ctx* c, const DevParams& D, int B, int64_t sumA, int64_t
             // launch waits for the previous one of this context.
             if (!c->coopDone) HIPCHK(c, hipEventCreateWithFlags(&c->coopDone, hipEventDisableTiming));
             if (c->coopIssued) HIPCHK(c, hipStreamWaitEvent(WS.stream, c->coopDone, 0));
-            const hipError_t e = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(k_solve_wide<uint32_t>), dim3((unsigned)G), dim3(WIDE_NT), args, wideLds, WS.stream);
+            const hipError_t e = hipLaunchCooperativeKernel(wideFn, dim3((unsigned)G), dim3(WIDE_NT), args, wideLds, WS.stream);
             if (e == hipSuccess) { HIPCHK(c, hipEventRecord(c->coopDone, WS.stream)); c->coopIssued = true; }
             if (e != hipSuccess) {                              // not available here: the one-workgroup solver does the same work
                 (void)hipGetLastError();
                 fprintf(stderr, "[roman_hip] cooperative launch failed (%s); large problems use the single-workgroup solver\n", hipGetErrorString(e));
                 c->coop_ok = false; coop = false;
+                if (D.idx16) return fail(c, ROMAN_E_HIP, "cooperative launch of the large-problem solver failed (%s); run the call again (it now takes the single-workgroup solver)", hipGetErrorString(e));
             }
     DBG(c, "k_solve_wide");
         }
@@ -830,6 +851,10 @@ int fetch_last_csr(const roman_ctx* cc, std::vector<uint32_t>& rs, std::vector<u
             std::vector<uint16_t> c16((size_t)cap);
             HIPCHK(c, hipMemcpy(c16.data(), W0.cols16.p, sizeof(uint16_t) * (size_t)cap, hipMemcpyDeviceToHost));
             for (int64_t k = 0; k < cap; ++k) jcols[(size_t)k] = (c16[(size_t)k] & 0x8000u) ? (0x80000000u | (c16[(size_t)k] & 0x7fffu)) : c16[(size_t)k];
+        } else if (Lst.D.idx16) {                               // fallback layout with 16-bit labels: 0xffff = inert
+            std::vector<uint16_t> c16((size_t)cap);
+            HIPCHK(c, hipMemcpy(c16.data(), W0.cols16.p, sizeof(uint16_t) * (size_t)cap, hipMemcpyDeviceToHost));
+            for (int64_t k = 0; k < cap; ++k) jcols[(size_t)k] = (c16[(size_t)k] == 0xffffu) ? 0xffffffffu : (uint32_t)c16[(size_t)k];
         } else {
             HIPCHK(c, hipMemcpy(jcols.data(), W0.cols32.p, sizeof(uint32_t) * (size_t)cap, hipMemcpyDeviceToHost));
         }
@@ -853,7 +878,7 @@ int fetch_last_csr(const roman_ctx* cc, std::vector<uint32_t>& rs, std::vector<u
             const uint32_t pos = jpos[(size_t)k], sl = pos >> 6, slot = pos & 63u;
             for (uint32_t e = 0; e < jcnt[(size_t)k]; ++e) {
                 const uint32_t cq = jcols[h_col_pos(true, jsb[sl], slot, e)]; const double v = jvals[h_val_pos(true, jsb[sl], slot, e)];
-                if (v == 0.0 && (cq & 0x80000000u) && (cq & 0x7fffffffu) == pos) continue;         // inert slot (the row's own position, flagged)
+                if (cq == 0xffffffffu || (v == 0.0 && (cq & 0x80000000u) && (cq & 0x7fffffffu) == pos)) continue;   // inert slot (16-bit: no column; 32-bit: the row's own position, flagged)
                 rows[(size_t)k].push_back({jperm[(size_t)(cq & 0x7fffffffu)] | (cq & 0x80000000u), v});     // column labels are positions
             }
         }
@@ -1227,6 +1252,8 @@ int roman_set_matrix_data(roman_ctx_t* c, const roman_params_t* params, const do
     int rc = make_dev_params(c, &p, p.point_dim, &Lst.D);
     if (rc) return rc;
     const bool up = n <= STREAM_MAXL && Lst.D.p.maxiniters >= 1 && Lst.D.p.maxlsiters >= 1;
+    Lst.D.wide = (!up && c->coop_ok && Lst.D.p.maxiniters >= 1 && Lst.D.p.maxlsiters >= 1 && n <= (int64_t)WIDE_KW * c->num_cu * WIDE_NW * 64) ? 1 : 0;
+    Lst.D.idx16 = 0;                                           // dense problems may carry C flags: 32-bit labels
     Lst.D.stream_maxL = up ? std::max(64, (n + 63) & ~63) : 64;
     // full-symmetric rows over the union pattern of the strict upper triangles of M and C (like upstream only the
     // strict upper triangles are read)
