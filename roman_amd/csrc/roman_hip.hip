@@ -99,7 +99,8 @@ struct roman_ctx {
 
     // sizing history: largest observed need relative to what the host can bound before the launch
     struct Hist {
-        bool valid = false;
+        bool valid = false;                    // at least one batch of this block has reported its totals
+        bool tagged = false;                   // params / F below are set
         roman_params_t params; int32_t F = 0;  // the ratios belong to this parameter block
         double rMaxL = 0.0;                    // largest live set / largest association list
         double rMask = 0.0;                    // bit-matrix words / sum of nA * ceil(nA / 64)
@@ -285,8 +286,8 @@ void harvest_totals(roman_ctx* c, bool wait)
 void estimate_sizes(roman_ctx* c, const DevParams& D, const roman_params_t* params, int32_t F, const std::vector<ProbDesc>& hd, Sizing* S)
 {
     roman_ctx::Hist& H = c->hist;
-    if (!H.valid || H.F != F || memcmp(&H.params, params, sizeof(roman_params_t)) != 0) {   // other parameters: other ratios
-        H = roman_ctx::Hist{}; H.params = *params; H.F = F;
+    if (!H.tagged || H.F != F || memcmp(&H.params, params, sizeof(roman_params_t)) != 0) {   // other parameters: other ratios
+        H = roman_ctx::Hist{}; H.params = *params; H.F = F; H.tagged = true;
         ++c->histEpoch;                                         // totals still in flight belong to the old block: harvest_totals drops them
     }
     harvest_totals(c, false);

@@ -285,3 +285,20 @@ def test_fusion_variants_and_weights(ctx, orc):
         assert np.allclose(vv, v_o, rtol=1e-12, atol=0) and np.allclose(dd, d_o, rtol=1e-12, atol=0)
         ctx.solve(None)
         assert np.array_equal(ctx.solution()[0], sol["nodes"])
+
+
+@pytest.mark.parametrize("offset", [0.0, 1.0e3, 3.0e7])
+def test_pair_tests_far_from_the_origin(ctx, orc, offset):
+    """Both maps shifted far from the origin (the tables then hold differences of large coordinates): pattern and values
+    still equal the oracle's on the same shifted inputs — every gate is a stated sequence of exactly rounded operations."""
+    reg = registration_for("semanticgrav", semantics_dim=32); reg.set_context(ctx)
+    P = reg._abi_params()
+    pr = synth.make_pair(70, 64, 32, 515, tilt_deg=1.0)
+    D1, D2 = reg.pack(pr.map1).copy(), reg.pack(pr.map2).copy()
+    D1[:, :3] += offset; D2[:, :3] += offset * np.array([1.0, -1.0, 0.5])
+    mat, _ = orc.build_matrix(P, D1, D2)
+    ctx.score(P, D1, D2, None)
+    rp_o, c_o, v_o, d_o = mat.export()
+    rp, cc, vv, dd = ctx.upper_csr()
+    assert np.array_equal(rp, rp_o) and np.array_equal(cc, c_o) and np.array_equal(vv, v_o) and np.array_equal(dd, d_o)
+    assert len(c_o) > 0
