@@ -94,6 +94,8 @@ struct BatchTotals {
     int64_t needNnz;
     int32_t overflow;      // problems skipped for lack of workspace
     int32_t maxStreamL;    // largest L among stream-layout problems
+    int32_t minStreamL;    // smallest L among stream-layout problems (does the small-problem solver have work?)
+    int32_t pad0;
     unsigned long long listTop;    // bump pointer of the candidate-list pool = what the whole batch needs of it
 };
 
@@ -514,7 +516,7 @@ __global__ void __launch_bounds__(64) k_rowbase(int B, int RPB, long long capMas
 {
     // one wave; lane-strided blocks of 64 problems with a running carry (B is small)
     const int lane = threadIdx.x;
-    int accR = 0, accI = 0, mx = 0, mxs = 0, nover = 0; long long accM = 0, needM = 0;
+    int accR = 0, accI = 0, mx = 0, mxs = 0, nover = 0, mns = 0x7fffffff; long long accM = 0, needM = 0;
     for (int b0 = 0; b0 < B; b0 += WAVE) {
         const int b = b0 + lane;
         const int L = b < B ? st[b].L : 0;
@@ -537,14 +539,14 @@ __global__ void __launch_bounds__(64) k_rowbase(int B, int RPB, long long capMas
             st[b].rowBase = accR + pr - L; st[b].itemBase = accI + pi - it; st[b].maskOff = fits ? accM + pm - mw : 0;
             if (!fits) st[b].kind = 2;
         }
-        int m = L, ms = (b < B && st[b].kind == 0) ? L : 0, ov = (b < B && !fits) ? 1 : 0;
-        for (int off = 32; off > 0; off >>= 1) { m = max(m, __shfl_xor(m, off)); ms = max(ms, __shfl_xor(ms, off)); ov += __shfl_xor(ov, off); }
-        mx = max(mx, m); mxs = max(mxs, ms); nover += ov;
+        int m = L, ms = (b < B && st[b].kind == 0) ? L : 0, ov = (b < B && !fits) ? 1 : 0, mn = (b < B && st[b].kind == 0) ? L : 0x7fffffff;
+        for (int off = 32; off > 0; off >>= 1) { m = max(m, __shfl_xor(m, off)); ms = max(ms, __shfl_xor(ms, off)); ov += __shfl_xor(ov, off); mn = min(mn, __shfl_xor(mn, off)); }
+        mx = max(mx, m); mxs = max(mxs, ms); nover += ov; mns = min(mns, mn);
         accR += __shfl(pr, WAVE - 1); accI += __shfl(pi, WAVE - 1); accM += __shfl(pm, WAVE - 1); needM += __shfl(pn, WAVE - 1);
     }
     if (lane == 0) {
         tot->R = accR; tot->maxL = mx; tot->nnzTotal = 0; tot->maskWords = accM < capMaskWords ? accM : capMaskWords; tot->items = accI; tot->sliceGroups = 0;
-        tot->needMaskWords = needM; tot->needNnz = 0; tot->overflow = nover; tot->maxStreamL = mxs; tot->listTop = 0ull;
+        tot->needMaskWords = needM; tot->needNnz = 0; tot->overflow = nover; tot->maxStreamL = mxs; tot->minStreamL = mns; tot->pad0 = 0; tot->listTop = 0ull;
     }
 }
 
@@ -2071,6 +2073,7 @@ __global__ void __launch_bounds__(1024) k_solve(DevParams D, int B, const ProbDe
 #endif
 constexpr int ST_D = 3;                  // quads in flight per lane
 constexpr int ST_MAXSL = STREAM_MAXL / 64;
+constexpr int SMALL_MAXL = 128;           // live associations the one-wave-per-problem instantiation of k_solve_up takes
 constexpr uint32_t ST_CZ = 0x8000u, ST_MASK = 0x7fffu;
 constexpr unsigned long long FX_MAGIC_BITS = 0x4338000000000000ull;     // 2^52 + 2^51
 #define FX_MAGIC 6755399441055744.0
@@ -2140,7 +2143,15 @@ template <int NW, int NS, int NM>
 __device__ __forceinline__ void block_red(double (&sv)[NS > 0 ? NS : 1], double (&mv)[NM > 0 ? NM : 1], double* red, int& par, int tid)
 {
     static_assert(NS + NM <= RED_STRIDE, "reduction scratch");
-    static_assert(NW == 8 || NW == 16, "cross-wave butterfly");
+    static_assert(NW == 1 || NW == 8 || NW == 16, "cross-wave butterfly");
+    if (NW == 1) {                                              // a single wave: the wave reduction is the block reduction
+#pragma unroll
+        for (int i = 0; i < NS; ++i) sv[i] = uni(readlane63(wave_sum63(sv[i])));
+#pragma unroll
+        for (int i = 0; i < NM; ++i) mv[i] = uni(readlane63(wave_max63(mv[i])));
+        __syncthreads();                                        // (publishes the caller's LDS writes like the general path; one wave: no wait)
+        return;
+    }
     double* rr = red + NW * RED_STRIDE * par;
     par ^= 1;
     const int w = uni(tid >> 6);
@@ -2184,7 +2195,7 @@ __device__ __forceinline__ double fx_decode(unsigned long long a, double inv)
     return fma((double)(uint32_t)(a >> 32), 4294967296.0, (double)(uint32_t)a) * inv;
 }
 
-template <int NW, bool HASCZ>
+template <int NW, bool HASCZ, int MAXL>
 __device__ void solve_up(const DevParams& D, int b, const ProbDesc& pd, ProbState* st,
                          const double* __restrict__ feats, const int32_t* __restrict__ assoc,
                          const int32_t* __restrict__ plp /* position -> association index */, const int32_t* __restrict__ lpAsc,
@@ -2196,7 +2207,7 @@ __device__ void solve_up(const DevParams& D, int b, const ProbDesc& pd, ProbStat
                          uint32_t* cumQ /* [ST_MAXSL + 1] */, double* red, int* sint)
 {
     constexpr int NT = NW * 64;
-    constexpr int KMAX = (STREAM_MAXL + NT - 1) / NT;          // elements per thread
+    constexpr int KMAX = (MAXL + NT - 1) / NT;                 // elements per thread (the kernel takes problems of up to MAXL live associations)
     const roman_params_t& P = D.p;
     // the solver's parameters as scalars (the argument block sits in scratch memory: its address is taken for the shared tail)
     const double p_eps = uni(P.eps), p_beta = uni(P.beta), p_tol_u = uni(P.tol_u), p_tol_F = uni(P.tol_F);
@@ -2503,7 +2514,11 @@ __device__ void solve_up(const DevParams& D, int b, const ProbDesc& pd, ProbStat
 #undef CUMQ
 }
 
-template <int NW, bool HASCZ>
+// MAXL < STREAM_MAXL with NW = 1: the SMALL-problem instantiation — one wave per problem (no cross-wave barriers or
+// reductions at all), 64-thread workgroups, many of them per compute unit: submaps of the reference's demo scale (20-40
+// objects, ~60 live associations) would otherwise occupy a whole 8-wave workgroup — a whole compute unit, given the
+// registers of the general instantiation — for ~100 entries of matrix.  [Llo, Lhi]: the live-set sizes this launch takes.
+template <int NW, bool HASCZ, int MAXL>
 __global__ void __launch_bounds__(NW * 64) k_solve_up(DevParams D, int B, const ProbDesc* __restrict__ probs,
                                                       ProbState* __restrict__ st,
                                                       const double* __restrict__ feats, const int32_t* __restrict__ assoc,
@@ -2512,7 +2527,7 @@ __global__ void __launch_bounds__(NW * 64) k_solve_up(DevParams D, int B, const 
                                                       const uint32_t* __restrict__ sliceBase,
                                                       const uint16_t* __restrict__ cols, const double* __restrict__ vals,
                                                       const double* __restrict__ u0, SolveOut O,
-                                                      int* __restrict__ queue, int Lc)
+                                                      int* __restrict__ queue, int Lc, int Llo, int Lhi)
 {
     // LDS: xg[Lc] f64 | accM[Lc] u64 | accC[Lc] u64 | red[2 * NW * RED_STRIDE + 8] | cumQ[ST_MAXSL + 2] u32 | sint[4]
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -2530,11 +2545,11 @@ __global__ void __launch_bounds__(NW * 64) k_solve_up(DevParams D, int B, const 
         if (b >= B) break;
         // (plain if / else on a scalar, no `continue`: every wave must reach the two barriers above the same number of
         // times, and a `continue` out of a branch only thread 0 works in was compiled into a loop that did not)
-        const int kind = uni(st[b].kind);
-        if (kind == 0) {
+        const int kind = uni(st[b].kind), Lb = uni(st[b].L);
+        if (kind == 0 && Lb >= Llo && Lb <= Lhi) {
             const ProbDesc pd = probs[b];
-            solve_up<NW, HASCZ>(D, b, pd, st, feats, assoc, plp, lpAsc, rowPos, pld, sliceBase, cols, vals, u0, O,
-                                xg, accM, accC, Lc, cumQ, red, sint);
+            solve_up<NW, HASCZ, MAXL>(D, b, pd, st, feats, assoc, plp, lpAsc, rowPos, pld, sliceBase, cols, vals, u0, O,
+                                      xg, accM, accC, Lc, cumQ, red, sint);
         }                                                       // kind 1: the fallback solver's problem; kind 2: skipped (k_skipped)
     }
 }

@@ -106,6 +106,7 @@ struct roman_ctx {
         double rMask = 0.0;                    // bit-matrix words / sum of nA * ceil(nA / 64)
         double rNnz = 0.0;                     // matrix slots / sum of nA
         double rList = 0.0;                    // candidate-list elements / sum of nA
+        bool smallSeen = false;                // a stream-layout problem of at most SMALL_MAXL live associations has occurred
     } hist;
     unsigned histEpoch = 1;                    // bumped whenever the history is reset for another parameter block
     long long skippedTotal = 0;                // problems reported ROMAN_ST_WORKSPACE so far (harvested totals)
@@ -279,6 +280,7 @@ void harvest_totals(roman_ctx* c, bool wait)
         if (W.totMaskBound > 0) H.rMask = std::max(H.rMask, (double)t.needMaskWords / W.totMaskBound);
         if (W.totSumA > 0) H.rNnz = std::max(H.rNnz, (double)t.needNnz / W.totSumA);
         if (W.totSumA > 0) H.rList = std::max(H.rList, (double)t.listTop / W.totSumA);
+        if (t.minStreamL <= SMALL_MAXL) H.smallSeen = true;
         H.valid = true;
     }
 }
@@ -605,12 +607,28 @@ int enqueue_solve(roman_ctx* c, const DevParams& D, int B, int64_t sumA, int64_t
     StageTimer t3(c, ROMAN_STAGE_SOLVE);
     hipLaunchKernelGGL(k_skipped, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, WS.stream, B, WS.probs.as<ProbDesc>(), WS.state.as<ProbState>(), O, WS.queue.as<int>());
     DBG(c, "k_skipped");
+    // Small problems (<= SMALL_MAXL live associations: the reference's demo scale) take the one-wave-per-problem
+    // instantiation; it is launched when such problems have been seen with this parameter block (or, with no history
+    // yet, when the association lists are short enough to make them likely).  The general launch takes the rest — and
+    // everything when the small one is not part of the batch.
+    static const char* smallEnv = getenv("ROMAN_SMALL");        // "0": never
+    const bool small = !(smallEnv && smallEnv[0] == '0') && D.p.maxiniters >= 1 && D.p.maxlsiters >= 1 &&
+                       (c->hist.valid ? c->hist.smallSeen : maxA <= 16 * SMALL_MAXL);
+    const int Lc1 = SMALL_MAXL + 64;
+    const size_t ldsUp1 = (size_t)3 * 8 * Lc1 + sizeof(double) * (2 * 1 * RED_STRIDE + 8) + sizeof(uint32_t) * (ST_MAXSL + 2) + sizeof(int) * 4 + 16;
+    const int gridUp1 = std::max(1, std::min(B, c->num_cu * 24));
 #define ROMAN_LAUNCH_UP(CZ_)                                                                                                  \
     do {                                                                                                                      \
-        HIPCHK(c, dyn_lds(c, reinterpret_cast<const void*>(k_solve_up<NW, CZ_>), ldsUp)); \
-        hipLaunchKernelGGL((k_solve_up<NW, CZ_>), dim3(gridUp), dim3(NW * 64), ldsUp, WS.stream, D, B, WS.probs.as<ProbDesc>(), WS.state.as<ProbState>(), feats, assoc, \
+        HIPCHK(c, dyn_lds(c, reinterpret_cast<const void*>(k_solve_up<NW, CZ_, STREAM_MAXL>), ldsUp)); \
+        hipLaunchKernelGGL((k_solve_up<NW, CZ_, STREAM_MAXL>), dim3(gridUp), dim3(NW * 64), ldsUp, WS.stream, D, B, WS.probs.as<ProbDesc>(), WS.state.as<ProbState>(), feats, assoc, \
                            WS.plp.as<int32_t>(), WS.lp.as<int32_t>(), WS.rowPos.as<uint32_t>(), WS.pld.as<double>(), WS.sliceBase.as<uint32_t>(), \
-                           WS.cols16.as<uint16_t>(), WS.vals.as<double>(), u0, O, WS.queue.as<int>(), Lc);                     \
+                           WS.cols16.as<uint16_t>(), WS.vals.as<double>(), u0, O, WS.queue.as<int>(), Lc, small ? SMALL_MAXL + 1 : 0, STREAM_MAXL); \
+        if (small) {                                                                                                          \
+            HIPCHK(c, dyn_lds(c, reinterpret_cast<const void*>(k_solve_up<1, CZ_, SMALL_MAXL>), ldsUp1));                       \
+            hipLaunchKernelGGL((k_solve_up<1, CZ_, SMALL_MAXL>), dim3(gridUp1), dim3(64), ldsUp1, WS.stream, D, B, WS.probs.as<ProbDesc>(), WS.state.as<ProbState>(), feats, assoc, \
+                               WS.plp.as<int32_t>(), WS.lp.as<int32_t>(), WS.rowPos.as<uint32_t>(), WS.pld.as<double>(), WS.sliceBase.as<uint32_t>(), \
+                               WS.cols16.as<uint16_t>(), WS.vals.as<double>(), u0, O, WS.queue.as<int>() + 1, Lc1, 0, SMALL_MAXL); \
+        }                                                                                                                     \
     } while (0)
     if (hascz) ROMAN_LAUNCH_UP(true); else ROMAN_LAUNCH_UP(false);
 #undef ROMAN_LAUNCH_UP
