@@ -713,10 +713,24 @@ ORACLE_API int32_t oracle_register(const roman_params_t* P, const double* D1, in
  * thread: nested parallelism is off by default) — what a caller with many pairs and many cores would do.
  * assoc_out: B x kmax x 2 (rows beyond n_out[b] untouched), n_out[b] = selected associations of problem b.
  */
+ORACLE_API int oracle_register_many_u0(const roman_params_t* P, int32_t B, const double* feats,
+                                       const int64_t* off1, const int32_t* n1, const int64_t* off2, const int32_t* n2,
+                                       int32_t F, int faithful, int32_t kmax, int32_t* assoc_out, int32_t* n_out,
+                                       const double* u0 /* NULL, or the start vectors of the B problems concatenated (n1*n2 each) */);
 ORACLE_API int oracle_register_many(const roman_params_t* P, int32_t B, const double* feats,
                                     const int64_t* off1, const int32_t* n1, const int64_t* off2, const int32_t* n2,
                                     int32_t F, int faithful, int32_t kmax, int32_t* assoc_out, int32_t* n_out)
 {
+    return oracle_register_many_u0(P, B, feats, off1, n1, off2, n2, F, faithful, kmax, assoc_out, n_out, NULL);
+}
+ORACLE_API int oracle_register_many_u0(const roman_params_t* P, int32_t B, const double* feats,
+                                       const int64_t* off1, const int32_t* n1, const int64_t* off2, const int32_t* n2,
+                                       int32_t F, int faithful, int32_t kmax, int32_t* assoc_out, int32_t* n_out, const double* u0)
+{
+    int64_t* uoff = (int64_t*)malloc(sizeof(int64_t) * ((size_t)B + 1));
+    if (!uoff) return -1;
+    uoff[0] = 0;
+    for (int32_t b = 0; b < B; ++b) uoff[b + 1] = uoff[b] + (int64_t)n1[b] * n2[b];
     int bad = 0;
 #ifdef _OPENMP
     const int levels_before = omp_get_max_active_levels();
@@ -734,7 +748,7 @@ ORACLE_API int oracle_register_many(const roman_params_t* P, int32_t B, const do
             free(tmp); free(u);
             continue;
         }
-        const int32_t k = oracle_register(P, feats + off1[b] * F, n1[b], feats + off2[b] * F, n2[b], F, NULL, nA, NULL,
+        const int32_t k = oracle_register(P, feats + off1[b] * F, n1[b], feats + off2[b] * F, n2[b], F, NULL, nA, u0 ? u0 + uoff[b] : NULL,
                                           faithful, tmp, u, &st);
         const int32_t kk = k < kmax ? k : kmax;
         for (int32_t t = 0; t < kk; ++t) {
@@ -747,6 +761,7 @@ ORACLE_API int oracle_register_many(const roman_params_t* P, int32_t B, const do
 #ifdef _OPENMP
     omp_set_max_active_levels(levels_before);
 #endif
+    free(uoff);
     return bad ? -1 : 0;
 }
 

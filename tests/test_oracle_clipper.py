@@ -218,3 +218,9 @@ def test_register_many_equals_register_per_problem(orc):
     for (D1, D2), g in zip(mats, got):
         want = orc.register(P, D1, D2, faithful=False)["assoc"]
         assert np.array_equal(g, want)
+    # the same with explicit start vectors (concatenated per problem)
+    rng = np.random.default_rng(5)
+    u0s = [rng.random(len(D1) * len(D2)) for D1, D2 in mats]
+    got = orc.register_many(P, feats, off1, n1, off2, n2, kmax=40, u0=np.concatenate(u0s))
+    for (D1, D2), g, u0 in zip(mats, got, u0s):
+        assert np.array_equal(g, orc.register(P, D1, D2, u0=u0 if len(u0) else None, faithful=False)["assoc"])
