@@ -10,6 +10,23 @@ from roman_amd import synth
 pytestmark = pytest.mark.gpu
 
 
+class _Recorder:
+    """Logs the name of every C-ABI entry called through it (the real libroman_hip.so underneath)."""
+
+    def __init__(self, lib):
+        self._lib = lib; self.calls = []
+
+    def __getattr__(self, name):
+        fn = getattr(self._lib, name)
+        if not name.startswith("roman_"):
+            return fn
+
+        def wrapped(*a):
+            self.calls.append(name)
+            return fn(*a)
+        return wrapped
+
+
 def test_reference_call_sequence_through_shim(ctx, orc):
     clipperpy = roman_amd.install_clipperpy_shim(force=True)
     reg = registration_for("roman", semantics_dim=24)
@@ -26,9 +43,15 @@ def test_reference_call_sequence_through_shim(ctx, orc):
     clipper = clipperpy.CLIPPERPairwiseAndSingle(clipperpy.invariants.ROMAN(ip), clipperpy.Params())
     clipper._ctx = ctx
     A_init = clipperpy.utils.create_all_to_all(len(pr.map1), len(pr.map2))
-    clipper.score_pairwise_and_single_consistency(map1_cl.T, map2_cl.T, A_init)   # F-ordered (F,n) views
-    clipper.solve()
-    Ain = clipper.get_selected_associations()
+    rec = _Recorder(ctx._lib); ctx._lib = rec                     # the C-ABI calls of ONE register(): the same sequence the
+    try:                                                          # reference's unmodified files make on the CPU box (tests/test_reference_files_on_shim.py)
+        clipper.score_pairwise_and_single_consistency(map1_cl.T, map2_cl.T, A_init)   # F-ordered (F,n) views
+        clipper.solve()
+        Ain = clipper.get_selected_associations()
+    finally:
+        ctx._lib = rec._lib
+    from _recording_lib import EXPECTED_REGISTER_CALLS
+    assert [c for c in rec.calls if c != "roman_last_error"] == EXPECTED_REGISTER_CALLS, rec.calls
     ref = orc.register(reg._abi_params(), map1_cl, map2_cl)
     assert np.array_equal(Ain, ref["assoc"])
     sol = clipper.get_solution()
