@@ -102,7 +102,9 @@ def main():
             sys.exit(f"--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...`")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # ROMAN_BENCH_FORCE_DIST: run the process-group / all_gather path at world size 1 too (tools/scale_preflight.sh)
+    dist_on = world > 1 or (os.environ.get("ROMAN_BENCH_FORCE_DIST") and "RANK" in os.environ)
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     workload = args.workload if args.workload != "auto" else "pairs"
@@ -162,7 +164,7 @@ def main():
         # one output set per call in flight: call k writes set k % NSET while older sets are gathered
         NSET = max(args.pipeline, 2)
         O = out_sets(CB, kmax, NSET)
-        if world > 1:
+        if dist_on:
             rec_i = torch.empty((CB, 2 + 2 * kmax), dtype=torch.int32, device=dev)
             gat_i = torch.empty((world * CB, 2 + 2 * kmax), dtype=torch.int32, device=dev)
             gat_T = torch.empty((world * CB, 16), dtype=torch.float64, device=dev)
@@ -189,7 +191,7 @@ def main():
             o1, a1, o2, a2 = meta[ci]
             ctx.align_batch_dev(P, fptr, F, o1, a1, o2, a2, kmax,
                                 O.assoc[k].data_ptr(), O.n[k].data_ptr(), O.T[k].data_ptr(), O.status[k].data_ptr(), O.stats[k].data_ptr())
-            if world > 1:
+            if dist_on:
                 if args.pipeline >= 2:
                     if call_no[0] > 1:
                         ctx.join(skip_latest=True)                 # torch's stream waits for the OLDER calls only
@@ -219,12 +221,12 @@ def main():
         def drain():                                               # results of the last call
             if args.pipeline >= 2:
                 ctx.join(skip_latest=False)
-                if world > 1 and call_no[0] > 0:
+                if dist_on and call_no[0] > 0:
                     gather((call_no[0] - 1) % NSET)
 
         def fence():
             torch.cuda.synchronize(dev)
-            if world > 1:
+            if dist_on:
                 dist.barrier()
             torch.cuda.synchronize(dev)
 
@@ -246,7 +248,7 @@ def main():
             ctx.profile_enable(False)
         skipped = ctx.skipped(wait=True) - skipped0                 # problems the timed steps reported ROMAN_ST_WORKSPACE for (must be 0)
         ctx.set_pipeline(1)                                         # the latency probe and the checks below are single calls
-        if world > 1:
+        if dist_on:
             tt = torch.tensor([dt, float(skipped)], dtype=torch.float64, device=dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt[0].item()); skipped = int(tt[1].item())
@@ -268,7 +270,7 @@ def main():
     # BASELINE config 4 as a second leg — the 4096-pair grid (dealt over the ranks at N > 1: strong scaling)
     G = None
     if workload == "pairs" and not args.no_grid and (extras or world > 1):
-        G = measure("grid", args.grid_steps, args.grid_warmup, False)
+        G = measure("grid", max(args.grid_steps, 10) if world > 1 else args.grid_steps, max(args.grid_warmup, 3) if world > 1 else args.grid_warmup, False)
     # upload inside the timed region
     H2D = None
     if extras and world == 1:
@@ -343,11 +345,11 @@ def main():
         lat_break = {"host_enqueue_ms": float(np.median(enq) * 1e3),
                      "stage_ms": {k: float(np.median([x[k] for x in stg])) for k in stg[0]},
                      "note": "B=1, stage timers on (they add event records to the call)"}
-    if world > 1:
+    if dist_on:
         dist.barrier()
 
     if rank != 0:
-        if world > 1:
+        if dist_on:
             dist.destroy_process_group()
         return
 
@@ -521,7 +523,7 @@ def main():
         except Exception as e:                                  # side legs never cost the headline line
             out["side_legs_error"] = repr(e)
     print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

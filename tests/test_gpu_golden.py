@@ -43,6 +43,32 @@ def test_pose_kernel_accuracy_is_near_machine_precision(ctx):
     assert worst < 1e-11
 
 
+def test_pose_of_collinear_points_is_a_proper_rigid_fit(ctx, orc):
+    """SURVEY.md §8(c)(5) degenerate case: all correspondences on ONE line.  H has rank 1, the rotation about the line is
+    not determined: numpy's SVD (the reference) and the device's Jacobi pick different — equally optimal — members of the
+    family.  What is determined is checked: a proper rotation (orthonormal, det +1), the same residual as the reference
+    function's fit, and (noise-free) the points mapped onto each other; with k == dim points as well."""
+    rng = np.random.default_rng(99)
+    cases = []
+    for k in (3, 7, 40):
+        dirn = rng.standard_normal(3); dirn /= np.linalg.norm(dirn)
+        s = np.sort(rng.uniform(-12, 12, k))
+        p2 = np.outer(s, dirn) + np.array([1.0, -2.0, 0.5])
+        th = rng.uniform(-np.pi, np.pi); R = np.array([[np.cos(th), -np.sin(th), 0], [np.sin(th), np.cos(th), 0], [0, 0, 1.0]])
+        t = rng.uniform(-4, 4, 3)
+        cases.append(((R @ p2.T).T + t, p2))
+    off = np.cumsum([0] + [len(c[0]) for c in cases]).astype(np.int64)
+    T, status = ctx.pose_batch(3, np.concatenate([c[0] for c in cases]), np.concatenate([c[1] for c in cases]), off)
+    for i, (p1, p2) in enumerate(cases):
+        assert status[i] == 0
+        Rg, tg = T[i][:3, :3], T[i][:3, 3]
+        assert np.allclose(Rg @ Rg.T, np.eye(3), atol=1e-12) and abs(np.linalg.det(Rg) - 1.0) < 1e-12
+        res_gpu = np.linalg.norm((Rg @ p2.T).T + tg - p1)
+        To = orc.t_align(p1, p2)
+        res_ref = np.linalg.norm((To[:3, :3] @ p2.T).T + To[:3, 3] - p1)
+        assert res_gpu < 1e-9 and abs(res_gpu - res_ref) < 1e-9
+
+
 @pytest.mark.parametrize("case", RCASES, ids=[f"{i}-{c['method']}" for i, c in enumerate(RCASES)])
 def test_register_and_t_align_match_reference_plugins(ctx, case):
     """Same calls the reference's caller makes (submap_align.py:156-166): register() then T_align()."""
