@@ -69,6 +69,16 @@ extern "C" {
                                    [REF roman/align/dist_reg_with_pruning.py:48-57]            */
 #define ROMAN_INV_ROMAN      1  /* clipperpy.invariants.ROMAN + clipperpy.CLIPPERPairwiseAndSingle
                                    [REF roman/align/roman_registration.py:82-86]               */
+#define ROMAN_INV_EUCLIDEAN_PRUNED 2  /* DistRegWithPruning with its NumPy prefilter moved onto the device
+                                   [REF roman/align/dist_reg_with_pruning.py:71-97]: EuclideanDistance + clipperpy.CLIPPER on the
+                                   associations (i,j) of the all-to-all list that survive
+                                       NOT (<desc_i, desc_j> < cosine_min)                       (raw dot product, :75-80)
+                                       NOT (min(f_i, f_j) / max(f_i, f_j) < ratio_epsilon[f])    for each of the ratio features (:83-90)
+                                   and on ALL of them when none survives (the reference then hands clipperpy an empty list, which
+                                   means all-to-all, :94-96).  Feature row: [x y (z)] ++ ratio features (the reference uses volume,
+                                   linearity, planarity, scattering) ++ descriptor.  Same result as ROMAN_INV_EUCLIDEAN on the
+                                   explicit pruned list (the dot product is accumulated in the order of the f64 matrix core: a
+                                   product within rounding of cosine_min may fall on the other side than NumPy's BLAS puts it). */
 
 /* clipperpy.invariants.ROMAN.{GEOMETRIC_MEAN,ARITHMETIC_MEAN,PRODUCT}
    [REF roman/align/roman_registration.py:11-14] */

@@ -231,6 +231,18 @@ static double pow_w(double x, double w)
 static double single_score(const roman_params_t* P, const double* fi, const double* fj, double cosv)
 {
     const int pd = P->point_dim, Fr = P->ratio_feature_dim, Fc = P->cos_feature_dim;
+    if (P->invariant == ROMAN_INV_EUCLIDEAN_PRUNED) {
+        /* the prefilter of /root/reference/roman/align/dist_reg_with_pruning.py:71-90 as a 0/1 score: `cosv` is the RAW dot
+           product of the two descriptors; an association is deleted where  dot < cos_min  or  min/max < shape_epsilon
+           (NumPy comparisons: a NaN compares false, i.e. keeps the association) */
+        if (Fc > 0 && cosv < P->cosine_min) return 0.0;
+        for (int f = 0; f < Fr; ++f) {
+            const double a = fi[pd + f], b = fj[pd + f];
+            const double mn = a < b ? a : b, mx = a < b ? b : a;
+            if (mn / mx < P->ratio_epsilon[f]) return 0.0;
+        }
+        return 1.0;
+    }
     double wsum = 0.0, prod = 1.0, asum = 0.0;
     if (Fr > 0) {
         double rp = 1.0;
@@ -260,7 +272,7 @@ static double single_score(const roman_params_t* P, const double* fi, const doub
 
 static int has_single(const roman_params_t* P)
 {
-    return P->invariant == ROMAN_INV_ROMAN && (P->ratio_feature_dim > 0 || P->cos_feature_dim > 0);
+    return (P->invariant == ROMAN_INV_ROMAN || P->invariant == ROMAN_INV_EUCLIDEAN_PRUNED) && (P->ratio_feature_dim > 0 || P->cos_feature_dim > 0);
 }
 
 /* Single scores of all associations.  D1/D2: object-major (n x F).  s_out: nA doubles. */
@@ -271,6 +283,7 @@ ORACLE_API int oracle_single_scores(const roman_params_t* P, const double* D1, i
     if (!has_single(P)) { for (int32_t p = 0; p < nA; ++p) s_out[p] = 1.0; return 0; }
     const int Fc = P->cos_feature_dim, off = P->point_dim + P->ratio_feature_dim;
     double* nr1 = NULL; double* nr2 = NULL;
+    const int raw = P->invariant == ROMAN_INV_EUCLIDEAN_PRUNED;      /* the reference's prefilter compares the raw dot product */
     if (Fc > 0) {
         nr1 = (double*)malloc(sizeof(double) * (n1 > 0 ? n1 : 1));
         nr2 = (double*)malloc(sizeof(double) * (n2 > 0 ? n2 : 1));
@@ -284,7 +297,7 @@ ORACLE_API int oracle_single_scores(const roman_params_t* P, const double* D1, i
         double cosv = 0.0;
         if (Fc > 0) {
             const double dot = dot_fixed(fi + off, fj + off, Fc);
-            cosv = (nr1[i] > 0.0 && nr2[j] > 0.0) ? dot / (nr1[i] * nr2[j]) : 0.0;
+            cosv = raw ? dot : ((nr1[i] > 0.0 && nr2[j] > 0.0) ? dot / (nr1[i] * nr2[j]) : 0.0);
         }
         s_out[p] = single_score(P, fi, fj, cosv);
     }
@@ -359,6 +372,7 @@ static double pair_score(const roman_params_t* P, const pair_consts_t* K,
 static double fuse_pair(const roman_params_t* P, int single, double sa, double sp, double sq)
 {
     if (!single) return sa;
+    if (P->invariant == ROMAN_INV_EUCLIDEAN_PRUNED) return (sp == 0.0 || sq == 0.0) ? 0.0 : sa;   /* the pair score alone, among survivors */
     if (P->single_mode == ROMAN_SINGLE_DIAG_KEEP) return sa;  /* single scores on the diagonal only, nothing removed */
     if (sa == 0.0 || sp == 0.0 || sq == 0.0) return 0.0;
     if (P->single_mode == ROMAN_SINGLE_DIAG) return sa;       /* single scores on the diagonal only */
@@ -426,10 +440,18 @@ ORACLE_API oracle_mat_t* oracle_build(const roman_params_t* P, const double* D1,
     double* s = (double*)malloc(sizeof(double) * (nA > 0 ? nA : 1));
     m->live = (uint8_t*)malloc((size_t)(nA > 0 ? nA : 1));
     oracle_single_scores(P, D1, n1, D2, n2, F, A, nA, s);
-    const int keep = single && P->single_mode == ROMAN_SINGLE_DIAG_KEEP;   /* a zero single score removes nothing */
+    int keep = single && P->single_mode == ROMAN_SINGLE_DIAG_KEEP;   /* a zero single score removes nothing */
+    const int pruned = P->invariant == ROMAN_INV_EUCLIDEAN_PRUNED;
+    if (pruned && single) {            /* nothing survives the prefilter: the reference scores the all-to-all list (dist_reg_with_pruning.py:94-96) */
+        int32_t any = 0;
+        for (int32_t p = 0; p < nA; ++p) any |= (s[p] > 0.0);
+        if (!any) keep = 1;
+    }
     for (int32_t p = 0; p < nA; ++p) {
         m->live[p] = keep || s[p] > 0.0;
-        m->diag[p] = (single && P->single_mode == ROMAN_SINGLE_OFFDIAG) ? (m->live[p] ? 1.0 : 0.0) : s[p];
+        m->diag[p] = pruned ? (m->live[p] ? 1.0 : 0.0)
+                            : ((single && P->single_mode == ROMAN_SINGLE_OFFDIAG) ? (m->live[p] ? 1.0 : 0.0) : s[p]);
+        if (pruned) s[p] = m->live[p] ? 1.0 : 0.0;
     }
     pair_consts_t K; K.sig2 = P->sigma * P->sigma; K.sin_unc = sin(P->gravity_unc_ang_rad);
 
@@ -676,6 +698,16 @@ ORACLE_API int oracle_solve(const roman_params_t* P, const oracle_mat_t* m, cons
 
     const double om = round(F);
     int32_t omega = (om >= 2147483647.0) ? 2147483647 : (om < 1.0 ? 0 : (int32_t)om);
+    if (P->invariant == ROMAN_INV_EUCLIDEAN_PRUNED) {
+        /* upstream's vector has one entry per association of the PRUNED list: removed associations are not candidates of the
+           top-omega selection at all (they could otherwise win a tie at u == 0 by their index) */
+        int32_t nl = 0;
+        double* ul = (double*)malloc(sizeof(double) * (size_t)n); int32_t* il = (int32_t*)malloc(sizeof(int32_t) * (size_t)n);
+        for (int32_t p = 0; p < n; ++p) if (m->live[p]) { ul[nl] = u[p]; il[nl] = p; ++nl; }
+        *n_nodes = oracle_k_largest(ul, nl, omega, nodes_out);
+        for (int32_t t = 0; t < *n_nodes; ++t) nodes_out[t] = il[nodes_out[t]];
+        free(ul); free(il);
+    } else
     *n_nodes = oracle_k_largest(u, n, omega, nodes_out);
     if (u_out) memcpy(u_out, u, sizeof(double) * n);
     if (st) *st = S;

@@ -22,6 +22,7 @@ ROMAN_ST_INTERNAL = 64
 
 ROMAN_INV_EUCLIDEAN = 0
 ROMAN_INV_ROMAN = 1
+ROMAN_INV_EUCLIDEAN_PRUNED = 2
 
 ROMAN_FUSE_GEOMETRIC_MEAN = 0
 ROMAN_FUSE_ARITHMETIC_MEAN = 1

@@ -27,8 +27,14 @@ def _zyx_euler(R):
 class DistRegWithPruning(ObjectRegistration):
 
     def __init__(self, sigma, epsilon, mindist=0.0, shape_epsilon=0.0, cos_min=0.85,
-                 dim=3, use_gravity=False, roll_pitch_thresh=np.deg2rad(5)):
+                 dim=3, use_gravity=False, roll_pitch_thresh=np.deg2rad(5), prune_on_device=False, semantics_dim=None):
+        """The reference's arguments ([REF roman/align/dist_reg_with_pruning.py:17-27]) plus two of this package's:
+        prune_on_device — evaluate the prefilter on the GPU instead of in NumPy (ROMAN_INV_EUCLIDEAN_PRUNED: the descriptors
+        and shape attributes travel with the centroids, the pruned list never exists on the host; SURVEY.md §8 row f4);
+        semantics_dim — descriptor length for that mode (default: taken from the first object packed)."""
         super().__init__(dim)
+        self.prune_on_device = bool(prune_on_device)
+        self.semantics_dim = semantics_dim
         self.sigma = sigma
         self.epsilon = epsilon
         self.mindist = mindist
@@ -45,10 +51,32 @@ class DistRegWithPruning(ObjectRegistration):
         p.invariant = _abi.ROMAN_INV_EUCLIDEAN
         p.point_dim = self.dim
         p.sigma, p.epsilon, p.mindist = self.sigma, self.epsilon, self.mindist
+        if self.prune_on_device:                              # the prefilter's thresholds ride in the ROMAN-invariant fields
+            if self.semantics_dim is None:
+                raise ValueError("prune_on_device needs semantics_dim (or pack a map first)")
+            p.invariant = _abi.ROMAN_INV_EUCLIDEAN_PRUNED
+            p.ratio_feature_dim = 4
+            p.cos_feature_dim = int(self.semantics_dim)
+            p.cosine_min = self.cos_min
+            for f in range(4):
+                p.ratio_epsilon[f] = self.shape_epsilon
         return p
 
     def _object_to_clipper_list(self, object):
         return object.center.reshape(-1)[:self.dim].tolist()
+
+    def pack(self, object_map):
+        """Host prefilter: centroids only, as the reference hands them over ([REF :92-96]).  Device prefilter: one row per
+        object [centroid | volume, linearity, planarity, scattering | descriptor] — the inputs of [REF :75-90]."""
+        if not self.prune_on_device:
+            return super().pack(object_map)
+        if self.semantics_dim is None and len(object_map):
+            self.semantics_dim = int(np.asarray(object_map[0].semantic_descriptor).size)
+        F = self.dim + 4 + int(self.semantics_dim or 0)
+        if len(object_map) == 0:
+            return np.zeros((0, F), dtype=np.float64)
+        return np.array([np.concatenate([o.center.reshape(-1)[:self.dim], self._object_shape_attributes(o),
+                                         np.asarray(o.semantic_descriptor, dtype=np.float64).flatten()]) for o in object_map], dtype=np.float64)
 
     def _object_shape_attributes(self, object):
         return np.array([object.volume, object.linearity, object.planarity, object.scattering])
@@ -57,6 +85,8 @@ class DistRegWithPruning(ObjectRegistration):
         """The NumPy prefilter of [REF roman/align/dist_reg_with_pruning.py:71-90] (a9): cosine of the
         raw descriptors below cos_min, or any min/max shape ratio below shape_epsilon, removes an
         association.  Host-side index logic; the pruned list goes to the device as-is."""
+        if self.prune_on_device:
+            return None                                       # all-to-all: the device applies the prefilter (ROMAN_INV_EUCLIDEAN_PRUNED)
         A_all = create_all_to_all(len(map1), len(map2))
         descriptors1 = np.array([p.semantic_descriptor.flatten() for p in map1])
         descriptors2 = np.array([p.semantic_descriptor.flatten() for p in map2])

@@ -54,7 +54,7 @@ class ObjectRegistration:
     def pack(self, object_map) -> np.ndarray:
         """(n, F) float64 object-major feature matrix of one map — what the reference builds per
         call at [REF roman/align/object_registration.py:43-44] (and hands over transposed)."""
-        F = self._abi_params().feature_dim() if self._abi_params().invariant == _abi.ROMAN_INV_ROMAN else self.dim
+        F = self._abi_params().feature_dim() if self._abi_params().invariant != _abi.ROMAN_INV_EUCLIDEAN else self.dim
         if len(object_map) == 0:
             return np.zeros((0, F), dtype=np.float64)
         return np.array([self._object_to_clipper_list(p) for p in object_map], dtype=np.float64)

@@ -50,6 +50,8 @@ struct DevParams {
     int32_t gmode;      // 0: no gravity; 1 + ROMAN_GRAV_* otherwise (1 combined, 2 separate gates, 3 z gate on full lengths)
     int32_t diag_one;   // single scores present but the diagonal is the identity (ROMAN_SINGLE_OFFDIAG)
     int32_t keep_all;   // single scores present but a zero one removes nothing (ROMAN_SINGLE_DIAG_KEEP): every association is live
+    int32_t pruned;     // ROMAN_INV_EUCLIDEAN_PRUNED: the single score is the 0/1 prefilter on the RAW descriptor product; pair score alone in M,
+                        // identity diagonal; a problem in which nothing survives keeps every association; rounding over survivors only
     int32_t allow_fallback;  // the fallback kernels are part of this launch; otherwise a problem that does not fit the stream layout is
                              // SKIPPED (kind 2, ROMAN_ST_WORKSPACE) and runs again with them (set per launch, from the sizing history)
     int32_t wide;            // fallback problems of this launch go to k_solve_wide (few, large) instead of k_solve (set per launch)
@@ -209,6 +211,15 @@ __device__ inline double single_score(const DevParams& D, const double* __restri
 {
     const roman_params_t& P = D.p;
     const int pd = P.point_dim, Fr = P.ratio_feature_dim, Fc = P.cos_feature_dim;
+    if (D.pruned) {                         // the reference's NumPy prefilter ([REF roman/align/dist_reg_with_pruning.py:75-90]) as a 0/1 score;
+        if (Fc > 0 && cosv < P.cosine_min) return 0.0;          // cosv is the RAW product here; a NaN compares false = keeps, as in NumPy
+        for (int f = 0; f < Fr; ++f) {
+            const double a = fi[pd + f], b = fj[pd + f];
+            const double mn = a < b ? a : b, mx = a < b ? b : a;
+            if (mn / mx < P.ratio_epsilon[f]) return 0.0;
+        }
+        return 1.0;
+    }
     double wsum = 0.0, prod = 1.0, asum = 0.0;
     if (Fr > 0) {
         double rp = 1.0;
@@ -241,6 +252,7 @@ __device__ __forceinline__ double fuse_pair(const DevParams& D, double sa, doubl
 {
     if (!D.single || D.keep_all) return sa;
     if (sa == 0.0 || sp == 0.0 || sq == 0.0) return 0.0;
+    if (D.pruned) return sa;
     if (D.p.single_mode == ROMAN_SINGLE_DIAG) return sa;
     const double ss = sp * sq, wd = D.p.distance_weight;
     switch (D.p.fusion_method) {
@@ -359,7 +371,7 @@ __global__ void __launch_bounds__(256) k_cos(DevParams D, int B, int G /* workgr
                 const int row = i0 + 16 * x + kq + 4 * r;
                 const double na = __shfl(sa[x], kq + 4 * r);       // norm of row 16x + (kq + 4r): held by lanes with lr == kq + 4r
                 if (row < pd.n1 && col < pd.n2)
-                    cosPool[pd.cosOff + (int64_t)row * pd.n2 + col] = (na > 0.0 && nb > 0.0) ? acc[x][y][r] / (na * nb) : 0.0;
+                    cosPool[pd.cosOff + (int64_t)row * pd.n2 + col] = D.pruned ? acc[x][y][r] : ((na > 0.0 && nb > 0.0) ? acc[x][y][r] / (na * nb) : 0.0);
             }
     }
 }
@@ -485,17 +497,21 @@ __global__ void __launch_bounds__(256) k_live(DevParams D, const ProbDesc* __res
     }
     if (lane == 0) wtot[w] = cnt;
     __syncthreads();
+    // ROMAN_INV_EUCLIDEAN_PRUNED with NO survivor: the reference hands clipperpy an empty list, i.e. the all-to-all one
+    const bool all_live = D.pruned && cbase[1] == 0 && nA > 0;
     int base = cbase[0];
     for (int k = 0; k < w; ++k) base += wtot[k];
+    if (all_live) base = p_beg;                                 // live index == association index
+    const int Ltot = all_live ? nA : cbase[1];
     if (c == 0 && tid == 0) {
-        st[b].L = cbase[1]; st[b].nnzUpper = 0ull;
-        st[b].kind = (cbase[1] <= D.stream_maxL && D.p.maxiniters >= 1 && D.p.maxlsiters >= 1) ? 0 : (D.allow_fallback ? 1 : 2);
+        st[b].L = Ltot; st[b].nnzUpper = 0ull;
+        st[b].kind = (Ltot <= D.stream_maxL && D.p.maxiniters >= 1 && D.p.maxlsiters >= 1) ? 0 : (D.allow_fallback ? 1 : 2);
     }
 
     const int64_t lo = pd.liveOff;
     for (int p0 = p_beg; p0 < p_end; p0 += WAVE) {
         const int p = p0 + lane;
-        const double s = (p < p_end) ? sT[p] : 0.0;
+        const double s = (p < p_end) ? (all_live ? 1.0 : sT[p]) : 0.0;
         const bool live = p < p_end && (s > 0.0 || D.keep_all);
         const unsigned long long m = __ballot(live);
         if (live) {
@@ -1666,13 +1682,15 @@ __device__ __noinline__ void write_pose(double* T, int d, const double* H, const
 __device__ inline bool hp_less(double va, int ia, double vb, int ib) { return va < vb || (va == vb && ia < ib); }
 __device__ __noinline__ void heap_select_serial(const double* u, const int32_t* lp /* ascending: live order */,
                                    const uint32_t* vecOfLive /* live index -> index into u, or nullptr = identity */,
-                                   int L, int nA, int k,
+                                   int L, int nA, int k, bool liveOnly /* removed associations are not candidates at all (pruned list) */,
                                    double* hv, int32_t* hi /* capacity k */, int32_t* outNodesOrig)
 {
     int sz = 0, nl = 0;
-    for (int p = 0; p < nA; ++p) {
-        double x = 0.0;
-        if (nl < L && lp[nl] == p) { x = u[vecOfLive ? (int)vecOfLive[nl] : nl]; ++nl; }
+    const int nIter = liveOnly ? L : nA;
+    for (int it = 0; it < nIter; ++it) {
+        int p = it; double x = 0.0;
+        if (liveOnly) { p = lp[it]; x = u[vecOfLive ? (int)vecOfLive[it] : it]; }
+        else if (nl < L && lp[nl] == p) { x = u[vecOfLive ? (int)vecOfLive[nl] : nl]; ++nl; }
         if (sz < k) {
             int c = sz++; hv[c] = x; hi[c] = p;
             while (c > 0) { const int par = (c - 1) >> 1; if (!hp_less(hv[c], hi[c], hv[par], hi[par])) break;
@@ -1727,7 +1745,7 @@ __device__ __noinline__ void finish_one(const DevParams& D, int b, const ProbDes
         // ---- top-omega rounding --------------------------------------------------------------
         const double om = round(F);
         int omega = (om >= 2147483647.0) ? 2147483647 : (om < 1.0 ? 0 : (int)om);
-        if (omega > pd.nA) omega = pd.nA;
+        if (omega > (D.pruned ? L : pd.nA)) omega = D.pruned ? L : pd.nA;
         int32_t* nodesOrig = O.nodesOrig + rb;        // capacity L
         if (tid == 0) { sint[0] = 0; sint[1] = 0; }
         __syncthreads();
@@ -1769,7 +1787,7 @@ __device__ __noinline__ void finish_one(const DevParams& D, int b, const ProbDes
                 __syncthreads();
                 if (tid == 0) {
                     const int kk = min(omega, L);      // heap capacity bounded by the scratch size
-                    heap_select_serial(u, lpAsc + lo, vecOfLive ? vecOfLive + lo : nullptr, L, pd.nA, kk, pv, pidx, nodesOrig);
+                    heap_select_serial(u, lpAsc + lo, vecOfLive ? vecOfLive + lo : nullptr, L, pd.nA, kk, D.pruned != 0, pv, pidx, nodesOrig);
                     sint[0] = kk;
                 }
                 __syncthreads();

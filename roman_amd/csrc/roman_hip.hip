@@ -192,7 +192,7 @@ int make_dev_params(roman_ctx* c, const roman_params_t* p, int32_t F, DevParams*
 {
     if (!p) return fail(c, ROMAN_E_INVALID, "params is NULL");
     if (p->point_dim != 2 && p->point_dim != 3) return fail(c, ROMAN_E_INVALID, "point_dim must be 2 or 3 (got %d)", p->point_dim);
-    if (p->invariant != ROMAN_INV_EUCLIDEAN && p->invariant != ROMAN_INV_ROMAN) return fail(c, ROMAN_E_INVALID, "unknown invariant %d", p->invariant);
+    if (p->invariant != ROMAN_INV_EUCLIDEAN && p->invariant != ROMAN_INV_ROMAN && p->invariant != ROMAN_INV_EUCLIDEAN_PRUNED) return fail(c, ROMAN_E_INVALID, "unknown invariant %d", p->invariant);
     if (p->ratio_feature_dim < 0 || p->ratio_feature_dim > ROMAN_MAX_RATIO_FEATURES) return fail(c, ROMAN_E_INVALID, "ratio_feature_dim out of range");
     if (p->cos_feature_dim < 0) return fail(c, ROMAN_E_INVALID, "cos_feature_dim < 0");
     if (p->drift_aware) return fail(c, ROMAN_E_UNSUPPORTED, "drift_aware is not defined by the reference call sites (always False)");
@@ -202,7 +202,7 @@ int make_dev_params(roman_ctx* c, const roman_params_t* p, int32_t F, DevParams*
     if (p->single_mode < 0 || p->single_mode > 3) return fail(c, ROMAN_E_INVALID, "unknown single_mode %d", p->single_mode);
     if (p->reserved != 0) return fail(c, ROMAN_E_INVALID, "roman_params_t.reserved must be 0");
     if (!(p->sigma > 0.0)) return fail(c, ROMAN_E_INVALID, "sigma must be > 0");
-    const int need = (p->invariant == ROMAN_INV_ROMAN) ? p->point_dim + p->ratio_feature_dim + p->cos_feature_dim : p->point_dim;
+    const int need = (p->invariant != ROMAN_INV_EUCLIDEAN) ? p->point_dim + p->ratio_feature_dim + p->cos_feature_dim : p->point_dim;
     if (F < need) return fail(c, ROMAN_E_INVALID, "F=%d smaller than the %d features the invariant reads", F, need);
     memset(D, 0, sizeof(*D));
     D->p = *p;
@@ -211,10 +211,12 @@ int make_dev_params(roman_ctx* c, const roman_params_t* p, int32_t F, DevParams*
     D->sin_unc = std::sin(p->gravity_unc_ang_rad);
     D->x_eps = sqrt_threshold(p->epsilon);
     D->x_mindist = sqrt_threshold(p->mindist);
-    D->single = (p->invariant == ROMAN_INV_ROMAN) && (p->ratio_feature_dim > 0 || p->cos_feature_dim > 0);
+    if (p->invariant == ROMAN_INV_EUCLIDEAN_PRUNED) { D->p.gravity_guided = 0; D->p.gravity_mode = 0; D->p.single_mode = ROMAN_SINGLE_DIAG; }   // the pair score alone in M
+    D->single = (p->invariant != ROMAN_INV_EUCLIDEAN) && (p->ratio_feature_dim > 0 || p->cos_feature_dim > 0);
+    D->pruned = (p->invariant == ROMAN_INV_EUCLIDEAN_PRUNED && D->single) ? 1 : 0;
     D->gravity = (p->invariant == ROMAN_INV_ROMAN) && p->gravity_guided;
     D->gmode = D->gravity ? 1 + p->gravity_mode : 0;
-    D->diag_one = D->single && D->p.single_mode == ROMAN_SINGLE_OFFDIAG;
+    D->diag_one = D->single && (D->p.single_mode == ROMAN_SINGLE_OFFDIAG || D->pruned);
     D->keep_all = D->single && D->p.single_mode == ROMAN_SINGLE_DIAG_KEEP;
     D->F = F;
     D->stream_maxL = STREAM_MAXL;

@@ -422,3 +422,35 @@ def test_sizing_history_of_one_parameter_block_is_not_applied_to_another(orc):
             assert np.array_equal(a[b, :n[b]], ob["assoc"]), b
     finally:
         hip.free_all(); c.close()
+
+
+def test_prefilter_on_the_device_equals_the_host_prefilter(ctx, orc):
+    """DistRegWithPruning(prune_on_device=True) — the cosine / shape-ratio prefilter of
+    [REF roman/align/dist_reg_with_pruning.py:71-97] evaluated by the single-score kernels (raw descriptor products on the f64
+    matrix core, ratio gates), the pruned list never on the host — against (a) the same plugin with the NumPy prefilter and an
+    explicit list and (b) the oracle, in ONE ragged batch that includes a pair where nothing survives (all-to-all then)."""
+    from roman_amd.align.dist_reg_with_pruning import DistRegWithPruning
+    specs = [({"cosine_min": 0.5, "epsilon_shape": 0.1}, 50, 50, 64, 1012), ({"cosine_min": 0.6}, 40, 30, 64, 1013), ({"cosine_min": 0.9999}, 24, 24, 64, 1015),
+             ({"cosine_min": 0.5}, 60, 60, 64, 15)]
+    for kw, n, m, d, seed in specs:
+        host = registration_for("clipper+prune", **kw); host.set_context(ctx)
+        dev = DistRegWithPruning(host.sigma, host.epsilon, host.mindist, host.shape_epsilon, host.cos_min, dim=3, use_gravity=True, prune_on_device=True)
+        dev.set_context(ctx)
+        pr = synth.make_pair(n, m, d, seed)
+        want = host.register_and_align_batch([(pr.map1, pr.map2)])
+        got = dev.register_and_align_batch([(pr.map1, pr.map2)])
+        assert np.array_equal(got.assoc[0], want.assoc[0]) and got.status[0] == want.status[0]
+        assert got.stats["n_live"][0] == want.stats["n_live"][0] and got.stats["nnz_upper"][0] == want.stats["nnz_upper"][0]
+        assert got.stats["n_assoc_in"][0] == n * m                     # the device scored the all-to-all list itself
+        if got.status[0] == 0:
+            assert np.linalg.norm(got.T[0] - want.T[0]) < POSE_TOL
+        o = orc.register(dev._abi_params(), dev.pack(pr.map1), dev.pack(pr.map2))
+        assert np.array_equal(got.assoc[0], o["assoc"]) and got.stats["n_pass"][0] == o["stats"].n_pass
+    # several pairs in one call (one parameter block: the descriptor length is part of it)
+    kw = {"cosine_min": 0.55, "epsilon_shape": 0.05}
+    host = registration_for("clipper+prune", **kw); host.set_context(ctx)
+    dev = DistRegWithPruning(host.sigma, host.epsilon, host.mindist, host.shape_epsilon, host.cos_min, dim=3, use_gravity=True, prune_on_device=True); dev.set_context(ctx)
+    prs = [synth.make_pair(30 + 5 * k, 28 + 3 * k, 32, 1700 + k) for k in range(5)]
+    want = host.register_and_align_batch([(p.map1, p.map2) for p in prs]); got = dev.register_and_align_batch([(p.map1, p.map2) for p in prs])
+    for b in range(5):
+        assert np.array_equal(got.assoc[b], want.assoc[b]), b

@@ -224,3 +224,23 @@ def test_register_many_equals_register_per_problem(orc):
     got = orc.register_many(P, feats, off1, n1, off2, n2, kmax=40, u0=np.concatenate(u0s))
     for (D1, D2), g, u0 in zip(mats, got, u0s):
         assert np.array_equal(g, orc.register(P, D1, D2, u0=u0 if len(u0) else None, faithful=False)["assoc"])
+
+
+@pytest.mark.parametrize("kw, n, m, d, seed", [({"cosine_min": 0.5, "epsilon_shape": 0.1}, 50, 50, 64, 1012), ({"cosine_min": 0.6}, 40, 30, 32, 1013),
+                                              ({"cosine_min": 0.9999}, 24, 24, 16, 1015)])
+def test_prefilter_as_an_invariant_equals_the_explicit_pruned_list(orc, kw, n, m, d, seed):
+    """ROMAN_INV_EUCLIDEAN_PRUNED (the prefilter of [REF roman/align/dist_reg_with_pruning.py:71-97] moved
+    behind the C ABI) gives what the reference's sequence gives — NumPy prefilter, then plain CLIPPER on the pruned list,
+    and on the all-to-all list when nothing survives: same associations, same matrix size."""
+    from roman_amd.align.dist_reg_with_pruning import DistRegWithPruning
+    host = registration_for("clipper+prune", **kw)
+    dev = DistRegWithPruning(host.sigma, host.epsilon, host.mindist, host.shape_epsilon, host.cos_min, dim=3, use_gravity=True, prune_on_device=True)
+    pr = synth.make_pair(n, m, d, seed)
+    A = host._association_list(pr.map1, pr.map2)               # the reference's NumPy prefilter (None: nothing survived -> all-to-all)
+    want = orc.register(host._abi_params(), host.pack(pr.map1), host.pack(pr.map2), A)
+    D1, D2 = dev.pack(pr.map1), dev.pack(pr.map2)
+    assert D1.shape[1] == 3 + 4 + d and dev._association_list(pr.map1, pr.map2) is None
+    got = orc.register(dev._abi_params(), D1, D2)
+    assert np.array_equal(got["assoc"], want["assoc"])
+    assert got["stats"].nnz_upper == want["stats"].nnz_upper and got["stats"].n_live == (len(A) if A is not None else n * m)
+    assert got["stats"].n_pass == want["stats"].n_pass
