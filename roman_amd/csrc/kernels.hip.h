@@ -2560,19 +2560,25 @@ __global__ void __launch_bounds__(NW * 64) k_solve_up(DevParams D, int B, const 
     uint32_t* cumQ = reinterpret_cast<uint32_t*>(red + 2 * NW * RED_STRIDE + 8);
     int* sint = reinterpret_cast<int*>(cumQ + ST_MAXSL + 2);
     for (;;) {
-        if (threadIdx.x == 0) sint[2] = atomicAdd(queue, 1);
+        // thread 0 claims problems until it finds one this launch takes (stream layout, live-set size in [Llo, Lhi]): the
+        // others — the fallback solver's, skipped ones, the other instantiation's — cost one atomic and two loads, no barrier
+        if (threadIdx.x == 0) {
+            int b_;
+            for (;;) {
+                b_ = atomicAdd(queue, 1);
+                if (b_ >= B) break;
+                const int Lq = st[b_].L;
+                if (st[b_].kind == 0 && Lq >= Llo && Lq <= Lhi) break;
+            }
+            sint[2] = b_;
+        }
         __syncthreads();
         const int b = uni(sint[2]);
         __syncthreads();
         if (b >= B) break;
-        // (plain if / else on a scalar, no `continue`: every wave must reach the two barriers above the same number of
-        // times, and a `continue` out of a branch only thread 0 works in was compiled into a loop that did not)
-        const int kind = uni(st[b].kind), Lb = uni(st[b].L);
-        if (kind == 0 && Lb >= Llo && Lb <= Lhi) {
-            const ProbDesc pd = probs[b];
-            solve_up<NW, HASCZ, MAXL>(D, b, pd, st, feats, assoc, plp, lpAsc, rowPos, pld, sliceBase, cols, vals, u0, O,
-                                      xg, accM, accC, Lc, cumQ, red, sint);
-        }                                                       // kind 1: the fallback solver's problem; kind 2: skipped (k_skipped)
+        const ProbDesc pd = probs[b];
+        solve_up<NW, HASCZ, MAXL>(D, b, pd, st, feats, assoc, plp, lpAsc, rowPos, pld, sliceBase, cols, vals, u0, O,
+                                  xg, accM, accC, Lc, cumQ, red, sint);
     }
 }
 
