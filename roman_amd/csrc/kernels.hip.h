@@ -1418,10 +1418,10 @@ __device__ __forceinline__ double fill_value(const DevParams& D, double a, doubl
     return fuse_pair(D, sa, sk, sq);
 }
 
-template <bool GRAV, bool FAST>
+template <bool GRAV, bool FAST, bool OBJ>
 __global__ void __launch_bounds__(1024) k_fill_list(DevParams D, int B, const ProbDesc* __restrict__ probs,
                                                     ProbState* __restrict__ st, const BatchTotals* __restrict__ tot,
-                                                    const double* __restrict__ tabPool,
+                                                    const double* __restrict__ tabPool, const double* __restrict__ feats, int NO /* OBJ: object capacity per map */,
                                                     const int32_t* __restrict__ li, const int32_t* __restrict__ lj,
                                                     const double* __restrict__ ls,
                                                     const double* __restrict__ lza, const double* __restrict__ lzb,
@@ -1432,12 +1432,16 @@ __global__ void __launch_bounds__(1024) k_fill_list(DevParams D, int B, const Pr
                                                     const uint32_t* __restrict__ sliceBase,
                                                     uint16_t* __restrict__ cols, double* __restrict__ vals, int TC, int NG, int SPI /* LDS capacity: slices per group */)
 {
-    // LDS: cS[TC] [GRAV: cZa[TC] cZb[TC]] cI[TC] cJ[TC] | gK gCnt gOff [SPI*64] | gQ[SPI+1] gSB[SPI+1] | cP[TC] (u16)
+    // LDS: cS[TC] [OBJ: sO[2*NO] (x, y, z, -) | else GRAV: cZa[TC] cZb[TC]] cI[TC] cJ[TC] | gK gCnt gOff [SPI*64] | gQ[SPI+1] gSB[SPI+1] | cP[TC] (u16)
+    // OBJ: the two distances of an entry are RECOMPUTED from the objects' coordinates (LDS) with k_tables' own operation
+    // sequence — the same bits — instead of gathered from the tables: a wave's 64 lanes are 64 different rows, every table
+    // gather touched 64 cache lines for 64 doubles (4 GB of L2 -> L1 line traffic per batch of 256 at config 3, the kernel's bound).
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* cS = reinterpret_cast<double*>(smem);
-    double* cZa = cS + TC;
-    double* cZb = cZa + (GRAV ? TC : 0);
-    int32_t* cI = reinterpret_cast<int32_t*>(cZb + (GRAV ? TC : 0));
+    dbl2_t* sO = reinterpret_cast<dbl2_t*>(cS + TC);            // object o of map 1: sO[2o], sO[2o+1]; of map 2: sO[2(NO+o)], ...
+    double* cZa = OBJ ? cS + TC + 8 * NO : cS + TC;
+    double* cZb = cZa + ((GRAV && !OBJ) ? TC : 0);
+    int32_t* cI = reinterpret_cast<int32_t*>(cZb + ((GRAV && !OBJ) ? TC : 0));
     int32_t* cJ = cI + TC;
     uint32_t* gK = reinterpret_cast<uint32_t*>(cJ + TC);         // rows of the group's slices: live index (~0: no row)
     uint32_t* gCnt = gK + SPI * 64;                     //   kept candidates
@@ -1474,8 +1478,18 @@ __global__ void __launch_bounds__(1024) k_fill_list(DevParams D, int B, const Pr
         __syncthreads();                        // every wave is done with the previous group's tile
         for (int q = tid; q < L; q += nt) {
             cI[q] = li[lo + q]; cJ[q] = lj[lo + q]; cS[q] = ls[lo + q]; cP[q] = (uint16_t)rowPos[lo + q];
-            if (GRAV) { cZa[q] = lza[lo + q]; cZb[q] = lzb[lo + q]; }
+            if (GRAV && !OBJ) { cZa[q] = lza[lo + q]; cZb[q] = lzb[lo + q]; }
         }
+        if (OBJ) {
+            const int pdim = D.p.point_dim;
+            for (int o = tid; o < pd.n1 + pd.n2; o += nt) {
+                const double* f = feats + (o < pd.n1 ? pd.off1 + o : pd.off2 + (o - pd.n1)) * D.F;
+                const int slot = o < pd.n1 ? o : NO + (o - pd.n1);
+                sO[2 * slot] = dbl2_t{f[0], pdim > 1 ? f[1] : 0.0};
+                sO[2 * slot + 1] = dbl2_t{pdim > 2 ? f[2] : 0.0, 0.0};
+            }
+        }
+        const bool horiz = D.gmode == 1 || D.gmode == 2;        // the tables hold horizontal distances (k_tables)
         for (int x = tid; x < ns * 64; x += nt) {
             const int p = s_begin * 64 + x;
             const bool row = p < L;
@@ -1504,7 +1518,9 @@ __global__ void __launch_bounds__(1024) k_fill_list(DevParams D, int B, const Pr
             const double sk = cS[k];
             const double* TAr = TA + (int64_t)cI[k] * pd.n1;
             const double* TBr = TB + (int64_t)cJ[k] * pd.n2;
-            const double zak = GRAV ? cZa[k] : 0.0, zbk = GRAV ? cZb[k] : 0.0;
+            const double zak = (GRAV && !OBJ) ? cZa[k] : 0.0, zbk = (GRAV && !OBJ) ? cZb[k] : 0.0;
+            dbl2_t oa0 = {0.0, 0.0}, oa1 = {0.0, 0.0}, ob0 = {0.0, 0.0}, ob1 = {0.0, 0.0};
+            if (OBJ) { oa0 = sO[2 * cI[k]]; oa1 = sO[2 * cI[k] + 1]; ob0 = sO[2 * (NO + cJ[k])]; ob1 = sO[2 * (NO + cJ[k]) + 1]; }
             const uint32_t inert = ((uint32_t)L + (uint32_t)lane) | 0x8000u;     // the lane slot's own dummy column
             uint32_t cw[4]; double vv[4];
 #pragma unroll
@@ -1512,10 +1528,21 @@ __global__ void __launch_bounds__(1024) k_fill_list(DevParams D, int B, const Pr
                 const bool have = e0 + (uint32_t)j < cnt;
                 const uint32_t qr = ((j < 2 ? qq.x : qq.y) >> (16 * (j & 1))) & 0xffffu;
                 const int q = have ? (int)qr : k;               // (a padding entry evaluates the row against itself: discarded)
-                double a = TAr[cI[q]], bb = TBr[cJ[q]];
+                double a, bb, dza, dzb;
+                if (OBJ) {                                      // k_tables' sequence: dx*dx + dy*dy (+ dz*dz), one correctly rounded sqrt
+                    const dbl2_t pa0 = sO[2 * cI[q]], pa1 = sO[2 * cI[q] + 1], pb0 = sO[2 * (NO + cJ[q])], pb1 = sO[2 * (NO + cJ[q]) + 1];
+                    const double dxa = oa0.x - pa0.x, dya = oa0.y - pa0.y, dxb = ob0.x - pb0.x, dyb = ob0.y - pb0.y;
+                    dza = oa1.x - pa1.x; dzb = ob1.x - pb1.x;
+                    const double h2a = dxa * dxa + dya * dya, h2b = dxb * dxb + dyb * dyb;
+                    a = horiz ? sqrt(h2a) : sqrt(h2a + dza * dza);
+                    bb = horiz ? sqrt(h2b) : sqrt(h2b + dzb * dzb);
+                } else {
+                    a = TAr[cI[q]]; bb = TBr[cJ[q]];
+                    dza = GRAV ? zak - cZa[q] : 0.0; dzb = GRAV ? zbk - cZb[q] : 0.0;
+                }
                 if (!have) { a = 0.0; bb = 0.0; }
                 const double sq = cS[q];
-                const double v = fill_value<GRAV, FAST>(D, a, bb, GRAV ? zak - cZa[q] : 0.0, GRAV ? zbk - cZb[q] : 0.0, sk * sq, sk, sq);
+                const double v = fill_value<GRAV, FAST>(D, a, bb, GRAV ? dza : 0.0, GRAV ? dzb : 0.0, sk * sq, sk, sq);
                 const bool keep = have && v > D.p.affinityeps;  // otherwise the slot stays inert: neither in M nor in C
                 cw[j] = keep ? (uint32_t)cP[q] : inert;
                 vv[j] = keep ? v : 0.0;

@@ -534,14 +534,21 @@ int enqueue_score(roman_ctx* c, const DevParams& Din, const roman_params_t* para
         // list fill (stream layout): column tile + the rows and slice tables of one group
         const int colBytesF = D.gravity ? 32 : 16;
         const int TCs = D.stream_maxL;
-        const size_t sliceLds = (size_t)TCs * (colBytesF + 2) + sizeof(uint32_t) * (size_t)(3 * SPI * 64 + 2 * (SPI + 1) + 2);
+        // the objects' coordinates in LDS (32 bytes per object) instead of the z columns, when they fit: the fill then
+        // recomputes the distances instead of gathering them from the tables
+        static const char* objEnv = getenv("ROMAN_FILL_OBJ");
+        const int NO = (std::max(maxN, 1) + 1) & ~1;
+        const size_t groupLds = sizeof(uint32_t) * (size_t)(3 * SPI * 64 + 2 * (SPI + 1) + 2);
+        const bool obj = (objEnv ? atoi(objEnv) != 0 : true) && (size_t)TCs * (16 + 2) + (size_t)64 * NO + groupLds <= c->lds_max;
+        const size_t sliceLds = obj ? (size_t)TCs * (16 + 2) + (size_t)64 * NO + groupLds : (size_t)TCs * (colBytesF + 2) + groupLds;
         if (sliceLds > c->lds_max) return fail(c, ROMAN_E_TOO_LARGE, "internal: stream column tile does not fit the LDS");
         const bool fast = D.single && (D.p.single_mode == ROMAN_SINGLE_BOTH || D.p.single_mode == ROMAN_SINGLE_OFFDIAG) && D.p.distance_weight == 1.0 &&
                           D.p.fusion_method != ROMAN_FUSE_ARITHMETIC_MEAN && D.p.fusion_method != ROMAN_FUSE_PRODUCT;
-        auto kf = D.gravity ? (fast ? k_fill_list<true, true> : k_fill_list<true, false>) : (fast ? k_fill_list<false, true> : k_fill_list<false, false>);
+        auto kf = D.gravity ? (fast ? k_fill_list<true, true, false> : k_fill_list<true, false, false>) : (fast ? k_fill_list<false, true, false> : k_fill_list<false, false, false>);
+        if (obj) kf = D.gravity ? (fast ? k_fill_list<true, true, true> : k_fill_list<true, false, true>) : (fast ? k_fill_list<false, true, true> : k_fill_list<false, false, true>);
         HIPCHK(c, dyn_lds(c, reinterpret_cast<const void*>(kf), sliceLds));
         hipLaunchKernelGGL(kf, dim3((unsigned)(c->num_cu & ~7)), dim3(1024), sliceLds, WS.stream,
-                           D, B, dP, dS, dT, WS.tabPool.as<double>(), LP.li, LP.lj, LP.ls, LP.lza, LP.lzb,
+                           D, B, dP, dS, dT, WS.tabPool.as<double>(), in.feats, NO, LP.li, LP.lj, LP.ls, LP.lza, LP.lzb,
                            WS.listPool.as<uint16_t>(), WS.listOff.as<uint32_t>(), WS.rowCnt.as<uint32_t>(), WS.perm.as<uint32_t>(), WS.rowPos.as<uint32_t>(),
                            WS.sliceWidth.as<uint32_t>(), WS.sliceBase.as<uint32_t>(), WS.cols16.as<uint16_t>(), WS.vals.as<double>(), TCs, NG, SPI);
     DBG(c, "k_fill_list");
