@@ -206,15 +206,16 @@ __device__ __forceinline__ double root_w(double x, double w)
 __device__ __forceinline__ double pow_w(double x, double w) { return (w == 1.0) ? x : pow(x, w); }
 
 // Single score of one association; mirrors oracle single_score() operation for operation.
-__device__ inline double single_score(const DevParams& D, const double* __restrict__ fi,
-                                      const double* __restrict__ fj, double cosv)
+// ra(f), rb(f): ratio feature f of the two objects.
+template <class RA, class RB>
+__device__ __forceinline__ double single_score(const DevParams& D, RA ra, RB rb, double cosv)
 {
     const roman_params_t& P = D.p;
-    const int pd = P.point_dim, Fr = P.ratio_feature_dim, Fc = P.cos_feature_dim;
+    const int Fr = P.ratio_feature_dim, Fc = P.cos_feature_dim;
     if (D.pruned) {                         // the reference's NumPy prefilter ([REF roman/align/dist_reg_with_pruning.py:75-90]) as a 0/1 score;
         if (Fc > 0 && cosv < P.cosine_min) return 0.0;          // cosv is the RAW product here; a NaN compares false = keeps, as in NumPy
         for (int f = 0; f < Fr; ++f) {
-            const double a = fi[pd + f], b = fj[pd + f];
+            const double a = ra(f), b = rb(f);
             const double mn = a < b ? a : b, mx = a < b ? b : a;
             if (mn / mx < P.ratio_epsilon[f]) return 0.0;
         }
@@ -224,7 +225,7 @@ __device__ inline double single_score(const DevParams& D, const double* __restri
     if (Fr > 0) {
         double rp = 1.0;
         for (int f = 0; f < Fr; ++f) {
-            const double a = fi[pd + f], b = fj[pd + f];
+            const double a = ra(f), b = rb(f);
             const double mn = a < b ? a : b, mx = a < b ? b : a;
             const double r = (mx > 0.0) ? mn / mx : 1.0;
             if (r < P.ratio_epsilon[f]) return 0.0;
@@ -377,6 +378,186 @@ __global__ void __launch_bounds__(256) k_cos(DevParams D, int B, int G /* workgr
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_cos_tile<KC>: the same products, operands staged through LDS.  A workgroup (4 waves) owns an output tile of up to 64x64,
+// wave (wy, wx) the 2x2 MFMA blocks of its quarter.  Per stage of KC descriptor elements the 256 threads copy the tile's
+// row pieces of KC doubles from global memory to LDS with 16-byte loads whose lanes run ALONG a row (SEGS lanes cover one
+// row piece contiguously): every cache line that is touched is used completely, and a row is fetched once per workgroup
+// instead of once per wave — 256 bytes of loads per MFMA instead of 512.  Why that matters (rocprofv3 round 3, config 3):
+// the matrix pipe of k_cos is busy 42 % of the time; a load takes ~1.6 us under this load, so keeping the pipe fed takes
+// (bytes per MFMA) x (MFMA rate) x 1.6 us ~ 100 KB in flight per compute unit, and a wave of k_cos has nothing in flight
+// while it multiplies.  Here the loads of stages s + 1 and s + 2 are in flight while stage s is multiplied (two register
+// sets, two LDS stages, one barrier per stage).
+// Tiles are BALANCED: a dimension of nb 16-row blocks is cut into ceil(nb / 4) tiles of nb / tiles blocks, rounded either
+// way (13 blocks: 3 + 3 + 3 + 4, not 4 + 4 + 4 + 1) — a workgroup with one block column would wait for its loads 32 times
+// to issue a quarter of the MFMAs while it holds a quarter of the compute unit's registers.
+// The contraction order of every output element is k_cos' own — chunks of 16 ascending, MFMA t of a chunk contracts
+// k = k0 + 4 * (lane >> 4) + t —, so are the norm sums: identical bits.
+// ---------------------------------------------------------------------------------------------
+struct __attribute__((packed, aligned(8))) d2u_t { double v[2]; };      // 8-byte aligned 16-byte load
+
+__device__ __forceinline__ int cos_tiles(int n) { return (((n + 15) >> 4) + 3) >> 2; }            // tiles along a dimension of n rows
+
+template <int KC>
+__global__ void __launch_bounds__(256) k_cos_tile(DevParams D, int B, int G /* workgroups (tiles) per problem */,
+                                                  const ProbDesc* __restrict__ probs,
+                                                  const double* __restrict__ feats,
+                                                  double* __restrict__ cosPool)
+{
+    constexpr int PITCH = KC * 8 + 16;           // bytes per staged row piece (the 16 spread the rows over the banks)
+    constexpr int SEGS = KC / 2;                 // 16-byte segments per row piece
+    constexpr int RPI = 256 / SEGS;              // rows per load instruction of the workgroup
+    constexpr int NLD = 128 / RPI;               // load instructions per stage and thread (first half: A rows, second half: B rows)
+    constexpr int STAGE = 128 * PITCH;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 2 stages x (64 A rows + 64 B rows) x PITCH
+    // (the grid may be smaller than the number of tiles: the workgroups then loop)
+    const int xcd = blockIdx.x & 7, nSlots = G * ((B + 7) >> 3);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    for (int slot = blockIdx.x >> 3; slot < nSlots; slot += gridDim.x >> 3) {
+    const int b = (slot / G) * 8 + xcd;          // all tiles of a problem on one XCD (k_cos)
+    if (b >= B) continue;
+    const ProbDesc pd = probs[b];
+    const int ti_n = cos_tiles(pd.n1), tj_n = cos_tiles(pd.n2);
+    const int tile = slot % G;
+    if (tile >= ti_n * tj_n) continue;
+    const int ti = tile / tj_n, tj = tile - ti * tj_n;
+    const int nbi = (pd.n1 + 15) >> 4, nbj = (pd.n2 + 15) >> 4;
+    const int bi0 = ti * nbi / ti_n, bj0 = tj * nbj / tj_n;                    // first block of the tile
+    const int nbx = (ti + 1) * nbi / ti_n - bi0, nby = (tj + 1) * nbj / tj_n - bj0;   // blocks of the tile: 1..4
+    const int i0 = bi0 * 16, j0 = bj0 * 16;
+    const int iEnd = min(pd.n1, i0 + 16 * nbx), jEnd = min(pd.n2, j0 + 16 * nby);    // rows / columns of the tile
+    const int Fc = D.p.cos_feature_dim, coff = D.p.point_dim + D.p.ratio_feature_dim;
+    const int lr = lane & 15, kq = lane >> 4;
+    // which quarter a wave takes rotates with the tile: a tile of 3 blocks gives its quarters 2 and 1, and a wave index is a SIMD
+    const int ws = (w + tile) & 3, wy = ws >> 1, wx = ws & 1;
+
+    // the thread's share of a stage
+    const int seg = tid % SEGS, row0 = tid / SEGS;
+    const double* gp[NLD]; bool gv[NLD];
+#pragma unroll
+    for (int q = 0; q < NLD; ++q) {
+        const int r = (q * RPI + row0) & 63;
+        const bool isA = q < NLD / 2;
+        const int gr = (isA ? i0 : j0) + r;
+        gv[q] = gr < (isA ? iEnd : jEnd);
+        gp[q] = feats + ((isA ? pd.off1 : pd.off2) + (gv[q] ? gr : 0)) * D.F + coff + 2 * seg;
+    }
+    // (no control flow around the loads of the main loop: the compiler's wait-count pass then lets two stages fly)
+    auto gload = [&](dbl2_t (&stg)[NLD], int k0) {
+#pragma unroll
+        for (int q = 0; q < NLD; ++q) {
+            const d2u_t t = *reinterpret_cast<const d2u_t*>(gp[q] + k0);
+            stg[q] = dbl2_t{t.v[0], t.v[1]};
+        }
+    };
+    auto gload_ragged = [&](dbl2_t (&stg)[NLD], int k0) {      // last stage of a descriptor that is no multiple of KC: element by element
+        const int k = k0 + 2 * seg;
+#pragma unroll
+        for (int q = 0; q < NLD; ++q) stg[q] = dbl2_t{k < Fc ? gp[q][k0] : 0.0, k + 1 < Fc ? gp[q][k0 + 1] : 0.0};
+    };
+    auto lstore = [&](const dbl2_t (&stg)[NLD], int buf) {
+#pragma unroll
+        for (int q = 0; q < NLD; ++q)                // rows behind the tile: zeros
+            *reinterpret_cast<dbl2_t*>(smem + buf * STAGE + (q * RPI + row0) * PITCH + seg * 16) = gv[q] ? stg[q] : dbl2_t{0.0, 0.0};
+    };
+
+    bool onA[2], onB[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        onA[h] = uni_i(2 * wy + h < nbx) != 0;
+        onB[h] = uni_i(2 * wx + h < nby) != 0;
+    }
+    double4_t acc[2][2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) acc[x][y] = double4_t{0.0, 0.0, 0.0, 0.0};
+    double sa[2] = {0.0, 0.0}, sb[2] = {0.0, 0.0};
+    const int offA = (32 * wy + lr) * PITCH + 32 * kq, offB = (64 + 32 * wx + lr) * PITCH + 32 * kq;
+
+    auto compute = [&](int s) {
+        const unsigned char* base = smem + (s & 1) * STAGE;
+        if (onA[0] && onB[0]) {
+#pragma unroll
+            for (int kc = 0; kc < KC; kc += 16) {
+                if (s * KC + kc < Fc) {
+                    double a[2][4], bq[2][4];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const dbl2_t a0 = *reinterpret_cast<const dbl2_t*>(base + offA + 16 * h * PITCH + kc * 8);
+                        const dbl2_t a1 = *reinterpret_cast<const dbl2_t*>(base + offA + 16 * h * PITCH + kc * 8 + 16);
+                        const dbl2_t b0 = *reinterpret_cast<const dbl2_t*>(base + offB + 16 * h * PITCH + kc * 8);
+                        const dbl2_t b1 = *reinterpret_cast<const dbl2_t*>(base + offB + 16 * h * PITCH + kc * 8 + 16);
+                        a[h][0] = a0.x; a[h][1] = a0.y; a[h][2] = a1.x; a[h][3] = a1.y;
+                        bq[h][0] = b0.x; bq[h][1] = b0.y; bq[h][2] = b1.x; bq[h][3] = b1.y;
+                    }
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) { sa[h] = fma(a[h][t], a[h][t], sa[h]); sb[h] = fma(bq[h][t], bq[h][t], sb[h]); }
+#pragma unroll
+                        for (int x = 0; x < 2; ++x)
+#pragma unroll
+                            for (int y = 0; y < 2; ++y)
+                                if (onA[x] && onB[y]) acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[x][t], bq[y][t], acc[x][y], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    };
+
+    // stage s is multiplied while the loads of stages s + 1 (register set of the other parity) and s + 2 (this parity's) fly
+    // (every load of the loop is UNCONDITIONAL — beyond the last stage it fetches that stage again: a load inside an `if`
+    // makes the compiler's wait-count pass assume the shorter queue at the join and wait for everything in flight)
+    const int SF = Fc / KC;                          // full stages; a ragged one may follow
+    dbl2_t r0[NLD], r1[NLD];
+    if (SF > 0) {
+        gload(r0, 0);
+        gload(r1, min(1, SF - 1) * KC);
+        lstore(r0, 0);
+        __syncthreads();
+        for (int s = 0; s < SF; s += 2) {
+            gload(r0, min(s + 2, SF - 1) * KC);
+            compute(s);
+            lstore(r1, 1);
+            __syncthreads();
+            gload(r1, min(s + 3, SF - 1) * KC);
+            if (s + 1 < SF) compute(s + 1);
+            lstore(r0, 0);
+            __syncthreads();
+        }
+    }
+    if (SF * KC < Fc) {                              // (every wave is behind the last barrier: both LDS stages are free)
+        gload_ragged(r0, SF * KC);
+        lstore(r0, SF & 1);
+        __syncthreads();
+        compute(SF);
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {                    // every lane (lr, *) ends with the norm of row 16h + lr
+        sa[h] += __shfl_xor(sa[h], 16); sa[h] += __shfl_xor(sa[h], 32);
+        sb[h] += __shfl_xor(sb[h], 16); sb[h] += __shfl_xor(sb[h], 32);
+        sa[h] = sqrt(sa[h]); sb[h] = sqrt(sb[h]);
+    }
+#pragma unroll
+    for (int y = 0; y < 2; ++y) {
+        const int col = j0 + 32 * wx + 16 * y + lr;
+        const double nb = sb[y];
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+            if (onA[x] && onB[y])                    // (the divisions run on the same f64 units as the MFMAs)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = i0 + 32 * wy + 16 * x + kq + 4 * r;
+                const double na = __shfl(sa[x], kq + 4 * r);       // norm of row 16x + (kq + 4r): held by lanes with lr == kq + 4r
+                if (row < iEnd && col < jEnd)
+                    cosPool[pd.cosOff + (int64_t)row * pd.n2 + col] = D.pruned ? acc[x][y][r] : ((na > 0.0 && nb > 0.0) ? acc[x][y][r] / (na * nb) : 0.0);
+            }
+    }
+    __syncthreads();                                 // the next tile's first stage overwrites LDS stage 0
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_tables: TA[i][i'] (n1 x n1) and TB[j][j'] (n2 x n2).  Entry = horizontal distance (gravity)
 // or full distance (otherwise) between two objects of the same map; NaN when the two objects
 // coincide (distinctness) or are closer than mindist — every comparison against NaN is false, so
@@ -422,10 +603,10 @@ __global__ void __launch_bounds__(256) k_tables(DevParams D, const ProbDesc* __r
 // k_live<PHASE>: single score of every association and ordered (ascending association index)
 // compaction of the live ones, in two launches over chunks of LIVE_CHUNK associations (grid:
 // chunks x problems, so a single problem is spread over many CUs as well):
-//   PHASE 0  scores -> sTmp, number of live associations of the chunk -> chunkCnt
-//   PHASE 1  chunk base = sum of the counts in front of it (fixed order), ordered compaction; the
+//   PHASE 0  every wave owns a contiguous quarter of the chunk (a segment) and leaves the segment's live associations
+//            (index, score; in order) at the head of the segment's slice of a scratch pool, their number in segCnt
+//   PHASE 1  segment base = sum of the counts in front of it (fixed order), copy into the live pools; the
 //            workgroup of chunk 0 also publishes L.
-// Wave w of a workgroup owns a contiguous quarter of the chunk, so the order needs one cross-wave prefix.
 // ---------------------------------------------------------------------------------------------
 constexpr int LIVE_CHUNK = 4096;
 
@@ -435,96 +616,131 @@ __global__ void __launch_bounds__(256) k_live(DevParams D, const ProbDesc* __res
                                               const double* __restrict__ feats,
                                               const int32_t* __restrict__ assoc,
                                               const double* __restrict__ cosPool,
-                                              double* __restrict__ sTmp, int32_t* __restrict__ chunkCnt, int maxChunks,
+                                              double* __restrict__ qS, int32_t* __restrict__ qP /* the segments' live associations: score, index */,
+                                              int32_t* __restrict__ segCnt, int maxChunks,
                                               int32_t* __restrict__ lp, int32_t* __restrict__ li,
                                               int32_t* __restrict__ lj, double* __restrict__ ls, double* __restrict__ ld,
                                               double* __restrict__ lza, double* __restrict__ lzb)
 {
-    __shared__ int wtot[4];
     __shared__ int cbase[2];
+    __shared__ uint16_t survQ[PHASE == 0 ? 4 : 1][PHASE == 0 ? LIVE_CHUNK / 4 : 1];     // phase 0: per wave, the associations behind the cosine gate
     const int b = blockIdx.y, c = blockIdx.x;
     const ProbDesc pd = probs[b];
-    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, nw = blockDim.x >> 6;
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int nA = pd.nA;
     const int nChunks = (nA + LIVE_CHUNK - 1) / LIVE_CHUNK;
     if (c >= nChunks && !(PHASE == 1 && c == 0)) return;
-    const int seg = LIVE_CHUNK / 4;                              // per wave (blockDim.x == 256)
-    const int p_beg = min(nA, c * LIVE_CHUNK + w * seg), p_end = min(nA, p_beg + seg);
+    constexpr int SEG = LIVE_CHUNK / 4;                          // associations per wave (blockDim.x == 256)
+    constexpr int NIT = SEG / WAVE;
+    const int p_beg = min(nA, c * LIVE_CHUNK + w * SEG), p_end = min(nA, p_beg + SEG);
     const int Fc = D.p.cos_feature_dim;
-    double* sT = sTmp + pd.liveOff;
-    int32_t* cc = chunkCnt + (int64_t)b * maxChunks;
+    const int64_t lo = pd.liveOff;
+    int32_t* sc = segCnt + (int64_t)b * maxChunks * 4;           // live associations per wave segment, in association order
+    const unsigned long long lt = (1ull << lane) - 1ull;
 
     if (PHASE == 0) {
-        int cnt = 0;
-        for (int p0 = p_beg; p0 < p_end; p0 += WAVE) {
-            const int p = p0 + lane;
-            double s = 0.0;
-            if (p < p_end) {
-                int i, j;
-                decode_assoc(pd, assoc, p, i, j);
-                if (D.single) {
-                    const double cosv = (Fc > 0) ? cosPool[pd.cosOff + (int64_t)i * pd.n2 + j] : 0.0;
-                    s = single_score(D, feats + (pd.off1 + i) * D.F, feats + (pd.off2 + j) * D.F, cosv);
-                } else {
-                    s = 1.0;
+        // The wave leaves its segment's LIVE associations — index and score, in order — at the head of the segment's slice
+        // of (qP, qS), and their number in segCnt: nothing is written for the ~95 % that fail (a score array over all
+        // associations, written here and read back by phase 1, was 2 x 84 MB per batch of 256 at config 3 — these two
+        // kernels' whole time).  With a cosine term the cheap part of the score is a gate: the wave first sweeps its
+        // segment with the gate alone (all cosine loads in flight together), queues the survivors in LDS, and then
+        // evaluates the full score — ratios, roots, fusion: ~250 f64 instructions — for the survivors only, 64 at a time.
+        // single_score() returns 0 for an association that fails the gate whatever its ratios are, so nothing changes.
+        const int pdm = D.p.point_dim;
+        auto full_score = [&](int p) {
+            int i, j;
+            decode_assoc(pd, assoc, p, i, j);
+            const double cosv = (Fc > 0) ? cosPool[pd.cosOff + (int64_t)i * pd.n2 + j] : 0.0;
+            const double* fi = feats + (pd.off1 + i) * D.F + pdm; const double* fj = feats + (pd.off2 + j) * D.F + pdm;
+            return single_score(D, [&](int f) { return fi[f]; }, [&](int f) { return fj[f]; }, cosv);
+        };
+        int nlive = 0;
+        auto emit = [&](bool valid, int p, double s) {          // ordered append of the lanes with a live association
+            const bool live = valid && (s > 0.0 || D.keep_all);
+            const unsigned long long m = __ballot(live);
+            if (live) { const int k = p_beg + nlive + __popcll(m & lt); qP[lo + k] = p; qS[lo + k] = s; }
+            nlive += __popcll(m);
+        };
+        if (D.single && Fc > 0 && !D.keep_all) {
+            uint16_t* q = survQ[w];
+            const double cden = D.p.cosine_max - D.p.cosine_min;
+            int ns = 0;
+            double cv[NIT];
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int p = p_beg + it * WAVE + lane;
+                cv[it] = 0.0;
+                if (p < p_end) {
+                    int i, j;
+                    decode_assoc(pd, assoc, p, i, j);
+                    cv[it] = cosPool[pd.cosOff + (int64_t)i * pd.n2 + j];
                 }
-                sT[p] = s;
             }
-            cnt += __popcll(__ballot(p < p_end && (s > 0.0 || D.keep_all)));
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int p = p_beg + it * WAVE + lane;
+                const bool pass = p < p_end && (D.pruned ? !(cv[it] < D.p.cosine_min) : ((cv[it] - D.p.cosine_min) / cden > 0.0));
+                const unsigned long long m = __ballot(pass);
+                if (pass) q[ns + __popcll(m & lt)] = (uint16_t)(p - p_beg);
+                ns += __popcll(m);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (int k0 = 0; k0 < ns; k0 += WAVE) {
+                const int k = k0 + lane;
+                const int p = p_beg + (int)q[min(k, max(ns - 1, 0))];
+                emit(k < ns, p, k < ns ? full_score(p) : 0.0);
+            }
+        } else {
+            for (int p0 = p_beg; p0 < p_end; p0 += WAVE) {
+                const int p = p0 + lane;
+                emit(p < p_end, p, (p < p_end && D.single) ? full_score(p) : 1.0);
+            }
         }
-        if (lane == 0) wtot[w] = cnt;
-        __syncthreads();
-        if (tid == 0) { int t = 0; for (int k = 0; k < nw; ++k) t += wtot[k]; cc[c] = t; }
+        if (lane == 0) sc[c * 4 + w] = nlive;
         return;
     }
 
     // PHASE 1
-    if (w == 0) {                                               // counts in front of this chunk, and the problem total
+    if (w == 0) {                                               // live associations in front of this chunk, and the problem total
         int front = 0, total = 0;
-        for (int k0 = 0; k0 < nChunks; k0 += WAVE) {
+        for (int k0 = 0; k0 < nChunks * 4; k0 += WAVE) {
             const int k = k0 + lane;
-            const int v = k < nChunks ? cc[k] : 0;
-            int f = k < c ? v : 0, t = v;
+            const int v = k < nChunks * 4 ? sc[k] : 0;
+            int f = k < c * 4 ? v : 0, t = v;
             for (int off = 32; off > 0; off >>= 1) { f += __shfl_xor(f, off); t += __shfl_xor(t, off); }
             front += f; total += t;
         }
         if (lane == 0) { cbase[0] = front; cbase[1] = total; }
     }
-    int cnt = 0;
-    for (int p0 = p_beg; p0 < p_end; p0 += WAVE) {
-        const int p = p0 + lane;
-        cnt += __popcll(__ballot(p < p_end && (D.keep_all || sT[p] > 0.0)));
-    }
-    if (lane == 0) wtot[w] = cnt;
     __syncthreads();
     // ROMAN_INV_EUCLIDEAN_PRUNED with NO survivor: the reference hands clipperpy an empty list, i.e. the all-to-all one
     const bool all_live = D.pruned && cbase[1] == 0 && nA > 0;
-    int base = cbase[0];
-    for (int k = 0; k < w; ++k) base += wtot[k];
-    if (all_live) base = p_beg;                                 // live index == association index
     const int Ltot = all_live ? nA : cbase[1];
     if (c == 0 && tid == 0) {
         st[b].L = Ltot; st[b].nnzUpper = 0ull;
         st[b].kind = (Ltot <= D.stream_maxL && D.p.maxiniters >= 1 && D.p.maxlsiters >= 1) ? 0 : (D.allow_fallback ? 1 : 2);
     }
-
-    const int64_t lo = pd.liveOff;
-    for (int p0 = p_beg; p0 < p_end; p0 += WAVE) {
-        const int p = p0 + lane;
-        const double s = (p < p_end) ? (all_live ? 1.0 : sT[p]) : 0.0;
-        const bool live = p < p_end && (s > 0.0 || D.keep_all);
-        const unsigned long long m = __ballot(live);
-        if (live) {
-            const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+    if (c >= nChunks) return;
+    int base = cbase[0];
+    for (int k = 0; k < w; ++k) base += sc[c * 4 + k];
+    const int n = all_live ? p_end - p_beg : sc[c * 4 + w];
+    if (all_live) base = p_beg;                                 // live index == association index
+    const bool has_z = D.p.point_dim == 3;
+    for (int k0 = 0; k0 < n; k0 += WAVE) {
+        const int k = k0 + lane;
+        if (k < n) {
+            const int p = all_live ? p_beg + k : qP[lo + p_beg + k];
+            const double s = all_live ? 1.0 : qS[lo + p_beg + k];
             int i, j;
             decode_assoc(pd, assoc, p, i, j);
+            const int pos = base + k;
             lp[lo + pos] = p; li[lo + pos] = i; lj[lo + pos] = j; ls[lo + pos] = s;
             ld[lo + pos] = D.diag_one ? 1.0 : s;               // M_pp: the single score, or the identity (ROMAN_SINGLE_OFFDIAG)
-            const bool has_z = D.p.point_dim == 3;
             lza[lo + pos] = has_z ? feats[(pd.off1 + i) * D.F + 2] : 0.0;
             lzb[lo + pos] = has_z ? feats[(pd.off2 + j) * D.F + 2] : 0.0;
         }
-        base += __popcll(m);
     }
 }
 
@@ -906,6 +1122,33 @@ __global__ void __launch_bounds__(1024) k_rowprefix(const ProbDesc* __restrict__
         const int64_t lo = probs[b].liveOff, mo = st[b].maskOff;
         const int nrows = min(RPB, L - it.row0);
         const bool wantPrefix = st[b].kind != 0;               // the stream layout takes its prefix counts in k_upper
+        if (W <= WAVE) {                                        // one word per lane: four rows per step, their loads in flight together
+            constexpr int U = 4;
+            for (int r = w; r < nrows; r += U * wpb) {
+                uint32_t c[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int k = it.row0 + min(r + u * wpb, nrows - 1);
+                    c[u] = (lane < W) ? (uint32_t)__popcll(maskPool[mo + (int64_t)k * W + lane]) : 0u;
+                }
+                uint32_t inc[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) inc[u] = c[u];
+#pragma unroll
+                for (int off = 1; off < WAVE; off <<= 1)
+#pragma unroll
+                    for (int u = 0; u < U; ++u) { const uint32_t t_ = __shfl_up(inc[u], off); if (lane >= off) inc[u] += t_; }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (r + u * wpb < nrows) {
+                        const int k = it.row0 + r + u * wpb;
+                        if (wantPrefix && lane < W) prefPool[mo + (int64_t)k * W + lane] = inc[u] - c[u];
+                        if (lane == WAVE - 1) rowCnt[lo + k] = inc[u];
+                    }
+                }
+            }
+            continue;
+        }
         for (int r = w; r < nrows; r += wpb) {
             const int k = it.row0 + r;
             const unsigned long long* mrow = maskPool + mo + (int64_t)k * W;

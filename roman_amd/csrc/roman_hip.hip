@@ -326,12 +326,40 @@ int may_fallback(const DevParams& D, const std::vector<ProbDesc>& hd);
 // ---- the launch sequence of one batch (score + solve), on workspace c->cur and its stream; never waits -------------
 struct BatchOut { int32_t kmax; int32_t* assoc_out; int32_t* n_assoc_out; double* T_out; int32_t* status_out; roman_stats_t* stats_out; };
 
+// Cosine matrices of B problems: k_cos_tile (64x64 tile per workgroup, operands through LDS) by default; ROMAN_COS=0 selects
+// k_cos (32x32 tile per wave, operands from global memory), ROMAN_COS=16 / 32 the stage depth.
+static hipError_t launch_cos(roman_ctx* c, hipStream_t stream, const DevParams& D, int B, int maxN1, int maxN2, const ProbDesc* dP, const double* feats, double* cosPool)
+{
+    static const char* env = getenv("ROMAN_COS");
+    const int mode = env ? atoi(env) : 16;
+    if (mode == 0) {
+        const int tiles = ((maxN1 + COS_TILE - 1) / COS_TILE) * ((maxN2 + COS_TILE - 1) / COS_TILE), G = (tiles + 3) / 4;
+        hipLaunchKernelGGL(k_cos, dim3((unsigned)(G * ((B + 7) / 8) * 8)), dim3(256), 0, stream, D, B, G, dP, feats, cosPool);
+        return hipGetLastError();
+    }
+    auto tiles = [](int n) { return (((n + 15) >> 4) + 3) >> 2; };     // cos_tiles()
+    const int G = tiles(maxN1) * tiles(maxN2);
+    const int KC = mode == 32 ? 32 : 16;
+    const size_t lds = (size_t)2 * 128 * (KC * 8 + 16);
+    auto kf = KC == 16 ? k_cos_tile<16> : k_cos_tile<32>;
+    const hipError_t e = dyn_lds(c, reinterpret_cast<const void*>(kf), lds);
+    if (e != hipSuccess) return e;
+    // one workgroup per tile; ROMAN_COS_WGS=n: n persistent workgroups per compute unit looping over the tiles (measured
+    // slower at config 3: 376 against 324 us — the static deal balances worse than the dispatcher)
+    static const char* wgEnv = getenv("ROMAN_COS_WGS");
+    const int perCu = wgEnv ? atoi(wgEnv) : 0;
+    const int total = G * ((B + 7) / 8) * 8;
+    const int grid = perCu > 0 ? std::min(total, (c->num_cu & ~7) * perCu) : total;
+    hipLaunchKernelGGL(kf, dim3((unsigned)grid), dim3(256), lds, stream, D, B, G, dP, feats, cosPool);
+    return hipGetLastError();
+}
+
 int enqueue_score(roman_ctx* c, const DevParams& Din, const roman_params_t* params, const BatchIn& in, std::vector<ProbDesc>& hd, DevParams* Dout)
 {
     const int B = in.B;
     hd.assign(B, ProbDesc{});
     int64_t sumA = 0, sumCos = 0, sumTab = 0;
-    int maxN12 = 0, maxTiles = 0, maxN = 0, maxA = 0; int64_t maxTab = 0;
+    int maxN12 = 0, maxN = 0, maxA = 0, maxN1 = 0, maxN2 = 0; int64_t maxTab = 0;
     for (int b = 0; b < B; ++b) {
         ProbDesc& d = hd[b];
         d.off1 = in.off1[b]; d.off2 = in.off2[b]; d.n1 = in.n1[b]; d.n2 = in.n2[b];
@@ -351,7 +379,7 @@ int enqueue_score(roman_ctx* c, const DevParams& Din, const roman_params_t* para
         maxA = std::max(maxA, d.nA);
         sumA += d.nA; sumCos += (int64_t)d.n1 * d.n2; sumTab += (int64_t)d.n1 * d.n1 + (int64_t)d.n2 * d.n2;
         maxN12 = std::max(maxN12, d.n1 + d.n2); maxN = std::max(maxN, std::max(d.n1, d.n2));
-        maxTiles = std::max(maxTiles, ((d.n1 + COS_TILE - 1) / COS_TILE) * ((d.n2 + COS_TILE - 1) / COS_TILE));
+        maxN1 = std::max(maxN1, d.n1); maxN2 = std::max(maxN2, d.n2);
         maxTab = std::max(maxTab, (int64_t)d.n1 * d.n1 + (int64_t)d.n2 * d.n2);
     }
     if (sumA > 2000000000LL) return fail(c, ROMAN_E_TOO_LARGE, "batch has %lld associations; split it (limit 2e9 per call)", (long long)sumA);
@@ -429,9 +457,8 @@ int enqueue_score(roman_ctx* c, const DevParams& Din, const roman_params_t* para
     const LivePools PP{WS.plp.as<int32_t>(), WS.pli.as<int32_t>(), WS.plj.as<int32_t>(), WS.pls.as<double>(), WS.pld.as<double>(), WS.plza.as<double>(), WS.plzb.as<double>()};
 
     StageTimer t0(c, ROMAN_STAGE_SINGLE);
-    if (cosOn && maxN12 > 0 && maxTiles > 0) {
-        const int G = (maxTiles + 3) / 4;
-        hipLaunchKernelGGL(k_cos, dim3((unsigned)(G * ((B + 7) / 8) * 8)), dim3(256), 0, WS.stream, D, B, G, dP, in.feats, WS.cosPool.as<double>());
+    if (cosOn && maxN1 > 0 && maxN2 > 0) {
+        HIPCHK(c, launch_cos(c, WS.stream, D, B, maxN1, maxN2, dP, in.feats, WS.cosPool.as<double>()));
     DBG(c, "k_cos");
     }
     if (maxTab > 0) {
@@ -443,10 +470,10 @@ int enqueue_score(roman_ctx* c, const DevParams& Din, const roman_params_t* para
     }
     {   // single scores, then the ordered compaction of the live associations: chunks x problems
         const int maxChunks = std::max(1, (maxA + LIVE_CHUNK - 1) / LIVE_CHUNK);
-        HIPCHK(c, WS.chunkCnt.ensure(sizeof(int32_t) * (size_t)B * (size_t)maxChunks));
-        hipLaunchKernelGGL(k_live<0>, dim3((unsigned)maxChunks, (unsigned)B), dim3(256), 0, WS.stream, D, dP, dS, in.feats, in.assoc, WS.cosPool.as<double>(), WS.sTmp.as<double>(),
+        HIPCHK(c, WS.chunkCnt.ensure(sizeof(int32_t) * (size_t)B * (size_t)maxChunks * 4));      // live associations per wave segment
+        hipLaunchKernelGGL(k_live<0>, dim3((unsigned)maxChunks, (unsigned)B), dim3(256), 0, WS.stream, D, dP, dS, in.feats, in.assoc, WS.cosPool.as<double>(), WS.sTmp.as<double>(), PP.lp /* scratch until k_upper */,
                            WS.chunkCnt.as<int32_t>(), maxChunks, LP.lp, LP.li, LP.lj, LP.ls, LP.ld, LP.lza, LP.lzb);
-        hipLaunchKernelGGL(k_live<1>, dim3((unsigned)maxChunks, (unsigned)B), dim3(256), 0, WS.stream, D, dP, dS, in.feats, in.assoc, WS.cosPool.as<double>(), WS.sTmp.as<double>(),
+        hipLaunchKernelGGL(k_live<1>, dim3((unsigned)maxChunks, (unsigned)B), dim3(256), 0, WS.stream, D, dP, dS, in.feats, in.assoc, WS.cosPool.as<double>(), WS.sTmp.as<double>(), PP.lp /* scratch until k_upper */,
                            WS.chunkCnt.as<int32_t>(), maxChunks, LP.lp, LP.li, LP.lj, LP.ls, LP.ld, LP.lza, LP.lzb);
     DBG(c, "k_live");
     }
@@ -1572,9 +1599,7 @@ int roman_debug_cosine(roman_ctx_t* c, const roman_params_t* params, const doubl
     HIPCHK(c, WS.probs.ensure(sizeof(ProbDesc)));
     HIPCHK(c, WS.cosPool.ensure(sizeof(double) * (size_t)n1 * n2));
     HIPCHK(c, hipMemcpyAsync(WS.probs.p, &pd, sizeof(pd), hipMemcpyHostToDevice, WS.stream));
-    const int tiles = ((n1 + COS_TILE - 1) / COS_TILE) * ((n2 + COS_TILE - 1) / COS_TILE);
-    hipLaunchKernelGGL(k_cos, dim3((unsigned)(((tiles + 3) / 4) * 8)), dim3(256), 0, WS.stream, D, 1, (tiles + 3) / 4, WS.probs.as<ProbDesc>(), WS.hFeats.as<double>(), WS.cosPool.as<double>());
-    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, launch_cos(c, WS.stream, D, 1, n1, n2, WS.probs.as<ProbDesc>(), WS.hFeats.as<double>(), WS.cosPool.as<double>()));
     HIPCHK(c, hipMemcpyAsync(out, WS.cosPool.p, sizeof(double) * (size_t)n1 * n2, hipMemcpyDeviceToHost, WS.stream));
     HIPCHK(c, hipStreamSynchronize(WS.stream));
     c->last.scored = false; c->last.solved = false;

@@ -9,6 +9,7 @@
 #         large[:<n>]                tools/gpu_large_case.py <n> (large-live-set solver, default 200)
 #         ubench:<name>              tools/ubench/<name> (prebuilt binary travels with the snapshot)
 #         py:<script and args>       python <script and args>
+#         env:NAME=VALUE             export NAME=VALUE for the steps that follow (env:NAME= clears it)
 TAG=$1; shift
 OUT=$PWD/gpurun_out; mkdir -p $OUT
 export TMPDIR=/tmp
@@ -33,6 +34,7 @@ for step in "$@"; do
     large) timeout 900 python tools/gpu_large_case.py ${arg:-200} > $OUT/${TAG}_large_${arg:-200}.txt 2>&1; echo "large rc=$?"; tail -12 $OUT/${TAG}_large_${arg:-200}.txt ;;
     ubench) timeout 300 tools/ubench/$arg > $OUT/${TAG}_ubench_$arg.txt 2>&1; echo "ubench rc=$?"; cat $OUT/${TAG}_ubench_$arg.txt ;;
     py)    timeout 1200 python $arg > $OUT/${TAG}_py_$(echo $arg | tr ' /' '__' | cut -c1-40).txt 2>&1; echo "py rc=$?"; tail -30 $OUT/${TAG}_py_$(echo $arg | tr ' /' '__' | cut -c1-40).txt ;;
+    env)   export "$arg"; echo "exported $arg" ;;
     *) echo "unknown step $name" ;;
   esac
 done

@@ -10,13 +10,18 @@ __global__ void __launch_bounds__(256) k(double* out, double s, int iters)
     for (int i = 0; i < 4; ++i) acc[i] = double4_t{0, 0, 0, 0};
     double a = out[threadIdx.x], b = out[threadIdx.x + 256];
     double f[16];
-    for (int i = 0; i < 16; ++i) f[i] = a + i;
+    for (int i = 0; i < 16; ++i) f[i] = (OP == 3) ? out[512 + 16 * threadIdx.x + i] : a + i;
     for (int it = 0; it < iters; ++it) {
         if (OP == 0) {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+        } else if (OP == 3) {                   // 8 distinct operand registers holding random values (data-dependent power)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[r + 4 * (i >> 1)], f[8 + r + 4 * (i & 1)], acc[i], 0, 0, 0);
         } else if (OP == 1) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) asm volatile("v_fma_f64 %0, %1, %2, %0" : "+v"(f[i]) : "s"(s), "v"(b));
@@ -46,9 +51,16 @@ template <int OP> void run(const char* name, double* d, int wavesPerSimd, double
 }
 int main()
 {
-    double* d; hipMalloc(&d, 512 * sizeof(double)); hipMemset(d, 0, 512 * sizeof(double));
+    const int N = 512 + 16 * 256;
+    double* d; hipMalloc(&d, N * sizeof(double)); hipMemset(d, 0, N * sizeof(double));
+    {   // random operands in [-1, 1) for the data-dependent variant
+        double* h = new double[N]; unsigned long long x = 88172645463325252ull;
+        for (int i = 0; i < N; ++i) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; h[i] = i < 512 ? 0.0 : (double)(x >> 11) / 4503599627370496.0 - 1.0; }
+        hipMemcpy(d, h, N * sizeof(double), hipMemcpyHostToDevice); delete[] h;
+    }
     for (int w : {1, 2, 4}) {
         run<0>("mfma_f64_16x16x4", d, w, 2048.0);
+        run<3>("mfma_f64 random data", d, w, 2048.0);
         run<1>("v_fma_f64 (sgpr src)", d, w, 128.0);
         run<2>("v_mul_f64+v_add_f64", d, w, 128.0);
     }
