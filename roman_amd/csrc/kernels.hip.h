@@ -563,17 +563,18 @@ __global__ void __launch_bounds__(256) k_cos_tile(DevParams D, int B, int G /* w
 // coincide (distinctness) or are closer than mindist — every comparison against NaN is false, so
 // one table lookup implements the distinctness skip, the mindist gate and the distance itself.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_tables(DevParams D, const ProbDesc* __restrict__ probs,
-                                                const double* __restrict__ feats,
-                                                double* __restrict__ tabPool)
+__global__ void __launch_bounds__(1024) k_tables(DevParams D, const ProbDesc* __restrict__ probs,
+                                                 const double* __restrict__ feats,
+                                                 double* __restrict__ tabPool, int RB /* rows per band */)
 {
-    // grid: (row bands of 8 rows over max(n1,n2), 2 maps, B).  The map's points are staged in LDS once per
-    // block (3 doubles per object); a wave writes table rows with lanes along the row (coalesced).
+    // grid: (row bands of RB rows over max(n1,n2), 2 maps, B).  The map's points are staged in LDS once per
+    // block (3 doubles per object: n gathers from rows 8 F bytes apart — the band is as tall as the batch allows, one band
+    // per map when there are enough problems to fill the device); a wave writes table rows with lanes along the row (coalesced).
     extern __shared__ __attribute__((aligned(16))) double s_xyz[];
     const ProbDesc pd = probs[blockIdx.z];
     const int which = blockIdx.y;
     const int n = which == 0 ? pd.n1 : pd.n2;
-    const int r0 = blockIdx.x * 8;
+    const int r0 = blockIdx.x * RB;
     if (r0 >= n) return;
     const int64_t base = which == 0 ? pd.off1 : pd.off2;
     const int pdim = D.p.point_dim;
@@ -583,8 +584,8 @@ __global__ void __launch_bounds__(256) k_tables(DevParams D, const ProbDesc* __r
     }
     __syncthreads();
     double* tab = tabPool + pd.tabOff + (which == 0 ? 0 : (int64_t)pd.n1 * pd.n1);
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    for (int rr = w; rr < 8; rr += 4) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (int rr = w; rr < RB; rr += nw) {
         const int a = r0 + rr;
         if (a >= n) break;
         const double ax = s_xyz[3 * a], ay = s_xyz[3 * a + 1], az = s_xyz[3 * a + 2];
@@ -807,13 +808,20 @@ __global__ void __launch_bounds__(256) k_items(int RPB, const ProbState* __restr
 // Problems whose live set does not fit the LDS column tile read the columns from HBM/L2 instead.
 // ---------------------------------------------------------------------------------------------
 // exclusive prefix sum over the 64 lanes of a wave
-__device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, int lane)
+// (DPP: six VALU instructions — row_shr:1,2,4,8 inside the rows of 16 lanes, row_bcast:15 / :31 across them; lanes without a
+// source add the `old` operand, 0.  The __shfl_up form compiles to six DEPENDENT ds_bpermute round trips through the LDS
+// crossbar, ~500 cycles of latency per scan: k_upper spends one scan per matrix row.)
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
 {
-    uint32_t inc = v;
-#pragma unroll
-    for (int off = 1; off < WAVE; off <<= 1) { const uint32_t t = __shfl_up(inc, off); if (lane >= off) inc += t; }
-    return inc - v;
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
+    return v;
 }
+__device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, int lane) { (void)lane; return wave_incl_scan(v) - v; }
 
 // Generic sweep (columns read from HBM/L2): used when the live set does not fit the LDS column tile.
 // GM: 0 no gravity prior, 1 ROMAN_GRAV_COMBINED, 2 ROMAN_GRAV_SEPARATE, 3 ROMAN_GRAV_ZGATE (tables then hold full lengths)
@@ -1073,10 +1081,20 @@ __device__ __forceinline__ unsigned long long transpose64(unsigned long long x, 
     return x;
 }
 
-__global__ void __launch_bounds__(512) k_mirror(const ProbState* __restrict__ st, unsigned long long* __restrict__ maskPool)
+__global__ void __launch_bounds__(512) k_mirror(int B, int T /* workgroups per problem */, const ProbState* __restrict__ st, unsigned long long* __restrict__ maskPool)
 {
+    // The bit matrices are SPARSE (1.8 set bits per 64-bit word at config 3): a block is transposed by scattering its set
+    // bits — lane l (source row) ORs bit l into word j of the wave's LDS tile for every set bit j of its word, one LDS atomic
+    // per set bit — instead of the dense 6-stage butterfly (transpose64: ~130 instructions per block whatever it holds;
+    // this kernel was bound by them, 153 us per batch of 256).  LDS operations of one wave execute in order: no barriers.
+    __shared__ unsigned long long tile[8][8][64];                 // per wave: 8 blocks x 64 target words
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    const int b = blockIdx.y;
+    // All T workgroups of a problem carry ids that are congruent modulo 8: one XCD, one L2 (k_cos).  A 128-byte line of the
+    // lower triangle collects its 16 words from 16 different tasks; dealt round-robin over the 8 non-coherent L2s every one
+    // of them wrote its part of the line back separately (2.2 x the bytes, read-modify-write in HBM: half this kernel's time).
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int b = (slot / T) * 8 + xcd, tb = slot % T;
+    if (b >= B) return;
     if (st[b].kind == 2) return;
     const int L = st[b].L;
     const int W = (L + 63) >> 6;
@@ -1084,7 +1102,7 @@ __global__ void __launch_bounds__(512) k_mirror(const ProbState* __restrict__ st
     const int nTasks = ((W + 7) / 8) * max(nR, 1);                // (column strip of 8 words) x (source row block)
     unsigned long long* mb = maskPool + st[b].maskOff;
     // the grid was sized from an ESTIMATE of the largest live set: a larger problem takes several rounds
-    for (int task = blockIdx.x * nw + w; task < nTasks; task += gridDim.x * nw) {
+    for (int task = tb * nw + w; task < nTasks; task += T * nw) {
         const int ct = task / max(nR, 1), R = task - ct * nR;
         const int cb = ct * 8;
         if (R >= W - 1 || cb >= W || cb + 7 <= R) continue;       // nothing below the diagonal in this strip
@@ -1093,13 +1111,35 @@ __global__ void __launch_bounds__(512) k_mirror(const ProbState* __restrict__ st
 #pragma unroll
         for (int i = 0; i < 8; ++i) x[i] = (cb + i > R && cb + i < W) ? src[cb + i] : 0ull;
 #pragma unroll
+        for (int i = 0; i < 8; ++i) tile[w][i][lane] = 0ull;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const unsigned long long me = 1ull << lane;
+        for (;;) {
+            unsigned long long left = 0ull;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (x[i]) {
+                    const int j = __builtin_ctzll(x[i]);
+                    (void)__hip_atomic_fetch_or(&tile[w][i][j], me, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    x[i] &= x[i] - 1ull;
+                }
+                left |= x[i];
+            }
+            if (__ballot(left != 0ull) == 0ull) break;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int c = cb + i;
             if (c > R && c < W) {                                // wave-uniform
-                const unsigned long long y = transpose64(x[i], lane);
+                const unsigned long long y = tile[w][i][lane];
                 if (c * 64 + lane < L) mb[(int64_t)(c * 64 + lane) * W + R] = y;
             }
         }
+        __builtin_amdgcn_wave_barrier();                         // (the next task zeroes the tile behind these reads: in order)
     }
 }
 
@@ -1133,11 +1173,7 @@ __global__ void __launch_bounds__(1024) k_rowprefix(const ProbDesc* __restrict__
                 }
                 uint32_t inc[U];
 #pragma unroll
-                for (int u = 0; u < U; ++u) inc[u] = c[u];
-#pragma unroll
-                for (int off = 1; off < WAVE; off <<= 1)
-#pragma unroll
-                    for (int u = 0; u < U; ++u) { const uint32_t t_ = __shfl_up(inc[u], off); if (lane >= off) inc[u] += t_; }
+                for (int u = 0; u < U; ++u) inc[u] = wave_incl_scan(c[u]);
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     if (r + u * wpb < nrows) {
@@ -1225,8 +1261,7 @@ __global__ void __launch_bounds__(1024) k_rowsort(const ProbDesc* __restrict__ p
                 const int q = tid * PER + t;
                 if (q < L) sum += (min((hist[q] >> 12) - 1u, (uint32_t)(L - 1 - q)) + 3u) & ~3u;
             }
-            uint32_t inc = sum;
-            for (int off = 1; off < WAVE; off <<= 1) { const uint32_t t = __shfl_up(inc, off); if (lane >= off) inc += t; }
+            const uint32_t inc = wave_incl_scan(sum);
             if (lane == WAVE - 1) wsum[w] = inc;
             __syncthreads();
             uint32_t wbase = 0, total = 0;
@@ -1252,8 +1287,7 @@ __global__ void __launch_bounds__(1024) k_rowsort(const ProbDesc* __restrict__ p
         constexpr int PER = SORT_KEYS / 1024;
         uint32_t loc[PER]; uint32_t sum = 0;
         for (int t = 0; t < PER; ++t) { loc[t] = hist[tid * PER + t]; sum += loc[t]; }
-        uint32_t inc = sum;
-        for (int off = 1; off < WAVE; off <<= 1) { const uint32_t t = __shfl_up(inc, off); if (lane >= off) inc += t; }
+        const uint32_t inc = wave_incl_scan(sum);
         if (lane == WAVE - 1) wsum[w] = inc;
         __syncthreads();
         uint32_t wbase = 0;
@@ -1280,8 +1314,7 @@ __global__ void __launch_bounds__(1024) k_rowsort(const ProbDesc* __restrict__ p
             sliceWidth[lo + s] = width;
         }
         const uint32_t v = width * 64u;
-        uint32_t inc = v;
-        for (int off = 1; off < WAVE; off <<= 1) { const uint32_t t = __shfl_up(inc, off); if (lane >= off) inc += t; }
+        const uint32_t inc = wave_incl_scan(v);
         if (lane == WAVE - 1) wsum[w] = inc;
         __syncthreads();
         uint32_t wbase = 0, tot = 0;
@@ -1366,7 +1399,7 @@ __global__ void __launch_bounds__(1024) k_upper(const ProbDesc* __restrict__ pro
                 const unsigned long long mine = raw & behind;
                 const uint32_t c = (uint32_t)__popcll(mine);
                 const uint32_t ex = wave_excl_scan(c, lane);
-                const uint32_t cnt = (uint32_t)__shfl((int)(ex + c), WAVE - 1);
+                const uint32_t cnt = (uint32_t)__builtin_amdgcn_readlane((int)(ex + c), WAVE - 1);
                 {   // the row's candidate list: live column indices in ascending order, padded to a whole quad
                     uint16_t* lst = lists + (uint32_t)__builtin_amdgcn_readlane((int)ov, i);
                     unsigned long long m = mine; uint32_t e = ex;

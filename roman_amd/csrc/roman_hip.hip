@@ -465,7 +465,11 @@ int enqueue_score(roman_ctx* c, const DevParams& Din, const roman_params_t* para
         const size_t tabLds = sizeof(double) * 3 * (size_t)std::max(maxN, 1);
         if (tabLds > c->lds_max) return fail(c, ROMAN_E_TOO_LARGE, "maps of %d objects exceed the LDS point staging of this build", maxN);
         HIPCHK(c, dyn_lds(c, reinterpret_cast<const void*>(k_tables), tabLds));
-        hipLaunchKernelGGL(k_tables, dim3((unsigned)((maxN + 7) / 8), 2, B), dim3(256), tabLds, WS.stream, D, dP, in.feats, WS.tabPool.as<double>());
+        // bands: enough workgroups to fill the device twice, no more (every band stages the whole map's points)
+        const int bands = std::max(1, std::min((maxN + 15) / 16, (2 * c->num_cu + 2 * B - 1) / (2 * B)));
+        const int RBt = (((maxN + bands - 1) / bands) + 15) & ~15;
+        const int thr = RBt >= 64 ? 1024 : 256;
+        hipLaunchKernelGGL(k_tables, dim3((unsigned)((maxN + RBt - 1) / RBt), 2, B), dim3(thr), tabLds, WS.stream, D, dP, in.feats, WS.tabPool.as<double>(), RBt);
     DBG(c, "k_tables");
     }
     {   // single scores, then the ordered compaction of the live associations: chunks x problems
@@ -520,7 +524,8 @@ int enqueue_score(roman_ctx* c, const DevParams& Din, const roman_params_t* para
             // the kernel loops when a problem is larger)
             const int Wexp = (expL + 63) / 64;
             const int tasks = ((Wexp + 7) / 8) * ((std::max(Wexp - 1, 1) + 7) / 8);          // workgroups of 8 waves
-            hipLaunchKernelGGL(k_mirror, dim3((unsigned)std::max(tasks, 1), (unsigned)B), dim3(512), 0, WS.stream, dS, WS.maskPool.as<unsigned long long>());
+            const int T = std::max(tasks, 1);
+            hipLaunchKernelGGL(k_mirror, dim3((unsigned)(T * ((B + 7) / 8) * 8)), dim3(512), 0, WS.stream, B, T, dS, WS.maskPool.as<unsigned long long>());
     DBG(c, "k_mirror");
         }
         hipLaunchKernelGGL(k_rowprefix, dim3(c->num_cu * 2), dim3(1024), 0, WS.stream, dP, dS, dT, WS.items.as<ItemDesc>(),
