@@ -890,7 +890,7 @@ __device__ __forceinline__ void count_rows_global(const DevParams& D, const Prob
     }
 }
 
-// Fast sweep: columns in LDS as {8*i_q, 8*(n1+1+j_q)} byte offsets into a table slice (+ the two z
+// Fast sweep: columns in LDS as the packed pair {i_q, n1+1+j_q} of indices into a table slice (+ the two z
 // coordinates), padded to a multiple of 256 columns with a sentinel whose table entry is NaN (fails every
 // test), so the inner loop has no bounds logic at all.  A wave sweeps NR ADJACENT rows at once (NR = 2 when
 // the table slices fit): the column data is read once for both, the two rows' instruction streams are
@@ -899,7 +899,7 @@ __device__ __forceinline__ void count_rows_global(const DevParams& D, const Prob
 template <int GM, int NR>
 __device__ __forceinline__ void count_rows_lds(const DevParams& D, const ProbDesc& pd, int L, int row0, int nrows,
                                                int w, int wpb, int lane,
-                                               const int2* cIJ, const double2* cZZ,
+                                               const uint32_t* cIJ /* i_q | (n1 + 1 + j_q) << 16: table-slice indices */, const double2* cZZ,
                                                const double* __restrict__ TA, const double* __restrict__ TB,
                                                double* tA /* NR slices of ldsPerRow doubles */, int ldsPerRow,
                                                unsigned long long* __restrict__ mbase)
@@ -919,7 +919,7 @@ __device__ __forceinline__ void count_rows_lds(const DevParams& D, const ProbDes
 #pragma unroll
         for (int x = 0; x < NR; ++x) {
             const int k_ = row0 + min(r_ + x, nrows - 1);
-            const int i_ = cIJ[k_].x >> 3, j_ = (cIJ[k_].y >> 3) - (pd.n1 + 1);
+            const int i_ = (int)(cIJ[k_] & 0xffffu), j_ = (int)(cIJ[k_] >> 16) - (pd.n1 + 1);
             const double* gA_ = TA + (int64_t)i_ * pd.n1;
             const double* gB_ = TB + (int64_t)j_ * pd.n2;
 #pragma unroll
@@ -948,7 +948,7 @@ __device__ __forceinline__ void count_rows_lds(const DevParams& D, const ProbDes
                     if (lane + m_ * WAVE < pd.n2) sB[lane + m_ * WAVE] = rb[x][m_];
                 }
             } else {
-                const int i = cIJ[k[x]].x >> 3, j = (cIJ[k[x]].y >> 3) - (pd.n1 + 1);
+                const int i = (int)(cIJ[k[x]] & 0xffffu), j = (int)(cIJ[k[x]] >> 16) - (pd.n1 + 1);
                 const double* gA = TA + (int64_t)i * pd.n1;
                 const double* gB = TB + (int64_t)j * pd.n2;
                 for (int t = lane; t < pd.n1; t += WAVE) sA[t] = gA[t];
@@ -973,7 +973,8 @@ __device__ __forceinline__ void count_rows_lds(const DevParams& D, const ProbDes
             int2 ij[U]; double2 zz[U];
 #pragma unroll
             for (int t = 0; t < U; ++t) {
-                ij[t] = cIJ[q0 + t * WAVE + lane];
+                const uint32_t pk = cIJ[q0 + t * WAVE + lane];
+                ij[t] = make_int2((int)((pk & 0xffffu) << 3), (int)((pk >> 16) << 3));     // byte offsets into a table slice
                 if (GM) zz[t] = cZZ[q0 + t * WAVE + lane];
             }
 #pragma unroll
@@ -1025,7 +1026,7 @@ __global__ void __launch_bounds__(1024) k_count(DevParams D, const ProbDesc* __r
     // LDS: [GM: cZZ[TC]] cIJ[TC] | per wave NR table slices (n1 + 1 + n2 doubles each)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double2* cZZ = reinterpret_cast<double2*>(smem);
-    int2* cIJ = reinterpret_cast<int2*>(cZZ + (GM ? TC : 0));
+    uint32_t* cIJ = reinterpret_cast<uint32_t*>(cZZ + (GM ? TC : 0));
     double* tabs = reinterpret_cast<double*>(cIJ + TC);
     const int tid = threadIdx.x, nt = blockDim.x;
     const int lane = tid & 63, w = tid >> 6, wpb = nt >> 6;
@@ -1046,7 +1047,7 @@ __global__ void __launch_bounds__(1024) k_count(DevParams D, const ProbDesc* __r
         if (ldscol) {
             for (int q = tid; q < Lpad; q += nt) {
                 const bool v = q < L;
-                cIJ[q] = v ? make_int2(8 * li[lo + q], 8 * (pd.n1 + 1 + lj[lo + q])) : make_int2(8 * pd.n1, 8 * (pd.n1 + 1));
+                cIJ[q] = v ? ((uint32_t)li[lo + q] | ((uint32_t)(pd.n1 + 1 + lj[lo + q]) << 16)) : ((uint32_t)pd.n1 | ((uint32_t)(pd.n1 + 1) << 16));
                 if (GM) cZZ[q] = v ? make_double2(lza[lo + q], lzb[lo + q]) : make_double2(0.0, 0.0);
             }
         }

@@ -492,10 +492,14 @@ int enqueue_score(roman_ctx* c, const DevParams& Din, const roman_params_t* para
     // for the EXPECTED largest live set; a problem that exceeds it reads its columns from memory instead.
     const int expL = std::max(SZ.expectMaxL, 1);
     const int ldsPerRow = ((2 * std::max(maxN, 1) + 1 + 1) & ~1) + 2;     // n1 + sentinel + n2 doubles
-    const int colBytesC = D.gravity ? 24 : 8;
+    const int colBytesC = D.gravity ? 20 : 4;                             // [z pair] + packed 16-bit table-slice indices
     const int Lneed = (expL + 255) & ~255;
     int NRc = ((size_t)16 * 2 * ldsPerRow * sizeof(double) + (size_t)Lneed * colBytesC <= c->lds_max) ? 2 : 1;
     int wpb = 16;
+    static const char* nrEnv = getenv("ROMAN_COUNT_NR");
+    static const char* wpbEnv = getenv("ROMAN_COUNT_WPB");
+    if (nrEnv) NRc = atoi(nrEnv) == 2 ? 2 : 1;
+    if (wpbEnv) wpb = std::max(1, std::min(16, atoi(wpbEnv)));
     while (wpb > 1 && (size_t)wpb * NRc * ldsPerRow * sizeof(double) + 256 * colBytesC > c->lds_max) wpb >>= 1;
     if ((size_t)wpb * NRc * ldsPerRow * sizeof(double) + 256 * colBytesC > c->lds_max)
         return fail(c, ROMAN_E_TOO_LARGE, "maps of %d objects exceed the LDS table staging of this build", maxN);
