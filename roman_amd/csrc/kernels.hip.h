@@ -427,8 +427,13 @@ __global__ void __launch_bounds__(256) k_cos_tile(DevParams D, int B, int G /* w
     const int iEnd = min(pd.n1, i0 + 16 * nbx), jEnd = min(pd.n2, j0 + 16 * nby);    // rows / columns of the tile
     const int Fc = D.p.cos_feature_dim, coff = D.p.point_dim + D.p.ratio_feature_dim;
     const int lr = lane & 15, kq = lane >> 4;
-    // which quarter a wave takes rotates with the tile: a tile of 3 blocks gives its quarters 2 and 1, and a wave index is a SIMD
-    const int ws = (w + tile) & 3, wy = ws >> 1, wx = ws & 1;
+    // A wave takes ONE block row of the tile (all its nby blocks) or, when the tile has more block columns than rows, one block
+    // column: a 3x3 tile keeps three waves busy with 3 blocks each, 3x4 and 4x3 tiles all four — dealt as 2x2 quarters they
+    // were 4 + 2 + 2 + 1 and the workgroup as slow as a full tile (tools/ubench/mfma_tiles.hip: 213 us against the 169 of a
+    // perfect deal for config 3).  Which wave takes which row rotates with the tile: a wave index is a SIMD.
+    const bool byRows = nbx >= nby;
+    const int ws = (w + tile) & 3;                               // the wave's block row (byRows) or block column
+    const int nMin = uni_i(ws < (byRows ? nbx : nby) ? (byRows ? nby : nbx) : 0);      // blocks of this wave: 0..4
 
     // the thread's share of a stage
     const int seg = tid % SEGS, row0 = tid / SEGS;
@@ -460,45 +465,44 @@ __global__ void __launch_bounds__(256) k_cos_tile(DevParams D, int B, int G /* w
             *reinterpret_cast<dbl2_t*>(smem + buf * STAGE + (q * RPI + row0) * PITCH + seg * 16) = gv[q] ? stg[q] : dbl2_t{0.0, 0.0};
     };
 
-    bool onA[2], onB[2];
+    double4_t acc[4];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        onA[h] = uni_i(2 * wy + h < nbx) != 0;
-        onB[h] = uni_i(2 * wx + h < nby) != 0;
-    }
-    double4_t acc[2][2];
-#pragma unroll
-    for (int x = 0; x < 2; ++x)
-#pragma unroll
-        for (int y = 0; y < 2; ++y) acc[x][y] = double4_t{0.0, 0.0, 0.0, 0.0};
-    double sa[2] = {0.0, 0.0}, sb[2] = {0.0, 0.0};
-    const int offA = (32 * wy + lr) * PITCH + 32 * kq, offB = (64 + 32 * wx + lr) * PITCH + 32 * kq;
+    for (int m = 0; m < 4; ++m) acc[m] = double4_t{0.0, 0.0, 0.0, 0.0};
+    double sMaj = 0.0, sMin[4] = {0.0, 0.0, 0.0, 0.0};
+    // LDS offsets of the lane's 32-byte pieces: A rows are stage rows 0..63, B rows 64..127
+    const int offMaj = ((byRows ? 0 : 64) + 16 * ws + lr) * PITCH + 32 * kq;
+    const int offMin = ((byRows ? 64 : 0) + lr) * PITCH + 32 * kq;
 
     auto compute = [&](int s) {
         const unsigned char* base = smem + (s & 1) * STAGE;
-        if (onA[0] && onB[0]) {
+        if (nMin > 0) {
 #pragma unroll
             for (int kc = 0; kc < KC; kc += 16) {
                 if (s * KC + kc < Fc) {
-                    double a[2][4], bq[2][4];
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const dbl2_t a0 = *reinterpret_cast<const dbl2_t*>(base + offA + 16 * h * PITCH + kc * 8);
-                        const dbl2_t a1 = *reinterpret_cast<const dbl2_t*>(base + offA + 16 * h * PITCH + kc * 8 + 16);
-                        const dbl2_t b0 = *reinterpret_cast<const dbl2_t*>(base + offB + 16 * h * PITCH + kc * 8);
-                        const dbl2_t b1 = *reinterpret_cast<const dbl2_t*>(base + offB + 16 * h * PITCH + kc * 8 + 16);
-                        a[h][0] = a0.x; a[h][1] = a0.y; a[h][2] = a1.x; a[h][3] = a1.y;
-                        bq[h][0] = b0.x; bq[h][1] = b0.y; bq[h][2] = b1.x; bq[h][3] = b1.y;
+                    // block by block (the four MFMAs of a block depend on each other through the accumulator: forwarded in the
+                    // matrix pipe; every accumulator still sees t = 0..3 of chunk after chunk — its own order is unchanged):
+                    // 16 operand registers instead of 40, and the reads of the next block fly behind the MFMAs of this one
+                    double mj[4];
+                    {
+                        const dbl2_t v0 = *reinterpret_cast<const dbl2_t*>(base + offMaj + kc * 8);
+                        const dbl2_t v1 = *reinterpret_cast<const dbl2_t*>(base + offMaj + kc * 8 + 16);
+                        mj[0] = v0.x; mj[1] = v0.y; mj[2] = v1.x; mj[3] = v1.y;
                     }
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) {
+                    for (int t = 0; t < 4; ++t) sMaj = fma(mj[t], mj[t], sMaj);
 #pragma unroll
-                        for (int h = 0; h < 2; ++h) { sa[h] = fma(a[h][t], a[h][t], sa[h]); sb[h] = fma(bq[h][t], bq[h][t], sb[h]); }
+                    for (int m = 0; m < 4; ++m) {
+                        if (m < nMin) {
+                            const dbl2_t v0 = *reinterpret_cast<const dbl2_t*>(base + offMin + 16 * m * PITCH + kc * 8);
+                            const dbl2_t v1 = *reinterpret_cast<const dbl2_t*>(base + offMin + 16 * m * PITCH + kc * 8 + 16);
+                            const double mn[4] = {v0.x, v0.y, v1.x, v1.y};
 #pragma unroll
-                        for (int x = 0; x < 2; ++x)
-#pragma unroll
-                            for (int y = 0; y < 2; ++y)
-                                if (onA[x] && onB[y]) acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[x][t], bq[y][t], acc[x][y], 0, 0, 0);
+                            for (int t = 0; t < 4; ++t) {
+                                sMin[m] = fma(mn[t], mn[t], sMin[m]);
+                                // a column wave multiplies B A^T: the TRANSPOSED block — the same products, summed in the same k order
+                                acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(mj[t], mn[t], acc[m], 0, 0, 0);
+                            }
+                        }
                     }
                 }
             }
@@ -532,26 +536,25 @@ __global__ void __launch_bounds__(256) k_cos_tile(DevParams D, int B, int G /* w
         __syncthreads();
         compute(SF);
     }
+    // every lane (lr, *) ends with the norm of row lr of the block
+    sMaj += __shfl_xor(sMaj, 16); sMaj += __shfl_xor(sMaj, 32); sMaj = sqrt(sMaj);
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {                    // every lane (lr, *) ends with the norm of row 16h + lr
-        sa[h] += __shfl_xor(sa[h], 16); sa[h] += __shfl_xor(sa[h], 32);
-        sb[h] += __shfl_xor(sb[h], 16); sb[h] += __shfl_xor(sb[h], 32);
-        sa[h] = sqrt(sa[h]); sb[h] = sqrt(sb[h]);
-    }
+    for (int m = 0; m < 4; ++m) { sMin[m] += __shfl_xor(sMin[m], 16); sMin[m] += __shfl_xor(sMin[m], 32); sMin[m] = sqrt(sMin[m]); }
 #pragma unroll
-    for (int y = 0; y < 2; ++y) {
-        const int col = j0 + 32 * wx + 16 * y + lr;
-        const double nb = sb[y];
-#pragma unroll
-        for (int x = 0; x < 2; ++x)
-            if (onA[x] && onB[y])                    // (the divisions run on the same f64 units as the MFMAs)
+    for (int m = 0; m < 4; ++m) {
+        if (m < nMin) {                              // (the divisions run on the same f64 units as the MFMAs)
+            // acc[m][r] of lane (lr, kq) is element (kq + 4r, lr) of (own block) x (block m across)^T
+            const double nLr = sMin[m];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = i0 + 32 * wy + 16 * x + kq + 4 * r;
-                const double na = __shfl(sa[x], kq + 4 * r);       // norm of row 16x + (kq + 4r): held by lanes with lr == kq + 4r
+                const double nOwn = __shfl(sMaj, kq + 4 * r);      // norm of row (kq + 4r) of the own block: held by lanes with lr == kq + 4r
+                const int row = byRows ? i0 + 16 * ws + kq + 4 * r : i0 + 16 * m + lr;
+                const int col = byRows ? j0 + 16 * m + lr : j0 + 16 * ws + kq + 4 * r;
+                const double na = byRows ? nOwn : nLr, nb = byRows ? nLr : nOwn;
                 if (row < iEnd && col < jEnd)
-                    cosPool[pd.cosOff + (int64_t)row * pd.n2 + col] = D.pruned ? acc[x][y][r] : ((na > 0.0 && nb > 0.0) ? acc[x][y][r] / (na * nb) : 0.0);
+                    cosPool[pd.cosOff + (int64_t)row * pd.n2 + col] = D.pruned ? acc[m][r] : ((na > 0.0 && nb > 0.0) ? acc[m][r] / (na * nb) : 0.0);
             }
+        }
     }
     __syncthreads();                                 // the next tile's first stage overwrites LDS stage 0
     }
