@@ -439,13 +439,13 @@ def main():
                         "bound": "f64 VALU", "pair_tests": tests, "flops_at_30_per_test": 30.0 * tests, "stage_ms": iso_stage["count"],
                         "achieved_TFLOPs": 30.0 * tests / (iso_stage["count"] * 1e-3) / 1e12, "peak_TFLOPs": F64_PEAK_TFLOPS,
                         "frac": 30.0 * tests / (iso_stage["count"] * 1e-3) / 1e12 / F64_PEAK_TFLOPS,
-                        "note": "frac of the whole stage; k_count alone is ~60 % of it (profiles/r03 kernel stats): its own fraction is ~1.6x this"},
+                        "note": "frac of the whole stage; k_count alone is ~65 % of it (profiles/r03 kernel stats): its own fraction is ~1.5x this"},
                     "k_cos (stage 'single' = cosine MFMA + tables + single scores + live list)": {
                         "bound": "MFMA f64", "flops": cosflops, "stage_ms": iso_stage["single"],
                         "achieved_TFLOPs": cosflops / (iso_stage["single"] * 1e-3) / 1e12, "peak_TFLOPs": F64_PEAK_TFLOPS,
                         "measured_mfma_ceiling_TFLOPs": F64_MFMA_MEASURED_TFLOPS,
                         "frac": cosflops / (iso_stage["single"] * 1e-3) / 1e12 / F64_PEAK_TFLOPS,
-                        "note": "frac of the whole stage; k_cos alone is ~65 % of it"}}
+                        "note": "frac of the whole stage; k_cos_tile alone is ~75 % of it (0.32 of 0.42 ms): 33 TFLOP/s"}}
                 # the whole step against SURVEY.md §8(d)'s ideal time t* = W/Pi + (B_b + B_s)/beta (pair tests among LIVE associations)
                 Wb = 30.0 * tests + cosflops
                 Bb = float(np.sum(12.0 * nnz)) + 8.0 * float(np.sum(a1[:C0].astype(np.float64) + a2[:C0])) * F
