@@ -748,45 +748,86 @@ __global__ void __launch_bounds__(256) k_live(DevParams D, const ProbDesc* __res
     }
 }
 
-// k_rowbase: serial prefix of the live counts (B is small); also the batch maxima, the offsets of
+// k_rowbase: prefix of the live counts over the problems of the batch; also the batch maxima, the offsets of
 // the per-problem candidate bit matrices (L rows of ceil(L/64) words) and the work-item prefix
 // (a work item = a block of up to RPB consecutive live rows of one problem).  The bit-matrix pools were sized
 // before L was known: a problem whose matrix would end beyond `capMaskWords` becomes kind 2 (skipped).
-__global__ void __launch_bounds__(64) k_rowbase(int B, int RPB, long long capMaskWords, ProbState* __restrict__ st, BatchTotals* __restrict__ tot)
+// Block-wide exclusive prefix sum (blockDim.x a multiple of 64, <= 1024): every thread gets the sum of the values of the
+// threads in front of it, `total` the sum over the block.  sh: 17 elements of scratch; two barriers.
+template <class T>
+__device__ __forceinline__ T block_excl_scan(T v, T* sh, T& total)
 {
-    // one wave; lane-strided blocks of 64 problems with a running carry (B is small)
-    const int lane = threadIdx.x;
-    int accR = 0, accI = 0, mx = 0, mxs = 0, nover = 0, mns = 0x7fffffff; long long accM = 0, needM = 0;
-    for (int b0 = 0; b0 < B; b0 += WAVE) {
-        const int b = b0 + lane;
-        const int L = b < B ? st[b].L : 0;
-        const bool skip = b < B && st[b].kind == 2;             // already skipped (k_live: no fallback kernels in this launch)
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    T inc = v;
+    for (int off = 1; off < WAVE; off <<= 1) { const T t = __shfl_up(inc, off); if (lane >= off) inc += t; }
+    __syncthreads();                                             // (sh may still be read from the previous call)
+    if (lane == WAVE - 1) sh[w] = inc;
+    __syncthreads();
+    T base = 0, tot = 0;
+    for (int k = 0; k < nw; ++k) { const T x = sh[k]; if (k < w) base += x; tot += x; }
+    total = tot;
+    return base + inc - v;
+}
+
+__global__ void __launch_bounds__(1024) k_rowbase(int B, int RPB, long long capMaskWords, ProbState* __restrict__ st, BatchTotals* __restrict__ tot)
+{
+    // one workgroup; a thread takes PER consecutive problems (a serial sweep of one wave over 4096 problems was 93 us —
+    // 64 dependent round trips to memory — of the 1.4 ms the whole batch takes at the reference's demo scale)
+    __shared__ long long shl[17];
+    __shared__ int shi[17];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int PER = (B + nt - 1) / nt;
+    const int b0 = tid * PER, b1 = min(B, b0 + PER);
+    long long sM = 0, sN = 0; int sR = 0;
+    for (int b = b0; b < b1; ++b) {
+        const int L = st[b].L;
         const long long mwAll = (long long)L * ((L + 63) >> 6);
-        const long long mw = skip ? 0 : mwAll;
-        long long pm = mw, pn = mwAll;
-        for (int off = 1; off < WAVE; off <<= 1) {
-            const long long tm = __shfl_up(pm, off), tn = __shfl_up(pn, off);
-            if (lane >= off) { pm += tm; pn += tn; }
-        }
-        const bool fits = !skip && accM + pm <= capMaskWords;  // the prefix is monotone: once a problem does not fit, none behind it does
-        const int it = fits ? (L + RPB - 1) / RPB : 0;
-        int pr = L, pi = it;
-        for (int off = 1; off < WAVE; off <<= 1) {
-            const int tr = __shfl_up(pr, off), ti = __shfl_up(pi, off);
-            if (lane >= off) { pr += tr; pi += ti; }
-        }
-        if (b < B) {
-            st[b].rowBase = accR + pr - L; st[b].itemBase = accI + pi - it; st[b].maskOff = fits ? accM + pm - mw : 0;
-            if (!fits) st[b].kind = 2;
-        }
-        int m = L, ms = (b < B && st[b].kind == 0) ? L : 0, ov = (b < B && !fits) ? 1 : 0, mn = (b < B && st[b].kind == 0) ? L : 0x7fffffff;
-        for (int off = 32; off > 0; off >>= 1) { m = max(m, __shfl_xor(m, off)); ms = max(ms, __shfl_xor(ms, off)); ov += __shfl_xor(ov, off); mn = min(mn, __shfl_xor(mn, off)); }
-        mx = max(mx, m); mxs = max(mxs, ms); nover += ov; mns = min(mns, mn);
-        accR += __shfl(pr, WAVE - 1); accI += __shfl(pi, WAVE - 1); accM += __shfl(pm, WAVE - 1); needM += __shfl(pn, WAVE - 1);
+        sN += mwAll; sR += L;
+        if (st[b].kind != 2) sM += mwAll;                        // kind 2: already skipped (k_live: no fallback kernels in this launch)
     }
-    if (lane == 0) {
-        tot->R = accR; tot->maxL = mx; tot->nnzTotal = 0; tot->maskWords = accM < capMaskWords ? accM : capMaskWords; tot->items = accI; tot->sliceGroups = 0;
-        tot->needMaskWords = needM; tot->needNnz = 0; tot->overflow = nover; tot->maxStreamL = mxs; tot->minStreamL = mns; tot->pad0 = 0; tot->listTop = 0ull;
+    long long totM, totN; int totR, totI;
+    const long long baseM = block_excl_scan(sM, shl, totM);
+    (void)block_excl_scan(sN, shl, totN);
+    const int baseR = block_excl_scan(sR, shi, totR);
+    // the prefix is monotone: once a problem does not fit, none behind it does
+    int sI = 0;
+    {
+        long long accM = baseM;
+        for (int b = b0; b < b1; ++b) {
+            const int L = st[b].L;
+            const bool skip = st[b].kind == 2;
+            const long long mw = skip ? 0 : (long long)L * ((L + 63) >> 6);
+            accM += mw;
+            if (!skip && accM <= capMaskWords) sI += (L + RPB - 1) / RPB;
+        }
+    }
+    const int baseI = block_excl_scan(sI, shi, totI);
+    int mx = 0, mxs = 0, nover = 0, mns = 0x7fffffff;
+    {
+        long long accM = baseM; int accR = baseR, accI = baseI;
+        for (int b = b0; b < b1; ++b) {
+            const int L = st[b].L;
+            const bool skip = st[b].kind == 2;
+            const long long mw = skip ? 0 : (long long)L * ((L + 63) >> 6);
+            const bool fits = !skip && accM + mw <= capMaskWords;
+            const int it = fits ? (L + RPB - 1) / RPB : 0;
+            st[b].rowBase = accR; st[b].itemBase = accI; st[b].maskOff = fits ? accM : 0;
+            if (!fits) { st[b].kind = 2; ++nover; }
+            else if (st[b].kind == 0) { mxs = max(mxs, L); mns = min(mns, L); }
+            mx = max(mx, L);
+            accM += mw; accR += L; accI += it;
+        }
+    }
+    // batch maxima / counts: wave reduction, then one atomic per wave on LDS words
+    __shared__ int red[4];
+    if (tid == 0) { red[0] = 0; red[1] = 0; red[2] = 0; red[3] = 0x7fffffff; }
+    __syncthreads();
+    for (int off = 32; off > 0; off >>= 1) { mx = max(mx, __shfl_xor(mx, off)); mxs = max(mxs, __shfl_xor(mxs, off)); nover += __shfl_xor(nover, off); mns = min(mns, __shfl_xor(mns, off)); }
+    if ((tid & 63) == 0) { atomicMax(&red[0], mx); atomicMax(&red[1], mxs); atomicAdd(&red[2], nover); atomicMin(&red[3], mns); }
+    __syncthreads();
+    if (tid == 0) {
+        tot->R = totR; tot->maxL = red[0]; tot->nnzTotal = 0; tot->maskWords = totM < capMaskWords ? totM : capMaskWords; tot->items = totI; tot->sliceGroups = 0;
+        tot->needMaskWords = totN; tot->needNnz = 0; tot->overflow = red[2]; tot->maxStreamL = red[1]; tot->minStreamL = red[3]; tot->pad0 = 0; tot->listTop = 0ull;
     }
 }
 
@@ -1442,35 +1483,51 @@ __global__ void __launch_bounds__(64) k_slicegeom(const ProbDesc* __restrict__ p
     if (lane == WAVE - 1) st[b].nnzCap = ex + v;
 }
 
-// k_probscan: serial prefix of the per-problem slot totals and of the slice-group counts (k_fill_slice work items:
+// k_probscan: prefix over the problems of the per-problem slot totals and of the slice-group counts (k_fill_slice work items:
 // min(NG, slices) groups of consecutive slices per stream-layout problem).  A problem whose matrix segment would end beyond
 // `capNnz` slots becomes kind 2 (skipped; nothing has been written for it yet).
-__global__ void __launch_bounds__(64) k_probscan(int B, int NG /* fill groups per problem */, long long capNnz, ProbState* __restrict__ st, BatchTotals* __restrict__ tot)
+__global__ void __launch_bounds__(1024) k_probscan(int B, int NG /* fill groups per problem */, long long capNnz, ProbState* __restrict__ st, BatchTotals* __restrict__ tot)
 {
-    const int lane = threadIdx.x;
-    long long acc = 0;
-    int gacc = 0, nover = 0;
-    for (int b0 = 0; b0 < B; b0 += WAVE) {
-        const int b = b0 + lane;
-        const int kind = b < B ? st[b].kind : 2;
-        const long long cap = (b < B && kind != 2) ? (long long)st[b].nnzCap : 0;
-        long long pc = cap;
-        for (int off = 1; off < WAVE; off <<= 1) { const long long t = __shfl_up(pc, off); if (lane >= off) pc += t; }
-        const bool fits = acc + pc <= capNnz;
-        const int ng = (b < B && kind == 0 && fits) ? min(NG, (st[b].L + 63) >> 6) : 0;
-        int pg = ng;
-        for (int off = 1; off < WAVE; off <<= 1) { const int tg = __shfl_up(pg, off); if (lane >= off) pg += tg; }
-        if (b < B) {
-            st[b].nnzOff = fits ? acc + pc - cap : 0; st[b].sgBase = gacc + pg - ng;
-            if (!fits && kind != 2) st[b].kind = 2;
+    // one workgroup, PER consecutive problems per thread (k_rowbase)
+    __shared__ long long shl[17];
+    __shared__ int shi[17];
+    __shared__ int red[1];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int PER = (B + nt - 1) / nt;
+    const int b0 = tid * PER, b1 = min(B, b0 + PER);
+    long long sC = 0;
+    for (int b = b0; b < b1; ++b) if (st[b].kind != 2) sC += (long long)st[b].nnzCap;
+    long long totC; int totG;
+    const long long baseC = block_excl_scan(sC, shl, totC);
+    int sG = 0;
+    {
+        long long acc = baseC;
+        for (int b = b0; b < b1; ++b) {
+            const int kind = st[b].kind;
+            acc += kind != 2 ? (long long)st[b].nnzCap : 0;
+            if (kind == 0 && acc <= capNnz) sG += min(NG, (st[b].L + 63) >> 6);
         }
-        int ov = (b < B && kind != 2 && !fits) ? 1 : 0;
-        for (int off = 32; off > 0; off >>= 1) ov += __shfl_xor(ov, off);
-        nover += ov;
-        acc += __shfl(pc, WAVE - 1);
-        gacc += __shfl(pg, WAVE - 1);
     }
-    if (lane == 0) { tot->nnzTotal = acc < capNnz ? acc : capNnz; tot->sliceGroups = gacc; tot->needNnz = acc; tot->overflow += nover; }
+    const int baseG = block_excl_scan(sG, shi, totG);
+    if (tid == 0) red[0] = 0;
+    __syncthreads();
+    int nover = 0;
+    {
+        long long acc = baseC; int gacc = baseG;
+        for (int b = b0; b < b1; ++b) {
+            const int kind = st[b].kind;
+            const long long cap = kind != 2 ? (long long)st[b].nnzCap : 0;
+            const bool fits = acc + cap <= capNnz;
+            const int ng = (kind == 0 && fits) ? min(NG, (st[b].L + 63) >> 6) : 0;
+            st[b].nnzOff = fits ? acc : 0; st[b].sgBase = gacc;
+            if (!fits && kind != 2) { st[b].kind = 2; ++nover; }
+            acc += cap; gacc += ng;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) nover += __shfl_xor(nover, off);
+    if ((tid & 63) == 0 && nover) atomicAdd(&red[0], nover);
+    __syncthreads();
+    if (tid == 0) { tot->nnzTotal = totC < capNnz ? totC : capNnz; tot->sliceGroups = totG; tot->needNnz = totC; tot->overflow += red[0]; }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2856,9 +2913,9 @@ __global__ void __launch_bounds__(NW * 64) k_solve_up(DevParams D, int B, const 
                                                       const uint32_t* __restrict__ sliceBase,
                                                       const uint16_t* __restrict__ cols, const double* __restrict__ vals,
                                                       const double* __restrict__ u0, SolveOut O,
-                                                      int* __restrict__ queue, int Lc, int Llo, int Lhi)
+                                                      int* __restrict__ queue, int Lc, int Llo, int Lhi, int R /* problems per claim: 1..64 */)
 {
-    // LDS: xg[Lc] f64 | accM[Lc] u64 | accC[Lc] u64 | red[2 * NW * RED_STRIDE + 8] | cumQ[ST_MAXSL + 2] u32 | sint[4]
+    // LDS: xg[Lc] f64 | accM[Lc] u64 | accC[Lc] u64 | red[2 * NW * RED_STRIDE + 8] | cumQ[ST_MAXSL + 2] u32 | sint[8]
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* xg = reinterpret_cast<double*>(smem);
     unsigned long long* accM = reinterpret_cast<unsigned long long*>(xg + Lc);
@@ -2867,25 +2924,39 @@ __global__ void __launch_bounds__(NW * 64) k_solve_up(DevParams D, int B, const 
     uint32_t* cumQ = reinterpret_cast<uint32_t*>(red + 2 * NW * RED_STRIDE + 8);
     int* sint = reinterpret_cast<int*>(cumQ + ST_MAXSL + 2);
     for (;;) {
-        // thread 0 claims problems until it finds one this launch takes (stream layout, live-set size in [Llo, Lhi]): the
-        // others — the fallback solver's, skipped ones, the other instantiation's — cost one atomic and two loads, no barrier
-        if (threadIdx.x == 0) {
-            int b_;
+        // The first wave claims R consecutive problems at a time (R = 1 unless this launch expects to find nothing: a batch
+        // of small problems passes through the general instantiation and vice versa) until the range holds one this launch
+        // takes (stream layout, live-set size in [Llo, Lhi]): the others — the fallback solver's, skipped ones, the other
+        // instantiation's — cost one atomic and two loads per range, no barrier.
+        if (threadIdx.x < WAVE) {
+            const int ln = threadIdx.x;
+            int base_ = B; unsigned long long m_ = 0ull;
             for (;;) {
-                b_ = atomicAdd(queue, 1);
-                if (b_ >= B) break;
-                const int Lq = st[b_].L;
-                if (st[b_].kind == 0 && Lq >= Llo && Lq <= Lhi) break;
+                int t_ = 0;
+                if (ln == 0) t_ = atomicAdd(queue, R);
+                base_ = __builtin_amdgcn_readfirstlane(t_);
+                if (base_ >= B) break;
+                const int b_ = base_ + ln;
+                bool take = false;
+                if (ln < R && b_ < B) { const int Lq = st[b_].L; take = st[b_].kind == 0 && Lq >= Llo && Lq <= Lhi; }
+                m_ = __ballot(take);
+                if (m_) break;
             }
-            sint[2] = b_;
+            if (ln == 0) { sint[2] = base_; sint[3] = (int)(uint32_t)m_; sint[4] = (int)(uint32_t)(m_ >> 32); }
         }
         __syncthreads();
-        const int b = uni(sint[2]);
+        const int base = uni(sint[2]);
+        unsigned long long mask = ((unsigned long long)(uint32_t)uni(sint[4]) << 32) | (unsigned long long)(uint32_t)uni(sint[3]);
         __syncthreads();
-        if (b >= B) break;
+        if (base >= B) break;
+        while (mask) {
+        const int b = base + __builtin_ctzll(mask);
+        mask &= mask - 1ull;
         const ProbDesc pd = probs[b];
         solve_up<NW, HASCZ, MAXL>(D, b, pd, st, feats, assoc, plp, lpAsc, rowPos, pld, sliceBase, cols, vals, u0, O,
                                   xg, accM, accC, Lc, cumQ, red, sint);
+        __syncthreads();                                         // the next problem of the range reuses the LDS state
+        }
     }
 }
 

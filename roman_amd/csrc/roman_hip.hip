@@ -107,6 +107,7 @@ struct roman_ctx {
         double rNnz = 0.0;                     // matrix slots / sum of nA
         double rList = 0.0;                    // candidate-list elements / sum of nA
         bool smallSeen = false;                // a stream-layout problem of at most SMALL_MAXL live associations has occurred
+        bool largeSeen = false;                // ... one of more than SMALL_MAXL
     } hist;
     unsigned histEpoch = 1;                    // bumped whenever the history is reset for another parameter block
     long long skippedTotal = 0;                // problems reported ROMAN_ST_WORKSPACE so far (harvested totals)
@@ -283,6 +284,7 @@ void harvest_totals(roman_ctx* c, bool wait)
         if (W.totSumA > 0) H.rNnz = std::max(H.rNnz, (double)t.needNnz / W.totSumA);
         if (W.totSumA > 0) H.rList = std::max(H.rList, (double)t.listTop / W.totSumA);
         if (t.minStreamL <= SMALL_MAXL) H.smallSeen = true;
+        if (t.maxStreamL > SMALL_MAXL) H.largeSeen = true;
         H.valid = true;
     }
 }
@@ -481,7 +483,7 @@ int enqueue_score(roman_ctx* c, const DevParams& Din, const roman_params_t* para
                            WS.chunkCnt.as<int32_t>(), maxChunks, LP.lp, LP.li, LP.lj, LP.ls, LP.ld, LP.lza, LP.lzb);
     DBG(c, "k_live");
     }
-    hipLaunchKernelGGL(k_rowbase, dim3(1), dim3(64), 0, WS.stream, B, RPB, SZ.capMaskWords, dS, dT);
+    hipLaunchKernelGGL(k_rowbase, dim3(1), dim3(B > 256 ? 1024 : 256), 0, WS.stream, B, RPB, SZ.capMaskWords, dS, dT);
     DBG(c, "k_rowbase");
     hipLaunchKernelGGL(k_items, dim3(B), dim3(256), 0, WS.stream, RPB, dS, WS.items.as<ItemDesc>());
     DBG(c, "k_items");
@@ -535,7 +537,11 @@ int enqueue_score(roman_ctx* c, const DevParams& Din, const roman_params_t* para
         hipLaunchKernelGGL(k_rowprefix, dim3(c->num_cu * 2), dim3(1024), 0, WS.stream, dP, dS, dT, WS.items.as<ItemDesc>(),
                            WS.maskPool.as<unsigned long long>(), WS.prefPool.as<uint32_t>(), WS.rowCnt.as<uint32_t>(), RPB);
     DBG(c, "k_rowprefix");
-        hipLaunchKernelGGL(k_rowsort, dim3(B), dim3(1024), 0, WS.stream, dP, dS, dT, WS.rowCnt.as<uint32_t>(), WS.rowPos.as<uint32_t>(), WS.perm.as<uint32_t>(),
+        // the stream layout's bitonic sort takes N/2 threads for N = 2^k >= L keys; the fallback layout's counting sort is written
+        // for 1024 (at the reference's demo scale — 60 live associations — 4096 workgroups of 1024 threads were 99 us of a 1.4 ms call)
+        int sortThr = 1024;
+        if (!D.allow_fallback) { int N2 = 64; while (N2 < expL) N2 <<= 1; sortThr = std::max(64, std::min(1024, N2 / 2)); }
+        hipLaunchKernelGGL(k_rowsort, dim3(B), dim3(sortThr), 0, WS.stream, dP, dS, dT, WS.rowCnt.as<uint32_t>(), WS.rowPos.as<uint32_t>(), WS.perm.as<uint32_t>(),
                            WS.sliceWidth.as<uint32_t>(), WS.sliceBase.as<uint32_t>(), WS.listOff.as<uint32_t>(), SZ.capList);
     DBG(c, "k_rowsort");
         hipLaunchKernelGGL(k_upper, dim3(c->num_cu * 2), dim3(1024), 0, WS.stream, dP, dS, dT, WS.items.as<ItemDesc>(),
@@ -561,7 +567,7 @@ int enqueue_score(roman_ctx* c, const DevParams& Din, const roman_params_t* para
     if (ngEnv) NG = std::max(1, std::min(FILLS_MAXSPI, atoi(ngEnv)));
     const int Wmax = std::max(1, D.stream_maxL / 64);
     const int SPI = (Wmax + std::min(NG, Wmax) - 1) / std::min(NG, Wmax);       // slices per group at most (LDS capacity)
-    hipLaunchKernelGGL(k_probscan, dim3(1), dim3(64), 0, WS.stream, B, NG, SZ.capNnz, dS, dT);
+    hipLaunchKernelGGL(k_probscan, dim3(1), dim3(B > 256 ? 1024 : 256), 0, WS.stream, B, NG, SZ.capNnz, dS, dT);
     DBG(c, "k_probscan");
     t1.stop();
 
@@ -645,7 +651,7 @@ int enqueue_solve(roman_ctx* c, const DevParams& D, int B, int64_t sumA, int64_t
     // inert padding entries point at) + reduction scratch + slice table
     constexpr int NW = ROMAN_SOLVE_WAVES;
     const int Lc = ((D.stream_maxL + 63) & ~63) + 64;
-    const size_t ldsUp = (size_t)3 * 8 * Lc + sizeof(double) * (2 * NW * RED_STRIDE + 8) + sizeof(uint32_t) * (ST_MAXSL + 2) + sizeof(int) * 4 + 16;
+    const size_t ldsUp = (size_t)3 * 8 * Lc + sizeof(double) * (2 * NW * RED_STRIDE + 8) + sizeof(uint32_t) * (ST_MAXSL + 2) + sizeof(int) * 8 + 16;
     const int wgPerCu = std::max(1, std::min((int)(c->lds_max / ldsUp), 2048 / (NW * 64)));
     const int gridUp = std::max(1, std::min(B, c->num_cu * wgPerCu));
 
@@ -660,19 +666,19 @@ int enqueue_solve(roman_ctx* c, const DevParams& D, int B, int64_t sumA, int64_t
     const bool small = !(smallEnv && smallEnv[0] == '0') && D.p.maxiniters >= 1 && D.p.maxlsiters >= 1 &&
                        (c->hist.valid ? c->hist.smallSeen : maxA <= 16 * SMALL_MAXL);
     const int Lc1 = SMALL_MAXL + 64;
-    const size_t ldsUp1 = (size_t)3 * 8 * Lc1 + sizeof(double) * (2 * 1 * RED_STRIDE + 8) + sizeof(uint32_t) * (ST_MAXSL + 2) + sizeof(int) * 4 + 16;
+    const size_t ldsUp1 = (size_t)3 * 8 * Lc1 + sizeof(double) * (2 * 1 * RED_STRIDE + 8) + sizeof(uint32_t) * (ST_MAXSL + 2) + sizeof(int) * 8 + 16;
     const int gridUp1 = std::max(1, std::min(B, c->num_cu * 24));
 #define ROMAN_LAUNCH_UP(CZ_)                                                                                                  \
     do {                                                                                                                      \
         HIPCHK(c, dyn_lds(c, reinterpret_cast<const void*>(k_solve_up<NW, CZ_, STREAM_MAXL>), ldsUp)); \
         hipLaunchKernelGGL((k_solve_up<NW, CZ_, STREAM_MAXL>), dim3(gridUp), dim3(NW * 64), ldsUp, WS.stream, D, B, WS.probs.as<ProbDesc>(), WS.state.as<ProbState>(), feats, assoc, \
                            WS.plp.as<int32_t>(), WS.lp.as<int32_t>(), WS.rowPos.as<uint32_t>(), WS.pld.as<double>(), WS.sliceBase.as<uint32_t>(), \
-                           WS.cols16.as<uint16_t>(), WS.vals.as<double>(), u0, O, WS.queue.as<int>(), Lc, small ? SMALL_MAXL + 1 : 0, STREAM_MAXL); \
+                           WS.cols16.as<uint16_t>(), WS.vals.as<double>(), u0, O, WS.queue.as<int>(), Lc, small ? SMALL_MAXL + 1 : 0, STREAM_MAXL, (small && c->hist.valid && !c->hist.largeSeen) ? 64 : 1); \
         if (small) {                                                                                                          \
             HIPCHK(c, dyn_lds(c, reinterpret_cast<const void*>(k_solve_up<1, CZ_, SMALL_MAXL>), ldsUp1));                       \
             hipLaunchKernelGGL((k_solve_up<1, CZ_, SMALL_MAXL>), dim3(gridUp1), dim3(64), ldsUp1, WS.stream, D, B, WS.probs.as<ProbDesc>(), WS.state.as<ProbState>(), feats, assoc, \
                                WS.plp.as<int32_t>(), WS.lp.as<int32_t>(), WS.rowPos.as<uint32_t>(), WS.pld.as<double>(), WS.sliceBase.as<uint32_t>(), \
-                               WS.cols16.as<uint16_t>(), WS.vals.as<double>(), u0, O, WS.queue.as<int>() + 1, Lc1, 0, SMALL_MAXL); \
+                               WS.cols16.as<uint16_t>(), WS.vals.as<double>(), u0, O, WS.queue.as<int>() + 1, Lc1, 0, SMALL_MAXL, 1); \
         }                                                                                                                     \
     } while (0)
     if (hascz) ROMAN_LAUNCH_UP(true); else ROMAN_LAUNCH_UP(false);

@@ -2,6 +2,8 @@
 seeded inputs.  Bar: bit-exact integer/index results (live list, sparsity pattern, selected nodes in
 order, association indices); M values within a few ulp (exp/cbrt/pow are the only inexact ops);
 pose within 1e-5 Frobenius (north_star) — in practice ~1e-15."""
+import os
+
 import numpy as np
 import pytest
 
@@ -160,7 +162,10 @@ def test_mfma_cosine_kernel(ctx, n1, n2, d):
     assert np.max(np.abs(got - ref)) < 1e-14
 
 
-@pytest.mark.parametrize("n1,n2,d", [(16, 16, 4), (20, 24, 16), (37, 53, 70), (64, 64, 512), (9, 7, 768), (5, 3, 1)])
+@pytest.mark.parametrize("n1,n2,d", [(16, 16, 4), (20, 24, 16), (37, 53, 70), (64, 64, 512), (9, 7, 768), (5, 3, 1),
+                                     # the tiled kernel's cases: several balanced tiles, waves owning block rows (n1 >= n2 per tile) and block
+                                     # columns (the transposed product), descriptor lengths with 0, 1, 2, 3 full stages of 16 and a ragged one
+                                     (65, 17, 33), (200, 200, 48), (130, 40, 16), (40, 130, 31), (49, 49, 15), (1, 1, 16), (63, 200, 96)])
 def test_cosine_bits_equal_the_oracles_stated_order(ctx, orc, n1, n2, d):
     """The f64 matrix-core contraction accumulates in the order the oracle states (dot_fixed / norm_fixed in
     oracle/clipper_oracle.c): the cosine matrix is BIT-identical, so the cosine gate decides on the same value."""
@@ -170,6 +175,24 @@ def test_cosine_bits_equal_the_oracles_stated_order(ctx, orc, n1, n2, d):
     got = ctx.debug_cosine(P, D1, D2)
     ref = np.array([[orc.cosine(D1[i, 3:], D2[j, 3:]) for j in range(n2)] for i in range(n1)])
     assert np.array_equal(got, ref)
+
+
+def test_both_cosine_kernels_give_the_same_bits(ctx, tmp_path):
+    """ROMAN_COS=0 selects the per-wave kernel k_cos (32x32 tile per wave, operands from global memory) that k_cos_tile
+    replaced as the default: same contraction order per element, same bits.  The switch is read once per process, so the
+    other kernel runs in a child process."""
+    import subprocess, sys
+    rng = np.random.default_rng(5)
+    P = _abi.RomanParams.default(); P.cos_feature_dim = 70
+    D1 = rng.standard_normal((137, 73)); D2 = rng.standard_normal((53, 73))
+    here = ctx.debug_cosine(P, D1, D2)
+    np.savez(tmp_path / "in.npz", D1=D1, D2=D2)
+    code = ("import numpy as np, sys; from roman_amd import _abi; from roman_amd.runtime import Context\n"
+            "z = np.load(sys.argv[1]); P = _abi.RomanParams.default(); P.cos_feature_dim = 70\n"
+            "c = Context(0); np.save(sys.argv[2], c.debug_cosine(P, z['D1'], z['D2'])); c.close()\n")
+    env = dict(os.environ, ROMAN_COS="0", PYTHONPATH=os.pathsep.join([os.path.dirname(os.path.dirname(os.path.abspath(__file__)))] + sys.path))
+    subprocess.run([sys.executable, "-c", code, str(tmp_path / "in.npz"), str(tmp_path / "out.npy")], check=True, env=env, timeout=300)
+    assert np.array_equal(here, np.load(tmp_path / "out.npy"))
 
 
 def _nudge(x, k):
