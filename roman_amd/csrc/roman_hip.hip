@@ -544,7 +544,10 @@ int enqueue_score(roman_ctx* c, const DevParams& Din, const roman_params_t* para
         hipLaunchKernelGGL(k_rowsort, dim3(B), dim3(sortThr), 0, WS.stream, dP, dS, dT, WS.rowCnt.as<uint32_t>(), WS.rowPos.as<uint32_t>(), WS.perm.as<uint32_t>(),
                            WS.sliceWidth.as<uint32_t>(), WS.sliceBase.as<uint32_t>(), WS.listOff.as<uint32_t>(), SZ.capList);
     DBG(c, "k_rowsort");
-        hipLaunchKernelGGL(k_upper, dim3(c->num_cu * 2), dim3(1024), 0, WS.stream, dP, dS, dT, WS.items.as<ItemDesc>(),
+        // small live sets (the reference's demo scale): a work item is a whole problem of a few dozen rows — more, smaller
+        // workgroups keep more of them in flight (a row is a chain of dependent memory round trips)
+        const int upThr = expL <= 256 ? 256 : 1024;
+        hipLaunchKernelGGL(k_upper, dim3(c->num_cu * 2 * (1024 / upThr)), dim3(upThr), 0, WS.stream, dP, dS, dT, WS.items.as<ItemDesc>(),
                            WS.maskPool.as<unsigned long long>(), WS.listPool.as<uint16_t>(), WS.listOff.as<uint32_t>(),
                            WS.rowCnt.as<uint32_t>(), WS.perm.as<uint32_t>(), WS.rowPos.as<uint32_t>(), LP, PP, RPB);
     DBG(c, "k_upper");
@@ -589,7 +592,9 @@ int enqueue_score(roman_ctx* c, const DevParams& Din, const roman_params_t* para
         auto kf = D.gravity ? (fast ? k_fill_list<true, true, false> : k_fill_list<true, false, false>) : (fast ? k_fill_list<false, true, false> : k_fill_list<false, false, false>);
         if (obj) kf = D.gravity ? (fast ? k_fill_list<true, true, true> : k_fill_list<true, false, true>) : (fast ? k_fill_list<false, true, true> : k_fill_list<false, false, true>);
         HIPCHK(c, dyn_lds(c, reinterpret_cast<const void*>(kf), sliceLds));
-        hipLaunchKernelGGL(kf, dim3((unsigned)(c->num_cu & ~7)), dim3(1024), sliceLds, WS.stream,
+        const int fillThr = expL <= 256 ? 256 : 1024;          // (k_upper: small problems, small workgroups, more of them)
+        const int fillWgs = std::max(1, std::min(1024 / fillThr, (int)(c->lds_max / sliceLds)));
+        hipLaunchKernelGGL(kf, dim3((unsigned)((c->num_cu & ~7) * fillWgs)), dim3(fillThr), sliceLds, WS.stream,
                            D, B, dP, dS, dT, WS.tabPool.as<double>(), in.feats, NO, LP.li, LP.lj, LP.ls, LP.lza, LP.lzb,
                            WS.listPool.as<uint16_t>(), WS.listOff.as<uint32_t>(), WS.rowCnt.as<uint32_t>(), WS.perm.as<uint32_t>(), WS.rowPos.as<uint32_t>(),
                            WS.sliceWidth.as<uint32_t>(), WS.sliceBase.as<uint32_t>(), WS.cols16.as<uint16_t>(), WS.vals.as<double>(), TCs, NG, SPI);
