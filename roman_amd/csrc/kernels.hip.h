@@ -1896,6 +1896,107 @@ __global__ void __launch_bounds__(1024) k_fill_list(DevParams D, int B, const Pr
 }
 
 // ---------------------------------------------------------------------------------------------
+// Dense problems (roman_set_matrix_data: the set_matrix_data / solve loop of [REF roman/align/object_registration.py:60-72]).
+// The caller's M and C (n x n, row major) become the layouts the scored problems use, on the device: k_dense_mask writes
+// the symmetric candidate bit matrix, the kernels of the scored path (k_rowprefix, k_rowsort, k_upper, k_slicegeom,
+// k_probscan) turn it into positions, lists and slice geometry, k_dense_fill writes labels and values.  Like upstream
+// only the STRICT UPPER triangles are read: entry (k, q) is M[min][max] / C[min][max]; it is stored when either is
+// non-zero and carries the C flag when C is zero there.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void dense_entry(const double* __restrict__ M, const double* __restrict__ C, int n, int k, int q, double& mv, double& cv)
+{
+    const int a = min(k, q), b = max(k, q);
+    mv = M[(int64_t)a * n + b]; cv = C[(int64_t)a * n + b];
+}
+
+__global__ void __launch_bounds__(256) k_dense_mask(int n, const double* __restrict__ M, const double* __restrict__ C,
+                                                    unsigned long long* __restrict__ mask /* n rows x ceil(n/64) words */,
+                                                    int* __restrict__ flags /* [0]: some stored entry has C == 0 */)
+{
+    const int lane = threadIdx.x & 63;
+    const int W = (n + 63) >> 6;
+    const int nwaves = (int)(gridDim.x * (blockDim.x >> 6));
+    for (int k = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)); k < n; k += nwaves) {
+        bool cz = false;
+        for (int w = 0; w < W; ++w) {
+            const int q = (w << 6) + lane;
+            bool cand = false;
+            if (q < n && q != k) {
+                double mv, cv;
+                dense_entry(M, C, n, k, q, mv, cv);
+                cand = (mv != 0.0) || (cv != 0.0);
+                cz = cz || (cand && cv == 0.0);
+            }
+            const unsigned long long m = __ballot(cand);
+            if (lane == 0) mask[(int64_t)k * W + w] = m;
+        }
+        if (__ballot(cz) != 0ull && lane == 0) atomicOr(flags, 1);
+    }
+}
+
+// One thread per slot of the problem's matrix segment (slot t of the COLUMN array; the value sits at val_pos of the same
+// (slice, lane slot, entry)).  KIND 0: stream layout — entry e of position row p is element e of its candidate list;
+// padding points at the dummy element n + lane slot.  KIND 1: symmetric sorted SELL-64 in quads — entry e of row k is the
+// e-th set bit of its mask row (per-word prefix counts from k_rowprefix); padding = the row's own position, flagged.
+template <int KIND>
+__global__ void __launch_bounds__(256) k_dense_fill(int n, const double* __restrict__ M, const double* __restrict__ C,
+                                                    ProbState* __restrict__ st,
+                                                    const uint32_t* __restrict__ rowCnt, const uint32_t* __restrict__ rowPos, const uint32_t* __restrict__ perm,
+                                                    const uint32_t* __restrict__ sliceWidth, const uint32_t* __restrict__ sliceBase,
+                                                    const uint16_t* __restrict__ listPool, const uint32_t* __restrict__ listOff,
+                                                    const unsigned long long* __restrict__ mask, const uint32_t* __restrict__ pref,
+                                                    uint16_t* __restrict__ cols16, uint32_t* __restrict__ cols32, double* __restrict__ vals)
+{
+    const uint32_t total = st[0].nnzCap;
+    const int64_t no = st[0].nnzOff;
+    const int nsl = (n + 63) >> 6, W = nsl;
+    const uint16_t* lists = listPool + st[0].listOff;
+    unsigned upper = 0;
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
+        int sl = 0;
+        {   // last slice with sliceBase <= t (slices of width 0 share a base with their successor: skipped by the search)
+            int lo_ = 0, hi_ = nsl - 1;
+            while (lo_ < hi_) { const int mid = (lo_ + hi_ + 1) >> 1; if (sliceBase[mid] <= t) lo_ = mid; else hi_ = mid - 1; }
+            sl = lo_;
+        }
+        const uint32_t sb = sliceBase[sl], off = t - sb;
+        const uint32_t slot = (off & 255u) >> 2, e = ((off >> 8) << 2) | (off & 3u);
+        const int pos = sl * 64 + (int)slot;
+        const int k = pos < n ? (int)perm[pos] : -1;
+        double val = 0.0;
+        if (KIND == 0) {
+            uint32_t label = ((uint32_t)n + slot) | 0x8000u;
+            if (k >= 0 && e < rowCnt[pos]) {
+                const int q = (int)lists[listOff[pos] + e];
+                double mv, cv;
+                dense_entry(M, C, n, k, q, mv, cv);
+                label = rowPos[q] | (cv == 0.0 ? 0x8000u : 0u); val = mv; ++upper;
+            }
+            cols16[no + t] = (uint16_t)label;
+        } else {
+            uint32_t label = (uint32_t)(k >= 0 ? pos : 0) | 0x80000000u;
+            if (k >= 0 && e < rowCnt[k]) {
+                const unsigned long long* mrow = mask + (int64_t)k * W;
+                const uint32_t* prow = pref + (int64_t)k * W;
+                int lo_ = 0, hi_ = W - 1;                        // last word with prefix <= e
+                while (lo_ < hi_) { const int mid = (lo_ + hi_ + 1) >> 1; if (prow[mid] <= e) lo_ = mid; else hi_ = mid - 1; }
+                unsigned long long m = mrow[lo_];
+                for (uint32_t i = prow[lo_]; i < e; ++i) m &= m - 1ull;
+                const int q = (lo_ << 6) + __builtin_ctzll(m);
+                double mv, cv;
+                dense_entry(M, C, n, k, q, mv, cv);
+                label = rowPos[q] | (cv == 0.0 ? 0x80000000u : 0u); val = mv;
+                if (q > k) ++upper;
+            }
+            cols32[no + t] = label;
+        }
+        vals[no + val_pos<true>(sb, slot, e)] = val;
+    }
+    for (int off = 32; off > 0; off >>= 1) upper += __shfl_xor(upper, off);
+    if ((threadIdx.x & 63) == 0 && upper) atomicAdd(&st[0].nnzUpper, (unsigned long long)upper);
+}
+
+// ---------------------------------------------------------------------------------------------
 // solver
 // ---------------------------------------------------------------------------------------------
 
@@ -2525,6 +2626,10 @@ __device__ __forceinline__ double readlane63(double v)
 // reduction tree.  `red`: two ping-pong areas of NW*8 doubles (a buffer is rewritten only after the barrier of the
 // next call).  The barrier inside also publishes whatever the caller wrote to LDS before the call.
 constexpr int RED_STRIDE = 8;
+// doubles of reduction scratch a stream-solver workgroup of NW waves owns: the solver's ping-pong areas, and at least the 72 that
+// finish_one() uses whatever the workgroup size (two areas of 32 + the slot red[64]).  (With 2 * NW * RED_STRIDE + 8 = 24 the
+// one-wave instantiation wrote red[32..33] over its unused slice table and red[64] BEHIND its LDS allocation.)
+constexpr int red_doubles(int NW) { return 2 * NW * RED_STRIDE + 8 > 72 ? 2 * NW * RED_STRIDE + 8 : 72; }
 template <int NW, int NS, int NM>
 __device__ __forceinline__ void block_red(double (&sv)[NS > 0 ? NS : 1], double (&mv)[NM > 0 ? NM : 1], double* red, int& par, int tid)
 {
@@ -2915,13 +3020,13 @@ __global__ void __launch_bounds__(NW * 64) k_solve_up(DevParams D, int B, const 
                                                       const double* __restrict__ u0, SolveOut O,
                                                       int* __restrict__ queue, int Lc, int Llo, int Lhi, int R /* problems per claim: 1..64 */)
 {
-    // LDS: xg[Lc] f64 | accM[Lc] u64 | accC[Lc] u64 | red[2 * NW * RED_STRIDE + 8] | cumQ[ST_MAXSL + 2] u32 | sint[8]
+    // LDS: xg[Lc] f64 | accM[Lc] u64 | accC[Lc] u64 | red[red_doubles(NW)] | cumQ[ST_MAXSL + 2] u32 | sint[8]
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* xg = reinterpret_cast<double*>(smem);
     unsigned long long* accM = reinterpret_cast<unsigned long long*>(xg + Lc);
     unsigned long long* accC = accM + Lc;
     double* red = reinterpret_cast<double*>(accC + Lc);
-    uint32_t* cumQ = reinterpret_cast<uint32_t*>(red + 2 * NW * RED_STRIDE + 8);
+    uint32_t* cumQ = reinterpret_cast<uint32_t*>(red + red_doubles(NW));
     int* sint = reinterpret_cast<int*>(cumQ + ST_MAXSL + 2);
     for (;;) {
         // The first wave claims R consecutive problems at a time (R = 1 unless this launch expects to find nothing: a batch

@@ -656,7 +656,7 @@ int enqueue_solve(roman_ctx* c, const DevParams& D, int B, int64_t sumA, int64_t
     // inert padding entries point at) + reduction scratch + slice table
     constexpr int NW = ROMAN_SOLVE_WAVES;
     const int Lc = ((D.stream_maxL + 63) & ~63) + 64;
-    const size_t ldsUp = (size_t)3 * 8 * Lc + sizeof(double) * (2 * NW * RED_STRIDE + 8) + sizeof(uint32_t) * (ST_MAXSL + 2) + sizeof(int) * 8 + 16;
+    const size_t ldsUp = (size_t)3 * 8 * Lc + sizeof(double) * red_doubles(NW) + sizeof(uint32_t) * (ST_MAXSL + 2) + sizeof(int) * 8 + 16;
     const int wgPerCu = std::max(1, std::min((int)(c->lds_max / ldsUp), 2048 / (NW * 64)));
     const int gridUp = std::max(1, std::min(B, c->num_cu * wgPerCu));
 
@@ -671,7 +671,7 @@ int enqueue_solve(roman_ctx* c, const DevParams& D, int B, int64_t sumA, int64_t
     const bool small = !(smallEnv && smallEnv[0] == '0') && D.p.maxiniters >= 1 && D.p.maxlsiters >= 1 &&
                        (c->hist.valid ? c->hist.smallSeen : maxA <= 16 * SMALL_MAXL);
     const int Lc1 = SMALL_MAXL + 64;
-    const size_t ldsUp1 = (size_t)3 * 8 * Lc1 + sizeof(double) * (2 * 1 * RED_STRIDE + 8) + sizeof(uint32_t) * (ST_MAXSL + 2) + sizeof(int) * 8 + 16;
+    const size_t ldsUp1 = (size_t)3 * 8 * Lc1 + sizeof(double) * red_doubles(1) + sizeof(uint32_t) * (ST_MAXSL + 2) + sizeof(int) * 8 + 16;
     const int gridUp1 = std::max(1, std::min(B, c->num_cu * 24));
 #define ROMAN_LAUNCH_UP(CZ_)                                                                                                  \
     do {                                                                                                                      \
@@ -873,26 +873,6 @@ int solve_last(roman_ctx* c, const double* u0_host)
     for (int k = 0; k < L; ++k) Lst.u[(size_t)lpv[k]] = ul[k];
     Lst.solved = true;
     return ROMAN_OK;
-}
-
-// Host twin of the fallback branch of k_rowsort: sorted SELL-64 geometry (widths in whole quads) from the row lengths (stable descending sort).
-void sell_geometry(const std::vector<uint32_t>& cnt, int L, std::vector<uint32_t>& rowPos, std::vector<uint32_t>& perm,
-                   std::vector<uint32_t>& sliceWidth, std::vector<uint32_t>& sliceBase, uint64_t* total)
-{
-    perm.resize((size_t)std::max(L, 1)); rowPos.assign((size_t)std::max(L, 1), 0);
-    for (int k = 0; k < L; ++k) perm[(size_t)k] = (uint32_t)k;
-    std::stable_sort(perm.begin(), perm.begin() + L, [&](uint32_t a, uint32_t b) { return cnt[a] > cnt[b]; });
-    for (int p = 0; p < L; ++p) rowPos[perm[(size_t)p]] = (uint32_t)p;
-    const int nsl = (L + 63) / 64;
-    sliceWidth.assign((size_t)std::max(nsl, 1), 0); sliceBase.assign((size_t)std::max(nsl, 1), 0);
-    uint64_t acc = 0;
-    for (int sl = 0; sl < nsl; ++sl) {
-        uint32_t wmax = 0;
-        for (int p = sl * 64; p < std::min(L, sl * 64 + 64); ++p) wmax = std::max(wmax, cnt[perm[(size_t)p]]);
-        wmax = (wmax + 3u) & ~3u;                               // quad layout
-        sliceWidth[(size_t)sl] = wmax; sliceBase[(size_t)sl] = (uint32_t)acc; acc += (uint64_t)wmax * 64u;
-    }
-    *total = acc;
 }
 
 // Download the matrix of the last single problem and decode it into per-row lists over LIVE indices, both triangles,
@@ -1330,115 +1310,88 @@ int roman_set_matrix_data(roman_ctx_t* c, const roman_params_t* params, const do
     Lst.D.wide = (!up && c->coop_ok && Lst.D.p.maxiniters >= 1 && Lst.D.p.maxlsiters >= 1 && n <= (int64_t)WIDE_KW * c->num_cu * WIDE_NW * 64) ? 1 : 0;
     Lst.D.idx16 = 0;                                           // dense problems may carry C flags: 32-bit labels
     Lst.D.stream_maxL = up ? std::max(64, (n + 63) & ~63) : 64;
-    // full-symmetric rows over the union pattern of the strict upper triangles of M and C (like upstream only the
-    // strict upper triangles are read)
+    // The conversion runs on the device (kernels.hip.h, "Dense problems"): upload M and C, candidate bit matrix, then the
+    // scored path's own layout kernels.  Two small read-backs size the matrix pools (the slot total is known only after the
+    // sort) and fetch the C-flag / capacity status.
     const size_t n1_ = (size_t)std::max(n, 1);
-    std::vector<std::vector<std::pair<uint32_t, double>>> rows(n1_);       // (column | flag in bit 31, value)
-    int64_t upper = 0; bool anycz = false;
-    for (int a = 0; a < n; ++a)
-        for (int b = a + 1; b < n; ++b) {
-            const double mv = M[(int64_t)a * n + b], cv = Cm[(int64_t)a * n + b];
-            if (mv != 0.0 || cv != 0.0) {
-                const uint32_t flag = (cv == 0.0) ? 0x80000000u : 0u;
-                anycz = anycz || flag;
-                rows[(size_t)a].push_back({(uint32_t)b | flag, mv}); rows[(size_t)b].push_back({(uint32_t)a | flag, mv});
-                ++upper;
-                if (upper > 1500000000LL) return fail(c, ROMAN_E_TOO_LARGE, "dense matrix has too many non-zeros");
-            }
-        }
-    for (auto& r : rows) std::sort(r.begin(), r.end(), [](const std::pair<uint32_t, double>& x, const std::pair<uint32_t, double>& y) { return (x.first & 0x7fffffffu) < (y.first & 0x7fffffffu); });
-    Lst.hascz = anycz;
-    std::vector<uint32_t> deg(n1_, 0), rowPos, perm, sliceWidth, sliceBase, rowCnt(n1_, 0);
-    for (int k = 0; k < n; ++k) deg[(size_t)k] = (uint32_t)rows[(size_t)k].size();
-    uint64_t total = 0;
-    std::vector<uint16_t> c16; std::vector<uint32_t> c32; std::vector<double> jvals;
-    if (up) {
-        // stream layout: positions = stable rank by descending degree; row p keeps its strict-upper entries (p, q > p)
-        // in ascending q; slices padded to whole quads; inert entries point at the dummy elements n + slot
-        perm.resize(n1_); rowPos.assign(n1_, 0);
-        for (int k = 0; k < n; ++k) perm[(size_t)k] = (uint32_t)k;
-        std::stable_sort(perm.begin(), perm.begin() + n, [&](uint32_t a, uint32_t b) { return deg[a] > deg[b]; });
-        for (int q = 0; q < n; ++q) rowPos[perm[(size_t)q]] = (uint32_t)q;
-        std::vector<std::vector<std::pair<uint32_t, double>>> urows(n1_);
-        for (int q = 0; q < n; ++q) {
-            for (auto& e : rows[perm[(size_t)q]]) {
-                const uint32_t qq = rowPos[e.first & 0x7fffffffu];
-                if ((int)qq > q) urows[(size_t)q].push_back({qq | (e.first & 0x80000000u), e.second});
-            }
-            std::sort(urows[(size_t)q].begin(), urows[(size_t)q].end(), [](const std::pair<uint32_t, double>& x, const std::pair<uint32_t, double>& y) { return (x.first & 0x7fffffffu) < (y.first & 0x7fffffffu); });
-            rowCnt[(size_t)q] = (uint32_t)urows[(size_t)q].size();
-        }
-        const int nsl = (n + 63) / 64;
-        sliceWidth.assign((size_t)std::max(nsl, 1), 0); sliceBase.assign((size_t)std::max(nsl, 1), 0);
-        for (int sl = 0; sl < nsl; ++sl) {
-            uint32_t wmax = 0;
-            for (int q = sl * 64; q < std::min(n, sl * 64 + 64); ++q) wmax = std::max(wmax, rowCnt[(size_t)q]);
-            wmax = (wmax + 3u) & ~3u;
-            sliceWidth[(size_t)sl] = wmax; sliceBase[(size_t)sl] = (uint32_t)total; total += (uint64_t)wmax * 64u;
-        }
-        c16.assign((size_t)std::max<uint64_t>(total, 1), 0); jvals.assign((size_t)std::max<uint64_t>(total, 1), 0.0);
-        for (int sl = 0; sl < nsl; ++sl)
-            for (uint32_t slot = 0; slot < 64; ++slot) {
-                const int q = sl * 64 + (int)slot;
-                for (uint32_t e = 0; e < sliceWidth[(size_t)sl]; ++e) {
-                    const size_t pc = h_col_pos(true, sliceBase[(size_t)sl], slot, e), pv = h_val_pos(true, sliceBase[(size_t)sl], slot, e);
-                    if (q < n && e < rowCnt[(size_t)q]) {
-                        const auto& en = urows[(size_t)q][e];
-                        c16[pc] = (uint16_t)((en.first & 0x7fffu) | ((en.first & 0x80000000u) ? 0x8000u : 0u)); jvals[pv] = en.second;
-                    } else { c16[pc] = (uint16_t)(((uint32_t)n + slot) | 0x8000u); jvals[pv] = 0.0; }
-                }
-            }
-    } else {
-        // fallback layout: symmetric sorted SELL-64 in quads, the caller's numbering, 32-bit indices
-        sell_geometry(deg, n, rowPos, perm, sliceWidth, sliceBase, &total);
-        if (total > 4000000000ull) return fail(c, ROMAN_E_TOO_LARGE, "dense matrix has too many non-zeros");
-        c32.assign((size_t)std::max<uint64_t>(total, 1), 0); jvals.assign((size_t)std::max<uint64_t>(total, 1), 0.0);
-        for (int sl = 0; sl < (n + 63) / 64; ++sl)
-            for (uint32_t slot = 0; slot < 64; ++slot) {
-                const int pos = sl * 64 + (int)slot;
-                const int k = pos < n ? (int)perm[(size_t)pos] : -1;                 // -1: lane slot without a row
-                const uint32_t inert = (uint32_t)(k >= 0 ? pos : 0) | 0x80000000u;       // the row's own position, flagged
-                for (uint32_t e = 0; e < sliceWidth[(size_t)sl]; ++e) {
-                    const size_t pc = h_col_pos(true, sliceBase[(size_t)sl], slot, e), pv = h_val_pos(true, sliceBase[(size_t)sl], slot, e);
-                    if (k >= 0 && e < deg[(size_t)k]) {          // column label = POSITION of the column (+ the C flag)
-                        const uint32_t cw = rows[(size_t)k][e].first;
-                        c32[pc] = rowPos[cw & 0x7fffffffu] | (cw & 0x80000000u); jvals[pv] = rows[(size_t)k][e].second;
-                    } else { c32[pc] = inert; jvals[pv] = 0.0; }
-                }
-            }
-        for (int k = 0; k < n; ++k) rowCnt[(size_t)k] = deg[(size_t)k];
+    const int W = (n + 63) / 64;
+    const int RPB = 128;
+    const size_t maskWords = std::max<size_t>((size_t)n * (size_t)W, 1);
+    const long long capList = up ? (long long)n * (n - 1) / 2 + 4LL * n + 4 : 4;
+    HIPCHK(c, WS.probs.ensure(sizeof(ProbDesc))); HIPCHK(c, WS.state.ensure(sizeof(ProbState))); HIPCHK(c, WS.totals.ensure(sizeof(BatchTotals)));
+    HIPCHK(c, WS.queue.ensure(sizeof(int) * 8));
+    {
+        DevBuf* i32s[] = {&WS.lp, &WS.plp, &WS.rowCnt, &WS.rowPos, &WS.perm, &WS.sliceWidth, &WS.sliceBase, &WS.listOff};
+        for (DevBuf* b_ : i32s) HIPCHK(c, b_->ensure(sizeof(int32_t) * n1_));
+        DevBuf* f64s[] = {&WS.ls, &WS.ld, &WS.pld};
+        for (DevBuf* b_ : f64s) HIPCHK(c, b_->ensure(sizeof(double) * n1_));
     }
-    const size_t nnz1 = (size_t)std::max<uint64_t>(total, 1), nsl1 = (size_t)std::max((n + 63) / 64, 1);
-    HIPCHK(c, WS.probs.ensure(sizeof(ProbDesc))); HIPCHK(c, WS.state.ensure(sizeof(ProbState))); HIPCHK(c, WS.queue.ensure(sizeof(int) * 8));
-    HIPCHK(c, WS.lp.ensure(sizeof(int32_t) * n1_)); HIPCHK(c, WS.plp.ensure(sizeof(int32_t) * n1_));
-    HIPCHK(c, WS.ls.ensure(sizeof(double) * n1_)); HIPCHK(c, WS.ld.ensure(sizeof(double) * n1_)); HIPCHK(c, WS.pld.ensure(sizeof(double) * n1_));
-    HIPCHK(c, WS.rowCnt.ensure(sizeof(uint32_t) * n1_)); HIPCHK(c, WS.rowPos.ensure(sizeof(uint32_t) * n1_)); HIPCHK(c, WS.perm.ensure(sizeof(uint32_t) * n1_));
-    HIPCHK(c, WS.sliceWidth.ensure(sizeof(uint32_t) * n1_)); HIPCHK(c, WS.sliceBase.ensure(sizeof(uint32_t) * n1_));
+    HIPCHK(c, WS.maskPool.ensure(sizeof(unsigned long long) * maskWords)); HIPCHK(c, WS.prefPool.ensure(sizeof(uint32_t) * maskWords));
+    HIPCHK(c, WS.listPool.ensure(sizeof(uint16_t) * (size_t)capList));
+    HIPCHK(c, WS.items.ensure(sizeof(ItemDesc) * ((size_t)n / RPB + 2)));
+    HIPCHK(c, WS.hAux1.ensure(sizeof(double) * n1_ * n1_)); HIPCHK(c, WS.hAux2.ensure(sizeof(double) * n1_ * n1_)); HIPCHK(c, WS.hAux3.ensure(sizeof(int) * 4));
+    WS.capMaskWords = std::max<long long>(WS.capMaskWords, (long long)maskWords); WS.capList = std::max<long long>(WS.capList, capList);
+    ProbDesc pd{}; pd.off1 = 0; pd.off2 = 0; pd.assocOff = -1; pd.liveOff = 0; pd.n1 = n; pd.n2 = 1; pd.nA = n;
+    ProbState ps{}; ps.L = n; ps.kind = up ? 0 : 1;
+    HIPCHK(c, hipMemcpyAsync(WS.probs.p, &pd, sizeof(pd), hipMemcpyHostToDevice, WS.stream));
+    HIPCHK(c, hipMemcpyAsync(WS.state.p, &ps, sizeof(ps), hipMemcpyHostToDevice, WS.stream));
+    HIPCHK(c, hipMemsetAsync(WS.hAux3.p, 0, sizeof(int) * 4, WS.stream));
+    HIPCHK(c, hipStreamSynchronize(WS.stream));                  // (pd, ps live on this frame)
+    const ProbDesc* dP = WS.probs.as<ProbDesc>(); ProbState* dS = WS.state.as<ProbState>(); BatchTotals* dT = WS.totals.as<BatchTotals>();
+    const double* dM = WS.hAux1.as<double>(); const double* dC = WS.hAux2.as<double>();
+    if (n > 0) {
+        std::vector<int32_t> ident(n1_); std::vector<double> ones(n1_, 1.0);
+        for (int k = 0; k < n; ++k) ident[(size_t)k] = k;
+        HIPCHK(c, hipMemcpy(WS.hAux1.p, M, sizeof(double) * n1_ * n1_, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(WS.hAux2.p, Cm, sizeof(double) * n1_ * n1_, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(WS.lp.p, ident.data(), sizeof(int32_t) * n1_, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(WS.plp.p, ident.data(), sizeof(int32_t) * n1_, hipMemcpyHostToDevice));      // (stream layout: k_upper overwrites it with the permutation)
+        HIPCHK(c, hipMemcpy(WS.ls.p, ones.data(), sizeof(double) * n1_, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(WS.ld.p, ones.data(), sizeof(double) * n1_, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(WS.pld.p, ones.data(), sizeof(double) * n1_, hipMemcpyHostToDevice));
+    }
+    const LivePools LP{WS.lp.as<int32_t>(), nullptr, nullptr, WS.ls.as<double>(), WS.ld.as<double>(), nullptr, nullptr};
+    const LivePools PP{WS.plp.as<int32_t>(), nullptr, nullptr, nullptr, WS.pld.as<double>(), nullptr, nullptr};
+    hipLaunchKernelGGL(k_rowbase, dim3(1), dim3(256), 0, WS.stream, 1, RPB, (long long)maskWords, dS, dT);
+    hipLaunchKernelGGL(k_items, dim3(1), dim3(256), 0, WS.stream, RPB, dS, WS.items.as<ItemDesc>());
+    if (n > 0) {
+        hipLaunchKernelGGL(k_dense_mask, dim3((unsigned)std::min(c->num_cu * 8, (n + 3) / 4)), dim3(256), 0, WS.stream, n, dM, dC,
+                           WS.maskPool.as<unsigned long long>(), WS.hAux3.as<int>());
+        hipLaunchKernelGGL(k_rowprefix, dim3(c->num_cu * 2), dim3(1024), 0, WS.stream, dP, dS, dT, WS.items.as<ItemDesc>(),
+                           WS.maskPool.as<unsigned long long>(), WS.prefPool.as<uint32_t>(), WS.rowCnt.as<uint32_t>(), RPB);
+        hipLaunchKernelGGL(k_rowsort, dim3(1), dim3(1024), 0, WS.stream, dP, dS, dT, WS.rowCnt.as<uint32_t>(), WS.rowPos.as<uint32_t>(), WS.perm.as<uint32_t>(),
+                           WS.sliceWidth.as<uint32_t>(), WS.sliceBase.as<uint32_t>(), WS.listOff.as<uint32_t>(), capList);
+        if (up) {
+            hipLaunchKernelGGL(k_upper, dim3(c->num_cu * 2), dim3(1024), 0, WS.stream, dP, dS, dT, WS.items.as<ItemDesc>(),
+                               WS.maskPool.as<unsigned long long>(), WS.listPool.as<uint16_t>(), WS.listOff.as<uint32_t>(),
+                               WS.rowCnt.as<uint32_t>(), WS.perm.as<uint32_t>(), WS.rowPos.as<uint32_t>(), LP, PP, RPB);
+            hipLaunchKernelGGL(k_slicegeom, dim3(1), dim3(64), 0, WS.stream, dP, dS, WS.rowCnt.as<uint32_t>(), WS.sliceWidth.as<uint32_t>(), WS.sliceBase.as<uint32_t>());
+        }
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(&ps, WS.state.p, sizeof(ps), hipMemcpyDeviceToHost, WS.stream));
+    HIPCHK(c, hipStreamSynchronize(WS.stream));
+    if (ps.kind == 2) return fail(c, ROMAN_E_NOMEM, "internal: dense problem does not fit its own workspace");
+    const uint64_t total = ps.nnzCap;
+    if (total > 4000000000ull) return fail(c, ROMAN_E_TOO_LARGE, "dense matrix has too many non-zeros");
+    const size_t nnz1 = (size_t)std::max<uint64_t>(total, 1);
     HIPCHK(c, WS.vals.ensure(sizeof(double) * nnz1)); HIPCHK(c, WS.cols16.ensure(sizeof(uint16_t) * nnz1)); HIPCHK(c, WS.cols32.ensure(sizeof(uint32_t) * nnz1));
     WS.capNnz = std::max<long long>(WS.capNnz, (long long)nnz1);
-    ProbDesc pd{}; pd.off1 = 0; pd.off2 = 0; pd.assocOff = -1; pd.liveOff = 0; pd.n1 = n; pd.n2 = 1; pd.nA = n;
-    ProbState ps{}; ps.L = n; ps.rowBase = 0; ps.nnzOff = 0; ps.maskOff = 0; ps.nnzCap = (uint32_t)total; ps.nnzUpper = (unsigned long long)upper; ps.kind = up ? 0 : 1;
-    std::vector<int32_t> ident(n1_), plp(n1_); std::vector<double> ones(n1_, 1.0);
-    for (int k = 0; k < n; ++k) { ident[(size_t)k] = k; plp[(size_t)k] = up ? (int32_t)perm[(size_t)k] : k; }
-    HIPCHK(c, hipMemcpy(WS.probs.p, &pd, sizeof(pd), hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(WS.state.p, &ps, sizeof(ps), hipMemcpyHostToDevice));
-    if (n > 0) {
-        HIPCHK(c, hipMemcpy(WS.lp.p, ident.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice));
-        HIPCHK(c, hipMemcpy(WS.plp.p, plp.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice));
-        HIPCHK(c, hipMemcpy(WS.ls.p, ones.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
-        HIPCHK(c, hipMemcpy(WS.ld.p, ones.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
-        HIPCHK(c, hipMemcpy(WS.pld.p, ones.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
-        HIPCHK(c, hipMemcpy(WS.rowCnt.p, rowCnt.data(), sizeof(uint32_t) * (size_t)n, hipMemcpyHostToDevice));
-        HIPCHK(c, hipMemcpy(WS.rowPos.p, rowPos.data(), sizeof(uint32_t) * (size_t)n, hipMemcpyHostToDevice));
-        HIPCHK(c, hipMemcpy(WS.perm.p, perm.data(), sizeof(uint32_t) * (size_t)n, hipMemcpyHostToDevice));
-        HIPCHK(c, hipMemcpy(WS.sliceWidth.p, sliceWidth.data(), sizeof(uint32_t) * nsl1, hipMemcpyHostToDevice));
-        HIPCHK(c, hipMemcpy(WS.sliceBase.p, sliceBase.data(), sizeof(uint32_t) * nsl1, hipMemcpyHostToDevice));
-    }
+    hipLaunchKernelGGL(k_probscan, dim3(1), dim3(256), 0, WS.stream, 1, 1, (long long)nnz1, dS, dT);
     if (total > 0) {
-        HIPCHK(c, hipMemcpy(WS.vals.p, jvals.data(), sizeof(double) * (size_t)total, hipMemcpyHostToDevice));
-        if (up) HIPCHK(c, hipMemcpy(WS.cols16.p, c16.data(), sizeof(uint16_t) * (size_t)total, hipMemcpyHostToDevice));
-        else    HIPCHK(c, hipMemcpy(WS.cols32.p, c32.data(), sizeof(uint32_t) * (size_t)total, hipMemcpyHostToDevice));
+        const unsigned grid = (unsigned)std::min<uint64_t>((total + 255) / 256, (uint64_t)c->num_cu * 16);
+        auto kf = up ? k_dense_fill<0> : k_dense_fill<1>;
+        hipLaunchKernelGGL(kf, dim3(grid), dim3(256), 0, WS.stream, n, dM, dC, dS, WS.rowCnt.as<uint32_t>(), WS.rowPos.as<uint32_t>(), WS.perm.as<uint32_t>(),
+                           WS.sliceWidth.as<uint32_t>(), WS.sliceBase.as<uint32_t>(), WS.listPool.as<uint16_t>(), WS.listOff.as<uint32_t>(),
+                           WS.maskPool.as<unsigned long long>(), WS.prefPool.as<uint32_t>(), WS.cols16.as<uint16_t>(), WS.cols32.as<uint32_t>(), WS.vals.as<double>());
     }
+    HIPCHK(c, hipGetLastError());
+    int flags[4] = {0, 0, 0, 0};
+    HIPCHK(c, hipMemcpyAsync(&ps, WS.state.p, sizeof(ps), hipMemcpyDeviceToHost, WS.stream));
+    HIPCHK(c, hipMemcpyAsync(flags, WS.hAux3.p, sizeof(flags), hipMemcpyDeviceToHost, WS.stream));
+    HIPCHK(c, hipStreamSynchronize(WS.stream));
+    if (ps.kind == 2) return fail(c, ROMAN_E_NOMEM, "internal: dense problem does not fit its own workspace");
+    Lst.hascz = flags[0] != 0;
     Lst.pd = pd; Lst.nA = n; Lst.L = n; Lst.kind = ps.kind; Lst.nnzCap = (int64_t)total;
     Lst.scored = true;
     return ROMAN_OK;

@@ -95,6 +95,16 @@ def test_tie_fallback_matches_published_heap(ctx, orc):
     ref = orc.solve(P, orc.matrix_from_dense(M, C))
     assert nodes.tolist() == ref["nodes"].tolist() == [2, 1, 0]
     assert abs(score - 2.5) < 1e-12
+    # a context without sizing history sends so small a problem to the ONE-WAVE instantiation of the solver (the shared
+    # context of this session may or may not, depending on which tests ran before): same rounding there
+    from roman_amd.runtime import Context
+    fresh = Context(0)
+    try:
+        fresh.set_matrix_data(P, M, C); fresh.solve(None)
+        nodes1, _, score1, _ = fresh.solution()
+    finally:
+        fresh.close()
+    assert nodes1.tolist() == [2, 1, 0] and abs(score1 - 2.5) < 1e-12
 
 
 def test_dense_matrix_path_and_mno_clipper(ctx, orc):
@@ -115,6 +125,55 @@ def test_dense_matrix_path_and_mno_clipper(ctx, orc):
         assert abs(sols[k][1] - u_sol @ Mo @ u_sol / (u_sol @ u_sol)) < 1e-9
         Mw[np.ix_(s["nodes"], s["nodes"])] = 0.0
     assert len(sols[0][0]) >= 5
+
+
+def _random_dense_problem(n, density, seed, flag_fraction=0.2):
+    """Symmetric M (weights in (0, 1]) and C over a random pattern; a fraction of the stored pairs has C == 0 with a
+    non-zero weight (the `C flag`), a few have M == 0 with C == 1 (a consistent pair of weight 0)."""
+    rng = np.random.default_rng(seed)
+    iu = np.triu_indices(n, 1)
+    keep = rng.random(len(iu[0])) < density
+    clique = rng.choice(n, size=min(n, 12), replace=False)              # a planted consistent subset, so the solve has something to find
+    w = np.where(keep, rng.uniform(0.05, 1.0, len(iu[0])), 0.0)
+    M = np.zeros((n, n)); C = np.zeros((n, n))
+    M[iu] = w; C[iu] = (w > 0).astype(float)
+    r = rng.random(len(iu[0]))
+    flagged = keep & (r < flag_fraction)
+    zero_w = keep & (r > 0.97)
+    Cu = C[iu]; Cu[flagged] = 0.0; C[iu] = Cu
+    Mu = M[iu]; Mu[zero_w & ~flagged] = 0.0; M[iu] = Mu
+    for a in clique:
+        for b in clique:
+            if a < b: M[a, b] = rng.uniform(0.8, 1.0); C[a, b] = 1.0
+    M = M + M.T; C = C + C.T
+    np.fill_diagonal(M, 1.0); np.fill_diagonal(C, 1.0)
+    return M, C
+
+
+@pytest.mark.parametrize("n,density,iters", [(5, 0.8, None), (64, 0.3, None), (65, 0.2, None), (300, 0.05, None), (700, 0.02, None), (300, 0.05, 0)],
+                         ids=["n5", "n64", "n65", "n300", "n700", "n300_fallback_layout"])
+def test_dense_conversion_on_the_device(ctx, orc, n, density, iters):
+    """roman_set_matrix_data builds the layouts on the device: the matrix it holds — read back through
+    roman_get_dense_matrices — is the caller's (strict upper triangles, C flags, zero weights), and the solve is the oracle's.
+    maxiniters = 0 selects the fallback layout (symmetric SELL-64, 32-bit labels) for a small problem."""
+    M, C = _random_dense_problem(n, density, 1000 + n)
+    P = _abi.RomanParams.default(); P.invariant = _abi.ROMAN_INV_EUCLIDEAN
+    if iters is not None:
+        P.maxiniters = iters
+    ctx.set_matrix_data(P, M, C)
+    Mg, Cg = ctx.dense_matrices()
+    assert np.array_equal(Mg, M) and np.array_equal(Cg, C)
+    ctx.solve(None)
+    nodes, u, score, st = ctx.solution()
+    ref = orc.solve(P, orc.matrix_from_dense(M, C))
+    assert np.allclose(u, ref["u"], rtol=0, atol=1e-9)
+    # the selected SET is the oracle's; the ORDER (descending u) may differ only between entries whose u agree to within the
+    # iteration's own tolerance (the two solvers' u agree to 1e-9, not bitwise: tests/test_u0_stability.py)
+    assert sorted(nodes.tolist()) == sorted(ref["nodes"].tolist())
+    uo = ref["u"][ref["nodes"]]
+    for r in np.nonzero(nodes != ref["nodes"])[0]:
+        assert abs(uo[r] - uo[min(r + 1, len(uo) - 1)]) < 1e-6 or abs(uo[r] - uo[max(r - 1, 0)]) < 1e-6
+    assert st.nnz_upper == int(np.count_nonzero(np.triu((M != 0) | (C != 0), 1)))
 
 
 def test_mno_clipper_leaves_the_registration_untouched(ctx, orc):
