@@ -1076,7 +1076,12 @@ __global__ void __launch_bounds__(1024) k_count(DevParams D, const ProbDesc* __r
     const int lane = tid & 63, w = tid >> 6, wpb = nt >> 6;
     double* tA = tabs + (size_t)w * ldsPerWave;
     const int nItems = tot->items;
-    for (int t = blockIdx.x; t < nItems; t += gridDim.x) {
+    // XCD-aware order (workgroup ids are dealt to the 8 XCDs round-robin): XCD x takes the CONTIGUOUS range [x Gx, (x + 1) Gx) of
+    // work items — the items of a problem, which share its tables, columns and mask rows, run on one L2
+    const int Gx_ = (nItems + 7) >> 3;
+    for (int sIdx_ = blockIdx.x; (sIdx_ >> 3) < Gx_; sIdx_ += gridDim.x) {
+        const int t = (sIdx_ & 7) * Gx_ + (sIdx_ >> 3);
+        if (t >= nItems) continue;
         const ItemDesc it = items[t];
         const int b = it.b;
         const ProbDesc pd = probs[b];
@@ -1199,7 +1204,12 @@ __global__ void __launch_bounds__(1024) k_rowprefix(const ProbDesc* __restrict__
 {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, wpb = blockDim.x >> 6;
     const int nItems = tot->items;
-    for (int t = blockIdx.x; t < nItems; t += gridDim.x) {
+    // XCD-aware order (workgroup ids are dealt to the 8 XCDs round-robin): XCD x takes the CONTIGUOUS range [x Gx, (x + 1) Gx) of
+    // work items — the items of a problem, which share its tables, columns and mask rows, run on one L2
+    const int Gx_ = (nItems + 7) >> 3;
+    for (int sIdx_ = blockIdx.x; (sIdx_ >> 3) < Gx_; sIdx_ += gridDim.x) {
+        const int t = (sIdx_ & 7) * Gx_ + (sIdx_ >> 3);
+        if (t >= nItems) continue;
         const ItemDesc it = items[t];
         const int b = it.b;
         const int L = st[b].L;
@@ -1396,7 +1406,12 @@ __global__ void __launch_bounds__(1024) k_upper(const ProbDesc* __restrict__ pro
     const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, w = tid >> 6, wpb = nt >> 6;
     const int nItems = tot->items;
     int staged = -1;
-    for (int t = blockIdx.x; t < nItems; t += gridDim.x) {
+    // XCD-aware order (workgroup ids are dealt to the 8 XCDs round-robin): XCD x takes the CONTIGUOUS range [x Gx, (x + 1) Gx) of
+    // work items — the items of a problem, which share its tables, columns and mask rows, run on one L2
+    const int Gx_ = (nItems + 7) >> 3;
+    for (int sIdx_ = blockIdx.x; (sIdx_ >> 3) < Gx_; sIdx_ += gridDim.x) {
+        const int t = (sIdx_ & 7) * Gx_ + (sIdx_ >> 3);
+        if (t >= nItems) continue;
         const ItemDesc it = items[t];
         const int b = it.b;
         if (uni_i(st[b].kind) == 0) {                           // (no `continue` around the barriers below)
@@ -1665,7 +1680,12 @@ __global__ void __launch_bounds__(1024) k_fill(DevParams D, const ProbDesc* __re
     uint32_t* qQ = qK + FILL_Q;
     uint32_t* qE = qQ + FILL_Q;
     const int nItems = tot->items;
-    for (int t = blockIdx.x; t < nItems; t += gridDim.x) {
+    // XCD-aware order (workgroup ids are dealt to the 8 XCDs round-robin): XCD x takes the CONTIGUOUS range [x Gx, (x + 1) Gx) of
+    // work items — the items of a problem, which share its tables, columns and mask rows, run on one L2
+    const int Gx_ = (nItems + 7) >> 3;
+    for (int sIdx_ = blockIdx.x; (sIdx_ >> 3) < Gx_; sIdx_ += gridDim.x) {
+        const int t = (sIdx_ & 7) * Gx_ + (sIdx_ >> 3);
+        if (t >= nItems) continue;
         const ItemDesc it = items[t];
         const int b = it.b;
         if (uni_i(st[b].kind) == 1) {           // stream-layout problems are filled by k_fill_slice, skipped ones not at all
