@@ -431,9 +431,14 @@ __global__ void __launch_bounds__(256) k_cos_tile(DevParams D, int B, int G /* w
     // column: a 3x3 tile keeps three waves busy with 3 blocks each, 3x4 and 4x3 tiles all four — dealt as 2x2 quarters they
     // were 4 + 2 + 2 + 1 and the workgroup as slow as a full tile (tools/ubench/mfma_tiles.hip: 213 us against the 169 of a
     // perfect deal for config 3).  Which wave takes which row rotates with the tile: a wave index is a SIMD.
-    const bool byRows = nbx >= nby;
-    const int ws = (w + tile) & 3;                               // the wave's block row (byRows) or block column
-    const int nMin = uni_i(ws < (byRows ? nbx : nby) ? (byRows ? nby : nbx) : 0);      // blocks of this wave: 0..4
+    // A tile of at most 2x2 blocks (maps of up to 32 objects: the reference's demo scale) gives every wave ONE block.
+    const bool oneBlock = nbx <= 2 && nby <= 2;
+    const bool byRows = oneBlock || nbx >= nby;
+    const int wsr = (w + tile) & 3;
+    const int ws = oneBlock ? (wsr >> 1) : wsr;                  // the wave's block row (byRows) or block column
+    const int m0 = oneBlock ? (wsr & 1) : 0;                     // first of its blocks across
+    const int nMin = uni_i(oneBlock ? ((ws < nbx && m0 < nby) ? 1 : 0)
+                                    : (ws < (byRows ? nbx : nby) ? (byRows ? nby : nbx) : 0));      // blocks of this wave: 0..4
 
     // the thread's share of a stage
     const int seg = tid % SEGS, row0 = tid / SEGS;
@@ -471,7 +476,7 @@ __global__ void __launch_bounds__(256) k_cos_tile(DevParams D, int B, int G /* w
     double sMaj = 0.0, sMin[4] = {0.0, 0.0, 0.0, 0.0};
     // LDS offsets of the lane's 32-byte pieces: A rows are stage rows 0..63, B rows 64..127
     const int offMaj = ((byRows ? 0 : 64) + 16 * ws + lr) * PITCH + 32 * kq;
-    const int offMin = ((byRows ? 64 : 0) + lr) * PITCH + 32 * kq;
+    const int offMin = ((byRows ? 64 : 0) + 16 * m0 + lr) * PITCH + 32 * kq;
 
     auto compute = [&](int s) {
         const unsigned char* base = smem + (s & 1) * STAGE;
@@ -510,6 +515,7 @@ __global__ void __launch_bounds__(256) k_cos_tile(DevParams D, int B, int G /* w
     };
 
     // stage s is multiplied while the loads of stages s + 1 (register set of the other parity) and s + 2 (this parity's) fly
+    // (a third set — three stages in flight — measured 3 % slower at config 3 and at the demo scale)
     // (every load of the loop is UNCONDITIONAL — beyond the last stage it fetches that stage again: a load inside an `if`
     // makes the compiler's wait-count pass assume the shorter queue at the join and wait for everything in flight)
     const int SF = Fc / KC;                          // full stages; a ragged one may follow
@@ -548,8 +554,8 @@ __global__ void __launch_bounds__(256) k_cos_tile(DevParams D, int B, int G /* w
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const double nOwn = __shfl(sMaj, kq + 4 * r);      // norm of row (kq + 4r) of the own block: held by lanes with lr == kq + 4r
-                const int row = byRows ? i0 + 16 * ws + kq + 4 * r : i0 + 16 * m + lr;
-                const int col = byRows ? j0 + 16 * m + lr : j0 + 16 * ws + kq + 4 * r;
+                const int row = byRows ? i0 + 16 * ws + kq + 4 * r : i0 + 16 * (m0 + m) + lr;
+                const int col = byRows ? j0 + 16 * (m0 + m) + lr : j0 + 16 * ws + kq + 4 * r;
                 const double na = byRows ? nOwn : nLr, nb = byRows ? nLr : nOwn;
                 if (row < iEnd && col < jEnd)
                     cosPool[pd.cosOff + (int64_t)row * pd.n2 + col] = D.pruned ? acc[m][r] : ((na > 0.0 && nb > 0.0) ? acc[m][r] / (na * nb) : 0.0);
