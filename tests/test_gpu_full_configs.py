@@ -76,6 +76,30 @@ def test_config4_grid_16x16_every_pair_matches_the_oracle(ctx, orc):
     assert ok >= 0.9 * len(batch)                                            # overlapping submaps do align
 
 
+def test_demo_scale_1024_pairs_match_the_oracle(ctx, orc):
+    """The scale the reference's demo runs at ([REF params/demo/submap_align.yaml:2,7,15]: submap_max_size 40, method 'roman',
+    768-d descriptors): 1024 pairs with n, m uniform in [20, 40] in ONE call — the path of the small kernels (one-wave
+    solver, one-block cosine tiles, parallel batch scans, small list / fill workgroups); every result is the oracle's."""
+    from roman_amd.align import SubmapAlignParams
+    reg = SubmapAlignParams(method="roman", semantics_dim=768).get_object_registration(); reg.set_context(ctx)
+    rng = np.random.default_rng(5000)
+    sizes = rng.integers(20, 41, size=(256, 2))
+    base = [synth.make_pair(int(a), int(b), 768, 5000 + k, tilt_deg=1.0) for k, (a, b) in enumerate(sizes)]
+    b256 = rb.batch_from_pairs(reg, [(p.map1, p.map2) for p in base])
+    rep = 4                                           # the 256 distinct pairs four times: 1024 problems per call
+    batch = rb.AlignmentBatch(b256.feats, np.tile(b256.off1, rep), np.tile(b256.n1, rep), np.tile(b256.off2, rep), np.tile(b256.n2, rep))
+    for _ in range(2):                                # the second call runs with the sizing history (small workgroups, range claims)
+        res = rb.run_batch(reg, batch)
+    problems = [(batch.feats[batch.off1[b]:batch.off1[b] + batch.n1[b]], batch.feats[batch.off2[b]:batch.off2[b] + batch.n2[b]]) for b in range(256)]
+    bad, worst, traj = _compare(orc, reg, res, problems)
+    print(f"demo scale: {256 - len(bad)}/256 identical results, worst pose error {worst:.2e}, iteration counts differ on {traj}")
+    assert not bad, f"{len(bad)} of 256 problems differ from the oracle: {bad[:10]}"
+    assert worst < POSE_TOL and len(traj) <= 12
+    for r in range(1, rep):                           # the replicas are the same problems: the same results
+        for b in range(256):
+            assert np.array_equal(res.assoc[r * 256 + b], res.assoc[b]) and res.status[r * 256 + b] == res.status[b]
+
+
 def test_mixed_batch_large_and_small_live_sets(ctx, orc):
     """One problem whose live set exceeds the streaming solver's capacity next to ordinary ones: each problem
     takes the layout / solver that fits it, results equal the oracle's for all of them."""
