@@ -311,7 +311,9 @@ ROMAN_API int roman_score(roman_ctx_t* ctx, const roman_params_t* params,
 
 /* clipper.set_matrix_data(M=, C=) [REF roman/align/object_registration.py:64]: dense
    row-major (n,n) float64 M and C; like upstream only the strict upper triangles are used
-   and the diagonal is the implicit identity.  Keeps the matrices in the context. */
+   and the diagonal is the implicit identity.  M and C are uploaded and converted to the
+   solver's layout on the device (host pointers in, two small read-backs); the matrices stay
+   in the context. */
 ROMAN_API int roman_set_matrix_data(roman_ctx_t* ctx, const roman_params_t* params,
                           const double* M, const double* C, int32_t n);
 
