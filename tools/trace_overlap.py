@@ -10,7 +10,7 @@ for r in rows:
     n = re.sub(r"<.*", "", n)
     ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), n))
 ev.sort()
-solves = [e for e in ev if e[2] == "k_solve_stream"]
+solves = [e for e in ev if e[2] in ("k_solve_up", "k_solve_stream")]
 big = [e for e in solves if e[1] - e[0] > 1_000_000]
 if len(big) < 4:
     print("too few batch launches"); sys.exit()
