@@ -784,12 +784,24 @@ __global__ void __launch_bounds__(1024) k_rowbase(int B, int RPB, long long capM
     const int tid = threadIdx.x, nt = blockDim.x;
     const int PER = (B + nt - 1) / nt;
     const int b0 = tid * PER, b1 = min(B, b0 + PER);
+    // the thread's problems are read ONCE (up to PC of them are kept in registers: the three sweeps below would otherwise be
+    // three dependent round trips to memory each)
+    constexpr int PC = 8;
+    int cL[PC], cK[PC];
+#pragma unroll
+    for (int j = 0; j < PC; ++j) { const int b = b0 + j; const bool in = j < PER && b < b1; cL[j] = in ? st[b].L : 0; cK[j] = in ? st[b].kind : 2; }
+    auto getL = [&](int b) { const int j = b - b0; int v = 0; if (j < PC) {
+#pragma unroll
+        for (int t = 0; t < PC; ++t) if (t == j) v = cL[t]; } else v = st[b].L; return v; };
+    auto getK = [&](int b) { const int j = b - b0; int v = 2; if (j < PC) {
+#pragma unroll
+        for (int t = 0; t < PC; ++t) if (t == j) v = cK[t]; } else v = st[b].kind; return v; };
     long long sM = 0, sN = 0; int sR = 0;
     for (int b = b0; b < b1; ++b) {
-        const int L = st[b].L;
+        const int L = getL(b);
         const long long mwAll = (long long)L * ((L + 63) >> 6);
         sN += mwAll; sR += L;
-        if (st[b].kind != 2) sM += mwAll;                        // kind 2: already skipped (k_live: no fallback kernels in this launch)
+        if (getK(b) != 2) sM += mwAll;                           // kind 2: already skipped (k_live: no fallback kernels in this launch)
     }
     long long totM, totN; int totR, totI;
     const long long baseM = block_excl_scan(sM, shl, totM);
@@ -800,8 +812,8 @@ __global__ void __launch_bounds__(1024) k_rowbase(int B, int RPB, long long capM
     {
         long long accM = baseM;
         for (int b = b0; b < b1; ++b) {
-            const int L = st[b].L;
-            const bool skip = st[b].kind == 2;
+            const int L = getL(b);
+            const bool skip = getK(b) == 2;
             const long long mw = skip ? 0 : (long long)L * ((L + 63) >> 6);
             accM += mw;
             if (!skip && accM <= capMaskWords) sI += (L + RPB - 1) / RPB;
@@ -812,14 +824,15 @@ __global__ void __launch_bounds__(1024) k_rowbase(int B, int RPB, long long capM
     {
         long long accM = baseM; int accR = baseR, accI = baseI;
         for (int b = b0; b < b1; ++b) {
-            const int L = st[b].L;
-            const bool skip = st[b].kind == 2;
+            const int L = getL(b);
+            const int kind = getK(b);
+            const bool skip = kind == 2;
             const long long mw = skip ? 0 : (long long)L * ((L + 63) >> 6);
             const bool fits = !skip && accM + mw <= capMaskWords;
             const int it = fits ? (L + RPB - 1) / RPB : 0;
             st[b].rowBase = accR; st[b].itemBase = accI; st[b].maskOff = fits ? accM : 0;
             if (!fits) { st[b].kind = 2; ++nover; }
-            else if (st[b].kind == 0) { mxs = max(mxs, L); mns = min(mns, L); }
+            else if (kind == 0) { mxs = max(mxs, L); mns = min(mns, L); }
             mx = max(mx, L);
             accM += mw; accR += L; accI += it;
         }
@@ -1516,17 +1529,29 @@ __global__ void __launch_bounds__(1024) k_probscan(int B, int NG /* fill groups 
     const int tid = threadIdx.x, nt = blockDim.x;
     const int PER = (B + nt - 1) / nt;
     const int b0 = tid * PER, b1 = min(B, b0 + PER);
+    constexpr int PC = 8;                                        // (k_rowbase: the thread's problems are read once)
+    int cK[PC], cL[PC]; uint32_t cC[PC];
+#pragma unroll
+    for (int j = 0; j < PC; ++j) { const int b = b0 + j; const bool in = j < PER && b < b1; cK[j] = in ? st[b].kind : 2; cL[j] = in ? st[b].L : 0; cC[j] = in ? st[b].nnzCap : 0u; }
+    auto get = [&](int b, int& kind, int& L, long long& cap) {
+        const int j = b - b0;
+        if (j < PC) {
+#pragma unroll
+            for (int t = 0; t < PC; ++t) if (t == j) { kind = cK[t]; L = cL[t]; cap = (long long)cC[t]; }
+        } else { kind = st[b].kind; L = st[b].L; cap = (long long)st[b].nnzCap; }
+        if (kind == 2) cap = 0;
+    };
     long long sC = 0;
-    for (int b = b0; b < b1; ++b) if (st[b].kind != 2) sC += (long long)st[b].nnzCap;
+    for (int b = b0; b < b1; ++b) { int kind, L; long long cap; get(b, kind, L, cap); sC += cap; }
     long long totC; int totG;
     const long long baseC = block_excl_scan(sC, shl, totC);
     int sG = 0;
     {
         long long acc = baseC;
         for (int b = b0; b < b1; ++b) {
-            const int kind = st[b].kind;
-            acc += kind != 2 ? (long long)st[b].nnzCap : 0;
-            if (kind == 0 && acc <= capNnz) sG += min(NG, (st[b].L + 63) >> 6);
+            int kind, L; long long cap; get(b, kind, L, cap);
+            acc += cap;
+            if (kind == 0 && acc <= capNnz) sG += min(NG, (L + 63) >> 6);
         }
     }
     const int baseG = block_excl_scan(sG, shi, totG);
@@ -1536,10 +1561,9 @@ __global__ void __launch_bounds__(1024) k_probscan(int B, int NG /* fill groups 
     {
         long long acc = baseC; int gacc = baseG;
         for (int b = b0; b < b1; ++b) {
-            const int kind = st[b].kind;
-            const long long cap = kind != 2 ? (long long)st[b].nnzCap : 0;
+            int kind, L; long long cap; get(b, kind, L, cap);
             const bool fits = acc + cap <= capNnz;
-            const int ng = (kind == 0 && fits) ? min(NG, (st[b].L + 63) >> 6) : 0;
+            const int ng = (kind == 0 && fits) ? min(NG, (L + 63) >> 6) : 0;
             st[b].nnzOff = fits ? acc : 0; st[b].sgBase = gacc;
             if (!fits && kind != 2) { st[b].kind = 2; ++nover; }
             acc += cap; gacc += ng;
