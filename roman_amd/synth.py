@@ -109,14 +109,18 @@ def yaw_transform(yaw, t, roll=0.0, pitch=0.0):
 
 
 def make_pair(n=200, m=200, d=512, seed=2000, inlier_frac=0.5, noise=0.1, n_classes=20,
-              desc_noise=0.35, tilt_deg=0.0):
-    """One synthetic submap pair."""
+              desc_noise=0.35, tilt_deg=0.0, roll_pitch_deg=None):
+    """One synthetic submap pair.  `tilt_deg` draws a random roll / pitch of that
+    scale; `roll_pitch_deg=(roll, pitch)` plants exact angles instead (gravity-check cases,
+    [REF roman/align/dist_reg_with_pruning.py:38-44]) without consuming random draws."""
     rng = np.random.default_rng(seed)
     c1 = _sample_centroids(rng, n)
     yaw = rng.uniform(-np.pi, np.pi)
     roll = pitch = 0.0
     if tilt_deg > 0.0:
         roll, pitch = np.deg2rad(tilt_deg) * rng.standard_normal(2)
+    if roll_pitch_deg is not None:
+        roll, pitch = np.deg2rad(float(roll_pitch_deg[0])), np.deg2rad(float(roll_pitch_deg[1]))
     t = np.array([rng.uniform(-5, 5), rng.uniform(-5, 5), rng.uniform(-0.5, 0.5)])
     T_gt = yaw_transform(yaw, t, roll, pitch)
     T_inv = np.linalg.inv(T_gt)

@@ -112,6 +112,21 @@ class RecordingLib:
         _put(Mp, M, np.float64); _put(Cp, Cm, np.float64)
         return 0
 
+    def roman_pose_batch(self, h, dim, B, p1p, p2p, offp, Tp, statp):
+        """[include/roman_hip.h roman_pose_batch]: B ragged correspondence sets -> (dim+1)^2 poses in 16-double records."""
+        self._log("roman_pose_batch")
+        off = _arr(offp, B + 1, np.int64)
+        p1 = _arr(p1p, int(off[-1]) * dim, np.float64).reshape(-1, dim); p2 = _arr(p2p, int(off[-1]) * dim, np.float64).reshape(-1, dim)
+        T = np.full((B, 16), np.nan); status = np.zeros(B, dtype=np.int32)
+        for b in range(B):
+            k = int(off[b + 1] - off[b])
+            if k < dim:
+                status[b] = _abi.ROMAN_ST_INSUFFICIENT
+            else:
+                T[b, :(dim + 1) ** 2] = self.orc.t_align(p1[off[b]:off[b + 1]], p2[off[b]:off[b + 1]]).ravel()
+        _put(Tp, T, np.float64); _put(statp, status, np.int32)
+        return 0
+
     def __getattr__(self, name):                                   # any other entry: a loud failure naming it
         if name.startswith("roman_"):
             def missing(*a):

@@ -68,6 +68,19 @@ def golden_pair(case):
     return pr
 
 
+def golden_gravity_cases():
+    """tests/golden/gravity_golden.npz: the reference's DistRegWithPruning.register on both sides of the roll/pitch threshold."""
+    z = np.load(os.path.join(GOLDEN, "gravity_golden.npz"), allow_pickle=False)
+    return [dict(n=int(z[f"n_{i}"]), m=int(z[f"m_{i}"]), d=int(z[f"d_{i}"]), seed=int(z[f"seed_{i}"]), kw=ast.literal_eval(str(z[f"kw_{i}"])),
+                 roll=float(z[f"roll_{i}"]), pitch=float(z[f"pitch_{i}"]), noise=float(z[f"noise_{i}"]), raised=int(z[f"raised_{i}"]),
+                 assoc=z[f"assoc_{i}"], T=z[f"T_{i}"], ypr=z[f"ypr_{i}"]) for i in range(int(z["n"]))]
+
+
+def golden_gravity_pair(case):
+    from roman_amd import synth
+    return synth.make_pair(case["n"], case["m"], case["d"], case["seed"], noise=case["noise"], roll_pitch_deg=(case["roll"], case["pitch"]))
+
+
 def golden_t_align_cases():
     z = np.load(os.path.join(GOLDEN, "t_align_golden.npz"), allow_pickle=False)
     return [dict(dim=int(z[f"dim{i}"]), p1=z[f"p1_{i}"], p2=z[f"p2_{i}"], T=z[f"T_{i}"], ok=int(z[f"ok{i}"]), tag=str(z[f"tag{i}"]))

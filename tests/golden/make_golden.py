@@ -12,6 +12,9 @@
    against the reference's Python; the CLIPPER arithmetic itself remains a restatement
    (PARITY UNPINNED, see oracle/clipper_oracle.c).
 
+3. gravity_golden.npz — the roll/pitch check of DistRegWithPruning.register (row a10), see gen_gravity().
+4. submap_align_golden.npz — the pair loop and the writers (rows f1/f3), see gen_submap_align().
+
 /root/reference does not exist on the GPU box: tests only read the committed .npz files.
 """
 import os
@@ -206,6 +209,55 @@ def gen_register():
     print(f"register_golden.npz: {len(cases)} cases")
 
 
+GRAVITY_SPECS = [
+    # (n, m, d, seed, SubmapAlignParams kwargs, (roll, pitch) in degrees planted in T_gt, centroid noise)
+    (40, 40, 32, 1100, {"cosine_min": 0.5}, (8.0, 0.0), 0.05),        # roll above the 5 degree threshold -> raises
+    (40, 40, 32, 1101, {"cosine_min": 0.5}, (0.0, 8.0), 0.05),        # pitch above -> raises
+    (40, 40, 32, 1102, {"cosine_min": 0.5}, (0.0, -8.0), 0.05),       # negative pitch, |.| above -> raises
+    (40, 36, 32, 1103, {"cosine_min": 0.5}, (4.9, 0.0), 0.0),         # just below (noise-free: the estimate IS 4.9) -> passes
+    (40, 36, 32, 1104, {"cosine_min": 0.5}, (0.0, -4.9), 0.0),        # -> passes
+    (36, 40, 32, 1105, {"cosine_min": 0.5}, (5.1, 0.0), 0.0),         # just above -> raises
+    (36, 40, 32, 1106, {"cosine_min": 0.5}, (-4.9, 4.9), 0.0),        # both just below -> passes
+    (36, 40, 32, 1107, {"cosine_min": 0.5}, (3.0, -7.0), 0.05),       # one below, one above -> raises
+    (50, 50, 64, 1108, {"cosine_min": 0.5, "epsilon_shape": 0.1}, (0.0, 0.0), 0.1),   # no tilt -> passes
+    (30, 30, 16, 1109, {"cosine_min": 0.6}, (12.0, 12.0), 0.02),      # both far above -> raises
+]
+
+
+def gen_gravity():
+    """gravity_golden.npz — PINS row a10: the reference's unmodified DistRegWithPruning.register
+    (/root/reference/roman/align/dist_reg_with_pruning.py:29-46, the roll/pitch check at :38-44 with scipy's
+    as_euler('ZYX')) through the factory's method='clipper+prune' (use_gravity=True), on pairs whose planted
+    roll / pitch lie on both sides of the 5 degree threshold.  Records whether the reference raised, the selected
+    associations (solve without the check), the pose and the Euler angles scipy reported."""
+    from scipy.spatial.transform import Rotation as Rot
+    from roman.params.submap_align_params import SubmapAlignParams as RefParams
+    from roman.align.dist_reg_with_pruning import GravityConstraintError
+    from roman_amd import synth
+    out = {"n": len(GRAVITY_SPECS)}
+    for i, (n, m, d, seed, kw, rp, noise) in enumerate(GRAVITY_SPECS):
+        reg = RefParams(method="clipper+prune", **kw).get_object_registration()
+        assert reg.use_gravity
+        pr = synth.make_pair(n, m, d, seed, noise=noise, roll_pitch_deg=rp)
+        try:
+            reg.register(pr.map1, pr.map2)
+            raised = 0
+        except GravityConstraintError:
+            raised = 1
+        reg.use_gravity = False                                    # the same solve without the check: what was selected
+        assoc = np.asarray(reg.register(pr.map1, pr.map2)).astype(np.int64).reshape(-1, 2)
+        T = reg.T_align(pr.map1, pr.map2, assoc)
+        ypr = Rot.from_matrix(T[:3, :3]).as_euler('ZYX')
+        assert raised == int(not (abs(ypr[2]) < reg.roll_pitch_thresh and abs(ypr[1]) < reg.roll_pitch_thresh))
+        for k, v in dict(n=n, m=m, d=d, seed=seed, kw=repr(kw), roll=rp[0], pitch=rp[1], noise=noise, raised=raised,
+                         assoc=assoc, T=T, ypr=ypr).items():
+            out[f"{k}_{i}"] = v
+        print(f"  clipper+prune planted roll/pitch {rp}: k={len(assoc)} estimated roll/pitch "
+              f"{np.rad2deg(ypr[2]):+.3f}/{np.rad2deg(ypr[1]):+.3f} deg raised={raised}")
+    np.savez_compressed(os.path.join(HERE, "gravity_golden.npz"), **out)
+    print(f"gravity_golden.npz: {len(GRAVITY_SPECS)} cases")
+
+
 def gen_submap_align():
     """submap_align_golden.npz — PINS rows f1/f3: the reference's unmodified pair loop
     (/root/reference/roman/align/submap_align.py:28-220) and result writers (roman/align/results.py:122-198)
@@ -291,10 +343,12 @@ if __name__ == "__main__":
     if not os.path.isdir(REF):
         sys.exit("reference checkout not present: golden fixtures can only be regenerated where /root/reference exists")
     install_reference_stubs()
-    which = sys.argv[1:] or ["t_align", "register", "submap_align"]
+    which = sys.argv[1:] or ["t_align", "register", "gravity", "submap_align"]
     if "t_align" in which:
         gen_t_align()
     if "register" in which:
         gen_register()
+    if "gravity" in which:
+        gen_gravity()
     if "submap_align" in which:
         gen_submap_align()

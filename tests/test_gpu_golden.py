@@ -4,15 +4,17 @@ results of the reference's unmodified plugin classes."""
 import numpy as np
 import pytest
 
-from conftest import golden_pair, golden_register_cases, golden_t_align_cases, registration_for
+from conftest import (golden_gravity_cases, golden_gravity_pair, golden_pair, golden_register_cases, golden_t_align_cases,
+                      registration_for)
 from roman_amd import _abi
-from roman_amd.align import InsufficientAssociationsException
+from roman_amd.align import GravityConstraintError, InsufficientAssociationsException
 
 pytestmark = pytest.mark.gpu
 
 POSE_TOL = 1e-5
 TCASES = golden_t_align_cases()
 RCASES = golden_register_cases()
+GCASES = golden_gravity_cases()
 
 
 def test_pose_kernel_matches_reference_t_align(ctx):
@@ -85,3 +87,25 @@ def test_register_and_t_align_match_reference_plugins(ctx, case):
     else:
         with pytest.raises(InsufficientAssociationsException):
             reg.T_align(pr.map1, pr.map2, assoc)
+
+
+@pytest.mark.parametrize("case", GCASES, ids=[f"roll{c['roll']:+g}_pitch{c['pitch']:+g}" for c in GCASES])
+def test_gravity_constraint_error_raised_where_the_reference_raises(ctx, case):
+    """Row a10 on the device path: `method='clipper+prune'` through roman_amd.align raises GravityConstraintError for exactly
+    the pairs the reference's own class raised on ([REF roman/align/dist_reg_with_pruning.py:38-44]; planted roll / pitch 8,
+    5.1, 4.9 degrees ...), with the host prefilter and with the prefilter on the device; without the check the selected
+    associations and the pose are the reference's."""
+    pr = golden_gravity_pair(case)
+    for on_device in (False, True):
+        reg = registration_for("clipper+prune", **case["kw"]); reg.set_context(ctx)
+        if on_device:
+            reg.prune_on_device = True; reg.semantics_dim = case["d"]
+        if case["raised"]:
+            with pytest.raises(GravityConstraintError, match="Roll and pitch must be less than"):
+                reg.register(pr.map1, pr.map2)
+        else:
+            assert np.array_equal(np.asarray(reg.register(pr.map1, pr.map2), dtype=np.int64), case["assoc"])
+        reg.use_gravity = False
+        assoc = np.asarray(reg.register(pr.map1, pr.map2), dtype=np.int64)
+        assert np.array_equal(assoc, case["assoc"])
+        assert np.linalg.norm(reg.T_align(pr.map1, pr.map2, assoc) - case["T"]) < POSE_TOL
