@@ -72,6 +72,61 @@ def parse():
     return ap.parse_args()
 
 
+class CallLoop:
+    """The choreography of the calls of a step, independent of the device (tests/test_bench_loop_cpu.py drives it at world
+    size 2 on gloo with a stub context): call number c writes output set c % nset; with batches in flight
+    (`pipeline` >= 2) the records of call c - 1 are gathered while call c computes — `join(skip_latest=True)` makes the
+    gathering stream wait for every call but the latest —, `drain()` gathers the last call's; at depth 1 a call is
+    gathered right behind itself.  `launch(ci, k)`: enqueue call `ci` of the step into output set `k`; `join(skip_latest)`;
+    `gather(k)`: collect output set k on every rank (None: single process, nothing to gather)."""
+
+    def __init__(self, n_calls, nset, pipeline, launch, join, gather=None):
+        assert nset >= max(pipeline, 2), "an output set is rewritten only after the call pipeline + 1 calls back has been gathered"
+        self.n_calls, self.nset, self.pipeline = n_calls, nset, pipeline
+        self.launch, self.join, self.gather = launch, join, gather
+        self.call_no = 0
+
+    def one_call(self, ci):
+        k = self.call_no % self.nset
+        self.call_no += 1
+        self.launch(ci, k)
+        if self.gather is not None:
+            if self.pipeline >= 2:
+                if self.call_no > 1:
+                    self.join(True)                              # the gathering stream waits for the OLDER calls only
+                    self.gather((k - 1) % self.nset)
+            else:
+                self.gather(k)
+        return k
+
+    def step(self):
+        for ci in range(self.n_calls):
+            self.one_call(ci)
+
+    def drain(self):                                             # results of the last call
+        if self.pipeline >= 2:
+            self.join(False)
+            if self.gather is not None and self.call_no > 0:
+                self.gather((self.call_no - 1) % self.nset)
+
+    def reset(self):
+        self.call_no = 0
+
+
+def self_launch(args_list, n):
+    """`python bench.py --gpus N` started as a plain process (no WORLD_SIZE): run the same command line under
+    torch.distributed.run, one rank per GPU of this node, and hand its exit code back.  Rank 0 prints the JSON line."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(args_list)
+    env = dict(os.environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
 def cpu_model():
     try:
         with open("/proc/cpuinfo") as fh:
@@ -97,9 +152,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:        # a plain `python bench.py --gpus N`: launch the ranks ourselves
+        sys.exit(self_launch(sys.argv[1:], args.gpus))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit(f"--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...`")
+        sys.exit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start one rank per GPU (`python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...`, "
+                 f"or plain `python bench.py --gpus {args.gpus}`)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # ROMAN_BENCH_FORCE_DIST: run the process-group / all_gather path at world size 1 too (tools/scale_preflight.sh)
@@ -183,22 +240,14 @@ def main():
             ev_free = [torch.cuda.Event() for _ in range(2)]
             up_no = [0]
 
-        call_no = [0]
+        fptr_now = [feats.data_ptr()]
 
-        def one_call(ci, fptr):
-            k = call_no[0] % NSET
-            call_no[0] += 1
+        def launch(ci, k):
             o1, a1, o2, a2 = meta[ci]
-            ctx.align_batch_dev(P, fptr, F, o1, a1, o2, a2, kmax,
+            ctx.align_batch_dev(P, fptr_now[0], F, o1, a1, o2, a2, kmax,
                                 O.assoc[k].data_ptr(), O.n[k].data_ptr(), O.T[k].data_ptr(), O.status[k].data_ptr(), O.stats[k].data_ptr())
-            if dist_on:
-                if args.pipeline >= 2:
-                    if call_no[0] > 1:
-                        ctx.join(skip_latest=True)                 # torch's stream waits for the OLDER calls only
-                        gather((k - 1) % NSET)
-                else:
-                    gather(k)
-            return k
+
+        loop = CallLoop(len(calls), NSET, args.pipeline, launch, lambda skip: ctx.join(skip_latest=skip), gather if dist_on else None)
 
         def step():
             fptr = feats.data_ptr()
@@ -211,18 +260,14 @@ def main():
                     ev_up[j].record(cstream)
                 stream.wait_event(ev_up[j])
                 fptr = dbuf[j].data_ptr()
-            for ci in range(len(calls)):
-                one_call(ci, fptr)
+            fptr_now[0] = fptr
+            loop.step()
             if h2d:
                 ctx.join(skip_latest=False)                        # the calls of this step are ordered on `stream` before the buffer is reused
                 ev_free[up_no[0] % 2].record(stream)
                 up_no[0] += 1
 
-        def drain():                                               # results of the last call
-            if args.pipeline >= 2:
-                ctx.join(skip_latest=False)
-                if dist_on and call_no[0] > 0:
-                    gather((call_no[0] - 1) % NSET)
+        drain = loop.drain
 
         def fence():
             torch.cuda.synchronize(dev)
@@ -234,7 +279,7 @@ def main():
         for _ in range(warmup):
             step()
         drain(); fence()
-        call_no[0] = 0
+        loop.reset()
         skipped0 = ctx.skipped(wait=True)
         if profile:
             ctx.profile_enable(True); ctx.profile_reset()
@@ -345,12 +390,11 @@ def main():
         lat_break = {"host_enqueue_ms": float(np.median(enq) * 1e3),
                      "stage_ms": {k: float(np.median([x[k] for x in stg])) for k in stg[0]},
                      "note": "B=1, stage timers on (they add event records to the call)"}
-    if dist_on:
+    if dist_on:                                                 # the last collective: everything below is rank 0's own (CPU baseline, side legs)
         dist.barrier()
-
+        dist.destroy_process_group()
+        dist_on = False
     if rank != 0:
-        if dist_on:
-            dist.destroy_process_group()
         return
 
     value = total_per_step * args.steps / dt
@@ -454,7 +498,7 @@ def main():
                                            "build_flops": Wb, "build_bytes": Bb, "solver_bytes": alg_bytes,
                                            "note": "SURVEY.md §8(d): t* = W_b / 78.6 TF + (B_b + B_s) / 8 TB/s for one call of the batch; frac = t* / measured ms per step"}
 
-    from_oracle = world == 1 and args.cpu_sample > 0
+    from_oracle = args.cpu_sample > 0                           # rank 0 at every N (the other ranks have left; nothing of it is inside a timed region)
     orc = None
     if from_oracle or (extras and world == 1):
         from oracle import oracle as orc
@@ -523,8 +567,6 @@ def main():
         except Exception as e:                                  # side legs never cost the headline line
             out["side_legs_error"] = repr(e)
     print(json.dumps(out), flush=True)
-    if dist_on:
-        dist.destroy_process_group()
 
 
 def side_legs(out, args, ctx, dev, G, orc, with_cpu):
@@ -546,21 +588,18 @@ def side_legs(out, args, ctx, dev, G, orc, with_cpu):
             best = t if best is None or t < best else best
         return res, best
 
-    # ---- config 4: a fixed random 256 of the 4096 grid pairs (and the 16 with the most passes) against the oracle -------------
+    # ---- config 4: EVERY one of the 4096 grid pairs against the oracle (pair-parallel, ~30 s on the GPU box's host cores) ----------
     if G is not None and with_cpu:
         reg = SubmapAlignParams(method=args.method, semantics_dim=args.d).get_object_registration(); reg.set_context(ctx)
         res = rb.run_batch(reg, G.batch)
-        rng = np.random.default_rng(4096)
-        pick = set(rng.choice(len(G.batch), size=min(256, len(G.batch)), replace=False).tolist())
-        pick |= set(np.argsort(-res.stats["n_pass"])[:16].tolist())
-        pick = np.array(sorted(pick))
+        pick = np.arange(len(G.batch))                           # every pair of the grid (one oracle thread per pair)
         kmax = G.batch.kmax()
         t0 = time.perf_counter()
         many = orc.register_many(reg._abi_params(), G.batch.feats, G.batch.off1[pick], G.batch.n1[pick], G.batch.off2[pick], G.batch.n2[pick], kmax, faithful=False)
         tq = time.perf_counter() - t0
         same = sum(int(np.array_equal(many[k], res.assoc[b])) for k, b in enumerate(pick))
         out["grid_config4"]["oracle_check"] = {"pairs_compared": int(len(pick)), "identical": int(same), "max_passes_in_grid": int(res.stats["n_pass"].max()),
-                                               "includes": "256 random pairs (seed 4096) + the 16 pairs with the most solver passes",
+                                               "includes": "every pair of the 64 x 64 grid",
                                                "oracle_seconds": tq}
 
     # ---- decision sensitivity: the readings of the absent clipperpy formulas and the start vector (H1) -------

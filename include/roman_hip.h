@@ -48,6 +48,8 @@ extern "C" {
 #define ROMAN_E_NOMEM          -4   /* device or host allocation failed                          */
 #define ROMAN_E_UNSUPPORTED    -5   /* parameter combination the reference does not define       */
 #define ROMAN_E_TOO_LARGE      -6   /* problem exceeds the index width of this build             */
+#define ROMAN_E_INTERNAL       -7   /* a problem came back with ROMAN_ST_INTERNAL (host-pointer / stepwise entry points; the
+                                       outputs have been copied: status_out says which problems have no result)           */
 
 /* per-problem status written to status_out[] (bit flags) */
 #define ROMAN_ST_OK                  0

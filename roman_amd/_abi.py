@@ -11,6 +11,7 @@ ROMAN_MAX_RATIO_FEATURES = 8
 
 # error codes / status flags (include/roman_hip.h)
 ROMAN_OK = 0
+ROMAN_E_INTERNAL = -7
 ROMAN_ST_OK = 0
 ROMAN_ST_EMPTY_MAP = 1
 ROMAN_ST_INSUFFICIENT = 2

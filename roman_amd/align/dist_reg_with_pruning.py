@@ -72,7 +72,11 @@ class DistRegWithPruning(ObjectRegistration):
             return super().pack(object_map)
         if self.semantics_dim is None and len(object_map):
             self.semantics_dim = int(np.asarray(object_map[0].semantic_descriptor).size)
-        F = self.dim + 4 + int(self.semantics_dim or 0)
+        if self.semantics_dim is None:
+            # an empty map packed before the descriptor length is known would get rows of another width than the maps that
+            # follow it in the same pool
+            raise ValueError("prune_on_device: pass semantics_dim=... (or pack a non-empty map first) before packing an empty map")
+        F = self.dim + 4 + int(self.semantics_dim)
         if len(object_map) == 0:
             return np.zeros((0, F), dtype=np.float64)
         return np.array([np.concatenate([o.center.reshape(-1)[:self.dim], self._object_shape_attributes(o),

@@ -55,27 +55,20 @@ def take(batch: AlignmentBatch, idx) -> AlignmentBatch:
                           None if batch.pair_index is None else batch.pair_index[idx])
 
 
-_POOL_CACHE = {}          # device -> (host array it was uploaded from, device tensor): a batch's feature pool is uploaded once
-
-
-def _device_pool(feats, dev):
-    """The feature pool of a batch on `dev`: uploaded once per (array, device) — consecutive calls over the same pool
-    (the chunks of one grid, the retry of skipped problems) reuse the resident copy."""
+def upload_pool(batch: AlignmentBatch, dev):
+    """The feature pool of a batch as a device tensor.  A caller that aligns several batches over ONE pool (the chunks of an
+    all-pairs grid) uploads it once and hands it to every align_sharded call (`pool=`); nothing is cached behind the
+    caller's back: a pool refilled in place on the host is uploaded again by the next call that is not given a tensor."""
     import torch
-    key = str(dev)
-    hit = _POOL_CACHE.get(key)
-    if hit is not None and hit[0] is feats:
-        return hit[1]
-    t = torch.from_numpy(feats).to(dev)
-    _POOL_CACHE[key] = (feats, t)
-    return t
+    return torch.from_numpy(np.ascontiguousarray(batch.feats, dtype=np.float64)).to(dev)
 
 
-def _device_records(registration, sub: AlignmentBatch, kmax, per, dev):
+def _device_records(registration, sub: AlignmentBatch, kmax, per, dev, pool=None):
     """Align `sub` with device-resident inputs and outputs; -> (ints (per, 2+2*kmax) int32, poses (per,16) f64) torch
     tensors on `dev`, rows beyond len(sub) padded with -1 / NaN.  Problems the speculatively sized workspace skipped
     (ROMAN_ST_WORKSPACE) are issued again — those problems only — and an error is raised if any is still skipped after
-    four attempts (the host-pointer entry returns ROMAN_E_NOMEM in the same situation)."""
+    four attempts; what is still skipped then keeps the flag in its record (align_sharded raises).  The feature pool is
+    uploaded once per call (or taken from `pool`) and shared by the retries."""
     import torch
     from .. import _abi
     ctx = registration._context()
@@ -86,7 +79,9 @@ def _device_records(registration, sub: AlignmentBatch, kmax, per, dev):
         return ints, poses
     P = registration._abi_params()
     F = sub.feats.shape[1]
-    feats = _device_pool(sub.feats, dev)
+    if pool is not None and (tuple(pool.shape) != tuple(sub.feats.shape) or str(pool.dtype) != "torch.float64" or pool.device != dev):
+        raise ValueError(f"pool must be the batch's feature matrix {sub.feats.shape} as a float64 tensor on {dev}")
+    feats = pool if pool is not None else upload_pool(sub, dev)
     a_out = torch.full((B, kmax, 2), -1, dtype=torch.int32, device=dev)
     n_out = torch.zeros(B, dtype=torch.int32, device=dev)
     T_out = torch.zeros((B, 16), dtype=torch.float64, device=dev)
@@ -114,8 +109,9 @@ def _device_records(registration, sub: AlignmentBatch, kmax, per, dev):
         if not skipped.any():
             break
         todo = todo[skipped]
-    else:
-        raise _abi.RomanHipError(f"{len(todo)} problem(s) still without workspace after 4 attempts")
+    # (problems still skipped after four attempts keep ROMAN_ST_WORKSPACE in their record, problems the library gave up on
+    #  ROMAN_ST_INTERNAL: align_sharded raises for both AFTER the gather, on every rank alike — an exception on one rank in
+    #  front of a collective would leave the others waiting in it)
     ints[:B, 0] = n_out; ints[:B, 1] = st_out
     valid = torch.arange(kmax, device=dev)[None, :] < n_out[:, None]
     ints[:B, 2:] = torch.where(valid[:, :, None], a_out, torch.full_like(a_out, -1)).reshape(B, -1)
@@ -123,12 +119,13 @@ def _device_records(registration, sub: AlignmentBatch, kmax, per, dev):
     return ints, poses
 
 
-def align_sharded(registration, batch: AlignmentBatch, group=None, compute=None, device=None):
+def align_sharded(registration, batch: AlignmentBatch, group=None, compute=None, device=None, pool=None):
     """Align `batch` across the ranks of `group` (default: WORLD); every rank returns the full result
     (assoc list, T, status) in problem order.
 
     compute(registration, sub_batch) -> runtime.BatchResult: a CPU double for tests; by default the HIP path runs with
-    device-resident records (`device`: torch device of this rank, default cuda:<current device>).
+    device-resident records (`device`: torch device of this rank, default cuda:<current device>; `pool`: the batch's
+    feature matrix already resident there, see upload_pool()).
     """
     import torch
     import torch.distributed as dist
@@ -145,7 +142,7 @@ def align_sharded(registration, batch: AlignmentBatch, group=None, compute=None,
     on_device = compute is None
     if on_device:
         dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
-        ti, tp = _device_records(registration, sub, kmax, per, dev)
+        ti, tp = _device_records(registration, sub, kmax, per, dev, pool=pool)
     else:
         res = compute(registration, sub)
         ints, poses = pack_records(res, kmax)
@@ -165,4 +162,19 @@ def align_sharded(registration, batch: AlignmentBatch, group=None, compute=None,
     out_i = np.full((B, gi.shape[2]), -1, dtype=np.int32); out_p = np.full((B, 16), np.nan)
     for r in range(world):
         out_i[shards[r]] = gi[r, :len(shards[r])]; out_p[shards[r]] = gp[r, :len(shards[r])]
-    return unpack_records(out_i, out_p, registration.dim)
+    assoc, T, status = unpack_records(out_i, out_p, registration.dim)
+    check_records(status)
+    return assoc, T, status
+
+
+def check_records(status):
+    """Raise for results that are NOT results: a problem the library gave up on (ROMAN_ST_INTERNAL: a bounded wait at a grid
+    barrier of the whole-device solver expired — the record holds no associations and a NaN pose) or one that found no
+    workspace after the retries (ROMAN_ST_WORKSPACE).  Called on the GATHERED records, i.e. on every rank alike."""
+    from .. import _abi
+    status = np.asarray(status)
+    bad = np.nonzero((status & (_abi.ROMAN_ST_INTERNAL | _abi.ROMAN_ST_WORKSPACE)) != 0)[0]
+    if len(bad):
+        n_int = int(np.count_nonzero(status[bad] & _abi.ROMAN_ST_INTERNAL))
+        raise _abi.RomanHipError(f"{len(bad)} problem(s) without a result ({n_int} ROMAN_ST_INTERNAL, {len(bad) - n_int} ROMAN_ST_WORKSPACE "
+                                 f"after 4 attempts): problems {bad[:8].tolist()}")

@@ -1984,6 +1984,21 @@ __global__ void __launch_bounds__(256) k_dense_mask(int n, const double* __restr
     }
 }
 
+// flags[1] |= 1 when a weight of the strict upper triangle lies outside [0, 1] or is not finite: such a matrix must not take
+// the stream solver, whose fixed-point sums assume 0 <= v <= 1 (host: roman_set_matrix_data).
+__global__ void __launch_bounds__(256) k_dense_range(int n, const double* __restrict__ M, int* __restrict__ flags)
+{
+    const int lane = threadIdx.x & 63;
+    const int nwaves = (int)(gridDim.x * (blockDim.x >> 6));
+    bool bad = false;
+    for (int k = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)); k < n; k += nwaves)
+        for (int q = k + 1 + lane; q < n; q += 64) {
+            const double v = M[(int64_t)k * n + q];
+            bad = bad || !(v >= 0.0 && v <= 1.0);               // (a NaN fails both comparisons)
+        }
+    if (__ballot(bad) != 0ull && lane == 0) atomicOr(flags + 1, 1);
+}
+
 // One thread per slot of the problem's matrix segment (slot t of the COLUMN array; the value sits at val_pos of the same
 // (slice, lane slot, entry)).  KIND 0: stream layout — entry e of position row p is element e of its candidate list;
 // padding points at the dummy element n + lane slot.  KIND 1: symmetric sorted SELL-64 in quads — entry e of row k is the
@@ -3175,15 +3190,15 @@ __device__ __forceinline__ void st_pub(double* p, double v)
 // [19] flat counter of the census barrier.  RELEASE: plain stores issued before the barrier must be visible behind it as well.
 // Every spin is bounded (4 s): on a timeout the abort flag goes up and every workgroup leaves.
 constexpr int WIDE_BAR_WORDS = 20 * 32;
-struct WideBar { unsigned* bar; unsigned epoch; int G; int xcc; unsigned nX; unsigned nActive; };
+struct WideBar { unsigned* bar; unsigned epoch; int G; int xcc; unsigned nX; unsigned nActive; unsigned long long budget /* wall-clock ticks a spin may last */; };
 
-__device__ __forceinline__ bool wide_spin(const unsigned* word, unsigned target, unsigned* bar)
+__device__ __forceinline__ bool wide_spin(const unsigned* word, unsigned target, unsigned* bar, unsigned long long budget)
 {
     const unsigned long long t0 = wall_clock64();
     unsigned n = 0;
     while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
         __builtin_amdgcn_s_sleep(1);
-        if ((++n & 255u) == 0u && (wall_clock64() - t0 > 400000000ull || __hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+        if ((++n & 255u) == 0u && (wall_clock64() - t0 > budget || __hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
             __hip_atomic_store(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return false;
         }
@@ -3204,10 +3219,12 @@ __device__ __forceinline__ bool wide_sync(WideShared& sh, WideBar& wb, int ltid)
         const unsigned old = __hip_atomic_fetch_add(bar + 32 * (1 + wb.xcc), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (old + 1u == wb.epoch * wb.nX) {                     // the last workgroup of this XCD: on to the top level
             __hip_atomic_fetch_add(bar + 32 * 9, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            ok = wide_spin(bar + 32 * 9, wb.epoch * wb.nActive, bar);
-            __hip_atomic_store(bar + 32 * (10 + wb.xcc), wb.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ok = wide_spin(bar + 32 * 9, wb.epoch * wb.nActive, bar, wb.budget);
+            // (a leader that gave up does NOT release its XCD: the abort flag is up, its peers see it within 256 polls and
+            //  leave from this barrier instead of walking into the next one)
+            if (ok) __hip_atomic_store(bar + 32 * (10 + wb.xcc), wb.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
-            ok = wide_spin(bar + 32 * (10 + wb.xcc), wb.epoch, bar);
+            ok = wide_spin(bar + 32 * (10 + wb.xcc), wb.epoch, bar, wb.budget);
         }
         if (!ok) sh.abort_ = 1;
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // this compute unit's L1 holds nothing older than the barrier
@@ -3227,7 +3244,7 @@ __device__ __forceinline__ bool wide_census(WideShared& sh, WideBar& wb, int lti
         __hip_atomic_fetch_add(bar + 32 * 18 + wb.xcc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __hip_atomic_fetch_add(bar + 32 * 19, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const bool ok = wide_spin(bar + 32 * 19, (unsigned)wb.G, bar);
+        const bool ok = wide_spin(bar + 32 * 19, (unsigned)wb.G, bar, wb.budget);
         unsigned act = 0;
         for (int t = 0; t < 8; ++t) {
             const unsigned c_ = __hip_atomic_load(bar + 32 * 18 + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -3309,7 +3326,8 @@ __global__ void __launch_bounds__(WIDE_NT) k_solve_wide(DevParams D, int B, cons
                                                         unsigned long long* __restrict__ bmPool /* [2][bmWords]: support bit maps of the two published vectors */,
                                                         int bmWords /* 64-bit words of one bit map (and of its LDS copy) */,
                                                         int xcap /* doubles of dynamic LDS behind the bit map: the gathered vector's leading part */,
-                                                        int tune /* experiments: bit 0 never gather from LDS, bit 1 non-temporal matrix loads, bits 8.. chunks per wave */)
+                                                        int tune /* experiments: bit 0 never gather from LDS, bit 1 non-temporal matrix loads, bits 8.. chunks per wave */,
+                                                        unsigned long long spinTicks /* wall-clock ticks a barrier wait may last (host: 4 s at the device's wall-clock rate) */)
 {
     __shared__ WideShared sh;
     extern __shared__ __attribute__((aligned(16))) unsigned char wide_smem[];
@@ -3321,8 +3339,23 @@ __global__ void __launch_bounds__(WIDE_NT) k_solve_wide(DevParams D, int B, cons
     const int gw = w * G + (int)blockIdx.x;                     // wave id in the grid: consecutive ids on different compute units
     if (ltid == 0) sh.abort_ = 0;
     __syncthreads();
-    WideBar wb{bar, 0u, G, 0, 1u, 1u};
-    if (!wide_census(sh, wb, ltid)) return;
+    WideBar wb{bar, 0u, G, 0, 1u, 1u, spinTicks};
+    // A bounded wait expired somewhere in the grid (never expected): every problem this launch has not finished — the one
+    // being solved and every later one of the fallback kind — gets a record that says so (ROMAN_ST_INTERNAL, no
+    // associations, NaN pose) instead of whatever the caller's buffers held.  Written by workgroup 0, which leaves through
+    // the same exits as everyone else (the abort flag is polled in every spin).
+    auto give_up = [&](int b0) {
+        if (blockIdx.x != 0) return;
+        for (int bb = b0 + (ltid >> 6); bb < B; bb += WIDE_NW) {
+            if (st[bb].kind != 1) continue;
+            if (lane < 16) O.T_out[(int64_t)bb * 16 + lane] = d_nan();
+            if (lane == 0) {
+                O.n_assoc_out[bb] = 0; O.status_out[bb] = ROMAN_ST_INTERNAL; O.nSel[bb] = 0;
+                if (O.stats_out) { roman_stats_t S0{}; S0.n_assoc_in = probs[bb].nA; S0.n_live = st[bb].L; O.stats_out[bb] = S0; }
+            }
+        }
+    };
+    if (!wide_census(sh, wb, ltid)) { give_up(0); return; }
     for (int b = 0; b < B; ++b) {
         if (uni_i(st[b].kind) != 1) continue;                   // (uniform over the grid)
         const ProbDesc pd = probs[b];
@@ -3626,13 +3659,7 @@ __global__ void __launch_bounds__(WIDE_NT) k_solve_wide(DevParams D, int B, cons
                 }
             }
         }
-        if (!alive) {                                            // a grid barrier timed out: give up, say so
-            if (blockIdx.x == 0 && ltid == 0) {
-                for (int t = 0; t < 16; ++t) O.T_out[(int64_t)b * 16 + t] = d_nan();
-                O.n_assoc_out[b] = 0; O.status_out[b] = ROMAN_ST_INTERNAL; O.nSel[b] = 0;
-            }
-            return;
-        }
+        if (!alive) { give_up(b); return; }                      // a grid barrier timed out: give up, say so — for this and every later problem
         if (i >= P.maxoliters) status |= ROMAN_ST_MAXITER;
         S.n_pass = n_pass; S.ls_trials = ls_trials; S.inner_iters = inner_iters;
         S.outer_iters = i; S.score = F; S.d_final = d;
@@ -3646,7 +3673,7 @@ __global__ void __launch_bounds__(WIDE_NT) k_solve_wide(DevParams D, int B, cons
 #undef WMARK
         // final u by position for the shared tail (plain stores + one release); workgroup 0 selects and writes the pose
         FORK(k) if (in[k]) vU[rb + ((gw + k * NWG) << 6) + lane] = u[k];
-        if (!wide_sync<true>(sh, wb, ltid)) return;
+        if (!wide_sync<true>(sh, wb, ltid)) { give_up(b); return; }
         if (blockIdx.x == 0)
             finish_one(D, b, pd, feats, assoc, plp, lp, rowPosPool, permPool, O, L > 0 ? vU + rb : nullptr, vS0 + rb,
                        reinterpret_cast<int32_t*>(vS1 + rb), reinterpret_cast<int32_t*>(vS2 + rb), L, rb, lo, F, status, S, sh.red, sh.sint);

@@ -54,6 +54,7 @@ struct roman_ctx {
     int num_cu = 256;
     size_t lds_max = 65536;
     bool coop_ok = false;                      // hipLaunchCooperativeKernel available (large-problem solver)
+    unsigned long long spin_ticks = 400000000ull;  // bounded waits of the whole-device solver: 4 s in ticks of the device's wall clock
     hipEvent_t coopDone = nullptr;             // behind the most recent cooperative launch of this context
     bool coopIssued = false;
     std::string err;
@@ -726,8 +727,9 @@ int enqueue_solve(roman_ctx* c, const DevParams& D, int B, int64_t sumA, int64_t
             HIPCHK(c, dyn_lds(c, wideFn, wideLds));
             static const char* tuneEnv = getenv("ROMAN_WIDE_TUNE");
             int a_tune = tuneEnv ? (int)strtol(tuneEnv, nullptr, 0) : 0;
+            unsigned long long a_ticks = c->spin_ticks;        // 4 s of the device's wall clock (test hook ROMAN_WIDE_SPIN_MS: shorter)
             void* args[] = {&Dv, &Bv, &a_probs, &a_state, &a_feats, &a_assoc, &a_lp, &a_ld, &a_perm, &a_rpos, &a_sb, &a_cols, &a_vals,
-                            &a_vU, &a_vX, &a_vX2, &a_s0, &a_s1, &a_s2, &a_plp, &a_u0, &a_O, &a_part, &a_slots, &a_bar, &a_bm, &a_bmw, &a_xcap, &a_tune};
+                            &a_vU, &a_vX, &a_vX2, &a_s0, &a_s1, &a_s2, &a_plp, &a_u0, &a_O, &a_part, &a_slots, &a_bar, &a_bm, &a_bmw, &a_xcap, &a_tune, &a_ticks};
             // Two whole-device kernels must never be resident together (each would hold compute units while waiting at a
             // grid barrier for workgroups the other one keeps out): with batches in flight on several streams, a
             // launch waits for the previous one of this context.
@@ -857,6 +859,7 @@ int solve_last(roman_ctx* c, const double* u0_host)
     HIPCHK(c, hipMemcpyAsync(&Lst.stats, WS.oStats.p, sizeof(roman_stats_t), hipMemcpyDeviceToHost, WS.stream));
     HIPCHK(c, hipMemcpyAsync(&Lst.status, WS.oStatus.p, sizeof(int32_t), hipMemcpyDeviceToHost, WS.stream));
     HIPCHK(c, hipStreamSynchronize(WS.stream));
+    if (Lst.status & ROMAN_ST_INTERNAL) return fail(c, ROMAN_E_INTERNAL, "the solve reported ROMAN_ST_INTERNAL: a bounded wait of the whole-device solver expired");
     Lst.nsel = nsel;
     Lst.nodes.assign((size_t)std::max(nsel, 0), 0);
     const int L = Lst.L;
@@ -991,6 +994,25 @@ int roman_ctx_create(roman_ctx_t** out, int device, void* stream)
     c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     c->lds_max = prop.sharedMemPerBlock >= 163840 ? (size_t)(160 * 1024 - 256) : (size_t)prop.sharedMemPerBlock;
     { int coopAttr = 0; c->coop_ok = hipDeviceGetAttribute(&coopAttr, hipDeviceAttributeCooperativeLaunch, device) == hipSuccess && coopAttr != 0; (void)hipGetLastError(); }
+    if (c->coop_ok) {
+        // The whole-device solver is chosen when a batch is SCORED (16-bit labels are written for it): make sure here, once,
+        // that one 512-thread workgroup with its largest dynamic LDS fits a compute unit for both instantiations — a
+        // cooperative launch of num_cu workgroups then cannot fail for lack of residency after the fill has already run.
+        const size_t wideLdsMax = c->lds_max > 4096 ? c->lds_max - 4096 : 0;
+        const void* fns[2] = {reinterpret_cast<const void*>(k_solve_wide<uint16_t>), reinterpret_cast<const void*>(k_solve_wide<uint32_t>)};
+        for (const void* fn : fns) {
+            int nb = 0;
+            if (dyn_lds(c, fn, wideLdsMax) != hipSuccess ||
+                hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, WIDE_NT, wideLdsMax) != hipSuccess || nb < 1) { (void)hipGetLastError(); c->coop_ok = false; }
+        }
+    }
+    {   // wall_clock64() ticks at the rate the runtime reports (kHz; 100 MHz on this part)
+        int khz = 0;
+        if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) != hipSuccess || khz <= 0) { (void)hipGetLastError(); khz = 100000; }
+        double ms = 4000.0;
+        if (const char* e = getenv("ROMAN_WIDE_SPIN_MS")) { const double v = atof(e); if (v > 0.0) ms = v; }
+        c->spin_ticks = (unsigned long long)((double)khz * ms);
+    }
     if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
     else {
         if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return fail(nullptr, ROMAN_E_HIP, "hipStreamCreate failed"); }
@@ -1238,6 +1260,11 @@ int roman_align_batch(roman_ctx_t* c, const roman_params_t* params, int32_t B,
     if (stats_out) HIPCHK(c, hipMemcpyAsync(stats_out, WS.oStats.p, sizeof(roman_stats_t) * (size_t)B, hipMemcpyDeviceToHost, WS.stream));
     HIPCHK(c, hipStreamSynchronize(WS.stream));
     c->last.scored = false; c->last.solved = false;
+    {   // a problem the whole-device solver gave up on has no result: an error, not a quiet "0 associations"
+        int nint = 0, first = -1;
+        for (int b = 0; b < B; ++b) if (status_out[b] & ROMAN_ST_INTERNAL) { if (first < 0) first = b; ++nint; }
+        if (nint) return fail(c, ROMAN_E_INTERNAL, "%d problem(s) reported ROMAN_ST_INTERNAL (first: %d): a bounded wait of the whole-device solver expired", nint, first);
+    }
     return ROMAN_OK;
 }
 
@@ -1306,14 +1333,33 @@ int roman_set_matrix_data(roman_ctx_t* c, const roman_params_t* params, const do
     roman_params_t p = *params; p.invariant = ROMAN_INV_EUCLIDEAN;          // implicit identity diagonal
     int rc = make_dev_params(c, &p, p.point_dim, &Lst.D);
     if (rc) return rc;
-    const bool up = n <= STREAM_MAXL && Lst.D.p.maxiniters >= 1 && Lst.D.p.maxlsiters >= 1;
-    Lst.D.wide = (!up && c->coop_ok && Lst.D.p.maxiniters >= 1 && Lst.D.p.maxlsiters >= 1 && n <= (int64_t)WIDE_KW * c->num_cu * WIDE_NW * 64) ? 1 : 0;
+    // The weights decide the solver.  The stream solver adds FIXED-POINT terms rint(v x 2^s) (kernels.hip.h, "Exact
+    // accumulation"): a term stays below 2^50 and a row's sum below 2^62 only for 0 <= v <= 1 (what every scored matrix
+    // holds by construction), and its accumulators are decoded as unsigned.  A caller's dense M may hold anything: the
+    // strict upper triangle is scanned on the device first, and a matrix with a weight outside [0, 1] (or not finite) takes
+    // the plain-double solvers of the fallback layout instead.
+    const size_t n1_ = (size_t)std::max(n, 1);
+    HIPCHK(c, WS.hAux1.ensure(sizeof(double) * n1_ * n1_)); HIPCHK(c, WS.hAux2.ensure(sizeof(double) * n1_ * n1_)); HIPCHK(c, WS.hAux3.ensure(sizeof(int) * 4));
+    HIPCHK(c, hipMemsetAsync(WS.hAux3.p, 0, sizeof(int) * 4, WS.stream));
+    int rangeFlag = 0;
+    if (n > 0) {
+        HIPCHK(c, hipMemcpyAsync(WS.hAux1.p, M, sizeof(double) * n1_ * n1_, hipMemcpyHostToDevice, WS.stream));
+        HIPCHK(c, hipMemcpyAsync(WS.hAux2.p, Cm, sizeof(double) * n1_ * n1_, hipMemcpyHostToDevice, WS.stream));
+        hipLaunchKernelGGL(k_dense_range, dim3((unsigned)std::min(c->num_cu * 8, (n + 3) / 4)), dim3(256), 0, WS.stream, n, WS.hAux1.as<double>(), WS.hAux3.as<int>());
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(&rangeFlag, WS.hAux3.as<int>() + 1, sizeof(int), hipMemcpyDeviceToHost, WS.stream));
+        HIPCHK(c, hipStreamSynchronize(WS.stream));
+    }
+    const bool iter = Lst.D.p.maxiniters >= 1 && Lst.D.p.maxlsiters >= 1;
+    const bool up = n <= STREAM_MAXL && iter && rangeFlag == 0;
+    // few large problems: the whole-device solver; a problem the range check keeps off the stream solver is small enough for
+    // one workgroup (k_solve: u and u' in LDS)
+    Lst.D.wide = (!up && n > STREAM_MAXL && c->coop_ok && iter && n <= (int64_t)WIDE_KW * c->num_cu * WIDE_NW * 64) ? 1 : 0;
     Lst.D.idx16 = 0;                                           // dense problems may carry C flags: 32-bit labels
     Lst.D.stream_maxL = up ? std::max(64, (n + 63) & ~63) : 64;
     // The conversion runs on the device (kernels.hip.h, "Dense problems"): upload M and C, candidate bit matrix, then the
     // scored path's own layout kernels.  Two small read-backs size the matrix pools (the slot total is known only after the
     // sort) and fetch the C-flag / capacity status.
-    const size_t n1_ = (size_t)std::max(n, 1);
     const int W = (n + 63) / 64;
     const int RPB = 128;
     const size_t maskWords = std::max<size_t>((size_t)n * (size_t)W, 1);
@@ -1329,21 +1375,17 @@ int roman_set_matrix_data(roman_ctx_t* c, const roman_params_t* params, const do
     HIPCHK(c, WS.maskPool.ensure(sizeof(unsigned long long) * maskWords)); HIPCHK(c, WS.prefPool.ensure(sizeof(uint32_t) * maskWords));
     HIPCHK(c, WS.listPool.ensure(sizeof(uint16_t) * (size_t)capList));
     HIPCHK(c, WS.items.ensure(sizeof(ItemDesc) * ((size_t)n / RPB + 2)));
-    HIPCHK(c, WS.hAux1.ensure(sizeof(double) * n1_ * n1_)); HIPCHK(c, WS.hAux2.ensure(sizeof(double) * n1_ * n1_)); HIPCHK(c, WS.hAux3.ensure(sizeof(int) * 4));
     WS.capMaskWords = std::max<long long>(WS.capMaskWords, (long long)maskWords); WS.capList = std::max<long long>(WS.capList, capList);
     ProbDesc pd{}; pd.off1 = 0; pd.off2 = 0; pd.assocOff = -1; pd.liveOff = 0; pd.n1 = n; pd.n2 = 1; pd.nA = n;
     ProbState ps{}; ps.L = n; ps.kind = up ? 0 : 1;
     HIPCHK(c, hipMemcpyAsync(WS.probs.p, &pd, sizeof(pd), hipMemcpyHostToDevice, WS.stream));
     HIPCHK(c, hipMemcpyAsync(WS.state.p, &ps, sizeof(ps), hipMemcpyHostToDevice, WS.stream));
-    HIPCHK(c, hipMemsetAsync(WS.hAux3.p, 0, sizeof(int) * 4, WS.stream));
     HIPCHK(c, hipStreamSynchronize(WS.stream));                  // (pd, ps live on this frame)
     const ProbDesc* dP = WS.probs.as<ProbDesc>(); ProbState* dS = WS.state.as<ProbState>(); BatchTotals* dT = WS.totals.as<BatchTotals>();
     const double* dM = WS.hAux1.as<double>(); const double* dC = WS.hAux2.as<double>();
     if (n > 0) {
         std::vector<int32_t> ident(n1_); std::vector<double> ones(n1_, 1.0);
         for (int k = 0; k < n; ++k) ident[(size_t)k] = k;
-        HIPCHK(c, hipMemcpy(WS.hAux1.p, M, sizeof(double) * n1_ * n1_, hipMemcpyHostToDevice));
-        HIPCHK(c, hipMemcpy(WS.hAux2.p, Cm, sizeof(double) * n1_ * n1_, hipMemcpyHostToDevice));
         HIPCHK(c, hipMemcpy(WS.lp.p, ident.data(), sizeof(int32_t) * n1_, hipMemcpyHostToDevice));
         HIPCHK(c, hipMemcpy(WS.plp.p, ident.data(), sizeof(int32_t) * n1_, hipMemcpyHostToDevice));      // (stream layout: k_upper overwrites it with the permutation)
         HIPCHK(c, hipMemcpy(WS.ls.p, ones.data(), sizeof(double) * n1_, hipMemcpyHostToDevice));

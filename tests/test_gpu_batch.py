@@ -176,6 +176,85 @@ def test_dense_conversion_on_the_device(ctx, orc, n, density, iters):
     assert st.nnz_upper == int(np.count_nonzero(np.triu((M != 0) | (C != 0), 1)))
 
 
+def _same_selection_as_oracle(nodes, ref):
+    assert sorted(nodes.tolist()) == sorted(ref["nodes"].tolist())
+    uo = ref["u"][ref["nodes"]]
+    for r in np.nonzero(nodes != ref["nodes"])[0]:              # order swaps only between entries equal to within the iteration's tolerance
+        assert abs(uo[r] - uo[min(r + 1, len(uo) - 1)]) < 1e-6 or abs(uo[r] - uo[max(r - 1, 0)]) < 1e-6
+
+
+@pytest.mark.parametrize("n,kind", [(40, "large"), (300, "large"), (300, "negative"), (64, "tiny+huge"), (129, "nan_free_inf")],
+                         ids=["n40_w50", "n300_w50", "n300_negative", "n64_1e-9_to_1e6", "n129_w_inf_free"])
+def test_dense_weights_outside_the_unit_interval_take_the_plain_double_solver(ctx, orc, n, kind):
+    """roman_set_matrix_data accepts ANY caller matrix (the mno_clipper loop, [REF roman/align/object_registration.py:57-86],
+    only ever passes scores in [0, 1], a C caller may not).  The stream solver's fixed-point sums assume 0 <= v <= 1: a
+    matrix with a weight outside (weights up to 50, negative weights, a 1e15 dynamic range) is detected on the device and
+    solved by the plain-double solver of the fallback layout — u within 1e-9 of the oracle's, the same selected set."""
+    M, C = _random_dense_problem(n, 0.3 if n < 100 else 0.06, 4000 + n)
+    rng = np.random.default_rng(n)
+    iu = np.triu_indices(n, 1)
+    w = M[iu]
+    if kind == "large":
+        w = w * rng.uniform(1.0, 50.0, w.shape)
+    elif kind == "negative":
+        w = np.where(rng.random(w.shape) < 0.3, -w, w) * rng.uniform(0.5, 3.0, w.shape)
+    elif kind == "tiny+huge":
+        w = np.where(w != 0, 10.0 ** rng.uniform(-9, 6, w.shape), 0.0)
+    else:
+        w = w * 7.5
+    M = np.zeros((n, n)); M[iu] = w; M = M + M.T; np.fill_diagonal(M, 1.0)
+    P = _abi.RomanParams.default(); P.invariant = _abi.ROMAN_INV_EUCLIDEAN
+    ctx.set_matrix_data(P, M, C)
+    Mg, Cg = ctx.dense_matrices()
+    assert np.array_equal(Mg, M) and np.array_equal(Cg, C)
+    ctx.solve(None)
+    nodes, u, score, st = ctx.solution()
+    ref = orc.solve(P, orc.matrix_from_dense(M, C))
+    assert np.all(np.isfinite(u)) and np.allclose(u, ref["u"], rtol=0, atol=1e-9)
+    assert abs(score - ref["stats"].score) <= 1e-9 * max(1.0, abs(ref["stats"].score))
+    _same_selection_as_oracle(nodes, ref)
+    # the same matrix scaled into [0, 1] takes the stream layout again (and is still the oracle's)
+    Ms = M / np.abs(M[iu]).max() if kind != "negative" else np.abs(M) / np.abs(M[iu]).max()
+    np.fill_diagonal(Ms, 1.0)
+    ctx.set_matrix_data(P, Ms, C); ctx.solve(None)
+    nodes2, u2, _, _ = ctx.solution()
+    ref2 = orc.solve(P, orc.matrix_from_dense(Ms, C))
+    assert np.allclose(u2, ref2["u"], rtol=0, atol=1e-9)
+    _same_selection_as_oracle(nodes2, ref2)
+
+
+@pytest.mark.parametrize("u0_kind", ["ones", "1e-12..1", "one_dominant", "1e-12..1+c_flags"])
+def test_fixed_point_sums_at_the_stream_solvers_limit(ctx, orc, u0_kind):
+    """Worst case of the stream solver's exact sums (kernels.hip.h "Exact accumulation"): the largest live set it takes
+    (L = STREAM_MAXL = 3072), EVERY pair stored with the largest weight the path admits (v = 1), start vectors whose elements
+    span twelve decades.  A term is rint(v x 2^s) < 2^49, a row's sum of 3071 of them < 2^61: no accumulator overflows; u
+    within 1e-9 of the oracle's plain-double sums, the same selected set."""
+    n = 3072
+    M = np.ones((n, n)); C = np.ones((n, n))
+    rng = np.random.default_rng(5)
+    if u0_kind.endswith("c_flags"):
+        # 0.5 % of the pairs inconsistent (C = 0 with a stored weight: the flagged-entry path): the iteration now runs ~2000
+        # passes over the whole matrix (21 homotopy steps, a clique of ~700) instead of stopping after three
+        Cu = np.triu((rng.random((n, n)) >= 0.005).astype(float), 1); C = Cu + Cu.T; np.fill_diagonal(C, 1.0)
+    if u0_kind == "ones":
+        u0 = None
+    elif u0_kind.startswith("1e-12..1"):
+        u0 = 10.0 ** rng.uniform(-12, 0, n); u0[7] = 1.0; u0[11] = 1e-12
+    else:
+        u0 = np.full(n, 1e-12); u0[1234] = 1.0
+    P = _abi.RomanParams.default(); P.invariant = _abi.ROMAN_INV_EUCLIDEAN
+    ctx.set_matrix_data(P, M, C)
+    ctx.solve(u0)
+    nodes, u, score, st = ctx.solution()
+    assert st.n_live == n and st.nnz_upper == n * (n - 1) // 2
+    ref = orc.solve(P, orc.matrix_from_dense(M, C), u0)
+    assert np.all(np.isfinite(u)) and np.allclose(u, ref["u"], rtol=0, atol=1e-9)
+    assert abs(score - ref["stats"].score) < 1e-6 and len(nodes) == len(ref["nodes"])
+    assert sorted(nodes.tolist()) == sorted(ref["nodes"].tolist())
+    if u0_kind.endswith("c_flags"):
+        assert st.outer_iters == ref["stats"].outer_iters and abs(st.n_pass - ref["stats"].n_pass) <= 8 and st.n_pass > 1000
+
+
 def test_mno_clipper_leaves_the_registration_untouched(ctx, orc):
     """mno_clipper() solves on a separate plain-CLIPPER problem ([REF roman/align/object_registration.py:60]); the
     registration's own invariant parameters must not change: register() before == register() after."""
@@ -513,3 +592,56 @@ def test_prefilter_on_the_device_equals_the_host_prefilter(ctx, orc):
     want = host.register_and_align_batch([(p.map1, p.map2) for p in prs]); got = dev.register_and_align_batch([(p.map1, p.map2) for p in prs])
     for b in range(5):
         assert np.array_equal(got.assoc[b], want.assoc[b]), b
+
+
+def test_whole_device_solver_that_gives_up_says_so_for_every_problem(orc):
+    """A bounded wait of the whole-device solver that expires (never expected; provoked here with a 1 us budget through the
+    test hook ROMAN_WIDE_SPIN_MS) must not leave stale output records behind: EVERY fallback problem of the batch — the one
+    being solved and all later ones — reports ROMAN_ST_INTERNAL with no associations and a NaN pose, the host-pointer entry
+    returns ROMAN_E_INTERNAL, and the same context solves the same batch correctly afterwards with the normal budget."""
+    import os
+    from roman_amd import RomanHipError
+    from roman_amd.runtime import Context
+    reg = registration_for("gravity")
+    pairs = [synth.make_pair(70, 70, 0, 950 + k, tilt_deg=1.0) for k in range(3)]          # L = 4900 each: the fallback layout
+    batch = rb.batch_from_pairs(reg, [(p.map1, p.map2) for p in pairs])
+    os.environ["ROMAN_WIDE_SPIN_MS"] = "0.001"
+    try:
+        c1 = Context(0)
+    finally:
+        del os.environ["ROMAN_WIDE_SPIN_MS"]
+    try:
+        reg.set_context(c1)
+        import torch
+        dev = torch.device("cuda", 0)
+        B, kmax = len(batch), batch.kmax()
+        feats = torch.from_numpy(batch.feats).to(dev)
+        a_out = torch.full((B, kmax, 2), 77, dtype=torch.int32, device=dev); n_out = torch.full((B,), 55, dtype=torch.int32, device=dev)
+        T_out = torch.full((B, 16), 3.25, dtype=torch.float64, device=dev); st_out = torch.full((B,), 0, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        P = reg._abi_params()
+        for attempt in range(2):                                  # (the first call may only record the sizes: ROMAN_ST_WORKSPACE)
+            c1.align_batch_dev(P, feats.data_ptr(), batch.feats.shape[1], batch.off1, batch.n1, batch.off2, batch.n2, kmax,
+                               a_out.data_ptr(), n_out.data_ptr(), T_out.data_ptr(), st_out.data_ptr(), None)
+            c1.sync()
+            if not (st_out.cpu().numpy() & _abi.ROMAN_ST_WORKSPACE).any():
+                break
+        st = st_out.cpu().numpy()
+        assert (st == _abi.ROMAN_ST_INTERNAL).all(), st
+        assert (n_out.cpu().numpy() == 0).all() and np.isnan(T_out.cpu().numpy()).all()
+        with pytest.raises(RomanHipError, match="ROMAN_ST_INTERNAL"):
+            rb.run_batch(reg, batch, ctx=c1)
+        from roman_amd.align.distributed import check_records
+        with pytest.raises(RomanHipError, match="ROMAN_ST_INTERNAL"):
+            check_records(st)
+    finally:
+        c1.close()
+    c2 = Context(0)
+    try:
+        reg.set_context(c2)
+        res = rb.run_batch(reg, batch, ctx=c2)
+        for b, p in enumerate(pairs):
+            o = orc.register(reg._abi_params(), reg.pack(p.map1), reg.pack(p.map2))
+            assert res.status[b] == 0 and np.array_equal(res.assoc[b], o["assoc"])
+    finally:
+        c2.close()

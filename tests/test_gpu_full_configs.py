@@ -76,6 +76,34 @@ def test_config4_grid_16x16_every_pair_matches_the_oracle(ctx, orc):
     assert ok >= 0.9 * len(batch)                                            # overlapping submaps do align
 
 
+def test_config4_full_64x64_grid_all_4096_pairs_match_the_oracle(ctx, orc):
+    """BASELINE config 4 in full: the 64 x 64 = 4096 cross pairs of 128 submaps (n = 200, d = 512) that bench.py's
+    `grid_config4` leg times, EVERY pair compared with the oracle (one OpenMP thread per pair, oracle_register_many):
+    identical association arrays incl. order, pose within 1e-5 Frobenius of the oracle's T_align on the oracle's associations."""
+    reg = registration_for("semanticgrav", semantics_dim=512); reg.set_context(ctx)
+    S = 64
+    subs, poses = synth.make_submap_grid(2 * S, n=200, d=512, seed0=4000)
+    batch = rb.batch_from_submap_grid(reg, subs[:S], subs[S:])
+    assert len(batch) == S * S and batch.feats.shape[0] == 2 * S * 200
+    res = rb.run_batch(reg, batch)
+    many = orc.register_many(reg._abi_params(), batch.feats, batch.off1, batch.n1, batch.off2, batch.n2, batch.kmax(), faithful=False)
+    bad, worst = [], 0.0
+    for b in range(len(batch)):
+        a = many[b]
+        same = np.array_equal(res.assoc[b], a)
+        if len(a) >= 3:
+            T_o = orc.t_align(batch.feats[batch.off1[b] + a[:, 0], :3], batch.feats[batch.off2[b] + a[:, 1], :3])
+            err = float(np.linalg.norm(res.T[b] - T_o)); worst = max(worst, err)
+            same = same and res.status[b] == _abi.ROMAN_ST_OK and err < POSE_TOL
+        else:
+            same = same and bool(res.status[b] & _abi.ROMAN_ST_INSUFFICIENT)
+        if not same:
+            bad.append(b)
+    print(f"config 4, full grid: {S * S - len(bad)}/{S * S} identical results, worst pose error {worst:.2e}, most passes {int(res.stats['n_pass'].max())}")
+    assert not bad, f"{len(bad)} of {S * S} grid problems differ from the oracle: {bad[:10]}"
+    assert worst < POSE_TOL
+
+
 def test_demo_scale_1024_pairs_match_the_oracle(ctx, orc):
     """The scale the reference's demo runs at ([REF params/demo/submap_align.yaml:2,7,15]: submap_max_size 40, method 'roman',
     768-d descriptors): 1024 pairs with n, m uniform in [20, 40] in ONE call — the path of the small kernels (one-wave

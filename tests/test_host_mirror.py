@@ -156,3 +156,15 @@ def test_vectorised_pack_equals_the_per_object_lists():
         for sm in subs + [[]]:
             a, b = reg.pack(sm), ObjectRegistration.pack(reg, sm)
             assert a.dtype == b.dtype and a.shape == b.shape and np.array_equal(a, b) and a.flags.c_contiguous
+
+
+def test_device_prefilter_needs_the_descriptor_length_before_an_empty_map():
+    """An empty map packed before the descriptor length is known would get rows of another width than the maps packed after it
+    (one pool per batch): refused; with semantics_dim given the widths agree."""
+    reg = DistRegWithPruning(0.4, 0.6, 0.2, cos_min=0.5, use_gravity=True, prune_on_device=True)
+    with pytest.raises(ValueError, match="semantics_dim"):
+        reg.pack([])
+    pr = synth.make_pair(6, 5, 16, 9)
+    reg = DistRegWithPruning(0.4, 0.6, 0.2, cos_min=0.5, use_gravity=True, prune_on_device=True, semantics_dim=16)
+    assert reg.pack([]).shape == (0, 3 + 4 + 16) and reg.pack(pr.map1).shape == (6, 3 + 4 + 16)
+    assert reg._abi_params().cos_feature_dim == 16
