@@ -2626,6 +2626,8 @@ __global__ void __launch_bounds__(1024) k_solve(DevParams D, int B, const ProbDe
 constexpr int ST_D = 3;                  // quads in flight per lane
 constexpr int ST_MAXSL = STREAM_MAXL / 64;
 constexpr int SMALL_MAXL = 128;           // live associations the one-wave-per-problem instantiation of k_solve_up takes
+constexpr int LEAN_MAXL = 2560;           // live associations the 128-register instantiation takes (two workgroups per compute unit)
+constexpr int LEAN_D = 2;                 // ... and its quads in flight per lane
 constexpr uint32_t ST_CZ = 0x8000u, ST_MASK = 0x7fffu;
 constexpr unsigned long long FX_MAGIC_BITS = 0x4338000000000000ull;     // 2^52 + 2^51
 #define FX_MAGIC 6755399441055744.0
@@ -2751,7 +2753,7 @@ __device__ __forceinline__ double fx_decode(unsigned long long a, double inv)
     return fma((double)(uint32_t)(a >> 32), 4294967296.0, (double)(uint32_t)a) * inv;
 }
 
-template <int NW, bool HASCZ, int MAXL>
+template <int NW, bool HASCZ, int MAXL, int DEPTH = ST_D, bool LEAN = false>
 __device__ void solve_up(const DevParams& D, int b, const ProbDesc& pd, ProbState* st,
                          const double* __restrict__ feats, const int32_t* __restrict__ assoc,
                          const int32_t* __restrict__ plp /* position -> association index */, const int32_t* __restrict__ lpAsc,
@@ -2838,11 +2840,11 @@ __device__ void solve_up(const DevParams& D, int b, const ProbDesc& pd, ProbStat
                 s = lo_;
             }
             uint32_t nextB = CUMQ(s + 1);
-            // ring of ST_D quads in flight per lane; loads are issued unconditionally (clamped index) so that the wait
+            // ring of DEPTH quads in flight per lane; loads are issued unconditionally (clamped index) so that the wait
             // counters stay exact
-            unsigned long long rc[ST_D]; dbl2_t rv0[ST_D], rv1[ST_D];
+            unsigned long long rc[DEPTH]; dbl2_t rv0[DEPTH], rv1[DEPTH];
 #pragma unroll
-            for (int t = 0; t < ST_D; ++t) {
+            for (int t = 0; t < DEPTH; ++t) {
                 const uint32_t qq = min(qs + (uint32_t)t, qe - 1u);
                 rc[t] = cbase[(size_t)qq * 64];
                 rv0[t] = vbase[(size_t)(2 * qq) * 64]; rv1[t] = vbase[(size_t)(2 * qq + 1) * 64];
@@ -2897,20 +2899,20 @@ __device__ void solve_up(const DevParams& D, int b, const ProbDesc& pd, ProbStat
                 }                                                                                           \
             }
             uint32_t q0 = qs;
-            for (; q0 + ST_D <= qe; q0 += ST_D) {
+            for (; q0 + DEPTH <= qe; q0 += DEPTH) {
 #pragma unroll
-                for (int t = 0; t < ST_D; ++t) {
+                for (int t = 0; t < DEPTH; ++t) {
                     const uint32_t q = q0 + t;
                     const unsigned long long c = rc[t];
                     const dbl2_t v0 = rv0[t], v1 = rv1[t];
-                    const uint32_t qn = min(q + (uint32_t)ST_D, qe - 1u);
+                    const uint32_t qn = min(q + (uint32_t)DEPTH, qe - 1u);
                     rc[t] = cbase[(size_t)qn * 64];
                     rv0[t] = vbase[(size_t)(2 * qn) * 64]; rv1[t] = vbase[(size_t)(2 * qn + 1) * 64];
                     UP_CONSUME(q, c, v0, v1)
                 }
             }
 #pragma unroll
-            for (int t = 0; t < ST_D; ++t) {                    // tail: fewer than ST_D quads, already in the ring
+            for (int t = 0; t < DEPTH; ++t) {                    // tail: fewer than DEPTH quads, already in the ring
                 const uint32_t q = q0 + t;
                 if (q < qe) { UP_CONSUME(q, rc[t], rv0[t], rv1[t]) }
             }
@@ -2923,7 +2925,10 @@ __device__ void solve_up(const DevParams& D, int b, const ProbDesc& pd, ProbStat
             if (p < L) {
                 Mn[k] = fx_decode(accM[p], inv); Cn[k] = fx_decode(accC[p], inv);
                 accM[p] = 0ull; accC[p] = 0ull;                 // clean for the next pass (published by its barrier)
-            } else { Mn[k] = 0.0; Cn[k] = 0.0; }
+                // LEAN: the multiplied vector was not kept in registers across the stream: xg holds x * 2^s, and a power-of-two
+                // scaling is exact in both directions
+                if (LEAN) tk[k] = xg[p] * inv;
+            } else { Mn[k] = 0.0; Cn[k] = 0.0; if (LEAN) tk[k] = 0.0; }
         }
         ++n_pass;
         TMARK(2);
@@ -3074,8 +3079,8 @@ __device__ void solve_up(const DevParams& D, int b, const ProbDesc& pd, ProbStat
 // reductions at all), 64-thread workgroups, many of them per compute unit: submaps of the reference's demo scale (20-40
 // objects, ~60 live associations) would otherwise occupy a whole 8-wave workgroup — a whole compute unit, given the
 // registers of the general instantiation — for ~100 entries of matrix.  [Llo, Lhi]: the live-set sizes this launch takes.
-template <int NW, bool HASCZ, int MAXL>
-__global__ void __launch_bounds__(NW * 64) k_solve_up(DevParams D, int B, const ProbDesc* __restrict__ probs,
+template <int NW, bool HASCZ, int MAXL, int DEPTH = ST_D, bool LEAN = false>
+__global__ void __launch_bounds__(NW * 64, LEAN ? 4 : 1) k_solve_up(DevParams D, int B, const ProbDesc* __restrict__ probs,
                                                       ProbState* __restrict__ st,
                                                       const double* __restrict__ feats, const int32_t* __restrict__ assoc,
                                                       const int32_t* __restrict__ plp, const int32_t* __restrict__ lpAsc,
@@ -3123,7 +3128,7 @@ __global__ void __launch_bounds__(NW * 64) k_solve_up(DevParams D, int B, const 
         const int b = base + __builtin_ctzll(mask);
         mask &= mask - 1ull;
         const ProbDesc pd = probs[b];
-        solve_up<NW, HASCZ, MAXL>(D, b, pd, st, feats, assoc, plp, lpAsc, rowPos, pld, sliceBase, cols, vals, u0, O,
+        solve_up<NW, HASCZ, MAXL, DEPTH, LEAN>(D, b, pd, st, feats, assoc, plp, lpAsc, rowPos, pld, sliceBase, cols, vals, u0, O,
                                   xg, accM, accC, Lc, cumQ, red, sint);
         __syncthreads();                                         // the next problem of the range reuses the LDS state
         }

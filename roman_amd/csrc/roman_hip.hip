@@ -674,10 +674,17 @@ int enqueue_solve(roman_ctx* c, const DevParams& D, int B, int64_t sumA, int64_t
     const int Lc1 = SMALL_MAXL + 64;
     const size_t ldsUp1 = (size_t)3 * 8 * Lc1 + sizeof(double) * red_doubles(1) + sizeof(uint32_t) * (ST_MAXSL + 2) + sizeof(int) * 8 + 16;
     const int gridUp1 = std::max(1, std::min(B, c->num_cu * 24));
+    // The general instantiation keeps a thread's six vector elements and three quads of the stream in flight in 189 registers:
+    // one workgroup per compute unit.  When every live set of the launch fits LEAN_MAXL (the LDS vectors are sized for
+    // stream_maxL), the LEAN instantiation runs instead: five elements, the multiplied vector not held across the stream, two
+    // quads in flight, 128 registers — two workgroups (two problems, or a problem and another batch's kernels) per compute unit.
+    static const char* leanEnv = getenv("ROMAN_SOLVE_LEAN");    // "0": never
+    const bool lean = !(leanEnv && leanEnv[0] == '0') && D.stream_maxL <= LEAN_MAXL;
 #define ROMAN_LAUNCH_UP(CZ_)                                                                                                  \
     do {                                                                                                                      \
-        HIPCHK(c, dyn_lds(c, reinterpret_cast<const void*>(k_solve_up<NW, CZ_, STREAM_MAXL>), ldsUp)); \
-        hipLaunchKernelGGL((k_solve_up<NW, CZ_, STREAM_MAXL>), dim3(gridUp), dim3(NW * 64), ldsUp, WS.stream, D, B, WS.probs.as<ProbDesc>(), WS.state.as<ProbState>(), feats, assoc, \
+        auto kup = lean ? k_solve_up<NW, CZ_, LEAN_MAXL, LEAN_D, true> : k_solve_up<NW, CZ_, STREAM_MAXL>;                      \
+        HIPCHK(c, dyn_lds(c, reinterpret_cast<const void*>(kup), ldsUp)); \
+        hipLaunchKernelGGL(kup, dim3(gridUp), dim3(NW * 64), ldsUp, WS.stream, D, B, WS.probs.as<ProbDesc>(), WS.state.as<ProbState>(), feats, assoc, \
                            WS.plp.as<int32_t>(), WS.lp.as<int32_t>(), WS.rowPos.as<uint32_t>(), WS.pld.as<double>(), WS.sliceBase.as<uint32_t>(), \
                            WS.cols16.as<uint16_t>(), WS.vals.as<double>(), u0, O, WS.queue.as<int>(), Lc, small ? SMALL_MAXL + 1 : 0, STREAM_MAXL, (small && c->hist.valid && !c->hist.largeSeen) ? 64 : 1); \
         if (small) {                                                                                                          \
