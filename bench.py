@@ -27,6 +27,7 @@ The printed JSON line also carries (rank 0, N=1; `--no-extras` leaves the side l
   decision_sensitivity what the headline becomes under every reading of the two formulas that live only in the absent
                        clipperpy sources (ROMAN_SINGLE_* x ROMAN_GRAV_*), and under random instead of all-ones starts;
   large_live           the large-live-set path (method 'gravity', every association live: k_solve_wide) with its own roofline;
+  mid_live             64 pairs of method 'gravity' at n = m = 100 in ONE call (k_solve_wide in team mode), roofline + oracle check;
   demo_scale           the scale the reference's demo configuration runs at (method 'roman', n, m in [20, 40], d = 768).
 """
 import argparse
@@ -678,6 +679,49 @@ def side_legs(out, args, ctx, dev, G, orc, with_cpu):
             row["cpu_oracle_seconds"] = to
         ll.append(row)
     out["large_live"] = ll
+
+    # ---- MANY mid-size live sets in one call: 64 pairs of method 'gravity' at n = m = 100 (L = 10 000 each) — the scale a
+    #      method without a semantic gate runs at ([REF roman/params/submap_align_params.py:98-116]); k_solve_wide in TEAM mode ----
+    NM = 64
+    reg = SubmapAlignParams(method="gravity").get_object_registration(); reg.set_context(ctx)
+    prs = [synth.make_pair(100, 100, 0, 7100 + k, tilt_deg=1.0) for k in range(NM)]
+    bt = rb.batch_from_pairs(reg, [(p.map1, p.map2) for p in prs])
+    Pm = reg._abi_params(); Fm = bt.feats.shape[1]; kmax = bt.kmax()
+    featsm = torch.from_numpy(bt.feats).to(dev)
+    Om = [torch.zeros((NM, kmax, 2), dtype=torch.int32, device=dev), torch.zeros(NM, dtype=torch.int32, device=dev),
+          torch.zeros((NM, 16), dtype=torch.float64, device=dev), torch.zeros(NM, dtype=torch.int32, device=dev),
+          torch.zeros(NM * _abi.STATS_NBYTES, dtype=torch.uint8, device=dev)]
+
+    def mcall():
+        ctx.align_batch_dev(Pm, featsm.data_ptr(), Fm, bt.off1, bt.n1, bt.off2, bt.n2, kmax, Om[0].data_ptr(), Om[1].data_ptr(), Om[2].data_ptr(), Om[3].data_ptr(), Om[4].data_ptr())
+    torch.cuda.synchronize(dev)
+    for _ in range(3):                                          # (the first calls size the pools: ROMAN_ST_WORKSPACE until the history knows the need)
+        mcall(); torch.cuda.synchronize(dev)
+    reps = 4
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        mcall()
+    torch.cuda.synchronize(dev)
+    tm = (time.perf_counter() - t0) / reps
+    ctx.profile_enable(True); ctx.profile_reset(); mcall(); torch.cuda.synchronize(dev); pf = ctx.profile_get(); ctx.profile_enable(False)
+    stm = np.frombuffer(Om[4].cpu().numpy().tobytes(), dtype=stats_dtype())[:NM]
+    nm_ = Om[1].cpu().numpy(); am_ = Om[0].cpu().numpy(); sm_ = Om[3].cpu().numpy()
+    algm = float(np.sum(stm["n_pass"].astype(np.float64) * (12.0 * stm["nnz_upper"].astype(np.float64) + 24.0 * stm["n_live"].astype(np.float64))))
+    solve_ms = pf["solve"][0]
+    mid = {"workload": f"{NM} submap pairs in ONE call, method 'gravity', n = m = 100: L = 10 000 live associations each",
+           "value": NM / tm, "unit": "alignments/s", "ms_per_call": tm * 1e3, "stage_ms": {k: v[0] for k, v in pf.items()},
+           "mean_nnz_upper": float(stm["nnz_upper"].mean()), "mean_passes": float(stm["n_pass"].mean()), "max_passes": int(stm["n_pass"].max()),
+           "status_ok_frac": float(np.mean(sm_ == 0)),
+           "roofline": {"kernel": "k_solve_wide (team mode: the workgroups of an XCD, or half of one, per problem)", "bound": "hbm", "algorithmic_bytes": algm,
+                        "achieved": algm / (solve_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": algm / (solve_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "note": "§8(d) bytes summed over the 64 problems / the solve stage's hipEvent time of the call"}}
+    if with_cpu:
+        t0 = time.perf_counter()
+        many = orc.register_many(Pm, bt.feats, bt.off1, bt.n1, bt.off2, bt.n2, kmax, faithful=False)
+        tq = time.perf_counter() - t0
+        mid["oracle_identical"] = f"{sum(int(np.array_equal(many[b], am_[b, :nm_[b]])) for b in range(NM))}/{NM}"
+        mid["cpu_baseline"] = {"value": NM / tq, "unit": "alignments/s", "cores": orc.num_threads(), "kind": "port", "sample": f"the {NM} pairs, oracle, one OpenMP thread per pair"}
+    out["mid_live"] = mid
 
     # ---- the scale the reference's demo runs at: method 'roman' (pca + volume + gravity + 768-d descriptors), submaps of 20..40 objects -----
     reg = SubmapAlignParams(method="roman", semantics_dim=768).get_object_registration(); reg.set_context(ctx)

@@ -2626,7 +2626,7 @@ __global__ void __launch_bounds__(1024) k_solve(DevParams D, int B, const ProbDe
 constexpr int ST_D = 3;                  // quads in flight per lane
 constexpr int ST_MAXSL = STREAM_MAXL / 64;
 constexpr int SMALL_MAXL = 128;           // live associations the one-wave-per-problem instantiation of k_solve_up takes
-constexpr int LEAN_MAXL = 2560;           // live associations the 128-register instantiation takes (two workgroups per compute unit)
+constexpr int LEAN_MAXL = STREAM_MAXL;    // live associations the 128-register instantiation takes (two workgroups per compute unit)
 constexpr int LEAN_D = 2;                 // ... and its quads in flight per lane
 constexpr uint32_t ST_CZ = 0x8000u, ST_MASK = 0x7fffu;
 constexpr unsigned long long FX_MAGIC_BITS = 0x4338000000000000ull;     // 2^52 + 2^51
@@ -3194,8 +3194,15 @@ __device__ __forceinline__ void st_pub(double* p, double v)
 // line each: [0] abort flag, [1+x] arrivals of XCD x, [9] top arrivals, [10+x] generation of XCD x, [18] census (8 words),
 // [19] flat counter of the census barrier.  RELEASE: plain stores issued before the barrier must be visible behind it as well.
 // Every spin is bounded (4 s): on a timeout the abort flag goes up and every workgroup leaves.
-constexpr int WIDE_BAR_WORDS = 20 * 32;
-struct WideBar { unsigned* bar; unsigned epoch; int G; int xcc; unsigned nX; unsigned nActive; unsigned long long budget /* wall-clock ticks a spin may last */; };
+// TEAM mode (several fallback problems in a batch): the workgroups of an XCD — or of a half / a quarter of it (`sub` teams per
+// XCD) — form a team that solves its own problem; a team barrier is ONE level (the team's counter, released by the last
+// arriver through the team's generation word) and the teams never meet after the census.  Further lines of `bar`: [20] the
+// problem queue, [21] number of fallback problems (written by k_skipped), [24 + t] arrivals of team t, [56 + t] generation
+// of team t (t < 32).
+constexpr int WIDE_MAX_TEAMS = 32;
+constexpr int WIDE_BAR_WORDS = (56 + WIDE_MAX_TEAMS) * 32;
+struct WideBar { unsigned* bar; unsigned epoch; int G; int xcc; unsigned nX; unsigned nActive; unsigned long long budget /* wall-clock ticks a spin may last */;
+                 int teamMode; int tG /* workgroups of my team */; int tRank /* my rank in it */; int team; };
 
 __device__ __forceinline__ bool wide_spin(const unsigned* word, unsigned target, unsigned* bar, unsigned long long budget)
 {
@@ -3220,7 +3227,14 @@ __device__ __forceinline__ bool wide_sync(WideShared& sh, WideBar& wb, int ltid)
     if (ltid == 0) {
         if (RELEASE) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
         unsigned* bar = wb.bar;
-        bool ok;
+        bool ok = true;
+        if (wb.teamMode) {                                      // one level: the team's counter, the last arriver releases the team
+            const unsigned old = __hip_atomic_fetch_add(bar + 32 * (24 + wb.team), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (old + 1u == wb.epoch * (unsigned)wb.tG) __hip_atomic_store(bar + 32 * (56 + wb.team), wb.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else ok = wide_spin(bar + 32 * (56 + wb.team), wb.epoch, bar, wb.budget);
+            if (!ok) sh.abort_ = 1;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        } else {
         const unsigned old = __hip_atomic_fetch_add(bar + 32 * (1 + wb.xcc), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (old + 1u == wb.epoch * wb.nX) {                     // the last workgroup of this XCD: on to the top level
             __hip_atomic_fetch_add(bar + 32 * 9, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -3233,6 +3247,7 @@ __device__ __forceinline__ bool wide_sync(WideShared& sh, WideBar& wb, int ltid)
         }
         if (!ok) sh.abort_ = 1;
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // this compute unit's L1 holds nothing older than the barrier
+        }
     }
     __syncthreads();
     return sh.abort_ == 0;
@@ -3246,7 +3261,7 @@ __device__ __forceinline__ bool wide_census(WideShared& sh, WideBar& wb, int lti
     wb.xcc = (int)(x & 7u);
     if (ltid == 0) {
         unsigned* bar = wb.bar;
-        __hip_atomic_fetch_add(bar + 32 * 18 + wb.xcc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sh.sint[2] = (int)__hip_atomic_fetch_add(bar + 32 * 18 + wb.xcc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // my rank among the XCD's workgroups
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __hip_atomic_fetch_add(bar + 32 * 19, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const bool ok = wide_spin(bar + 32 * 19, (unsigned)wb.G, bar, wb.budget);
@@ -3261,7 +3276,15 @@ __device__ __forceinline__ bool wide_census(WideShared& sh, WideBar& wb, int lti
     }
     __syncthreads();
     wb.nX = (unsigned)sh.sint[0]; wb.nActive = (unsigned)sh.sint[1];
+    const int rankX = sh.sint[2];
     __syncthreads();
+    if (wb.teamMode) {                                          // `teamMode` sub-teams per XCD: ranks [first(s), first(s + 1)), first(s) = ceil(s nX / sub)
+        const int sub = wb.teamMode, nX = (int)wb.nX;
+        const int sidx = min(sub - 1, (rankX * sub) / max(nX, 1));
+        const int f0 = (sidx * nX + sub - 1) / sub, f1 = ((sidx + 1) * nX + sub - 1) / sub;
+        // (rank r belongs to sub-team floor(r sub / nX) — first(s) is the smallest r with r sub >= s nX)
+        wb.tG = f1 - f0; wb.tRank = rankX - f0; wb.team = wb.xcc * sub + sidx;
+    } else { wb.tG = wb.G; wb.tRank = (int)blockIdx.x; wb.team = 0; }
     return sh.abort_ == 0;
 }
 
@@ -3273,7 +3296,8 @@ __device__ __forceinline__ bool wide_reduce(double (&v)[N > 0 ? N : 1], WideShar
 {
     static_assert(N <= WIDE_NRED && NM <= N, "slot width");
     const int lane = ltid & 63, w = ltid >> 6, par = (int)(wb.epoch & 1u);
-    const int G = wb.G;
+    const int G = wb.tG;                                        // the team's workgroups (whole-device mode: the grid)
+    slots += (size_t)wb.team * 2 * (size_t)wb.G * WIDE_NRED;    // a team's own ping-pong slot array
     if (N > 0) {
 #pragma unroll
         for (int i = 0; i < N; ++i) {
@@ -3287,7 +3311,7 @@ __device__ __forceinline__ bool wide_reduce(double (&v)[N > 0 ? N : 1], WideShar
             double t = 0.0;
             if (ltid < N - NM) { for (int ww = 0; ww < WIDE_NW; ++ww) t += sh.wred[par][ww][ltid]; }
             else { for (int ww = 0; ww < WIDE_NW; ++ww) t = fmax(t, sh.wred[par][ww][ltid]); }
-            st_pub(slots + ((size_t)par * G + blockIdx.x) * WIDE_NRED + ltid, t);
+            st_pub(slots + ((size_t)par * G + wb.tRank) * WIDE_NRED + ltid, t);
         }
     }
     if (!wide_sync<false>(sh, wb, ltid)) return false;
@@ -3332,7 +3356,10 @@ __global__ void __launch_bounds__(WIDE_NT) k_solve_wide(DevParams D, int B, cons
                                                         int bmWords /* 64-bit words of one bit map (and of its LDS copy) */,
                                                         int xcap /* doubles of dynamic LDS behind the bit map: the gathered vector's leading part */,
                                                         int tune /* experiments: bit 0 never gather from LDS, bit 1 non-temporal matrix loads, bits 8.. chunks per wave */,
-                                                        unsigned long long spinTicks /* wall-clock ticks a barrier wait may last (host: 4 s at the device's wall-clock rate) */)
+                                                        unsigned long long spinTicks /* wall-clock ticks a barrier wait may last (host: 4 s at the device's wall-clock rate) */,
+                                                        int teams /* 0: the whole device on one problem at a time; s >= 1: s teams per XCD, a problem each */,
+                                                        const int32_t* __restrict__ fbList /* the batch's fallback problems (k_skipped) */,
+                                                        long long partStride /* doubles of `part` a team owns */)
 {
     __shared__ WideShared sh;
     extern __shared__ __attribute__((aligned(16))) unsigned char wide_smem[];
@@ -3340,29 +3367,39 @@ __global__ void __launch_bounds__(WIDE_NT) k_solve_wide(DevParams D, int B, cons
     double* xl = reinterpret_cast<double*>(bml + bmWords);                             // its leading xcap elements
     const roman_params_t& P = D.p;
     const int ltid = threadIdx.x, lane = ltid & 63, w = uni_i(ltid >> 6);
-    const int G = (int)gridDim.x, NWG = G * WIDE_NW;
-    const int gw = w * G + (int)blockIdx.x;                     // wave id in the grid: consecutive ids on different compute units
     if (ltid == 0) sh.abort_ = 0;
     __syncthreads();
-    WideBar wb{bar, 0u, G, 0, 1u, 1u, spinTicks};
-    // A bounded wait expired somewhere in the grid (never expected): every problem this launch has not finished — the one
-    // being solved and every later one of the fallback kind — gets a record that says so (ROMAN_ST_INTERNAL, no
-    // associations, NaN pose) instead of whatever the caller's buffers held.  Written by workgroup 0, which leaves through
-    // the same exits as everyone else (the abort flag is polled in every spin).
-    auto give_up = [&](int b0) {
-        if (blockIdx.x != 0) return;
-        for (int bb = b0 + (ltid >> 6); bb < B; bb += WIDE_NW) {
-            if (st[bb].kind != 1) continue;
-            if (lane < 16) O.T_out[(int64_t)bb * 16 + lane] = d_nan();
-            if (lane == 0) {
-                O.n_assoc_out[bb] = 0; O.status_out[bb] = ROMAN_ST_INTERNAL; O.nSel[bb] = 0;
-                if (O.stats_out) { roman_stats_t S0{}; S0.n_assoc_in = probs[bb].nA; S0.n_live = st[bb].L; O.stats_out[bb] = S0; }
+    WideBar wb{bar, 0u, (int)gridDim.x, 0, 1u, 1u, spinTicks, teams, (int)gridDim.x, (int)blockIdx.x, 0};
+    // (a problem this launch does not finish keeps the record k_skipped pre-wrote for it: ROMAN_ST_INTERNAL, no associations,
+    //  NaN pose — whatever exit a workgroup takes after a bounded wait expired, nothing stale is left behind)
+    if (!wide_census(sh, wb, ltid)) return;
+    const int G = wb.tG, NWG = G * WIDE_NW;                      // my team (whole-device mode: the grid)
+    const int gw = w * G + wb.tRank;                            // wave id in the team: consecutive ids on different compute units
+    part += (size_t)wb.team * (size_t)partStride;
+    bmPool += (size_t)wb.team * 2 * (size_t)bmWords;
+    const int nFb = (int)__hip_atomic_load(bar + 32 * 21, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int jq = 0; ; ++jq) {
+        int b;
+        if (teams) {                                            // the team's first workgroup claims the next problem; a barrier carries it to the others
+            double claim[1] = {0.0};
+            if (wb.tRank == 0) {
+                if (ltid == 0) { const unsigned j_ = __hip_atomic_fetch_add(bar + 32 * 20, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); sh.sint[3] = j_ < (unsigned)nFb ? fbList[j_] + 1 : 0; }
+                __syncthreads();
+                claim[0] = (double)sh.sint[3];
+                __syncthreads();
             }
+            if (!wide_reduce<1, 1>(claim, sh, slots, wb, ltid)) return;
+            b = (int)claim[0] - 1;
+            if (b < 0) break;
+        } else {
+            if (jq >= nFb) break;
+            b = fbList[jq];
         }
-    };
-    if (!wide_census(sh, wb, ltid)) { give_up(0); return; }
-    for (int b = 0; b < B; ++b) {
-        if (uni_i(st[b].kind) != 1) continue;                   // (uniform over the grid)
+        b = uni_i(b);
+        // beyond this team's registers or its share of the partials buffer (the host sizes teams so that this does not happen):
+        // the problem keeps its pre-written ROMAN_ST_INTERNAL record
+        if ((int64_t)WIDE_KW * NWG * 64 < (int64_t)st[b].L ||
+            ((int64_t)NWG * WIDE_MAXCH + (((int64_t)st[b].L + 63) >> 6) + 4) * 128 > (int64_t)partStride) continue;
         const ProbDesc pd = probs[b];
         const int L = uni_i(st[b].L), rb = uni_i(st[b].rowBase);
         const int64_t lo = pd.liveOff;
@@ -3664,13 +3701,13 @@ __global__ void __launch_bounds__(WIDE_NT) k_solve_wide(DevParams D, int B, cons
                 }
             }
         }
-        if (!alive) { give_up(b); return; }                      // a grid barrier timed out: give up, say so — for this and every later problem
+        if (!alive) return;                                      // a bounded wait expired: give up (the pre-written records say so)
         if (i >= P.maxoliters) status |= ROMAN_ST_MAXITER;
         S.n_pass = n_pass; S.ls_trials = ls_trials; S.inner_iters = inner_iters;
         S.outer_iters = i; S.score = F; S.d_final = d;
 #ifdef ROMAN_SOLVE_TIMING
         WMARK(6);
-        if (blockIdx.x == 0 && ltid == 0 && O.dbg) {            // 100 MHz ticks -> the host prints them as "cycles": x 10 ns
+        if (wb.tRank == 0 && ltid == 0 && O.dbg) {              // 100 MHz ticks -> the host prints them as "cycles": x 10 ns
             unsigned long long* dg = O.dbg + (size_t)b * 16;
             for (int t = 0; t < 8; ++t) { dg[t] = wacc[t]; dg[8 + t] = wcnt[t]; }
         }
@@ -3678,8 +3715,8 @@ __global__ void __launch_bounds__(WIDE_NT) k_solve_wide(DevParams D, int B, cons
 #undef WMARK
         // final u by position for the shared tail (plain stores + one release); workgroup 0 selects and writes the pose
         FORK(k) if (in[k]) vU[rb + ((gw + k * NWG) << 6) + lane] = u[k];
-        if (!wide_sync<true>(sh, wb, ltid)) { give_up(b); return; }
-        if (blockIdx.x == 0)
+        if (!wide_sync<true>(sh, wb, ltid)) return;
+        if (wb.tRank == 0)
             finish_one(D, b, pd, feats, assoc, plp, lp, rowPosPool, permPool, O, L > 0 ? vU + rb : nullptr, vS0 + rb,
                        reinterpret_cast<int32_t*>(vS1 + rb), reinterpret_cast<int32_t*>(vS2 + rb), L, rb, lo, F, status, S, sh.red, sh.sint);
 #undef CUMW
@@ -3689,11 +3726,22 @@ __global__ void __launch_bounds__(WIDE_NT) k_solve_wide(DevParams D, int B, cons
 
 // k_skipped: result records of the problems that found no workspace (kind 2): ROMAN_ST_WORKSPACE, no associations,
 // NaN pose.  One thread per problem.  Runs right before the solver kernels and also resets their problem queues.
+// With `fbList` (the whole-device solver is part of the launch): the fallback problems are listed for it (count in
+// wideBar line 21, zeroed by the host before this kernel) and their records PRE-WRITTEN as "not finished" (ROMAN_ST_INTERNAL,
+// no associations, NaN pose): the solver overwrites a record when it finishes the problem, so a launch that gives up (a
+// bounded wait expired) leaves a statement, not stale memory, for every problem it did not get to.
 __global__ void __launch_bounds__(256) k_skipped(int B, const ProbDesc* __restrict__ probs, const ProbState* __restrict__ st, SolveOut O,
-                                                 int* __restrict__ queue /* the solvers' problem queues (8 ints): cleared here */)
+                                                 int* __restrict__ queue /* the solvers' problem queues (8 ints): cleared here */,
+                                                 int32_t* __restrict__ fbList, unsigned* __restrict__ wideBar)
 {
     if (blockIdx.x == 0 && threadIdx.x < 8) queue[threadIdx.x] = 0;
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B && fbList != nullptr && st[b].kind == 1) {
+        fbList[atomicAdd(wideBar + 32 * 21, 1u)] = b;
+        for (int t = 0; t < 16; ++t) O.T_out[(int64_t)b * 16 + t] = d_nan();
+        O.n_assoc_out[b] = 0; O.status_out[b] = ROMAN_ST_INTERNAL; O.nSel[b] = 0;
+        if (O.stats_out) { roman_stats_t S{}; S.n_assoc_in = probs[b].nA; S.n_live = st[b].L; O.stats_out[b] = S; }
+    }
     if (b >= B || st[b].kind != 2) return;
     for (int t = 0; t < 16; ++t) O.T_out[(int64_t)b * 16 + t] = d_nan();
     O.n_assoc_out[b] = 0; O.status_out[b] = ROMAN_ST_WORKSPACE; O.nSel[b] = 0;

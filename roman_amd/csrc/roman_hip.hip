@@ -73,7 +73,7 @@ struct roman_ctx {
         DevBuf lp, li, lj, ls, ld, lza, lzb;                       // per live association, live order
         DevBuf plp, pli, plj, pls, pld, plza, plzb;                // the same in position order (stream layout)
         DevBuf rowCnt, rowPos, perm, sliceWidth, sliceBase, items, maskPool, prefPool, listPool, listOff;
-        DevBuf vMu, vCu, vMun, vCun, gU, gUn, uOut, nodesOrig, nSel, widePart, wideSlots, wideBar, wideBm;
+        DevBuf vMu, vCu, vMun, vCun, gU, gUn, uOut, nodesOrig, nSel, widePart, wideSlots, wideBar, wideBm, fbList;
         DevBuf cols16, cols32, vals;
         long long capMaskWords = 0, capNnz = 0, capList = 0;       // what the sparse pools hold (elements)
         // staging for the host-pointer entry points
@@ -407,7 +407,7 @@ int enqueue_score(roman_ctx* c, const DevParams& Din, const roman_params_t* para
         static const char* wideEnv = getenv("ROMAN_WIDE");      // "0": never, "1": whenever a fallback problem can exist
         const int mayFb = may_fallback(D, hd);
         D.wide = (c->coop_ok && mayFb > 0 && D.p.maxiniters >= 1 && D.p.maxlsiters >= 1 && maxA <= (int64_t)WIDE_KW * c->num_cu * WIDE_NW * 64 &&
-                  (wideEnv ? wideEnv[0] == '1' : mayFb <= std::max(1, c->num_cu / 16))) ? 1 : 0;
+                  (wideEnv ? wideEnv[0] == '1' : mayFb <= std::max(1, c->num_cu / 4))) ? 1 : 0;   // (several: teams of compute units, one problem each)
         static const char* i16Env = getenv("ROMAN_WIDE_IDX16");  // "0": 32-bit labels always
         D.idx16 = (D.wide && maxA <= 65534 && !(i16Env && i16Env[0] == '0')) ? 1 : 0;
     }
@@ -662,7 +662,14 @@ int enqueue_solve(roman_ctx* c, const DevParams& D, int B, int64_t sumA, int64_t
     const int gridUp = std::max(1, std::min(B, c->num_cu * wgPerCu));
 
     StageTimer t3(c, ROMAN_STAGE_SOLVE);
-    hipLaunchKernelGGL(k_skipped, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, WS.stream, B, WS.probs.as<ProbDesc>(), WS.state.as<ProbState>(), O, WS.queue.as<int>());
+    const bool coopPlanned = mayFallback && D.wide != 0 && c->coop_ok;
+    if (coopPlanned) {                                          // the whole-device solver's barrier words, problem queue and list (k_skipped fills the list)
+        HIPCHK(c, WS.wideBar.ensure(sizeof(unsigned) * WIDE_BAR_WORDS));
+        HIPCHK(c, WS.fbList.ensure(sizeof(int32_t) * (size_t)B));
+        HIPCHK(c, hipMemsetAsync(WS.wideBar.p, 0, sizeof(unsigned) * WIDE_BAR_WORDS, WS.stream));      // counters, generations, queue and the abort flag start at 0 in every launch
+    }
+    hipLaunchKernelGGL(k_skipped, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, WS.stream, B, WS.probs.as<ProbDesc>(), WS.state.as<ProbState>(), O, WS.queue.as<int>(),
+                       coopPlanned ? WS.fbList.as<int32_t>() : (int32_t*)nullptr, coopPlanned ? WS.wideBar.as<unsigned>() : (unsigned*)nullptr);
     DBG(c, "k_skipped");
     // Small problems (<= SMALL_MAXL live associations: the reference's demo scale) take the one-wave-per-problem
     // instantiation; it is launched when such problems have been seen with this parameter block (or, with no history
@@ -706,12 +713,23 @@ int enqueue_solve(roman_ctx* c, const DevParams& D, int B, int64_t sumA, int64_t
         // launch so that every workgroup is resident); many: one workgroup per problem, u and u' in LDS when they fit.
         bool coop = D.wide != 0 && c->coop_ok;                  // decided when the batch was scored (enqueue_score / roman_set_matrix_data)
         if (coop) {
-            const int G = c->num_cu, NWG = G * WIDE_NW;
-            const size_t partDoubles = ((size_t)NWG * WIDE_MAXCH + (size_t)(maxA + 63) / 64 + 4) * 64 * 2;    // pieces: chunks + slices
-            HIPCHK(c, WS.widePart.ensure(sizeof(double) * partDoubles));
-            HIPCHK(c, WS.wideSlots.ensure(sizeof(double) * 2 * (size_t)G * WIDE_NRED));
-            HIPCHK(c, WS.wideBar.ensure(sizeof(unsigned) * WIDE_BAR_WORDS));
-            HIPCHK(c, hipMemsetAsync(WS.wideBar.p, 0, sizeof(unsigned) * WIDE_BAR_WORDS, WS.stream));      // counters, generations and the abort flag start at 0 in every launch
+            const int G = c->num_cu;
+            // Several fallback problems: TEAMS — the workgroups of an XCD (or of half an XCD) solve one problem each, with a
+            // one-level barrier among themselves; the whole device on one problem at a time otherwise (one huge problem, or
+            // live sets beyond a team's registers: a thread owns WIDE_KW elements).
+            int a_teams = 0;
+            {
+                const int perXcd = std::max(1, G / 8);
+                auto cap = [&](int sub) { return (int64_t)WIDE_KW * std::max(1, perXcd / sub - 2) * WIDE_NW * 64; };   // (a margin of two workgroups against uneven placement)
+                if (mayFallback >= 2 && maxA <= cap(1)) a_teams = (mayFallback > 12 && maxA <= cap(2)) ? 2 : 1;
+                const char* teamEnv = getenv("ROMAN_WIDE_TEAMS");          // experiments / tests: 0 never, 1 / 2 / 4 teams per XCD whenever the live sets fit (read per call)
+                if (teamEnv) { const int t = atoi(teamEnv); a_teams = (t >= 1 && t <= 4 && mayFallback >= 1 && maxA <= cap(t)) ? t : 0; }
+            }
+            const int nTeams = a_teams ? 8 * a_teams : 1;
+            const int NWGt = a_teams ? std::min(G, 2 * (G / 8 / a_teams) + 8) * WIDE_NW : G * WIDE_NW;     // waves a team can have at most
+            long long a_partStride = (long long)(((size_t)NWGt * WIDE_MAXCH + (size_t)(maxA + 63) / 64 + 4) * 64 * 2);   // pieces: chunks + slices
+            HIPCHK(c, WS.widePart.ensure(sizeof(double) * (size_t)a_partStride * (size_t)nTeams));
+            HIPCHK(c, WS.wideSlots.ensure(sizeof(double) * 2 * (size_t)G * WIDE_NRED * (size_t)nTeams));
             DevParams Dv = D; int Bv = B;
             const ProbDesc* a_probs = WS.probs.as<ProbDesc>(); ProbState* a_state = WS.state.as<ProbState>();
             const double* a_feats = feats; const int32_t* a_assoc = assoc;
@@ -725,7 +743,7 @@ int enqueue_solve(roman_ctx* c, const DevParams& D, int B, int64_t sumA, int64_t
             double* a_part = WS.widePart.as<double>(); double* a_slots = WS.wideSlots.as<double>(); unsigned* a_bar = WS.wideBar.as<unsigned>();
             // dynamic LDS: the support bit map of the gathered vector + its leading part (everything the static part leaves of the 160 KB)
             int a_bmw = (int)((maxA + 63) / 64) + 1;
-            HIPCHK(c, WS.wideBm.ensure(sizeof(unsigned long long) * 2 * (size_t)a_bmw));
+            HIPCHK(c, WS.wideBm.ensure(sizeof(unsigned long long) * 2 * (size_t)a_bmw * (size_t)nTeams));
             unsigned long long* a_bm = WS.wideBm.as<unsigned long long>();
             int a_xcap = (int)(((int64_t)c->lds_max - 4096 - 8 * (int64_t)a_bmw) / (int64_t)sizeof(double)) & ~63;
             if (a_xcap < 0) a_xcap = 0;
@@ -735,8 +753,10 @@ int enqueue_solve(roman_ctx* c, const DevParams& D, int B, int64_t sumA, int64_t
             static const char* tuneEnv = getenv("ROMAN_WIDE_TUNE");
             int a_tune = tuneEnv ? (int)strtol(tuneEnv, nullptr, 0) : 0;
             unsigned long long a_ticks = c->spin_ticks;        // 4 s of the device's wall clock (test hook ROMAN_WIDE_SPIN_MS: shorter)
+            const int32_t* a_fb = WS.fbList.as<int32_t>();
             void* args[] = {&Dv, &Bv, &a_probs, &a_state, &a_feats, &a_assoc, &a_lp, &a_ld, &a_perm, &a_rpos, &a_sb, &a_cols, &a_vals,
-                            &a_vU, &a_vX, &a_vX2, &a_s0, &a_s1, &a_s2, &a_plp, &a_u0, &a_O, &a_part, &a_slots, &a_bar, &a_bm, &a_bmw, &a_xcap, &a_tune, &a_ticks};
+                            &a_vU, &a_vX, &a_vX2, &a_s0, &a_s1, &a_s2, &a_plp, &a_u0, &a_O, &a_part, &a_slots, &a_bar, &a_bm, &a_bmw, &a_xcap, &a_tune, &a_ticks,
+                            &a_teams, &a_fb, &a_partStride};
             // Two whole-device kernels must never be resident together (each would hold compute units while waiting at a
             // grid barrier for workgroups the other one keeps out): with batches in flight on several streams, a
             // launch waits for the previous one of this context.
@@ -1048,7 +1068,7 @@ int roman_ctx_destroy(roman_ctx_t* c)
         DevBuf* all[] = {&W.probs, &W.state, &W.totals, &W.queue, &W.cosPool, &W.tabPool, &W.sTmp, &W.chunkCnt,
                          &W.lp, &W.li, &W.lj, &W.ls, &W.ld, &W.lza, &W.lzb, &W.plp, &W.pli, &W.plj, &W.pls, &W.pld, &W.plza, &W.plzb,
                          &W.rowCnt, &W.rowPos, &W.perm, &W.sliceWidth, &W.sliceBase, &W.items, &W.maskPool, &W.prefPool, &W.listPool, &W.listOff,
-                         &W.vMu, &W.vCu, &W.vMun, &W.vCun, &W.gU, &W.gUn, &W.uOut, &W.nodesOrig, &W.nSel, &W.widePart, &W.wideSlots, &W.wideBar, &W.wideBm, &W.cols16, &W.cols32, &W.vals,
+                         &W.vMu, &W.vCu, &W.vMun, &W.vCun, &W.gU, &W.gUn, &W.uOut, &W.nodesOrig, &W.nSel, &W.widePart, &W.wideSlots, &W.wideBar, &W.wideBm, &W.fbList, &W.cols16, &W.cols32, &W.vals,
                          &W.hFeats, &W.hAssoc, &W.hU0, &W.oAssoc, &W.oN, &W.oT, &W.oStatus, &W.oStats, &W.hAux1, &W.hAux2, &W.hAux3};
         for (DevBuf* b : all) b->release();
         if (W.pinnedTotals) (void)hipHostFree(W.pinnedTotals);

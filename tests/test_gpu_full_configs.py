@@ -143,6 +143,28 @@ def test_mixed_batch_large_and_small_live_sets(ctx, orc):
     assert res.stats["n_live"].tolist() == [1600, 6000, 1050, 400]
 
 
+@pytest.mark.parametrize("teams", [None, "2", "0"], ids=["teams_auto", "two_teams_per_xcd", "whole_device"])
+def test_batch_of_mid_size_live_sets_matches_the_oracle(ctx, orc, teams, monkeypatch):
+    """Methods without a semantic gate ('gravity', 'clipper', 'pcavolgrav': [REF roman/params/submap_align_params.py:98-116])
+    make every association live: L = n * m, 3600 ... 10 000 at 60-100 objects per submap — beyond the stream layout.  A batch
+    of such problems is solved by TEAMS of compute units (the workgroups of an XCD, or of half an XCD, on one problem each,
+    k_solve_wide in team mode); every result equals the oracle's, as it does with the whole device on one problem at a time."""
+    if teams is not None:
+        monkeypatch.setenv("ROMAN_WIDE_TEAMS", teams)
+    reg = registration_for("gravity"); reg.set_context(ctx)
+    rng = np.random.default_rng(77)
+    sizes = [(int(a), int(b)) for a, b in rng.integers(60, 101, size=(18, 2))] + [(100, 100), (30, 30), (64, 48)]   # (30 x 30, 64 x 48: stream layout)
+    pairs = [synth.make_pair(n, m, 0, 980 + k, tilt_deg=1.0) for k, (n, m) in enumerate(sizes)]
+    batch = rb.batch_from_pairs(reg, [(p.map1, p.map2) for p in pairs])
+    res = rb.run_batch(reg, batch)
+    problems = [(batch.feats[batch.off1[b]:batch.off1[b] + batch.n1[b]], batch.feats[batch.off2[b]:batch.off2[b] + batch.n2[b]])
+                for b in range(len(batch))]
+    bad, worst, traj = _compare(orc, reg, res, problems)
+    print(f"mid-size live sets ({teams}): {len(batch) - len(bad)}/{len(batch)} identical, iteration counts differ on {traj}")
+    assert not bad and worst < POSE_TOL and len(traj) <= 2
+    assert res.stats["n_live"].tolist() == [n * m for n, m in sizes]
+
+
 def test_gravity_200x200_all_associations_live(ctx, orc):
     """method 'gravity' has no semantic gate: at n = m = 200 every one of the 40 000 associations is live — far beyond
     the stream layout (L <= 3072).  The problem takes the symmetric SELL-64 layout and the COOPERATIVE fallback

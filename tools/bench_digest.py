@@ -11,7 +11,7 @@ def g(x, *ks):
     return x
 print("value", round(d["value"]), d["unit"], "| ms/step", round(d["ms_per_step"], 3), "| steps", d["steps"], "| p50", d.get("p50_latency_ms"))
 print("roofline", {k: (round(v, 4) if isinstance(v, float) else v) for k, v in (d.get("roofline") or {}).items() if not isinstance(v, (dict, list, str))})
-for k in ("stage_ms_per_call", "result_check", "grid_config4", "demo_scale", "large_live", "value_incl_h2d", "decision_sensitivity", "u0_stability"):
+for k in ("stage_ms_per_call", "result_check", "grid_config4", "demo_scale", "large_live", "mid_live", "value_incl_h2d", "decision_sensitivity", "u0_stability"):
     if d.get(k) is not None:
         print(k, json.dumps(d[k])[:900])
 cb = d.get("cpu_baseline")
