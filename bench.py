@@ -723,15 +723,16 @@ def side_legs(out, args, ctx, dev, G, orc, with_cpu):
         mid["cpu_baseline"] = {"value": NM / tq, "unit": "alignments/s", "cores": orc.num_threads(), "kind": "port", "sample": f"the {NM} pairs, oracle, one OpenMP thread per pair"}
     out["mid_live"] = mid
 
-    # ---- the scale the reference's demo runs at: method 'roman' (pca + volume + gravity + 768-d descriptors), submaps of 20..40 objects -----
+    # ---- the scale the reference's demo runs at: method 'roman' (pca + volume + gravity + 768-d descriptors), submaps of 20..40 objects:
+    #      the all-pairs grid of two robots' 64 + 64 DISTINCT submaps = 4096 distinct pairs in one call -----------------------------------
     reg = SubmapAlignParams(method="roman", semantics_dim=768).get_object_registration(); reg.set_context(ctx)
     rng = np.random.default_rng(5000)
-    ND = 4096
-    sizes = rng.integers(20, 41, size=(ND, 2))
-    base = [synth.make_pair(int(a), int(b), 768, 5000 + k, tilt_deg=1.0) for k, (a, b) in enumerate(sizes[:256])]
-    b256 = rb.batch_from_pairs(reg, [(p.map1, p.map2) for p in base])          # 256 distinct pairs packed once; the 4096 problems refer to them 16 times
-    rep = ND // 256                                                            # (packing 8192 maps of 768-d descriptors on the host would dominate the leg)
-    bt = rb.AlignmentBatch(b256.feats, np.tile(b256.off1, rep), np.tile(b256.n1, rep), np.tile(b256.off2, rep), np.tile(b256.n2, rep))
+    SD = 64
+    ND = SD * SD
+    dsubs, _ = synth.make_submap_grid(2 * SD, n=40, d=768, seed0=5000)
+    dsizes = rng.integers(20, 41, size=2 * SD)
+    dsubs = [sm[:int(k)] for sm, k in zip(dsubs, dsizes)]                       # (objects are in random order inside a submap: a prefix is a random subset)
+    bt = rb.batch_from_submap_grid(reg, dsubs[:SD], dsubs[SD:])
     Pd = reg._abi_params(); Fd = Pd.feature_dim(); kmax = bt.kmax()
     featsd = torch.from_numpy(bt.feats).to(dev)
     Od = [torch.zeros((ND, kmax, 2), dtype=torch.int32, device=dev), torch.zeros(ND, dtype=torch.int32, device=dev),
@@ -753,20 +754,21 @@ def side_legs(out, args, ctx, dev, G, orc, with_cpu):
     ctx.profile_enable(True); ctx.profile_reset(); dcall(); torch.cuda.synchronize(dev); pf = ctx.profile_get(); ctx.profile_enable(False)
     std = np.frombuffer(Od[4].cpu().numpy().tobytes(), dtype=stats_dtype())[:ND]
     nd = Od[1].cpu().numpy(); ad = Od[0].cpu().numpy(); sd_ = Od[3].cpu().numpy()
-    demo = {"workload": f"{ND} submap pairs, method 'roman' (xyz + pca + volume + 768-d descriptors + gravity prior), n, m uniform in [20, 40] "
+    demo = {"workload": f"{ND} submap pairs (64 x 64 grid of 128 distinct submaps), method 'roman' (xyz + pca + volume + 768-d descriptors + gravity prior), n, m uniform in [20, 40] "
                         f"([REF params/demo/submap_align.yaml]: submap_max_size 40, DINOv2 768-d): A <= 1600 per pair",
             "value": ND / td, "unit": "alignments/s", "ms_per_call": td * 1e3, "stage_ms": {k: v[0] for k, v in pf.items()},
             "mean_live": float(std["n_live"].mean()), "mean_nnz_upper": float(std["nnz_upper"].mean()), "mean_passes": float(std["n_pass"].mean()),
             "status_ok_frac": float(np.mean((sd_ == 0) | (sd_ == _abi.ROMAN_ST_INSUFFICIENT))),
-            "note": "one roman_align_batch_dev call of 4096 problems (256 distinct pairs x 16), inputs resident; one 8-wave workgroup per problem"}
+            "note": "one roman_align_batch_dev call of 4096 DISTINCT pairs: the 64 x 64 cross pairs of 128 distinct submaps (each packed once), inputs resident"}
     if with_cpu:
-        NCd = 512
+        NCd = 1024
+        pickd = np.sort(np.random.default_rng(11).choice(ND, size=NCd, replace=False))
         t0 = time.perf_counter()
-        many = orc.register_many(Pd, bt.feats, bt.off1[:NCd], bt.n1[:NCd], bt.off2[:NCd], bt.n2[:NCd], kmax, faithful=False)
+        many = orc.register_many(Pd, bt.feats, bt.off1[pickd], bt.n1[pickd], bt.off2[pickd], bt.n2[pickd], kmax, faithful=False)
         tq = time.perf_counter() - t0
         demo["cpu_baseline"] = {"value": NCd / tq, "unit": "alignments/s", "cores": orc.num_threads(), "kind": "port",
-                                "sample": f"{NCd} of the pairs, oracle, one OpenMP thread per pair",
-                                "identical_to_gpu": int(sum(int(np.array_equal(many[b], ad[b, :nd[b]])) for b in range(NCd))), "compared": NCd}
+                                "sample": f"{NCd} random pairs of the grid, oracle, one OpenMP thread per pair",
+                                "identical_to_gpu": int(sum(int(np.array_equal(many[k], ad[b, :nd[b]])) for k, b in enumerate(pickd))), "compared": NCd}
     out["demo_scale"] = demo
 
 

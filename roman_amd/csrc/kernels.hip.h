@@ -2628,6 +2628,8 @@ constexpr int ST_MAXSL = STREAM_MAXL / 64;
 constexpr int SMALL_MAXL = 128;           // live associations the one-wave-per-problem instantiation of k_solve_up takes
 constexpr int LEAN_MAXL = STREAM_MAXL;    // live associations the 128-register instantiation takes (two workgroups per compute unit)
 constexpr int LEAN_D = 2;                 // ... and its quads in flight per lane
+constexpr int COO_E = 6;                  // one-wave instantiation: stored pairs a lane holds in registers (coordinate form)
+constexpr int COO_CAP = 64 * COO_E;       // ... per problem; larger matrices take the quad stream
 constexpr uint32_t ST_CZ = 0x8000u, ST_MASK = 0x7fffu;
 constexpr unsigned long long FX_MAGIC_BITS = 0x4338000000000000ull;     // 2^52 + 2^51
 #define FX_MAGIC 6755399441055744.0
@@ -2762,7 +2764,7 @@ __device__ void solve_up(const DevParams& D, int b, const ProbDesc& pd, ProbStat
                          const uint16_t* __restrict__ colsPool, const double* __restrict__ valsPool,
                          const double* __restrict__ u0, const SolveOut& O,
                          double* xg /* [Lc] */, unsigned long long* accM /* [Lc] */, unsigned long long* accC /* [Lc] */, int Lc,
-                         uint32_t* cumQ /* [ST_MAXSL + 1] */, double* red, int* sint)
+                         uint32_t* cumQ /* [ST_MAXSL + 1] */, double* red, int* sint, unsigned char* cooLds /* one-wave instantiation: COO_CAP * 12 bytes */)
 {
     constexpr int NT = NW * 64;
     constexpr int KMAX = (MAXL + NT - 1) / NT;                 // elements per thread (the kernel takes problems of up to MAXL live associations)
@@ -2812,6 +2814,53 @@ __device__ void solve_up(const DevParams& D, int b, const ProbDesc& pd, ProbStat
     }
     __syncthreads();
 
+    // ---- one-wave instantiation: the matrix as a COORDINATE list in registers ----------------------------------------
+    // A problem of the reference's demo scale has ~60 live associations and ~140 stored pairs; its one slice of 64 rows is
+    // as wide as its longest row, so those 140 entries occupy ~1500 slots of the quad layout, and every pass walks them all.
+    // The wave compacts the real entries once (ballot ranks, through LDS) into COO_E registers per lane — (row, column, flag)
+    // in one word + the value — and a pass is COO_E rounds of two gathers and four pushes, no memory traffic at all.  The sums
+    // are the same integers in another order: identical bits.  More than 64 * COO_E stored pairs: the quad stream below.
+    [[maybe_unused]] uint32_t cpq[COO_E]; [[maybe_unused]] double cv[COO_E];
+    [[maybe_unused]] int cooRounds = -1;                       // -1: not in use
+    if constexpr (NW == 1) {
+        uint32_t* lpq = reinterpret_cast<uint32_t*>(cooLds); double* lv = reinterpret_cast<double*>(cooLds + 4 * COO_CAP);
+        const uint32_t Tq = CUMQ(nsl);
+        const uint32_t q1 = nsl > 1 ? CUMQ(1) : Tq;             // (L <= 128: at most two slices)
+        uint32_t cnt = 0;
+        if ((unsigned long long)st[b].nnzUpper <= (unsigned long long)COO_CAP && nsl <= 2) {
+            for (uint32_t qq = 0; qq < Tq; ++qq) {
+                const unsigned long long cw = cbase[(size_t)qq * 64];
+                const dbl2_t v0 = vbase[(size_t)(2 * qq) * 64], v1 = vbase[(size_t)(2 * qq + 1) * 64];
+                const uint32_t row = (qq >= q1 ? 64u : 0u) + (uint32_t)lane;
+                const double v4[4] = {v0.x, v0.y, v1.x, v1.y};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const uint32_t lab = (uint32_t)(cw >> (16 * e)) & 0xffffu, col = lab & ST_MASK;
+                    const bool real = col < (uint32_t)L;        // (padding points at the dummy elements L + lane)
+                    const unsigned long long m_ = __ballot(real);
+                    if (real) {
+                        const uint32_t at = cnt + (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(m_ >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_, 0u));
+                        if (at < (uint32_t)COO_CAP) { lpq[at] = row | (col << 8) | ((lab & ST_CZ) ? 0x10000u : 0u); lv[at] = v4[e]; }
+                    }
+                    cnt += (uint32_t)__popcll(m_);
+                }
+            }
+            __syncthreads();
+            if (cnt <= (uint32_t)COO_CAP) {
+                cooRounds = (int)((cnt + 63u) >> 6);
+#pragma unroll
+                for (int e = 0; e < COO_E; ++e) {
+                    const uint32_t at = (uint32_t)e * 64u + (uint32_t)lane;
+                    const bool have = at < cnt;
+                    const uint32_t dummy = (uint32_t)L + (uint32_t)lane;                // inert: value 0 between two dummy elements
+                    cpq[e] = have ? lpq[at] : (dummy | (dummy << 8) | 0x10000u);
+                    cv[e] = have ? lv[at] : 0.0;
+                }
+            }
+            __syncthreads();
+        }
+    }
+
     // ---- (M x, C x) -> (Mn, Cn) for the vector x held in tk[] (elements >= 0), with xmax = max x and
     //      mp1 = 1 + the largest position with x > 0 (0: x is the zero vector) --------------------------------
     auto spmv = [&](double xmax, int mp1) {
@@ -2829,7 +2878,29 @@ __device__ void solve_up(const DevParams& D, int b, const ProbDesc& pd, ProbStat
         FOR_K(k, p) if (p < L) xg[p] = tk[k] * sc;
         __syncthreads();                                        // the scaled vector is published; accumulators are clean
         TMARK(6);
-        const int Sx = min(nsl, (mp1 + 63) >> 6);
+        bool streamed = false;
+        if constexpr (NW == 1) {
+            if (cooRounds >= 0) {                               // the matrix is in registers: pushes only
+                streamed = true;
+#pragma unroll
+                for (int e = 0; e < COO_E; ++e) {
+                    if (e < cooRounds) {
+                        const uint32_t p_ = cpq[e] & 0xffu, q_ = (cpq[e] >> 8) & 0xffu;
+                        const bool cz = HASCZ && (cpq[e] & 0x10000u);
+                        const double xp_ = xl[p_], xq_ = xl[q_];
+                        if (xq_ != 0.0) {
+                            __hip_atomic_fetch_add(aM + p_, (unsigned long long)__double_as_longlong(fma(cv[e], xq_, FX_MAGIC)) - FX_MAGIC_BITS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            if (!cz) __hip_atomic_fetch_add(aC + p_, (unsigned long long)__double_as_longlong(xq_ + FX_MAGIC) - FX_MAGIC_BITS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                        if (xp_ != 0.0) {
+                            __hip_atomic_fetch_add(aM + q_, (unsigned long long)__double_as_longlong(fma(cv[e], xp_, FX_MAGIC)) - FX_MAGIC_BITS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            if (!cz) __hip_atomic_fetch_add(aC + q_, (unsigned long long)__double_as_longlong(xp_ + FX_MAGIC) - FX_MAGIC_BITS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                    }
+                }
+            }
+        }
+        const int Sx = streamed ? 0 : min(nsl, (mp1 + 63) >> 6);
         const uint32_t T = CUMQ(Sx);
         const uint32_t qs = (uint32_t)(((unsigned long long)T * (unsigned)w) / NW), qe = (uint32_t)(((unsigned long long)T * (unsigned)(w + 1)) / NW);
         if (qs < qe) {
@@ -3098,6 +3169,7 @@ __global__ void __launch_bounds__(NW * 64, LEAN ? 4 : 1) k_solve_up(DevParams D,
     double* red = reinterpret_cast<double*>(accC + Lc);
     uint32_t* cumQ = reinterpret_cast<uint32_t*>(red + red_doubles(NW));
     int* sint = reinterpret_cast<int*>(cumQ + ST_MAXSL + 2);
+    unsigned char* cooLds = reinterpret_cast<unsigned char*>(sint + 8);        // (one-wave instantiation only: COO_CAP * 12 bytes)
     for (;;) {
         // The first wave claims R consecutive problems at a time (R = 1 unless this launch expects to find nothing: a batch
         // of small problems passes through the general instantiation and vice versa) until the range holds one this launch
@@ -3129,7 +3201,7 @@ __global__ void __launch_bounds__(NW * 64, LEAN ? 4 : 1) k_solve_up(DevParams D,
         mask &= mask - 1ull;
         const ProbDesc pd = probs[b];
         solve_up<NW, HASCZ, MAXL, DEPTH, LEAN>(D, b, pd, st, feats, assoc, plp, lpAsc, rowPos, pld, sliceBase, cols, vals, u0, O,
-                                  xg, accM, accC, Lc, cumQ, red, sint);
+                                  xg, accM, accC, Lc, cumQ, red, sint, cooLds);
         __syncthreads();                                         // the next problem of the range reuses the LDS state
         }
     }

@@ -679,14 +679,16 @@ int enqueue_solve(roman_ctx* c, const DevParams& D, int B, int64_t sumA, int64_t
     const bool small = !(smallEnv && smallEnv[0] == '0') && D.p.maxiniters >= 1 && D.p.maxlsiters >= 1 &&
                        (c->hist.valid ? c->hist.smallSeen : maxA <= 16 * SMALL_MAXL);
     const int Lc1 = SMALL_MAXL + 64;
-    const size_t ldsUp1 = (size_t)3 * 8 * Lc1 + sizeof(double) * red_doubles(1) + sizeof(uint32_t) * (ST_MAXSL + 2) + sizeof(int) * 8 + 16;
+    const size_t ldsUp1 = (size_t)3 * 8 * Lc1 + sizeof(double) * red_doubles(1) + sizeof(uint32_t) * (ST_MAXSL + 2) + sizeof(int) * 8 + 16 + (size_t)COO_CAP * 12;
     const int gridUp1 = std::max(1, std::min(B, c->num_cu * 24));
     // The general instantiation keeps a thread's six vector elements and three quads of the stream in flight in 189 registers:
-    // one workgroup per compute unit.  When every live set of the launch fits LEAN_MAXL (the LDS vectors are sized for
-    // stream_maxL), the LEAN instantiation runs instead: five elements, the multiplied vector not held across the stream, two
-    // quads in flight, 128 registers — two workgroups (two problems, or a problem and another batch's kernels) per compute unit.
-    static const char* leanEnv = getenv("ROMAN_SOLVE_LEAN");    // "0": never
-    const bool lean = !(leanEnv && leanEnv[0] == '0') && D.stream_maxL <= LEAN_MAXL;
+    // one workgroup per compute unit.  ROMAN_SOLVE_LEAN=1 selects the 128-register instantiation instead (the multiplied vector
+    // not held across the stream, two quads in flight, the rest of the state spilled by the compiler around the stream loop):
+    // two workgroups — two problems, or a problem and another batch's kernels — per compute unit.  MEASURED SLOWER (round 4,
+    // config 3: 1.34 against 1.09 ms per isolated launch, 119-121 k against 123-125 k alignments/s with three batches in
+    // flight; B = 1: 0.52 against 0.47 ms): the second workgroup does not buy back what the thinner stream loses.  Off by default.
+    static const char* leanEnv = getenv("ROMAN_SOLVE_LEAN");    // "1": use it
+    const bool lean = leanEnv && leanEnv[0] == '1' && D.stream_maxL <= LEAN_MAXL;
 #define ROMAN_LAUNCH_UP(CZ_)                                                                                                  \
     do {                                                                                                                      \
         auto kup = lean ? k_solve_up<NW, CZ_, LEAN_MAXL, LEAN_D, true> : k_solve_up<NW, CZ_, STREAM_MAXL>;                      \
