@@ -56,6 +56,7 @@ struct DevParams {
                              // SKIPPED (kind 2, ROMAN_ST_WORKSPACE) and runs again with them (set per launch, from the sizing history)
     int32_t wide;            // fallback problems of this launch go to k_solve_wide (few, large) instead of k_solve (set per launch)
     int32_t idx16;           // ... and their column labels are 16 bits wide (no C flag; 0xffff = inert): 10 instead of 12 bytes per entry
+    int32_t solve_flags;     // experiments: bit 0 = the one-wave solver keeps the quad stream (no coordinate list in registers)
     int32_t stream_maxL;     // problems of up to this many live associations take the stream layout (<= STREAM_MAXL; set per launch:
                              // it is also the column capacity of k_fill_slice's LDS tile and of the stream solver's LDS vectors)
 };
@@ -868,7 +869,7 @@ __global__ void __launch_bounds__(256) k_items(int RPB, const ProbState* __restr
 // gathers and ~12 f64 VALU ops, all exactly rounded (+,-,*,compare).  Output per row: the candidate
 // bit mask (one ballot word per 64 columns), the running candidate count in front of every word
 // (k_fill turns it into the entry index without another scan) and the row total.
-// Problems whose live set does not fit the LDS column tile read the columns from HBM/L2 instead.
+// A live set that does not fit the LDS column tile is swept tile by tile.
 // ---------------------------------------------------------------------------------------------
 // exclusive prefix sum over the 64 lanes of a wave
 // (DPP: six VALU instructions — row_shr:1,2,4,8 inside the rows of 16 lanes, row_bcast:15 / :31 across them; lanes without a
@@ -886,7 +887,6 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
 }
 __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, int lane) { (void)lane; return wave_incl_scan(v) - v; }
 
-// Generic sweep (columns read from HBM/L2): used when the live set does not fit the LDS column tile.
 // GM: 0 no gravity prior, 1 ROMAN_GRAV_COMBINED, 2 ROMAN_GRAV_SEPARATE, 3 ROMAN_GRAV_ZGATE (tables then hold full lengths)
 template <int GM>
 __device__ __forceinline__ bool pair_gate(const DevParams& D, double a, double bb, double dz)
@@ -914,45 +914,6 @@ __device__ __forceinline__ bool pair_gate(const DevParams& D, double a, double b
     }
 }
 
-template <int GM>
-__device__ __forceinline__ void count_rows_global(const DevParams& D, const ProbDesc& pd, int L, int row0, int nrows,
-                                                  int w, int wpb, int lane,
-                                                  const int32_t* __restrict__ gI, const int32_t* __restrict__ gJ,
-                                                  const double* __restrict__ gZa, const double* __restrict__ gZb,
-                                                  const double* __restrict__ TA, const double* __restrict__ TB, double* tA,
-                                                  uint32_t* __restrict__ rowCnt, unsigned long long* __restrict__ mbase,
-                                                  uint32_t* __restrict__ pbase)
-{
-    const int W = (L + 63) >> 6;
-    double* tB = tA + pd.n1 + 1;
-    for (int r = w; r < nrows; r += wpb) {
-        const int k = row0 + r;
-        const int i = gI[k], j = gJ[k];
-        const double zi = GM ? gZa[k] : 0.0, zj = GM ? gZb[k] : 0.0;
-        const double* gA = TA + (int64_t)i * pd.n1;
-        const double* gB = TB + (int64_t)j * pd.n2;
-        for (int t = lane; t < pd.n1; t += WAVE) tA[t] = gA[t];
-        for (int t = lane; t < pd.n2; t += WAVE) tB[t] = gB[t];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        unsigned long long* mrow = mbase + (int64_t)k * W;
-        for (int q0 = 0; q0 < L; q0 += WAVE) {
-            const int q = q0 + lane;
-            const bool vq = q < L;
-            const int qi = vq ? q : 0;
-            const double a = tA[gI[qi]], bb = tB[gJ[qi]];
-            const double dz = GM ? fabs((zi - gZa[qi]) - (zj - gZb[qi])) : 0.0;
-            const bool is = vq && pair_gate<GM>(D, a, bb, dz);
-            const unsigned long long m = __ballot(is);
-            if (lane == 0) mrow[q0 >> 6] = m;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
-}
-
 // Fast sweep: columns in LDS as the packed pair {i_q, n1+1+j_q} of indices into a table slice (+ the two z
 // coordinates), padded to a multiple of 256 columns with a sentinel whose table entry is NaN (fails every
 // test), so the inner loop has no bounds logic at all.  A wave sweeps NR ADJACENT rows at once (NR = 2 when
@@ -965,9 +926,14 @@ __device__ __forceinline__ void count_rows_lds(const DevParams& D, const ProbDes
                                                const uint32_t* cIJ /* i_q | (n1 + 1 + j_q) << 16: table-slice indices */, const double2* cZZ,
                                                const double* __restrict__ TA, const double* __restrict__ TB,
                                                double* tA /* NR slices of ldsPerRow doubles */, int ldsPerRow,
-                                               unsigned long long* __restrict__ mbase)
+                                               unsigned long long* __restrict__ mbase,
+                                               int c0 /* first column of the LDS tile */, int clen /* its columns (multiple of 256) */,
+                                               const int32_t* __restrict__ gI, const int32_t* __restrict__ gJ,
+                                               const double* __restrict__ gZa, const double* __restrict__ gZb /* the rows' own data when the tile does not hold them (c0 > 0 or clen < Lpad) */)
 {
     const int W = (L + 63) >> 6;
+    const bool tiled = !(c0 == 0 && clen >= ((L + 255) & ~255));
+    const int cend = c0 + clen;
     const char* tbytes = reinterpret_cast<const char*>(tA);
     const int sliceBytes = ldsPerRow * 8;
     constexpr int U = 2;                                        // column chunks per step (with 2 rows per wave: 2 beats 1 and 4)
@@ -982,7 +948,7 @@ __device__ __forceinline__ void count_rows_lds(const DevParams& D, const ProbDes
 #pragma unroll
         for (int x = 0; x < NR; ++x) {
             const int k_ = row0 + min(r_ + x, nrows - 1);
-            const int i_ = (int)(cIJ[k_] & 0xffffu), j_ = (int)(cIJ[k_] >> 16) - (pd.n1 + 1);
+            const int i_ = tiled ? gI[k_] : (int)(cIJ[k_] & 0xffffu), j_ = tiled ? gJ[k_] : (int)(cIJ[k_] >> 16) - (pd.n1 + 1);
             const double* gA_ = TA + (int64_t)i_ * pd.n1;
             const double* gB_ = TB + (int64_t)j_ * pd.n2;
 #pragma unroll
@@ -998,7 +964,7 @@ __device__ __forceinline__ void count_rows_lds(const DevParams& D, const ProbDes
 #pragma unroll
         for (int x = 0; x < NR; ++x) {
             k[x] = __builtin_amdgcn_readfirstlane(row0 + min(r + x, nrows - 1));   // wave-uniform: loop bounds and lane selects in SGPRs
-            zi[x] = GM ? cZZ[k[x]].x : 0.0; zj[x] = GM ? cZZ[k[x]].y : 0.0;
+            zi[x] = GM ? (tiled ? gZa[k[x]] : cZZ[k[x]].x) : 0.0; zj[x] = GM ? (tiled ? gZb[k[x]] : cZZ[k[x]].y) : 0.0;
         }
         // stage the table rows (wave-private slices; LDS ops of one wave execute in order)
 #pragma unroll
@@ -1011,7 +977,7 @@ __device__ __forceinline__ void count_rows_lds(const DevParams& D, const ProbDes
                     if (lane + m_ * WAVE < pd.n2) sB[lane + m_ * WAVE] = rb[x][m_];
                 }
             } else {
-                const int i = (int)(cIJ[k[x]] & 0xffffu), j = (int)(cIJ[k[x]] >> 16) - (pd.n1 + 1);
+                const int i = tiled ? gI[k[x]] : (int)(cIJ[k[x]] & 0xffffu), j = tiled ? gJ[k[x]] : (int)(cIJ[k[x]] >> 16) - (pd.n1 + 1);
                 const double* gA = TA + (int64_t)i * pd.n1;
                 const double* gB = TB + (int64_t)j * pd.n2;
                 for (int t = lane; t < pd.n1; t += WAVE) sA[t] = gA[t];
@@ -1032,13 +998,14 @@ __device__ __forceinline__ void count_rows_lds(const DevParams& D, const ProbDes
         uint32_t mlo[NR], mhi[NR];                              // lane l: word (block*64 + l) of the current 64-word block
 #pragma unroll
         for (int x = 0; x < NR; ++x) { mlo[x] = 0u; mhi[x] = 0u; }
-        for (int q0 = (R << 6) & ~(U * WAVE - 1); q0 < Lpad; q0 += U * WAVE) {
+        const int qEnd = min(Lpad, cend);                       // (a live set larger than the LDS tile is swept tile by tile: k_count)
+        for (int q0 = max((R << 6) & ~(U * WAVE - 1), c0); q0 < qEnd; q0 += U * WAVE) {
             int2 ij[U]; double2 zz[U];
 #pragma unroll
             for (int t = 0; t < U; ++t) {
-                const uint32_t pk = cIJ[q0 + t * WAVE + lane];
+                const uint32_t pk = cIJ[q0 - c0 + t * WAVE + lane];
                 ij[t] = make_int2((int)((pk & 0xffffu) << 3), (int)((pk >> 16) << 3));     // byte offsets into a table slice
-                if (GM) zz[t] = cZZ[q0 + t * WAVE + lane];
+                if (GM) zz[t] = cZZ[q0 - c0 + t * WAVE + lane];
             }
 #pragma unroll
             for (int t = 0; t < U; ++t) {
@@ -1058,12 +1025,13 @@ __device__ __forceinline__ void count_rows_lds(const DevParams& D, const ProbDes
                 }
             }
             const int wend = min(W, (q0 >> 6) + U);             // words [.., wend) are complete
-            if ((wend & 63) == 0 || wend == W) {                // flush the block of <= 64 words, coalesced
+            if ((wend & 63) == 0 || wend == W || q0 + U * WAVE >= qEnd) {   // flush the block of <= 64 words, coalesced (also at the end of a tile)
                 const int wb = (wend - 1) & ~63;
+                const int wlo = max(R, c0 >> 6);                // words in front of this tile were written when their tile was swept
 #pragma unroll
                 for (int x = 0; x < NR; ++x) {
                     const unsigned long long mreg = ((unsigned long long)mhi[x] << 32) | mlo[x];
-                    if (r + x < nrows && wb + lane < wend && wb + lane >= R) mbase[(int64_t)k[x] * W + wb + lane] = mreg;
+                    if (r + x < nrows && wb + lane < wend && wb + lane >= wlo) mbase[(int64_t)k[x] * W + wb + lane] = mreg;
                 }
             }
         }
@@ -1110,21 +1078,23 @@ __global__ void __launch_bounds__(1024) k_count(DevParams D, const ProbDesc* __r
         const double* TA = tabPool + pd.tabOff;
         const double* TB = TA + (int64_t)pd.n1 * pd.n1;
         const int Lpad = (L + 255) & ~255;
-        const bool ldscol = Lpad <= TC;
-        __syncthreads();                        // every wave is done with the previous item's columns
-        if (ldscol) {
-            for (int q = tid; q < Lpad; q += nt) {
-                const bool v = q < L;
-                cIJ[q] = v ? ((uint32_t)li[lo + q] | ((uint32_t)(pd.n1 + 1 + lj[lo + q]) << 16)) : ((uint32_t)pd.n1 | ((uint32_t)(pd.n1 + 1) << 16));
-                if (GM) cZZ[q] = v ? make_double2(lza[lo + q], lzb[lo + q]) : make_double2(0.0, 0.0);
+        // The column data of the whole live set in LDS when it fits (the usual case); a larger live set (no semantic gate:
+        // L = n1 * n2) is swept TILE BY TILE — the item's rows are staged once per tile (a row needs only the words at and
+        // behind its own 64-row block: tiles in front of the item's first row are skipped).
+        const int cFirst = (Lpad <= TC) ? 0 : ((((it.row0 >> 6) << 6) / TC) * TC);
+        for (int c0 = cFirst; c0 < Lpad; c0 += TC) {
+            const int clen = min(TC, Lpad - c0);
+            __syncthreads();                    // every wave is done with the previous tile's columns
+            for (int q = tid; q < clen; q += nt) {
+                const int qq = c0 + q;
+                const bool v = qq < L;
+                cIJ[q] = v ? ((uint32_t)li[lo + qq] | ((uint32_t)(pd.n1 + 1 + lj[lo + qq]) << 16)) : ((uint32_t)pd.n1 | ((uint32_t)(pd.n1 + 1) << 16));
+                if (GM) cZZ[q] = v ? make_double2(lza[lo + qq], lzb[lo + qq]) : make_double2(0.0, 0.0);
             }
+            __syncthreads();
+            count_rows_lds<GM, NR>(D, pd, L, it.row0, nrows, w, wpb, lane, cIJ, cZZ, TA, TB, tA, ldsPerWave / NR, maskPool + mo,
+                                   c0, clen, li + lo, lj + lo, lza + lo, lzb + lo);
         }
-        __syncthreads();
-        if (ldscol)
-            count_rows_lds<GM, NR>(D, pd, L, it.row0, nrows, w, wpb, lane, cIJ, cZZ, TA, TB, tA, ldsPerWave / NR, maskPool + mo);
-        else
-            count_rows_global<GM>(D, pd, L, it.row0, nrows, w, wpb, lane, li + lo, lj + lo, lza + lo, lzb + lo,
-                                    TA, TB, tA, rowCnt + lo, maskPool + mo, prefPool + mo);
     }
 }
 
@@ -2827,7 +2797,7 @@ __device__ void solve_up(const DevParams& D, int b, const ProbDesc& pd, ProbStat
         const uint32_t Tq = CUMQ(nsl);
         const uint32_t q1 = nsl > 1 ? CUMQ(1) : Tq;             // (L <= 128: at most two slices)
         uint32_t cnt = 0;
-        if ((unsigned long long)st[b].nnzUpper <= (unsigned long long)COO_CAP && nsl <= 2) {
+        if ((unsigned long long)st[b].nnzUpper <= (unsigned long long)COO_CAP && nsl <= 2 && !(D.solve_flags & 1)) {
             for (uint32_t qq = 0; qq < Tq; ++qq) {
                 const unsigned long long cw = cbase[(size_t)qq * 64];
                 const dbl2_t v0 = vbase[(size_t)(2 * qq) * 64], v1 = vbase[(size_t)(2 * qq + 1) * 64];

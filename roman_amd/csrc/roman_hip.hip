@@ -223,6 +223,7 @@ int make_dev_params(roman_ctx* c, const roman_params_t* p, int32_t F, DevParams*
     D->F = F;
     D->stream_maxL = STREAM_MAXL;
     D->allow_fallback = 1;
+    { static const char* cooEnv = getenv("ROMAN_COO"); D->solve_flags = (cooEnv && cooEnv[0] == '0') ? 1 : 0; }   // ROMAN_COO=0: A/B switch of the one-wave solver's coordinate form
     return ROMAN_OK;
 }
 
@@ -497,7 +498,9 @@ int enqueue_score(roman_ctx* c, const DevParams& Din, const roman_params_t* para
     const int ldsPerRow = ((2 * std::max(maxN, 1) + 1 + 1) & ~1) + 2;     // n1 + sentinel + n2 doubles
     const int colBytesC = D.gravity ? 20 : 4;                             // [z pair] + packed 16-bit table-slice indices
     const int Lneed = (expL + 255) & ~255;
-    int NRc = ((size_t)16 * 2 * ldsPerRow * sizeof(double) + (size_t)Lneed * colBytesC <= c->lds_max) ? 2 : 1;
+    // (two rows per wave when their table slices leave room for the whole expected live set — or, for live sets beyond any
+    //  tile, for a tile of at least 2048 columns: k_count sweeps larger live sets tile by tile)
+    int NRc = ((size_t)16 * 2 * ldsPerRow * sizeof(double) + (size_t)std::min(Lneed, 2048) * colBytesC <= c->lds_max) ? 2 : 1;
     int wpb = 16;
     static const char* nrEnv = getenv("ROMAN_COUNT_NR");
     static const char* wpbEnv = getenv("ROMAN_COUNT_WPB");

@@ -116,8 +116,13 @@ class Context:
         rc = self._lib.roman_align_batch(self._h, C.byref(params), B, _ptr(feats), n_obj, _ptr(off1), _ptr(n1),
                                          _ptr(off2), _ptr(n2), F, _ptr(assoc), _ptr(assoc_off), _ptr(u0), kmax,
                                          _ptr(a_out), _ptr(n_out), _ptr(T), _ptr(status), _ptr(stats))
-        self._check(rc, "roman_align_batch")
         s = dim + 1
+        if rc == _abi.ROMAN_E_INTERNAL:                          # outputs were copied: the error says which problems have no result
+            msg = self._lib.roman_last_error(self._h)
+            err = RomanHipError(f"roman_align_batch failed ({rc}): {msg.decode() if msg else ''}")
+            err.result = BatchResult([a_out[b, :n_out[b]].copy() for b in range(B)], T[:, :s * s].reshape(B, s, s).copy(), status, stats)
+            raise err
+        self._check(rc, "roman_align_batch")
         Ts = T[:, :s * s].reshape(B, s, s).copy()
         return BatchResult([a_out[b, :n_out[b]].copy() for b in range(B)], Ts, status, stats)
 
