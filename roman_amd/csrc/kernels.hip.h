@@ -3252,7 +3252,8 @@ __device__ __forceinline__ bool wide_spin(const unsigned* word, unsigned target,
     unsigned n = 0;
     while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
         __builtin_amdgcn_s_sleep(1);
-        if ((++n & 255u) == 0u && (wall_clock64() - t0 > budget || __hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+        // (budget 0 — the test hook ROMAN_WIDE_SPIN_MS=0 — makes the very first unsuccessful poll a timeout)
+        if (((++n & 255u) == 0u || budget == 0ull) && (wall_clock64() - t0 > budget || __hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
             __hip_atomic_store(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return false;
         }

@@ -1042,7 +1042,7 @@ int roman_ctx_create(roman_ctx_t** out, int device, void* stream)
         int khz = 0;
         if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) != hipSuccess || khz <= 0) { (void)hipGetLastError(); khz = 100000; }
         double ms = 4000.0;
-        if (const char* e = getenv("ROMAN_WIDE_SPIN_MS")) { const double v = atof(e); if (v > 0.0) ms = v; }
+        if (const char* e = getenv("ROMAN_WIDE_SPIN_MS")) { const double v = atof(e); if (v >= 0.0) ms = v; }   // test hook (0: the first unsuccessful poll of a wait is a timeout)
         c->spin_ticks = (unsigned long long)((double)khz * ms);
     }
     if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
