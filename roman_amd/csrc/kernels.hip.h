@@ -2743,8 +2743,13 @@ __device__ void solve_up(const DevParams& D, int b, const ProbDesc& pd, ProbStat
     const double p_eps = uni(P.eps), p_beta = uni(P.beta), p_tol_u = uni(P.tol_u), p_tol_F = uni(P.tol_F);
     const int p_maxin = uni(P.maxiniters), p_maxout = uni(P.maxoliters), p_maxls = uni(P.maxlsiters), p_rescale = uni(P.rescale_u0);
     const int tid = threadIdx.x, lane = tid & 63, w = uni(tid >> 6);
-#define FOR_K(k_, p_) _Pragma("unroll") for (int k_ = 0; k_ < KMAX; ++k_) if ([[maybe_unused]] const int p_ = tid + k_ * NT; true)
+    // FOR_K: the thread's elements that exist in THIS problem (k < ceil(L / NT): a problem of 2100 live associations uses five of the
+    // six element slots of the general instantiation, one of 60 one of the two of the one-wave instantiation — the slots behind
+    // are zero and stay zero, their share of the element-wise work is skipped); FOR_K_ALL: every slot (initialisation)
+#define FOR_K_ALL(k_, p_) _Pragma("unroll") for (int k_ = 0; k_ < KMAX; ++k_) if ([[maybe_unused]] const int p_ = tid + k_ * NT; true)
+#define FOR_K(k_, p_) _Pragma("unroll") for (int k_ = 0; k_ < KMAX; ++k_) if ([[maybe_unused]] const int p_ = tid + k_ * NT; k_ < kUsed)
     const int L = uni(st[b].L), rb = uni(st[b].rowBase);
+    const int kUsed = uni((L + NT - 1) / NT);
     const int64_t lo = pd.liveOff;
     const int nsl = (L + 63) >> 6;
     int par = 0;
@@ -2776,7 +2781,7 @@ __device__ void solve_up(const DevParams& D, int b, const ProbDesc& pd, ProbStat
 #define CUMQ(s_) ((uint32_t)__builtin_amdgcn_readlane((int)cqv, (s_)))
     for (int p = tid; p < Lc; p += NT) { xg[p] = 0.0; accM[p] = 0ull; accC[p] = 0ull; }
     double u[KMAX], Mu[KMAX], Cu[KMAX], sd[KMAX], tk[KMAX], Mn[KMAX], Cn[KMAX];
-    FOR_K(k, p) {
+    FOR_K_ALL(k, p) {
         const bool in = p < L;
         sd[k] = in ? pld[lo + p] : 0.0;
         u[k] = in ? (u0 ? u0[lo + plp[lo + p]] : 1.0) : 0.0;
@@ -3113,6 +3118,7 @@ __device__ void solve_up(const DevParams& D, int b, const ProbDesc& pd, ProbStat
     finish_one(D, b, pd, feats, assoc, plp, lpAsc, rowPosPool, nullptr, O, xg, reinterpret_cast<double*>(accM),
                reinterpret_cast<int32_t*>(accC), reinterpret_cast<int32_t*>(accC) + Lc, L, rb, lo, F, status, S, red, sint);
 #undef FOR_K
+#undef FOR_K_ALL
 #undef CUMQ
 }
 
