@@ -802,7 +802,7 @@ __global__ void __launch_bounds__(1024) k_rowbase(int B, int RPB, long long capM
         const int L = getL(b);
         const long long mwAll = (long long)L * ((L + 63) >> 6);
         sN += mwAll; sR += L;
-        if (getK(b) != 2) sM += mwAll;                           // kind 2: already skipped (k_live: no fallback kernels in this launch)
+        if (getK(b) < 2) sM += mwAll;                            // kind 2: already skipped (k_live: no fallback kernels in this launch); kind 3: finished by k_small
     }
     long long totM, totN; int totR, totI;
     const long long baseM = block_excl_scan(sM, shl, totM);
@@ -814,7 +814,7 @@ __global__ void __launch_bounds__(1024) k_rowbase(int B, int RPB, long long capM
         long long accM = baseM;
         for (int b = b0; b < b1; ++b) {
             const int L = getL(b);
-            const bool skip = getK(b) == 2;
+            const bool skip = getK(b) >= 2;
             const long long mw = skip ? 0 : (long long)L * ((L + 63) >> 6);
             accM += mw;
             if (!skip && accM <= capMaskWords) sI += (L + RPB - 1) / RPB;
@@ -827,12 +827,13 @@ __global__ void __launch_bounds__(1024) k_rowbase(int B, int RPB, long long capM
         for (int b = b0; b < b1; ++b) {
             const int L = getL(b);
             const int kind = getK(b);
-            const bool skip = kind == 2;
+            const bool skip = kind >= 2;
             const long long mw = skip ? 0 : (long long)L * ((L + 63) >> 6);
             const bool fits = !skip && accM + mw <= capMaskWords;
             const int it = fits ? (L + RPB - 1) / RPB : 0;
             st[b].rowBase = accR; st[b].itemBase = accI; st[b].maskOff = fits ? accM : 0;
-            if (!fits) { st[b].kind = 2; ++nover; }
+            if (kind == 3) mns = min(mns, L);                    // finished by k_small: still a small problem the history should know of
+            else if (!fits) { st[b].kind = 2; ++nover; }
             else if (kind == 0) { mxs = max(mxs, L); mns = min(mns, L); }
             mx = max(mx, L);
             accM += mw; accR += L; accI += it;
@@ -856,7 +857,7 @@ __global__ void __launch_bounds__(256) k_items(int RPB, const ProbState* __restr
 {
     const int b = blockIdx.x;
     const int L = st[b].L, ib = st[b].itemBase;
-    const int n = (st[b].kind == 2) ? 0 : (L + RPB - 1) / RPB;
+    const int n = (st[b].kind >= 2) ? 0 : (L + RPB - 1) / RPB;
     for (int t = threadIdx.x; t < n; t += blockDim.x) { ItemDesc d; d.b = b; d.row0 = t * RPB; items[ib + t] = d; }
 }
 
@@ -1134,7 +1135,7 @@ __global__ void __launch_bounds__(512) k_mirror(int B, int T /* workgroups per p
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int b = (slot / T) * 8 + xcd, tb = slot % T;
     if (b >= B) return;
-    if (st[b].kind == 2) return;
+    if (st[b].kind >= 2) return;
     const int L = st[b].L;
     const int W = (L + 63) >> 6;
     const int nR = ((W - 1 + nw - 1) / nw) * nw;                  // source row blocks 0..W-2, padded to whole workgroups
@@ -1271,7 +1272,7 @@ __global__ void __launch_bounds__(1024) k_rowsort(const ProbDesc* __restrict__ p
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nt = blockDim.x, nw = nt >> 6;
     const int L = st[b].L;
     const int64_t lo = probs[b].liveOff;
-    if (st[b].kind == 2) return;
+    if (st[b].kind >= 2) return;
     if (st[b].kind == 0) {
         // stream layout: bitonic sort (descending) of the UNIQUE keys ((degree + 1) << 12) | (4095 - row): larger degree
         // first, equal degrees in row order — the rank is the row's position.  N = next power of two >= L keys in LDS
@@ -1509,7 +1510,7 @@ __global__ void __launch_bounds__(1024) k_probscan(int B, int NG /* fill groups 
 #pragma unroll
             for (int t = 0; t < PC; ++t) if (t == j) { kind = cK[t]; L = cL[t]; cap = (long long)cC[t]; }
         } else { kind = st[b].kind; L = st[b].L; cap = (long long)st[b].nnzCap; }
-        if (kind == 2) cap = 0;
+        if (kind >= 2) cap = 0;
     };
     long long sC = 0;
     for (int b = b0; b < b1; ++b) { int kind, L; long long cap; get(b, kind, L, cap); sC += cap; }
@@ -1535,7 +1536,7 @@ __global__ void __launch_bounds__(1024) k_probscan(int B, int NG /* fill groups 
             const bool fits = acc + cap <= capNnz;
             const int ng = (kind == 0 && fits) ? min(NG, (L + 63) >> 6) : 0;
             st[b].nnzOff = fits ? acc : 0; st[b].sgBase = gacc;
-            if (!fits && kind != 2) { st[b].kind = 2; ++nover; }
+            if (!fits && kind < 2) { st[b].kind = 2; ++nover; }
             acc += cap; gacc += ng;
         }
     }
@@ -2734,7 +2735,9 @@ __device__ void solve_up(const DevParams& D, int b, const ProbDesc& pd, ProbStat
                          const uint16_t* __restrict__ colsPool, const double* __restrict__ valsPool,
                          const double* __restrict__ u0, const SolveOut& O,
                          double* xg /* [Lc] */, unsigned long long* accM /* [Lc] */, unsigned long long* accC /* [Lc] */, int Lc,
-                         uint32_t* cumQ /* [ST_MAXSL + 1] */, double* red, int* sint, unsigned char* cooLds /* one-wave instantiation: COO_CAP * 12 bytes */)
+                         uint32_t* cumQ /* [ST_MAXSL + 1] */, double* red, int* sint, unsigned char* cooLds /* one-wave instantiation: COO_CAP * 12 bytes */,
+                         int cooPre = -1 /* >= 0: cooLds already holds that many entries (k_small); no quad layout exists for the problem */,
+                         int rbPre = -1 /* >= 0: offset of the problem in the row pools (k_small runs before k_rowbase) */)
 {
     constexpr int NT = NW * 64;
     constexpr int KMAX = (MAXL + NT - 1) / NT;                 // elements per thread (the kernel takes problems of up to MAXL live associations)
@@ -2748,7 +2751,7 @@ __device__ void solve_up(const DevParams& D, int b, const ProbDesc& pd, ProbStat
     // are zero and stay zero, their share of the element-wise work is skipped); FOR_K_ALL: every slot (initialisation)
 #define FOR_K_ALL(k_, p_) _Pragma("unroll") for (int k_ = 0; k_ < KMAX; ++k_) if ([[maybe_unused]] const int p_ = tid + k_ * NT; true)
 #define FOR_K(k_, p_) _Pragma("unroll") for (int k_ = 0; k_ < KMAX; ++k_) if ([[maybe_unused]] const int p_ = tid + k_ * NT; k_ < kUsed)
-    const int L = uni(st[b].L), rb = uni(st[b].rowBase);
+    const int L = uni(st[b].L), rb = rbPre >= 0 ? rbPre : uni(st[b].rowBase);
     const int kUsed = uni((L + NT - 1) / NT);
     const int64_t lo = pd.liveOff;
     const int nsl = (L + 63) >> 6;
@@ -2777,7 +2780,7 @@ __device__ void solve_up(const DevParams& D, int b, const ProbDesc& pd, ProbStat
     // ---- per-problem set-up: quad prefix of the slices, owned elements, clean LDS --------------------------
     __syncthreads();
     // slice table: lane s of every wave holds the first quad of slice s (lane nsl: the total), read with v_readlane
-    const uint32_t cqv = (lane < nsl) ? (sliceBasePool[lo + lane] >> 8) : (st[b].nnzCap >> 8);
+    const uint32_t cqv = cooPre >= 0 ? 0u : ((lane < nsl) ? (sliceBasePool[lo + lane] >> 8) : (st[b].nnzCap >> 8));
 #define CUMQ(s_) ((uint32_t)__builtin_amdgcn_readlane((int)cqv, (s_)))
     for (int p = tid; p < Lc; p += NT) { xg[p] = 0.0; accM[p] = 0ull; accC[p] = 0ull; }
     double u[KMAX], Mu[KMAX], Cu[KMAX], sd[KMAX], tk[KMAX], Mn[KMAX], Cn[KMAX];
@@ -2802,6 +2805,19 @@ __device__ void solve_up(const DevParams& D, int b, const ProbDesc& pd, ProbStat
         const uint32_t Tq = CUMQ(nsl);
         const uint32_t q1 = nsl > 1 ? CUMQ(1) : Tq;             // (L <= 128: at most two slices)
         uint32_t cnt = 0;
+        if (cooPre >= 0) {                                      // the caller (k_small) compacted the entries itself
+            cnt = (uint32_t)cooPre;
+            cooRounds = (int)((cnt + 63u) >> 6);
+#pragma unroll
+            for (int e = 0; e < COO_E; ++e) {
+                const uint32_t at = (uint32_t)e * 64u + (uint32_t)lane;
+                const bool have = at < cnt;
+                const uint32_t dummy = (uint32_t)L + (uint32_t)lane;
+                cpq[e] = have ? lpq[at] : (dummy | (dummy << 8) | 0x10000u);
+                cv[e] = have ? lv[at] : 0.0;
+            }
+            __syncthreads();
+        } else
         if ((unsigned long long)st[b].nnzUpper <= (unsigned long long)COO_CAP && nsl <= 2 && !(D.solve_flags & 1)) {
             for (uint32_t qq = 0; qq < Tq; ++qq) {
                 const unsigned long long cw = cbase[(size_t)qq * 64];
@@ -3179,6 +3195,196 @@ __global__ void __launch_bounds__(NW * 64, LEAN ? 4 : 1) k_solve_up(DevParams D,
         solve_up<NW, HASCZ, MAXL, DEPTH, LEAN>(D, b, pd, st, feats, assoc, plp, lpAsc, rowPos, pld, sliceBase, cols, vals, u0, O,
                                   xg, accM, accC, Lc, cumQ, red, sint, cooLds);
         __syncthreads();                                         // the next problem of the range reuses the LDS state
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_small: a problem of the reference's DEMO scale (submaps of 20-40 objects: ~60 live associations, ~110 stored pairs)
+// from the live list to the pose in ONE kernel, one wave per problem, nothing but the result written to memory.  The general
+// path spends eleven launches on such a problem (pair tests, mirror, prefix, sort, lists, geometry, scans, fill, solve ...):
+// at 4096 problems per call every one of them costs 5-130 us for a few hundred bytes of work each.  Here lane = live row
+// (two rows per lane: L <= SMALL_MAXL = 128):
+//   pair tests   row k against every live column q, sequentially over q (both triangles: no transposition), the same
+//                gate on the same table entries as k_count -> the row's candidate bits in registers;
+//   positions    rank by (degree descending, row ascending): one sweep over the degrees in LDS — the order k_rowsort's
+//                bitonic sort produces;
+//   kept pairs   a candidate pair belongs to its endpoint of smaller position: listed in LDS, then evaluated 64 at a time
+//                with k_fill_list's own value sequence (fill_value) and filter;
+//   solve        the kept entries ARE the coordinate list the one-wave solver keeps in registers (solve_up, cooPre).
+// Same candidates, same positions, same values, exact sums: the same bits as the general path.  A problem with more than
+// SMALL_PAIR_CAP candidates or COO_CAP stored pairs is left to the general path (kind stays 0); a finished one becomes kind 3.
+// ---------------------------------------------------------------------------------------------
+constexpr int SMALL_PAIR_CAP = 2304;      // candidate pairs the LDS of the solver's three vectors can list (16 bits each)
+
+__device__ __forceinline__ bool pair_gate_rt(const DevParams& D, int gm, double a, double bb, double dz)
+{
+    switch (gm) {
+    case 1: return pair_gate<1>(D, a, bb, dz);
+    case 2: return pair_gate<2>(D, a, bb, dz);
+    case 3: return pair_gate<3>(D, a, bb, dz);
+    default: return pair_gate<0>(D, a, bb, dz);
+    }
+}
+
+template <bool FAST>
+__global__ void __launch_bounds__(64) k_small(DevParams D, int B, const ProbDesc* __restrict__ probs, ProbState* __restrict__ st,
+                                              const double* __restrict__ feats, const int32_t* __restrict__ assoc,
+                                              const double* __restrict__ tabPool,
+                                              const int32_t* __restrict__ lp, const int32_t* __restrict__ li, const int32_t* __restrict__ lj,
+                                              const double* __restrict__ ls, const double* __restrict__ ld,
+                                              const double* __restrict__ lza, const double* __restrict__ lzb,
+                                              int32_t* __restrict__ plp, double* __restrict__ pld, uint32_t* __restrict__ rowPos,
+                                              const double* __restrict__ u0, SolveOut O, int* __restrict__ queue)
+{
+    // LDS: xg | accM | accC [Lc1 each] (before the solve: the candidate pair list) | red | cumQ | sint | coordinate list | cIJ | cZ | cS | posS | degS
+    constexpr int Lc1 = SMALL_MAXL + 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double* xg = reinterpret_cast<double*>(smem);
+    unsigned long long* accM = reinterpret_cast<unsigned long long*>(xg + Lc1);
+    unsigned long long* accC = accM + Lc1;
+    double* red = reinterpret_cast<double*>(accC + Lc1);
+    uint32_t* cumQ = reinterpret_cast<uint32_t*>(red + red_doubles(1));
+    int* sint = reinterpret_cast<int*>(cumQ + ST_MAXSL + 2);
+    unsigned char* cooLds = smem + (((size_t)(reinterpret_cast<unsigned char*>(sint + 8) - smem) + 15) & ~(size_t)15);   // 16-byte aligned (cZ behind it holds double2)
+    uint32_t* lpq = reinterpret_cast<uint32_t*>(cooLds); double* lv = reinterpret_cast<double*>(cooLds + 4 * COO_CAP);
+    double2* cZ = reinterpret_cast<double2*>(cooLds + 12 * COO_CAP);
+    static_assert((12 * COO_CAP) % 16 == 0, "cZ alignment");
+    double* cS = reinterpret_cast<double*>(cZ + SMALL_MAXL);
+    uint32_t* cIJ = reinterpret_cast<uint32_t*>(cS + SMALL_MAXL);
+    uint16_t* posS = reinterpret_cast<uint16_t*>(cIJ + SMALL_MAXL);
+    uint16_t* degS = posS + SMALL_MAXL;
+    uint16_t* pairs = reinterpret_cast<uint16_t*>(smem);       // (the solver's vectors are not in use yet)
+    static_assert(SMALL_PAIR_CAP * 2 <= 3 * 8 * Lc1, "pair list fits the solver's vectors");
+    const int lane = threadIdx.x;
+    const int gm = D.gmode;
+    for (;;) {
+        {                                                       // one problem per claim: thousands of short problems balance over ~3000 resident waves
+            int t_ = 0;
+            if (lane == 0) t_ = atomicAdd(queue, 1);
+            const int b = __builtin_amdgcn_readfirstlane(t_);
+            if (b >= B) break;
+            {
+                const int Lq = uni_i(st[b].L);
+                if (!(uni_i(st[b].kind) == 0 && Lq >= 1 && Lq <= SMALL_MAXL)) continue;
+            }
+            const ProbDesc pd = probs[b];
+            const int L = uni_i(st[b].L);
+            const int64_t lo = pd.liveOff;
+            const double* TA = tabPool + pd.tabOff;
+            const double* TB = TA + (int64_t)pd.n1 * pd.n1;
+            __syncthreads();                                    // the previous problem is done with the LDS
+            // ---- rows ------------------------------------------------------------------------------------
+            int ri[2], rj[2], rlp[2]; double rd[2], rza[2], rzb[2]; bool rv[2];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int k = r * 64 + lane;
+                rv[r] = k < L;
+                const int kk = rv[r] ? k : 0;
+                ri[r] = li[lo + kk]; rj[r] = lj[lo + kk]; rlp[r] = lp[lo + kk]; rd[r] = ld[lo + kk];
+                rza[r] = lza[lo + kk]; rzb[r] = lzb[lo + kk];
+                if (rv[r]) { cIJ[k] = (uint32_t)ri[r] | ((uint32_t)rj[r] << 16); cZ[k] = make_double2(rza[r], rzb[r]); cS[k] = ls[lo + kk]; }
+            }
+            __syncthreads();
+            // ---- pair tests: row k against every live column ---------------------------------------------------
+            unsigned long long m[2][2] = {{0ull, 0ull}, {0ull, 0ull}};
+            const double* rowA[2] = {TA + (int64_t)ri[0] * pd.n1, TA + (int64_t)ri[1] * pd.n1};
+            const double* rowB[2] = {TB + (int64_t)rj[0] * pd.n2, TB + (int64_t)rj[1] * pd.n2};
+            const int nr = L > 64 ? 2 : 1;                      // row halves in use
+#pragma unroll
+            for (int wd = 0; wd < 2; ++wd) {
+                const int q1 = min(L, (wd + 1) * 64);
+#pragma unroll 4
+                for (int q = wd * 64; q < q1; ++q) {
+                    const uint32_t pk = cIJ[q];
+                    const int iq = (int)(pk & 0xffffu), jq = (int)(pk >> 16);
+                    const double2 zz = cZ[q];
+#pragma unroll
+                    for (int r = 0; r < 2; ++r) {
+                        if (r < nr) {
+                            const double a = rowA[r][iq], bb = rowB[r][jq];
+                            const double dz = gm ? fabs((rza[r] - zz.x) - (rzb[r] - zz.y)) : 0.0;
+                            const bool is = pair_gate_rt(D, gm, a, bb, dz);
+                            m[r][wd] |= (unsigned long long)(is ? 1u : 0u) << (q & 63);
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 2; ++r) if (!rv[r]) { m[r][0] = 0ull; m[r][1] = 0ull; }
+            // ---- positions: rank by (degree descending, row ascending) -----------------------------------------
+            int dg[2], pos[2];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) { dg[r] = __popcll(m[r][0]) + __popcll(m[r][1]); if (rv[r]) degS[r * 64 + lane] = (uint16_t)dg[r]; }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                int rank = 0;
+                const int k = r * 64 + lane;
+                if (r < nr) for (int k2 = 0; k2 < L; ++k2) { const int d2 = (int)degS[k2]; rank += (d2 > dg[r] || (d2 == dg[r] && k2 < k)) ? 1 : 0; }
+                pos[r] = rank;
+                if (rv[r]) { posS[k] = (uint16_t)rank; rowPos[lo + k] = (uint32_t)rank; plp[lo + rank] = rlp[r]; pld[lo + rank] = rd[r]; }
+            }
+            __syncthreads();
+            // ---- the candidates a row KEEPS: those whose position is larger than its own ---------------------------
+            uint32_t cnt[2] = {0u, 0u};
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int wd = 0; wd < 2; ++wd) {
+                    unsigned long long x = m[r][wd], keep = 0ull;
+                    while (x) {
+                        const int bit = __builtin_ctzll(x);
+                        x &= x - 1ull;
+                        if ((int)posS[wd * 64 + bit] > pos[r]) { keep |= 1ull << bit; ++cnt[r]; }
+                    }
+                    m[r][wd] = keep;
+                }
+            const uint32_t inc0 = wave_incl_scan(cnt[0]), tot0 = (uint32_t)__builtin_amdgcn_readlane((int)inc0, 63);
+            const uint32_t inc1 = wave_incl_scan(cnt[1]), tot1 = (uint32_t)__builtin_amdgcn_readlane((int)inc1, 63);
+            const uint32_t cand = tot0 + tot1;
+            if (cand > (uint32_t)SMALL_PAIR_CAP) continue;       // too many candidates for the list: the general path takes the problem
+            uint32_t off[2] = {inc0 - cnt[0], tot0 + inc1 - cnt[1]};
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int wd = 0; wd < 2; ++wd) {
+                    unsigned long long x = m[r][wd];
+                    while (x) {
+                        const int bit = __builtin_ctzll(x);
+                        x &= x - 1ull;
+                        pairs[off[r]++] = (uint16_t)((r * 64 + lane) | ((wd * 64 + bit) << 8));
+                    }
+                }
+            __syncthreads();
+            // ---- values of the kept candidates, 64 at a time; entries above affinityeps form the coordinate list -------------
+            uint32_t nk = 0;
+            for (uint32_t c0 = 0; c0 < cand; c0 += 64u) {
+                const uint32_t idx = c0 + (uint32_t)lane;
+                const bool have = idx < cand;
+                const uint32_t pr = pairs[have ? idx : 0u];
+                const int k = (int)(pr & 0xffu), q = (int)(pr >> 8);
+                const uint32_t pkk = cIJ[k], pkq = cIJ[q];
+                const double a = TA[(int64_t)(pkk & 0xffffu) * pd.n1 + (pkq & 0xffffu)], bb = TB[(int64_t)(pkk >> 16) * pd.n2 + (pkq >> 16)];
+                const double2 zk = cZ[k], zq = cZ[q];
+                const double sk = cS[k], sq = cS[q];
+                double v;
+                if (D.gravity) v = fill_value<true, FAST>(D, a, bb, zk.x - zq.x, zk.y - zq.y, sk * sq, sk, sq);
+                else v = fill_value<false, FAST>(D, a, bb, 0.0, 0.0, sk * sq, sk, sq);
+                const bool keep = have && v > D.p.affinityeps;
+                const unsigned long long km = __ballot(keep);
+                if (keep) {
+                    const uint32_t at = nk + (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(km >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)km, 0u));
+                    if (at < (uint32_t)COO_CAP) { lpq[at] = (uint32_t)posS[k] | ((uint32_t)posS[q] << 8); lv[at] = v; }
+                }
+                nk += (uint32_t)__popcll(km);
+            }
+            if (nk > (uint32_t)COO_CAP) continue;                // more stored pairs than the registers hold: the general path
+            if (lane == 0) st[b].nnzUpper = (unsigned long long)nk;
+            __syncthreads();                                    // the pair list is spent: its LDS becomes the solver's vectors
+            solve_up<1, false, SMALL_MAXL>(D, b, pd, st, feats, assoc, plp, lp, rowPos, pld, nullptr, nullptr, nullptr, u0, O,
+                                           xg, accM, accC, Lc1, cumQ, red, sint, cooLds, (int)nk, (int)lo);
+            if (lane == 0) st[b].kind = 3;                      // done: the general kernels pass it by
         }
     }
 }

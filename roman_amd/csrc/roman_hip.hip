@@ -327,8 +327,21 @@ void estimate_sizes(roman_ctx* c, const DevParams& D, const roman_params_t* para
 
 int may_fallback(const DevParams& D, const std::vector<ProbDesc>& hd);
 
-// ---- the launch sequence of one batch (score + solve), on workspace c->cur and its stream; never waits -------------
 struct BatchOut { int32_t kmax; int32_t* assoc_out; int32_t* n_assoc_out; double* T_out; int32_t* status_out; roman_stats_t* stats_out; };
+
+// device pointers of a batch's outputs + the row pools the solvers' shared tail writes (sized by the association total)
+int make_solve_out(roman_ctx* c, int B, int64_t sumA, const BatchOut& out, SolveOut* O)
+{
+    const size_t R1 = (size_t)std::max<int64_t>(sumA, 1);
+    HIPCHK(c, WS.uOut.ensure(sizeof(double) * R1)); HIPCHK(c, WS.nodesOrig.ensure(sizeof(int32_t) * R1));
+    HIPCHK(c, WS.nSel.ensure(sizeof(int32_t) * (size_t)B));
+    O->assoc_out = out.assoc_out; O->n_assoc_out = out.n_assoc_out; O->T_out = out.T_out; O->status_out = out.status_out; O->stats_out = out.stats_out; O->kmax = out.kmax;
+    O->nodesOrig = WS.nodesOrig.as<int32_t>(); O->nSel = WS.nSel.as<int32_t>(); O->uOut = WS.uOut.as<double>();
+    O->dbg = nullptr;
+    return ROMAN_OK;
+}
+
+// ---- the launch sequence of one batch (score + solve), on workspace c->cur and its stream; never waits -------------
 
 // Cosine matrices of B problems: k_cos_tile (64x64 tile per workgroup, operands through LDS) by default; ROMAN_COS=0 selects
 // k_cos (32x32 tile per wave, operands from global memory), ROMAN_COS=16 / 32 the stage depth.
@@ -358,7 +371,12 @@ static hipError_t launch_cos(roman_ctx* c, hipStream_t stream, const DevParams& 
     return hipGetLastError();
 }
 
-int enqueue_score(roman_ctx* c, const DevParams& Din, const roman_params_t* params, const BatchIn& in, std::vector<ProbDesc>& hd, DevParams* Dout)
+// smallOut != NULL (batch calls: score and solve in one go): problems of the reference's demo scale (<= SMALL_MAXL live
+// associations) are finished by k_small right behind the live lists — tests, positions, values, solve, pose in one kernel —
+// and pass the rest of the sequence by.  The stepwise entry points (roman_score, then roman_solve / the export calls) keep
+// the general layout for every problem.
+int enqueue_score(roman_ctx* c, const DevParams& Din, const roman_params_t* params, const BatchIn& in, std::vector<ProbDesc>& hd, DevParams* Dout,
+                  const BatchOut* smallOut = nullptr, const double* smallU0 = nullptr)
 {
     const int B = in.B;
     hd.assign(B, ProbDesc{});
@@ -417,7 +435,7 @@ int enqueue_score(roman_ctx* c, const DevParams& Din, const roman_params_t* para
     HIPCHK(c, WS.probs.ensure(sizeof(ProbDesc) * (size_t)B));
     HIPCHK(c, WS.state.ensure(sizeof(ProbState) * (size_t)B));
     HIPCHK(c, WS.totals.ensure(sizeof(BatchTotals)));
-    HIPCHK(c, WS.queue.ensure(sizeof(int) * 8));
+    HIPCHK(c, WS.queue.ensure(sizeof(int) * 16));              // [0..7]: the solvers' queues (k_skipped clears them), [8]: k_small's
     HIPCHK(c, WS.cosPool.ensure(sizeof(double) * (size_t)(cosOn ? std::max<int64_t>(sumCos, 1) : 1)));
     HIPCHK(c, WS.tabPool.ensure(sizeof(double) * (size_t)std::max<int64_t>(sumTab, 1)));
     HIPCHK(c, WS.sTmp.ensure(sizeof(double) * nA1));
@@ -485,10 +503,6 @@ int enqueue_score(roman_ctx* c, const DevParams& Din, const roman_params_t* para
                            WS.chunkCnt.as<int32_t>(), maxChunks, LP.lp, LP.li, LP.lj, LP.ls, LP.ld, LP.lza, LP.lzb);
     DBG(c, "k_live");
     }
-    hipLaunchKernelGGL(k_rowbase, dim3(1), dim3(B > 256 ? 1024 : 256), 0, WS.stream, B, RPB, SZ.capMaskWords, dS, dT);
-    DBG(c, "k_rowbase");
-    hipLaunchKernelGGL(k_items, dim3(B), dim3(256), 0, WS.stream, RPB, dS, WS.items.as<ItemDesc>());
-    DBG(c, "k_items");
     t0.stop();
 
     // pair-test kernel LDS: a column tile (objects [+ z] of every live association) + per wave the table rows of
@@ -516,7 +530,32 @@ int enqueue_score(roman_ctx* c, const DevParams& Din, const roman_params_t* para
     const size_t pairLds = tabLds + (size_t)TCc * colBytesC;
     const int pairGrid = c->num_cu * std::max(1, std::min(2048 / (wpb * 64), (int)(c->lds_max / pairLds)));
 
-    StageTimer t1(c, ROMAN_STAGE_COUNT_PASS);
+    StageTimer t1(c, ROMAN_STAGE_COUNT_PASS);                  // (the stage also holds k_small: at the demo scale it IS the rest of the alignment)
+    {   // demo-scale problems: finished here, in one kernel (k_small); launched when such problems have been seen with this
+        // parameter block (or, with no history yet, when the association lists are short enough to make them likely)
+        static const char* fusedEnv = getenv("ROMAN_SMALL_FUSED");     // "0": never (A/B)
+        const bool want = smallOut != nullptr && !(fusedEnv && fusedEnv[0] == '0') && D.p.maxiniters >= 1 && D.p.maxlsiters >= 1 && maxTab > 0 &&
+                          (c->hist.valid ? c->hist.smallSeen : maxA <= 16 * SMALL_MAXL);
+        if (want) {
+            SolveOut O;
+            int rc = make_solve_out(c, B, sumA, *smallOut, &O);
+            if (rc) return rc;
+            HIPCHK(c, hipMemsetAsync(WS.queue.as<int>() + 8, 0, sizeof(int), WS.stream));
+            const bool fast = D.single && (D.p.single_mode == ROMAN_SINGLE_BOTH || D.p.single_mode == ROMAN_SINGLE_OFFDIAG) && D.p.distance_weight == 1.0 &&
+                              D.p.fusion_method != ROMAN_FUSE_ARITHMETIC_MEAN && D.p.fusion_method != ROMAN_FUSE_PRODUCT;      // (k_fill_list's own choice)
+            constexpr size_t ldsSmall = 14336;                 // 3 vectors of 192 + reduction scratch + coordinate list + the problem's columns
+            const int grid = std::max(1, std::min(B, c->num_cu * 12));
+            auto ks = fast ? k_small<true> : k_small<false>;
+            hipLaunchKernelGGL(ks, dim3(grid), dim3(64), ldsSmall, WS.stream, D, B, dP, dS, in.feats, in.assoc, WS.tabPool.as<double>(),
+                               LP.lp, LP.li, LP.lj, LP.ls, LP.ld, LP.lza, LP.lzb, WS.plp.as<int32_t>(), WS.pld.as<double>(), WS.rowPos.as<uint32_t>(),
+                               smallU0, O, WS.queue.as<int>() + 8);
+    DBG(c, "k_small");
+        }
+    }
+    hipLaunchKernelGGL(k_rowbase, dim3(1), dim3(B > 256 ? 1024 : 256), 0, WS.stream, B, RPB, SZ.capMaskWords, dS, dT);
+    DBG(c, "k_rowbase");
+    hipLaunchKernelGGL(k_items, dim3(B), dim3(256), 0, WS.stream, RPB, dS, WS.items.as<ItemDesc>());
+    DBG(c, "k_items");
     if (sumA > 0) {
         auto kc = NRc == 2 ? k_count<0, 2> : k_count<0, 1>;
         switch (D.gmode) {
@@ -645,12 +684,8 @@ int enqueue_solve(roman_ctx* c, const DevParams& D, int B, int64_t sumA, int64_t
                   const double* u0, bool hascz, int mayFallback /* problems that can be of the fallback kind */, const BatchOut& out)
 {
     const size_t R1 = (size_t)std::max<int64_t>(sumA, 1);
-    HIPCHK(c, WS.uOut.ensure(sizeof(double) * R1)); HIPCHK(c, WS.nodesOrig.ensure(sizeof(int32_t) * R1));
-    HIPCHK(c, WS.nSel.ensure(sizeof(int32_t) * (size_t)B));
     SolveOut O;
-    O.assoc_out = out.assoc_out; O.n_assoc_out = out.n_assoc_out; O.T_out = out.T_out; O.status_out = out.status_out; O.stats_out = out.stats_out; O.kmax = out.kmax;
-    O.nodesOrig = WS.nodesOrig.as<int32_t>(); O.nSel = WS.nSel.as<int32_t>(); O.uOut = WS.uOut.as<double>();
-    O.dbg = nullptr;
+    { int rc_ = make_solve_out(c, B, sumA, out, &O); if (rc_) return rc_; }
 #ifdef ROMAN_SOLVE_TIMING
     HIPCHK(c, WS.hAux3.ensure(sizeof(unsigned long long) * 16 * (size_t)B));
     HIPCHK(c, hipMemsetAsync(WS.hAux3.p, 0, sizeof(unsigned long long) * 16 * (size_t)B, WS.stream));
@@ -848,7 +883,7 @@ int run_batch(roman_ctx* c, const DevParams& D0, const roman_params_t* params, c
 {
     std::vector<ProbDesc> hd;
     DevParams D;
-    int rc = enqueue_score(c, D0, params, in, hd, &D);
+    int rc = enqueue_score(c, D0, params, in, hd, &D, &out, u0);
     if (rc) return rc;
     int64_t sumA = 0, maxA = 0; for (const ProbDesc& d : hd) { sumA += d.nA; maxA = std::max<int64_t>(maxA, d.nA); }
     return enqueue_solve(c, D, in.B, sumA, maxA, in.feats, in.assoc, u0, false, may_fallback(D, hd), out);
