@@ -57,6 +57,8 @@ struct DevParams {
     int32_t wide;            // fallback problems of this launch go to k_solve_wide (few, large) instead of k_solve (set per launch)
     int32_t idx16;           // ... and their column labels are 16 bits wide (no C flag; 0xffff = inert): 10 instead of 12 bytes per entry
     int32_t solve_flags;     // experiments: bit 0 = the one-wave solver keeps the quad stream (no coordinate list in registers)
+    int32_t small_only;      // the general kernels are NOT part of this launch (every problem of this parameter block has so far been finished by
+                             // k_small): a problem k_small leaves behind is skipped (kind 2, ROMAN_ST_WORKSPACE) and takes them on its second run
     int32_t stream_maxL;     // problems of up to this many live associations take the stream layout (<= STREAM_MAXL; set per launch:
                              // it is also the column capacity of k_fill_slice's LDS tile and of the stream solver's LDS vectors)
 };
@@ -98,7 +100,7 @@ struct BatchTotals {
     int32_t overflow;      // problems skipped for lack of workspace
     int32_t maxStreamL;    // largest L among stream-layout problems
     int32_t minStreamL;    // smallest L among stream-layout problems (does the small-problem solver have work?)
-    int32_t pad0;
+    int32_t nGeneral;      // problems left to the general kernels (not finished by k_small, not skipped)
     unsigned long long listTop;    // bump pointer of the candidate-list pool = what the whole batch needs of it
 };
 
@@ -776,7 +778,8 @@ __device__ __forceinline__ T block_excl_scan(T v, T* sh, T& total)
     return base + inc - v;
 }
 
-__global__ void __launch_bounds__(1024) k_rowbase(int B, int RPB, long long capMaskWords, ProbState* __restrict__ st, BatchTotals* __restrict__ tot)
+__global__ void __launch_bounds__(1024) k_rowbase(int B, int RPB, long long capMaskWords, ProbState* __restrict__ st, BatchTotals* __restrict__ tot,
+                                                  int smallOnly /* the general kernels are not launched: what k_small left behind is skipped */)
 {
     // one workgroup; a thread takes PER consecutive problems (a serial sweep of one wave over 4096 problems was 93 us —
     // 64 dependent round trips to memory — of the 1.4 ms the whole batch takes at the reference's demo scale)
@@ -821,7 +824,7 @@ __global__ void __launch_bounds__(1024) k_rowbase(int B, int RPB, long long capM
         }
     }
     const int baseI = block_excl_scan(sI, shi, totI);
-    int mx = 0, mxs = 0, nover = 0, mns = 0x7fffffff;
+    int mx = 0, mxs = 0, nover = 0, mns = 0x7fffffff, ngen = 0;
     {
         long long accM = baseM; int accR = baseR, accI = baseI;
         for (int b = b0; b < b1; ++b) {
@@ -829,26 +832,27 @@ __global__ void __launch_bounds__(1024) k_rowbase(int B, int RPB, long long capM
             const int kind = getK(b);
             const bool skip = kind >= 2;
             const long long mw = skip ? 0 : (long long)L * ((L + 63) >> 6);
-            const bool fits = !skip && accM + mw <= capMaskWords;
+            const bool fits = !skip && !smallOnly && accM + mw <= capMaskWords;
             const int it = fits ? (L + RPB - 1) / RPB : 0;
             st[b].rowBase = accR; st[b].itemBase = accI; st[b].maskOff = fits ? accM : 0;
+            if (kind < 2) ++ngen;                                // (also when it is skipped here: the history must learn that the general kernels are needed)
             if (kind == 3) mns = min(mns, L);                    // finished by k_small: still a small problem the history should know of
-            else if (!fits) { st[b].kind = 2; ++nover; }
+            else if (!fits) { if (kind != 2) ++nover; st[b].kind = 2; }
             else if (kind == 0) { mxs = max(mxs, L); mns = min(mns, L); }
             mx = max(mx, L);
             accM += mw; accR += L; accI += it;
         }
     }
     // batch maxima / counts: wave reduction, then one atomic per wave on LDS words
-    __shared__ int red[4];
-    if (tid == 0) { red[0] = 0; red[1] = 0; red[2] = 0; red[3] = 0x7fffffff; }
+    __shared__ int red[5];
+    if (tid == 0) { red[0] = 0; red[1] = 0; red[2] = 0; red[3] = 0x7fffffff; red[4] = 0; }
     __syncthreads();
-    for (int off = 32; off > 0; off >>= 1) { mx = max(mx, __shfl_xor(mx, off)); mxs = max(mxs, __shfl_xor(mxs, off)); nover += __shfl_xor(nover, off); mns = min(mns, __shfl_xor(mns, off)); }
-    if ((tid & 63) == 0) { atomicMax(&red[0], mx); atomicMax(&red[1], mxs); atomicAdd(&red[2], nover); atomicMin(&red[3], mns); }
+    for (int off = 32; off > 0; off >>= 1) { mx = max(mx, __shfl_xor(mx, off)); mxs = max(mxs, __shfl_xor(mxs, off)); nover += __shfl_xor(nover, off); mns = min(mns, __shfl_xor(mns, off)); ngen += __shfl_xor(ngen, off); }
+    if ((tid & 63) == 0) { atomicMax(&red[0], mx); atomicMax(&red[1], mxs); atomicAdd(&red[2], nover); atomicMin(&red[3], mns); atomicAdd(&red[4], ngen); }
     __syncthreads();
     if (tid == 0) {
         tot->R = totR; tot->maxL = red[0]; tot->nnzTotal = 0; tot->maskWords = totM < capMaskWords ? totM : capMaskWords; tot->items = totI; tot->sliceGroups = 0;
-        tot->needMaskWords = totN; tot->needNnz = 0; tot->overflow = red[2]; tot->maxStreamL = red[1]; tot->minStreamL = red[3]; tot->pad0 = 0; tot->listTop = 0ull;
+        tot->needMaskWords = totN; tot->needNnz = 0; tot->overflow = red[2]; tot->maxStreamL = red[1]; tot->minStreamL = red[3]; tot->nGeneral = red[4]; tot->listTop = 0ull;
     }
 }
 

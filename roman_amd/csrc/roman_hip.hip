@@ -109,6 +109,7 @@ struct roman_ctx {
         double rList = 0.0;                    // candidate-list elements / sum of nA
         bool smallSeen = false;                // a stream-layout problem of at most SMALL_MAXL live associations has occurred
         bool largeSeen = false;                // ... one of more than SMALL_MAXL
+        bool generalSeen = false;              // a problem was left to the general kernels (k_small did not finish it)
     } hist;
     unsigned histEpoch = 1;                    // bumped whenever the history is reset for another parameter block
     long long skippedTotal = 0;                // problems reported ROMAN_ST_WORKSPACE so far (harvested totals)
@@ -287,6 +288,7 @@ void harvest_totals(roman_ctx* c, bool wait)
         if (W.totSumA > 0) H.rList = std::max(H.rList, (double)t.listTop / W.totSumA);
         if (t.minStreamL <= SMALL_MAXL) H.smallSeen = true;
         if (t.maxStreamL > SMALL_MAXL) H.largeSeen = true;
+        if (t.nGeneral > 0) H.generalSeen = true;
         H.valid = true;
     }
 }
@@ -550,13 +552,21 @@ int enqueue_score(roman_ctx* c, const DevParams& Din, const roman_params_t* para
                                LP.lp, LP.li, LP.lj, LP.ls, LP.ld, LP.lza, LP.lzb, WS.plp.as<int32_t>(), WS.pld.as<double>(), WS.rowPos.as<uint32_t>(),
                                smallU0, O, WS.queue.as<int>() + 8);
     DBG(c, "k_small");
+            // Every problem of this parameter block has so far been finished by k_small: the general kernels (twelve launches
+            // that would find nothing to do: ~0.25 ms per call of 4096 problems) are left out.  A problem k_small leaves behind
+            // is then skipped like a workspace overflow (ROMAN_ST_WORKSPACE) and the history remembers that they are needed.
+            static const char* onlyEnv = getenv("ROMAN_SMALL_ONLY");   // "0": never leave them out
+            D.small_only = (c->hist.valid && !c->hist.generalSeen && !(onlyEnv && onlyEnv[0] == '0')) ? 1 : 0;
+            Dout->small_only = D.small_only;
         }
     }
-    hipLaunchKernelGGL(k_rowbase, dim3(1), dim3(B > 256 ? 1024 : 256), 0, WS.stream, B, RPB, SZ.capMaskWords, dS, dT);
+    hipLaunchKernelGGL(k_rowbase, dim3(1), dim3(B > 256 ? 1024 : 256), 0, WS.stream, B, RPB, SZ.capMaskWords, dS, dT, D.small_only);
     DBG(c, "k_rowbase");
+    if (!D.small_only) {
     hipLaunchKernelGGL(k_items, dim3(B), dim3(256), 0, WS.stream, RPB, dS, WS.items.as<ItemDesc>());
     DBG(c, "k_items");
-    if (sumA > 0) {
+    }
+    if (sumA > 0 && !D.small_only) {
         auto kc = NRc == 2 ? k_count<0, 2> : k_count<0, 1>;
         switch (D.gmode) {
         case 1: kc = NRc == 2 ? k_count<1, 2> : k_count<1, 1>; break;
@@ -613,12 +623,14 @@ int enqueue_score(roman_ctx* c, const DevParams& Din, const roman_params_t* para
     if (ngEnv) NG = std::max(1, std::min(FILLS_MAXSPI, atoi(ngEnv)));
     const int Wmax = std::max(1, D.stream_maxL / 64);
     const int SPI = (Wmax + std::min(NG, Wmax) - 1) / std::min(NG, Wmax);       // slices per group at most (LDS capacity)
+    if (!D.small_only) {
     hipLaunchKernelGGL(k_probscan, dim3(1), dim3(B > 256 ? 1024 : 256), 0, WS.stream, B, NG, SZ.capNnz, dS, dT);
     DBG(c, "k_probscan");
+    }
     t1.stop();
 
     StageTimer t2(c, ROMAN_STAGE_FILL);
-    if (sumA > 0) {
+    if (sumA > 0 && !D.small_only) {
         // list fill (stream layout): column tile + the rows and slice tables of one group
         const int colBytesF = D.gravity ? 32 : 16;
         const int TCs = D.stream_maxL;
@@ -709,6 +721,7 @@ int enqueue_solve(roman_ctx* c, const DevParams& D, int B, int64_t sumA, int64_t
     hipLaunchKernelGGL(k_skipped, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, WS.stream, B, WS.probs.as<ProbDesc>(), WS.state.as<ProbState>(), O, WS.queue.as<int>(),
                        coopPlanned ? WS.fbList.as<int32_t>() : (int32_t*)nullptr, coopPlanned ? WS.wideBar.as<unsigned>() : (unsigned*)nullptr);
     DBG(c, "k_skipped");
+    if (D.small_only) { t3.stop(); HIPCHK(c, hipGetLastError()); return ROMAN_OK; }   // every problem was k_small's (or is reported skipped)
     // Small problems (<= SMALL_MAXL live associations: the reference's demo scale) take the one-wave-per-problem
     // instantiation; it is launched when such problems have been seen with this parameter block (or, with no history
     // yet, when the association lists are short enough to make them likely).  The general launch takes the rest — and
@@ -1461,7 +1474,7 @@ int roman_set_matrix_data(roman_ctx_t* c, const roman_params_t* params, const do
     }
     const LivePools LP{WS.lp.as<int32_t>(), nullptr, nullptr, WS.ls.as<double>(), WS.ld.as<double>(), nullptr, nullptr};
     const LivePools PP{WS.plp.as<int32_t>(), nullptr, nullptr, nullptr, WS.pld.as<double>(), nullptr, nullptr};
-    hipLaunchKernelGGL(k_rowbase, dim3(1), dim3(256), 0, WS.stream, 1, RPB, (long long)maskWords, dS, dT);
+    hipLaunchKernelGGL(k_rowbase, dim3(1), dim3(256), 0, WS.stream, 1, RPB, (long long)maskWords, dS, dT, 0);
     hipLaunchKernelGGL(k_items, dim3(1), dim3(256), 0, WS.stream, RPB, dS, WS.items.as<ItemDesc>());
     if (n > 0) {
         hipLaunchKernelGGL(k_dense_mask, dim3((unsigned)std::min(c->num_cu * 8, (n + 3) / 4)), dim3(256), 0, WS.stream, n, dM, dC,

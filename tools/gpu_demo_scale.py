@@ -44,9 +44,20 @@ for _ in range(10):
     call()
 torch.cuda.synchronize(dev)
 td = (time.perf_counter() - t0) / 10
+ctx.set_pipeline(3)                                             # three calls in flight, like bench.py's headline loop (the outputs are the same every call)
+for _ in range(3):
+    call()
+ctx.sync(); torch.cuda.synchronize(dev)
+t0 = time.perf_counter()
+for _ in range(30):
+    call()
+ctx.sync(); torch.cuda.synchronize(dev)
+tp = (time.perf_counter() - t0) / 30
+ctx.set_pipeline(1)
 ctx.profile_enable(True); ctx.profile_reset(); call(); torch.cuda.synchronize(dev); pf = ctx.profile_get(); ctx.profile_enable(False)
 st = np.frombuffer(O[4].cpu().numpy().tobytes(), dtype=stats_dtype())[:ND]
-print(f"ROMAN_COO={os.environ.get('ROMAN_COO')}: {ND / td / 1e6:.2f} M alignments/s, {td * 1e3:.3f} ms per call, stages " + ", ".join(f"{k} {v[0]:.3f}" for k, v in pf.items()) +
+print(f"ROMAN_COO={os.environ.get('ROMAN_COO')} ROMAN_SMALL_FUSED={os.environ.get('ROMAN_SMALL_FUSED')} ROMAN_SMALL_ONLY={os.environ.get('ROMAN_SMALL_ONLY')}: "
+      f"one call at a time {ND / td / 1e6:.2f} M alignments/s ({td * 1e3:.3f} ms per call), three in flight {ND / tp / 1e6:.2f} M/s ({tp * 1e3:.3f} ms per call), stages " + ", ".join(f"{k} {v[0]:.3f}" for k, v in pf.items()) +
       f" | mean live {st['n_live'].mean():.1f}, nnz {st['nnz_upper'].mean():.1f}, passes {st['n_pass'].mean():.2f}, L<=128: {(st['n_live'] <= 128).mean():.3f}, nnz<=384: {(st['nnz_upper'] <= 384).mean():.3f}, "
       f"checksum {int(O[1].sum().item())} {int(O[0].sum().item())}")
 ctx.close()
