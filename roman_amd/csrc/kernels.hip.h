@@ -837,7 +837,7 @@ __global__ void __launch_bounds__(1024) k_rowbase(int B, int RPB, long long capM
             st[b].rowBase = accR; st[b].itemBase = accI; st[b].maskOff = fits ? accM : 0;
             if (kind < 2) ++ngen;                                // (also when it is skipped here: the history must learn that the general kernels are needed)
             if (kind == 3) mns = min(mns, L);                    // finished by k_small: still a small problem the history should know of
-            else if (!fits) { if (kind != 2) ++nover; st[b].kind = 2; }
+            else if (!fits) { st[b].kind = 2; ++nover; }        // (also a problem k_live already skipped: no fallback kernels in this launch)
             else if (kind == 0) { mxs = max(mxs, L); mns = min(mns, L); }
             mx = max(mx, L);
             accM += mw; accR += L; accI += it;
@@ -2603,6 +2603,7 @@ constexpr int ST_MAXSL = STREAM_MAXL / 64;
 constexpr int SMALL_MAXL = 128;           // live associations the one-wave-per-problem instantiation of k_solve_up takes
 constexpr int LEAN_MAXL = STREAM_MAXL;    // live associations the 128-register instantiation takes (two workgroups per compute unit)
 constexpr int LEAN_D = 2;                 // ... and its quads in flight per lane
+constexpr int DEEP_D = 6;                 // quads in flight per lane of the few-problems instantiation (latency-bound wide passes)
 constexpr int COO_E = 6;                  // one-wave instantiation: stored pairs a lane holds in registers (coordinate form)
 constexpr int COO_CAP = 64 * COO_E;       // ... per problem; larger matrices take the quad stream
 constexpr uint32_t ST_CZ = 0x8000u, ST_MASK = 0x7fffu;
@@ -2730,7 +2731,7 @@ __device__ __forceinline__ double fx_decode(unsigned long long a, double inv)
     return fma((double)(uint32_t)(a >> 32), 4294967296.0, (double)(uint32_t)a) * inv;
 }
 
-template <int NW, bool HASCZ, int MAXL, int DEPTH = ST_D, bool LEAN = false>
+template <int NW, bool HASCZ, int MAXL, int DEPTH = ST_D, bool LEAN = false, bool COOONLY = false /* the matrix is ALWAYS a pre-built coordinate list (k_small): no quad stream in the code */>
 __device__ void solve_up(const DevParams& D, int b, const ProbDesc& pd, ProbState* st,
                          const double* __restrict__ feats, const int32_t* __restrict__ assoc,
                          const int32_t* __restrict__ plp /* position -> association index */, const int32_t* __restrict__ lpAsc,
@@ -2754,7 +2755,7 @@ __device__ void solve_up(const DevParams& D, int b, const ProbDesc& pd, ProbStat
     // six element slots of the general instantiation, one of 60 one of the two of the one-wave instantiation — the slots behind
     // are zero and stay zero, their share of the element-wise work is skipped); FOR_K_ALL: every slot (initialisation)
 #define FOR_K_ALL(k_, p_) _Pragma("unroll") for (int k_ = 0; k_ < KMAX; ++k_) if ([[maybe_unused]] const int p_ = tid + k_ * NT; true)
-#define FOR_K(k_, p_) _Pragma("unroll") for (int k_ = 0; k_ < KMAX; ++k_) if ([[maybe_unused]] const int p_ = tid + k_ * NT; k_ < kUsed)
+#define FOR_K(k_, p_) _Pragma("unroll") for (int k_ = 0; k_ < KMAX; ++k_) if ([[maybe_unused]] const int p_ = tid + k_ * NT; true || k_ < kUsed)
     const int L = uni(st[b].L), rb = rbPre >= 0 ? rbPre : uni(st[b].rowBase);
     const int kUsed = uni((L + NT - 1) / NT);
     const int64_t lo = pd.liveOff;
@@ -2822,7 +2823,7 @@ __device__ void solve_up(const DevParams& D, int b, const ProbDesc& pd, ProbStat
             }
             __syncthreads();
         } else
-        if ((unsigned long long)st[b].nnzUpper <= (unsigned long long)COO_CAP && nsl <= 2 && !(D.solve_flags & 1)) {
+        if (!COOONLY && (unsigned long long)st[b].nnzUpper <= (unsigned long long)COO_CAP && nsl <= 2 && !(D.solve_flags & 1)) {
             for (uint32_t qq = 0; qq < Tq; ++qq) {
                 const unsigned long long cw = cbase[(size_t)qq * 64];
                 const dbl2_t v0 = vbase[(size_t)(2 * qq) * 64], v1 = vbase[(size_t)(2 * qq + 1) * 64];
@@ -2891,14 +2892,15 @@ __device__ void solve_up(const DevParams& D, int b, const ProbDesc& pd, ProbStat
                             __hip_atomic_fetch_add(aM + q_, (unsigned long long)__double_as_longlong(fma(cv[e], xp_, FX_MAGIC)) - FX_MAGIC_BITS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                             if (!cz) __hip_atomic_fetch_add(aC + q_, (unsigned long long)__double_as_longlong(xp_ + FX_MAGIC) - FX_MAGIC_BITS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         }
+                        __builtin_amdgcn_sched_barrier(0);      // (one round at a time: hoisting all six rounds' gathers costs a wave of occupancy)
                     }
                 }
             }
         }
-        const int Sx = streamed ? 0 : min(nsl, (mp1 + 63) >> 6);
-        const uint32_t T = CUMQ(Sx);
+        const int Sx = (COOONLY || streamed) ? 0 : min(nsl, (mp1 + 63) >> 6);
+        const uint32_t T = COOONLY ? 0u : CUMQ(Sx);
         const uint32_t qs = (uint32_t)(((unsigned long long)T * (unsigned)w) / NW), qe = (uint32_t)(((unsigned long long)T * (unsigned)(w + 1)) / NW);
-        if (qs < qe) {
+        if (!COOONLY && qs < qe) {
             int s = 0;
             {   // largest s with cumQ[s] <= qs (skips empty slices)
                 int lo_ = 0, hi_ = Sx;
@@ -3147,7 +3149,7 @@ __device__ void solve_up(const DevParams& D, int b, const ProbDesc& pd, ProbStat
 // objects, ~60 live associations) would otherwise occupy a whole 8-wave workgroup — a whole compute unit, given the
 // registers of the general instantiation — for ~100 entries of matrix.  [Llo, Lhi]: the live-set sizes this launch takes.
 template <int NW, bool HASCZ, int MAXL, int DEPTH = ST_D, bool LEAN = false>
-__global__ void __launch_bounds__(NW * 64, LEAN ? 4 : 1) k_solve_up(DevParams D, int B, const ProbDesc* __restrict__ probs,
+__global__ void __launch_bounds__(NW * 64, LEAN ? 4 : (NW == 1 ? 3 : 1)) k_solve_up(DevParams D, int B, const ProbDesc* __restrict__ probs,
                                                       ProbState* __restrict__ st,
                                                       const double* __restrict__ feats, const int32_t* __restrict__ assoc,
                                                       const int32_t* __restrict__ plp, const int32_t* __restrict__ lpAsc,
@@ -3232,7 +3234,7 @@ __device__ __forceinline__ bool pair_gate_rt(const DevParams& D, int gm, double 
 }
 
 template <bool FAST>
-__global__ void __launch_bounds__(64) k_small(DevParams D, int B, const ProbDesc* __restrict__ probs, ProbState* __restrict__ st,
+__global__ void __launch_bounds__(64, 3) k_small(DevParams D, int B, const ProbDesc* __restrict__ probs, ProbState* __restrict__ st,
                                               const double* __restrict__ feats, const int32_t* __restrict__ assoc,
                                               const double* __restrict__ tabPool,
                                               const int32_t* __restrict__ lp, const int32_t* __restrict__ li, const int32_t* __restrict__ lj,
@@ -3298,7 +3300,7 @@ __global__ void __launch_bounds__(64) k_small(DevParams D, int B, const ProbDesc
 #pragma unroll
             for (int wd = 0; wd < 2; ++wd) {
                 const int q1 = min(L, (wd + 1) * 64);
-#pragma unroll 4
+#pragma unroll 2
                 for (int q = wd * 64; q < q1; ++q) {
                     const uint32_t pk = cIJ[q];
                     const int iq = (int)(pk & 0xffffu), jq = (int)(pk >> 16);
@@ -3386,7 +3388,7 @@ __global__ void __launch_bounds__(64) k_small(DevParams D, int B, const ProbDesc
             if (nk > (uint32_t)COO_CAP) continue;                // more stored pairs than the registers hold: the general path
             if (lane == 0) st[b].nnzUpper = (unsigned long long)nk;
             __syncthreads();                                    // the pair list is spent: its LDS becomes the solver's vectors
-            solve_up<1, false, SMALL_MAXL>(D, b, pd, st, feats, assoc, plp, lp, rowPos, pld, nullptr, nullptr, nullptr, u0, O,
+            solve_up<1, false, SMALL_MAXL, ST_D, false, true>(D, b, pd, st, feats, assoc, plp, lp, rowPos, pld, nullptr, nullptr, nullptr, u0, O,
                                            xg, accM, accC, Lc1, cumQ, red, sint, cooLds, (int)nk, (int)lo);
             if (lane == 0) st[b].kind = 3;                      // done: the general kernels pass it by
         }

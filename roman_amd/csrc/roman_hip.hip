@@ -740,9 +740,13 @@ int enqueue_solve(roman_ctx* c, const DevParams& D, int B, int64_t sumA, int64_t
     // flight; B = 1: 0.52 against 0.47 ms): the second workgroup does not buy back what the thinner stream loses.  Off by default.
     static const char* leanEnv = getenv("ROMAN_SOLVE_LEAN");    // "1": use it
     const bool lean = leanEnv && leanEnv[0] == '1' && D.stream_maxL <= LEAN_MAXL;
+    // A handful of problems (the single-pair call whose latency bench.py reports): the wide passes are bound by how many bytes
+    // ONE compute unit keeps in flight, not by the memory system — twice the quads in flight per lane (ROMAN_SOLVE_DEEP=0/1 forces).
+    static const char* deepEnv = getenv("ROMAN_SOLVE_DEEP");
+    const bool deep = deepEnv ? deepEnv[0] == '1' : B <= std::max(1, c->num_cu / 16);
 #define ROMAN_LAUNCH_UP(CZ_)                                                                                                  \
     do {                                                                                                                      \
-        auto kup = lean ? k_solve_up<NW, CZ_, LEAN_MAXL, LEAN_D, true> : k_solve_up<NW, CZ_, STREAM_MAXL>;                      \
+        auto kup = lean ? k_solve_up<NW, CZ_, LEAN_MAXL, LEAN_D, true> : (deep ? k_solve_up<NW, CZ_, STREAM_MAXL, DEEP_D> : k_solve_up<NW, CZ_, STREAM_MAXL>); \
         HIPCHK(c, dyn_lds(c, reinterpret_cast<const void*>(kup), ldsUp)); \
         hipLaunchKernelGGL(kup, dim3(gridUp), dim3(NW * 64), ldsUp, WS.stream, D, B, WS.probs.as<ProbDesc>(), WS.state.as<ProbState>(), feats, assoc, \
                            WS.plp.as<int32_t>(), WS.lp.as<int32_t>(), WS.rowPos.as<uint32_t>(), WS.pld.as<double>(), WS.sliceBase.as<uint32_t>(), \
