@@ -49,10 +49,12 @@ for _ in range(3):
     call()
 ctx.sync(); torch.cuda.synchronize(dev)
 t0 = time.perf_counter()
+host = []
 for _ in range(30):
-    call()
+    h0 = time.perf_counter(); call(); host.append((time.perf_counter() - h0) * 1e3)
 ctx.sync(); torch.cuda.synchronize(dev)
 tp = (time.perf_counter() - t0) / 30
+print("host ms per call (pipelined loop):", " ".join(f"{h:.2f}" for h in host))
 ctx.set_pipeline(1)
 ctx.profile_enable(True); ctx.profile_reset(); call(); torch.cuda.synchronize(dev); pf = ctx.profile_get(); ctx.profile_enable(False)
 st = np.frombuffer(O[4].cpu().numpy().tobytes(), dtype=stats_dtype())[:ND]
