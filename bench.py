@@ -739,10 +739,11 @@ def side_legs(out, args, ctx, dev, G, orc, with_cpu):
           torch.zeros((ND, 16), dtype=torch.float64, device=dev), torch.zeros(ND, dtype=torch.int32, device=dev),
           torch.zeros(ND * _abi.STATS_NBYTES, dtype=torch.uint8, device=dev)]
 
-    Od2 = [[torch.zeros_like(t) for t in Od] for _ in range(2)]               # three output sets: three calls in flight
+    DEPTH = 6                                                   # calls in flight for this leg (a call lasts as long as its slowest problem: they pack better at 6)
+    Od2 = [[torch.zeros_like(t) for t in Od] for _ in range(DEPTH - 1)]     # one output set per call in flight
 
     def dcall(k=0):
-        o = Od if k % 3 == 0 else Od2[k % 3 - 1]
+        o = Od if k % DEPTH == 0 else Od2[k % DEPTH - 1]
         ctx.align_batch_dev(Pd, featsd.data_ptr(), Fd, bt.off1, bt.n1, bt.off2, bt.n2, kmax, o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(), o[3].data_ptr(), o[4].data_ptr())
     torch.cuda.synchronize(dev)
     for _ in range(3):
@@ -754,11 +755,11 @@ def side_legs(out, args, ctx, dev, G, orc, with_cpu):
         dcall()
     torch.cuda.synchronize(dev)
     td1 = (time.perf_counter() - t0) / reps
-    ctx.set_pipeline(args.pipeline)                             # like the headline: `pipeline` calls in flight (the tail of one call's solver
-    for k in range(3):                                          # — a problem of 200+ passes among thousands of 10 — overlaps the next calls)
+    ctx.set_pipeline(DEPTH)                                     # like the headline, calls in flight: the tail of one call's kernel — a problem of
+    for k in range(DEPTH):                                      # 200+ passes among thousands of 10 — overlaps the next calls
         dcall(k)
     ctx.sync(); torch.cuda.synchronize(dev)
-    reps = 30
+    reps = 60
     t0 = time.perf_counter()
     for k in range(reps):
         dcall(k)
@@ -770,7 +771,7 @@ def side_legs(out, args, ctx, dev, G, orc, with_cpu):
     nd = Od[1].cpu().numpy(); ad = Od[0].cpu().numpy(); sd_ = Od[3].cpu().numpy()
     demo = {"workload": f"{ND} submap pairs (64 x 64 grid of 128 distinct submaps), method 'roman' (xyz + pca + volume + 768-d descriptors + gravity prior), n, m uniform in [20, 40] "
                         f"([REF params/demo/submap_align.yaml]: submap_max_size 40, DINOv2 768-d): A <= 1600 per pair",
-            "value": ND / td, "unit": "alignments/s", "ms_per_call": td * 1e3, "batches_in_flight": args.pipeline,
+            "value": ND / td, "unit": "alignments/s", "ms_per_call": td * 1e3, "batches_in_flight": DEPTH,
             "one_call_at_a_time": {"value": ND / td1, "ms_per_call": td1 * 1e3},
             "max_passes": int(std["n_pass"].max()),
             "stage_ms": {k: v[0] for k, v in pf.items()},

@@ -191,7 +191,7 @@ ROMAN_API int roman_ctx_create(roman_ctx_t** ctx, int device, void* stream);
 ROMAN_API int roman_ctx_destroy(roman_ctx_t* ctx);
 
 /* Batches in flight.  depth 1 (default): every call runs on the context's stream and its results are
-   complete once that stream is synchronised.  depth 2 or 3: consecutive roman_align_batch_dev calls rotate
+   complete once that stream is synchronised.  depth 2 ... 6: consecutive roman_align_batch_dev calls rotate
    over that many internal workspaces, each on an internal stream that starts behind the work already queued
    on the context's stream, so the straggler tail of one batch's kernels overlaps the next batch's
    affinity build (the reference's loop [REF roman/align/submap_align.py:93-200] has no dependency

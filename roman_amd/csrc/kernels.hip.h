@@ -2751,11 +2751,12 @@ __device__ void solve_up(const DevParams& D, int b, const ProbDesc& pd, ProbStat
     const double p_eps = uni(P.eps), p_beta = uni(P.beta), p_tol_u = uni(P.tol_u), p_tol_F = uni(P.tol_F);
     const int p_maxin = uni(P.maxiniters), p_maxout = uni(P.maxoliters), p_maxls = uni(P.maxlsiters), p_rescale = uni(P.rescale_u0);
     const int tid = threadIdx.x, lane = tid & 63, w = uni(tid >> 6);
-    // FOR_K: the thread's elements that exist in THIS problem (k < ceil(L / NT): a problem of 2100 live associations uses five of the
-    // six element slots of the general instantiation, one of 60 one of the two of the one-wave instantiation — the slots behind
-    // are zero and stay zero, their share of the element-wise work is skipped); FOR_K_ALL: every slot (initialisation)
+    // FOR_K: the thread's elements; in the one-wave instantiation only those that exist in THIS problem (k < ceil(L / 64): a problem
+    // of 60 live associations uses one of the two element slots — the other is zero and stays zero, its half of the element-wise
+    // work, the bulk of a pass at this size, is skipped; in the general instantiation the same guard costs 20 registers and
+    // buys a sixth of 8 % of the time: not applied).  FOR_K_ALL: every slot (initialisation)
 #define FOR_K_ALL(k_, p_) _Pragma("unroll") for (int k_ = 0; k_ < KMAX; ++k_) if ([[maybe_unused]] const int p_ = tid + k_ * NT; true)
-#define FOR_K(k_, p_) _Pragma("unroll") for (int k_ = 0; k_ < KMAX; ++k_) if ([[maybe_unused]] const int p_ = tid + k_ * NT; true || k_ < kUsed)
+#define FOR_K(k_, p_) _Pragma("unroll") for (int k_ = 0; k_ < KMAX; ++k_) if ([[maybe_unused]] const int p_ = tid + k_ * NT; NW != 1 || k_ < kUsed)
     const int L = uni(st[b].L), rb = rbPre >= 0 ? rbPre : uni(st[b].rowBase);
     const int kUsed = uni((L + NT - 1) / NT);
     const int64_t lo = pd.liveOff;

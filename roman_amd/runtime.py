@@ -64,7 +64,7 @@ class Context:
             pass
 
     def set_pipeline(self, depth):
-        """Batches in flight (1 or 2), see roman_ctx_set_pipeline in include/roman_hip.h.  With depth 2 the
+        """Batches in flight (1 ... 6), see roman_ctx_set_pipeline in include/roman_hip.h.  With depth 2 the
         results of align_batch_dev calls are complete after sync() (or a device-wide synchronise)."""
         self._check(self._lib.roman_ctx_set_pipeline(self._h, int(depth)), "roman_ctx_set_pipeline")
 

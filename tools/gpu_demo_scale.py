@@ -44,17 +44,19 @@ for _ in range(10):
     call()
 torch.cuda.synchronize(dev)
 td = (time.perf_counter() - t0) / 10
-ctx.set_pipeline(3)                                             # three calls in flight, like bench.py's headline loop (the outputs are the same every call)
-for _ in range(3):
-    call()
-ctx.sync(); torch.cuda.synchronize(dev)
-t0 = time.perf_counter()
-host = []
-for _ in range(30):
-    h0 = time.perf_counter(); call(); host.append((time.perf_counter() - h0) * 1e3)
-ctx.sync(); torch.cuda.synchronize(dev)
-tp = (time.perf_counter() - t0) / 30
-print("host ms per call (pipelined loop):", " ".join(f"{h:.2f}" for h in host))
+tps = {}
+for depth in (3, 4, 6):                                         # calls in flight (the outputs are the same every call)
+    ctx.set_pipeline(depth)
+    for _ in range(depth):
+        call()
+    ctx.sync(); torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(60):
+        call()
+    ctx.sync(); torch.cuda.synchronize(dev)
+    tps[depth] = (time.perf_counter() - t0) / 60
+tp = tps[3]
+print("ms per call by calls in flight:", {k: round(v * 1e3, 3) for k, v in tps.items()})
 ctx.set_pipeline(1)
 ctx.profile_enable(True); ctx.profile_reset(); call(); torch.cuda.synchronize(dev); pf = ctx.profile_get(); ctx.profile_enable(False)
 st = np.frombuffer(O[4].cpu().numpy().tobytes(), dtype=stats_dtype())[:ND]
