@@ -743,8 +743,9 @@ int enqueue_solve(roman_ctx* c, const DevParams& D, int B, int64_t sumA, int64_t
     const bool lean = leanEnv && leanEnv[0] == '1' && D.stream_maxL <= LEAN_MAXL;
     // A handful of problems (the single-pair call whose latency bench.py reports): the wide passes are bound by how many bytes
     // ONE compute unit keeps in flight, not by the memory system — twice the quads in flight per lane (ROMAN_SOLVE_DEEP=0/1 forces).
+    // MEASURED (round 4, config 2, B = 1): p50 0.678 ms with six quads in flight against 0.667 with three — no gain: off unless forced.
     static const char* deepEnv = getenv("ROMAN_SOLVE_DEEP");
-    const bool deep = deepEnv ? deepEnv[0] == '1' : B <= std::max(1, c->num_cu / 16);
+    const bool deep = deepEnv && deepEnv[0] == '1';
 #define ROMAN_LAUNCH_UP(CZ_)                                                                                                  \
     do {                                                                                                                      \
         auto kup = lean ? k_solve_up<NW, CZ_, LEAN_MAXL, LEAN_D, true> : (deep ? k_solve_up<NW, CZ_, STREAM_MAXL, DEEP_D> : k_solve_up<NW, CZ_, STREAM_MAXL>); \
