@@ -925,20 +925,22 @@ __device__ __forceinline__ bool pair_gate(const DevParams& D, double a, double b
 // the table slices fit): the column data is read once for both, the two rows' instruction streams are
 // independent (the kernel is bound by LDS/VALU/scalar latency, not by any one pipe), and the loop overhead
 // is shared.  Per 64 columns and row: 2 LDS gathers, 12 f64 VALU ops, 2 address adds, 2 v_writelane.
-template <int GM, int NR>
+template <int GM, int NR, bool TILED>
 __device__ __forceinline__ void count_rows_lds(const DevParams& D, const ProbDesc& pd, int L, int row0, int nrows,
                                                int w, int wpb, int lane,
                                                const uint32_t* cIJ /* i_q | (n1 + 1 + j_q) << 16: table-slice indices */, const double2* cZZ,
                                                const double* __restrict__ TA, const double* __restrict__ TB,
                                                double* tA /* NR slices of ldsPerRow doubles */, int ldsPerRow,
                                                unsigned long long* __restrict__ mbase,
-                                               int c0 /* first column of the LDS tile */, int clen /* its columns (multiple of 256) */,
+                                               int c0_ /* first column of the LDS tile */, int clen /* its columns (multiple of 256) */,
                                                const int32_t* __restrict__ gI, const int32_t* __restrict__ gJ,
                                                const double* __restrict__ gZa, const double* __restrict__ gZb /* the rows' own data when the tile does not hold them (c0 > 0 or clen < Lpad) */)
 {
     const int W = (L + 63) >> 6;
-    const bool tiled = !(c0 == 0 && clen >= ((L + 255) & ~255));
-    const int cend = c0 + clen;
+    // TILED == false: the tile holds the whole live set (c0 = 0 folds away: the sweep is the one-tile code of rounds 1-3)
+    constexpr bool tiled = TILED;
+    const int c0 = TILED ? c0_ : 0;
+    const int cend = TILED ? c0 + clen : 0x7fffffff;
     const char* tbytes = reinterpret_cast<const char*>(tA);
     const int sliceBytes = ldsPerRow * 8;
     constexpr int U = 2;                                        // column chunks per step (with 2 rows per wave: 2 beats 1 and 4)
@@ -1003,7 +1005,7 @@ __device__ __forceinline__ void count_rows_lds(const DevParams& D, const ProbDes
         uint32_t mlo[NR], mhi[NR];                              // lane l: word (block*64 + l) of the current 64-word block
 #pragma unroll
         for (int x = 0; x < NR; ++x) { mlo[x] = 0u; mhi[x] = 0u; }
-        const int qEnd = min(Lpad, cend);                       // (a live set larger than the LDS tile is swept tile by tile: k_count)
+        const int qEnd = TILED ? min(Lpad, cend) : Lpad;        // (a live set larger than the LDS tile is swept tile by tile: k_count)
         for (int q0 = max((R << 6) & ~(U * WAVE - 1), c0); q0 < qEnd; q0 += U * WAVE) {
             int2 ij[U]; double2 zz[U];
 #pragma unroll
@@ -1030,9 +1032,9 @@ __device__ __forceinline__ void count_rows_lds(const DevParams& D, const ProbDes
                 }
             }
             const int wend = min(W, (q0 >> 6) + U);             // words [.., wend) are complete
-            if ((wend & 63) == 0 || wend == W || q0 + U * WAVE >= qEnd) {   // flush the block of <= 64 words, coalesced (also at the end of a tile)
+            if ((wend & 63) == 0 || wend == W || (TILED && q0 + U * WAVE >= qEnd)) {   // flush the block of <= 64 words, coalesced (also at the end of a tile)
                 const int wb = (wend - 1) & ~63;
-                const int wlo = max(R, c0 >> 6);                // words in front of this tile were written when their tile was swept
+                const int wlo = TILED ? max(R, c0 >> 6) : R;    // words in front of this tile were written when their tile was swept
 #pragma unroll
                 for (int x = 0; x < NR; ++x) {
                     const unsigned long long mreg = ((unsigned long long)mhi[x] << 32) | mlo[x];
@@ -1086,7 +1088,8 @@ __global__ void __launch_bounds__(1024) k_count(DevParams D, const ProbDesc* __r
         // The column data of the whole live set in LDS when it fits (the usual case); a larger live set (no semantic gate:
         // L = n1 * n2) is swept TILE BY TILE — the item's rows are staged once per tile (a row needs only the words at and
         // behind its own 64-row block: tiles in front of the item's first row are skipped).
-        const int cFirst = (Lpad <= TC) ? 0 : ((((it.row0 >> 6) << 6) / TC) * TC);
+        const bool onetile = Lpad <= TC;
+        const int cFirst = onetile ? 0 : ((((it.row0 >> 6) << 6) / TC) * TC);
         for (int c0 = cFirst; c0 < Lpad; c0 += TC) {
             const int clen = min(TC, Lpad - c0);
             __syncthreads();                    // every wave is done with the previous tile's columns
@@ -1097,8 +1100,12 @@ __global__ void __launch_bounds__(1024) k_count(DevParams D, const ProbDesc* __r
                 if (GM) cZZ[q] = v ? make_double2(lza[lo + qq], lzb[lo + qq]) : make_double2(0.0, 0.0);
             }
             __syncthreads();
-            count_rows_lds<GM, NR>(D, pd, L, it.row0, nrows, w, wpb, lane, cIJ, cZZ, TA, TB, tA, ldsPerWave / NR, maskPool + mo,
-                                   c0, clen, li + lo, lj + lo, lza + lo, lzb + lo);
+            if (onetile)
+                count_rows_lds<GM, NR, false>(D, pd, L, it.row0, nrows, w, wpb, lane, cIJ, cZZ, TA, TB, tA, ldsPerWave / NR, maskPool + mo,
+                                              0, clen, li + lo, lj + lo, lza + lo, lzb + lo);
+            else
+                count_rows_lds<GM, NR, true>(D, pd, L, it.row0, nrows, w, wpb, lane, cIJ, cZZ, TA, TB, tA, ldsPerWave / NR, maskPool + mo,
+                                             c0, clen, li + lo, lj + lo, lza + lo, lzb + lo);
         }
     }
 }
