@@ -1016,7 +1016,7 @@ __device__ __forceinline__ void count_rows_lds(const DevParams& D, const ProbDes
             }
 #pragma unroll
             for (int t = 0; t < U; ++t) {
-                const int widx = (q0 >> 6) + t;                 // words >= W are all-zero (sentinel columns)
+                const int widx = TILED ? uni_i((q0 >> 6) + t) : (q0 >> 6) + t;   // words >= W are all-zero (sentinel columns); (out-of-line tiled path: arguments arrive in vector registers)
 #pragma unroll
                 for (int x = 0; x < NR; ++x) {
                     const double a = *reinterpret_cast<const double*>(tbytes + x * sliceBytes + ij[t].x);
@@ -1045,6 +1045,33 @@ __device__ __forceinline__ void count_rows_lds(const DevParams& D, const ProbDes
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();                        // table slices are rewritten by the next rows
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
+// A work item of a live set that does not fit the LDS column tile (no semantic gate: L = n1 * n2): the item's rows are swept
+// against one tile of columns after the other (a row needs only the words at and behind its own 64-row block: the tiles in
+// front of the item's first row are skipped).  Out of line: the one-tile case keeps the code it had.
+template <int GM, int NR>
+__device__ __noinline__ void count_item_tiled(const DevParams& D, const ProbDesc& pd, int L, int row0, int nrows,
+                                              uint32_t* cIJ, double2* cZZ, const double* __restrict__ TA, const double* __restrict__ TB,
+                                              double* tA, int ldsPerRow, unsigned long long* __restrict__ mbase, int TC,
+                                              const int32_t* __restrict__ gI, const int32_t* __restrict__ gJ,
+                                              const double* __restrict__ gZa, const double* __restrict__ gZb)
+{
+    const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, w = uni_i(tid >> 6), wpb = nt >> 6;
+    L = uni_i(L); row0 = uni_i(row0); nrows = uni_i(nrows); TC = uni_i(TC); ldsPerRow = uni_i(ldsPerRow);   // (wave-uniform: back into scalar registers)
+    const int Lpad = (L + 255) & ~255;
+    for (int c0 = (((row0 >> 6) << 6) / TC) * TC; c0 < Lpad; c0 += TC) {
+        const int clen = min(TC, Lpad - c0);
+        __syncthreads();                        // every wave is done with the previous tile's columns
+        for (int q = tid; q < clen; q += nt) {
+            const int qq = c0 + q;
+            const bool v = qq < L;
+            cIJ[q] = v ? ((uint32_t)gI[qq] | ((uint32_t)(pd.n1 + 1 + gJ[qq]) << 16)) : ((uint32_t)pd.n1 | ((uint32_t)(pd.n1 + 1) << 16));
+            if (GM) cZZ[q] = v ? make_double2(gZa[qq], gZb[qq]) : make_double2(0.0, 0.0);
+        }
+        __syncthreads();
+        count_rows_lds<GM, NR, true>(D, pd, L, row0, nrows, w, wpb, lane, cIJ, cZZ, TA, TB, tA, ldsPerRow, mbase, c0, clen, gI, gJ, gZa, gZb);
     }
 }
 
@@ -1088,24 +1115,19 @@ __global__ void __launch_bounds__(1024) k_count(DevParams D, const ProbDesc* __r
         // The column data of the whole live set in LDS when it fits (the usual case); a larger live set (no semantic gate:
         // L = n1 * n2) is swept TILE BY TILE — the item's rows are staged once per tile (a row needs only the words at and
         // behind its own 64-row block: tiles in front of the item's first row are skipped).
-        const bool onetile = Lpad <= TC;
-        const int cFirst = onetile ? 0 : ((((it.row0 >> 6) << 6) / TC) * TC);
-        for (int c0 = cFirst; c0 < Lpad; c0 += TC) {
-            const int clen = min(TC, Lpad - c0);
-            __syncthreads();                    // every wave is done with the previous tile's columns
-            for (int q = tid; q < clen; q += nt) {
-                const int qq = c0 + q;
-                const bool v = qq < L;
-                cIJ[q] = v ? ((uint32_t)li[lo + qq] | ((uint32_t)(pd.n1 + 1 + lj[lo + qq]) << 16)) : ((uint32_t)pd.n1 | ((uint32_t)(pd.n1 + 1) << 16));
-                if (GM) cZZ[q] = v ? make_double2(lza[lo + qq], lzb[lo + qq]) : make_double2(0.0, 0.0);
+        if (Lpad <= TC) {                       // the usual case: the whole live set's columns in LDS
+            __syncthreads();                    // every wave is done with the previous item's columns
+            for (int q = tid; q < Lpad; q += nt) {
+                const bool v = q < L;
+                cIJ[q] = v ? ((uint32_t)li[lo + q] | ((uint32_t)(pd.n1 + 1 + lj[lo + q]) << 16)) : ((uint32_t)pd.n1 | ((uint32_t)(pd.n1 + 1) << 16));
+                if (GM) cZZ[q] = v ? make_double2(lza[lo + q], lzb[lo + q]) : make_double2(0.0, 0.0);
             }
             __syncthreads();
-            if (onetile)
-                count_rows_lds<GM, NR, false>(D, pd, L, it.row0, nrows, w, wpb, lane, cIJ, cZZ, TA, TB, tA, ldsPerWave / NR, maskPool + mo,
-                                              0, clen, li + lo, lj + lo, lza + lo, lzb + lo);
-            else
-                count_rows_lds<GM, NR, true>(D, pd, L, it.row0, nrows, w, wpb, lane, cIJ, cZZ, TA, TB, tA, ldsPerWave / NR, maskPool + mo,
-                                             c0, clen, li + lo, lj + lo, lza + lo, lzb + lo);
+            count_rows_lds<GM, NR, false>(D, pd, L, it.row0, nrows, w, wpb, lane, cIJ, cZZ, TA, TB, tA, ldsPerWave / NR, maskPool + mo,
+                                          0, Lpad, li + lo, lj + lo, lza + lo, lzb + lo);
+        } else {
+            count_item_tiled<GM, NR>(D, pd, L, it.row0, nrows, cIJ, cZZ, TA, TB, tA, ldsPerWave / NR, maskPool + mo, TC,
+                                     li + lo, lj + lo, lza + lo, lzb + lo);
         }
     }
 }
