@@ -1050,9 +1050,9 @@ __device__ __forceinline__ void count_rows_lds(const DevParams& D, const ProbDes
 
 // A work item of a live set that does not fit the LDS column tile (no semantic gate: L = n1 * n2): the item's rows are swept
 // against one tile of columns after the other (a row needs only the words at and behind its own 64-row block: the tiles in
-// front of the item's first row are skipped).  Out of line: the one-tile case keeps the code it had.
+// front of the item's first row are skipped).  Its own kernel instantiation (k_count<..., true>): the one-tile kernel keeps the code it had.
 template <int GM, int NR>
-__device__ __noinline__ void count_item_tiled(const DevParams& D, const ProbDesc& pd, int L, int row0, int nrows,
+__device__ __forceinline__ void count_item_tiled(const DevParams& D, const ProbDesc& pd, int L, int row0, int nrows,
                                               uint32_t* cIJ, double2* cZZ, const double* __restrict__ TA, const double* __restrict__ TB,
                                               double* tA, int ldsPerRow, unsigned long long* __restrict__ mbase, int TC,
                                               const int32_t* __restrict__ gI, const int32_t* __restrict__ gJ,
@@ -1075,7 +1075,7 @@ __device__ __noinline__ void count_item_tiled(const DevParams& D, const ProbDesc
     }
 }
 
-template <int GM, int NR>
+template <int GM, int NR, bool TILED>
 __global__ void __launch_bounds__(1024) k_count(DevParams D, const ProbDesc* __restrict__ probs,
                                                 const ProbState* __restrict__ st,
                                                 const BatchTotals* __restrict__ tot,
@@ -1115,7 +1115,10 @@ __global__ void __launch_bounds__(1024) k_count(DevParams D, const ProbDesc* __r
         // The column data of the whole live set in LDS when it fits (the usual case); a larger live set (no semantic gate:
         // L = n1 * n2) is swept TILE BY TILE — the item's rows are staged once per tile (a row needs only the words at and
         // behind its own 64-row block: tiles in front of the item's first row are skipped).
-        if (Lpad <= TC) {                       // the usual case: the whole live set's columns in LDS
+        // TILED == false: the items whose whole live set fits the LDS column tile (the usual case: one sweep per row);
+        // TILED == true (a second launch, only when such problems can exist): the others, tile by tile.
+        if ((Lpad <= TC) == TILED) continue;
+        if (!TILED) {
             __syncthreads();                    // every wave is done with the previous item's columns
             for (int q = tid; q < Lpad; q += nt) {
                 const bool v = q < L;

@@ -568,17 +568,23 @@ int enqueue_score(roman_ctx* c, const DevParams& Din, const roman_params_t* para
     DBG(c, "k_items");
     }
     if (sumA > 0 && !D.small_only) {
-        auto kc = NRc == 2 ? k_count<0, 2> : k_count<0, 1>;
-        switch (D.gmode) {
-        case 1: kc = NRc == 2 ? k_count<1, 2> : k_count<1, 1>; break;
-        case 2: kc = NRc == 2 ? k_count<2, 2> : k_count<2, 1>; break;
-        case 3: kc = NRc == 2 ? k_count<3, 2> : k_count<3, 1>; break;
-        default: break;
+        // two instantiations over the same items: the one-tile sweep for live sets that fit the LDS column tile, and — launched
+        // only when such problems can exist (fallback problems, or a tile capped by the LDS) — the tile-by-tile sweep for the rest
+        const bool needTiled = D.allow_fallback || TCc < Lneed;
+        for (int tiled = 0; tiled < (needTiled ? 2 : 1); ++tiled) {
+            const void* kc = nullptr;
+#define ROMAN_KC(GM_) kc = tiled ? (NRc == 2 ? reinterpret_cast<const void*>(k_count<GM_, 2, true>) : reinterpret_cast<const void*>(k_count<GM_, 1, true>)) \
+                                 : (NRc == 2 ? reinterpret_cast<const void*>(k_count<GM_, 2, false>) : reinterpret_cast<const void*>(k_count<GM_, 1, false>))
+            switch (D.gmode) { case 1: ROMAN_KC(1); break; case 2: ROMAN_KC(2); break; case 3: ROMAN_KC(3); break; default: ROMAN_KC(0); break; }
+#undef ROMAN_KC
+            HIPCHK(c, dyn_lds(c, kc, pairLds));
+            DevParams a_D = D; const ProbDesc* a_dP = dP; const ProbState* a_dS = dS; const BatchTotals* a_dT = dT; const ItemDesc* a_items = WS.items.as<ItemDesc>();
+            const double* a_tab = WS.tabPool.as<double>(); const int32_t* a_li = LP.li; const int32_t* a_lj = LP.lj; const double* a_za = LP.lza; const double* a_zb = LP.lzb;
+            uint32_t* a_rc = WS.rowCnt.as<uint32_t>(); unsigned long long* a_mask = WS.maskPool.as<unsigned long long>(); uint32_t* a_pref = WS.prefPool.as<uint32_t>();
+            int a_TC = TCc, a_lpw = ldsPerWave, a_RPB = RPB;
+            void* args[] = {&a_D, &a_dP, &a_dS, &a_dT, &a_items, &a_tab, &a_li, &a_lj, &a_za, &a_zb, &a_rc, &a_mask, &a_pref, &a_TC, &a_lpw, &a_RPB};
+            HIPCHK(c, hipLaunchKernel(kc, dim3(pairGrid), dim3(wpb * 64), args, pairLds, WS.stream));
         }
-        HIPCHK(c, dyn_lds(c, reinterpret_cast<const void*>(kc), pairLds));
-        hipLaunchKernelGGL(kc, dim3(pairGrid), dim3(wpb * 64), pairLds, WS.stream, D, dP, dS, dT, WS.items.as<ItemDesc>(), WS.tabPool.as<double>(),
-                           LP.li, LP.lj, LP.lza, LP.lzb,
-                           WS.rowCnt.as<uint32_t>(), WS.maskPool.as<unsigned long long>(), WS.prefPool.as<uint32_t>(), TCc, ldsPerWave, RPB);
     DBG(c, "k_count");
         {   // lower triangle of the bit matrices = transposed blocks of the upper triangle (grid for the expected size;
             // the kernel loops when a problem is larger)
