@@ -5,7 +5,8 @@
 #         smoke                      __graft_entry__.smoke()
 #         bench[:<extra args>]       python bench.py <args>  (default: --steps 20 --warmup 5)
 #         prof[:<bench args>]        rocprofv3 --kernel-trace --stats of bench.py <args> (default: B=256 launches only)
-#         pmc                        rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE / SQ set) of the same, summarised by tools/pmc_summary.py
+#         pmc[:<bench args>]         rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE / two SQ sets incl. MFMA busy and LDS bank conflicts) of the
+#                                    same (or of bench.py <args>), each pass on its own with --kernel-trace only, summarised by tools/pmc_summary.py
 #         large[:<n>]                tools/gpu_large_case.py <n> (large-live-set solver, default 200)
 #         ubench:<name>              tools/ubench/<name> (prebuilt binary travels with the snapshot)
 #         py:<script and args>       python <script and args>
@@ -25,9 +26,9 @@ for step in "$@"; do
     prof)  ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof -o bench -- python $REPO/bench.py ${arg:---steps 5 --warmup 2 --pipeline 1 --latency-reps -1 --cpu-sample 0 --no-extras} > $OUT/${TAG}_prof_bench.txt 2>$OUT/${TAG}_prof.err ); echo "rocprof rc=$?"
            F=$(find $OUT/${TAG}_prof -name "*kernel_stats.csv" | head -1); [ -n "$F" ] && cp "$F" $OUT/${TAG}_kernel_stats.csv && head -24 "$F" | cut -c1-200
            find $OUT/${TAG}_prof -name "*kernel_trace.csv" -size +20M -delete ;;
-    pmc)   for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU"; do
+    pmc)   for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU" "SQ_WAVES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_INSTS_LDS SQ_INSTS_SALU"; do
              g=$(echo $grp | tr ' ' '_' | cut -c1-24)
-             ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/${TAG}_pmc/$g -o bench -- python $REPO/bench.py --steps 3 --warmup 2 --pipeline 1 --latency-reps -1 --cpu-sample 0 --no-extras > /dev/null 2>$OUT/${TAG}_pmc_$g.err ); echo "pmc $g rc=$?"
+             ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/${TAG}_pmc/$g -o bench -- python $REPO/bench.py ${arg:---steps 3 --warmup 2 --pipeline 1 --latency-reps -1 --cpu-sample 0 --no-extras} > /dev/null 2>$OUT/${TAG}_pmc_$g.err ); echo "pmc $g rc=$?"
              find $OUT/${TAG}_pmc/$g -name "*kernel_trace.csv" -size +20M -delete
            done
            python tools/pmc_summary.py $OUT/${TAG}_pmc > $OUT/${TAG}_pmc_summary.txt 2>&1; tail -40 $OUT/${TAG}_pmc_summary.txt ;;
