@@ -35,7 +35,7 @@ for n in sorted(names, key=lambda x: -table[x].get("SQ_WAVE_CYCLES", 0)):
         print(f"   -> wait_any/wave_cycles={t.get('SQ_WAIT_ANY',0)/wc:.2f} wait_inst_any={t.get('SQ_WAIT_INST_ANY',0)/wc:.2f} active_inst_any={t.get('SQ_ACTIVE_INST_ANY',0)/wc:.2f}"
               f" valu_insts/wave={t.get('SQ_INSTS_VALU',0)/max(t.get('SQ_WAVES',1),1):.0f} salu/wave={t.get('SQ_INSTS_SALU',0)/max(t.get('SQ_WAVES',1),1):.0f}")
     if "SQ_VALU_MFMA_BUSY_CYCLES" in t and t.get("SQ_BUSY_CYCLES", 0) > 0:
-        print(f"   -> mfma_busy/sq_busy={t['SQ_VALU_MFMA_BUSY_CYCLES'] / t['SQ_BUSY_CYCLES']:.3f} (cycles the matrix pipe is busy / cycles the SQ is busy, summed over SEs)")
+        print(f"   -> matrix pipe busy {t['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024:.0f} cycles per SIMD and launch (1024 SIMDs; divide by the launch's duration in cycles for the busy fraction)")
     if "SQ_LDS_IDX_ACTIVE" in t and t["SQ_LDS_IDX_ACTIVE"] > 0:
         print(f"   -> lds_bank_conflict/lds_idx_active={t.get('SQ_LDS_BANK_CONFLICT', 0) / t['SQ_LDS_IDX_ACTIVE']:.3f} lds_insts/wave={t.get('SQ_INSTS_LDS', 0) / max(t.get('SQ_WAVES', 1), 1):.0f}")
     if "FETCH_SIZE" in t or "WRITE_SIZE" in t:
