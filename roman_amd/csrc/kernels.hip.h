@@ -381,6 +381,105 @@ __global__ void __launch_bounds__(256) k_cos(DevParams D, int B, int G /* workgr
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_cos_wave: the reference's DEMO scale (submaps of at most 48 objects): ONE WAVE computes a problem's whole cosine matrix —
+// up to 3 x 3 MFMA blocks in registers, operands straight from global memory with 32-byte loads (the descriptors of a few
+// hundred small submaps are L2-resident), no LDS, no barrier.  k_cos_tile gives such a problem a 4-wave workgroup that
+// meets at a barrier 48 times (768-d descriptors) to multiply at most 9 blocks: 0.32 ms per 4096 problems, three times the
+// matrix pipe's own time.  Per 16 descriptor elements a lane loads 4 consecutive doubles of each of its <= 3 + 3 rows and
+// feeds element t of every load to the MFMAs of step t: the contraction order of every output element — chunks of 16
+// ascending, step t of a chunk contracts k = k0 + 4 * (lane >> 4) + t — and the norm sums are k_cos's own: identical bits.
+// Blocks that hold no object (n <= 32: the third, n <= 16: the second) are skipped, wave-uniformly.
+// ---------------------------------------------------------------------------------------------
+constexpr int COSW_NB = 3;               // MFMA blocks per dimension a wave can hold: maps of up to 48 objects
+
+__global__ void __launch_bounds__(256) k_cos_wave(DevParams D, int B, const ProbDesc* __restrict__ probs,
+                                                  const double* __restrict__ feats, double* __restrict__ cosPool)
+{
+    const int b = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    if (b >= B) return;
+    const ProbDesc pd = probs[b];
+    if (pd.n1 <= 0 || pd.n2 <= 0) return;
+    const int lane = threadIdx.x & 63;
+    const int Fc = D.p.cos_feature_dim, coff = D.p.point_dim + D.p.ratio_feature_dim;
+    const int lr = lane & 15, kq = lane >> 4;
+    const int nbi = uni_i((pd.n1 + 15) >> 4), nbj = uni_i((pd.n2 + 15) >> 4);      // blocks in use per dimension (<= COSW_NB)
+    const double* fa[COSW_NB]; const double* fb[COSW_NB]; bool va[COSW_NB], vb[COSW_NB];
+#pragma unroll
+    for (int h = 0; h < COSW_NB; ++h) {
+        const int ia = 16 * h + lr, jb = 16 * h + lr;
+        va[h] = ia < pd.n1; vb[h] = jb < pd.n2;
+        fa[h] = feats + (pd.off1 + (va[h] ? ia : 0)) * D.F + coff + 4 * kq;
+        fb[h] = feats + (pd.off2 + (vb[h] ? jb : 0)) * D.F + coff + 4 * kq;
+    }
+    double4_t acc[COSW_NB][COSW_NB];
+#pragma unroll
+    for (int x = 0; x < COSW_NB; ++x)
+#pragma unroll
+        for (int y = 0; y < COSW_NB; ++y) acc[x][y] = double4_t{0.0, 0.0, 0.0, 0.0};
+    double sa[COSW_NB], sb[COSW_NB];
+#pragma unroll
+    for (int h = 0; h < COSW_NB; ++h) { sa[h] = 0.0; sb[h] = 0.0; }
+    int k0 = 0;
+    for (; k0 + 16 <= Fc; k0 += 16) {
+        d4u_t a[COSW_NB], bq[COSW_NB];
+#pragma unroll
+        for (int h = 0; h < COSW_NB; ++h) {
+            if (h < nbi) a[h] = *reinterpret_cast<const d4u_t*>(fa[h] + k0); else a[h] = d4u_t{{0.0, 0.0, 0.0, 0.0}};
+            if (h < nbj) bq[h] = *reinterpret_cast<const d4u_t*>(fb[h] + k0); else bq[h] = d4u_t{{0.0, 0.0, 0.0, 0.0}};
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+#pragma unroll
+            for (int h = 0; h < COSW_NB; ++h) { sa[h] = fma(a[h].v[t], a[h].v[t], sa[h]); sb[h] = fma(bq[h].v[t], bq[h].v[t], sb[h]); }
+#pragma unroll
+            for (int x = 0; x < COSW_NB; ++x)
+#pragma unroll
+                for (int y = 0; y < COSW_NB; ++y)
+                    if (x < nbi && y < nbj) acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(va[x] ? a[x].v[t] : 0.0, vb[y] ? bq[y].v[t] : 0.0, acc[x][y], 0, 0, 0);
+        }
+    }
+    if (k0 < Fc) {                                   // ragged tail of the descriptor (< 16 elements)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int kk = k0 + 4 * kq + t;
+            const bool vk = kk < Fc;
+            double av[COSW_NB], bv[COSW_NB];
+#pragma unroll
+            for (int h = 0; h < COSW_NB; ++h) {
+                av[h] = (h < nbi && va[h] && vk) ? fa[h][k0 + t] : 0.0;
+                bv[h] = (h < nbj && vb[h] && vk) ? fb[h][k0 + t] : 0.0;
+                sa[h] = fma(av[h], av[h], sa[h]); sb[h] = fma(bv[h], bv[h], sb[h]);
+            }
+#pragma unroll
+            for (int x = 0; x < COSW_NB; ++x)
+#pragma unroll
+                for (int y = 0; y < COSW_NB; ++y)
+                    if (x < nbi && y < nbj) acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[x], bv[y], acc[x][y], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < COSW_NB; ++h) {              // every lane (lr, *) ends with the norm of row 16h + lr
+        sa[h] += __shfl_xor(sa[h], 16); sa[h] += __shfl_xor(sa[h], 32);
+        sb[h] += __shfl_xor(sb[h], 16); sb[h] += __shfl_xor(sb[h], 32);
+        sa[h] = sqrt(sa[h]); sb[h] = sqrt(sb[h]);
+    }
+#pragma unroll
+    for (int y = 0; y < COSW_NB; ++y) {
+        const int col = 16 * y + lr;
+        const double nb = sb[y];
+#pragma unroll
+        for (int x = 0; x < COSW_NB; ++x)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * x + kq + 4 * r;
+                const double na = __shfl(sa[x], kq + 4 * r);       // norm of row 16x + (kq + 4r): held by lanes with lr == kq + 4r
+                if (row < pd.n1 && col < pd.n2)
+                    cosPool[pd.cosOff + (int64_t)row * pd.n2 + col] = D.pruned ? acc[x][y][r] : ((na > 0.0 && nb > 0.0) ? acc[x][y][r] / (na * nb) : 0.0);
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_cos_tile<KC>: the same products, operands staged through LDS.  A workgroup (4 waves) owns an output tile of up to 64x64,
 // wave (wy, wx) the 2x2 MFMA blocks of its quarter.  Per stage of KC descriptor elements the 256 threads copy the tile's
 // row pieces of KC doubles from global memory to LDS with 16-byte loads whose lanes run ALONG a row (SEGS lanes cover one

@@ -352,6 +352,12 @@ static hipError_t launch_cos(roman_ctx* c, hipStream_t stream, const DevParams& 
 {
     static const char* env = getenv("ROMAN_COS");
     const int mode = env ? atoi(env) : 16;
+    static const char* waveEnv = getenv("ROMAN_COS_WAVE");      // "0": never the one-wave-per-problem kernel (A/B)
+    if (mode != 0 && maxN1 <= 16 * COSW_NB && maxN2 <= 16 * COSW_NB && !(waveEnv && waveEnv[0] == '0')) {
+        // the reference's demo scale: one wave per problem, no LDS, no barrier (k_cos_wave)
+        hipLaunchKernelGGL(k_cos_wave, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, stream, D, B, dP, feats, cosPool);
+        return hipGetLastError();
+    }
     if (mode == 0) {
         const int tiles = ((maxN1 + COS_TILE - 1) / COS_TILE) * ((maxN2 + COS_TILE - 1) / COS_TILE), G = (tiles + 3) / 4;
         hipLaunchKernelGGL(k_cos, dim3((unsigned)(G * ((B + 7) / 8) * 8)), dim3(256), 0, stream, D, B, G, dP, feats, cosPool);

@@ -165,7 +165,9 @@ def test_mfma_cosine_kernel(ctx, n1, n2, d):
 @pytest.mark.parametrize("n1,n2,d", [(16, 16, 4), (20, 24, 16), (37, 53, 70), (64, 64, 512), (9, 7, 768), (5, 3, 1),
                                      # the tiled kernel's cases: several balanced tiles, waves owning block rows (n1 >= n2 per tile) and block
                                      # columns (the transposed product), descriptor lengths with 0, 1, 2, 3 full stages of 16 and a ragged one
-                                     (65, 17, 33), (200, 200, 48), (130, 40, 16), (40, 130, 31), (49, 49, 15), (1, 1, 16), (63, 200, 96)])
+                                     (65, 17, 33), (200, 200, 48), (130, 40, 16), (40, 130, 31), (49, 49, 15), (1, 1, 16), (63, 200, 96),
+                                     # maps of at most 48 objects: the one-wave-per-problem kernel (k_cos_wave), 1-3 blocks per dimension
+                                     (40, 40, 768), (48, 48, 100), (33, 47, 70), (17, 48, 16), (32, 16, 37), (48, 1, 15)])
 def test_cosine_bits_equal_the_oracles_stated_order(ctx, orc, n1, n2, d):
     """The f64 matrix-core contraction accumulates in the order the oracle states (dot_fixed / norm_fixed in
     oracle/clipper_oracle.c): the cosine matrix is BIT-identical, so the cosine gate decides on the same value."""
