@@ -419,24 +419,41 @@ __global__ void __launch_bounds__(256) k_cos_wave(DevParams D, int B, const Prob
     double sa[COSW_NB], sb[COSW_NB];
 #pragma unroll
     for (int h = 0; h < COSW_NB; ++h) { sa[h] = 0.0; sb[h] = 0.0; }
+    // the loads of chunk k0 + 16 are in flight while chunk k0 is multiplied (two register sets; all loads unconditional —
+    // clamped to the last full chunk — so that the compiler waits with a count, not for an empty queue)
     int k0 = 0;
-    for (; k0 + 16 <= Fc; k0 += 16) {
-        d4u_t a[COSW_NB], bq[COSW_NB];
+    const int nfull = Fc >> 4;                       // full chunks of 16
+    d4u_t a[COSW_NB], bq[COSW_NB], a2[COSW_NB], b2[COSW_NB];
+    auto fetch = [&](d4u_t (&ra)[COSW_NB], d4u_t (&rb)[COSW_NB], int kk) {
 #pragma unroll
         for (int h = 0; h < COSW_NB; ++h) {
-            if (h < nbi) a[h] = *reinterpret_cast<const d4u_t*>(fa[h] + k0); else a[h] = d4u_t{{0.0, 0.0, 0.0, 0.0}};
-            if (h < nbj) bq[h] = *reinterpret_cast<const d4u_t*>(fb[h] + k0); else bq[h] = d4u_t{{0.0, 0.0, 0.0, 0.0}};
+            if (h < nbi) ra[h] = *reinterpret_cast<const d4u_t*>(fa[h] + kk); else ra[h] = d4u_t{{0.0, 0.0, 0.0, 0.0}};
+            if (h < nbj) rb[h] = *reinterpret_cast<const d4u_t*>(fb[h] + kk); else rb[h] = d4u_t{{0.0, 0.0, 0.0, 0.0}};
         }
+    };
+    auto multiply = [&](const d4u_t (&ra)[COSW_NB], const d4u_t (&rb)[COSW_NB]) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
 #pragma unroll
-            for (int h = 0; h < COSW_NB; ++h) { sa[h] = fma(a[h].v[t], a[h].v[t], sa[h]); sb[h] = fma(bq[h].v[t], bq[h].v[t], sb[h]); }
+            for (int h = 0; h < COSW_NB; ++h) { sa[h] = fma(ra[h].v[t], ra[h].v[t], sa[h]); sb[h] = fma(rb[h].v[t], rb[h].v[t], sb[h]); }
 #pragma unroll
             for (int x = 0; x < COSW_NB; ++x)
 #pragma unroll
                 for (int y = 0; y < COSW_NB; ++y)
-                    if (x < nbi && y < nbj) acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(va[x] ? a[x].v[t] : 0.0, vb[y] ? bq[y].v[t] : 0.0, acc[x][y], 0, 0, 0);
+                    if (x < nbi && y < nbj) acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(va[x] ? ra[x].v[t] : 0.0, vb[y] ? rb[y].v[t] : 0.0, acc[x][y], 0, 0, 0);
         }
+    };
+    if (nfull > 0) {
+        fetch(a, bq, 0);
+        for (int c = 0; c < nfull; c += 2) {
+            fetch(a2, b2, 16 * min(c + 1, nfull - 1));
+            multiply(a, bq);
+            if (c + 1 < nfull) {
+                fetch(a, bq, 16 * min(c + 2, nfull - 1));
+                multiply(a2, b2);
+            }
+        }
+        k0 = 16 * nfull;
     }
     if (k0 < Fc) {                                   // ragged tail of the descriptor (< 16 elements)
 #pragma unroll
