@@ -28,7 +28,8 @@ The printed JSON line also carries (rank 0, N=1; `--no-extras` leaves the side l
                        clipperpy sources (ROMAN_SINGLE_* x ROMAN_GRAV_*), and under random instead of all-ones starts;
   large_live           the large-live-set path (method 'gravity', every association live: k_solve_wide) with its own roofline;
   mid_live             64 pairs of method 'gravity' at n = m = 100 in ONE call (k_solve_wide in team mode), roofline + oracle check;
-  demo_scale           the scale the reference's demo configuration runs at (method 'roman', n, m in [20, 40], d = 768).
+  demo_scale           the scale the reference's demo configuration runs at (method 'roman', n, m in [20, 40], d = 768): 4096 DISTINCT
+                       pairs per call (the 64 x 64 grid of 128 distinct submaps), six calls in flight and one at a time.
 """
 import argparse
 import json

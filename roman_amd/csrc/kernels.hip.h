@@ -15,8 +15,12 @@
 //     k_fill_list  candidate lists -> values, one quad (4 entries per lane = row) at a time, straight into the layout
 //     k_solve_up   persistent per-problem CLIPPER solve on the upper triangle (pull + push SpMV)
 //   kind 1 (fallback, any L): symmetric sorted SELL-64 in live numbering: k_fill, then k_solve (a workgroup per
-//     problem) or k_solve_coop (cooperative launch: the whole device on one large problem at a time)
+//     problem) or k_solve_wide (cooperative launch: the whole device on one large problem at a time, or teams of compute
+//     units — the workgroups of an XCD or of half an XCD — on one problem each)
 //   kind 2: skipped for lack of workspace (k_skipped writes ROMAN_ST_WORKSPACE)
+//   kind 3: finished by k_small — batch calls, <= 128 live associations (the reference's demo scale): pair tests, positions,
+//     values, solve and pose in ONE kernel right behind k_live; the kernels above pass such a problem by
+//   (k_cos_wave: the cosine matrices of maps of at most 48 objects, one wave per problem)
 //
 // Matrix layout of kind 0: only the strict upper triangle of M in position numbering is stored
 // (entry (p,q), p < q, in row p) — 10 bytes per non-zero of the upper triangle.  Rows are cut into slices of 64

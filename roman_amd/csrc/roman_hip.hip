@@ -425,7 +425,7 @@ int enqueue_score(roman_ctx* c, const DevParams& Din, const roman_params_t* para
     // stream layout: as many live associations as the LDS tiles of this launch are sized for
     D.stream_maxL = std::min(STREAM_MAXL, std::max(64, (SZ.expectMaxL + 63) & ~63));
     { static const char* smEnv = getenv("ROMAN_STREAM_MAXL"); if (smEnv) D.stream_maxL = std::max(64, std::min(D.stream_maxL, atoi(smEnv))); }   // experiments: force the fallback layout for smaller live sets
-    // The fallback layout's kernels (symmetric SELL fill, k_solve / k_solve_coop) are launched only when a problem can
+    // The fallback layout's kernels (symmetric SELL fill, k_solve / k_solve_wide) are launched only when a problem can
     // need them: no history yet, a live set beyond the stream layout expected, or parameters only k_solve handles.  Else a
     // problem that turns out too large for the LDS tiles of this launch is skipped (ROMAN_ST_WORKSPACE) and, the
     // history corrected, takes them on its second run.
