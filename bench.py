@@ -228,10 +228,15 @@ def main():
             gat_i = torch.empty((world * CB, 2 + 2 * kmax), dtype=torch.int32, device=dev)
             gat_T = torch.empty((world * CB, 16), dtype=torch.float64, device=dev)
 
+            gstream = torch.cuda.Stream(dev)                       # the gathers' own stream: a collective never sits between two batch calls
+            ev_g = [None] * NSET                                   # behind the gather that read output set k
+
         def gather(k):                                             # collect inlier sets + poses of output set k on every rank
-            rec_i[:, 0] = O.n[k]; rec_i[:, 1] = O.status[k]; rec_i[:, 2:] = O.assoc[k].view(CB, -1)
-            dist.all_gather_into_tensor(gat_i, rec_i)
-            dist.all_gather_into_tensor(gat_T, O.T[k])
+            with torch.cuda.stream(gstream):
+                rec_i[:, 0] = O.n[k]; rec_i[:, 1] = O.status[k]; rec_i[:, 2:] = O.assoc[k].view(CB, -1)
+                dist.all_gather_into_tensor(gat_i, rec_i)
+                dist.all_gather_into_tensor(gat_T, O.T[k])
+                ev_g[k] = torch.cuda.Event(); ev_g[k].record(gstream)
 
         # h2d: pinned host copy of the pool, two device buffers, a copy stream
         if h2d:
@@ -246,10 +251,16 @@ def main():
 
         def launch(ci, k):
             o1, a1, o2, a2 = meta[ci]
+            if dist_on and ev_g[k] is not None:                    # output set k is rewritten: behind the gather that read it (NSET calls ago)
+                stream.wait_event(ev_g[k])
             ctx.align_batch_dev(P, fptr_now[0], F, o1, a1, o2, a2, kmax,
                                 O.assoc[k].data_ptr(), O.n[k].data_ptr(), O.T[k].data_ptr(), O.status[k].data_ptr(), O.stats[k].data_ptr())
 
-        loop = CallLoop(len(calls), NSET, args.pipeline, launch, lambda skip: ctx.join(skip_latest=skip), gather if dist_on else None)
+        # (with a process group the waits for finished calls go onto the gathers' stream: the context's stream — behind which every
+        #  batch call starts — stays free of them, and all `pipeline` calls stay in flight)
+        loop = CallLoop(len(calls), NSET, args.pipeline, launch,
+                        (lambda skip: ctx.join(skip_latest=skip, stream=gstream.cuda_stream)) if dist_on else (lambda skip: ctx.join(skip_latest=skip)),
+                        gather if dist_on else None)
 
         def step():
             fptr = feats.data_ptr()

@@ -1185,17 +1185,27 @@ int roman_ctx_set_pipeline(roman_ctx_t* c, int depth)
 // far: all of them (skip_latest == 0) or all but the most recent one (skip_latest != 0), so that work queued on
 // the caller's stream afterwards (e.g. the RCCL all_gather of batch k-1's records) sees their results while the
 // latest batch keeps running.
-int roman_ctx_join(roman_ctx_t* c, int skip_latest)
+int roman_ctx_join_on(roman_ctx_t* c, int skip_latest, void* stream)
 {
     if (!c) return fail(nullptr, ROMAN_E_INVALID, "ctx is NULL");
-    if (c->pipeline < 2) return ROMAN_OK;                       // everything already runs on the caller's stream
     HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t target = stream ? (hipStream_t)stream : c->stream;
+    if (c->pipeline < 2) {                                      // everything runs on the context's stream: another stream waits for what is queued there
+        if (target != c->stream) {
+            if (!c->evIn) HIPCHK(c, hipEventCreateWithFlags(&c->evIn, hipEventDisableTiming));
+            HIPCHK(c, hipEventRecord(c->evIn, c->stream));
+            HIPCHK(c, hipStreamWaitEvent(target, c->evIn, 0));
+        }
+        return ROMAN_OK;
+    }
     for (int k = 0; k < c->pipeline; ++k) {
         if (skip_latest && k == c->latest_ws) continue;
-        if (c->ws[k].done && c->ws[k].issued) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ws[k].done, 0));
+        if (c->ws[k].done && c->ws[k].issued) HIPCHK(c, hipStreamWaitEvent(target, c->ws[k].done, 0));
     }
     return ROMAN_OK;
 }
+
+int roman_ctx_join(roman_ctx_t* c, int skip_latest) { return roman_ctx_join_on(c, skip_latest, nullptr); }
 
 int roman_ctx_sync(roman_ctx_t* c)
 {

@@ -71,9 +71,13 @@ class Context:
     def sync(self):
         self._check(self._lib.roman_ctx_sync(self._h), "roman_ctx_sync")
 
-    def join(self, skip_latest=False):
-        """Make the context's stream wait for the pipelined batches issued so far (optionally all but the latest)."""
-        self._check(self._lib.roman_ctx_join(self._h, int(bool(skip_latest))), "roman_ctx_join")
+    def join(self, skip_latest=False, stream=None):
+        """Make the context's stream — or `stream` (a hipStream_t handle, e.g. torch.cuda.Stream.cuda_stream) — wait for the
+        pipelined batches issued so far (optionally all but the latest)."""
+        if stream is None:
+            self._check(self._lib.roman_ctx_join(self._h, int(bool(skip_latest))), "roman_ctx_join")
+        else:
+            self._check(self._lib.roman_ctx_join_on(self._h, int(bool(skip_latest)), C.c_void_p(int(stream))), "roman_ctx_join_on")
 
     def skipped(self, wait=True):
         """Running total of problems that batch calls on this context reported with ROMAN_ST_WORKSPACE
