@@ -143,6 +143,11 @@ def cpu_model():
 def main():
     args = parse()
     import types
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("ROMAN_BENCH_FORCE_DIST"):
+        # three internal streams + torch's + the gathers' + RCCL's own share the runtime's 4 hardware queues by default, and a wait
+        # queued on one of them holds back whatever another stream put behind it: 8 queues (measured at world size 1 with the
+        # process group forced on: 104 -> 112 k alignments/s; without a process group 4 queues are as good or better)
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
     import torch
     import torch.distributed as dist
@@ -221,7 +226,9 @@ def main():
         CB = chunk                                                 # rows of the output sets / gathered records
 
         # one output set per call in flight: call k writes set k % NSET while older sets are gathered
-        NSET = max(args.pipeline, 2)
+        # one output set per call in flight — and one more with a process group: the gather of call c - 1 runs on its own stream while
+        # call c computes, and the set call c + pipeline - 1 rewrites must not be the one that gather is still reading
+        NSET = max(args.pipeline, 2) + (1 if dist_on else 0)
         O = out_sets(CB, kmax, NSET)
         if dist_on:
             rec_i = torch.empty((CB, 2 + 2 * kmax), dtype=torch.int32, device=dev)

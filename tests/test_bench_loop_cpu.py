@@ -60,7 +60,7 @@ def _worker(rank, world, port, q, pipeline, n_calls, steps):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         rows = 5
-        nset = max(pipeline, 2)
+        nset = max(pipeline, 2) + 1                                  # (bench.py with a process group: one set more than calls in flight)
         ctx = StubContext(rank, nset, rows)
         gathered = []                                                # (step, ci) in gather order
         problems = []
