@@ -7,6 +7,6 @@ TAG=${1:-preflight}
 OUT=$PWD/gpurun_out; mkdir -p $OUT
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
 ROMAN_BENCH_FORCE_DIST=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29541 \
-    bench.py --gpus 1 --steps 10 --warmup 3 --no-extras --cpu-sample 0 > $OUT/${TAG}_dist1.txt 2> $OUT/${TAG}_dist1.err
+    bench.py --gpus 1 --steps 20 --warmup 5 --no-extras --cpu-sample 0 > $OUT/${TAG}_dist1.txt 2> $OUT/${TAG}_dist1.err
 echo "torchrun bench rc=$?"; tail -3 $OUT/${TAG}_dist1.err; python tools/bench_digest.py $OUT/${TAG}_dist1.txt
 timeout 300 python -m pytest tests -q -m gpu -k "align_sharded" 2>&1 | tail -3
