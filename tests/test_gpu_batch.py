@@ -661,3 +661,32 @@ def test_whole_device_solver_that_gives_up_says_so_for_every_problem(orc):
             assert res.status[b] == 0 and np.array_equal(res.assoc[b], o["assoc"])
     finally:
         c2.close()
+
+
+def test_problem_beyond_the_fused_small_path_after_a_history_of_small_ones(orc):
+    """Once every problem of a parameter block has been finished by k_small, the general kernels are not launched (`small_only`).
+    A batch that then contains a larger problem (more than 128 live associations) must still come out right: the problem is
+    skipped on the first attempt (ROMAN_ST_WORKSPACE), the history learns that the general kernels are needed, and the
+    host-pointer entry runs the batch again — every result equals the oracle's, the small ones included."""
+    from roman_amd.runtime import Context
+    c = Context(0)
+    try:
+        reg = registration_for("roman", semantics_dim=16); reg.set_context(c)
+        small = [synth.make_pair(14 + k % 5, 12 + k % 7, 16, 8000 + k, tilt_deg=1.0) for k in range(24)]
+        for _ in range(3):                                    # the history now says: k_small finishes everything
+            r0 = reg.register_and_align_batch([(p.map1, p.map2) for p in small])
+        assert (r0.stats["n_live"] <= 128).all() and ((r0.status == 0) | (r0.status == _abi.ROMAN_ST_INSUFFICIENT)).all()
+        for b, p in enumerate(small):
+            assert np.array_equal(r0.assoc[b], oracle_one(orc, reg, p.map1, p.map2)["assoc"])
+        big = synth.make_pair(90, 90, 16, 8100, tilt_deg=1.0, desc_noise=0.2)
+        mixed = small[:5] + [big] + small[5:9]
+        res = reg.register_and_align_batch([(p.map1, p.map2) for p in mixed])
+        assert res.stats["n_live"][5] > 128
+        for b, p in enumerate(mixed):
+            o = oracle_one(orc, reg, p.map1, p.map2)
+            assert np.array_equal(res.assoc[b], o["assoc"]) and not (res.status[b] & _abi.ROMAN_ST_WORKSPACE), b
+        res2 = reg.register_and_align_batch([(p.map1, p.map2) for p in small])          # and small batches keep working afterwards
+        for b in range(len(small)):
+            assert np.array_equal(res2.assoc[b], r0.assoc[b])
+    finally:
+        c.close()
