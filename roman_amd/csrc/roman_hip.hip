@@ -226,6 +226,7 @@ int make_dev_params(roman_ctx* c, const roman_params_t* p, int32_t F, DevParams*
     D->stream_maxL = STREAM_MAXL;
     D->allow_fallback = 1;
     { static const char* cooEnv = getenv("ROMAN_COO"); D->solve_flags = (cooEnv && cooEnv[0] == '0') ? 1 : 0; }   // ROMAN_COO=0: A/B switch of the one-wave solver's coordinate form
+    { static const char* rotEnv = getenv("ROMAN_FILL_ROTATE"); if (rotEnv && rotEnv[0] == '1') D->solve_flags |= 2; }   // experiment: rotated entry order inside a row
     return ROMAN_OK;
 }
 
@@ -1022,7 +1023,7 @@ int fetch_last_csr(const roman_ctx* cc, std::vector<uint32_t>& rs, std::vector<u
         for (int p = 0; p < L; ++p) {
             const uint32_t sl = (uint32_t)p >> 6, slot = (uint32_t)p & 63u;
             const uint32_t kp = jperm[(size_t)p];
-            for (uint32_t e = 0; e < jcnt[(size_t)p]; ++e) {
+            for (uint32_t e = 0; e < ((jcnt[(size_t)p] + 3u) & ~3u); ++e) {                         // (every slot of the row's quads: the fill may rotate them)
                 const uint32_t cq = jcols[h_col_pos(true, jsb[sl], slot, e)]; const double v = jvals[h_val_pos(true, jsb[sl], slot, e)];
                 const uint32_t q = cq & 0x7fffffffu;
                 if (q >= (uint32_t)L) continue;                                                      // inert slot (dummy column L + slot)
