@@ -2032,7 +2032,7 @@ __global__ void __launch_bounds__(1024) k_fill_list(DevParams D, int B, const Pr
             // once (LDS atomics onto one address serialise: SQ_LDS_BANK_CONFLICT 0.55 of the LDS-active cycles of k_solve_up).
             const uint32_t nq = (cnt + 3u) >> 2;
             uint32_t e0 = g << 2;
-            if (D.solve_flags & 2) { if (g < nq) e0 = ((g + (uint32_t)x * 5u) % nq) << 2; }
+            if (D.solve_flags & 2) { if (g < nq) { uint32_t gs = g + ((((uint32_t)x & 63u) * nq) >> 6); if (gs >= nq) gs -= nq; e0 = gs << 2; } }   // lane l starts l/64 of the way into its row
             uint2 qq = make_uint2(0u, 0u);
             if (e0 < cnt) qq = *reinterpret_cast<const uint2*>(lists + gOff[x] + e0);
             const int k = (kraw == 0xffffffffu) ? 0 : (int)kraw;
