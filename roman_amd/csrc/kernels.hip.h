@@ -60,8 +60,8 @@ struct DevParams {
                              // SKIPPED (kind 2, ROMAN_ST_WORKSPACE) and runs again with them (set per launch, from the sizing history)
     int32_t wide;            // fallback problems of this launch go to k_solve_wide (few, large) instead of k_solve (set per launch)
     int32_t idx16;           // ... and their column labels are 16 bits wide (no C flag; 0xffff = inert): 10 instead of 12 bytes per entry
-    int32_t solve_flags;     // experiments: bit 0 = the one-wave solver keeps the quad stream (no coordinate list in registers); bit 1 = k_fill_list rotates
-                             // the entries of a row (decorrelates the lanes' LDS pushes in the solver)
+    int32_t solve_flags;     // experiments: bit 0 = the one-wave solver keeps the quad stream (no coordinate list in registers); bit 1 = k_fill_list does NOT rotate
+                             // the entries of a row (the rotation decorrelates the lanes' LDS pushes in the solver)
     int32_t small_only;      // the general kernels are NOT part of this launch (every problem of this parameter block has so far been finished by
                              // k_small): a problem k_small leaves behind is skipped (kind 2, ROMAN_ST_WORKSPACE) and takes them on its second run
     int32_t stream_maxL;     // problems of up to this many live associations take the stream layout (<= STREAM_MAXL; set per launch:
@@ -2030,9 +2030,11 @@ __global__ void __launch_bounds__(1024) k_fill_list(DevParams D, int B, const Pr
             // entries is free (the solver's sums are exact), and the 64 rows of a slice — lanes of one wave — hold much the same
             // columns in the same (live-index) order: unrotated, the lanes of a solver step push onto the same few columns at
             // once (LDS atomics onto one address serialise: SQ_LDS_BANK_CONFLICT 0.55 of the LDS-active cycles of k_solve_up).
+            // Measured (round 4, two boxes, alternating): solver launch in flight 1.41-1.45 -> 1.36-1.37 ms, p50 0.665-0.674 -> 0.640 ms,
+            // throughput +0.5-1.5 %; starting lane l at l/64 of its row instead: p50 0.648.
             const uint32_t nq = (cnt + 3u) >> 2;
             uint32_t e0 = g << 2;
-            if (D.solve_flags & 2) { if (g < nq) { uint32_t gs = g + ((((uint32_t)x & 63u) * nq) >> 6); if (gs >= nq) gs -= nq; e0 = gs << 2; } }   // lane l starts l/64 of the way into its row
+            if (!(D.solve_flags & 2)) { if (g < nq) e0 = ((g + (uint32_t)x * 5u) % nq) << 2; }   // (ROMAN_FILL_ROTATE=0 keeps the list order)
             uint2 qq = make_uint2(0u, 0u);
             if (e0 < cnt) qq = *reinterpret_cast<const uint2*>(lists + gOff[x] + e0);
             const int k = (kraw == 0xffffffffu) ? 0 : (int)kraw;
