@@ -2031,13 +2031,11 @@ __global__ void __launch_bounds__(1024) k_fill_list(DevParams D, int B, const Pr
             // columns in the same (live-index) order: unrotated, the lanes of a solver step push onto the same few columns at
             // once (LDS atomics onto one address serialise: SQ_LDS_BANK_CONFLICT 0.55 of the LDS-active cycles of k_solve_up).
             // Measured (round 4, two boxes, alternating): solver launch in flight 1.41-1.45 -> 1.36-1.37 ms, p50 0.665-0.674 -> 0.640 ms,
-            // throughput +0.5-1.5 %; starting lane l at l/64 of its row instead: p50 0.648.
+            // throughput +0.5-1.5 %, isolated solver launch 1.09-1.11 -> 1.02-1.03 ms.  Starting lane l at l/64 of its row instead, with or
+            // without a further rotation inside the quad: 1.04-1.06 ms, p50 0.64-0.65 (same boxes, alternating): the plain one stays.
             const uint32_t nq = (cnt + 3u) >> 2;
             uint32_t e0 = g << 2;
-            const int rotv = (D.solve_flags >> 1) & 3;           // 0: x * 5 quads (default), 1: none, 2: lane l starts l/64 into its row, 3: 2 + rotation inside the quad
-            if (rotv == 0) { if (g < nq) e0 = ((g + (uint32_t)x * 5u) % nq) << 2; }
-            else if (rotv >= 2) { if (g < nq) { uint32_t gs = g + ((((uint32_t)x & 63u) * nq) >> 6); if (gs >= nq) gs -= nq; e0 = gs << 2; } }
-            const int jrot = rotv == 3 ? (lane & 3) : 0;
+            if (!(D.solve_flags & 2)) { if (g < nq) e0 = ((g + (uint32_t)x * 5u) % nq) << 2; }   // (ROMAN_FILL_ROTATE=0 keeps the list order)
             uint2 qq = make_uint2(0u, 0u);
             if (e0 < cnt) qq = *reinterpret_cast<const uint2*>(lists + gOff[x] + e0);
             const int k = (kraw == 0xffffffffu) ? 0 : (int)kraw;
@@ -2073,17 +2071,6 @@ __global__ void __launch_bounds__(1024) k_fill_list(DevParams D, int B, const Pr
                 cw[j] = keep ? (uint32_t)cP[q] : inert;
                 vv[j] = keep ? v : 0.0;
                 upper += keep ? 1u : 0u;                        // every stored entry is kept once: a strict-upper one
-            }
-            if (jrot) {                                         // slot j of the quad <- entry (j + lane) & 3
-                uint32_t c2[4]; double v2[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int sj = (j + jrot) & 3;
-                    c2[j] = sj == 0 ? cw[0] : sj == 1 ? cw[1] : sj == 2 ? cw[2] : cw[3];
-                    v2[j] = sj == 0 ? vv[0] : sj == 1 ? vv[1] : sj == 2 ? vv[2] : vv[3];
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { cw[j] = c2[j]; vv[j] = v2[j]; }
             }
             *reinterpret_cast<uint2*>(cols + sb + (int64_t)g * 256 + lane * 4) = make_uint2(cw[0] | (cw[1] << 16), cw[2] | (cw[3] << 16));
             *reinterpret_cast<double2*>(vals + sb + (int64_t)(2 * g) * 128 + lane * 2) = make_double2(vv[0], vv[1]);

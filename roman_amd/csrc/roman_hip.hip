@@ -226,11 +226,7 @@ int make_dev_params(roman_ctx* c, const roman_params_t* p, int32_t F, DevParams*
     D->stream_maxL = STREAM_MAXL;
     D->allow_fallback = 1;
     { static const char* cooEnv = getenv("ROMAN_COO"); D->solve_flags = (cooEnv && cooEnv[0] == '0') ? 1 : 0; }   // ROMAN_COO=0: A/B switch of the one-wave solver's coordinate form
-    {   // ROMAN_FILL_ROTATE: 1 (default) quads rotated by 5 * row, 0 list order, 2 lane l starts l/64 into its row, 3 = 2 + rotation inside the quad (A/B)
-        static const char* rotEnv = getenv("ROMAN_FILL_ROTATE");
-        const int v = rotEnv ? atoi(rotEnv) : 1;
-        D->solve_flags |= (v == 0 ? 1 : v == 2 ? 2 : v == 3 ? 3 : 0) << 1;
-    }
+    { static const char* rotEnv = getenv("ROMAN_FILL_ROTATE"); if (rotEnv && rotEnv[0] == '0') D->solve_flags |= 2; }   // ROMAN_FILL_ROTATE=0: list order inside a row (A/B)
     return ROMAN_OK;
 }
 
