@@ -2035,7 +2035,7 @@ __global__ void __launch_bounds__(1024) k_fill_list(DevParams D, int B, const Pr
             // without a further rotation inside the quad: 1.04-1.06 ms, p50 0.64-0.65 (same boxes, alternating): the plain one stays.
             const uint32_t nq = (cnt + 3u) >> 2;
             uint32_t e0 = g << 2;
-            if (!(D.solve_flags & 2)) { if (g < nq) e0 = ((g + (uint32_t)x * 5u) % nq) << 2; }   // (ROMAN_FILL_ROTATE=0 keeps the list order)
+            if (!(D.solve_flags & 2)) { if (g < nq) e0 = ((g + (uint32_t)x * (uint32_t)(D.solve_flags >> 8)) % nq) << 2; }   // (ROMAN_FILL_ROTATE=0 keeps the list order)
             uint2 qq = make_uint2(0u, 0u);
             if (e0 < cnt) qq = *reinterpret_cast<const uint2*>(lists + gOff[x] + e0);
             const int k = (kraw == 0xffffffffu) ? 0 : (int)kraw;

@@ -226,7 +226,11 @@ int make_dev_params(roman_ctx* c, const roman_params_t* p, int32_t F, DevParams*
     D->stream_maxL = STREAM_MAXL;
     D->allow_fallback = 1;
     { static const char* cooEnv = getenv("ROMAN_COO"); D->solve_flags = (cooEnv && cooEnv[0] == '0') ? 1 : 0; }   // ROMAN_COO=0: A/B switch of the one-wave solver's coordinate form
-    { static const char* rotEnv = getenv("ROMAN_FILL_ROTATE"); if (rotEnv && rotEnv[0] == '0') D->solve_flags |= 2; }   // ROMAN_FILL_ROTATE=0: list order inside a row (A/B)
+    {   // ROMAN_FILL_ROTATE=0: list order inside a row (A/B); =m: rotate a row's quads by m * row (default 5)
+        static const char* rotEnv = getenv("ROMAN_FILL_ROTATE");
+        const int m = rotEnv ? atoi(rotEnv) : 5;
+        if (m <= 0) D->solve_flags |= 2; else D->solve_flags |= (m & 0xffff) << 8;
+    }
     return ROMAN_OK;
 }
 
