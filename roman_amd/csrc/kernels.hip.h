@@ -2978,8 +2978,10 @@ __device__ void solve_up(const DevParams& D, int b, const ProbDesc& pd, ProbStat
             cooRounds = (int)((cnt + 63u) >> 6);
 #pragma unroll
             for (int e = 0; e < COO_E; ++e) {
-                const uint32_t at = (uint32_t)e * 64u + (uint32_t)lane;
-                const bool have = at < cnt;
+                // (lane l holds the CONSECUTIVE entries l R .. l R + R - 1: the list is row-major, so the 64 lanes of a round
+                //  push onto 64 different rows instead of onto the few rows 64 consecutive entries belong to)
+                const uint32_t at = (uint32_t)lane * (uint32_t)cooRounds + (uint32_t)e;
+                const bool have = e < cooRounds && at < cnt;
                 const uint32_t dummy = (uint32_t)L + (uint32_t)lane;
                 cpq[e] = have ? lpq[at] : (dummy | (dummy << 8) | 0x10000u);
                 cv[e] = have ? lv[at] : 0.0;
@@ -3009,8 +3011,8 @@ __device__ void solve_up(const DevParams& D, int b, const ProbDesc& pd, ProbStat
                 cooRounds = (int)((cnt + 63u) >> 6);
 #pragma unroll
                 for (int e = 0; e < COO_E; ++e) {
-                    const uint32_t at = (uint32_t)e * 64u + (uint32_t)lane;
-                    const bool have = at < cnt;
+                    const uint32_t at = (uint32_t)lane * (uint32_t)cooRounds + (uint32_t)e;   // (consecutive entries per lane, see above)
+                    const bool have = e < cooRounds && at < cnt;
                     const uint32_t dummy = (uint32_t)L + (uint32_t)lane;                // inert: value 0 between two dummy elements
                     cpq[e] = have ? lpq[at] : (dummy | (dummy << 8) | 0x10000u);
                     cv[e] = have ? lv[at] : 0.0;
