@@ -3387,6 +3387,14 @@ __global__ void __launch_bounds__(NW * 64, LEAN ? 4 : (NW == 1 ? 3 : 1)) k_solve
 // SMALL_PAIR_CAP candidates or COO_CAP stored pairs is left to the general path (kind stays 0); a finished one becomes kind 3.
 // ---------------------------------------------------------------------------------------------
 constexpr int SMALL_PAIR_CAP = 2304;      // candidate pairs the LDS of the solver's three vectors can list (16 bits each)
+// dynamic LDS of a k_small workgroup (the host launches with this): solver vectors | reduction scratch | slice table | sint | (16-byte
+// alignment) | coordinate list | column data z / single score / objects / positions / degrees of up to SMALL_MAXL live associations
+constexpr size_t small_lds_bytes()
+{
+    size_t o = (size_t)3 * 8 * (SMALL_MAXL + 64) + sizeof(double) * red_doubles(1) + sizeof(uint32_t) * (ST_MAXSL + 2) + sizeof(int) * 8;
+    o = (o + 15) & ~(size_t)15;
+    return o + (size_t)12 * COO_CAP + (size_t)SMALL_MAXL * (16 + 8 + 4 + 2 + 2);
+}
 
 __device__ __forceinline__ bool pair_gate_rt(const DevParams& D, int gm, double a, double bb, double dz)
 {
@@ -3426,6 +3434,7 @@ __global__ void __launch_bounds__(64, 3) k_small(DevParams D, int B, const ProbD
     uint16_t* posS = reinterpret_cast<uint16_t*>(cIJ + SMALL_MAXL);
     uint16_t* degS = posS + SMALL_MAXL;
     uint16_t* pairs = reinterpret_cast<uint16_t*>(smem);       // (the solver's vectors are not in use yet)
+    // (layout above == small_lds_bytes(): degS ends at cooLds + 12 COO_CAP + SMALL_MAXL (16 + 8 + 4 + 2 + 2))
     static_assert(SMALL_PAIR_CAP * 2 <= 3 * 8 * Lc1, "pair list fits the solver's vectors");
     const int lane = threadIdx.x;
     const int gm = D.gmode;

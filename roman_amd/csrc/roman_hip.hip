@@ -558,7 +558,7 @@ int enqueue_score(roman_ctx* c, const DevParams& Din, const roman_params_t* para
             HIPCHK(c, hipMemsetAsync(WS.queue.as<int>() + 8, 0, sizeof(int), WS.stream));
             const bool fast = D.single && (D.p.single_mode == ROMAN_SINGLE_BOTH || D.p.single_mode == ROMAN_SINGLE_OFFDIAG) && D.p.distance_weight == 1.0 &&
                               D.p.fusion_method != ROMAN_FUSE_ARITHMETIC_MEAN && D.p.fusion_method != ROMAN_FUSE_PRODUCT;      // (k_fill_list's own choice)
-            constexpr size_t ldsSmall = 14336;                 // 3 vectors of 192 + reduction scratch + coordinate list + the problem's columns
+            constexpr size_t ldsSmall = small_lds_bytes();     // 3 vectors of 192 + reduction scratch + coordinate list + the problem's columns (~14 KB)
             const int grid = std::max(1, std::min(B, c->num_cu * 12));
             auto ks = fast ? k_small<true> : k_small<false>;
             hipLaunchKernelGGL(ks, dim3(grid), dim3(64), ldsSmall, WS.stream, D, B, dP, dS, in.feats, in.assoc, WS.tabPool.as<double>(),
