@@ -89,6 +89,23 @@ def test_register_and_t_align_match_reference_plugins(ctx, case):
             reg.T_align(pr.map1, pr.map2, assoc)
 
 
+@pytest.mark.parametrize("case", RCASES, ids=[f"{i}-{c['method']}" for i, c in enumerate(RCASES)])
+def test_batch_entry_matches_reference_plugins(ctx, case):
+    """The same golden cases through the BATCHED entry (register_and_align_batch -> roman_align_batch): problems of at most 128
+    live associations are finished by the fused small-problem kernel (k_small) — every method string of the factory, 2-D points,
+    explicit (pruned) association lists, the all-pruned case — larger ones by the general path; twice, so that the second call
+    runs with the sizing history (and, where every problem was k_small's, without the general kernels)."""
+    reg = registration_for(case["method"], **case["kw"]); reg.set_context(ctx)
+    pr = golden_pair(case)
+    for _ in range(2):
+        res = reg.register_and_align_batch([(pr.map1, pr.map2), (pr.map2, pr.map1)])
+        assert np.array_equal(res.assoc[0].astype(np.int64), case["assoc"])
+        if len(case["assoc"]) >= reg.dim:
+            assert res.status[0] == 0 and np.linalg.norm(res.T[0] - case["T"]) < POSE_TOL
+        else:
+            assert res.status[0] & _abi.ROMAN_ST_INSUFFICIENT and np.all(np.isnan(res.T[0]))
+
+
 @pytest.mark.parametrize("case", GCASES, ids=[f"roll{c['roll']:+g}_pitch{c['pitch']:+g}" for c in GCASES])
 def test_gravity_constraint_error_raised_where_the_reference_raises(ctx, case):
     """Row a10 on the device path: `method='clipper+prune'` through roman_amd.align raises GravityConstraintError for exactly
