@@ -146,3 +146,19 @@ def test_world_size_2_gloo_matches_serial(which):
             assert np.allclose(np.array(T[b]), serial.T[b], equal_nan=True)
         assert status == serial.status.tolist()
     assert any(len(a) >= 3 for a in outs[0][1])
+
+
+def test_records_without_a_result_raise_on_every_rank_alike():
+    """check_records() runs on the GATHERED statuses (identical on every rank, so every rank raises or none does): a problem the
+    library gave up on (ROMAN_ST_INTERNAL) or that found no workspace after the retries (ROMAN_ST_WORKSPACE) is an error, the
+    reference's own per-pair conditions (insufficient associations, empty map, iteration limit, ties) are not."""
+    from roman_amd import RomanHipError, _abi
+    from roman_amd.align.distributed import check_records
+    ok = np.array([0, _abi.ROMAN_ST_INSUFFICIENT, _abi.ROMAN_ST_EMPTY_MAP | _abi.ROMAN_ST_INSUFFICIENT, _abi.ROMAN_ST_MAXITER,
+                   _abi.ROMAN_ST_TIE_FALLBACK, _abi.ROMAN_ST_ASSOC_TRUNCATED], dtype=np.int32)
+    check_records(ok)
+    for bad in (_abi.ROMAN_ST_INTERNAL, _abi.ROMAN_ST_WORKSPACE, _abi.ROMAN_ST_INTERNAL | _abi.ROMAN_ST_INSUFFICIENT):
+        st = ok.copy(); st[3] = bad
+        with pytest.raises(RomanHipError, match="without a result") as ei:
+            check_records(st)
+        assert "[3]" in str(ei.value)
