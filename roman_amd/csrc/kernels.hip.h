@@ -691,6 +691,211 @@ __global__ void __launch_bounds__(256) k_cos_tile(DevParams D, int B, int G /* w
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_cos_deal<T>: the cosine matrices of a BATCH of mid-size maps (config 3: 256 pairs of 200 x 200 objects).  k_cos_tile's tiles
+// are at most 4 x 4 blocks and a wave owns one block row of its tile: at 13 blocks per dimension (200 objects) the balanced
+// tiling is 3 + 3 + 3 + 4, nine of the sixteen tiles are 3 x 3 and leave one wave of four without a block — the matrix pipe
+// cannot be busier than 169 / 256 of the time (measured: 0.5).  Here a tile is up to T x T blocks (T = 5; 13 blocks: 5 + 4 + 4)
+// and its BLOCKS are dealt to the four waves as equal runs of the row-major block list — 25, 20, 16 blocks: 6-7, 5, 4 per wave,
+// 169 of 172 block slots used —; a wave holds up to 7 accumulators, reads the operands of its next block from LDS in front of
+// the MFMAs of the current one, and a staged row feeds 4-5 blocks instead of 3-4.  LDS: two stages of (80 + 80) row pieces of
+// 16 doubles = 46 KB, 153 registers: three workgroups per compute unit.
+// Measured alone on config 3's shape (tools/ubench/cos_time.hip, one box): k_cos_tile 361 us, T = 7 (two workgroups per CU, 13
+// accumulators) 344, T = 6 362, T = 5 321, T = 4 365; in the batch pipeline (rocprofv3) 322 -> 290 us.  The same tool strips parts
+// of the kernel: without global loads, LDS stores, barriers and norms the T = 5 loop takes 208 us (the matrix pipe's own time for
+// this deal), and every part that is put back costs 20-80 us, sub-additively — because the kernel is POWER-bound: a probe wave
+// per XCD (clock64 against wall_clock64) sees the shader clock fall from 2.4 GHz (idle) to 2.1-2.2 GHz under the stripped loop
+// and to 1.7-2.0 GHz under the complete kernel (k_cos_tile alike).  What makes this kernel faster is less work per MFMA.
+// The launcher picks it when the batch has at least two workgroups per compute unit of such tiles; a single alignment keeps
+// k_cos_tile's sixteen small tiles (latency).
+// Bits: a block's MFMA sequence is k_cos's own (chunks of 16 ascending, MFMA t of a chunk contracts k = k0 + 4 (lane >> 4) + t);
+// the norms are summed by a separate pass over the staged rows in the order of k_cos_tile's (lane (lr, kq): its k's ascending,
+// then the two cross-quarter adds) and handed over through LDS.  Identical bits.
+// ---------------------------------------------------------------------------------------------
+constexpr int COSD_PITCH = 16 * 8 + 16;          // bytes per staged row piece (k_cos_tile<16>'s)
+template <int T> struct CosDeal {                // T: blocks per tile and dimension
+    static constexpr int ROWS = 2 * 16 * T;      // staged row pieces: A rows 0..16T-1, B rows 16T..32T-1
+    static constexpr int STAGE = ROWS * COSD_PITCH;
+    static constexpr int MAXB = (T * T + 3) / 4; // blocks of a wave
+    static constexpr int LDS = 2 * STAGE + ROWS * 8;                    // two stages + the norms
+    static constexpr int WAVES = T <= 5 ? 3 : 2; // waves per SIMD the registers are capped for (workgroups per compute unit)
+    __device__ __host__ static int tiles(int n) { return (((n + 15) >> 4) + T - 1) / T; }
+};
+
+template <int T, int DBG /* 0; tools/ubench/cos_time.hip strips parts of the kernel to time the rest: 1 no loads in the loop, 2 no LDS stores / barriers, 4 no MFMAs, 8 no norms */>
+__global__ void __launch_bounds__(256, CosDeal<T>::WAVES) k_cos_deal(DevParams D, int B, int G /* workgroups (tiles) per problem */,
+                                                     const ProbDesc* __restrict__ probs,
+                                                     const double* __restrict__ feats,
+                                                     double* __restrict__ cosPool)
+{
+    using CD = CosDeal<T>;
+    constexpr int KC = 16, PITCH = COSD_PITCH, SEGS = KC / 2, RPI = 256 / SEGS, NLD = CD::ROWS / RPI, STAGE = CD::STAGE, MAXB = CD::MAXB;
+    static_assert(NLD * RPI == CD::ROWS, "the workgroup's loads cover a stage exactly");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double* nrm = reinterpret_cast<double*>(smem + 2 * STAGE);          // norm of staged row r
+    // eight problems or more: all tiles of a problem on one XCD (they share its rows); fewer (grid = B * G): tiles over all XCDs
+    const int xcd = blockIdx.x & 7, slot = B >= 8 ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, w = uni_i(tid >> 6);
+    const int b = B >= 8 ? (slot / G) * 8 + xcd : slot / G;
+    if (b >= B) return;
+    const ProbDesc pd = probs[b];
+    const int ti_n = CD::tiles(pd.n1), tj_n = CD::tiles(pd.n2);
+    const int tile = slot % G;
+    if (tile >= ti_n * tj_n) return;
+    const int ti = tile / tj_n, tj = tile - ti * tj_n;
+    const int nbi = (pd.n1 + 15) >> 4, nbj = (pd.n2 + 15) >> 4;
+    const int bi0 = ti * nbi / ti_n, bj0 = tj * nbj / tj_n;                    // first block of the tile (balanced cut)
+    const int nbx = uni_i((ti + 1) * nbi / ti_n - bi0), nby = uni_i((tj + 1) * nbj / tj_n - bj0);   // blocks of the tile: 1..T
+    const int i0 = bi0 * 16, j0 = bj0 * 16;
+    const int iEnd = min(pd.n1, i0 + 16 * nbx), jEnd = min(pd.n2, j0 + 16 * nby);
+    const int Fc = D.p.cos_feature_dim, coff = D.p.point_dim + D.p.ratio_feature_dim;
+    const int lr = lane & 15, kq = lane >> 4;
+    // the wave's run of the tile's row-major block list (which wave takes which run rotates with the tile: a wave index is a SIMD)
+    const int wsr = (w + tile) & 3, nblk = nbx * nby;
+    const int e0 = uni_i(wsr * nblk / 4), cnt = uni_i((wsr + 1) * nblk / 4 - e0);        // <= MAXB
+    const int lanePart = lr * PITCH + 32 * kq;
+    int offA[MAXB], offB[MAXB]; bool newRow[MAXB];
+#pragma unroll
+    for (int m = 0; m < MAXB; ++m) {
+        const int e = min(e0 + m, nblk - 1), bx = e / nby, by = e - bx * nby;
+        offA[m] = uni_i(16 * bx * PITCH); offB[m] = uni_i((16 * T + 16 * by) * PITCH);
+        newRow[m] = uni_i((by == 0 && e0 + m < nblk) ? 1 : 0) != 0;
+    }
+
+    // the thread's share of a stage
+    const int seg = tid % SEGS, row0 = tid / SEGS;
+    const double* gp[NLD]; bool gv[NLD];
+#pragma unroll
+    for (int q = 0; q < NLD; ++q) {
+        const int r = q * RPI + row0;
+        const bool isA = r < 16 * T;
+        const int gr = isA ? i0 + r : j0 + r - 16 * T;
+        gv[q] = gr < (isA ? iEnd : jEnd);
+        gp[q] = feats + ((isA ? pd.off1 : pd.off2) + (gv[q] ? gr : 0)) * D.F + coff + 2 * seg;
+    }
+    // (no control flow around the loads of the main loop — k_cos_tile)
+    auto gload = [&](dbl2_t (&stg)[NLD], int k0) {
+#pragma unroll
+        for (int q = 0; q < NLD; ++q) {
+            const d2u_t t = *reinterpret_cast<const d2u_t*>(gp[q] + k0);
+            stg[q] = dbl2_t{t.v[0], t.v[1]};
+        }
+    };
+    auto gload_ragged = [&](dbl2_t (&stg)[NLD], int k0) {      // last stage of a descriptor that is no multiple of 16: element by element
+        const int k = k0 + 2 * seg;
+#pragma unroll
+        for (int q = 0; q < NLD; ++q) stg[q] = dbl2_t{k < Fc ? gp[q][k0] : 0.0, k + 1 < Fc ? gp[q][k0 + 1] : 0.0};
+    };
+    auto lstore = [&](const dbl2_t (&stg)[NLD], int buf) {
+#pragma unroll
+        for (int q = 0; q < NLD; ++q)                // rows behind the tile: zeros
+            *reinterpret_cast<dbl2_t*>(smem + buf * STAGE + (q * RPI + row0) * PITCH + seg * 16) = gv[q] ? stg[q] : dbl2_t{0.0, 0.0};
+    };
+
+    double4_t acc[MAXB];
+#pragma unroll
+    for (int m = 0; m < MAXB; ++m) acc[m] = double4_t{0.0, 0.0, 0.0, 0.0};
+    // norms: wave w sums the 16-row blocks w, w + 4, w + 8, ... of the stage's 2 T (those that hold rows of the tile)
+    constexpr int NNB = (2 * T + 3) / 4;
+    double sN[NNB]; bool nOn[NNB];
+#pragma unroll
+    for (int h = 0; h < NNB; ++h) {
+        const int hb = w + 4 * h;
+        sN[h] = 0.0;
+        nOn[h] = uni_i((hb < T ? hb < nbx : (hb < 2 * T && hb - T < nby)) ? 1 : 0) != 0;
+    }
+
+    // Operands of block m + 1 are read from LDS BEFORE the four MFMAs of block m are issued (two register sets): the wave never
+    // waits for LDS with an idle matrix pipe behind it.  The read behind the last block fetches that block again (offsets clamped).
+    // The norms' f64 FMAs (the units the f64 MFMAs occupy) come as one burst behind the stage's MFMAs: measured equal to spreading
+    // them between the blocks with their operands read ahead (tools/ubench/cos_time.hip).  A norm's own order — its lane's k
+    // ascending — is k_cos_tile's.
+    auto norm_sum = [&](int h, const dbl2_t& v0, const dbl2_t& v1) {
+        sN[h] = fma(v0.x, v0.x, sN[h]); sN[h] = fma(v0.y, v0.y, sN[h]); sN[h] = fma(v1.x, v1.x, sN[h]); sN[h] = fma(v1.y, v1.y, sN[h]);
+    };
+    auto compute = [&](int s) {
+        const unsigned char* base = smem + (s & 1) * STAGE + lanePart;
+        dbl2_t a0, a1, b0, b1;
+        a0 = *reinterpret_cast<const dbl2_t*>(base + offA[0]); a1 = *reinterpret_cast<const dbl2_t*>(base + offA[0] + 16);
+        b0 = *reinterpret_cast<const dbl2_t*>(base + offB[0]); b1 = *reinterpret_cast<const dbl2_t*>(base + offB[0] + 16);
+#pragma unroll
+        for (int m = 0; m < MAXB; ++m) {
+            if (m < cnt) {
+                dbl2_t na0 = a0, na1 = a1, nb0 = b0, nb1 = b1;
+                if (m + 1 < MAXB) {
+                    nb0 = *reinterpret_cast<const dbl2_t*>(base + offB[m + 1]); nb1 = *reinterpret_cast<const dbl2_t*>(base + offB[m + 1] + 16);
+                    if (newRow[m + 1]) {                 // the next block starts a block row: its A operand
+                        na0 = *reinterpret_cast<const dbl2_t*>(base + offA[m + 1]); na1 = *reinterpret_cast<const dbl2_t*>(base + offA[m + 1] + 16);
+                    }
+                }
+                if (!(DBG & 4)) {
+                    acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.x, b0.x, acc[m], 0, 0, 0);
+                    acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.y, b0.y, acc[m], 0, 0, 0);
+                    acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.x, b1.x, acc[m], 0, 0, 0);
+                    acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.y, b1.y, acc[m], 0, 0, 0);
+                } else { acc[m][0] += a0.x + b0.x; acc[m][1] += a0.y + b0.y; acc[m][2] += a1.x + b1.x; acc[m][3] += a1.y + b1.y; }
+                a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
+            }
+        }
+        if (!(DBG & 8)) {
+#pragma unroll
+            for (int h = 0; h < NNB; ++h)
+                if (nOn[h]) {
+                    const dbl2_t v0 = *reinterpret_cast<const dbl2_t*>(base + 16 * (w + 4 * h) * PITCH);
+                    const dbl2_t v1 = *reinterpret_cast<const dbl2_t*>(base + 16 * (w + 4 * h) * PITCH + 16);
+                    norm_sum(h, v0, v1);
+                }
+        }
+    };
+
+    // stage s is multiplied while the loads of stages s + 1 and s + 2 fly (k_cos_tile's loop)
+    const int SF = Fc / KC;
+    dbl2_t r0[NLD], r1[NLD];
+    if (SF > 0) {
+        gload(r0, 0);
+        gload(r1, min(1, SF - 1) * KC);
+        lstore(r0, 0);
+        __syncthreads();
+        for (int s = 0; s < SF; s += 2) {
+            if (!(DBG & 1)) gload(r0, min(s + 2, SF - 1) * KC);
+            compute(s);
+            if (!(DBG & 2)) { lstore(r1, 1); __syncthreads(); }
+            if (!(DBG & 1)) gload(r1, min(s + 3, SF - 1) * KC);
+            if (s + 1 < SF) compute(s + 1);
+            if (!(DBG & 2)) { lstore(r0, 0); __syncthreads(); }
+        }
+    }
+    if (SF * KC < Fc) {                              // (every wave is behind the last barrier: both LDS stages are free)
+        gload_ragged(r0, SF * KC);
+        lstore(r0, SF & 1);
+        __syncthreads();
+        compute(SF);
+    }
+#pragma unroll
+    for (int h = 0; h < NNB; ++h) {
+        double v = sN[h];
+        v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+        if (nOn[h] && kq == 0) nrm[16 * (w + 4 * h) + lr] = sqrt(v);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < MAXB; ++m) {
+        if (m < cnt) {
+            // acc[m][r] of lane (lr, kq) is element (kq + 4r, lr) of (block row bx) x (block column by)^T
+            const int e = e0 + m, bx = e / nby, by = e - bx * nby;
+            const int col = j0 + 16 * by + lr;
+            const double nb = nrm[16 * T + 16 * by + lr];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = i0 + 16 * bx + kq + 4 * r;
+                const double na = nrm[16 * bx + kq + 4 * r];
+                if (row < iEnd && col < jEnd)
+                    cosPool[pd.cosOff + (int64_t)row * pd.n2 + col] = D.pruned ? acc[m][r] : ((na > 0.0 && nb > 0.0) ? acc[m][r] / (na * nb) : 0.0);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_tables: TA[i][i'] (n1 x n1) and TB[j][j'] (n2 x n2).  Entry = horizontal distance (gravity)
 // or full distance (otherwise) between two objects of the same map; NaN when the two objects
 // coincide (distinctness) or are closer than mindist — every comparison against NaN is false, so

@@ -351,13 +351,28 @@ int make_solve_out(roman_ctx* c, int B, int64_t sumA, const BatchOut& out, Solve
 
 // ---- the launch sequence of one batch (score + solve), on workspace c->cur and its stream; never waits -------------
 
-// Cosine matrices of B problems: k_cos_tile (64x64 tile per workgroup, operands through LDS) by default; ROMAN_COS=0 selects
+// Cosine matrices of B problems: k_cos_tile (64x64 tile per workgroup, operands through LDS) by default, k_cos_deal (80x80 tiles, blocks
+// dealt evenly to the waves) for batches of mid-size maps, k_cos_wave (one wave per problem) for maps of at most 48 objects; ROMAN_COS=0 selects
 // k_cos (32x32 tile per wave, operands from global memory), ROMAN_COS=16 / 32 the stage depth.
 static hipError_t launch_cos(roman_ctx* c, hipStream_t stream, const DevParams& D, int B, int maxN1, int maxN2, const ProbDesc* dP, const double* feats, double* cosPool)
 {
     static const char* env = getenv("ROMAN_COS");
     const int mode = env ? atoi(env) : 16;
     static const char* waveEnv = getenv("ROMAN_COS_WAVE");      // "0": never the one-wave-per-problem kernel (A/B)
+    {   // a batch with at least two workgroups per compute unit of 5 x 5-block tiles: k_cos_deal (blocks dealt evenly to the waves).
+        // ROMAN_COS_DEAL=0 never, =1 always (A/B, tests; read per call)
+        const char* dealEnv = getenv("ROMAN_COS_DEAL");
+        constexpr int TD = 5;
+        using CD = CosDeal<TD>;
+        const int Gd = CD::tiles(maxN1) * CD::tiles(maxN2);
+        const bool deal = (dealEnv && dealEnv[0]) ? dealEnv[0] == '1' : (mode == 16 && (maxN1 > 16 * COSW_NB || maxN2 > 16 * COSW_NB) && (int64_t)Gd * B >= 2 * (int64_t)c->num_cu);
+        if (deal) {
+            const hipError_t e = dyn_lds(c, reinterpret_cast<const void*>(k_cos_deal<TD, 0>), (size_t)CD::LDS);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((k_cos_deal<TD, 0>), dim3((unsigned)(B >= 8 ? Gd * ((B + 7) / 8) * 8 : Gd * B)), dim3(256), (size_t)CD::LDS, stream, D, B, Gd, dP, feats, cosPool);
+            return hipGetLastError();
+        }
+    }
     if (mode != 0 && maxN1 <= 16 * COSW_NB && maxN2 <= 16 * COSW_NB && !(waveEnv && waveEnv[0] == '0')) {
         // the reference's demo scale: one wave per problem, no LDS, no barrier (k_cos_wave)
         hipLaunchKernelGGL(k_cos_wave, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, stream, D, B, dP, feats, cosPool);

@@ -179,6 +179,27 @@ def test_cosine_bits_equal_the_oracles_stated_order(ctx, orc, n1, n2, d):
     assert np.array_equal(got, ref)
 
 
+@pytest.mark.parametrize("n1,n2,d", [(200, 200, 512), (200, 200, 48), (200, 200, 7), (113, 97, 31), (300, 130, 33), (130, 300, 16), (224, 225, 17),
+                                     (1, 1, 16), (16, 112, 64), (49, 49, 15), (64, 64, 512), (5, 3, 1), (111, 113, 80), (80, 96, 24), (81, 79, 40)])
+def test_dealt_cosine_kernel_gives_the_oracles_bits(ctx, orc, monkeypatch, n1, n2, d):
+    """k_cos_deal (tiles of up to 5 x 5 blocks whose blocks are dealt to the waves as equal runs; what a batch of mid-size maps
+    takes) forced on for a single problem: one tile and several (exactly 5 and 6 blocks per dimension among them), runs that
+    start in the middle of a block row, waves without a block, ragged descriptor lengths, norms handed over through LDS —
+    BIT-identical to the oracle's stated order."""
+    rng = np.random.default_rng(n1 * 977 + n2 * 13 + d)
+    P = _abi.RomanParams.default(); P.cos_feature_dim = d
+    D1 = rng.standard_normal((n1, 3 + d)); D2 = rng.standard_normal((n2, 3 + d))
+    if n1 > 2:
+        D1[2, 3:] = 0.0                                  # a zero descriptor: cosine 0 by the reference's guard
+    monkeypatch.setenv("ROMAN_COS_DEAL", "1")
+    got = ctx.debug_cosine(P, D1, D2)
+    monkeypatch.setenv("ROMAN_COS_DEAL", "0")
+    other = ctx.debug_cosine(P, D1, D2)
+    ref = np.array([[orc.cosine(D1[i, 3:], D2[j, 3:]) for j in range(n2)] for i in range(n1)])
+    assert np.array_equal(got, ref)
+    assert np.array_equal(other, ref)
+
+
 def test_both_cosine_kernels_give_the_same_bits(ctx, tmp_path):
     """ROMAN_COS=0 selects the per-wave kernel k_cos (32x32 tile per wave, operands from global memory) that k_cos_tile
     replaced as the default: same contraction order per element, same bits.  The switch is read once per process, so the

@@ -1,5 +1,5 @@
-// Microbenchmark: issue cost of v_mfma_f64_16x16x4_f64 (4 independent accumulators) vs v_fma_f64 with an SGPR
-// operand.  Build: hipcc --offload-arch=gfx950 -O3 -o mfma_rate mfma_rate.hip
+// Microbenchmark: issue cost of v_mfma_f64_16x16x4_f64 (4 independent accumulators, chains of 4 dependent ones, with v_fma_f64
+// mixed in: the f64 vector FMA runs on the units the f64 MFMA occupies) vs v_fma_f64 with an SGPR operand.  Cycles per 16 MFMAs / 16.  Build: hipcc --offload-arch=gfx950 -O3 -o mfma_rate mfma_rate.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef double double4_t __attribute__((ext_vector_type(4)));
@@ -22,6 +22,32 @@ __global__ void __launch_bounds__(256) k(double* out, double s, int iters)
             for (int r = 0; r < 4; ++r)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[r + 4 * (i >> 1)], f[8 + r + 4 * (i & 1)], acc[i], 0, 0, 0);
+        } else if (OP == 4) {                   // chains of 4 DEPENDENT MFMAs (one accumulator at a time: the cosine kernels' block-by-block order)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+        } else if (OP == 5) {                   // 16 MFMAs (chains of 4), then a burst of 4 dependent v_fma_f64 (the norms of k_cos_deal: 14 per 52 MFMAs)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) asm volatile("v_fma_f64 %0, %1, %2, %0" : "+v"(f[0]) : "s"(s), "v"(b));
+        } else if (OP == 6) {                   // the same 4 v_fma_f64, one behind every chain of 4 MFMAs
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+                asm volatile("v_fma_f64 %0, %1, %2, %0" : "+v"(f[0]) : "s"(s), "v"(b));
+            }
+        } else if (OP == 7) {                   // 16 MFMAs, then 4 INDEPENDENT v_fma_f64
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) asm volatile("v_fma_f64 %0, %1, %2, %0" : "+v"(f[i]) : "s"(s), "v"(b));
         } else if (OP == 1) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) asm volatile("v_fma_f64 %0, %1, %2, %0" : "+v"(f[i]) : "s"(s), "v"(b));
@@ -61,6 +87,10 @@ int main()
     for (int w : {1, 2, 4}) {
         run<0>("mfma_f64_16x16x4", d, w, 2048.0);
         run<3>("mfma_f64 random data", d, w, 2048.0);
+        run<4>("mfma chains of 4", d, w, 2048.0);
+        run<5>("16 mfma + 4 dep. v_fma burst", d, w, 2048.0);
+        run<6>("4 x (4 mfma + v_fma)", d, w, 2048.0);
+        run<7>("16 mfma + 4 indep. v_fma", d, w, 2048.0);
         run<1>("v_fma_f64 (sgpr src)", d, w, 128.0);
         run<2>("v_mul_f64+v_add_f64", d, w, 128.0);
     }
