@@ -509,7 +509,7 @@ def main():
                         "achieved_TFLOPs": cosflops / (iso_stage["single"] * 1e-3) / 1e12, "peak_TFLOPs": F64_PEAK_TFLOPS,
                         "measured_mfma_ceiling_TFLOPs": F64_MFMA_MEASURED_TFLOPS,
                         "frac": cosflops / (iso_stage["single"] * 1e-3) / 1e12 / F64_PEAK_TFLOPS,
-                        "note": "frac of the whole stage; k_cos_tile alone is ~75 % of it (0.32 of 0.42 ms): 33 TFLOP/s"}}
+                        "note": "frac of the whole stage; k_cos_deal alone is ~75 % of it (0.29 of 0.39 ms): 36 TFLOP/s"}}
                 # the whole step against SURVEY.md §8(d)'s ideal time t* = W/Pi + (B_b + B_s)/beta (pair tests among LIVE associations)
                 Wb = 30.0 * tests + cosflops
                 Bb = float(np.sum(12.0 * nnz)) + 8.0 * float(np.sum(a1[:C0].astype(np.float64) + a2[:C0])) * F
