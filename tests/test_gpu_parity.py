@@ -200,6 +200,24 @@ def test_dealt_cosine_kernel_gives_the_oracles_bits(ctx, orc, monkeypatch, n1, n
     assert np.array_equal(other, ref)
 
 
+def test_large_single_cosine_product_takes_the_dealt_kernel_by_itself(ctx, monkeypatch):
+    """A single product large enough for two workgroups per compute unit of k_cos_deal's tiles (the submap-descriptor gate of a
+    long session: thousands of submaps a side) picks that kernel without the switch, its tiles spread over all XCDs (fewer than
+    eight problems): equal to numpy within rounding, and bit-identical to k_cos_tile on the same operands."""
+    rng = np.random.default_rng(77)
+    A = rng.standard_normal((1900, 40)); Bm = rng.standard_normal((1830, 40))
+    A[5] = 0.0
+    monkeypatch.delenv("ROMAN_COS_DEAL", raising=False)
+    got = ctx.cosine_matrix(A, Bm)
+    monkeypatch.setenv("ROMAN_COS_DEAL", "0")
+    other = ctx.cosine_matrix(A, Bm)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        ref = (A @ Bm.T) / np.outer(np.linalg.norm(A, axis=1), np.linalg.norm(Bm, axis=1))
+    ref[~np.isfinite(ref)] = 0.0
+    assert np.max(np.abs(got - ref)) < 1e-14
+    assert np.array_equal(got, other)
+
+
 def test_both_cosine_kernels_give_the_same_bits(ctx, tmp_path):
     """ROMAN_COS=0 selects the per-wave kernel k_cos (32x32 tile per wave, operands from global memory) that k_cos_tile
     replaced as the default: same contraction order per element, same bits.  The switch is read once per process, so the
