@@ -68,7 +68,7 @@ def parse():
     ap.add_argument("--latency-reps", type=int, default=30)
     ap.add_argument("--no-profile", action="store_true", help="do not bracket stages with hipEvents")
     ap.add_argument("--no-extras", action="store_true", help="main measurement only: no grid / sensitivity / large-live / demo-scale / sustained / h2d legs")
-    ap.add_argument("--pipeline", type=int, default=3, choices=[1, 2, 3],
+    ap.add_argument("--pipeline", type=int, default=3, choices=[1, 2, 3, 4, 5, 6],
                     help="batches in flight per GPU (roman_ctx_set_pipeline): the straggler tail of one call's solver overlaps the "
                          "next calls' affinity builds; results are complete at the closing device-wide synchronise")
     return ap.parse_args()
