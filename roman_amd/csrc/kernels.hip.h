@@ -3999,12 +3999,17 @@ __global__ void __launch_bounds__(WIDE_NT) k_solve_wide(DevParams D, int B, cons
                                                         unsigned long long spinTicks /* wall-clock ticks a barrier wait may last (host: 4 s at the device's wall-clock rate) */,
                                                         int teams /* 0: the whole device on one problem at a time; s >= 1: s teams per XCD, a problem each */,
                                                         const int32_t* __restrict__ fbList /* the batch's fallback problems (k_skipped) */,
-                                                        long long partStride /* doubles of `part` a team owns */)
+                                                        long long partStride /* doubles of `part` a team owns */,
+                                                        IdxT* colsC, double* valsC /* (no __restrict__: a compacted copy is compacted again in place) mirror of the matrix pools: the column-compacted copy (same offsets) */,
+                                                        int ccfg /* column compaction: bits 0-7 compactions allowed per problem (0: off), 8-15 threshold (x / 256 of the columns in use), 16-23 passes per window */)
 {
     __shared__ WideShared sh;
     extern __shared__ __attribute__((aligned(16))) unsigned char wide_smem[];
     unsigned long long* bml = reinterpret_cast<unsigned long long*>(wide_smem);      // support bit map of the vector being multiplied
-    double* xl = reinterpret_cast<double*>(bml + bmWords);                             // its leading xcap elements
+    unsigned long long* bmC = bml + bmWords;                                         // columns of the compacted copy in use
+    unsigned long long* bmA = bmC + bmWords;                                         // union of the supports multiplied in the current window
+    uint32_t* cw = reinterpret_cast<uint32_t*>(bmA + bmWords);                       // cumulative slice widths (steps) of the stream in use: bmWords + 1 (+ 1 pad)
+    double* xl = reinterpret_cast<double*>(cw + bmWords + 2);                        // the multiplied vector's leading xcap elements
     const roman_params_t& P = D.p;
     const int ltid = threadIdx.x, lane = ltid & 63, w = uni_i(ltid >> 6);
     if (ltid == 0) sh.abort_ = 0;
@@ -4015,8 +4020,11 @@ __global__ void __launch_bounds__(WIDE_NT) k_solve_wide(DevParams D, int B, cons
     if (!wide_census(sh, wb, ltid)) return;
     const int G = wb.tG, NWG = G * WIDE_NW;                      // my team (whole-device mode: the grid)
     const int gw = w * G + wb.tRank;                            // wave id in the team: consecutive ids on different compute units
+    const int gwc = (tune & 4) ? wb.tRank * WIDE_NW + w : gw;   // wave id for the deal of stream chunks (experiment: the waves of a compute unit take consecutive chunks)
     part += (size_t)wb.team * (size_t)partStride;
-    bmPool += (size_t)wb.team * 2 * (size_t)bmWords;
+    bmPool += (size_t)wb.team * 3 * (size_t)bmWords;            // two bit maps + the new slice widths of a compaction
+    uint32_t* wNew = reinterpret_cast<uint32_t*>(bmPool + 2 * (size_t)bmWords);
+    const int cmax = ccfg & 0xff, cthr = (ccfg >> 8) & 0xff, cwin = max(1, (ccfg >> 16) & 0xff);
     const int nFb = (int)__hip_atomic_load(bar + 32 * 21, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (int jq = 0; ; ++jq) {
         int b;
@@ -4044,35 +4052,59 @@ __global__ void __launch_bounds__(WIDE_NT) k_solve_wide(DevParams D, int B, cons
         const int L = uni_i(st[b].L), rb = uni_i(st[b].rowBase);
         const int64_t lo = pd.liveOff;
         const int nsl = (L + 63) >> 6;
-        const uint32_t T = st[b].nnzCap >> 8;                   // steps of the flat stream (a step = one quad of the 64 lanes of a slice: 256 entries)
+        const uint32_t Tfull = st[b].nnzCap >> 8;               // steps of the flat stream (a step = one quad of the 64 lanes of a slice: 256 entries)
         const uint32_t* perm = permPool + lo; const uint32_t* sbase = sliceBasePool + lo;
         const IdxT* cols = colsPool + st[b].nnzOff; const double* vals = valsPool + st[b].nnzOff;
+        IdxT* colsK = colsC + st[b].nnzOff; double* valsK = valsC + st[b].nnzOff;   // the compacted copy: same slice bases, fewer steps per slice
         double* xva = vXa + rb; double* xvb = vXb + rb;
         unsigned long long* bma = bmPool; unsigned long long* bmb = bmPool + bmWords;
         const int kw = min(WIDE_KW, (nsl + NWG - 1) / NWG);     // element rounds in use (the host guarantees L <= WIDE_KW * NWG * 64)
-#define CUMW(s_) ((s_) < nsl ? (sbase[(s_)] >> 8) : T)
+#define CUMW(s_) (cw[(s_)])
+#define MEMW(s_) (sbase[(s_)] >> 8)                              /* first step of slice s_ in memory (both copies) */
 #define FORK(k_) _Pragma("unroll") for (int k_ = 0; k_ < WIDE_KW; ++k_) if (k_ < kw)
-        // chunks of CS steps, dealt round-robin to the waves (chunk c to wave c % NWG): at any moment the waves of the grid
-        // read one contiguous window of the matrix.  Every wave takes the same number m <= WIDE_MAXCH of chunks (the last
-        // round may be short): about 16 steps (12 KB per lane-row... 48 KB per wave) per chunk, more when the matrix is larger.
-        uint32_t mch = max(1u, min((uint32_t)WIDE_MAXCH, (T + (uint32_t)NWG * 16u - 1u) / ((uint32_t)NWG * 16u)));
-        if ((tune >> 8) & 0xff) mch = min((uint32_t)WIDE_MAXCH, (uint32_t)((tune >> 8) & 0xff));
-        const uint32_t CS = max(1u, (T + (uint32_t)NWG * mch - 1u) / ((uint32_t)NWG * mch));
-        const uint32_t nCh = (T + CS - 1u) / CS;                // <= NWG * mch
+        // The stream in use: the full matrix (cw = the layout's own slice bases) or its column-compacted copy (fewer steps per
+        // slice, the slices at their old places).  Chunks of CS steps, dealt round-robin to the waves (chunk c to wave c % NWG):
+        // at any moment the waves of the grid read one contiguous window of the matrix.  Every wave takes the same number
+        // m <= WIDE_MAXCH of chunks (the last round may be short): about 16 steps per chunk, more when the matrix is larger.
+        uint32_t T = Tfull, CS = 1u, nCh = 0u;
+        int cmode = 0, ncomp = 0, winPass = 0; uint32_t curCols = (uint32_t)L;      // compaction state (identical in every workgroup of the team)
+        uint32_t pcf[WIDE_KW], pcn[WIDE_KW];
         static_assert(WIDE_MAXCH <= 8, "sS capacity");
-        __syncthreads();                                        // (the previous problem's stream is done with sS)
-        if (lane < WIDE_MAXCH) {                                // lane j: first slice of this wave's chunk j (-1: no such chunk)
-            const uint32_t c = (uint32_t)gw + (uint32_t)lane * (uint32_t)NWG;
-            int s_ = -1;
-            if (c < nCh) {                                      // largest s with cumW[s] <= first step of the chunk
-                const uint32_t t0 = c * CS;
-                int lo_ = 0, hi_ = nsl;
-                while (hi_ - lo_ > 1) { const int mid_ = (lo_ + hi_) >> 1; if (CUMW(mid_) <= t0) lo_ = mid_; else hi_ = mid_; }
-                s_ = lo_;
+        auto geometry = [&]() {                                 // (cw and T are set; every thread of the workgroup calls this)
+            uint32_t mch = max(1u, min((uint32_t)WIDE_MAXCH, (T + (uint32_t)NWG * 16u - 1u) / ((uint32_t)NWG * 16u)));
+            if ((tune >> 8) & 0xff) mch = min((uint32_t)WIDE_MAXCH, (uint32_t)((tune >> 8) & 0xff));
+            CS = max(1u, (T + (uint32_t)NWG * mch - 1u) / ((uint32_t)NWG * mch));
+            nCh = (T + CS - 1u) / CS;                            // <= NWG * mch
+            __syncthreads();                                    // (the previous stream is done with sS; cw is complete)
+            if (lane < WIDE_MAXCH) {                            // lane j: first slice of this wave's chunk j (-1: no such chunk)
+                const uint32_t c = (uint32_t)gwc + (uint32_t)lane * (uint32_t)NWG;
+                int s_ = -1;
+                if (c < nCh) {                                  // largest s with cumW[s] <= first step of the chunk
+                    const uint32_t t0 = c * CS;
+                    int lo_ = 0, hi_ = nsl;
+                    while (hi_ - lo_ > 1) { const int mid_ = (lo_ + hi_) >> 1; if (CUMW(mid_) <= t0) lo_ = mid_; else hi_ = mid_; }
+                    s_ = lo_;
+                }
+                sh.sS[w][lane] = s_;
             }
-            sh.sS[w][lane] = s_;
-        }
-        __syncthreads();
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < WIDE_KW; ++k) {                 // pieces (chunk c, slice s_) have id c + s_
+                const int s_ = gw + k * NWG;
+                pcf[k] = 0u; pcn[k] = 0u;
+                if (k < kw && s_ < nsl) {
+                    const uint32_t a0 = CUMW(s_), e0 = CUMW(s_ + 1);
+                    if (e0 > a0) { pcf[k] = a0 / CS + (uint32_t)s_; pcn[k] = (e0 - 1u) / CS - a0 / CS + 1u; }
+                }
+            }
+        };
+        auto full_stream = [&]() {                              // cw <- the layout's own slice bases
+            __syncthreads();
+            for (int p = ltid; p <= nsl; p += WIDE_NT) cw[p] = p < nsl ? MEMW(p) : Tfull;
+            T = Tfull; cmode = 0; curCols = (uint32_t)L;
+            geometry();
+        };
+        full_stream();
 
         int status = ROMAN_ST_OK;
         roman_stats_t S;
@@ -4084,7 +4116,7 @@ __global__ void __launch_bounds__(WIDE_NT) k_solve_wide(DevParams D, int B, cons
 
         // owned elements (registers) and the pieces of their slices
         double u[WIDE_KW], Mu[WIDE_KW], Cu[WIDE_KW], sd[WIDE_KW], tt[WIDE_KW], Mn[WIDE_KW], Cn[WIDE_KW], tb[WIDE_KW], ta[WIDE_KW];
-        int kk[WIDE_KW]; bool in[WIDE_KW]; uint32_t pcf[WIDE_KW], pcn[WIDE_KW];
+        int kk[WIDE_KW]; bool in[WIDE_KW];
 #pragma unroll
         for (int k = 0; k < WIDE_KW; ++k) {
             const int s_ = gw + k * NWG;
@@ -4096,11 +4128,6 @@ __global__ void __launch_bounds__(WIDE_NT) k_solve_wide(DevParams D, int B, cons
             if (in[k]) plp[lo + pos] = a_;
             u[k] = in[k] ? (u0 ? u0[lo + a_] : 1.0) : 0.0;
             Mu[k] = Cu[k] = tt[k] = Mn[k] = Cn[k] = tb[k] = ta[k] = 0.0;
-            pcf[k] = 0u; pcn[k] = 0u;
-            if (k < kw && s_ < nsl) {                           // pieces (chunk c, slice s_) have id c + s_
-                const uint32_t a0 = CUMW(s_), e0 = CUMW(s_ + 1);
-                if (e0 > a0) { pcf[k] = a0 / CS + (uint32_t)s_; pcn[k] = (e0 - 1u) / CS - a0 / CS + 1u; }
-            }
         }
         double dummy1[1] = {0.0};
         bool alive = true;
@@ -4123,13 +4150,12 @@ __global__ void __launch_bounds__(WIDE_NT) k_solve_wide(DevParams D, int B, cons
         };
         // one piece [t, stop) of slice s: partial row sums -> partials buffer.  Blocks of WIDE_U quads (three 16-byte loads
         // per lane and quad), the next block's matrix loads in flight while the current block gathers and accumulates.
-        auto piece = [&](const double* xv, uint32_t nl, uint32_t t, uint32_t stop, uint32_t pid) {
+        constexpr bool W16 = sizeof(IdxT) == 2;                  // 16-bit column words: 8 bytes per lane and quad, no C flag, 0xffff = no column
+        typedef typename std::conditional<W16, unsigned long long, uint4_t>::type cword_t;
+        auto piece = [&](const double* xv, uint32_t nl, uint32_t tm /* first step in memory */, uint32_t n /* steps */, uint32_t pid) {
             double am = 0.0, ac = 0.0;
-            constexpr bool W16 = sizeof(IdxT) == 2;              // 16-bit column words: 8 bytes per lane and quad, no C flag, 0xffff = no column
-            typedef typename std::conditional<W16, unsigned long long, uint4_t>::type cword_t;
-            const cword_t* cp = reinterpret_cast<const cword_t*>(cols) + (size_t)t * 64 + lane;
-            const dbl2_t* vp = reinterpret_cast<const dbl2_t*>(vals) + (size_t)t * 128 + lane;
-            const uint32_t n = stop - t;
+            const cword_t* cp = reinterpret_cast<const cword_t*>(cmode ? (const IdxT*)colsK : cols) + (size_t)tm * 64 + lane;
+            const dbl2_t* vp = reinterpret_cast<const dbl2_t*>(cmode ? (const double*)valsK : vals) + (size_t)tm * 128 + lane;
             cword_t cA[WIDE_U], cB[WIDE_U]; dbl2_t vA0[WIDE_U], vA1[WIDE_U], vB0[WIDE_U], vB1[WIDE_U];
 #define WIDE_ISSUE(C_, V0_, V1_, off_, n_)                                                                    \
             _Pragma("unroll") for (int e = 0; e < WIDE_U; ++e) {                                              \
@@ -4177,10 +4203,125 @@ __global__ void __launch_bounds__(WIDE_NT) k_solve_wide(DevParams D, int B, cons
         // position) and (b) the leading min(mp1, xcap) elements of x — positions are ranks by degree, so the leading
         // elements are the columns most entries point at, and the support collapses onto them within a few passes.  A
         // gather is then an LDS read; only a column beyond the LDS part whose bit is set goes to L2.
-        auto stream = [&](const double* xv, const unsigned long long* bm, uint32_t mp1) {
+        // Column compaction (round 4).  The iterate's support collapses in plateaus (n = m = 200, method 'gravity': 40 000 -> 22 000
+        // for 67 passes -> 3 800 for 89 -> 655 for 29 -> ~100 for 57) while its LARGEST position stays high, so streaming a prefix
+        // of the rows gains nothing; but a pass only needs the entries whose COLUMN is in the support.  Every workgroup sees the
+        // published support bit map anyway: it keeps the union of the supports multiplied during a window of `cwin` passes, and
+        // when that union has fallen to `cthr`/256 of the columns in use the team rewrites the matrix without the other columns —
+        // a wave per slice, every lane packs its row's kept entries to the front of the slice (same slice bases, in a mirror of
+        // the matrix pools; a compacted copy is compacted again in place), the new widths go through one barrier — and streams
+        // the copy from then on.  A vector whose support leaves the copy's column set (the line search can re-admit an element)
+        // sends the team back to the full matrix.  Dropped entries multiplied zeros: the products are the same up to the
+        // grouping of the partial sums (pieces are cut from the shorter stream).
+        auto slice_compact = [&](int s_, const IdxT* srcC, const double* srcV) {
+            const uint32_t ms = MEMW(s_), nst = CUMW(s_ + 1) - CUMW(s_);
+            const cword_t* cp = reinterpret_cast<const cword_t*>(srcC) + (size_t)ms * 64 + lane;
+            const dbl2_t* vp = reinterpret_cast<const dbl2_t*>(srcV) + (size_t)ms * 128 + lane;
+            cword_t* cq = reinterpret_cast<cword_t*>(colsK) + (size_t)ms * 64 + lane;
+            dbl2_t* vq = reinterpret_cast<dbl2_t*>(valsK) + (size_t)ms * 128 + lane;
+            const uint32_t inert = W16 ? 0xffffu : ((uint32_t)((s_ << 6) + lane) | 0x80000000u);     // fb_inert of this lane's row
+            uint32_t kc = 0u, pc[4] = {inert, inert, inert, inert}; double pv[4] = {0.0, 0.0, 0.0, 0.0};
+            auto put = [&](uint32_t q_) {                        // the pending quad -> quad q_ of this lane
+                if constexpr (W16) cq[(size_t)q_ * 64] = (unsigned long long)pc[0] | ((unsigned long long)pc[1] << 16) | ((unsigned long long)pc[2] << 32) | ((unsigned long long)pc[3] << 48);
+                else { uint4_t o_; o_.x = pc[0]; o_.y = pc[1]; o_.z = pc[2]; o_.w = pc[3]; cq[(size_t)q_ * 64] = o_; }
+                vq[(size_t)(2u * q_) * 64] = dbl2_t{pv[0], pv[1]}; vq[(size_t)(2u * q_ + 1u) * 64] = dbl2_t{pv[2], pv[3]};
+            };
+            cword_t cN = cword_t{}; dbl2_t v0N = dbl2_t{0.0, 0.0}, v1N = dbl2_t{0.0, 0.0};
+            if (nst > 0u) { cN = cp[0]; v0N = vp[0]; v1N = vp[64]; }
+            for (uint32_t g = 0; g < nst; ++g) {
+                const cword_t cC = cN; const dbl2_t v0 = v0N, v1 = v1N;
+                if (g + 1u < nst) { cN = cp[(size_t)(g + 1u) * 64]; v0N = vp[(size_t)(2u * g + 2u) * 64]; v1N = vp[(size_t)(2u * g + 3u) * 64]; }
+                uint32_t c4[4];
+                if constexpr (W16) { const unsigned long long cw_ = *reinterpret_cast<const unsigned long long*>(&cC);
+                    c4[0] = (uint32_t)(cw_ & 0xffffu); c4[1] = (uint32_t)((cw_ >> 16) & 0xffffu); c4[2] = (uint32_t)((cw_ >> 32) & 0xffffu); c4[3] = (uint32_t)(cw_ >> 48); }
+                else { const uint4_t cw_ = *reinterpret_cast<const uint4_t*>(&cC); c4[0] = cw_.x; c4[1] = cw_.y; c4[2] = cw_.z; c4[3] = cw_.w; }
+                const double v4[4] = {v0.x, v0.y, v1.x, v1.y};
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    const uint32_t ci = W16 ? c4[h] : (c4[h] & 0x7fffffffu);
+                    // (an inert slot: 0xffff, or flagged with value 0 — a real flagged entry has a non-zero value)
+                    const bool real = W16 ? (ci != 0xffffu) : !((c4[h] & 0x80000000u) && v4[h] == 0.0);
+                    if (real && ci < (uint32_t)L && ((bmA[ci >> 6] >> (ci & 63u)) & 1ull)) {
+                        const uint32_t j_ = kc & 3u;
+#pragma unroll
+                        for (int z = 0; z < 4; ++z) if ((uint32_t)z == j_) { pc[z] = c4[h]; pv[z] = v4[h]; }
+                        ++kc;
+                        if ((kc & 3u) == 0u) {
+                            put((kc >> 2) - 1u);
+#pragma unroll
+                            for (int z = 0; z < 4; ++z) { pc[z] = inert; pv[z] = 0.0; }
+                        }
+                    }
+                }
+            }
+            if (kc & 3u) {
+                put(kc >> 2);
+#pragma unroll
+                for (int z = 0; z < 4; ++z) { pc[z] = inert; pv[z] = 0.0; }
+            }
+            const uint32_t nq = (kc + 3u) >> 2;
+            uint32_t wmax = nq;
+            for (int off = 32; off > 0; off >>= 1) wmax = max(wmax, (uint32_t)__shfl_xor((int)wmax, off));
+            for (uint32_t q_ = nq; q_ < wmax; ++q_) put(q_);     // (pending quad is inert here)
+            if (lane == 0) __hip_atomic_store(wNew + s_, wmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        };
+        // Where the gathered values come from.  A 320 KB vector against a 32 KB L1 makes every gather an L2 access, and the
+        // whole device does 280 G of those per second: 150 us for the 42 M entries of the n = m = 200 problem, more than
+        // the matrix stream itself.  So every workgroup first copies into LDS (a) the support bit map of x (one bit per
+        // position) and (b) the leading min(mp1, xcap) elements of x — positions are ranks by degree, so the leading
+        // elements are the columns most entries point at, and the support collapses onto them within a few passes.  A
+        // gather is then an LDS read; only a column beyond the LDS part whose bit is set goes to L2.
+        auto stream = [&](const double* xv, const unsigned long long* bm, uint32_t mp1) -> bool {
             const uint32_t nl = (tune & 1) ? 0u : min(mp1, (uint32_t)xcap);
             for (uint32_t p = (uint32_t)ltid; p < (uint32_t)nsl; p += WIDE_NT) bml[p] = bm[p];
             for (uint32_t p = (uint32_t)ltid; p < nl; p += WIDE_NT) xl[p] = xv[p];
+            if (cmax > 0) {                                     // support bookkeeping: the same words, the same verdict in every workgroup of the team
+                if (ltid == 0) { sh.sint[0] = 0; sh.sint[1] = 0; }
+                __syncthreads();
+                int viol = 0;
+                for (uint32_t p = (uint32_t)ltid; p < (uint32_t)nsl; p += WIDE_NT) {
+                    const unsigned long long w_ = bml[p];
+                    if (cmode && (w_ & ~bmC[p])) viol = 1;
+                    bmA[p] = (winPass == 0 ? 0ull : bmA[p]) | w_;
+                }
+                if (viol) atomicOr(&sh.sint[0], 1);
+                __syncthreads();
+                ++winPass;
+                const bool out_ = sh.sint[0] != 0;
+                bool doc = false; uint32_t cntA = 0u;
+                if (!out_ && winPass >= cwin) {                 // end of a window: how many columns did it touch?
+                    int c_ = 0;
+                    for (uint32_t p = (uint32_t)ltid; p < (uint32_t)nsl; p += WIDE_NT) c_ += __popcll(bmA[p]);
+                    for (int off = 32; off > 0; off >>= 1) c_ += __shfl_xor(c_, off);
+                    if (lane == 0 && c_) atomicAdd(&sh.sint[1], c_);
+                    __syncthreads();
+                    cntA = (uint32_t)sh.sint[1];
+                    doc = ncomp < cmax && (unsigned long long)cntA * 256ull <= (unsigned long long)curCols * (unsigned long long)cthr && T >= 4u * (uint32_t)NWG;
+                    winPass = 0;
+                }
+                if (out_) {                                     // the vector left the copy's columns: back to the full matrix
+                    full_stream();
+                    winPass = 0;
+                } else if (doc) {
+                    const IdxT* srcC = cmode ? (const IdxT*)colsK : cols; const double* srcV = cmode ? (const double*)valsK : vals;
+                    for (int s_ = gwc; s_ < nsl; s_ += NWG) slice_compact(s_, srcC, srcV);
+                    for (uint32_t p = (uint32_t)ltid; p < (uint32_t)nsl; p += WIDE_NT) bmC[p] = bmA[p];
+                    if (!wide_sync<true>(sh, wb, ltid)) return false;
+                    if (w == 0) {                               // cw <- prefix of the new widths
+                        uint32_t run = 0u;
+                        for (int p0 = 0; p0 < nsl; p0 += WAVE) {
+                            const uint32_t wv = (p0 + lane < nsl) ? __hip_atomic_load(wNew + p0 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+                            const uint32_t inc = wave_incl_scan(wv);
+                            if (p0 + lane < nsl) cw[p0 + lane] = run + inc - wv;
+                            run += (uint32_t)__shfl((int)inc, 63);
+                        }
+                        if (lane == 0) cw[nsl] = run;
+                    }
+                    __syncthreads();
+                    T = cw[nsl]; cmode = 1; curCols = cntA; ++ncomp;
+                    geometry();
+                }
+            }
             __syncthreads();
 #ifdef ROMAN_SOLVE_TIMING
             wcnt[7] += (mp1 <= (uint32_t)xcap) ? 1 : 0;
@@ -4188,19 +4329,20 @@ __global__ void __launch_bounds__(WIDE_NT) k_solve_wide(DevParams D, int B, cons
             for (int j = 0; j < WIDE_MAXCH; ++j) {
                 int s = uni_i(sh.sS[w][j]);
                 if (s >= 0) {
-                    const uint32_t c = (uint32_t)gw + (uint32_t)j * (uint32_t)NWG;
+                    const uint32_t c = (uint32_t)gwc + (uint32_t)j * (uint32_t)NWG;
                     uint32_t t = c * CS;
                     const uint32_t tEnd = min(T, t + CS);
                     uint32_t sEnd = CUMW(s + 1);
                     while (t < tEnd) {
                         const uint32_t stop = min(sEnd, tEnd);
-                        piece(xv, nl, t, stop, c + (uint32_t)s);
+                        piece(xv, nl, MEMW(s) + (t - CUMW(s)), stop - t, c + (uint32_t)s);
                         t = stop;
                         if (t < tEnd) { do { ++s; sEnd = CUMW(s + 1); } while (sEnd <= t); }
                     }
                 }
             }
             ++n_pass;
+            return true;
         };
         // (M x, C x) of the owned rows: the pieces of their slice in ascending order
         auto collect = [&](double (&om)[WIDE_KW], double (&oc)[WIDE_KW]) {
@@ -4265,7 +4407,7 @@ __global__ void __launch_bounds__(WIDE_NT) k_solve_wide(DevParams D, int B, cons
             if (phase == PH_INIT) alive = normalise();
             if (alive) { publish(xva, bma, u); alive = wide_reduce<0>(dummy1, sh, slots, wb, ltid); }
             while (alive) {
-                stream(xcur, bmcur, mpcur);
+                if (!(alive = stream(xcur, bmcur, mpcur))) break;
                 WMARK(2);
                 if (!(alive = wide_reduce<0>(dummy1, sh, slots, wb, ltid))) break;
                 WMARK(3);

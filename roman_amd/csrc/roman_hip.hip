@@ -75,7 +75,7 @@ struct roman_ctx {
         DevBuf plp, pli, plj, pls, pld, plza, plzb;                // the same in position order (stream layout)
         DevBuf rowCnt, rowPos, perm, sliceWidth, sliceBase, items, maskPool, prefPool, listPool, listOff;
         DevBuf vMu, vCu, vMun, vCun, gU, gUn, uOut, nodesOrig, nSel, widePart, wideSlots, wideBar, wideBm, fbList;
-        DevBuf cols16, cols32, vals;
+        DevBuf cols16, cols32, vals, colsC, valsC;
         long long capMaskWords = 0, capNnz = 0, capList = 0;       // what the sparse pools hold (elements)
         // staging for the host-pointer entry points
         DevBuf hFeats, hAssoc, hU0, oAssoc, oN, oT, oStatus, oStats, hAux1, hAux2, hAux3;
@@ -835,11 +835,23 @@ int enqueue_solve(roman_ctx* c, const DevParams& D, int B, int64_t sumA, int64_t
             double* a_part = WS.widePart.as<double>(); double* a_slots = WS.wideSlots.as<double>(); unsigned* a_bar = WS.wideBar.as<unsigned>();
             // dynamic LDS: the support bit map of the gathered vector + its leading part (everything the static part leaves of the 160 KB)
             int a_bmw = (int)((maxA + 63) / 64) + 1;
-            HIPCHK(c, WS.wideBm.ensure(sizeof(unsigned long long) * 2 * (size_t)a_bmw * (size_t)nTeams));
+            HIPCHK(c, WS.wideBm.ensure(sizeof(unsigned long long) * 3 * (size_t)a_bmw * (size_t)nTeams));      // two bit maps + the new slice widths of a compaction
             unsigned long long* a_bm = WS.wideBm.as<unsigned long long>();
-            int a_xcap = (int)(((int64_t)c->lds_max - 4096 - 8 * (int64_t)a_bmw) / (int64_t)sizeof(double)) & ~63;
+            // LDS: three bit maps (the multiplied vector's support, the compacted copy's columns, the window's union), the
+            // cumulative slice widths of the stream in use, the multiplied vector's leading part
+            const int64_t wideFixed = 3 * 8 * (int64_t)a_bmw + 4 * ((int64_t)a_bmw + 2);
+            int a_xcap = (int)(((int64_t)c->lds_max - 4096 - wideFixed) / (int64_t)sizeof(double)) & ~63;
             if (a_xcap < 0) a_xcap = 0;
-            const size_t wideLds = sizeof(double) * (size_t)a_xcap + 8 * (size_t)a_bmw;
+            const size_t wideLds = sizeof(double) * (size_t)a_xcap + (size_t)wideFixed;
+            // Column compaction (kernels.hip.h, k_solve_wide): a mirror of the matrix pools holds the compacted copy.
+            // ROMAN_WIDE_COMPACT=0 turns it off; =0xWWTTCC sets passes per window / threshold (x/256) / compactions allowed per problem.
+            int a_ccfg = 6 | (128 << 8) | (4 << 16);
+            { const char* e_ = getenv("ROMAN_WIDE_COMPACT"); if (e_ && e_[0]) a_ccfg = (int)strtol(e_, nullptr, 0); }
+            if (a_ccfg & 0xff) {
+                HIPCHK(c, WS.valsC.ensure(sizeof(double) * (size_t)WS.capNnz));
+                HIPCHK(c, WS.colsC.ensure((D.idx16 ? sizeof(uint16_t) : sizeof(uint32_t)) * (size_t)WS.capNnz));
+            }
+            void* a_colsC = WS.colsC.p; double* a_valsC = WS.valsC.as<double>();
             const void* wideFn = D.idx16 ? reinterpret_cast<const void*>(k_solve_wide<uint16_t>) : reinterpret_cast<const void*>(k_solve_wide<uint32_t>);
             HIPCHK(c, dyn_lds(c, wideFn, wideLds));
             static const char* tuneEnv = getenv("ROMAN_WIDE_TUNE");
@@ -848,7 +860,7 @@ int enqueue_solve(roman_ctx* c, const DevParams& D, int B, int64_t sumA, int64_t
             const int32_t* a_fb = WS.fbList.as<int32_t>();
             void* args[] = {&Dv, &Bv, &a_probs, &a_state, &a_feats, &a_assoc, &a_lp, &a_ld, &a_perm, &a_rpos, &a_sb, &a_cols, &a_vals,
                             &a_vU, &a_vX, &a_vX2, &a_s0, &a_s1, &a_s2, &a_plp, &a_u0, &a_O, &a_part, &a_slots, &a_bar, &a_bm, &a_bmw, &a_xcap, &a_tune, &a_ticks,
-                            &a_teams, &a_fb, &a_partStride};
+                            &a_teams, &a_fb, &a_partStride, &a_colsC, &a_valsC, &a_ccfg};
             // Two whole-device kernels must never be resident together (each would hold compute units while waiting at a
             // grid barrier for workgroups the other one keeps out): with batches in flight on several streams, a
             // launch waits for the previous one of this context.
@@ -1160,7 +1172,7 @@ int roman_ctx_destroy(roman_ctx_t* c)
         DevBuf* all[] = {&W.probs, &W.state, &W.totals, &W.queue, &W.cosPool, &W.tabPool, &W.sTmp, &W.chunkCnt,
                          &W.lp, &W.li, &W.lj, &W.ls, &W.ld, &W.lza, &W.lzb, &W.plp, &W.pli, &W.plj, &W.pls, &W.pld, &W.plza, &W.plzb,
                          &W.rowCnt, &W.rowPos, &W.perm, &W.sliceWidth, &W.sliceBase, &W.items, &W.maskPool, &W.prefPool, &W.listPool, &W.listOff,
-                         &W.vMu, &W.vCu, &W.vMun, &W.vCun, &W.gU, &W.gUn, &W.uOut, &W.nodesOrig, &W.nSel, &W.widePart, &W.wideSlots, &W.wideBar, &W.wideBm, &W.fbList, &W.cols16, &W.cols32, &W.vals,
+                         &W.vMu, &W.vCu, &W.vMun, &W.vCun, &W.gU, &W.gUn, &W.uOut, &W.nodesOrig, &W.nSel, &W.widePart, &W.wideSlots, &W.wideBar, &W.wideBm, &W.fbList, &W.cols16, &W.cols32, &W.vals, &W.colsC, &W.valsC,
                          &W.hFeats, &W.hAssoc, &W.hU0, &W.oAssoc, &W.oN, &W.oT, &W.oStatus, &W.oStats, &W.hAux1, &W.hAux2, &W.hAux3};
         for (DevBuf* b : all) b->release();
         if (W.pinnedTotals) (void)hipHostFree(W.pinnedTotals);

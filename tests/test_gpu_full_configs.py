@@ -149,14 +149,25 @@ def test_mixed_batch_large_and_small_live_sets(ctx, orc):
     assert res.stats["n_live"].tolist() == [1600, 6000, 1050, 400]
 
 
-@pytest.mark.parametrize("teams", [None, "2", "0"], ids=["teams_auto", "two_teams_per_xcd", "whole_device"])
-def test_batch_of_mid_size_live_sets_matches_the_oracle(ctx, orc, teams, monkeypatch):
+# ROMAN_WIDE_COMPACT: 0 = k_solve_wide never compacts the matrix's columns; 0x01FF10 = a window of ONE pass, threshold 255/256,
+# 16 compactions per problem: a copy is cut at almost every pass, the next vector's support leaves its columns again and again
+# (the line search re-admits elements) — the way back to the full matrix and the compaction of a copy in place run many times
+_COMPACT_CASES = [(None, None), ("2", None), ("0", None), (None, "0"), (None, "0x01FF10"), ("0", "0x01FF10"), ("2", "0x02C008")]
+_COMPACT_IDS = ["teams_auto", "two_teams_per_xcd", "whole_device", "teams_auto-no_compaction", "teams_auto-compaction_every_pass",
+                "whole_device-compaction_every_pass", "two_teams_per_xcd-eager_compaction"]
+
+
+@pytest.mark.parametrize("teams,compact", _COMPACT_CASES, ids=_COMPACT_IDS)
+def test_batch_of_mid_size_live_sets_matches_the_oracle(ctx, orc, teams, compact, monkeypatch):
     """Methods without a semantic gate ('gravity', 'clipper', 'pcavolgrav': [REF roman/params/submap_align_params.py:98-116])
     make every association live: L = n * m, 3600 ... 10 000 at 60-100 objects per submap — beyond the stream layout.  A batch
     of such problems is solved by TEAMS of compute units (the workgroups of an XCD, or of half an XCD, on one problem each,
-    k_solve_wide in team mode); every result equals the oracle's, as it does with the whole device on one problem at a time."""
+    k_solve_wide in team mode); every result equals the oracle's, as it does with the whole device on one problem at a time —
+    with the solver's column compaction as the library sets it, off, and forced at (almost) every pass."""
     if teams is not None:
         monkeypatch.setenv("ROMAN_WIDE_TEAMS", teams)
+    if compact is not None:
+        monkeypatch.setenv("ROMAN_WIDE_COMPACT", compact)
     reg = registration_for("gravity"); reg.set_context(ctx)
     rng = np.random.default_rng(77)
     sizes = [(int(a), int(b)) for a, b in rng.integers(60, 101, size=(18, 2))] + [(100, 100), (30, 30), (64, 48)]   # (30 x 30, 64 x 48: stream layout)
@@ -166,21 +177,27 @@ def test_batch_of_mid_size_live_sets_matches_the_oracle(ctx, orc, teams, monkeyp
     problems = [(batch.feats[batch.off1[b]:batch.off1[b] + batch.n1[b]], batch.feats[batch.off2[b]:batch.off2[b] + batch.n2[b]])
                 for b in range(len(batch))]
     bad, worst, traj = _compare(orc, reg, res, problems)
-    print(f"mid-size live sets ({teams}): {len(batch) - len(bad)}/{len(batch)} identical, iteration counts differ on {traj}")
+    print(f"mid-size live sets ({teams}, {compact}): {len(batch) - len(bad)}/{len(batch)} identical, iteration counts differ on {traj}")
     assert not bad and worst < POSE_TOL and len(traj) <= 2
     assert res.stats["n_live"].tolist() == [n * m for n, m in sizes]
 
 
-def test_gravity_200x200_all_associations_live(ctx, orc):
+def test_gravity_200x200_all_associations_live(ctx, orc, monkeypatch):
     """method 'gravity' has no semantic gate: at n = m = 200 every one of the 40 000 associations is live — far beyond
     the stream layout (L <= 3072).  The problem takes the symmetric SELL-64 layout and the COOPERATIVE fallback
-    solver (all compute units on one problem, grid barriers; k_solve_coop): results and pass counts equal the oracle's."""
+    solver (all compute units on one problem, grid barriers; k_solve_wide): results and pass counts equal the oracle's —
+    with the column compaction the library chooses (three or four copies over the 244 passes) and with one forced at almost
+    every pass (copies of copies in place, many returns to the full matrix)."""
     reg = registration_for("gravity"); reg.set_context(ctx)
     pr = synth.make_pair(200, 200, 0, 7001, tilt_deg=1.0)
     res = reg.register_and_align_batch([(pr.map1, pr.map2)])
     D1, D2 = reg.pack(pr.map1), reg.pack(pr.map2)
     bad, worst, traj = _compare(orc, reg, res, [(D1, D2)])
     assert not bad and worst < POSE_TOL
+    monkeypatch.setenv("ROMAN_WIDE_COMPACT", "0x01FF10")
+    res2 = reg.register_and_align_batch([(pr.map1, pr.map2)])
+    assert np.array_equal(res2.assoc[0], res.assoc[0]) and int(res2.stats["n_pass"][0]) == int(res.stats["n_pass"][0])
+    assert np.max(np.abs(res2.T[0] - res.T[0])) < POSE_TOL
     assert res.stats["n_live"][0] == 40000
     truth = set(map(tuple, pr.inliers.tolist()))
     assert len(truth & set(map(tuple, res.assoc[0].tolist()))) >= 0.9 * len(truth)
