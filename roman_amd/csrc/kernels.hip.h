@@ -4067,7 +4067,8 @@ __global__ void __launch_bounds__(WIDE_NT) k_solve_wide(DevParams D, int B, cons
         // at any moment the waves of the grid read one contiguous window of the matrix.  Every wave takes the same number
         // m <= WIDE_MAXCH of chunks (the last round may be short): about 16 steps per chunk, more when the matrix is larger.
         uint32_t T = Tfull, CS = 1u, nCh = 0u;
-        int cmode = 0, ncomp = 0, winPass = 0; uint32_t curCols = (uint32_t)L;      // compaction state (identical in every workgroup of the team)
+        int cmode = 0 /* stream in use: 0 full, 1 the copy */, ncomp = 0, winPass = 0, winOut = 0; bool haveCopy = false;
+        uint32_t copyCols = 0u, Tcopy = 0u;                     // compaction state (identical in every workgroup of the team)
         uint32_t pcf[WIDE_KW], pcn[WIDE_KW];
         static_assert(WIDE_MAXCH <= 8, "sS capacity");
         auto geometry = [&]() {                                 // (cw and T are set; every thread of the workgroup calls this)
@@ -4101,7 +4102,23 @@ __global__ void __launch_bounds__(WIDE_NT) k_solve_wide(DevParams D, int B, cons
         auto full_stream = [&]() {                              // cw <- the layout's own slice bases
             __syncthreads();
             for (int p = ltid; p <= nsl; p += WIDE_NT) cw[p] = p < nsl ? MEMW(p) : Tfull;
-            T = Tfull; cmode = 0; curCols = (uint32_t)L;
+            T = Tfull; cmode = 0;
+            geometry();
+        };
+        auto copy_stream = [&]() {                              // cw <- prefix of the copy's slice widths (wNew, written by its compaction)
+            __syncthreads();
+            if (w == 0) {
+                uint32_t run = 0u;
+                for (int p0 = 0; p0 < nsl; p0 += WAVE) {
+                    const uint32_t wv = (p0 + lane < nsl) ? __hip_atomic_load(wNew + p0 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+                    const uint32_t inc = wave_incl_scan(wv);
+                    if (p0 + lane < nsl) cw[p0 + lane] = run + inc - wv;
+                    run += (uint32_t)__shfl((int)inc, 63);
+                }
+                if (lane == 0) cw[nsl] = run;
+            }
+            __syncthreads();
+            T = cw[nsl]; Tcopy = T; cmode = 1;
             geometry();
         };
         full_stream();
@@ -4210,9 +4227,11 @@ __global__ void __launch_bounds__(WIDE_NT) k_solve_wide(DevParams D, int B, cons
         // when that union has fallen to `cthr`/256 of the columns in use the team rewrites the matrix without the other columns —
         // a wave per slice, every lane packs its row's kept entries to the front of the slice (same slice bases, in a mirror of
         // the matrix pools; a compacted copy is compacted again in place), the new widths go through one barrier — and streams
-        // the copy from then on.  A vector whose support leaves the copy's column set (the line search can re-admit an element)
-        // sends the team back to the full matrix.  Dropped entries multiplied zeros: the products are the same up to the
-        // grouping of the partial sums (pieces are cut from the shorter stream).
+        // the copy for every vector whose support lies in the copy's columns.  A vector that leaves them (the line search can
+        // re-admit an element) is multiplied with the full matrix, the copy stays; a window that stayed inside the copy and has
+        // shrunk again compacts the copy in place, one that left it twice or more makes a new copy from the full matrix.
+        // Dropped entries multiplied zeros: the products are the same up to the grouping of the partial sums (pieces are cut
+        // from the shorter stream).
         auto slice_compact = [&](int s_, const IdxT* srcC, const double* srcV) {
             const uint32_t ms = MEMW(s_), nst = CUMW(s_ + 1) - CUMW(s_);
             const cword_t* cp = reinterpret_cast<const cword_t*>(srcC) + (size_t)ms * 64 + lane;
@@ -4276,50 +4295,49 @@ __global__ void __launch_bounds__(WIDE_NT) k_solve_wide(DevParams D, int B, cons
             for (uint32_t p = (uint32_t)ltid; p < (uint32_t)nsl; p += WIDE_NT) bml[p] = bm[p];
             for (uint32_t p = (uint32_t)ltid; p < nl; p += WIDE_NT) xl[p] = xv[p];
             if (cmax > 0) {                                     // support bookkeeping: the same words, the same verdict in every workgroup of the team
-                if (ltid == 0) { sh.sint[0] = 0; sh.sint[1] = 0; }
+                if (ltid == 0) { sh.sint[0] = 0; sh.sint[1] = 0; sh.sint[2] = 0; }
                 __syncthreads();
-                int viol = 0;
-                for (uint32_t p = (uint32_t)ltid; p < (uint32_t)nsl; p += WIDE_NT) {
-                    const unsigned long long w_ = bml[p];
-                    if (cmode && (w_ & ~bmC[p])) viol = 1;
-                    bmA[p] = (winPass == 0 ? 0ull : bmA[p]) | w_;
+                const bool wend = winPass + 1 >= cwin;          // this pass closes a window
+                {
+                    int out_ = 0, outA = 0, c_ = 0;
+                    for (uint32_t p = (uint32_t)ltid; p < (uint32_t)nsl; p += WIDE_NT) {
+                        const unsigned long long w_ = bml[p], a_ = (winPass == 0 ? 0ull : bmA[p]) | w_, c0 = haveCopy ? bmC[p] : 0ull;
+                        bmA[p] = a_;
+                        if (w_ & ~c0) out_ = 1;
+                        if (a_ & ~c0) outA = 1;
+                        if (wend) c_ += __popcll(a_);
+                    }
+                    if (out_ | outA) atomicOr(&sh.sint[0], out_ | (outA << 1));
+                    if (wend) {
+                        for (int off = 32; off > 0; off >>= 1) c_ += __shfl_xor(c_, off);
+                        if (lane == 0 && c_) atomicAdd(&sh.sint[1], c_);
+                    }
                 }
-                if (viol) atomicOr(&sh.sint[0], 1);
                 __syncthreads();
+                bool fits = haveCopy && !(sh.sint[0] & 1);      // the vector's support lies in the copy's columns
                 ++winPass;
-                const bool out_ = sh.sint[0] != 0;
-                bool doc = false; uint32_t cntA = 0u;
-                if (!out_ && winPass >= cwin) {                 // end of a window: how many columns did it touch?
-                    int c_ = 0;
-                    for (uint32_t p = (uint32_t)ltid; p < (uint32_t)nsl; p += WIDE_NT) c_ += __popcll(bmA[p]);
-                    for (int off = 32; off > 0; off >>= 1) c_ += __shfl_xor(c_, off);
-                    if (lane == 0 && c_) atomicAdd(&sh.sint[1], c_);
-                    __syncthreads();
-                    cntA = (uint32_t)sh.sint[1];
-                    doc = ncomp < cmax && (unsigned long long)cntA * 256ull <= (unsigned long long)curCols * (unsigned long long)cthr && T >= 4u * (uint32_t)NWG;
-                    winPass = 0;
+                if (haveCopy && !fits) ++winOut;
+                int doc = 0;                                     // 1: compact the copy in place, 2: a new copy from the full matrix
+                const uint32_t cntA = (uint32_t)sh.sint[1];
+                if (wend) {
+                    const bool sub = haveCopy && !(sh.sint[0] & 2);          // the whole window stayed inside the copy
+                    if (ncomp < cmax) {
+                        if (sub) { if ((unsigned long long)cntA * 256ull <= (unsigned long long)copyCols * (unsigned long long)cthr && Tcopy >= 4u * (uint32_t)NWG) doc = 1; }
+                        else if ((!haveCopy || winOut >= 2) && (unsigned long long)cntA * 256ull <= (unsigned long long)L * (unsigned long long)cthr && Tfull >= 4u * (uint32_t)NWG) doc = 2;
+                    }
+                    winPass = 0; winOut = 0;
                 }
-                if (out_) {                                     // the vector left the copy's columns: back to the full matrix
-                    full_stream();
-                    winPass = 0;
-                } else if (doc) {
-                    const IdxT* srcC = cmode ? (const IdxT*)colsK : cols; const double* srcV = cmode ? (const double*)valsK : vals;
+                if (doc) {
+                    if (doc == 1 && cmode == 0) copy_stream();  // (slice_compact reads the source's widths from cw)
+                    if (doc == 2 && cmode == 1) full_stream();
+                    const IdxT* srcC = doc == 1 ? (const IdxT*)colsK : cols; const double* srcV = doc == 1 ? (const double*)valsK : vals;
                     for (int s_ = gwc; s_ < nsl; s_ += NWG) slice_compact(s_, srcC, srcV);
                     for (uint32_t p = (uint32_t)ltid; p < (uint32_t)nsl; p += WIDE_NT) bmC[p] = bmA[p];
                     if (!wide_sync<true>(sh, wb, ltid)) return false;
-                    if (w == 0) {                               // cw <- prefix of the new widths
-                        uint32_t run = 0u;
-                        for (int p0 = 0; p0 < nsl; p0 += WAVE) {
-                            const uint32_t wv = (p0 + lane < nsl) ? __hip_atomic_load(wNew + p0 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-                            const uint32_t inc = wave_incl_scan(wv);
-                            if (p0 + lane < nsl) cw[p0 + lane] = run + inc - wv;
-                            run += (uint32_t)__shfl((int)inc, 63);
-                        }
-                        if (lane == 0) cw[nsl] = run;
-                    }
-                    __syncthreads();
-                    T = cw[nsl]; cmode = 1; curCols = cntA; ++ncomp;
-                    geometry();
+                    haveCopy = true; copyCols = cntA; ++ncomp; fits = true;
+                    copy_stream();
+                } else if (fits != (cmode == 1)) {
+                    if (fits) copy_stream(); else full_stream();
                 }
             }
             __syncthreads();
