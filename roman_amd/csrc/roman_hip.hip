@@ -457,7 +457,7 @@ int enqueue_score(roman_ctx* c, const DevParams& Din, const roman_params_t* para
         const int mayFb = may_fallback(D, hd);
         D.wide = (c->coop_ok && mayFb > 0 && D.p.maxiniters >= 1 && D.p.maxlsiters >= 1 && maxA <= (int64_t)WIDE_KW * c->num_cu * WIDE_NW * 64 &&
                   (wideEnv ? wideEnv[0] == '1' : mayFb <= std::max(1, c->num_cu / 4))) ? 1 : 0;   // (several: teams of compute units, one problem each)
-        static const char* i16Env = getenv("ROMAN_WIDE_IDX16");  // "0": 32-bit labels always
+        const char* i16Env = getenv("ROMAN_WIDE_IDX16");         // "0": 32-bit labels always (read per call: tests)
         D.idx16 = (D.wide && maxA <= 65534 && !(i16Env && i16Env[0] == '0')) ? 1 : 0;
     }
     *Dout = D;

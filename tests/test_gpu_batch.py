@@ -224,6 +224,27 @@ def test_dense_weights_outside_the_unit_interval_take_the_plain_double_solver(ct
     _same_selection_as_oracle(nodes2, ref2)
 
 
+@pytest.mark.parametrize("compact", [None, "0x01FF10"], ids=["compaction_default", "compaction_every_pass"])
+def test_dense_problem_beyond_the_stream_layout_on_the_whole_device_solver(ctx, orc, compact, monkeypatch):
+    """A caller's dense matrix of 3200 rows (the mno_clipper loop on a large association set) is beyond the stream layout: the
+    fallback layout with 32-bit labels and C flags, the whole-device solver k_solve_wide — and its column compaction, which must
+    keep flagged entries (C == 0, weight non-zero), consistent pairs of weight 0 (C == 1) and drop the inert padding: u within
+    1e-9 of the oracle's, the same selected set, as the library compacts and with a compaction forced at almost every pass."""
+    if compact is not None:
+        monkeypatch.setenv("ROMAN_WIDE_COMPACT", compact)
+    n = 3200
+    M, C = _random_dense_problem(n, 0.5, 9100)
+    P = _abi.RomanParams.default(); P.invariant = _abi.ROMAN_INV_EUCLIDEAN
+    ctx.set_matrix_data(P, M, C)
+    ctx.solve(None)
+    nodes, u, score, st = ctx.solution()
+    ref = orc.solve(P, orc.matrix_from_dense(M, C))
+    assert st.nnz_upper == int(np.count_nonzero(np.triu((M != 0) | (C != 0), 1)))
+    assert np.max(np.abs(u - ref["u"])) < 1e-9, (np.max(np.abs(u - ref["u"])), st.n_pass, ref["stats"].n_pass)
+    assert abs(score - ref["stats"].score) <= 1e-9 * max(1.0, abs(ref["stats"].score))
+    _same_selection_as_oracle(nodes, ref)
+
+
 @pytest.mark.parametrize("u0_kind", ["ones", "1e-12..1", "one_dominant", "1e-12..1+c_flags"])
 def test_fixed_point_sums_at_the_stream_solvers_limit(ctx, orc, u0_kind):
     """Worst case of the stream solver's exact sums (kernels.hip.h "Exact accumulation"): the largest live set it takes

@@ -152,13 +152,15 @@ def test_mixed_batch_large_and_small_live_sets(ctx, orc):
 # ROMAN_WIDE_COMPACT: 0 = k_solve_wide never compacts the matrix's columns; 0x01FF10 = a window of ONE pass, threshold 255/256,
 # 16 compactions per problem: a copy is cut at almost every pass, the next vector's support leaves its columns again and again
 # (the line search re-admits elements) — the way back to the full matrix and the compaction of a copy in place run many times
-_COMPACT_CASES = [(None, None), ("2", None), ("0", None), (None, "0"), (None, "0x01FF10"), ("0", "0x01FF10"), ("2", "0x02C008")]
+_COMPACT_CASES = [(None, None, None), ("2", None, None), ("0", None, None), (None, "0", None), (None, "0x01FF10", None), ("0", "0x01FF10", None),
+                  ("2", "0x02C008", None), (None, "0x01FF10", "0"), (None, None, "0")]
 _COMPACT_IDS = ["teams_auto", "two_teams_per_xcd", "whole_device", "teams_auto-no_compaction", "teams_auto-compaction_every_pass",
-                "whole_device-compaction_every_pass", "two_teams_per_xcd-eager_compaction"]
+                "whole_device-compaction_every_pass", "two_teams_per_xcd-eager_compaction", "teams_auto-compaction_every_pass-32bit_labels",
+                "teams_auto-32bit_labels"]
 
 
-@pytest.mark.parametrize("teams,compact", _COMPACT_CASES, ids=_COMPACT_IDS)
-def test_batch_of_mid_size_live_sets_matches_the_oracle(ctx, orc, teams, compact, monkeypatch):
+@pytest.mark.parametrize("teams,compact,idx16", _COMPACT_CASES, ids=_COMPACT_IDS)
+def test_batch_of_mid_size_live_sets_matches_the_oracle(ctx, orc, teams, compact, idx16, monkeypatch):
     """Methods without a semantic gate ('gravity', 'clipper', 'pcavolgrav': [REF roman/params/submap_align_params.py:98-116])
     make every association live: L = n * m, 3600 ... 10 000 at 60-100 objects per submap — beyond the stream layout.  A batch
     of such problems is solved by TEAMS of compute units (the workgroups of an XCD, or of half an XCD, on one problem each,
@@ -168,6 +170,8 @@ def test_batch_of_mid_size_live_sets_matches_the_oracle(ctx, orc, teams, compact
         monkeypatch.setenv("ROMAN_WIDE_TEAMS", teams)
     if compact is not None:
         monkeypatch.setenv("ROMAN_WIDE_COMPACT", compact)
+    if idx16 is not None:
+        monkeypatch.setenv("ROMAN_WIDE_IDX16", idx16)           # "0": 32-bit column labels (the layout of dense problems with C-flags)
     reg = registration_for("gravity"); reg.set_context(ctx)
     rng = np.random.default_rng(77)
     sizes = [(int(a), int(b)) for a, b in rng.integers(60, 101, size=(18, 2))] + [(100, 100), (30, 30), (64, 48)]   # (30 x 30, 64 x 48: stream layout)
