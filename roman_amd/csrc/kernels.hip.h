@@ -4294,7 +4294,8 @@ __global__ void __launch_bounds__(WIDE_NT) k_solve_wide(DevParams D, int B, cons
             const uint32_t nl = (tune & 1) ? 0u : min(mp1, (uint32_t)xcap);
             for (uint32_t p = (uint32_t)ltid; p < (uint32_t)nsl; p += WIDE_NT) bml[p] = bm[p];
             for (uint32_t p = (uint32_t)ltid; p < nl; p += WIDE_NT) xl[p] = xv[p];
-            if (cmax > 0) {                                     // support bookkeeping: the same words, the same verdict in every workgroup of the team
+            if (cmax > 0 && Tfull >= 16u * (uint32_t)NWG) {     // support bookkeeping: the same words, the same verdict in every workgroup of the team
+                // (a matrix of fewer than 16 steps per wave is not worth a copy: its passes are barriers, and the books cost 3 us a pass)
                 if (ltid == 0) { sh.sint[0] = 0; sh.sint[1] = 0; sh.sint[2] = 0; }
                 __syncthreads();
                 const bool wend = winPass + 1 >= cwin;          // this pass closes a window
@@ -4322,8 +4323,8 @@ __global__ void __launch_bounds__(WIDE_NT) k_solve_wide(DevParams D, int B, cons
                 if (wend) {
                     const bool sub = haveCopy && !(sh.sint[0] & 2);          // the whole window stayed inside the copy
                     if (ncomp < cmax) {
-                        if (sub) { if ((unsigned long long)cntA * 256ull <= (unsigned long long)copyCols * (unsigned long long)cthr && Tcopy >= 4u * (uint32_t)NWG) doc = 1; }
-                        else if ((!haveCopy || winOut >= 2) && (unsigned long long)cntA * 256ull <= (unsigned long long)L * (unsigned long long)cthr && Tfull >= 4u * (uint32_t)NWG) doc = 2;
+                        if (sub) { if ((unsigned long long)cntA * 256ull <= (unsigned long long)copyCols * (unsigned long long)cthr && Tcopy >= 16u * (uint32_t)NWG) doc = 1; }
+                        else if ((!haveCopy || winOut >= 2) && (unsigned long long)cntA * 256ull <= (unsigned long long)L * (unsigned long long)cthr) doc = 2;
                     }
                     winPass = 0; winOut = 0;
                 }
