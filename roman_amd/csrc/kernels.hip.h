@@ -3800,6 +3800,8 @@ __global__ void __launch_bounds__(64, 3) k_small(DevParams D, int B, const ProbD
 //    cooperative_groups' grid.sync()).  Grid sums ride on it: workgroup partials into a ping-pong slot array before the
 //    arrival, every workgroup adds the slots in one fixed order afterwards.  Every spin is bounded (4 s): on a timeout the
 //    kernel gives up and reports ROMAN_ST_INTERNAL instead of hanging the device.
+//  * Column compaction (round 4): the team keeps books on the published support bit maps and, when the support has left half
+//    of the columns in use, rewrites the matrix without them into a mirror of the pools and streams that copy (see `stream`).
 //  Mirrors oracle_solve() like solve_one; the sums are plain doubles in a fixed (different) order.
 // ---------------------------------------------------------------------------------------------
 constexpr int WIDE_NT = 512;             // threads per workgroup (one workgroup per compute unit; 8 waves: 256 registers each)
