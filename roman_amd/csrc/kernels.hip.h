@@ -3811,6 +3811,10 @@ constexpr int WIDE_NRED = 8;             // doubles per workgroup slot of a grid
 constexpr int WIDE_U = 3;                // quads (of 4 entries per lane) per block of the stream; two blocks in flight per wave
 constexpr int WIDE_MAXCH = 8;            // chunks of the flat stream a wave takes per pass at most
 
+// dynamic LDS of k_solve_wide in front of the gathered vector's leading part: three bit maps of bmWords 64-bit words and the
+// cumulative slice widths (bmWords + 2 32-bit words), rounded up to 16 bytes (host and kernel use this one function)
+__host__ __device__ constexpr size_t wide_fixed_lds(int bmWords) { return ((size_t)3 * 8 * (size_t)bmWords + 4 * ((size_t)bmWords + 2) + 15) & ~(size_t)15; }
+
 struct WideShared {
     double wred[2][WIDE_NW][WIDE_NRED];  // wave partials of a reduction (ping-pong)
     double bc[2][WIDE_NRED];             // reduced values for the whole workgroup (ping-pong)
@@ -4011,7 +4015,7 @@ __global__ void __launch_bounds__(WIDE_NT) k_solve_wide(DevParams D, int B, cons
     unsigned long long* bmC = bml + bmWords;                                         // columns of the compacted copy in use
     unsigned long long* bmA = bmC + bmWords;                                         // union of the supports multiplied in the current window
     uint32_t* cw = reinterpret_cast<uint32_t*>(bmA + bmWords);                       // cumulative slice widths (steps) of the stream in use: bmWords + 1 (+ 1 pad)
-    double* xl = reinterpret_cast<double*>(cw + bmWords + 2);                        // the multiplied vector's leading xcap elements
+    double* xl = reinterpret_cast<double*>(wide_smem + wide_fixed_lds(bmWords));     // the multiplied vector's leading xcap elements (16-byte aligned)
     const roman_params_t& P = D.p;
     const int ltid = threadIdx.x, lane = ltid & 63, w = uni_i(ltid >> 6);
     if (ltid == 0) sh.abort_ = 0;

@@ -839,7 +839,7 @@ int enqueue_solve(roman_ctx* c, const DevParams& D, int B, int64_t sumA, int64_t
             unsigned long long* a_bm = WS.wideBm.as<unsigned long long>();
             // LDS: three bit maps (the multiplied vector's support, the compacted copy's columns, the window's union), the
             // cumulative slice widths of the stream in use, the multiplied vector's leading part
-            const int64_t wideFixed = 3 * 8 * (int64_t)a_bmw + 4 * ((int64_t)a_bmw + 2);
+            const int64_t wideFixed = (int64_t)wide_fixed_lds(a_bmw);
             int a_xcap = (int)(((int64_t)c->lds_max - 4096 - wideFixed) / (int64_t)sizeof(double)) & ~63;
             if (a_xcap < 0) a_xcap = 0;
             const size_t wideLds = sizeof(double) * (size_t)a_xcap + (size_t)wideFixed;
