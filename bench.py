@@ -58,7 +58,7 @@ def parse():
     ap.add_argument("--grid-warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=256, help="pairs workload: submap pairs per GPU per step (config 3: 256)")
     ap.add_argument("--grid", type=int, default=64, help="grid workload: submaps per robot (config 4: 64 -> 4096 alignments)")
-    ap.add_argument("--chunk", type=int, default=2048, help="grid workload: pairs per roman_align_batch_dev call (2048: +5 % over 512 on one GPU — launches and the solver tail amortise; capped at a rank's share)")
+    ap.add_argument("--chunk", type=int, default=2048, help="grid workload: pairs per roman_align_batch_dev call (2048: +5 %% over 512 on one GPU — launches and the solver tail amortise; capped at a rank's share)")
     ap.add_argument("--n", type=int, default=200)
     ap.add_argument("--m", type=int, default=200)
     ap.add_argument("--d", type=int, default=512)

@@ -143,3 +143,13 @@ def test_plain_start_with_gpus_n_launches_its_own_ranks(monkeypatch):
     i = cmd.index(os.path.join(ROOT, "bench.py"))
     assert cmd[i + 1:] == ["--gpus", "2", "--steps", "3", "--warmup", "1"]
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_bench_help_renders(capsys, monkeypatch):
+    """`python bench.py --help` prints the options (a bare per-cent sign in a help string makes argparse raise)."""
+    import bench
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--help"])
+    with pytest.raises(SystemExit) as ei:
+        bench.parse()
+    assert ei.value.code == 0 and "--pipeline" in capsys.readouterr().out
+
