@@ -24,8 +24,10 @@ def _compare(orc, reg, res, problems):
     P = reg._abi_params()
     bad, traj = [], []
     worst = 0.0
+    # many problems: one host thread per problem (oracle.register_each); a few large ones: one after the other on all threads
+    oracle_results = orc.register_each(P, problems) if len(problems) >= 64 else [orc.register(P, D1, D2, faithful=False) for D1, D2 in problems]
     for b, (D1, D2) in enumerate(problems):
-        o = orc.register(P, D1, D2, faithful=False)
+        o = oracle_results[b]
         st = o["stats"]
         same = (np.array_equal(res.assoc[b], o["assoc"]) and res.stats["n_live"][b] == st.n_live
                 and res.stats["nnz_upper"][b] == st.nnz_upper and res.stats["outer_iters"][b] == st.outer_iters

@@ -244,3 +244,21 @@ def test_prefilter_as_an_invariant_equals_the_explicit_pruned_list(orc, kw, n, m
     assert np.array_equal(got["assoc"], want["assoc"])
     assert got["stats"].nnz_upper == want["stats"].nnz_upper and got["stats"].n_live == (len(A) if A is not None else n * m)
     assert got["stats"].n_pass == want["stats"].n_pass
+
+
+def test_register_each_equals_register_one_by_one(orc):
+    """oracle.register_each (one host thread per problem, what the GPU suites use for hundreds of problems) returns exactly what
+    register() returns problem by problem: associations, u, every statistic."""
+    reg = registration_for("semanticgrav", semantics_dim=16)
+    P = reg._abi_params()
+    problems = []
+    for k in range(70):
+        pr = synth.make_pair(10 + k % 7, 9 + k % 5, 16, 8800 + k)
+        problems.append((reg.pack(pr.map1), reg.pack(pr.map2)))
+    par = orc.register_each(P, problems, workers=8)
+    for (D1, D2), o in zip(problems, par):
+        r = orc.register(P, D1, D2)
+        assert np.array_equal(o["assoc"], r["assoc"]) and np.array_equal(o["u"], r["u"])
+        for f in ("n_live", "nnz_upper", "n_pass", "outer_iters", "inner_iters", "ls_trials", "score", "d_final"):
+            assert getattr(o["stats"], f) == getattr(r["stats"], f), f
+
