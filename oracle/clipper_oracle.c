@@ -58,6 +58,23 @@ static int g_plain_arith = 0;     /* 0: stated-order dot + oracle_exp/oracle_cbr
 ORACLE_API void oracle_set_arith(int plain) { g_plain_arith = plain ? 1 : 0; }
 ORACLE_API int oracle_get_arith(void) { return g_plain_arith; }
 
+/* How the solver's passes over M are organised (oracle_solve below).  Both are the same iteration; they differ in where the
+ * penalty d enters the sums, i.e. by rounding only:
+ *   0 CARRIED  every pass forms M x and C x separately; the products of the accepted trial are carried to the d update
+ *              (findDenseClique as published: one pass per line-search trial);
+ *   1 FUSED    a line-search pass forms ONE product W x = (M + d C) x (the only thing the gradient needs); the d update, which
+ *              needs M u and C u apart, takes one split pass over the accepted vector ("1 per gradient
+ *              evaluation incl. each line-search trial, 1 per d update").  This is the order of the device's stream solver
+ *              (k_solve_up: one LDS accumulator per element instead of two);
+ *   2 AUTO     (default) FUSED for the problems the device gives to its stream solver — at most ORACLE_STREAM_MAXL live
+ *              associations, every stored weight in [0, 1], maxiniters >= 1 and maxlsiters >= 1 — and CARRIED for the others
+ *              (the whole-device / plain-double device solvers keep both sums of every pass), so that pass counts compare
+ *              whichever solver a problem takes.  Selections do not depend on the mode (tests/test_oracle_clipper.py). */
+#define ORACLE_STREAM_MAXL 3072     /* roman_amd/csrc/kernels.hip.h STREAM_MAXL */
+static int g_pass_mode = 2;
+ORACLE_API void oracle_set_pass_mode(int mode) { g_pass_mode = (mode == 0 || mode == 1) ? mode : 2; }
+ORACLE_API int oracle_get_pass_mode(void) { return g_pass_mode; }
+
 static inline double from_bits(uint64_t b) { double d; memcpy(&d, &b, 8); return d; }
 static inline uint64_t to_bits(double d) { uint64_t b; memcpy(&b, &d, 8); return b; }
 
@@ -561,6 +578,33 @@ static double grad_and_F(const oracle_mat_t* m, double d, const double* u, const
     return F;
 }
 
+/* W = (M_off + d C_off) x from the strict upper CSR: one product per stored pair and triangle, weight v + d (v alone where
+ * the entry's C is 0), accumulated in the order of spmv_sym. */
+static void spmv_fused(const oracle_mat_t* m, double d, const double* x, double* W)
+{
+    const int32_t n = m->n;
+    for (int32_t p = 0; p < n; ++p) W[p] = 0.0;
+    for (int32_t p = 0; p < n; ++p) {
+        const double xp = x[p];
+        for (int64_t k = m->rowptr[p]; k < m->rowptr[p + 1]; ++k) {
+            const int32_t q = m->cols[k];
+            const double w = (!m->czero || !m->czero[k]) ? m->vals[k] + d : m->vals[k];
+            W[p] += w * x[q]; W[q] += w * xp;
+        }
+    }
+}
+
+/* the same gradient with the fused product: gradF_p = ((s_p + d) u_p - d*sum(u)) + W_p */
+static double grad_and_F_fused(const oracle_mat_t* m, double d, const double* u, const double* W, double usum, double* g)
+{
+    double F = 0.0;
+    for (int32_t p = 0; p < m->n; ++p) {
+        g[p] = ((m->diag[p] + d) * u[p] - d * usum) + W[p];
+        F += u[p] * g[p];
+    }
+    return F;
+}
+
 /* mean over {p : Cbu_p > eps and u_p > eps} of |(M u)_p / Cbu_p| (absval=0: signed), with
  * Cbu = 1*sum(u) - C u - u  and  M u including the diagonal.  Returns 0 and *cnt=0 if none.  */
 static double d_ratio_mean(const oracle_mat_t* m, const roman_params_t* P, const double* u,
@@ -625,9 +669,12 @@ ORACLE_API int32_t oracle_k_largest(const double* x, int32_t n, int32_t k, int32
  * DECISION H1: u0 == NULL means the all-ones vector (upstream draws a random u0 from
  *   std::random_device, which no bit-exact comparison can follow).
  * DECISION H6: rounding is upstream's omega = round(F), take the omega largest entries of u.
- * M u and C u of the current u are carried from the accepting line-search trial instead of
- * being recomputed (bitwise identical inputs -> bitwise identical values); n_pass counts the
- * SpMV passes actually needed: 1 (rescale) + 1 (initial) + line-search trials.
+ * Pass mode CARRIED (oracle_set_pass_mode(0)): M u and C u of the current u are carried from the
+ * accepting line-search trial instead of being recomputed (bitwise identical inputs -> bitwise
+ * identical values); n_pass = 1 (rescale) + 1 (initial) + line-search trials.
+ * Pass mode FUSED (default, the device stream solver's order): a trial forms W = (M + d C) u' in one
+ * product; every d update is preceded by one split pass (M u, C u) over the accepted vector;
+ * n_pass = 1 + 1 + line-search trials + d updates evaluated.
  * support_trace (optional, length >= n_pass+2): number of u_p > 0 feeding each pass.
  */
 ORACLE_API int oracle_solve(const roman_params_t* P, const oracle_mat_t* m, const double* u0_in,
@@ -670,6 +717,44 @@ ORACLE_API int oracle_solve(const roman_params_t* P, const oracle_mat_t* m, cons
 
     double F = 0.0;
     int32_t i, j = 0, k;
+    int fused = g_pass_mode == 1;
+    if (g_pass_mode == 2) {
+        fused = S.n_live <= ORACLE_STREAM_MAXL && P->maxiniters >= 1 && P->maxlsiters >= 1;
+        for (int64_t e = 0; fused && e < m->nnz; ++e) fused = m->vals[e] >= 0.0 && m->vals[e] <= 1.0;
+    }
+    if (fused) {
+        /* FUSED: W/Wn stand where (Mu, Cu)/(Mun, Cun) stood; Mu, Cu hold the split products of the current u only between the
+           split pass and the start of the next outer iteration */
+        double* W  = Mun;      /* (Mun / Cun are free in this mode) */
+        double* Wn = Cun;
+        for (i = 0; i < P->maxoliters; ++i) {
+            for (int32_t p = 0; p < n; ++p) W[p] = Mu[p] + Cu[p] * d;
+            F = grad_and_F_fused(m, d, u, W, usum, g);
+            for (j = 0; j < P->maxiniters; ++j) {
+                double alpha = 1.0, Fnew = 0.0, deltaF = 0.0, unsum = 0.0;
+                for (k = 0; k < P->maxlsiters; ++k) {
+                    for (int32_t p = 0; p < n; ++p) { const double t = u[p] + alpha * g[p]; un[p] = t > 0.0 ? t : 0.0; }
+                    { const double nr = vnorm(un, n); if (nr > 0.0) for (int32_t p = 0; p < n; ++p) un[p] /= nr; }
+                    unsum = vsum(un, n);
+                    TRACE(un); spmv_fused(m, d, un, Wn); ++npass; ++S.ls_trials;
+                    Fnew = grad_and_F_fused(m, d, un, Wn, unsum, gn);
+                    deltaF = Fnew - F;
+                    if (deltaF < -P->eps) alpha *= P->beta; else break;
+                }
+                double du = 0.0;
+                for (int32_t p = 0; p < n; ++p) { const double t = un[p] - u[p]; du += t * t; }
+                du = sqrt(du);
+                F = Fnew; usum = unsum;
+                { double* t; t = u; u = un; un = t; t = g; g = gn; gn = t; t = W; W = Wn; Wn = t; }
+                ++S.inner_iters;
+                if (du < P->tol_u || fabs(deltaF) < P->tol_F) break;
+            }
+            TRACE(u); spmv_sym(m, u, Mu, Cu); ++npass;          /* the split pass of the d update */
+            const double dd = d_ratio_mean(m, P, u, Mu, Cu, usum, 1, &cnt);
+            if (cnt > 0) d += dd; else break;
+        }
+        Mun = W; Cun = Wn;                                       /* (whichever way the swaps left them: both are freed below) */
+    } else
     for (i = 0; i < P->maxoliters; ++i) {
         F = grad_and_F(m, d, u, Mu, Cu, usum, g);
         for (j = 0; j < P->maxiniters; ++j) {

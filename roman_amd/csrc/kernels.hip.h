@@ -1218,6 +1218,17 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
 }
 __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, int lane) { (void)lane; return wave_incl_scan(v) - v; }
 
+// lane `sel` of (hi:lo) <- the wave-uniform 64-bit value m (two v_writelane_b32: uniform value, uniform lane select).  The
+// instruction's constant bus takes one SGPR: the lane select travels in m0.  This compiler exposes no writelane builtin, and
+// m0 is a reserved register that an asm statement may not list as clobbered: the statement saves and restores it itself.
+__device__ __forceinline__ void writelane2(uint32_t& lo, uint32_t& hi, unsigned long long m, uint32_t sel)
+{
+    const uint32_t ml_ = (uint32_t)m, mh_ = (uint32_t)(m >> 32);
+    uint32_t keep_;
+    asm("s_mov_b32 %2, m0\n\ts_mov_b32 m0, %4\n\tv_writelane_b32 %0, %3, m0\n\tv_writelane_b32 %1, %5, m0\n\ts_mov_b32 m0, %2"
+        : "+v"(lo), "+v"(hi), "=&s"(keep_) : "s"(ml_), "s"(sel), "s"(mh_));
+}
+
 // GM: 0 no gravity prior, 1 ROMAN_GRAV_COMBINED, 2 ROMAN_GRAV_SEPARATE, 3 ROMAN_GRAV_ZGATE (tables then hold full lengths)
 template <int GM>
 __device__ __forceinline__ bool pair_gate(const DevParams& D, double a, double bb, double dz)
@@ -1350,11 +1361,8 @@ __device__ __forceinline__ void count_rows_lds(const DevParams& D, const ProbDes
                     const double dz = GM ? fabs((zi[x] - zz[t].x) - (zj[x] - zz[t].y)) : 0.0;
                     const bool is = pair_gate<GM>(D, a, bb, dz);
                     const unsigned long long m = __ballot(is);
-                    {   // lane (widx & 63) of (mhi:mlo) <- m  (v_writelane_b32: uniform value, uniform lane select)
-                        const uint32_t ml_ = (uint32_t)m, mh_ = (uint32_t)(m >> 32), sel_ = (uint32_t)(widx & 63);
-                        asm("s_mov_b32 m0, %3\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %4, m0"
-                            : "+v"(mlo[x]), "+v"(mhi[x]) : "s"(ml_), "s"(sel_), "s"(mh_) : "m0");
-                    }
+                    // lane (widx & 63) of (mhi:mlo) <- m
+                    writelane2(mlo[x], mhi[x], m, (uint32_t)(widx & 63));
                 }
             }
             const int wend = min(W, (q0 >> 6) + U);             // words [.., wend) are complete
@@ -1787,9 +1795,7 @@ __global__ void __launch_bounds__(1024) k_upper(const ProbDesc* __restrict__ pro
             uint32_t glo = 0u, ghi = 0u;                         // lane wd: columns of word wd with a position > p
             for (int wd = 0; wd < W; ++wd) {
                 const unsigned long long gt = __ballot((int)posS[(wd << 6) + lane] > p0);
-                const uint32_t gl_ = (uint32_t)gt, gh_ = (uint32_t)(gt >> 32), sel_ = (uint32_t)__builtin_amdgcn_readfirstlane(wd);
-                asm("s_mov_b32 m0, %3\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %4, m0"
-                    : "+v"(glo), "+v"(ghi) : "s"(gl_), "s"(sel_), "s"(gh_) : "m0");
+                writelane2(glo, ghi, gt, (uint32_t)__builtin_amdgcn_readfirstlane(wd));
             }
             unsigned long long behind = ((unsigned long long)ghi << 32) | glo;
             // the wave's rows: live index and list offset of row r0 + l in lane l (read back with v_readlane), and the
@@ -2958,6 +2964,12 @@ __global__ void __launch_bounds__(1024) k_solve(DevParams D, int B, const ProbDe
 // The rounding unit 2^-s is 2^-48 relative to the largest element of x, the same order as the rounding of an f64
 // summation.  The conversion is one fma against 2^52 + 2^51 (the integer appears in the low mantissa bits).
 //
+// Fused passes (round 5).  Inside the line search only the sum (M + d C) x enters the gradient; M x and C x are needed
+// apart only where d itself is updated (once per outer iteration).  A line-search pass therefore accumulates ONE
+// fixed-point sum per element with the weight v + d (v alone where C_pq = 0): one LDS gather and ONE ds_add_u64 per
+// stored pair instead of one and two; the d update is preceded by a SPLIT pass (both sums) over the accepted vector.
+// The same order is stated in the oracle (oracle_set_pass_mode(1), its default).
+//
 // One balanced stream: the S slices of a pass are contiguous in memory (quads); wave w streams the quads
 // [w T / NW, (w+1) T / NW) with ST_D quads (9 wide loads) in flight per lane, whatever slices the range covers
 // (lane = row slot of the current slice) and flushes its pulled sums when it leaves a slice or its range.
@@ -3156,12 +3168,14 @@ __device__ void solve_up(const DevParams& D, int b, const ProbDesc& pd, ProbStat
     const uint32_t cqv = cooPre >= 0 ? 0u : ((lane < nsl) ? (sliceBasePool[lo + lane] >> 8) : (st[b].nnzCap >> 8));
 #define CUMQ(s_) ((uint32_t)__builtin_amdgcn_readlane((int)cqv, (s_)))
     for (int p = tid; p < Lc; p += NT) { xg[p] = 0.0; accM[p] = 0ull; accC[p] = 0ull; }
-    double u[KMAX], Mu[KMAX], Cu[KMAX], sd[KMAX], tk[KMAX], Mn[KMAX], Cn[KMAX];
+    // Wu: the fused product (M + d C) u of the current u at the current d; Mn / Cn: the products of the pass just done —
+    // a fused pass leaves (M + d C) x in Mn and nothing in Cn, a split pass M x and C x
+    double u[KMAX], Wu[KMAX], sd[KMAX], tk[KMAX], Mn[KMAX], Cn[KMAX];
     FOR_K_ALL(k, p) {
         const bool in = p < L;
         sd[k] = in ? pld[lo + p] : 0.0;
         u[k] = in ? (u0 ? u0[lo + plp[lo + p]] : 1.0) : 0.0;
-        Mu[k] = Cu[k] = tk[k] = Mn[k] = Cn[k] = 0.0;
+        Wu[k] = tk[k] = Mn[k] = Cn[k] = 0.0;
     }
     __syncthreads();
 
@@ -3227,18 +3241,21 @@ __device__ void solve_up(const DevParams& D, int b, const ProbDesc& pd, ProbStat
         }
     }
 
-    // ---- (M x, C x) -> (Mn, Cn) for the vector x held in tk[] (elements >= 0), with xmax = max x and
-    //      mp1 = 1 + the largest position with x > 0 (0: x is the zero vector) --------------------------------
-    auto spmv = [&](double xmax, int mp1) {
+    // ---- products of the vector x held in tk[] (elements >= 0), with xmax = max x and mp1 = 1 + the largest position with
+    //      x > 0 (0: x is the zero vector):  split: (M x, C x) -> (Mn, Cn);  fused: (M + de C) x -> Mn (de >= 0; 0: M x alone)
+    auto spmv = [&](double xmax, int mp1, const bool split, const double de_) {
         TMARK(3);
         if (!(xmax > 0.0) || mp1 <= 0) {                       // zero vector: zero products, nothing to publish
             FOR_K(k, p) { Mn[k] = 0.0; Cn[k] = 0.0; }
             ++n_pass;
             return;
         }
-        // scale: x_max * 2^s in [2^48, 2^49)
+        const double de = (!split && de_ > 0.0) ? de_ : 0.0;    // what is added to a weight (wave-uniform)
+        // scale: the largest term w x 2^s stays below 2^49: x_max 2^s in [2^48, 2^49) when the weights are those of M (<= 1),
+        // and a further factor 2^(exponent(1 + de) + 1) >= 1 + de down when de is added to them
         int e_ = (int)((__double_as_longlong(xmax) >> 52) & 0x7ff) - 1023;
         int s_ = 48 - e_;
+        if (de > 0.0) s_ -= (int)((__double_as_longlong(1.0 + de) >> 52) & 0x7ff) - 1023 + 1;
         s_ = s_ > 960 ? 960 : (s_ < -960 ? -960 : s_);
         const double sc = bits_f64((unsigned long long)(1023 + s_) << 52), inv = bits_f64((unsigned long long)(1023 - s_) << 52);
         FOR_K(k, p) if (p < L) xg[p] = tk[k] * sc;
@@ -3254,13 +3271,14 @@ __device__ void solve_up(const DevParams& D, int b, const ProbDesc& pd, ProbStat
                         const uint32_t p_ = cpq[e] & 0xffu, q_ = (cpq[e] >> 8) & 0xffu;
                         const bool cz = HASCZ && (cpq[e] & 0x10000u);
                         const double xp_ = xl[p_], xq_ = xl[q_];
+                        const double w_ = cz ? cv[e] : cv[e] + de;      // (split: de == 0, the weight of M)
                         if (xq_ != 0.0) {
-                            __hip_atomic_fetch_add(aM + p_, (unsigned long long)__double_as_longlong(fma(cv[e], xq_, FX_MAGIC)) - FX_MAGIC_BITS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            if (!cz) __hip_atomic_fetch_add(aC + p_, (unsigned long long)__double_as_longlong(xq_ + FX_MAGIC) - FX_MAGIC_BITS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            __hip_atomic_fetch_add(aM + p_, (unsigned long long)__double_as_longlong(fma(w_, xq_, FX_MAGIC)) - FX_MAGIC_BITS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            if (split && !cz) __hip_atomic_fetch_add(aC + p_, (unsigned long long)__double_as_longlong(xq_ + FX_MAGIC) - FX_MAGIC_BITS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         }
                         if (xp_ != 0.0) {
-                            __hip_atomic_fetch_add(aM + q_, (unsigned long long)__double_as_longlong(fma(cv[e], xp_, FX_MAGIC)) - FX_MAGIC_BITS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            if (!cz) __hip_atomic_fetch_add(aC + q_, (unsigned long long)__double_as_longlong(xp_ + FX_MAGIC) - FX_MAGIC_BITS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            __hip_atomic_fetch_add(aM + q_, (unsigned long long)__double_as_longlong(fma(w_, xp_, FX_MAGIC)) - FX_MAGIC_BITS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            if (split && !cz) __hip_atomic_fetch_add(aC + q_, (unsigned long long)__double_as_longlong(xp_ + FX_MAGIC) - FX_MAGIC_BITS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         }
                         __builtin_amdgcn_sched_barrier(0);      // (one round at a time: hoisting all six rounds' gathers costs a wave of occupancy)
                     }
@@ -3297,35 +3315,45 @@ __device__ void solve_up(const DevParams& D, int b, const ProbDesc& pd, ProbStat
                 const uint32_t clo = (uint32_t)(C_), chi = (uint32_t)((C_) >> 32);                          \
                 const uint32_t c0 = clo & ST_MASK, c1 = (clo >> 16) & ST_MASK, c2 = chi & ST_MASK, c3 = (chi >> 16) & ST_MASK; \
                 const double x0 = xl[c0], x1 = xl[c1], x2 = xl[c2], x3 = xl[c3];                            \
-                smI += (unsigned long long)__double_as_longlong(fma((V0_).x, x0, FX_MAGIC));                \
-                smI += (unsigned long long)__double_as_longlong(fma((V0_).y, x1, FX_MAGIC));                \
-                smI += (unsigned long long)__double_as_longlong(fma((V1_).x, x2, FX_MAGIC));                \
-                smI += (unsigned long long)__double_as_longlong(fma((V1_).y, x3, FX_MAGIC));                \
-                if (HASCZ) {                                                                                \
-                    scI += (unsigned long long)__double_as_longlong(((clo & ST_CZ) ? 0.0 : x0) + FX_MAGIC); \
-                    scI += (unsigned long long)__double_as_longlong(((clo & (ST_CZ << 16)) ? 0.0 : x1) + FX_MAGIC); \
-                    scI += (unsigned long long)__double_as_longlong(((chi & ST_CZ) ? 0.0 : x2) + FX_MAGIC); \
-                    scI += (unsigned long long)__double_as_longlong(((chi & (ST_CZ << 16)) ? 0.0 : x3) + FX_MAGIC); \
-                } else {              /* the only C-flagged entries are inert: they gather a zero */        \
-                    scI += (unsigned long long)__double_as_longlong(x0 + FX_MAGIC);                         \
-                    scI += (unsigned long long)__double_as_longlong(x1 + FX_MAGIC);                         \
-                    scI += (unsigned long long)__double_as_longlong(x2 + FX_MAGIC);                         \
-                    scI += (unsigned long long)__double_as_longlong(x3 + FX_MAGIC);                         \
+                /* weights of this pass: v (split; fused with de == 0) or v + de, v alone where C_pq == 0 (inert entries  \
+                   carry the flag when HASCZ: they keep their 0) */                                         \
+                const double w0 = (HASCZ && (clo & ST_CZ)) ? (V0_).x : (V0_).x + de;                        \
+                const double w1 = (HASCZ && (clo & (ST_CZ << 16))) ? (V0_).y : (V0_).y + de;                \
+                const double w2 = (HASCZ && (chi & ST_CZ)) ? (V1_).x : (V1_).x + de;                        \
+                const double w3 = (HASCZ && (chi & (ST_CZ << 16))) ? (V1_).y : (V1_).y + de;                \
+                smI += (unsigned long long)__double_as_longlong(fma(w0, x0, FX_MAGIC));                     \
+                smI += (unsigned long long)__double_as_longlong(fma(w1, x1, FX_MAGIC));                     \
+                smI += (unsigned long long)__double_as_longlong(fma(w2, x2, FX_MAGIC));                     \
+                smI += (unsigned long long)__double_as_longlong(fma(w3, x3, FX_MAGIC));                     \
+                if (split) {                                                                                \
+                    if (HASCZ) {                                                                            \
+                        scI += (unsigned long long)__double_as_longlong(((clo & ST_CZ) ? 0.0 : x0) + FX_MAGIC); \
+                        scI += (unsigned long long)__double_as_longlong(((clo & (ST_CZ << 16)) ? 0.0 : x1) + FX_MAGIC); \
+                        scI += (unsigned long long)__double_as_longlong(((chi & ST_CZ) ? 0.0 : x2) + FX_MAGIC); \
+                        scI += (unsigned long long)__double_as_longlong(((chi & (ST_CZ << 16)) ? 0.0 : x3) + FX_MAGIC); \
+                    } else {          /* the only C-flagged entries are inert: they gather a zero */        \
+                        scI += (unsigned long long)__double_as_longlong(x0 + FX_MAGIC);                     \
+                        scI += (unsigned long long)__double_as_longlong(x1 + FX_MAGIC);                     \
+                        scI += (unsigned long long)__double_as_longlong(x2 + FX_MAGIC);                     \
+                        scI += (unsigned long long)__double_as_longlong(x3 + FX_MAGIC);                     \
+                    }                                                                                       \
                 }                                                                                           \
                 if (xp != 0.0) {                      /* push this row's element to the columns */          \
-                    __hip_atomic_fetch_add(aM + c0, (unsigned long long)__double_as_longlong(fma((V0_).x, xp, FX_MAGIC)) - FX_MAGIC_BITS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
-                    __hip_atomic_fetch_add(aM + c1, (unsigned long long)__double_as_longlong(fma((V0_).y, xp, FX_MAGIC)) - FX_MAGIC_BITS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
-                    __hip_atomic_fetch_add(aM + c2, (unsigned long long)__double_as_longlong(fma((V1_).x, xp, FX_MAGIC)) - FX_MAGIC_BITS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
-                    __hip_atomic_fetch_add(aM + c3, (unsigned long long)__double_as_longlong(fma((V1_).y, xp, FX_MAGIC)) - FX_MAGIC_BITS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
-                    if (!HASCZ || !(clo & ST_CZ)) __hip_atomic_fetch_add(aC + c0, iCp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
-                    if (!HASCZ || !(clo & (ST_CZ << 16))) __hip_atomic_fetch_add(aC + c1, iCp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
-                    if (!HASCZ || !(chi & ST_CZ)) __hip_atomic_fetch_add(aC + c2, iCp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
-                    if (!HASCZ || !(chi & (ST_CZ << 16))) __hip_atomic_fetch_add(aC + c3, iCp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+                    __hip_atomic_fetch_add(aM + c0, (unsigned long long)__double_as_longlong(fma(w0, xp, FX_MAGIC)) - FX_MAGIC_BITS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+                    __hip_atomic_fetch_add(aM + c1, (unsigned long long)__double_as_longlong(fma(w1, xp, FX_MAGIC)) - FX_MAGIC_BITS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+                    __hip_atomic_fetch_add(aM + c2, (unsigned long long)__double_as_longlong(fma(w2, xp, FX_MAGIC)) - FX_MAGIC_BITS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+                    __hip_atomic_fetch_add(aM + c3, (unsigned long long)__double_as_longlong(fma(w3, xp, FX_MAGIC)) - FX_MAGIC_BITS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+                    if (split) {                                                                            \
+                        if (!HASCZ || !(clo & ST_CZ)) __hip_atomic_fetch_add(aC + c0, iCp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+                        if (!HASCZ || !(clo & (ST_CZ << 16))) __hip_atomic_fetch_add(aC + c1, iCp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+                        if (!HASCZ || !(chi & ST_CZ)) __hip_atomic_fetch_add(aC + c2, iCp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+                        if (!HASCZ || !(chi & (ST_CZ << 16))) __hip_atomic_fetch_add(aC + c3, iCp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+                    }                                                                                       \
                 }                                                                                           \
                 if ((Q_) + 1 == nextB || (Q_) + 1 == qe) {            /* end of this slice's piece: flush the pulled sums */ \
                     const unsigned long long nterm = (unsigned long long)(((Q_) + 1 - pieceQ) * 4u) * FX_MAGIC_BITS; \
                     __hip_atomic_fetch_add(aM + (s * 64 + lane), smI - nterm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
-                    __hip_atomic_fetch_add(aC + (s * 64 + lane), scI - nterm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+                    if (split) __hip_atomic_fetch_add(aC + (s * 64 + lane), scI - nterm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
                     smI = 0ull; scI = 0ull; pieceQ = (Q_) + 1;                                              \
                     if ((Q_) + 1 < qe) {                                                                    \
                         const int s_old_ = s;                                                               \
@@ -3361,8 +3389,8 @@ __device__ void solve_up(const DevParams& D, int b, const ProbDesc& pd, ProbStat
         TMARK(1);
         FOR_K(k, p) {
             if (p < L) {
-                Mn[k] = fx_decode(accM[p], inv); Cn[k] = fx_decode(accC[p], inv);
-                accM[p] = 0ull; accC[p] = 0ull;                 // clean for the next pass (published by its barrier)
+                Mn[k] = fx_decode(accM[p], inv); accM[p] = 0ull;            // clean for the next pass (published by its barrier)
+                if (split) { Cn[k] = fx_decode(accC[p], inv); accC[p] = 0ull; } else Cn[k] = 0.0;
                 // LEAN: the multiplied vector was not kept in registers across the stream: xg holds x * 2^s, and a power-of-two
                 // scaling is exact in both directions
                 if (LEAN) tk[k] = xg[p] * inv;
@@ -3373,7 +3401,7 @@ __device__ void solve_up(const DevParams& D, int b, const ProbDesc& pd, ProbStat
     };
 
     // ---- the iteration as a state machine around ONE SpMV call site ------------------------------------
-    enum { PH_RESCALE, PH_INIT, PH_TRIAL };
+    enum { PH_RESCALE, PH_INIT, PH_TRIAL, PH_SPLIT };
     int phase = p_rescale ? PH_RESCALE : PH_INIT;
     double usum = 0.0, alpha = 1.0, unsum = 0.0, du2 = 0.0, xmaxT = 0.0;
     int mp1T = 0;
@@ -3392,12 +3420,13 @@ __device__ void solve_up(const DevParams& D, int b, const ProbDesc& pd, ProbStat
         block_red<NW, 0, 2>(r0, m2, red, par, tid);             // NS == 0: r0 is not touched
         xmaxT = m2[0]; mp1T = (int)m2[1];
     };
+    // gradient of the current u: ((s_p + d) u_p - d sum(u)) + ((M + d C) u)_p  (oracle: grad_and_F_fused)
     // trial vector u' = normalize(max(u + alpha g, 0)) into tk (+ its sums and support)
     auto build_trial = [&]() {
         double r[1] = {0.0}, m2[2] = {0.0, 0.0};
         FOR_K(k, p) {
             const double up = u[k];
-            const double g = (((sd[k] + d) * up - d * usum) + Mu[k]) + Cu[k] * d;
+            const double g = ((sd[k] + d) * up - d * usum) + Wu[k];
             double t = up + alpha * g;
             t = (p < L && t > 0.0) ? t : 0.0;
             tk[k] = t; r[0] += t * t;
@@ -3421,21 +3450,22 @@ __device__ void solve_up(const DevParams& D, int b, const ProbDesc& pd, ProbStat
         unsum = q[0]; du2 = q[1];
         xmaxT = (nr > 0.0) ? m2[0] / nr : m2[0]; mp1T = (int)m2[1];
     };
-    auto objective = [&](const double (&uu)[KMAX], const double (&mm)[KMAX], const double (&cc)[KMAX], double us) -> double {
+    auto objective = [&](const double (&uu)[KMAX], const double (&ww)[KMAX], double us) -> double {
         double r[1] = {0.0}, m0[1] = {0.0};
         FOR_K(k, p) {
             const double up = uu[k];
-            const double g = (((sd[k] + d) * up - d * us) + mm[k]) + cc[k] * d;
+            const double g = ((sd[k] + d) * up - d * us) + ww[k];
             r[0] += up * g;
         }
         block_red<NW, 1, 0>(r, m0, red, par, tid);
         return r[0];
     };
-    auto d_ratio = [&](bool absval, double& acc, double& cnt) { // mean of (M u)_p / Cbu_p over the active set
+    // mean of (M u)_p / Cbu_p over the active set, from the products (Mn, Cn) of the split pass over u just done
+    auto d_ratio = [&](bool absval, double& acc, double& cnt) {
         double r2[2] = {0.0, 0.0}, m0[1] = {0.0};
         FOR_K(k, p) {
-            const double up = u[k], Cbu = (usum - Cu[k]) - up;
-            if (p < L && Cbu > p_eps && up > p_eps) { const double r_ = (Mu[k] + sd[k] * up) / Cbu; r2[0] += absval ? fabs(r_) : r_; r2[1] += 1.0; }
+            const double up = u[k], Cbu = (usum - Cn[k]) - up;
+            if (p < L && Cbu > p_eps && up > p_eps) { const double r_ = (Mn[k] + sd[k] * up) / Cbu; r2[0] += absval ? fabs(r_) : r_; r2[1] += 1.0; }
         }
         block_red<NW, 2, 0>(r2, m0, red, par, tid);
         acc = r2[0]; cnt = r2[1];
@@ -3444,7 +3474,8 @@ __device__ void solve_up(const DevParams& D, int b, const ProbDesc& pd, ProbStat
     if (phase == PH_INIT) normalize_u();
     load_u_as_x();
     for (;;) {
-        spmv(xmaxT, mp1T);
+        // RESCALE: M x alone (a fused pass with nothing added); INIT / SPLIT: both products; TRIAL: (M + d C) x
+        spmv(xmaxT, mp1T, phase == PH_INIT || phase == PH_SPLIT, phase == PH_TRIAL ? d : 0.0);
         if (phase == PH_RESCALE) {                              // u = normalize(M u0 + diag u0)
             FOR_K(k, p) u[k] = (p < L) ? Mn[k] + sd[k] * u[k] : 0.0;
             normalize_u();
@@ -3452,9 +3483,7 @@ __device__ void solve_up(const DevParams& D, int b, const ProbDesc& pd, ProbStat
             phase = PH_INIT;
             continue;
         }
-        bool new_outer = false;
         if (phase == PH_INIT) {
-            FOR_K(k, p) { Mu[k] = Mn[k]; Cu[k] = Cn[k]; }
             double r1[1] = {0.0}, m0[1] = {0.0};
             FOR_K(k, p) r1[0] += u[k];
             block_red<NW, 1, 0>(r1, m0, red, par, tid);
@@ -3464,32 +3493,36 @@ __device__ void solve_up(const DevParams& D, int b, const ProbDesc& pd, ProbStat
             d = (cnt > 0.0) ? acc / cnt : 0.0;
             i = 0;
             if (i >= p_maxout) break;
-            new_outer = true;
-        } else {                                                // PH_TRIAL: products of the trial vector
+        } else if (phase == PH_SPLIT) {                         // end of an inner loop: homotopy update of d from (M u, C u)
+            double acc, cnt;
+            d_ratio(true, acc, cnt);
+            if (cnt > 0.0) d += acc / cnt; else break;
+            ++i;
+            if (i >= p_maxout) break;
+        } else {                                                // PH_TRIAL: the fused product of the trial vector
             ++ls_trials;
-            const double Fnew = objective(tk, Mn, Cn, unsum);
+            const double Fnew = objective(tk, Mn, unsum);
             const double deltaF = Fnew - F;
             if (deltaF < -p_eps && kk + 1 < p_maxls) {          // backtrack
                 alpha *= p_beta; ++kk;
                 build_trial();
                 continue;
             }
-            // accept: the trial vector and its products become the current ones
+            // accept: the trial vector and its product become the current ones
             const double du = sqrt(du2);
             F = Fnew; usum = unsum;
-            FOR_K(k, p) { u[k] = tk[k]; Mu[k] = Mn[k]; Cu[k] = Cn[k]; }
+            FOR_K(k, p) { u[k] = tk[k]; Wu[k] = Mn[k]; }
             ++inner_iters; ++j;
             const bool stop = du < p_tol_u || fabs(deltaF) < p_tol_F;
-            if (stop || j >= p_maxin) {                    // end of the inner loop: homotopy update of d
-                double acc, cnt;
-                d_ratio(true, acc, cnt);
-                if (cnt > 0.0) d += acc / cnt; else break;
-                ++i;
-                if (i >= p_maxout) break;
-                new_outer = true;
+            if (stop || j >= p_maxin) {                         // the d update needs M u and C u apart: one split pass over
+                phase = PH_SPLIT;                               // the accepted vector (tk, xmaxT, mp1T are still its own)
+                continue;
             }
         }
-        if (new_outer) { F = objective(u, Mu, Cu, usum); j = 0; }
+        if (phase != PH_TRIAL) {                                // a new outer iteration: the fused product at the new d
+            FOR_K(k, p) Wu[k] = Mn[k] + Cn[k] * d;
+            F = objective(u, Wu, usum); j = 0;
+        }
         alpha = 1.0; kk = 0;
         build_trial();
         phase = PH_TRIAL;
@@ -3679,7 +3712,6 @@ __global__ void __launch_bounds__(64, 3) k_small(DevParams D, int B, const ProbD
 #pragma unroll
             for (int wd = 0; wd < 2; ++wd) {
                 const int q1 = min(L, (wd + 1) * 64);
-#pragma unroll 2
                 for (int q = wd * 64; q < q1; ++q) {
                     const uint32_t pk = cIJ[q];
                     const int iq = (int)(pk & 0xffffu), jq = (int)(pk >> 16);

@@ -35,7 +35,7 @@ def find_dense_clique(M, C, u0=None, tol_u=1e-8, tol_F=1e-9, maxiniters=200, max
         return float(np.mean(np.abs(r) if absval else r))
 
     d = penalty_step(u, False) or 0.0
-    inner = trials = 0
+    inner = trials = updates = 0
     for outer in range(maxoliters):
         Md = M - d * Cb
         g = Md @ u
@@ -61,6 +61,7 @@ def find_dense_clique(M, C, u0=None, tol_u=1e-8, tol_F=1e-9, maxiniters=200, max
             if du < tol_u or abs(dF) < tol_F:
                 break
         inc = penalty_step(u, True)
+        updates += 1
         if inc is None:
             outer_done = outer
             break
@@ -72,5 +73,8 @@ def find_dense_clique(M, C, u0=None, tol_u=1e-8, tol_F=1e-9, maxiniters=200, max
     # the omega largest entries, descending; ties by descending index like a (value, index) min-heap pops
     order = sorted(range(n), key=lambda i: (u[i], i), reverse=True)
     nodes = np.array(order[:omega], dtype=np.int64)
+    # n_pass: the published count (one product per line-search trial; M u, C u of the accepted trial carried to the d update);
+    # n_pass_fused: the count of an implementation that forms M_d u' as ONE product in the line search — as this statement
+    # does — and therefore needs M u and C u apart, one more pass, at every d update (the device's stream solver)
     return dict(nodes=nodes, u=u, F=F, d=d, inner_iters=inner, ls_trials=trials, outer_iters=outer_done,
-                n_pass=passes + trials)
+                n_pass=passes + trials, n_pass_fused=passes + trials + updates)

@@ -43,16 +43,20 @@ def test_c_oracle_matches_dense_numpy_statement(orc, case):
     A = reg._association_list(pr.map1, pr.map2)
     mat, _ = orc.build_matrix(P, D1, D2, A)
     M, C = mat.dense()
-    sol_c = orc.solve(P, mat)
     sol_d = find_dense_clique(M, C, tol_u=P.tol_u, tol_F=P.tol_F, maxiniters=P.maxiniters, maxoliters=P.maxoliters,
                               beta=P.beta, maxlsiters=P.maxlsiters, eps=P.eps, rescale_u0=bool(P.rescale_u0))
-    st = sol_c["stats"]
-    assert np.array_equal(sol_c["nodes"], sol_d["nodes"]), "selected nodes / order differ"
-    assert (st.inner_iters, st.ls_trials, st.outer_iters, st.n_pass) == \
-        (sol_d["inner_iters"], sol_d["ls_trials"], sol_d["outer_iters"], sol_d["n_pass"])
-    assert abs(st.score - sol_d["F"]) <= 1e-9 * max(1.0, abs(sol_d["F"]))
-    assert abs(st.d_final - sol_d["d"]) <= 1e-9 * max(1.0, abs(sol_d["d"]))
-    assert np.allclose(sol_c["u"], sol_d["u"], rtol=0, atol=1e-10)
+    # both organisations of the oracle's passes (published: products carried to the d update; the device stream solver's:
+    # fused line-search products + a split pass per d update) against the one dense statement
+    for mode, key in (("carried", "n_pass"), ("fused", "n_pass_fused")):
+        with orc.pass_mode(mode):
+            sol_c = orc.solve(P, mat)
+        st = sol_c["stats"]
+        assert np.array_equal(sol_c["nodes"], sol_d["nodes"]), "selected nodes / order differ"
+        assert (st.inner_iters, st.ls_trials, st.outer_iters, st.n_pass) == \
+            (sol_d["inner_iters"], sol_d["ls_trials"], sol_d["outer_iters"], sol_d[key]), mode
+        assert abs(st.score - sol_d["F"]) <= 1e-9 * max(1.0, abs(sol_d["F"]))
+        assert abs(st.d_final - sol_d["d"]) <= 1e-9 * max(1.0, abs(sol_d["d"]))
+        assert np.allclose(sol_c["u"], sol_d["u"], rtol=0, atol=1e-10)
 
 
 def test_dense_statement_with_explicit_u0_and_no_rescale(orc):
@@ -64,10 +68,12 @@ def test_dense_statement_with_explicit_u0_and_no_rescale(orc):
     u0 = rng.uniform(0.1, 1.0, mat.n)
     P2 = type(P).from_buffer_copy(P); P2.rescale_u0 = 0
     for PP in (P, P2):
-        sc = orc.solve(PP, mat, u0)
         sd = find_dense_clique(M, C, u0=u0, rescale_u0=bool(PP.rescale_u0))
-        assert np.array_equal(sc["nodes"], sd["nodes"])
-        assert sc["stats"].n_pass == sd["n_pass"]
+        for mode, key in (("carried", "n_pass"), ("fused", "n_pass_fused")):
+            with orc.pass_mode(mode):
+                sc = orc.solve(PP, mat, u0)
+            assert np.array_equal(sc["nodes"], sd["nodes"])
+            assert sc["stats"].n_pass == sd[key]
 
 
 def test_dense_statement_recovers_a_planted_clique():
