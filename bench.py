@@ -74,45 +74,7 @@ def parse():
     return ap.parse_args()
 
 
-class CallLoop:
-    """The choreography of the calls of a step, independent of the device (tests/test_bench_loop_cpu.py drives it at world
-    size 2 on gloo with a stub context): call number c writes output set c % nset; with batches in flight
-    (`pipeline` >= 2) the records of call c - 1 are gathered while call c computes — `join(skip_latest=True)` makes the
-    gathering stream wait for every call but the latest —, `drain()` gathers the last call's; at depth 1 a call is
-    gathered right behind itself.  `launch(ci, k)`: enqueue call `ci` of the step into output set `k`; `join(skip_latest)`;
-    `gather(k)`: collect output set k on every rank (None: single process, nothing to gather)."""
-
-    def __init__(self, n_calls, nset, pipeline, launch, join, gather=None):
-        assert nset >= max(pipeline, 2), "an output set is rewritten only after the call pipeline + 1 calls back has been gathered"
-        self.n_calls, self.nset, self.pipeline = n_calls, nset, pipeline
-        self.launch, self.join, self.gather = launch, join, gather
-        self.call_no = 0
-
-    def one_call(self, ci):
-        k = self.call_no % self.nset
-        self.call_no += 1
-        self.launch(ci, k)
-        if self.gather is not None:
-            if self.pipeline >= 2:
-                if self.call_no > 1:
-                    self.join(True)                              # the gathering stream waits for the OLDER calls only
-                    self.gather((k - 1) % self.nset)
-            else:
-                self.gather(k)
-        return k
-
-    def step(self):
-        for ci in range(self.n_calls):
-            self.one_call(ci)
-
-    def drain(self):                                             # results of the last call
-        if self.pipeline >= 2:
-            self.join(False)
-            if self.gather is not None and self.call_no > 0:
-                self.gather((self.call_no - 1) % self.nset)
-
-    def reset(self):
-        self.call_no = 0
+from roman_amd.align.pipeline import CallLoop  # noqa: E402,F401  (the choreography lives in the package; tests/test_bench_loop_cpu.py drives it)
 
 
 def self_launch(args_list, n):
@@ -225,25 +187,14 @@ def main():
         meta = [(batch.off1[ix], batch.n1[ix], batch.off2[ix], batch.n2[ix]) for ix in calls]
         CB = chunk                                                 # rows of the output sets / gathered records
 
-        # one output set per call in flight: call k writes set k % NSET while older sets are gathered
-        # one output set per call in flight — and one more with a process group: the gather of call c - 1 runs on its own stream while
-        # call c computes, and the set call c + pipeline - 1 rewrites must not be the one that gather is still reading
-        NSET = max(args.pipeline, 2) + (1 if dist_on else 0)
-        O = out_sets(CB, kmax, NSET)
-        if dist_on:
-            rec_i = torch.empty((CB, 2 + 2 * kmax), dtype=torch.int32, device=dev)
-            gat_i = torch.empty((world * CB, 2 + 2 * kmax), dtype=torch.int32, device=dev)
-            gat_T = torch.empty((world * CB, 16), dtype=torch.float64, device=dev)
-
-            gstream = torch.cuda.Stream(dev)                       # the gathers' own stream: a collective never sits between two batch calls
-            ev_g = [None] * NSET                                   # behind the gather that read output set k
-
-        def gather(k):                                             # collect inlier sets + poses of output set k on every rank
-            with torch.cuda.stream(gstream):
-                rec_i[:, 0] = O.n[k]; rec_i[:, 1] = O.status[k]; rec_i[:, 2:] = O.assoc[k].view(CB, -1)
-                dist.all_gather_into_tensor(gat_i, rec_i)
-                dist.all_gather_into_tensor(gat_T, O.T[k])
-                ev_g[k] = torch.cuda.Event(); ev_g[k].record(gstream)
+        # The timed loop is the PACKAGE's: roman_amd.align.pipeline.AlignStream — `pipeline` batch calls in flight, call c writes
+        # output set c % nset, and with a process group the records of call c - 1 are all-gathered on the stream's own collector
+        # stream while call c computes.  What this function adds is the workload and the clock.
+        from roman_amd.align.pipeline import AlignStream
+        S = AlignStream(reg, ctx, dev, rows=CB, kmax=kmax, in_flight=args.pipeline, stream=stream, use_group=bool(dist_on))
+        NSET = S.nset
+        O = types.SimpleNamespace(assoc=[x.assoc for x in S.sets], n=[x.n for x in S.sets], T=[x.T for x in S.sets],
+                                  status=[x.status for x in S.sets], stats=[x.stats for x in S.sets])
 
         # h2d: pinned host copy of the pool, two device buffers, a copy stream
         if h2d:
@@ -256,18 +207,15 @@ def main():
 
         fptr_now = [feats.data_ptr()]
 
-        def launch(ci, k):
-            o1, a1, o2, a2 = meta[ci]
-            if dist_on and ev_g[k] is not None:                    # output set k is rewritten: behind the gather that read it (NSET calls ago)
-                stream.wait_event(ev_g[k])
-            ctx.align_batch_dev(P, fptr_now[0], F, o1, a1, o2, a2, kmax,
-                                O.assoc[k].data_ptr(), O.n[k].data_ptr(), O.T[k].data_ptr(), O.status[k].data_ptr(), O.stats[k].data_ptr())
-
-        # (with a process group the waits for finished calls go onto the gathers' stream: the context's stream — behind which every
-        #  batch call starts — stays free of them, and all `pipeline` calls stay in flight)
-        loop = CallLoop(len(calls), NSET, args.pipeline, launch,
-                        (lambda skip: ctx.join(skip_latest=skip, stream=gstream.cuda_stream)) if dist_on else (lambda skip: ctx.join(skip_latest=skip)),
-                        gather if dist_on else None)
+        class _Loop:                                               # one step = the calls of the workload, in order
+            @staticmethod
+            def step():
+                for ci in range(len(calls)):
+                    o1, a1, o2, a2 = meta[ci]
+                    S.submit(fptr_now[0], F, o1, a1, o2, a2)
+            drain = staticmethod(S.drain)
+            reset = staticmethod(S.reset)
+        loop = _Loop
 
         def step():
             fptr = feats.data_ptr()

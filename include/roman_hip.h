@@ -215,6 +215,13 @@ ROMAN_API int roman_ctx_join(roman_ctx_t* ctx, int skip_latest);
 ROMAN_API int roman_ctx_join_on(roman_ctx_t* ctx, int skip_latest, void* stream);
 /* Wait for every batch in flight on this context (all internal streams and the context's stream). */
 ROMAN_API int roman_ctx_sync(roman_ctx_t* ctx);
+/* How roman_align_batch (host pointers) issues a LARGE batch: more than `chunk` problems (default 512) go to the device as
+   calls of `chunk` problems with `depth` of them in flight (default 3; 1 = one call for the whole batch, as before round 5) —
+   the pipelined loop a device-pointer caller would write around roman_align_batch_dev, done by the library for the caller of
+   the reference's serial loop [REF roman/align/submap_align.py:93-200] who hands over every surviving pair at once.  Problems
+   a call skipped for workspace are issued again (those only); without a sizing history for the parameter block the first call
+   is waited for before the others are queued.  The depth set with roman_ctx_set_pipeline is restored on return. */
+ROMAN_API int roman_ctx_set_host_batching(roman_ctx_t* ctx, int chunk, int depth);
 
 /* Human-readable text of the last error on this context (or of the last context-less error
    when ctx == NULL).  The pointer stays valid until the next call on the same context. */
@@ -285,7 +292,7 @@ ROMAN_API int roman_align_batch_dev(roman_ctx_t* ctx, const roman_params_t* para
        if (after != before) { ... status_out[b] & ROMAN_ST_WORKSPACE marks the problems: issue THOSE again — same call
                                   with off1/n1/off2/n2/assoc_off restricted to them; the context has recorded their need,
                                   so the second attempt sizes its pools for them ... }
-   roman_align_batch (host pointers) runs exactly this loop itself (at most 4 attempts, then ROMAN_E_NOMEM). */
+   roman_align_batch (host pointers) runs exactly this loop itself (at most 5 attempts, then ROMAN_E_NOMEM). */
 ROMAN_API int roman_ctx_skipped(roman_ctx_t* ctx, int wait, int64_t* n_skipped);
 
 /* Same contract with HOST pointers everywhere; `n_objects` = number of objects in `feats`.

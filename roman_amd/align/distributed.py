@@ -63,14 +63,23 @@ def upload_pool(batch: AlignmentBatch, dev):
     return torch.from_numpy(np.ascontiguousarray(batch.feats, dtype=np.float64)).to(dev)
 
 
-def _device_records(registration, sub: AlignmentBatch, kmax, per, dev, pool=None):
-    """Align `sub` with device-resident inputs and outputs; -> (ints (per, 2+2*kmax) int32, poses (per,16) f64) torch
-    tensors on `dev`, rows beyond len(sub) padded with -1 / NaN.  Problems the speculatively sized workspace skipped
-    (ROMAN_ST_WORKSPACE) are issued again — those problems only — and an error is raised if any is still skipped after
-    four attempts; what is still skipped then keeps the flag in its record (align_sharded raises).  The feature pool is
-    uploaded once per call (or taken from `pool`) and shared by the retries."""
+def _same_device(a, b):
+    """torch devices compared by type and index (an index-less device means the current one)."""
     import torch
-    from .. import _abi
+    norm = lambda d: (d.type, d.index if d.index is not None else (torch.cuda.current_device() if d.type == "cuda" else 0))
+    return norm(torch.device(a)) == norm(torch.device(b))
+
+
+def _device_records(registration, sub: AlignmentBatch, kmax, per, dev, pool=None, chunk=256, in_flight=3):
+    """Align `sub` with device-resident inputs and outputs; -> (ints (per, 2+2*kmax) int32, poses (per,16) f64) torch
+    tensors on `dev`, rows beyond len(sub) padded with -1 / NaN.  The problems go out as calls of `chunk` problems with
+    `in_flight` of them on the device at once (pipeline.issue_chunked: a rank's share of a large grid in ONE call would last
+    as long as its slowest problem); problems the speculatively sized workspace skipped (ROMAN_ST_WORKSPACE) are issued
+    again — those only; what is still skipped after the attempts, or came back ROMAN_ST_INTERNAL (no further attempts then),
+    keeps the flag in its record (align_sharded raises AFTER the gather, on every rank alike — an exception on one rank in
+    front of a collective would leave the others waiting in it).  The feature pool is uploaded once per call (or taken from `pool`)."""
+    import torch
+    from .pipeline import issue_chunked
     ctx = registration._context()
     B = len(sub)
     ints = torch.full((per, 2 + 2 * kmax), -1, dtype=torch.int32, device=dev)
@@ -78,40 +87,16 @@ def _device_records(registration, sub: AlignmentBatch, kmax, per, dev, pool=None
     if B == 0:
         return ints, poses
     P = registration._abi_params()
-    F = sub.feats.shape[1]
-    if pool is not None and (tuple(pool.shape) != tuple(sub.feats.shape) or str(pool.dtype) != "torch.float64" or pool.device != dev):
+    if pool is not None and (tuple(pool.shape) != tuple(sub.feats.shape) or str(pool.dtype) != "torch.float64" or not _same_device(pool.device, dev)):
         raise ValueError(f"pool must be the batch's feature matrix {sub.feats.shape} as a float64 tensor on {dev}")
     feats = pool if pool is not None else upload_pool(sub, dev)
     a_out = torch.full((B, kmax, 2), -1, dtype=torch.int32, device=dev)
     n_out = torch.zeros(B, dtype=torch.int32, device=dev)
     T_out = torch.zeros((B, 16), dtype=torch.float64, device=dev)
     st_out = torch.zeros(B, dtype=torch.int32, device=dev)
-    torch.cuda.current_stream(dev).synchronize()               # inputs are in place before the library's stream reads them
-    todo = np.arange(B)
-    for attempt in range(4):                                   # the device-pointer entry sizes its pools speculatively
-        part = sub if len(todo) == B else take(sub, todo)
-        assoc = None if part.assoc is None else torch.from_numpy(np.ascontiguousarray(part.assoc, dtype=np.int32)).to(dev)
-        if len(todo) == B:
-            ao, no, To, so = a_out, n_out, T_out, st_out
-        else:
-            nb = len(todo)
-            ao = torch.full((nb, kmax, 2), -1, dtype=torch.int32, device=dev); no = torch.zeros(nb, dtype=torch.int32, device=dev)
-            To = torch.zeros((nb, 16), dtype=torch.float64, device=dev); so = torch.zeros(nb, dtype=torch.int32, device=dev)
-            torch.cuda.current_stream(dev).synchronize()
-        ctx.align_batch_dev(P, feats.data_ptr(), F, part.off1, part.n1, part.off2, part.n2, kmax, ao.data_ptr(), no.data_ptr(),
-                            To.data_ptr(), so.data_ptr(), None,
-                            assoc_ptr=None if assoc is None else assoc.data_ptr(), assoc_off=part.assoc_off)
-        ctx.sync()
-        if len(todo) != B:
-            ix = torch.from_numpy(todo).to(dev)
-            a_out[ix] = ao; n_out[ix] = no; T_out[ix] = To; st_out[ix] = so
-        skipped = ((so & _abi.ROMAN_ST_WORKSPACE) != 0).cpu().numpy()
-        if not skipped.any():
-            break
-        todo = todo[skipped]
-    # (problems still skipped after four attempts keep ROMAN_ST_WORKSPACE in their record, problems the library gave up on
-    #  ROMAN_ST_INTERNAL: align_sharded raises for both AFTER the gather, on every rank alike — an exception on one rank in
-    #  front of a collective would leave the others waiting in it)
+    assoc = None if sub.assoc is None else torch.from_numpy(np.ascontiguousarray(sub.assoc, dtype=np.int32)).to(dev)
+    torch.cuda.current_stream(dev).synchronize()               # inputs are in place before the library's streams read them
+    issue_chunked(ctx, P, feats, sub, kmax, a_out, n_out, T_out, st_out, None, assoc, chunk, in_flight)
     ints[:B, 0] = n_out; ints[:B, 1] = st_out
     valid = torch.arange(kmax, device=dev)[None, :] < n_out[:, None]
     ints[:B, 2:] = torch.where(valid[:, :, None], a_out, torch.full_like(a_out, -1)).reshape(B, -1)
@@ -119,9 +104,10 @@ def _device_records(registration, sub: AlignmentBatch, kmax, per, dev, pool=None
     return ints, poses
 
 
-def align_sharded(registration, batch: AlignmentBatch, group=None, compute=None, device=None, pool=None):
+def align_sharded(registration, batch: AlignmentBatch, group=None, compute=None, device=None, pool=None, chunk=256, in_flight=3):
     """Align `batch` across the ranks of `group` (default: WORLD); every rank returns the full result
-    (assoc list, T, status) in problem order.
+    (assoc list, T, status) in problem order.  A rank's share goes to its GPU as calls of `chunk` problems with `in_flight`
+    of them on the device at once.
 
     compute(registration, sub_batch) -> runtime.BatchResult: a CPU double for tests; by default the HIP path runs with
     device-resident records (`device`: torch device of this rank, default cuda:<current device>; `pool`: the batch's
@@ -142,7 +128,7 @@ def align_sharded(registration, batch: AlignmentBatch, group=None, compute=None,
     on_device = compute is None
     if on_device:
         dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
-        ti, tp = _device_records(registration, sub, kmax, per, dev, pool=pool)
+        ti, tp = _device_records(registration, sub, kmax, per, dev, pool=pool, chunk=chunk, in_flight=in_flight)
     else:
         res = compute(registration, sub)
         ints, poses = pack_records(res, kmax)
@@ -177,4 +163,4 @@ def check_records(status):
     if len(bad):
         n_int = int(np.count_nonzero(status[bad] & _abi.ROMAN_ST_INTERNAL))
         raise _abi.RomanHipError(f"{len(bad)} problem(s) without a result ({n_int} ROMAN_ST_INTERNAL, {len(bad) - n_int} ROMAN_ST_WORKSPACE "
-                                 f"after 4 attempts): problems {bad[:8].tolist()}")
+                                 f"after the retries): problems {bad[:8].tolist()}")

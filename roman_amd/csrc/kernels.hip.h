@@ -3125,6 +3125,9 @@ __device__ void solve_up(const DevParams& D, int b, const ProbDesc& pd, ProbStat
 {
     constexpr int NT = NW * 64;
     constexpr int KMAX = (MAXL + NT - 1) / NT;                 // elements per thread (the kernel takes problems of up to MAXL live associations)
+    // The three LDS vectors lie at a FIXED distance from each other — accM == xg + LCAP, accC == xg + 2 LCAP (the callers lay them
+    // out so; Lc == LCAP) —: the stream addresses the accumulators of a column through the column's gather address + an immediate
+    constexpr int LCAP = MAXL + 64;
     const roman_params_t& P = D.p;
     // the solver's parameters as scalars (the argument block sits in scratch memory: its address is taken for the shared tail)
     const double p_eps = uni(P.eps), p_beta = uni(P.beta), p_tol_u = uni(P.tol_u), p_tol_F = uni(P.tol_F);
@@ -3258,13 +3261,32 @@ __device__ void solve_up(const DevParams& D, int b, const ProbDesc& pd, ProbStat
         if (de > 0.0) s_ -= (int)((__double_as_longlong(1.0 + de) >> 52) & 0x7ff) - 1023 + 1;
         s_ = s_ > 960 ? 960 : (s_ < -960 ? -960 : s_);
         const double sc = bits_f64((unsigned long long)(1023 + s_) << 52), inv = bits_f64((unsigned long long)(1023 - s_) << 52);
+        // This wave's range of the stream and its first DEPTH quads, requested BEFORE the vector is published: the matrix does
+        // not depend on x, and a narrow pass is a dozen quads per wave — four or five dependent round trips to the L2 —, so the
+        // first of them now runs under the publish, the barrier and its skew instead of behind them.  (Unconditional loads at
+        // clamped indices, as in the loop below: the wait counters stay exact.  No quads at all: any valid address.)
+        bool streamed = false;
+        if constexpr (NW == 1) streamed = cooRounds >= 0;       // the matrix is in registers: pushes only
+        const int Sx = (COOONLY || streamed) ? 0 : min(nsl, (mp1 + 63) >> 6);
+        const uint32_t T = COOONLY ? 0u : CUMQ(Sx);
+        const uint32_t qs = (uint32_t)(((unsigned long long)T * (unsigned)w) / NW), qe = (uint32_t)(((unsigned long long)T * (unsigned)(w + 1)) / NW);
+        [[maybe_unused]] unsigned long long rc[DEPTH]; [[maybe_unused]] dbl2_t rv0[DEPTH], rv1[DEPTH];
+        if constexpr (!COOONLY) {
+            const uint32_t qlast = (qe > qs ? qe : qs + 1u) - 1u;
+            g_quad_cp cb0 = T ? cbase : (g_quad_cp)colsPool + lane;
+            g_pair_cp vb0 = T ? vbase : (g_pair_cp)valsPool + lane;
+#pragma unroll
+            for (int t = 0; t < DEPTH; ++t) {
+                const uint32_t qq = min(qs + (uint32_t)t, qlast);
+                rc[t] = cb0[(size_t)qq * 64];
+                rv0[t] = vb0[(size_t)(2 * qq) * 64]; rv1[t] = vb0[(size_t)(2 * qq + 1) * 64];
+            }
+        }
         FOR_K(k, p) if (p < L) xg[p] = tk[k] * sc;
         __syncthreads();                                        // the scaled vector is published; accumulators are clean
         TMARK(6);
-        bool streamed = false;
         if constexpr (NW == 1) {
-            if (cooRounds >= 0) {                               // the matrix is in registers: pushes only
-                streamed = true;
+            if (cooRounds >= 0) {
 #pragma unroll
                 for (int e = 0; e < COO_E; ++e) {
                     if (e < cooRounds) {
@@ -3285,10 +3307,12 @@ __device__ void solve_up(const DevParams& D, int b, const ProbDesc& pd, ProbStat
                 }
             }
         }
-        const int Sx = (COOONLY || streamed) ? 0 : min(nsl, (mp1 + 63) >> 6);
-        const uint32_t T = COOONLY ? 0u : CUMQ(Sx);
-        const uint32_t qs = (uint32_t)(((unsigned long long)T * (unsigned)w) / NW), qe = (uint32_t)(((unsigned long long)T * (unsigned)(w + 1)) / NW);
-        if (!COOONLY && qs < qe) {
+        // The stream itself, once per kind of pass (SPLIT a compile-time constant: the line search's fused passes carry no code
+        // for the second sum).  A wave is alone with one other on its SIMD: nothing hides a latency for it, so the four gathers of
+        // quad q + 1 are requested BEFORE quad q is worked on (its labels arrived with the ring), and the accumulators sit at fixed
+        // distances LCAP behind the gathered vector — gather and push of a column share one address register.
+        auto stream = [&](auto split_tag) {
+            constexpr bool SPLIT = decltype(split_tag)::value;
             int s = 0;
             {   // largest s with cumQ[s] <= qs (skips empty slices)
                 int lo_ = 0, hi_ = Sx;
@@ -3296,64 +3320,65 @@ __device__ void solve_up(const DevParams& D, int b, const ProbDesc& pd, ProbStat
                 s = lo_;
             }
             uint32_t nextB = CUMQ(s + 1);
-            // ring of DEPTH quads in flight per lane; loads are issued unconditionally (clamped index) so that the wait
-            // counters stay exact
-            unsigned long long rc[DEPTH]; dbl2_t rv0[DEPTH], rv1[DEPTH];
-#pragma unroll
-            for (int t = 0; t < DEPTH; ++t) {
-                const uint32_t qq = min(qs + (uint32_t)t, qe - 1u);
-                rc[t] = cbase[(size_t)qq * 64];
-                rv0[t] = vbase[(size_t)(2 * qq) * 64]; rv1[t] = vbase[(size_t)(2 * qq + 1) * 64];
-            }
-            unsigned long long smI = 0ull, scI = 0ull;          // pulled sums of this lane's row: sum of bits(MAGIC + term)
+            // ring of DEPTH quads in flight per lane (filled above, in front of the barrier); loads are issued unconditionally
+            // (clamped index) so that the wait counters stay exact
+            unsigned long long smI = 0ull; [[maybe_unused]] unsigned long long scI = 0ull;   // pulled sums of this lane's row: sum of bits(MAGIC + term)
             uint32_t pieceQ = qs;                               // first quad of the current piece
             double xp = xl[s * 64 + lane];                      // this lane's row element (scaled); rows >= L read zeros
             double xpn = xl[(s + 1) * 64 + lane];               // ... and the next slice's, fetched ahead of the transition
-            unsigned long long iCp = (unsigned long long)__double_as_longlong(xp + FX_MAGIC) - FX_MAGIC_BITS;
+            [[maybe_unused]] unsigned long long iCp = (unsigned long long)__double_as_longlong(xp + FX_MAGIC) - FX_MAGIC_BITS;
+            // gathered elements of a quad: addresses (the accumulators of the same columns lie LCAP and 2 LCAP elements behind) and values
+            l_vec_cp ga[4], gn[4]; double xa[4], xn[4];
+#define UP_GATHER(C_, G_, X_)                                                                               \
+            {                                                                                               \
+                const uint32_t lo__ = (uint32_t)(C_), hi__ = (uint32_t)((C_) >> 32);                        \
+                (G_)[0] = xl + (lo__ & ST_MASK); (G_)[1] = xl + ((lo__ >> 16) & ST_MASK);                   \
+                (G_)[2] = xl + (hi__ & ST_MASK); (G_)[3] = xl + ((hi__ >> 16) & ST_MASK);                   \
+                (X_)[0] = *(G_)[0]; (X_)[1] = *(G_)[1]; (X_)[2] = *(G_)[2]; (X_)[3] = *(G_)[3];             \
+            }
+#define UP_PUSH(G_, OFF_, V_) __hip_atomic_fetch_add((l_acc_p)(G_) + (OFF_), (V_), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 #define UP_CONSUME(Q_, C_, V0_, V1_)                                                                        \
             {                                                                                               \
-                const uint32_t clo = (uint32_t)(C_), chi = (uint32_t)((C_) >> 32);                          \
-                const uint32_t c0 = clo & ST_MASK, c1 = (clo >> 16) & ST_MASK, c2 = chi & ST_MASK, c3 = (chi >> 16) & ST_MASK; \
-                const double x0 = xl[c0], x1 = xl[c1], x2 = xl[c2], x3 = xl[c3];                            \
+                [[maybe_unused]] const uint32_t clo = (uint32_t)(C_), chi = (uint32_t)((C_) >> 32);         \
                 /* weights of this pass: v (split; fused with de == 0) or v + de, v alone where C_pq == 0 (inert entries  \
                    carry the flag when HASCZ: they keep their 0) */                                         \
-                const double w0 = (HASCZ && (clo & ST_CZ)) ? (V0_).x : (V0_).x + de;                        \
-                const double w1 = (HASCZ && (clo & (ST_CZ << 16))) ? (V0_).y : (V0_).y + de;                \
-                const double w2 = (HASCZ && (chi & ST_CZ)) ? (V1_).x : (V1_).x + de;                        \
-                const double w3 = (HASCZ && (chi & (ST_CZ << 16))) ? (V1_).y : (V1_).y + de;                \
-                smI += (unsigned long long)__double_as_longlong(fma(w0, x0, FX_MAGIC));                     \
-                smI += (unsigned long long)__double_as_longlong(fma(w1, x1, FX_MAGIC));                     \
-                smI += (unsigned long long)__double_as_longlong(fma(w2, x2, FX_MAGIC));                     \
-                smI += (unsigned long long)__double_as_longlong(fma(w3, x3, FX_MAGIC));                     \
-                if (split) {                                                                                \
+                const double w0 = SPLIT ? (V0_).x : ((HASCZ && (clo & ST_CZ)) ? (V0_).x : (V0_).x + de);    \
+                const double w1 = SPLIT ? (V0_).y : ((HASCZ && (clo & (ST_CZ << 16))) ? (V0_).y : (V0_).y + de); \
+                const double w2 = SPLIT ? (V1_).x : ((HASCZ && (chi & ST_CZ)) ? (V1_).x : (V1_).x + de);    \
+                const double w3 = SPLIT ? (V1_).y : ((HASCZ && (chi & (ST_CZ << 16))) ? (V1_).y : (V1_).y + de); \
+                smI += (unsigned long long)__double_as_longlong(fma(w0, xa[0], FX_MAGIC));                  \
+                smI += (unsigned long long)__double_as_longlong(fma(w1, xa[1], FX_MAGIC));                  \
+                smI += (unsigned long long)__double_as_longlong(fma(w2, xa[2], FX_MAGIC));                  \
+                smI += (unsigned long long)__double_as_longlong(fma(w3, xa[3], FX_MAGIC));                  \
+                if constexpr (SPLIT) {                                                                      \
                     if (HASCZ) {                                                                            \
-                        scI += (unsigned long long)__double_as_longlong(((clo & ST_CZ) ? 0.0 : x0) + FX_MAGIC); \
-                        scI += (unsigned long long)__double_as_longlong(((clo & (ST_CZ << 16)) ? 0.0 : x1) + FX_MAGIC); \
-                        scI += (unsigned long long)__double_as_longlong(((chi & ST_CZ) ? 0.0 : x2) + FX_MAGIC); \
-                        scI += (unsigned long long)__double_as_longlong(((chi & (ST_CZ << 16)) ? 0.0 : x3) + FX_MAGIC); \
+                        scI += (unsigned long long)__double_as_longlong(((clo & ST_CZ) ? 0.0 : xa[0]) + FX_MAGIC); \
+                        scI += (unsigned long long)__double_as_longlong(((clo & (ST_CZ << 16)) ? 0.0 : xa[1]) + FX_MAGIC); \
+                        scI += (unsigned long long)__double_as_longlong(((chi & ST_CZ) ? 0.0 : xa[2]) + FX_MAGIC); \
+                        scI += (unsigned long long)__double_as_longlong(((chi & (ST_CZ << 16)) ? 0.0 : xa[3]) + FX_MAGIC); \
                     } else {          /* the only C-flagged entries are inert: they gather a zero */        \
-                        scI += (unsigned long long)__double_as_longlong(x0 + FX_MAGIC);                     \
-                        scI += (unsigned long long)__double_as_longlong(x1 + FX_MAGIC);                     \
-                        scI += (unsigned long long)__double_as_longlong(x2 + FX_MAGIC);                     \
-                        scI += (unsigned long long)__double_as_longlong(x3 + FX_MAGIC);                     \
+                        scI += (unsigned long long)__double_as_longlong(xa[0] + FX_MAGIC);                  \
+                        scI += (unsigned long long)__double_as_longlong(xa[1] + FX_MAGIC);                  \
+                        scI += (unsigned long long)__double_as_longlong(xa[2] + FX_MAGIC);                  \
+                        scI += (unsigned long long)__double_as_longlong(xa[3] + FX_MAGIC);                  \
                     }                                                                                       \
                 }                                                                                           \
                 if (xp != 0.0) {                      /* push this row's element to the columns */          \
-                    __hip_atomic_fetch_add(aM + c0, (unsigned long long)__double_as_longlong(fma(w0, xp, FX_MAGIC)) - FX_MAGIC_BITS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
-                    __hip_atomic_fetch_add(aM + c1, (unsigned long long)__double_as_longlong(fma(w1, xp, FX_MAGIC)) - FX_MAGIC_BITS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
-                    __hip_atomic_fetch_add(aM + c2, (unsigned long long)__double_as_longlong(fma(w2, xp, FX_MAGIC)) - FX_MAGIC_BITS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
-                    __hip_atomic_fetch_add(aM + c3, (unsigned long long)__double_as_longlong(fma(w3, xp, FX_MAGIC)) - FX_MAGIC_BITS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
-                    if (split) {                                                                            \
-                        if (!HASCZ || !(clo & ST_CZ)) __hip_atomic_fetch_add(aC + c0, iCp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
-                        if (!HASCZ || !(clo & (ST_CZ << 16))) __hip_atomic_fetch_add(aC + c1, iCp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
-                        if (!HASCZ || !(chi & ST_CZ)) __hip_atomic_fetch_add(aC + c2, iCp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
-                        if (!HASCZ || !(chi & (ST_CZ << 16))) __hip_atomic_fetch_add(aC + c3, iCp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+                    UP_PUSH(ga[0], LCAP, (unsigned long long)__double_as_longlong(fma(w0, xp, FX_MAGIC)) - FX_MAGIC_BITS); \
+                    UP_PUSH(ga[1], LCAP, (unsigned long long)__double_as_longlong(fma(w1, xp, FX_MAGIC)) - FX_MAGIC_BITS); \
+                    UP_PUSH(ga[2], LCAP, (unsigned long long)__double_as_longlong(fma(w2, xp, FX_MAGIC)) - FX_MAGIC_BITS); \
+                    UP_PUSH(ga[3], LCAP, (unsigned long long)__double_as_longlong(fma(w3, xp, FX_MAGIC)) - FX_MAGIC_BITS); \
+                    if constexpr (SPLIT) {                                                                  \
+                        if (!HASCZ || !(clo & ST_CZ)) UP_PUSH(ga[0], 2 * LCAP, iCp);                        \
+                        if (!HASCZ || !(clo & (ST_CZ << 16))) UP_PUSH(ga[1], 2 * LCAP, iCp);                \
+                        if (!HASCZ || !(chi & ST_CZ)) UP_PUSH(ga[2], 2 * LCAP, iCp);                        \
+                        if (!HASCZ || !(chi & (ST_CZ << 16))) UP_PUSH(ga[3], 2 * LCAP, iCp);                \
                     }                                                                                       \
                 }                                                                                           \
                 if ((Q_) + 1 == nextB || (Q_) + 1 == qe) {            /* end of this slice's piece: flush the pulled sums */ \
                     const unsigned long long nterm = (unsigned long long)(((Q_) + 1 - pieceQ) * 4u) * FX_MAGIC_BITS; \
-                    __hip_atomic_fetch_add(aM + (s * 64 + lane), smI - nterm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
-                    if (split) __hip_atomic_fetch_add(aC + (s * 64 + lane), scI - nterm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+                    UP_PUSH(xl + (s * 64 + lane), LCAP, smI - nterm);                                       \
+                    if constexpr (SPLIT) UP_PUSH(xl + (s * 64 + lane), 2 * LCAP, scI - nterm);              \
                     smI = 0ull; scI = 0ull; pieceQ = (Q_) + 1;                                              \
                     if ((Q_) + 1 < qe) {                                                                    \
                         const int s_old_ = s;                                                               \
@@ -3364,6 +3389,7 @@ __device__ void solve_up(const DevParams& D, int b, const ProbDesc& pd, ProbStat
                     }                                                                                       \
                 }                                                                                           \
             }
+            UP_GATHER(rc[0], ga, xa)
             uint32_t q0 = qs;
             for (; q0 + DEPTH <= qe; q0 += DEPTH) {
 #pragma unroll
@@ -3374,17 +3400,30 @@ __device__ void solve_up(const DevParams& D, int b, const ProbDesc& pd, ProbStat
                     const uint32_t qn = min(q + (uint32_t)DEPTH, qe - 1u);
                     rc[t] = cbase[(size_t)qn * 64];
                     rv0[t] = vbase[(size_t)(2 * qn) * 64]; rv1[t] = vbase[(size_t)(2 * qn + 1) * 64];
+                    UP_GATHER(rc[(t + 1) % DEPTH], gn, xn)           // quad q + 1 (behind the last quad: a duplicate, unused)
                     UP_CONSUME(q, c, v0, v1)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { ga[e] = gn[e]; xa[e] = xn[e]; }
                 }
             }
 #pragma unroll
             for (int t = 0; t < DEPTH; ++t) {                    // tail: fewer than DEPTH quads, already in the ring
                 const uint32_t q = q0 + t;
-                if (q < qe) { UP_CONSUME(q, rc[t], rv0[t], rv1[t]) }
+                if (q < qe) {
+                    UP_GATHER(rc[(t + 1) % DEPTH], gn, xn)
+                    UP_CONSUME(q, rc[t], rv0[t], rv1[t])
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { ga[e] = gn[e]; xa[e] = xn[e]; }
+                }
             }
 #undef UP_CONSUME
+#undef UP_PUSH
+#undef UP_GATHER
+        };
+        if (!COOONLY && qs < qe) {
+            if (split) stream(std::true_type{}); else stream(std::false_type{});
         }
-        TMARK(0);
+        TMARK(Sx <= 2 ? 4 : 0);                                 // (timing build: the stream of narrow passes — at most two slices — apart)
         __syncthreads();                                        // every contribution has landed
         TMARK(1);
         FOR_K(k, p) {
@@ -3422,6 +3461,25 @@ __device__ void solve_up(const DevParams& D, int b, const ProbDesc& pd, ProbStat
     };
     // gradient of the current u: ((s_p + d) u_p - d sum(u)) + ((M + d C) u)_p  (oracle: grad_and_F_fused)
     // trial vector u' = normalize(max(u + alpha g, 0)) into tk (+ its sums and support)
+    // second half of a trial vector: tk holds max(u + alpha g, 0), r2 is its squared norm, m2 its maximum and 1 + its last
+    // non-zero position -> tk normalised, its sums, its distance from u, its maximum and support bound
+    auto finish_trial = [&](double r2, const double (&m2)[2]) {
+        const double nr = sqrt(r2);
+        double q[2] = {0.0, 0.0}, m0[1] = {0.0};                // sum u', |u'-u|^2
+        FOR_K(k, p) {
+            double t = tk[k];
+            // (0 / nr == 0: an element outside the support skips the division — once the support has collapsed that is every
+            //  element of seven of the eight waves, and an f64 division is ~40 instructions)
+            if (nr > 0.0 && t != 0.0) { t /= nr; tk[k] = t; }
+            q[0] += t;
+            const double df = t - u[k]; q[1] += df * df;
+        }
+        TMARK(3);
+        block_red<NW, 2, 0>(q, m0, red, par, tid);
+        TMARK(7);
+        unsum = q[0]; du2 = q[1];
+        xmaxT = (nr > 0.0) ? m2[0] / nr : m2[0]; mp1T = (int)m2[1];
+    };
     auto build_trial = [&]() {
         double r[1] = {0.0}, m2[2] = {0.0, 0.0};
         FOR_K(k, p) {
@@ -3436,19 +3494,7 @@ __device__ void solve_up(const DevParams& D, int b, const ProbDesc& pd, ProbStat
         TMARK(3);
         block_red<NW, 1, 2>(r, m2, red, par, tid);
         TMARK(6);
-        const double nr = sqrt(r[0]);
-        double q[2] = {0.0, 0.0}, m0[1] = {0.0};                // sum u', |u'-u|^2
-        FOR_K(k, p) {
-            double t = tk[k];
-            if (nr > 0.0) { t /= nr; tk[k] = t; }
-            q[0] += t;
-            const double df = t - u[k]; q[1] += df * df;
-        }
-        TMARK(3);
-        block_red<NW, 2, 0>(q, m0, red, par, tid);
-        TMARK(7);
-        unsum = q[0]; du2 = q[1];
-        xmaxT = (nr > 0.0) ? m2[0] / nr : m2[0]; mp1T = (int)m2[1];
+        finish_trial(r[0], m2);
     };
     auto objective = [&](const double (&uu)[KMAX], const double (&ww)[KMAX], double us) -> double {
         double r[1] = {0.0}, m0[1] = {0.0};
@@ -3501,6 +3547,9 @@ __device__ void solve_up(const DevParams& D, int b, const ProbDesc& pd, ProbStat
             if (i >= p_maxout) break;
         } else {                                                // PH_TRIAL: the fused product of the trial vector
             ++ls_trials;
+            // (Forming the first half of the NEXT trial — max(u' + g(u'), 0), its norm, maximum and support bound — in the same
+            //  reduction as this objective saves a workgroup barrier per accepted trial and was built in round 5: the four-value
+            //  reduction and the discarded work of rejected trials cost more than the barrier, 0.99 against 0.96 ms per launch.)
             const double Fnew = objective(tk, Mn, unsum);
             const double deltaF = Fnew - F;
             if (deltaF < -p_eps && kk + 1 < p_maxls) {          // backtrack
@@ -3519,7 +3568,7 @@ __device__ void solve_up(const DevParams& D, int b, const ProbDesc& pd, ProbStat
                 continue;
             }
         }
-        if (phase != PH_TRIAL) {                                // a new outer iteration: the fused product at the new d
+        if (phase != PH_TRIAL) {                                // a new outer iteration (INIT / SPLIT): the fused product at the new d
             FOR_K(k, p) Wu[k] = Mn[k] + Cn[k] * d;
             F = objective(u, Wu, usum); j = 0;
         }
@@ -3564,6 +3613,7 @@ __global__ void __launch_bounds__(NW * 64, LEAN ? 4 : (NW == 1 ? 3 : 1)) k_solve
 {
     // LDS: xg[Lc] f64 | accM[Lc] u64 | accC[Lc] u64 | red[red_doubles(NW)] | cumQ[ST_MAXSL + 2] u32 | sint[8]
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // (Lc == MAXL + 64: solve_up addresses the accumulators at fixed distances from xg)
     double* xg = reinterpret_cast<double*>(smem);
     unsigned long long* accM = reinterpret_cast<unsigned long long*>(xg + Lc);
     unsigned long long* accC = accM + Lc;

@@ -98,6 +98,9 @@ struct roman_ctx {
     hipStream_t istream[ROMAN_MAX_PIPELINE] = {};              // internal streams of the workspaces while pipelining
     int latest_ws = -1;                        // workspace of the most recent pipelined batch call
     hipEvent_t evIn = nullptr;                 // inputs ready on the caller's stream
+    // roman_align_batch (host pointers): a batch of more than host_chunk problems is issued as calls of host_chunk problems with
+    // host_depth of them in flight (roman_ctx_set_host_batching)
+    int host_chunk = 512, host_depth = 3;
 
     // sizing history: largest observed need relative to what the host can bound before the launch
     struct Hist {
@@ -329,7 +332,7 @@ void estimate_sizes(roman_ctx* c, const DevParams& D, const roman_params_t* para
     }
     S->capMaskWords = std::max<long long>(S->capMaskWords, 64);
     // tests: force the first attempt of a batch to overflow (exercises the skip / retry path)
-    static const char* tcap = getenv("ROMAN_TEST_CAPNNZ");
+    const char* tcap = getenv("ROMAN_TEST_CAPNNZ");            // (read per call: a test sets it for some of its contexts)
     if (tcap && !H.valid) S->capNnz = atoll(tcap);
 }
 
@@ -740,7 +743,7 @@ int enqueue_solve(roman_ctx* c, const DevParams& D, int B, int64_t sumA, int64_t
     // stream solver: LDS = three vectors of Lc elements (Lc: whole slices of stream_maxL + the 64 dummy elements the
     // inert padding entries point at) + reduction scratch + slice table
     constexpr int NW = ROMAN_SOLVE_WAVES;
-    const int Lc = ((D.stream_maxL + 63) & ~63) + 64;
+    const int Lc = STREAM_MAXL + 64;                            // (fixed: the kernel addresses the three vectors at compile-time distances)
     const size_t ldsUp = (size_t)3 * 8 * Lc + sizeof(double) * red_doubles(NW) + sizeof(uint32_t) * (ST_MAXSL + 2) + sizeof(int) * 8 + 16;
     const int wgPerCu = std::max(1, std::min((int)(c->lds_max / ldsUp), 2048 / (NW * 64)));
     const int gridUp = std::max(1, std::min(B, c->num_cu * wgPerCu));
@@ -900,7 +903,7 @@ int enqueue_solve(roman_ctx* c, const DevParams& D, int B, int64_t sumA, int64_t
         for (int b = 0; b < B; ++b) for (int t = 0; t < 16; ++t) acc[t] += (double)h[(size_t)b * 16 + t];
         // (k_solve_up: cycles of the phases named here; k_solve_wide: 10 ns ticks of trial+publish, barrier 1, stream, barrier 2,
         //  collect+objective, barrier 3, everything else — in slots 0..6)
-        const char* nm[8] = {"stream", "spmv-barrier", "decode", "elementwise", "-", "-", "publish", "red-sums"};
+        const char* nm[8] = {"stream", "spmv-barrier", "decode", "elementwise", "stream-narrow", "-", "publish", "red-sums"};
         fprintf(stderr, "[solve timing] B=%d cycles/problem:", B);
         double tot_ = 0; for (int t = 0; t < 8; ++t) tot_ += acc[t] / B;
         for (int t = 0; t < 8; ++t) fprintf(stderr, " %s %.0f (n=%.1f)", nm[t], acc[t] / B, acc[8 + t] / B);
@@ -1331,6 +1334,81 @@ int roman_align_batch_dev(roman_ctx_t* c, const roman_params_t* params, int32_t 
     return ROMAN_OK;
 }
 
+int roman_ctx_set_host_batching(roman_ctx_t* c, int chunk, int depth)
+{
+    if (!c) return fail(nullptr, ROMAN_E_INVALID, "ctx is NULL");
+    if (chunk < 1 || depth < 1 || depth > ROMAN_MAX_PIPELINE) return fail(c, ROMAN_E_INVALID, "chunk must be >= 1 and depth 1..%d", ROMAN_MAX_PIPELINE);
+    c->host_chunk = chunk; c->host_depth = depth;
+    return ROMAN_OK;
+}
+
+namespace {
+// Attempts a problem gets before the host-pointer entry points give up on its workspace: the speculative sizes can be corrected
+// once per pool (live set beyond the launch's LDS tiles / fallback kernels not launched, bit matrix, matrix slots, lists), and a
+// skip the library chose itself (small_only: the general kernels left out) is one more.
+constexpr int MAX_ATTEMPTS = 5;
+
+// The host-pointer batch in CALLS of c->host_chunk problems, c->host_depth of them in flight: what the pipelined loop of a
+// device-pointer caller does, for callers that hold host arrays — the straggler tail of one call's solver
+// overlaps the next calls' affinity builds.  Inputs are already on the device; every call writes its own rows of the output
+// arrays.  Problems a call skipped for workspace (ROMAN_ST_WORKSPACE) are issued again, those only, in runs of consecutive
+// problems.  With no sizing history for this parameter block the first call runs alone and is waited for: the calls queued
+// behind it size their pools from what it needed instead of repeating its guess.
+int align_chunked(roman_ctx* c, const roman_params_t* params, const BatchIn& in, const double* dU0, const BatchOut& out)
+{
+    const int B = in.B, chunk = c->host_chunk;
+    const int saved = c->pipeline;
+    int rc = roman_ctx_set_pipeline(c, c->host_depth);
+    if (rc) return rc;
+    std::vector<int64_t> uoff;                                  // start of problem b's slice of u0
+    if (dU0) {
+        uoff.assign((size_t)B + 1, 0);
+        for (int b = 0; b < B; ++b) {
+            const int64_t na = in.assoc ? in.assoc_off[b + 1] - in.assoc_off[b] : 0;
+            uoff[b + 1] = uoff[b] + (na > 0 ? na : (int64_t)in.n1[b] * in.n2[b]);
+        }
+    }
+    auto issue = [&](int lo, int hi) -> int {
+        return roman_align_batch_dev(c, params, hi - lo, in.feats, in.off1 + lo, in.n1 + lo, in.off2 + lo, in.n2 + lo, in.F,
+                                     in.assoc, in.assoc ? in.assoc_off + lo : nullptr, dU0 ? dU0 + uoff[lo] : nullptr, out.kmax,
+                                     out.assoc_out + (size_t)lo * (size_t)out.kmax * 2, out.n_assoc_out + lo, out.T_out + (size_t)lo * 16, out.status_out + lo,
+                                     out.stats_out ? out.stats_out + lo : nullptr);
+    };
+    auto restore = [&](int code) -> int { const int r2 = roman_ctx_set_pipeline(c, saved); c->cur = 0; c->ws[0].stream = c->stream; return code ? code : r2; };
+    int lo = 0;
+    const roman_ctx::Hist& H = c->hist;
+    if (!(H.valid && H.tagged && H.F == in.F && memcmp(&H.params, params, sizeof(roman_params_t)) == 0)) {
+        rc = issue(0, std::min(B, chunk));
+        if (rc) return restore(rc);
+        rc = roman_ctx_sync(c);
+        if (rc) return restore(rc);
+        harvest_totals(c, true);
+        lo = std::min(B, chunk);
+    }
+    for (; lo < B; lo += chunk) { rc = issue(lo, std::min(B, lo + chunk)); if (rc) return restore(rc); }
+    std::vector<int32_t> st((size_t)B);
+    for (int attempt = 1; ; ++attempt) {
+        rc = roman_ctx_sync(c);
+        if (rc) return restore(rc);
+        harvest_totals(c, true);
+        if (hipMemcpy(st.data(), out.status_out, sizeof(int32_t) * (size_t)B, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return restore(fail(c, ROMAN_E_HIP, "status read-back failed")); }
+        int nskip = 0, nint = 0;
+        for (int b = 0; b < B; ++b) { nskip += (st[b] & ROMAN_ST_WORKSPACE) ? 1 : 0; nint += (st[b] & ROMAN_ST_INTERNAL) ? 1 : 0; }
+        if (!nskip || nint) break;                              // (a problem the library gave up on: no point in further attempts — the caller reports it)
+        if (attempt >= MAX_ATTEMPTS) return restore(fail(c, ROMAN_E_NOMEM, "the sparse workspace of %d problem(s) still does not fit after %d attempts", nskip, attempt));
+        for (int b = 0; b < B; ) {                              // runs of consecutive skipped problems, at most a chunk long
+            if (!(st[b] & ROMAN_ST_WORKSPACE)) { ++b; continue; }
+            int e = b + 1;
+            while (e < B && e - b < chunk && (st[e] & ROMAN_ST_WORKSPACE)) ++e;
+            rc = issue(b, e);
+            if (rc) return restore(rc);
+            b = e;
+        }
+    }
+    return restore(ROMAN_OK);
+}
+}  // namespace
+
 int roman_align_batch(roman_ctx_t* c, const roman_params_t* params, int32_t B,
                       const double* feats, int64_t n_objects,
                       const int64_t* off1, const int32_t* n1, const int64_t* off2, const int32_t* n2, int32_t F,
@@ -1385,6 +1463,11 @@ int roman_align_batch(roman_ctx_t* c, const roman_params_t* params, int32_t B,
     HIPCHK(c, WS.oStats.ensure(sizeof(roman_stats_t) * (size_t)B));
     const BatchIn in{B, WS.hFeats.as<double>(), off1, n1, off2, n2, F, dA, assoc_off};
     const BatchOut out{kmax, WS.oAssoc.as<int32_t>(), WS.oN.as<int32_t>(), WS.oT.as<double>(), WS.oStatus.as<int32_t>(), WS.oStats.as<roman_stats_t>()};
+    if (B > c->host_chunk && c->host_depth >= 2) {
+        // many problems: calls of host_chunk problems, host_depth of them in flight, skipped problems issued again (align_chunked)
+        rc = align_chunked(c, params, in, dU0, out);
+        if (rc) return rc;
+    } else
     // this entry point is synchronous anyway: when a problem did not fit the speculatively sized pools, run again
     // with the need the first attempt recorded
     for (int attempt = 0; ; ++attempt) {
@@ -1392,7 +1475,7 @@ int roman_align_batch(roman_ctx_t* c, const roman_params_t* params, int32_t B,
         if (rc) return rc;
         HIPCHK(c, hipStreamSynchronize(WS.stream));
         if (!batch_overflowed(c)) break;
-        if (attempt >= 3) return fail(c, ROMAN_E_NOMEM, "the sparse workspace still does not fit after %d attempts", attempt + 1);
+        if (attempt + 1 >= MAX_ATTEMPTS) return fail(c, ROMAN_E_NOMEM, "the sparse workspace still does not fit after %d attempts", attempt + 1);
     }
     if (kmax > 0) HIPCHK(c, hipMemcpyAsync(assoc_out, WS.oAssoc.p, sizeof(int32_t) * 2 * (size_t)B * (size_t)kmax, hipMemcpyDeviceToHost, WS.stream));
     HIPCHK(c, hipMemcpyAsync(n_assoc_out, WS.oN.p, sizeof(int32_t) * (size_t)B, hipMemcpyDeviceToHost, WS.stream));
@@ -1457,7 +1540,7 @@ int roman_score(roman_ctx_t* c, const roman_params_t* params, const double* D1, 
         HIPCHK(c, hipMemcpyAsync(&ps, WS.state.p, sizeof(ProbState), hipMemcpyDeviceToHost, WS.stream));
         HIPCHK(c, hipStreamSynchronize(WS.stream));
         if (!batch_overflowed(c)) break;
-        if (attempt >= 3) return fail(c, ROMAN_E_NOMEM, "the sparse workspace still does not fit after %d attempts", attempt + 1);
+        if (attempt + 1 >= MAX_ATTEMPTS) return fail(c, ROMAN_E_NOMEM, "the sparse workspace still does not fit after %d attempts", attempt + 1);
     }
     Lst.pd = hd[0]; Lst.nA = hd[0].nA; Lst.L = ps.L; Lst.kind = ps.kind; Lst.nnzCap = ps.nnzCap; Lst.scored = true;
     return ROMAN_OK;

@@ -711,3 +711,58 @@ def test_problem_beyond_the_fused_small_path_after_a_history_of_small_ones(orc):
             assert np.array_equal(res2.assoc[b], r0.assoc[b])
     finally:
         c.close()
+
+
+@pytest.mark.parametrize("capnnz", [None, "3000"], ids=["sized_by_history", "first_calls_overflow"])
+def test_large_host_batch_goes_out_in_calls_in_flight_and_equals_one_call(orc, capnnz, monkeypatch):
+    """roman_align_batch (host pointers) issues a batch of more than `chunk` problems as calls of `chunk` problems with `depth`
+    of them in flight (roman_ctx_set_host_batching: the pipelined loop of a device-pointer caller, done by the library for the
+    caller of [REF roman/align/submap_align.py:93-200] who hands over every surviving pair at once): every result — associations
+    incl. order, pose bits, status, statistics — equals the one-call result and the oracle's, with explicit association lists
+    and start vectors sliced per call, on a fresh context (no sizing history: the first call is waited for) and when the
+    first calls' workspace is too small (ROMAN_TEST_CAPNNZ: skipped problems are issued again, those only)."""
+    from roman_amd.runtime import Context
+    if capnnz is not None:
+        monkeypatch.setenv("ROMAN_TEST_CAPNNZ", capnnz)
+    reg = registration_for("semanticgrav", semantics_dim=16)
+    pairs = [synth.make_pair(22 + (7 * k) % 19, 20 + (5 * k) % 23, 16, 9300 + k, tilt_deg=1.0) for k in range(150)]
+    batch = rb.batch_from_pairs(reg, [(p.map1, p.map2) for p in pairs])
+    rng = np.random.default_rng(3)
+    u0 = rng.uniform(0.2, 1.0, int(np.sum(batch.n1.astype(np.int64) * batch.n2)))
+    results = {}
+    for name, (chunk, depth) in {"one_call": (100000, 1), "chunks_32x3": (32, 3), "chunks_50x2": (50, 2)}.items():
+        c = Context(0)                                         # fresh: no sizing history, first-call heuristics
+        try:
+            reg.set_context(c)
+            c.set_host_batching(chunk, depth)
+            results[name] = (rb.run_batch(reg, batch), rb.run_batch(reg, batch, u0=u0))
+            assert c.skipped() >= 0
+        finally:
+            c.close()
+    ref, ref_u0 = results["one_call"]
+    for name in ("chunks_32x3", "chunks_50x2"):
+        for got, want in zip(results[name], (ref, ref_u0)):
+            assert np.array_equal(got.status, want.status) and not (got.status & _abi.ROMAN_ST_WORKSPACE).any(), name
+            for b in range(len(batch)):
+                assert np.array_equal(got.assoc[b], want.assoc[b]), (name, b)
+            assert np.array_equal(got.T, want.T, equal_nan=True)
+            for f in ("n_live", "nnz_upper", "n_pass", "score"):
+                assert np.array_equal(got.stats[f], want.stats[f]), (name, f)
+    for b in range(0, len(pairs), 7):
+        o = oracle_one(orc, reg, pairs[b].map1, pairs[b].map2)
+        assert np.array_equal(ref.assoc[b], o["assoc"]), b
+    # explicit association lists (the pruning plugin): the lists are sliced per call by their row offsets
+    prune = registration_for("clipper+prune", cosine_min=0.4)
+    pb = rb.batch_from_pairs(prune, [(p.map1, p.map2) for p in pairs[:90]])
+    assert pb.assoc is not None
+    out = []
+    for chunk, depth in ((100000, 1), (16, 3)):
+        c = Context(0)
+        try:
+            prune.set_context(c); c.set_host_batching(chunk, depth)
+            out.append(rb.run_batch(prune, pb))
+        finally:
+            c.close()
+    for b in range(len(pb)):
+        assert np.array_equal(out[0].assoc[b], out[1].assoc[b]), b
+    assert np.array_equal(out[0].T, out[1].T, equal_nan=True) and np.array_equal(out[0].status, out[1].status)

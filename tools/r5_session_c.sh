@@ -1,0 +1,19 @@
+#!/bin/bash
+# round-5 session C: the restructured stream loop (F3: fused passes, split a compile-time constant, gathers one quad ahead, fixed LDS
+# strides) against round 4 (R4) on ONE box + the solver-facing tests + the chunked host batch test.
+export TMPDIR=/tmp; OUT=$PWD/gpurun_out; mkdir -p $OUT; REPO=$PWD
+timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_full_configs.py tests/test_gpu_batch.py -q -m gpu -k "stagewise or config3 or demo_scale or fixed_point or large_host_batch or dense_matrix or ragged or tie_fallback or explicit_u0" > $OUT/r5c_pytest.txt 2>&1; echo "pytest rc=$?"; tail -15 $OUT/r5c_pytest.txt
+for cfg in R4 F3 R4 F3; do
+  L=$cfg
+  export ROMAN_HIP_LIBRARY=$REPO/roman_amd/csrc/variants/lib$L.so
+  ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ab_tmp -o b -- python $REPO/bench.py --steps 5 --warmup 2 --pipeline 1 --latency-reps -1 --cpu-sample 0 --no-extras --no-grid --check-pairs 0 > /dev/null 2>&1 )
+  F=$(find $OUT/ab_tmp -name "*kernel_stats.csv" | head -1)
+  python - "$F" "$L" <<'PY'
+import csv, sys
+for r in csv.DictReader(open(sys.argv[1])):
+    if 'k_solve_up<8' in r['Name']: print(sys.argv[2], r['Name'][:44], round(float(r['AverageNs']) / 1e3, 1), 'us')
+PY
+  rm -rf $OUT/ab_tmp
+  timeout 600 python bench.py --steps 20 --warmup 5 --no-extras --no-grid --cpu-sample 0 --check-pairs 0 --latency-reps 20 > $OUT/r5c_bench_${L}.txt 2>$OUT/r5c_bench_${L}.err
+  echo "== $L"; python tools/bench_digest.py $OUT/r5c_bench_${L}.txt | head -3
+done
