@@ -222,6 +222,14 @@ ROMAN_API int roman_ctx_sync(roman_ctx_t* ctx);
    a call skipped for workspace are issued again (those only); without a sizing history for the parameter block the first call
    is waited for before the others are queued.  The depth set with roman_ctx_set_pipeline is restored on return. */
 ROMAN_API int roman_ctx_set_host_batching(roman_ctx_t* ctx, int chunk, int depth);
+/* Team mode of the whole-device solver for LARGE live sets (methods without a semantic gate,
+   [REF roman/params/submap_align_params.py:98-116]: every association live): -1 (default) the library decides — several such
+   problems in a batch are solved side by side, the workgroups of an XCD (or of half an XCD) on one problem each —, 0 never (the
+   whole device on one problem at a time), 1 / 2 / 4 teams per XCD whenever the live sets fit.  Teams are formed on the device
+   from the XCD every workgroup really runs on, their buffers are sized on the host from the XCD count the runtime reports: a
+   team that cannot hold its problem leaves it ROMAN_ST_INTERNAL; roman_align_batch runs such problems again with teams off, a
+   caller of roman_align_batch_dev does the same through this setter. */
+ROMAN_API int roman_ctx_set_wide_teams(roman_ctx_t* ctx, int teams_per_xcd);
 
 /* Human-readable text of the last error on this context (or of the last context-less error
    when ctx == NULL).  The pointer stays valid until the next call on the same context. */

@@ -158,6 +158,7 @@ def load_library():
         "roman_ctx_set_pipeline": (C.c_int, [ctxp, C.c_int]),
         "roman_ctx_sync": (C.c_int, [ctxp]),
         "roman_ctx_set_host_batching": (C.c_int, [ctxp, C.c_int, C.c_int]),
+        "roman_ctx_set_wide_teams": (C.c_int, [ctxp, C.c_int]),
         "roman_ctx_join": (C.c_int, [ctxp, C.c_int]),
         "roman_ctx_join_on": (C.c_int, [ctxp, C.c_int, C.c_void_p]),
         "roman_ctx_skipped": (C.c_int, [ctxp, C.c_int, P(i64)]),
@@ -195,7 +196,7 @@ def load_library():
 
 
 EXPORTED_SYMBOLS = (
-    "roman_params_default", "roman_ctx_create", "roman_ctx_destroy", "roman_ctx_set_pipeline", "roman_ctx_sync", "roman_ctx_set_host_batching", "roman_ctx_join", "roman_ctx_join_on",
+    "roman_params_default", "roman_ctx_create", "roman_ctx_destroy", "roman_ctx_set_pipeline", "roman_ctx_sync", "roman_ctx_set_host_batching", "roman_ctx_set_wide_teams", "roman_ctx_join", "roman_ctx_join_on",
     "roman_ctx_skipped", "roman_last_error",
     "roman_align_batch_dev", "roman_align_batch", "roman_create_all_to_all", "roman_score",
     "roman_set_matrix_data", "roman_solve", "roman_num_associations", "roman_num_selected",

@@ -200,6 +200,7 @@ def issue_chunked(ctx, P, pool, batch, kmax, a_out, n_out, T_out, st_out, stats_
                             assoc_off=None if batch.assoc_off is None else batch.assoc_off[lo:hi + 1])
 
     status = np.zeros(0, dtype=np.int32)
+    teams_off = False
     ctx.set_pipeline(max(1, int(in_flight)))
     try:
         lo = 0
@@ -209,11 +210,18 @@ def issue_chunked(ctx, P, pool, batch, kmax, a_out, n_out, T_out, st_out, stats_
         ctx._sized_block = block
         for l in range(lo, B, chunk):
             issue(l, min(B, l + chunk))
+        again, teams_off = _abi.ROMAN_ST_WORKSPACE, False
         for attempt in range(1, MAX_ATTEMPTS + 1):
             ctx.sync()
             status = st_out.cpu().numpy()[:B]
-            skipped = np.nonzero((status & _abi.ROMAN_ST_WORKSPACE) != 0)[0]
-            if not len(skipped) or (status & _abi.ROMAN_ST_INTERNAL).any() or attempt == MAX_ATTEMPTS:
+            if (status & _abi.ROMAN_ST_INTERNAL).any():
+                # a team of the whole-device solver that could not hold its problem leaves ROMAN_ST_INTERNAL like an expired wait
+                # does: those problems once more with the whole device per problem; a second ROMAN_ST_INTERNAL is final
+                if teams_off:
+                    break
+                teams_off = True; ctx.set_wide_teams(0); again |= _abi.ROMAN_ST_INTERNAL
+            skipped = np.nonzero((status & again) != 0)[0]
+            if not len(skipped) or attempt == MAX_ATTEMPTS:
                 break
             b = 0
             while b < len(skipped):                                 # runs of consecutive skipped problems, a chunk at most
@@ -224,6 +232,8 @@ def issue_chunked(ctx, P, pool, batch, kmax, a_out, n_out, T_out, st_out, stats_
                 b = e
     finally:
         ctx.set_pipeline(1)
+        if teams_off:
+            ctx.set_wide_teams(-1)
     return status.copy()
 
 

@@ -53,6 +53,9 @@ struct roman_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     int num_cu = 256;
+    int num_xcc = 8;                           // XCDs the runtime reports for this device / partition (hipDeviceAttributeNumberOfXccs)
+    int wide_teams = -1;                       // team mode of the whole-device solver: -1 automatic, 0 never, 1 / 2 / 4 teams per XCD (roman_ctx_set_wide_teams)
+    bool teams_launched = false;               // a launch since the last reset ran in team mode (a ROMAN_ST_INTERNAL record may be a team that could not hold its problem)
     size_t lds_max = 65536;
     bool coop_ok = false;                      // hipLaunchCooperativeKernel available (large-problem solver)
     unsigned long long spin_ticks = 400000000ull;  // bounded waits of the whole-device solver: 4 s in ticks of the device's wall clock
@@ -813,15 +816,22 @@ int enqueue_solve(roman_ctx* c, const DevParams& D, int B, int64_t sumA, int64_t
             // one-level barrier among themselves; the whole device on one problem at a time otherwise (one huge problem, or
             // live sets beyond a team's registers: a thread owns WIDE_KW elements).
             int a_teams = 0;
+            // The kernel forms its teams from a census of the XCD every workgroup really runs on; the HOST sizes a team's share of
+            // the buffers from the XCD count the runtime reports (8 on an MI355X in SPX mode; a CPX partition has 1).  Should the
+            // two ever disagree — a team larger than its share of the partials, or too small for a live set — the kernel leaves
+            // the problem its pre-written ROMAN_ST_INTERNAL record, and the host-pointer entry points run those problems again
+            // with the whole device per problem (roman_ctx_set_wide_teams(ctx, 0) does the same for a device-pointer caller).
+            const int perXcd = std::max(1, (G + c->num_xcc - 1) / c->num_xcc);
             {
-                const int perXcd = std::max(1, G / 8);
                 auto cap = [&](int sub) { return (int64_t)WIDE_KW * std::max(1, perXcd / sub - 2) * WIDE_NW * 64; };   // (a margin of two workgroups against uneven placement)
                 if (mayFallback >= 2 && maxA <= cap(1)) a_teams = (mayFallback > 12 && maxA <= cap(2)) ? 2 : 1;
                 const char* teamEnv = getenv("ROMAN_WIDE_TEAMS");          // experiments / tests: 0 never, 1 / 2 / 4 teams per XCD whenever the live sets fit (read per call)
-                if (teamEnv) { const int t = atoi(teamEnv); a_teams = (t >= 1 && t <= 4 && mayFallback >= 1 && maxA <= cap(t)) ? t : 0; }
+                const int forced = teamEnv ? atoi(teamEnv) : c->wide_teams;
+                if (teamEnv || c->wide_teams >= 0) a_teams = (forced >= 1 && forced <= 4 && mayFallback >= 1 && maxA <= cap(forced)) ? forced : 0;
             }
-            const int nTeams = a_teams ? 8 * a_teams : 1;
-            const int NWGt = a_teams ? std::min(G, 2 * (G / 8 / a_teams) + 8) * WIDE_NW : G * WIDE_NW;     // waves a team can have at most
+            if (a_teams) c->teams_launched = true;
+            const int nTeams = a_teams ? 8 * a_teams : 1;       // (teams are numbered XCC_ID * teams-per-XCD + sub-team: 8 XCC ids whatever the partition)
+            const int NWGt = a_teams ? std::min(G, 2 * ((perXcd + a_teams - 1) / a_teams) + 8) * WIDE_NW : G * WIDE_NW;     // waves a team can have at most
             long long a_partStride = (long long)(((size_t)NWGt * WIDE_MAXCH + (size_t)(maxA + 63) / 64 + 4) * 64 * 2);   // pieces: chunks + slices
             HIPCHK(c, WS.widePart.ensure(sizeof(double) * (size_t)a_partStride * (size_t)nTeams));
             HIPCHK(c, WS.wideSlots.ensure(sizeof(double) * 2 * (size_t)G * WIDE_NRED * (size_t)nTeams));
@@ -1126,6 +1136,12 @@ int roman_ctx_create(roman_ctx_t** out, int device, void* stream)
     if (!c) return fail(nullptr, ROMAN_E_NOMEM, "out of host memory");
     c->device = device;
     c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    {   // XCDs of this device (8 on an MI355X in SPX mode, 1 in CPX mode): the team mode of k_solve_wide sizes a team's buffers from it
+        int nx = 0;
+        if (hipDeviceGetAttribute(&nx, hipDeviceAttributeNumberOfXccs, device) != hipSuccess || nx < 1 || nx > 8) { (void)hipGetLastError(); nx = 8; }
+        if (const char* e = getenv("ROMAN_NUM_XCC")) { const int v = atoi(e); if (v >= 1 && v <= 64) nx = v; }   // test hook: a host-side count that does not match the device's
+        c->num_xcc = nx;
+    }
     c->lds_max = prop.sharedMemPerBlock >= 163840 ? (size_t)(160 * 1024 - 256) : (size_t)prop.sharedMemPerBlock;
     { int coopAttr = 0; c->coop_ok = hipDeviceGetAttribute(&coopAttr, hipDeviceAttributeCooperativeLaunch, device) == hipSuccess && coopAttr != 0; (void)hipGetLastError(); }
     if (c->coop_ok) {
@@ -1334,6 +1350,15 @@ int roman_align_batch_dev(roman_ctx_t* c, const roman_params_t* params, int32_t 
     return ROMAN_OK;
 }
 
+int roman_ctx_set_wide_teams(roman_ctx_t* c, int teams_per_xcd)
+{
+    if (!c) return fail(nullptr, ROMAN_E_INVALID, "ctx is NULL");
+    if (!(teams_per_xcd == -1 || teams_per_xcd == 0 || teams_per_xcd == 1 || teams_per_xcd == 2 || teams_per_xcd == 4))
+        return fail(c, ROMAN_E_INVALID, "teams per XCD must be -1 (automatic), 0, 1, 2 or 4");
+    c->wide_teams = teams_per_xcd;
+    return ROMAN_OK;
+}
+
 int roman_ctx_set_host_batching(roman_ctx_t* c, int chunk, int depth)
 {
     if (!c) return fail(nullptr, ROMAN_E_INVALID, "ctx is NULL");
@@ -1360,6 +1385,7 @@ int align_chunked(roman_ctx* c, const roman_params_t* params, const BatchIn& in,
     const int saved = c->pipeline;
     int rc = roman_ctx_set_pipeline(c, c->host_depth);
     if (rc) return rc;
+    c->teams_launched = false;
     std::vector<int64_t> uoff;                                  // start of problem b's slice of u0
     if (dU0) {
         uoff.assign((size_t)B + 1, 0);
@@ -1387,25 +1413,34 @@ int align_chunked(roman_ctx* c, const roman_params_t* params, const BatchIn& in,
     }
     for (; lo < B; lo += chunk) { rc = issue(lo, std::min(B, lo + chunk)); if (rc) return restore(rc); }
     std::vector<int32_t> st((size_t)B);
+    const int teams_saved = c->wide_teams;
+    bool no_teams_tried = false;
+    auto restore2 = [&](int code) -> int { c->wide_teams = teams_saved; return restore(code); };
     for (int attempt = 1; ; ++attempt) {
         rc = roman_ctx_sync(c);
-        if (rc) return restore(rc);
+        if (rc) return restore2(rc);
         harvest_totals(c, true);
-        if (hipMemcpy(st.data(), out.status_out, sizeof(int32_t) * (size_t)B, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return restore(fail(c, ROMAN_E_HIP, "status read-back failed")); }
+        if (hipMemcpy(st.data(), out.status_out, sizeof(int32_t) * (size_t)B, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return restore2(fail(c, ROMAN_E_HIP, "status read-back failed")); }
         int nskip = 0, nint = 0;
         for (int b = 0; b < B; ++b) { nskip += (st[b] & ROMAN_ST_WORKSPACE) ? 1 : 0; nint += (st[b] & ROMAN_ST_INTERNAL) ? 1 : 0; }
-        if (!nskip || nint) break;                              // (a problem the library gave up on: no point in further attempts — the caller reports it)
-        if (attempt >= MAX_ATTEMPTS) return restore(fail(c, ROMAN_E_NOMEM, "the sparse workspace of %d problem(s) still does not fit after %d attempts", nskip, attempt));
-        for (int b = 0; b < B; ) {                              // runs of consecutive skipped problems, at most a chunk long
-            if (!(st[b] & ROMAN_ST_WORKSPACE)) { ++b; continue; }
+        int again = ROMAN_ST_WORKSPACE;
+        if (nint) {
+            // a team of the whole-device solver that could not hold its problem leaves ROMAN_ST_INTERNAL like an expired wait does:
+            // those problems once more, the whole device on one problem at a time; a second ROMAN_ST_INTERNAL is final
+            if (!c->teams_launched || no_teams_tried) break;
+            no_teams_tried = true; c->wide_teams = 0; again |= ROMAN_ST_INTERNAL;
+        } else if (!nskip) break;
+        if (attempt >= MAX_ATTEMPTS) return restore2(fail(c, ROMAN_E_NOMEM, "the sparse workspace of %d problem(s) still does not fit after %d attempts", nskip, attempt));
+        for (int b = 0; b < B; ) {                              // runs of consecutive problems to issue again, at most a chunk long
+            if (!(st[b] & again)) { ++b; continue; }
             int e = b + 1;
-            while (e < B && e - b < chunk && (st[e] & ROMAN_ST_WORKSPACE)) ++e;
+            while (e < B && e - b < chunk && (st[e] & again)) ++e;
             rc = issue(b, e);
-            if (rc) return restore(rc);
+            if (rc) return restore2(rc);
             b = e;
         }
     }
-    return restore(ROMAN_OK);
+    return restore2(ROMAN_OK);
 }
 }  // namespace
 
@@ -1470,12 +1505,28 @@ int roman_align_batch(roman_ctx_t* c, const roman_params_t* params, int32_t B,
     } else
     // this entry point is synchronous anyway: when a problem did not fit the speculatively sized pools, run again
     // with the need the first attempt recorded
-    for (int attempt = 0; ; ++attempt) {
-        rc = run_batch(c, D, params, in, dU0, out);
-        if (rc) return rc;
-        HIPCHK(c, hipStreamSynchronize(WS.stream));
-        if (!batch_overflowed(c)) break;
-        if (attempt + 1 >= MAX_ATTEMPTS) return fail(c, ROMAN_E_NOMEM, "the sparse workspace still does not fit after %d attempts", attempt + 1);
+    {
+        const int teams_saved = c->wide_teams;
+        for (int attempt = 0; ; ++attempt) {
+            c->teams_launched = false;
+            rc = run_batch(c, D, params, in, dU0, out);
+            if (rc) { c->wide_teams = teams_saved; return rc; }
+            if (hipStreamSynchronize(WS.stream) != hipSuccess) { (void)hipGetLastError(); c->wide_teams = teams_saved; return fail(c, ROMAN_E_HIP, "hipStreamSynchronize failed"); }
+            if (batch_overflowed(c)) {
+                if (attempt + 1 >= MAX_ATTEMPTS) { c->wide_teams = teams_saved; return fail(c, ROMAN_E_NOMEM, "the sparse workspace still does not fit after %d attempts", attempt + 1); }
+                continue;
+            }
+            if (c->teams_launched && c->wide_teams != 0) {      // a team that could not hold its problem leaves ROMAN_ST_INTERNAL: once more, the whole device per problem
+                std::vector<int32_t> stv((size_t)B);
+                if (hipMemcpy(stv.data(), WS.oStatus.p, sizeof(int32_t) * (size_t)B, hipMemcpyDeviceToHost) == hipSuccess) {
+                    bool anyInt = false;
+                    for (int b = 0; b < B; ++b) anyInt = anyInt || (stv[b] & ROMAN_ST_INTERNAL);
+                    if (anyInt && attempt + 1 < MAX_ATTEMPTS) { c->wide_teams = 0; continue; }
+                } else (void)hipGetLastError();
+            }
+            break;
+        }
+        c->wide_teams = teams_saved;
     }
     if (kmax > 0) HIPCHK(c, hipMemcpyAsync(assoc_out, WS.oAssoc.p, sizeof(int32_t) * 2 * (size_t)B * (size_t)kmax, hipMemcpyDeviceToHost, WS.stream));
     HIPCHK(c, hipMemcpyAsync(n_assoc_out, WS.oN.p, sizeof(int32_t) * (size_t)B, hipMemcpyDeviceToHost, WS.stream));

@@ -76,6 +76,12 @@ class Context:
         `chunk` problems with `depth` of them in flight (roman_ctx_set_host_batching; depth 1 = one call for everything)."""
         self._check(self._lib.roman_ctx_set_host_batching(self._h, int(chunk), int(depth)), "roman_ctx_set_host_batching")
 
+    def set_wide_teams(self, teams_per_xcd=-1):
+        """Team mode of the whole-device solver for large live sets (roman_ctx_set_wide_teams): -1 automatic, 0 never, 1 / 2 / 4
+        teams per XCD.  A device-pointer caller that gets ROMAN_ST_INTERNAL records back from a batch with several large live
+        sets issues those problems again with 0 (pipeline.issue_chunked does)."""
+        self._check(self._lib.roman_ctx_set_wide_teams(self._h, int(teams_per_xcd)), "roman_ctx_set_wide_teams")
+
     def join(self, skip_latest=False, stream=None):
         """Make the context's stream — or `stream` (a hipStream_t handle, e.g. torch.cuda.Stream.cuda_stream) — wait for the
         pipelined batches issued so far (optionally all but the latest)."""

@@ -766,3 +766,98 @@ def test_large_host_batch_goes_out_in_calls_in_flight_and_equals_one_call(orc, c
     for b in range(len(pb)):
         assert np.array_equal(out[0].assoc[b], out[1].assoc[b]), b
     assert np.array_equal(out[0].T, out[1].T, equal_nan=True) and np.array_equal(out[0].status, out[1].status)
+
+
+def test_align_resident_and_align_stream_equal_run_batch():
+    """roman_amd.align.pipeline on the GPU (torch for device memory: its own process, torch imported first): (1) align_resident —
+    a 150-pair batch over a resident pool as calls of 32 pairs, three in flight, on a fresh context with the first calls'
+    workspace too small (ROMAN_TEST_CAPNNZ: skipped problems are issued again) — equals run_batch problem by problem, with
+    explicit association lists too; (2) AlignStream — ten calls of distinct batches, three in flight, every call's output set
+    collected by `on_collect` before the set is rewritten — equals the same calls one at a time."""
+    import subprocess, sys, textwrap
+    from conftest import ROOT
+    code = textwrap.dedent("""
+        import os, sys
+        import numpy as np
+        import torch
+        sys.path.insert(0, %r)
+        from roman_amd import _abi, synth
+        from roman_amd.align import SubmapAlignParams, batch as rb
+        from roman_amd.align.pipeline import AlignStream, align_resident
+        from roman_amd.runtime import Context
+        dev = torch.device("cuda", 0)
+        stream = torch.cuda.Stream(dev); torch.cuda.set_stream(stream)
+        reg = SubmapAlignParams(method="semanticgrav", semantics_dim=16).get_object_registration()
+        pairs = [synth.make_pair(22 + (7 * k) %% 19, 20 + (5 * k) %% 23, 16, 9300 + k, tilt_deg=1.0) for k in range(150)]
+        batch = rb.batch_from_pairs(reg, [(p.map1, p.map2) for p in pairs])
+        c0 = Context(0, stream=stream.cuda_stream); reg.set_context(c0)
+        want = rb.run_batch(reg, batch)
+        pool = torch.from_numpy(batch.feats).to(dev)
+        os.environ["ROMAN_TEST_CAPNNZ"] = "3000"
+        c1 = Context(0, stream=stream.cuda_stream); reg.set_context(c1)
+        got = align_resident(reg, batch, pool, chunk=32, in_flight=3, ctx=c1)
+        assert c1.skipped() > 0, "the test hook did not make the first calls overflow"
+        del os.environ["ROMAN_TEST_CAPNNZ"]
+        for b in range(len(batch)):
+            assert np.array_equal(got.assoc[b], want.assoc[b]), b
+        assert np.array_equal(got.T, want.T, equal_nan=True) and np.array_equal(got.status, want.status)
+        assert np.array_equal(got.stats["n_pass"], want.stats["n_pass"])
+        prune = SubmapAlignParams(method="clipper+prune", cosine_min=0.4).get_object_registration(); prune.set_context(c1)
+        pb = rb.batch_from_pairs(prune, [(p.map1, p.map2) for p in pairs[:70]])
+        wp = rb.run_batch(prune, pb)
+        gp = align_resident(prune, pb, torch.from_numpy(pb.feats).to(dev), chunk=16, in_flight=3, ctx=c1)
+        for b in range(len(pb)):
+            assert np.array_equal(gp.assoc[b], wp.assoc[b]), b
+        # AlignStream: ten distinct calls of 15 problems, three in flight, collected before their set is rewritten
+        reg.set_context(c0)
+        kmax = batch.kmax(); F = batch.feats.shape[1]
+        seen = {}
+        def collect(k, tag):
+            O = S.sets[k]
+            seen[tag] = (O.n.clone(), O.assoc.clone(), O.T.clone(), O.status.clone())
+        S = AlignStream(reg, c0, dev, rows=15, kmax=kmax, in_flight=3, stream=stream, on_collect=collect)
+        for ci in range(10):
+            sl = slice(15 * ci, 15 * ci + 15)
+            S.submit(pool.data_ptr(), F, batch.off1[sl], batch.n1[sl], batch.off2[sl], batch.n2[sl], tag=ci)
+        S.drain(); torch.cuda.synchronize(dev); S.close()
+        assert sorted(seen) == list(range(10))
+        for ci in range(10):
+            n, a, T, st = (x.cpu().numpy() for x in seen[ci])
+            for r in range(15):
+                b = 15 * ci + r
+                assert np.array_equal(a[r, :n[r]], want.assoc[b]), (ci, r)
+                assert st[r] == want.status[b]
+                if st[r] == 0:
+                    assert np.array_equal(T[r].reshape(4, 4), want.T[b])
+        c0.close(); c1.close()
+        print("PIPELINE_OK")
+    """ % (ROOT,))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "PIPELINE_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_team_that_cannot_hold_its_problem_is_solved_again_by_the_whole_device(orc, monkeypatch):
+    """the host sizes a team's buffers from the XCD count the runtime reports, the kernel forms teams from the XCD
+    every workgroup really runs on.  ROMAN_NUM_XCC=32 makes the host believe in XCDs of 8 compute units: the real teams (32
+    workgroups) exceed their share of the partials buffer, the kernel leaves those problems ROMAN_ST_INTERNAL — and
+    roman_align_batch runs them again with the whole device per problem: every result is the oracle's, no error surfaces.
+    With teams forced off from the start (roman_ctx_set_wide_teams(0)) the same results come out in one attempt."""
+    from roman_amd.runtime import Context
+    monkeypatch.setenv("ROMAN_NUM_XCC", "32")
+    c = Context(0)
+    monkeypatch.delenv("ROMAN_NUM_XCC")
+    c2 = Context(0)
+    try:
+        reg = registration_for("gravity")
+        pairs = [synth.make_pair(60, 58 + k, 0, 9500 + k, tilt_deg=1.0) for k in range(3)]      # L = 3480 .. 3600: beyond the stream layout
+        reg.set_context(c)
+        res = reg.register_and_align_batch([(p.map1, p.map2) for p in pairs])
+        c2.set_wide_teams(0); reg.set_context(c2)
+        res0 = reg.register_and_align_batch([(p.map1, p.map2) for p in pairs])
+        assert (res.stats["n_live"] > 3072).all()
+        for b, p in enumerate(pairs):
+            o = oracle_one(orc, reg, p.map1, p.map2)
+            assert np.array_equal(res.assoc[b], o["assoc"]) and np.array_equal(res0.assoc[b], o["assoc"]), b
+            assert not (res.status[b] & _abi.ROMAN_ST_INTERNAL) and res.stats["n_pass"][b] == o["stats"].n_pass == res0.stats["n_pass"][b]
+    finally:
+        c.close(); c2.close()
