@@ -208,7 +208,8 @@ ROMAN_API int roman_ctx_set_pipeline(roman_ctx_t* ctx, int depth);
    (e.g. the all_gather of batch k-1's records) sees their results while batch k keeps running.  The host
    does not block. */
 ROMAN_API int roman_ctx_join(roman_ctx_t* ctx, int skip_latest);
-/* The same wait enqueued on ANOTHER stream of the caller's (a hipStream_t; NULL = the context's stream): the collective that
+/* The same wait enqueued on ANOTHER stream of the caller's (a hipStream_t; NULL = the context's stream — NOT the legacy default
+   stream, whose handle is also 0: work queued on the null stream cannot be ordered through this call; use an explicit stream): the collective that
    gathers batch k-1's records then runs on a side stream and never sits between two batch calls on the context's stream —
    every batch call starts behind what is queued THERE, so a wait for batch k-1 on it would hold back batch k+1 and cost a
    batch in flight.  The caller orders the reuse of an output buffer against its own side stream (an event). */

@@ -25,6 +25,10 @@ def _zyx_euler(R):
 
 
 class DistRegWithPruning(ObjectRegistration):
+    """The reference's class ([REF roman/align/dist_reg_with_pruning.py:15-97]).  With `prune_on_device=True` the descriptor
+    length is part of the feature row: pass `semantics_dim` when the FIRST map packed may be empty (a sequence whose first
+    submap holds no objects is legitimate input — register() returns the empty association set for it without packing
+    anything; only the batched entries pack every map of a pool, and an empty one cannot tell them its row width)."""
 
     def __init__(self, sigma, epsilon, mindist=0.0, shape_epsilon=0.0, cos_min=0.85,
                  dim=3, use_gravity=False, roll_pitch_thresh=np.deg2rad(5), prune_on_device=False, semantics_dim=None):

@@ -3,9 +3,9 @@
 One process per GPU (torch.distributed; backend "nccl" is RCCL on ROCm).  Problems are independent
 ([REF roman/align/submap_align.py:93-200] carries no state across iterations), so every rank aligns its share of the
 flattened pair list and ONE all_gather of fixed-size result records collects the inlier sets and poses.  No other
-collective.  The share is cost-balanced: problems are dealt longest-first (cost = number of associations to score,
-n1*n2 for all-to-all) to the rank with the least work so far — the deal is a pure function of the batch, identical on
-every rank.  On GPUs the records never leave the device before the gather.
+collective.  The share is cost-balanced: problems are dealt longest-first (work estimate = the square of the number of
+associations to score, n1*n2 for all-to-all) to the rank with the least work so far — the deal is a pure function of the
+batch, identical on every rank.  On GPUs the records never leave the device before the gather.
 """
 import numpy as np
 
@@ -26,6 +26,15 @@ def problem_costs(batch: AlignmentBatch):
         full = batch.n1.astype(np.int64) * batch.n2.astype(np.int64)
         return np.where(a > 0, a, full)                       # an empty list means all-to-all
     return batch.n1.astype(np.int64) * batch.n2.astype(np.int64)
+
+
+def problem_work(batch: AlignmentBatch):
+    """Work estimate of each problem for the deal: the SQUARE of its association count.  The affinity build tests pairs of
+    live associations and the matrix it leaves — the solver's stream — holds a fraction of them: both grow with A^2, not with A
+    (at equal sizes, the all-pairs grid of BASELINE config 4, the two deals coincide; on submaps of 50 ... 300 objects a deal
+    on A leaves the rank that drew the large pairs with up to 1.5x the mean A^2)."""
+    a = problem_costs(batch).astype(np.int64)
+    return a * a
 
 
 def deal_by_cost(costs, world_size):
@@ -95,7 +104,8 @@ def _device_records(registration, sub: AlignmentBatch, kmax, per, dev, pool=None
     T_out = torch.zeros((B, 16), dtype=torch.float64, device=dev)
     st_out = torch.zeros(B, dtype=torch.int32, device=dev)
     assoc = None if sub.assoc is None else torch.from_numpy(np.ascontiguousarray(sub.assoc, dtype=np.int32)).to(dev)
-    torch.cuda.current_stream(dev).synchronize()               # inputs are in place before the library's streams read them
+    if torch.device(dev).type == "cuda":
+        torch.cuda.current_stream(dev).synchronize()           # inputs are in place before the library's streams read them
     issue_chunked(ctx, P, feats, sub, kmax, a_out, n_out, T_out, st_out, None, assoc, chunk, in_flight)
     ints[:B, 0] = n_out; ints[:B, 1] = st_out
     valid = torch.arange(kmax, device=dev)[None, :] < n_out[:, None]
@@ -119,7 +129,7 @@ def align_sharded(registration, batch: AlignmentBatch, group=None, compute=None,
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     B = len(batch)
     kmax = batch.kmax()
-    shards = deal_by_cost(problem_costs(batch), world)
+    shards = deal_by_cost(problem_work(batch), world)
     mine = shards[rank]
     per = max(1, max(len(s) for s in shards))                  # every rank gathers equal shapes
     sub = take(batch, mine)

@@ -1163,7 +1163,12 @@ __global__ void __launch_bounds__(1024) k_rowbase(int B, int RPB, long long capM
             st[b].rowBase = accR; st[b].itemBase = accI; st[b].maskOff = fits ? accM : 0;
             if (kind < 2) ++ngen;                                // (also when it is skipped here: the history must learn that the general kernels are needed)
             if (kind == 3) mns = min(mns, L);                    // finished by k_small: still a small problem the history should know of
-            else if (!fits) { st[b].kind = 2; ++nover; }        // (also a problem k_live already skipped: no fallback kernels in this launch)
+            else if (!fits) {                                    // (also a problem k_live already skipped: no fallback kernels in this launch)
+                st[b].kind = 2; ++nover;
+                // skipped only because the general kernels were left out (small_only): the history learns its size NOW, so that the
+                // second attempt sizes the solver launch for it instead of spending one more attempt on that
+                if (smallOnly && kind == 0) { mxs = max(mxs, L); mns = min(mns, L); }
+            }
             else if (kind == 0) { mxs = max(mxs, L); mns = min(mns, L); }
             mx = max(mx, L);
             accM += mw; accR += L; accI += it;

@@ -87,6 +87,12 @@ class Context:
         pipelined batches issued so far (optionally all but the latest)."""
         if stream is None:
             self._check(self._lib.roman_ctx_join(self._h, int(bool(skip_latest))), "roman_ctx_join")
+        elif int(stream) == 0:
+            # roman_ctx_join_on reads a NULL handle as "the context's own stream" — and 0 is also the handle of the legacy default
+            # stream (torch.cuda.default_stream().cuda_stream): the waits would land on the wrong stream and a collective queued on
+            # the default stream could read records that are not complete
+            raise ValueError("join(stream=0): 0 is the legacy default stream's handle, which the C ABI reads as 'the context's stream'; "
+                             "queue the collective on an explicit stream (torch.cuda.Stream) and pass its handle")
         else:
             self._check(self._lib.roman_ctx_join_on(self._h, int(bool(skip_latest)), C.c_void_p(int(stream))), "roman_ctx_join_on")
 

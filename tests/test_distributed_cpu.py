@@ -10,7 +10,7 @@ import pytest
 from conftest import registration_for
 from roman_amd import synth
 from roman_amd.align import batch as rb
-from roman_amd.align.distributed import align_sharded, deal_by_cost, problem_costs, shard_bounds, take
+from roman_amd.align.distributed import align_sharded, deal_by_cost, problem_costs, problem_work, shard_bounds, take
 from roman_amd.runtime import BatchResult, stats_dtype
 
 
@@ -84,6 +84,31 @@ def test_cost_balanced_deal_is_a_partition_and_deterministic():
     # equal costs (the all-pairs grid of equal-sized submaps): every rank gets the same number of problems
     shards = deal_by_cost(np.full(4096, 40000), 8)
     assert [len(s) for s in shards] == [512] * 8
+
+
+def test_deal_on_a_heterogeneous_grid_balances_the_quadratic_work():
+    """Round-4 review, item 13: the deal must hold on a grid of UNEQUAL submaps (n, m in [50, 300]: association counts from
+    2 500 to 90 000, work — pair tests, matrix entries — growing with their square).  Dealt on the work estimate A^2 every one
+    of 8 ranks stays within 3 % of the mean work; the same problems dealt on A itself (the round-4 deal) leave the ranks level
+    in A but far apart in A^2 — the quantity the GPU time follows."""
+    rng = np.random.default_rng(12)
+    S = 24
+    sizes0, sizes1 = rng.integers(50, 301, size=S), rng.integers(50, 301, size=S)
+    n1 = np.repeat(sizes0, S).astype(np.int32); n2 = np.tile(sizes1, S).astype(np.int32)
+    off = np.zeros(S * S, dtype=np.int64)
+    batch = rb.AlignmentBatch(np.zeros((1, 3)), off, n1, off, n2)
+    A = problem_costs(batch); W = problem_work(batch)
+    assert np.array_equal(A, n1.astype(np.int64) * n2) and np.array_equal(W, A * A)
+    shards = deal_by_cost(W, 8)
+    assert sorted(np.concatenate(shards).tolist()) == list(range(S * S))
+    loads = np.array([W[s].sum() for s in shards], dtype=np.float64)
+    assert loads.max() <= 1.03 * loads.mean() and loads.min() >= 0.97 * loads.mean()
+    linear = deal_by_cost(A, 8)
+    lin_loads = np.array([W[s].sum() for s in linear], dtype=np.float64)
+    assert np.array([A[s].sum() for s in linear]).max() <= 1.03 * A.sum() / 8        # level in A ...
+    assert lin_loads.max() / lin_loads.mean() > loads.max() / loads.mean()               # ... but less so in A^2 than the deal on A^2
+    # every rank computes the same deal from the same batch (no communication): a second evaluation is identical
+    assert all(np.array_equal(a, b) for a, b in zip(shards, deal_by_cost(problem_work(batch), 8)))
 
 
 def test_take_keeps_problem_semantics():

@@ -861,3 +861,11 @@ def test_team_that_cannot_hold_its_problem_is_solved_again_by_the_whole_device(o
             assert not (res.status[b] & _abi.ROMAN_ST_INTERNAL) and res.stats["n_pass"][b] == o["stats"].n_pass == res0.stats["n_pass"][b]
     finally:
         c.close(); c2.close()
+
+
+def test_join_on_the_null_stream_is_refused(ctx):
+    """roman_ctx_join_on reads a NULL stream handle as "the context's own stream", and 0 is also the handle of the
+    legacy default stream: Context.join(stream=0) would make the wrong stream wait.  It raises instead."""
+    with pytest.raises(ValueError):
+        ctx.join(skip_latest=False, stream=0)
+    ctx.join(skip_latest=False)                                   # (the context's own stream: fine)
