@@ -588,7 +588,7 @@ def caller_legs(out, args, reg, ctx, dev, stream, G, orc, with_cpu):
                             "rows": rows, "steady_state_alignments_per_s": steady,
                             "host_arrays_in": {"ms": float(min(th) * 1e3), "alignments_per_s": B / min(th), "pool_bytes": int(gb.feats.nbytes),
                                                "identical": bool(all(np.array_equal(a, b) for a, b in zip(resh.assoc, ref.assoc))),
-                                               "note": "run_batch(): roman_align_batch chunks and pipelines the batch itself (512 pairs per call, three in flight); upload of the pool and read-back included"}}
+                                               "note": "run_batch(): roman_align_batch chunks and pipelines the batch itself (2048 pairs per call, three in flight); upload of the pool and read-back included"}}
         # ---- cold call ------------------------------------------------------------------------------------------
         c2 = Context(dev.index if dev.index is not None else 0)
         try:
@@ -638,9 +638,9 @@ def caller_legs(out, args, reg, ctx, dev, stream, G, orc, with_cpu):
                            "ratio": res_rates["different_batch_every_step"]["alignments_per_s"] / res_rates["same_batch_every_step"]["alignments_per_s"]}
         # ---- 8-GPU projection of config 4 on one GPU -----------------------------------------------------------------
         WORLD = 8
-        t_all = next(r["ms"] for r in rows if r["chunk"] == 512)
+        t_all = min(r["ms"] for r in rows)                                       # the whole grid, one shot, at its best call size (pipeline.default_chunk: 2 x 2048)
         proj = []
-        for chunk in (512, 128):
+        for chunk in (512, 256):                                                 # a rank's 512 pairs as ONE call (pipeline.default_chunk) / as two calls in flight
             per_rank = []
             for r in range(WORLD):
                 sub = take(gb, np.arange(r, B, WORLD))                         # bench.py's deal of the grid: round-robin

@@ -216,7 +216,7 @@ ROMAN_API int roman_ctx_join(roman_ctx_t* ctx, int skip_latest);
 ROMAN_API int roman_ctx_join_on(roman_ctx_t* ctx, int skip_latest, void* stream);
 /* Wait for every batch in flight on this context (all internal streams and the context's stream). */
 ROMAN_API int roman_ctx_sync(roman_ctx_t* ctx);
-/* How roman_align_batch (host pointers) issues a LARGE batch: more than `chunk` problems (default 512) go to the device as
+/* How roman_align_batch (host pointers) issues a LARGE batch: more than `chunk` problems (default 2048) go to the device as
    calls of `chunk` problems with `depth` of them in flight (default 3; 1 = one call for the whole batch, as before round 5) —
    the pipelined loop a device-pointer caller would write around roman_align_batch_dev, done by the library for the caller of
    the reference's serial loop [REF roman/align/submap_align.py:93-200] who hands over every surviving pair at once.  Problems

@@ -79,7 +79,7 @@ def _same_device(a, b):
     return norm(torch.device(a)) == norm(torch.device(b))
 
 
-def _device_records(registration, sub: AlignmentBatch, kmax, per, dev, pool=None, chunk=256, in_flight=3):
+def _device_records(registration, sub: AlignmentBatch, kmax, per, dev, pool=None, chunk=None, in_flight=3):
     """Align `sub` with device-resident inputs and outputs; -> (ints (per, 2+2*kmax) int32, poses (per,16) f64) torch
     tensors on `dev`, rows beyond len(sub) padded with -1 / NaN.  The problems go out as calls of `chunk` problems with
     `in_flight` of them on the device at once (pipeline.issue_chunked: a rank's share of a large grid in ONE call would last
@@ -114,10 +114,11 @@ def _device_records(registration, sub: AlignmentBatch, kmax, per, dev, pool=None
     return ints, poses
 
 
-def align_sharded(registration, batch: AlignmentBatch, group=None, compute=None, device=None, pool=None, chunk=256, in_flight=3):
+def align_sharded(registration, batch: AlignmentBatch, group=None, compute=None, device=None, pool=None, chunk=None, in_flight=3):
     """Align `batch` across the ranks of `group` (default: WORLD); every rank returns the full result
-    (assoc list, T, status) in problem order.  A rank's share goes to its GPU as calls of `chunk` problems with `in_flight`
-    of them on the device at once.
+    (assoc list, T, status) in problem order.  A rank's share goes to its GPU as calls of `chunk` problems (default:
+    pipeline.default_chunk — one call up to 512 problems, two up to 4096, calls of 2048 beyond) with `in_flight` of them on
+    the device at once.
 
     compute(registration, sub_batch) -> runtime.BatchResult: a CPU double for tests; by default the HIP path runs with
     device-resident records (`device`: torch device of this rank, default cuda:<current device>; `pool`: the batch's

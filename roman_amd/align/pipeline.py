@@ -180,7 +180,18 @@ class AlignStream:
         self.ctx.set_pipeline(1)
 
 
-def issue_chunked(ctx, P, pool, batch, kmax, a_out, n_out, T_out, st_out, stats_out=None, assoc_dev=None, chunk=256, in_flight=3):
+def default_chunk(B):
+    """Problems per call for a ONE-SHOT batch of B problems: one call up to 512 problems, two calls up to 4096, calls of 2048
+    beyond.  Measured on config 4 (bench.py `caller.one_shot`, one MI355X): 4096 pairs as 2 x 2048 take 37.7 ms, as 8 x 512 or
+    16 x 256 41-42 ms; a rank's 512-pair share as ONE call 5.4-7.4 ms, as 4 x 128 6.2-8.0 ms — every call pays its launches
+    and its own solver tail, two calls in flight already overlap one build with one tail."""
+    B = int(B)
+    if B <= 512:
+        return max(B, 1)
+    return min(2048, ((-(-B // 2)) + 63) & ~63)
+
+
+def issue_chunked(ctx, P, pool, batch, kmax, a_out, n_out, T_out, st_out, stats_out=None, assoc_dev=None, chunk=None, in_flight=3):
     """The problems of `batch` over the device-resident `pool` as calls of `chunk` problems with `in_flight` of them on the device
     at once; problem b writes row b of the output tensors (torch, on the pool's device).  Problems a call skipped for workspace
     (ROMAN_ST_WORKSPACE: the pools are sized before the live counts are known) are issued again — those only, in runs of
@@ -190,7 +201,7 @@ def issue_chunked(ctx, P, pool, batch, kmax, a_out, n_out, T_out, st_out, stats_
     Synchronises the context; leaves its pipeline depth at 1."""
     B = len(batch)
     F = int(pool.shape[1])
-    chunk = max(1, int(chunk))
+    chunk = default_chunk(B) if chunk is None else max(1, int(chunk))
 
     def issue(lo, hi):
         ctx.align_batch_dev(P, pool.data_ptr(), F, batch.off1[lo:hi], batch.n1[lo:hi], batch.off2[lo:hi], batch.n2[lo:hi], kmax,
@@ -237,7 +248,7 @@ def issue_chunked(ctx, P, pool, batch, kmax, a_out, n_out, T_out, st_out, stats_
     return status.copy()
 
 
-def align_resident(registration, batch, pool, chunk=256, in_flight=3, device=None, ctx=None, stats=True):
+def align_resident(registration, batch, pool, chunk=None, in_flight=3, device=None, ctx=None, stats=True):
     """ONE batch of any size over a feature pool that is already in HBM (`pool`: the batch's (n_objects, F) float64 matrix as a
     torch tensor on `device`) -> runtime.BatchResult on the host: issue_chunked() + the read-back.  ROMAN_ST_INTERNAL / a
     problem still skipped after MAX_ATTEMPTS raise RomanHipError (the result so far in `.result`)."""

@@ -71,7 +71,7 @@ class Context:
     def sync(self):
         self._check(self._lib.roman_ctx_sync(self._h), "roman_ctx_sync")
 
-    def set_host_batching(self, chunk=512, depth=3):
+    def set_host_batching(self, chunk=2048, depth=3):
         """How align_batch() (host pointers) issues a large batch: more than `chunk` problems go to the device as calls of
         `chunk` problems with `depth` of them in flight (roman_ctx_set_host_batching; depth 1 = one call for everything)."""
         self._check(self._lib.roman_ctx_set_host_batching(self._h, int(chunk), int(depth)), "roman_ctx_set_host_batching")
