@@ -375,7 +375,9 @@ def main():
         "dtype_note": "every gate and every stored value is IEEE f64; the stream solver's matrix-vector sums are 64-bit FIXED POINT "
                       "(each term rint(v*x*2^s), s = 48 - exponent(max x), added as integers: order-free, absolute error 2^-48 * max x "
                       "per term against 2^-53 relative for a double sum; u agrees with the oracle's double sums to <= 1e-9, selected sets "
-                      "identical); the large-live-set solver sums plain doubles in a fixed order",
+                      "identical).  Line-search passes sum (v + d) * x in ONE accumulator (weight v + d, scale lowered by exponent(1 + d) + 1), "
+                      "a split pass (M x and C x apart) precedes every d update: n_pass counts both, as SURVEY 8(d) does, and the oracle states the "
+                      "same order (oracle_set_pass_mode); the large-live-set solver sums plain doubles in a fixed order and keeps both sums of every pass",
         "config": {"workload": wl_text, "alignments_per_step": total_per_step, "pairs_per_call": CB, "calls_per_step_per_gpu": len(calls),
                    "n": args.n, "m": args.m, "d": args.d, "method": args.method,
                    "sharding": f"pairs x{world}, all_gather of records" if world > 1 else "single GPU",
