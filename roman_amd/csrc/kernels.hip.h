@@ -2987,7 +2987,8 @@ constexpr int ST_MAXSL = STREAM_MAXL / 64;
 constexpr int SMALL_MAXL = 128;           // live associations the one-wave-per-problem instantiation of k_solve_up takes
 constexpr int LEAN_MAXL = STREAM_MAXL;    // live associations the 128-register instantiation takes (two workgroups per compute unit)
 constexpr int LEAN_D = 2;                 // ... and its quads in flight per lane
-constexpr int DEEP_D = 6;                 // quads in flight per lane of the few-problems instantiation (latency-bound wide passes)
+constexpr int DEEP_D = 4;                 // quads in flight per lane of the ROMAN_SOLVE_DEEP=1 instantiation (round 5: four — six no longer fit 256 registers
+                                          // next to the gathers held one quad ahead; measured 0.953-0.961 against 0.941-0.950 ms per launch: no gain)
 constexpr int COO_E = 6;                  // one-wave instantiation: stored pairs a lane holds in registers (coordinate form)
 constexpr int COO_CAP = 64 * COO_E;       // ... per problem; larger matrices take the quad stream
 constexpr uint32_t ST_CZ = 0x8000u, ST_MASK = 0x7fffu;
@@ -3106,6 +3107,38 @@ __device__ __forceinline__ void block_red(double (&sv)[NS > 0 ? NS : 1], double 
         v = fmax(v, dpp_mov<0x124, 0xf>(v));
         if (NW > 8) v = fmax(v, dpp_mov<0x128, 0xf>(v));
         mv[i] = uni(v);
+    }
+}
+
+// The same reduction of NS sums in two halves, for a result that is not needed before the caller's NEXT workgroup barrier anyway:
+// block_post() leaves every wave's partial in the ping-pong area (no barrier), block_collect() — behind any later __syncthreads()
+// of the caller, and before the second block_red() / block_post() after the post — finishes it.  Same tree, same bits as block_red().
+template <int NW, int NS>
+__device__ __forceinline__ const double* block_post(const double (&sv)[NS], double* red, int& par, int tid)
+{
+    static_assert(NW == 8 || NW == 16, "cross-wave butterfly");
+    double* rr = red + NW * RED_STRIDE * par;
+    par ^= 1;
+    const int w = uni(tid >> 6);
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        const double s = readlane63(wave_sum63(sv[i]));
+        if ((tid & 63) == 0) rr[RED_STRIDE * w + i] = s;
+    }
+    return rr;
+}
+template <int NW, int NS>
+__device__ __forceinline__ void block_collect(double (&sv)[NS], const double* rr, int tid)
+{
+    const int src = (tid & 63) & (NW - 1);
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        double v = rr[RED_STRIDE * src + i];
+        v += dpp_mov<0xB1, 0xf>(v);          // quad_perm [1,0,3,2]
+        v += dpp_mov<0x4E, 0xf>(v);          // quad_perm [2,3,0,1]
+        v += dpp_mov<0x124, 0xf>(v);         // row_ror:4
+        if (NW > 8) v += dpp_mov<0x128, 0xf>(v);     // row_ror:8
+        sv[i] = uni(v);
     }
 }
 
@@ -3251,9 +3284,17 @@ __device__ void solve_up(const DevParams& D, int b, const ProbDesc& pd, ProbStat
 
     // ---- products of the vector x held in tk[] (elements >= 0), with xmax = max x and mp1 = 1 + the largest position with
     //      x > 0 (0: x is the zero vector):  split: (M x, C x) -> (Mn, Cn);  fused: (M + de C) x -> Mn (de >= 0; 0: M x alone)
+    [[maybe_unused]] const double* pendRR = nullptr; [[maybe_unused]] bool pend = false;    // a posted reduction of (sum u', |u' - u|^2) waiting for its barrier
+    double usum = 0.0, alpha = 1.0, unsum = 0.0, du2 = 0.0, xmaxT = 0.0;
+    auto collect_pending = [&]() {
+        if constexpr (NW != 1) {
+            if (pend) { double q2[2]; block_collect<NW, 2>(q2, pendRR, tid); unsum = q2[0]; du2 = q2[1]; pend = false; }
+        }
+    };
     auto spmv = [&](double xmax, int mp1, const bool split, const double de_) {
         TMARK(3);
         if (!(xmax > 0.0) || mp1 <= 0) {                       // zero vector: zero products, nothing to publish
+            if constexpr (NW != 1) { if (pend) { __syncthreads(); collect_pending(); } }
             FOR_K(k, p) { Mn[k] = 0.0; Cn[k] = 0.0; }
             ++n_pass;
             return;
@@ -3289,6 +3330,7 @@ __device__ void solve_up(const DevParams& D, int b, const ProbDesc& pd, ProbStat
         }
         FOR_K(k, p) if (p < L) xg[p] = tk[k] * sc;
         __syncthreads();                                        // the scaled vector is published; accumulators are clean
+        collect_pending();                                      // (the trial vector's sums, posted by finish_trial in front of this barrier)
         TMARK(6);
         if constexpr (NW == 1) {
             if (cooRounds >= 0) {
@@ -3447,7 +3489,6 @@ __device__ void solve_up(const DevParams& D, int b, const ProbDesc& pd, ProbStat
     // ---- the iteration as a state machine around ONE SpMV call site ------------------------------------
     enum { PH_RESCALE, PH_INIT, PH_TRIAL, PH_SPLIT };
     int phase = p_rescale ? PH_RESCALE : PH_INIT;
-    double usum = 0.0, alpha = 1.0, unsum = 0.0, du2 = 0.0, xmaxT = 0.0;
     int mp1T = 0;
     int i = 0, j = 0, kk = 0;
 
@@ -3480,9 +3521,12 @@ __device__ void solve_up(const DevParams& D, int b, const ProbDesc& pd, ProbStat
             const double df = t - u[k]; q[1] += df * df;
         }
         TMARK(3);
-        block_red<NW, 2, 0>(q, m0, red, par, tid);
+        // sum u' and |u' - u|^2 are not looked at before the products of u' are back: their reduction rides on the barrier that
+        // publishes u' (spmv collects it behind that barrier) instead of having one of its own — four workgroup barriers per
+        // pass instead of five
+        if constexpr (NW == 1) { block_red<NW, 2, 0>(q, m0, red, par, tid); unsum = q[0]; du2 = q[1]; }
+        else { pendRR = block_post<NW, 2>(q, red, par, tid); pend = true; }
         TMARK(7);
-        unsum = q[0]; du2 = q[1];
         xmaxT = (nr > 0.0) ? m2[0] / nr : m2[0]; mp1T = (int)m2[1];
     };
     auto build_trial = [&]() {

@@ -783,6 +783,7 @@ int enqueue_solve(roman_ctx* c, const DevParams& D, int B, int64_t sumA, int64_t
     // A handful of problems (the single-pair call whose latency bench.py reports): the wide passes are bound by how many bytes
     // ONE compute unit keeps in flight, not by the memory system — twice the quads in flight per lane (ROMAN_SOLVE_DEEP=0/1 forces).
     // MEASURED (round 4, config 2, B = 1): p50 0.678 ms with six quads in flight against 0.667 with three — no gain: off unless forced.
+    // Round 5 (four quads, the rebuilt stream loop): 0.953-0.961 against 0.941-0.950 ms per isolated launch of 256 problems, p50 0.588 / 0.586.
     static const char* deepEnv = getenv("ROMAN_SOLVE_DEEP");
     const bool deep = deepEnv && deepEnv[0] == '1';
 #define ROMAN_LAUNCH_UP(CZ_)                                                                                                  \
