@@ -1496,7 +1496,7 @@ __device__ __forceinline__ unsigned long long transpose64(unsigned long long x, 
     return x;
 }
 
-__global__ void __launch_bounds__(512) k_mirror(int B, int T /* workgroups per problem */, const ProbState* __restrict__ st, unsigned long long* __restrict__ maskPool)
+__global__ void __launch_bounds__(512) k_mirror(int B, int T /* workgroups per problem */, const ProbState* __restrict__ st, unsigned long long* __restrict__ maskPool, int skip0)
 {
     // The bit matrices are SPARSE (1.8 set bits per 64-bit word at config 3): a block is transposed by scattering its set
     // bits — lane l (source row) ORs bit l into word j of the wave's LDS tile for every set bit j of its word, one LDS atomic
@@ -1510,7 +1510,7 @@ __global__ void __launch_bounds__(512) k_mirror(int B, int T /* workgroups per p
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int b = (slot / T) * 8 + xcd, tb = slot % T;
     if (b >= B) return;
-    if (st[b].kind >= 2) return;
+    if (st[b].kind >= 2 || (skip0 && st[b].kind == 0)) return;    // (skip0: the stream-layout problems take k_lists — no symmetric matrix needed)
     const int L = st[b].L;
     const int W = (L + 63) >> 6;
     const int nR = ((W - 1 + nw - 1) / nw) * nw;                  // source row blocks 0..W-2, padded to whole workgroups
@@ -1565,7 +1565,7 @@ __global__ void __launch_bounds__(512) k_mirror(int B, int T /* workgroups per p
 __global__ void __launch_bounds__(1024) k_rowprefix(const ProbDesc* __restrict__ probs, const ProbState* __restrict__ st,
                                                     const BatchTotals* __restrict__ tot, const ItemDesc* __restrict__ items,
                                                     const unsigned long long* __restrict__ maskPool, uint32_t* __restrict__ prefPool,
-                                                    uint32_t* __restrict__ rowCnt, int RPB)
+                                                    uint32_t* __restrict__ rowCnt, int RPB, int skip0 /* stream-layout problems take k_lists */)
 {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, wpb = blockDim.x >> 6;
     const int nItems = tot->items;
@@ -1582,6 +1582,7 @@ __global__ void __launch_bounds__(1024) k_rowprefix(const ProbDesc* __restrict__
         const int64_t lo = probs[b].liveOff, mo = st[b].maskOff;
         const int nrows = min(RPB, L - it.row0);
         const bool wantPrefix = st[b].kind != 0;               // the stream layout takes its prefix counts in k_upper
+        if (skip0 && !wantPrefix) continue;
         if (W <= WAVE) {                                        // one word per lane: four rows per step, their loads in flight together
             constexpr int U = 4;
             for (int r = w; r < nrows; r += U * wpb) {
@@ -1639,7 +1640,7 @@ __global__ void __launch_bounds__(1024) k_rowsort(const ProbDesc* __restrict__ p
                                                   const uint32_t* __restrict__ rowCnt,
                                                   uint32_t* __restrict__ rowPos, uint32_t* __restrict__ perm,
                                                   uint32_t* __restrict__ sliceWidth, uint32_t* __restrict__ sliceBase,
-                                                  uint32_t* __restrict__ listOff, long long capList)
+                                                  uint32_t* __restrict__ listOff, long long capList, int skip0 /* stream-layout problems take k_lists */)
 {
     __shared__ uint32_t hist[SORT_KEYS];         // indexed by SORT_KEYS-1-key: ascending index = descending count
     __shared__ uint32_t wsum[16];
@@ -1648,6 +1649,7 @@ __global__ void __launch_bounds__(1024) k_rowsort(const ProbDesc* __restrict__ p
     const int L = st[b].L;
     const int64_t lo = probs[b].liveOff;
     if (st[b].kind >= 2) return;
+    if (st[b].kind == 0 && skip0) return;
     if (st[b].kind == 0) {
         // stream layout: bitonic sort (descending) of the UNIQUE keys ((degree + 1) << 12) | (4095 - row): larger degree
         // first, equal degrees in row order — the rank is the row's position.  N = next power of two >= L keys in LDS
@@ -1834,6 +1836,176 @@ __global__ void __launch_bounds__(1024) k_upper(const ProbDesc* __restrict__ pro
             }
         }
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_lists (kind 0; launches in which no fallback problem can occur): from the UPPER blocks of the candidate bit matrix — what
+// k_count writes — straight to positions and kept-candidate lists, one workgroup per problem, everything that is looked up by
+// index in LDS.  It stands for k_mirror + k_rowprefix + k_rowsort + k_upper, which reach the same lists through the symmetric
+// matrix (0.55 MB per problem written and read again, four dependent launches: 0.31 ms of a 2.0 ms step at config 3):
+//   degrees    a stored bit (k, q), k < q, counts for row k (popcount of the row's words) and for row q (one LDS atomic per
+//              set bit): the full degree of the symmetric matrix without ever forming it;
+//   positions  rank by (degree descending, row ascending): k_rowsort's bitonic sort of unique keys, in LDS;
+//   lists      room for position p as k_rowsort sizes it (min(degree, L - 1 - p) entries, whole quads, bump pointer of the
+//              batch); a second sweep over the bits hands every pair to its endpoint of SMALLER position (slot by an LDS
+//              cursor, the other endpoint's live column index as the entry), then the rows are padded to whole quads and their
+//              upper degrees written in position order with the position-ordered copies of the pools the solver reads.
+// The ENTRIES of a list arrive in the order the cursors were taken, not ascending: where an entry sits in its row is immaterial
+// (the fill labels it with its column's position, the solver's sums are exact integers) — roman_get_upper_csr sorts its rows.
+// Sweep: 16 lanes per row, four rows per wave step, lane = one 64-column word of the row's upper part (the diagonal word keeps
+// its bits behind the row's own); a row's words come in one or two coalesced 128-byte pieces.
+// ---------------------------------------------------------------------------------------------
+constexpr int LISTS_NT = 1024;
+
+__global__ void __launch_bounds__(LISTS_NT) k_lists(int B, const ProbDesc* __restrict__ probs, ProbState* __restrict__ st, BatchTotals* __restrict__ tot,
+                                                   const unsigned long long* __restrict__ maskPool,
+                                                   uint16_t* __restrict__ listPool, uint32_t* __restrict__ listOff,
+                                                   uint32_t* __restrict__ rowCnt, uint32_t* __restrict__ perm, uint32_t* __restrict__ rowPos,
+                                                   LivePools src, LivePools dst, long long capList)
+{
+    __shared__ uint32_t degS[STREAM_MAXL + 64];                 // full degree of a live row; after the sort: the row's list cursor
+    __shared__ uint32_t keyS[4096];                             // sort keys
+    __shared__ unsigned long long tabS[STREAM_MAXL + 64];       // per live row: list offset << 16 | position (one LDS read serves both)
+    __shared__ uint32_t wsum[LISTS_NT / 64];
+    __shared__ int okS;
+    static_assert(STREAM_MAXL <= 4096, "sort capacity");
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    constexpr int NW = LISTS_NT / 64;
+    const int g = lane >> 4, sl = lane & 15;                    // row of the wave step, word of the row's piece
+    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+        __syncthreads();                                        // (the previous problem's LDS is no longer read)
+        if (st[b].kind != 0) continue;
+        const int L = st[b].L;
+        if (L <= 0) continue;
+        const int W = (L + 63) >> 6;
+        const int64_t lo = probs[b].liveOff, mo = st[b].maskOff;
+        const unsigned long long* mrow = maskPool + mo;
+        // f(k, m, c): word c (strictly-upper bits only) of live row k, for every row and every word at or behind its diagonal one.
+        // A wave step = four rows (one 64-row block: k0 is a multiple of four) x sixteen words from c0 on; the words of the next
+        // six steps are in flight while one is worked on (unconditional loads at clamped addresses: the wait counters stay exact)
+        auto fetch = [&](int k0_, int c0_) -> unsigned long long {
+            const int k = k0_ + g, c = c0_ + sl;
+            const bool valid = k < L && c < W;                  // (c >= k >> 6 by construction: c0 starts at the rows' diagonal word)
+            unsigned long long m = mrow[(int64_t)min(k, L - 1) * W + min(c, W - 1)];
+            if (!valid) m = 0ull;
+            if (c == (k >> 6)) m &= ((k & 63) == 63) ? 0ull : (~0ull << ((k & 63) + 1));   // the diagonal block holds both triangles: columns behind k only
+            return m;
+        };
+        auto advance = [&](int& k0_, int& c0_) { c0_ += 16; if (c0_ >= W) { k0_ += 4 * NW; c0_ = k0_ >> 6; } };
+        auto sweep = [&](auto f) {
+            constexpr int PF = 6;                               // steps in flight: a wave walks ~50 steps, each a dependent round trip otherwise
+            int kr[PF], cr[PF]; unsigned long long mr[PF];
+            int kn = 4 * w, cn = kn >> 6;
+#pragma unroll
+            for (int i = 0; i < PF; ++i) { kr[i] = kn; cr[i] = cn; mr[i] = fetch(kn, cn); advance(kn, cn); }
+            while (kr[0] < L) {                                 // (steps are in ascending row order; a step behind the last row carries no bits)
+#pragma unroll
+                for (int i = 0; i < PF; ++i) {
+                    const int kc = kr[i], cc = cr[i]; const unsigned long long mc = mr[i];
+                    kr[i] = kn; cr[i] = cn; mr[i] = fetch(kn, cn); advance(kn, cn);
+                    f(kc + g, mc, cc + sl);
+                }
+            }
+        };
+#ifdef ROMAN_LISTS_TIMING
+        unsigned long long tl_[6]; tl_[0] = __builtin_readcyclecounter();
+#define LMARK(i_) tl_[i_] = __builtin_readcyclecounter()
+#else
+#define LMARK(i_) do { } while (0)
+#endif
+        for (int q = tid; q < L; q += LISTS_NT) degS[q] = 0u;
+        __syncthreads();
+        // ---- degrees ----
+        sweep([&](int k, unsigned long long m, int c) {
+            if (m) {
+                atomicAdd(&degS[k], (uint32_t)__popcll(m));
+                while (m) { atomicAdd(&degS[(c << 6) + __builtin_ctzll(m)], 1u); m &= m - 1ull; }
+            }
+        });
+        __syncthreads();
+        LMARK(1);
+        // ---- positions: bitonic sort (descending) of the unique keys ((degree + 1) << 12) | (4095 - row) (k_rowsort's order) ----
+        int N = 64; while (N < L) N <<= 1;
+        for (int t = tid; t < N; t += LISTS_NT) keyS[t] = (t < L) ? (((degS[t] + 1u) << 12) | (uint32_t)(4095 - t)) : 0u;
+        __syncthreads();
+        for (int k2 = 2; k2 <= N; k2 <<= 1)
+            for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
+                for (int t = tid; t < (N >> 1); t += LISTS_NT) {
+                    const int i1 = ((t & ~(j2 - 1)) << 1) | (t & (j2 - 1)), i2 = i1 | j2;
+                    const uint32_t a = keyS[i1], c2 = keyS[i2];
+                    const bool desc = (i1 & k2) == 0;
+                    if ((a < c2) == desc) { keyS[i1] = c2; keyS[i2] = a; }
+                }
+                __syncthreads();                                // (stages inside a wave's own 128 keys without the barrier: measured, no faster)
+            }
+        LMARK(2);
+        // ---- list room per position (whole quads), the problem's base from the batch's bump pointer ----
+        {
+            const int PER = (L + LISTS_NT - 1) / LISTS_NT;      // consecutive positions per thread (<= 3)
+            uint32_t sum = 0;
+            for (int t = 0; t < PER; ++t) {
+                const int q = tid * PER + t;
+                if (q < L) sum += (min((keyS[q] >> 12) - 1u, (uint32_t)(L - 1 - q)) + 3u) & ~3u;
+            }
+            const uint32_t inc = wave_incl_scan(sum);
+            if (lane == WAVE - 1) wsum[w] = inc;
+            __syncthreads();
+            uint32_t wbase = 0, total = 0;
+            for (int t = 0; t < NW; ++t) { if (t < w) wbase += wsum[t]; total += wsum[t]; }
+            if (tid == 0) {
+                const unsigned long long base = atomicAdd(&tot->listTop, (unsigned long long)total);
+                st[b].listOff = (int64_t)base;
+                const bool fits = (long long)(base + total) <= capList;
+                if (!fits) { st[b].kind = 2; atomicAdd(&tot->overflow, 1); }
+                okS = fits ? 1 : 0;
+            }
+            uint32_t run = wbase + inc - sum;
+            for (int t = 0; t < PER; ++t) {
+                const int q = tid * PER + t;
+                if (q < L) {
+                    const uint32_t k = 4095u - (keyS[q] & 4095u);
+                    perm[lo + q] = k; rowPos[lo + k] = (uint32_t)q;
+                    tabS[k] = ((unsigned long long)run << 16) | (unsigned long long)q; listOff[lo + q] = run; degS[k] = 0u;     // (degS: now the row's list cursor)
+                    run += (min((keyS[q] >> 12) - 1u, (uint32_t)(L - 1 - q)) + 3u) & ~3u;
+                }
+            }
+        }
+        __syncthreads();
+        if (!okS) continue;                                     // lists beyond the pool: skipped like any workspace overflow (the history now knows the need)
+        uint16_t* const lists = listPool + st[b].listOff;
+        LMARK(3);
+        // ---- every stored pair to its endpoint of smaller position ----
+        sweep([&](int k, unsigned long long m, int c) {
+            if (!m) return;
+            const unsigned long long tk = tabS[k];
+            const uint32_t pk = (uint32_t)tk & 0xffffu, ok = (uint32_t)(tk >> 16);
+            while (m) {
+                const uint32_t q = (uint32_t)((c << 6) + __builtin_ctzll(m));
+                m &= m - 1ull;
+                const unsigned long long tq = tabS[q];
+                const bool mine = pk < ((uint32_t)tq & 0xffffu);                       // the pair belongs to its endpoint of smaller position
+                const uint32_t slot = atomicAdd(&degS[mine ? (uint32_t)k : q], 1u);
+                lists[(mine ? ok : (uint32_t)(tq >> 16)) + slot] = (uint16_t)(mine ? q : (uint32_t)k);
+            }
+        });
+        __syncthreads();
+        LMARK(4);
+        // ---- padding, upper degrees and the position-ordered pools ----
+        for (int p = tid; p < L; p += LISTS_NT) {
+            const uint32_t k = 4095u - (keyS[p] & 4095u);
+            const uint32_t cnt = degS[k];
+            rowCnt[lo + p] = cnt;
+            uint16_t* lst = lists + (uint32_t)(tabS[k] >> 16);
+            for (uint32_t e = cnt; e < ((cnt + 3u) & ~3u); ++e) lst[e] = (uint16_t)0xffffu;
+            dst.lp[lo + p] = src.lp[lo + k]; dst.ld[lo + p] = src.ld[lo + k];
+        }
+#ifdef ROMAN_LISTS_TIMING
+        LMARK(5);
+        if (tid == 0 && (b & 63) == 0) printf("[k_lists] b=%d L=%d cycles: degrees %llu sort %llu offsets %llu scatter %llu tail %llu\n", b, L,
+                                              tl_[1] - tl_[0], tl_[2] - tl_[1], tl_[3] - tl_[2], tl_[4] - tl_[3], tl_[5] - tl_[4]);
+#endif
+#undef LMARK
     }
 }
 

@@ -619,24 +619,39 @@ int enqueue_score(roman_ctx* c, const DevParams& Din, const roman_params_t* para
             HIPCHK(c, hipLaunchKernel(kc, dim3(pairGrid), dim3(wpb * 64), args, pairLds, WS.stream));
         }
     DBG(c, "k_count");
+        // Stream-layout problems (kind 0) go from the upper blocks straight to positions and kept-candidate lists in ONE kernel, one
+        // workgroup per problem (k_lists, round 5); the symmetric matrix and its four kernels remain for the fallback layout's
+        // problems — launched only when such problems can occur — and, with ROMAN_LISTS=0 in the environment, for everything (A/B).
+        // (a handful of problems — the single-pair call — keep the four kernels: they spread ONE problem over the device, k_lists
+        //  gives it one compute unit: 0.59 against 0.66 ms for B = 1)
+        const char* listsEnv = getenv("ROMAN_LISTS");           // "0": never, "1": always (A/B and tests: read per call)
+        const int fusedLists = listsEnv ? (listsEnv[0] == '0' ? 0 : 1) : (B >= std::max(8, c->num_cu / 8) ? 1 : 0);
+        if (fusedLists) {
+            hipLaunchKernelGGL(k_lists, dim3((unsigned)std::max(1, std::min(B, 2 * c->num_cu))), dim3(LISTS_NT), 0, WS.stream, B, dP, dS, dT,
+                               WS.maskPool.as<unsigned long long>(), WS.listPool.as<uint16_t>(), WS.listOff.as<uint32_t>(),
+                               WS.rowCnt.as<uint32_t>(), WS.perm.as<uint32_t>(), WS.rowPos.as<uint32_t>(), LP, PP, (long long)SZ.capList);
+    DBG(c, "k_lists");
+        }
+        if (!fusedLists || D.allow_fallback) {
         {   // lower triangle of the bit matrices = transposed blocks of the upper triangle (grid for the expected size;
             // the kernel loops when a problem is larger)
             const int Wexp = (expL + 63) / 64;
             const int tasks = ((Wexp + 7) / 8) * ((std::max(Wexp - 1, 1) + 7) / 8);          // workgroups of 8 waves
             const int T = std::max(tasks, 1);
-            hipLaunchKernelGGL(k_mirror, dim3((unsigned)(T * ((B + 7) / 8) * 8)), dim3(512), 0, WS.stream, B, T, dS, WS.maskPool.as<unsigned long long>());
+            hipLaunchKernelGGL(k_mirror, dim3((unsigned)(T * ((B + 7) / 8) * 8)), dim3(512), 0, WS.stream, B, T, dS, WS.maskPool.as<unsigned long long>(), fusedLists);
     DBG(c, "k_mirror");
         }
         hipLaunchKernelGGL(k_rowprefix, dim3(c->num_cu * 2), dim3(1024), 0, WS.stream, dP, dS, dT, WS.items.as<ItemDesc>(),
-                           WS.maskPool.as<unsigned long long>(), WS.prefPool.as<uint32_t>(), WS.rowCnt.as<uint32_t>(), RPB);
+                           WS.maskPool.as<unsigned long long>(), WS.prefPool.as<uint32_t>(), WS.rowCnt.as<uint32_t>(), RPB, fusedLists);
     DBG(c, "k_rowprefix");
         // the stream layout's bitonic sort takes N/2 threads for N = 2^k >= L keys; the fallback layout's counting sort is written
         // for 1024 (at the reference's demo scale — 60 live associations — 4096 workgroups of 1024 threads were 99 us of a 1.4 ms call)
         int sortThr = 1024;
         if (!D.allow_fallback) { int N2 = 64; while (N2 < expL) N2 <<= 1; sortThr = std::max(64, std::min(1024, N2 / 2)); }
         hipLaunchKernelGGL(k_rowsort, dim3(B), dim3(sortThr), 0, WS.stream, dP, dS, dT, WS.rowCnt.as<uint32_t>(), WS.rowPos.as<uint32_t>(), WS.perm.as<uint32_t>(),
-                           WS.sliceWidth.as<uint32_t>(), WS.sliceBase.as<uint32_t>(), WS.listOff.as<uint32_t>(), SZ.capList);
+                           WS.sliceWidth.as<uint32_t>(), WS.sliceBase.as<uint32_t>(), WS.listOff.as<uint32_t>(), SZ.capList, fusedLists);
     DBG(c, "k_rowsort");
+        if (!fusedLists) {
         // small live sets (the reference's demo scale): a work item is a whole problem of a few dozen rows — more, smaller
         // workgroups keep more of them in flight (a row is a chain of dependent memory round trips)
         const int upThr = expL <= 256 ? 256 : 1024;
@@ -644,6 +659,8 @@ int enqueue_score(roman_ctx* c, const DevParams& Din, const roman_params_t* para
                            WS.maskPool.as<unsigned long long>(), WS.listPool.as<uint16_t>(), WS.listOff.as<uint32_t>(),
                            WS.rowCnt.as<uint32_t>(), WS.perm.as<uint32_t>(), WS.rowPos.as<uint32_t>(), LP, PP, RPB);
     DBG(c, "k_upper");
+        }
+        }
         hipLaunchKernelGGL(k_slicegeom, dim3(B), dim3(64), 0, WS.stream, dP, dS, WS.rowCnt.as<uint32_t>(), WS.sliceWidth.as<uint32_t>(), WS.sliceBase.as<uint32_t>());
     DBG(c, "k_slicegeom");
     }
@@ -1676,9 +1693,9 @@ int roman_set_matrix_data(roman_ctx_t* c, const roman_params_t* params, const do
         hipLaunchKernelGGL(k_dense_mask, dim3((unsigned)std::min(c->num_cu * 8, (n + 3) / 4)), dim3(256), 0, WS.stream, n, dM, dC,
                            WS.maskPool.as<unsigned long long>(), WS.hAux3.as<int>());
         hipLaunchKernelGGL(k_rowprefix, dim3(c->num_cu * 2), dim3(1024), 0, WS.stream, dP, dS, dT, WS.items.as<ItemDesc>(),
-                           WS.maskPool.as<unsigned long long>(), WS.prefPool.as<uint32_t>(), WS.rowCnt.as<uint32_t>(), RPB);
+                           WS.maskPool.as<unsigned long long>(), WS.prefPool.as<uint32_t>(), WS.rowCnt.as<uint32_t>(), RPB, 0);
         hipLaunchKernelGGL(k_rowsort, dim3(1), dim3(1024), 0, WS.stream, dP, dS, dT, WS.rowCnt.as<uint32_t>(), WS.rowPos.as<uint32_t>(), WS.perm.as<uint32_t>(),
-                           WS.sliceWidth.as<uint32_t>(), WS.sliceBase.as<uint32_t>(), WS.listOff.as<uint32_t>(), capList);
+                           WS.sliceWidth.as<uint32_t>(), WS.sliceBase.as<uint32_t>(), WS.listOff.as<uint32_t>(), capList, 0);
         if (up) {
             hipLaunchKernelGGL(k_upper, dim3(c->num_cu * 2), dim3(1024), 0, WS.stream, dP, dS, dT, WS.items.as<ItemDesc>(),
                                WS.maskPool.as<unsigned long long>(), WS.listPool.as<uint16_t>(), WS.listOff.as<uint32_t>(),

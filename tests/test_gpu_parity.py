@@ -66,8 +66,12 @@ def make(case):
     return reg, pr
 
 
+@pytest.mark.parametrize("lists", ["0", "1"], ids=["four_list_kernels", "k_lists"])
 @pytest.mark.parametrize("case", LADDER, ids=[c[0] for c in LADDER])
-def test_stagewise_parity(ctx, orc, case):
+def test_stagewise_parity(ctx, orc, case, lists, monkeypatch):
+    # positions and kept-candidate lists of the stream layout: through the symmetric bit matrix (k_mirror, k_rowprefix, k_rowsort,
+    # k_upper) or from its upper blocks in one kernel (k_lists, what batches of >= 32 problems take): the same matrix either way
+    monkeypatch.setenv("ROMAN_LISTS", lists)
     reg, pr = make(case)
     reg.set_context(ctx)
     P = reg._abi_params()
