@@ -316,6 +316,18 @@ ROMAN_API int roman_align_batch(roman_ctx_t* ctx, const roman_params_t* params, 
                       int32_t kmax, int32_t* assoc_out, int32_t* n_assoc_out,
                       double* T_out, int32_t* status_out, roman_stats_t* stats_out);
 
+/* The deal of a batch over `world` ranks (one process per GPU), for a C / C++ caller that shards with its own collective
+   (roman_ros, [REF README.md:11]; the Python side is roman_amd.align.distributed.align_sharded).  The pairs of the serial loop
+   [REF roman/align/submap_align.py:93-200] are independent: every rank aligns its share with roman_align_batch[_dev] and ONE
+   all_gather of the outputs (n_assoc_out, assoc_out, T_out, status_out: fixed-size rows per problem) collects them — no other
+   exchange.  The deal is a pure host function of the problem sizes, identical on every rank without communication: problems
+   longest-first (work estimate = the SQUARE of the association count, n1*n2 for all-to-all: pair tests and matrix entries grow
+   with it) to the rank with the least work so far, ties to the rank holding fewer problems, then to the lowest rank.
+   assoc_off: NULL (all-to-all) or int64[B+1] (an empty list means all-to-all).  idx_out: int32[B] capacity; on return its first
+   *n_out entries are the ascending problem indices of `rank`. */
+ROMAN_API int roman_deal_problems(int32_t B, const int32_t* n1, const int32_t* n2, const int64_t* assoc_off,
+                                  int32_t world, int32_t rank, int32_t* idx_out, int32_t* n_out);
+
 /* ------------------------------------------------------------------------------------------- */
 /* stepwise surface for the clipperpy-compatible shim (single problem, host pointers)          */
 /* ------------------------------------------------------------------------------------------- */

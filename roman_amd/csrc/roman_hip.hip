@@ -1561,6 +1561,36 @@ int roman_align_batch(roman_ctx_t* c, const roman_params_t* params, int32_t B,
     return ROMAN_OK;
 }
 
+// --- the deal of a batch over ranks (pure host function; roman_amd.align.distributed.deal_by_cost states the same) ------------
+int roman_deal_problems(int32_t B, const int32_t* n1, const int32_t* n2, const int64_t* assoc_off,
+                        int32_t world, int32_t rank, int32_t* idx_out, int32_t* n_out)
+{
+    if (B < 0 || world < 1 || rank < 0 || rank >= world || !n_out || (B > 0 && (!n1 || !n2 || !idx_out)))
+        return fail(nullptr, ROMAN_E_INVALID, "bad arguments");
+    std::vector<int64_t> work((size_t)B);
+    for (int b = 0; b < B; ++b) {
+        int64_t a = assoc_off ? assoc_off[b + 1] - assoc_off[b] : 0;
+        if (a <= 0) a = (int64_t)n1[b] * n2[b];                 // no list, or an empty one: all-to-all
+        work[(size_t)b] = a * a;
+    }
+    std::vector<int32_t> order((size_t)B);
+    for (int b = 0; b < B; ++b) order[(size_t)b] = b;
+    std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return work[(size_t)x] > work[(size_t)y]; });
+    std::vector<int64_t> load((size_t)world, 0), count((size_t)world, 0);
+    std::vector<int32_t> mine;
+    for (int32_t b : order) {
+        int r = 0;
+        for (int t = 1; t < world; ++t)
+            if (load[(size_t)t] < load[(size_t)r] || (load[(size_t)t] == load[(size_t)r] && count[(size_t)t] < count[(size_t)r])) r = t;
+        load[(size_t)r] += std::max<int64_t>(work[(size_t)b], 1); count[(size_t)r] += 1;
+        if (r == rank) mine.push_back(b);
+    }
+    std::sort(mine.begin(), mine.end());
+    for (size_t t = 0; t < mine.size(); ++t) idx_out[t] = mine[t];
+    *n_out = (int32_t)mine.size();
+    return ROMAN_OK;
+}
+
 // --- stepwise surface for the clipperpy-compatible shim -----------------------------------------------
 int roman_create_all_to_all(int32_t n1, int32_t n2, int32_t* out)
 {

@@ -111,6 +111,33 @@ def test_deal_on_a_heterogeneous_grid_balances_the_quadratic_work():
     assert all(np.array_equal(a, b) for a, b in zip(shards, deal_by_cost(problem_work(batch), 8)))
 
 
+def test_the_c_abis_deal_is_the_python_deal():
+    """roman_deal_problems (include/roman_hip.h: the deal for a C / C++ caller that shards with its own collective) is a pure
+    host function — callable without a GPU — and hands every rank exactly the share align_sharded computes, on all-to-all
+    batches of unequal submaps and on explicit association lists (an empty list counting as all-to-all)."""
+    import ctypes as C
+    from roman_amd import _abi
+    lib = _abi.load_library()
+    rng = np.random.default_rng(21)
+    for trial in range(4):
+        B = int(rng.integers(1, 400)); world = int(rng.choice([1, 2, 3, 8]))
+        n1 = rng.integers(0, 301, size=B).astype(np.int32); n2 = rng.integers(0, 301, size=B).astype(np.int32)
+        assoc_off = None
+        if trial % 2:
+            lens = rng.integers(0, 500, size=B); lens[rng.random(B) < 0.2] = 0
+            assoc_off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        batch = rb.AlignmentBatch(np.zeros((1, 3)), np.zeros(B, np.int64), n1, np.zeros(B, np.int64), n2,
+                                  None if assoc_off is None else np.zeros((int(assoc_off[-1]), 2), np.int32), assoc_off)
+        want = deal_by_cost(problem_work(batch), world)
+        for rank in range(world):
+            idx = np.full(B, -1, dtype=np.int32); n = C.c_int32(0)
+            rc = lib.roman_deal_problems(B, n1.ctypes.data_as(C.c_void_p), n2.ctypes.data_as(C.c_void_p),
+                                         None if assoc_off is None else assoc_off.ctypes.data_as(C.c_void_p), world, rank,
+                                         idx.ctypes.data_as(C.c_void_p), C.byref(n))
+            assert rc == 0 and np.array_equal(idx[:n.value], want[rank]), (trial, rank)
+    assert lib.roman_deal_problems(4, None, None, None, 2, 0, None, None) != 0          # bad arguments are refused, not dereferenced
+
+
 def test_take_keeps_problem_semantics():
     reg = registration_for("clipper+prune", cosine_min=0.5)
     pairs = [(p.map1, p.map2) for p in (synth.make_pair(12 + k, 10, 16, 300 + k) for k in range(5))]
