@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-5 GPU sessions, one per letter:  bash tools/r5_sessions.sh <a..m>   (repo root on an MI355X box; everything under gpurun_out/).
+# Round-5 GPU sessions, one per letter:  bash tools/r5_sessions.sh <a..n>   (repo root on an MI355X box; everything under gpurun_out/).
 # The A/B sessions compare library builds kept under roman_amd/csrc/variants/ (git-ignored; rebuilt from the commits named in
 # DESIGN.md 4.2 / profiles/r05/README.md): they are the record of what was measured, not something a fresh checkout can re-run as is.
 S=$1
@@ -207,6 +207,29 @@ PY
   rm -rf $OUT/ab_tmp
   timeout 600 python bench.py --steps 40 --warmup 5 --no-extras --no-grid --cpu-sample 0 --check-pairs 256 --latency-reps 20 > $OUT/r5l_bench_$cfg.txt 2>$OUT/r5l_bench_$cfg.err
   echo "== lists=$cfg"; python tools/bench_digest.py $OUT/r5l_bench_$cfg.txt | head -1
+done
+;;
+n)
+# round-5 session N: the stream solver's waves take interleaved quads (default) against contiguous ranges (ROMAN_SOLVE_STRIDED=0),
+# one build, one box: solver-facing tests under the new default, kernel averages, bench, phase cycles under both
+export TMPDIR=/tmp; OUT=$PWD/gpurun_out; mkdir -p $OUT; REPO=$PWD
+timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_full_configs.py tests/test_gpu_batch.py tests/test_u0_stability.py -q -m gpu -k "stagewise or config3 or config4_grid or demo_scale or fixed_point or dense_matrix or ragged or tie_fallback or explicit_u0 or random_start" > $OUT/r5n_pytest.txt 2>&1; echo "pytest rc=$?"; tail -4 $OUT/r5n_pytest.txt
+for ST in 0 1 0 1; do
+  export ROMAN_SOLVE_STRIDED=$ST
+  ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ab_tmp -o b -- python $REPO/bench.py --steps 5 --warmup 2 --pipeline 1 --latency-reps -1 --cpu-sample 0 --no-extras --no-grid --check-pairs 0 > /dev/null 2>&1 )
+  F=$(find $OUT/ab_tmp -name "*kernel_stats.csv" | head -1)
+  python - "$F" "strided=$ST" <<'PY'
+import csv, sys
+for r in csv.DictReader(open(sys.argv[1])):
+    if 'k_solve_up<8' in r['Name']: print(sys.argv[2], r['Name'][:44], round(float(r['AverageNs']) / 1e3, 1), 'us')
+PY
+  rm -rf $OUT/ab_tmp
+  timeout 600 python bench.py --steps 40 --warmup 5 --no-extras --no-grid --cpu-sample 0 --check-pairs 64 --latency-reps 20 > $OUT/r5n_bench_$ST.txt 2>$OUT/r5n_bench_$ST.err
+  echo "== strided=$ST"; python tools/bench_digest.py $OUT/r5n_bench_$ST.txt | head -1
+done
+for ST in 0 1; do
+  ROMAN_SOLVE_STRIDED=$ST ROMAN_HIP_LIBRARY=$REPO/roman_amd/csrc/variants/libT.so timeout 600 python bench.py --steps 2 --warmup 1 --pipeline 1 --no-extras --no-grid --cpu-sample 0 --check-pairs 0 --latency-reps 2 > $OUT/r5n_benchT_$ST.txt 2> $OUT/r5n_timing_$ST.txt
+  echo "== phases strided=$ST"; grep -A5 "solve timing" $OUT/r5n_timing_$ST.txt | grep -v "^--" | sed -n '1,6p;$p'
 done
 ;;
 m)
