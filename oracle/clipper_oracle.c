@@ -74,6 +74,11 @@ ORACLE_API int oracle_get_arith(void) { return g_plain_arith; }
 static int g_pass_mode = 2;
 ORACLE_API void oracle_set_pass_mode(int mode) { g_pass_mode = (mode == 0 || mode == 1) ? mode : 2; }
 ORACLE_API int oracle_get_pass_mode(void) { return g_pass_mode; }
+/* Analysis hook (tools/wide_compaction_sim.py): when set, oracle_solve also records WHICH elements are positive in the vector
+ * fed to each pass — one row of `words_per_pass` 64-bit words per pass, up to `max_pass` rows.  Not thread-safe; off by default. */
+static uint64_t* g_support_dump = NULL; static int64_t g_dump_words = 0; static int32_t g_dump_passes = 0;
+ORACLE_API void oracle_set_support_dump(uint64_t* buf, int64_t words_per_pass, int32_t max_pass)
+{ g_support_dump = buf; g_dump_words = words_per_pass; g_dump_passes = max_pass; }
 
 static inline double from_bits(uint64_t b) { double d; memcpy(&d, &b, 8); return d; }
 static inline uint64_t to_bits(double d) { uint64_t b; memcpy(&b, &d, 8); return b; }
@@ -699,7 +704,10 @@ ORACLE_API int oracle_solve(const roman_params_t* P, const oracle_mat_t* m, cons
 #define TRACE(vec) do { if (support_trace && npass < trace_cap) { \
         int32_t c_ = 0; \
         for (int32_t p_ = 0; p_ < n; ++p_) { c_ += ((vec)[p_] > 0.0); } \
-        support_trace[npass] = c_; } } while (0)
+        support_trace[npass] = c_; } \
+    if (g_support_dump && npass < g_dump_passes && (int64_t)(n + 63) / 64 <= g_dump_words) { \
+        uint64_t* r_ = g_support_dump + (int64_t)npass * g_dump_words; \
+        for (int32_t p_ = 0; p_ < n; ++p_) { if ((vec)[p_] > 0.0) r_[p_ >> 6] |= 1ull << (p_ & 63); } } } while (0)
 
     /* removed associations (zero single score) take no part: their u is 0 whatever u0 says */
     for (int32_t p = 0; p < n; ++p) u[p] = m->live[p] ? (u0_in ? u0_in[p] : 1.0) : 0.0;

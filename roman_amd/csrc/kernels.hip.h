@@ -502,6 +502,81 @@ __global__ void __launch_bounds__(256) k_cos_wave(DevParams D, int B, const Prob
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_cos_block: k_cos_wave for a FEW demo-size problems (a serial caller's one pair at a time).  One wave alone walks a problem's
+// 48 chunks x 36 matrix instructions in 68 us — the whole device idle beside it; here a wave takes ONE 16 x 16 block of the
+// cosine matrix (up to nine waves per problem): four matrix instructions per chunk, eight chunks of loads in flight (a ring of
+// 32-byte loads, refilled as it is consumed).  Every output element sees k_cos_wave's own contraction order — chunks of 16
+// ascending, step t of a chunk contracts k = k0 + 4 * (lane >> 4) + t — and the norm sums are formed the same way: identical bits.
+// ---------------------------------------------------------------------------------------------
+constexpr int COSB_DEPTH = 8;
+
+__global__ void __launch_bounds__(256) k_cos_block(DevParams D, int B, const ProbDesc* __restrict__ probs,
+                                                   const double* __restrict__ feats, double* __restrict__ cosPool)
+{
+    const int wid = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    const int b = uni_i(wid / (COSW_NB * COSW_NB));
+    if (b >= B) return;
+    const int blk = uni_i(wid - b * (COSW_NB * COSW_NB)), xs = blk / COSW_NB, ys = blk - xs * COSW_NB;
+    const ProbDesc pd = probs[b];
+    if (16 * xs >= pd.n1 || 16 * ys >= pd.n2) return;
+    const int lane = threadIdx.x & 63;
+    const int Fc = D.p.cos_feature_dim, coff = D.p.point_dim + D.p.ratio_feature_dim;
+    const int lr = lane & 15, kq = lane >> 4;
+    const int ia = 16 * xs + lr, jb = 16 * ys + lr;
+    const bool va = ia < pd.n1, vb = jb < pd.n2;
+    const double* fa = feats + (pd.off1 + (va ? ia : 0)) * D.F + coff + 4 * kq;
+    const double* fb = feats + (pd.off2 + (vb ? jb : 0)) * D.F + coff + 4 * kq;
+    double4_t acc = double4_t{0.0, 0.0, 0.0, 0.0};
+    double sa = 0.0, sb = 0.0;
+    const int nfull = Fc >> 4;
+    if (nfull > 0) {
+        d4u_t ra[COSB_DEPTH], rb[COSB_DEPTH];
+#pragma unroll
+        for (int t = 0; t < COSB_DEPTH; ++t) {
+            const int kk = 16 * min(t, nfull - 1);
+            ra[t] = *reinterpret_cast<const d4u_t*>(fa + kk); rb[t] = *reinterpret_cast<const d4u_t*>(fb + kk);
+        }
+        for (int c0 = 0; c0 < nfull; c0 += COSB_DEPTH) {
+#pragma unroll
+            for (int t = 0; t < COSB_DEPTH; ++t) {
+                const d4u_t a = ra[t], q = rb[t];
+                const int kn = 16 * min(c0 + t + COSB_DEPTH, nfull - 1);
+                ra[t] = *reinterpret_cast<const d4u_t*>(fa + kn); rb[t] = *reinterpret_cast<const d4u_t*>(fb + kn);
+                if (c0 + t < nfull) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        sa = fma(a.v[e], a.v[e], sa); sb = fma(q.v[e], q.v[e], sb);
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(va ? a.v[e] : 0.0, vb ? q.v[e] : 0.0, acc, 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    const int k0 = 16 * nfull;
+    if (k0 < Fc) {                                   // ragged tail of the descriptor (< 16 elements)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int kk = k0 + 4 * kq + t;
+            const bool vk = kk < Fc;
+            const double av = (va && vk) ? fa[k0 + t] : 0.0, bv = (vb && vk) ? fb[k0 + t] : 0.0;
+            sa = fma(av, av, sa); sb = fma(bv, bv, sb);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+        }
+    }
+    sa += __shfl_xor(sa, 16); sa += __shfl_xor(sa, 32);
+    sb += __shfl_xor(sb, 16); sb += __shfl_xor(sb, 32);
+    sa = sqrt(sa); sb = sqrt(sb);
+    const int col = 16 * ys + lr;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = 16 * xs + kq + 4 * r;
+        const double na = __shfl(sa, kq + 4 * r);
+        if (row < pd.n1 && col < pd.n2)
+            cosPool[pd.cosOff + (int64_t)row * pd.n2 + col] = D.pruned ? acc[r] : ((na > 0.0 && sb > 0.0) ? acc[r] / (na * sb) : 0.0);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_cos_tile<KC>: the same products, operands staged through LDS.  A workgroup (4 waves) owns an output tile of up to 64x64,
 // wave (wy, wx) the 2x2 MFMA blocks of its quarter.  Per stage of KC descriptor elements the 256 threads copy the tile's
 // row pieces of KC doubles from global memory to LDS with 16-byte loads whose lanes run ALONG a row (SEGS lanes cover one
@@ -2663,72 +2738,185 @@ __device__ __forceinline__ void spmv_sell(const double* u, int L, const uint32_t
 // One-sided Jacobi (Hestenes) SVD of a dxd matrix (d = 2 or 3), then the proper rotation
 // R = u1 v1' + u2 v2' + (u1 x u2)(v1 x v2)'   — equal to the reference's  U Vh  with the last
 // row of Vh negated when det = -1 ([REF roman/align/object_registration.py:121-126]).
-__device__ __noinline__ void kabsch_rotation(const double* H, int d, double* R)
+__device__ __forceinline__ double wave_sum63(double v);       // (defined with the stream solver's reductions below)
+__device__ __forceinline__ double readlane63(double v);
+
+// One-sided Jacobi step on the column pair (P, Q) of G (V accumulates the rotations).  Everything is indexed at compile time:
+// G and V stay in registers (the round-1 form walked p, q, r with run-time indices — 76 scratch accesses of ~500 cycles each
+// on the one thread that runs it: 47 k cycles per alignment, a twentieth of a config-3 solve and half of a demo-scale one).
+template <int P, int Q>
+__device__ __forceinline__ void jacobi_pair(double (&G)[9], double (&V)[9], bool& moved)
+{
+    double al = 0.0, be = 0.0, ga = 0.0;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) { al += G[r * 3 + P] * G[r * 3 + P]; be += G[r * 3 + Q] * G[r * 3 + Q]; ga += G[r * 3 + P] * G[r * 3 + Q]; }
+    if (ga == 0.0) return;
+    const double sab = sqrt(al * be);
+    if (fabs(ga) <= 1e-17 * sab) return;
+    if (!(fabs(ga) < 1e-15 * sab)) moved = true;               // the sweep still found a pair of columns that is not orthogonal to working precision
+    const double zeta = (be - al) / (2.0 * ga);
+    const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+    const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const double gp = G[r * 3 + P], gq = G[r * 3 + Q];
+        G[r * 3 + P] = c * gp - s * gq; G[r * 3 + Q] = s * gp + c * gq;
+        const double vp = V[r * 3 + P], vq = V[r * 3 + Q];
+        V[r * 3 + P] = c * vp - s * vq; V[r * 3 + Q] = s * vp + c * vq;
+    }
+}
+// column c (run-time index) of a 3 x 3 matrix held in registers
+__device__ __forceinline__ double col3(const double (&A)[9], int r3, int c) { return c == 0 ? A[r3] : (c == 1 ? A[r3 + 1] : A[r3 + 2]); }
+
+// Rotation of the Kabsch / Umeyama fit from the d x d cross-covariance H (d = 2 or 3; rows and columns >= d of H are ignored):
+// one-sided Jacobi SVD of H, the two leading singular pairs, the third by cross products (a proper rotation whatever the rank).
+__device__ __forceinline__ void kabsch_rotation(const double (&H)[9], int d, double (&R)[9])
 {
     double G[9], V[9];
-    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) {
-        G[r * 3 + c] = (r < d && c < d) ? H[r * 3 + c] : 0.0;
-        V[r * 3 + c] = (r == c) ? 1.0 : 0.0;
-    }
-    for (int sweep = 0; sweep < 30; ++sweep) {
-        double off = 0.0;
-        for (int p = 0; p < d - 1; ++p) for (int q = p + 1; q < d; ++q) {
-            double al = 0.0, be = 0.0, ga = 0.0;
-            for (int r = 0; r < d; ++r) { al += G[r * 3 + p] * G[r * 3 + p]; be += G[r * 3 + q] * G[r * 3 + q]; ga += G[r * 3 + p] * G[r * 3 + q]; }
-            if (ga == 0.0 || fabs(ga) <= 1e-17 * sqrt(al * be)) continue;
-            off = fmax(off, fabs(ga) / sqrt(al * be));
-            const double zeta = (be - al) / (2.0 * ga);
-            const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-            const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
-            for (int r = 0; r < d; ++r) {
-                const double gp = G[r * 3 + p], gq = G[r * 3 + q];
-                G[r * 3 + p] = c * gp - s * gq; G[r * 3 + q] = s * gp + c * gq;
-                const double vp = V[r * 3 + p], vq = V[r * 3 + q];
-                V[r * 3 + p] = c * vp - s * vq; V[r * 3 + q] = s * vp + c * vq;
-            }
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            G[r * 3 + c] = (r < d && c < d) ? H[r * 3 + c] : 0.0;
+            V[r * 3 + c] = (r == c) ? 1.0 : 0.0;
+            R[r * 3 + c] = 0.0;
         }
-        if (off < 1e-15) break;
+    for (int sweep = 0; sweep < 30; ++sweep) {                 // (d == 2: the pairs with column 2 find ga == 0 and return)
+        bool moved = false;
+        jacobi_pair<0, 1>(G, V, moved);
+        jacobi_pair<0, 2>(G, V, moved);
+        jacobi_pair<1, 2>(G, V, moved);
+        if (!moved) break;
     }
-    double sg[3] = {0, 0, 0};
-    for (int c = 0; c < d; ++c) { double s = 0.0; for (int r = 0; r < d; ++r) s += G[r * 3 + c] * G[r * 3 + c]; sg[c] = sqrt(s); }
-    int i1 = 0; for (int c = 1; c < d; ++c) if (sg[c] > sg[i1]) i1 = c;
-    int i2 = -1; for (int c = 0; c < d; ++c) if (c != i1 && (i2 < 0 || sg[c] > sg[i2])) i2 = c;
+    double sg[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { double s = 0.0;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) s += G[r * 3 + c] * G[r * 3 + c];
+        sg[c] = sqrt(s); }
+    int i1 = 0;
+#pragma unroll
+    for (int c = 1; c < 3; ++c) if (c < d && sg[c] > (i1 == 0 ? sg[0] : (i1 == 1 ? sg[1] : sg[2]))) i1 = c;
+    int i2 = -1;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) if (c < d && c != i1 && (i2 < 0 || sg[c] > (i2 == 0 ? sg[0] : (i2 == 1 ? sg[1] : sg[2])))) i2 = c;
+    const double s1 = i1 == 0 ? sg[0] : (i1 == 1 ? sg[1] : sg[2]), s2 = i2 == 0 ? sg[0] : (i2 == 1 ? sg[1] : sg[2]);
     double u1[3] = {0, 0, 0}, u2[3] = {0, 0, 0}, v1[3] = {0, 0, 0}, v2[3] = {0, 0, 0};
-    for (int r = 0; r < d; ++r) { v1[r] = V[r * 3 + i1]; v2[r] = V[r * 3 + i2]; }
-    if (sg[i1] > 0.0) { for (int r = 0; r < d; ++r) u1[r] = G[r * 3 + i1] / sg[i1]; }
-    else { u1[0] = 1.0; }                                               // H == 0: any rotation
+#pragma unroll
+    for (int r = 0; r < 3; ++r) if (r < d) { v1[r] = col3(V, r * 3, i1); v2[r] = col3(V, r * 3, i2); }
+    if (s1 > 0.0) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) if (r < d) u1[r] = col3(G, r * 3, i1) / s1;
+    } else { u1[0] = 1.0; }                                             // H == 0: any rotation
     if (d == 2) {
         // R = u1 v1' + perp(u1) perp(v1)'
         const double pu[2] = {-u1[1], u1[0]}, pv[2] = {-v1[1], v1[0]};
-        for (int r = 0; r < 2; ++r) for (int c = 0; c < 2; ++c) R[r * 3 + c] = u1[r] * v1[c] + pu[r] * pv[c];
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) R[r * 3 + c] = u1[r] * v1[c] + pu[r] * pv[c];
         return;
     }
-    if (sg[i2] > 1e-300 && sg[i2] > 1e-14 * sg[i1]) { for (int r = 0; r < 3; ++r) u2[r] = G[r * 3 + i2] / sg[i2]; }
-    else {                                                              // rank <= 1: complete u1 arbitrarily
-        int m = 0; for (int r = 1; r < 3; ++r) if (fabs(u1[r]) < fabs(u1[m])) m = r;
-        double e[3] = {0, 0, 0}; e[m] = 1.0;
-        const double dp = u1[m];
-        double nn = 0.0; for (int r = 0; r < 3; ++r) { u2[r] = e[r] - dp * u1[r]; nn += u2[r] * u2[r]; }
-        nn = sqrt(nn); for (int r = 0; r < 3; ++r) u2[r] /= nn;
+    if (s2 > 1e-300 && s2 > 1e-14 * s1) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) u2[r] = col3(G, r * 3, i2) / s2;
+    } else {                                                            // rank <= 1: complete u1 arbitrarily
+        int m = 0;
+        if (fabs(u1[1]) < fabs(u1[0])) m = 1;
+        if (fabs(u1[2]) < fabs(m == 0 ? u1[0] : u1[1])) m = 2;
+        const double dp = m == 0 ? u1[0] : (m == 1 ? u1[1] : u1[2]);
+        double nn = 0.0;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { u2[r] = (r == m ? 1.0 : 0.0) - dp * u1[r]; nn += u2[r] * u2[r]; }
+        nn = sqrt(nn);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) u2[r] /= nn;
     }
     const double u3[3] = {u1[1] * u2[2] - u1[2] * u2[1], u1[2] * u2[0] - u1[0] * u2[2], u1[0] * u2[1] - u1[1] * u2[0]};
     const double v3[3] = {v1[1] * v2[2] - v1[2] * v2[1], v1[2] * v2[0] - v1[0] * v2[2], v1[0] * v2[1] - v1[1] * v2[0]};
-    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) R[r * 3 + c] = u1[r] * v1[c] + u2[r] * v2[c] + u3[r] * v3[c];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) R[r * 3 + c] = u1[r] * v1[c] + u2[r] * v2[c] + u3[r] * v3[c];
 }
 
 // T (row-major (d+1)x(d+1) in the leading entries of 16 doubles) from centred sums.
-__device__ __noinline__ void write_pose(double* T, int d, const double* H, const double* m1, const double* m2)
+__device__ __forceinline__ void write_pose(double (&T)[16], int d, const double (&H)[9], const double (&m1)[3], const double (&m2)[3])
 {
     double R[9];
     kabsch_rotation(H, d, R);
+#pragma unroll
     for (int t = 0; t < 16; ++t) T[t] = 0.0;
-    const int s = d + 1;
-    for (int r = 0; r < d; ++r) {
-        double tr = m1[r];
-        for (int c = 0; c < d; ++c) { T[r * s + c] = R[r * 3 + c]; tr -= R[r * 3 + c] * m2[c]; }
-        T[r * s + d] = tr;
+    if (d == 3) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            double tr = m1[r];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { T[r * 4 + c] = R[r * 3 + c]; tr -= R[r * 3 + c] * m2[c]; }
+            T[r * 4 + 3] = tr;
+        }
+        T[15] = 1.0;
+    } else {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            double tr = m1[r];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) { T[r * 3 + c] = R[r * 3 + c]; tr -= R[r * 3 + c] * m2[c]; }
+            T[r * 3 + 2] = tr;
+        }
+        T[8] = 1.0;
     }
-    T[d * s + d] = 1.0;
+}
+
+// Centred cross-covariance of the nsel selected correspondences and the pose, by ONE wave (all 64 lanes active): nsel is tens to a
+// few hundred — lanes stride over them, the 6 + 9 sums are reduced with DPP (no workgroup barrier, no LDS round trip), lane 63's
+// totals are broadcast, and every lane forms the same pose in registers (the caller lets one of them store it).
+template <typename Fetch>
+__device__ __forceinline__ void wave_pose(double (&T)[16], int dim, int nsel, int lane, Fetch&& fetch /* (t, a[3], b[3]): the t-th pair of points */)
+{
+    constexpr int KEEP = 2;                                     // pairs a lane keeps in registers for the second sweep (128 of them: beyond, the points are fetched again)
+    double ka[KEEP][3], kq[KEEP][3];
+    double m1[3] = {0, 0, 0}, m2[3] = {0, 0, 0};
+#pragma unroll
+    for (int x = 0; x < KEEP; ++x) {
+        const int t = lane + 64 * x;
+        if (t < nsel) fetch(t, ka[x], kq[x]);
+        else {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { ka[x][c] = 0.0; kq[x][c] = 0.0; }
+        }
+    }
+#pragma unroll
+    for (int x = 0; x < KEEP; ++x)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { m1[c] += ka[x][c]; m2[c] += kq[x][c]; }
+    for (int t = lane + 64 * KEEP; t < nsel; t += 64) {
+        double a[3], q[3];
+        fetch(t, a, q);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { m1[c] += a[c]; m2[c] += q[c]; }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { m1[c] = readlane63(wave_sum63(m1[c])) / (double)nsel; m2[c] = readlane63(wave_sum63(m2[c])) / (double)nsel; }
+    double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    auto add = [&](double (&a)[3], double (&q)[3]) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { a[c] -= m1[c]; q[c] -= m2[c]; }
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) H[r * 3 + c] += a[r] * q[c];
+    };
+#pragma unroll
+    for (int x = 0; x < KEEP; ++x) if (lane + 64 * x < nsel) add(ka[x], kq[x]);
+    for (int t = lane + 64 * KEEP; t < nsel; t += 64) {
+        double a[3], q[3];
+        fetch(t, a, q);
+        add(a, q);
+    }
+#pragma unroll
+    for (int e = 0; e < 9; ++e) H[e] = readlane63(wave_sum63(H[e]));
+    write_pose(T, dim, H, m1, m2);
 }
 
 // Exact emulation of findIndicesOfkLargest (min-heap on (value,index); strict '<' replacement)
@@ -2788,11 +2976,16 @@ __device__ __noinline__ void finish_one(const DevParams& D, int b, const ProbDes
                                         double* red, int* sint)
 {
     const roman_params_t& P = D.p;
-    const int tid = threadIdx.x, nt = blockDim.x, nw = nt >> 6;
+    const int tid = threadIdx.x, nt = blockDim.x;
     const int dim = P.point_dim;
-    int par = 0;
     int nsel = 0;
     __syncthreads();
+#ifdef ROMAN_SMALL_TIMING
+    unsigned long long tf_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; tf_[0] = __builtin_readcyclecounter();
+#define FMARK(i_) tf_[i_] = __builtin_readcyclecounter()
+#else
+#define FMARK(i_) do { } while (0)
+#endif
     if (L > 0) {
         // final u to the row pool (stepwise API, tests)
         for (int p = tid; p < L; p += nt) O.uOut[rb + (outIdx ? (int)outIdx[lo + p] : p)] = u[p];
@@ -2805,37 +2998,39 @@ __device__ __noinline__ void finish_one(const DevParams& D, int b, const ProbDes
         if (tid == 0) { sint[0] = 0; sint[1] = 0; }
         __syncthreads();
         if (omega > 0) {
-            // compact the positive entries (order irrelevant: ranks below are order-free)
+            // compact the positive entries (order irrelevant: ranks below are order-free) as (value, association index)
             for (int p = tid; p < L; p += nt) {
                 const double up = u[p];
-                if (up > 0.0) { const int pos = atomicAdd(&sint[0], 1); pv[pos] = up; pidx[pos] = p; }
+                if (up > 0.0) { const int pos = atomicAdd(&sint[0], 1); pv[pos] = up; pidx[pos] = lp[lo + p]; }
             }
             __syncthreads();
+            FMARK(1);
             const int Pn = sint[0];
             bool fallback = (Pn < omega) || (omega > L);
             if (!fallback) {
-                // rank of e = number of entries greater in (value, association index) order
+                // rank of e = number of entries greater in (value, association index) order (the inner loop reads LDS only)
                 for (int e = tid; e < Pn; e += nt) {
-                    const double ve = pv[e]; const int ie = pidx[e]; const int ae = lp[lo + ie];
+                    const double ve = pv[e]; const int ae = pidx[e];
                     int rank = 0;
-                    for (int f2 = 0; f2 < Pn; ++f2) { const double vf = pv[f2]; rank += (vf > ve) || (vf == ve && lp[lo + pidx[f2]] > ae); }
-                    if (rank < omega) nodesLive[rank] = ie;
+                    for (int f0 = 0; f0 < Pn; f0 += 8) {            // eight LDS reads in flight (one per iteration: the loop ran at the LDS latency)
+                        double vf[8]; int af[8];
+#pragma unroll
+                        for (int x = 0; x < 8; ++x) { const int f2 = min(f0 + x, Pn - 1); vf[x] = pv[f2]; af[x] = pidx[f2]; }
+#pragma unroll
+                        for (int x = 0; x < 8; ++x) rank += (f0 + x < Pn && ((vf[x] > ve) || (vf[x] == ve && af[x] > ae))) ? 1 : 0;
+                    }
+                    if (rank < omega) nodesLive[rank] = ae;
                     if (rank == omega - 1) { red[64] = ve; }
                 }
                 __syncthreads();
+                FMARK(2);
+                // a tie at the cut: an entry as large as the omega-th one ranks behind it <=> more than omega entries are >= that value
                 const double vstar = red[64];
-                int tie = 0;
-                for (int e = tid; e < Pn; e += nt) {
-                    if (pv[e] == vstar) {
-                        const double ve = pv[e]; const int ae = lp[lo + pidx[e]];
-                        int rank = 0;
-                        for (int f2 = 0; f2 < Pn; ++f2) { const double vf = pv[f2]; rank += (vf > ve) || (vf == ve && lp[lo + pidx[f2]] > ae); }
-                        if (rank >= omega) tie = 1;
-                    }
-                }
-                if (tie) atomicOr(&sint[1], 1);
+                int ge = 0;
+                for (int e = tid; e < Pn; e += nt) ge += (pv[e] >= vstar) ? 1 : 0;
+                if (ge) atomicAdd(&sint[1], ge);
                 __syncthreads();
-                fallback = sint[1] != 0;
+                fallback = sint[1] > omega;
             }
             if (fallback) {
                 status |= ROMAN_ST_TIE_FALLBACK;
@@ -2849,12 +3044,13 @@ __device__ __noinline__ void finish_one(const DevParams& D, int b, const ProbDes
                 nsel = sint[0];
             } else {
                 nsel = omega;
-                for (int t = tid; t < nsel; t += nt) nodesOrig[t] = lp[lo + nodesLive[t]];
+                for (int t = tid; t < nsel; t += nt) nodesOrig[t] = nodesLive[t];
             }
             __syncthreads();
         }
     }
 
+    FMARK(3);
     // ---- outputs: associations, pose, stats ------------------------------------------------------
     const int32_t* nodesOrigR = O.nodesOrig + rb;
     const int kout = min(nsel, O.kmax);
@@ -2865,32 +3061,22 @@ __device__ __noinline__ void finish_one(const DevParams& D, int b, const ProbDes
         O.assoc_out[((int64_t)b * O.kmax + t) * 2 + 0] = i;
         O.assoc_out[((int64_t)b * O.kmax + t) * 2 + 1] = j;
     }
+    FMARK(4);
     // pose from ALL selected associations ([REF object_registration.py:110-128], unit weights)
     double Tp[16];
     bool have_pose = false;
     if (nsel >= dim && feats != nullptr && !(status & ROMAN_ST_EMPTY_MAP)) {
-        double m1[3] = {0, 0, 0}, m2[3] = {0, 0, 0};
-        for (int t = tid; t < nsel; t += nt) {
-            int i, j;
-            decode_assoc(pd, assoc, nodesOrigR[t], i, j);
-            const double* a = feats + (pd.off1 + i) * D.F; const double* bb = feats + (pd.off2 + j) * D.F;
-            for (int c = 0; c < dim; ++c) { m1[c] += a[c]; m2[c] += bb[c]; }
+        if (tid < 64) {                                         // (wave 0: wave_pose)
+            wave_pose(Tp, dim, nsel, tid, [&](int t, double (&a)[3], double (&q)[3]) {
+                int i, j;
+                decode_assoc(pd, assoc, nodesOrigR[t], i, j);
+                const double* pa = feats + (pd.off1 + i) * D.F; const double* pb = feats + (pd.off2 + j) * D.F;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { a[c] = c < dim ? pa[c] : 0.0; q[c] = c < dim ? pb[c] : 0.0; }
+            });
         }
-        block_sum2(m1[0], m1[1], red, par, tid, nw); block_sum2(m1[2], m2[0], red, par, tid, nw); block_sum2(m2[1], m2[2], red, par, tid, nw);
-        for (int c = 0; c < 3; ++c) { m1[c] /= (double)nsel; m2[c] /= (double)nsel; }
-        double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-        for (int t = tid; t < nsel; t += nt) {
-            int i, j;
-            decode_assoc(pd, assoc, nodesOrigR[t], i, j);
-            const double* a = feats + (pd.off1 + i) * D.F; const double* bb = feats + (pd.off2 + j) * D.F;
-            double q1[3] = {0, 0, 0}, q2[3] = {0, 0, 0};
-            for (int c = 0; c < dim; ++c) { q1[c] = a[c] - m1[c]; q2[c] = bb[c] - m2[c]; }
-            for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) H[r * 3 + c] += q1[r] * q2[c];
-        }
-        double z = 0.0;
-        block_sum2(H[0], H[1], red, par, tid, nw); block_sum2(H[2], H[3], red, par, tid, nw); block_sum2(H[4], H[5], red, par, tid, nw);
-        block_sum2(H[6], H[7], red, par, tid, nw); block_sum2(H[8], z, red, par, tid, nw);
-        if (tid == 0) write_pose(Tp, dim, H, m1, m2);
+        FMARK(5);
+        FMARK(6);
         have_pose = true;
     } else {
         status |= ROMAN_ST_INSUFFICIENT;
@@ -2903,6 +3089,12 @@ __device__ __noinline__ void finish_one(const DevParams& D, int b, const ProbDes
         if (O.stats_out) O.stats_out[b] = S;
     }
     __syncthreads();
+#ifdef ROMAN_SMALL_TIMING
+    FMARK(7);
+    if (tid == 0 && ((b & 255) == 0 || b < 2)) printf("[finish_one nt=%d] b=%d L=%d nsel=%d cycles: compact %llu ranks %llu ties %llu outputs %llu sums %llu rotation %llu write %llu\n", nt, b, L, nsel,
+                                                       tf_[1] - tf_[0], tf_[2] - tf_[1], tf_[3] - tf_[2], tf_[4] - tf_[3], tf_[5] - tf_[4], tf_[6] - tf_[5], tf_[7] - tf_[6]);
+#endif
+#undef FMARK
 }
 
 
@@ -3810,8 +4002,14 @@ __device__ void solve_up(const DevParams& D, int b, const ProbDesc& pd, ProbStat
     // final u (unscaled) to LDS for the shared tail; scratch: the two accumulator arrays
     __syncthreads();
     FOR_K(k, p) if (p < L) xg[p] = u[k];
+#ifdef ROMAN_SMALL_TIMING
+    const unsigned long long tt0_ = __builtin_readcyclecounter();
+#endif
     finish_one(D, b, pd, feats, assoc, plp, lpAsc, rowPosPool, nullptr, O, xg, reinterpret_cast<double*>(accM),
                reinterpret_cast<int32_t*>(accC), reinterpret_cast<int32_t*>(accC) + Lc, L, rb, lo, F, status, S, red, sint);
+#ifdef ROMAN_SMALL_TIMING
+    if (tid == 0 && ((b & 255) == 0 || b < 2)) printf("[solve_up<%d>] b=%d L=%d passes %d tail (selection, pose, outputs) %llu cycles\n", NW, b, L, n_pass, __builtin_readcyclecounter() - tt0_);
+#endif
 #undef FOR_K
 #undef FOR_K_ALL
 #undef CUMQ
@@ -3963,6 +4161,12 @@ __global__ void __launch_bounds__(64, 3) k_small(DevParams D, int B, const ProbD
             const double* TA = tabPool + pd.tabOff;
             const double* TB = TA + (int64_t)pd.n1 * pd.n1;
             __syncthreads();                                    // the previous problem is done with the LDS
+#ifdef ROMAN_SMALL_TIMING
+            unsigned long long ts_[8]; ts_[0] = __builtin_readcyclecounter();
+#define SMARK(i_) ts_[i_] = __builtin_readcyclecounter()
+#else
+#define SMARK(i_) do { } while (0)
+#endif
             // ---- rows ------------------------------------------------------------------------------------
             int ri[2], rj[2], rlp[2]; double rd[2], rza[2], rzb[2]; bool rv[2];
 #pragma unroll
@@ -3975,6 +4179,7 @@ __global__ void __launch_bounds__(64, 3) k_small(DevParams D, int B, const ProbD
                 if (rv[r]) { cIJ[k] = (uint32_t)ri[r] | ((uint32_t)rj[r] << 16); cZ[k] = make_double2(rza[r], rzb[r]); cS[k] = ls[lo + kk]; }
             }
             __syncthreads();
+            SMARK(1);
             // ---- pair tests: row k against every live column ---------------------------------------------------
             unsigned long long m[2][2] = {{0ull, 0ull}, {0ull, 0ull}};
             const double* rowA[2] = {TA + (int64_t)ri[0] * pd.n1, TA + (int64_t)ri[1] * pd.n1};
@@ -4000,6 +4205,7 @@ __global__ void __launch_bounds__(64, 3) k_small(DevParams D, int B, const ProbD
             }
 #pragma unroll
             for (int r = 0; r < 2; ++r) if (!rv[r]) { m[r][0] = 0ull; m[r][1] = 0ull; }
+            SMARK(2);
             // ---- positions: rank by (degree descending, row ascending) -----------------------------------------
             int dg[2], pos[2];
 #pragma unroll
@@ -4014,6 +4220,7 @@ __global__ void __launch_bounds__(64, 3) k_small(DevParams D, int B, const ProbD
                 if (rv[r]) { posS[k] = (uint16_t)rank; rowPos[lo + k] = (uint32_t)rank; plp[lo + rank] = rlp[r]; pld[lo + rank] = rd[r]; }
             }
             __syncthreads();
+            SMARK(3);
             // ---- the candidates a row KEEPS: those whose position is larger than its own ---------------------------
             uint32_t cnt[2] = {0u, 0u};
 #pragma unroll
@@ -4045,6 +4252,7 @@ __global__ void __launch_bounds__(64, 3) k_small(DevParams D, int B, const ProbD
                     }
                 }
             __syncthreads();
+            SMARK(4);
             // ---- values of the kept candidates, 64 at a time; entries above affinityeps form the coordinate list -------------
             uint32_t nk = 0;
             for (uint32_t c0 = 0; c0 < cand; c0 += 64u) {
@@ -4070,9 +4278,16 @@ __global__ void __launch_bounds__(64, 3) k_small(DevParams D, int B, const ProbD
             if (nk > (uint32_t)COO_CAP) continue;                // more stored pairs than the registers hold: the general path
             if (lane == 0) st[b].nnzUpper = (unsigned long long)nk;
             __syncthreads();                                    // the pair list is spent: its LDS becomes the solver's vectors
+            SMARK(5);
             solve_up<1, false, SMALL_MAXL, ST_D, false, true>(D, b, pd, st, feats, assoc, plp, lp, rowPos, pld, nullptr, nullptr, nullptr, u0, O,
                                            xg, accM, accC, Lc1, cumQ, red, sint, cooLds, (int)nk, (int)lo);
             if (lane == 0) st[b].kind = 3;                      // done: the general kernels pass it by
+#ifdef ROMAN_SMALL_TIMING
+            SMARK(6);
+            if (lane == 0 && ((b & 255) == 0 || B <= 4)) printf("[k_small] b=%d L=%d cand=%u nnz=%u cycles: rows %llu tests %llu ranks %llu keep %llu values %llu solve+tail %llu\n", b, L, cand, nk,
+                                                                ts_[1] - ts_[0], ts_[2] - ts_[1], ts_[3] - ts_[2], ts_[4] - ts_[3], ts_[5] - ts_[4], ts_[6] - ts_[5]);
+#endif
+#undef SMARK
         }
     }
 }
@@ -4872,19 +5087,18 @@ __global__ void __launch_bounds__(64) k_pose(int dim, const double* __restrict__
         if (lane == 0) { for (int t = 0; t < 16; ++t) T_out[(int64_t)b * 16 + t] = d_nan(); status_out[b] = ROMAN_ST_INSUFFICIENT; }
         return;
     }
-    double m1[3] = {0, 0, 0}, m2[3] = {0, 0, 0};
-    for (int t = lane; t < k; t += WAVE) for (int c = 0; c < dim; ++c) { m1[c] += pts1[(o + t) * dim + c]; m2[c] += pts2[(o + t) * dim + c]; }
-    for (int c = 0; c < 3; ++c) for (int off = 32; off > 0; off >>= 1) { m1[c] += __shfl_xor(m1[c], off); m2[c] += __shfl_xor(m2[c], off); }
-    for (int c = 0; c < 3; ++c) { m1[c] /= (double)k; m2[c] /= (double)k; }
-    double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (int t = lane; t < k; t += WAVE) {
-        double q1[3] = {0, 0, 0}, q2[3] = {0, 0, 0};
-        for (int c = 0; c < dim; ++c) { q1[c] = pts1[(o + t) * dim + c] - m1[c]; q2[c] = pts2[(o + t) * dim + c] - m2[c]; }
-        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) H[r * 3 + c] += q1[r] * q2[c];
+    double T[16];
+    wave_pose(T, dim, k, lane, [&](int t, double (&a)[3], double (&q)[3]) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { a[c] = c < dim ? pts1[(o + t) * dim + c] : 0.0; q[c] = c < dim ? pts2[(o + t) * dim + c] : 0.0; }
+    });
+    if (lane == 0) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) T_out[(int64_t)b * 16 + t] = T[t];
+        status_out[b] = ROMAN_ST_OK;
     }
-    for (int e = 0; e < 9; ++e) for (int off = 32; off > 0; off >>= 1) H[e] += __shfl_xor(H[e], off);
-    if (lane == 0) { double T[16]; write_pose(T, dim, H, m1, m2); for (int t = 0; t < 16; ++t) T_out[(int64_t)b * 16 + t] = T[t]; status_out[b] = ROMAN_ST_OK; }
 }
+
 
 // elementwise math probe for tests
 __global__ void k_debug_math(int kind, const double* __restrict__ a, const double* __restrict__ b,

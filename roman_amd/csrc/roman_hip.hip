@@ -380,8 +380,12 @@ static hipError_t launch_cos(roman_ctx* c, hipStream_t stream, const DevParams& 
         }
     }
     if (mode != 0 && maxN1 <= 16 * COSW_NB && maxN2 <= 16 * COSW_NB && !(waveEnv && waveEnv[0] == '0')) {
-        // the reference's demo scale: one wave per problem, no LDS, no barrier (k_cos_wave)
-        hipLaunchKernelGGL(k_cos_wave, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, stream, D, B, dP, feats, cosPool);
+        // the reference's demo scale: one wave per problem, no LDS, no barrier (k_cos_wave); a few problems (a serial caller's one
+        // pair per call): one wave per 16 x 16 block (k_cos_block).  ROMAN_COS_BLOCK=0 never, =1 always (A/B, tests; read per call)
+        const char* blockEnv = getenv("ROMAN_COS_BLOCK");
+        const bool perBlock = (blockEnv && blockEnv[0]) ? blockEnv[0] == '1' : B * COSW_NB * COSW_NB <= 4 * c->num_cu;
+        if (perBlock) hipLaunchKernelGGL(k_cos_block, dim3((unsigned)((B * COSW_NB * COSW_NB + 3) / 4)), dim3(256), 0, stream, D, B, dP, feats, cosPool);
+        else hipLaunchKernelGGL(k_cos_wave, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, stream, D, B, dP, feats, cosPool);
         return hipGetLastError();
     }
     if (mode == 0) {

@@ -183,6 +183,23 @@ def test_cosine_bits_equal_the_oracles_stated_order(ctx, orc, n1, n2, d):
     assert np.array_equal(got, ref)
 
 
+@pytest.mark.parametrize("n1,n2,d", [(40, 40, 768), (48, 48, 100), (33, 47, 70), (17, 48, 16), (32, 16, 37), (48, 1, 15), (1, 48, 160), (20, 37, 7), (16, 16, 128), (9, 7, 768)])
+def test_demo_scale_cosine_kernels_give_the_oracles_bits(ctx, orc, monkeypatch, n1, n2, d):
+    """Maps of at most 48 objects: one wave per problem (k_cos_wave, what a batch takes) and one wave per 16 x 16 block (k_cos_block,
+    what a serial caller's single pair takes: ROMAN_COS_BLOCK forces either) — 1 to 3 blocks per dimension, descriptor lengths
+    below one chunk of 16, below and above the eight chunks of k_cos_block's load ring, ragged tails: both BIT-identical to the
+    oracle's stated order."""
+    rng = np.random.default_rng(n1 * 977 + n2 * 13 + d)
+    P = _abi.RomanParams.default(); P.cos_feature_dim = d
+    D1 = rng.standard_normal((n1, 3 + d)); D2 = rng.standard_normal((n2, 3 + d))
+    if n1 > 2:
+        D1[2, 3:] = 0.0                                  # a zero descriptor: cosine 0 by the reference's guard
+    ref = np.array([[orc.cosine(D1[i, 3:], D2[j, 3:]) for j in range(n2)] for i in range(n1)])
+    for setting in ("0", "1"):
+        monkeypatch.setenv("ROMAN_COS_BLOCK", setting)
+        assert np.array_equal(ctx.debug_cosine(P, D1, D2), ref), f"ROMAN_COS_BLOCK={setting}"
+
+
 @pytest.mark.parametrize("n1,n2,d", [(200, 200, 512), (200, 200, 48), (200, 200, 7), (113, 97, 31), (300, 130, 33), (130, 300, 16), (224, 225, 17),
                                      (1, 1, 16), (16, 112, 64), (49, 49, 15), (64, 64, 512), (5, 3, 1), (111, 113, 80), (80, 96, 24), (81, 79, 40)])
 def test_dealt_cosine_kernel_gives_the_oracles_bits(ctx, orc, monkeypatch, n1, n2, d):

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-5 GPU sessions, one per letter:  bash tools/r5_sessions.sh <a..n>   (repo root on an MI355X box; everything under gpurun_out/).
+# Round-5 GPU sessions, one per letter:  bash tools/r5_sessions.sh <a..q>   (repo root on an MI355X box; everything under gpurun_out/).
 # The A/B sessions compare library builds kept under roman_amd/csrc/variants/ (git-ignored; rebuilt from the commits named in
 # DESIGN.md 4.2 / profiles/r05/README.md): they are the record of what was measured, not something a fresh checkout can re-run as is.
 S=$1
@@ -231,6 +231,43 @@ for ST in 0 1; do
   ROMAN_SOLVE_STRIDED=$ST ROMAN_HIP_LIBRARY=$REPO/roman_amd/csrc/variants/libT.so timeout 600 python bench.py --steps 2 --warmup 1 --pipeline 1 --no-extras --no-grid --cpu-sample 0 --check-pairs 0 --latency-reps 2 > $OUT/r5n_benchT_$ST.txt 2> $OUT/r5n_timing_$ST.txt
   echo "== phases strided=$ST"; grep -A5 "solve timing" $OUT/r5n_timing_$ST.txt | grep -v "^--" | sed -n '1,6p;$p'
 done
+;;
+o)
+# round-5 session O/P: one demo-size pair per call (the serial caller at the reference's own scale).  Parts of the call's time
+# (tools/gpu_demo_latency.py) with one wave per cosine block (k_cos_block, default for a few problems) and with one wave per
+# problem (ROMAN_COS_BLOCK=0); phase cycles of k_small (variants/libST.so) for single pairs and inside the 4096-pair batch
+export TMPDIR=/tmp; OUT=$PWD/gpurun_out; mkdir -p $OUT; REPO=$PWD
+timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_full_configs.py -q -m gpu -k "cosine or demo_scale" > $OUT/r5p_pytest.txt 2>&1; echo "pytest rc=$?"; tail -4 $OUT/r5p_pytest.txt
+for CB in 0 1 0 1; do
+  echo "== ROMAN_COS_BLOCK=$CB"; ROMAN_COS_BLOCK=$CB python tools/gpu_demo_latency.py 24 2>&1 | tee -a $OUT/r5p_demo_latency_$CB.txt
+done
+echo "== k_small phases, single pairs"
+ROMAN_HIP_LIBRARY=$REPO/roman_amd/csrc/variants/libST.so python tools/gpu_demo_latency.py 4 2>&1 | grep "k_small" | sort | uniq -c | sort -rn | head -12
+echo "== k_small phases, 4096 pairs per call"
+ROMAN_HIP_LIBRARY=$REPO/roman_amd/csrc/variants/libST.so python tools/gpu_demo_scale.py 2>&1 | grep "k_small" | tail -16
+;;
+q)
+# round-5 session Q: the solvers' shared tail (selection of the omega largest, cross-covariance, rotation) rebuilt — ranks from LDS
+# only, the sums by one wave with DPP, the Jacobi rotation in registers: whole GPU suite, the tail's phase cycles (variants/libST.so),
+# bench line, demo-scale latency and rate
+export TMPDIR=/tmp; OUT=$PWD/gpurun_out; mkdir -p $OUT; REPO=$PWD
+timeout 1500 python -m pytest tests -q -m gpu -x --durations=5 > $OUT/r5q_pytest.txt 2>&1; echo "pytest rc=$?"; tail -12 $OUT/r5q_pytest.txt
+( export ROMAN_HIP_LIBRARY=$REPO/roman_amd/csrc/variants/libST.so
+  python tools/gpu_demo_latency.py 4 2>&1 | grep "finish_one\|k_small" | sort | uniq -c | sort -rn | head -4
+  python tools/gpu_demo_scale.py 2>&1 | grep "finish_one\|k_small" | tail -6
+  python bench.py --steps 2 --warmup 1 --pipeline 1 --no-extras --no-grid --cpu-sample 0 --check-pairs 0 --latency-reps 2 2>&1 | grep "finish_one" | tail -4 )
+timeout 900 python bench.py --steps 40 --warmup 5 --no-extras --no-grid --cpu-sample 0 --check-pairs 256 --latency-reps 20 > $OUT/r5q_bench.txt 2>$OUT/r5q_bench.err
+python tools/bench_digest.py $OUT/r5q_bench.txt | head -4
+( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ab_tmp -o b -- python $REPO/bench.py --steps 5 --warmup 2 --pipeline 1 --latency-reps -1 --cpu-sample 0 --no-extras --no-grid --check-pairs 0 > /dev/null 2>&1 )
+F=$(find $OUT/ab_tmp -name "*kernel_stats.csv" | head -1)
+python - "$F" <<'PY'
+import csv, sys
+for r in csv.DictReader(open(sys.argv[1])):
+    if 'k_solve_up<8' in r['Name']: print(r['Name'][:44], round(float(r['AverageNs']) / 1e3, 1), 'us')
+PY
+rm -rf $OUT/ab_tmp
+python tools/gpu_demo_latency.py 24 2>&1 | tee $OUT/r5q_demo_latency.txt
+python tools/gpu_demo_scale.py 2>&1 | tail -12 | tee $OUT/r5q_demo_scale.txt
 ;;
 m)
 # round-5 session M (final tree): the whole GPU suite, smoke, the driver's bench command, rocprofv3 kernel stats + the four PMC groups, solver phase cycles
