@@ -3526,6 +3526,9 @@ __device__ void solve_up(const DevParams& D, int b, const ProbDesc& pd, ProbStat
                          int rbPre = -1 /* >= 0: offset of the problem in the row pools (k_small runs before k_rowbase) */)
 {
     constexpr int NT = NW * 64;
+#ifdef ROMAN_SOLVE_TIMING
+    const unsigned long long tentry_ = __builtin_readcyclecounter();
+#endif
     constexpr int KMAX = (MAXL + NT - 1) / NT;                 // elements per thread (the kernel takes problems of up to MAXL live associations)
     // The three LDS vectors lie at a FIXED distance from each other — accM == xg + LCAP, accC == xg + 2 LCAP (the callers lay them
     // out so; Lc == LCAP) —: the stream addresses the accumulators of a column through the column's gather address + an immediate
@@ -3994,10 +3997,6 @@ __device__ void solve_up(const DevParams& D, int b, const ProbDesc& pd, ProbStat
     S.outer_iters = i; S.score = F; S.d_final = d;
 #ifdef ROMAN_SOLVE_TIMING
     TMARK(3);
-    if (tid == 0 && O.dbg) {
-        unsigned long long* dg = O.dbg + (size_t)b * 16;
-        for (int t = 0; t < 8; ++t) { dg[t] = tacc[t]; dg[8 + t] = tcnt[t]; }
-    }
 #endif
     // final u (unscaled) to LDS for the shared tail; scratch: the two accumulator arrays
     __syncthreads();
@@ -4007,6 +4006,14 @@ __device__ void solve_up(const DevParams& D, int b, const ProbDesc& pd, ProbStat
 #endif
     finish_one(D, b, pd, feats, assoc, plp, lpAsc, rowPosPool, nullptr, O, xg, reinterpret_cast<double*>(accM),
                reinterpret_cast<int32_t*>(accC), reinterpret_cast<int32_t*>(accC) + Lc, L, rb, lo, F, status, S, red, sint);
+#ifdef ROMAN_SOLVE_TIMING
+    if (tid == 0 && O.dbg) {                                    // slot 5: everything outside the phases (set-up in front of the first pass, the tail: selection, pose, outputs)
+        unsigned long long sum_ = 0; for (int t = 0; t < 8; ++t) sum_ += tacc[t];
+        tacc[5] = __builtin_readcyclecounter() - tentry_ - sum_; tcnt[5] = 1;
+        unsigned long long* dg = O.dbg + (size_t)b * 16;
+        for (int t = 0; t < 8; ++t) { dg[t] = tacc[t]; dg[8 + t] = tcnt[t]; }
+    }
+#endif
 #ifdef ROMAN_SMALL_TIMING
     if (tid == 0 && ((b & 255) == 0 || b < 2)) printf("[solve_up<%d>] b=%d L=%d passes %d tail (selection, pose, outputs) %llu cycles\n", NW, b, L, n_pass, __builtin_readcyclecounter() - tt0_);
 #endif
@@ -4188,17 +4195,26 @@ __global__ void __launch_bounds__(64, 3) k_small(DevParams D, int B, const ProbD
 #pragma unroll
             for (int wd = 0; wd < 2; ++wd) {
                 const int q1 = min(L, (wd + 1) * 64);
-                for (int q = wd * 64; q < q1; ++q) {
-                    const uint32_t pk = cIJ[q];
-                    const int iq = (int)(pk & 0xffffu), jq = (int)(pk >> 16);
-                    const double2 zz = cZ[q];
+                for (int q0 = wd * 64; q0 < q1; q0 += 4) {       // four columns at a time: their table gathers (global memory) in flight together
+                    uint32_t pk[4]; double2 zz[4]; double a[2][4], bb[2][4];
 #pragma unroll
-                    for (int r = 0; r < 2; ++r) {
-                        if (r < nr) {
-                            const double a = rowA[r][iq], bb = rowB[r][jq];
-                            const double dz = gm ? fabs((rza[r] - zz.x) - (rzb[r] - zz.y)) : 0.0;
-                            const bool is = pair_gate_rt(D, gm, a, bb, dz);
-                            m[r][wd] |= (unsigned long long)(is ? 1u : 0u) << (q & 63);
+                    for (int x = 0; x < 4; ++x) { const int q = min(q0 + x, q1 - 1); pk[x] = cIJ[q]; zz[x] = cZ[q]; }
+#pragma unroll
+                    for (int x = 0; x < 4; ++x)
+#pragma unroll
+                        for (int r = 0; r < 2; ++r)
+                            if (r < nr) { a[r][x] = rowA[r][pk[x] & 0xffffu]; bb[r][x] = rowB[r][pk[x] >> 16]; }
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) {
+                        if (q0 + x < q1) {
+#pragma unroll
+                            for (int r = 0; r < 2; ++r) {
+                                if (r < nr) {
+                                    const double dz = gm ? fabs((rza[r] - zz[x].x) - (rzb[r] - zz[x].y)) : 0.0;
+                                    const bool is = pair_gate_rt(D, gm, a[r][x], bb[r][x], dz);
+                                    m[r][wd] |= (unsigned long long)(is ? 1u : 0u) << ((q0 + x) & 63);
+                                }
+                            }
                         }
                     }
                 }

@@ -380,10 +380,12 @@ static hipError_t launch_cos(roman_ctx* c, hipStream_t stream, const DevParams& 
         }
     }
     if (mode != 0 && maxN1 <= 16 * COSW_NB && maxN2 <= 16 * COSW_NB && !(waveEnv && waveEnv[0] == '0')) {
-        // the reference's demo scale: one wave per problem, no LDS, no barrier (k_cos_wave); a few problems (a serial caller's one
-        // pair per call): one wave per 16 x 16 block (k_cos_block).  ROMAN_COS_BLOCK=0 never, =1 always (A/B, tests; read per call)
+        // the reference's demo scale: one wave per problem, no LDS, no barrier (k_cos_wave); up to two problems per compute unit (a
+        // serial caller's one pair per call, a small batch): one wave per 16 x 16 block (k_cos_block: 31 against 80 us for one pair,
+        // 75 against 127 for 256, 114 against 135 for 512, 196 against 152 for 1024 — tools/gpu_cos_block_sweep.py).
+        // ROMAN_COS_BLOCK=0 never, =1 always (A/B, tests; read per call)
         const char* blockEnv = getenv("ROMAN_COS_BLOCK");
-        const bool perBlock = (blockEnv && blockEnv[0]) ? blockEnv[0] == '1' : B * COSW_NB * COSW_NB <= 4 * c->num_cu;
+        const bool perBlock = (blockEnv && blockEnv[0]) ? blockEnv[0] == '1' : B <= 2 * c->num_cu;
         if (perBlock) hipLaunchKernelGGL(k_cos_block, dim3((unsigned)((B * COSW_NB * COSW_NB + 3) / 4)), dim3(256), 0, stream, D, B, dP, feats, cosPool);
         else hipLaunchKernelGGL(k_cos_wave, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, stream, D, B, dP, feats, cosPool);
         return hipGetLastError();
@@ -935,7 +937,7 @@ int enqueue_solve(roman_ctx* c, const DevParams& D, int B, int64_t sumA, int64_t
         for (int b = 0; b < B; ++b) for (int t = 0; t < 16; ++t) acc[t] += (double)h[(size_t)b * 16 + t];
         // (k_solve_up: cycles of the phases named here; k_solve_wide: 10 ns ticks of trial+publish, barrier 1, stream, barrier 2,
         //  collect+objective, barrier 3, everything else — in slots 0..6)
-        const char* nm[8] = {"stream", "spmv-barrier", "decode", "elementwise", "stream-narrow", "-", "publish", "red-sums"};
+        const char* nm[8] = {"stream", "spmv-barrier", "decode", "elementwise", "stream-narrow", "setup+tail", "publish", "red-sums"};
         fprintf(stderr, "[solve timing] B=%d cycles/problem:", B);
         double tot_ = 0; for (int t = 0; t < 8; ++t) tot_ += acc[t] / B;
         for (int t = 0; t < 8; ++t) fprintf(stderr, " %s %.0f (n=%.1f)", nm[t], acc[t] / B, acc[8 + t] / B);

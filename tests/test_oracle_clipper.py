@@ -294,3 +294,32 @@ def test_selection_does_not_depend_on_how_the_passes_are_organised(orc):
             d_updates = sa.outer_iters + (0 if sa.outer_iters >= P.maxoliters else 1)
             assert sb.n_pass == sa.n_pass + d_updates
     assert same_traj >= len(cases) - 4
+
+
+def test_support_dump_hook_records_the_sets_the_trace_counts(orc):
+    """oracle_set_support_dump (the analysis hook tools/wide_compaction_sim.py replays compaction policies on): one bit row per pass,
+    bit p = the vector fed to that pass is positive at p; the rows' populations are support_trace, the last rows contain the
+    selected associations, and switching the hook off leaves later solves untouched."""
+    import ctypes as C
+    reg = registration_for("gravity")
+    P = reg._abi_params()
+    pr = synth.make_pair(14, 12, 0, 4242, tilt_deg=1.0)
+    D1, D2 = packed(reg, pr)
+    mat, _ = orc.build_matrix(P, D1, D2)
+    n, W, cap = mat.n, (mat.n + 63) // 64, 512
+    buf = np.zeros((cap, W), dtype=np.uint64)
+    L = orc.lib()
+    L.oracle_set_support_dump.argtypes = [C.c_void_p, C.c_int64, C.c_int32]
+    L.oracle_set_support_dump(buf.ctypes.data, W, cap)
+    try:
+        out = orc.solve(P, mat, trace=True)
+    finally:
+        L.oracle_set_support_dump(None, 0, 0)
+    npass = int(out["stats"].n_pass)
+    assert 2 <= npass <= cap
+    bits = np.unpackbits(buf[:npass].view(np.uint8), axis=1, bitorder="little")[:, :n]
+    assert np.array_equal(bits.sum(1), out["support_trace"])
+    assert not buf[npass:].any()
+    assert bits[-1][out["nodes"]].all()                             # what is selected was positive in the last vector multiplied
+    again = orc.solve(P, mat, trace=True)                           # hook off: nothing written, same result
+    assert not buf[npass:].any() and np.array_equal(again["nodes"], out["nodes"])

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-5 GPU sessions, one per letter:  bash tools/r5_sessions.sh <a..q>   (repo root on an MI355X box; everything under gpurun_out/).
+# Round-5 GPU sessions, one per letter:  bash tools/r5_sessions.sh <a..r>   (repo root on an MI355X box; everything under gpurun_out/).
 # The A/B sessions compare library builds kept under roman_amd/csrc/variants/ (git-ignored; rebuilt from the commits named in
 # DESIGN.md 4.2 / profiles/r05/README.md): they are the record of what was measured, not something a fresh checkout can re-run as is.
 S=$1
@@ -268,6 +268,26 @@ PY
 rm -rf $OUT/ab_tmp
 python tools/gpu_demo_latency.py 24 2>&1 | tee $OUT/r5q_demo_latency.txt
 python tools/gpu_demo_scale.py 2>&1 | tail -12 | tee $OUT/r5q_demo_scale.txt
+;;
+r)
+# round-5 session R: the tree with the rebuilt tail against the tree before it (variants/libR5m.so = commit 62e4741) on ONE box,
+# alternating: bench line (40 steps) and the isolated launch of k_solve_up; phase cycles incl. set-up + tail (variants/libT.so);
+# k_cos_block against k_cos_wave by batch size
+export TMPDIR=/tmp; OUT=$PWD/gpurun_out; mkdir -p $OUT; REPO=$PWD
+for L in R5m new R5m new; do
+  if [ "$L" = "new" ]; then unset ROMAN_HIP_LIBRARY; else export ROMAN_HIP_LIBRARY=$REPO/roman_amd/csrc/variants/lib$L.so; fi
+  timeout 600 python bench.py --steps 40 --warmup 5 --no-extras --no-grid --cpu-sample 0 --check-pairs 0 --latency-reps 20 > $OUT/r5r_bench_$L.txt 2>$OUT/r5r_bench_$L.err
+  echo "== $L"; python tools/bench_digest.py $OUT/r5r_bench_$L.txt | head -1
+  python - $OUT/r5r_bench_$L.txt <<'PY'
+import json, sys
+d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+print("   isolated launch", d["roofline"]["isolated"]["avg_launch_ms"], "ms, roofline frac isolated", round(d["roofline"]["isolated"]["frac"], 3), "| B=1 stages", d["latency_breakdown"]["stage_ms"])
+PY
+done
+unset ROMAN_HIP_LIBRARY
+ROMAN_HIP_LIBRARY=$REPO/roman_amd/csrc/variants/libT.so timeout 600 python bench.py --steps 2 --warmup 1 --pipeline 1 --no-extras --no-grid --cpu-sample 0 --check-pairs 0 --latency-reps 2 > $OUT/r5r_benchT.txt 2> $OUT/r5r_timing.txt
+grep -A5 "solve timing" $OUT/r5r_timing.txt | grep -v "^--" | sed -n '1,6p;$p'
+python tools/gpu_cos_block_sweep.py 2>&1 | tee $OUT/r5r_cos_block_sweep.txt
 ;;
 m)
 # round-5 session M (final tree): the whole GPU suite, smoke, the driver's bench command, rocprofv3 kernel stats + the four PMC groups, solver phase cycles
