@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-5 GPU sessions, one per letter:  bash tools/r5_sessions.sh <a..r>   (repo root on an MI355X box; everything under gpurun_out/).
+# Round-5 GPU sessions, one per letter:  bash tools/r5_sessions.sh <a..r, z>   (repo root on an MI355X box; everything under gpurun_out/).
 # The A/B sessions compare library builds kept under roman_amd/csrc/variants/ (git-ignored; rebuilt from the commits named in
 # DESIGN.md 4.2 / profiles/r05/README.md): they are the record of what was measured, not something a fresh checkout can re-run as is.
 S=$1
@@ -288,6 +288,16 @@ unset ROMAN_HIP_LIBRARY
 ROMAN_HIP_LIBRARY=$REPO/roman_amd/csrc/variants/libT.so timeout 600 python bench.py --steps 2 --warmup 1 --pipeline 1 --no-extras --no-grid --cpu-sample 0 --check-pairs 0 --latency-reps 2 > $OUT/r5r_benchT.txt 2> $OUT/r5r_timing.txt
 grep -A5 "solve timing" $OUT/r5r_timing.txt | grep -v "^--" | sed -n '1,6p;$p'
 python tools/gpu_cos_block_sweep.py 2>&1 | tee $OUT/r5r_cos_block_sweep.txt
+;;
+z)
+# round-5 session Z (final tree, after the tail rewrite): the whole GPU suite, smoke, the driver's bench command, rocprofv3 kernel
+# stats + the four PMC groups, solver phase cycles, the serial caller at demo scale, the N > 1 code path on one GPU
+bash tools/gpu_session.sh r5z tests smoke bench prof pmc
+export TMPDIR=/tmp; OUT=$PWD/gpurun_out; REPO=$PWD
+ROMAN_HIP_LIBRARY=$REPO/roman_amd/csrc/variants/libT.so timeout 600 python bench.py --steps 2 --warmup 1 --pipeline 1 --no-extras --no-grid --cpu-sample 0 --check-pairs 0 --latency-reps 2 > $OUT/r5z_benchT.txt 2> $OUT/r5z_timing.txt
+grep -A5 "solve timing" $OUT/r5z_timing.txt | grep -v "^--" | sed -n '1,6p;$p' | tee $OUT/r5z_phase_cycles.txt
+python tools/gpu_demo_latency.py 24 2>&1 | tee $OUT/r5z_demo_latency.txt
+bash tools/scale_preflight.sh 2>&1 | tail -6
 ;;
 m)
 # round-5 session M (final tree): the whole GPU suite, smoke, the driver's bench command, rocprofv3 kernel stats + the four PMC groups, solver phase cycles
