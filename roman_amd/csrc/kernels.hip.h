@@ -3529,6 +3529,9 @@ __device__ void solve_up(const DevParams& D, int b, const ProbDesc& pd, ProbStat
 #ifdef ROMAN_SOLVE_TIMING
     const unsigned long long tentry_ = __builtin_readcyclecounter();
 #endif
+#ifdef ROMAN_SMALL_TIMING
+    const unsigned long long tw0_ = wall_clock64();
+#endif
     constexpr int KMAX = (MAXL + NT - 1) / NT;                 // elements per thread (the kernel takes problems of up to MAXL live associations)
     // The three LDS vectors lie at a FIXED distance from each other — accM == xg + LCAP, accC == xg + 2 LCAP (the callers lay them
     // out so; Lc == LCAP) —: the stream addresses the accumulators of a column through the column's gather address + an immediate
@@ -4003,6 +4006,7 @@ __device__ void solve_up(const DevParams& D, int b, const ProbDesc& pd, ProbStat
     FOR_K(k, p) if (p < L) xg[p] = u[k];
 #ifdef ROMAN_SMALL_TIMING
     const unsigned long long tt0_ = __builtin_readcyclecounter();
+    const unsigned long long tw1_ = wall_clock64();              // (100 MHz, the same on every compute unit: when did this problem's iteration end?)
 #endif
     finish_one(D, b, pd, feats, assoc, plp, lpAsc, rowPosPool, nullptr, O, xg, reinterpret_cast<double*>(accM),
                reinterpret_cast<int32_t*>(accC), reinterpret_cast<int32_t*>(accC) + Lc, L, rb, lo, F, status, S, red, sint);
@@ -4015,7 +4019,9 @@ __device__ void solve_up(const DevParams& D, int b, const ProbDesc& pd, ProbStat
     }
 #endif
 #ifdef ROMAN_SMALL_TIMING
-    if (tid == 0 && ((b & 255) == 0 || b < 2)) printf("[solve_up<%d>] b=%d L=%d passes %d tail (selection, pose, outputs) %llu cycles\n", NW, b, L, n_pass, __builtin_readcyclecounter() - tt0_);
+    if (tid == 0 && ((b & 255) == 0 || b < 2 || (NW == 1 && n_pass >= 100)))
+        printf("[solve_up<%d>] b=%d L=%d nnz=%llu passes %d tail (selection, pose, outputs) %llu cycles; wall clock (10 ns): entered %llu iteration done %llu left %llu\n", NW, b, L,
+               (unsigned long long)st[b].nnzUpper, n_pass, __builtin_readcyclecounter() - tt0_, tw0_, tw1_, wall_clock64());
 #endif
 #undef FOR_K
 #undef FOR_K_ALL
