@@ -2751,12 +2751,14 @@ __device__ __forceinline__ void jacobi_pair(double (&G)[9], double (&V)[9], bool
 #pragma unroll
     for (int r = 0; r < 3; ++r) { al += G[r * 3 + P] * G[r * 3 + P]; be += G[r * 3 + Q] * G[r * 3 + Q]; ga += G[r * 3 + P] * G[r * 3 + Q]; }
     if (ga == 0.0) return;
-    const double sab = sqrt(al * be);
-    if (fabs(ga) <= 1e-17 * sab) return;
-    if (!(fabs(ga) < 1e-15 * sab)) moved = true;               // the sweep still found a pair of columns that is not orthogonal to working precision
-    const double zeta = (be - al) / (2.0 * ga);
-    const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-    const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+    const double ab = al * be, g2 = ga * ga;                    // |ga| <= 1e-17 sqrt(al be), squared (no square root on the one thread's critical path)
+    if (g2 <= 1e-34 * ab) return;
+    if (!(g2 < 1e-30 * ab)) moved = true;                      // the sweep still found a pair of columns that is not orthogonal to working precision
+    // t = sign(zeta) / (|zeta| + sqrt(1 + zeta^2)), zeta = (be - al) / (2 ga), with numerator and denominator multiplied by |2 ga|:
+    // one division and one square root instead of two and one; c = 1 / sqrt(1 + t^2) as a reciprocal square root
+    const double a2 = be - al, b2 = 2.0 * ga;
+    const double t = (((a2 >= 0.0) == (b2 >= 0.0)) ? fabs(b2) : -fabs(b2)) / (fabs(a2) + sqrt(a2 * a2 + b2 * b2));
+    const double c = rsqrt(1.0 + t * t), s = c * t;
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
         const double gp = G[r * 3 + P], gq = G[r * 3 + Q];
@@ -2999,9 +3001,20 @@ __device__ __noinline__ void finish_one(const DevParams& D, int b, const ProbDes
         __syncthreads();
         if (omega > 0) {
             // compact the positive entries (order irrelevant: ranks below are order-free) as (value, association index)
-            for (int p = tid; p < L; p += nt) {
-                const double up = u[p];
-                if (up > 0.0) { const int pos = atomicAdd(&sint[0], 1); pv[pos] = up; pidx[pos] = lp[lo + p]; }
+            // (one LDS atomic per wave and sweep — the wave's count — instead of one per positive element on the same word)
+            for (int p0 = 0; p0 < L; p0 += nt) {
+                const int p = p0 + tid;
+                const double up = p < L ? u[p] : 0.0;
+                const unsigned long long pm = __ballot(up > 0.0);
+                if (pm) {
+                    int base_ = 0;
+                    if ((tid & 63) == 0) base_ = atomicAdd(&sint[0], (int)__popcll(pm));
+                    base_ = __builtin_amdgcn_readfirstlane(base_);
+                    if (up > 0.0) {
+                        const int pos = base_ + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
+                        pv[pos] = up; pidx[pos] = lp[lo + p];
+                    }
+                }
             }
             __syncthreads();
             FMARK(1);
@@ -3009,18 +3022,29 @@ __device__ __noinline__ void finish_one(const DevParams& D, int b, const ProbDes
             bool fallback = (Pn < omega) || (omega > L);
             if (!fallback) {
                 // rank of e = number of entries greater in (value, association index) order (the inner loop reads LDS only)
-                for (int e = tid; e < Pn; e += nt) {
-                    const double ve = pv[e]; const int ae = pidx[e];
+                // `parts` adjacent lanes share an entry (a power of two, as many as the threads allow: a hundred entries leave four fifths
+                // of a 512-thread workgroup idle otherwise), each counts a part of the list, a butterfly inside the group adds the counts
+                int parts = 1;
+                while (parts < 8 && 2 * parts * Pn <= nt) parts <<= 1;
+                const int chunk = (Pn + parts - 1) / parts;
+                for (int base = 0; base < Pn * parts; base += nt) {
+                    const int idx = base + tid, e = idx / parts, part = idx & (parts - 1);
+                    const bool act = e < Pn;
+                    const double ve = pv[act ? e : 0]; const int ae = pidx[act ? e : 0];
+                    const int flo = part * chunk, fhi = min(Pn, flo + chunk);
                     int rank = 0;
-                    for (int f0 = 0; f0 < Pn; f0 += 8) {            // eight LDS reads in flight (one per iteration: the loop ran at the LDS latency)
+                    for (int f0 = flo; f0 < fhi; f0 += 8) {         // eight LDS reads in flight (one per iteration: the loop ran at the LDS latency)
                         double vf[8]; int af[8];
 #pragma unroll
                         for (int x = 0; x < 8; ++x) { const int f2 = min(f0 + x, Pn - 1); vf[x] = pv[f2]; af[x] = pidx[f2]; }
 #pragma unroll
-                        for (int x = 0; x < 8; ++x) rank += (f0 + x < Pn && ((vf[x] > ve) || (vf[x] == ve && af[x] > ae))) ? 1 : 0;
+                        for (int x = 0; x < 8; ++x) rank += (f0 + x < fhi && ((vf[x] > ve) || (vf[x] == ve && af[x] > ae))) ? 1 : 0;
                     }
-                    if (rank < omega) nodesLive[rank] = ae;
-                    if (rank == omega - 1) { red[64] = ve; }
+                    for (int off = 1; off < parts; off <<= 1) rank += __shfl_xor(rank, off);
+                    if (act && part == 0) {
+                        if (rank < omega) nodesLive[rank] = ae;
+                        if (rank == omega - 1) { red[64] = ve; }
+                    }
                 }
                 __syncthreads();
                 FMARK(2);

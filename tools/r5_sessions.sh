@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-5 GPU sessions, one per letter:  bash tools/r5_sessions.sh <a..r, z>   (repo root on an MI355X box; everything under gpurun_out/).
+# Round-5 GPU sessions, one per letter:  bash tools/r5_sessions.sh <a..s, z>   (repo root on an MI355X box; everything under gpurun_out/).
 # The A/B sessions compare library builds kept under roman_amd/csrc/variants/ (git-ignored; rebuilt from the commits named in
 # DESIGN.md 4.2 / profiles/r05/README.md): they are the record of what was measured, not something a fresh checkout can re-run as is.
 S=$1
@@ -288,6 +288,26 @@ unset ROMAN_HIP_LIBRARY
 ROMAN_HIP_LIBRARY=$REPO/roman_amd/csrc/variants/libT.so timeout 600 python bench.py --steps 2 --warmup 1 --pipeline 1 --no-extras --no-grid --cpu-sample 0 --check-pairs 0 --latency-reps 2 > $OUT/r5r_benchT.txt 2> $OUT/r5r_timing.txt
 grep -A5 "solve timing" $OUT/r5r_timing.txt | grep -v "^--" | sed -n '1,6p;$p'
 python tools/gpu_cos_block_sweep.py 2>&1 | tee $OUT/r5r_cos_block_sweep.txt
+;;
+s)
+# round-5 session S: the tail once more — the ranks by groups of lanes, the compaction's counter once per wave, one division and
+# one square root less per Jacobi step: whole GPU suite, the tail's phase cycles (variants/libST.so), and the tree of session Z
+# (variants/libR5z.so) against this one on ONE box, alternating
+export TMPDIR=/tmp; OUT=$PWD/gpurun_out; mkdir -p $OUT; REPO=$PWD
+timeout 1500 python -m pytest tests -q -m gpu -x > $OUT/r5s_pytest.txt 2>&1; echo "pytest rc=$?"; tail -3 $OUT/r5s_pytest.txt
+( export ROMAN_HIP_LIBRARY=$REPO/roman_amd/csrc/variants/libST.so
+  python tools/gpu_demo_latency.py 4 2>&1 | grep "finish_one" | sort | uniq -c | sort -rn | head -2
+  python bench.py --steps 2 --warmup 1 --pipeline 1 --no-extras --no-grid --cpu-sample 0 --check-pairs 0 --latency-reps 2 2>&1 | grep "finish_one" | tail -3 )
+for L in R5z new R5z new; do
+  if [ "$L" = "new" ]; then unset ROMAN_HIP_LIBRARY; else export ROMAN_HIP_LIBRARY=$REPO/roman_amd/csrc/variants/lib$L.so; fi
+  timeout 600 python bench.py --steps 40 --warmup 5 --no-extras --no-grid --cpu-sample 0 --check-pairs 64 --latency-reps 20 > $OUT/r5s_bench_$L.txt 2>$OUT/r5s_bench_$L.err
+  echo "== $L"; python tools/bench_digest.py $OUT/r5s_bench_$L.txt | head -1
+  python - $OUT/r5s_bench_$L.txt <<'PY'
+import json, sys
+d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+print("   isolated launch", d["roofline"]["isolated"]["avg_launch_ms"], "ms | B=1 stages", d["latency_breakdown"]["stage_ms"], "| identical", d["result_check"].get("oracle_identical"))
+PY
+done
 ;;
 z)
 # round-5 session Z (final tree, after the tail rewrite): the whole GPU suite, smoke, the driver's bench command, rocprofv3 kernel
