@@ -1708,6 +1708,65 @@ __global__ void __launch_bounds__(1024) k_rowprefix(const ProbDesc* __restrict__
 //    changes where a row is stored, never what is computed for it), then the sorted SELL-64 geometry:
 //    rowPos[k] = sorted position of row k, perm[pos] = row, per slice its width (longest row) and base offset.
 // ---------------------------------------------------------------------------------------------
+// Positions of the stream layout WITHOUT a sort.  The position of row k is its rank by (degree descending, row ascending):
+//   #(rows of larger degree) + #(rows of the same degree and smaller index).
+// Degrees are small integers: a histogram (LDS atomics), its scan in descending degree order (= where every degree's range of
+// positions starts), a scatter of the rows into their degree's range in whatever order the atomics grant, and the rank of a row inside
+// its range by counting the smaller row indices there (a dozen rows share a degree on average).  keys[0 .. L) receives what the
+// bitonic sort of the unique keys ((degree + 1) << 12) | (4095 - row) left there — the same array, bit for bit — and zeros up to N.
+// The bitonic sort it stands for was 67 k cycles of k_lists' 390 k per problem and 30 us of the single-pair call (k_rowsort).
+// Returns false (nothing written that matters) when more than eqMax rows share one degree — the ranks inside a range cost its
+// square —: the caller sorts.  deg(k): degree of live row k (< L).  wsum: nt / 64 + 2 words.
+template <class DegF>
+__device__ __forceinline__ bool place_keys(int L, int N, int eqMax, DegF deg, uint32_t* keys, uint32_t* hcnt /* [L] */, uint32_t* hcur /* [L] */,
+                                           uint16_t* tmp /* [L] */, uint32_t* wsum)
+{
+    const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, w = tid >> 6, nw = nt >> 6;
+    for (int d = tid; d < L; d += nt) hcnt[d] = 0u;
+    if (tid == 0) { wsum[nw] = 0u; wsum[nw + 1] = 0u; }           // carry of the scan, largest group of equal degrees
+    __syncthreads();
+    for (int k = tid; k < L; k += nt) atomicAdd(&hcnt[deg(k)], 1u);
+    __syncthreads();
+    uint32_t mx = 0u;
+    for (int r0 = 0; r0 < L; r0 += nt) {                           // exclusive scan over the bins, LARGEST degree first
+        const int r = r0 + tid;
+        const uint32_t v = r < L ? hcnt[L - 1 - r] : 0u;
+        mx = max(mx, v);
+        const uint32_t inc = wave_incl_scan(v);
+        if (lane == WAVE - 1) wsum[w] = inc;
+        __syncthreads();
+        uint32_t wbase = 0u, tot = 0u;
+        for (int t = 0; t < nw; ++t) { if (t < w) wbase += wsum[t]; tot += wsum[t]; }
+        const uint32_t carry = wsum[nw];
+        if (r < L) hcur[L - 1 - r] = carry + wbase + inc - v;
+        __syncthreads();
+        if (tid == 0) wsum[nw] = carry + tot;
+        __syncthreads();
+    }
+    for (int off = 32; off > 0; off >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, off));
+    if (lane == 0) atomicMax(&wsum[nw + 1], mx);
+    __syncthreads();
+    if ((int)wsum[nw + 1] > eqMax) return false;                   // (the same word in every thread)
+    for (int k = tid; k < L; k += nt) { const uint32_t slot = atomicAdd(&hcur[deg(k)], 1u); tmp[slot] = (uint16_t)k; }   // hcur[d] ends as the END of d's range
+    for (int t = L + tid; t < N; t += nt) keys[t] = 0u;
+    __syncthreads();
+    for (int i = tid; i < L; i += nt) {
+        const uint32_t k = tmp[i], d = (uint32_t)deg((int)k);
+        const uint32_t end = hcur[d], start = end - hcnt[d];
+        uint32_t r = 0u;
+        for (uint32_t j = start; j < end; j += 4u) {
+            uint32_t o[4];
+#pragma unroll
+            for (uint32_t x = 0; x < 4u; ++x) o[x] = tmp[min(j + x, end - 1u)];
+#pragma unroll
+            for (uint32_t x = 0; x < 4u; ++x) r += (j + x < end && o[x] < k) ? 1u : 0u;
+        }
+        keys[start + r] = ((d + 1u) << 12) | (4095u - k);
+    }
+    __syncthreads();
+    return true;
+}
+
 constexpr int SORT_KEYS = 8192;
 
 __global__ void __launch_bounds__(1024) k_rowsort(const ProbDesc* __restrict__ probs, ProbState* __restrict__ st,
@@ -1715,10 +1774,13 @@ __global__ void __launch_bounds__(1024) k_rowsort(const ProbDesc* __restrict__ p
                                                   const uint32_t* __restrict__ rowCnt,
                                                   uint32_t* __restrict__ rowPos, uint32_t* __restrict__ perm,
                                                   uint32_t* __restrict__ sliceWidth, uint32_t* __restrict__ sliceBase,
-                                                  uint32_t* __restrict__ listOff, long long capList, int skip0 /* stream-layout problems take k_lists */)
+                                                  uint32_t* __restrict__ listOff, long long capList, int skip0 /* stream-layout problems take k_lists */,
+                                                  int eqMax /* place_keys(): rows of one degree at most; 0: always the bitonic sort */)
 {
     __shared__ uint32_t hist[SORT_KEYS];         // indexed by SORT_KEYS-1-key: ascending index = descending count
-    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t wsum[20];
+    __shared__ uint32_t hcntS[STREAM_MAXL], hcurS[STREAM_MAXL];     // place_keys(): rows per degree, cursor / end of the degree's range
+    __shared__ uint16_t tmpS[STREAM_MAXL], dgS[STREAM_MAXL];        // ... the rows in their ranges (any order), the degrees
     __shared__ uint32_t carry_s;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nt = blockDim.x, nw = nt >> 6;
     const int L = st[b].L;
@@ -1731,7 +1793,11 @@ __global__ void __launch_bounds__(1024) k_rowsort(const ProbDesc* __restrict__ p
         // (padding keys 0 sort last), log2(N)(log2(N)+1)/2 <= 78 compare-exchange stages of N/2 pairs.
         static_assert(STREAM_MAXL <= 4096 && SORT_KEYS >= 4096, "bitonic sort capacity");
         int N = 64; while (N < L) N <<= 1;
-        for (int t = tid; t < N; t += nt) hist[t] = (t < L) ? (((rowCnt[lo + t] + 1u) << 12) | (uint32_t)(4095 - t)) : 0u;
+        for (int t = tid; t < L; t += nt) dgS[t] = (uint16_t)rowCnt[lo + t];
+        __syncthreads();
+        // (round 5: the sorted key array without the sort — place_keys() above; the sort remains for live sets in which very many rows share a degree)
+        if (eqMax <= 0 || !place_keys(L, N, eqMax, [&](int k) { return (uint32_t)dgS[k]; }, hist, hcntS, hcurS, tmpS, wsum)) {
+        for (int t = tid; t < N; t += nt) hist[t] = (t < L) ? ((((uint32_t)dgS[t] + 1u) << 12) | (uint32_t)(4095 - t)) : 0u;
         __syncthreads();
         for (int k2 = 2; k2 <= N; k2 <<= 1)
             for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
@@ -1743,6 +1809,7 @@ __global__ void __launch_bounds__(1024) k_rowsort(const ProbDesc* __restrict__ p
                 }
                 __syncthreads();
             }
+        }
         for (int q = tid; q < L; q += nt) {
             const uint32_t k = 4095u - (hist[q] & 4095u);
             perm[lo + q] = k; rowPos[lo + k] = (uint32_t)q;
@@ -1937,12 +2004,14 @@ __global__ void __launch_bounds__(LISTS_NT) k_lists(int B, const ProbDesc* __res
                                                    const unsigned long long* __restrict__ maskPool,
                                                    uint16_t* __restrict__ listPool, uint32_t* __restrict__ listOff,
                                                    uint32_t* __restrict__ rowCnt, uint32_t* __restrict__ perm, uint32_t* __restrict__ rowPos,
-                                                   LivePools src, LivePools dst, long long capList)
+                                                   LivePools src, LivePools dst, long long capList,
+                                                   int eqMax /* place_keys(): rows of one degree at most; 0: always the bitonic sort */)
 {
     __shared__ uint32_t degS[STREAM_MAXL + 64];                 // full degree of a live row; after the sort: the row's list cursor
     __shared__ uint32_t keyS[4096];                             // sort keys
-    __shared__ unsigned long long tabS[STREAM_MAXL + 64];       // per live row: list offset << 16 | position (one LDS read serves both)
-    __shared__ uint32_t wsum[LISTS_NT / 64];
+    __shared__ unsigned long long tabS[STREAM_MAXL + 64];       // per live row: list offset << 16 | position (one LDS read serves both); before: place_keys()' two tables
+    __shared__ uint16_t tmpS[STREAM_MAXL + 64];                 // place_keys(): the rows in their degree's range
+    __shared__ uint32_t wsum[LISTS_NT / 64 + 4];
     __shared__ int okS;
     static_assert(STREAM_MAXL <= 4096, "sort capacity");
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -2002,6 +2071,8 @@ __global__ void __launch_bounds__(LISTS_NT) k_lists(int B, const ProbDesc* __res
         LMARK(1);
         // ---- positions: bitonic sort (descending) of the unique keys ((degree + 1) << 12) | (4095 - row) (k_rowsort's order) ----
         int N = 64; while (N < L) N <<= 1;
+        // (the sorted key array without the sort: place_keys(); its two tables of L words each lie in tabS, which is written behind this phase)
+        if (eqMax <= 0 || !place_keys(L, N, eqMax, [&](int k) { return degS[k]; }, keyS, reinterpret_cast<uint32_t*>(tabS), reinterpret_cast<uint32_t*>(tabS) + (STREAM_MAXL + 64), tmpS, wsum)) {
         for (int t = tid; t < N; t += LISTS_NT) keyS[t] = (t < L) ? (((degS[t] + 1u) << 12) | (uint32_t)(4095 - t)) : 0u;
         __syncthreads();
         for (int k2 = 2; k2 <= N; k2 <<= 1)
@@ -2014,6 +2085,7 @@ __global__ void __launch_bounds__(LISTS_NT) k_lists(int B, const ProbDesc* __res
                 }
                 __syncthreads();                                // (stages inside a wave's own 128 keys without the barrier: measured, no faster)
             }
+        }
         LMARK(2);
         // ---- list room per position (whole quads), the problem's base from the batch's bump pointer ----
         {

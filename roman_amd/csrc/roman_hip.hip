@@ -357,6 +357,14 @@ int make_solve_out(roman_ctx* c, int B, int64_t sumA, const BatchOut& out, Solve
 
 // ---- the launch sequence of one batch (score + solve), on workspace c->cur and its stream; never waits -------------
 
+// Positions of the stream layout: rows of one degree at most for the sort-free placement (place_keys(), kernels.hip.h); beyond, the
+// bitonic sort.  ROMAN_SORT_EQMAX=n sets it (0: always the sort — A/B, tests; read per call).
+static int sort_eq_max()
+{
+    const char* e = getenv("ROMAN_SORT_EQMAX");
+    return (e && e[0]) ? std::max(0, atoi(e)) : 512;
+}
+
 // Cosine matrices of B problems: k_cos_tile (64x64 tile per workgroup, operands through LDS) by default, k_cos_deal (80x80 tiles, blocks
 // dealt evenly to the waves) for batches of mid-size maps, k_cos_wave (one wave per problem) for maps of at most 48 objects; ROMAN_COS=0 selects
 // k_cos (32x32 tile per wave, operands from global memory), ROMAN_COS=16 / 32 the stage depth.
@@ -635,7 +643,7 @@ int enqueue_score(roman_ctx* c, const DevParams& Din, const roman_params_t* para
         if (fusedLists) {
             hipLaunchKernelGGL(k_lists, dim3((unsigned)std::max(1, std::min(B, 2 * c->num_cu))), dim3(LISTS_NT), 0, WS.stream, B, dP, dS, dT,
                                WS.maskPool.as<unsigned long long>(), WS.listPool.as<uint16_t>(), WS.listOff.as<uint32_t>(),
-                               WS.rowCnt.as<uint32_t>(), WS.perm.as<uint32_t>(), WS.rowPos.as<uint32_t>(), LP, PP, (long long)SZ.capList);
+                               WS.rowCnt.as<uint32_t>(), WS.perm.as<uint32_t>(), WS.rowPos.as<uint32_t>(), LP, PP, (long long)SZ.capList, sort_eq_max());
     DBG(c, "k_lists");
         }
         if (!fusedLists || D.allow_fallback) {
@@ -655,7 +663,7 @@ int enqueue_score(roman_ctx* c, const DevParams& Din, const roman_params_t* para
         int sortThr = 1024;
         if (!D.allow_fallback) { int N2 = 64; while (N2 < expL) N2 <<= 1; sortThr = std::max(64, std::min(1024, N2 / 2)); }
         hipLaunchKernelGGL(k_rowsort, dim3(B), dim3(sortThr), 0, WS.stream, dP, dS, dT, WS.rowCnt.as<uint32_t>(), WS.rowPos.as<uint32_t>(), WS.perm.as<uint32_t>(),
-                           WS.sliceWidth.as<uint32_t>(), WS.sliceBase.as<uint32_t>(), WS.listOff.as<uint32_t>(), SZ.capList, fusedLists);
+                           WS.sliceWidth.as<uint32_t>(), WS.sliceBase.as<uint32_t>(), WS.listOff.as<uint32_t>(), SZ.capList, fusedLists, sort_eq_max());
     DBG(c, "k_rowsort");
         if (!fusedLists) {
         // small live sets (the reference's demo scale): a work item is a whole problem of a few dozen rows — more, smaller
@@ -1731,7 +1739,7 @@ int roman_set_matrix_data(roman_ctx_t* c, const roman_params_t* params, const do
         hipLaunchKernelGGL(k_rowprefix, dim3(c->num_cu * 2), dim3(1024), 0, WS.stream, dP, dS, dT, WS.items.as<ItemDesc>(),
                            WS.maskPool.as<unsigned long long>(), WS.prefPool.as<uint32_t>(), WS.rowCnt.as<uint32_t>(), RPB, 0);
         hipLaunchKernelGGL(k_rowsort, dim3(1), dim3(1024), 0, WS.stream, dP, dS, dT, WS.rowCnt.as<uint32_t>(), WS.rowPos.as<uint32_t>(), WS.perm.as<uint32_t>(),
-                           WS.sliceWidth.as<uint32_t>(), WS.sliceBase.as<uint32_t>(), WS.listOff.as<uint32_t>(), capList, 0);
+                           WS.sliceWidth.as<uint32_t>(), WS.sliceBase.as<uint32_t>(), WS.listOff.as<uint32_t>(), capList, 0, sort_eq_max());
         if (up) {
             hipLaunchKernelGGL(k_upper, dim3(c->num_cu * 2), dim3(1024), 0, WS.stream, dP, dS, dT, WS.items.as<ItemDesc>(),
                                WS.maskPool.as<unsigned long long>(), WS.listPool.as<uint16_t>(), WS.listOff.as<uint32_t>(),

@@ -123,6 +123,47 @@ def test_stagewise_parity(ctx, orc, case, lists, monkeypatch):
         assert len(got & truth) >= 0.85 * len(truth)
 
 
+@pytest.mark.parametrize("lists", ["0", "1"], ids=["k_rowsort", "k_lists"])
+@pytest.mark.parametrize("name", ["cfg2", "roman50", "dense45", "tiny_4x5", "words3_12x14", "roman_diagkeep", "gravity40", "semgrav_zgate_200"])
+def test_positions_without_a_sort_equal_the_sorted_ones(ctx, orc, name, lists, monkeypatch):
+    """The stream layout's positions — rank by (degree descending, row ascending) — come from a histogram of the degrees, its scan
+    and ranks inside the ranges of equal degree (place_keys, kernels.hip.h); the bitonic sort of the keys they stand for remains for
+    live sets in which very many rows share a degree.  ROMAN_SORT_EQMAX sets where: default (512), 0 (always the sort), 2 (the sort
+    as soon as three rows share a degree: both branches inside one process), 100000 (never the sort, whatever the degrees: dense45
+    and the DIAG_KEEP reading have hundreds of rows per degree).  Every setting: the oracle's matrix, the oracle's nodes in the
+    oracle's order, the same iterate bit for bit (the solver's sums are exact: the layout cannot show in them), the same pass counts."""
+    case = next(c for c in LADDER if c[0] == name)
+    reg, pr = make(case)
+    reg.set_context(ctx)
+    P = reg._abi_params()
+    D1, D2 = reg.pack(pr.map1), reg.pack(pr.map2)
+    A = reg._association_list(pr.map1, pr.map2)
+    mat, Ao = orc.build_matrix(P, D1, D2, A)
+    sol = orc.solve(P, mat)
+    rp_o, c_o, v_o, d_o = mat.export()
+    monkeypatch.setenv("ROMAN_LISTS", lists)
+    first = None
+    for eq in (None, "0", "2", "100000"):
+        if eq is None:
+            monkeypatch.delenv("ROMAN_SORT_EQMAX", raising=False)
+        else:
+            monkeypatch.setenv("ROMAN_SORT_EQMAX", eq)
+        ctx.score(P, D1, D2, A)
+        rp, cc, vv, dd = ctx.upper_csr()
+        assert np.array_equal(rp, rp_o) and np.array_equal(cc, c_o) and np.array_equal(vv, v_o) and np.array_equal(dd, d_o), eq
+        ctx.solve(None)
+        nodes, u, score, st = ctx.solution()
+        assert np.array_equal(nodes, sol["nodes"]), eq
+        assert (st.n_pass, st.outer_iters, st.inner_iters, st.ls_trials) == (sol["stats"].n_pass, sol["stats"].outer_iters, sol["stats"].inner_iters, sol["stats"].ls_trials), eq
+        res = reg.register_and_align_batch([(pr.map1, pr.map2)] * 3)
+        got = (u.copy(), [a.copy() for a in res.assoc], res.T.copy())
+        if first is None:
+            first = got
+        else:
+            assert np.array_equal(got[0], first[0]), eq
+            assert all(np.array_equal(a, b) for a, b in zip(got[1], first[1])) and np.array_equal(got[2], first[2], equal_nan=True), eq     # (fewer associations than dimensions: the NaN pose)
+
+
 def test_device_arithmetic_is_bit_exact(ctx, orc):
     """The ops every threshold is applied to (+,-,*,/,sqrt,fma and the two fixed-sequence functions) give the
     host's bits on gfx950; the device's own libm stays within 2 ulp of glibc (it is only used for pow with

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-5 GPU sessions, one per letter:  bash tools/r5_sessions.sh <a..s, z>   (repo root on an MI355X box; everything under gpurun_out/).
+# Round-5 GPU sessions, one per letter:  bash tools/r5_sessions.sh <a..t, z>   (repo root on an MI355X box; everything under gpurun_out/).
 # The A/B sessions compare library builds kept under roman_amd/csrc/variants/ (git-ignored; rebuilt from the commits named in
 # DESIGN.md 4.2 / profiles/r05/README.md): they are the record of what was measured, not something a fresh checkout can re-run as is.
 S=$1
@@ -307,6 +307,26 @@ import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
 print("   isolated launch", d["roofline"]["isolated"]["avg_launch_ms"], "ms | B=1 stages", d["latency_breakdown"]["stage_ms"], "| identical", d["result_check"].get("oracle_identical"))
 PY
+done
+;;
+t)
+# round-5 session T: positions of the stream layout without a sort (place_keys: histogram of the degrees, scan, ranks inside the
+# ranges of equal degree) in k_lists and k_rowsort: whole GPU suite, then the tree before it (variants/libR5s.so) against this one
+# on ONE box, alternating: bench line, p50, and the kernels' rocprofv3 averages (k_lists in the batch, k_rowsort in the single-pair call)
+export TMPDIR=/tmp; OUT=$PWD/gpurun_out; mkdir -p $OUT; REPO=$PWD
+timeout 1500 python -m pytest tests -q -m gpu -x > $OUT/r5t_pytest.txt 2>&1; echo "pytest rc=$?"; tail -3 $OUT/r5t_pytest.txt
+for L in R5s new R5s new; do
+  if [ "$L" = "new" ]; then unset ROMAN_HIP_LIBRARY; else export ROMAN_HIP_LIBRARY=$REPO/roman_amd/csrc/variants/lib$L.so; fi
+  timeout 600 python bench.py --steps 40 --warmup 5 --no-extras --no-grid --cpu-sample 0 --check-pairs 0 --latency-reps 20 > $OUT/r5t_bench_$L.txt 2>$OUT/r5t_bench_$L.err
+  echo "== $L"; python tools/bench_digest.py $OUT/r5t_bench_$L.txt | head -1
+  ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ab_tmp -o b -- python $REPO/bench.py --steps 5 --warmup 2 --pipeline 1 --latency-reps 100 --cpu-sample 0 --no-extras --no-grid --check-pairs 0 > /dev/null 2>&1 )
+  F=$(find $OUT/ab_tmp -name "*kernel_stats.csv" | head -1)
+  python - "$F" "$L" <<'PY'
+import csv, sys
+for r in csv.DictReader(open(sys.argv[1])):
+    if 'k_lists' in r['Name'] or 'k_rowsort' in r['Name']: print('  ', sys.argv[2], r['Name'][:24], r['Calls'], 'calls, avg', round(float(r['AverageNs']) / 1e3, 1), 'us')
+PY
+  rm -rf $OUT/ab_tmp
 done
 ;;
 z)
