@@ -502,7 +502,8 @@ __global__ void __launch_bounds__(256) k_cos_wave(DevParams D, int B, const Prob
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_cos_block: k_cos_wave for a FEW demo-size problems (a serial caller's one pair at a time).  One wave alone walks a problem's
+// k_cos_block: the cosine matrices of a FEW problems (a serial caller's one pair at a time) — maps of any size: a single pair of 200-object
+// maps is 169 blocks on 169 waves, 6 us where the tile kernel's sixteen workgroups, two stages of loads in flight, take 29.  One wave alone walks a demo-size problem's
 // 48 chunks x 36 matrix instructions in 68 us — the whole device idle beside it; here a wave takes ONE 16 x 16 block of the
 // cosine matrix (up to nine waves per problem): four matrix instructions per chunk, eight chunks of loads in flight (a ring of
 // 32-byte loads, refilled as it is consumed).  Every output element sees k_cos_wave's own contraction order — chunks of 16
@@ -510,13 +511,15 @@ __global__ void __launch_bounds__(256) k_cos_wave(DevParams D, int B, const Prob
 // ---------------------------------------------------------------------------------------------
 constexpr int COSB_DEPTH = 8;
 
-__global__ void __launch_bounds__(256) k_cos_block(DevParams D, int B, const ProbDesc* __restrict__ probs,
+__global__ void __launch_bounds__(256) k_cos_block(DevParams D, int B, int nbx, int nby /* blocks per dimension of the largest problem of the call */,
+                                                   const ProbDesc* __restrict__ probs,
                                                    const double* __restrict__ feats, double* __restrict__ cosPool)
 {
     const int wid = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
-    const int b = uni_i(wid / (COSW_NB * COSW_NB));
+    const int per = nbx * nby;
+    const int b = uni_i(wid / per);
     if (b >= B) return;
-    const int blk = uni_i(wid - b * (COSW_NB * COSW_NB)), xs = blk / COSW_NB, ys = blk - xs * COSW_NB;
+    const int blk = uni_i(wid - b * per), xs = blk / nby, ys = blk - xs * nby;
     const ProbDesc pd = probs[b];
     if (16 * xs >= pd.n1 || 16 * ys >= pd.n2) return;
     const int lane = threadIdx.x & 63;

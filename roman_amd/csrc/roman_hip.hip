@@ -394,9 +394,21 @@ static hipError_t launch_cos(roman_ctx* c, hipStream_t stream, const DevParams& 
         // ROMAN_COS_BLOCK=0 never, =1 always (A/B, tests; read per call)
         const char* blockEnv = getenv("ROMAN_COS_BLOCK");
         const bool perBlock = (blockEnv && blockEnv[0]) ? blockEnv[0] == '1' : B <= 2 * c->num_cu;
-        if (perBlock) hipLaunchKernelGGL(k_cos_block, dim3((unsigned)((B * COSW_NB * COSW_NB + 3) / 4)), dim3(256), 0, stream, D, B, dP, feats, cosPool);
+        const int nbx = (maxN1 + 15) / 16, nby = (maxN2 + 15) / 16;
+        if (perBlock) hipLaunchKernelGGL(k_cos_block, dim3((unsigned)((B * nbx * nby + 3) / 4)), dim3(256), 0, stream, D, B, nbx, nby, dP, feats, cosPool);
         else hipLaunchKernelGGL(k_cos_wave, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, stream, D, B, dP, feats, cosPool);
         return hipGetLastError();
+    }
+    if (mode == 16) {
+        // a few problems of larger maps (the single-pair call: 200 x 200 objects = 169 blocks): one wave per 16 x 16 block as well, eight
+        // chunks of loads in flight per wave — the tile kernel below gives such a call sixteen workgroups with two stages in flight
+        // (29 us; the contraction over the descriptor is serial either way).  Up to eight waves per compute unit; ROMAN_COS_BLOCK=0: never
+        const char* blockEnv = getenv("ROMAN_COS_BLOCK");
+        const int nbx = (maxN1 + 15) / 16, nby = (maxN2 + 15) / 16;
+        if (!(blockEnv && blockEnv[0] == '0') && (int64_t)B * nbx * nby <= 8 * (int64_t)c->num_cu) {
+            hipLaunchKernelGGL(k_cos_block, dim3((unsigned)((B * nbx * nby + 3) / 4)), dim3(256), 0, stream, D, B, nbx, nby, dP, feats, cosPool);
+            return hipGetLastError();
+        }
     }
     if (mode == 0) {
         const int tiles = ((maxN1 + COS_TILE - 1) / COS_TILE) * ((maxN2 + COS_TILE - 1) / COS_TILE), G = (tiles + 3) / 4;

@@ -213,21 +213,29 @@ def test_mfma_cosine_kernel(ctx, n1, n2, d):
                                      (65, 17, 33), (200, 200, 48), (130, 40, 16), (40, 130, 31), (49, 49, 15), (1, 1, 16), (63, 200, 96),
                                      # maps of at most 48 objects: the one-wave-per-problem kernel (k_cos_wave), 1-3 blocks per dimension
                                      (40, 40, 768), (48, 48, 100), (33, 47, 70), (17, 48, 16), (32, 16, 37), (48, 1, 15)])
-def test_cosine_bits_equal_the_oracles_stated_order(ctx, orc, n1, n2, d):
+def test_cosine_bits_equal_the_oracles_stated_order(ctx, orc, monkeypatch, n1, n2, d):
     """The f64 matrix-core contraction accumulates in the order the oracle states (dot_fixed / norm_fixed in
-    oracle/clipper_oracle.c): the cosine matrix is BIT-identical, so the cosine gate decides on the same value."""
+    oracle/clipper_oracle.c): the cosine matrix is BIT-identical, so the cosine gate decides on the same value.  A call of one
+    problem takes the one-wave-per-block kernel (k_cos_block) by itself; ROMAN_COS_BLOCK=0 gives it the tile / one-wave kernels."""
     rng = np.random.default_rng(n1 * 977 + n2 * 13 + d)
     P = _abi.RomanParams.default(); P.cos_feature_dim = d
     D1 = rng.standard_normal((n1, 3 + d)); D2 = rng.standard_normal((n2, 3 + d))
-    got = ctx.debug_cosine(P, D1, D2)
     ref = np.array([[orc.cosine(D1[i, 3:], D2[j, 3:]) for j in range(n2)] for i in range(n1)])
-    assert np.array_equal(got, ref)
+    for setting in (None, "0"):
+        if setting is None:
+            monkeypatch.delenv("ROMAN_COS_BLOCK", raising=False)
+        else:
+            monkeypatch.setenv("ROMAN_COS_BLOCK", setting)
+        assert np.array_equal(ctx.debug_cosine(P, D1, D2), ref), setting
 
 
-@pytest.mark.parametrize("n1,n2,d", [(40, 40, 768), (48, 48, 100), (33, 47, 70), (17, 48, 16), (32, 16, 37), (48, 1, 15), (1, 48, 160), (20, 37, 7), (16, 16, 128), (9, 7, 768)])
+@pytest.mark.parametrize("n1,n2,d", [(40, 40, 768), (48, 48, 100), (33, 47, 70), (17, 48, 16), (32, 16, 37), (48, 1, 15), (1, 48, 160), (20, 37, 7), (16, 16, 128), (9, 7, 768),
+                                     # larger maps in a call of one problem: k_cos_block as well (one wave per block) against the tile kernel
+                                     (200, 200, 512), (137, 53, 70), (65, 17, 33), (49, 300, 16), (300, 130, 129)])
 def test_demo_scale_cosine_kernels_give_the_oracles_bits(ctx, orc, monkeypatch, n1, n2, d):
     """Maps of at most 48 objects: one wave per problem (k_cos_wave, what a batch takes) and one wave per 16 x 16 block (k_cos_block,
-    what a serial caller's single pair takes: ROMAN_COS_BLOCK forces either) — 1 to 3 blocks per dimension, descriptor lengths
+    what a serial caller's single pair takes: ROMAN_COS_BLOCK forces either; for larger maps the switch chooses between k_cos_block
+    and the tile kernel k_cos_tile) — 1 to 3 blocks per dimension, descriptor lengths
     below one chunk of 16, below and above the eight chunks of k_cos_block's load ring, ragged tails: both BIT-identical to the
     oracle's stated order."""
     rng = np.random.default_rng(n1 * 977 + n2 * 13 + d)
