@@ -36,3 +36,39 @@ def test_tie_at_the_cut_is_a_count(seed):
         top = a[np.argsort(r)][:omega]                                                        # what nodesLive[rank] = association index collects
         want = sorted(zip(-v, -a))[:omega]
         assert [int(-x[1]) for x in want] == top.tolist()
+
+
+def place_keys_numpy(deg, rng):
+    """kernels.hip.h place_keys() restated: histogram of the degrees, exclusive scan with the LARGEST degree first, the rows scattered
+    into their degree's range in an ARBITRARY order (what the atomics grant: here a random permutation), a row's rank inside its range =
+    the number of smaller row indices there.  -> keys array as the bitonic sort of ((deg + 1) << 12 | (4095 - row)) leaves it."""
+    L = len(deg)
+    hcnt = np.bincount(deg, minlength=L)
+    start = np.zeros(L, dtype=np.int64)
+    run = 0
+    for d in range(L - 1, -1, -1):
+        start[d] = run; run += hcnt[d]
+    cur = start.copy()
+    tmp = np.zeros(L, dtype=np.int64)
+    for k in rng.permutation(L):
+        tmp[cur[deg[k]]] = k; cur[deg[k]] += 1
+    keys = np.zeros(L, dtype=np.int64)
+    for i in range(L):
+        k = tmp[i]; d = deg[k]
+        lo, hi = cur[d] - hcnt[d], cur[d]
+        r = int(np.sum(tmp[lo:hi] < k))
+        keys[lo + r] = ((d + 1) << 12) | (4095 - k)
+    return keys
+
+
+@pytest.mark.parametrize("seed", range(30))
+def test_positions_from_a_histogram_equal_the_sorted_keys(seed):
+    """Position of row k = #(rows of larger degree) + #(rows of the same degree and smaller index): the array place_keys() writes is the
+    descending sort of the unique keys, whatever order the scatter's atomics were granted in (the GPU test compares the kernels)."""
+    rng = np.random.default_rng(seed)
+    L = int(rng.integers(1, 400))
+    spread = [1, 3, 17, max(L, 1)][seed % 4]                        # all rows of one degree ... degrees spread over the whole range
+    deg = rng.integers(0, min(spread, L), size=L)
+    keys = place_keys_numpy(deg, rng)
+    want = np.sort(((deg.astype(np.int64) + 1) << 12) | (4095 - np.arange(L)))[::-1]
+    assert np.array_equal(keys, want)
