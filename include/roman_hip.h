@@ -316,6 +316,27 @@ ROMAN_API int roman_align_batch(roman_ctx_t* ctx, const roman_params_t* params, 
                       int32_t kmax, int32_t* assoc_out, int32_t* n_assoc_out,
                       double* T_out, int32_t* status_out, roman_stats_t* stats_out);
 
+/* Inputs in HBM as for roman_align_batch_dev (feats, assoc, u0: DEVICE pointers; the metadata arrays host memory), results on the
+   HOST as for roman_align_batch: what a caller needs whose submaps' feature pool stays resident (the all-pairs grid: every submap
+   is uploaded once, [REF roman/align/submap_align.py:93-94]) but who consumes associations and poses on the host
+   ([REF roman/align/submap_align.py:155-166]).  Synchronous; chunks, pipelines and retries like roman_align_batch.  The outputs of all
+   problems land in one device block and come back with ONE copy through a pinned landing block owned by the context (a single
+   pair's whole result — associations, count, pose, status, statistics — is 1.8 KB).  Device buffers must not be in use by work
+   queued on streams the context does not know (the call starts behind the context's stream). */
+ROMAN_API int roman_align_batch_resident(roman_ctx_t* ctx, const roman_params_t* params, int32_t B,
+                               const double* feats, const int64_t* off1, const int32_t* n1,
+                               const int64_t* off2, const int32_t* n2, int32_t F,
+                               const int32_t* assoc, const int64_t* assoc_off,
+                               const double* u0,
+                               int32_t kmax, int32_t* assoc_out, int32_t* n_assoc_out,
+                               double* T_out, int32_t* status_out, roman_stats_t* stats_out);
+
+/* Does the context hold a sizing history for this parameter block (params, F) — i.e. has a batch with it reported what its sparse
+   pools needed?  *yes = 1 / 0.  A device-pointer caller that queues several calls at once asks this first: without a history the
+   first call should be waited for (roman_ctx_sync), so that the calls behind it size their pools from what it needed instead of
+   repeating its guess (roman_align_batch does the same internally).  The context keeps ONE history: that of the latest block. */
+ROMAN_API int roman_ctx_has_history(roman_ctx_t* ctx, const roman_params_t* params, int32_t F, int32_t* yes);
+
 /* The deal of a batch over `world` ranks (one process per GPU), for a C / C++ caller that shards with its own collective
    (roman_ros, [REF README.md:11]; the Python side is roman_amd.align.distributed.align_sharded).  The pairs of the serial loop
    [REF roman/align/submap_align.py:93-200] are independent: every rank aligns its share with roman_align_batch[_dev] and ONE

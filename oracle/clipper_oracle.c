@@ -60,19 +60,20 @@ ORACLE_API int oracle_get_arith(void) { return g_plain_arith; }
 
 /* How the solver's passes over M are organised (oracle_solve below).  Both are the same iteration; they differ in where the
  * penalty d enters the sums, i.e. by rounding only:
- *   0 CARRIED  every pass forms M x and C x separately; the products of the accepted trial are carried to the d update
+ *   0 CARRIED  (default) every pass forms M x and C x separately; the products of the accepted trial are carried to the d update
  *              (findDenseClique as published: one pass per line-search trial);
  *   1 FUSED    a line-search pass forms ONE product W x = (M + d C) x (the only thing the gradient needs); the d update, which
  *              needs M u and C u apart, takes one split pass over the accepted vector ("1 per gradient
  *              evaluation incl. each line-search trial, 1 per d update").  This is the order of the device's stream solver
  *              (k_solve_up: one LDS accumulator per element instead of two);
- *   2 AUTO     (default) FUSED for the problems the device gives to its stream solver — at most ORACLE_STREAM_MAXL live
+ *   2 AUTO     FUSED for the problems the device gives to its stream solver — at most ORACLE_STREAM_MAXL live
  *              associations, every stored weight in [0, 1], maxiniters >= 1 and maxlsiters >= 1 — and CARRIED for the others
  *              (the whole-device / plain-double device solvers keep both sums of every pass), so that pass counts compare
  *              whichever solver a problem takes.  Selections do not depend on the mode (tests/test_oracle_clipper.py). */
 #define ORACLE_STREAM_MAXL 3072     /* roman_amd/csrc/kernels.hip.h STREAM_MAXL */
-static int g_pass_mode = 2;
-ORACLE_API void oracle_set_pass_mode(int mode) { g_pass_mode = (mode == 0 || mode == 1) ? mode : 2; }
+static int g_pass_mode = 0;        /* the default is the algorithm AS PUBLISHED (round 6; AUTO until round 5): a test that compares pass counts
+                                      with the device opts into the device's organisation (tests/conftest.py: `auto` for the GPU tests) */
+ORACLE_API void oracle_set_pass_mode(int mode) { g_pass_mode = (mode == 1 || mode == 2) ? mode : 0; }
 ORACLE_API int oracle_get_pass_mode(void) { return g_pass_mode; }
 /* Analysis hook (tools/wide_compaction_sim.py): when set, oracle_solve also records WHICH elements are positive in the vector
  * fed to each pass — one row of `words_per_pass` 64-bit words per pass, up to `max_pass` rows.  Not thread-safe; off by default. */
@@ -677,7 +678,7 @@ ORACLE_API int32_t oracle_k_largest(const double* x, int32_t n, int32_t k, int32
  * Pass mode CARRIED (oracle_set_pass_mode(0)): M u and C u of the current u are carried from the
  * accepting line-search trial instead of being recomputed (bitwise identical inputs -> bitwise
  * identical values); n_pass = 1 (rescale) + 1 (initial) + line-search trials.
- * Pass mode FUSED (default, the device stream solver's order): a trial forms W = (M + d C) u' in one
+ * Pass mode FUSED (oracle_set_pass_mode(1), the device stream solver's order): a trial forms W = (M + d C) u' in one
  * product; every d update is preceded by one split pass (M u, C u) over the accepted vector;
  * n_pass = 1 + 1 + line-search trials + d updates evaluated.
  * support_trace (optional, length >= n_pass+2): number of u_p > 0 feeding each pass.

@@ -131,6 +131,26 @@ def pack_records(result, kmax):
     return ints, poses
 
 
+def record_bytes(kmax):
+    """Bytes of ONE fixed-size result record (count, status, <= kmax index pairs, 16 doubles): the int32 part
+    [count, status, i0, j0, ...] — 8 * (1 + kmax) bytes, so the pose behind it is 8-byte aligned — then the pose."""
+    return 8 * (1 + int(kmax)) + 128
+
+
+def records_as_bytes(ints, poses):
+    """(ints (B, 2+2*kmax) int32, poses (B,16) float64) -> (B, record_bytes(kmax)) uint8: what ONE all_gather moves."""
+    ints = np.ascontiguousarray(ints, dtype=np.int32); poses = np.ascontiguousarray(poses, dtype=np.float64)
+    return np.concatenate([ints.view(np.uint8).reshape(ints.shape[0], -1), poses.view(np.uint8).reshape(poses.shape[0], -1)], axis=1)
+
+
+def records_from_bytes(rec, kmax):
+    """Inverse of records_as_bytes -> (ints, poses)."""
+    rec = np.ascontiguousarray(rec, dtype=np.uint8)
+    ib = 8 * (1 + int(kmax))
+    return (np.ascontiguousarray(rec[:, :ib]).view(np.int32).reshape(rec.shape[0], -1),
+            np.ascontiguousarray(rec[:, ib:]).view(np.float64).reshape(rec.shape[0], 16))
+
+
 def unpack_records(ints, poses, dim=3):
     """Inverse of pack_records -> (assoc list, T (B,dim+1,dim+1), status)."""
     ints = np.asarray(ints); poses = np.asarray(poses)

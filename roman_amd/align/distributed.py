@@ -3,13 +3,13 @@
 One process per GPU (torch.distributed; backend "nccl" is RCCL on ROCm).  Problems are independent
 ([REF roman/align/submap_align.py:93-200] carries no state across iterations), so every rank aligns its share of the
 flattened pair list and ONE all_gather of fixed-size result records collects the inlier sets and poses.  No other
-collective.  The share is cost-balanced: problems are dealt longest-first (work estimate = the square of the number of
+collective (one byte record per problem: int32 part and pose travel together).  The share is cost-balanced: problems are dealt longest-first (work estimate = the square of the number of
 associations to score, n1*n2 for all-to-all) to the rank with the least work so far — the deal is a pure function of the
 batch, identical on every rank.  On GPUs the records never leave the device before the gather.
 """
 import numpy as np
 
-from .batch import AlignmentBatch, pack_records, run_batch, unpack_records
+from .batch import AlignmentBatch, pack_records, record_bytes, records_from_bytes, run_batch, unpack_records
 
 
 def shard_bounds(n_items, rank, world_size):
@@ -148,17 +148,21 @@ def align_sharded(registration, batch: AlignmentBatch, group=None, compute=None,
         dev = device if device is not None else (torch.device("cuda", torch.cuda.current_device())
                                                  if dist.is_initialized() and dist.get_backend(group) == "nccl" else torch.device("cpu"))
         ti = torch.from_numpy(ints_p).to(dev); tp = torch.from_numpy(poses_p).to(dev)
+    # ONE fixed-size byte record per problem — [count, status, index pairs] int32 | pose f64 (batch.record_bytes) — and ONE
+    # all_gather_into_tensor; the shards are scattered back into problem order with one indexed store
+    ib = 8 * (1 + kmax)
+    rec = torch.empty((per, record_bytes(kmax)), dtype=torch.uint8, device=ti.device)
+    rec[:, :ib].view(torch.int32).copy_(ti); rec[:, ib:].view(torch.float64).copy_(tp)
     if world > 1:
-        gi = torch.empty((world * per, ti.shape[1]), dtype=ti.dtype, device=ti.device)    # concatenated along dim 0
-        gp = torch.empty((world * per, tp.shape[1]), dtype=tp.dtype, device=tp.device)
-        dist.all_gather_into_tensor(gi, ti, group=group)
-        dist.all_gather_into_tensor(gp, tp, group=group)
+        g = torch.empty((world * per, rec.shape[1]), dtype=torch.uint8, device=rec.device)     # concatenated along dim 0
+        dist.all_gather_into_tensor(g, rec, group=group)
     else:
-        gi, gp = ti, tp
-    gi = gi.cpu().numpy().reshape(world, per, -1); gp = gp.cpu().numpy().reshape(world, per, -1)
-    out_i = np.full((B, gi.shape[2]), -1, dtype=np.int32); out_p = np.full((B, 16), np.nan)
-    for r in range(world):
-        out_i[shards[r]] = gi[r, :len(shards[r])]; out_p[shards[r]] = gp[r, :len(shards[r])]
+        g = rec
+    gi, gp = records_from_bytes(g.cpu().numpy(), kmax)
+    src = np.concatenate([r * per + np.arange(len(shards[r]), dtype=np.int64) for r in range(world)]) if B else np.zeros(0, np.int64)
+    dst = np.concatenate(shards) if B else np.zeros(0, np.int64)
+    out_i = np.full((B, gi.shape[1]), -1, dtype=np.int32); out_p = np.full((B, 16), np.nan)
+    out_i[dst] = gi[src]; out_p[dst] = gp[src]
     assoc, T, status = unpack_records(out_i, out_p, registration.dim)
     check_records(status)
     return assoc, T, status

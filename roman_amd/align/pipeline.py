@@ -88,6 +88,25 @@ class OutputSet:
         return self.assoc.cpu().numpy()[:c], self.n.cpu().numpy()[:c], self.T.cpu().numpy()[:c], self.status.cpu().numpy()[:c], st
 
 
+class _HostStream:
+    """Stand-in for a torch.cuda.Stream when the tensors live on the CPU (tests over a stand-in context: every call is synchronous)."""
+    cuda_stream = None
+
+    def wait_event(self, ev):
+        pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+class _HostEvent:
+    def record(self, stream=None):
+        pass
+
+
 class AlignStream:
     """A stream of batch calls with `in_flight` of them on the device at once.
 
@@ -111,7 +130,8 @@ class AlignStream:
         self.rows, self.kmax, self.in_flight = int(rows), int(kmax), int(in_flight)
         self.dist_on = bool(use_group)
         self.group = group
-        self.stream = stream if stream is not None else torch.cuda.current_stream(device)
+        self.on_host = torch.device(device).type == "cpu"          # CPU tensors + a stand-in context (tests): no streams, synchronous calls
+        self.stream = stream if stream is not None else (_HostStream() if self.on_host else torch.cuda.current_stream(device))
         # one output set per call in flight — and one more with a collector stream: the collection of call c - 1 runs on its own
         # stream while call c computes, and the set call c + in_flight - 1 rewrites must not be the one it is still reading
         self.collecting = self.dist_on or on_collect is not None
@@ -121,14 +141,23 @@ class AlignStream:
         self.on_collect = on_collect
         self.ev_done = [None] * self.nset                          # behind the collection that read output set k
         if self.collecting:
-            self.cstream = torch.cuda.Stream(device)               # the collections' own stream: never between two batch calls
+            self.cstream = _HostStream() if self.on_host else torch.cuda.Stream(device)   # the collections' own stream: never between two batch calls
         if self.dist_on:
             import torch.distributed as dist
             self.world = dist.get_world_size(group)
-            self.rec_i = torch.empty((self.rows, 2 + 2 * self.kmax), dtype=torch.int32, device=device)
-            self.gathered_ints = torch.empty((self.world * self.rows, 2 + 2 * self.kmax), dtype=torch.int32, device=device)
-            self.gathered_T = torch.empty((self.world * self.rows, 16), dtype=torch.float64, device=device)
+            # ONE fixed-size byte record per problem (batch.record_bytes: [count, status, index pairs] int32 | pose f64) and ONE
+            # all_gather_into_tensor per call; gathered_ints / gathered_T are typed VIEWS of the gathered block
+            from .batch import record_bytes
+            rb_, ib_ = record_bytes(self.kmax), 8 * (1 + self.kmax)
+            self.rec = torch.empty((self.rows, rb_), dtype=torch.uint8, device=device)
+            self.rec_i = self.rec[:, :ib_].view(torch.int32)
+            self.rec_T = self.rec[:, ib_:].view(torch.float64)
+            self.gathered = torch.empty((self.world * self.rows, rb_), dtype=torch.uint8, device=device)
+            self.gathered_ints = self.gathered[:, :ib_].view(torch.int32)
+            self.gathered_T = self.gathered[:, ib_:].view(torch.float64)
+            self.gathers = 0                                           # collectives issued (tests: one per call)
         self._pending = None                                        # arguments of the call being launched
+        self._depth_before = getattr(ctx, "pipeline_depth", 1)
         self.loop = CallLoop(1, self.nset, self.in_flight, self._launch,
                              (lambda skip: ctx.join(skip_latest=skip, stream=self.cstream.cuda_stream)) if self.collecting else (lambda skip: ctx.join(skip_latest=skip)),
                              self._collect if self.collecting else None)
@@ -149,15 +178,16 @@ class AlignStream:
         O = self.sets[k]
         if self.in_flight < 2:                                      # one call at a time, on the context's stream: the collector waits for what is queued there
             self.ctx.join(skip_latest=False, stream=self.cstream.cuda_stream)
-        with torch.cuda.stream(self.cstream):
+        with (self.cstream if self.on_host else torch.cuda.stream(self.cstream)):
             if self.dist_on:
                 import torch.distributed as dist
                 self.rec_i[:, 0] = O.n; self.rec_i[:, 1] = O.status; self.rec_i[:, 2:] = O.assoc.view(self.rows, -1)
-                dist.all_gather_into_tensor(self.gathered_ints, self.rec_i, group=self.group)
-                dist.all_gather_into_tensor(self.gathered_T, O.T, group=self.group)
+                self.rec_T.copy_(O.T)
+                dist.all_gather_into_tensor(self.gathered, self.rec, group=self.group)
+                self.gathers += 1
             if self.on_collect is not None:
                 self.on_collect(k, self.tags[k])
-            self.ev_done[k] = torch.cuda.Event(); self.ev_done[k].record(self.cstream)
+            self.ev_done[k] = _HostEvent() if self.on_host else torch.cuda.Event(); self.ev_done[k].record(self.cstream)
 
     # -- the caller's side
     def submit(self, pool_ptr, F, off1, n1, off2, n2, assoc_ptr=None, assoc_off=None, u0_ptr=None, tag=None):
@@ -165,6 +195,8 @@ class AlignStream:
         set it writes.  A pure enqueue."""
         if len(n1) > self.rows:
             raise ValueError(f"{len(n1)} problems in a call of an AlignStream built for {self.rows}")
+        if getattr(self.ctx, "pipeline_depth", self.in_flight) != self.in_flight:     # a synchronous entry point in between put it back
+            self.ctx.set_pipeline(self.in_flight)
         self._pending = (pool_ptr, F, off1, n1, off2, n2, assoc_ptr, assoc_off, u0_ptr, tag)
         return self.loop.one_call(0)
 
@@ -177,7 +209,7 @@ class AlignStream:
         self.loop.reset()
 
     def close(self):
-        self.ctx.set_pipeline(1)
+        self.ctx.set_pipeline(self._depth_before)
 
 
 def default_chunk(B):
@@ -198,7 +230,7 @@ def issue_chunked(ctx, P, pool, batch, kmax, a_out, n_out, T_out, st_out, stats_
     consecutive problems — up to MAX_ATTEMPTS times; with no sizing history for this parameter block (as far as this module has
     seen) the first call is waited for, so that the calls queued behind it size their pools from what it needed.
     -> the status array on the host (the caller decides what ROMAN_ST_INTERNAL / a still skipped problem mean).
-    Synchronises the context; leaves its pipeline depth at 1."""
+    Synchronises the context; its pipeline depth and team mode are restored on return."""
     B = len(batch)
     F = int(pool.shape[1])
     chunk = default_chunk(B) if chunk is None else max(1, int(chunk))
@@ -212,24 +244,27 @@ def issue_chunked(ctx, P, pool, batch, kmax, a_out, n_out, T_out, st_out, stats_
 
     status = np.zeros(0, dtype=np.int32)
     teams_off = False
+    depth_before = getattr(ctx, "pipeline_depth", 1)              # restored on return (an AlignStream on the same context keeps its depth)
+    teams_before = getattr(ctx, "wide_teams", -1)                 # a team mode the caller chose survives the teams-off retry
     ctx.set_pipeline(max(1, int(in_flight)))
     try:
         lo = 0
-        block = bytes(P) + int(F).to_bytes(4, "little")          # the library keeps ONE sizing history: that of the latest parameter block
-        if B and getattr(ctx, "_sized_block", None) != block:
+        # the library keeps ONE sizing history — that of the latest parameter block — and is asked for it (roman_ctx_has_history);
+        # a context without the query (a stand-in in the CPU tests) is treated as having none
+        has = getattr(ctx, "has_history", None)
+        if B and not (has(P, F) if has is not None else False):
             issue(0, min(B, chunk)); ctx.sync(); lo = min(B, chunk)
-        ctx._sized_block = block
         for l in range(lo, B, chunk):
             issue(l, min(B, l + chunk))
         again, teams_off = _abi.ROMAN_ST_WORKSPACE, False
         for attempt in range(1, MAX_ATTEMPTS + 1):
             ctx.sync()
             status = st_out.cpu().numpy()[:B]
-            if (status & _abi.ROMAN_ST_INTERNAL).any():
+            again = _abi.ROMAN_ST_WORKSPACE
+            if (status & _abi.ROMAN_ST_INTERNAL).any() and not teams_off and teams_before != 0:
                 # a team of the whole-device solver that could not hold its problem leaves ROMAN_ST_INTERNAL like an expired wait
-                # does: those problems once more with the whole device per problem; a second ROMAN_ST_INTERNAL is final
-                if teams_off:
-                    break
+                # does: those problems once more with the whole device per problem; a second ROMAN_ST_INTERNAL is final — but the
+                # problems still flagged ROMAN_ST_WORKSPACE keep being issued again while attempts remain
                 teams_off = True; ctx.set_wide_teams(0); again |= _abi.ROMAN_ST_INTERNAL
             skipped = np.nonzero((status & again) != 0)[0]
             if not len(skipped) or attempt == MAX_ATTEMPTS:
@@ -242,16 +277,18 @@ def issue_chunked(ctx, P, pool, batch, kmax, a_out, n_out, T_out, st_out, stats_
                 issue(int(skipped[b]), int(skipped[e - 1]) + 1)
                 b = e
     finally:
-        ctx.set_pipeline(1)
+        ctx.set_pipeline(depth_before)
         if teams_off:
-            ctx.set_wide_teams(-1)
+            ctx.set_wide_teams(teams_before)
     return status.copy()
 
 
 def align_resident(registration, batch, pool, chunk=None, in_flight=3, device=None, ctx=None, stats=True):
     """ONE batch of any size over a feature pool that is already in HBM (`pool`: the batch's (n_objects, F) float64 matrix as a
-    torch tensor on `device`) -> runtime.BatchResult on the host: issue_chunked() + the read-back.  ROMAN_ST_INTERNAL / a
-    problem still skipped after MAX_ATTEMPTS raise RomanHipError (the result so far in `.result`)."""
+    torch tensor on `device`) -> runtime.BatchResult on the host.  On a real context this is ONE library call
+    (roman_align_batch_resident: calls of `chunk` problems, `in_flight` at once, skipped problems issued again, one read-back);
+    a stand-in context without that entry gets issue_chunked() + the read-back of the torch outputs.  ROMAN_ST_INTERNAL / a
+    problem still skipped after MAX_ATTEMPTS raise RomanHipError (the result so far in `.result` where the library copied it)."""
     import torch
     from ..runtime import BatchResult, stats_dtype
     ctx = ctx or registration._context()
@@ -260,6 +297,18 @@ def align_resident(registration, batch, pool, chunk=None, in_flight=3, device=No
     B, kmax = len(batch), batch.kmax()
     if tuple(pool.shape) != tuple(batch.feats.shape) or pool.dtype != torch.float64:
         raise ValueError(f"pool must be the batch's feature matrix {batch.feats.shape} as a float64 tensor")
+    if hasattr(ctx, "align_batch_resident"):
+        # the library's own entry for resident inputs and host results (roman_align_batch_resident): it chunks, pipelines and
+        # re-issues as issue_chunked() does, and the whole result comes back with ONE copy through pinned memory
+        assoc_dev = None if batch.assoc is None else torch.from_numpy(np.ascontiguousarray(batch.assoc, dtype=np.int32)).to(dev)
+        torch.cuda.current_stream(dev).synchronize()           # the pool (and the list) are in place before the library's streams read them
+        before = getattr(ctx, "host_batching", (2048, 3))
+        ctx.set_host_batching(default_chunk(B) if chunk is None else max(1, int(chunk)), max(1, int(in_flight)))
+        try:
+            return ctx.align_batch_resident(P, pool.data_ptr(), int(pool.shape[1]), batch.off1, batch.n1, batch.off2, batch.n2, kmax,
+                                            assoc_ptr=None if assoc_dev is None else assoc_dev.data_ptr(), assoc_off=batch.assoc_off)
+        finally:
+            ctx.set_host_batching(*before)
     a_out = torch.full((max(B, 1), kmax, 2), -1, dtype=torch.int32, device=dev)
     n_out = torch.zeros(max(B, 1), dtype=torch.int32, device=dev)
     T_out = torch.zeros((max(B, 1), 16), dtype=torch.float64, device=dev)

@@ -82,6 +82,7 @@ struct roman_ctx {
         long long capMaskWords = 0, capNnz = 0, capList = 0;       // what the sparse pools hold (elements)
         // staging for the host-pointer entry points
         DevBuf hFeats, hAssoc, hU0, oAssoc, oN, oT, oStatus, oStats, hAux1, hAux2, hAux3;
+        DevBuf oAll;                           // outputs of a host-output batch call as ONE block (T | stats | assoc | n | status): one copy brings it back
         // totals of the most recent batch on this workspace, copied back without waiting
         BatchTotals* pinnedTotals = nullptr;
         ProbDesc* pinnedProbs = nullptr; size_t pinnedProbsCap = 0;   // staging of the problem descriptors (truly asynchronous upload)
@@ -103,6 +104,7 @@ struct roman_ctx {
     hipEvent_t evIn = nullptr;                 // inputs ready on the caller's stream
     // roman_align_batch (host pointers): a batch of more than host_chunk problems is issued as calls of host_chunk problems with
     // host_depth of them in flight (roman_ctx_set_host_batching)
+    void* hostOut = nullptr; size_t hostOutCap = 0;            // pinned landing block of the host-output entry points' single read-back
     int host_chunk = 2048, host_depth = 3;     // (config 4, 4096 pairs: 2 x 2048 take 37.7 ms, 8 x 512 41 ms — a call pays its launches and its own solver tail)
 
     // sizing history: largest observed need relative to what the host can bound before the launch
@@ -1236,7 +1238,7 @@ int roman_ctx_destroy(roman_ctx_t* c)
                          &W.lp, &W.li, &W.lj, &W.ls, &W.ld, &W.lza, &W.lzb, &W.plp, &W.pli, &W.plj, &W.pls, &W.pld, &W.plza, &W.plzb,
                          &W.rowCnt, &W.rowPos, &W.perm, &W.sliceWidth, &W.sliceBase, &W.items, &W.maskPool, &W.prefPool, &W.listPool, &W.listOff,
                          &W.vMu, &W.vCu, &W.vMun, &W.vCun, &W.gU, &W.gUn, &W.uOut, &W.nodesOrig, &W.nSel, &W.widePart, &W.wideSlots, &W.wideBar, &W.wideBm, &W.fbList, &W.cols16, &W.cols32, &W.vals, &W.colsC, &W.valsC,
-                         &W.hFeats, &W.hAssoc, &W.hU0, &W.oAssoc, &W.oN, &W.oT, &W.oStatus, &W.oStats, &W.hAux1, &W.hAux2, &W.hAux3};
+                         &W.hFeats, &W.hAssoc, &W.hU0, &W.oAssoc, &W.oN, &W.oT, &W.oStatus, &W.oStats, &W.hAux1, &W.hAux2, &W.hAux3, &W.oAll};
         for (DevBuf* b : all) b->release();
         if (W.pinnedTotals) (void)hipHostFree(W.pinnedTotals);
         if (W.totEvent) (void)hipEventDestroy(W.totEvent);
@@ -1245,6 +1247,7 @@ int roman_ctx_destroy(roman_ctx_t* c)
         for (int s = 0; s < ROMAN_STAGE_COUNT; ++s) { if (W.evA[s]) (void)hipEventDestroy(W.evA[s]); if (W.evB[s]) (void)hipEventDestroy(W.evB[s]); }
         if (W.done) (void)hipEventDestroy(W.done);
     }
+    if (c->hostOut) (void)hipHostFree(c->hostOut);
     if (c->evIn) (void)hipEventDestroy(c->evIn);
     if (c->coopDone) (void)hipEventDestroy(c->coopDone);
     for (int k = 0; k < ROMAN_MAX_PIPELINE; ++k) if (c->istream[k]) (void)hipStreamDestroy(c->istream[k]);
@@ -1394,6 +1397,16 @@ int roman_align_batch_dev(roman_ctx_t* c, const roman_params_t* params, int32_t 
     return ROMAN_OK;
 }
 
+int roman_ctx_has_history(roman_ctx_t* c, const roman_params_t* params, int32_t F, int32_t* yes)
+{
+    if (!c) return fail(nullptr, ROMAN_E_INVALID, "ctx is NULL");
+    if (!params || !yes) return fail(c, ROMAN_E_INVALID, "NULL argument");
+    harvest_totals(c, false);
+    const roman_ctx::Hist& H = c->hist;
+    *yes = (H.valid && H.tagged && H.F == F && memcmp(&H.params, params, sizeof(roman_params_t)) == 0) ? 1 : 0;
+    return ROMAN_OK;
+}
+
 int roman_ctx_set_wide_teams(roman_ctx_t* c, int teams_per_xcd)
 {
     if (!c) return fail(nullptr, ROMAN_E_INVALID, "ctx is NULL");
@@ -1468,13 +1481,16 @@ int align_chunked(roman_ctx* c, const roman_params_t* params, const BatchIn& in,
         int nskip = 0, nint = 0;
         for (int b = 0; b < B; ++b) { nskip += (st[b] & ROMAN_ST_WORKSPACE) ? 1 : 0; nint += (st[b] & ROMAN_ST_INTERNAL) ? 1 : 0; }
         int again = ROMAN_ST_WORKSPACE;
-        if (nint) {
+        if (nint && c->teams_launched && !no_teams_tried) {
             // a team of the whole-device solver that could not hold its problem leaves ROMAN_ST_INTERNAL like an expired wait does:
-            // those problems once more, the whole device on one problem at a time; a second ROMAN_ST_INTERNAL is final
-            if (!c->teams_launched || no_teams_tried) break;
+            // those problems once more, the whole device on one problem at a time
             no_teams_tried = true; c->wide_teams = 0; again |= ROMAN_ST_INTERNAL;
-        } else if (!nskip) break;
-        if (attempt >= MAX_ATTEMPTS) return restore2(fail(c, ROMAN_E_NOMEM, "the sparse workspace of %d problem(s) still does not fit after %d attempts", nskip, attempt));
+        } else if (!nskip) break;                              // nothing left to issue again (a remaining ROMAN_ST_INTERNAL is final: the caller reports it)
+        // (a final ROMAN_ST_INTERNAL does not end the loop while skipped problems remain: they are still solvable)
+        if (attempt >= MAX_ATTEMPTS) {
+            if (!nskip) break;                                  // only the teams-off retry was pending: the ROMAN_ST_INTERNAL records speak for themselves
+            return restore2(fail(c, ROMAN_E_NOMEM, "the sparse workspace of %d problem(s) still does not fit after %d attempts", nskip, attempt));
+        }
         for (int b = 0; b < B; ) {                              // runs of consecutive problems to issue again, at most a chunk long
             if (!(st[b] & again)) { ++b; continue; }
             int e = b + 1;
@@ -1485,6 +1501,83 @@ int align_chunked(roman_ctx* c, const roman_params_t* params, const BatchIn& in,
         }
     }
     return restore2(ROMAN_OK);
+}
+}  // namespace
+
+namespace {
+// The synchronous part shared by the two host-output entry points: inputs are on the device (`in`, dU0), the outputs of every call
+// land in ONE device block (T | stats | assoc | n | status) and come back with ONE copy through a pinned landing block — a single
+// pair's whole result is 1.8 KB, and five separate read-backs cost more than its build kernels.
+int align_to_host(roman_ctx* c, const DevParams& D, const roman_params_t* params, const BatchIn& in, const double* dU0,
+                  int32_t kmax, int32_t* assoc_out, int32_t* n_assoc_out, double* T_out, int32_t* status_out, roman_stats_t* stats_out)
+{
+    const int32_t B = in.B;
+    int rc = ROMAN_OK;
+    bool copied = false;
+    const size_t kb = (size_t)B * (size_t)std::max(kmax, 1);
+    const size_t oT = 0, oS = oT + sizeof(double) * 16 * (size_t)B, oA = oS + sizeof(roman_stats_t) * (size_t)B,
+                 oNn = oA + sizeof(int32_t) * 2 * kb, oSt = oNn + sizeof(int32_t) * (size_t)B, total = oSt + sizeof(int32_t) * (size_t)B;
+    static_assert(sizeof(roman_stats_t) % 8 == 0, "the blocks behind the statistics stay 8-byte aligned");
+    HIPCHK(c, WS.oAll.ensure(total));
+    if (c->hostOutCap < total) {
+        if (c->hostOut) { (void)hipHostFree(c->hostOut); c->hostOut = nullptr; c->hostOutCap = 0; }
+        const size_t want = total + total / 4 + 4096;
+        HIPCHK(c, hipHostMalloc(&c->hostOut, want, hipHostMallocDefault));
+        c->hostOutCap = want;
+    }
+    char* const dev = WS.oAll.as<char>();
+    const BatchOut out{kmax, reinterpret_cast<int32_t*>(dev + oA), reinterpret_cast<int32_t*>(dev + oNn), reinterpret_cast<double*>(dev + oT),
+                       reinterpret_cast<int32_t*>(dev + oSt), reinterpret_cast<roman_stats_t*>(dev + oS)};
+    if (B > c->host_chunk && c->host_depth >= 2) {
+        // many problems: calls of host_chunk problems, host_depth of them in flight, skipped problems issued again (align_chunked)
+        rc = align_chunked(c, params, in, dU0, out);
+        if (rc) return rc;
+    } else
+    // this entry point is synchronous anyway: when a problem did not fit the speculatively sized pools, run again
+    // with the need the first attempt recorded
+    {
+        const int teams_saved = c->wide_teams;
+        for (int attempt = 0; ; ++attempt) {
+            c->teams_launched = false;
+            rc = run_batch(c, D, params, in, dU0, out);
+            if (rc) { c->wide_teams = teams_saved; return rc; }
+            // the read-back rides behind the batch on the same stream: ONE wait covers both (a retry below overwrites the landing block)
+            if (hipMemcpyAsync(c->hostOut, dev, total, hipMemcpyDeviceToHost, WS.stream) != hipSuccess) { (void)hipGetLastError(); c->wide_teams = teams_saved; return fail(c, ROMAN_E_HIP, "result read-back failed"); }
+            if (hipStreamSynchronize(WS.stream) != hipSuccess) { (void)hipGetLastError(); c->wide_teams = teams_saved; return fail(c, ROMAN_E_HIP, "hipStreamSynchronize failed"); }
+            copied = true;
+            if (batch_overflowed(c)) {
+                if (attempt + 1 >= MAX_ATTEMPTS) { c->wide_teams = teams_saved; return fail(c, ROMAN_E_NOMEM, "the sparse workspace still does not fit after %d attempts", attempt + 1); }
+                continue;
+            }
+            if (c->teams_launched && c->wide_teams != 0) {      // a team that could not hold its problem leaves ROMAN_ST_INTERNAL: once more, the whole device per problem
+                const int32_t* stv = reinterpret_cast<const int32_t*>(static_cast<const char*>(c->hostOut) + oSt);
+                bool anyInt = false;
+                for (int b = 0; b < B; ++b) anyInt = anyInt || (stv[b] & ROMAN_ST_INTERNAL);
+                if (anyInt && attempt + 1 < MAX_ATTEMPTS) { c->wide_teams = 0; continue; }
+            }
+            break;
+        }
+        c->wide_teams = teams_saved;
+    }
+    if (!copied) {
+        HIPCHK(c, hipMemcpyAsync(c->hostOut, dev, total, hipMemcpyDeviceToHost, WS.stream));
+        HIPCHK(c, hipStreamSynchronize(WS.stream));
+    }
+    {
+        const char* h = static_cast<const char*>(c->hostOut);
+        if (kmax > 0) memcpy(assoc_out, h + oA, sizeof(int32_t) * 2 * (size_t)B * (size_t)kmax);
+        memcpy(n_assoc_out, h + oNn, sizeof(int32_t) * (size_t)B);
+        memcpy(T_out, h + oT, sizeof(double) * 16 * (size_t)B);
+        memcpy(status_out, h + oSt, sizeof(int32_t) * (size_t)B);
+        if (stats_out) memcpy(stats_out, h + oS, sizeof(roman_stats_t) * (size_t)B);
+    }
+    c->last.scored = false; c->last.solved = false;
+    {   // a problem the whole-device solver gave up on has no result: an error, not a quiet "0 associations"
+        int nint = 0, first = -1;
+        for (int b = 0; b < B; ++b) if (status_out[b] & ROMAN_ST_INTERNAL) { if (first < 0) first = b; ++nint; }
+        if (nint) return fail(c, ROMAN_E_INTERNAL, "%d problem(s) reported ROMAN_ST_INTERNAL (first: %d): a bounded wait of the whole-device solver expired", nint, first);
+    }
+    return ROMAN_OK;
 }
 }  // namespace
 
@@ -1536,55 +1629,39 @@ int roman_align_batch(roman_ctx_t* c, const roman_params_t* params, int32_t B,
         if (sumA > 0) HIPCHK(c, hipMemcpyAsync(WS.hU0.p, u0, sizeof(double) * (size_t)sumA, hipMemcpyHostToDevice, WS.stream));
         dU0 = WS.hU0.as<double>();
     }
-    const size_t kb = (size_t)B * (size_t)std::max(kmax, 1);
-    HIPCHK(c, WS.oAssoc.ensure(sizeof(int32_t) * 2 * kb)); HIPCHK(c, WS.oN.ensure(sizeof(int32_t) * (size_t)B));
-    HIPCHK(c, WS.oT.ensure(sizeof(double) * 16 * (size_t)B)); HIPCHK(c, WS.oStatus.ensure(sizeof(int32_t) * (size_t)B));
-    HIPCHK(c, WS.oStats.ensure(sizeof(roman_stats_t) * (size_t)B));
     const BatchIn in{B, WS.hFeats.as<double>(), off1, n1, off2, n2, F, dA, assoc_off};
-    const BatchOut out{kmax, WS.oAssoc.as<int32_t>(), WS.oN.as<int32_t>(), WS.oT.as<double>(), WS.oStatus.as<int32_t>(), WS.oStats.as<roman_stats_t>()};
-    if (B > c->host_chunk && c->host_depth >= 2) {
-        // many problems: calls of host_chunk problems, host_depth of them in flight, skipped problems issued again (align_chunked)
-        rc = align_chunked(c, params, in, dU0, out);
-        if (rc) return rc;
-    } else
-    // this entry point is synchronous anyway: when a problem did not fit the speculatively sized pools, run again
-    // with the need the first attempt recorded
-    {
-        const int teams_saved = c->wide_teams;
-        for (int attempt = 0; ; ++attempt) {
-            c->teams_launched = false;
-            rc = run_batch(c, D, params, in, dU0, out);
-            if (rc) { c->wide_teams = teams_saved; return rc; }
-            if (hipStreamSynchronize(WS.stream) != hipSuccess) { (void)hipGetLastError(); c->wide_teams = teams_saved; return fail(c, ROMAN_E_HIP, "hipStreamSynchronize failed"); }
-            if (batch_overflowed(c)) {
-                if (attempt + 1 >= MAX_ATTEMPTS) { c->wide_teams = teams_saved; return fail(c, ROMAN_E_NOMEM, "the sparse workspace still does not fit after %d attempts", attempt + 1); }
-                continue;
-            }
-            if (c->teams_launched && c->wide_teams != 0) {      // a team that could not hold its problem leaves ROMAN_ST_INTERNAL: once more, the whole device per problem
-                std::vector<int32_t> stv((size_t)B);
-                if (hipMemcpy(stv.data(), WS.oStatus.p, sizeof(int32_t) * (size_t)B, hipMemcpyDeviceToHost) == hipSuccess) {
-                    bool anyInt = false;
-                    for (int b = 0; b < B; ++b) anyInt = anyInt || (stv[b] & ROMAN_ST_INTERNAL);
-                    if (anyInt && attempt + 1 < MAX_ATTEMPTS) { c->wide_teams = 0; continue; }
-                } else (void)hipGetLastError();
-            }
-            break;
-        }
-        c->wide_teams = teams_saved;
+    return align_to_host(c, D, params, in, dU0, kmax, assoc_out, n_assoc_out, T_out, status_out, stats_out);
+}
+
+/* roman_align_batch_resident: inputs in HBM (as roman_align_batch_dev), results on the HOST (as roman_align_batch). */
+int roman_align_batch_resident(roman_ctx_t* c, const roman_params_t* params, int32_t B,
+                               const double* feats, const int64_t* off1, const int32_t* n1,
+                               const int64_t* off2, const int32_t* n2, int32_t F,
+                               const int32_t* assoc, const int64_t* assoc_off, const double* u0,
+                               int32_t kmax, int32_t* assoc_out, int32_t* n_assoc_out,
+                               double* T_out, int32_t* status_out, roman_stats_t* stats_out)
+{
+    if (!c) return fail(nullptr, ROMAN_E_INVALID, "ctx is NULL");
+    if (B < 0 || F < 0) return fail(c, ROMAN_E_INVALID, "negative size");
+    if (B == 0) return ROMAN_OK;
+    if (!off1 || !n1 || !off2 || !n2 || !assoc_out || !n_assoc_out || !T_out || !status_out || kmax < 0)
+        return fail(c, ROMAN_E_INVALID, "NULL metadata/output pointer or kmax < 0");
+    if (assoc && !assoc_off) return fail(c, ROMAN_E_INVALID, "assoc given without assoc_off");
+    if (assoc && assoc_off[0] != 0) return fail(c, ROMAN_E_INVALID, "assoc_off[0] must be 0");
+    bool any = false;
+    for (int b = 0; b < B; ++b) {
+        if (n1[b] < 0 || n2[b] < 0 || off1[b] < 0 || off2[b] < 0) return fail(c, ROMAN_E_INVALID, "problem %d: negative size or offset", b);
+        if (assoc && assoc_off[b + 1] < assoc_off[b]) return fail(c, ROMAN_E_INVALID, "assoc_off is not non-decreasing at problem %d", b);
+        any = any || n1[b] > 0 || n2[b] > 0;
     }
-    if (kmax > 0) HIPCHK(c, hipMemcpyAsync(assoc_out, WS.oAssoc.p, sizeof(int32_t) * 2 * (size_t)B * (size_t)kmax, hipMemcpyDeviceToHost, WS.stream));
-    HIPCHK(c, hipMemcpyAsync(n_assoc_out, WS.oN.p, sizeof(int32_t) * (size_t)B, hipMemcpyDeviceToHost, WS.stream));
-    HIPCHK(c, hipMemcpyAsync(T_out, WS.oT.p, sizeof(double) * 16 * (size_t)B, hipMemcpyDeviceToHost, WS.stream));
-    HIPCHK(c, hipMemcpyAsync(status_out, WS.oStatus.p, sizeof(int32_t) * (size_t)B, hipMemcpyDeviceToHost, WS.stream));
-    if (stats_out) HIPCHK(c, hipMemcpyAsync(stats_out, WS.oStats.p, sizeof(roman_stats_t) * (size_t)B, hipMemcpyDeviceToHost, WS.stream));
-    HIPCHK(c, hipStreamSynchronize(WS.stream));
-    c->last.scored = false; c->last.solved = false;
-    {   // a problem the whole-device solver gave up on has no result: an error, not a quiet "0 associations"
-        int nint = 0, first = -1;
-        for (int b = 0; b < B; ++b) if (status_out[b] & ROMAN_ST_INTERNAL) { if (first < 0) first = b; ++nint; }
-        if (nint) return fail(c, ROMAN_E_INTERNAL, "%d problem(s) reported ROMAN_ST_INTERNAL (first: %d): a bounded wait of the whole-device solver expired", nint, first);
-    }
-    return ROMAN_OK;
+    if (!feats && any) return fail(c, ROMAN_E_INVALID, "feats is NULL");
+    HIPCHK(c, hipSetDevice(c->device));
+    { int rc0 = use_ws0(c); if (rc0) return rc0; }
+    DevParams D;
+    int rc = make_dev_params(c, params, F, &D);
+    if (rc) return rc;
+    const BatchIn in{B, feats, off1, n1, off2, n2, F, assoc, assoc_off};
+    return align_to_host(c, D, params, in, u0, kmax, assoc_out, n_assoc_out, T_out, status_out, stats_out);
 }
 
 // --- the deal of a batch over ranks (pure host function; roman_amd.align.distributed.deal_by_cost states the same) ------------

@@ -51,6 +51,9 @@ class Context:
         # that replaces or invalidates it bumps this counter; holders of a problem (the clipperpy shim's CLIPPER
         # objects) remember the value they loaded at and re-send their inputs when it has moved on.
         self._generation = 0
+        self.pipeline_depth = 1                 # what set_pipeline() last set (callers that change it restore it)
+        self.wide_teams = -1                    # what set_wide_teams() last set
+        self.host_batching = (2048, 3)          # what set_host_batching() last set (the library's defaults)
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
@@ -67,6 +70,7 @@ class Context:
         """Batches in flight (1 ... 6), see roman_ctx_set_pipeline in include/roman_hip.h.  With depth 2 the
         results of align_batch_dev calls are complete after sync() (or a device-wide synchronise)."""
         self._check(self._lib.roman_ctx_set_pipeline(self._h, int(depth)), "roman_ctx_set_pipeline")
+        self.pipeline_depth = int(depth)
 
     def sync(self):
         self._check(self._lib.roman_ctx_sync(self._h), "roman_ctx_sync")
@@ -75,12 +79,21 @@ class Context:
         """How align_batch() (host pointers) issues a large batch: more than `chunk` problems go to the device as calls of
         `chunk` problems with `depth` of them in flight (roman_ctx_set_host_batching; depth 1 = one call for everything)."""
         self._check(self._lib.roman_ctx_set_host_batching(self._h, int(chunk), int(depth)), "roman_ctx_set_host_batching")
+        self.host_batching = (int(chunk), int(depth))
 
     def set_wide_teams(self, teams_per_xcd=-1):
         """Team mode of the whole-device solver for large live sets (roman_ctx_set_wide_teams): -1 automatic, 0 never, 1 / 2 / 4
         teams per XCD.  A device-pointer caller that gets ROMAN_ST_INTERNAL records back from a batch with several large live
         sets issues those problems again with 0 (pipeline.issue_chunked does)."""
         self._check(self._lib.roman_ctx_set_wide_teams(self._h, int(teams_per_xcd)), "roman_ctx_set_wide_teams")
+        self.wide_teams = int(teams_per_xcd)
+
+    def has_history(self, params, F):
+        """Does the library hold a sizing history for this parameter block (roman_ctx_has_history)?  Without one the first of
+        several queued calls should be waited for, so that the others size their pools from what it needed."""
+        yes = C.c_int32(0)
+        self._check(self._lib.roman_ctx_has_history(self._h, C.byref(params), int(F), C.byref(yes)), "roman_ctx_has_history")
+        return bool(yes.value)
 
     def join(self, skip_latest=False, stream=None):
         """Make the context's stream — or `stream` (a hipStream_t handle, e.g. torch.cuda.Stream.cuda_stream) — wait for the
@@ -146,6 +159,34 @@ class Context:
         self._check(rc, "roman_align_batch")
         Ts = T[:, :s * s].reshape(B, s, s).copy()
         return BatchResult([a_out[b, :n_out[b]].copy() for b in range(B)], Ts, status, stats)
+
+    def align_batch_resident(self, params, feats_ptr, F, off1, n1, off2, n2, kmax=None, assoc_ptr=None, assoc_off=None, u0_ptr=None):
+        """Inputs in HBM (device pointers as integers, e.g. torch.Tensor.data_ptr()), results on the host
+        (roman_align_batch_resident): -> BatchResult.  Synchronous; the library chunks, pipelines and retries like align_batch(),
+        and the whole result comes back with one copy."""
+        off1 = np.ascontiguousarray(off1, dtype=np.int64); off2 = np.ascontiguousarray(off2, dtype=np.int64)
+        n1 = np.ascontiguousarray(n1, dtype=np.int32); n2 = np.ascontiguousarray(n2, dtype=np.int32)
+        B = int(n1.shape[0])
+        if assoc_off is not None:
+            assoc_off = np.ascontiguousarray(assoc_off, dtype=np.int64)
+        if kmax is None:
+            kmax = int(max(1, np.max(np.minimum(n1, n2)))) if B else 1
+        a_out = np.empty((B, kmax, 2), dtype=np.int32); n_out = np.empty(B, dtype=np.int32)
+        T = np.empty((B, 16), dtype=np.float64); status = np.empty(B, dtype=np.int32); stats = np.empty(B, dtype=stats_dtype())
+        vp = lambda x: C.c_void_p(int(x)) if x else None
+        self._generation += 1
+        rc = self._lib.roman_align_batch_resident(self._h, C.byref(params), B, vp(feats_ptr), _ptr(off1), _ptr(n1), _ptr(off2), _ptr(n2),
+                                                  int(F), vp(assoc_ptr), _ptr(assoc_off), vp(u0_ptr), int(kmax),
+                                                  _ptr(a_out), _ptr(n_out), _ptr(T), _ptr(status), _ptr(stats))
+        s = params.point_dim + 1
+        res = lambda: BatchResult([a_out[b, :n_out[b]].copy() for b in range(B)], T[:, :s * s].reshape(B, s, s).copy(), status, stats)
+        if rc == _abi.ROMAN_E_INTERNAL:                          # outputs were copied: the error says which problems have no result
+            msg = self._lib.roman_last_error(self._h)
+            err = RomanHipError(f"roman_align_batch_resident failed ({rc}): {msg.decode() if msg else ''}")
+            err.result = res()
+            raise err
+        self._check(rc, "roman_align_batch_resident")
+        return res()
 
     def align_batch_dev(self, params, feats_ptr, F, off1, n1, off2, n2, kmax, assoc_out_ptr, n_assoc_out_ptr,
                         T_out_ptr, status_out_ptr, stats_out_ptr=None, assoc_ptr=None, assoc_off=None,

@@ -29,6 +29,7 @@ class OracleContext:
         self.internal_with_teams = set(internal_with_teams)
         self.calls = []                                # (pipeline depth, problems) of every call
         self.pipeline, self.wide_teams, self.syncs = 1, -1, 0
+        self._block, self._hist = None, None           # parameter block of the latest call / the ONE block the sizing history is for
 
     def set_pipeline(self, depth):
         self.pipeline = int(depth)
@@ -38,11 +39,20 @@ class OracleContext:
 
     def sync(self):
         self.syncs += 1
+        if self._block is not None:                    # a finished batch has reported what it needed (roman_ctx_has_history)
+            self._hist = self._block
+
+    def join(self, skip_latest=False, stream=None):      # every call of this stand-in is complete when it returns
+        pass
+
+    def has_history(self, P, F):
+        return self._hist == bytes(P) + int(F).to_bytes(4, "little")
 
     def align_batch_dev(self, P, feats_ptr, F, off1, n1, off2, n2, kmax, a_ptr, n_ptr, T_ptr, st_ptr, stats_ptr=None,
                         assoc_ptr=None, assoc_off=None, u0_ptr=None):
         B = len(n1)
         self.calls.append((self.pipeline, B, self.syncs))
+        self._block = bytes(P) + int(F).to_bytes(4, "little")
         feats = _view(feats_ptr, (self.n_objects, F), np.float64)
         a_out = _view(a_ptr, (B, kmax, 2), np.int32); n_out = _view(n_ptr, (B,), np.int32)
         T_out = _view(T_ptr, (B, 16), np.float64); st_out = _view(st_ptr, (B,), np.int32)

@@ -46,6 +46,28 @@ def _compare(orc, reg, res, problems):
     return bad, worst, traj
 
 
+def _as_published(orc, P, feats, off1, n1, off2, n2, kmax, res):
+    """The same problems once more through the oracle AS PUBLISHED — pass mode `carried` (every pass forms M x and C x, the
+    accepted trial's products are carried to the d update: findDenseClique's own order) and PLAIN arithmetic (sequential
+    descriptor dot, glibc exp / cbrt instead of the stated-order sequences the device reproduces) — i.e. with nothing of the
+    oracle shaped after the device.  -> (problems whose association array — indices AND order — or pose differs, worst pose
+    error, number of problems whose pass count differs from the device's (reported, not asserted: the device counts one
+    split pass per d update))."""
+    with orc.pass_mode("carried"), orc.plain_arith():
+        many = orc.register_many(P, feats, off1, n1, off2, n2, kmax, faithful=False)
+    bad, worst = [], 0.0
+    for b in range(len(n1)):
+        a = many[b]
+        same = np.array_equal(res.assoc[b], a)
+        if len(a) >= 3:
+            T_o = orc.t_align(feats[off1[b] + a[:, 0], :3], feats[off2[b] + a[:, 1], :3])
+            err = float(np.linalg.norm(res.T[b] - T_o)); worst = max(worst, err)
+            same = same and err < POSE_TOL
+        if not same:
+            bad.append(b)
+    return bad, worst
+
+
 def test_config3_every_one_of_the_256_pairs_matches_the_oracle(ctx, orc):
     reg = registration_for("semanticgrav", semantics_dim=512); reg.set_context(ctx)
     pairs = [synth.make_pair(200, 200, 512, 3000 + k) for k in range(256)]
@@ -59,6 +81,10 @@ def test_config3_every_one_of_the_256_pairs_matches_the_oracle(ctx, orc):
     assert not bad, f"{len(bad)} of 256 problems differ from the oracle: {bad[:10]}"
     assert worst < POSE_TOL and len(traj) <= 12
     assert (res.stats["n_assoc_in"] == 40000).all()
+    # ... and against the oracle as published (carried passes, libm, sequential dot): same associations incl. order, same poses
+    bad_p, worst_p = _as_published(orc, reg._abi_params(), batch.feats, batch.off1, batch.n1, batch.off2, batch.n2, batch.kmax(), res)
+    print(f"config 3 vs the oracle as published (carried + plain arithmetic): {256 - len(bad_p)}/256 identical, worst pose error {worst_p:.2e}")
+    assert not bad_p, f"{len(bad_p)} of 256 problems differ from the published-order oracle: {bad_p[:10]}"
 
 
 def test_config4_grid_16x16_every_pair_matches_the_oracle(ctx, orc):
@@ -104,6 +130,9 @@ def test_config4_full_64x64_grid_all_4096_pairs_match_the_oracle(ctx, orc):
     print(f"config 4, full grid: {S * S - len(bad)}/{S * S} identical results, worst pose error {worst:.2e}, most passes {int(res.stats['n_pass'].max())}")
     assert not bad, f"{len(bad)} of {S * S} grid problems differ from the oracle: {bad[:10]}"
     assert worst < POSE_TOL
+    bad_p, worst_p = _as_published(orc, reg._abi_params(), batch.feats, batch.off1, batch.n1, batch.off2, batch.n2, batch.kmax(), res)
+    print(f"config 4 vs the oracle as published (carried + plain arithmetic): {S * S - len(bad_p)}/{S * S} identical, worst pose error {worst_p:.2e}")
+    assert not bad_p, f"{len(bad_p)} of {S * S} grid problems differ from the published-order oracle: {bad_p[:10]}"
 
 
 def test_demo_scale_1024_pairs_match_the_oracle(ctx, orc):

@@ -138,3 +138,75 @@ def test_chunked_align_sharded_world_size_2_gloo():
         assert status == serial.status.tolist()
         assert max(calls) <= 3 and len(calls) >= 3                  # a rank's share in calls of at most 3 problems (+ the re-issues)
     assert sum(sum(o[4]) for o in outs) >= 16 + 2                   # every problem once, the two skipped ones twice
+
+
+def _stream_worker(rank, world, port, q, in_flight):
+    """The loop bench.py times at N > 1 (BASELINE config 4, strong scaling), on CPU tensors: the grid's pairs dealt by
+    deal_by_cost, a rank's share as calls of `chunk` problems through the package's AlignStream WITH the process group — every
+    call's fixed-size byte records collected on every rank by ONE all_gather_into_tensor."""
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from roman_amd.align.distributed import deal_by_cost, problem_work
+        from roman_amd.align.pipeline import AlignStream
+        reg = registration_for("gravity")
+        batch = _grid(reg)
+        shards = deal_by_cost(problem_work(batch), world)
+        mine = shards[rank]
+        chunk = 3
+        kmax = batch.kmax()
+        stub = OracleContext(batch.feats.shape[0])
+        pool = torch.from_numpy(batch.feats.copy())
+        seen = []                                                   # (tag, ints, poses) of every collection, in order
+
+        def on_collect(k, tag):
+            seen.append((tag, S.gathered_ints.clone().numpy(), S.gathered_T.clone().numpy()))
+        S = AlignStream(reg, stub, torch.device("cpu"), rows=chunk, kmax=kmax, in_flight=in_flight, use_group=True, on_collect=on_collect)
+        ncalls = max(-(-len(s) // chunk) for s in shards)            # every rank issues the same number of calls (a collective per call)
+        for c in range(ncalls):
+            ix = mine[c * chunk:(c + 1) * chunk]
+            S.submit(pool.data_ptr(), batch.feats.shape[1], batch.off1[ix], batch.n1[ix], batch.off2[ix], batch.n2[ix], tag=c)
+        S.drain()
+        q.put((rank, S.gathers, [(t, i.tolist(), np.nan_to_num(p, nan=-1.0).tolist()) for t, i, p in seen], [c[1] for c in stub.calls]))
+        S.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("in_flight", [1, 3])
+def test_align_stream_with_a_process_group_one_gather_per_call_world_size_2_gloo(in_flight):
+    import torch.multiprocessing as mp
+    from roman_amd.align.distributed import deal_by_cost, problem_work
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_stream_worker, args=(r, 2, port, q, in_flight)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    reg = registration_for("gravity")
+    batch = _grid(reg)
+    serial = oracle_compute(reg, batch)
+    shards = deal_by_cost(problem_work(batch), 2)
+    chunk, kmax = 3, batch.kmax()
+    ncalls = max(-(-len(s_) // chunk) for s_ in shards)
+    for rank, gathers, seen, calls in outs:
+        assert gathers == ncalls == len(seen)                       # ONE collective per call, nothing else
+        assert [t for t, _, _ in seen] == list(range(ncalls))       # collected in issue order
+        for c, ints, poses in seen:
+            ints = np.array(ints); poses = np.array(poses)
+            assert ints.shape == (2 * chunk, 2 + 2 * kmax) and poses.shape == (2 * chunk, 16)
+            for r in range(2):                                      # rows [r * rows, (r + 1) * rows) hold rank r's records of call c
+                ix = shards[r][c * chunk:(c + 1) * chunk]
+                for j, b in enumerate(ix):
+                    row = ints[r * chunk + j]
+                    k = int(row[0])
+                    assert row[1] == serial.status[b] and np.array_equal(row[2:2 + 2 * k].reshape(-1, 2), serial.assoc[b]), (rank, c, r, b)
+                    if serial.status[b] == 0:
+                        assert np.allclose(poses[r * chunk + j].reshape(4, 4), serial.T[b])
+        assert all(n <= chunk for n in calls)
