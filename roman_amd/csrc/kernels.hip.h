@@ -66,6 +66,8 @@ struct DevParams {
                              // k_small): a problem k_small leaves behind is skipped (kind 2, ROMAN_ST_WORKSPACE) and takes them on its second run
     int32_t stream_maxL;     // problems of up to this many live associations take the stream layout (<= STREAM_MAXL; set per launch:
                              // it is also the column capacity of k_fill_slice's LDS tile and of the stream solver's LDS vectors)
+    int32_t pre_K;           // k_count's integer prefilter: a pair goes to the exact gate iff its two quantised table entries differ by at most pre_K bins
+    double  pre_invw;        // ... bins per metre (1 / bin width; bin width = epsilon / 8)
 };
 
 struct ProbDesc {
@@ -1465,6 +1467,168 @@ __device__ __forceinline__ void count_rows_lds(const DevParams& D, const ProbDes
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same pair tests with CANDIDATE GENERATION in front of the exact gate (round 6).  Every reading of the gate needs
+// |TA[i][i'] - TB[j][j']| < epsilon (the horizontal / full-length difference is one of its terms and the other is >= 0), and only
+// ~3 % of the live pairs pass it: the sweep therefore tests the pair's two table entries as 16-bit BIN numbers (bin width epsilon / 8,
+// quantised once per row next to the f64 table slices: two ds_read_u16 gathers, one v_sad, one compare per 64 columns and row
+// instead of two f64 gathers and twelve f64 operations), compacts the survivors (~6 % of the columns) into a per-wave LDS queue
+// and runs the EXISTING exact f64 gate on the queue, 64 candidates at a time with every lane busy; a passing candidate sets its
+// bit in the row's mask words in LDS (ds_or_b64), which go out coalesced at the end of the row.
+// The prefilter is a superset of the gate by construction: q(x) = min(trunc(x * invw), 0xff00) is monotone, so |a - b| <= eps'
+// gives |q(a) - q(b)| <= ceil(eps' * invw + rounding) <= 8 + 1; pre_K is 10.  NaN entries (the same object twice, or closer than
+// mindist) are bin 0xffff: a NaN never meets a finite entry (clamped at 0xff00), and a NaN-NaN pair is rejected by the exact gate
+// like every other false positive.  The exact gate sees the same operands in the same operation order as count_rows_lds: the
+// mask words are bit-identical (tests/test_gpu_parity.py runs the ladder and the +-1-ulp plants through both kernels).
+// ---------------------------------------------------------------------------------------------
+// per-wave LDS of the prefiltered sweep behind the table slices: NR mask rows (TC / 64 words), NR bin slices, the queue
+__host__ __device__ constexpr int count_pre_wave_bytes(int NR, int ldsPerRow, int TC)
+{
+    return NR * (TC >> 6) * 8 + ((NR * ldsPerRow + 3) & ~3) * 2 + (64 + NR * 2 * 64) * 2;
+}
+__device__ __forceinline__ uint32_t quant_bin(double v, double invw)
+{
+    const double t = __builtin_fmin(v * invw, 65280.0);         // (v >= 0: a distance; NaN * invw = NaN -> fmin gives 65280: overridden below)
+    return (v == v) ? (uint32_t)t : 0xffffu;
+}
+
+template <int GM, int NR>
+__device__ __forceinline__ void count_rows_pre(const DevParams& D, const ProbDesc& pd, int L, int row0, int nrows,
+                                               int w, int wpb, int lane,
+                                               const uint32_t* cIJ /* i_q | (n1 + 1 + j_q) << 16: table-slice indices, Lpad entries */,
+                                               const double* __restrict__ TA, const double* __restrict__ TB,
+                                               double* tA /* NR slices of ldsPerRow doubles */, int ldsPerRow,
+                                               uint16_t* qS /* NR slices of ldsPerRow bins */, uint16_t* queue /* 64 + NR * 2 * 64 entries */,
+                                               unsigned long long* rmask /* NR rows of Wcap words, zero on entry and on exit */, int Wcap,
+                                               unsigned long long* __restrict__ mbase,
+                                               const double* __restrict__ gZa, const double* __restrict__ gZb)
+{
+    const int W = (L + 63) >> 6;
+    const char* tbytes = reinterpret_cast<const char*>(tA);
+    const char* qbytes = reinterpret_cast<const char*>(qS);
+    const int sliceBytes = ldsPerRow * 8, qsliceBytes = ldsPerRow * 2;
+    constexpr int U = 2;
+    const int Lpad = (L + U * WAVE - 1) & ~(U * WAVE - 1);
+    const double invw = D.pre_invw;
+    const uint32_t K = (uint32_t)D.pre_K;
+    constexpr int TR = 4;
+    const bool pre = pd.n1 <= TR * WAVE && pd.n2 <= TR * WAVE;
+    double ra[NR][TR], rb[NR][TR];
+    auto fetch_tab = [&](int r_) {
+#pragma unroll
+        for (int x = 0; x < NR; ++x) {
+            const int k_ = row0 + min(r_ + x, nrows - 1);
+            const int i_ = (int)(cIJ[k_] & 0xffffu), j_ = (int)(cIJ[k_] >> 16) - (pd.n1 + 1);
+            const double* gA_ = TA + (int64_t)i_ * pd.n1;
+            const double* gB_ = TB + (int64_t)j_ * pd.n2;
+#pragma unroll
+            for (int m_ = 0; m_ < TR; ++m_) {
+                ra[x][m_] = (lane + m_ * WAVE < pd.n1) ? gA_[lane + m_ * WAVE] : 0.0;
+                rb[x][m_] = (lane + m_ * WAVE < pd.n2) ? gB_[lane + m_ * WAVE] : 0.0;
+            }
+        }
+    };
+    if (pre && NR * w < nrows) fetch_tab(__builtin_amdgcn_readfirstlane(NR * w));
+    uint32_t qn = 0;                                            // queue fill (wave-uniform)
+    // one step of the exact gate over `n` queue entries (the top of the queue): lane = candidate
+    auto consume = [&](uint32_t base, uint32_t n, const int (&k)[NR], const double (&zi)[NR], const double (&zj)[NR]) {
+        const bool act = (uint32_t)lane < n;
+        const uint32_t e = act ? (uint32_t)queue[base + lane] : 0u;
+        const uint32_t qq = e & 0x7fffu, x = (NR > 1) ? (e >> 15) : 0u;
+        const uint32_t pk = cIJ[act ? qq : 0u];
+        const uint32_t so = x * (uint32_t)sliceBytes;
+        const double a = *reinterpret_cast<const double*>(tbytes + so + ((pk & 0xffffu) << 3));
+        const double bb = *reinterpret_cast<const double*>(tbytes + so + ((pk >> 16) << 3));
+        double dz = 0.0;
+        if (GM) {
+            const double za = gZa[act ? qq : 0u], zb = gZb[act ? qq : 0u];
+            const double zi_ = (NR > 1 && x) ? zi[NR - 1] : zi[0], zj_ = (NR > 1 && x) ? zj[NR - 1] : zj[0];
+            dz = fabs((zi_ - za) - (zj_ - zb));
+        }
+        const bool is = act && pair_gate<GM>(D, a, bb, dz);
+        if (is) (void)__hip_atomic_fetch_or(&rmask[x * (uint32_t)Wcap + (qq >> 6)], 1ull << (qq & 63u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        (void)k;
+    };
+    for (int r = NR * w; r < nrows; r += NR * wpb) {
+        int k[NR]; double zi[NR], zj[NR];
+#pragma unroll
+        for (int x = 0; x < NR; ++x) {
+            k[x] = __builtin_amdgcn_readfirstlane(row0 + min(r + x, nrows - 1));
+            zi[x] = GM ? gZa[k[x]] : 0.0; zj[x] = GM ? gZb[k[x]] : 0.0;
+        }
+        // stage the table rows and their bins (wave-private slices; LDS ops of one wave execute in order)
+#pragma unroll
+        for (int x = 0; x < NR; ++x) {
+            double* sA = tA + x * ldsPerRow; double* sB = sA + pd.n1 + 1;
+            uint16_t* qA = qS + x * ldsPerRow; uint16_t* qB = qA + pd.n1 + 1;
+            if (pre) {
+#pragma unroll
+                for (int m_ = 0; m_ < TR; ++m_) {
+                    if (lane + m_ * WAVE < pd.n1) { sA[lane + m_ * WAVE] = ra[x][m_]; qA[lane + m_ * WAVE] = (uint16_t)quant_bin(ra[x][m_], invw); }
+                    if (lane + m_ * WAVE < pd.n2) { sB[lane + m_ * WAVE] = rb[x][m_]; qB[lane + m_ * WAVE] = (uint16_t)quant_bin(rb[x][m_], invw); }
+                }
+            } else {
+                const int i = (int)(cIJ[k[x]] & 0xffffu), j = (int)(cIJ[k[x]] >> 16) - (pd.n1 + 1);
+                const double* gA = TA + (int64_t)i * pd.n1;
+                const double* gB = TB + (int64_t)j * pd.n2;
+                for (int t = lane; t < pd.n1; t += WAVE) { const double v = gA[t]; sA[t] = v; qA[t] = (uint16_t)quant_bin(v, invw); }
+                for (int t = lane; t < pd.n2; t += WAVE) { const double v = gB[t]; sB[t] = v; qB[t] = (uint16_t)quant_bin(v, invw); }
+            }
+            if (lane == 0) { sA[pd.n1] = d_nan(); qA[pd.n1] = (uint16_t)0xffffu; }     // sentinel entry of the padding columns
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (pre && r + NR * wpb < nrows) fetch_tab(__builtin_amdgcn_readfirstlane(r + NR * wpb));
+
+        const int R = k[0] >> 6;                                // the NR rows of a wave lie in the same 64-row block
+        const int qBeg = (R << 6);
+        for (int q0 = qBeg & ~(U * WAVE - 1); q0 < Lpad; q0 += U * WAVE) {
+            uint32_t pk[U];
+#pragma unroll
+            for (int t = 0; t < U; ++t) pk[t] = cIJ[q0 + t * WAVE + lane];
+#pragma unroll
+            for (int t = 0; t < U; ++t) {
+                if (q0 + t * WAVE < qBeg) continue;             // (the chunk in front of the row's own block: its words are another row's)
+                const uint32_t oa = (pk[t] & 0xffffu) << 1, ob = (pk[t] >> 16) << 1;
+#pragma unroll
+                for (int x = 0; x < NR; ++x) {
+                    const uint32_t qa = *reinterpret_cast<const uint16_t*>(qbytes + x * qsliceBytes + oa);
+                    const uint32_t qb = *reinterpret_cast<const uint16_t*>(qbytes + x * qsliceBytes + ob);
+                    const uint32_t dd = __builtin_amdgcn_sad_u16(qa, qb, 0u);       // |qa - qb| (upper halves are zero)
+                    const bool cand = dd <= K;
+                    const unsigned long long m = __ballot(cand);
+                    if (m != 0ull) {
+                        const uint32_t at = qn + (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                        if (cand) queue[at] = (uint16_t)((uint32_t)(q0 + t * WAVE + lane) | ((uint32_t)x << 15));
+                        qn += (uint32_t)__popcll(m);
+                    }
+                }
+            }
+            if (qn >= 64u) {                                    // (ds_write / ds_read of one wave execute in order: the barrier is for the compiler)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                while (qn >= 64u) { qn -= 64u; consume(qn, 64u, k, zi, zj); }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (qn) { consume(0u, qn, k, zi, zj); qn = 0u; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // the rows' words [R, W): out, coalesced, and cleared for the next rows
+#pragma unroll
+        for (int x = 0; x < NR; ++x) {
+            for (int wv = R + lane; wv < W; wv += WAVE) {
+                const unsigned long long mreg = rmask[x * Wcap + wv];
+                rmask[x * Wcap + wv] = 0ull;
+                if (r + x < nrows) mbase[(int64_t)k[x] * W + wv] = mreg;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();                        // table slices are rewritten by the next rows
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
 // A work item of a live set that does not fit the LDS column tile (no semantic gate: L = n1 * n2): the item's rows are swept
 // against one tile of columns after the other (a row needs only the words at and behind its own 64-row block: the tiles in
 // front of the item's first row are skipped).  Its own kernel instantiation (k_count<..., true>): the one-tile kernel keeps the code it had.
@@ -1492,7 +1656,7 @@ __device__ __forceinline__ void count_item_tiled(const DevParams& D, const ProbD
     }
 }
 
-template <int GM, int NR, bool TILED>
+template <int GM, int NR, bool TILED, bool PRE = false /* candidate generation in front of the exact gate (one-tile sweep only): count_rows_pre */>
 __global__ void __launch_bounds__(1024) k_count(DevParams D, const ProbDesc* __restrict__ probs,
                                                 const ProbState* __restrict__ st,
                                                 const BatchTotals* __restrict__ tot,
@@ -1506,13 +1670,21 @@ __global__ void __launch_bounds__(1024) k_count(DevParams D, const ProbDesc* __r
                                                 int TC /* LDS column tile (multiple of 256) */, int ldsPerWave /* doubles: NR table slices */, int RPB)
 {
     // LDS: [GM: cZZ[TC]] cIJ[TC] | per wave NR table slices (n1 + 1 + n2 doubles each)
+    // PRE: cIJ[TC] | per wave NR table slices | per wave: NR bin slices (u16), the candidate queue (64 + NR * 128 u16), NR mask rows of TC / 64 words
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double2* cZZ = reinterpret_cast<double2*>(smem);
-    uint32_t* cIJ = reinterpret_cast<uint32_t*>(cZZ + (GM ? TC : 0));
+    uint32_t* cIJ = reinterpret_cast<uint32_t*>(cZZ + ((GM && !PRE) ? TC : 0));
     double* tabs = reinterpret_cast<double*>(cIJ + TC);
     const int tid = threadIdx.x, nt = blockDim.x;
     const int lane = tid & 63, w = tid >> 6, wpb = nt >> 6;
     double* tA = tabs + (size_t)w * ldsPerWave;
+    // (PRE) per-wave extras behind all waves' table slices
+    const int preBytes = PRE ? count_pre_wave_bytes(NR, ldsPerWave / NR, TC) : 0;
+    unsigned char* pw = reinterpret_cast<unsigned char*>(tabs + (size_t)wpb * ldsPerWave) + (size_t)w * preBytes;
+    unsigned long long* rmask = reinterpret_cast<unsigned long long*>(pw);
+    uint16_t* qS = reinterpret_cast<uint16_t*>(rmask + NR * (TC >> 6));
+    uint16_t* queue = qS + ((NR * (ldsPerWave / NR) + 3) & ~3);
+    if (PRE) { for (int x = lane; x < NR * (TC >> 6); x += WAVE) rmask[x] = 0ull; }
     const int nItems = tot->items;
     // XCD-aware order (workgroup ids are dealt to the 8 XCDs round-robin): XCD x takes the CONTIGUOUS range [x Gx, (x + 1) Gx) of
     // work items — the items of a problem, which share its tables, columns and mask rows, run on one L2
@@ -1540,9 +1712,13 @@ __global__ void __launch_bounds__(1024) k_count(DevParams D, const ProbDesc* __r
             for (int q = tid; q < Lpad; q += nt) {
                 const bool v = q < L;
                 cIJ[q] = v ? ((uint32_t)li[lo + q] | ((uint32_t)(pd.n1 + 1 + lj[lo + q]) << 16)) : ((uint32_t)pd.n1 | ((uint32_t)(pd.n1 + 1) << 16));
-                if (GM) cZZ[q] = v ? make_double2(lza[lo + q], lzb[lo + q]) : make_double2(0.0, 0.0);
+                if (GM && !PRE) cZZ[q] = v ? make_double2(lza[lo + q], lzb[lo + q]) : make_double2(0.0, 0.0);
             }
             __syncthreads();
+            if (PRE)
+                count_rows_pre<GM, NR>(D, pd, L, it.row0, nrows, w, wpb, lane, cIJ, TA, TB, tA, ldsPerWave / NR, qS, queue, rmask, TC >> 6,
+                                       maskPool + mo, lza + lo, lzb + lo);
+            else
             count_rows_lds<GM, NR, false>(D, pd, L, it.row0, nrows, w, wpb, lane, cIJ, cZZ, TA, TB, tA, ldsPerWave / NR, maskPool + mo,
                                           0, Lpad, li + lo, lj + lo, lza + lo, lzb + lo);
         } else {

@@ -232,6 +232,8 @@ int make_dev_params(roman_ctx* c, const roman_params_t* p, int32_t F, DevParams*
     D->keep_all = D->single && D->p.single_mode == ROMAN_SINGLE_DIAG_KEEP;
     D->F = F;
     D->stream_maxL = STREAM_MAXL;
+    D->pre_invw = (p->epsilon > 0.0 && std::isfinite(p->epsilon)) ? 8.0 / p->epsilon : 0.0;   // k_count's prefilter: bins of epsilon / 8 ...
+    D->pre_K = 10;                                              // ... a gate-passing pair's entries are at most 8 + 1 bins apart (rounding); one bin of margin
     D->allow_fallback = 1;
     { static const char* cooEnv = getenv("ROMAN_COO"); D->solve_flags = (cooEnv && cooEnv[0] == '0') ? 1 : 0; }   // ROMAN_COO=0: A/B switch of the one-wave solver's coordinate form
     {   // ROMAN_FILL_ROTATE=0: list order inside a row (A/B); =m: rotate a row's quads by m * row (default 5)
@@ -593,6 +595,27 @@ int enqueue_score(roman_ctx* c, const DevParams& Din, const roman_params_t* para
     TCc = std::min(TCc, Lneed);
     const size_t pairLds = tabLds + (size_t)TCc * colBytesC;
     const int pairGrid = c->num_cu * std::max(1, std::min(2048 / (wpb * 64), (int)(c->lds_max / pairLds)));
+    // The one-tile sweep with candidate generation in front of the exact gate (count_rows_pre, round 6): column tile without the z
+    // pairs (the exact gate reads them from memory for the ~6 % of the columns that reach it) + per wave the table slices, their
+    // 16-bit bin slices, the candidate queue and the rows' mask words.  Taken when the whole expected live set fits its tile;
+    // ROMAN_COUNT_PRE=0 / 1 in the environment forces the plain sweep / the prefilter where it fits (A/B and tests: read per call).
+    int preNR = 0, preWpb = 0, preTC = 0; size_t preLds = 0;
+    {
+        const char* preEnv = getenv("ROMAN_COUNT_PRE");
+        const bool want = (preEnv ? preEnv[0] != '0' : true) && D.pre_invw > 0.0 && std::isfinite(D.pre_invw) && Lneed <= 32768;
+        if (want) {
+            const int tc = Lneed;
+            for (int nr = 2; nr >= 1 && !preNR; --nr)
+                for (int wp = 16; wp >= 8; wp -= 4) {
+                    const size_t need = (size_t)tc * 4 + (size_t)wp * ((size_t)nr * ldsPerRow * sizeof(double) + (size_t)count_pre_wave_bytes(nr, ldsPerRow, tc));
+                    if (need <= c->lds_max) { preNR = nr; preWpb = wp; preTC = tc; preLds = need; break; }
+                }
+            if (wpbEnv && preNR) {                               // (A/B: ROMAN_COUNT_WPB also caps the prefiltered sweep's waves)
+                preWpb = std::min(preWpb, wpb);
+                preLds = (size_t)preTC * 4 + (size_t)preWpb * ((size_t)preNR * ldsPerRow * sizeof(double) + (size_t)count_pre_wave_bytes(preNR, ldsPerRow, preTC));
+            }
+        }
+    }
 
     StageTimer t1(c, ROMAN_STAGE_COUNT_PASS);                  // (the stage also holds k_small: at the demo scale it IS the rest of the alignment)
     {   // demo-scale problems: finished here, in one kernel (k_small); launched when such problems have been seen with this
@@ -638,13 +661,22 @@ int enqueue_score(roman_ctx* c, const DevParams& Din, const roman_params_t* para
                                  : (NRc == 2 ? reinterpret_cast<const void*>(k_count<GM_, 2, false>) : reinterpret_cast<const void*>(k_count<GM_, 1, false>))
             switch (D.gmode) { case 1: ROMAN_KC(1); break; case 2: ROMAN_KC(2); break; case 3: ROMAN_KC(3); break; default: ROMAN_KC(0); break; }
 #undef ROMAN_KC
-            HIPCHK(c, dyn_lds(c, kc, pairLds));
+            const bool usePre = !tiled && preNR > 0;
+            if (usePre) {
+#define ROMAN_KP(GM_) kc = preNR == 2 ? reinterpret_cast<const void*>(k_count<GM_, 2, false, true>) : reinterpret_cast<const void*>(k_count<GM_, 1, false, true>)
+                switch (D.gmode) { case 1: ROMAN_KP(1); break; case 2: ROMAN_KP(2); break; case 3: ROMAN_KP(3); break; default: ROMAN_KP(0); break; }
+#undef ROMAN_KP
+            }
+            const size_t ldsK = usePre ? preLds : pairLds;
+            const int wpbK = usePre ? preWpb : wpb;
+            const int gridK = usePre ? c->num_cu * std::max(1, std::min(2048 / (wpbK * 64), (int)(c->lds_max / ldsK))) : pairGrid;
+            HIPCHK(c, dyn_lds(c, kc, ldsK));
             DevParams a_D = D; const ProbDesc* a_dP = dP; const ProbState* a_dS = dS; const BatchTotals* a_dT = dT; const ItemDesc* a_items = WS.items.as<ItemDesc>();
             const double* a_tab = WS.tabPool.as<double>(); const int32_t* a_li = LP.li; const int32_t* a_lj = LP.lj; const double* a_za = LP.lza; const double* a_zb = LP.lzb;
             uint32_t* a_rc = WS.rowCnt.as<uint32_t>(); unsigned long long* a_mask = WS.maskPool.as<unsigned long long>(); uint32_t* a_pref = WS.prefPool.as<uint32_t>();
-            int a_TC = TCc, a_lpw = ldsPerWave, a_RPB = RPB;
+            int a_TC = usePre ? preTC : TCc, a_lpw = usePre ? preNR * ldsPerRow : ldsPerWave, a_RPB = RPB;
             void* args[] = {&a_D, &a_dP, &a_dS, &a_dT, &a_items, &a_tab, &a_li, &a_lj, &a_za, &a_zb, &a_rc, &a_mask, &a_pref, &a_TC, &a_lpw, &a_RPB};
-            HIPCHK(c, hipLaunchKernel(kc, dim3(pairGrid), dim3(wpb * 64), args, pairLds, WS.stream));
+            HIPCHK(c, hipLaunchKernel(kc, dim3(gridK), dim3(wpbK * 64), args, ldsK, WS.stream));
         }
     DBG(c, "k_count");
         // Stream-layout problems (kind 0) go from the upper blocks straight to positions and kept-candidate lists in ONE kernel, one

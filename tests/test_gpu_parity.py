@@ -436,3 +436,51 @@ def test_pair_tests_far_from_the_origin(ctx, orc, offset):
     rp, cc, vv, dd = ctx.upper_csr()
     assert np.array_equal(rp, rp_o) and np.array_equal(cc, c_o) and np.array_equal(vv, v_o) and np.array_equal(dd, d_o)
     assert len(c_o) > 0
+
+
+PRE_CASES = ["cfg1", "clipper_2d", "gravity40", "semgrav60", "cfg2", "gravity100", "tiny_4x5", "words3_12x14", "dense45", "maps300",
+             "grav_separate", "grav_zgate", "semgrav_zgate_200", "roman_diagkeep"]
+
+
+@pytest.mark.parametrize("name", PRE_CASES)
+def test_pair_tests_with_candidate_generation_give_the_plain_sweeps_matrix(ctx, orc, name, monkeypatch):
+    """k_count with the integer prefilter in front of the exact gate (count_rows_pre: 16-bit bins of the two table entries, survivors
+    compacted into an LDS queue, the exact f64 gate on the queue; ROMAN_COUNT_PRE=1, the default) against the plain sweep that
+    tests every live pair (ROMAN_COUNT_PRE=0): the same upper CSR — pattern AND values — which is the oracle's.  Replaces
+    clipper.score_pairwise_and_single_consistency [REF roman/align/roman_registration.py:95]."""
+    case = next(c for c in LADDER if c[0] == name)
+    reg, pr = make(case)
+    reg.set_context(ctx)
+    P = reg._abi_params()
+    D1, D2 = reg.pack(pr.map1), reg.pack(pr.map2)
+    A = reg._association_list(pr.map1, pr.map2)
+    mat, _ = orc.build_matrix(P, D1, D2, A)
+    rp_o, c_o, v_o, _ = mat.export()
+    got = {}
+    for pre in ("1", "0"):
+        monkeypatch.setenv("ROMAN_COUNT_PRE", pre)
+        ctx.score(P, D1, D2, A)
+        got[pre] = ctx.upper_csr()
+        assert np.array_equal(got[pre][0], rp_o) and np.array_equal(got[pre][1], c_o) and np.array_equal(got[pre][2], v_o), pre
+    assert all(np.array_equal(a, b) for a, b in zip(got["0"], got["1"]))
+
+
+@pytest.mark.parametrize("scale,epsilon,noise", [(1.0, 0.6, 0.1), (400.0, 0.6, 0.1), (1.0, 0.004, 0.0005), (1.0, 30.0, 0.1), (1.0e-3, 0.6, 0.0)])
+def test_candidate_generation_at_the_ends_of_the_bin_range(ctx, orc, scale, epsilon, noise, monkeypatch):
+    """The prefilter's bins are epsilon / 8 wide and clamp at 65280: maps 400 times as large (distances up to 12 km: everything
+    beyond 4.9 km shares the last bin), an epsilon of 4 mm (everything beyond 33 m shares it), an epsilon of 30 m and maps shrunk
+    to centimetres (every distance in the first bins: every pair is a candidate) — the matrix stays the oracle's and the plain
+    sweep's in every case (a false positive costs an exact test, never a bit)."""
+    reg = registration_for("semanticgrav", semantics_dim=32, epsilon=epsilon, sigma=max(epsilon / 1.5, 1e-3), mindist=0.0 if scale < 1 else 0.2)
+    reg.set_context(ctx)
+    P = reg._abi_params()
+    pr = synth.make_pair(90, 80, 32, 616, tilt_deg=1.0, noise=noise)
+    D1, D2 = reg.pack(pr.map1).copy(), reg.pack(pr.map2).copy()
+    D1[:, :3] *= scale; D2[:, :3] *= scale
+    mat, _ = orc.build_matrix(P, D1, D2)
+    rp_o, c_o, v_o, _ = mat.export()
+    for pre in ("1", "0"):
+        monkeypatch.setenv("ROMAN_COUNT_PRE", pre)
+        ctx.score(P, D1, D2, None)
+        rp, cc, vv, _ = ctx.upper_csr()
+        assert np.array_equal(rp, rp_o) and np.array_equal(cc, c_o) and np.array_equal(vv, v_o), pre
