@@ -67,7 +67,7 @@ struct DevParams {
     int32_t stream_maxL;     // problems of up to this many live associations take the stream layout (<= STREAM_MAXL; set per launch:
                              // it is also the column capacity of k_fill_slice's LDS tile and of the stream solver's LDS vectors)
     int32_t pre_K;           // k_count's integer prefilter: a pair goes to the exact gate iff its two quantised table entries differ by at most pre_K bins
-    double  pre_invw;        // ... bins per metre (1 / bin width; bin width = epsilon / 8)
+    double  pre_invw;        // ... bins per metre (1 / bin width; bin width = epsilon / 32)
 };
 
 struct ProbDesc {
@@ -77,7 +77,8 @@ struct ProbDesc {
     int64_t cosOff;        // offset into the cosine pool (n1*n2)
     int64_t tabOff;        // offset into the table pool (n1*n1 then n2*n2)
     int64_t normOff;       // offset into the norm pool (n1 then n2)
-    int32_t n1, n2, nA, pad;
+    int32_t n1, n2, nA;
+    int32_t qtabOff4;      // offset into the pool of 16-bit table bins (k_count's prefilter), in units of four entries: n1 rows of (n1 + 3 & ~3), then n2 rows of (n2 + 3 & ~3)
 };
 
 struct ProbState {
@@ -983,7 +984,8 @@ __global__ void __launch_bounds__(256, CosDeal<T>::WAVES) k_cos_deal(DevParams D
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(1024) k_tables(DevParams D, const ProbDesc* __restrict__ probs,
                                                  const double* __restrict__ feats,
-                                                 double* __restrict__ tabPool, int RB /* rows per band */)
+                                                 double* __restrict__ tabPool, int RB /* rows per band */,
+                                                 uint16_t* __restrict__ qtabPool /* the same entries as 15-bit bins of width epsilon / 32 (k_count's prefilter), or NULL */)
 {
     // grid: (row bands of RB rows over max(n1,n2), 2 maps, B).  The map's points are staged in LDS once per
     // block (3 doubles per object: n gathers from rows 8 F bytes apart — the band is as tall as the batch allows, one band
@@ -1002,6 +1004,8 @@ __global__ void __launch_bounds__(1024) k_tables(DevParams D, const ProbDesc* __
     }
     __syncthreads();
     double* tab = tabPool + pd.tabOff + (which == 0 ? 0 : (int64_t)pd.n1 * pd.n1);
+    const int nq = (n + 3) & ~3;                                  // row stride of the bins (a row is whole 8-byte words)
+    uint16_t* qtab = qtabPool ? qtabPool + 4 * (int64_t)pd.qtabOff4 + (which == 0 ? 0 : (int64_t)pd.n1 * ((pd.n1 + 3) & ~3)) : nullptr;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
     for (int rr = w; rr < RB; rr += nw) {
         const int a = r0 + rr;
@@ -1014,6 +1018,8 @@ __global__ void __launch_bounds__(1024) k_tables(DevParams D, const ProbDesc* __
             const bool bad = (a == b) || (D.p.mindist > 0.0 && l2 < D.x_mindist);
             const double v = (D.gmode == 1 || D.gmode == 2) ? sqrt(h2) : sqrt(l2);     // z-gate mode compares full lengths
             tab[(int64_t)a * n + b] = bad ? d_nan() : v;
+            // NaN entries and everything beyond the bins' range share the last bin (fmin returns the number)
+            if (qtab) qtab[(int64_t)a * nq + b] = (uint16_t)(uint32_t)__builtin_fmin((bad ? d_nan() : v) * D.pre_invw, 32767.0);
         }
     }
 }
@@ -1470,150 +1476,253 @@ __device__ __forceinline__ void count_rows_lds(const DevParams& D, const ProbDes
 // ---------------------------------------------------------------------------------------------
 // The same pair tests with CANDIDATE GENERATION in front of the exact gate (round 6).  Every reading of the gate needs
 // |TA[i][i'] - TB[j][j']| < epsilon (the horizontal / full-length difference is one of its terms and the other is >= 0), and only
-// ~3 % of the live pairs pass it: the sweep therefore tests the pair's two table entries as 16-bit BIN numbers (bin width epsilon / 8,
-// quantised once per row next to the f64 table slices: two ds_read_u16 gathers, one v_sad, one compare per 64 columns and row
-// instead of two f64 gathers and twelve f64 operations), compacts the survivors (~6 % of the columns) into a per-wave LDS queue
-// and runs the EXISTING exact f64 gate on the queue, 64 candidates at a time with every lane busy; a passing candidate sets its
-// bit in the row's mask words in LDS (ds_or_b64), which go out coalesced at the end of the row.
-// The prefilter is a superset of the gate by construction: q(x) = min(trunc(x * invw), 0xff00) is monotone, so |a - b| <= eps'
-// gives |q(a) - q(b)| <= ceil(eps' * invw + rounding) <= 8 + 1; pre_K is 10.  NaN entries (the same object twice, or closer than
-// mindist) are bin 0xffff: a NaN never meets a finite entry (clamped at 0xff00), and a NaN-NaN pair is rejected by the exact gate
-// like every other false positive.  The exact gate sees the same operands in the same operation order as count_rows_lds: the
-// mask words are bit-identical (tests/test_gpu_parity.py runs the ladder and the +-1-ulp plants through both kernels).
+// ~3 % of the live pairs pass it.  What bounds the plain sweep is its two random f64 LDS gathers per 64 tests and row (one LDS per
+// compute unit serves sixteen waves); a first prefilter that kept two gathers per row — 16-bit bins instead of doubles — was
+// bit-identical and SLOWER (650 against 570 us per batch: profiles/r06).  Here a wave sweeps FOUR adjacent rows at once and the
+// four rows' bins of one table column are ONE 8-byte LDS word: two 8-byte gathers per 64 columns serve 256 pair tests.  Bins are
+// epsilon / 32 wide (15 bits; NaN entries and everything beyond the range share the last bin), compared as packed 16-bit halves;
+// the survivors (~6 % of the columns) are compacted into a per-wave LDS queue, and the EXISTING exact f64 gate runs on the queue,
+// 64 candidates at a time with every lane busy, its operands fetched from the tables in memory (L2) for those few; a passing
+// candidate sets its bit in the row's mask words in LDS (ds_or_b64), which go out coalesced at the end of the rows.
+// The prefilter is a superset of the gate by construction: q(x) = trunc(min(x * invw, 32767)) is monotone, so |a - b| <= eps'
+// gives |q(a) - q(b)| <= ceil(eps' * invw + rounding) <= 32 + 1; pre_K is 34.  A false positive (the last bin's far / NaN pairs
+// included) costs an exact test, never a bit.  The exact gate sees the same operands in the same operation order as
+// count_rows_lds: the mask words are bit-identical (tests/test_gpu_parity.py runs ladder cases, the ends of the bin range and
+// the +-1-ulp plants through both kernels).
 // ---------------------------------------------------------------------------------------------
-// per-wave LDS of the prefiltered sweep behind the table slices: NR mask rows (TC / 64 words), NR bin slices, the queue
-__host__ __device__ constexpr int count_pre_wave_bytes(int NR, int ldsPerRow, int TC)
+constexpr int PRE_NR = 4;                 // rows a wave sweeps together (their bins share an LDS word)
+constexpr int PRE_COLPAD = 128;           // sentinel columns behind the column tile (a sweep starts at the rows' own 64-column block and advances by 128)
+constexpr int PRE_QCAP = 640;             // queue entries: the exact gate runs while 256 are waiting; a window's candidates go in at once when they fit (else 64 at a time)
+#ifndef ROMAN_PRE_WAVES
+#define ROMAN_PRE_WAVES 16                // waves per workgroup of the prefiltered sweep (118 registers per lane: no spills; 12 waves measured 7 % slower)
+#endif
+constexpr int PRE_WAVES = ROMAN_PRE_WAVES;
+// per-wave LDS of the prefiltered sweep: PRE_NR mask rows (TC / 64 words), the packed bin table (n1 + 1 + n2 entries of 8 bytes, ldsPerRow
+// rounded), the queue (16-bit entries), the rows' own data (4 x 32 bytes)
+__host__ __device__ constexpr int count_pre_wave_bytes(int ldsPerRow, int TC)
 {
-    return NR * (TC >> 6) * 8 + ((NR * ldsPerRow + 3) & ~3) * 2 + (64 + NR * 2 * 64) * 2;
+    return PRE_NR * (TC >> 6) * 8 + ldsPerRow * 8 + PRE_QCAP * 2 + PRE_NR * 32;
 }
-__device__ __forceinline__ uint32_t quant_bin(double v, double invw)
-{
-    const double t = __builtin_fmin(v * invw, 65280.0);         // (v >= 0: a distance; NaN * invw = NaN -> fmin gives 65280: overridden below)
-    return (v == v) ? (uint32_t)t : 0xffffu;
-}
+struct PreRow { double zi, zj; uint32_t rowA, rowB, moff, pad1; };   // heights of the row's objects; first entries of its two table rows; byte offset of its mask words
+typedef short pre_s2 __attribute__((ext_vector_type(2)));
 
-template <int GM, int NR>
+template <int GM>
 __device__ __forceinline__ void count_rows_pre(const DevParams& D, const ProbDesc& pd, int L, int row0, int nrows,
-                                               int w, int wpb, int lane,
-                                               const uint32_t* cIJ /* i_q | (n1 + 1 + j_q) << 16: table-slice indices, Lpad entries */,
+                                               uint32_t* qctr /* LDS: next quad of rows to hand out (0 on entry) */, int lane,
+                                               const uint32_t* cIJ /* i_q | (n1 + 1 + j_q) << 16: table-slice indices; sentinel columns up to ((L + 127) & ~127) + 128 */,
                                                const double* __restrict__ TA, const double* __restrict__ TB,
-                                               double* tA /* NR slices of ldsPerRow doubles */, int ldsPerRow,
-                                               uint16_t* qS /* NR slices of ldsPerRow bins */, uint16_t* queue /* 64 + NR * 2 * 64 entries */,
-                                               unsigned long long* rmask /* NR rows of Wcap words, zero on entry and on exit */, int Wcap,
+                                               const uint16_t* __restrict__ QA, const uint16_t* __restrict__ QB /* the tables as bins (k_tables): rows of (n + 3 & ~3) entries */,
+                                               uint2* qT /* n1 + 1 + n2 packed bin entries */, uint16_t* queue,
+                                               unsigned long long* rmask /* PRE_NR rows of Wcap words, zero on entry and on exit */, int Wcap,
+                                               PreRow* rowinfo,
                                                unsigned long long* __restrict__ mbase,
                                                const double* __restrict__ gZa, const double* __restrict__ gZb)
 {
+    constexpr int NR = PRE_NR;
     const int W = (L + 63) >> 6;
-    const char* tbytes = reinterpret_cast<const char*>(tA);
-    const char* qbytes = reinterpret_cast<const char*>(qS);
-    const int sliceBytes = ldsPerRow * 8, qsliceBytes = ldsPerRow * 2;
-    constexpr int U = 2;
-    const int Lpad = (L + U * WAVE - 1) & ~(U * WAVE - 1);
-    const double invw = D.pre_invw;
-    const uint32_t K = (uint32_t)D.pre_K;
-    constexpr int TR = 4;
-    const bool pre = pd.n1 <= TR * WAVE && pd.n2 <= TR * WAVE;
-    double ra[NR][TR], rb[NR][TR];
+    const int Lpad = (L + 2 * WAVE - 1) & ~(2 * WAVE - 1);
+    const uint32_t K2 = (uint32_t)D.pre_K * 0x00010001u;
+    const int n1 = pd.n1, n2 = pd.n2;
+    const int nq1 = (n1 + 3) & ~3, nq2 = (n2 + 3) & ~3;
+    const bool pre = n1 <= 4 * WAVE && n2 <= 4 * WAVE;         // a lane holds four consecutive entries of a row: one 8-byte load per row
+    uint2 ra[NR], rb[NR];
+    int pi[NR], pj[NR];                                         // objects of the rows whose bin rows are in ra / rb
+    double pzi = 0.0, pzj = 0.0;                                // lane x < NR: the heights of row x's two objects
     auto fetch_tab = [&](int r_) {
+        if (GM) { const int kz_ = row0 + min(r_ + min(lane, NR - 1), nrows - 1); pzi = gZa[kz_]; pzj = gZb[kz_]; }
 #pragma unroll
         for (int x = 0; x < NR; ++x) {
             const int k_ = row0 + min(r_ + x, nrows - 1);
-            const int i_ = (int)(cIJ[k_] & 0xffffu), j_ = (int)(cIJ[k_] >> 16) - (pd.n1 + 1);
-            const double* gA_ = TA + (int64_t)i_ * pd.n1;
-            const double* gB_ = TB + (int64_t)j_ * pd.n2;
-#pragma unroll
-            for (int m_ = 0; m_ < TR; ++m_) {
-                ra[x][m_] = (lane + m_ * WAVE < pd.n1) ? gA_[lane + m_ * WAVE] : 0.0;
-                rb[x][m_] = (lane + m_ * WAVE < pd.n2) ? gB_[lane + m_ * WAVE] : 0.0;
-            }
+            const uint32_t pk_ = cIJ[k_];
+            pi[x] = __builtin_amdgcn_readfirstlane((int)(pk_ & 0xffffu)); pj[x] = __builtin_amdgcn_readfirstlane((int)(pk_ >> 16) - (n1 + 1));
+            ra[x] = *reinterpret_cast<const uint2*>(QA + (int64_t)pi[x] * nq1 + min(4 * lane, nq1 - 4));
+            rb[x] = *reinterpret_cast<const uint2*>(QB + (int64_t)pj[x] * nq2 + min(4 * lane, nq2 - 4));
         }
     };
-    if (pre && NR * w < nrows) fetch_tab(__builtin_amdgcn_readfirstlane(NR * w));
+    // Quads of rows are handed out in order (an LDS counter): the rows in front sweep the most columns, so the longest quads start
+    // first and the waves of a workgroup finish within one quad of each other whatever their number
+    auto grab = [&]() -> int {
+        uint32_t g = 0u;
+        if (lane == 0) g = __hip_atomic_fetch_add(qctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return NR * __builtin_amdgcn_readfirstlane((int)g);
+    };
+    int r = grab(), rnext = nrows;
+    if (pre && r < nrows) fetch_tab(r);
     uint32_t qn = 0;                                            // queue fill (wave-uniform)
-    // one step of the exact gate over `n` queue entries (the top of the queue): lane = candidate
-    auto consume = [&](uint32_t base, uint32_t n, const int (&k)[NR], const double (&zi)[NR], const double (&zj)[NR]) {
-        const bool act = (uint32_t)lane < n;
-        const uint32_t e = act ? (uint32_t)queue[base + lane] : 0u;
-        const uint32_t qq = e & 0x7fffu, x = (NR > 1) ? (e >> 15) : 0u;
-        const uint32_t pk = cIJ[act ? qq : 0u];
-        const uint32_t so = x * (uint32_t)sliceBytes;
-        const double a = *reinterpret_cast<const double*>(tbytes + so + ((pk & 0xffffu) << 3));
-        const double bb = *reinterpret_cast<const double*>(tbytes + so + ((pk >> 16) << 3));
-        double dz = 0.0;
-        if (GM) {
-            const double za = gZa[act ? qq : 0u], zb = gZb[act ? qq : 0u];
-            const double zi_ = (NR > 1 && x) ? zi[NR - 1] : zi[0], zj_ = (NR > 1 && x) ? zj[NR - 1] : zj[0];
-            dz = fabs((zi_ - za) - (zj_ - zb));
-        }
-        const bool is = act && pair_gate<GM>(D, a, bb, dz);
-        if (is) (void)__hip_atomic_fetch_or(&rmask[x * (uint32_t)Wcap + (qq >> 6)], 1ull << (qq & 63u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        (void)k;
+#ifdef ROMAN_COUNT_TIMING
+    unsigned long long tc_[6] = {0, 0, 0, 0, 0, 0}; unsigned long long tm_; unsigned nq_ = 0, ncons_ = 0, npush_ = 0;   // stage, sweep, push, consume, store, (unused)
+#define TCK(k_) do { const unsigned long long n_ = __builtin_readcyclecounter(); tc_[k_] += n_ - tm_; tm_ = n_; } while (0)
+#else
+#define TCK(k_) do { } while (0)
+#endif
+    auto lds_order = [&]() {                                    // LDS operations of one wave execute in order: this is for the compiler
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
-    for (int r = NR * w; r < nrows; r += NR * wpb) {
-        int k[NR]; double zi[NR], zj[NR];
+    // The exact gate over up to 256 queue entries starting at `base`: four candidates per lane, the operands of all four requested
+    // (tables and heights from memory: L2) before the first is used — a single chain's round trip would otherwise be all a wave does
+    auto consume = [&](uint32_t base, uint32_t n) {
+        constexpr int CH = 4;
+        uint32_t e[CH]; double a[CH], bb[CH], za[CH], zb[CH];
 #pragma unroll
-        for (int x = 0; x < NR; ++x) {
-            k[x] = __builtin_amdgcn_readfirstlane(row0 + min(r + x, nrows - 1));
-            zi[x] = GM ? gZa[k[x]] : 0.0; zj[x] = GM ? gZb[k[x]] : 0.0;
+        for (int c = 0; c < CH; ++c) {
+            const uint32_t idx = (uint32_t)(c * WAVE + lane);
+            e[c] = idx < n ? (uint32_t)queue[base + idx] : 0xffffu;     // (0x3fff: a column beyond every live set: inactive below)
+            const uint32_t qq = e[c] & 0x3fffu;
+            const bool act = (int)qq < L;                       // (a sentinel column can only get here through the last bin)
+            const uint32_t pk = cIJ[act ? qq : 0u];
+            const PreRow* ri = rowinfo + (e[c] >> 14);
+            a[c] = TA[ri->rowA + (pk & 0xffffu)];               // (32-bit element offsets: maps of at most 32767 objects take this sweep)
+            bb[c] = TB[ri->rowB + (pk >> 16)];                  // (rowB is short of the row's start by n1 + 1: the packed index carries it)
+            if (GM) { za[c] = gZa[act ? qq : 0u]; zb[c] = gZb[act ? qq : 0u]; }
         }
-        // stage the table rows and their bins (wave-private slices; LDS ops of one wave execute in order)
 #pragma unroll
-        for (int x = 0; x < NR; ++x) {
-            double* sA = tA + x * ldsPerRow; double* sB = sA + pd.n1 + 1;
-            uint16_t* qA = qS + x * ldsPerRow; uint16_t* qB = qA + pd.n1 + 1;
-            if (pre) {
-#pragma unroll
-                for (int m_ = 0; m_ < TR; ++m_) {
-                    if (lane + m_ * WAVE < pd.n1) { sA[lane + m_ * WAVE] = ra[x][m_]; qA[lane + m_ * WAVE] = (uint16_t)quant_bin(ra[x][m_], invw); }
-                    if (lane + m_ * WAVE < pd.n2) { sB[lane + m_ * WAVE] = rb[x][m_]; qB[lane + m_ * WAVE] = (uint16_t)quant_bin(rb[x][m_], invw); }
+        for (int c = 0; c < CH; ++c) {
+            const uint32_t qq = e[c] & 0x3fffu, x = e[c] >> 14;
+            double dz = 0.0;
+            if (GM) { const PreRow* ri = rowinfo + x; dz = fabs((ri->zi - za[c]) - (ri->zj - zb[c])); }
+            const bool is = (int)qq < L && pair_gate<GM>(D, a[c], bb[c], dz);
+            if (is) (void)__hip_atomic_fetch_or(reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(rmask) + rowinfo[x].moff + ((qq >> 6) << 3)),
+                                                1ull << (qq & 63u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    };
+    // candidate bits of a window (up to four steps of two 64-column chunks: bit 8 s + 4 t + x of a lane = column qwin + (2 s + t) 64 + lane,
+    // row x) -> queue entries; the exact gate runs whenever 256 entries are waiting
+    auto flush = [&](uint32_t acc, int qwin) {
+        const uint32_t cnt = (uint32_t)__builtin_popcount(acc);
+        const uint32_t incl = wave_incl_scan(cnt);
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        const uint32_t qb = (uint32_t)(qwin + lane);
+        if (qn + total <= (uint32_t)PRE_QCAP) {
+            // the usual case: every lane writes its own candidates behind those of the lanes in front of it (one scan, no ballots)
+            uint32_t at = qn + incl - cnt;
+            while (__ballot(acc != 0u) != 0ull) {
+                if (acc != 0u) {
+                    const uint32_t b = (uint32_t)__builtin_ctz(acc);
+                    acc &= acc - 1u;
+                    queue[at++] = (uint16_t)((qb + ((b >> 2) << 6)) | ((b & 3u) << 14));
                 }
-            } else {
-                const int i = (int)(cIJ[k[x]] & 0xffffu), j = (int)(cIJ[k[x]] >> 16) - (pd.n1 + 1);
-                const double* gA = TA + (int64_t)i * pd.n1;
-                const double* gB = TB + (int64_t)j * pd.n2;
-                for (int t = lane; t < pd.n1; t += WAVE) { const double v = gA[t]; sA[t] = v; qA[t] = (uint16_t)quant_bin(v, invw); }
-                for (int t = lane; t < pd.n2; t += WAVE) { const double v = gB[t]; sB[t] = v; qB[t] = (uint16_t)quant_bin(v, invw); }
+#ifdef ROMAN_COUNT_TIMING
+                ++npush_;
+#endif
             }
-            if (lane == 0) { sA[pd.n1] = d_nan(); qA[pd.n1] = (uint16_t)0xffffu; }     // sentinel entry of the padding columns
+            qn += total;
+        } else {
+            // a window with more candidates than the queue has room for: 64 at a time, the exact gate in between
+            while (true) {
+                const unsigned long long m = __ballot(acc != 0u);
+                if (m == 0ull) break;
+                const uint32_t b = (uint32_t)__builtin_ctz(acc | 0x80000000u);
+                const bool has = acc != 0u;
+                acc &= acc - 1u;
+                const uint32_t at = qn + (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                if (has) queue[at] = (uint16_t)((qb + ((b >> 2) << 6)) | ((b & 3u) << 14));
+                qn += (uint32_t)__popcll(m);
+                if (qn >= 256u) { TCK(2); lds_order(); qn -= 256u; consume(qn, 256u); lds_order(); TCK(3); }
+            }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (pre && r + NR * wpb < nrows) fetch_tab(__builtin_amdgcn_readfirstlane(r + NR * wpb));
+        if (qn >= 256u) {
+            TCK(2); lds_order();
+            while (qn >= 256u) { qn -= 256u; consume(qn, 256u);
+#ifdef ROMAN_COUNT_TIMING
+                ++ncons_;
+#endif
+            }
+            lds_order(); TCK(3);
+        }
+    };
+    for (; r < nrows; r = rnext) {
+#ifdef ROMAN_COUNT_TIMING
+        tm_ = __builtin_readcyclecounter(); ++nq_;
+#endif
+        int k[NR];
+#pragma unroll
+        for (int x = 0; x < NR; ++x) k[x] = __builtin_amdgcn_readfirstlane(row0 + min(r + x, nrows - 1));
+        if (!pre) {
+#pragma unroll
+            for (int x = 0; x < NR; ++x) {
+                const uint32_t pk_ = cIJ[k[x]];
+                pi[x] = __builtin_amdgcn_readfirstlane((int)(pk_ & 0xffffu)); pj[x] = __builtin_amdgcn_readfirstlane((int)(pk_ >> 16) - (n1 + 1));
+            }
+        }
+        if (!pre && GM) { const int kz_ = row0 + min(r + min(lane, NR - 1), nrows - 1); pzi = gZa[kz_]; pzj = gZb[kz_]; }
+        if (lane < NR) {                                        // the rows' own objects and heights, for the exact gate
+            int i_ = pi[0], j_ = pj[0];
+#pragma unroll
+            for (int x = 1; x < NR; ++x) if (lane == x) { i_ = pi[x]; j_ = pj[x]; }
+            PreRow ri; ri.rowA = (uint32_t)i_ * (uint32_t)n1; ri.rowB = (uint32_t)j_ * (uint32_t)n2 - (uint32_t)(n1 + 1);
+            ri.moff = (uint32_t)lane * (uint32_t)Wcap * 8u; ri.pad1 = 0; ri.zi = pzi; ri.zj = pzj;
+            rowinfo[lane] = ri;
+        }
+        // the packed bin table: entry t = the NR rows' bins of table column t (map-1 columns, the sentinel, map-2 columns)
+        if (pre) {
+            // lane l holds entries 4 l .. 4 l + 3 of every row: the low / high halves of its two words, zipped over the rows
+            const int t0 = 4 * lane;
+            if (t0 < n1) qT[t0] = make_uint2(__builtin_amdgcn_perm(ra[1].x, ra[0].x, 0x05040100u), __builtin_amdgcn_perm(ra[3].x, ra[2].x, 0x05040100u));
+            if (t0 + 1 < n1) qT[t0 + 1] = make_uint2(__builtin_amdgcn_perm(ra[1].x, ra[0].x, 0x07060302u), __builtin_amdgcn_perm(ra[3].x, ra[2].x, 0x07060302u));
+            if (t0 + 2 < n1) qT[t0 + 2] = make_uint2(__builtin_amdgcn_perm(ra[1].y, ra[0].y, 0x05040100u), __builtin_amdgcn_perm(ra[3].y, ra[2].y, 0x05040100u));
+            if (t0 + 3 < n1) qT[t0 + 3] = make_uint2(__builtin_amdgcn_perm(ra[1].y, ra[0].y, 0x07060302u), __builtin_amdgcn_perm(ra[3].y, ra[2].y, 0x07060302u));
+            uint2* qB = qT + n1 + 1;
+            if (t0 < n2) qB[t0] = make_uint2(__builtin_amdgcn_perm(rb[1].x, rb[0].x, 0x05040100u), __builtin_amdgcn_perm(rb[3].x, rb[2].x, 0x05040100u));
+            if (t0 + 1 < n2) qB[t0 + 1] = make_uint2(__builtin_amdgcn_perm(rb[1].x, rb[0].x, 0x07060302u), __builtin_amdgcn_perm(rb[3].x, rb[2].x, 0x07060302u));
+            if (t0 + 2 < n2) qB[t0 + 2] = make_uint2(__builtin_amdgcn_perm(rb[1].y, rb[0].y, 0x05040100u), __builtin_amdgcn_perm(rb[3].y, rb[2].y, 0x05040100u));
+            if (t0 + 3 < n2) qB[t0 + 3] = make_uint2(__builtin_amdgcn_perm(rb[1].y, rb[0].y, 0x07060302u), __builtin_amdgcn_perm(rb[3].y, rb[2].y, 0x07060302u));
+        } else {
+            for (int t = lane; t < n1; t += WAVE) {
+                uint32_t b_[NR];
+#pragma unroll
+                for (int x = 0; x < NR; ++x) b_[x] = QA[(int64_t)pi[x] * nq1 + t];
+                qT[t] = make_uint2(b_[0] | (b_[1] << 16), b_[2] | (b_[3] << 16));
+            }
+            for (int t = lane; t < n2; t += WAVE) {
+                uint32_t b_[NR];
+#pragma unroll
+                for (int x = 0; x < NR; ++x) b_[x] = QB[(int64_t)pj[x] * nq2 + t];
+                qT[n1 + 1 + t] = make_uint2(b_[0] | (b_[1] << 16), b_[2] | (b_[3] << 16));
+            }
+        }
+        if (lane == 0) qT[n1] = make_uint2(0x7fff7fffu, 0x7fff7fffu);   // sentinel entry of the padding columns
+        lds_order();
+        rnext = grab();
+        if (pre && rnext < nrows) fetch_tab(rnext);
 
+        TCK(0);
         const int R = k[0] >> 6;                                // the NR rows of a wave lie in the same 64-row block
-        const int qBeg = (R << 6);
-        for (int q0 = qBeg & ~(U * WAVE - 1); q0 < Lpad; q0 += U * WAVE) {
-            uint32_t pk[U];
+        const char* qbytes = reinterpret_cast<const char*>(qT);
+        uint32_t nacc = 0u;                                     // NOT-candidate bits of the current window
+        int step = 0, qwin = R << 6;
+        for (int q0 = R << 6; q0 < Lpad; q0 += 2 * WAVE, ++step) {
+            uint32_t pk[2]; uint2 ea[2], eb[2];
 #pragma unroll
-            for (int t = 0; t < U; ++t) pk[t] = cIJ[q0 + t * WAVE + lane];
+            for (int t = 0; t < 2; ++t) pk[t] = cIJ[q0 + t * WAVE + lane];
 #pragma unroll
-            for (int t = 0; t < U; ++t) {
-                if (q0 + t * WAVE < qBeg) continue;             // (the chunk in front of the row's own block: its words are another row's)
-                const uint32_t oa = (pk[t] & 0xffffu) << 1, ob = (pk[t] >> 16) << 1;
-#pragma unroll
-                for (int x = 0; x < NR; ++x) {
-                    const uint32_t qa = *reinterpret_cast<const uint16_t*>(qbytes + x * qsliceBytes + oa);
-                    const uint32_t qb = *reinterpret_cast<const uint16_t*>(qbytes + x * qsliceBytes + ob);
-                    const uint32_t dd = __builtin_amdgcn_sad_u16(qa, qb, 0u);       // |qa - qb| (upper halves are zero)
-                    const bool cand = dd <= K;
-                    const unsigned long long m = __ballot(cand);
-                    if (m != 0ull) {
-                        const uint32_t at = qn + (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                        if (cand) queue[at] = (uint16_t)((uint32_t)(q0 + t * WAVE + lane) | ((uint32_t)x << 15));
-                        qn += (uint32_t)__popcll(m);
-                    }
-                }
+            for (int t = 0; t < 2; ++t) {
+                ea[t] = *reinterpret_cast<const uint2*>(qbytes + ((pk[t] & 0xffffu) << 3));
+                eb[t] = *reinterpret_cast<const uint2*>(qbytes + ((pk[t] >> 16) << 3));
             }
-            if (qn >= 64u) {                                    // (ds_write / ds_read of one wave execute in order: the barrier is for the compiler)
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                while (qn >= 64u) { qn -= 64u; consume(qn, 64u, k, zi, zj); }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            uint32_t n8 = 0u;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                // per 16-bit half: K - |a - b| is negative (sign bit set) where the pair is NOT a candidate
+                const pre_s2 c0 = __builtin_bit_cast(pre_s2, K2) - __builtin_elementwise_abs(__builtin_bit_cast(pre_s2, ea[t].x) - __builtin_bit_cast(pre_s2, eb[t].x));
+                const pre_s2 c1 = __builtin_bit_cast(pre_s2, K2) - __builtin_elementwise_abs(__builtin_bit_cast(pre_s2, ea[t].y) - __builtin_bit_cast(pre_s2, eb[t].y));
+                const uint32_t u = ((__builtin_bit_cast(uint32_t, c0) & 0x80008000u) >> 15) | ((__builtin_bit_cast(uint32_t, c1) & 0x80008000u) >> 13);
+                n8 |= ((u | (u >> 15)) & 0xfu) << (4 * t);      // row 0 -> bit 0, row 1 (bit 16) -> bit 1, row 2 -> bit 2, row 3 (bit 18) -> bit 3
+            }
+            nacc |= n8 << ((step & 3) << 3);
+            if ((step & 3) == 3) {
+                TCK(1);
+                flush(~nacc, qwin);
+                TCK(2);
+                nacc = 0u; qwin = q0 + 2 * WAVE;
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (qn) { consume(0u, qn, k, zi, zj); qn = 0u; }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        TCK(1);
+        if (step & 3) flush(~nacc & ((1u << ((step & 3) << 3)) - 1u), qwin);
+        TCK(2);
+        lds_order();
+        if (qn) { consume(0u, qn); qn = 0u; }
+        lds_order();
+        TCK(3);
         // the rows' words [R, W): out, coalesced, and cleared for the next rows
 #pragma unroll
         for (int x = 0; x < NR; ++x) {
@@ -1623,10 +1732,15 @@ __device__ __forceinline__ void count_rows_pre(const DevParams& D, const ProbDes
                 if (r + x < nrows) mbase[(int64_t)k[x] * W + wv] = mreg;
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();                        // table slices are rewritten by the next rows
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        lds_order();                                            // the bin table and the rows' data are rewritten by the next rows
+        TCK(4);
     }
+#ifdef ROMAN_COUNT_TIMING
+    if (lane == 0 && (threadIdx.x >> 6) == 0 && (blockIdx.x & 63) == 0 && row0 == 0 && nq_ > 0)
+        printf("[k_count pre] wg %d L %d quads %u: stage %llu sweep %llu push %llu (iterations %u) consume %llu (+%u inside the sweep) store %llu cycles per quad\n", (int)blockIdx.x, L, nq_,
+               tc_[0] / nq_, tc_[1] / nq_, tc_[2] / nq_, npush_ / nq_, tc_[3] / nq_, ncons_, tc_[4] / nq_);
+#endif
+#undef TCK
 }
 
 // A work item of a live set that does not fit the LDS column tile (no semantic gate: L = n1 * n2): the item's rows are swept
@@ -1657,7 +1771,7 @@ __device__ __forceinline__ void count_item_tiled(const DevParams& D, const ProbD
 }
 
 template <int GM, int NR, bool TILED, bool PRE = false /* candidate generation in front of the exact gate (one-tile sweep only): count_rows_pre */>
-__global__ void __launch_bounds__(1024) k_count(DevParams D, const ProbDesc* __restrict__ probs,
+__global__ void __launch_bounds__(PRE ? PRE_WAVES * 64 : 1024) k_count(DevParams D, const ProbDesc* __restrict__ probs,
                                                 const ProbState* __restrict__ st,
                                                 const BatchTotals* __restrict__ tot,
                                                 const ItemDesc* __restrict__ items,
@@ -1667,10 +1781,11 @@ __global__ void __launch_bounds__(1024) k_count(DevParams D, const ProbDesc* __r
                                                 uint32_t* __restrict__ rowCnt,
                                                 unsigned long long* __restrict__ maskPool,
                                                 uint32_t* __restrict__ prefPool,
-                                                int TC /* LDS column tile (multiple of 256) */, int ldsPerWave /* doubles: NR table slices */, int RPB)
+                                                int TC /* LDS column tile (multiple of 256) */, int ldsPerWave /* doubles: NR table slices */, int RPB,
+                                                const uint16_t* __restrict__ qtabPool /* PRE: the tables as bins (k_tables) */)
 {
     // LDS: [GM: cZZ[TC]] cIJ[TC] | per wave NR table slices (n1 + 1 + n2 doubles each)
-    // PRE: cIJ[TC] | per wave NR table slices | per wave: NR bin slices (u16), the candidate queue (64 + NR * 128 u16), NR mask rows of TC / 64 words
+    // PRE (NR is ignored: PRE_NR rows per wave; ldsPerWave = entries of the packed bin table): cIJ[TC] | per wave count_pre_wave_bytes()
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double2* cZZ = reinterpret_cast<double2*>(smem);
     uint32_t* cIJ = reinterpret_cast<uint32_t*>(cZZ + ((GM && !PRE) ? TC : 0));
@@ -1678,26 +1793,32 @@ __global__ void __launch_bounds__(1024) k_count(DevParams D, const ProbDesc* __r
     const int tid = threadIdx.x, nt = blockDim.x;
     const int lane = tid & 63, w = tid >> 6, wpb = nt >> 6;
     double* tA = tabs + (size_t)w * ldsPerWave;
-    // (PRE) per-wave extras behind all waves' table slices
-    const int preBytes = PRE ? count_pre_wave_bytes(NR, ldsPerWave / NR, TC) : 0;
-    unsigned char* pw = reinterpret_cast<unsigned char*>(tabs + (size_t)wpb * ldsPerWave) + (size_t)w * preBytes;
+    // (PRE) no f64 table slices at all: per wave the mask rows, the packed bin table, the queue, the rows' data
+    const int preBytes = PRE ? count_pre_wave_bytes(ldsPerWave, TC) : 0;
+    uint32_t* qctr = cIJ + TC + PRE_COLPAD;                      // (PRE) the rows' hand-out counter, 16 bytes
+    unsigned char* pw = reinterpret_cast<unsigned char*>(cIJ + TC + PRE_COLPAD + 4) + (size_t)w * preBytes;
     unsigned long long* rmask = reinterpret_cast<unsigned long long*>(pw);
-    uint16_t* qS = reinterpret_cast<uint16_t*>(rmask + NR * (TC >> 6));
-    uint16_t* queue = qS + ((NR * (ldsPerWave / NR) + 3) & ~3);
-    if (PRE) { for (int x = lane; x < NR * (TC >> 6); x += WAVE) rmask[x] = 0ull; }
-    const int nItems = tot->items;
+    uint2* qT = reinterpret_cast<uint2*>(rmask + PRE_NR * (TC >> 6));
+    uint16_t* queue = reinterpret_cast<uint16_t*>(qT + ldsPerWave);
+    PreRow* rowinfo = reinterpret_cast<PreRow*>(queue + PRE_QCAP);
+    if (PRE) { for (int x = lane; x < PRE_NR * (TC >> 6); x += WAVE) rmask[x] = 0ull; }
+    // PRE with RPB < 0: a work item is a whole PROBLEM (B = -RPB problems; batches with at least a problem per compute unit): the
+    // column tile is staged once per problem instead of once per 128 rows, and the rows go to the waves quad by quad
+    const bool whole = PRE && RPB < 0;
+    const int nItems = whole ? -RPB : tot->items;
     // XCD-aware order (workgroup ids are dealt to the 8 XCDs round-robin): XCD x takes the CONTIGUOUS range [x Gx, (x + 1) Gx) of
     // work items — the items of a problem, which share its tables, columns and mask rows, run on one L2
     const int Gx_ = (nItems + 7) >> 3;
     for (int sIdx_ = blockIdx.x; (sIdx_ >> 3) < Gx_; sIdx_ += gridDim.x) {
         const int t = (sIdx_ & 7) * Gx_ + (sIdx_ >> 3);
         if (t >= nItems) continue;
-        const ItemDesc it = items[t];
+        ItemDesc it;
+        if (whole) { it.b = t; it.row0 = 0; if (st[t].kind >= 2 || st[t].L <= 0) continue; } else it = items[t];
         const int b = it.b;
         const ProbDesc pd = probs[b];
         const int L = st[b].L;
         const int64_t lo = pd.liveOff, mo = st[b].maskOff;
-        const int nrows = min(RPB, L - it.row0);
+        const int nrows = whole ? L : min(RPB, L - it.row0);
         const double* TA = tabPool + pd.tabOff;
         const double* TB = TA + (int64_t)pd.n1 * pd.n1;
         const int Lpad = (L + 255) & ~255;
@@ -1709,15 +1830,17 @@ __global__ void __launch_bounds__(1024) k_count(DevParams D, const ProbDesc* __r
         if ((Lpad <= TC) == TILED) continue;
         if (!TILED) {
             __syncthreads();                    // every wave is done with the previous item's columns
-            for (int q = tid; q < Lpad; q += nt) {
+            for (int q = tid; q < Lpad + (PRE ? PRE_COLPAD : 0); q += nt) {     // (PRE: sentinel columns up to the end of a sweep's last step)
                 const bool v = q < L;
                 cIJ[q] = v ? ((uint32_t)li[lo + q] | ((uint32_t)(pd.n1 + 1 + lj[lo + q]) << 16)) : ((uint32_t)pd.n1 | ((uint32_t)(pd.n1 + 1) << 16));
                 if (GM && !PRE) cZZ[q] = v ? make_double2(lza[lo + q], lzb[lo + q]) : make_double2(0.0, 0.0);
             }
+            if (PRE && tid == 0) *qctr = 0u;
             __syncthreads();
             if (PRE)
-                count_rows_pre<GM, NR>(D, pd, L, it.row0, nrows, w, wpb, lane, cIJ, TA, TB, tA, ldsPerWave / NR, qS, queue, rmask, TC >> 6,
-                                       maskPool + mo, lza + lo, lzb + lo);
+                count_rows_pre<GM>(D, pd, L, it.row0, nrows, qctr, lane, cIJ, TA, TB,
+                                   qtabPool + 4 * (int64_t)pd.qtabOff4, qtabPool + 4 * (int64_t)pd.qtabOff4 + (int64_t)pd.n1 * ((pd.n1 + 3) & ~3),
+                                   qT, queue, rmask, TC >> 6, rowinfo, maskPool + mo, lza + lo, lzb + lo);
             else
             count_rows_lds<GM, NR, false>(D, pd, L, it.row0, nrows, w, wpb, lane, cIJ, cZZ, TA, TB, tA, ldsPerWave / NR, maskPool + mo,
                                           0, Lpad, li + lo, lj + lo, lza + lo, lzb + lo);

@@ -73,7 +73,7 @@ struct roman_ctx {
         bool issued = false;
         // pools (see DESIGN.md "Data layout in HBM")
         DevBuf probs, state, totals, queue;
-        DevBuf cosPool, tabPool, sTmp, chunkCnt;
+        DevBuf cosPool, tabPool, qtabPool, sTmp, chunkCnt;
         DevBuf lp, li, lj, ls, ld, lza, lzb;                       // per live association, live order
         DevBuf plp, pli, plj, pls, pld, plza, plzb;                // the same in position order (stream layout)
         DevBuf rowCnt, rowPos, perm, sliceWidth, sliceBase, items, maskPool, prefPool, listPool, listOff;
@@ -232,8 +232,11 @@ int make_dev_params(roman_ctx* c, const roman_params_t* p, int32_t F, DevParams*
     D->keep_all = D->single && D->p.single_mode == ROMAN_SINGLE_DIAG_KEEP;
     D->F = F;
     D->stream_maxL = STREAM_MAXL;
-    D->pre_invw = (p->epsilon > 0.0 && std::isfinite(p->epsilon)) ? 8.0 / p->epsilon : 0.0;   // k_count's prefilter: bins of epsilon / 8 ...
-    D->pre_K = 10;                                              // ... a gate-passing pair's entries are at most 8 + 1 bins apart (rounding); one bin of margin
+    // k_count's prefilter: bins of epsilon / 32 (15 bits: 1023 epsilon of range, 614 m at the reference's 0.6 m; everything beyond shares the
+    // last bin) — a gate-passing pair's entries are at most 32 + 1 bins apart (rounding); one bin of margin: pairs up to 1.09 epsilon apart
+    // reach the exact gate (bins of epsilon / 8, the first version: 1.375 epsilon, a quarter more candidates)
+    D->pre_invw = (p->epsilon > 0.0 && std::isfinite(p->epsilon)) ? 32.0 / p->epsilon : 0.0;
+    D->pre_K = 34;
     D->allow_fallback = 1;
     { static const char* cooEnv = getenv("ROMAN_COO"); D->solve_flags = (cooEnv && cooEnv[0] == '0') ? 1 : 0; }   // ROMAN_COO=0: A/B switch of the one-wave solver's coordinate form
     {   // ROMAN_FILL_ROTATE=0: list order inside a row (A/B); =m: rotate a row's quads by m * row (default 5)
@@ -445,7 +448,7 @@ int enqueue_score(roman_ctx* c, const DevParams& Din, const roman_params_t* para
 {
     const int B = in.B;
     hd.assign(B, ProbDesc{});
-    int64_t sumA = 0, sumCos = 0, sumTab = 0;
+    int64_t sumA = 0, sumCos = 0, sumTab = 0, sumQ4 = 0;
     int maxN12 = 0, maxN = 0, maxA = 0, maxN1 = 0, maxN2 = 0; int64_t maxTab = 0;
     for (int b = 0; b < B; ++b) {
         ProbDesc& d = hd[b];
@@ -463,6 +466,9 @@ int enqueue_score(roman_ctx* c, const DevParams& Din, const roman_params_t* para
             d.nA = (int32_t)na;
         }
         d.liveOff = sumA; d.cosOff = sumCos; d.tabOff = sumTab; d.normOff = 0;
+        if (sumQ4 > 2147483647LL) return fail(c, ROMAN_E_TOO_LARGE, "the tables of this batch exceed the bin pool's 32-bit offsets; split it");
+        d.qtabOff4 = (int32_t)sumQ4;
+        sumQ4 += ((int64_t)d.n1 * ((d.n1 + 3) & ~3) + (int64_t)d.n2 * ((d.n2 + 3) & ~3)) / 4;
         maxA = std::max(maxA, d.nA);
         sumA += d.nA; sumCos += (int64_t)d.n1 * d.n2; sumTab += (int64_t)d.n1 * d.n1 + (int64_t)d.n2 * d.n2;
         maxN12 = std::max(maxN12, d.n1 + d.n2); maxN = std::max(maxN, std::max(d.n1, d.n2));
@@ -557,7 +563,13 @@ int enqueue_score(roman_ctx* c, const DevParams& Din, const roman_params_t* para
         const int bands = std::max(1, std::min((maxN + 15) / 16, (2 * c->num_cu + 2 * B - 1) / (2 * B)));
         const int RBt = (((maxN + bands - 1) / bands) + 15) & ~15;
         const int thr = RBt >= 64 ? 1024 : 256;
-        hipLaunchKernelGGL(k_tables, dim3((unsigned)((maxN + RBt - 1) / RBt), 2, B), dim3(thr), tabLds, WS.stream, D, dP, in.feats, WS.tabPool.as<double>(), RBt);
+        // (the same entries as 15-bit bins for k_count's prefilter: 2 more bytes per entry)
+        uint16_t* qtab = nullptr;
+        if (D.pre_invw > 0.0 && std::isfinite(D.pre_invw)) {
+            HIPCHK(c, WS.qtabPool.ensure(sizeof(uint16_t) * 4 * (size_t)std::max<int64_t>(sumQ4, 1) + 64));
+            qtab = WS.qtabPool.as<uint16_t>();
+        }
+        hipLaunchKernelGGL(k_tables, dim3((unsigned)((maxN + RBt - 1) / RBt), 2, B), dim3(thr), tabLds, WS.stream, D, dP, in.feats, WS.tabPool.as<double>(), RBt, qtab);
     DBG(c, "k_tables");
     }
     {   // single scores, then the ordered compaction of the live associations: chunks x problems
@@ -600,19 +612,19 @@ int enqueue_score(roman_ctx* c, const DevParams& Din, const roman_params_t* para
     // 16-bit bin slices, the candidate queue and the rows' mask words.  Taken when the whole expected live set fits its tile;
     // ROMAN_COUNT_PRE=0 / 1 in the environment forces the plain sweep / the prefilter where it fits (A/B and tests: read per call).
     int preNR = 0, preWpb = 0, preTC = 0; size_t preLds = 0;
+    const int preRow = (2 * std::max(maxN, 1) + 1 + 3) & ~3;                 // entries of the packed bin table (n1 + sentinel + n2)
     {
         const char* preEnv = getenv("ROMAN_COUNT_PRE");
-        const bool want = (preEnv ? preEnv[0] != '0' : true) && D.pre_invw > 0.0 && std::isfinite(D.pre_invw) && Lneed <= 32768;
+        const bool want = (preEnv ? preEnv[0] != '0' : true) && D.pre_invw > 0.0 && std::isfinite(D.pre_invw) && Lneed <= 16000 && maxN <= 32767;
         if (want) {
             const int tc = Lneed;
-            for (int nr = 2; nr >= 1 && !preNR; --nr)
-                for (int wp = 16; wp >= 8; wp -= 4) {
-                    const size_t need = (size_t)tc * 4 + (size_t)wp * ((size_t)nr * ldsPerRow * sizeof(double) + (size_t)count_pre_wave_bytes(nr, ldsPerRow, tc));
-                    if (need <= c->lds_max) { preNR = nr; preWpb = wp; preTC = tc; preLds = need; break; }
-                }
+            for (int wp = PRE_WAVES; wp >= 8; wp -= 4) {
+                const size_t need = (size_t)(tc + PRE_COLPAD + 4) * 4 + (size_t)wp * (size_t)count_pre_wave_bytes(preRow, tc);
+                if (need <= c->lds_max) { preNR = PRE_NR; preWpb = wp; preTC = tc; preLds = need; break; }
+            }
             if (wpbEnv && preNR) {                               // (A/B: ROMAN_COUNT_WPB also caps the prefiltered sweep's waves)
                 preWpb = std::min(preWpb, wpb);
-                preLds = (size_t)preTC * 4 + (size_t)preWpb * ((size_t)preNR * ldsPerRow * sizeof(double) + (size_t)count_pre_wave_bytes(preNR, ldsPerRow, preTC));
+                preLds = (size_t)(preTC + PRE_COLPAD + 4) * 4 + (size_t)preWpb * (size_t)count_pre_wave_bytes(preRow, preTC);
             }
         }
     }
@@ -663,7 +675,7 @@ int enqueue_score(roman_ctx* c, const DevParams& Din, const roman_params_t* para
 #undef ROMAN_KC
             const bool usePre = !tiled && preNR > 0;
             if (usePre) {
-#define ROMAN_KP(GM_) kc = preNR == 2 ? reinterpret_cast<const void*>(k_count<GM_, 2, false, true>) : reinterpret_cast<const void*>(k_count<GM_, 1, false, true>)
+#define ROMAN_KP(GM_) kc = reinterpret_cast<const void*>(k_count<GM_, 1, false, true>)
                 switch (D.gmode) { case 1: ROMAN_KP(1); break; case 2: ROMAN_KP(2); break; case 3: ROMAN_KP(3); break; default: ROMAN_KP(0); break; }
 #undef ROMAN_KP
             }
@@ -674,8 +686,14 @@ int enqueue_score(roman_ctx* c, const DevParams& Din, const roman_params_t* para
             DevParams a_D = D; const ProbDesc* a_dP = dP; const ProbState* a_dS = dS; const BatchTotals* a_dT = dT; const ItemDesc* a_items = WS.items.as<ItemDesc>();
             const double* a_tab = WS.tabPool.as<double>(); const int32_t* a_li = LP.li; const int32_t* a_lj = LP.lj; const double* a_za = LP.lza; const double* a_zb = LP.lzb;
             uint32_t* a_rc = WS.rowCnt.as<uint32_t>(); unsigned long long* a_mask = WS.maskPool.as<unsigned long long>(); uint32_t* a_pref = WS.prefPool.as<uint32_t>();
-            int a_TC = usePre ? preTC : TCc, a_lpw = usePre ? preNR * ldsPerRow : ldsPerWave, a_RPB = RPB;
-            void* args[] = {&a_D, &a_dP, &a_dS, &a_dT, &a_items, &a_tab, &a_li, &a_lj, &a_za, &a_zb, &a_rc, &a_mask, &a_pref, &a_TC, &a_lpw, &a_RPB};
+            int a_TC = usePre ? preTC : TCc, a_lpw = usePre ? preRow : ldsPerWave;
+            // (the prefiltered sweep of a batch with at least a problem per compute unit takes whole problems as work items: RPB = -B;
+            //  ROMAN_COUNT_WHOLE=0 / 1 forces the row blocks / whole problems)
+            const char* wholeEnv = getenv("ROMAN_COUNT_WHOLE");
+            const bool wholeP = usePre && (wholeEnv ? wholeEnv[0] != '0' : B >= c->num_cu);
+            int a_RPB = wholeP ? -B : RPB;
+            const uint16_t* a_qtab = WS.qtabPool.as<uint16_t>();
+            void* args[] = {&a_D, &a_dP, &a_dS, &a_dT, &a_items, &a_tab, &a_li, &a_lj, &a_za, &a_zb, &a_rc, &a_mask, &a_pref, &a_TC, &a_lpw, &a_RPB, &a_qtab};
             HIPCHK(c, hipLaunchKernel(kc, dim3(gridK), dim3(wpbK * 64), args, ldsK, WS.stream));
         }
     DBG(c, "k_count");
@@ -1266,7 +1284,7 @@ int roman_ctx_destroy(roman_ctx_t* c)
     (void)roman_ctx_sync(c);
     for (int k = 0; k < ROMAN_MAX_PIPELINE; ++k) {
         roman_ctx::Workspace& W = c->ws[k];
-        DevBuf* all[] = {&W.probs, &W.state, &W.totals, &W.queue, &W.cosPool, &W.tabPool, &W.sTmp, &W.chunkCnt,
+        DevBuf* all[] = {&W.probs, &W.state, &W.totals, &W.queue, &W.cosPool, &W.tabPool, &W.qtabPool, &W.sTmp, &W.chunkCnt,
                          &W.lp, &W.li, &W.lj, &W.ls, &W.ld, &W.lza, &W.lzb, &W.plp, &W.pli, &W.plj, &W.pls, &W.pld, &W.plza, &W.plzb,
                          &W.rowCnt, &W.rowPos, &W.perm, &W.sliceWidth, &W.sliceBase, &W.items, &W.maskPool, &W.prefPool, &W.listPool, &W.listOff,
                          &W.vMu, &W.vCu, &W.vMun, &W.vCun, &W.gU, &W.gUn, &W.uOut, &W.nodesOrig, &W.nSel, &W.widePart, &W.wideSlots, &W.wideBar, &W.wideBm, &W.fbList, &W.cols16, &W.cols32, &W.vals, &W.colsC, &W.valsC,

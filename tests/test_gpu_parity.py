@@ -467,10 +467,10 @@ def test_pair_tests_with_candidate_generation_give_the_plain_sweeps_matrix(ctx, 
 
 @pytest.mark.parametrize("scale,epsilon,noise", [(1.0, 0.6, 0.1), (400.0, 0.6, 0.1), (1.0, 0.004, 0.0005), (1.0, 30.0, 0.1), (1.0e-3, 0.6, 0.0)])
 def test_candidate_generation_at_the_ends_of_the_bin_range(ctx, orc, scale, epsilon, noise, monkeypatch):
-    """The prefilter's bins are epsilon / 8 wide and clamp at 65280: maps 400 times as large (distances up to 12 km: everything
-    beyond 4.9 km shares the last bin), an epsilon of 4 mm (everything beyond 33 m shares it), an epsilon of 30 m and maps shrunk
-    to centimetres (every distance in the first bins: every pair is a candidate) — the matrix stays the oracle's and the plain
-    sweep's in every case (a false positive costs an exact test, never a bit)."""
+    """The prefilter's bins are epsilon / 32 wide and the last of the 32768 takes everything beyond: maps 400 times as large (distances
+    up to 12 km: everything beyond 614 m shares the last bin), an epsilon of 4 mm (everything beyond 4 m shares it), an epsilon of 30 m
+    and maps shrunk to centimetres (every distance in the first bins: every pair is a candidate) — the matrix stays the oracle's and
+    the plain sweep's in every case (a false positive costs an exact test, never a bit)."""
     reg = registration_for("semanticgrav", semantics_dim=32, epsilon=epsilon, sigma=max(epsilon / 1.5, 1e-3), mindist=0.0 if scale < 1 else 0.2)
     reg.set_context(ctx)
     P = reg._abi_params()
