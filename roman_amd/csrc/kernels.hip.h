@@ -1810,7 +1810,8 @@ __global__ void __launch_bounds__(PRE ? PRE_WAVES * 64 : 1024) k_count(DevParams
     // work items — the items of a problem, which share its tables, columns and mask rows, run on one L2
     const int Gx_ = (nItems + 7) >> 3;
     for (int sIdx_ = blockIdx.x; (sIdx_ >> 3) < Gx_; sIdx_ += gridDim.x) {
-        const int t = (sIdx_ & 7) * Gx_ + (sIdx_ >> 3);
+        // (whole problems: problem t on the XCD t mod 8, where k_lists — one workgroup per problem, b = blockIdx — reads its mask rows)
+        const int t = whole ? sIdx_ : (sIdx_ & 7) * Gx_ + (sIdx_ >> 3);
         if (t >= nItems) continue;
         ItemDesc it;
         if (whole) { it.b = t; it.row0 = 0; if (st[t].kind >= 2 || st[t].L <= 0) continue; } else it = items[t];
@@ -3048,6 +3049,43 @@ struct SolveOut {           // device pointers of the batch outputs
     unsigned long long* dbg;   // timing build only: 16 counters per problem
 };
 
+// Bounded launches of the stream solver (round 6).  A problem never leaves its workgroup, and a call with more problems than compute
+// units hands them out from a queue: a problem of 400 passes that is claimed late holds its unit long after the others have nothing left
+// to claim.  With a pass budget `cap` a problem that is still iterating after `cap` passes of this launch is SUSPENDED at the top of a
+// pass: its iterate (u, the fused product of u, the vector about to be multiplied: 3 L doubles) and sixteen scalars go to a slot of
+// `spill`, its number to `list`; a second launch of the same kernel (`resume`) picks the suspended problems up — all at once, one
+// workgroup each — and runs them to the end.  The resumed iteration executes the same instructions on the same values (order-free sums,
+// the same thread-to-element mapping, the same reduction trees): identical bits, identical pass counts.  No slot free: the problem
+// simply keeps running.
+struct SolveCont {
+    double*  spill;        // slots * slotDoubles
+    int32_t* list;         // problem number of every used slot
+    int*     counters;     // [0]: slots handed out (may exceed `slots`), [1]: the resume launch's claim counter
+    int32_t  cap;          // passes a problem may run in this launch before it is suspended (0: no limit)
+    int32_t  slots, slotDoubles, maxL;   // a slot: 16 scalars, then u, Wu, x at distances of maxL doubles
+    int32_t  resume;       // this launch takes the suspended problems
+};
+
+// The two copies between a slot and the workgroup's LDS (out of line: the solver's registers are full, and neither belongs in its loop).
+// LDS image: x0 = u, x1 = the fused product of u, x2 = the vector about to be multiplied (L doubles each), sc = the sixteen scalars.
+__device__ __noinline__ void cont_spill(const SolveCont* cont, int slot, int b, int L, const double* x0, const double* x1, const double* x2, const double* sc)
+{
+    double* sp = cont->spill + (size_t)slot * (size_t)cont->slotDoubles;
+    const int Lm = cont->maxL;
+    for (int p = threadIdx.x; p < L; p += blockDim.x) { sp[16 + p] = x0[p]; sp[16 + Lm + p] = x1[p]; sp[16 + 2 * Lm + p] = x2[p]; }
+    if (threadIdx.x < 16) sp[threadIdx.x] = sc[threadIdx.x];
+    if (threadIdx.x == 0) cont->list[slot] = b;
+    __threadfence();                                            // the resume launch (same stream) reads it
+}
+__device__ __noinline__ void cont_load(const SolveCont* cont, int slot, int L, double* x0, double* x1, double* x2, double* sc)
+{
+    const double* sp = cont->spill + (size_t)slot * (size_t)cont->slotDoubles;
+    const int Lm = cont->maxL;
+    for (int p = threadIdx.x; p < L; p += blockDim.x) { x0[p] = sp[16 + p]; x1[p] = sp[16 + Lm + p]; x2[p] = sp[16 + 2 * Lm + p]; }
+    if (threadIdx.x < 16) sc[threadIdx.x] = sp[threadIdx.x];
+    __syncthreads();
+}
+
 // Sum of (a, b) over the block, identical in every thread; fixed reduction tree.  `red` holds two
 // ping-pong scratch areas of 32 doubles (`par` flips on every call), so consecutive reductions need a
 // single barrier each: a buffer is rewritten only after the barrier of the following reduction.
@@ -3921,7 +3959,8 @@ __device__ void solve_up(const DevParams& D, int b, const ProbDesc& pd, ProbStat
                          double* xg /* [Lc] */, unsigned long long* accM /* [Lc] */, unsigned long long* accC /* [Lc] */, int Lc,
                          uint32_t* cumQ /* [ST_MAXSL + 1] */, double* red, int* sint, unsigned char* cooLds /* one-wave instantiation: COO_CAP * 12 bytes */,
                          int cooPre = -1 /* >= 0: cooLds already holds that many entries (k_small); no quad layout exists for the problem */,
-                         int rbPre = -1 /* >= 0: offset of the problem in the row pools (k_small runs before k_rowbase) */)
+                         int rbPre = -1 /* >= 0: offset of the problem in the row pools (k_small runs before k_rowbase) */,
+                         const SolveCont* cont = nullptr /* pass budget / suspended problems (general instantiation only) */, int resumeSlot = -1)
 {
     constexpr int NT = NW * 64;
 #ifdef ROMAN_SOLVE_TIMING
@@ -4334,9 +4373,54 @@ __device__ void solve_up(const DevParams& D, int b, const ProbDesc& pd, ProbStat
         acc = r2[0]; cnt = r2[1];
     };
 
-    if (phase == PH_INIT) normalize_u();
-    load_u_as_x();
+    [[maybe_unused]] int passes0 = 0;                           // n_pass when this launch took the problem
+    [[maybe_unused]] bool budget = false;
+    if constexpr (NW != 1 && !COOONLY) budget = cont != nullptr && cont->cap > 0;
+    bool resumed = false;
+    if constexpr (NW != 1 && !COOONLY) {
+        if (cont != nullptr && resumeSlot >= 0) {               // a suspended problem: the state it was spilled with, through LDS
+            double* x1 = reinterpret_cast<double*>(accM); double* x2 = reinterpret_cast<double*>(accC);
+            cont_load(cont, resumeSlot, L, xg, x1, x2, red);
+            phase = (int)uni(red[1]); i = (int)uni(red[2]); j = (int)uni(red[3]); kk = (int)uni(red[4]); n_pass = (int)uni(red[5]);
+            ls_trials = (int)uni(red[6]); inner_iters = (int)uni(red[7]); mp1T = (int)uni(red[8]);
+            alpha = uni(red[9]); F = uni(red[10]); d = uni(red[11]); usum = uni(red[12]); unsum = uni(red[13]); du2 = uni(red[14]); xmaxT = uni(red[15]);
+            FOR_K_ALL(k, p) {
+                const bool in = p < L;
+                u[k] = in ? xg[p] : 0.0; Wu[k] = in ? x1[p] : 0.0; tk[k] = in ? x2[p] : 0.0;
+            }
+            __syncthreads();
+            for (int p = tid; p < L; p += NT) { xg[p] = 0.0; accM[p] = 0ull; accC[p] = 0ull; }     // clean again: the first pass publishes into them
+            __syncthreads();
+            passes0 = n_pass; resumed = true;
+        }
+    }
+    if (!resumed) {
+        if (phase == PH_INIT) normalize_u();
+        load_u_as_x();
+    }
     for (;;) {
+        if constexpr (NW != 1 && !COOONLY) {
+            if (budget && n_pass - passes0 >= cont->cap) {      // out of budget: suspend here, in front of a pass (workgroup-uniform)
+                if (pend) { __syncthreads(); collect_pending(); }
+                __syncthreads();
+                if (tid == 0) sint[5] = atomicAdd(cont->counters, 1);
+                __syncthreads();
+                const int slot = uni(sint[5]);
+                if (slot < cont->slots) {
+                    double* x1 = reinterpret_cast<double*>(accM); double* x2 = reinterpret_cast<double*>(accC);
+                    FOR_K(k, p) if (p < L) { xg[p] = u[k]; x1[p] = Wu[k]; x2[p] = tk[k]; }
+                    if (tid == 0) {
+                        red[0] = (double)b; red[1] = (double)phase; red[2] = (double)i; red[3] = (double)j; red[4] = (double)kk; red[5] = (double)n_pass;
+                        red[6] = (double)ls_trials; red[7] = (double)inner_iters; red[8] = (double)mp1T; red[9] = alpha; red[10] = F; red[11] = d;
+                        red[12] = usum; red[13] = unsum; red[14] = du2; red[15] = xmaxT;
+                    }
+                    __syncthreads();
+                    cont_spill(cont, slot, b, L, xg, x1, x2, red);
+                    return;
+                }
+                budget = false;                                 // no slot left: this problem runs on
+            }
+        }
         // RESCALE: M x alone (a fused pass with nothing added); INIT / SPLIT: both products; TRIAL: (M + d C) x
         spmv(xmaxT, mp1T, phase == PH_INIT || phase == PH_SPLIT, phase == PH_TRIAL ? d : 0.0);
         if (phase == PH_RESCALE) {                              // u = normalize(M u0 + diag u0)
@@ -4439,7 +4523,8 @@ __global__ void __launch_bounds__(NW * 64, LEAN ? 4 : (NW == 1 ? 3 : 1)) k_solve
                                                       const uint32_t* __restrict__ sliceBase,
                                                       const uint16_t* __restrict__ cols, const double* __restrict__ vals,
                                                       const double* __restrict__ u0, SolveOut O,
-                                                      int* __restrict__ queue, int Lc, int Llo, int Lhi, int R /* problems per claim: 1..64 */)
+                                                      int* __restrict__ queue, int Lc, int Llo, int Lhi, int R /* problems per claim: 1..64 */,
+                                                      SolveCont cont /* pass budget / the suspended problems of the launch in front (NW == 1: unused) */)
 {
     // LDS: xg[Lc] f64 | accM[Lc] u64 | accC[Lc] u64 | red[red_doubles(NW)] | cumQ[ST_MAXSL + 2] u32 | sint[8]
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -4451,6 +4536,23 @@ __global__ void __launch_bounds__(NW * 64, LEAN ? 4 : (NW == 1 ? 3 : 1)) k_solve
     uint32_t* cumQ = reinterpret_cast<uint32_t*>(red + red_doubles(NW));
     int* sint = reinterpret_cast<int*>(cumQ + ST_MAXSL + 2);
     unsigned char* cooLds = reinterpret_cast<unsigned char*>(sint + 8);        // (one-wave instantiation only: COO_CAP * 12 bytes)
+    if constexpr (NW != 1) {
+        if (cont.resume) {                                      // the suspended problems of the launch in front, one workgroup each
+            for (;;) {
+                if (threadIdx.x == 0) sint[2] = atomicAdd(cont.counters + 1, 1);
+                __syncthreads();
+                const int slot = uni(sint[2]);
+                __syncthreads();
+                if (slot >= min(*cont.counters, cont.slots)) break;
+                const int b = cont.list[slot];
+                const ProbDesc pd = probs[b];
+                solve_up<NW, HASCZ, MAXL, DEPTH, LEAN>(D, b, pd, st, feats, assoc, plp, lpAsc, rowPos, pld, sliceBase, cols, vals, u0, O,
+                                          xg, accM, accC, Lc, cumQ, red, sint, cooLds, -1, -1, &cont, slot);
+                __syncthreads();
+            }
+            return;
+        }
+    }
     for (;;) {
         // The first wave claims R consecutive problems at a time (R = 1 unless this launch expects to find nothing: a batch
         // of small problems passes through the general instantiation and vice versa) until the range holds one this launch
@@ -4482,7 +4584,7 @@ __global__ void __launch_bounds__(NW * 64, LEAN ? 4 : (NW == 1 ? 3 : 1)) k_solve
         mask &= mask - 1ull;
         const ProbDesc pd = probs[b];
         solve_up<NW, HASCZ, MAXL, DEPTH, LEAN>(D, b, pd, st, feats, assoc, plp, lpAsc, rowPos, pld, sliceBase, cols, vals, u0, O,
-                                  xg, accM, accC, Lc, cumQ, red, sint, cooLds);
+                                  xg, accM, accC, Lc, cumQ, red, sint, cooLds, -1, -1, NW != 1 ? &cont : nullptr, -1);
         __syncthreads();                                         // the next problem of the range reuses the LDS state
         }
     }
@@ -5479,7 +5581,7 @@ __global__ void __launch_bounds__(256) k_skipped(int B, const ProbDesc* __restri
                                                  int* __restrict__ queue /* the solvers' problem queues (8 ints): cleared here */,
                                                  int32_t* __restrict__ fbList, unsigned* __restrict__ wideBar)
 {
-    if (blockIdx.x == 0 && threadIdx.x < 8) queue[threadIdx.x] = 0;
+    if (blockIdx.x == 0 && (threadIdx.x < 8 || threadIdx.x == 10 || threadIdx.x == 11)) queue[threadIdx.x] = 0;   // ([10], [11]: the stream solver's continuation counters)
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b < B && fbList != nullptr && st[b].kind == 1) {
         fbList[atomicAdd(wideBar + 32 * 21, 1u)] = b;

@@ -78,7 +78,7 @@ struct roman_ctx {
         DevBuf plp, pli, plj, pls, pld, plza, plzb;                // the same in position order (stream layout)
         DevBuf rowCnt, rowPos, perm, sliceWidth, sliceBase, items, maskPool, prefPool, listPool, listOff;
         DevBuf vMu, vCu, vMun, vCun, gU, gUn, uOut, nodesOrig, nSel, widePart, wideSlots, wideBar, wideBm, fbList;
-        DevBuf cols16, cols32, vals, colsC, valsC;
+        DevBuf cols16, cols32, vals, colsC, valsC, contSpill, contList;
         long long capMaskWords = 0, capNnz = 0, capList = 0;       // what the sparse pools hold (elements)
         // staging for the host-pointer entry points
         DevBuf hFeats, hAssoc, hU0, oAssoc, oN, oT, oStatus, oStats, hAux1, hAux2, hAux3;
@@ -846,6 +846,30 @@ int enqueue_solve(roman_ctx* c, const DevParams& D, int B, int64_t sumA, int64_t
     const int wgPerCu = std::max(1, std::min((int)(c->lds_max / ldsUp), 2048 / (NW * 64)));
     const int gridUp = std::max(1, std::min(B, c->num_cu * wgPerCu));
 
+    // Bounded launches (SolveCont, kernels.hip.h): a problem still iterating after `cap` passes of the launch is suspended and a second
+    // launch resumes the suspended ones, all at once, one workgroup each.  Built for the round-5 review's item 2 (a call with more
+    // problems than workgroups hands them out from a queue, and a 400-pass problem claimed late was thought to hold the tail), correct
+    // bit for bit (tests/test_gpu_batch.py::test_bounded_solver_launches_...), and MEASURED WITHOUT EFFECT (round 6, one box, budget 64
+    // against none, alternating): a rank's 512-pair share of the config-4 grid 4.4 ... 6.5 ms either way, the slowest rank 6.5 ms, one
+    // shot of the 4096-pair grid 32-33 ms, headline 157-160 k alignments/s.  The tail IS the long problem's own passes — 364 x ~10 us on
+    // its one compute unit, whenever they start —, not its place in the queue.  OFF unless ROMAN_SOLVE_CAP=n asks for a budget of n
+    // passes (read per call).
+    SolveCont cont{}; SolveCont contResume{};
+    {
+        const char* capEnv = getenv("ROMAN_SOLVE_CAP");
+        const int cap = capEnv ? std::max(0, atoi(capEnv)) : 0;
+        if (cap > 0 && !D.small_only) {
+            const int slots = std::max(64, std::min(B, 1024));
+            const int maxL = std::max(64, (D.stream_maxL + 63) & ~63);
+            const int slotDoubles = 16 + 3 * maxL;
+            HIPCHK(c, WS.contSpill.ensure(sizeof(double) * (size_t)slots * (size_t)slotDoubles));
+            HIPCHK(c, WS.contList.ensure(sizeof(int32_t) * (size_t)slots));
+            cont.spill = WS.contSpill.as<double>(); cont.list = WS.contList.as<int32_t>(); cont.counters = WS.queue.as<int>() + 10;
+            cont.cap = cap; cont.slots = slots; cont.slotDoubles = slotDoubles; cont.maxL = maxL; cont.resume = 0;
+            contResume = cont; contResume.cap = 0; contResume.resume = 1;
+        }
+    }
+
     StageTimer t3(c, ROMAN_STAGE_SOLVE);
     const bool coopPlanned = mayFallback && D.wide != 0 && c->coop_ok;
     if (coopPlanned) {                                          // the whole-device solver's barrier words, problem queue and list (k_skipped fills the list)
@@ -887,12 +911,16 @@ int enqueue_solve(roman_ctx* c, const DevParams& D, int B, int64_t sumA, int64_t
         HIPCHK(c, dyn_lds(c, reinterpret_cast<const void*>(kup), ldsUp)); \
         hipLaunchKernelGGL(kup, dim3(gridUp), dim3(NW * 64), ldsUp, WS.stream, D, B, WS.probs.as<ProbDesc>(), WS.state.as<ProbState>(), feats, assoc, \
                            WS.plp.as<int32_t>(), WS.lp.as<int32_t>(), WS.rowPos.as<uint32_t>(), WS.pld.as<double>(), WS.sliceBase.as<uint32_t>(), \
-                           WS.cols16.as<uint16_t>(), WS.vals.as<double>(), u0, O, WS.queue.as<int>(), Lc, small ? SMALL_MAXL + 1 : 0, STREAM_MAXL, (small && c->hist.valid && !c->hist.largeSeen) ? 64 : 1); \
+                           WS.cols16.as<uint16_t>(), WS.vals.as<double>(), u0, O, WS.queue.as<int>(), Lc, small ? SMALL_MAXL + 1 : 0, STREAM_MAXL, (small && c->hist.valid && !c->hist.largeSeen) ? 64 : 1, cont); \
+        if (cont.cap > 0)         /* the suspended problems, one workgroup each, to the end */                                  \
+            hipLaunchKernelGGL(kup, dim3(std::min(cont.slots, gridUp)), dim3(NW * 64), ldsUp, WS.stream, D, B, WS.probs.as<ProbDesc>(), WS.state.as<ProbState>(), feats, assoc, \
+                               WS.plp.as<int32_t>(), WS.lp.as<int32_t>(), WS.rowPos.as<uint32_t>(), WS.pld.as<double>(), WS.sliceBase.as<uint32_t>(), \
+                               WS.cols16.as<uint16_t>(), WS.vals.as<double>(), u0, O, WS.queue.as<int>(), Lc, small ? SMALL_MAXL + 1 : 0, STREAM_MAXL, 1, contResume); \
         if (small) {                                                                                                          \
             HIPCHK(c, dyn_lds(c, reinterpret_cast<const void*>(k_solve_up<1, CZ_, SMALL_MAXL>), ldsUp1));                       \
             hipLaunchKernelGGL((k_solve_up<1, CZ_, SMALL_MAXL>), dim3(gridUp1), dim3(64), ldsUp1, WS.stream, D, B, WS.probs.as<ProbDesc>(), WS.state.as<ProbState>(), feats, assoc, \
                                WS.plp.as<int32_t>(), WS.lp.as<int32_t>(), WS.rowPos.as<uint32_t>(), WS.pld.as<double>(), WS.sliceBase.as<uint32_t>(), \
-                               WS.cols16.as<uint16_t>(), WS.vals.as<double>(), u0, O, WS.queue.as<int>() + 1, Lc1, 0, SMALL_MAXL, 1); \
+                               WS.cols16.as<uint16_t>(), WS.vals.as<double>(), u0, O, WS.queue.as<int>() + 1, Lc1, 0, SMALL_MAXL, 1, SolveCont{}); \
         }                                                                                                                     \
     } while (0)
     if (hascz) ROMAN_LAUNCH_UP(true); else ROMAN_LAUNCH_UP(false);
@@ -1287,7 +1315,7 @@ int roman_ctx_destroy(roman_ctx_t* c)
         DevBuf* all[] = {&W.probs, &W.state, &W.totals, &W.queue, &W.cosPool, &W.tabPool, &W.qtabPool, &W.sTmp, &W.chunkCnt,
                          &W.lp, &W.li, &W.lj, &W.ls, &W.ld, &W.lza, &W.lzb, &W.plp, &W.pli, &W.plj, &W.pls, &W.pld, &W.plza, &W.plzb,
                          &W.rowCnt, &W.rowPos, &W.perm, &W.sliceWidth, &W.sliceBase, &W.items, &W.maskPool, &W.prefPool, &W.listPool, &W.listOff,
-                         &W.vMu, &W.vCu, &W.vMun, &W.vCun, &W.gU, &W.gUn, &W.uOut, &W.nodesOrig, &W.nSel, &W.widePart, &W.wideSlots, &W.wideBar, &W.wideBm, &W.fbList, &W.cols16, &W.cols32, &W.vals, &W.colsC, &W.valsC,
+                         &W.vMu, &W.vCu, &W.vMun, &W.vCun, &W.gU, &W.gUn, &W.uOut, &W.nodesOrig, &W.nSel, &W.widePart, &W.wideSlots, &W.wideBar, &W.wideBm, &W.fbList, &W.cols16, &W.cols32, &W.vals, &W.colsC, &W.valsC, &W.contSpill, &W.contList,
                          &W.hFeats, &W.hAssoc, &W.hU0, &W.oAssoc, &W.oN, &W.oT, &W.oStatus, &W.oStats, &W.hAux1, &W.hAux2, &W.hAux3, &W.oAll};
         for (DevBuf* b : all) b->release();
         if (W.pinnedTotals) (void)hipHostFree(W.pinnedTotals);
@@ -1841,7 +1869,7 @@ int roman_set_matrix_data(roman_ctx_t* c, const roman_params_t* params, const do
     const size_t maskWords = std::max<size_t>((size_t)n * (size_t)W, 1);
     const long long capList = up ? (long long)n * (n - 1) / 2 + 4LL * n + 4 : 4;
     HIPCHK(c, WS.probs.ensure(sizeof(ProbDesc))); HIPCHK(c, WS.state.ensure(sizeof(ProbState))); HIPCHK(c, WS.totals.ensure(sizeof(BatchTotals)));
-    HIPCHK(c, WS.queue.ensure(sizeof(int) * 8));
+    HIPCHK(c, WS.queue.ensure(sizeof(int) * 16));
     {
         DevBuf* i32s[] = {&WS.lp, &WS.plp, &WS.rowCnt, &WS.rowPos, &WS.perm, &WS.sliceWidth, &WS.sliceBase, &WS.listOff};
         for (DevBuf* b_ : i32s) HIPCHK(c, b_->ensure(sizeof(int32_t) * n1_));

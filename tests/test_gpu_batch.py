@@ -869,3 +869,35 @@ def test_join_on_the_null_stream_is_refused(ctx):
     with pytest.raises(ValueError):
         ctx.join(skip_latest=False, stream=0)
     ctx.join(skip_latest=False)                                   # (the context's own stream: fine)
+
+
+@pytest.mark.parametrize("cap,B", [("3", 24), ("1", 24), ("7", 100)], ids=["budget_3_passes", "budget_1_pass", "more_suspended_than_slots"])
+def test_bounded_solver_launches_resume_suspended_problems_bit_for_bit(ctx, cap, B, monkeypatch):
+    """The stream solver with a pass budget (SolveCont, kernels.hip.h: a problem still iterating after `cap` passes of a launch is
+    suspended — iterate, fused product, the vector about to be multiplied and sixteen scalars to a slot — and a second launch resumes
+    the suspended ones) against the same batch without one: EVERY output identical bit for bit — associations incl. order, poses,
+    scores, d, pass / trial / iteration counts.  A budget of 1 suspends in front of the second pass (the rescale pass done), 3 inside
+    the first line searches; 100 problems with a budget of 7 are more suspended problems than the launch has slots (64 for a batch of
+    100): the rest runs on where it is.  The pairs of the reference's loop are independent ([REF roman/align/submap_align.py:93-200]):
+    when and where a problem's iteration continues must not show."""
+    reg = registration_for("semanticgrav", semantics_dim=48); reg.set_context(ctx)
+    rng = np.random.default_rng(42)
+    pairs = []
+    for k in range(B):
+        n, m = int(rng.integers(55, 90)), int(rng.integers(55, 90))
+        pr = synth.make_pair(n, m, 48, 9000 + k, tilt_deg=1.0)
+        pairs.append((pr.map1, pr.map2))
+    batch = rb.batch_from_pairs(reg, pairs)
+    got = {}
+    for setting in ("0", cap):
+        monkeypatch.setenv("ROMAN_SOLVE_CAP", setting)
+        got[setting] = rb.run_batch(reg, batch)
+    a, b_ = got["0"], got[cap]
+    assert (a.stats["n_live"] > 128).sum() >= B // 2              # (the general instantiation's problems: the one-wave solver has no budget)
+    assert (a.stats["n_pass"] > int(cap)).sum() >= B // 2         # ... and most of them run out of it
+    assert np.array_equal(a.status, b_.status)
+    for k in range(B):
+        assert np.array_equal(a.assoc[k], b_.assoc[k]), k
+    assert np.array_equal(a.T, b_.T, equal_nan=True)
+    for f in ("n_live", "nnz_upper", "n_pass", "outer_iters", "inner_iters", "ls_trials", "score", "d_final"):
+        assert np.array_equal(a.stats[f], b_.stats[f]), f
