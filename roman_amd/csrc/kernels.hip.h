@@ -2080,6 +2080,9 @@ __global__ void __launch_bounds__(1024) k_rowsort(const ProbDesc* __restrict__ p
                                                   uint32_t* __restrict__ listOff, long long capList, int skip0 /* stream-layout problems take k_lists */,
                                                   int eqMax /* place_keys(): rows of one degree at most; 0: always the bitonic sort */)
 {
+    // (static LDS of this kernel: ~70 KB — hist 32 KB, place_keys()' tables 24 KB, rows and degrees 12 KB.  gfx950 has 160 KB per
+    //  workgroup; the 64 KB parts before it are NOT a target of this library: see the static_assert below and the Makefile)
+    static_assert(sizeof(uint32_t) * (SORT_KEYS + 2 * STREAM_MAXL) + sizeof(uint16_t) * 2 * STREAM_MAXL <= 160 * 1024, "k_rowsort's tables must fit the LDS of a gfx950 workgroup");
     __shared__ uint32_t hist[SORT_KEYS];         // indexed by SORT_KEYS-1-key: ascending index = descending count
     __shared__ uint32_t wsum[20];
     __shared__ uint32_t hcntS[STREAM_MAXL], hcurS[STREAM_MAXL];     // place_keys(): rows per degree, cursor / end of the degree's range
@@ -3948,7 +3951,8 @@ __device__ __forceinline__ double fx_decode(unsigned long long a, double inv)
     return fma((double)(uint32_t)(a >> 32), 4294967296.0, (double)(uint32_t)a) * inv;
 }
 
-template <int NW, bool HASCZ, int MAXL, int DEPTH = ST_D, bool LEAN = false, bool COOONLY = false /* the matrix is ALWAYS a pre-built coordinate list (k_small): no quad stream in the code */>
+template <int NW, bool HASCZ, int MAXL, int DEPTH = ST_D, bool LEAN = false, bool COOONLY = false /* the matrix is ALWAYS a pre-built coordinate list (k_small): no quad stream in the code */,
+          bool BUDGET = false /* pass budgets / suspended problems (SolveCont): an instantiation of its own — the extra live state cost the default one 4 % */>
 __device__ void solve_up(const DevParams& D, int b, const ProbDesc& pd, ProbState* st,
                          const double* __restrict__ feats, const int32_t* __restrict__ assoc,
                          const int32_t* __restrict__ plp /* position -> association index */, const int32_t* __restrict__ lpAsc,
@@ -4375,9 +4379,9 @@ __device__ void solve_up(const DevParams& D, int b, const ProbDesc& pd, ProbStat
 
     [[maybe_unused]] int passes0 = 0;                           // n_pass when this launch took the problem
     [[maybe_unused]] bool budget = false;
-    if constexpr (NW != 1 && !COOONLY) budget = cont != nullptr && cont->cap > 0;
+    if constexpr (BUDGET && NW != 1 && !COOONLY) budget = cont != nullptr && cont->cap > 0;
     bool resumed = false;
-    if constexpr (NW != 1 && !COOONLY) {
+    if constexpr (BUDGET && NW != 1 && !COOONLY) {
         if (cont != nullptr && resumeSlot >= 0) {               // a suspended problem: the state it was spilled with, through LDS
             double* x1 = reinterpret_cast<double*>(accM); double* x2 = reinterpret_cast<double*>(accC);
             cont_load(cont, resumeSlot, L, xg, x1, x2, red);
@@ -4399,7 +4403,7 @@ __device__ void solve_up(const DevParams& D, int b, const ProbDesc& pd, ProbStat
         load_u_as_x();
     }
     for (;;) {
-        if constexpr (NW != 1 && !COOONLY) {
+        if constexpr (BUDGET && NW != 1 && !COOONLY) {
             if (budget && n_pass - passes0 >= cont->cap) {      // out of budget: suspend here, in front of a pass (workgroup-uniform)
                 if (pend) { __syncthreads(); collect_pending(); }
                 __syncthreads();
@@ -4514,7 +4518,7 @@ __device__ void solve_up(const DevParams& D, int b, const ProbDesc& pd, ProbStat
 // reductions at all), 64-thread workgroups, many of them per compute unit: submaps of the reference's demo scale (20-40
 // objects, ~60 live associations) would otherwise occupy a whole 8-wave workgroup — a whole compute unit, given the
 // registers of the general instantiation — for ~100 entries of matrix.  [Llo, Lhi]: the live-set sizes this launch takes.
-template <int NW, bool HASCZ, int MAXL, int DEPTH = ST_D, bool LEAN = false>
+template <int NW, bool HASCZ, int MAXL, int DEPTH = ST_D, bool LEAN = false, bool BUDGET = false>
 __global__ void __launch_bounds__(NW * 64, LEAN ? 4 : (NW == 1 ? 3 : 1)) k_solve_up(DevParams D, int B, const ProbDesc* __restrict__ probs,
                                                       ProbState* __restrict__ st,
                                                       const double* __restrict__ feats, const int32_t* __restrict__ assoc,
@@ -4536,7 +4540,7 @@ __global__ void __launch_bounds__(NW * 64, LEAN ? 4 : (NW == 1 ? 3 : 1)) k_solve
     uint32_t* cumQ = reinterpret_cast<uint32_t*>(red + red_doubles(NW));
     int* sint = reinterpret_cast<int*>(cumQ + ST_MAXSL + 2);
     unsigned char* cooLds = reinterpret_cast<unsigned char*>(sint + 8);        // (one-wave instantiation only: COO_CAP * 12 bytes)
-    if constexpr (NW != 1) {
+    if constexpr (BUDGET && NW != 1) {
         if (cont.resume) {                                      // the suspended problems of the launch in front, one workgroup each
             for (;;) {
                 if (threadIdx.x == 0) sint[2] = atomicAdd(cont.counters + 1, 1);
@@ -4546,7 +4550,7 @@ __global__ void __launch_bounds__(NW * 64, LEAN ? 4 : (NW == 1 ? 3 : 1)) k_solve
                 if (slot >= min(*cont.counters, cont.slots)) break;
                 const int b = cont.list[slot];
                 const ProbDesc pd = probs[b];
-                solve_up<NW, HASCZ, MAXL, DEPTH, LEAN>(D, b, pd, st, feats, assoc, plp, lpAsc, rowPos, pld, sliceBase, cols, vals, u0, O,
+                solve_up<NW, HASCZ, MAXL, DEPTH, LEAN, false, true>(D, b, pd, st, feats, assoc, plp, lpAsc, rowPos, pld, sliceBase, cols, vals, u0, O,
                                           xg, accM, accC, Lc, cumQ, red, sint, cooLds, -1, -1, &cont, slot);
                 __syncthreads();
             }
@@ -4583,8 +4587,8 @@ __global__ void __launch_bounds__(NW * 64, LEAN ? 4 : (NW == 1 ? 3 : 1)) k_solve
         const int b = base + __builtin_ctzll(mask);
         mask &= mask - 1ull;
         const ProbDesc pd = probs[b];
-        solve_up<NW, HASCZ, MAXL, DEPTH, LEAN>(D, b, pd, st, feats, assoc, plp, lpAsc, rowPos, pld, sliceBase, cols, vals, u0, O,
-                                  xg, accM, accC, Lc, cumQ, red, sint, cooLds, -1, -1, NW != 1 ? &cont : nullptr, -1);
+        solve_up<NW, HASCZ, MAXL, DEPTH, LEAN, false, BUDGET>(D, b, pd, st, feats, assoc, plp, lpAsc, rowPos, pld, sliceBase, cols, vals, u0, O,
+                                  xg, accM, accC, Lc, cumQ, red, sint, cooLds, -1, -1, (BUDGET && NW != 1) ? &cont : nullptr, -1);
         __syncthreads();                                         // the next problem of the range reuses the LDS state
         }
     }

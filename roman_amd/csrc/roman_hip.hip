@@ -907,7 +907,8 @@ int enqueue_solve(roman_ctx* c, const DevParams& D, int B, int64_t sumA, int64_t
     const bool deep = deepEnv && deepEnv[0] == '1';
 #define ROMAN_LAUNCH_UP(CZ_)                                                                                                  \
     do {                                                                                                                      \
-        auto kup = lean ? k_solve_up<NW, CZ_, LEAN_MAXL, LEAN_D, true> : (deep ? k_solve_up<NW, CZ_, STREAM_MAXL, DEEP_D> : k_solve_up<NW, CZ_, STREAM_MAXL>); \
+        auto kup = cont.cap > 0 ? k_solve_up<NW, CZ_, STREAM_MAXL, ST_D, false, true>     /* (the budgeted instantiation: plain stream depth only) */ \
+                                : (lean ? k_solve_up<NW, CZ_, LEAN_MAXL, LEAN_D, true> : (deep ? k_solve_up<NW, CZ_, STREAM_MAXL, DEEP_D> : k_solve_up<NW, CZ_, STREAM_MAXL>)); \
         HIPCHK(c, dyn_lds(c, reinterpret_cast<const void*>(kup), ldsUp)); \
         hipLaunchKernelGGL(kup, dim3(gridUp), dim3(NW * 64), ldsUp, WS.stream, D, B, WS.probs.as<ProbDesc>(), WS.state.as<ProbState>(), feats, assoc, \
                            WS.plp.as<int32_t>(), WS.lp.as<int32_t>(), WS.rowPos.as<uint32_t>(), WS.pld.as<double>(), WS.sliceBase.as<uint32_t>(), \
