@@ -1503,7 +1503,7 @@ __host__ __device__ constexpr int count_pre_wave_bytes(int ldsPerRow, int TC)
 {
     return PRE_NR * (TC >> 6) * 8 + ldsPerRow * 8 + PRE_QCAP * 2 + PRE_NR * 32;
 }
-struct PreRow { double zi, zj; uint32_t rowA, rowB, moff, pad1; };   // heights of the row's objects; first entries of its two table rows; byte offset of its mask words
+struct PreRow { double zi, zj; uint32_t rowA, rowB, moff, krow; };   // heights of the row's objects; first entries of its two table rows; byte offset of its mask words; the live row
 typedef short pre_s2 __attribute__((ext_vector_type(2)));
 
 template <int GM>
@@ -1516,7 +1516,8 @@ __device__ __forceinline__ void count_rows_pre(const DevParams& D, const ProbDes
                                                unsigned long long* rmask /* PRE_NR rows of Wcap words, zero on entry and on exit */, int Wcap,
                                                PreRow* rowinfo,
                                                unsigned long long* __restrict__ mbase,
-                                               const double* __restrict__ gZa, const double* __restrict__ gZb)
+                                               const double* __restrict__ gZa, const double* __restrict__ gZb,
+                                               uint32_t* degS /* LDS, or NULL: the full degree of every live row, counted as the pairs pass (whole problems only) */)
 {
     constexpr int NR = PRE_NR;
     const int W = (L + 63) >> 6;
@@ -1581,8 +1582,16 @@ __device__ __forceinline__ void count_rows_pre(const DevParams& D, const ProbDes
             double dz = 0.0;
             if (GM) { const PreRow* ri = rowinfo + x; dz = fabs((ri->zi - za[c]) - (ri->zj - zb[c])); }
             const bool is = (int)qq < L && pair_gate<GM>(D, a[c], bb[c], dz);
-            if (is) (void)__hip_atomic_fetch_or(reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(rmask) + rowinfo[x].moff + ((qq >> 6) << 3)),
-                                                1ull << (qq & 63u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (is) {
+                const PreRow* ri = rowinfo + x;
+                (void)__hip_atomic_fetch_or(reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(rmask) + ri->moff + ((qq >> 6) << 3)),
+                                            1ull << (qq & 63u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                // a pair of the strict upper triangle counts for both of its rows (k_lists' degrees: it then skips its own sweep)
+                if (degS != nullptr && qq > ri->krow) {
+                    (void)__hip_atomic_fetch_add(degS + ri->krow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    (void)__hip_atomic_fetch_add(degS + qq, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
         }
     };
     // candidate bits of a window (up to four steps of two 64-column chunks: bit 8 s + 4 t + x of a lane = column qwin + (2 s + t) 64 + lane,
@@ -1650,7 +1659,11 @@ __device__ __forceinline__ void count_rows_pre(const DevParams& D, const ProbDes
 #pragma unroll
             for (int x = 1; x < NR; ++x) if (lane == x) { i_ = pi[x]; j_ = pj[x]; }
             PreRow ri; ri.rowA = (uint32_t)i_ * (uint32_t)n1; ri.rowB = (uint32_t)j_ * (uint32_t)n2 - (uint32_t)(n1 + 1);
-            ri.moff = (uint32_t)lane * (uint32_t)Wcap * 8u; ri.pad1 = 0; ri.zi = pzi; ri.zj = pzj;
+            ri.moff = (uint32_t)lane * (uint32_t)Wcap * 8u; ri.zi = pzi; ri.zj = pzj;
+            int kr_ = k[0];
+#pragma unroll
+            for (int x = 1; x < NR; ++x) if (lane == x) kr_ = (r + x < nrows) ? k[x] : 0x7fffffff;   // (a duplicated last row counts nothing)
+            ri.krow = (uint32_t)kr_;
             rowinfo[lane] = ri;
         }
         // the packed bin table: entry t = the NR rows' bins of table column t (map-1 columns, the sentinel, map-2 columns)
@@ -1796,7 +1809,8 @@ __global__ void __launch_bounds__(PRE ? PRE_WAVES * 64 : 1024) k_count(DevParams
     // (PRE) no f64 table slices at all: per wave the mask rows, the packed bin table, the queue, the rows' data
     const int preBytes = PRE ? count_pre_wave_bytes(ldsPerWave, TC) : 0;
     uint32_t* qctr = cIJ + TC + PRE_COLPAD;                      // (PRE) the rows' hand-out counter, 16 bytes
-    unsigned char* pw = reinterpret_cast<unsigned char*>(cIJ + TC + PRE_COLPAD + 4) + (size_t)w * preBytes;
+    uint32_t* degL = cIJ + TC + PRE_COLPAD + 4;                  // (PRE, whole problems) TC row degrees
+    unsigned char* pw = reinterpret_cast<unsigned char*>(cIJ + TC + PRE_COLPAD + 4 + ((PRE && RPB < 0) ? TC : 0)) + (size_t)w * preBytes;
     unsigned long long* rmask = reinterpret_cast<unsigned long long*>(pw);
     uint2* qT = reinterpret_cast<uint2*>(rmask + PRE_NR * (TC >> 6));
     uint16_t* queue = reinterpret_cast<uint16_t*>(qT + ldsPerWave);
@@ -1837,11 +1851,17 @@ __global__ void __launch_bounds__(PRE ? PRE_WAVES * 64 : 1024) k_count(DevParams
                 if (GM && !PRE) cZZ[q] = v ? make_double2(lza[lo + q], lzb[lo + q]) : make_double2(0.0, 0.0);
             }
             if (PRE && tid == 0) *qctr = 0u;
+            if (PRE && whole) for (int q = tid; q < L; q += nt) degL[q] = 0u;
             __syncthreads();
-            if (PRE)
+            if (PRE) {
                 count_rows_pre<GM>(D, pd, L, it.row0, nrows, qctr, lane, cIJ, TA, TB,
                                    qtabPool + 4 * (int64_t)pd.qtabOff4, qtabPool + 4 * (int64_t)pd.qtabOff4 + (int64_t)pd.n1 * ((pd.n1 + 3) & ~3),
-                                   qT, queue, rmask, TC >> 6, rowinfo, maskPool + mo, lza + lo, lzb + lo);
+                                   qT, queue, rmask, TC >> 6, rowinfo, maskPool + mo, lza + lo, lzb + lo, whole ? degL : nullptr);
+                if (whole) {                                    // the problem's degrees, for k_lists (live order)
+                    __syncthreads();
+                    for (int q = tid; q < L; q += nt) rowCnt[lo + q] = degL[q];
+                }
+            }
             else
             count_rows_lds<GM, NR, false>(D, pd, L, it.row0, nrows, w, wpb, lane, cIJ, cZZ, TA, TB, tA, ldsPerWave / NR, maskPool + mo,
                                           0, Lpad, li + lo, lj + lo, lza + lo, lzb + lo);
@@ -2311,7 +2331,8 @@ __global__ void __launch_bounds__(LISTS_NT) k_lists(int B, const ProbDesc* __res
                                                    uint16_t* __restrict__ listPool, uint32_t* __restrict__ listOff,
                                                    uint32_t* __restrict__ rowCnt, uint32_t* __restrict__ perm, uint32_t* __restrict__ rowPos,
                                                    LivePools src, LivePools dst, long long capList,
-                                                   int eqMax /* place_keys(): rows of one degree at most; 0: always the bitonic sort */)
+                                                   int eqMax /* place_keys(): rows of one degree at most; 0: always the bitonic sort */,
+                                                   int degGiven /* rowCnt holds every live row's full degree (k_count counted the pairs as they passed: whole problems): no degree sweep */)
 {
     __shared__ uint32_t degS[STREAM_MAXL + 64];                 // full degree of a live row; after the sort: the row's list cursor
     __shared__ uint32_t keyS[4096];                             // sort keys
@@ -2364,9 +2385,10 @@ __global__ void __launch_bounds__(LISTS_NT) k_lists(int B, const ProbDesc* __res
 #else
 #define LMARK(i_) do { } while (0)
 #endif
-        for (int q = tid; q < L; q += LISTS_NT) degS[q] = 0u;
+        for (int q = tid; q < L; q += LISTS_NT) degS[q] = degGiven ? rowCnt[lo + q] : 0u;
         __syncthreads();
         // ---- degrees ----
+        if (!degGiven) {
         sweep([&](int k, unsigned long long m, int c) {
             if (m) {
                 atomicAdd(&degS[k], (uint32_t)__popcll(m));
@@ -2374,6 +2396,7 @@ __global__ void __launch_bounds__(LISTS_NT) k_lists(int B, const ProbDesc* __res
             }
         });
         __syncthreads();
+        }
         LMARK(1);
         // ---- positions: bitonic sort (descending) of the unique keys ((degree + 1) << 12) | (4095 - row) (k_rowsort's order) ----
         int N = 64; while (N < L) N <<= 1;

@@ -667,6 +667,7 @@ int enqueue_score(roman_ctx* c, const DevParams& Din, const roman_params_t* para
         // two instantiations over the same items: the one-tile sweep for live sets that fit the LDS column tile, and — launched
         // only when such problems can exist (fallback problems, or a tile capped by the LDS) — the tile-by-tile sweep for the rest
         const bool needTiled = D.allow_fallback || TCc < Lneed;
+        int degGiven = 0;
         for (int tiled = 0; tiled < (needTiled ? 2 : 1); ++tiled) {
             const void* kc = nullptr;
 #define ROMAN_KC(GM_) kc = tiled ? (NRc == 2 ? reinterpret_cast<const void*>(k_count<GM_, 2, true>) : reinterpret_cast<const void*>(k_count<GM_, 1, true>)) \
@@ -682,19 +683,20 @@ int enqueue_score(roman_ctx* c, const DevParams& Din, const roman_params_t* para
             const size_t ldsK = usePre ? preLds : pairLds;
             const int wpbK = usePre ? preWpb : wpb;
             const int gridK = usePre ? c->num_cu * std::max(1, std::min(2048 / (wpbK * 64), (int)(c->lds_max / ldsK))) : pairGrid;
-            HIPCHK(c, dyn_lds(c, kc, ldsK));
+            // (the prefiltered sweep of a batch with at least a problem per compute unit takes whole problems as work items: RPB = -B;
+            //  ROMAN_COUNT_WHOLE=0 / 1 forces the row blocks / whole problems; + the rows' degrees in LDS then)
+            const char* wholeEnv = getenv("ROMAN_COUNT_WHOLE");
+            const bool wholeP = usePre && (wholeEnv ? wholeEnv[0] != '0' : B >= c->num_cu) && preLds + (size_t)preTC * 4 <= c->lds_max;
+            if (wholeP) degGiven = 1;                            // k_count counts the degrees as the pairs pass: k_lists skips its degree sweep
+            HIPCHK(c, dyn_lds(c, kc, ldsK + (wholeP ? (size_t)preTC * 4 : 0)));
             DevParams a_D = D; const ProbDesc* a_dP = dP; const ProbState* a_dS = dS; const BatchTotals* a_dT = dT; const ItemDesc* a_items = WS.items.as<ItemDesc>();
             const double* a_tab = WS.tabPool.as<double>(); const int32_t* a_li = LP.li; const int32_t* a_lj = LP.lj; const double* a_za = LP.lza; const double* a_zb = LP.lzb;
             uint32_t* a_rc = WS.rowCnt.as<uint32_t>(); unsigned long long* a_mask = WS.maskPool.as<unsigned long long>(); uint32_t* a_pref = WS.prefPool.as<uint32_t>();
             int a_TC = usePre ? preTC : TCc, a_lpw = usePre ? preRow : ldsPerWave;
-            // (the prefiltered sweep of a batch with at least a problem per compute unit takes whole problems as work items: RPB = -B;
-            //  ROMAN_COUNT_WHOLE=0 / 1 forces the row blocks / whole problems)
-            const char* wholeEnv = getenv("ROMAN_COUNT_WHOLE");
-            const bool wholeP = usePre && (wholeEnv ? wholeEnv[0] != '0' : B >= c->num_cu);
             int a_RPB = wholeP ? -B : RPB;
             const uint16_t* a_qtab = WS.qtabPool.as<uint16_t>();
             void* args[] = {&a_D, &a_dP, &a_dS, &a_dT, &a_items, &a_tab, &a_li, &a_lj, &a_za, &a_zb, &a_rc, &a_mask, &a_pref, &a_TC, &a_lpw, &a_RPB, &a_qtab};
-            HIPCHK(c, hipLaunchKernel(kc, dim3(gridK), dim3(wpbK * 64), args, ldsK, WS.stream));
+            HIPCHK(c, hipLaunchKernel(kc, dim3(gridK), dim3(wpbK * 64), args, ldsK + (wholeP ? (size_t)preTC * 4 : 0), WS.stream));
         }
     DBG(c, "k_count");
         // Stream-layout problems (kind 0) go from the upper blocks straight to positions and kept-candidate lists in ONE kernel, one
@@ -707,7 +709,7 @@ int enqueue_score(roman_ctx* c, const DevParams& Din, const roman_params_t* para
         if (fusedLists) {
             hipLaunchKernelGGL(k_lists, dim3((unsigned)std::max(1, std::min(B, 2 * c->num_cu))), dim3(LISTS_NT), 0, WS.stream, B, dP, dS, dT,
                                WS.maskPool.as<unsigned long long>(), WS.listPool.as<uint16_t>(), WS.listOff.as<uint32_t>(),
-                               WS.rowCnt.as<uint32_t>(), WS.perm.as<uint32_t>(), WS.rowPos.as<uint32_t>(), LP, PP, (long long)SZ.capList, sort_eq_max());
+                               WS.rowCnt.as<uint32_t>(), WS.perm.as<uint32_t>(), WS.rowPos.as<uint32_t>(), LP, PP, (long long)SZ.capList, sort_eq_max(), degGiven);
     DBG(c, "k_lists");
         }
         if (!fusedLists || D.allow_fallback) {
