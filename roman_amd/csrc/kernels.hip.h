@@ -3890,7 +3890,7 @@ template <int NW, int NS, int NM>
 __device__ __forceinline__ void block_red(double (&sv)[NS > 0 ? NS : 1], double (&mv)[NM > 0 ? NM : 1], double* red, int& par, int tid)
 {
     static_assert(NS + NM <= RED_STRIDE, "reduction scratch");
-    static_assert(NW == 1 || NW == 8 || NW == 16, "cross-wave butterfly");
+    static_assert(NW == 1 || NW == 4 || NW == 8 || NW == 16, "cross-wave butterfly");
     if (NW == 1) {                                              // a single wave: the wave reduction is the block reduction
 #pragma unroll
         for (int i = 0; i < NS; ++i) sv[i] = uni(readlane63(wave_sum63(sv[i])));
@@ -3921,7 +3921,7 @@ __device__ __forceinline__ void block_red(double (&sv)[NS > 0 ? NS : 1], double 
         double v = rr[RED_STRIDE * src + i];
         v += dpp_mov<0xB1, 0xf>(v);          // quad_perm [1,0,3,2]
         v += dpp_mov<0x4E, 0xf>(v);          // quad_perm [2,3,0,1]
-        v += dpp_mov<0x124, 0xf>(v);         // row_ror:4
+        if (NW > 4) v += dpp_mov<0x124, 0xf>(v);         // row_ror:4
         if (NW > 8) v += dpp_mov<0x128, 0xf>(v);     // row_ror:8
         sv[i] = uni(v);
     }
@@ -3930,7 +3930,7 @@ __device__ __forceinline__ void block_red(double (&sv)[NS > 0 ? NS : 1], double 
         double v = rr[RED_STRIDE * src + NS + i];
         v = fmax(v, dpp_mov<0xB1, 0xf>(v));
         v = fmax(v, dpp_mov<0x4E, 0xf>(v));
-        v = fmax(v, dpp_mov<0x124, 0xf>(v));
+        if (NW > 4) v = fmax(v, dpp_mov<0x124, 0xf>(v));
         if (NW > 8) v = fmax(v, dpp_mov<0x128, 0xf>(v));
         mv[i] = uni(v);
     }
@@ -3942,7 +3942,7 @@ __device__ __forceinline__ void block_red(double (&sv)[NS > 0 ? NS : 1], double 
 template <int NW, int NS>
 __device__ __forceinline__ const double* block_post(const double (&sv)[NS], double* red, int& par, int tid)
 {
-    static_assert(NW == 8 || NW == 16, "cross-wave butterfly");
+    static_assert(NW == 4 || NW == 8 || NW == 16, "cross-wave butterfly");
     double* rr = red + NW * RED_STRIDE * par;
     par ^= 1;
     const int w = uni(tid >> 6);
@@ -3962,7 +3962,7 @@ __device__ __forceinline__ void block_collect(double (&sv)[NS], const double* rr
         double v = rr[RED_STRIDE * src + i];
         v += dpp_mov<0xB1, 0xf>(v);          // quad_perm [1,0,3,2]
         v += dpp_mov<0x4E, 0xf>(v);          // quad_perm [2,3,0,1]
-        v += dpp_mov<0x124, 0xf>(v);         // row_ror:4
+        if (NW > 4) v += dpp_mov<0x124, 0xf>(v);         // row_ror:4
         if (NW > 8) v += dpp_mov<0x128, 0xf>(v);     // row_ror:8
         sv[i] = uni(v);
     }
