@@ -707,7 +707,14 @@ int enqueue_score(roman_ctx* c, const DevParams& Din, const roman_params_t* para
         const char* listsEnv = getenv("ROMAN_LISTS");           // "0": never, "1": always (A/B and tests: read per call)
         const int fusedLists = listsEnv ? (listsEnv[0] == '0' ? 0 : 1) : (B >= std::max(8, c->num_cu / 8) ? 1 : 0);
         if (fusedLists) {
-            hipLaunchKernelGGL(k_lists, dim3((unsigned)std::max(1, std::min(B, 2 * c->num_cu))), dim3(LISTS_NT), 0, WS.stream, B, dP, dS, dT,
+            // One workgroup per compute unit when there is at most a problem per unit: the kernel's ~60 KB of static LDS let the dispatcher
+            // put TWO workgroups on one unit and leave another empty, and it sometimes does — the launch then lasts 200 instead of 163 us
+            // (round 6: the same build alternated between the two on one box; 30 KB of unused dynamic LDS: 163-164 us every time).  With
+            // two problems per unit or more the co-resident pairs are wanted (both sweeps are latency-bound).  ROMAN_LISTS_LDS=n forces n bytes.
+            const char* llEnv = getenv("ROMAN_LISTS_LDS");
+            const size_t listsPad = llEnv ? (size_t)std::max(0, atoi(llEnv)) : (B <= c->num_cu ? (size_t)30000 : 0);
+            if (listsPad) HIPCHK(c, dyn_lds(c, reinterpret_cast<const void*>(k_lists), listsPad));
+            hipLaunchKernelGGL(k_lists, dim3((unsigned)std::max(1, std::min(B, 2 * c->num_cu))), dim3(LISTS_NT), listsPad, WS.stream, B, dP, dS, dT,
                                WS.maskPool.as<unsigned long long>(), WS.listPool.as<uint16_t>(), WS.listOff.as<uint32_t>(),
                                WS.rowCnt.as<uint32_t>(), WS.perm.as<uint32_t>(), WS.rowPos.as<uint32_t>(), LP, PP, (long long)SZ.capList, sort_eq_max(), degGiven);
     DBG(c, "k_lists");

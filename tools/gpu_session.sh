@@ -22,6 +22,7 @@ for step in "$@"; do
     tests) timeout 2400 python -m pytest tests -q -x -m gpu --durations=8 ${arg:+-k "$arg"} > $OUT/${TAG}_pytest_gpu.txt 2>&1; echo "pytest rc=$?"; tail -25 $OUT/${TAG}_pytest_gpu.txt ;;
     smoke) timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/${TAG}_smoke.txt 2>&1; echo "smoke rc=$?"; tail -2 $OUT/${TAG}_smoke.txt ;;
     bench) timeout 900 python bench.py ${arg:---steps 20 --warmup 5} > $OUT/${TAG}_bench.txt 2>$OUT/${TAG}_bench.err; echo "bench rc=$?"; tail -3 $OUT/${TAG}_bench.err
+           cp bench_extras.json $OUT/${TAG}_bench_extras.json 2>/dev/null     # (the full record of THIS run: later steps' bench runs overwrite bench_extras.json)
            python tools/bench_digest.py $OUT/${TAG}_bench.txt ;;
     prof)  ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof -o bench -- python $REPO/bench.py ${arg:---steps 5 --warmup 2 --pipeline 1 --latency-reps -1 --cpu-sample 0 --no-extras} > $OUT/${TAG}_prof_bench.txt 2>$OUT/${TAG}_prof.err ); echo "rocprof rc=$?"
            F=$(find $OUT/${TAG}_prof -name "*kernel_stats.csv" | head -1); [ -n "$F" ] && cp "$F" $OUT/${TAG}_kernel_stats.csv && head -24 "$F" | cut -c1-200
