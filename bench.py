@@ -492,13 +492,13 @@ def main():
                         "bound": "f64 VALU", "pair_tests": tests, "flops_at_30_per_test": 30.0 * tests, "stage_ms": iso_stage["count"],
                         "achieved_TFLOPs": 30.0 * tests / (iso_stage["count"] * 1e-3) / 1e12, "peak_TFLOPs": F64_PEAK_TFLOPS,
                         "frac": 30.0 * tests / (iso_stage["count"] * 1e-3) / 1e12 / F64_PEAK_TFLOPS,
-                        "note": "frac of the whole stage; k_count alone is ~65 % of it (profiles/r03 kernel stats): its own fraction is ~1.5x this"},
+                        "note": "frac of the whole stage (k_count + k_lists + scans) on 30 flop per LIVE pair: algorithmic credit — since round 6 k_count tests every pair as 15-bit bins and only ~6 % in f64 (profiles/r06: k_count 0.36 of the stage's 0.55 ms)"},
                     "k_cos (stage 'single' = cosine MFMA + tables + single scores + live list)": {
                         "bound": "MFMA f64", "flops": cosflops, "stage_ms": iso_stage["single"],
                         "achieved_TFLOPs": cosflops / (iso_stage["single"] * 1e-3) / 1e12, "peak_TFLOPs": F64_PEAK_TFLOPS,
                         "measured_mfma_ceiling_TFLOPs": F64_MFMA_MEASURED_TFLOPS,
                         "frac": cosflops / (iso_stage["single"] * 1e-3) / 1e12 / F64_PEAK_TFLOPS,
-                        "note": "frac of the whole stage; k_cos_deal alone is ~75 % of it (0.29 of 0.39 ms): 36 TFLOP/s"}}
+                        "note": "frac of the whole stage; k_cos_deal alone is ~75 % of it (0.30 of 0.40 ms): 35 TFLOP/s"}}
                 # the whole step against SURVEY.md §8(d)'s ideal time t* = W/Pi + (B_b + B_s)/beta (pair tests among LIVE associations)
                 Wb = 30.0 * tests + cosflops
                 Bb = float(np.sum(12.0 * nnz)) + 8.0 * float(np.sum(a1[:C0].astype(np.float64) + a2[:C0])) * F

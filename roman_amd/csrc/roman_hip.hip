@@ -615,7 +615,7 @@ int enqueue_score(roman_ctx* c, const DevParams& Din, const roman_params_t* para
     const int preRow = (2 * std::max(maxN, 1) + 1 + 3) & ~3;                 // entries of the packed bin table (n1 + sentinel + n2)
     {
         const char* preEnv = getenv("ROMAN_COUNT_PRE");
-        const bool want = (preEnv ? preEnv[0] != '0' : true) && D.pre_invw > 0.0 && std::isfinite(D.pre_invw) && Lneed <= 16000 && maxN <= 32767;
+        const bool want = (preEnv ? preEnv[0] != '0' : true) && D.pre_invw > 0.0 && std::isfinite(D.pre_invw) && Lneed <= (preEnv ? 16000 : 4096) && maxN <= 32767;   // (live sets beyond the stream layout's: measured slower there — 64 x L = 10 000: 5.8 against 4.0 ms with the tiled plain sweep; forced on by ROMAN_COUNT_PRE=1 up to 16 000)
         if (want) {
             const int tc = Lneed;
             for (int wp = PRE_WAVES; wp >= 8; wp -= 4) {
