@@ -707,12 +707,14 @@ int enqueue_score(roman_ctx* c, const DevParams& Din, const roman_params_t* para
         const char* listsEnv = getenv("ROMAN_LISTS");           // "0": never, "1": always (A/B and tests: read per call)
         const int fusedLists = listsEnv ? (listsEnv[0] == '0' ? 0 : 1) : (B >= std::max(8, c->num_cu / 8) ? 1 : 0);
         if (fusedLists) {
-            // One workgroup per compute unit when there is at most a problem per unit: the kernel's ~60 KB of static LDS let the dispatcher
-            // put TWO workgroups on one unit and leave another empty, and it sometimes does — the launch then lasts 200 instead of 163 us
-            // (round 6: the same build alternated between the two on one box; 30 KB of unused dynamic LDS: 163-164 us every time).  With
-            // two problems per unit or more the co-resident pairs are wanted (both sweeps are latency-bound).  ROMAN_LISTS_LDS=n forces n bytes.
+            // ROMAN_LISTS_LDS=n: n bytes of unused dynamic LDS on top of the kernel's ~60 KB (above 20 KB a compute unit holds ONE workgroup).
+            // Probe of round 6: behind the prefiltered k_count with whole problems as work items k_lists takes 162-165 us in some
+            // processes and 192-210 us in others (every launch of a process alike; identical instruction and byte counters,
+            // SQ_WAIT_INST_ANY 122 M -> 190-220 M wave-cycles; behind the plain sweep or row-block work items always 160-169 us).  NOT the
+            // cause, each measured (tools/r6_lists_probe*.sh): two workgroups on one compute unit (this pad), which workgroup takes which
+            // problem (rotations by 1, 4, 8, 128), dirty mask lines in L2 (non-temporal stores: -3 us).  Open.
             const char* llEnv = getenv("ROMAN_LISTS_LDS");
-            const size_t listsPad = llEnv ? (size_t)std::max(0, atoi(llEnv)) : (B <= c->num_cu ? (size_t)30000 : 0);
+            const size_t listsPad = llEnv ? (size_t)std::max(0, atoi(llEnv)) : 0;
             if (listsPad) HIPCHK(c, dyn_lds(c, reinterpret_cast<const void*>(k_lists), listsPad));
             hipLaunchKernelGGL(k_lists, dim3((unsigned)std::max(1, std::min(B, 2 * c->num_cu))), dim3(LISTS_NT), listsPad, WS.stream, B, dP, dS, dT,
                                WS.maskPool.as<unsigned long long>(), WS.listPool.as<uint16_t>(), WS.listOff.as<uint32_t>(),
