@@ -711,7 +711,7 @@ int enqueue_score(roman_ctx* c, const DevParams& Din, const roman_params_t* para
             // Probe of round 6: behind the prefiltered k_count with whole problems as work items k_lists takes 162-165 us in some
             // processes and 192-210 us in others (every launch of a process alike; identical instruction and byte counters,
             // SQ_WAIT_INST_ANY 122 M -> 190-220 M wave-cycles; behind the plain sweep or row-block work items always 160-169 us).  NOT the
-            // cause, each measured (tools/r6_lists_probe*.sh): two workgroups on one compute unit (this pad), which workgroup takes which
+            // cause, each measured with a throw-away build (tools/r6_lists_probe.sh is the per-process probe): two workgroups on one compute unit (this pad), which workgroup takes which
             // problem (rotations by 1, 4, 8, 128), dirty mask lines in L2 (non-temporal stores: -3 us).  Open.
             const char* llEnv = getenv("ROMAN_LISTS_LDS");
             const size_t listsPad = llEnv ? (size_t)std::max(0, atoi(llEnv)) : 0;
