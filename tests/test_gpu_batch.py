@@ -808,6 +808,19 @@ def test_align_resident_and_align_stream_equal_run_batch():
         gp = align_resident(prune, pb, torch.from_numpy(pb.feats).to(dev), chunk=16, in_flight=3, ctx=c1)
         for b in range(len(pb)):
             assert np.array_equal(gp.assoc[b], wp.assoc[b]), b
+        # the library entry itself (roman_align_batch_resident) with start vectors in device memory: equals the host-pointer entry
+        sub = rb.batch_from_pairs(reg, [(p.map1, p.map2) for p in pairs[:20]])
+        u0 = np.concatenate([np.random.default_rng(77 + b).uniform(0.05, 1.0, int(sub.n1[b]) * int(sub.n2[b])) for b in range(20)])
+        reg.set_context(c1)
+        wu = rb.run_batch(reg, sub, u0=u0)
+        spool = torch.from_numpy(sub.feats).to(dev); du0 = torch.from_numpy(u0).to(dev); torch.cuda.synchronize(dev)
+        gu = c1.align_batch_resident(reg._abi_params(), spool.data_ptr(), sub.feats.shape[1], sub.off1, sub.n1, sub.off2, sub.n2, sub.kmax(), u0_ptr=du0.data_ptr())
+        for b in range(20):
+            assert np.array_equal(gu.assoc[b], wu.assoc[b]), b
+        assert np.array_equal(gu.T, wu.T, equal_nan=True) and np.array_equal(gu.stats["n_pass"], wu.stats["n_pass"]) and np.array_equal(gu.stats["score"], wu.stats["score"])
+        assert c1.has_history(reg._abi_params(), sub.feats.shape[1])             # (roman_ctx_has_history: this block has reported its needs)
+        other = SubmapAlignParams(method="semanticgrav", semantics_dim=16, epsilon=0.55).get_object_registration()
+        assert not c1.has_history(other._abi_params(), sub.feats.shape[1])
         # AlignStream: ten distinct calls of 15 problems, three in flight, collected before their set is rewritten
         reg.set_context(c0)
         kmax = batch.kmax(); F = batch.feats.shape[1]
