@@ -484,3 +484,32 @@ def test_candidate_generation_at_the_ends_of_the_bin_range(ctx, orc, scale, epsi
         ctx.score(P, D1, D2, None)
         rp, cc, vv, _ = ctx.upper_csr()
         assert np.array_equal(rp, rp_o) and np.array_equal(cc, c_o) and np.array_equal(vv, v_o), pre
+
+
+@pytest.mark.parametrize("name", ["cfg2", "semgrav60", "roman50", "tiny_4x5", "words3_12x14", "dense45", "semgrav_zgate_200", "sevg45", "prune60", "clipper_ragged"])
+def test_whole_problem_pair_tests_hand_k_lists_the_degrees(ctx, orc, name, monkeypatch):
+    """Batches of at least a problem per compute unit give k_count whole problems as work items; its exact gate then counts every live
+    row's degree as the pairs pass (LDS atomics) and k_lists skips its degree sweep.  Forced here for single problems
+    (ROMAN_COUNT_WHOLE=1, ROMAN_LISTS=1) against the row-block path: the same layout — matrix pattern and values, the iterate bit for
+    bit, selection and pass counts —, and the oracle's."""
+    case = next(c for c in LADDER if c[0] == name)
+    reg, pr = make(case)
+    reg.set_context(ctx)
+    P = reg._abi_params()
+    D1, D2 = reg.pack(pr.map1), reg.pack(pr.map2)
+    A = reg._association_list(pr.map1, pr.map2)
+    mat, Ao = orc.build_matrix(P, D1, D2, A)
+    sol = orc.solve(P, mat)
+    rp_o, c_o, v_o, d_o = mat.export()
+    monkeypatch.setenv("ROMAN_LISTS", "1")
+    got = {}
+    for whole in ("1", "0"):
+        monkeypatch.setenv("ROMAN_COUNT_WHOLE", whole)
+        ctx.score(P, D1, D2, A)
+        rp, cc, vv, dd = ctx.upper_csr()
+        assert np.array_equal(rp, rp_o) and np.array_equal(cc, c_o) and np.array_equal(vv, v_o) and np.array_equal(dd, d_o), whole
+        ctx.solve(None)
+        nodes, u, score, st = ctx.solution()
+        assert np.array_equal(nodes, sol["nodes"]) and st.n_pass == sol["stats"].n_pass, whole
+        got[whole] = (u, score)
+    assert np.array_equal(got["0"][0], got["1"][0]) and got["0"][1] == got["1"][1]
