@@ -68,6 +68,7 @@ def parse():
     ap.add_argument("--latency-reps", type=int, default=30)
     ap.add_argument("--no-profile", action="store_true", help="do not bracket stages with hipEvents")
     ap.add_argument("--no-extras", action="store_true", help="main measurement only: no grid / sensitivity / large-live / demo-scale / sustained / h2d legs")
+    ap.add_argument("--no-live-traffic", action="store_true", help="do not re-run the main measurement under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE for roofline.traffic (the committed pass is quoted instead)")
     ap.add_argument("--pipeline", type=int, default=3, choices=[1, 2, 3, 4, 5, 6],
                     help="batches in flight per GPU (roman_ctx_set_pipeline): the straggler tail of one call's solver overlaps the "
                          "next calls' affinity builds; results are complete at the closing device-wide synchronise")
@@ -89,6 +90,55 @@ def self_launch(args_list, n):
            "--master-port", str(port), os.path.abspath(__file__)] + list(args_list)
     env = dict(os.environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     return subprocess.call(cmd, env=env)
+
+
+def live_traffic(kernel="k_solve_up<8", timeout_s=150):
+    """HBM bytes per launch of the dominant kernel, MEASURED on this box with this build: bench.py's main measurement (one call in flight,
+    3 timed steps, nothing else) re-run under rocprofv3 twice — `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE`, separate passes with
+    `--kernel-trace` only, as /opt/skills/guides/MI355X_MICROARCH.md prescribes — and the counter averaged over the kernel's dispatches of
+    the largest grid (the B = 256 launches).  -> (bytes = (2 FETCH_SIZE + WRITE_SIZE) KB x 1024: the guide's gfx950 correction for wide
+    coalesced reads, dict of the raw numbers) or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None, "rocprofv3 not on PATH"
+    raw = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        td = tempfile.mkdtemp(prefix="roman_pmc_", dir="/tmp")
+        try:
+            cmd = [exe, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", td, "-o", "b", "--", sys.executable, os.path.abspath(__file__),
+                   "--steps", "3", "--warmup", "2", "--pipeline", "1", "--latency-reps", "-1", "--cpu-sample", "0", "--no-extras", "--no-grid", "--check-pairs", "0",
+                   "--no-live-traffic"]
+            env = dict(os.environ); env["TMPDIR"] = "/tmp"
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=timeout_s)
+            files = glob.glob(os.path.join(td, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, f"rocprofv3 --pmc {ctr} failed (rc {r.returncode}): {r.stderr.decode(errors='replace')[-200:]}"
+            per = {}
+            gmax = 0
+            with open(files[0]) as fh:
+                for row in csv.DictReader(fh):
+                    if kernel not in row.get("Kernel_Name", "") or row.get("Counter_Name") != ctr:
+                        continue
+                    g = int(row.get("Grid_Size", 0) or 0)
+                    gmax = max(gmax, g)
+                    per.setdefault((g, row["Dispatch_Id"]), 0.0)
+                    per[(g, row["Dispatch_Id"])] += float(row["Counter_Value"])
+            vals = [v for (g, _), v in per.items() if g == gmax]
+            if not vals:
+                return None, f"no {kernel} dispatch in the {ctr} pass"
+            raw[ctr + "_KB_per_launch"] = sum(vals) / len(vals); raw[ctr + "_launches"] = len(vals)
+        except subprocess.TimeoutExpired:
+            return None, f"rocprofv3 --pmc {ctr} pass exceeded {timeout_s} s"
+        except Exception as e:                                   # a reported extra: never lose the line over it
+            return None, f"{ctr} pass: {e!r}"
+        finally:
+            shutil.rmtree(td, ignore_errors=True)
+    return (2.0 * raw["FETCH_SIZE_KB_per_launch"] + raw["WRITE_SIZE_KB_per_launch"]) * 1024.0, raw
 
 
 def cpu_model():
@@ -507,6 +557,18 @@ def main():
                                            "build_flops": Wb, "build_bytes": Bb, "solver_bytes": alg_bytes,
                                            "note": "SURVEY.md §8(d): t* = W_b / 78.6 TF + (B_b + B_s) / 8 TB/s for one call of the batch; frac = t* / measured ms per step"}
 
+    # roofline.traffic LIVE: the PMC passes of this box and this build (two short re-runs of the main measurement under rocprofv3)
+    if "roofline" in out and extras and world == 1 and not args.no_live_traffic and workload == "pairs" and C0 == 256 and (args.n, args.m, args.d) == (200, 200, 512):
+        tb, raw = live_traffic()
+        r_ = out["roofline"]
+        if tb is not None:
+            r_["traffic"] = tb; r_["traffic_measured_live"] = True; r_["traffic_raw"] = raw
+            r_["traffic_source"] = "MEASURED in this run: bench.py re-run under rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes), 2 x FETCH_SIZE + WRITE_SIZE per k_solve_up launch"
+            iso_ms_ = (r_.get("isolated") or {}).get("avg_launch_ms")
+            if iso_ms_:
+                r_["traffic_frac"] = tb / (iso_ms_ * 1e-3) / 1e9 / HBM_PEAK_GBS
+        else:
+            r_["traffic_measured_live"] = False; r_["traffic_live_error"] = str(raw)[:300]
     from_oracle = args.cpu_sample > 0                           # rank 0 at every N (the other ranks have left; nothing of it is inside a timed region)
     orc = None
     if from_oracle or (extras and world == 1):
@@ -1066,7 +1128,7 @@ def headline(out):
     if r:
         line["roofline"] = {
             "kernel": r.get("kernel"), "bound": r.get("bound"), "achieved": r.get("achieved"), "peak": r.get("peak"), "unit": r.get("unit"),
-            "frac": r.get("frac"), "traffic": r.get("traffic"), "traffic_frac": r.get("traffic_frac"), "traffic_measured_live": False if r.get("traffic") else None,
+            "frac": r.get("frac"), "traffic": r.get("traffic"), "traffic_frac": r.get("traffic_frac"), "traffic_measured_live": bool(r.get("traffic_measured_live")) if r.get("traffic") else None,
             "algorithmic_bytes_per_launch": r.get("algorithmic_bytes_per_launch"), "avg_launch_ms": r.get("avg_launch_ms"),
             "launches_timed": r.get("launches_timed"), "timing": "hipEvents, timed region, other batches in flight",
             "isolated": {"avg_launch_ms": _get(r, "isolated", "avg_launch_ms"), "frac": _get(r, "isolated", "frac"), "of": "mean of 5 single launches"},

@@ -68,3 +68,13 @@ def test_emit_prints_the_headline_last_and_alone(tmp_path, capsys, monkeypatch):
     line = json.loads(lines[0])
     extras = json.load(open(tmp_path / "bench_extras.json"))
     assert line["extras"] == "bench_extras.json" and "caller" in extras and "decision_sensitivity" in extras
+
+
+def test_live_traffic_reports_why_when_there_is_no_profiler(monkeypatch):
+    """roofline.traffic is measured by re-running the main measurement under rocprofv3 --pmc (bench.live_traffic); without the tool the
+    bench says so and quotes the committed pass instead — it never loses the line over it."""
+    import shutil
+    import bench
+    monkeypatch.setattr(shutil, "which", lambda name: None)
+    tb, why = bench.live_traffic()
+    assert tb is None and "rocprofv3" in why
