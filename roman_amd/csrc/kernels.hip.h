@@ -806,7 +806,8 @@ template <int T, int DBG /* 0; tools/ubench/cos_time.hip strips parts of the ker
 __global__ void __launch_bounds__(256, CosDeal<T>::WAVES) k_cos_deal(DevParams D, int B, int G /* workgroups (tiles) per problem */,
                                                      const ProbDesc* __restrict__ probs,
                                                      const double* __restrict__ feats,
-                                                     double* __restrict__ cosPool)
+                                                     double* __restrict__ cosPool,
+                                                     const int32_t* __restrict__ only /* NULL, or [B]: problems with a 0 are skipped (behind k_cos_sel) */)
 {
     using CD = CosDeal<T>;
     constexpr int KC = 16, PITCH = COSD_PITCH, SEGS = KC / 2, RPI = 256 / SEGS, NLD = CD::ROWS / RPI, STAGE = CD::STAGE, MAXB = CD::MAXB;
@@ -818,6 +819,7 @@ __global__ void __launch_bounds__(256, CosDeal<T>::WAVES) k_cos_deal(DevParams D
     const int tid = threadIdx.x, lane = tid & 63, w = uni_i(tid >> 6);
     const int b = B >= 8 ? (slot / G) * 8 + xcd : slot / G;
     if (b >= B) return;
+    if (only && !only[b]) return;
     const ProbDesc pd = probs[b];
     const int ti_n = CD::tiles(pd.n1), tj_n = CD::tiles(pd.n2);
     const int tile = slot % G;
@@ -974,6 +976,346 @@ __global__ void __launch_bounds__(256, CosDeal<T>::WAVES) k_cos_deal(DevParams D
             }
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_cos_sel (round 6): the cosine matrices of a batch whose cosines are only used behind the gate cos > cosine_min
+// (single_score(): an association with (cos - cosine_min) / (cosine_max - cosine_min) <= 0 scores 0 whatever its cosine is).
+// k_cos_deal computes all n1 x n2 cosines in f64 on the matrix core and is POWER-bound (295 us at config 3); ~95 % of its
+// products are thrown away by the gate.  Here one workgroup of 16 waves takes a problem:
+//   pass 1  approximate cosines of all pairs: rows converted to bf16 on the way into LDS, v_mfma_f32_16x16x32_bf16 (1/32 of the
+//           f64 MFMA's matrix-pipe time), divided by the EXACT f64 norms (summed here in the oracle's stated order: four chains,
+//           (s0 + s1) + (s2 + s3));
+//   select  pair (i, j) is a CANDIDATE unless approx < cosine_min - delta.  |approx - cos| <= 2^-8 (two bf16 roundings of 2^-9
+//           each, Cauchy-Schwarz over the contraction) + 512 * 2^-22 (f32 accumulation, any order, truncating or not) < 0.0041
+//           for rows whose norm lies in [2^-40, 2^40] (no element over- or underflows in bf16 / f32 beyond 2^-86 of the product of
+//           the norms); rows with any other non-zero norm (huge, tiny, inf, NaN) make all their pairs candidates.  delta = 2^-6.
+//   pass 2  the candidates' dot products in f64 with k_cos_deal's own contraction order (oracle dot_fixed(): per chunk of 16, t = 0..3
+//           outer, g = 0..3 inner, k = k0 + 4 g + t, ONE fma chain), rows staged through LDS chunk by chunk, candidates sorted by i so
+//           that the lanes of a wave read few distinct a rows (LDS broadcast); cos = dot / (na * nb) as everywhere.
+// A non-candidate's entry of the pool holds the APPROXIMATE cosine (< cosine_min - delta + 0.0041 < cosine_min, and so is the exact one:
+// both fail the gate alike).  Candidates' entries are bit-identical to k_cos_deal's.  A problem with more than CSEL_CAP candidates (or maps
+// of more than 256 objects) is flagged in dense[] and left to k_cos_deal<., ., true>, which the launcher runs behind this kernel for the
+// flagged problems only.  Never used for roman_debug_cosine / the pruned prefilter (raw products) / cosine_max <= cosine_min.
+// ---------------------------------------------------------------------------------------------
+constexpr int CSEL_ROWS = 512;                   // staged rows: A rows [0, 16 nb1), B rows [16 nb1, 16 nb1 + 16 nb2)
+constexpr int CSEL_MAXN = 256;                   // objects per map
+constexpr int CSEL_CAP = 4096;                   // candidates per problem (config 3: ~2200 of 40000); four per thread in pass 2
+constexpr int CSEL_NPT = CSEL_CAP / 1024;        // candidates per thread
+constexpr int CSEL_P1 = 256 + 16;                // bytes per staged row of pass 1: 128 bf16 + pad
+constexpr int CSEL_P2 = 128 + 16;                // bytes per staged row of pass 2: 16 doubles + pad
+constexpr int CSEL_MP = 11;                    // blocks of the product per wave: problems of up to 176 blocks of 16 x 16 (200 x 200 objects: 169)
+constexpr int CSEL_STAGE = CSEL_ROWS * CSEL_P1;  // pass 1: the tile; behind it: pass 2's chunk and the candidate lists
+static_assert(CSEL_ROWS * CSEL_P2 + 2 * CSEL_CAP * 4 <= CSEL_STAGE, "pass 2 fits where the tile was");
+constexpr int CSEL_LDS = CSEL_STAGE + CSEL_ROWS * 8 + 2 * 260 * 4;
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+struct __attribute__((packed, aligned(8))) d8u_t { double v[8]; };     // 8-byte aligned 64-byte load
+
+__device__ __forceinline__ bool csel_unsafe(double n) { return !(n >= 0x1p-40 && n <= 0x1p40); }
+
+__global__ void __launch_bounds__(1024) k_cos_sel(DevParams D, int B, const ProbDesc* __restrict__ probs, const double* __restrict__ feats,
+                                                  double* __restrict__ cosPool, int32_t* __restrict__ dense /* [B] out: 1 = left to the dense kernel */,
+                                                  double thr /* cosine_min - delta; +inf: no candidates (the approximate matrix, tests) */)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* stage = smem;
+    double* nrm = reinterpret_cast<double*>(smem + CSEL_STAGE);
+    uint32_t* U = reinterpret_cast<uint32_t*>(smem + CSEL_ROWS * CSEL_P2);   // candidates as found: i | j << 16 (where the tile was: behind pass 2's chunk)
+    uint32_t* S = U + CSEL_CAP;                                          // sorted by i
+    int* hist = reinterpret_cast<int*>(nrm + CSEL_ROWS);                 // [0, 256): candidates of row i; [256]: all
+    int* cur = hist + 260;
+    const int b = blockIdx.x;
+    if (b >= B) return;
+    const ProbDesc pd = probs[b];
+    const int tid = threadIdx.x, lane = tid & 63, w = uni_i(tid >> 6);
+    const int n1 = pd.n1, n2 = pd.n2;
+    if (n1 <= 0 || n2 <= 0) { if (tid == 0) dense[b] = 0; return; }
+    const int nb1 = (n1 + 15) >> 4, nb2 = (n2 + 15) >> 4, RB = 16 * nb1, nblk = nb1 * nb2, rowsTot = RB + 16 * nb2;
+    if (n1 > CSEL_MAXN || n2 > CSEL_MAXN || nblk > 16 * CSEL_MP) { if (tid == 0) dense[b] = 1; return; }
+    const int Fc = D.p.cos_feature_dim, coff = D.p.point_dim + D.p.ratio_feature_dim;
+    if (tid < 260) hist[tid] = 0;
+    const double* base1 = feats + pd.off1 * D.F + coff;
+    const double* base2 = feats + pd.off2 * D.F + coff;
+    // staged row R holds object R of map 1 (R < RB) or object R - RB of map 2; rows behind a map's last object: zeros
+
+    // ---- pass 1 -------------------------------------------------------------------------------------------
+    // loads: one wave instruction reads 128 consecutive elements — ONE KILOBYTE — of one row: lane l the elements k0 + 2 l, k0 + 2 l + 1.
+    // (Pieces of 128 / 256 B of eight / four rows per instruction — what a tile of 16 / 32 elements of every row needs — ran this pass
+    // at 127 / 115 us whatever the prefetch depth: 256 workgroups x 416 rows are 10^5 streams of short bursts for the DRAM.)  A tile is
+    // 128 elements of every row as bf16 (rows x 272 B); wave w owns the rows w, w + 16, ...; four rows per register set, two sets, each
+    // re-loaded as soon as it is staged — also across the tile's barrier and its MFMAs.
+    // The screen's norms are the bf16 rows' own (the diagonals of the products of every block of 16 rows with itself: wave w the
+    // blocks w, w + 16 — no f64 arithmetic in this pass): cos(a^, b^) against cos(a, b) — two angles of at most asin(2^-9).
+    constexpr int KT = 128, G1 = 4;
+    const int nt = rowsTot >> 4;                                         // rows of a wave
+    // No branch and no address arithmetic inside the stream of loads (a branch makes the compiler wait for ALL outstanding loads at its
+    // join; the rows' addresses computed per load were 5800 scalar instructions per wave — the scalar unit busy 40 % of the pass): lane t
+    // of the wave holds the address of the wave's row slot t — a slot behind the wave's last row, or a row behind its map's last object,
+    // holds the last real one's (a cache hit; staged into a tile row whose products nobody reads: C[i][j] depends on rows i and j alone)
+    // — and a slot's load takes it from there (v_readlane) as its scalar base.
+    const int NG8 = ((nt + 2 * G1 - 1) / (2 * G1)) * 2;                  // groups of a tile, an even number
+    const int NSF = Fc / KT;                                             // full tiles
+    uint32_t slotLo, slotHi;
+    {
+        const int R = w + 16 * min(lane, nt - 1);
+        const bool isA = R < RB;
+        const int idx = min(isA ? R : R - RB, (isA ? n1 : n2) - 1);
+        const uint64_t pa = reinterpret_cast<uint64_t>((isA ? base1 : base2) + (int64_t)idx * D.F);
+        slotLo = (uint32_t)pa; slotHi = (uint32_t)(pa >> 32);
+    }
+    auto slot_ptr = [&](int t) -> const double* {                        // (wave-uniform)
+        const uint64_t lo = (uint32_t)__builtin_amdgcn_readlane((int)slotLo, t), hi = (uint32_t)__builtin_amdgcn_readlane((int)slotHi, t);
+        return reinterpret_cast<const double*>((hi << 32) | lo);
+    };
+    auto load_group = [&](dbl2_t (&x)[G1], int st, int g) {
+        const int ko = st * KT + 2 * lane;
+#pragma unroll
+        for (int j = 0; j < G1; ++j) {
+            const d2u_t tv = *reinterpret_cast<const d2u_t*>(slot_ptr(G1 * g + j) + ko);
+            x[j] = dbl2_t{tv.v[0], tv.v[1]};
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto load_group_ragged = [&](dbl2_t (&x)[G1], int st, int g) {
+        const int k = st * KT + 2 * lane;
+#pragma unroll
+        for (int j = 0; j < G1; ++j) {
+            const double* rp = slot_ptr(G1 * g + j);
+            x[j] = dbl2_t{k < Fc ? rp[k] : 0.0, k + 1 < Fc ? rp[k + 1] : 0.0};
+        }
+    };
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    auto stage_group = [&](const dbl2_t (&x)[G1], int g) {
+#pragma unroll
+        for (int j = 0; j < G1; ++j) {                                   // (slot t < 32: a row of the tile's 512 whatever nt is)
+            const bf16x2_t h2 = {(__bf16)(float)x[j].x, (__bf16)(float)x[j].y};
+            *reinterpret_cast<bf16x2_t*>(stage + (w + 16 * (G1 * g + j)) * CSEL_P1 + 4 * lane) = h2;
+        }
+    };
+    // wave w multiplies a run of the product's row-major block list (the A operand is read again only where a block row starts)
+    const int e0 = uni_i(w * nblk / 16), cntP = uni_i((w + 1) * nblk / 16 - e0);         // <= CSEL_MP
+    f32x4_t acc[CSEL_MP], accD[2];
+#pragma unroll
+    for (int m = 0; m < CSEL_MP; ++m) acc[m] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    accD[0] = accD[1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    int offA[CSEL_MP], offB[CSEL_MP], offD[2]; bool newRow[CSEL_MP];
+#pragma unroll
+    for (int m = 0; m < CSEL_MP; ++m) {
+        const int e = min(e0 + m, e0 + cntP - 1), bx = e / nb2, by = e - bx * nb2;
+        offA[m] = uni_i(16 * bx * CSEL_P1); offB[m] = uni_i((RB + 16 * by) * CSEL_P1);
+        newRow[m] = uni_i((m == 0 || by == 0) ? 1 : 0) != 0;
+    }
+    offD[0] = uni_i(16 * min(w, nt - 1) * CSEL_P1); offD[1] = uni_i(16 * min(w + 16, nt - 1) * CSEL_P1);
+    const int lanePart = (lane & 15) * CSEL_P1 + (lane >> 4) * 16;
+    auto multiply = [&]() {
+#pragma unroll
+        for (int sub = 0; sub < KT / 32; ++sub) {
+            const unsigned char* tb = stage + lanePart + 64 * sub;
+            bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(tb + offA[0]);
+#pragma unroll
+            for (int m = 0; m < CSEL_MP; ++m)
+                if (m < cntP) {
+                    if (m > 0 && newRow[m]) a = *reinterpret_cast<const bf16x8_t*>(tb + offA[m]);
+                    const bf16x8_t bq = *reinterpret_cast<const bf16x8_t*>(tb + offB[m]);
+                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bq, acc[m], 0, 0, 0);
+                }
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {            // (staged rows: map 1's blocks, then map 2's)
+                const bf16x8_t dg = *reinterpret_cast<const bf16x8_t*>(tb + offD[m]);
+                accD[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dg, dg, accD[m], 0, 0, 0);
+            }
+        }
+    };
+    {
+        dbl2_t xa[G1], xb[G1];
+        if (NSF > 0) { load_group(xa, 0, 0); load_group(xb, 0, 1); }
+        for (int st = 0; st < NSF; ++st) {
+            for (int g = 0; g < NG8; g += 2) {
+                // (the groups two ahead: the next tile's first two behind this tile's last — the last tile loads its own first two again)
+                const int gn = g + 2 < NG8 ? g + 2 : 0, stn = g + 2 < NG8 ? st : min(st + 1, NSF - 1);
+                stage_group(xa, g);
+                load_group(xa, stn, gn);
+                stage_group(xb, g + 1);
+                load_group(xb, stn, gn + 1);
+            }
+            __syncthreads();
+            multiply();
+            __syncthreads();
+        }
+        if (NSF * KT < Fc) {                         // a ragged last tile: zeros behind the descriptor's end
+            for (int g = 0; g < NG8; ++g) { load_group_ragged(xa, NSF, g); stage_group(xa, g); }
+            __syncthreads();
+            multiply();
+            __syncthreads();
+        }
+    }
+    // norms of the bf16 rows: element (r, r) of a diagonal block is register (lane & 3) of the lane with (lane & 15) >> 2 == lane >> 4
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+        if (w + 16 * m < nt) {
+            const int r4 = lane & 3;
+            const float v = r4 == 0 ? accD[m][0] : r4 == 1 ? accD[m][1] : r4 == 2 ? accD[m][2] : accD[m][3];
+            if (((lane & 15) >> 2) == (lane >> 4)) nrm[16 * (w + 16 * m) + (lane & 15)] = sqrt((double)v);
+        }
+    __syncthreads();
+
+    // ---- select -------------------------------------------------------------------------------------------
+    const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int m = 0; m < CSEL_MP; ++m)
+        if (m < cntP) {
+            const int e = e0 + m, bx = e / nb2, by = e - bx * nb2;
+            const int j = 16 * by + (lane & 15);
+            const double nbv = nrm[RB + j];
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int i = 16 * bx + 4 * (lane >> 4) + rr;
+                const double na = nrm[i];
+                const bool ok = i < n1 && j < n2;
+                // (a row whose f32 norm is zero, tiny, huge or no number is left to the exact pass altogether: its guard for zero norms too)
+                const double cv = (double)acc[m][rr] / (na * nbv);
+                const bool cand = ok && (csel_unsafe(na) || csel_unsafe(nbv) || !(cv < thr));
+                if (ok && !cand) cosPool[pd.cosOff + (int64_t)i * n2 + j] = cv;
+                const unsigned long long bm = __ballot(cand);
+                if (bm) {
+                    int base = 0;
+                    if (lane == 0) base = atomicAdd(&hist[256], __popcll(bm));
+                    base = __shfl(base, 0);
+                    if (cand) {
+                        const int slot = base + __popcll(bm & lt);
+                        if (slot < CSEL_CAP) U[slot] = (uint32_t)i | ((uint32_t)j << 16);
+                        atomicAdd(&hist[i], 1);
+                    }
+                }
+            }
+        }
+    __syncthreads();
+    const int nc = hist[256];
+    if (nc > CSEL_CAP) { if (tid == 0) dense[b] = 1; return; }
+    if (tid == 0) dense[b] = 0;
+    if (nc == 0) return;
+    if (w == 0) {                                // cursors: exclusive prefix of the 256 row counts
+        const int c0 = hist[4 * lane], c1 = hist[4 * lane + 1], c2 = hist[4 * lane + 2], c3 = hist[4 * lane + 3];
+        int incl = c0 + c1 + c2 + c3;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d); if (lane >= d) incl += t; }
+        const int ex = incl - (c0 + c1 + c2 + c3);
+        cur[4 * lane] = ex; cur[4 * lane + 1] = ex + c0; cur[4 * lane + 2] = ex + c0 + c1; cur[4 * lane + 3] = ex + c0 + c1 + c2;
+    }
+    __syncthreads();
+    for (int q = tid; q < nc; q += 1024) { const uint32_t v = U[q]; S[atomicAdd(&cur[v & 0xffffu], 1)] = v; }
+    __syncthreads();
+
+    // ---- pass 2 -------------------------------------------------------------------------------------------
+    // The rows come again, chunk by chunk, as f64 (the same lanes, the same two register sets in flight).  The exact norms (the oracle's
+    // stated order) are summed from the staged chunks: thread (r, h) takes chains 2 h and 2 h + 1 of row r.
+    // (no branch inside the stream of loads, as in pass 1: every lane loads in each of the NQ rounds — behind the staged rows, or behind
+    // its map's last object, the last real row again: a staged row that no candidate names)
+    constexpr int NQ = CSEL_ROWS / 128;
+    const int pp = lane & 7, laneRow = 8 * w + (lane >> 3);
+    // (the launcher guarantees a feature pool of less than 4 GB: a lane's row is a 32-bit byte offset from the pool's start)
+    uint32_t rofs[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int R = min(128 * q + laneRow, rowsTot - 1);
+        const bool isA = R < RB;
+        const int idx = min(isA ? R : R - RB, (isA ? n1 : n2) - 1);
+        rofs[q] = (uint32_t)((((isA ? pd.off1 : pd.off2) + idx) * D.F + coff + 2 * pp) * 8);
+    }
+    const char* pool = reinterpret_cast<const char*>(feats);
+    auto load16 = [&](dbl2_t (&x)[NQ], int k0) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) { const d2u_t t = *reinterpret_cast<const d2u_t*>(pool + (rofs[q] + (uint32_t)(8 * k0))); x[q] = dbl2_t{t.v[0], t.v[1]}; }
+    };
+    auto load16_ragged = [&](dbl2_t (&x)[NQ], int k0) {
+        const int k = k0 + 2 * pp;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) { const double* rb = reinterpret_cast<const double*>(pool + rofs[q]); x[q] = dbl2_t{k < Fc ? rb[k0] : 0.0, k + 1 < Fc ? rb[k0 + 1] : 0.0}; }
+    };
+    uint32_t my[CSEL_NPT]; double dot[CSEL_NPT];
+    const int cnt2 = nc > tid ? (nc - tid + 1023) >> 10 : 0;
+#pragma unroll
+    for (int m = 0; m < CSEL_NPT; ++m) { my[m] = m < cnt2 ? S[m * 1024 + tid] : 0u; dot[m] = 0.0; }
+    const int rN = tid >> 1, hN = tid & 1;
+    double s0 = 0.0, s1 = 0.0;
+    auto put16 = [&](const dbl2_t (&x)[NQ]) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+            *reinterpret_cast<dbl2_t*>(stage + (128 * q + laneRow) * CSEL_P2 + 16 * pp) = x[q];
+    };
+    auto compute = [&](int s, auto fullChunk) {
+        {   // (zeros behind a ragged descriptor's end: fma(0, 0, s) = s for a sum of squares)
+            const dbl2_t* pr = reinterpret_cast<const dbl2_t*>(stage + rN * CSEL_P2 + 64 * hN);
+            const dbl2_t e0_ = pr[0], e1_ = pr[1], e2_ = pr[2], e3_ = pr[3];
+            s0 = fma(e0_.x, e0_.x, s0); s0 = fma(e0_.y, e0_.y, s0); s0 = fma(e1_.x, e1_.x, s0); s0 = fma(e1_.y, e1_.y, s0);
+            s1 = fma(e2_.x, e2_.x, s1); s1 = fma(e2_.y, e2_.y, s1); s1 = fma(e3_.x, e3_.x, s1); s1 = fma(e3_.y, e3_.y, s1);
+        }
+        const int kleft = uni_i(Fc - 16 * s);    // elements of this chunk: >= 16 except the last of a ragged descriptor
+#pragma unroll
+        for (int m = 0; m < CSEL_NPT; ++m)
+            if (m < cnt2) {
+                const dbl2_t* pa = reinterpret_cast<const dbl2_t*>(stage + (my[m] & 0xffffu) * CSEL_P2);
+                const dbl2_t* pb = reinterpret_cast<const dbl2_t*>(stage + (RB + (my[m] >> 16)) * CSEL_P2);
+                double d = dot[m];
+#pragma unroll
+                for (int tp = 0; tp < 2; ++tp) {             // t = 2 tp, 2 tp + 1: the pairs (4 g + 2 tp, 4 g + 2 tp + 1), g = 0..3
+                    dbl2_t av[4], bv[4];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) { av[g] = pa[2 * g + tp]; bv[g] = pb[2 * g + tp]; }
+                    if (decltype(fullChunk)::value) {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) d = fma(av[g].x, bv[g].x, d);
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) d = fma(av[g].y, bv[g].y, d);
+                    } else {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) if (4 * g + 2 * tp < kleft) d = fma(av[g].x, bv[g].x, d);
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) if (4 * g + 2 * tp + 1 < kleft) d = fma(av[g].y, bv[g].y, d);
+                    }
+                }
+                dot[m] = d;
+            }
+    };
+    {
+        const int NCF = Fc >> 4;                     // full chunks
+        dbl2_t ya[NQ], yb[NQ];
+        if (NCF > 0) { load16(ya, 0); load16(yb, 16 * min(1, NCF - 1)); }
+        for (int s = 0; s < NCF; s += 2) {           // (two ahead; behind the last chunk that one again)
+            put16(ya);
+            __syncthreads();
+            load16(ya, 16 * min(s + 2, NCF - 1));
+            compute(s, std::true_type{});
+            __syncthreads();
+            if (s + 1 < NCF) {
+                put16(yb);
+                __syncthreads();
+                load16(yb, 16 * min(s + 3, NCF - 1));
+                compute(s + 1, std::true_type{});
+                __syncthreads();
+            }
+        }
+        if (NCF * 16 < Fc) {
+            load16_ragged(ya, 16 * NCF);
+            put16(ya);
+            __syncthreads();
+            compute(NCF, std::false_type{});
+            __syncthreads();
+        }
+    }
+    {
+        const double p = s0 + s1, q = __shfl_xor(p, 1);
+        if (hN == 0) nrm[rN] = sqrt(p + q);      // (s0 + s1) + (s2 + s3)
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < CSEL_NPT; ++m)
+        if (m < cnt2) {
+            const int i = (int)(my[m] & 0xffffu), j = (int)(my[m] >> 16);
+            const double na = nrm[i], nbv = nrm[RB + j];
+            cosPool[pd.cosOff + (int64_t)i * n2 + j] = (na > 0.0 && nbv > 0.0) ? dot[m] / (na * nbv) : 0.0;
+        }
 }
 
 // ---------------------------------------------------------------------------------------------

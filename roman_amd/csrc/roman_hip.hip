@@ -73,7 +73,7 @@ struct roman_ctx {
         bool issued = false;
         // pools (see DESIGN.md "Data layout in HBM")
         DevBuf probs, state, totals, queue;
-        DevBuf cosPool, tabPool, qtabPool, sTmp, chunkCnt;
+        DevBuf cosPool, cosDense, tabPool, qtabPool, sTmp, chunkCnt;
         DevBuf lp, li, lj, ls, ld, lza, lzb;                       // per live association, live order
         DevBuf plp, pli, plj, pls, pld, plza, plzb;                // the same in position order (stream layout)
         DevBuf rowCnt, rowPos, perm, sliceWidth, sliceBase, items, maskPool, prefPool, listPool, listOff;
@@ -362,6 +362,38 @@ int make_solve_out(roman_ctx* c, int B, int64_t sumA, const BatchOut& out, Solve
     return ROMAN_OK;
 }
 
+// The cosines of a batch that are only used behind the gate cos > cosine_min: k_cos_sel (bf16 screen of all pairs, exact f64 for the
+// candidates), then k_cos_deal for the problems it flagged (more candidates than its list holds).  `approx`: no candidates at all —
+// the screen's own matrix (tests).
+static hipError_t launch_cos_sel(roman_ctx* c, hipStream_t stream, const DevParams& D, int B, int maxN1, int maxN2, const ProbDesc* dP, const double* feats, double* cosPool,
+                                 int32_t* dense, bool approx)
+{
+    hipError_t e = dyn_lds(c, reinterpret_cast<const void*>(k_cos_sel), (size_t)CSEL_LDS);
+    if (e != hipSuccess) return e;
+    const double thr = approx ? INFINITY : D.p.cosine_min - 0x1p-6;
+    hipLaunchKernelGGL(k_cos_sel, dim3((unsigned)B), dim3(1024), (size_t)CSEL_LDS, stream, D, B, dP, feats, cosPool, dense, thr);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    constexpr int TD = 5;
+    using CD = CosDeal<TD>;
+    const int Gd = CD::tiles(maxN1) * CD::tiles(maxN2);
+    e = dyn_lds(c, reinterpret_cast<const void*>(k_cos_deal<TD, 0>), (size_t)CD::LDS);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_cos_deal<TD, 0>), dim3((unsigned)(B >= 8 ? Gd * ((B + 7) / 8) * 8 : Gd * B)), dim3(256), (size_t)CD::LDS, stream, D, B, Gd, dP, feats, cosPool, (const int32_t*)dense);
+    return hipGetLastError();
+}
+// When: the score is the gated one (single scores on, not the pruned prefilter's raw products, cosine_max > cosine_min), maps of at most
+// CSEL_MAXN objects, and a batch that gives most compute units a problem.  ROMAN_COS_SEL=0 never, =1 whenever the results allow it (tests).
+static bool cos_sel_applies(const roman_ctx* c, const DevParams& D, int B, int maxN1, int maxN2, int64_t poolRows)
+{
+    if (!D.single || D.pruned || !(D.p.cosine_max > D.p.cosine_min) || !std::isfinite(D.p.cosine_min) || !std::isfinite(D.p.cosine_max)) return false;
+    if (maxN1 > CSEL_MAXN || maxN2 > CSEL_MAXN || maxN1 <= 0 || maxN2 <= 0) return false;
+    if (poolRows * (int64_t)D.F * 8 >= (1LL << 32)) return false;         // (the exact pass addresses a row by a 32-bit byte offset into the pool)
+    const char* env = getenv("ROMAN_COS_SEL");
+    if (env && env[0]) return env[0] == '1';
+    return false;
+}
+
 // ---- the launch sequence of one batch (score + solve), on workspace c->cur and its stream; never waits -------------
 
 // Positions of the stream layout: rows of one degree at most for the sort-free placement (place_keys(), kernels.hip.h); beyond, the
@@ -390,7 +422,7 @@ static hipError_t launch_cos(roman_ctx* c, hipStream_t stream, const DevParams& 
         if (deal) {
             const hipError_t e = dyn_lds(c, reinterpret_cast<const void*>(k_cos_deal<TD, 0>), (size_t)CD::LDS);
             if (e != hipSuccess) return e;
-            hipLaunchKernelGGL((k_cos_deal<TD, 0>), dim3((unsigned)(B >= 8 ? Gd * ((B + 7) / 8) * 8 : Gd * B)), dim3(256), (size_t)CD::LDS, stream, D, B, Gd, dP, feats, cosPool);
+            hipLaunchKernelGGL((k_cos_deal<TD, 0>), dim3((unsigned)(B >= 8 ? Gd * ((B + 7) / 8) * 8 : Gd * B)), dim3(256), (size_t)CD::LDS, stream, D, B, Gd, dP, feats, cosPool, (const int32_t*)nullptr);
             return hipGetLastError();
         }
     }
@@ -449,7 +481,7 @@ int enqueue_score(roman_ctx* c, const DevParams& Din, const roman_params_t* para
     const int B = in.B;
     hd.assign(B, ProbDesc{});
     int64_t sumA = 0, sumCos = 0, sumTab = 0, sumQ4 = 0;
-    int maxN12 = 0, maxN = 0, maxA = 0, maxN1 = 0, maxN2 = 0; int64_t maxTab = 0;
+    int maxN12 = 0, maxN = 0, maxA = 0, maxN1 = 0, maxN2 = 0; int64_t maxTab = 0, poolRows = 0 /* rows of the feature pool the batch names */;
     for (int b = 0; b < B; ++b) {
         ProbDesc& d = hd[b];
         d.off1 = in.off1[b]; d.off2 = in.off2[b]; d.n1 = in.n1[b]; d.n2 = in.n2[b];
@@ -474,6 +506,7 @@ int enqueue_score(roman_ctx* c, const DevParams& Din, const roman_params_t* para
         maxN12 = std::max(maxN12, d.n1 + d.n2); maxN = std::max(maxN, std::max(d.n1, d.n2));
         maxN1 = std::max(maxN1, d.n1); maxN2 = std::max(maxN2, d.n2);
         maxTab = std::max(maxTab, (int64_t)d.n1 * d.n1 + (int64_t)d.n2 * d.n2);
+        poolRows = std::max(poolRows, std::max(d.off1 + d.n1, d.off2 + d.n2));
     }
     if (sumA > 2000000000LL) return fail(c, ROMAN_E_TOO_LARGE, "batch has %lld associations; split it (limit 2e9 per call)", (long long)sumA);
     const size_t nA1 = (size_t)std::max<int64_t>(sumA, 1);
@@ -552,6 +585,10 @@ int enqueue_score(roman_ctx* c, const DevParams& Din, const roman_params_t* para
 
     StageTimer t0(c, ROMAN_STAGE_SINGLE);
     if (cosOn && maxN1 > 0 && maxN2 > 0) {
+        if (cos_sel_applies(c, D, B, maxN1, maxN2, poolRows)) {
+            HIPCHK(c, WS.cosDense.ensure(sizeof(int32_t) * (size_t)B));
+            HIPCHK(c, launch_cos_sel(c, WS.stream, D, B, maxN1, maxN2, dP, in.feats, WS.cosPool.as<double>(), WS.cosDense.as<int32_t>(), false));
+        } else
         HIPCHK(c, launch_cos(c, WS.stream, D, B, maxN1, maxN2, dP, in.feats, WS.cosPool.as<double>()));
     DBG(c, "k_cos");
     }
@@ -1324,7 +1361,7 @@ int roman_ctx_destroy(roman_ctx_t* c)
     (void)roman_ctx_sync(c);
     for (int k = 0; k < ROMAN_MAX_PIPELINE; ++k) {
         roman_ctx::Workspace& W = c->ws[k];
-        DevBuf* all[] = {&W.probs, &W.state, &W.totals, &W.queue, &W.cosPool, &W.tabPool, &W.qtabPool, &W.sTmp, &W.chunkCnt,
+        DevBuf* all[] = {&W.probs, &W.state, &W.totals, &W.queue, &W.cosPool, &W.cosDense, &W.tabPool, &W.qtabPool, &W.sTmp, &W.chunkCnt,
                          &W.lp, &W.li, &W.lj, &W.ls, &W.ld, &W.lza, &W.lzb, &W.plp, &W.pli, &W.plj, &W.pls, &W.pld, &W.plza, &W.plzb,
                          &W.rowCnt, &W.rowPos, &W.perm, &W.sliceWidth, &W.sliceBase, &W.items, &W.maskPool, &W.prefPool, &W.listPool, &W.listOff,
                          &W.vMu, &W.vCu, &W.vMun, &W.vCun, &W.gU, &W.gUn, &W.uOut, &W.nodesOrig, &W.nSel, &W.widePart, &W.wideSlots, &W.wideBar, &W.wideBm, &W.fbList, &W.cols16, &W.cols32, &W.vals, &W.colsC, &W.valsC, &W.contSpill, &W.contList,
@@ -2130,6 +2167,12 @@ int roman_debug_cosine(roman_ctx_t* c, const roman_params_t* params, const doubl
     HIPCHK(c, WS.probs.ensure(sizeof(ProbDesc)));
     HIPCHK(c, WS.cosPool.ensure(sizeof(double) * (size_t)n1 * n2));
     HIPCHK(c, hipMemcpyAsync(WS.probs.p, &pd, sizeof(pd), hipMemcpyHostToDevice, WS.stream));
+    // ROMAN_COS_SEL=approx / gated (tests): k_cos_sel's screen matrix / k_cos_sel's matrix (exact where cos >= cosine_min - 2^-6, the screen elsewhere)
+    const char* selEnv = getenv("ROMAN_COS_SEL");
+    if (selEnv && (!strcmp(selEnv, "approx") || !strcmp(selEnv, "gated")) && n1 <= CSEL_MAXN && n2 <= CSEL_MAXN) {
+        HIPCHK(c, WS.cosDense.ensure(sizeof(int32_t)));
+        HIPCHK(c, launch_cos_sel(c, WS.stream, D, 1, n1, n2, WS.probs.as<ProbDesc>(), WS.hFeats.as<double>(), WS.cosPool.as<double>(), WS.cosDense.as<int32_t>(), selEnv[0] == 'a'));
+    } else
     HIPCHK(c, launch_cos(c, WS.stream, D, 1, n1, n2, WS.probs.as<ProbDesc>(), WS.hFeats.as<double>(), WS.cosPool.as<double>()));
     HIPCHK(c, hipMemcpyAsync(out, WS.cosPool.p, sizeof(double) * (size_t)n1 * n2, hipMemcpyDeviceToHost, WS.stream));
     HIPCHK(c, hipStreamSynchronize(WS.stream));

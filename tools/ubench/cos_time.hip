@@ -8,15 +8,15 @@
 #include <algorithm>
 using namespace roman;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
-template <typename K> static int run(const char* name, K kern, dim3 grid, size_t lds, DevParams D, int B, int G, ProbDesc* dP, double* feats, double* cosPool)
+template <typename K, typename... A> static int run(const char* name, K kern, dim3 grid, size_t lds, A... a)
 {
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const int reps = 10;
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, 0, D, B, G, dP, feats, cosPool);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, 0, a...);
     CK(hipGetLastError());
     hipEventRecord(e0);
-    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(kern, grid, dim3(256), lds, 0, D, B, G, dP, feats, cosPool);
+    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(kern, grid, dim3(256), lds, 0, a...);
     hipEventRecord(e1); CK(hipEventSynchronize(e1));
     float ms; hipEventElapsedTime(&ms, e0, e1);
     printf("%-44s grid %5u  LDS %6zu B : %7.1f us per launch\n", name, grid.x, lds, ms * 1e3 / reps);
@@ -35,7 +35,7 @@ __global__ void k_probe(unsigned long long* out, int windows, unsigned long long
         out[(blockIdx.x * windows + wdw) * 2] = t1 - t0; out[(blockIdx.x * windows + wdw) * 2 + 1] = c1 - c0;
     }
 }
-template <typename K> static int probe(const char* name, K kern, dim3 grid, size_t lds, DevParams D, int B, int G, ProbDesc* dP, double* feats, double* cosPool)
+template <typename K, typename... A> static int probe(const char* name, K kern, dim3 grid, size_t lds, A... a)
 {
     int wallKhz = 100000; hipDeviceGetAttribute(&wallKhz, hipDeviceAttributeWallClockRate, 0);
     const int windows = 40; const unsigned long long tpw = (unsigned long long)wallKhz * 100 / 1000;     // 100 us windows
@@ -44,7 +44,7 @@ template <typename K> static int probe(const char* name, K kern, dim3 grid, size
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     CK(hipDeviceSynchronize());
     hipLaunchKernelGGL(k_probe, dim3(8), dim3(64), 0, sa, d, windows, tpw);
-    for (int r = 0; r < 9; ++r) hipLaunchKernelGGL(kern, grid, dim3(256), lds, sb, D, B, G, dP, feats, cosPool);
+    for (int r = 0; r < 9; ++r) hipLaunchKernelGGL(kern, grid, dim3(256), lds, sb, a...);
     CK(hipDeviceSynchronize());
     unsigned long long h[8 * windows * 2]; CK(hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost));
     printf("%-44s shader MHz per 100 us window (XCD of probe 0):", name);
@@ -81,7 +81,7 @@ int main(int argc, char** argv)
         hipMemset(cosPool, 0, ref.size() * 8);
     };
 #define DEAL(T, DBG, label) { using CD = CosDeal<T>; const int Gd = CD::tiles(n) * CD::tiles(n); const dim3 gd((unsigned)(B >= 8 ? Gd * ((B + 7) / 8) * 8 : Gd * B)); \
-        if (run(label, k_cos_deal<T, DBG>, gd, (size_t)CD::LDS, D, B, Gd, dP, feats, cosPool)) return 1; }
+        if (run(label, k_cos_deal<T, DBG>, gd, (size_t)CD::LDS, D, B, Gd, dP, feats, cosPool, (const int32_t*)nullptr)) return 1; }
     CK(hipMemset(cosPool, 0, ref.size() * 8));
     DEAL(7, 0, "k_cos_deal<7>"); check("k_cos_deal<7>");
     DEAL(5, 0, "k_cos_deal<5>"); check("k_cos_deal<5>");
@@ -98,7 +98,7 @@ int main(int argc, char** argv)
     DEAL(5, 8, "k_cos_deal<5> no norms");
     DEAL(5, 2, "k_cos_deal<5> no stores/barriers");
 #define PROBE(T, DBG, label) { using CD = CosDeal<T>; const int Gd = CD::tiles(n) * CD::tiles(n); const dim3 gd((unsigned)(B >= 8 ? Gd * ((B + 7) / 8) * 8 : Gd * B)); \
-        if (probe(label, k_cos_deal<T, DBG>, gd, (size_t)CD::LDS, D, B, Gd, dP, feats, cosPool)) return 1; }
+        if (probe(label, k_cos_deal<T, DBG>, gd, (size_t)CD::LDS, D, B, Gd, dP, feats, cosPool, (const int32_t*)nullptr)) return 1; }
     if (probe("k_cos_tile<16>", k_cos_tile<16>, gt, (size_t)2 * 128 * (16 * 8 + 16), D, B, Gt, dP, feats, cosPool)) return 1;
     PROBE(7, 0, "k_cos_deal<7>");
     PROBE(7, 11, "k_cos_deal<7> no loads/stores/barriers/norms");
