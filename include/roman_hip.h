@@ -337,6 +337,14 @@ ROMAN_API int roman_align_batch_resident(roman_ctx_t* ctx, const roman_params_t*
    repeating its guess (roman_align_batch does the same internally).  The context keeps ONE history: that of the latest block. */
 ROMAN_API int roman_ctx_has_history(roman_ctx_t* ctx, const roman_params_t* params, int32_t F, int32_t* yes);
 
+/* The cosine stage of a batch ([REF roman/align/roman_registration.py:52-59]: the semantic similarity only counts above cosine_min) has two
+   implementations: the dense f64 matrix-core product of all pairs, and a bf16 screen of all pairs followed by the exact f64 contraction of
+   the pairs the screen cannot rule out (k_cos_sel: same bits wherever the gate lets a pair through).  The library picks per batch — large
+   batches of maps of at most 256 objects take the screen unless the latest screened batch of the parameter block left more than a quarter of
+   its problems to the dense kernel (descriptors that are all alike).  Diagnostics: the numbers of batches that took either since the context
+   was created, and the share of the latest screened batch that fell back (any pointer may be NULL).  ROMAN_COS_SEL=0 / 1 forces either. */
+ROMAN_API int roman_ctx_cosine_screen_stats(roman_ctx_t* ctx, int64_t* screened_batches, int64_t* dense_batches, double* latest_fallback_share);
+
 /* The deal of a batch over `world` ranks (one process per GPU), for a C / C++ caller that shards with its own collective
    (roman_ros, [REF README.md:11]; the Python side is roman_amd.align.distributed.align_sharded).  The pairs of the serial loop
    [REF roman/align/submap_align.py:93-200] are independent: every rank aligns its share with roman_align_batch[_dev] and ONE

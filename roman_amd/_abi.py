@@ -170,6 +170,7 @@ def load_library():
         "roman_align_batch_resident": (C.c_int, [ctxp, P(RomanParams), i32, vp, vp, vp, vp, vp, i32,
                                                  vp, vp, vp, i32, vp, vp, vp, vp, vp]),
         "roman_ctx_has_history": (C.c_int, [ctxp, P(RomanParams), i32, P(i32)]),
+        "roman_ctx_cosine_screen_stats": (C.c_int, [ctxp, P(C.c_int64), P(C.c_int64), P(C.c_double)]),
         "roman_create_all_to_all": (C.c_int, [i32, i32, vp]),
         "roman_deal_problems": (C.c_int, [i32, vp, vp, vp, i32, i32, vp, P(i32)]),
         "roman_score": (C.c_int, [ctxp, P(RomanParams), vp, i32, vp, i32, i32, vp, i32]),
@@ -202,7 +203,7 @@ def load_library():
 EXPORTED_SYMBOLS = (
     "roman_params_default", "roman_ctx_create", "roman_ctx_destroy", "roman_ctx_set_pipeline", "roman_ctx_sync", "roman_ctx_set_host_batching", "roman_ctx_set_wide_teams", "roman_ctx_join", "roman_ctx_join_on",
     "roman_ctx_skipped", "roman_last_error",
-    "roman_align_batch_dev", "roman_align_batch", "roman_align_batch_resident", "roman_ctx_has_history", "roman_deal_problems", "roman_create_all_to_all", "roman_score",
+    "roman_align_batch_dev", "roman_align_batch", "roman_align_batch_resident", "roman_ctx_has_history", "roman_ctx_cosine_screen_stats", "roman_deal_problems", "roman_create_all_to_all", "roman_score",
     "roman_set_matrix_data", "roman_solve", "roman_num_associations", "roman_num_selected",
     "roman_get_selected_associations", "roman_get_solution", "roman_get_dense_matrices",
     "roman_get_upper_csr", "roman_pose_batch", "roman_profile_enable", "roman_profile_reset",

@@ -110,6 +110,8 @@ struct BatchTotals {
     int32_t minStreamL;    // smallest L among stream-layout problems (does the small-problem solver have work?)
     int32_t nGeneral;      // problems left to the general kernels (not finished by k_small, not skipped)
     unsigned long long listTop;    // bump pointer of the candidate-list pool = what the whole batch needs of it
+    int32_t cosScreened;   // problems whose cosines went through k_cos_sel (0: the dense kernels took the batch) ...
+    int32_t cosDense;      // ... and how many of them it left to the dense kernel (more candidates than its list holds)
 };
 
 struct ItemDesc { int32_t b, row0; };   // a block of consecutive live rows of problem b
@@ -1533,7 +1535,8 @@ __device__ __forceinline__ T block_excl_scan(T v, T* sh, T& total)
 }
 
 __global__ void __launch_bounds__(1024) k_rowbase(int B, int RPB, long long capMaskWords, ProbState* __restrict__ st, BatchTotals* __restrict__ tot,
-                                                  int smallOnly /* the general kernels are not launched: what k_small left behind is skipped */)
+                                                  int smallOnly /* the general kernels are not launched: what k_small left behind is skipped */,
+                                                  const int32_t* __restrict__ cosDense /* NULL, or k_cos_sel's flags of the batch */)
 {
     // one workgroup; a thread takes PER consecutive problems (a serial sweep of one wave over 4096 problems was 93 us —
     // 64 dependent round trips to memory — of the 1.4 ms the whole batch takes at the reference's demo scale)
@@ -1578,10 +1581,11 @@ __global__ void __launch_bounds__(1024) k_rowbase(int B, int RPB, long long capM
         }
     }
     const int baseI = block_excl_scan(sI, shi, totI);
-    int mx = 0, mxs = 0, nover = 0, mns = 0x7fffffff, ngen = 0;
+    int mx = 0, mxs = 0, nover = 0, mns = 0x7fffffff, ngen = 0, ndense = 0;
     {
         long long accM = baseM; int accR = baseR, accI = baseI;
         for (int b = b0; b < b1; ++b) {
+            if (cosDense) ndense += cosDense[b] != 0;
             const int L = getL(b);
             const int kind = getK(b);
             const bool skip = kind >= 2;
@@ -1603,13 +1607,14 @@ __global__ void __launch_bounds__(1024) k_rowbase(int B, int RPB, long long capM
         }
     }
     // batch maxima / counts: wave reduction, then one atomic per wave on LDS words
-    __shared__ int red[5];
-    if (tid == 0) { red[0] = 0; red[1] = 0; red[2] = 0; red[3] = 0x7fffffff; red[4] = 0; }
+    __shared__ int red[6];
+    if (tid == 0) { red[0] = 0; red[1] = 0; red[2] = 0; red[3] = 0x7fffffff; red[4] = 0; red[5] = 0; }
     __syncthreads();
-    for (int off = 32; off > 0; off >>= 1) { mx = max(mx, __shfl_xor(mx, off)); mxs = max(mxs, __shfl_xor(mxs, off)); nover += __shfl_xor(nover, off); mns = min(mns, __shfl_xor(mns, off)); ngen += __shfl_xor(ngen, off); }
-    if ((tid & 63) == 0) { atomicMax(&red[0], mx); atomicMax(&red[1], mxs); atomicAdd(&red[2], nover); atomicMin(&red[3], mns); atomicAdd(&red[4], ngen); }
+    for (int off = 32; off > 0; off >>= 1) { mx = max(mx, __shfl_xor(mx, off)); mxs = max(mxs, __shfl_xor(mxs, off)); nover += __shfl_xor(nover, off); mns = min(mns, __shfl_xor(mns, off)); ngen += __shfl_xor(ngen, off); ndense += __shfl_xor(ndense, off); }
+    if ((tid & 63) == 0) { atomicMax(&red[0], mx); atomicMax(&red[1], mxs); atomicAdd(&red[2], nover); atomicMin(&red[3], mns); atomicAdd(&red[4], ngen); atomicAdd(&red[5], ndense); }
     __syncthreads();
     if (tid == 0) {
+        tot->cosScreened = cosDense ? B : 0; tot->cosDense = red[5];
         tot->R = totR; tot->maxL = red[0]; tot->nnzTotal = 0; tot->maskWords = totM < capMaskWords ? totM : capMaskWords; tot->items = totI; tot->sliceGroups = 0;
         tot->needMaskWords = totN; tot->needNnz = 0; tot->overflow = red[2]; tot->maxStreamL = red[1]; tot->minStreamL = red[3]; tot->nGeneral = red[4]; tot->listTop = 0ull;
     }

@@ -119,7 +119,11 @@ struct roman_ctx {
         bool smallSeen = false;                // a stream-layout problem of at most SMALL_MAXL live associations has occurred
         bool largeSeen = false;                // ... one of more than SMALL_MAXL
         bool generalSeen = false;              // a problem was left to the general kernels (k_small did not finish it)
+        bool cosSeen = false;                  // a batch of this block went through k_cos_sel ...
+        double cosDenseFrac = 0.0;             // ... and this share of the latest such batch was left to the dense kernel (too many candidates)
+        int cosSkipped = 0;                    // batches since that took the dense kernels for it (every 64th tries the screen again)
     } hist;
+    long long cosScreenBatches = 0, cosDenseBatches = 0;     // batches with a cosine stage that took k_cos_sel / the dense kernels
     unsigned histEpoch = 1;                    // bumped whenever the history is reset for another parameter block
     long long skippedTotal = 0;                // problems reported ROMAN_ST_WORKSPACE so far (harvested totals)
 
@@ -308,6 +312,7 @@ void harvest_totals(roman_ctx* c, bool wait)
         if (t.minStreamL <= SMALL_MAXL) H.smallSeen = true;
         if (t.maxStreamL > SMALL_MAXL) H.largeSeen = true;
         if (t.nGeneral > 0) H.generalSeen = true;
+        if (t.cosScreened > 0) { H.cosSeen = true; H.cosDenseFrac = (double)t.cosDense / t.cosScreened; }
         H.valid = true;
     }
 }
@@ -391,7 +396,17 @@ static bool cos_sel_applies(const roman_ctx* c, const DevParams& D, int B, int m
     if (poolRows * (int64_t)D.F * 8 >= (1LL << 32)) return false;         // (the exact pass addresses a row by a 32-bit byte offset into the pool)
     const char* env = getenv("ROMAN_COS_SEL");
     if (env && env[0]) return env[0] == '1';
-    return false;
+    // by itself: a batch that gives at least half the compute units a problem (one workgroup per problem; smaller batches keep the dense
+    // kernels' many workgroups per problem), descriptors long enough for the two sweeps to pay, and no history of this parameter block
+    // that says the screen rules out too little (a quarter of the latest screened batch left to the dense kernel: the dense kernel
+    // directly, the screen again every 64th batch)
+    if (2 * B < c->num_cu || D.p.cos_feature_dim < 64 || std::max(maxN1, maxN2) < 64) return false;
+    roman_ctx::Hist& H = const_cast<roman_ctx*>(c)->hist;
+    if (H.cosSeen && H.cosDenseFrac > 0.25) {
+        if (++H.cosSkipped < 64) return false;
+        H.cosSkipped = 0;
+    }
+    return true;
 }
 
 // ---- the launch sequence of one batch (score + solve), on workspace c->cur and its stream; never waits -------------
@@ -584,8 +599,11 @@ int enqueue_score(roman_ctx* c, const DevParams& Din, const roman_params_t* para
     const LivePools PP{WS.plp.as<int32_t>(), WS.pli.as<int32_t>(), WS.plj.as<int32_t>(), WS.pls.as<double>(), WS.pld.as<double>(), WS.plza.as<double>(), WS.plzb.as<double>()};
 
     StageTimer t0(c, ROMAN_STAGE_SINGLE);
+    bool cosScreen = false;
     if (cosOn && maxN1 > 0 && maxN2 > 0) {
-        if (cos_sel_applies(c, D, B, maxN1, maxN2, poolRows)) {
+        cosScreen = cos_sel_applies(c, D, B, maxN1, maxN2, poolRows);
+        ++(cosScreen ? c->cosScreenBatches : c->cosDenseBatches);
+        if (cosScreen) {
             HIPCHK(c, WS.cosDense.ensure(sizeof(int32_t) * (size_t)B));
             HIPCHK(c, launch_cos_sel(c, WS.stream, D, B, maxN1, maxN2, dP, in.feats, WS.cosPool.as<double>(), WS.cosDense.as<int32_t>(), false));
         } else
@@ -694,7 +712,7 @@ int enqueue_score(roman_ctx* c, const DevParams& Din, const roman_params_t* para
             Dout->small_only = D.small_only;
         }
     }
-    hipLaunchKernelGGL(k_rowbase, dim3(1), dim3(B > 256 ? 1024 : 256), 0, WS.stream, B, RPB, SZ.capMaskWords, dS, dT, D.small_only);
+    hipLaunchKernelGGL(k_rowbase, dim3(1), dim3(B > 256 ? 1024 : 256), 0, WS.stream, B, RPB, SZ.capMaskWords, dS, dT, D.small_only, cosScreen ? (const int32_t*)WS.cosDense.as<int32_t>() : (const int32_t*)nullptr);
     DBG(c, "k_rowbase");
     if (!D.small_only) {
     hipLaunchKernelGGL(k_items, dim3(B), dim3(256), 0, WS.stream, RPB, dS, WS.items.as<ItemDesc>());
@@ -1524,6 +1542,16 @@ int roman_align_batch_dev(roman_ctx_t* c, const roman_params_t* params, int32_t 
     return ROMAN_OK;
 }
 
+int roman_ctx_cosine_screen_stats(roman_ctx_t* c, int64_t* screened_batches, int64_t* dense_batches, double* latest_fallback_share)
+{
+    if (!c) return fail(nullptr, ROMAN_E_INVALID, "ctx is NULL");
+    harvest_totals(c, false);
+    if (screened_batches) *screened_batches = c->cosScreenBatches;
+    if (dense_batches) *dense_batches = c->cosDenseBatches;
+    if (latest_fallback_share) *latest_fallback_share = c->hist.cosSeen ? c->hist.cosDenseFrac : 0.0;
+    return ROMAN_OK;
+}
+
 int roman_ctx_has_history(roman_ctx_t* c, const roman_params_t* params, int32_t F, int32_t* yes)
 {
     if (!c) return fail(nullptr, ROMAN_E_INVALID, "ctx is NULL");
@@ -1947,7 +1975,7 @@ int roman_set_matrix_data(roman_ctx_t* c, const roman_params_t* params, const do
     }
     const LivePools LP{WS.lp.as<int32_t>(), nullptr, nullptr, WS.ls.as<double>(), WS.ld.as<double>(), nullptr, nullptr};
     const LivePools PP{WS.plp.as<int32_t>(), nullptr, nullptr, nullptr, WS.pld.as<double>(), nullptr, nullptr};
-    hipLaunchKernelGGL(k_rowbase, dim3(1), dim3(256), 0, WS.stream, 1, RPB, (long long)maskWords, dS, dT, 0);
+    hipLaunchKernelGGL(k_rowbase, dim3(1), dim3(256), 0, WS.stream, 1, RPB, (long long)maskWords, dS, dT, 0, (const int32_t*)nullptr);
     hipLaunchKernelGGL(k_items, dim3(1), dim3(256), 0, WS.stream, RPB, dS, WS.items.as<ItemDesc>());
     if (n > 0) {
         hipLaunchKernelGGL(k_dense_mask, dim3((unsigned)std::min(c->num_cu * 8, (n + 3) / 4)), dim3(256), 0, WS.stream, n, dM, dC,

@@ -95,6 +95,13 @@ class Context:
         self._check(self._lib.roman_ctx_has_history(self._h, C.byref(params), int(F), C.byref(yes)), "roman_ctx_has_history")
         return bool(yes.value)
 
+    def cosine_screen_stats(self):
+        """(batches whose cosine stage took the bf16 screen + exact candidates, batches that took the dense product, share of the latest
+        screened batch left to the dense kernel) — roman_ctx_cosine_screen_stats."""
+        a, b, f = C.c_int64(0), C.c_int64(0), C.c_double(0.0)
+        self._check(self._lib.roman_ctx_cosine_screen_stats(self._h, C.byref(a), C.byref(b), C.byref(f)), "roman_ctx_cosine_screen_stats")
+        return int(a.value), int(b.value), float(f.value)
+
     def join(self, skip_latest=False, stream=None):
         """Make the context's stream — or `stream` (a hipStream_t handle, e.g. torch.cuda.Stream.cuda_stream) — wait for the
         pipelined batches issued so far (optionally all but the latest)."""

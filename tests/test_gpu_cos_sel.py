@@ -134,3 +134,44 @@ def test_a_batch_scored_through_the_screen_equals_the_dense_kernel_bit_for_bit(c
     assert np.array_equal(a.T, b_.T, equal_nan=True)
     for f in ("n_live", "nnz_upper", "n_pass", "outer_iters", "inner_iters", "ls_trials", "score", "d_final"):
         assert np.array_equal(a.stats[f], b_.stats[f]), f
+
+
+def test_the_library_takes_the_screen_for_large_batches_and_drops_it_when_it_rules_out_too_little(monkeypatch):
+    """Without the switch: a batch that gives half the compute units a problem takes the screen; descriptors that are all alike (every
+    cosine above cosine_min: every problem overflows the candidate list and is left to the dense kernel) make the NEXT batches of that
+    parameter block take the dense kernels directly; results are the dense kernel's either way."""
+    from roman_amd.runtime import Context
+    monkeypatch.delenv("ROMAN_COS_SEL", raising=False)
+    d = 64
+    reg = registration_for("semanticgrav", semantics_dim=d)
+    c = Context(0)
+    try:
+        reg.set_context(c)
+        B = 160
+        pairs = []
+        for k in range(B):
+            pr = synth.make_pair(70, 72, d, 9100 + k, tilt_deg=1.0)
+            pairs.append((pr.map1, pr.map2))
+        batch = rb.batch_from_pairs(reg, pairs)
+        r1 = rb.run_batch(reg, batch); c.sync()
+        s1 = c.cosine_screen_stats()
+        assert s1[0] >= 1 and s1[2] == 0.0                 # screened, nothing left to the dense kernel
+        monkeypatch.setenv("ROMAN_COS_SEL", "0")
+        r0 = rb.run_batch(reg, batch); c.sync()
+        monkeypatch.delenv("ROMAN_COS_SEL", raising=False)
+        assert np.array_equal(r0.status, r1.status) and all(np.array_equal(a, b) for a, b in zip(r0.assoc, r1.assoc))
+        # the same maps with descriptors that are all alike
+        alike = rb.AlignmentBatch(batch.feats.copy(), batch.off1, batch.n1, batch.off2, batch.n2, batch.assoc, batch.assoc_off)
+        P = reg._abi_params(); lo = P.point_dim + P.ratio_feature_dim
+        alike.feats[:, lo:lo + d] = 1.0 + 0.01 * np.random.default_rng(1).standard_normal((alike.feats.shape[0], d))
+        before = c.cosine_screen_stats()
+        ra = rb.run_batch(reg, alike); c.sync()
+        mid = c.cosine_screen_stats()
+        assert mid[0] == before[0] + 1 and mid[2] == 1.0   # screened once more: every problem fell back
+        rb2 = rb.run_batch(reg, alike); c.sync()
+        after = c.cosine_screen_stats()
+        assert after[0] == mid[0] and after[1] == mid[1] + 1        # ... so this batch took the dense kernels directly
+        assert np.array_equal(ra.status, rb2.status) and all(np.array_equal(a, b) for a, b in zip(ra.assoc, rb2.assoc))
+        assert np.array_equal(ra.T, rb2.T, equal_nan=True)
+    finally:
+        c.close()
