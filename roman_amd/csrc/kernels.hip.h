@@ -5222,8 +5222,12 @@ __global__ void __launch_bounds__(64, 3) k_small(DevParams D, int B, const ProbD
 constexpr int WIDE_NT = 512;             // threads per workgroup (one workgroup per compute unit; 8 waves: 256 registers each)
 constexpr int WIDE_NW = WIDE_NT / 64;
 constexpr int WIDE_KW = 2;               // vector elements a thread can own: L <= WIDE_KW * 64 * (waves of the grid)
-constexpr int WIDE_NRED = 8;             // doubles per workgroup slot of a grid reduction
-constexpr int WIDE_U = 3;                // quads (of 4 entries per lane) per block of the stream; two blocks in flight per wave
+constexpr int WIDE_NRED = 10;            // doubles per workgroup slot of a grid reduction
+constexpr int WIDE_MAXBLK = 8;           // column blocks of the half copy (pull + push passes) at most
+#ifndef ROMAN_WIDE_U
+#define ROMAN_WIDE_U 3
+#endif
+constexpr int WIDE_U = ROMAN_WIDE_U;     // quads (of 4 entries per lane) per block of the stream; two blocks in flight per wave
 constexpr int WIDE_MAXCH = 8;            // chunks of the flat stream a wave takes per pass at most
 
 // dynamic LDS of k_solve_wide in front of the gathered vector's leading part: three bit maps of bmWords 64-bit words and the
@@ -5237,6 +5241,11 @@ struct WideShared {
     int sint[4];
     int abort_;
     int sS[WIDE_NT / 64][8];             // per wave: first slice of each of its chunks (-1: no such chunk)
+    // the half copy (pull + push passes): per column block its stream's steps, steps per chunk, first piece id, first step in the
+    // mirror pools, the team's workgroups that stream it (count, first rank); per wave the piece ranges of its owned slices per block
+    uint32_t upT[WIDE_MAXBLK], upCS[WIDE_MAXBLK], upPB[WIDE_MAXBLK], upSB[WIDE_MAXBLK];
+    int upG[WIDE_MAXBLK], upCU[WIDE_MAXBLK];
+    uint32_t upPc[WIDE_NT / 64][WIDE_KW][WIDE_MAXBLK][2];
 };
 
 // write-through store of a value other workgroups will read (global_store ... sc1: no release fence needed later)
@@ -5422,7 +5431,11 @@ __global__ void __launch_bounds__(WIDE_NT) k_solve_wide(DevParams D, int B, cons
                                                         const int32_t* __restrict__ fbList /* the batch's fallback problems (k_skipped) */,
                                                         long long partStride /* doubles of `part` a team owns */,
                                                         IdxT* colsC, double* valsC /* (no __restrict__: a compacted copy is compacted again in place) mirror of the matrix pools: the column-compacted copy (same offsets) */,
-                                                        int ccfg /* column compaction: bits 0-7 compactions allowed per problem (0: off), 8-15 threshold (x / 256 of the columns in use), 16-23 passes per window */)
+                                                        int ccfg /* column compaction: bits 0-7 compactions allowed per problem (0: off), 8-15 threshold (x / 256 of the columns in use), 16-23 passes per window */,
+                                                        int ucfg /* bit 0: pull + push passes over a half copy of the matrix — every pair stored once — (16-bit labels only) while no compacted copy exists */,
+                                                        unsigned long long* __restrict__ yPart /* [team][ySlots][2][ycap]: a workgroup's pushed fixed-point sums of its column block (M x, C x) */,
+                                                        int ySlots /* workgroups of a team the host sized yPart for */, int ycap /* columns of a block at most (multiple of 64, 3 ycap <= xcap) */,
+                                                        uint32_t* __restrict__ upMeta /* [team][WIDE_MAXBLK][bmWords + 1]: slice widths (steps) of the half copy per column block */)
 {
     __shared__ WideShared sh;
     extern __shared__ __attribute__((aligned(16))) unsigned char wide_smem[];
@@ -5488,18 +5501,25 @@ __global__ void __launch_bounds__(WIDE_NT) k_solve_wide(DevParams D, int B, cons
         // at any moment the waves of the grid read one contiguous window of the matrix.  Every wave takes the same number
         // m <= WIDE_MAXCH of chunks (the last round may be short): about 16 steps per chunk, more when the matrix is larger.
         uint32_t T = Tfull, CS = 1u, nCh = 0u;
-        int cmode = 0 /* stream in use: 0 full, 1 the copy */, ncomp = 0, winPass = 0, winOut = 0; bool haveCopy = false;
+        int cmode = 0 /* stream in use: 0 full, 1 the column-compacted copy, 2 my column block of the half copy (pull + push) */, ncomp = 0, winPass = 0, winOut = 0; bool haveCopy = false;
+        int cNWG = NWG, cgw = gwc;                              // the waves the stream in use is dealt to and my id among them (half copy: the workgroups of my column block)
+        // the half copy: column blocks, their width, my block, its workgroups / my rank among them, its first column, the fixed-point scale of the pass
+        bool upOn = false; int nblk = 1, Wc = 0, jb = 0, GU = 1, rkU = 0; double fxInv = 1.0;
+        [[maybe_unused]] uint32_t upSteps = 0u;
         uint32_t copyCols = 0u, Tcopy = 0u;                     // compaction state (identical in every workgroup of the team)
         uint32_t pcf[WIDE_KW], pcn[WIDE_KW];
         static_assert(WIDE_MAXCH <= 8, "sS capacity");
-        auto geometry = [&]() {                                 // (cw and T are set; every thread of the workgroup calls this)
-            uint32_t mch = max(1u, min((uint32_t)WIDE_MAXCH, (T + (uint32_t)NWG * 16u - 1u) / ((uint32_t)NWG * 16u)));
+        auto chunk_steps = [&](uint32_t T_, uint32_t nwg_) -> uint32_t {   // steps per chunk of a stream of T_ steps dealt to nwg_ waves
+            uint32_t mch = max(1u, min((uint32_t)WIDE_MAXCH, (T_ + nwg_ * 16u - 1u) / (nwg_ * 16u)));
             if ((tune >> 8) & 0xff) mch = min((uint32_t)WIDE_MAXCH, (uint32_t)((tune >> 8) & 0xff));
-            CS = max(1u, (T + (uint32_t)NWG * mch - 1u) / ((uint32_t)NWG * mch));
-            nCh = (T + CS - 1u) / CS;                            // <= NWG * mch
+            return max(1u, (T_ + nwg_ * mch - 1u) / (nwg_ * mch));
+        };
+        auto geometry = [&]() {                                 // (cw, T, cNWG and cgw are set; every thread of the workgroup calls this)
+            CS = chunk_steps(T, (uint32_t)cNWG);
+            nCh = (T + CS - 1u) / CS;                            // <= cNWG * WIDE_MAXCH
             __syncthreads();                                    // (the previous stream is done with sS; cw is complete)
             if (lane < WIDE_MAXCH) {                            // lane j: first slice of this wave's chunk j (-1: no such chunk)
-                const uint32_t c = (uint32_t)gwc + (uint32_t)lane * (uint32_t)NWG;
+                const uint32_t c = (uint32_t)cgw + (uint32_t)lane * (uint32_t)cNWG;
                 int s_ = -1;
                 if (c < nCh) {                                  // largest s with cumW[s] <= first step of the chunk
                     const uint32_t t0 = c * CS;
@@ -5523,7 +5543,7 @@ __global__ void __launch_bounds__(WIDE_NT) k_solve_wide(DevParams D, int B, cons
         auto full_stream = [&]() {                              // cw <- the layout's own slice bases
             __syncthreads();
             for (int p = ltid; p <= nsl; p += WIDE_NT) cw[p] = p < nsl ? MEMW(p) : Tfull;
-            T = Tfull; cmode = 0;
+            T = Tfull; cmode = 0; cNWG = NWG; cgw = gwc;
             geometry();
         };
         auto copy_stream = [&]() {                              // cw <- prefix of the copy's slice widths (wNew, written by its compaction)
@@ -5539,7 +5559,7 @@ __global__ void __launch_bounds__(WIDE_NT) k_solve_wide(DevParams D, int B, cons
                 if (lane == 0) cw[nsl] = run;
             }
             __syncthreads();
-            T = cw[nsl]; Tcopy = T; cmode = 1;
+            T = cw[nsl]; Tcopy = T; cmode = 1; cNWG = NWG; cgw = gwc;
             geometry();
         };
         full_stream();
@@ -5630,11 +5650,63 @@ __global__ void __launch_bounds__(WIDE_NT) k_solve_wide(DevParams D, int B, cons
                     WIDE_CONSUME(cB, vB0, vB1, n1)
                 }
             }
-#undef WIDE_ISSUE
 #undef WIDE_CONSUME
             double* pp = part + ((size_t)pid * 64 + lane) * 2;
             st_pub(pp, am); st_pub(pp + 1, ac);
         };
+        // One piece of my column block of the HALF copy (round 6): a stored entry (p, q, v) serves both (p, q) and (q, p) — pulled
+        // into the row's registers ((M x)_p += v x_q, (C x)_p += x_q: x of the block's columns is in LDS, all of it), and pushed
+        // into the block's accumulators ((M x)_q += v x_p, (C x)_q += x_p: two ds_add_u64 of fixed-point terms rint(. 2^s), s from the
+        // vector's largest element so that a column's sum stays below 2^62 — integer sums: no order, k_solve_up's "exact accumulation").
+        // Column labels of the copy are relative to the block's first column; 0xffff (>= Wc) is padding.
+        auto piece_up = [&](const double* xv, int s_, uint32_t tm /* first step in the mirror pools */, uint32_t n /* steps */, uint32_t pid, double fxScale) {
+            if constexpr (W16) {
+            const uint32_t rp = ((uint32_t)s_ << 6) + (uint32_t)lane;
+            const double xr = rp < (uint32_t)L ? xv[rp] : 0.0;
+            const cword_t* cp = reinterpret_cast<const cword_t*>((const IdxT*)colsK) + (size_t)tm * 64 + lane;
+            const dbl2_t* vp = reinterpret_cast<const dbl2_t*>((const double*)valsK) + (size_t)tm * 128 + lane;
+            cword_t cA[WIDE_U], cB[WIDE_U]; dbl2_t vA0[WIDE_U], vA1[WIDE_U], vB0[WIDE_U], vB1[WIDE_U];
+            WIDE_ISSUE(cA, vA0, vA1, 0u, n)
+            double am = 0.0, ac = 0.0;
+            const double xrS = xr * fxScale;
+            const unsigned long long fC = (unsigned long long)__double_as_longlong(xrS + FX_MAGIC) - FX_MAGIC_BITS;
+            const bool push = xr > 0.0;
+            l_vec_cp xloc = (l_vec_cp)xl;
+            l_acc_p aM = (l_acc_p)(xl + Wc), aC = (l_acc_p)(xl + 2 * Wc);
+#define WIDE_CONSUME_UP(C_, V0_, V1_, n_)                                                                     \
+            _Pragma("unroll") for (int e = 0; e < WIDE_U; ++e) {                                              \
+                if ((uint32_t)e < (n_)) {                                                                     \
+                    const unsigned long long cw_ = *reinterpret_cast<const unsigned long long*>(&C_[e]);      \
+                    const uint32_t c4[4] = {(uint32_t)(cw_ & 0xffffu), (uint32_t)((cw_ >> 16) & 0xffffu), (uint32_t)((cw_ >> 32) & 0xffffu), (uint32_t)(cw_ >> 48)}; \
+                    const double v4[4] = {V0_[e].x, V0_[e].y, V1_[e].x, V1_[e].y};                            \
+                    _Pragma("unroll") for (int h = 0; h < 4; ++h) {                                           \
+                        if (c4[h] < (uint32_t)Wc) {                                                           \
+                            const double uq = xloc[c4[h]];                                                    \
+                            am = fma(v4[h], uq, am); ac += uq;                                                \
+                            if (push) {                                                                       \
+                                __hip_atomic_fetch_add(aM + c4[h], (unsigned long long)__double_as_longlong(fma(v4[h], xrS, FX_MAGIC)) - FX_MAGIC_BITS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+                                __hip_atomic_fetch_add(aC + c4[h], fC, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+                            }                                                                                 \
+                        }                                                                                     \
+                    }                                                                                         \
+                }                                                                                             \
+            }
+            for (uint32_t o = 0; o < n; o += 2 * WIDE_U) {
+                const uint32_t n1 = (n > o + WIDE_U) ? n - o - WIDE_U : 0u;
+                if (n1) { WIDE_ISSUE(cB, vB0, vB1, o + WIDE_U, n1) }
+                WIDE_CONSUME_UP(cA, vA0, vA1, n - o)
+                if (n1) {
+                    const uint32_t n2 = (n > o + 2 * WIDE_U) ? n - o - 2 * WIDE_U : 0u;
+                    if (n2) { WIDE_ISSUE(cA, vA0, vA1, o + 2 * WIDE_U, n2) }
+                    WIDE_CONSUME_UP(cB, vB0, vB1, n1)
+                }
+            }
+#undef WIDE_CONSUME_UP
+            double* pp = part + ((size_t)pid * 64 + lane) * 2;
+            st_pub(pp, am); st_pub(pp + 1, ac);
+            }
+        };
+#undef WIDE_ISSUE
         // Where the gathered values come from.  A 320 KB vector against a 32 KB L1 makes every gather an L2 access, and the
         // whole device does 280 G of those per second: 150 us for the 42 M entries of the n = m = 200 problem, more than
         // the matrix stream itself.  So every workgroup first copies into LDS (a) the support bit map of x (one bit per
@@ -5711,10 +5783,11 @@ __global__ void __launch_bounds__(WIDE_NT) k_solve_wide(DevParams D, int B, cons
         // position) and (b) the leading min(mp1, xcap) elements of x — positions are ranks by degree, so the leading
         // elements are the columns most entries point at, and the support collapses onto them within a few passes.  A
         // gather is then an LDS read; only a column beyond the LDS part whose bit is set goes to L2.
-        auto stream = [&](const double* xv, const unsigned long long* bm, uint32_t mp1) -> bool {
+        auto stream = [&](const double* xv, const unsigned long long* bm, uint32_t mp1, double xmax /* largest element of xv */) -> bool {
             const uint32_t nl = (tune & 1) ? 0u : min(mp1, (uint32_t)xcap);
             for (uint32_t p = (uint32_t)ltid; p < (uint32_t)nsl; p += WIDE_NT) bml[p] = bm[p];
-            for (uint32_t p = (uint32_t)ltid; p < nl; p += WIDE_NT) xl[p] = xv[p];
+            const bool upIn = upOn;
+            if (!upOn) for (uint32_t p = (uint32_t)ltid; p < nl; p += WIDE_NT) xl[p] = xv[p];
             if (cmax > 0 && Tfull >= 16u * (uint32_t)NWG) {     // support bookkeeping: the same words, the same verdict in every workgroup of the team
                 // (a matrix of fewer than 16 steps per wave is not worth a copy: its passes are barriers, and the books cost 3 us a pass)
                 if (ltid == 0) { sh.sint[0] = 0; sh.sint[1] = 0; sh.sint[2] = 0; }
@@ -5751,7 +5824,8 @@ __global__ void __launch_bounds__(WIDE_NT) k_solve_wide(DevParams D, int B, cons
                 }
                 if (doc) {
                     if (doc == 1 && cmode == 0) copy_stream();  // (slice_compact reads the source's widths from cw)
-                    if (doc == 2 && cmode == 1) full_stream();
+                    if (doc == 2 && cmode != 0) full_stream();
+                    upOn = false;                               // (the compacted copy takes the mirror pools: the half copy is gone)
                     const IdxT* srcC = doc == 1 ? (const IdxT*)colsK : cols; const double* srcV = doc == 1 ? (const double*)valsK : vals;
                     for (int s_ = gwc; s_ < nsl; s_ += NWG) slice_compact(s_, srcC, srcV);
                     for (uint32_t p = (uint32_t)ltid; p < (uint32_t)nsl; p += WIDE_NT) bmC[p] = bmA[p];
@@ -5762,23 +5836,43 @@ __global__ void __launch_bounds__(WIDE_NT) k_solve_wide(DevParams D, int B, cons
                     if (fits) copy_stream(); else full_stream();
                 }
             }
+            if (upIn && !upOn) for (uint32_t p = (uint32_t)ltid; p < nl; p += WIDE_NT) xl[p] = xv[p];   // (left the half copy in this very pass)
+            double fxScale = 1.0;
+            if (upOn) {                                         // x over my block's columns, all of it; the pass's fixed-point scale
+                const int c0 = jb * Wc;
+                for (int p = ltid; p < Wc; p += WIDE_NT) xl[p] = (c0 + p < L) ? xv[c0 + p] : 0.0;
+                // a term v x 2^s (0 <= v <= 1) below 2^tb, a column's sum of fewer than L terms below 2^62
+                int e_ = 0;
+                if (xmax > 0.0 && xmax < 1.0e300) (void)frexp(xmax, &e_);
+                const int tb = min(49, 62 - (32 - __clz((unsigned)max(L - 1, 1))));
+                fxScale = ldexp(1.0, tb - e_); fxInv = ldexp(1.0, e_ - tb);
+            }
             __syncthreads();
-#ifdef ROMAN_SOLVE_TIMING
-            wcnt[7] += (mp1 <= (uint32_t)xcap) ? 1 : 0;
-#endif
             for (int j = 0; j < WIDE_MAXCH; ++j) {
                 int s = uni_i(sh.sS[w][j]);
                 if (s >= 0) {
-                    const uint32_t c = (uint32_t)gwc + (uint32_t)j * (uint32_t)NWG;
+                    const uint32_t c = (uint32_t)cgw + (uint32_t)j * (uint32_t)cNWG;
                     uint32_t t = c * CS;
                     const uint32_t tEnd = min(T, t + CS);
                     uint32_t sEnd = CUMW(s + 1);
                     while (t < tEnd) {
                         const uint32_t stop = min(sEnd, tEnd);
-                        piece(xv, nl, MEMW(s) + (t - CUMW(s)), stop - t, c + (uint32_t)s);
+                        if (upOn) piece_up(xv, s, sh.upSB[jb] + t, stop - t, sh.upPB[jb] + c + (uint32_t)s, fxScale);
+                        else piece(xv, nl, MEMW(s) + (t - CUMW(s)), stop - t, c + (uint32_t)s);
                         t = stop;
                         if (t < tEnd) { do { ++s; sEnd = CUMW(s + 1); } while (sEnd <= t); }
                     }
+                }
+            }
+            if (upOn) {                                         // my block's pushed sums -> yPart (write-through), accumulators clean for the next pass
+                __syncthreads();
+                unsigned long long* ys = yPart + ((size_t)wb.team * (size_t)ySlots + (size_t)wb.tRank) * 2 * (size_t)ycap;
+                unsigned long long* aM = reinterpret_cast<unsigned long long*>(xl + Wc);
+                const int nv = min(Wc, L - jb * Wc);
+                for (int p = ltid; p < nv; p += WIDE_NT) {
+                    __hip_atomic_store(ys + p, aM[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(ys + ycap + p, aM[Wc + p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    aM[p] = 0ull; aM[Wc + p] = 0ull;
                 }
             }
             ++n_pass;
@@ -5786,28 +5880,73 @@ __global__ void __launch_bounds__(WIDE_NT) k_solve_wide(DevParams D, int B, cons
         };
         // (M x, C x) of the owned rows: the pieces of their slice in ascending order
         auto collect = [&](double (&om)[WIDE_KW], double (&oc)[WIDE_KW]) {
-            FORK(k) {
-                double m_ = 0.0, c_ = 0.0;
-                const dbl2_t* pp = reinterpret_cast<const dbl2_t*>(part) + (size_t)pcf[k] * 64 + lane;
-                for (uint32_t q0 = 0; q0 < pcn[k]; q0 += 8) {     // 8 pieces in flight, added in ascending order
-                    dbl2_t x_[8];
+            static_assert(WIDE_KW == 2, "the two owned slices of a wave are collected together");
+            // the pieces of BOTH owned slices are loaded together (four of each in flight) and added per slice in ascending order:
+            // half as many dependent round trips to the L2 as one slice after the other
+            double m_[2] = {0.0, 0.0}, c_[2] = {0.0, 0.0};
+            auto add_pieces2 = [&](uint32_t f0, uint32_t n0, uint32_t f1, uint32_t n1) {
+                const dbl2_t* p0 = reinterpret_cast<const dbl2_t*>(part) + (size_t)f0 * 64 + lane;
+                const dbl2_t* p1 = reinterpret_cast<const dbl2_t*>(part) + (size_t)f1 * 64 + lane;
+                const uint32_t nm = max(n0, n1);
+                for (uint32_t q0 = 0; q0 < nm; q0 += 4) {
+                    dbl2_t x0[4], x1[4];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) x_[e] = pp[(size_t)min(q0 + (uint32_t)e, pcn[k] - 1u) * 64];
+                    for (int e = 0; e < 4; ++e) {
+                        x0[e] = p0[(size_t)((q0 + (uint32_t)e < n0) ? q0 + (uint32_t)e : 0u) * 64];
+                        x1[e] = p1[(size_t)((q0 + (uint32_t)e < n1) ? q0 + (uint32_t)e : 0u) * 64];
+                    }
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) if (q0 + (uint32_t)e < pcn[k]) { m_ += x_[e].x; c_ += x_[e].y; }
+                    for (int e = 0; e < 4; ++e) if (q0 + (uint32_t)e < n0) { m_[0] += x0[e].x; c_[0] += x0[e].y; }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (q0 + (uint32_t)e < n1) { m_[1] += x1[e].x; c_[1] += x1[e].y; }
                 }
-                om[k] = in[k] ? m_ : 0.0; oc[k] = in[k] ? c_ : 0.0;
-            }
+            };
+            if (upOn) {                                         // pulled pieces of every block's stream, then the pushed sums of the slices' own columns' block
+                // (a slice lies in ONE column block: Wc is a multiple of 64; the pushed sums are loaded first and fly while the pieces are added)
+                const unsigned long long* ys[2]; int ng[2];
+                unsigned long long a_[2][4], b_[2][4];
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int pos = ((gw + k * NWG) << 6) + lane;
+                    int jr = 0;
+#pragma unroll
+                    for (int z = 1; z < WIDE_MAXBLK; ++z) jr += (z < nblk && pos >= z * Wc) ? 1 : 0;
+                    const bool on_ = k < kw && in[k];
+                    ys[k] = yPart + ((size_t)wb.team * (size_t)ySlots + (size_t)sh.upCU[on_ ? jr : 0]) * 2 * (size_t)ycap + (on_ ? pos - jr * Wc : 0);
+                    ng[k] = on_ ? sh.upG[jr] : 0;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { const size_t o_ = (size_t)(e < ng[k] ? e : 0) * 2 * (size_t)ycap; a_[k][e] = ys[k][o_]; b_[k][e] = ys[k][o_ + ycap]; }
+                }
+                for (int j_ = 0; j_ < nblk; ++j_)
+                    add_pieces2((uint32_t)uni_i((int)sh.upPc[w][0][j_][0]), (uint32_t)uni_i((int)sh.upPc[w][0][j_][1]),
+                                (uint32_t)uni_i((int)sh.upPc[w][1][j_][0]), (uint32_t)uni_i((int)sh.upPc[w][1][j_][1]));
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    unsigned long long sm = 0ull, sc = 0ull;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (e < ng[k]) { sm += a_[k][e]; sc += b_[k][e]; }
+                    for (int g0 = 4; g0 < ng[k]; g0 += 4) {
+                        unsigned long long a2[4], b2[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { const size_t o_ = (size_t)min(g0 + e, ng[k] - 1) * 2 * (size_t)ycap; a2[e] = ys[k][o_]; b2[e] = ys[k][o_ + ycap]; }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) if (g0 + e < ng[k]) { sm += a2[e]; sc += b2[e]; }
+                    }
+                    if (ng[k] > 0) { m_[k] += fx_decode(sm, fxInv); c_[k] += fx_decode(sc, fxInv); }
+                }
+            } else add_pieces2(pcf[0], pcn[0], pcf[1], pcn[1]);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) { om[k] = (k < kw && in[k]) ? m_[k] : 0.0; oc[k] = (k < kw && in[k]) ? c_[k] : 0.0; }
         };
         // trial vector max(base + alpha grad(base), 0) of the owned elements, with the partials of sum t^2 and sum t
         auto trial = [&](const double (&ub)[WIDE_KW], const double (&mb)[WIDE_KW], const double (&cb)[WIDE_KW], double us, double alpha,
-                         double (&out)[WIDE_KW], double& ss, double& s1, double& mp) {
+                         double (&out)[WIDE_KW], double& ss, double& s1, double& mp, double& mx /* largest element: the scale of a pull + push pass */) {
             FORK(k) {
                 const double up = ub[k];
                 const double g = (((sd[k] + d) * up - d * us) + mb[k]) + cb[k] * d;
                 double t = up + alpha * g;
                 t = (in[k] && t > 0.0) ? t : 0.0;
-                out[k] = t; ss += t * t; s1 += t;
+                out[k] = t; ss += t * t; s1 += t; mx = fmax(mx, t);
                 if (t > 0.0) mp = fmax(mp, (double)(((gw + k * NWG) << 6) + lane + 1));
             }
         };
@@ -5827,6 +5966,171 @@ __global__ void __launch_bounds__(WIDE_NT) k_solve_wide(DevParams D, int B, cons
         // multiplied TOGETHER with the sums of both vectors that can come next — the backtracked trial from the same base
         // (published to xva) and the first trial from the accepted vector (xvb): whichever the objective selects is
         // already out when the barrier opens.  (The host sends problems with maxiniters < 1 or maxlsiters < 1 to k_solve.)
+        // The HALF copy (round 6; `upOn`, cmode 2).  While the iterate's support is wide no column-compacted copy pays (the columns of the
+        // early plateau hold three quarters of the entries), but every pair is stored twice.  At the start of a problem the team writes,
+        // into the mirror pools, ONE of the two stored copies of every pair (up_keeps: a checkerboard rule — every row keeps about half of
+        // its entries) — cut into COLUMN BLOCKS of at most ycap columns, a flat quad stream per block (a slice's rows' entries of block
+        // 0, padded to the slice's width there, then the next slice; then block 1 ...), labels relative to the block — and deals the
+        // team's workgroups to the blocks in proportion to their steps.  A workgroup keeps ALL of x over its block's columns in LDS
+        // next to two fixed-point accumulators per column: its waves pull into the rows' partials as before and push into the
+        // accumulators (piece_up); after the stream the accumulators go to yPart, and the owner of a row adds its pulled pieces
+        // (every block) and the pushed sums of the workgroups of its own column's block.  10 bytes per stored pair and pass instead
+        // of 20 — before padding: a (slice, block) cell is as wide as its longest row, 1.43 x the entries with two blocks
+        // (L = 10 000), 1.5 x with seven (L = 40 000) —, + 32 bytes per column and workgroup of the block.  The first column compaction
+        // takes the mirror pools (and every pass thereafter the old path).  Measured: the stream of a pass is
+        // bandwidth-bound at the same 4.1-4.3 TB/s either way, 72 against ~100 us per early pass of a 16-unit team.
+        auto build_upper = [&]() -> bool {
+            if constexpr (W16) {
+            if (!(ucfg & 1) || L < 1024 || Tfull < 16u * (uint32_t)NWG || G > ySlots || G < 2) return true;
+            const int WcMax = min(ycap, (int)((uint32_t)xcap / 3u) & ~63);
+            if (WcMax < 64) return true;
+            nblk = (L + WcMax - 1) / WcMax;
+            if (nblk > WIDE_MAXBLK || nblk > G) { nblk = 1; return true; }
+            Wc = (((L + nblk - 1) / nblk) + 63) & ~63;          // (<= WcMax: a multiple of 64 that is at least L / nblk)
+            const int nsl1 = nsl + 1;
+            uint32_t* upw = upMeta + (size_t)wb.team * WIDE_MAXBLK * (size_t)bmWords;     // [block][nsl1] (nsl1 <= bmWords)
+            // which of the two stored copies of a pair the half copy keeps: (p, q) with p < q when p + q is odd, with p > q when it is even —
+            // every row keeps about half of its entries whatever the positions of its neighbours (by position order alone the rows of a
+            // slice keep very different shares, and a slice is as wide as its longest row: 0.92 of the full stream instead of 0.5)
+            auto up_keeps = [](uint32_t rp_, uint32_t ci_) -> bool { return ((rp_ + ci_) & 1u) ? (rp_ < ci_) : (rp_ > ci_); };
+            auto blk_of = [&](uint32_t ci) -> int { int j_ = 0; _Pragma("unroll") for (int z = 1; z < WIDE_MAXBLK; ++z) j_ += (z < nblk && ci >= (uint32_t)(z * Wc)) ? 1 : 0; return j_; };
+            // (1) widths: a wave per slice counts, per lane, the entries the copy keeps per block
+            for (int s_ = cgw; s_ < nsl; s_ += NWG) {
+                const uint32_t ms = MEMW(s_), nst = CUMW(s_ + 1) - CUMW(s_);
+                const unsigned long long* cp = reinterpret_cast<const unsigned long long*>(cols) + (size_t)ms * 64 + lane;
+                const uint32_t rp = ((uint32_t)s_ << 6) + (uint32_t)lane;
+                uint32_t cnt[WIDE_MAXBLK];
+#pragma unroll
+                for (int z = 0; z < WIDE_MAXBLK; ++z) cnt[z] = 0u;
+                unsigned long long cN = nst > 0u ? cp[0] : ~0ull;
+                for (uint32_t g = 0; g < nst; ++g) {
+                    const unsigned long long cC = cN;
+                    if (g + 1u < nst) cN = cp[(size_t)(g + 1u) * 64];
+#pragma unroll
+                    for (int h = 0; h < 4; ++h) {
+                        const uint32_t ci = (uint32_t)(cC >> (16 * h)) & 0xffffu;
+                        if (ci < (uint32_t)L && up_keeps(rp, ci)) {
+                            const int j_ = blk_of(ci);
+#pragma unroll
+                            for (int z = 0; z < WIDE_MAXBLK; ++z) cnt[z] += (z == j_) ? 1u : 0u;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int z = 0; z < WIDE_MAXBLK; ++z) {
+                    uint32_t q_ = (cnt[z] + 3u) >> 2;
+                    for (int off = 32; off > 0; off >>= 1) q_ = max(q_, (uint32_t)__shfl_xor((int)q_, off));
+                    if (lane == 0 && z < nblk) __hip_atomic_store(upw + (size_t)z * nsl1 + s_, q_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            if (!wide_sync<false>(sh, wb, ltid)) return false;
+            // (2) every workgroup: cumulative widths per block (LDS, in the region of the gathered vector: no stream yet), the deal
+            uint32_t* lw = reinterpret_cast<uint32_t*>(xl);     // [block][nsl1]
+            if (w < nblk) {
+                uint32_t run = 0u;
+                for (int p0 = 0; p0 < nsl; p0 += WAVE) {
+                    const uint32_t wv = (p0 + lane < nsl) ? __hip_atomic_load(upw + (size_t)w * nsl1 + p0 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+                    const uint32_t inc = wave_incl_scan(wv);
+                    if (p0 + lane < nsl) lw[w * nsl1 + p0 + lane] = run + inc - wv;
+                    run += (uint32_t)__shfl((int)inc, 63);
+                }
+                if (lane == 0) lw[w * nsl1 + nsl] = run;
+            }
+            __syncthreads();
+            if (ltid == 0) {
+                unsigned long long Ttot = 0ull; int ne = 0;
+                for (int j_ = 0; j_ < nblk; ++j_) { const uint32_t t_ = lw[j_ * nsl1 + nsl]; Ttot += t_; ne += t_ ? 1 : 0; }
+                bool ok = Ttot > 0ull && Ttot <= (unsigned long long)Tfull && ne <= G;
+                // (the pushed sums a pass writes and reads, 32 bytes per column and workgroup, against the 2560 bytes of a step it saves)
+                ok = ok && (unsigned long long)G * (unsigned long long)Wc * 32ull * 2ull <= Ttot * 2560ull;
+                int rem = G, cu = 0; unsigned long long remT = Ttot; uint32_t pb = 0u, sb = 0u;
+                for (int j_ = 0; j_ < WIDE_MAXBLK; ++j_) {
+                    const uint32_t t_ = j_ < nblk ? lw[j_ * nsl1 + nsl] : 0u;
+                    sh.upT[j_] = t_; sh.upSB[j_] = sb; sb += t_; sh.upCU[j_] = cu; sh.upPB[j_] = pb; sh.upCS[j_] = 1u; sh.upG[j_] = 0;
+                    if (!ok || t_ == 0u) continue;
+                    --ne;
+                    int g_ = (int)(((unsigned long long)rem * t_ + remT / 2ull) / remT);
+                    g_ = max(1, min(g_, rem - ne));
+                    sh.upG[j_] = g_; cu += g_; rem -= g_; remT -= t_;
+                    const uint32_t cs_ = chunk_steps(t_, (uint32_t)g_ * WIDE_NW);
+                    sh.upCS[j_] = cs_; pb += (t_ + cs_ - 1u) / cs_ + (uint32_t)nsl;
+                }
+                if (((int64_t)pb + 4) * 128 > (int64_t)partStride) ok = false;
+                sh.sint[0] = ok ? 1 : 0; sh.sint[1] = (int)min(Ttot, 0x7fffffffull);
+            }
+            __syncthreads();
+            const bool ok = sh.sint[0] != 0;
+            upSteps = (uint32_t)sh.sint[1];
+            __syncthreads();
+            if (!ok) { nblk = 1; return true; }                 // (the same verdict in every workgroup of the team: the same words)
+#pragma unroll
+            for (int z = 0; z < WIDE_MAXBLK; ++z) if (sh.upG[z] > 0 && wb.tRank >= sh.upCU[z] && wb.tRank < sh.upCU[z] + sh.upG[z]) jb = z;
+            GU = sh.upG[jb]; rkU = wb.tRank - sh.upCU[jb];
+            if (lane < WIDE_KW * WIDE_MAXBLK) {                 // piece ranges of my owned slices in every block's stream
+                const int k = lane / WIDE_MAXBLK, j_ = lane % WIDE_MAXBLK, s_ = gw + k * NWG;
+                uint32_t f_ = 0u, n_ = 0u;
+                if (k < kw && s_ < nsl && j_ < nblk && sh.upG[j_] > 0) {
+                    const uint32_t a0 = lw[j_ * nsl1 + s_], e0 = lw[j_ * nsl1 + s_ + 1], cs_ = sh.upCS[j_];
+                    if (e0 > a0) { f_ = sh.upPB[j_] + a0 / cs_ + (uint32_t)s_; n_ = (e0 - 1u) / cs_ - a0 / cs_ + 1u; }
+                }
+                sh.upPc[w][k][j_][0] = f_; sh.upPc[w][k][j_][1] = n_;
+            }
+            // (3) the copy: every lane packs the entries of its row that the copy keeps block by block, pads to the slice's widths
+            for (int s_ = cgw; s_ < nsl; s_ += NWG) {
+                const uint32_t ms = MEMW(s_), nst = CUMW(s_ + 1) - CUMW(s_);
+                const unsigned long long* cp = reinterpret_cast<const unsigned long long*>(cols) + (size_t)ms * 64 + lane;
+                const dbl2_t* vp = reinterpret_cast<const dbl2_t*>(vals) + (size_t)ms * 128 + lane;
+                uint16_t* cq = reinterpret_cast<uint16_t*>(colsK); double* vq = valsK;
+                const uint32_t rp = ((uint32_t)s_ << 6) + (uint32_t)lane;
+                uint32_t cur[WIDE_MAXBLK];
+#pragma unroll
+                for (int z = 0; z < WIDE_MAXBLK; ++z) cur[z] = 0u;
+                // (the rows of a slice list their columns in the same ascending order: lane l starts l / 64 of the way into its cell, cyclically,
+                //  so that the lanes of a wave do not push to the same few accumulators in the same instruction)
+                auto put = [&](int j_, uint32_t e0_, uint32_t label, double v_) {
+                    const uint32_t a0_ = lw[j_ * nsl1 + s_], we_ = (lw[j_ * nsl1 + s_ + 1] - a0_) << 2;
+                    uint32_t e_ = e0_ + (we_ * (uint32_t)lane >> 6);
+                    e_ -= e_ >= we_ ? we_ : 0u;
+                    const size_t step = (size_t)sh.upSB[j_] + a0_ + (e_ >> 2);
+                    const uint32_t h = e_ & 3u;
+                    cq[(step * 64 + lane) * 4 + h] = (uint16_t)label;
+                    vq[(step * 128 + (size_t)(h >> 1) * 64 + lane) * 2 + (h & 1u)] = v_;
+                };
+                unsigned long long cN = ~0ull; dbl2_t v0N = dbl2_t{0.0, 0.0}, v1N = dbl2_t{0.0, 0.0};
+                if (nst > 0u) { cN = cp[0]; v0N = vp[0]; v1N = vp[64]; }
+                for (uint32_t g = 0; g < nst; ++g) {
+                    const unsigned long long cC = cN; const dbl2_t v0 = v0N, v1 = v1N;
+                    if (g + 1u < nst) { cN = cp[(size_t)(g + 1u) * 64]; v0N = vp[(size_t)(2u * g + 2u) * 64]; v1N = vp[(size_t)(2u * g + 3u) * 64]; }
+                    const double v4[4] = {v0.x, v0.y, v1.x, v1.y};
+#pragma unroll
+                    for (int h = 0; h < 4; ++h) {
+                        const uint32_t ci = (uint32_t)(cC >> (16 * h)) & 0xffffu;
+                        if (ci < (uint32_t)L && up_keeps(rp, ci)) {
+                            const int j_ = blk_of(ci);
+                            uint32_t e_ = 0u;
+#pragma unroll
+                            for (int z = 0; z < WIDE_MAXBLK; ++z) if (z == j_) { e_ = cur[z]; cur[z] += 1u; }
+                            put(j_, e_, ci - (uint32_t)(j_ * Wc), v4[h]);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int z = 0; z < WIDE_MAXBLK; ++z) if (z < nblk) {
+                    const uint32_t we = (lw[z * nsl1 + s_ + 1] - lw[z * nsl1 + s_]) << 2;
+                    for (uint32_t e_ = cur[z]; e_ < we; ++e_) put(z, e_, 0xffffu, 0.0);
+                }
+            }
+            __syncthreads();                                    // (every wave is done with the full matrix's widths in cw and with lw)
+            for (int p = ltid; p <= nsl; p += WIDE_NT) cw[p] = lw[jb * nsl1 + p];
+            __syncthreads();
+            for (int p = ltid; p < 2 * Wc; p += WIDE_NT) reinterpret_cast<unsigned long long*>(xl + Wc)[p] = 0ull;
+            if (!wide_sync<true>(sh, wb, ltid)) return false;   // the copy is complete (plain stores: release)
+            T = sh.upT[jb]; cmode = 2; cNWG = GU * WIDE_NW; cgw = w * GU + rkU;
+            geometry();
+            upOn = true;
+            }
+            return true;
+        };
         enum { PH_RESCALE, PH_INIT, PH_TRIAL };
         if (L > 0) {
             double r4[4] = {0.0, 0.0, 0.0, 0.0};
@@ -5834,21 +6138,31 @@ __global__ void __launch_bounds__(WIDE_NT) k_solve_wide(DevParams D, int B, cons
             int j = 0, k2 = 0;
             const double* xcur = xva; const unsigned long long* bmcur = bma;
             uint32_t mpcur = (uint32_t)L;                       // support bound of the vector in xcur
+            double mxcur = 0.0;                                 // ... and its largest element
             auto normalise = [&]() -> bool {                    // u /= |u|, usum = sum u
-                double r2[2] = {0.0, 0.0};
-                FORK(k) { r2[0] += u[k] * u[k]; r2[1] += u[k]; }
-                if (!wide_reduce<2>(r2, sh, slots, wb, ltid)) return false;
+                double r2[3] = {0.0, 0.0, 0.0};
+                FORK(k) { r2[0] += u[k] * u[k]; r2[1] += u[k]; r2[2] = fmax(r2[2], u[k]); }
+                if (!wide_reduce<3, 1>(r2, sh, slots, wb, ltid)) return false;
                 const double nr_ = sqrt(r2[0]);
                 if (nr_ > 0.0) FORK(k) u[k] /= nr_;
                 usum = (nr_ > 0.0) ? r2[1] / nr_ : r2[1];
+                mxcur = (nr_ > 0.0) ? (r2[2] / nr_) * 1.0000001 : r2[2];    // (a bound: the division rounds)
                 return true;
             };
             int phase = P.rescale_u0 ? PH_RESCALE : PH_INIT;
-            if (phase == PH_INIT) alive = normalise();
-            if (alive) { publish(xva, bma, u); alive = wide_reduce<0>(dummy1, sh, slots, wb, ltid); }
+            alive = build_upper();
+            if (alive && phase == PH_INIT) alive = normalise();
+            if (alive) {                                        // the first vector out; the barrier carries its largest element
+                publish(xva, bma, u);
+                double m1[2] = {0.0, 0.0};
+                FORK(k) { m1[0] = fmax(m1[0], u[k]); m1[1] = fmax(m1[1], -u[k]); }
+                alive = wide_reduce<2, 2>(m1, sh, slots, wb, ltid);
+                mxcur = m1[0];
+                if (alive && upOn && m1[1] > 0.0) { upOn = false; full_stream(); }   // (a caller's start vector with negative elements: the pushed sums are unsigned)
+            }
             while (alive) {
-                if (!(alive = stream(xcur, bmcur, mpcur))) break;
-                WMARK(2);
+                if (!(alive = stream(xcur, bmcur, mpcur, mxcur))) break;
+                WMARK(upOn ? 7 : 2);                            // (timing build: the pull + push passes apart)
                 if (!(alive = wide_reduce<0>(dummy1, sh, slots, wb, ltid))) break;
                 WMARK(3);
                 collect(Mn, Cn);
@@ -5857,6 +6171,7 @@ __global__ void __launch_bounds__(WIDE_NT) k_solve_wide(DevParams D, int B, cons
                     if (!(alive = normalise())) break;
                     publish(xva, bma, u);
                     if (!(alive = wide_reduce<0>(dummy1, sh, slots, wb, ltid))) break;
+                    mpcur = (uint32_t)L;
                     phase = PH_INIT;
                     continue;
                 }
@@ -5871,7 +6186,7 @@ __global__ void __launch_bounds__(WIDE_NT) k_solve_wide(DevParams D, int B, cons
                 } else {                                        // PH_TRIAL: products of the trial vector
                     ++ls_trials;
                     const double unsum = (nr > 0.0) ? s1cur / nr : s1cur;
-                    double r6[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};   // objective, |du|^2, sums of the two candidates, their support bounds
+                    double r6[10] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};   // objective, |du|^2, sums of the two candidates, their support bounds, their largest elements
                     FORK(k) {
                         if (nr > 0.0) { tt[k] /= nr; Mn[k] /= nr; Cn[k] /= nr; }
                         const double up = tt[k];
@@ -5880,16 +6195,16 @@ __global__ void __launch_bounds__(WIDE_NT) k_solve_wide(DevParams D, int B, cons
                         const double df = up - u[k]; r6[1] += df * df;
                     }
                     const bool can_back = k2 + 1 < P.maxlsiters, can_next = j + 1 < P.maxiniters;
-                    if (can_back) { trial(u, Mu, Cu, usum, alpha * P.beta, tb, r6[2], r6[3], r6[6]); publish(xva, bma, tb); }
-                    if (can_next) { trial(tt, Mn, Cn, unsum, 1.0, ta, r6[4], r6[5], r6[7]); publish(xvb, bmb, ta); }
+                    if (can_back) { trial(u, Mu, Cu, usum, alpha * P.beta, tb, r6[2], r6[3], r6[6], r6[8]); publish(xva, bma, tb); }
+                    if (can_next) { trial(tt, Mn, Cn, unsum, 1.0, ta, r6[4], r6[5], r6[7], r6[9]); publish(xvb, bmb, ta); }
                     WMARK(4);
-                    if (!(alive = (wide_reduce<8, 2>(r6, sh, slots, wb, ltid)))) break;
+                    if (!(alive = (wide_reduce<10, 4>(r6, sh, slots, wb, ltid)))) break;
                     WMARK(5);
                     const double Fnew = r6[0], deltaF = Fnew - F;
                     if (deltaF < -P.eps && can_back) {          // backtrack: the shorter step from the same base is already out
                         alpha *= P.beta; ++k2;
                         FORK(k) tt[k] = tb[k];
-                        nr = sqrt(r6[2]); s1cur = r6[3]; xcur = xva; bmcur = bma; mpcur = (uint32_t)r6[6];
+                        nr = sqrt(r6[2]); s1cur = r6[3]; xcur = xva; bmcur = bma; mpcur = (uint32_t)r6[6]; mxcur = r6[8];
                         continue;
                     }
                     // accept: the trial vector and its products become the current ones
@@ -5900,7 +6215,7 @@ __global__ void __launch_bounds__(WIDE_NT) k_solve_wide(DevParams D, int B, cons
                     if (!(du < P.tol_u || fabs(deltaF) < P.tol_F || !can_next)) {   // the inner loop goes on: its next trial is already out
                         alpha = 1.0; k2 = 0;
                         FORK(k) tt[k] = ta[k];
-                        nr = sqrt(r6[4]); s1cur = r6[5]; xcur = xvb; bmcur = bmb; mpcur = (uint32_t)r6[7];
+                        nr = sqrt(r6[4]); s1cur = r6[5]; xcur = xvb; bmcur = bmb; mpcur = (uint32_t)r6[7]; mxcur = r6[9];
                         continue;
                     }
                     if (!(alive = d_ratio(true, r4))) break;    // end of the inner loop: homotopy update of d
@@ -5912,13 +6227,13 @@ __global__ void __launch_bounds__(WIDE_NT) k_solve_wide(DevParams D, int B, cons
                 if (new_outer) {                                // first trial of an inner loop: nothing to overlap it with
                     F = r4[2] + d * r4[3];                      // u . gradF at the new d
                     alpha = 1.0; j = 0; k2 = 0;
-                    double r2[3] = {0.0, 0.0, 0.0};
-                    trial(u, Mu, Cu, usum, alpha, tt, r2[0], r2[1], r2[2]);
+                    double r2[4] = {0.0, 0.0, 0.0, 0.0};
+                    trial(u, Mu, Cu, usum, alpha, tt, r2[0], r2[1], r2[2], r2[3]);
                     publish(xva, bma, tt);
                     WMARK(0);
-                    if (!(alive = (wide_reduce<3, 1>(r2, sh, slots, wb, ltid)))) break;
+                    if (!(alive = (wide_reduce<4, 2>(r2, sh, slots, wb, ltid)))) break;
                     WMARK(1);
-                    nr = sqrt(r2[0]); s1cur = r2[1]; xcur = xva; bmcur = bma; mpcur = (uint32_t)r2[2];
+                    nr = sqrt(r2[0]); s1cur = r2[1]; xcur = xva; bmcur = bma; mpcur = (uint32_t)r2[2]; mxcur = r2[3];
                     phase = PH_TRIAL;
                 }
             }
@@ -5932,6 +6247,7 @@ __global__ void __launch_bounds__(WIDE_NT) k_solve_wide(DevParams D, int B, cons
         if (wb.tRank == 0 && ltid == 0 && O.dbg) {              // 100 MHz ticks -> the host prints them as "cycles": x 10 ns
             unsigned long long* dg = O.dbg + (size_t)b * 16;
             for (int t = 0; t < 8; ++t) { dg[t] = wacc[t]; dg[8 + t] = wcnt[t]; }
+            dg[8 + 5] = Tfull; dg[8 + 6] = upSteps;            // (steps of the full stream / of the half copy, all blocks)
         }
 #endif
 #undef WMARK

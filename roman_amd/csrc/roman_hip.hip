@@ -77,7 +77,7 @@ struct roman_ctx {
         DevBuf lp, li, lj, ls, ld, lza, lzb;                       // per live association, live order
         DevBuf plp, pli, plj, pls, pld, plza, plzb;                // the same in position order (stream layout)
         DevBuf rowCnt, rowPos, perm, sliceWidth, sliceBase, items, maskPool, prefPool, listPool, listOff;
-        DevBuf vMu, vCu, vMun, vCun, gU, gUn, uOut, nodesOrig, nSel, widePart, wideSlots, wideBar, wideBm, fbList;
+        DevBuf vMu, vCu, vMun, vCun, gU, gUn, uOut, nodesOrig, nSel, widePart, wideSlots, wideBar, wideBm, wideY, wideUp, fbList;
         DevBuf cols16, cols32, vals, colsC, valsC, contSpill, contList;
         long long capMaskWords = 0, capNnz = 0, capList = 0;       // what the sparse pools hold (elements)
         // staging for the host-pointer entry points
@@ -546,7 +546,8 @@ int enqueue_score(roman_ctx* c, const DevParams& Din, const roman_params_t* para
         static const char* wideEnv = getenv("ROMAN_WIDE");      // "0": never, "1": whenever a fallback problem can exist
         const int mayFb = may_fallback(D, hd);
         D.wide = (c->coop_ok && mayFb > 0 && D.p.maxiniters >= 1 && D.p.maxlsiters >= 1 && maxA <= (int64_t)WIDE_KW * c->num_cu * WIDE_NW * 64 &&
-                  (wideEnv ? wideEnv[0] == '1' : mayFb <= std::max(1, c->num_cu / 4))) ? 1 : 0;   // (several: teams of compute units, one problem each)
+                  (wideEnv ? wideEnv[0] == '1' : (mayFb <= std::max(1, c->num_cu / 4) || maxA >= 4608))) ? 1 : 0;   // (several: teams of compute units, one problem each;
+                  // measured, solve stage: 128 x L = 3 600 k_solve 10.7 ms / teams 12.9; 128 x L = 4 900 29 / ~24; 128 x L = 6 400 41.6 / 31.3; 96 x L = 10 000 118 / 63)
         const char* i16Env = getenv("ROMAN_WIDE_IDX16");         // "0": 32-bit labels always (read per call: tests)
         D.idx16 = (D.wide && maxA <= 65534 && !(i16Env && i16Env[0] == '0')) ? 1 : 0;
     }
@@ -1014,8 +1015,16 @@ int enqueue_solve(roman_ctx* c, const DevParams& D, int B, int64_t sumA, int64_t
             // with the whole device per problem (roman_ctx_set_wide_teams(ctx, 0) does the same for a device-pointer caller).
             const int perXcd = std::max(1, (G + c->num_xcc - 1) / c->num_xcc);
             {
-                auto cap = [&](int sub) { return (int64_t)WIDE_KW * std::max(1, perXcd / sub - 2) * WIDE_NW * 64; };   // (a margin of two workgroups against uneven placement)
-                if (mayFallback >= 2 && maxA <= cap(1)) a_teams = (mayFallback > 12 && maxA <= cap(2)) ? 2 : 1;
+                static const char* marginEnv = getenv("ROMAN_WIDE_MARGIN");
+                const int margin = marginEnv ? atoi(marginEnv) : 2;
+                auto cap = [&](int sub) { return (int64_t)WIDE_KW * std::max(1, perXcd / sub - margin) * WIDE_NW * 64; };   // (a margin of two workgroups against uneven placement)
+                // more, smaller teams while there are problems for them and the live sets fit their registers: a pass of a team is a stream the
+                // whole device's bandwidth bounds however it is shared out, plus two barriers and a collect whose latencies only other teams can
+                // hide (64 problems of L = 4 900: 24.7 / 16.9 / 12.4 / 12.1 ms with 1 / 2 / 3 / 4 teams per XCD)
+                if (mayFallback >= 2 && maxA <= cap(1)) {
+                    a_teams = 1;
+                    for (int s_ = 2; s_ <= 4; ++s_) if (mayFallback > 6 * s_ && maxA <= cap(s_)) a_teams = s_;
+                }
                 const char* teamEnv = getenv("ROMAN_WIDE_TEAMS");          // experiments / tests: 0 never, 1 / 2 / 4 teams per XCD whenever the live sets fit (read per call)
                 const int forced = teamEnv ? atoi(teamEnv) : c->wide_teams;
                 if (teamEnv || c->wide_teams >= 0) a_teams = (forced >= 1 && forced <= 4 && mayFallback >= 1 && maxA <= cap(forced)) ? forced : 0;
@@ -1023,7 +1032,10 @@ int enqueue_solve(roman_ctx* c, const DevParams& D, int B, int64_t sumA, int64_t
             if (a_teams) c->teams_launched = true;
             const int nTeams = a_teams ? 8 * a_teams : 1;       // (teams are numbered XCC_ID * teams-per-XCD + sub-team: 8 XCC ids whatever the partition)
             const int NWGt = a_teams ? std::min(G, 2 * ((perXcd + a_teams - 1) / a_teams) + 8) * WIDE_NW : G * WIDE_NW;     // waves a team can have at most
-            long long a_partStride = (long long)(((size_t)NWGt * WIDE_MAXCH + (size_t)(maxA + 63) / 64 + 4) * 64 * 2);   // pieces: chunks + slices
+            // Pull + push passes over a half copy of the matrix — every pair stored once — (kernels.hip.h, build_upper): 16-bit labels only; ROMAN_WIDE_UPPER=0 turns them off
+            int a_ucfg = D.idx16 ? 1 : 0;
+            { const char* e_ = getenv("ROMAN_WIDE_UPPER"); if (e_ && e_[0]) a_ucfg = (D.idx16 && e_[0] != '0') ? 1 : 0; }
+            long long a_partStride = (long long)(((size_t)NWGt * WIDE_MAXCH + (size_t)(a_ucfg ? WIDE_MAXBLK : 1) * ((size_t)(maxA + 63) / 64) + 4) * 64 * 2);   // pieces: chunks + slices (per column block of the half copy)
             HIPCHK(c, WS.widePart.ensure(sizeof(double) * (size_t)a_partStride * (size_t)nTeams));
             HIPCHK(c, WS.wideSlots.ensure(sizeof(double) * 2 * (size_t)G * WIDE_NRED * (size_t)nTeams));
             DevParams Dv = D; int Bv = B;
@@ -1051,7 +1063,16 @@ int enqueue_solve(roman_ctx* c, const DevParams& D, int B, int64_t sumA, int64_t
             // ROMAN_WIDE_COMPACT=0 turns it off; =0xWWTTCC sets passes per window / threshold (x/256) / compactions allowed per problem.
             int a_ccfg = 6 | (128 << 8) | (4 << 16);
             { const char* e_ = getenv("ROMAN_WIDE_COMPACT"); if (e_ && e_[0]) a_ccfg = (int)strtol(e_, nullptr, 0); }
-            if (a_ccfg & 0xff) {
+            // the pushed sums of the half copy's column blocks (one slot per workgroup of a team) and its slice widths
+            int a_ySlots = NWGt / WIDE_NW;
+            int a_ycap = a_ucfg ? ((a_xcap / 3) & ~63) : 0;
+            if (a_ucfg && a_ycap < 64) a_ucfg = 0;
+            if (a_ucfg) {
+                HIPCHK(c, WS.wideY.ensure(sizeof(unsigned long long) * 2 * (size_t)a_ycap * (size_t)a_ySlots * (size_t)nTeams));
+                HIPCHK(c, WS.wideUp.ensure(sizeof(uint32_t) * WIDE_MAXBLK * (size_t)a_bmw * (size_t)nTeams));
+            }
+            unsigned long long* a_yPart = WS.wideY.as<unsigned long long>(); uint32_t* a_upMeta = WS.wideUp.as<uint32_t>();
+            if ((a_ccfg & 0xff) || a_ucfg) {
                 HIPCHK(c, WS.valsC.ensure(sizeof(double) * (size_t)WS.capNnz));
                 HIPCHK(c, WS.colsC.ensure((D.idx16 ? sizeof(uint16_t) : sizeof(uint32_t)) * (size_t)WS.capNnz));
             }
@@ -1064,7 +1085,7 @@ int enqueue_solve(roman_ctx* c, const DevParams& D, int B, int64_t sumA, int64_t
             const int32_t* a_fb = WS.fbList.as<int32_t>();
             void* args[] = {&Dv, &Bv, &a_probs, &a_state, &a_feats, &a_assoc, &a_lp, &a_ld, &a_perm, &a_rpos, &a_sb, &a_cols, &a_vals,
                             &a_vU, &a_vX, &a_vX2, &a_s0, &a_s1, &a_s2, &a_plp, &a_u0, &a_O, &a_part, &a_slots, &a_bar, &a_bm, &a_bmw, &a_xcap, &a_tune, &a_ticks,
-                            &a_teams, &a_fb, &a_partStride, &a_colsC, &a_valsC, &a_ccfg};
+                            &a_teams, &a_fb, &a_partStride, &a_colsC, &a_valsC, &a_ccfg, &a_ucfg, &a_yPart, &a_ySlots, &a_ycap, &a_upMeta};
             // Two whole-device kernels must never be resident together (each would hold compute units while waiting at a
             // grid barrier for workgroups the other one keeps out): with batches in flight on several streams, a
             // launch waits for the previous one of this context.
@@ -1382,7 +1403,7 @@ int roman_ctx_destroy(roman_ctx_t* c)
         DevBuf* all[] = {&W.probs, &W.state, &W.totals, &W.queue, &W.cosPool, &W.cosDense, &W.tabPool, &W.qtabPool, &W.sTmp, &W.chunkCnt,
                          &W.lp, &W.li, &W.lj, &W.ls, &W.ld, &W.lza, &W.lzb, &W.plp, &W.pli, &W.plj, &W.pls, &W.pld, &W.plza, &W.plzb,
                          &W.rowCnt, &W.rowPos, &W.perm, &W.sliceWidth, &W.sliceBase, &W.items, &W.maskPool, &W.prefPool, &W.listPool, &W.listOff,
-                         &W.vMu, &W.vCu, &W.vMun, &W.vCun, &W.gU, &W.gUn, &W.uOut, &W.nodesOrig, &W.nSel, &W.widePart, &W.wideSlots, &W.wideBar, &W.wideBm, &W.fbList, &W.cols16, &W.cols32, &W.vals, &W.colsC, &W.valsC, &W.contSpill, &W.contList,
+                         &W.vMu, &W.vCu, &W.vMun, &W.vCun, &W.gU, &W.gUn, &W.uOut, &W.nodesOrig, &W.nSel, &W.widePart, &W.wideSlots, &W.wideBar, &W.wideBm, &W.wideY, &W.wideUp, &W.fbList, &W.cols16, &W.cols32, &W.vals, &W.colsC, &W.valsC, &W.contSpill, &W.contList,
                          &W.hFeats, &W.hAssoc, &W.hU0, &W.oAssoc, &W.oN, &W.oT, &W.oStatus, &W.oStats, &W.hAux1, &W.hAux2, &W.hAux3, &W.oAll};
         for (DevBuf* b : all) b->release();
         if (W.pinnedTotals) (void)hipHostFree(W.pinnedTotals);

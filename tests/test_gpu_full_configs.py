@@ -183,15 +183,20 @@ def test_mixed_batch_large_and_small_live_sets(ctx, orc):
 # ROMAN_WIDE_COMPACT: 0 = k_solve_wide never compacts the matrix's columns; 0x01FF10 = a window of ONE pass, threshold 255/256,
 # 16 compactions per problem: a copy is cut at almost every pass, the next vector's support leaves its columns again and again
 # (the line search re-admits elements) — the way back to the full matrix and the compaction of a copy in place run many times
-_COMPACT_CASES = [(None, None, None), ("2", None, None), ("0", None, None), (None, "0", None), (None, "0x01FF10", None), ("0", "0x01FF10", None),
-                  ("2", "0x02C008", None), (None, "0x01FF10", "0"), (None, None, "0")]
+# ROMAN_WIDE_UPPER: 0 = no pull + push passes over the half copy of the matrix (round 6: every stored pair once, column blocks with
+# fixed-point accumulators in LDS, until the first column compaction takes the mirror pools); with the compaction off the half copy
+# serves EVERY pass of a problem, with one at every pass it serves the first pass only
+_COMPACT_CASES = [(None, None, None, None), ("2", None, None, None), ("0", None, None, None), (None, "0", None, None), (None, "0x01FF10", None, None), ("0", "0x01FF10", None, None),
+                  ("2", "0x02C008", None, None), (None, "0x01FF10", "0", None), (None, None, "0", None),
+                  (None, None, None, "0"), ("2", "0", None, "0"), ("1", "0", None, None), ("1", "0x040010", None, None)]
 _COMPACT_IDS = ["teams_auto", "two_teams_per_xcd", "whole_device", "teams_auto-no_compaction", "teams_auto-compaction_every_pass",
                 "whole_device-compaction_every_pass", "two_teams_per_xcd-eager_compaction", "teams_auto-compaction_every_pass-32bit_labels",
-                "teams_auto-32bit_labels"]
+                "teams_auto-32bit_labels",
+                "teams_auto-no_half_copy", "two_teams_per_xcd-no_compaction-no_half_copy", "one_team_per_xcd-no_compaction", "one_team_per_xcd-late_compaction"]
 
 
-@pytest.mark.parametrize("teams,compact,idx16", _COMPACT_CASES, ids=_COMPACT_IDS)
-def test_batch_of_mid_size_live_sets_matches_the_oracle(ctx, orc, teams, compact, idx16, monkeypatch):
+@pytest.mark.parametrize("teams,compact,idx16,upper", _COMPACT_CASES, ids=_COMPACT_IDS)
+def test_batch_of_mid_size_live_sets_matches_the_oracle(ctx, orc, teams, compact, idx16, upper, monkeypatch):
     """Methods without a semantic gate ('gravity', 'clipper', 'pcavolgrav': [REF roman/params/submap_align_params.py:98-116])
     make every association live: L = n * m, 3600 ... 10 000 at 60-100 objects per submap — beyond the stream layout.  A batch
     of such problems is solved by TEAMS of compute units (the workgroups of an XCD, or of half an XCD, on one problem each,
@@ -203,6 +208,8 @@ def test_batch_of_mid_size_live_sets_matches_the_oracle(ctx, orc, teams, compact
         monkeypatch.setenv("ROMAN_WIDE_COMPACT", compact)
     if idx16 is not None:
         monkeypatch.setenv("ROMAN_WIDE_IDX16", idx16)           # "0": 32-bit column labels (the layout of dense problems with C-flags)
+    if upper is not None:
+        monkeypatch.setenv("ROMAN_WIDE_UPPER", upper)
     reg = registration_for("gravity"); reg.set_context(ctx)
     rng = np.random.default_rng(77)
     sizes = [(int(a), int(b)) for a, b in rng.integers(60, 101, size=(18, 2))] + [(100, 100), (30, 30), (64, 48)]   # (30 x 30, 64 x 48: stream layout)
@@ -215,6 +222,47 @@ def test_batch_of_mid_size_live_sets_matches_the_oracle(ctx, orc, teams, compact
     print(f"mid-size live sets ({teams}, {compact}): {len(batch) - len(bad)}/{len(batch)} identical, iteration counts differ on {traj}")
     assert not bad and worst < POSE_TOL and len(traj) <= 2
     assert res.stats["n_live"].tolist() == [n * m for n, m in sizes]
+
+
+@pytest.mark.parametrize("count,lo,hi", [(28, 62, 76), (70, 56, 66)], ids=["28_problems_four_teams_per_xcd", "70_problems_one_workgroup_each"])
+def test_many_mid_size_live_sets_take_the_solver_the_library_picks(ctx, orc, count, lo, hi):
+    """The library's own choice for a batch of gate-less problems (roman_hip.hip, enqueue_score / the launch of the fallback solvers): more
+    than 24 of them with at most 6 144 live associations go to FOUR teams per XCD (eight compute units per problem: the barrier and
+    collect latencies of a pass overlap across 32 teams); more than a quarter of the compute units' worth of problems below 4 608
+    live associations go to k_solve, one workgroup per problem.  Either way every result equals the oracle's."""
+    reg = registration_for("gravity"); reg.set_context(ctx)
+    rng = np.random.default_rng(count)
+    sizes = [(int(a), int(b)) for a, b in rng.integers(lo, hi + 1, size=(count, 2))]
+    pairs = [synth.make_pair(n, m, 0, 3300 + k, tilt_deg=1.0) for k, (n, m) in enumerate(sizes)]
+    batch = rb.batch_from_pairs(reg, [(p.map1, p.map2) for p in pairs])
+    res = rb.run_batch(reg, batch)
+    problems = [(batch.feats[batch.off1[b]:batch.off1[b] + batch.n1[b]], batch.feats[batch.off2[b]:batch.off2[b] + batch.n2[b]])
+                for b in range(len(batch))]
+    bad, worst, traj = _compare(orc, reg, res, problems)
+    assert not bad and worst < POSE_TOL and len(traj) <= 3, (bad, traj)
+    assert res.stats["n_live"].tolist() == [n * m for n, m in sizes]
+
+
+@pytest.mark.parametrize("upper", [None, "0"], ids=["half_copy", "no_half_copy"])
+def test_mid_size_live_sets_from_random_start_vectors(ctx, orc, upper, monkeypatch):
+    """Explicit start vectors (part of the C ABI) for live sets beyond the stream layout: the first product of the whole-device solver
+    is M u0 of the caller's RAW vector (rescale_u0) — the pull + push pass takes its fixed-point scale from that vector's largest
+    element.  Starts over six decades; results equal the oracle's from the same starts."""
+    if upper is not None:
+        monkeypatch.setenv("ROMAN_WIDE_UPPER", upper)
+    reg = registration_for("gravity"); reg.set_context(ctx)
+    sizes = [(90, 88), (70, 100), (100, 64)]
+    pairs = [synth.make_pair(n, m, 0, 1230 + k, tilt_deg=1.0) for k, (n, m) in enumerate(sizes)]
+    batch = rb.batch_from_pairs(reg, [(p.map1, p.map2) for p in pairs])
+    rng = np.random.default_rng(5)
+    u0s = [rng.uniform(0.05, 1.0, n * m) * 10.0 ** rng.integers(-3, 4) for n, m in sizes]
+    res = rb.run_batch(reg, batch, u0=np.concatenate(u0s))
+    P = reg._abi_params()
+    for b, (n, m) in enumerate(sizes):
+        D1 = batch.feats[batch.off1[b]:batch.off1[b] + batch.n1[b]]; D2 = batch.feats[batch.off2[b]:batch.off2[b] + batch.n2[b]]
+        o = orc.register(P, D1, D2, u0=u0s[b], faithful=False)
+        assert res.status[b] == _abi.ROMAN_ST_OK and np.array_equal(res.assoc[b], o["assoc"]), b
+        assert res.stats["outer_iters"][b] == o["stats"].outer_iters and abs(int(res.stats["n_pass"][b]) - int(o["stats"].n_pass)) <= 2
 
 
 def test_gravity_200x200_all_associations_live(ctx, orc, monkeypatch):

@@ -21,7 +21,8 @@ reg = SubmapAlignParams(method="gravity").get_object_registration(); reg.set_con
 pairs = [synth.make_pair(N, N, 0, 7100 + k, tilt_deg=1.0) for k in range(NP)]
 bt = rb.batch_from_pairs(reg, [(p.map1, p.map2) for p in pairs])
 ref = None
-for teams in (None, "0", "1", "2", "4"):
+for teams in tuple(os.environ.get("MIDLIVE_TEAMS", "None,0,1,2,4").split(",")):
+    teams = None if teams == "None" else teams
     if teams is None:
         os.environ.pop("ROMAN_WIDE_TEAMS", None)
     else:
