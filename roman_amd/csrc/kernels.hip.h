@@ -5407,7 +5407,7 @@ __device__ __forceinline__ bool wide_reduce(double (&v)[N > 0 ? N : 1], WideShar
     return true;
 }
 
-template <typename IdxT>
+template <typename IdxT, bool HALF /* the instantiation that can run pull + push passes over a half copy of the matrix (build_upper; 16-bit labels) */>
 __global__ void __launch_bounds__(WIDE_NT) k_solve_wide(DevParams D, int B, const ProbDesc* __restrict__ probs,
                                                         ProbState* __restrict__ st,
                                                         const double* __restrict__ feats, const int32_t* __restrict__ assoc,
@@ -5609,6 +5609,9 @@ __global__ void __launch_bounds__(WIDE_NT) k_solve_wide(DevParams D, int B, cons
         // one piece [t, stop) of slice s: partial row sums -> partials buffer.  Blocks of WIDE_U quads (three 16-byte loads
         // per lane and quad), the next block's matrix loads in flight while the current block gathers and accumulates.
         constexpr bool W16 = sizeof(IdxT) == 2;                  // 16-bit column words: 8 bytes per lane and quad, no C flag, 0xffff = no column
+        // (the half copy's code costs the whole kernel 20 registers and 240 bytes of scratch per lane — 5 us per pass of EVERY problem,
+        //  more than the copy saves —: an instantiation of its own, taken only under ROMAN_WIDE_UPPER=1)
+        constexpr bool HALF_ON = HALF && W16;
         typedef typename std::conditional<W16, unsigned long long, uint4_t>::type cword_t;
         auto piece = [&](const double* xv, uint32_t nl, uint32_t tm /* first step in memory */, uint32_t n /* steps */, uint32_t pid) {
             double am = 0.0, ac = 0.0;
@@ -5660,7 +5663,7 @@ __global__ void __launch_bounds__(WIDE_NT) k_solve_wide(DevParams D, int B, cons
         // vector's largest element so that a column's sum stays below 2^62 — integer sums: no order, k_solve_up's "exact accumulation").
         // Column labels of the copy are relative to the block's first column; 0xffff (>= Wc) is padding.
         auto piece_up = [&](const double* xv, int s_, uint32_t tm /* first step in the mirror pools */, uint32_t n /* steps */, uint32_t pid, double fxScale) {
-            if constexpr (W16) {
+            if constexpr (HALF_ON) {
             const uint32_t rp = ((uint32_t)s_ << 6) + (uint32_t)lane;
             const double xr = rp < (uint32_t)L ? xv[rp] : 0.0;
             const cword_t* cp = reinterpret_cast<const cword_t*>((const IdxT*)colsK) + (size_t)tm * 64 + lane;
@@ -5838,7 +5841,7 @@ __global__ void __launch_bounds__(WIDE_NT) k_solve_wide(DevParams D, int B, cons
             }
             if (upIn && !upOn) for (uint32_t p = (uint32_t)ltid; p < nl; p += WIDE_NT) xl[p] = xv[p];   // (left the half copy in this very pass)
             double fxScale = 1.0;
-            if (upOn) {                                         // x over my block's columns, all of it; the pass's fixed-point scale
+            if (HALF_ON && upOn) {                              // x over my block's columns, all of it; the pass's fixed-point scale
                 const int c0 = jb * Wc;
                 for (int p = ltid; p < Wc; p += WIDE_NT) xl[p] = (c0 + p < L) ? xv[c0 + p] : 0.0;
                 // a term v x 2^s (0 <= v <= 1) below 2^tb, a column's sum of fewer than L terms below 2^62
@@ -5857,14 +5860,14 @@ __global__ void __launch_bounds__(WIDE_NT) k_solve_wide(DevParams D, int B, cons
                     uint32_t sEnd = CUMW(s + 1);
                     while (t < tEnd) {
                         const uint32_t stop = min(sEnd, tEnd);
-                        if (upOn) piece_up(xv, s, sh.upSB[jb] + t, stop - t, sh.upPB[jb] + c + (uint32_t)s, fxScale);
+                        if (HALF_ON && upOn) piece_up(xv, s, sh.upSB[jb] + t, stop - t, sh.upPB[jb] + c + (uint32_t)s, fxScale);
                         else piece(xv, nl, MEMW(s) + (t - CUMW(s)), stop - t, c + (uint32_t)s);
                         t = stop;
                         if (t < tEnd) { do { ++s; sEnd = CUMW(s + 1); } while (sEnd <= t); }
                     }
                 }
             }
-            if (upOn) {                                         // my block's pushed sums -> yPart (write-through), accumulators clean for the next pass
+            if (HALF_ON && upOn) {                              // my block's pushed sums -> yPart (write-through), accumulators clean for the next pass
                 __syncthreads();
                 unsigned long long* ys = yPart + ((size_t)wb.team * (size_t)ySlots + (size_t)wb.tRank) * 2 * (size_t)ycap;
                 unsigned long long* aM = reinterpret_cast<unsigned long long*>(xl + Wc);
@@ -5901,7 +5904,7 @@ __global__ void __launch_bounds__(WIDE_NT) k_solve_wide(DevParams D, int B, cons
                     for (int e = 0; e < 4; ++e) if (q0 + (uint32_t)e < n1) { m_[1] += x1[e].x; c_[1] += x1[e].y; }
                 }
             };
-            if (upOn) {                                         // pulled pieces of every block's stream, then the pushed sums of the slices' own columns' block
+            if (HALF_ON && upOn) {                              // pulled pieces of every block's stream, then the pushed sums of the slices' own columns' block
                 // (a slice lies in ONE column block: Wc is a multiple of 64; the pushed sums are loaded first and fly while the pieces are added)
                 const unsigned long long* ys[2]; int ng[2];
                 unsigned long long a_[2][4], b_[2][4];
@@ -5933,6 +5936,15 @@ __global__ void __launch_bounds__(WIDE_NT) k_solve_wide(DevParams D, int B, cons
                         for (int e = 0; e < 4; ++e) if (g0 + e < ng[k]) { sm += a2[e]; sc += b2[e]; }
                     }
                     if (ng[k] > 0) { m_[k] += fx_decode(sm, fxInv); c_[k] += fx_decode(sc, fxInv); }
+                }
+            } else if (kw < 2) {                                // one owned slice (the whole device on a problem of fewer slices than waves): eight in flight
+                const dbl2_t* pp = reinterpret_cast<const dbl2_t*>(part) + (size_t)pcf[0] * 64 + lane;
+                for (uint32_t q0 = 0; q0 < pcn[0]; q0 += 8) {
+                    dbl2_t x_[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) x_[e] = pp[(size_t)min(q0 + (uint32_t)e, pcn[0] - 1u) * 64];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) if (q0 + (uint32_t)e < pcn[0]) { m_[0] += x_[e].x; c_[0] += x_[e].y; }
                 }
             } else add_pieces2(pcf[0], pcn[0], pcf[1], pcn[1]);
 #pragma unroll
@@ -5980,7 +5992,7 @@ __global__ void __launch_bounds__(WIDE_NT) k_solve_wide(DevParams D, int B, cons
         // takes the mirror pools (and every pass thereafter the old path).  Measured: the stream of a pass is
         // bandwidth-bound at the same 4.1-4.3 TB/s either way, 72 against ~100 us per early pass of a 16-unit team.
         auto build_upper = [&]() -> bool {
-            if constexpr (W16) {
+            if constexpr (HALF_ON) {
             if (!(ucfg & 1) || L < 1024 || Tfull < 16u * (uint32_t)NWG || G > ySlots || G < 2) return true;
             const int WcMax = min(ycap, (int)((uint32_t)xcap / 3u) & ~63);
             if (WcMax < 64) return true;
@@ -6142,7 +6154,8 @@ __global__ void __launch_bounds__(WIDE_NT) k_solve_wide(DevParams D, int B, cons
             auto normalise = [&]() -> bool {                    // u /= |u|, usum = sum u
                 double r2[3] = {0.0, 0.0, 0.0};
                 FORK(k) { r2[0] += u[k] * u[k]; r2[1] += u[k]; r2[2] = fmax(r2[2], u[k]); }
-                if (!wide_reduce<3, 1>(r2, sh, slots, wb, ltid)) return false;
+                if constexpr (HALF_ON) { if (!wide_reduce<3, 1>(r2, sh, slots, wb, ltid)) return false; }
+                else { double q2[2] = {r2[0], r2[1]}; if (!wide_reduce<2>(q2, sh, slots, wb, ltid)) return false; r2[0] = q2[0]; r2[1] = q2[1]; }
                 const double nr_ = sqrt(r2[0]);
                 if (nr_ > 0.0) FORK(k) u[k] /= nr_;
                 usum = (nr_ > 0.0) ? r2[1] / nr_ : r2[1];
@@ -6150,15 +6163,17 @@ __global__ void __launch_bounds__(WIDE_NT) k_solve_wide(DevParams D, int B, cons
                 return true;
             };
             int phase = P.rescale_u0 ? PH_RESCALE : PH_INIT;
-            alive = build_upper();
+            if constexpr (HALF_ON) alive = build_upper();
             if (alive && phase == PH_INIT) alive = normalise();
             if (alive) {                                        // the first vector out; the barrier carries its largest element
                 publish(xva, bma, u);
-                double m1[2] = {0.0, 0.0};
-                FORK(k) { m1[0] = fmax(m1[0], u[k]); m1[1] = fmax(m1[1], -u[k]); }
-                alive = wide_reduce<2, 2>(m1, sh, slots, wb, ltid);
-                mxcur = m1[0];
-                if (alive && upOn && m1[1] > 0.0) { upOn = false; full_stream(); }   // (a caller's start vector with negative elements: the pushed sums are unsigned)
+                if constexpr (HALF_ON) {
+                    double m1[2] = {0.0, 0.0};
+                    FORK(k) { m1[0] = fmax(m1[0], u[k]); m1[1] = fmax(m1[1], -u[k]); }
+                    alive = wide_reduce<2, 2>(m1, sh, slots, wb, ltid);
+                    mxcur = m1[0];
+                    if (alive && upOn && m1[1] > 0.0) { upOn = false; full_stream(); }   // (a caller's start vector with negative elements: the pushed sums are unsigned)
+                } else alive = wide_reduce<0>(dummy1, sh, slots, wb, ltid);
             }
             while (alive) {
                 if (!(alive = stream(xcur, bmcur, mpcur, mxcur))) break;
@@ -6198,7 +6213,13 @@ __global__ void __launch_bounds__(WIDE_NT) k_solve_wide(DevParams D, int B, cons
                     if (can_back) { trial(u, Mu, Cu, usum, alpha * P.beta, tb, r6[2], r6[3], r6[6], r6[8]); publish(xva, bma, tb); }
                     if (can_next) { trial(tt, Mn, Cn, unsum, 1.0, ta, r6[4], r6[5], r6[7], r6[9]); publish(xvb, bmb, ta); }
                     WMARK(4);
-                    if (!(alive = (wide_reduce<10, 4>(r6, sh, slots, wb, ltid)))) break;
+                    if constexpr (HALF_ON) { if (!(alive = (wide_reduce<10, 4>(r6, sh, slots, wb, ltid)))) break; }
+                    else {                                      // (the largest elements are the half copy's: eight values as before)
+                        double r8[8] = {r6[0], r6[1], r6[2], r6[3], r6[4], r6[5], r6[6], r6[7]};
+                        if (!(alive = (wide_reduce<8, 2>(r8, sh, slots, wb, ltid)))) break;
+#pragma unroll
+                        for (int z = 0; z < 8; ++z) r6[z] = r8[z];
+                    }
                     WMARK(5);
                     const double Fnew = r6[0], deltaF = Fnew - F;
                     if (deltaF < -P.eps && can_back) {          // backtrack: the shorter step from the same base is already out
@@ -6231,7 +6252,12 @@ __global__ void __launch_bounds__(WIDE_NT) k_solve_wide(DevParams D, int B, cons
                     trial(u, Mu, Cu, usum, alpha, tt, r2[0], r2[1], r2[2], r2[3]);
                     publish(xva, bma, tt);
                     WMARK(0);
-                    if (!(alive = (wide_reduce<4, 2>(r2, sh, slots, wb, ltid)))) break;
+                    if constexpr (HALF_ON) { if (!(alive = (wide_reduce<4, 2>(r2, sh, slots, wb, ltid)))) break; }
+                    else {
+                        double r3[3] = {r2[0], r2[1], r2[2]};
+                        if (!(alive = (wide_reduce<3, 1>(r3, sh, slots, wb, ltid)))) break;
+                        r2[0] = r3[0]; r2[1] = r3[1]; r2[2] = r3[2];
+                    }
                     WMARK(1);
                     nr = sqrt(r2[0]); s1cur = r2[1]; xcur = xva; bmcur = bma; mpcur = (uint32_t)r2[2]; mxcur = r2[3];
                     phase = PH_TRIAL;

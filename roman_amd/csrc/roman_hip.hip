@@ -1033,7 +1033,8 @@ int enqueue_solve(roman_ctx* c, const DevParams& D, int B, int64_t sumA, int64_t
             const int nTeams = a_teams ? 8 * a_teams : 1;       // (teams are numbered XCC_ID * teams-per-XCD + sub-team: 8 XCC ids whatever the partition)
             const int NWGt = a_teams ? std::min(G, 2 * ((perXcd + a_teams - 1) / a_teams) + 8) * WIDE_NW : G * WIDE_NW;     // waves a team can have at most
             // Pull + push passes over a half copy of the matrix — every pair stored once — (kernels.hip.h, build_upper): 16-bit labels only; ROMAN_WIDE_UPPER=0 turns them off
-            int a_ucfg = D.idx16 ? 1 : 0;
+            // (an instantiation of its own, k_solve_wide<uint16_t, true>, OFF by default: built, exact, and slower than the plain kernel — DESIGN.md 6.7)
+            int a_ucfg = 0;
             { const char* e_ = getenv("ROMAN_WIDE_UPPER"); if (e_ && e_[0]) a_ucfg = (D.idx16 && e_[0] != '0') ? 1 : 0; }
             long long a_partStride = (long long)(((size_t)NWGt * WIDE_MAXCH + (size_t)(a_ucfg ? WIDE_MAXBLK : 1) * ((size_t)(maxA + 63) / 64) + 4) * 64 * 2);   // pieces: chunks + slices (per column block of the half copy)
             HIPCHK(c, WS.widePart.ensure(sizeof(double) * (size_t)a_partStride * (size_t)nTeams));
@@ -1077,7 +1078,8 @@ int enqueue_solve(roman_ctx* c, const DevParams& D, int B, int64_t sumA, int64_t
                 HIPCHK(c, WS.colsC.ensure((D.idx16 ? sizeof(uint16_t) : sizeof(uint32_t)) * (size_t)WS.capNnz));
             }
             void* a_colsC = WS.colsC.p; double* a_valsC = WS.valsC.as<double>();
-            const void* wideFn = D.idx16 ? reinterpret_cast<const void*>(k_solve_wide<uint16_t>) : reinterpret_cast<const void*>(k_solve_wide<uint32_t>);
+            const void* wideFn = D.idx16 ? (a_ucfg ? reinterpret_cast<const void*>(k_solve_wide<uint16_t, true>) : reinterpret_cast<const void*>(k_solve_wide<uint16_t, false>))
+                                         : reinterpret_cast<const void*>(k_solve_wide<uint32_t, false>);
             HIPCHK(c, dyn_lds(c, wideFn, wideLds));
             static const char* tuneEnv = getenv("ROMAN_WIDE_TUNE");
             int a_tune = tuneEnv ? (int)strtol(tuneEnv, nullptr, 0) : 0;
@@ -1361,7 +1363,8 @@ int roman_ctx_create(roman_ctx_t** out, int device, void* stream)
         // that one 512-thread workgroup with its largest dynamic LDS fits a compute unit for both instantiations — a
         // cooperative launch of num_cu workgroups then cannot fail for lack of residency after the fill has already run.
         const size_t wideLdsMax = c->lds_max > 4096 ? c->lds_max - 4096 : 0;
-        const void* fns[2] = {reinterpret_cast<const void*>(k_solve_wide<uint16_t>), reinterpret_cast<const void*>(k_solve_wide<uint32_t>)};
+        const void* fns[3] = {reinterpret_cast<const void*>(k_solve_wide<uint16_t, false>), reinterpret_cast<const void*>(k_solve_wide<uint32_t, false>),
+                              reinterpret_cast<const void*>(k_solve_wide<uint16_t, true>)};
         for (const void* fn : fns) {
             int nb = 0;
             if (dyn_lds(c, fn, wideLdsMax) != hipSuccess ||

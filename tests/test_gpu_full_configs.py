@@ -183,16 +183,20 @@ def test_mixed_batch_large_and_small_live_sets(ctx, orc):
 # ROMAN_WIDE_COMPACT: 0 = k_solve_wide never compacts the matrix's columns; 0x01FF10 = a window of ONE pass, threshold 255/256,
 # 16 compactions per problem: a copy is cut at almost every pass, the next vector's support leaves its columns again and again
 # (the line search re-admits elements) — the way back to the full matrix and the compaction of a copy in place run many times
-# ROMAN_WIDE_UPPER: 0 = no pull + push passes over the half copy of the matrix (round 6: every stored pair once, column blocks with
-# fixed-point accumulators in LDS, until the first column compaction takes the mirror pools); with the compaction off the half copy
-# serves EVERY pass of a problem, with one at every pass it serves the first pass only
+# ROMAN_WIDE_UPPER=1: the instantiation of k_solve_wide with pull + push passes over the HALF copy of the matrix (round 6: every stored pair
+# once, column blocks with fixed-point accumulators in LDS, until the first column compaction takes the mirror pools; off by default —
+# measured slower than the plain kernel).  With the compaction off the half copy serves EVERY pass of a problem, with one
+# at every pass it serves the first pass only.
 _COMPACT_CASES = [(None, None, None, None), ("2", None, None, None), ("0", None, None, None), (None, "0", None, None), (None, "0x01FF10", None, None), ("0", "0x01FF10", None, None),
                   ("2", "0x02C008", None, None), (None, "0x01FF10", "0", None), (None, None, "0", None),
-                  (None, None, None, "0"), ("2", "0", None, "0"), ("1", "0", None, None), ("1", "0x040010", None, None)]
+                  (None, None, None, "1"), ("2", None, None, "1"), ("0", None, None, "1"), (None, "0", None, "1"), (None, "0x01FF10", None, "1"),
+                  ("1", "0", None, "1"), ("1", "0x040010", None, "1"), (None, None, "0", "1")]
 _COMPACT_IDS = ["teams_auto", "two_teams_per_xcd", "whole_device", "teams_auto-no_compaction", "teams_auto-compaction_every_pass",
                 "whole_device-compaction_every_pass", "two_teams_per_xcd-eager_compaction", "teams_auto-compaction_every_pass-32bit_labels",
                 "teams_auto-32bit_labels",
-                "teams_auto-no_half_copy", "two_teams_per_xcd-no_compaction-no_half_copy", "one_team_per_xcd-no_compaction", "one_team_per_xcd-late_compaction"]
+                "teams_auto-half_copy", "two_teams_per_xcd-half_copy", "whole_device-half_copy", "teams_auto-no_compaction-half_copy",
+                "teams_auto-compaction_every_pass-half_copy", "one_team_per_xcd-no_compaction-half_copy", "one_team_per_xcd-late_compaction-half_copy",
+                "teams_auto-32bit_labels-half_copy_asked_for"]
 
 
 @pytest.mark.parametrize("teams,compact,idx16,upper", _COMPACT_CASES, ids=_COMPACT_IDS)
@@ -243,7 +247,7 @@ def test_many_mid_size_live_sets_take_the_solver_the_library_picks(ctx, orc, cou
     assert res.stats["n_live"].tolist() == [n * m for n, m in sizes]
 
 
-@pytest.mark.parametrize("upper", [None, "0"], ids=["half_copy", "no_half_copy"])
+@pytest.mark.parametrize("upper", [None, "1"], ids=["plain", "half_copy"])
 def test_mid_size_live_sets_from_random_start_vectors(ctx, orc, upper, monkeypatch):
     """Explicit start vectors (part of the C ABI) for live sets beyond the stream layout: the first product of the whole-device solver
     is M u0 of the caller's RAW vector (rescale_u0) — the pull + push pass takes its fixed-point scale from that vector's largest
@@ -265,12 +269,15 @@ def test_mid_size_live_sets_from_random_start_vectors(ctx, orc, upper, monkeypat
         assert res.stats["outer_iters"][b] == o["stats"].outer_iters and abs(int(res.stats["n_pass"][b]) - int(o["stats"].n_pass)) <= 2
 
 
-def test_gravity_200x200_all_associations_live(ctx, orc, monkeypatch):
+@pytest.mark.parametrize("upper", [None, "1"], ids=["plain", "half_copy"])
+def test_gravity_200x200_all_associations_live(ctx, orc, upper, monkeypatch):
     """method 'gravity' has no semantic gate: at n = m = 200 every one of the 40 000 associations is live — far beyond
     the stream layout (L <= 3072).  The problem takes the symmetric SELL-64 layout and the COOPERATIVE fallback
     solver (all compute units on one problem, grid barriers; k_solve_wide): results and pass counts equal the oracle's —
     with the column compaction the library chooses (three or four copies over the 244 passes) and with one forced at almost
     every pass (copies of copies in place, many returns to the full matrix)."""
+    if upper is not None:
+        monkeypatch.setenv("ROMAN_WIDE_UPPER", upper)           # (seven column blocks, the whole device dealt to them)
     reg = registration_for("gravity"); reg.set_context(ctx)
     pr = synth.make_pair(200, 200, 0, 7001, tilt_deg=1.0)
     res = reg.register_and_align_batch([(pr.map1, pr.map2)])
