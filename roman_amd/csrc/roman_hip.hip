@@ -545,8 +545,12 @@ int enqueue_score(roman_ctx* c, const DevParams& Din, const roman_params_t* para
         // the wide solver when every position fits (10 instead of 12 bytes per entry of the stream it is bound by).
         static const char* wideEnv = getenv("ROMAN_WIDE");      // "0": never, "1": whenever a fallback problem can exist
         const int mayFb = may_fallback(D, hd);
+        // (many fallback problems: the teams take them when their live sets are KNOWN to be large — every association live (no single
+        //  scores to remove any), or this parameter block's history says so; the first call of a gated method, whose live sets are a
+        //  guess, keeps k_solve as its catch-all: no cooperative launch on the headline path)
+        const bool bigLiveSets = !(D.single && !D.keep_all) || c->hist.valid;
         D.wide = (c->coop_ok && mayFb > 0 && D.p.maxiniters >= 1 && D.p.maxlsiters >= 1 && maxA <= (int64_t)WIDE_KW * c->num_cu * WIDE_NW * 64 &&
-                  (wideEnv ? wideEnv[0] == '1' : (mayFb <= std::max(1, c->num_cu / 4) || maxA >= 4608))) ? 1 : 0;   // (several: teams of compute units, one problem each;
+                  (wideEnv ? wideEnv[0] == '1' : (mayFb <= std::max(1, c->num_cu / 4) || (bigLiveSets && SZ.expectMaxL >= 4608)))) ? 1 : 0;   // (several: teams of compute units, one problem each;
                   // measured, solve stage: 128 x L = 3 600 k_solve 10.7 ms / teams 12.9; 128 x L = 4 900 29 / ~24; 128 x L = 6 400 41.6 / 31.3; 96 x L = 10 000 118 / 63)
         const char* i16Env = getenv("ROMAN_WIDE_IDX16");         // "0": 32-bit labels always (read per call: tests)
         D.idx16 = (D.wide && maxA <= 65534 && !(i16Env && i16Env[0] == '0')) ? 1 : 0;
