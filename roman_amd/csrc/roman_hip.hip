@@ -1028,6 +1028,10 @@ int enqueue_solve(roman_ctx* c, const DevParams& D, int B, int64_t sumA, int64_t
                 if (mayFallback >= 2 && maxA <= cap(1)) {
                     a_teams = 1;
                     for (int s_ = 2; s_ <= 4; ++s_) if (mayFallback > 6 * s_ && maxA <= cap(s_)) a_teams = s_;
+                    // three teams per XCD WITHOUT the reserve when that is what the live sets need (L = 10 000 = 100 x 100 objects on teams of
+                    // 10-11 units): a cooperative launch of one workgroup per unit fills every XCD evenly on this part; should a team come out
+                    // smaller after all, its problems keep their ROMAN_ST_INTERNAL records and run again on the whole device (align_chunked)
+                    if (a_teams == 2 && mayFallback > 18 && G == c->num_cu && maxA <= (int64_t)WIDE_KW * (perXcd / 3) * WIDE_NW * 64) a_teams = 3;
                 }
                 const char* teamEnv = getenv("ROMAN_WIDE_TEAMS");          // experiments / tests: 0 never, 1 / 2 / 4 teams per XCD whenever the live sets fit (read per call)
                 const int forced = teamEnv ? atoi(teamEnv) : c->wide_teams;
