@@ -5246,6 +5246,8 @@ struct WideShared {
     uint32_t upT[WIDE_MAXBLK], upCS[WIDE_MAXBLK], upPB[WIDE_MAXBLK], upSB[WIDE_MAXBLK];
     int upG[WIDE_MAXBLK], upCU[WIDE_MAXBLK];
     uint32_t upPc[WIDE_NT / 64][WIDE_KW][WIDE_MAXBLK][2];
+    int upI[4];                          // column blocks, columns per block, my block, steps of the copy (read where needed: not kept in registers)
+    double upFx;                         // 2^-s of the pass on the copy
 };
 
 // write-through store of a value other workgroups will read (global_store ... sc1: no release fence needed later)
@@ -5446,7 +5448,7 @@ __global__ void __launch_bounds__(WIDE_NT) k_solve_wide(DevParams D, int B, cons
     double* xl = reinterpret_cast<double*>(wide_smem + wide_fixed_lds(bmWords));     // the multiplied vector's leading xcap elements (16-byte aligned)
     const roman_params_t& P = D.p;
     const int ltid = threadIdx.x, lane = ltid & 63, w = uni_i(ltid >> 6);
-    if (ltid == 0) sh.abort_ = 0;
+    if (ltid == 0) { sh.abort_ = 0; sh.upI[3] = 0; }
     __syncthreads();
     WideBar wb{bar, 0u, (int)gridDim.x, 0, 1u, 1u, spinTicks, teams, (int)gridDim.x, (int)blockIdx.x, 0};
     // (a problem this launch does not finish keeps the record k_skipped pre-wrote for it: ROMAN_ST_INTERNAL, no associations,
@@ -5504,8 +5506,7 @@ __global__ void __launch_bounds__(WIDE_NT) k_solve_wide(DevParams D, int B, cons
         int cmode = 0 /* stream in use: 0 full, 1 the column-compacted copy, 2 my column block of the half copy (pull + push) */, ncomp = 0, winPass = 0, winOut = 0; bool haveCopy = false;
         int cNWG = NWG, cgw = gwc;                              // the waves the stream in use is dealt to and my id among them (half copy: the workgroups of my column block)
         // the half copy: column blocks, their width, my block, its workgroups / my rank among them, its first column, the fixed-point scale of the pass
-        bool upOn = false; int nblk = 1, Wc = 0, jb = 0, GU = 1, rkU = 0; double fxInv = 1.0;
-        [[maybe_unused]] uint32_t upSteps = 0u;
+        bool upOn = false;                                      // (everything else about the copy lives in sh.up*: read where needed, no registers across the passes)
         uint32_t copyCols = 0u, Tcopy = 0u;                     // compaction state (identical in every workgroup of the team)
         uint32_t pcf[WIDE_KW], pcn[WIDE_KW];
         static_assert(WIDE_MAXCH <= 8, "sS capacity");
@@ -5662,7 +5663,7 @@ __global__ void __launch_bounds__(WIDE_NT) k_solve_wide(DevParams D, int B, cons
         // into the block's accumulators ((M x)_q += v x_p, (C x)_q += x_p: two ds_add_u64 of fixed-point terms rint(. 2^s), s from the
         // vector's largest element so that a column's sum stays below 2^62 — integer sums: no order, k_solve_up's "exact accumulation").
         // Column labels of the copy are relative to the block's first column; 0xffff (>= Wc) is padding.
-        auto piece_up = [&](const double* xv, int s_, uint32_t tm /* first step in the mirror pools */, uint32_t n /* steps */, uint32_t pid, double fxScale) {
+        auto piece_up = [&](const double* xv, int s_, uint32_t tm /* first step in the mirror pools */, uint32_t n /* steps */, uint32_t pid, double fxScale, int Wc) {
             if constexpr (HALF_ON) {
             const uint32_t rp = ((uint32_t)s_ << 6) + (uint32_t)lane;
             const double xr = rp < (uint32_t)L ? xv[rp] : 0.0;
@@ -5841,32 +5842,39 @@ __global__ void __launch_bounds__(WIDE_NT) k_solve_wide(DevParams D, int B, cons
             }
             if (upIn && !upOn) for (uint32_t p = (uint32_t)ltid; p < nl; p += WIDE_NT) xl[p] = xv[p];   // (left the half copy in this very pass)
             double fxScale = 1.0;
+            int Wc = 0, jb = 0; uint32_t upSB_ = 0u, upPB_ = 0u;
             if (HALF_ON && upOn) {                              // x over my block's columns, all of it; the pass's fixed-point scale
+                Wc = uni_i(sh.upI[1]); jb = uni_i(sh.upI[2]); upSB_ = uni((uint32_t)sh.upSB[jb]); upPB_ = uni((uint32_t)sh.upPB[jb]);
                 const int c0 = jb * Wc;
                 for (int p = ltid; p < Wc; p += WIDE_NT) xl[p] = (c0 + p < L) ? xv[c0 + p] : 0.0;
                 // a term v x 2^s (0 <= v <= 1) below 2^tb, a column's sum of fewer than L terms below 2^62
                 int e_ = 0;
                 if (xmax > 0.0 && xmax < 1.0e300) (void)frexp(xmax, &e_);
                 const int tb = min(49, 62 - (32 - __clz((unsigned)max(L - 1, 1))));
-                fxScale = ldexp(1.0, tb - e_); fxInv = ldexp(1.0, e_ - tb);
+                fxScale = ldexp(1.0, tb - e_);
+                if (ltid == 0) sh.upFx = ldexp(1.0, e_ - tb);
             }
             __syncthreads();
-            for (int j = 0; j < WIDE_MAXCH; ++j) {
-                int s = uni_i(sh.sS[w][j]);
-                if (s >= 0) {
-                    const uint32_t c = (uint32_t)cgw + (uint32_t)j * (uint32_t)cNWG;
-                    uint32_t t = c * CS;
-                    const uint32_t tEnd = min(T, t + CS);
-                    uint32_t sEnd = CUMW(s + 1);
-                    while (t < tEnd) {
-                        const uint32_t stop = min(sEnd, tEnd);
-                        if (HALF_ON && upOn) piece_up(xv, s, sh.upSB[jb] + t, stop - t, sh.upPB[jb] + c + (uint32_t)s, fxScale);
-                        else piece(xv, nl, MEMW(s) + (t - CUMW(s)), stop - t, c + (uint32_t)s);
-                        t = stop;
-                        if (t < tEnd) { do { ++s; sEnd = CUMW(s + 1); } while (sEnd <= t); }
+            auto chunks = [&](auto half_) {                     // (two copies of the loop: the allocator sees one kind of piece in each)
+                constexpr bool H_ = decltype(half_)::value;
+                for (int j = 0; j < WIDE_MAXCH; ++j) {
+                    int s = uni_i(sh.sS[w][j]);
+                    if (s >= 0) {
+                        const uint32_t c = (uint32_t)cgw + (uint32_t)j * (uint32_t)cNWG;
+                        uint32_t t = c * CS;
+                        const uint32_t tEnd = min(T, t + CS);
+                        uint32_t sEnd = CUMW(s + 1);
+                        while (t < tEnd) {
+                            const uint32_t stop = min(sEnd, tEnd);
+                            if constexpr (H_) piece_up(xv, s, upSB_ + t, stop - t, upPB_ + c + (uint32_t)s, fxScale, Wc);
+                            else piece(xv, nl, MEMW(s) + (t - CUMW(s)), stop - t, c + (uint32_t)s);
+                            t = stop;
+                            if (t < tEnd) { do { ++s; sEnd = CUMW(s + 1); } while (sEnd <= t); }
+                        }
                     }
                 }
-            }
+            };
+            if (HALF_ON && upOn) chunks(std::true_type{}); else chunks(std::false_type{});
             if (HALF_ON && upOn) {                              // my block's pushed sums -> yPart (write-through), accumulators clean for the next pass
                 __syncthreads();
                 unsigned long long* ys = yPart + ((size_t)wb.team * (size_t)ySlots + (size_t)wb.tRank) * 2 * (size_t)ycap;
@@ -5906,8 +5914,11 @@ __global__ void __launch_bounds__(WIDE_NT) k_solve_wide(DevParams D, int B, cons
             };
             if (HALF_ON && upOn) {                              // pulled pieces of every block's stream, then the pushed sums of the slices' own columns' block
                 // (a slice lies in ONE column block: Wc is a multiple of 64; the pushed sums are loaded first and fly while the pieces are added)
-                const unsigned long long* ys[2]; int ng[2];
-                unsigned long long a_[2][4], b_[2][4];
+                const int nblk = uni_i(sh.upI[0]), Wc = uni_i(sh.upI[1]); const double fxInv = sh.upFx;
+                for (int j_ = 0; j_ < nblk; ++j_)
+                    add_pieces2((uint32_t)uni_i((int)sh.upPc[w][0][j_][0]), (uint32_t)uni_i((int)sh.upPc[w][0][j_][1]),
+                                (uint32_t)uni_i((int)sh.upPc[w][1][j_][0]), (uint32_t)uni_i((int)sh.upPc[w][1][j_][1]));
+                // (a slice lies in ONE column block: Wc is a multiple of 64)
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
                     const int pos = ((gw + k * NWG) << 6) + lane;
@@ -5915,27 +5926,17 @@ __global__ void __launch_bounds__(WIDE_NT) k_solve_wide(DevParams D, int B, cons
 #pragma unroll
                     for (int z = 1; z < WIDE_MAXBLK; ++z) jr += (z < nblk && pos >= z * Wc) ? 1 : 0;
                     const bool on_ = k < kw && in[k];
-                    ys[k] = yPart + ((size_t)wb.team * (size_t)ySlots + (size_t)sh.upCU[on_ ? jr : 0]) * 2 * (size_t)ycap + (on_ ? pos - jr * Wc : 0);
-                    ng[k] = on_ ? sh.upG[jr] : 0;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { const size_t o_ = (size_t)(e < ng[k] ? e : 0) * 2 * (size_t)ycap; a_[k][e] = ys[k][o_]; b_[k][e] = ys[k][o_ + ycap]; }
-                }
-                for (int j_ = 0; j_ < nblk; ++j_)
-                    add_pieces2((uint32_t)uni_i((int)sh.upPc[w][0][j_][0]), (uint32_t)uni_i((int)sh.upPc[w][0][j_][1]),
-                                (uint32_t)uni_i((int)sh.upPc[w][1][j_][0]), (uint32_t)uni_i((int)sh.upPc[w][1][j_][1]));
-#pragma unroll
-                for (int k = 0; k < 2; ++k) {
+                    const unsigned long long* ys = yPart + ((size_t)wb.team * (size_t)ySlots + (size_t)sh.upCU[on_ ? jr : 0]) * 2 * (size_t)ycap + (on_ ? pos - jr * Wc : 0);
+                    const int ng = on_ ? sh.upG[jr] : 0;
                     unsigned long long sm = 0ull, sc = 0ull;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) if (e < ng[k]) { sm += a_[k][e]; sc += b_[k][e]; }
-                    for (int g0 = 4; g0 < ng[k]; g0 += 4) {
+                    for (int g0 = 0; g0 < ng; g0 += 4) {
                         unsigned long long a2[4], b2[4];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) { const size_t o_ = (size_t)min(g0 + e, ng[k] - 1) * 2 * (size_t)ycap; a2[e] = ys[k][o_]; b2[e] = ys[k][o_ + ycap]; }
+                        for (int e = 0; e < 4; ++e) { const size_t o_ = (size_t)min(g0 + e, ng - 1) * 2 * (size_t)ycap; a2[e] = ys[o_]; b2[e] = ys[o_ + ycap]; }
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) if (g0 + e < ng[k]) { sm += a2[e]; sc += b2[e]; }
+                        for (int e = 0; e < 4; ++e) if (g0 + e < ng) { sm += a2[e]; sc += b2[e]; }
                     }
-                    if (ng[k] > 0) { m_[k] += fx_decode(sm, fxInv); c_[k] += fx_decode(sc, fxInv); }
+                    if (ng > 0) { m_[k] += fx_decode(sm, fxInv); c_[k] += fx_decode(sc, fxInv); }
                 }
             } else if (kw < 2) {                                // one owned slice (the whole device on a problem of fewer slices than waves): eight in flight
                 const dbl2_t* pp = reinterpret_cast<const dbl2_t*>(part) + (size_t)pcf[0] * 64 + lane;
@@ -5993,6 +5994,7 @@ __global__ void __launch_bounds__(WIDE_NT) k_solve_wide(DevParams D, int B, cons
         // bandwidth-bound at the same 4.1-4.3 TB/s either way, 72 against ~100 us per early pass of a 16-unit team.
         auto build_upper = [&]() -> bool {
             if constexpr (HALF_ON) {
+            int nblk = 1, Wc = 0, jb = 0, GU = 1, rkU = 0; uint32_t upSteps = 0u;
             if (!(ucfg & 1) || L < 1024 || Tfull < 16u * (uint32_t)NWG || G > ySlots || G < 2) return true;
             const int WcMax = min(ycap, (int)((uint32_t)xcap / 3u) & ~63);
             if (WcMax < 64) return true;
@@ -6137,6 +6139,7 @@ __global__ void __launch_bounds__(WIDE_NT) k_solve_wide(DevParams D, int B, cons
             __syncthreads();
             for (int p = ltid; p < 2 * Wc; p += WIDE_NT) reinterpret_cast<unsigned long long*>(xl + Wc)[p] = 0ull;
             if (!wide_sync<true>(sh, wb, ltid)) return false;   // the copy is complete (plain stores: release)
+            if (ltid == 0) { sh.upI[0] = nblk; sh.upI[1] = Wc; sh.upI[2] = jb; sh.upI[3] = (int)upSteps; }
             T = sh.upT[jb]; cmode = 2; cNWG = GU * WIDE_NW; cgw = w * GU + rkU;
             geometry();
             upOn = true;
@@ -6273,7 +6276,7 @@ __global__ void __launch_bounds__(WIDE_NT) k_solve_wide(DevParams D, int B, cons
         if (wb.tRank == 0 && ltid == 0 && O.dbg) {              // 100 MHz ticks -> the host prints them as "cycles": x 10 ns
             unsigned long long* dg = O.dbg + (size_t)b * 16;
             for (int t = 0; t < 8; ++t) { dg[t] = wacc[t]; dg[8 + t] = wcnt[t]; }
-            dg[8 + 5] = Tfull; dg[8 + 6] = upSteps;            // (steps of the full stream / of the half copy, all blocks)
+            dg[8 + 5] = Tfull; dg[8 + 6] = HALF_ON ? (unsigned long long)sh.upI[3] : 0ull;            // (steps of the full stream / of the half copy, all blocks)
         }
 #endif
 #undef WMARK
