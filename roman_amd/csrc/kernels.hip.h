@@ -2926,7 +2926,33 @@ __global__ void __launch_bounds__(1024) k_probscan(int B, int NG /* fill groups 
 // SELL slot base) is staged in LDS once per work item.  Finally every row's slot column is padded
 // to the slice width with inert entries.
 // ---------------------------------------------------------------------------------------------
-constexpr int FILL_Q = 256;          // ring capacity per wave (>= 64 queued + 64 emitted per bit step)
+constexpr int FILL_E = 1;            // candidates a lane evaluates at a time (2: measured without gain, 212 B of scratch)
+constexpr int FILL_Q = 256;          // ring capacity per wave (>= 64 FILL_E queued + 64 emitted per bit step)
+
+// What k_fill needs of a live association whose problem's column data does not fit the LDS tile (live sets beyond ~2 800 with the gravity
+// prior, ~4 700 without): ONE 48-byte record instead of seven arrays.  An entry (k, q) then costs two record reads + two table reads instead
+// of fifteen scattered 4- and 8-byte reads — the kernel is bound by the L2's gather rate there (280 G requests/s device-wide:
+// tools/ubench/gatomic_rate.hip), 23-25 G entries/s before.
+struct alignas(16) FillPack { int32_t i, j; uint32_t pos, base /* slice base + lane slot */; double s, za, zb, pad; };
+
+__global__ void __launch_bounds__(256) k_fillpack(const ProbDesc* __restrict__ probs, const ProbState* __restrict__ st, int TC /* problems of at most TC live associations stage their columns in LDS */,
+                                                  const int32_t* __restrict__ li, const int32_t* __restrict__ lj, const double* __restrict__ ls,
+                                                  const double* __restrict__ lza, const double* __restrict__ lzb,
+                                                  const uint32_t* __restrict__ rowPos, const uint32_t* __restrict__ sliceBase, FillPack* __restrict__ pack)
+{
+    const int b = blockIdx.y;
+    if (st[b].kind != 1) return;
+    const int L = st[b].L;
+    if (L <= TC) return;
+    const int64_t lo = probs[b].liveOff;
+    for (int q = blockIdx.x * 256 + threadIdx.x; q < L; q += gridDim.x * 256) {
+        const uint32_t pos = rowPos[lo + q];
+        FillPack r;
+        r.i = li[lo + q]; r.j = lj[lo + q]; r.pos = pos; r.base = sliceBase[lo + (pos >> 6)] + (pos & 63u);
+        r.s = ls[lo + q]; r.za = lza ? lza[lo + q] : 0.0; r.zb = lzb ? lzb[lo + q] : 0.0; r.pad = 0.0;
+        pack[lo + q] = r;
+    }
+}
 
 template <bool GRAV, typename IdxT, bool LDSCOL, bool QUAD>
 __device__ __forceinline__ uint32_t fill_item(const DevParams& D, const ProbDesc& pd, int L, int row0, int nrows,
@@ -2935,69 +2961,99 @@ __device__ __forceinline__ uint32_t fill_item(const DevParams& D, const ProbDesc
                                               const double* cZa, const double* cZb, const uint32_t* cBase, const uint32_t* cPos,
                                               const double* __restrict__ TA, const double* __restrict__ TB,
                                               const unsigned long long* __restrict__ mbase, const uint32_t* __restrict__ pbase,
-                                              const uint32_t* __restrict__ rowPos, const uint32_t* __restrict__ sliceBase,
+                                              const uint32_t* __restrict__ perm /* position -> live row: an item is a block of consecutive POSITIONS */,
+                                              const FillPack* __restrict__ pack /* !LDSCOL: the problem's records (k_fillpack) */,
                                               uint32_t* qK, uint32_t* qQ, uint32_t* qE,
                                               IdxT* __restrict__ cols, double* __restrict__ vals)
 {
     const int W = (L + 63) >> 6;
     const int64_t nwords = (int64_t)nrows * W;
-    const unsigned long long* mw = mbase + (int64_t)row0 * W;
-    const uint32_t* pw = pbase + (int64_t)row0 * W;
+    // The item's rows are the rows at positions row0 .. row0 + nrows - 1: what it writes is a few consecutive slices of the matrix (a
+    // 128-byte line of the quad layout holds 16 bytes of each of eight NEIGHBOURING positions — with items of consecutive live rows its
+    // eight parts arrived from eight workgroups at eight different times: eight partial writes per line)
     const unsigned long long lt = (1ull << lane) - 1ull;
     uint32_t head = 0, queued = 0, upper = 0;
 
+    // up to FILL_E x 64 queued candidates at a time, FILL_E per lane: their record reads, then their table reads, are in flight together
+    // (one candidate per lane was a chain of two dependent L2 round trips per 64 entries and wave: the kernel was bound by that latency,
+    //  not by its gathers' number — packing seven arrays into one record changed nothing, 6.0 ms per 64 x L = 10 000 either way)
     auto evaluate = [&](uint32_t take) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if ((uint32_t)lane < take) {
-            const uint32_t s = (head + lane) & (FILL_Q - 1);
-            const int k = row0 + (int)qK[s];
-            const int q = (int)qQ[s];
-            const uint32_t e = qE[s];
-            const int i = cI[k], j = cJ[k], iq = cI[q], jq = cJ[q];
-            const double a = TA[(int64_t)i * pd.n1 + iq], bb = TB[(int64_t)j * pd.n2 + jq];
+        bool on[FILL_E]; int k[FILL_E], q[FILL_E]; uint32_t e[FILL_E];
+        int i[FILL_E], j[FILL_E], iq[FILL_E], jq[FILL_E]; double sk[FILL_E], sq[FILL_E], dz[FILL_E];
+        uint32_t base[FILL_E], pk[FILL_E], pq[FILL_E];       // slice base + lane slot (base is a multiple of 64); positions of row and column
+#pragma unroll
+        for (int h = 0; h < FILL_E; ++h) {
+            const uint32_t idx = (uint32_t)lane + 64u * (uint32_t)h;
+            on[h] = idx < take;
+            const uint32_t s = (head + (on[h] ? idx : 0u)) & (FILL_Q - 1);    // (an idle lane repeats the first candidate's reads; it stores nothing)
+            k[h] = (int)qK[s]; q[h] = (int)qQ[s]; e[h] = qE[s];
+        }
+#pragma unroll
+        for (int h = 0; h < FILL_E; ++h) {
+            if (LDSCOL) {
+                i[h] = cI[k[h]]; j[h] = cJ[k[h]]; iq[h] = cI[q[h]]; jq[h] = cJ[q[h]]; sk[h] = cS[k[h]]; sq[h] = cS[q[h]];
+                dz[h] = GRAV ? (cZa[k[h]] - cZa[q[h]]) - (cZb[k[h]] - cZb[q[h]]) : 0.0;
+                base[h] = cBase[k[h]]; pk[h] = cPos[k[h]]; pq[h] = cPos[q[h]];
+            } else {
+                const FillPack rk = pack[k[h]], rq = pack[q[h]];
+                i[h] = rk.i; j[h] = rk.j; iq[h] = rq.i; jq[h] = rq.j; sk[h] = rk.s; sq[h] = rq.s;
+                dz[h] = GRAV ? (rk.za - rq.za) - (rk.zb - rq.zb) : 0.0;
+                base[h] = rk.base; pk[h] = rk.pos; pq[h] = rq.pos;
+            }
+        }
+        double a[FILL_E], bb[FILL_E];
+#pragma unroll
+        for (int h = 0; h < FILL_E; ++h) { a[h] = TA[(int64_t)i[h] * pd.n1 + iq[h]]; bb[h] = TB[(int64_t)j[h] * pd.n2 + jq[h]]; }
+#pragma unroll
+        for (int h = 0; h < FILL_E; ++h) {
             double c;
             if (GRAV && D.gmode != 3) {
-                const double ch = fabs(a - bb);
-                const double hm = a > bb ? a : bb;
-                double cv = fabs((cZa[k] - cZa[q]) - (cZb[k] - cZb[q])) - D.sin_unc * hm;
+                const double ch = fabs(a[h] - bb[h]);
+                const double hm = a[h] > bb[h] ? a[h] : bb[h];
+                double cv = fabs(dz[h]) - D.sin_unc * hm;
                 if (cv < 0.0) cv = 0.0;
                 c = sqrt(ch * ch + cv * cv);
             } else {
-                c = fabs(a - bb);                               // no gravity prior, or the z-gate reading (full lengths)
+                c = fabs(a[h] - bb[h]);                         // no gravity prior, or the z-gate reading (full lengths)
             }
             const double sa = fx_exp(((-0.5 * c) * c) / D.sig2);
-            const double v = fuse_pair(D, sa, cS[k], cS[q]);
+            const double v = fuse_pair(D, sa, sk[h], sq[h]);
             const bool keep = v > D.p.affinityeps;
             // an entry at or below affinityeps belongs neither to M nor to C: inert slot
             // column labels are POSITIONS (sorted row order): the solvers keep their vectors in that order
-            uint32_t base, pk, pq;                              // slice base + lane slot (base is a multiple of 64); positions of row and column
-            if (LDSCOL) { base = cBase[k]; pk = cPos[k]; pq = cPos[q]; }
-            else { pk = rowPos[k]; pq = rowPos[q]; base = sliceBase[pk >> 6] + (pk & 63u); }
-            cols[col_pos<QUAD>(base & ~63u, base & 63u, e)] = keep ? (IdxT)pq : fb_inert<IdxT>(pk);
-            vals[val_pos<QUAD>(base & ~63u, base & 63u, e)] = keep ? v : 0.0;
-            upper += (keep && q > k) ? 1u : 0u;
+            if (on[h]) {
+                cols[col_pos<QUAD>(base[h] & ~63u, base[h] & 63u, e[h])] = keep ? (IdxT)pq[h] : fb_inert<IdxT>(pk[h]);
+                vals[val_pos<QUAD>(base[h] & ~63u, base[h] & 63u, e[h])] = keep ? v : 0.0;
+                upper += (keep && q[h] > k[h]) ? 1u : 0u;
+            }
         }
         head = (head + take) & (FILL_Q - 1); queued -= take;
     };
 
     const int64_t nblk = (nwords + 63) >> 6;
-    unsigned long long m_next = 0ull; uint32_t p_next = 0u;
+    unsigned long long m_next = 0ull; uint32_t p_next = 0u, k_next = 0u;
+    auto fetch = [&](int64_t x_) {                              // word x_ of the item's flat stream: live row, mask word, entries in front of it
+        const int r_ = (int)x_ / W;                             // (RPB * W < 2^31)
+        const uint32_t k_ = perm[row0 + r_];
+        const int64_t a_ = (int64_t)k_ * W + ((int)x_ - r_ * W);
+        k_next = k_; m_next = mbase[a_]; p_next = pbase[a_];
+    };
     {   // prefetch the wave's first block
         const int64_t x = (int64_t)w * 64 + lane;
-        if (w < nblk && x < nwords) { m_next = mw[x]; p_next = pw[x]; }
+        if (w < nblk && x < nwords) fetch(x);
     }
     for (int64_t blk = w; blk < nblk; blk += wpb) {
-        unsigned long long m = m_next; uint32_t e = p_next;
+        unsigned long long m = m_next; uint32_t e = p_next; const uint32_t kl = k_next;     // (kl: the word's LIVE row)
         const int64_t x = blk * 64 + lane;
         {   // prefetch the next block while this one is expanded / evaluated
             const int64_t xn = x + (int64_t)wpb * 64;
             m_next = 0ull; p_next = 0u;
-            if (blk + wpb < nblk && xn < nwords) { m_next = mw[xn]; p_next = pw[xn]; }
+            if (blk + wpb < nblk && xn < nwords) fetch(xn);
         }
-        const uint32_t kl = (uint32_t)((int)x / W);             // row of this word (local to the item; RPB*W < 2^31)
-        const uint32_t qb = (uint32_t)((int)x - (int)kl * W) << 6;  // first column of this word
+        const uint32_t qb = (uint32_t)((int)x - ((int)x / W) * W) << 6;  // first column of this word
         for (;;) {                                              // bit steps
             const bool has = m != 0ull;
             const unsigned long long act = __ballot(has);
@@ -3010,10 +3066,10 @@ __device__ __forceinline__ uint32_t fill_item(const DevParams& D, const ProbDesc
                 ++e;
             }
             queued += (uint32_t)__popcll(act);
-            while (queued >= 64u) evaluate(64u);
+            while (queued >= 64u * FILL_E) evaluate(64u * FILL_E);
         }
     }
-    if (queued > 0u) evaluate(queued);
+    while (queued > 0u) evaluate(min(queued, 64u * (uint32_t)FILL_E));
     return upper;
 }
 
@@ -3032,7 +3088,9 @@ __global__ void __launch_bounds__(1024) k_fill(DevParams D, const ProbDesc* __re
                                                const uint32_t* __restrict__ rowPos,
                                                const uint32_t* __restrict__ sliceWidth,
                                                const uint32_t* __restrict__ sliceBase,
-                                               IdxT* __restrict__ cols, double* __restrict__ vals, int TC, int RPB)
+                                               IdxT* __restrict__ cols, double* __restrict__ vals, int TC, int RPB,
+                                               const FillPack* __restrict__ packPool /* records of the problems beyond TC live associations (k_fillpack) */,
+                                               const uint32_t* __restrict__ permPool /* position -> live row */)
 {
     // LDS: cS[TC] [GRAV: cZa[TC] cZb[TC]] cI[TC] cJ[TC] cBase[TC] cPos[TC] | per-wave rings qK qQ qE
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -3079,15 +3137,15 @@ __global__ void __launch_bounds__(1024) k_fill(DevParams D, const ProbDesc* __re
         uint32_t upper;
         if (ldscol)
             upper = fill_item<GRAV, IdxT, true, QUAD>(D, pd, L, it.row0, nrows, w, wpb, lane, cI, cJ, cS, cZa, cZb, cBase, cPos, TA, TB,
-                                                maskPool + mo, prefPool + mo, rowPos + lo, sliceBase + lo, qK, qQ, qE, cols + no, vals + no);
+                                                maskPool + mo, prefPool + mo, permPool + lo, nullptr, qK, qQ, qE, cols + no, vals + no);
         else
-            upper = fill_item<GRAV, IdxT, false, QUAD>(D, pd, L, it.row0, nrows, w, wpb, lane, li + lo, lj + lo, ls + lo, lza + lo, lzb + lo, nullptr, nullptr, TA, TB,
-                                                 maskPool + mo, prefPool + mo, rowPos + lo, sliceBase + lo, qK, qQ, qE, cols + no, vals + no);
+            upper = fill_item<GRAV, IdxT, false, QUAD>(D, pd, L, it.row0, nrows, w, wpb, lane, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, TA, TB,
+                                                 maskPool + mo, prefPool + mo, permPool + lo, packPool + lo, qK, qQ, qE, cols + no, vals + no);
         // pad every row's slot column up to its slice width with inert entries (value 0, C-flag; the
         // column is the row's own position: a real, finite vector element whatever the solver gathers from)
         for (int r = w; r < nrows; r += wpb) {
-            const int k = it.row0 + r;
-            const uint32_t pos = rowPos[lo + k];
+            const uint32_t pos = (uint32_t)(it.row0 + r);        // (items are blocks of positions)
+            const int k = (int)permPool[lo + pos];
             const uint32_t width = sliceWidth[lo + (pos >> 6)];
             const int64_t sb = no + sliceBase[lo + (pos >> 6)];
             for (uint32_t e = rowCnt[lo + k] + lane; e < width; e += WAVE) {
