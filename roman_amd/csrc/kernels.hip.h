@@ -2954,8 +2954,10 @@ __global__ void __launch_bounds__(256) k_fillpack(const ProbDesc* __restrict__ p
     }
 }
 
-template <bool GRAV, typename IdxT, bool LDSCOL, bool QUAD>
-__device__ __forceinline__ uint32_t fill_item(const DevParams& D, const ProbDesc& pd, int L, int row0, int nrows,
+// CM: where an entry's per-association data comes from — 1: the problem's whole column tile in LDS (rows and columns); 2: a WINDOW of
+// columns [wq0, wq0 + 64 Ww) in LDS, the rows' records from `pack` (nearly wave-uniform reads); 0: records for both (not used)
+template <bool GRAV, typename IdxT, int CM, bool QUAD>
+__device__ __forceinline__ uint32_t fill_item(const DevParams& D, const ProbDesc& pd, int L, int row0, int nrows, int wq0, int Ww,
                                               int w, int wpb, int lane,
                                               const int32_t* cI, const int32_t* cJ, const double* cS,
                                               const double* cZa, const double* cZb, const uint32_t* cBase, const uint32_t* cPos,
@@ -2966,8 +2968,10 @@ __device__ __forceinline__ uint32_t fill_item(const DevParams& D, const ProbDesc
                                               uint32_t* qK, uint32_t* qQ, uint32_t* qE,
                                               IdxT* __restrict__ cols, double* __restrict__ vals)
 {
+    constexpr bool LDSCOL = CM == 1;
     const int W = (L + 63) >> 6;
-    const int64_t nwords = (int64_t)nrows * W;
+    const int64_t nwords = (int64_t)nrows * Ww;
+    const int w0 = wq0 >> 6;
     // The item's rows are the rows at positions row0 .. row0 + nrows - 1: what it writes is a few consecutive slices of the matrix (a
     // 128-byte line of the quad layout holds 16 bytes of each of eight NEIGHBOURING positions — with items of consecutive live rows its
     // eight parts arrived from eight workgroups at eight different times: eight partial writes per line)
@@ -2997,6 +3001,12 @@ __device__ __forceinline__ uint32_t fill_item(const DevParams& D, const ProbDesc
                 i[h] = cI[k[h]]; j[h] = cJ[k[h]]; iq[h] = cI[q[h]]; jq[h] = cJ[q[h]]; sk[h] = cS[k[h]]; sq[h] = cS[q[h]];
                 dz[h] = GRAV ? (cZa[k[h]] - cZa[q[h]]) - (cZb[k[h]] - cZb[q[h]]) : 0.0;
                 base[h] = cBase[k[h]]; pk[h] = cPos[k[h]]; pq[h] = cPos[q[h]];
+            } else if (CM == 2) {
+                const FillPack rk = pack[k[h]];
+                const int ql = q[h] - wq0;
+                i[h] = rk.i; j[h] = rk.j; iq[h] = cI[ql]; jq[h] = cJ[ql]; sk[h] = rk.s; sq[h] = cS[ql];
+                dz[h] = GRAV ? (rk.za - cZa[ql]) - (rk.zb - cZb[ql]) : 0.0;
+                base[h] = rk.base; pk[h] = rk.pos; pq[h] = cPos[ql];
             } else {
                 const FillPack rk = pack[k[h]], rq = pack[q[h]];
                 i[h] = rk.i; j[h] = rk.j; iq[h] = rq.i; jq[h] = rq.j; sk[h] = rk.s; sq[h] = rq.s;
@@ -3036,9 +3046,9 @@ __device__ __forceinline__ uint32_t fill_item(const DevParams& D, const ProbDesc
     const int64_t nblk = (nwords + 63) >> 6;
     unsigned long long m_next = 0ull; uint32_t p_next = 0u, k_next = 0u;
     auto fetch = [&](int64_t x_) {                              // word x_ of the item's flat stream: live row, mask word, entries in front of it
-        const int r_ = (int)x_ / W;                             // (RPB * W < 2^31)
+        const int r_ = (int)x_ / Ww;                            // (RPB * W < 2^31)
         const uint32_t k_ = perm[row0 + r_];
-        const int64_t a_ = (int64_t)k_ * W + ((int)x_ - r_ * W);
+        const int64_t a_ = (int64_t)k_ * W + (w0 + ((int)x_ - r_ * Ww));
         k_next = k_; m_next = mbase[a_]; p_next = pbase[a_];
     };
     {   // prefetch the wave's first block
@@ -3053,7 +3063,7 @@ __device__ __forceinline__ uint32_t fill_item(const DevParams& D, const ProbDesc
             m_next = 0ull; p_next = 0u;
             if (blk + wpb < nblk && xn < nwords) fetch(xn);
         }
-        const uint32_t qb = (uint32_t)((int)x - ((int)x / W) * W) << 6;  // first column of this word
+        const uint32_t qb = (uint32_t)(w0 + ((int)x - ((int)x / Ww) * Ww)) << 6;  // first column of this word
         for (;;) {                                              // bit steps
             const bool has = m != 0ull;
             const unsigned long long act = __ballot(has);
@@ -3134,13 +3144,29 @@ __global__ void __launch_bounds__(1024) k_fill(DevParams D, const ProbDesc* __re
             }
         }
         __syncthreads();
-        uint32_t upper;
+        uint32_t upper = 0u;
         if (ldscol)
-            upper = fill_item<GRAV, IdxT, true, QUAD>(D, pd, L, it.row0, nrows, w, wpb, lane, cI, cJ, cS, cZa, cZb, cBase, cPos, TA, TB,
+            upper = fill_item<GRAV, IdxT, 1, QUAD>(D, pd, L, it.row0, nrows, 0, (L + 63) >> 6, w, wpb, lane, cI, cJ, cS, cZa, cZb, cBase, cPos, TA, TB,
                                                 maskPool + mo, prefPool + mo, permPool + lo, nullptr, qK, qQ, qE, cols + no, vals + no);
-        else
-            upper = fill_item<GRAV, IdxT, false, QUAD>(D, pd, L, it.row0, nrows, w, wpb, lane, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, TA, TB,
-                                                 maskPool + mo, prefPool + mo, permPool + lo, packPool + lo, qK, qQ, qE, cols + no, vals + no);
+        else {
+            // live sets beyond the tile: WINDOWS of TC columns (a multiple of 64), one after the other — the window's columns from the
+            // records into LDS (coalesced), the item's word stream restricted to the window's words; an entry then costs its two table reads,
+            // its two stores and a (nearly wave-uniform) read of its row's record instead of ten requests to the L2
+            const int TCw = TC & ~63;
+            for (int q0 = 0; q0 < L; q0 += TCw) {
+                const int qn = min(TCw, L - q0);
+                if (q0 > 0) __syncthreads();    // every wave is done with the previous window's columns
+                for (int q = tid; q < qn; q += nt) {
+                    const FillPack r_ = packPool[lo + q0 + q];
+                    cI[q] = r_.i; cJ[q] = r_.j; cS[q] = r_.s;
+                    if (GRAV) { cZa[q] = r_.za; cZb[q] = r_.zb; }
+                    cPos[q] = r_.pos;
+                }
+                __syncthreads();
+                upper += fill_item<GRAV, IdxT, 2, QUAD>(D, pd, L, it.row0, nrows, q0, (qn + 63) >> 6, w, wpb, lane, cI, cJ, cS, cZa, cZb, cBase, cPos, TA, TB,
+                                                        maskPool + mo, prefPool + mo, permPool + lo, packPool + lo, qK, qQ, qE, cols + no, vals + no);
+            }
+        }
         // pad every row's slot column up to its slice width with inert entries (value 0, C-flag; the
         // column is the row's own position: a real, finite vector element whatever the solver gathers from)
         for (int r = w; r < nrows; r += wpb) {

@@ -866,7 +866,7 @@ int enqueue_score(roman_ctx* c, const DevParams& Din, const roman_params_t* para
             const int colBytesG = D.gravity ? 40 : 24;
             const size_t ringLds = (size_t)16 * 3 * FILL_Q * sizeof(uint32_t);
             int TCf = (int)std::min<size_t>((c->lds_max - ringLds) / colBytesG, 32768) & ~63;
-            TCf = std::min(TCf, Lneed);
+            TCf = std::min(TCf, std::max(64, (Lneed + 63) & ~63));      // (a multiple of 64, at least 64: k_fill cuts larger live sets into windows of TCf columns)
             const size_t fillLds = ringLds + (size_t)TCf * colBytesG;
             const int fillGrid = c->num_cu * std::max(1, std::min(2, (int)(c->lds_max / fillLds)));
             // one record per live association for the problems whose columns do not fit the LDS tile (kernels.hip.h, FillPack)
