@@ -2929,33 +2929,13 @@ __global__ void __launch_bounds__(1024) k_probscan(int B, int NG /* fill groups 
 constexpr int FILL_E = 1;            // candidates a lane evaluates at a time (2: measured without gain, 212 B of scratch)
 constexpr int FILL_Q = 256;          // ring capacity per wave (>= 64 FILL_E queued + 64 emitted per bit step)
 
-// What k_fill needs of a live association whose problem's column data does not fit the LDS tile (live sets beyond ~2 800 with the gravity
-// prior, ~4 700 without): ONE 48-byte record instead of seven arrays.  An entry (k, q) then costs two record reads + two table reads instead
-// of fifteen scattered 4- and 8-byte reads — the kernel is bound by the L2's gather rate there (280 G requests/s device-wide:
-// tools/ubench/gatomic_rate.hip), 23-25 G entries/s before.
-struct alignas(16) FillPack { int32_t i, j; uint32_t pos, base /* slice base + lane slot */; double s, za, zb, pad; };
-
-__global__ void __launch_bounds__(256) k_fillpack(const ProbDesc* __restrict__ probs, const ProbState* __restrict__ st, int TC /* problems of at most TC live associations stage their columns in LDS */,
-                                                  const int32_t* __restrict__ li, const int32_t* __restrict__ lj, const double* __restrict__ ls,
-                                                  const double* __restrict__ lza, const double* __restrict__ lzb,
-                                                  const uint32_t* __restrict__ rowPos, const uint32_t* __restrict__ sliceBase, FillPack* __restrict__ pack)
-{
-    const int b = blockIdx.y;
-    if (st[b].kind != 1) return;
-    const int L = st[b].L;
-    if (L <= TC) return;
-    const int64_t lo = probs[b].liveOff;
-    for (int q = blockIdx.x * 256 + threadIdx.x; q < L; q += gridDim.x * 256) {
-        const uint32_t pos = rowPos[lo + q];
-        FillPack r;
-        r.i = li[lo + q]; r.j = lj[lo + q]; r.pos = pos; r.base = sliceBase[lo + (pos >> 6)] + (pos & 63u);
-        r.s = ls[lo + q]; r.za = lza ? lza[lo + q] : 0.0; r.zb = lzb ? lzb[lo + q] : 0.0; r.pad = 0.0;
-        pack[lo + q] = r;
-    }
-}
+// The rows of a k_fill work item (at most FILL_RPB consecutive positions) in LDS: live row, objects, single score, z, slice base + lane slot
+constexpr int FILL_RPB = 128;
+struct FillRows { int32_t* k; int32_t* i; int32_t* j; uint32_t* base; double* s; double* za; double* zb; };
+constexpr int FILL_ROWBYTES = 4 * 4 + 3 * 8;    // per row
 
 // CM: where an entry's per-association data comes from — 1: the problem's whole column tile in LDS (rows and columns); 2: a WINDOW of
-// columns [wq0, wq0 + 64 Ww) in LDS, the rows' records from `pack` (nearly wave-uniform reads); 0: records for both (not used)
+// columns [wq0, wq0 + 64 Ww) in LDS, the item's rows from their own small tile (FillRows)
 template <bool GRAV, typename IdxT, int CM, bool QUAD>
 __device__ __forceinline__ uint32_t fill_item(const DevParams& D, const ProbDesc& pd, int L, int row0, int nrows, int wq0, int Ww,
                                               int w, int wpb, int lane,
@@ -2963,8 +2943,7 @@ __device__ __forceinline__ uint32_t fill_item(const DevParams& D, const ProbDesc
                                               const double* cZa, const double* cZb, const uint32_t* cBase, const uint32_t* cPos,
                                               const double* __restrict__ TA, const double* __restrict__ TB,
                                               const unsigned long long* __restrict__ mbase, const uint32_t* __restrict__ pbase,
-                                              const uint32_t* __restrict__ perm /* position -> live row: an item is a block of consecutive POSITIONS */,
-                                              const FillPack* __restrict__ pack /* !LDSCOL: the problem's records (k_fillpack) */,
+                                              const FillRows& R /* the item's rows (R.k: position row0 + r -> live row: an item is a block of consecutive POSITIONS) */,
                                               uint32_t* qK, uint32_t* qQ, uint32_t* qE,
                                               IdxT* __restrict__ cols, double* __restrict__ vals)
 {
@@ -2985,7 +2964,7 @@ __device__ __forceinline__ uint32_t fill_item(const DevParams& D, const ProbDesc
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        bool on[FILL_E]; int k[FILL_E], q[FILL_E]; uint32_t e[FILL_E];
+        bool on[FILL_E]; int rl[FILL_E], k[FILL_E], q[FILL_E]; uint32_t e[FILL_E];
         int i[FILL_E], j[FILL_E], iq[FILL_E], jq[FILL_E]; double sk[FILL_E], sq[FILL_E], dz[FILL_E];
         uint32_t base[FILL_E], pk[FILL_E], pq[FILL_E];       // slice base + lane slot (base is a multiple of 64); positions of row and column
 #pragma unroll
@@ -2993,7 +2972,7 @@ __device__ __forceinline__ uint32_t fill_item(const DevParams& D, const ProbDesc
             const uint32_t idx = (uint32_t)lane + 64u * (uint32_t)h;
             on[h] = idx < take;
             const uint32_t s = (head + (on[h] ? idx : 0u)) & (FILL_Q - 1);    // (an idle lane repeats the first candidate's reads; it stores nothing)
-            k[h] = (int)qK[s]; q[h] = (int)qQ[s]; e[h] = qE[s];
+            rl[h] = (int)qK[s]; k[h] = R.k[rl[h]]; q[h] = (int)qQ[s]; e[h] = qE[s];
         }
 #pragma unroll
         for (int h = 0; h < FILL_E; ++h) {
@@ -3001,17 +2980,11 @@ __device__ __forceinline__ uint32_t fill_item(const DevParams& D, const ProbDesc
                 i[h] = cI[k[h]]; j[h] = cJ[k[h]]; iq[h] = cI[q[h]]; jq[h] = cJ[q[h]]; sk[h] = cS[k[h]]; sq[h] = cS[q[h]];
                 dz[h] = GRAV ? (cZa[k[h]] - cZa[q[h]]) - (cZb[k[h]] - cZb[q[h]]) : 0.0;
                 base[h] = cBase[k[h]]; pk[h] = cPos[k[h]]; pq[h] = cPos[q[h]];
-            } else if (CM == 2) {
-                const FillPack rk = pack[k[h]];
-                const int ql = q[h] - wq0;
-                i[h] = rk.i; j[h] = rk.j; iq[h] = cI[ql]; jq[h] = cJ[ql]; sk[h] = rk.s; sq[h] = cS[ql];
-                dz[h] = GRAV ? (rk.za - cZa[ql]) - (rk.zb - cZb[ql]) : 0.0;
-                base[h] = rk.base; pk[h] = rk.pos; pq[h] = cPos[ql];
             } else {
-                const FillPack rk = pack[k[h]], rq = pack[q[h]];
-                i[h] = rk.i; j[h] = rk.j; iq[h] = rq.i; jq[h] = rq.j; sk[h] = rk.s; sq[h] = rq.s;
-                dz[h] = GRAV ? (rk.za - rq.za) - (rk.zb - rq.zb) : 0.0;
-                base[h] = rk.base; pk[h] = rk.pos; pq[h] = rq.pos;
+                const int r_ = rl[h], ql = q[h] - wq0;
+                i[h] = R.i[r_]; j[h] = R.j[r_]; iq[h] = cI[ql]; jq[h] = cJ[ql]; sk[h] = R.s[r_]; sq[h] = cS[ql];
+                dz[h] = GRAV ? (R.za[r_] - cZa[ql]) - (R.zb[r_] - cZb[ql]) : 0.0;
+                base[h] = R.base[r_]; pk[h] = (uint32_t)(row0 + r_); pq[h] = cPos[ql];
             }
         }
         double a[FILL_E], bb[FILL_E];
@@ -3047,16 +3020,15 @@ __device__ __forceinline__ uint32_t fill_item(const DevParams& D, const ProbDesc
     unsigned long long m_next = 0ull; uint32_t p_next = 0u, k_next = 0u;
     auto fetch = [&](int64_t x_) {                              // word x_ of the item's flat stream: live row, mask word, entries in front of it
         const int r_ = (int)x_ / Ww;                            // (RPB * W < 2^31)
-        const uint32_t k_ = perm[row0 + r_];
-        const int64_t a_ = (int64_t)k_ * W + (w0 + ((int)x_ - r_ * Ww));
-        k_next = k_; m_next = mbase[a_]; p_next = pbase[a_];
+        const int64_t a_ = (int64_t)R.k[r_] * W + (w0 + ((int)x_ - r_ * Ww));
+        k_next = (uint32_t)r_; m_next = mbase[a_]; p_next = pbase[a_];
     };
     {   // prefetch the wave's first block
         const int64_t x = (int64_t)w * 64 + lane;
         if (w < nblk && x < nwords) fetch(x);
     }
     for (int64_t blk = w; blk < nblk; blk += wpb) {
-        unsigned long long m = m_next; uint32_t e = p_next; const uint32_t kl = k_next;     // (kl: the word's LIVE row)
+        unsigned long long m = m_next; uint32_t e = p_next; const uint32_t kl = k_next;     // (kl: the word's row of the item)
         const int64_t x = blk * 64 + lane;
         {   // prefetch the next block while this one is expanded / evaluated
             const int64_t xn = x + (int64_t)wpb * 64;
@@ -3098,8 +3070,7 @@ __global__ void __launch_bounds__(1024) k_fill(DevParams D, const ProbDesc* __re
                                                const uint32_t* __restrict__ rowPos,
                                                const uint32_t* __restrict__ sliceWidth,
                                                const uint32_t* __restrict__ sliceBase,
-                                               IdxT* __restrict__ cols, double* __restrict__ vals, int TC, int RPB,
-                                               const FillPack* __restrict__ packPool /* records of the problems beyond TC live associations (k_fillpack) */,
+                                               IdxT* __restrict__ cols, double* __restrict__ vals, int TC, int RPB /* <= FILL_RPB */,
                                                const uint32_t* __restrict__ permPool /* position -> live row */)
 {
     // LDS: cS[TC] [GRAV: cZa[TC] cZb[TC]] cI[TC] cJ[TC] cBase[TC] cPos[TC] | per-wave rings qK qQ qE
@@ -3114,6 +3085,9 @@ __global__ void __launch_bounds__(1024) k_fill(DevParams D, const ProbDesc* __re
     uint32_t* rings = cPos + TC;
     const int tid = threadIdx.x, nt = blockDim.x;
     const int lane = tid & 63, w = tid >> 6, wpb = nt >> 6;
+    FillRows R;                                                  // behind the rings: the item's rows
+    R.s = reinterpret_cast<double*>(rings + (size_t)wpb * 3 * FILL_Q); R.za = R.s + FILL_RPB; R.zb = R.za + FILL_RPB;
+    R.k = reinterpret_cast<int32_t*>(R.zb + FILL_RPB); R.i = R.k + FILL_RPB; R.j = R.i + FILL_RPB; R.base = reinterpret_cast<uint32_t*>(R.j + FILL_RPB);
     uint32_t* qK = rings + (size_t)w * 3 * FILL_Q;
     uint32_t* qQ = qK + FILL_Q;
     uint32_t* qE = qQ + FILL_Q;
@@ -3134,7 +3108,14 @@ __global__ void __launch_bounds__(1024) k_fill(DevParams D, const ProbDesc* __re
         const double* TA = tabPool + pd.tabOff;
         const double* TB = TA + (int64_t)pd.n1 * pd.n1;
         const bool ldscol = L <= TC;
-        __syncthreads();                        // every wave is done with the previous item's columns
+        __syncthreads();                        // every wave is done with the previous item's columns and rows
+        for (int r = tid; r < nrows; r += nt) {
+            const uint32_t pos = (uint32_t)(it.row0 + r);
+            const int k = (int)permPool[lo + pos];
+            R.k[r] = k; R.i[r] = li[lo + k]; R.j[r] = lj[lo + k]; R.s[r] = ls[lo + k];
+            if (GRAV) { R.za[r] = lza[lo + k]; R.zb[r] = lzb[lo + k]; }
+            R.base[r] = sliceBase[lo + (pos >> 6)] + (pos & 63u);
+        }
         if (ldscol) {
             for (int q = tid; q < L; q += nt) {
                 cI[q] = li[lo + q]; cJ[q] = lj[lo + q]; cS[q] = ls[lo + q];
@@ -3147,24 +3128,24 @@ __global__ void __launch_bounds__(1024) k_fill(DevParams D, const ProbDesc* __re
         uint32_t upper = 0u;
         if (ldscol)
             upper = fill_item<GRAV, IdxT, 1, QUAD>(D, pd, L, it.row0, nrows, 0, (L + 63) >> 6, w, wpb, lane, cI, cJ, cS, cZa, cZb, cBase, cPos, TA, TB,
-                                                maskPool + mo, prefPool + mo, permPool + lo, nullptr, qK, qQ, qE, cols + no, vals + no);
+                                                maskPool + mo, prefPool + mo, R, qK, qQ, qE, cols + no, vals + no);
         else {
-            // live sets beyond the tile: WINDOWS of TC columns (a multiple of 64), one after the other — the window's columns from the
-            // records into LDS (coalesced), the item's word stream restricted to the window's words; an entry then costs its two table reads,
-            // its two stores and a (nearly wave-uniform) read of its row's record instead of ten requests to the L2
+            // live sets beyond the tile: WINDOWS of TC columns (a multiple of 64), one after the other — the window's columns into LDS
+            // (coalesced), the item's word stream restricted to the window's words; an entry then costs its two table reads and its two
+            // stores instead of fifteen requests to the L2
             const int TCw = TC & ~63;
             for (int q0 = 0; q0 < L; q0 += TCw) {
                 const int qn = min(TCw, L - q0);
                 if (q0 > 0) __syncthreads();    // every wave is done with the previous window's columns
                 for (int q = tid; q < qn; q += nt) {
-                    const FillPack r_ = packPool[lo + q0 + q];
-                    cI[q] = r_.i; cJ[q] = r_.j; cS[q] = r_.s;
-                    if (GRAV) { cZa[q] = r_.za; cZb[q] = r_.zb; }
-                    cPos[q] = r_.pos;
+                    const int64_t g_ = lo + q0 + q;
+                    cI[q] = li[g_]; cJ[q] = lj[g_]; cS[q] = ls[g_];
+                    if (GRAV) { cZa[q] = lza[g_]; cZb[q] = lzb[g_]; }
+                    cPos[q] = rowPos[g_];
                 }
                 __syncthreads();
                 upper += fill_item<GRAV, IdxT, 2, QUAD>(D, pd, L, it.row0, nrows, q0, (qn + 63) >> 6, w, wpb, lane, cI, cJ, cS, cZa, cZb, cBase, cPos, TA, TB,
-                                                        maskPool + mo, prefPool + mo, permPool + lo, packPool + lo, qK, qQ, qE, cols + no, vals + no);
+                                                        maskPool + mo, prefPool + mo, R, qK, qQ, qE, cols + no, vals + no);
             }
         }
         // pad every row's slot column up to its slice width with inert entries (value 0, C-flag; the

@@ -77,7 +77,7 @@ struct roman_ctx {
         DevBuf lp, li, lj, ls, ld, lza, lzb;                       // per live association, live order
         DevBuf plp, pli, plj, pls, pld, plza, plzb;                // the same in position order (stream layout)
         DevBuf rowCnt, rowPos, perm, sliceWidth, sliceBase, items, maskPool, prefPool, listPool, listOff;
-        DevBuf vMu, vCu, vMun, vCun, gU, gUn, uOut, nodesOrig, nSel, widePart, wideSlots, wideBar, wideBm, wideY, wideUp, fillPack, fbList;
+        DevBuf vMu, vCu, vMun, vCun, gU, gUn, uOut, nodesOrig, nSel, widePart, wideSlots, wideBar, wideBm, wideY, wideUp, fbList;
         DevBuf cols16, cols32, vals, colsC, valsC, contSpill, contList;
         long long capMaskWords = 0, capNnz = 0, capList = 0;       // what the sparse pools hold (elements)
         // staging for the host-pointer entry points
@@ -864,30 +864,26 @@ int enqueue_score(roman_ctx* c, const DevParams& Din, const roman_params_t* para
         // one can exist (the kernel would find no work otherwise)
         if (D.allow_fallback && (SZ.maxA > D.stream_maxL || D.p.maxiniters < 1 || D.p.maxlsiters < 1)) {
             const int colBytesG = D.gravity ? 40 : 24;
-            const size_t ringLds = (size_t)16 * 3 * FILL_Q * sizeof(uint32_t);
+            const size_t ringLds = (size_t)16 * 3 * FILL_Q * sizeof(uint32_t) + (size_t)FILL_RPB * FILL_ROWBYTES;     // per-wave rings + the item's rows
+            static_assert(FILL_RPB >= 128, "the work items of a batch are blocks of at most 128 rows");
             int TCf = (int)std::min<size_t>((c->lds_max - ringLds) / colBytesG, 32768) & ~63;
             TCf = std::min(TCf, std::max(64, (Lneed + 63) & ~63));      // (a multiple of 64, at least 64: k_fill cuts larger live sets into windows of TCf columns)
             const size_t fillLds = ringLds + (size_t)TCf * colBytesG;
             const int fillGrid = c->num_cu * std::max(1, std::min(2, (int)(c->lds_max / fillLds)));
-            // one record per live association for the problems whose columns do not fit the LDS tile (kernels.hip.h, FillPack)
-            HIPCHK(c, WS.fillPack.ensure(sizeof(FillPack) * (size_t)std::max<int64_t>((int64_t)SZ.sumA, 1)));
-            hipLaunchKernelGGL(k_fillpack, dim3((unsigned)std::max(1, std::min(64, (Lneed + 1023) / 1024)), (unsigned)B), dim3(256), 0, WS.stream, dP, dS, TCf,
-                               LP.li, LP.lj, LP.ls, D.gravity ? LP.lza : (const double*)nullptr, D.gravity ? LP.lzb : (const double*)nullptr,
-                               WS.rowPos.as<uint32_t>(), WS.sliceBase.as<uint32_t>(), WS.fillPack.as<FillPack>());
             if (D.idx16) {                                      // 16-bit column labels for k_solve_wide
                 auto kg = D.gravity ? k_fill<true, uint16_t, true> : k_fill<false, uint16_t, true>;
                 HIPCHK(c, dyn_lds(c, reinterpret_cast<const void*>(kg), fillLds));
                 hipLaunchKernelGGL(kg, dim3(fillGrid), dim3(1024), fillLds, WS.stream, D, dP, dS, dT, WS.items.as<ItemDesc>(), WS.tabPool.as<double>(),
                                    LP.li, LP.lj, LP.ls, LP.lza, LP.lzb,
                                    WS.rowCnt.as<uint32_t>(), WS.maskPool.as<unsigned long long>(), WS.prefPool.as<uint32_t>(), WS.rowPos.as<uint32_t>(),
-                                   WS.sliceWidth.as<uint32_t>(), WS.sliceBase.as<uint32_t>(), WS.cols16.as<uint16_t>(), WS.vals.as<double>(), TCf, RPB, (const FillPack*)WS.fillPack.as<FillPack>(), (const uint32_t*)WS.perm.as<uint32_t>());
+                                   WS.sliceWidth.as<uint32_t>(), WS.sliceBase.as<uint32_t>(), WS.cols16.as<uint16_t>(), WS.vals.as<double>(), TCf, RPB, (const uint32_t*)WS.perm.as<uint32_t>());
             } else {
                 auto kg = D.gravity ? k_fill<true, uint32_t, true> : k_fill<false, uint32_t, true>;
                 HIPCHK(c, dyn_lds(c, reinterpret_cast<const void*>(kg), fillLds));
                 hipLaunchKernelGGL(kg, dim3(fillGrid), dim3(1024), fillLds, WS.stream, D, dP, dS, dT, WS.items.as<ItemDesc>(), WS.tabPool.as<double>(),
                                    LP.li, LP.lj, LP.ls, LP.lza, LP.lzb,
                                    WS.rowCnt.as<uint32_t>(), WS.maskPool.as<unsigned long long>(), WS.prefPool.as<uint32_t>(), WS.rowPos.as<uint32_t>(),
-                                   WS.sliceWidth.as<uint32_t>(), WS.sliceBase.as<uint32_t>(), WS.cols32.as<uint32_t>(), WS.vals.as<double>(), TCf, RPB, (const FillPack*)WS.fillPack.as<FillPack>(), (const uint32_t*)WS.perm.as<uint32_t>());
+                                   WS.sliceWidth.as<uint32_t>(), WS.sliceBase.as<uint32_t>(), WS.cols32.as<uint32_t>(), WS.vals.as<double>(), TCf, RPB, (const uint32_t*)WS.perm.as<uint32_t>());
             }
     DBG(c, "k_fill");
         }
@@ -1419,7 +1415,7 @@ int roman_ctx_destroy(roman_ctx_t* c)
         DevBuf* all[] = {&W.probs, &W.state, &W.totals, &W.queue, &W.cosPool, &W.cosDense, &W.tabPool, &W.qtabPool, &W.sTmp, &W.chunkCnt,
                          &W.lp, &W.li, &W.lj, &W.ls, &W.ld, &W.lza, &W.lzb, &W.plp, &W.pli, &W.plj, &W.pls, &W.pld, &W.plza, &W.plzb,
                          &W.rowCnt, &W.rowPos, &W.perm, &W.sliceWidth, &W.sliceBase, &W.items, &W.maskPool, &W.prefPool, &W.listPool, &W.listOff,
-                         &W.vMu, &W.vCu, &W.vMun, &W.vCun, &W.gU, &W.gUn, &W.uOut, &W.nodesOrig, &W.nSel, &W.widePart, &W.wideSlots, &W.wideBar, &W.wideBm, &W.wideY, &W.wideUp, &W.fillPack, &W.fbList, &W.cols16, &W.cols32, &W.vals, &W.colsC, &W.valsC, &W.contSpill, &W.contList,
+                         &W.vMu, &W.vCu, &W.vMun, &W.vCun, &W.gU, &W.gUn, &W.uOut, &W.nodesOrig, &W.nSel, &W.widePart, &W.wideSlots, &W.wideBar, &W.wideBm, &W.wideY, &W.wideUp, &W.fbList, &W.cols16, &W.cols32, &W.vals, &W.colsC, &W.valsC, &W.contSpill, &W.contList,
                          &W.hFeats, &W.hAssoc, &W.hU0, &W.oAssoc, &W.oN, &W.oT, &W.oStatus, &W.oStats, &W.hAux1, &W.hAux2, &W.hAux3, &W.oAll};
         for (DevBuf* b : all) b->release();
         if (W.pinnedTotals) (void)hipHostFree(W.pinnedTotals);
