@@ -5807,30 +5807,43 @@ __global__ void __launch_bounds__(WIDE_NT) k_solve_wide(DevParams D, int B, cons
                 else { uint4_t o_; o_.x = pc[0]; o_.y = pc[1]; o_.z = pc[2]; o_.w = pc[3]; cq[(size_t)q_ * 64] = o_; }
                 vq[(size_t)(2u * q_) * 64] = dbl2_t{pv[0], pv[1]}; vq[(size_t)(2u * q_ + 1u) * 64] = dbl2_t{pv[2], pv[3]};
             };
-            cword_t cN = cword_t{}; dbl2_t v0N = dbl2_t{0.0, 0.0}, v1N = dbl2_t{0.0, 0.0};
-            if (nst > 0u) { cN = cp[0]; v0N = vp[0]; v1N = vp[64]; }
-            for (uint32_t g = 0; g < nst; ++g) {
-                const cword_t cC = cN; const dbl2_t v0 = v0N, v1 = v1N;
-                if (g + 1u < nst) { cN = cp[(size_t)(g + 1u) * 64]; v0N = vp[(size_t)(2u * g + 2u) * 64]; v1N = vp[(size_t)(2u * g + 3u) * 64]; }
-                uint32_t c4[4];
-                if constexpr (W16) { const unsigned long long cw_ = *reinterpret_cast<const unsigned long long*>(&cC);
-                    c4[0] = (uint32_t)(cw_ & 0xffffu); c4[1] = (uint32_t)((cw_ >> 16) & 0xffffu); c4[2] = (uint32_t)((cw_ >> 32) & 0xffffu); c4[3] = (uint32_t)(cw_ >> 48); }
-                else { const uint4_t cw_ = *reinterpret_cast<const uint4_t*>(&cC); c4[0] = cw_.x; c4[1] = cw_.y; c4[2] = cw_.z; c4[3] = cw_.w; }
-                const double v4[4] = {v0.x, v0.y, v1.x, v1.y};
+            // (a wave walks its slice alone, step by step: WIDE_CD steps of loads in flight — one step ahead, the walk of the widest slices, a
+            //  thousand dependent round trips, WAS the compaction: 560 us per copy of the n = m = 200 matrix, 0.76 TB/s)
+            constexpr int WIDE_CD = 4;
+            cword_t cR[WIDE_CD]; dbl2_t aR[WIDE_CD], bR[WIDE_CD];
 #pragma unroll
-                for (int h = 0; h < 4; ++h) {
-                    const uint32_t ci = W16 ? c4[h] : (c4[h] & 0x7fffffffu);
-                    // (an inert slot: 0xffff, or flagged with value 0 — a real flagged entry has a non-zero value)
-                    const bool real = W16 ? (ci != 0xffffu) : !((c4[h] & 0x80000000u) && v4[h] == 0.0);
-                    if (real && ci < (uint32_t)L && ((bmA[ci >> 6] >> (ci & 63u)) & 1ull)) {
-                        const uint32_t j_ = kc & 3u;
+            for (int d = 0; d < WIDE_CD; ++d) {
+                cR[d] = cword_t{}; aR[d] = dbl2_t{0.0, 0.0}; bR[d] = dbl2_t{0.0, 0.0};
+                if ((uint32_t)d < nst) { cR[d] = cp[(size_t)d * 64]; aR[d] = vp[(size_t)(2 * d) * 64]; bR[d] = vp[(size_t)(2 * d + 1) * 64]; }
+            }
+            for (uint32_t g0 = 0; g0 < nst; g0 += WIDE_CD) {
 #pragma unroll
-                        for (int z = 0; z < 4; ++z) if ((uint32_t)z == j_) { pc[z] = c4[h]; pv[z] = v4[h]; }
-                        ++kc;
-                        if ((kc & 3u) == 0u) {
-                            put((kc >> 2) - 1u);
+                for (int d = 0; d < WIDE_CD; ++d) {
+                    const uint32_t g = g0 + (uint32_t)d;
+                    if (g < nst) {
+                        const cword_t cC = cR[d]; const dbl2_t v0 = aR[d], v1 = bR[d];
+                        if (g + WIDE_CD < nst) { cR[d] = cp[(size_t)(g + WIDE_CD) * 64]; aR[d] = vp[(size_t)(2u * (g + WIDE_CD)) * 64]; bR[d] = vp[(size_t)(2u * (g + WIDE_CD) + 1u) * 64]; }
+                        uint32_t c4[4];
+                        if constexpr (W16) { const unsigned long long cw_ = *reinterpret_cast<const unsigned long long*>(&cC);
+                            c4[0] = (uint32_t)(cw_ & 0xffffu); c4[1] = (uint32_t)((cw_ >> 16) & 0xffffu); c4[2] = (uint32_t)((cw_ >> 32) & 0xffffu); c4[3] = (uint32_t)(cw_ >> 48); }
+                        else { const uint4_t cw_ = *reinterpret_cast<const uint4_t*>(&cC); c4[0] = cw_.x; c4[1] = cw_.y; c4[2] = cw_.z; c4[3] = cw_.w; }
+                        const double v4[4] = {v0.x, v0.y, v1.x, v1.y};
 #pragma unroll
-                            for (int z = 0; z < 4; ++z) { pc[z] = inert; pv[z] = 0.0; }
+                        for (int h = 0; h < 4; ++h) {
+                            const uint32_t ci = W16 ? c4[h] : (c4[h] & 0x7fffffffu);
+                            // (an inert slot: 0xffff, or flagged with value 0 — a real flagged entry has a non-zero value)
+                            const bool real = W16 ? (ci != 0xffffu) : !((c4[h] & 0x80000000u) && v4[h] == 0.0);
+                            if (real && ci < (uint32_t)L && ((bmA[ci >> 6] >> (ci & 63u)) & 1ull)) {
+                                const uint32_t j_ = kc & 3u;
+#pragma unroll
+                                for (int z = 0; z < 4; ++z) if ((uint32_t)z == j_) { pc[z] = c4[h]; pv[z] = v4[h]; }
+                                ++kc;
+                                if ((kc & 3u) == 0u) {
+                                    put((kc >> 2) - 1u);
+#pragma unroll
+                                    for (int z = 0; z < 4; ++z) { pc[z] = inert; pv[z] = 0.0; }
+                                }
+                            }
                         }
                     }
                 }
@@ -5891,6 +5904,9 @@ __global__ void __launch_bounds__(WIDE_NT) k_solve_wide(DevParams D, int B, cons
                     }
                     winPass = 0; winOut = 0;
                 }
+#ifdef ROMAN_SOLVE_TIMING
+                const unsigned long long tc0_ = wall_clock64();
+#endif
                 if (doc) {
                     if (doc == 1 && cmode == 0) copy_stream();  // (slice_compact reads the source's widths from cw)
                     if (doc == 2 && cmode != 0) full_stream();
@@ -5904,6 +5920,10 @@ __global__ void __launch_bounds__(WIDE_NT) k_solve_wide(DevParams D, int B, cons
                 } else if (fits != (cmode == 1)) {
                     if (fits) copy_stream(); else full_stream();
                 }
+#ifdef ROMAN_SOLVE_TIMING
+                if (!HALF_ON && doc) { const unsigned long long tc1_ = wall_clock64(); wacc[7] += tc1_ - tc0_; wcnt[7] += 1; wlast += tc1_ - tc0_; }   // (plain kernel: slot 7 = the compactions, taken out of the stream's slot)
+                if (!HALF_ON && cmode == 0) wcnt[6] += 1;       // (passes on the full matrix)
+#endif
             }
             if (upIn && !upOn) for (uint32_t p = (uint32_t)ltid; p < nl; p += WIDE_NT) xl[p] = xv[p];   // (left the half copy in this very pass)
             double fxScale = 1.0;
@@ -6341,7 +6361,7 @@ __global__ void __launch_bounds__(WIDE_NT) k_solve_wide(DevParams D, int B, cons
         if (wb.tRank == 0 && ltid == 0 && O.dbg) {              // 100 MHz ticks -> the host prints them as "cycles": x 10 ns
             unsigned long long* dg = O.dbg + (size_t)b * 16;
             for (int t = 0; t < 8; ++t) { dg[t] = wacc[t]; dg[8 + t] = wcnt[t]; }
-            dg[8 + 5] = Tfull; dg[8 + 6] = HALF_ON ? (unsigned long long)sh.upI[3] : 0ull;            // (steps of the full stream / of the half copy, all blocks)
+            dg[8 + 5] = Tfull; dg[8 + 6] = HALF_ON ? (unsigned long long)sh.upI[3] : wcnt[6];            // (steps of the full stream / of the half copy, all blocks)
         }
 #endif
 #undef WMARK
