@@ -1864,9 +1864,11 @@ __device__ __forceinline__ void count_rows_pre(const DevParams& D, const ProbDes
                                                PreRow* rowinfo,
                                                unsigned long long* __restrict__ mbase,
                                                const double* __restrict__ gZa, const double* __restrict__ gZb,
-                                               uint32_t* degS /* LDS, or NULL: the full degree of every live row, counted as the pairs pass (whole problems only) */)
+                                               uint32_t* degS /* LDS, or NULL: the full degree of every live row, counted as the pairs pass (whole problems only) */,
+                                               const dbl2_t* sO /* LDS: the objects' coordinates, (x, y) (z, -), map 1 at 0, map 2 at NO */, int NO /* 0: the exact gate reads the tables */)
 {
     constexpr int NR = PRE_NR;
+    const bool horiz = D.gmode == 1 || D.gmode == 2;            // the tables hold horizontal distances (k_tables)
     const int W = (L + 63) >> 6;
     const int Lpad = (L + 2 * WAVE - 1) & ~(2 * WAVE - 1);
     const uint32_t K2 = (uint32_t)D.pre_K * 0x00010001u;
@@ -1919,9 +1921,24 @@ __device__ __forceinline__ void count_rows_pre(const DevParams& D, const ProbDes
             const bool act = (int)qq < L;                       // (a sentinel column can only get here through the last bin)
             const uint32_t pk = cIJ[act ? qq : 0u];
             const PreRow* ri = rowinfo + (e[c] >> 14);
+            if (NO > 0) {
+                // the two distances RECOMPUTED from the coordinates in LDS with k_tables' own operation sequence (dx*dx + dy*dy (+ dz*dz), one
+                // correctly rounded sqrt: the same bits, as in k_fill_list), the heights from there too: no request leaves the compute unit
+                // (four L2 gathers per candidate before: 136 M per batch of 256 — the exact gate was a third of a quad's cycles)
+                const dbl2_t oa0 = sO[2 * ri->rowA], oa1 = sO[2 * ri->rowA + 1], ob0 = sO[2 * (NO + ri->rowB)], ob1 = sO[2 * (NO + ri->rowB) + 1];   // (rowA, rowB: the row's OBJECTS here)
+                const uint32_t iq = pk & 0xffffu, jq = (pk >> 16) - (uint32_t)(n1 + 1);
+                const dbl2_t pa0 = sO[2 * iq], pa1 = sO[2 * iq + 1], pb0 = sO[2 * (NO + jq)], pb1 = sO[2 * (NO + jq) + 1];
+                const double dxa = oa0.x - pa0.x, dya = oa0.y - pa0.y, dxb = ob0.x - pb0.x, dyb = ob0.y - pb0.y;
+                const double dza = oa1.x - pa1.x, dzb = ob1.x - pb1.x;
+                const double h2a = dxa * dxa + dya * dya, h2b = dxb * dxb + dyb * dyb;
+                a[c] = horiz ? sqrt(h2a) : sqrt(h2a + dza * dza);
+                bb[c] = horiz ? sqrt(h2b) : sqrt(h2b + dzb * dzb);
+                if (GM) { za[c] = pa1.x; zb[c] = pb1.x; }
+            } else {
             a[c] = TA[ri->rowA + (pk & 0xffffu)];               // (32-bit element offsets: maps of at most 32767 objects take this sweep)
             bb[c] = TB[ri->rowB + (pk >> 16)];                  // (rowB is short of the row's start by n1 + 1: the packed index carries it)
             if (GM) { za[c] = gZa[act ? qq : 0u]; zb[c] = gZb[act ? qq : 0u]; }
+            }
         }
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
@@ -2006,6 +2023,7 @@ __device__ __forceinline__ void count_rows_pre(const DevParams& D, const ProbDes
 #pragma unroll
             for (int x = 1; x < NR; ++x) if (lane == x) { i_ = pi[x]; j_ = pj[x]; }
             PreRow ri; ri.rowA = (uint32_t)i_ * (uint32_t)n1; ri.rowB = (uint32_t)j_ * (uint32_t)n2 - (uint32_t)(n1 + 1);
+            if (NO > 0) { ri.rowA = (uint32_t)i_; ri.rowB = (uint32_t)j_; }
             ri.moff = (uint32_t)lane * (uint32_t)Wcap * 8u; ri.zi = pzi; ri.zj = pzj;
             int kr_ = k[0];
 #pragma unroll
@@ -2143,7 +2161,8 @@ __global__ void __launch_bounds__(PRE ? PRE_WAVES * 64 : 1024) k_count(DevParams
                                                 unsigned long long* __restrict__ maskPool,
                                                 uint32_t* __restrict__ prefPool,
                                                 int TC /* LDS column tile (multiple of 256) */, int ldsPerWave /* doubles: NR table slices */, int RPB,
-                                                const uint16_t* __restrict__ qtabPool /* PRE: the tables as bins (k_tables) */)
+                                                const uint16_t* __restrict__ qtabPool /* PRE: the tables as bins (k_tables) */,
+                                                const double* __restrict__ feats, int NO /* PRE: object capacity per map of the coordinate tile in LDS (0: none — the exact gate reads the tables) */)
 {
     // LDS: [GM: cZZ[TC]] cIJ[TC] | per wave NR table slices (n1 + 1 + n2 doubles each)
     // PRE (NR is ignored: PRE_NR rows per wave; ldsPerWave = entries of the packed bin table): cIJ[TC] | per wave count_pre_wave_bytes()
@@ -2163,6 +2182,9 @@ __global__ void __launch_bounds__(PRE ? PRE_WAVES * 64 : 1024) k_count(DevParams
     uint2* qT = reinterpret_cast<uint2*>(rmask + PRE_NR * (TC >> 6));
     uint16_t* queue = reinterpret_cast<uint16_t*>(qT + ldsPerWave);
     PreRow* rowinfo = reinterpret_cast<PreRow*>(queue + PRE_QCAP);
+    // (PRE) behind the waves' regions: the objects' coordinates of the item's problem, 32 bytes per object
+    const size_t sOoff = ((size_t)(reinterpret_cast<unsigned char*>(cIJ + TC + PRE_COLPAD + 4 + ((PRE && RPB < 0) ? TC : 0)) - smem) + (size_t)wpb * (size_t)preBytes + 15) & ~(size_t)15;
+    dbl2_t* sO = reinterpret_cast<dbl2_t*>(smem + sOoff);
     if (PRE) { for (int x = lane; x < PRE_NR * (TC >> 6); x += WAVE) rmask[x] = 0ull; }
     // PRE with RPB < 0: a work item is a whole PROBLEM (B = -RPB problems; batches with at least a problem per compute unit): the
     // column tile is staged once per problem instead of once per 128 rows, and the rows go to the waves quad by quad
@@ -2198,13 +2220,22 @@ __global__ void __launch_bounds__(PRE ? PRE_WAVES * 64 : 1024) k_count(DevParams
                 cIJ[q] = v ? ((uint32_t)li[lo + q] | ((uint32_t)(pd.n1 + 1 + lj[lo + q]) << 16)) : ((uint32_t)pd.n1 | ((uint32_t)(pd.n1 + 1) << 16));
                 if (GM && !PRE) cZZ[q] = v ? make_double2(lza[lo + q], lzb[lo + q]) : make_double2(0.0, 0.0);
             }
+            if (PRE && NO > 0) {
+                const int pdim = D.p.point_dim;
+                for (int o = tid; o < pd.n1 + pd.n2; o += nt) {
+                    const double* f = feats + (o < pd.n1 ? pd.off1 + o : pd.off2 + (o - pd.n1)) * D.F;
+                    const int slot = o < pd.n1 ? o : NO + (o - pd.n1);
+                    sO[2 * slot] = dbl2_t{f[0], pdim > 1 ? f[1] : 0.0};
+                    sO[2 * slot + 1] = dbl2_t{pdim > 2 ? f[2] : 0.0, 0.0};
+                }
+            }
             if (PRE && tid == 0) *qctr = 0u;
             if (PRE && whole) for (int q = tid; q < L; q += nt) degL[q] = 0u;
             __syncthreads();
             if (PRE) {
                 count_rows_pre<GM>(D, pd, L, it.row0, nrows, qctr, lane, cIJ, TA, TB,
                                    qtabPool + 4 * (int64_t)pd.qtabOff4, qtabPool + 4 * (int64_t)pd.qtabOff4 + (int64_t)pd.n1 * ((pd.n1 + 3) & ~3),
-                                   qT, queue, rmask, TC >> 6, rowinfo, maskPool + mo, lza + lo, lzb + lo, whole ? degL : nullptr);
+                                   qT, queue, rmask, TC >> 6, rowinfo, maskPool + mo, lza + lo, lzb + lo, whole ? degL : nullptr, sO, NO);
                 if (whole) {                                    // the problem's degrees, for k_lists (live order)
                     __syncthreads();
                     for (int q = tid; q < L; q += nt) rowCnt[lo + q] = degL[q];

@@ -671,7 +671,7 @@ int enqueue_score(roman_ctx* c, const DevParams& Din, const roman_params_t* para
     // pairs (the exact gate reads them from memory for the ~6 % of the columns that reach it) + per wave the table slices, their
     // 16-bit bin slices, the candidate queue and the rows' mask words.  Taken when the whole expected live set fits its tile;
     // ROMAN_COUNT_PRE=0 / 1 in the environment forces the plain sweep / the prefilter where it fits (A/B and tests: read per call).
-    int preNR = 0, preWpb = 0, preTC = 0; size_t preLds = 0;
+    int preNR = 0, preWpb = 0, preTC = 0, preNO = 0; size_t preLds = 0;
     const int preRow = (2 * std::max(maxN, 1) + 1 + 3) & ~3;                 // entries of the packed bin table (n1 + sentinel + n2)
     {
         const char* preEnv = getenv("ROMAN_COUNT_PRE");
@@ -685,6 +685,16 @@ int enqueue_score(roman_ctx* c, const DevParams& Din, const roman_params_t* para
             if (wpbEnv && preNR) {                               // (A/B: ROMAN_COUNT_WPB also caps the prefiltered sweep's waves)
                 preWpb = std::min(preWpb, wpb);
                 preLds = (size_t)(preTC + PRE_COLPAD + 4) * 4 + (size_t)preWpb * (size_t)count_pre_wave_bytes(preRow, preTC);
+            }
+            // ROMAN_COUNT_OBJ=1 (A/B and tests; read per call): the exact gate recomputes its two distances from the objects' coordinates in
+            // LDS (32 bytes per object) instead of reading the tables and the heights from memory — four L2 gathers per candidate fewer,
+            // bit-identical masks (146 parity tests either way), and SLOWER: 397 against 373 us per batch of 256 on one box, twice: the
+            // sweep is bound by its LDS, which the eight extra reads per candidate load further; sixteen waves hide the L2 round trips.  Off.
+            if (preNR) {
+                const char* objEnv = getenv("ROMAN_COUNT_OBJ");
+                const int no = (std::max(maxN, 1) + 1) & ~1;
+                const size_t objBytes = (size_t)2 * no * 32 + 16;
+                if (objEnv && objEnv[0] == '1' && preLds + (size_t)preTC * 4 + objBytes <= c->lds_max) { preNO = no; preLds += objBytes; }
             }
         }
     }
@@ -755,7 +765,8 @@ int enqueue_score(roman_ctx* c, const DevParams& Din, const roman_params_t* para
             int a_TC = usePre ? preTC : TCc, a_lpw = usePre ? preRow : ldsPerWave;
             int a_RPB = wholeP ? -B : RPB;
             const uint16_t* a_qtab = WS.qtabPool.as<uint16_t>();
-            void* args[] = {&a_D, &a_dP, &a_dS, &a_dT, &a_items, &a_tab, &a_li, &a_lj, &a_za, &a_zb, &a_rc, &a_mask, &a_pref, &a_TC, &a_lpw, &a_RPB, &a_qtab};
+            const double* a_feats = in.feats; int a_NO = usePre ? preNO : 0;
+            void* args[] = {&a_D, &a_dP, &a_dS, &a_dT, &a_items, &a_tab, &a_li, &a_lj, &a_za, &a_zb, &a_rc, &a_mask, &a_pref, &a_TC, &a_lpw, &a_RPB, &a_qtab, &a_feats, &a_NO};
             HIPCHK(c, hipLaunchKernel(kc, dim3(gridK), dim3(wpbK * 64), args, ldsK + (wholeP ? (size_t)preTC * 4 : 0), WS.stream));
         }
     DBG(c, "k_count");
