@@ -5706,8 +5706,8 @@ __global__ void __launch_bounds__(WIDE_NT) k_solve_wide(DevParams D, int B, cons
         // one piece [t, stop) of slice s: partial row sums -> partials buffer.  Blocks of WIDE_U quads (three 16-byte loads
         // per lane and quad), the next block's matrix loads in flight while the current block gathers and accumulates.
         constexpr bool W16 = sizeof(IdxT) == 2;                  // 16-bit column words: 8 bytes per lane and quad, no C flag, 0xffff = no column
-        // (the half copy's code costs the whole kernel 20 registers and 240 bytes of scratch per lane — 5 us per pass of EVERY problem,
-        //  more than the copy saves —: an instantiation of its own, taken only under ROMAN_WIDE_UPPER=1)
+        // (the half copy's code costs the whole kernel 20 registers and 220 bytes of scratch per lane — several us per pass of EVERY problem
+        //   —: an instantiation of its own, taken where the copy saves more than that: teams on live sets of >= 9 000)
         constexpr bool HALF_ON = HALF && W16;
         typedef typename std::conditional<W16, unsigned long long, uint4_t>::type cword_t;
         auto piece = [&](const double* xv, uint32_t nl, uint32_t tm /* first step in memory */, uint32_t n /* steps */, uint32_t pid) {
@@ -5759,9 +5759,9 @@ __global__ void __launch_bounds__(WIDE_NT) k_solve_wide(DevParams D, int B, cons
         // into the block's accumulators ((M x)_q += v x_p, (C x)_q += x_p: two ds_add_u64 of fixed-point terms rint(. 2^s), s from the
         // vector's largest element so that a column's sum stays below 2^62 — integer sums: no order, k_solve_up's "exact accumulation").
         // Column labels of the copy are relative to the block's first column; 0xffff (>= Wc) is padding.
-        auto piece_up = [&](const double* xv, int s_, uint32_t tm /* first step in the mirror pools */, uint32_t n /* steps */, uint32_t pid, double fxScale, int Wc) {
+        auto piece_up = [&](const double* xv, int s_, uint32_t tm /* first step in the mirror pools */, uint32_t n /* steps */, uint32_t pid, double fxScale, int Wc, const uint16_t* rowAt /* my block's row order */) {
             if constexpr (HALF_ON) {
-            const uint32_t rp = ((uint32_t)s_ << 6) + (uint32_t)lane;
+            const uint32_t rp = (uint32_t)rowAt[((size_t)s_ << 6) + lane];       // (a slice of the block's own order: the lane's row is looked up)
             const double xr = rp < (uint32_t)L ? xv[rp] : 0.0;
             const cword_t* cp = reinterpret_cast<const cword_t*>((const IdxT*)colsK) + (size_t)tm * 64 + lane;
             const dbl2_t* vp = reinterpret_cast<const dbl2_t*>((const double*)valsK) + (size_t)tm * 128 + lane;
@@ -5958,9 +5958,10 @@ __global__ void __launch_bounds__(WIDE_NT) k_solve_wide(DevParams D, int B, cons
             }
             if (upIn && !upOn) for (uint32_t p = (uint32_t)ltid; p < nl; p += WIDE_NT) xl[p] = xv[p];   // (left the half copy in this very pass)
             double fxScale = 1.0;
-            int Wc = 0, jb = 0; uint32_t upSB_ = 0u, upPB_ = 0u;
+            int Wc = 0, jb = 0; uint32_t upSB_ = 0u, upPB_ = 0u; const uint16_t* rowAt = nullptr;
             if (HALF_ON && upOn) {                              // x over my block's columns, all of it; the pass's fixed-point scale
                 Wc = uni_i(sh.upI[1]); jb = uni_i(sh.upI[2]); upSB_ = uni((uint32_t)sh.upSB[jb]); upPB_ = uni((uint32_t)sh.upPB[jb]);
+                rowAt = reinterpret_cast<const uint16_t*>(upMeta + (size_t)wb.team * (size_t)bmWords * 1800 + (size_t)WIDE_MAXBLK * bmWords) + (size_t)(2 * WIDE_MAXBLK + jb) * ((size_t)bmWords * 64);
                 const int c0 = jb * Wc;
                 for (int p = ltid; p < Wc; p += WIDE_NT) xl[p] = (c0 + p < L) ? xv[c0 + p] : 0.0;
                 // a term v x 2^s (0 <= v <= 1) below 2^tb, a column's sum of fewer than L terms below 2^62
@@ -5982,7 +5983,7 @@ __global__ void __launch_bounds__(WIDE_NT) k_solve_wide(DevParams D, int B, cons
                         uint32_t sEnd = CUMW(s + 1);
                         while (t < tEnd) {
                             const uint32_t stop = min(sEnd, tEnd);
-                            if constexpr (H_) piece_up(xv, s, upSB_ + t, stop - t, upPB_ + c + (uint32_t)s, fxScale, Wc);
+                            if constexpr (H_) piece_up(xv, s, upSB_ + t, stop - t, upPB_ + c + (uint32_t)s, fxScale, Wc, rowAt);
                             else piece(xv, nl, MEMW(s) + (t - CUMW(s)), stop - t, c + (uint32_t)s);
                             t = stop;
                             if (t < tEnd) { do { ++s; sEnd = CUMW(s + 1); } while (sEnd <= t); }
@@ -6031,9 +6032,33 @@ __global__ void __launch_bounds__(WIDE_NT) k_solve_wide(DevParams D, int B, cons
             if (HALF_ON && upOn) {                              // pulled pieces of every block's stream, then the pushed sums of the slices' own columns' block
                 // (a slice lies in ONE column block: Wc is a multiple of 64; the pushed sums are loaded first and fly while the pieces are added)
                 const int nblk = uni_i(sh.upI[0]), Wc = uni_i(sh.upI[1]); const double fxInv = sh.upFx;
-                for (int j_ = 0; j_ < nblk; ++j_)
-                    add_pieces2((uint32_t)uni_i((int)sh.upPc[w][0][j_][0]), (uint32_t)uni_i((int)sh.upPc[w][0][j_][1]),
-                                (uint32_t)uni_i((int)sh.upPc[w][1][j_][0]), (uint32_t)uni_i((int)sh.upPc[w][1][j_][1]));
+                // a row's pulled pieces: per block the pieces of the slice of the block's order that holds the row, at the row's lane slot there
+                const uint2* gPin = reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(upMeta + (size_t)wb.team * (size_t)bmWords * 1800 + (size_t)WIDE_MAXBLK * bmWords) + (size_t)3 * WIDE_MAXBLK * ((size_t)bmWords * 64));
+                {   // (both owned rows of a lane together: their records, then their pieces, in flight at once)
+                    const int pos0 = (gw << 6) + lane, pos1 = ((gw + NWG) << 6) + lane;
+                    const bool on0 = kw > 0 && in[0], on1 = kw > 1 && in[1];
+                    for (int j_ = 0; j_ < nblk; ++j_) {
+                        const size_t jo = (size_t)j_ * ((size_t)bmWords * 64);
+                        const uint2 pin0 = on0 ? gPin[jo + pos0] : make_uint2(0u, 0u), pin1 = on1 ? gPin[jo + pos1] : make_uint2(0u, 0u);
+                        const uint32_t n0 = pin0.y & 0xffffu, n1 = pin1.y & 0xffffu;
+                        uint32_t nmax = max(n0, n1);
+                        for (int off = 32; off > 0; off >>= 1) nmax = max(nmax, (uint32_t)__shfl_xor((int)nmax, off));
+                        const dbl2_t* p0 = reinterpret_cast<const dbl2_t*>(part) + (size_t)pin0.x * 64 + (pin0.y >> 16);
+                        const dbl2_t* p1 = reinterpret_cast<const dbl2_t*>(part) + (size_t)pin1.x * 64 + (pin1.y >> 16);
+                        for (uint32_t q0 = 0; q0 < nmax; q0 += 4) {
+                            dbl2_t x0[4], x1[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                x0[e] = p0[(size_t)((q0 + (uint32_t)e < n0) ? q0 + (uint32_t)e : 0u) * 64];
+                                x1[e] = p1[(size_t)((q0 + (uint32_t)e < n1) ? q0 + (uint32_t)e : 0u) * 64];
+                            }
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) if (q0 + (uint32_t)e < n0) { m_[0] += x0[e].x; c_[0] += x0[e].y; }
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) if (q0 + (uint32_t)e < n1) { m_[1] += x1[e].x; c_[1] += x1[e].y; }
+                        }
+                    }
+                }
                 // (a slice lies in ONE column block: Wc is a multiple of 64)
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
@@ -6104,10 +6129,12 @@ __global__ void __launch_bounds__(WIDE_NT) k_solve_wide(DevParams D, int B, cons
         // next to two fixed-point accumulators per column: its waves pull into the rows' partials as before and push into the
         // accumulators (piece_up); after the stream the accumulators go to yPart, and the owner of a row adds its pulled pieces
         // (every block) and the pushed sums of the workgroups of its own column's block.  10 bytes per stored pair and pass instead
-        // of 20 — before padding: a (slice, block) cell is as wide as its longest row, 1.43 x the entries with two blocks
-        // (L = 10 000), 1.5 x with seven (L = 40 000) —, + 32 bytes per column and workgroup of the block.  The first column compaction
-        // takes the mirror pools (and every pass thereafter the old path).  Measured: the stream of a pass is
-        // bandwidth-bound at the same 4.1-4.3 TB/s either way, 72 against ~100 us per early pass of a 16-unit team.
+        // of 20 — and 1.08 x the entries in padding: the rows of a block's stream are in the block's OWN order (windows of 512 positions
+        // sorted by the number of entries the row keeps in that block: the 64 rows of a slice hold nearly equal numbers; by position a
+        // (slice, block) cell was as wide as the longest of 64 binomial counts: 1.43 x with two blocks, 1.5 x with seven) —, + 32 bytes per
+        // column and workgroup of the block.  The first column compaction takes the mirror pools (and every pass thereafter the old
+        // path).  Measured: the stream of a pass is bandwidth-bound at the same rate either way; 64 x L = 10 000 on teams
+        // 39.7 -> 36.6 ms of solve, smaller live sets lose (the rest of a pass is slower in this instantiation).
         auto build_upper = [&]() -> bool {
             if constexpr (HALF_ON) {
             int nblk = 1, Wc = 0, jb = 0, GU = 1, rkU = 0; uint32_t upSteps = 0u;
@@ -6118,7 +6145,16 @@ __global__ void __launch_bounds__(WIDE_NT) k_solve_wide(DevParams D, int B, cons
             if (nblk > WIDE_MAXBLK || nblk > G) { nblk = 1; return true; }
             Wc = (((L + nblk - 1) / nblk) + 63) & ~63;          // (<= WcMax: a multiple of 64 that is at least L / nblk)
             const int nsl1 = nsl + 1;
-            uint32_t* upw = upMeta + (size_t)wb.team * WIDE_MAXBLK * (size_t)bmWords;     // [block][nsl1] (nsl1 <= bmWords)
+            // per team: per block the kept entries of every row, the row's rank in the block's own ROW ORDER (windows of 512 positions sorted by
+            // that count: the 64 rows of a slice of the block's stream then hold nearly equal numbers of entries — by position a (slice, block)
+            // cell was as wide as the longest of 64 binomial counts, 1.43 x the entries with two blocks), the row at a rank, and where a row's
+            // pulled pieces are (first piece, pieces | lane slot << 16)
+            const size_t Lcap = (size_t)bmWords * 64;
+            uint32_t* upw = upMeta + (size_t)wb.team * (size_t)bmWords * 1800;
+            uint16_t* gCnt = reinterpret_cast<uint16_t*>(upw + (size_t)WIDE_MAXBLK * bmWords);
+            uint16_t* gRank = gCnt + WIDE_MAXBLK * Lcap;
+            uint16_t* gRow = gRank + WIDE_MAXBLK * Lcap;
+            uint2* gPin = reinterpret_cast<uint2*>(gRow + WIDE_MAXBLK * Lcap);
             // which of the two stored copies of a pair the half copy keeps: (p, q) with p < q when p + q is odd, with p > q when it is even —
             // every row keeps about half of its entries whatever the positions of its neighbours (by position order alone the rows of a
             // slice keep very different shares, and a slice is as wide as its longest row: 0.92 of the full stream instead of 0.5)
@@ -6147,19 +6183,45 @@ __global__ void __launch_bounds__(WIDE_NT) k_solve_wide(DevParams D, int B, cons
                     }
                 }
 #pragma unroll
-                for (int z = 0; z < WIDE_MAXBLK; ++z) {
-                    uint32_t q_ = (cnt[z] + 3u) >> 2;
-                    for (int off = 32; off > 0; off >>= 1) q_ = max(q_, (uint32_t)__shfl_xor((int)q_, off));
-                    if (lane == 0 && z < nblk) __hip_atomic_store(upw + (size_t)z * nsl1 + s_, q_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int z = 0; z < WIDE_MAXBLK; ++z) if (z < nblk) gCnt[(size_t)z * Lcap + rp] = (uint16_t)min(cnt[z], 0xffffu);
+            }
+            if (!wide_sync<true>(sh, wb, ltid)) return false;
+            // (1b) the blocks' row orders: a wave ranks a window of 512 positions of one block by (count descending, position ascending)
+            {
+                const int nwin = (nsl * 64 + 511) / 512;
+                uint16_t* sc = reinterpret_cast<uint16_t*>(xl) + (size_t)w * 512;     // (the gathered vector's region: no stream yet)
+                for (int t_ = cgw; t_ < nblk * nwin; t_ += NWG) {
+                    const int j_ = t_ / nwin, base = (t_ - j_ * nwin) * 512, nrow = min(512, nsl * 64 - base);
+                    uint32_t c_[8];
+#pragma unroll
+                    for (int i_ = 0; i_ < 8; ++i_) {
+                        const int idx = lane + 64 * i_;
+                        c_[i_] = idx < nrow ? (uint32_t)gCnt[(size_t)j_ * Lcap + base + idx] : 0u;
+                        sc[idx] = (uint16_t)c_[i_];
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    uint32_t rk_[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+                    for (int m_ = 0; m_ < nrow; ++m_) {
+                        const uint32_t cm = sc[m_];
+#pragma unroll
+                        for (int i_ = 0; i_ < 8; ++i_) rk_[i_] += (cm > c_[i_] || (cm == c_[i_] && m_ < lane + 64 * i_)) ? 1u : 0u;
+                    }
+#pragma unroll
+                    for (int i_ = 0; i_ < 8; ++i_) {
+                        const int idx = lane + 64 * i_;
+                        if (idx < nrow) { gRank[(size_t)j_ * Lcap + base + idx] = (uint16_t)(base + rk_[i_]); gRow[(size_t)j_ * Lcap + base + rk_[i_]] = (uint16_t)(base + idx); }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 }
             }
-            if (!wide_sync<false>(sh, wb, ltid)) return false;
+            if (!wide_sync<true>(sh, wb, ltid)) return false;
             // (2) every workgroup: cumulative widths per block (LDS, in the region of the gathered vector: no stream yet), the deal
             uint32_t* lw = reinterpret_cast<uint32_t*>(xl);     // [block][nsl1]
             if (w < nblk) {
                 uint32_t run = 0u;
                 for (int p0 = 0; p0 < nsl; p0 += WAVE) {
-                    const uint32_t wv = (p0 + lane < nsl) ? __hip_atomic_load(upw + (size_t)w * nsl1 + p0 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+                    // (a slice of the block's order is as wide as its first row: the windows are sorted by count, eight slices each)
+                    const uint32_t wv = (p0 + lane < nsl) ? (((uint32_t)gCnt[(size_t)w * Lcap + gRow[(size_t)w * Lcap + (size_t)(p0 + lane) * 64]] + 3u) >> 2) : 0u;
                     const uint32_t inc = wave_incl_scan(wv);
                     if (p0 + lane < nsl) lw[w * nsl1 + p0 + lane] = run + inc - wv;
                     run += (uint32_t)__shfl((int)inc, 63);
@@ -6196,35 +6258,31 @@ __global__ void __launch_bounds__(WIDE_NT) k_solve_wide(DevParams D, int B, cons
 #pragma unroll
             for (int z = 0; z < WIDE_MAXBLK; ++z) if (sh.upG[z] > 0 && wb.tRank >= sh.upCU[z] && wb.tRank < sh.upCU[z] + sh.upG[z]) jb = z;
             GU = sh.upG[jb]; rkU = wb.tRank - sh.upCU[jb];
-            if (lane < WIDE_KW * WIDE_MAXBLK) {                 // piece ranges of my owned slices in every block's stream
-                const int k = lane / WIDE_MAXBLK, j_ = lane % WIDE_MAXBLK, s_ = gw + k * NWG;
-                uint32_t f_ = 0u, n_ = 0u;
-                if (k < kw && s_ < nsl && j_ < nblk && sh.upG[j_] > 0) {
-                    const uint32_t a0 = lw[j_ * nsl1 + s_], e0 = lw[j_ * nsl1 + s_ + 1], cs_ = sh.upCS[j_];
-                    if (e0 > a0) { f_ = sh.upPB[j_] + a0 / cs_ + (uint32_t)s_; n_ = (e0 - 1u) / cs_ - a0 / cs_ + 1u; }
-                }
-                sh.upPc[w][k][j_][0] = f_; sh.upPc[w][k][j_][1] = n_;
-            }
-            // (3) the copy: every lane packs the entries of its row that the copy keeps block by block, pads to the slice's widths
+            // (3) the copy: every lane scatters the entries of its row that the copy keeps to the row's slot in every block's own order — slice
+            // rank / 64, lane slot rank % 64 —, pads the slot to that slice's width, and notes where the row's pulled pieces will be
             for (int s_ = cgw; s_ < nsl; s_ += NWG) {
                 const uint32_t ms = MEMW(s_), nst = CUMW(s_ + 1) - CUMW(s_);
                 const unsigned long long* cp = reinterpret_cast<const unsigned long long*>(cols) + (size_t)ms * 64 + lane;
                 const dbl2_t* vp = reinterpret_cast<const dbl2_t*>(vals) + (size_t)ms * 128 + lane;
                 uint16_t* cq = reinterpret_cast<uint16_t*>(colsK); double* vq = valsK;
                 const uint32_t rp = ((uint32_t)s_ << 6) + (uint32_t)lane;
-                uint32_t cur[WIDE_MAXBLK];
+                uint32_t cur[WIDE_MAXBLK], rkb[WIDE_MAXBLK];
 #pragma unroll
-                for (int z = 0; z < WIDE_MAXBLK; ++z) cur[z] = 0u;
-                // (the rows of a slice list their columns in the same ascending order: lane l starts l / 64 of the way into its cell, cyclically,
-                //  so that the lanes of a wave do not push to the same few accumulators in the same instruction)
+                for (int z = 0; z < WIDE_MAXBLK; ++z) { cur[z] = 0u; rkb[z] = z < nblk ? (uint32_t)gRank[(size_t)z * Lcap + rp] : 0u; }
+                // (a slot's entries start vl / 64 of the way into it, cyclically: the lanes of a wave do not push to the same few accumulators
+                //  in the same instruction)
                 auto put = [&](int j_, uint32_t e0_, uint32_t label, double v_) {
-                    const uint32_t a0_ = lw[j_ * nsl1 + s_], we_ = (lw[j_ * nsl1 + s_ + 1] - a0_) << 2;
-                    uint32_t e_ = e0_ + (we_ * (uint32_t)lane >> 6);
+                    uint32_t rk_ = 0u;
+#pragma unroll
+                    for (int z = 0; z < WIDE_MAXBLK; ++z) if (z == j_) rk_ = rkb[z];
+                    const uint32_t v_s = rk_ >> 6, vl = rk_ & 63u;
+                    const uint32_t a0_ = lw[j_ * nsl1 + v_s], we_ = (lw[j_ * nsl1 + v_s + 1] - a0_) << 2;
+                    uint32_t e_ = e0_ + (we_ * vl >> 6);
                     e_ -= e_ >= we_ ? we_ : 0u;
                     const size_t step = (size_t)sh.upSB[j_] + a0_ + (e_ >> 2);
                     const uint32_t h = e_ & 3u;
-                    cq[(step * 64 + lane) * 4 + h] = (uint16_t)label;
-                    vq[(step * 128 + (size_t)(h >> 1) * 64 + lane) * 2 + (h & 1u)] = v_;
+                    cq[(step * 64 + vl) * 4 + h] = (uint16_t)label;
+                    vq[(step * 128 + (size_t)(h >> 1) * 64 + vl) * 2 + (h & 1u)] = v_;
                 };
                 unsigned long long cN = ~0ull; dbl2_t v0N = dbl2_t{0.0, 0.0}, v1N = dbl2_t{0.0, 0.0};
                 if (nst > 0u) { cN = cp[0]; v0N = vp[0]; v1N = vp[64]; }
@@ -6246,8 +6304,12 @@ __global__ void __launch_bounds__(WIDE_NT) k_solve_wide(DevParams D, int B, cons
                 }
 #pragma unroll
                 for (int z = 0; z < WIDE_MAXBLK; ++z) if (z < nblk) {
-                    const uint32_t we = (lw[z * nsl1 + s_ + 1] - lw[z * nsl1 + s_]) << 2;
+                    const uint32_t v_s = rkb[z] >> 6, a0 = lw[z * nsl1 + v_s], e0 = lw[z * nsl1 + v_s + 1];
+                    const uint32_t we = (e0 - a0) << 2;
                     for (uint32_t e_ = cur[z]; e_ < we; ++e_) put(z, e_, 0xffffu, 0.0);
+                    uint32_t f_ = 0u, n_ = 0u;                   // the pieces of the slot's slice: chunks that overlap it
+                    if (e0 > a0 && sh.upG[z] > 0) { const uint32_t cs_ = sh.upCS[z]; f_ = sh.upPB[z] + a0 / cs_ + v_s; n_ = (e0 - 1u) / cs_ - a0 / cs_ + 1u; }
+                    gPin[(size_t)z * Lcap + rp] = make_uint2(f_, n_ | ((rkb[z] & 63u) << 16));
                 }
             }
             __syncthreads();                                    // (every wave is done with the full matrix's widths in cw and with lw)

@@ -1052,9 +1052,12 @@ int enqueue_solve(roman_ctx* c, const DevParams& D, int B, int64_t sumA, int64_t
             if (a_teams) c->teams_launched = true;
             const int nTeams = a_teams ? 8 * a_teams : 1;       // (teams are numbered XCC_ID * teams-per-XCD + sub-team: 8 XCC ids whatever the partition)
             const int NWGt = a_teams ? std::min(G, 2 * ((perXcd + a_teams - 1) / a_teams) + 8) * WIDE_NW : G * WIDE_NW;     // waves a team can have at most
-            // Pull + push passes over a half copy of the matrix — every pair stored once — (kernels.hip.h, build_upper): 16-bit labels only; ROMAN_WIDE_UPPER=0 turns them off
-            // (an instantiation of its own, k_solve_wide<uint16_t, true>, OFF by default: built, exact, and slower than the plain kernel — DESIGN.md 6.7)
-            int a_ucfg = 0;
+            // Pull + push passes over a half copy of the matrix — every pair stored once, rows in a per-block order — (kernels.hip.h, build_upper;
+            // an instantiation of its own, k_solve_wide<uint16_t, true>): taken where it was measured faster than the plain kernel — TEAMS on live
+            // sets of at least 9 000 associations (64 x L = 10 000: 39.7 -> 36.6 ms of solve, 96 x: 55.8 -> 52.6, 24 x: 15.9 -> 14.4; L = 8 100:
+            // 26.6 -> 25.8) —, not below (L = 4 900: 10.0 -> 12.2, L = 6 400: 27.5 -> 31.3: its passes outside the copy cost more registers and a
+            // longer collect) and not with the whole device on one problem (n = m = 200: 22.8 -> 22.4).  ROMAN_WIDE_UPPER=0 / 1 forces either.
+            int a_ucfg = (D.idx16 && a_teams > 0 && maxA >= 9000) ? 1 : 0;
             { const char* e_ = getenv("ROMAN_WIDE_UPPER"); if (e_ && e_[0]) a_ucfg = (D.idx16 && e_[0] != '0') ? 1 : 0; }
             long long a_partStride = (long long)(((size_t)NWGt * WIDE_MAXCH + (size_t)(a_ucfg ? WIDE_MAXBLK : 1) * ((size_t)(maxA + 63) / 64) + 4) * 64 * 2);   // pieces: chunks + slices (per column block of the half copy)
             HIPCHK(c, WS.widePart.ensure(sizeof(double) * (size_t)a_partStride * (size_t)nTeams));
@@ -1090,7 +1093,7 @@ int enqueue_solve(roman_ctx* c, const DevParams& D, int B, int64_t sumA, int64_t
             if (a_ucfg && a_ycap < 64) a_ucfg = 0;
             if (a_ucfg) {
                 HIPCHK(c, WS.wideY.ensure(sizeof(unsigned long long) * 2 * (size_t)a_ycap * (size_t)a_ySlots * (size_t)nTeams));
-                HIPCHK(c, WS.wideUp.ensure(sizeof(uint32_t) * WIDE_MAXBLK * (size_t)a_bmw * (size_t)nTeams));
+                HIPCHK(c, WS.wideUp.ensure(sizeof(uint32_t) * 1800 * (size_t)a_bmw * (size_t)nTeams));      // (kernels.hip.h, build_upper: widths, per-block counts / ranks / rows, piece records)
             }
             unsigned long long* a_yPart = WS.wideY.as<unsigned long long>(); uint32_t* a_upMeta = WS.wideUp.as<uint32_t>();
             if ((a_ccfg & 0xff) || a_ucfg) {

@@ -183,20 +183,24 @@ def test_mixed_batch_large_and_small_live_sets(ctx, orc):
 # ROMAN_WIDE_COMPACT: 0 = k_solve_wide never compacts the matrix's columns; 0x01FF10 = a window of ONE pass, threshold 255/256,
 # 16 compactions per problem: a copy is cut at almost every pass, the next vector's support leaves its columns again and again
 # (the line search re-admits elements) — the way back to the full matrix and the compaction of a copy in place run many times
-# ROMAN_WIDE_UPPER=1: the instantiation of k_solve_wide with pull + push passes over the HALF copy of the matrix (round 6: every stored pair
-# once, column blocks with fixed-point accumulators in LDS, until the first column compaction takes the mirror pools; off by default —
-# measured slower than the plain kernel).  With the compaction off the half copy serves EVERY pass of a problem, with one
-# at every pass it serves the first pass only.
+# ROMAN_WIDE_UPPER: the instantiation of k_solve_wide with pull + push passes over the HALF copy of the matrix (round 6: every stored pair
+# once, column blocks with fixed-point accumulators in LDS, rows in a per-block order, until the first column compaction takes the mirror
+# pools).  The library takes it for TEAMS on live sets of at least 9 000 associations (this batch: L up to 10 000) and not otherwise;
+# "1" / "0" force it / the plain kernel.  With the compaction off the half copy serves EVERY pass of a problem, with one at every pass it
+# serves the first pass only.
 _COMPACT_CASES = [(None, None, None, None), ("2", None, None, None), ("0", None, None, None), (None, "0", None, None), (None, "0x01FF10", None, None), ("0", "0x01FF10", None, None),
                   ("2", "0x02C008", None, None), (None, "0x01FF10", "0", None), (None, None, "0", None),
                   (None, None, None, "1"), ("2", None, None, "1"), ("0", None, None, "1"), (None, "0", None, "1"), (None, "0x01FF10", None, "1"),
-                  ("1", "0", None, "1"), ("1", "0x040010", None, "1"), (None, None, "0", "1")]
+                  ("1", "0", None, "1"), ("1", "0x040010", None, "1"), (None, None, "0", "1"),
+                  (None, None, None, "0"), ("2", None, None, "0"), (None, "0x01FF10", None, "0"), ("2", "0x02C008", None, "0"), (None, "0", None, "0")]
 _COMPACT_IDS = ["teams_auto", "two_teams_per_xcd", "whole_device", "teams_auto-no_compaction", "teams_auto-compaction_every_pass",
                 "whole_device-compaction_every_pass", "two_teams_per_xcd-eager_compaction", "teams_auto-compaction_every_pass-32bit_labels",
                 "teams_auto-32bit_labels",
                 "teams_auto-half_copy", "two_teams_per_xcd-half_copy", "whole_device-half_copy", "teams_auto-no_compaction-half_copy",
                 "teams_auto-compaction_every_pass-half_copy", "one_team_per_xcd-no_compaction-half_copy", "one_team_per_xcd-late_compaction-half_copy",
-                "teams_auto-32bit_labels-half_copy_asked_for"]
+                "teams_auto-32bit_labels-half_copy_asked_for",
+                "teams_auto-plain_kernel", "two_teams_per_xcd-plain_kernel", "teams_auto-compaction_every_pass-plain_kernel",
+                "two_teams_per_xcd-eager_compaction-plain_kernel", "teams_auto-no_compaction-plain_kernel"]
 
 
 @pytest.mark.parametrize("teams,compact,idx16,upper", _COMPACT_CASES, ids=_COMPACT_IDS)
@@ -247,7 +251,7 @@ def test_many_mid_size_live_sets_take_the_solver_the_library_picks(ctx, orc, cou
     assert res.stats["n_live"].tolist() == [n * m for n, m in sizes]
 
 
-@pytest.mark.parametrize("upper", [None, "1"], ids=["plain", "half_copy"])
+@pytest.mark.parametrize("upper", ["0", "1"], ids=["plain_kernel", "half_copy"])
 def test_mid_size_live_sets_from_random_start_vectors(ctx, orc, upper, monkeypatch):
     """Explicit start vectors (part of the C ABI) for live sets beyond the stream layout: the first product of the whole-device solver
     is M u0 of the caller's RAW vector (rescale_u0) — the pull + push pass takes its fixed-point scale from that vector's largest
