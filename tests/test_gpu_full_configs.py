@@ -232,7 +232,8 @@ def test_batch_of_mid_size_live_sets_matches_the_oracle(ctx, orc, teams, compact
     assert res.stats["n_live"].tolist() == [n * m for n, m in sizes]
 
 
-@pytest.mark.parametrize("count,lo,hi", [(28, 62, 76), (70, 56, 66)], ids=["28_problems_four_teams_per_xcd", "70_problems_one_workgroup_each"])
+@pytest.mark.parametrize("count,lo,hi", [(28, 62, 76), (70, 56, 66), (3, 114, 120)],
+                         ids=["28_problems_four_teams_per_xcd", "70_problems_one_workgroup_each", "3_problems_of_14000_half_copy_in_three_column_blocks"])
 def test_many_mid_size_live_sets_take_the_solver_the_library_picks(ctx, orc, count, lo, hi):
     """The library's own choice for a batch of gate-less problems (roman_hip.hip, enqueue_score / the launch of the fallback solvers): more
     than 24 of them with at most 6 144 live associations go to FOUR teams per XCD (eight compute units per problem: the barrier and
