@@ -5597,7 +5597,7 @@ __global__ void __launch_bounds__(WIDE_NT) k_solve_wide(DevParams D, int B, cons
         // The stream in use: the full matrix (cw = the layout's own slice bases) or its column-compacted copy (fewer steps per
         // slice, the slices at their old places).  Chunks of CS steps, dealt round-robin to the waves (chunk c to wave c % NWG):
         // at any moment the waves of the grid read one contiguous window of the matrix.  Every wave takes the same number
-        // m <= WIDE_MAXCH of chunks (the last round may be short): about 16 steps per chunk, more when the matrix is larger.
+        // m <= WIDE_MAXCH of chunks (the last round may be short): about 96 steps per chunk (chunk_steps), more when the matrix is larger.
         uint32_t T = Tfull, CS = 1u, nCh = 0u;
         int cmode = 0 /* stream in use: 0 full, 1 the column-compacted copy, 2 my column block of the half copy (pull + push) */, ncomp = 0, winPass = 0, winOut = 0; bool haveCopy = false;
         int cNWG = NWG, cgw = gwc;                              // the waves the stream in use is dealt to and my id among them (half copy: the workgroups of my column block)
@@ -5607,7 +5607,10 @@ __global__ void __launch_bounds__(WIDE_NT) k_solve_wide(DevParams D, int B, cons
         uint32_t pcf[WIDE_KW], pcn[WIDE_KW];
         static_assert(WIDE_MAXCH <= 8, "sS capacity");
         auto chunk_steps = [&](uint32_t T_, uint32_t nwg_) -> uint32_t {   // steps per chunk of a stream of T_ steps dealt to nwg_ waves
-            uint32_t mch = max(1u, min((uint32_t)WIDE_MAXCH, (T_ + nwg_ * 16u - 1u) / (nwg_ * 16u)));
+            // (about 96 steps per chunk: one or two long chunks per wave — round 3 had settled on 16 steps, up to eight chunks per wave; measured
+            //  again in round 6, one / two / four / auto chunks per wave: 64 x L = 10 000 37.8 / 37.9 / 38.4 / 40.0 ms of solve, on the half copy
+            //  35.5 / 35.1 / 37.4 / 37.0; n = m = 200 21.8 / 22.3 / 22.8 / 22.4 — fewer pieces per slice for the owners to collect)
+            uint32_t mch = max(1u, min((uint32_t)WIDE_MAXCH, (T_ + nwg_ * 96u - 1u) / (nwg_ * 96u)));
             if ((tune >> 8) & 0xff) mch = min((uint32_t)WIDE_MAXCH, (uint32_t)((tune >> 8) & 0xff));
             return max(1u, (T_ + nwg_ * mch - 1u) / (nwg_ * mch));
         };
