@@ -5338,10 +5338,9 @@ struct WideShared {
     int abort_;
     int sS[WIDE_NT / 64][8];             // per wave: first slice of each of its chunks (-1: no such chunk)
     // the half copy (pull + push passes): per column block its stream's steps, steps per chunk, first piece id, first step in the
-    // mirror pools, the team's workgroups that stream it (count, first rank); per wave the piece ranges of its owned slices per block
+    // mirror pools, the team's workgroups that stream it (count, first rank)
     uint32_t upT[WIDE_MAXBLK], upCS[WIDE_MAXBLK], upPB[WIDE_MAXBLK], upSB[WIDE_MAXBLK];
     int upG[WIDE_MAXBLK], upCU[WIDE_MAXBLK];
-    uint32_t upPc[WIDE_NT / 64][WIDE_KW][WIDE_MAXBLK][2];
     int upI[4];                          // column blocks, columns per block, my block, steps of the copy (read where needed: not kept in registers)
     double upFx;                         // 2^-s of the pass on the copy
 };
