@@ -548,7 +548,7 @@ def main():
                         "achieved_TFLOPs": cosflops / (iso_stage["single"] * 1e-3) / 1e12, "peak_TFLOPs": F64_PEAK_TFLOPS,
                         "measured_mfma_ceiling_TFLOPs": F64_MFMA_MEASURED_TFLOPS,
                         "frac": cosflops / (iso_stage["single"] * 1e-3) / 1e12 / F64_PEAK_TFLOPS,
-                        "note": "frac of the whole stage; k_cos_deal alone is ~75 % of it (0.30 of 0.40 ms): 35 TFLOP/s"}}
+                        "note": "frac of the whole stage on the f64 flops of all n1 x n2 products: algorithmic credit — since round 6 the products are screened on the bf16 matrix core and only the ~5 % that can pass the gate are contracted in f64 (k_cos_sel 0.23 of the stage's 0.34 ms; the dense k_cos_deal took 0.30)"}}
                 # the whole step against SURVEY.md §8(d)'s ideal time t* = W/Pi + (B_b + B_s)/beta (pair tests among LIVE associations)
                 Wb = 30.0 * tests + cosflops
                 Bb = float(np.sum(12.0 * nnz)) + 8.0 * float(np.sum(a1[:C0].astype(np.float64) + a2[:C0])) * F
