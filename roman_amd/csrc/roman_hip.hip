@@ -580,6 +580,7 @@ int enqueue_score(roman_ctx* c, const DevParams& Din, const roman_params_t* para
     // work items: blocks of RPB consecutive live rows of one problem (more, smaller items for small batches)
     int RPB = 32;
     while (RPB < 128 && (int64_t)RPB * c->num_cu * 64 < sumA) RPB <<= 1;     // 128: ~17 items per problem balance the static item loop best (measured 32..1024)
+    { const char* e_ = getenv("ROMAN_RPB"); if (e_ && e_[0]) { const int v_ = atoi(e_); if (v_ == 32 || v_ == 64 || v_ == 128) RPB = v_; } }   // (experiments: read per call)
     const size_t maxItems = (size_t)(sumA / RPB) + (size_t)B + 1;
     HIPCHK(c, WS.items.ensure(sizeof(ItemDesc) * maxItems));
 
