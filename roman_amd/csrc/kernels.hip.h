@@ -5721,7 +5721,7 @@ __global__ void __launch_bounds__(WIDE_NT) k_solve_wide(DevParams D, int B, cons
         // per lane and quad), the next block's matrix loads in flight while the current block gathers and accumulates.
         constexpr bool W16 = sizeof(IdxT) == 2;                  // 16-bit column words: 8 bytes per lane and quad, no C flag, 0xffff = no column
         // (the half copy's code costs the whole kernel 20 registers and 220 bytes of scratch per lane — several us per pass of EVERY problem
-        //   —: an instantiation of its own, taken where the copy saves more than that: teams on live sets of >= 9 000)
+        //   —: an instantiation of its own, taken where the copy saves more than that: teams on live sets of >= 8 000)
         constexpr bool HALF_ON = HALF && W16;
         typedef typename std::conditional<W16, unsigned long long, uint4_t>::type cword_t;
         auto piece = [&](const double* xv, uint32_t nl, uint32_t tm /* first step in memory */, uint32_t n /* steps */, uint32_t pid) {

@@ -1055,10 +1055,10 @@ int enqueue_solve(roman_ctx* c, const DevParams& D, int B, int64_t sumA, int64_t
             const int NWGt = a_teams ? std::min(G, 2 * ((perXcd + a_teams - 1) / a_teams) + 8) * WIDE_NW : G * WIDE_NW;     // waves a team can have at most
             // Pull + push passes over a half copy of the matrix — every pair stored once, rows in a per-block order — (kernels.hip.h, build_upper;
             // an instantiation of its own, k_solve_wide<uint16_t, true>): taken where it was measured faster than the plain kernel — TEAMS on live
-            // sets of at least 9 000 associations (64 x L = 10 000: 39.7 -> 36.6 ms of solve, 96 x: 55.8 -> 52.6, 24 x: 15.9 -> 14.4; L = 8 100:
+            // sets of at least 8 000 associations (break-even ~7 700: L = 7 225 19.1 -> 19.9, L = 8 100 25.8 -> 24.9, L = 9 025 30.0 -> 27.7; 64 x L = 10 000: 39.7 -> 36.6 ms of solve, 96 x: 55.8 -> 52.6, 24 x: 15.9 -> 14.4; L = 8 100:
             // 26.6 -> 25.8) —, not below (L = 4 900: 10.0 -> 12.2, L = 6 400: 27.5 -> 31.3: its passes outside the copy cost more registers and a
             // longer collect) and not with the whole device on one problem (n = m = 200: 22.8 -> 22.4).  ROMAN_WIDE_UPPER=0 / 1 forces either.
-            int a_ucfg = (D.idx16 && a_teams > 0 && maxA >= 9000) ? 1 : 0;
+            int a_ucfg = (D.idx16 && a_teams > 0 && maxA >= 8000) ? 1 : 0;
             { const char* e_ = getenv("ROMAN_WIDE_UPPER"); if (e_ && e_[0]) a_ucfg = (D.idx16 && e_[0] != '0') ? 1 : 0; }
             long long a_partStride = (long long)(((size_t)NWGt * WIDE_MAXCH + (size_t)(a_ucfg ? WIDE_MAXBLK : 1) * ((size_t)(maxA + 63) / 64) + 4) * 64 * 2);   // pieces: chunks + slices (per column block of the half copy)
             HIPCHK(c, WS.widePart.ensure(sizeof(double) * (size_t)a_partStride * (size_t)nTeams));

@@ -185,7 +185,7 @@ def test_mixed_batch_large_and_small_live_sets(ctx, orc):
 # (the line search re-admits elements) — the way back to the full matrix and the compaction of a copy in place run many times
 # ROMAN_WIDE_UPPER: the instantiation of k_solve_wide with pull + push passes over the HALF copy of the matrix (round 6: every stored pair
 # once, column blocks with fixed-point accumulators in LDS, rows in a per-block order, until the first column compaction takes the mirror
-# pools).  The library takes it for TEAMS on live sets of at least 9 000 associations (this batch: L up to 10 000) and not otherwise;
+# pools).  The library takes it for TEAMS on live sets of at least 8 000 associations (this batch: L up to 10 000) and not otherwise;
 # "1" / "0" force it / the plain kernel.  With the compaction off the half copy serves EVERY pass of a problem, with one at every pass it
 # serves the first pass only.
 _COMPACT_CASES = [(None, None, None, None), ("2", None, None, None), ("0", None, None, None), (None, "0", None, None), (None, "0x01FF10", None, None), ("0", "0x01FF10", None, None),
